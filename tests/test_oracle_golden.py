@@ -1,0 +1,365 @@
+"""Pin the CPU oracle against the reference's own golden vectors and known answers (CPU-only).
+
+Each test names the DSP.jl test (file:line) whose assertion it replays; ``≈`` is Julia's norm-wise
+``isapprox`` with rtol = sqrt(eps) (see conftest.isapprox); ``==`` cases are exact.
+"""
+import math
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from conftest import isapprox, relerr
+from oracle import design, dspbase, filt, periodograms as pg, stream_filt as sf, util, windows
+
+
+# ------------------------------------------------------------------------------------ helpers
+def test_nextfastfft_literals():
+    # test/util.jl:56-59
+    assert util.nextfastfft(64) == 64
+    assert util.nextfastfft(65) == 70
+    assert util.nextfastfft(127) == 128
+    assert [util.nextfastfft(n) for n in (1, 2, 11, 13, 211)] == [1, 2, 12, 14, 216]
+
+
+def test_optimalfftfiltlength_literals():
+    assert dspbase.optimalfftfiltlength(1, 3) == 1          # test/dsp.jl:39
+    assert dspbase.optimalfftfiltlength(256, 2 ** 30) == 2048   # BASELINE config 2
+    assert dspbase.optimalfftfiltlength(127, 10 ** 6) == 1024   # BASELINE config 1
+    assert abs(dspbase.os_fft_complexity(2048, 256) - 13.71) < 0.01
+
+
+def test_hanning128(golden):
+    # test/windows.jl:55-59
+    assert isapprox(windows.hanning(128), golden["hanning128"])
+    assert np.max(np.abs(windows.hanning(128) - golden["hanning128"])) < 5e-16
+
+
+def test_firwindow_taps(golden):
+    # test/filter_design.jl:988-1060: digitalfilter(Lowpass(0.25), FIRWindow(hamming(N); scale); fs=1)
+    for n in (128, 129):
+        for scaled, key in ((False, f"digitalfilter_hamming_{n}_lowpass_fc0p25_fs1p0"),
+                            (True, f"digitalfilter_hamming_{n}_lowpass_scaled_fc0p25_fs1p0")):
+            h = design.digitalfilter_lowpass_firwindow(0.25, windows.hamming(n), fs=1.0, scale=scaled)
+            assert isapprox(h, golden[key]), (n, scaled)
+
+
+def test_kaiserord_against_known():
+    # test/filter_design.jl:965-981 compares with scipy.signal.kaiserord; spot values
+    n, alpha = design.kaiserord(0.1, 60)
+    assert n == 74 and abs(alpha * math.pi - 5.65326) < 1e-5
+
+
+# ------------------------------------------------------------------------------ filt / conv
+def test_filt_exact_integers():
+    # test/dsp.jl:10-21
+    b = np.array([1., 2., 3., 4.])
+    x = np.array([1., 1., 0., 1., 1., 0., 0., 0.])
+    assert np.array_equal(dspbase.filt_ba(b, 1.0, x), [1., 3., 5., 8., 7., 5., 7., 4.])
+    assert np.array_equal(dspbase.filt_ba(b, [1., -0.5], x),
+                          [1., 3.5, 6.75, 11.375, 12.6875, 11.34375, 12.671875, 10.3359375])
+    assert np.array_equal(dspbase.filt_ba(b, 1.0, np.arange(1.0, 11.0)), [1., 4., 10., 20., 30., 40., 50., 60., 70., 80.])
+    X = np.stack([x, np.arange(1.0, 9.0)], axis=1)
+    both = dspbase.filt_ba(b, 1.0, X)
+    assert np.array_equal(both[:, 0], dspbase.filt_ba(b, 1.0, x))
+    assert np.array_equal(both[:, 1], dspbase.filt_ba(b, 1.0, np.arange(1.0, 9.0)))
+
+
+def test_conv_small_known():
+    # test/dsp.jl:53-70
+    a = np.array([1, 2, 1, 2]); b = np.array([1, 2, 3])
+    assert np.array_equal(dspbase.conv(a, b), [1, 4, 8, 10, 7, 6])
+    fa = a.astype(float); fb = b.astype(float)
+    assert isapprox(dspbase.conv(fa, fb), [1., 4, 8, 10, 7, 6])
+    got = dspbase.conv(fa + 1j, fb + 0j)
+    assert isapprox(got, np.array([1, 4, 8, 10, 7, 6]) + 1j * np.array([1, 3, 6, 6, 5, 3]))
+    assert np.array_equal(dspbase.conv(np.array([314159265]), np.array([314159265])), [314159265 ** 2])  # issue #410
+
+
+def test_conv_algorithms_agree():
+    # test/dsp.jl:72-76 and :98-121
+    rng = np.random.default_rng(1776)
+    u, v = rng.random(190), rng.random(200)
+    ref = dspbase.conv(u, v, "direct")
+    for alg in ("fft_simple", "fft_overlapsave", "fft", "fast", "auto"):
+        assert isapprox(dspbase.conv(u, v, alg), ref), alg
+    with pytest.raises(ValueError):
+        dspbase.conv(u, v, "quantum")
+    for M in (10, 200):
+        for N in (10, 200):
+            for cplx in (False, True):
+                u = rng.random(M) + (1j * rng.random(M) if cplx else 0)
+                v = rng.random(N) + (1j * rng.random(N) if cplx else 0)
+                d = dspbase.conv(u, v, "direct")
+                assert isapprox(dspbase.conv(u, v, "fft_simple"), d)
+                assert isapprox(dspbase.conv(u, v, "fft_overlapsave"), d)
+                for alg in ("direct", "fft_simple", "fft_overlapsave"):
+                    out = dspbase.conv(u, v, alg, out_len=M + N + 10)
+                    assert np.array_equal(out[:M + N - 1], dspbase.conv(u, v, alg))
+                    assert np.all(out[M + N - 1:] == 0)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex128])
+@pytest.mark.parametrize("nsmall", [12, 128])
+def test_overlap_save_kernel(dt, nsmall):
+    # test/dsp.jl:289-297 (N=1)
+    rng = np.random.default_rng(7)
+    nlarge = 128
+    u = rng.random(nlarge).astype(dt); v = rng.random(nsmall).astype(dt)
+    if np.dtype(dt).kind == "c":
+        u = u + 1j * rng.random(nlarge); v = v + 1j * rng.random(nsmall)
+    nfft = dspbase.optimalfftfiltlength(nsmall, nlarge)
+    n = nlarge + nsmall - 1
+    assert isapprox(dspbase.unsafe_conv_kern_os(u, v, nfft, n, dt), dspbase._conv_kern_fft(u, v, n, dt))
+
+
+@pytest.mark.parametrize("nlarge,nsmall,nfft", [(128, 12, 256), (128, 13, 32), (128, 12, 32), (25, 4, 16)])
+def test_overlap_save_adversarial(nlarge, nsmall, nfft):
+    # test/dsp.jl:304-313
+    rng = np.random.default_rng(8)
+    u, v = rng.random(nlarge), rng.random(nsmall)
+    n = nlarge + nsmall - 1
+    assert isapprox(dspbase.unsafe_conv_kern_os(u, v, nfft, n, np.float64), np.convolve(u, v))
+    if (nlarge, nsmall, nfft) == (25, 4, 16):
+        blocks, save, nblocks = dspbase.os_block_table(25, 4, 16, 28)
+        assert nblocks == 3 and all(b["edge"] for b in blocks)      # "three blocks need to be padded"
+
+
+def test_os_geometry_config2():
+    # 2^30 (+255) samples, nb=256 -> nfft 2048, save 1793, 598 853 blocks; first/last are edge blocks
+    su, sv, nfft = 2 ** 30, 256, 2048
+    ideal = nfft - sv + 1
+    assert ideal == 1793
+    assert -(-(su + sv - 1) // ideal) == 598853
+    assert -(-su // ideal) == 598853
+    L, rows = filt.fftfilt_block_table(256, 10 ** 4, 2048)
+    assert L == 1793 and rows[0] == (1, 255, 1, 1793, 1793) and rows[1][0] == 1794
+
+
+@pytest.mark.parametrize("xlen", [2 ** 7 - 1, 2 ** 10 - 1, 2 ** 13 - 1])
+@pytest.mark.parametrize("blen", [1, 3, 31, 127])
+def test_fftfilt_matches_tdfilt(xlen, blen):
+    # test/filt.jl:312-331
+    rng = np.random.default_rng(xlen * 131 + blen)
+    b = rng.standard_normal(blen)
+    for x in (rng.random(xlen), rng.random((xlen, 2))):
+        filtres = dspbase.filt_ba(b, [1.0], x)
+        assert isapprox(filt.fftfilt(b, x), filtres)
+        assert isapprox(filt.filt(b, x), filtres)
+        assert isapprox(filt.tdfilt(b, x), filtres)
+
+
+# ------------------------------------------------------------------------------- periodograms
+def test_spectrogram_matlab(golden):
+    # test/periodograms.jl:25-36
+    spec = pg.spectrogram(golden["spectrogram_x"], 256, 128, fs=10)
+    assert isapprox(spec.power, golden["spectrogram_p"])
+    assert isapprox(spec.freq, golden["spectrogram_f"])
+    assert isapprox(spec.time, golden["spectrogram_t"])
+    assert relerr(spec.power, golden["spectrogram_p"]) < 1e-13
+
+
+def test_stft_matlab(golden):
+    # test/periodograms.jl:332-344
+    S = pg.stft(golden["stft_x"], 400, 240, nfft=512, fs=16000, window=windows.hanning)
+    ref = golden["stft_S_real"] + 1j * golden["stft_S_imag"]
+    assert S.shape == (257, 29)
+    assert isapprox(S, ref)
+
+
+DATA07 = np.arange(8)
+
+
+def test_pwelch_0_7_twosided():
+    # test/periodograms.jl:92-135
+    data0 = np.array([98.0, 13.656854249492380, 4.0, 2.343145750507620, 2.0, 2.343145750507620, 4.0, 13.656854249492380])
+    assert isapprox(pg.periodogram(DATA07, onesided=False).power, data0)
+    assert isapprox(pg.welch_pgram(DATA07, 8, 0, onesided=False, window=None).power, data0)
+    assert isapprox(pg.spectrogram(DATA07, 8, 0, onesided=False).power[:, 0], data0)
+    z = DATA07 + 1j * DATA07
+    assert isapprox(pg.periodogram(z, onesided=False).power, data0 * 2)
+    assert isapprox(pg.welch_pgram(z, 8, 0, onesided=False, window=None).power, data0 * 2)
+    assert isapprox(pg.spectrogram(z, 8, 0, onesided=False).power[:, 0], data0 * 2)
+    for (n, nov, exp) in ((2, 0, [34.5, 0.5]), (3, 0, [25.5, 1.0, 1.0]), (3, 1, [35.0, 1.0, 1.0]), (4, 1, [45, 2, 1, 2])):
+        assert isapprox(pg.welch_pgram(DATA07, n, nov, onesided=False, window=None).power, np.array(exp, float))
+        assert isapprox(pg.welch_pgram(DATA07, n, nov, onesided=False, window=None, sequential=True).power, np.array(exp, float))
+        assert isapprox(pg.spectrogram(DATA07, n, nov, onesided=False).power.mean(axis=1), np.array(exp, float))
+
+
+def test_pwelch_0_7_windows():
+    # test/periodograms.jl:143-169
+    cases = ((windows.hamming, [65.461623986801527, 20.556791795515764, 0.369313143650544, 0.022167446610882,
+                                0.025502985564107, 0.022167446610882, 0.369313143650544, 20.556791795515764]),
+             (windows.bartlett, [62.999999999999993, 21.981076052592442, 0.285714285714286, 0.161781090264695,
+                                 0.142857142857143, 0.161781090264695, 0.285714285714286, 21.981076052592442]))
+    for w, exp in cases:
+        exp = np.array(exp)
+        for win in (w, w(8)):
+            assert isapprox(pg.periodogram(DATA07, window=win, onesided=False).power, exp)
+            assert isapprox(pg.welch_pgram(DATA07, 8, 0, window=win, onesided=False).power, exp)
+            assert isapprox(pg.spectrogram(DATA07, 8, 0, window=win, onesided=False).power[:, 0], exp)
+
+
+def test_padded_periodogram():
+    # test/periodograms.jl:171-220
+    exp = np.array([98, 174.463067389405, 121.968086934209, 65.4971744936088, 27.3137084989848, 12.1737815028909,
+                    10.3755170959439, 10.4034038628775, 8, 5.25810953219633, 4.47015397150535, 4.89522578856669,
+                    4.68629150101524, 3.69370284475603, 3.1862419983415, 3.61553458569862, 2])
+    assert isapprox(pg.periodogram(DATA07, nfft=32).power, exp)
+    assert isapprox(pg.welch_pgram(DATA07, 8, 0, nfft=32, window=None).power, exp)
+    assert isapprox(pg.spectrogram(DATA07, 8, 0, nfft=32).power[:, 0], exp)
+    exph = np.array([65.4616239868015, 122.101693164395, 98.8444689598445, 69.020252632913, 41.1135835910315,
+                     20.5496474310966, 8.43291449161938, 2.78001620362588, 0.738626287301088, 0.174995741770789,
+                     0.0501563022944516, 0.0327357460012861, 0.0443348932217643, 0.0553999745503552,
+                     0.0561319901616643, 0.0526025934871384, 0.0255029855641069])
+    assert isapprox(pg.periodogram(DATA07, window=windows.hamming, nfft=32).power, exph)
+    assert isapprox(pg.welch_pgram(DATA07, 8, 0, window=windows.hamming, nfft=32).power, exph)
+    cfg = pg.WelchConfig.create(8, DATA07.dtype, n=8, noverlap=0, window=windows.hamming, nfft=32)
+    a = pg.welch_pgram(DATA07, config=cfg).power
+    assert np.array_equal(a, pg.welch_pgram(DATA07, config=cfg).power)        # :222-224 (== on reuse)
+
+
+def test_fft2oneortwosided():
+    # test/periodograms.jl:346-379 semantics: two-sided completion of a real spectrum equals the full fft
+    rng = np.random.default_rng(3)
+    for nfft in (10, 12, 13):
+        x = rng.standard_normal(nfft)
+        full = np.fft.fft(x)
+        assert isapprox(pg.fft2oneortwosided(np.fft.rfft(x)[None, :], nfft, False)[0], full)
+        assert np.array_equal(pg.fft2oneortwosided(np.fft.rfft(x)[None, :], nfft, True)[0], np.fft.rfft(x))
+        p2 = pg.fft2pow(np.fft.rfft(x)[None, :], nfft, 1.0, False, np.float64)[0]
+        assert isapprox(p2, np.abs(full) ** 2)
+
+
+def test_arraysplit():
+    # test/periodograms.jl:393-402 and the docstring examples periodograms.jl:97-111
+    fr = pg.arraysplit(np.ones(1000), 100, 10)
+    assert fr.shape == (11, 100)
+    assert np.array_equal(pg.arraysplit(np.array([0.1, 0.2, 0.3, 0.4, 0.5]), 3, 1), [[0.1, 0.2, 0.3], [0.3, 0.4, 0.5]])
+    got = pg.arraysplit(np.array([0.1, 0.2, 0.3, 0.4, 0.5]), 3, 2, 8)
+    assert got.shape == (3, 8) and np.array_equal(got[1, :3], [0.2, 0.3, 0.4]) and np.all(got[:, 3:] == 0)
+    assert np.array_equal(pg.arraysplit(np.array([0.1, 0.2, 0.3, 0.4, 0.5]), 3, 1, 3, np.array([1, 2, 1])),
+                          np.array([[0.1, 0.4, 0.3], [0.3, 0.8, 0.5]]))
+    assert pg.frame_count(2 ** 30, 4096, 2048) == 524287        # BASELINE config 3
+    assert pg.frame_count(2 ** 26, 1024, 768) == 262141          # BASELINE config 4
+    with pytest.raises(ValueError):
+        pg.arraysplit(np.ones(10), 4, 4)
+    with pytest.raises(ValueError):
+        pg.arraysplit(np.ones(10), 4, 1, 3)
+
+
+def test_welch_sequential_vs_f64_sum():
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(20000).astype(np.float32)
+    a = pg.welch_pgram(x, 256, 128, window=windows.hanning, sequential=True).power
+    b = pg.welch_pgram(x, 256, 128, window=windows.hanning).power
+    c = pg.welch_pgram(x, 256, 128, window=windows.hanning, dtype=np.float64).power
+    assert a.dtype == np.float32 and b.dtype == np.float32 and c.dtype == np.float64
+    assert relerr(a, c) < 2e-6 and relerr(b, c) < 2e-6
+
+
+# --------------------------------------------------------------------------------- resampling
+@pytest.mark.parametrize("rate", [Fraction(1, 2), Fraction(2, 1), Fraction(3, 2), Fraction(2, 3)])
+def test_resample_matlab(golden, rate):
+    # test/resample.jl:8-24
+    x = golden["resample_x"]
+    h = golden[f"resample_taps_{rate.numerator}_{rate.denominator}"]
+    y = golden[f"resample_y_{rate.numerator}_{rate.denominator}"]
+    got = sf.resample(x, rate, h)
+    assert got.shape == y.shape
+    assert isapprox(got, y)
+    assert isapprox(sf.resample(x, rate), y, rtol=1e-3)     # default taps
+
+
+def test_resample_exact_small():
+    # test/filt_stream.jl:366-367
+    h = np.array([0, 0, 1, 0, 0, 0.0])
+    assert np.array_equal(sf.resample(np.array([1, 2]), 3, h), [1, 0, 0, 2, 0, 0])
+    assert np.array_equal(sf.resample(np.array([1, 2]), Fraction(3, 2), h), [1, 0, 0])
+
+
+def test_resample_dims(golden):
+    # test/resample.jl:35-45
+    x = golden["resample_x"]; h = golden["resample_taps_1_2"]; y = golden["resample_y_1_2"]
+    X = np.stack([x, math.e * x], axis=1)
+    got = sf.resample_dims(X, Fraction(1, 2), h, dims=0)
+    assert isapprox(got, np.stack([y, math.e * y], axis=1))
+    assert isapprox(sf.resample_dims(X.T, Fraction(1, 2), h, dims=1), np.stack([y, math.e * y], axis=1).T)
+
+
+def _naivefilt(h, x, L=1, M=1):
+    # test/filt_stream.jl:4-17: zero-stuff, filter, decimate
+    xz = np.zeros(len(x) * L, dtype=np.result_type(x.dtype, h.dtype))
+    xz[::L] = x
+    y = np.convolve(xz, h)[:len(xz)]
+    return y[::M]
+
+
+@pytest.mark.parametrize("L", [1, 5, 14, 23])
+@pytest.mark.parametrize("M", [1, 9, 17, 21])
+def test_firfilter_vs_naive_and_streaming(L, M):
+    # test/filt_stream.jl:231-281, :338-364
+    rng = np.random.default_rng(L * 100 + M)
+    for Th in (np.float32, np.float64):
+        for Tx in (np.float32, np.float64, np.complex64, np.complex128):
+            h = rng.random(int(rng.integers(16, 129))).astype(Th)
+            xlen = int(rng.integers(200, 301))
+            x = rng.random(xlen).astype(Tx)
+            if np.dtype(Tx).kind == "c":
+                x = (x + 1j * rng.random(xlen)).astype(Tx)
+            ratio = Fraction(L, M)
+            naive = _naivefilt(h, x, ratio.numerator, ratio.denominator)
+            tol = 1e-4 if (Th == np.float32 or np.dtype(Tx).itemsize in (4, 8) and np.dtype(Tx) in (np.dtype(np.float32), np.dtype(np.complex64))) else 1e-8
+            stateless = sf.filt_stateless(h, x, ratio)
+            assert stateless.shape == naive.shape
+            assert relerr(stateless, naive) < tol
+            # two chunks
+            f = sf.FIRFilter(h, ratio)
+            cut = xlen // 3
+            y2 = np.concatenate([f.filt(x[:cut]), f.filt(x[cut:])])
+            assert y2.shape == naive.shape and relerr(y2, naive) < tol
+            # inputlength(filt, len) == xLen   (filt_stream.jl:262)
+            g = sf.FIRFilter(h, ratio)
+            assert g.outputlength(g.inputlength(len(naive))) <= len(naive)
+    # one sample at a time (F64 only, it is slow)
+    h = rng.random(40); x = rng.random(120)
+    ratio = Fraction(L, M)
+    f = sf.FIRFilter(h, ratio)
+    pieces = [f.filt(x[i:i + 1]) for i in range(len(x))]
+    y1 = np.concatenate(pieces)
+    naive = _naivefilt(h, x, ratio.numerator, ratio.denominator)
+    assert y1.shape == naive.shape and relerr(y1, naive) < 1e-12
+
+
+def test_polyphase_closed_form_matches_recurrence():
+    # closed form == the serial recurrence of stream_filt.jl:506-508
+    for (L, M, phi0, d0) in ((160, 147, 1, 1), (160, 147, 77, 17), (3, 2, 2, 1), (5, 9, 4, 3), (23, 21, 23, 2)):
+        phi, idx = phi0, d0
+        ms = np.arange(500)
+        cphi, cidx = sf.polyphase_closed_form(phi0, d0, L, M, ms)
+        for m in ms:
+            assert (phi, idx) == (cphi[m], cidx[m])
+            idx += (phi + M - 1) // L
+            phi += M % L
+            if phi > L:
+                phi -= L
+
+
+def test_inputlength_outputlength_bracketing():
+    # test/resample.jl:154-166
+    rng = np.random.default_rng(5)
+    for _ in range(1000):
+        Mr = Fraction(int(rng.integers(1, 11)), int(rng.integers(1, 11)))
+        H = sf.FIRFilter(np.zeros(int(rng.integers(1, 101))), Mr)
+        if Mr != 1:
+            H.setphase(10 * rng.random())
+        yL = int(rng.integers(1, 101))
+        assert H.outputlength(H.inputlength(yL)) <= yL < H.outputlength(H.inputlength(yL) + 1)
+        assert H.outputlength(H.inputlength(yL, True) - 1) < yL <= H.outputlength(H.inputlength(yL, True))
+
+
+def test_config5_lengths():
+    # 2^28 inputs at 160//147 with a 5120-tap filter -> 292 174 646 outputs per channel
+    assert math.ceil(2 ** 28 * Fraction(160, 147)) == 292174646
+    pfb = sf.taps2pfb(np.arange(1, 10), 4)
+    assert np.array_equal(pfb, [[9, 0, 0, 0], [5, 6, 7, 8], [1, 2, 3, 4]])     # stream_filt.jl:286-292
