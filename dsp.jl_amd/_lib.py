@@ -1,0 +1,153 @@
+"""ctypes binding of libmi355dsp.so (the C ABI declared in include/mi355dsp.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing it is built with hipcc
+(cross-compiles without a GPU); if no HIP device is visible every compute entry point raises DeviceError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi355dsp.so")
+
+# ---- status codes / dtype / engine enums (mirror include/mi355dsp.h) -----------------------------------
+OK, ERR_ARGUMENT, ERR_DOMAIN, ERR_DIMENSION, ERR_ASSERTION, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7
+F32, F64, C32, C64 = 0, 1, 2, 3
+ENGINE_AUTO, ENGINE_FUSED, ENGINE_ROCFFT = 0, 1, 2
+OLS_FILT, OLS_CONV = 0, 1
+
+
+class ArgumentError(ValueError):
+    """Julia ``ArgumentError``."""
+
+
+class DomainError(ValueError):
+    """Julia ``DomainError``."""
+
+
+class DimensionMismatch(ValueError):
+    """Julia ``DimensionMismatch``."""
+
+
+class UnsupportedError(NotImplementedError):
+    """Valid DSP.jl call that this library does not accelerate (caller should use DSP.jl's CPU path)."""
+
+
+class DeviceError(RuntimeError):
+    """HIP / rocFFT failure, or no MI355X visible."""
+
+
+_EXC = {ERR_ARGUMENT: ArgumentError, ERR_DOMAIN: DomainError, ERR_DIMENSION: DimensionMismatch,
+        ERR_ASSERTION: AssertionError, ERR_UNSUPPORTED: UnsupportedError, ERR_DEVICE: DeviceError, ERR_NOMEM: MemoryError}
+
+i64, vp, ci, cd = C.c_int64, C.c_void_p, C.c_int, C.c_double
+pi64, pint, pdbl, pvp = C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/mi355dsp.h declares
+PROTOTYPES = {
+    "mdsp_version": (ci, []),
+    "mdsp_last_error_string": (C.c_char_p, []),
+    "mdsp_init": (ci, [ci]),
+    "mdsp_shutdown": (ci, []),
+    "mdsp_device_count": (ci, [pint]),
+    "mdsp_malloc": (ci, [pvp, C.c_size_t]),
+    "mdsp_free": (ci, [vp]),
+    "mdsp_memcpy_h2d": (ci, [vp, vp, C.c_size_t, vp]),
+    "mdsp_memcpy_d2h": (ci, [vp, vp, C.c_size_t, vp]),
+    "mdsp_memset": (ci, [vp, ci, C.c_size_t, vp]),
+    "mdsp_stream_synchronize": (ci, [vp]),
+    "mdsp_nextfastfft": (i64, [i64]),
+    "mdsp_optimal_fft_len": (i64, [i64, i64]),
+    "mdsp_frame_count": (i64, [i64, i64, i64]),
+    "mdsp_outputlength": (i64, [i64, i64, i64, i64]),
+    "mdsp_inputlength": (i64, [i64, i64, i64, i64, ci]),
+    "mdsp_ols_block_geometry": (ci, [i64, i64, i64, i64, pi64, pi64, pi64, pi64, pi64]),
+    "mdsp_ols_plan_create": (ci, [pvp, vp, i64, i64, i64, ci, ci, ci]),
+    "mdsp_ols_plan_destroy": (ci, [vp]),
+    "mdsp_ols_plan_info": (ci, [vp, pi64, pi64, pint]),
+    "mdsp_ols_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, vp]),
+    "mdsp_ols_segment": (ci, [vp, vp, i64, i64, i64, vp, vp]),
+    "mdsp_frames": (ci, [vp, i64, ci, i64, i64, i64, pdbl, i64, i64, vp, vp]),
+    "mdsp_welch_plan_create": (ci, [pvp, i64, i64, i64, pdbl, cd, ci, ci, ci]),
+    "mdsp_welch_plan_destroy": (ci, [vp]),
+    "mdsp_welch_plan_info": (ci, [vp, pi64, pint]),
+    "mdsp_welch_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, vp]),
+    "mdsp_channel_sum": (ci, [vp, i64, i64, i64, ci, vp, vp]),
+    "mdsp_stft_plan_create": (ci, [pvp, i64, i64, i64, pdbl, cd, ci, ci, ci, ci]),
+    "mdsp_stft_plan_destroy": (ci, [vp]),
+    "mdsp_stft_plan_info": (ci, [vp, pi64, pint]),
+    "mdsp_stft_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, vp]),
+    "mdsp_fir_create": (ci, [pvp, vp, i64, i64, i64, ci, ci, i64]),
+    "mdsp_fir_destroy": (ci, [vp]),
+    "mdsp_fir_reset": (ci, [vp]),
+    "mdsp_fir_setphase": (ci, [vp, cd]),
+    "mdsp_fir_timedelay": (ci, [vp, pdbl]),
+    "mdsp_fir_outputlength": (ci, [vp, i64, pi64]),
+    "mdsp_fir_inputlength": (ci, [vp, i64, ci, pi64]),
+    "mdsp_fir_info": (ci, [vp, pint, pi64, pi64, pi64, pi64, pint]),
+    "mdsp_fir_get_state": (ci, [vp, pi64, pi64, vp]),
+    "mdsp_fir_set_state": (ci, [vp, i64, i64, vp]),
+    "mdsp_fir_exec": (ci, [vp, vp, i64, i64, vp, i64, i64, pi64, vp]),
+    "mdsp_tdfir_exec": (ci, [vp, i64, ci, vp, i64, i64, i64, vp, i64, vp]),
+    "mdsp_event_create": (ci, [pvp]),
+    "mdsp_event_destroy": (ci, [vp]),
+    "mdsp_event_record": (ci, [vp, vp]),
+    "mdsp_event_elapsed_ms": (ci, [vp, vp, C.POINTER(C.c_float)]),
+    "mdsp_copy_bench": (ci, [vp, vp, C.c_size_t, vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_mdsp_build", os.path.join(HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(force=force, verbose=verbose)
+
+
+def lib() -> C.CDLL:
+    """Load (building first if needed) the shared library and attach prototypes."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                build()
+            try:
+                # torch (if the caller uses it for device arrays) must own the HIP runtime it was built with:
+                # importing it first makes libmi355dsp resolve libamdhip64/librocfft to the already-loaded copies.
+                import torch  # noqa: F401
+            except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+                pass
+            handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+            for name, (res, args) in PROTOTYPES.items():
+                fn = getattr(handle, name)      # AttributeError here = the .so does not export a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def check(status: int) -> None:
+    if status == OK:
+        return
+    msg = lib().mdsp_last_error_string()
+    msg = msg.decode("utf-8", "replace") if msg else f"libmi355dsp status {status}"
+    raise _EXC.get(status, RuntimeError)(msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().mdsp_device_count(C.byref(n)))
+    return n.value
+
+
+def require_device() -> None:
+    """The product path fails loudly without a GPU (no CPU fallback)."""
+    if device_count() < 1:
+        raise DeviceError("no HIP device visible: dsp.jl_amd runs on MI355X only (there is no CPU fallback; "
+                          "use DSP.jl itself on the CPU)")

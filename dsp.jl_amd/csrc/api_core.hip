@@ -1,0 +1,233 @@
+// Library core: error state, device selection, memory helpers, pure index arithmetic, measurement helpers.
+#include <cmath>
+
+#include "common.h"
+
+namespace mdsp {
+
+static thread_local std::string g_err;
+
+int set_error(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+void clear_error() { g_err.clear(); }
+
+int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// ---- pure index arithmetic ---------------------------------------------------------------------------
+static int64_t nextprod2357(int64_t n) {
+    if (n <= 1) return 1;
+    int64_t best = INT64_MAX;
+    for (int64_t p7 = 1; p7 < 2 * n && p7 > 0; p7 *= 7)
+        for (int64_t p5 = p7; p5 < 2 * n && p5 > 0; p5 *= 5)
+            for (int64_t p3 = p5; p3 < 2 * n && p3 > 0; p3 *= 3) {
+                int64_t v = p3;
+                while (v < n) v *= 2;
+                if (v < best) best = v;
+            }
+    return best;
+}
+
+static double os_fft_complexity(double nfft, double nb) { return (nfft * std::log2(nfft) + nfft) / (nfft - nb + 1); }
+
+static int64_t ceil_log2(int64_t v) {  // ceil(Int, log2(v)) for v >= 1, exact for powers of two
+    int64_t p = 0;
+    while ((int64_t(1) << p) < v) ++p;
+    return p;
+}
+
+// 128-bit helpers so (len*L - phi + 1)/M style expressions never overflow
+static int64_t ceil_div_i128(__int128 a, __int128 b) {
+    __int128 q = a / b, r = a % b;
+    if (r != 0 && ((r > 0) == (b > 0))) ++q;
+    return (int64_t)q;
+}
+static int64_t floor_div_i128(__int128 a, __int128 b) {
+    __int128 q = a / b, r = a % b;
+    if (r != 0 && ((r > 0) != (b > 0))) --q;
+    return (int64_t)q;
+}
+
+}  // namespace mdsp
+
+using namespace mdsp;
+
+extern "C" {
+
+int mdsp_version(void) { return MDSP_VERSION; }
+
+const char* mdsp_last_error_string(void) { return g_err.c_str(); }
+
+int mdsp_device_count(int* count) {
+    if (!count) MDSP_FAIL(MDSP_ERR_ARGUMENT, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return MDSP_OK;
+}
+
+int mdsp_init(int device) {
+    int n = 0;
+    MDSP_TRY(mdsp_device_count(&n));
+    if (n <= 0) MDSP_FAIL(MDSP_ERR_DEVICE, "no HIP device visible: libmi355dsp has no CPU fallback");
+    if (device < 0 || device >= n) MDSP_FAIL(MDSP_ERR_ARGUMENT, "device %d out of range [0,%d)", device, n);
+    MDSP_HIP(hipSetDevice(device));
+    return MDSP_OK;
+}
+
+int mdsp_shutdown(void) { return MDSP_OK; }
+
+int mdsp_malloc(void** dev_ptr, size_t bytes) {
+    if (!dev_ptr) MDSP_FAIL(MDSP_ERR_ARGUMENT, "dev_ptr is NULL");
+    *dev_ptr = nullptr;
+    if (bytes == 0) return MDSP_OK;
+    MDSP_HIP(hipMalloc(dev_ptr, bytes));
+    return MDSP_OK;
+}
+int mdsp_free(void* dev_ptr) {
+    if (dev_ptr) MDSP_HIP(hipFree(dev_ptr));
+    return MDSP_OK;
+}
+int mdsp_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+    if (bytes == 0) return MDSP_OK;
+    MDSP_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    MDSP_HIP(hipStreamSynchronize(as_stream(stream)));
+    return MDSP_OK;
+}
+int mdsp_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream) {
+    if (bytes == 0) return MDSP_OK;
+    MDSP_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    MDSP_HIP(hipStreamSynchronize(as_stream(stream)));
+    return MDSP_OK;
+}
+int mdsp_memset(void* dst_dev, int value, size_t bytes, void* stream) {
+    if (bytes == 0) return MDSP_OK;
+    MDSP_HIP(hipMemsetAsync(dst_dev, value, bytes, as_stream(stream)));
+    return MDSP_OK;
+}
+int mdsp_stream_synchronize(void* stream) {
+    MDSP_HIP(hipStreamSynchronize(as_stream(stream)));
+    return MDSP_OK;
+}
+
+// util.jl:134
+int64_t mdsp_nextfastfft(int64_t n) { return nextprod2357(n); }
+
+// dspbase.jl:268-291
+int64_t mdsp_optimal_fft_len(int64_t nb, int64_t nx) {
+    if (nb < 1 || nx < 0) return -1;
+    const int64_t nfull = nb + nx - 1;
+    if (nfull < 1) return 1;
+    const int64_t first_pow2 = ceil_log2(nb);
+    const int64_t max_pow2 = ceil_log2(nfull);
+    double prev = os_fft_complexity((double)(int64_t(1) << first_pow2), (double)nb);
+    int64_t pow2 = first_pow2 + 1;
+    while (pow2 <= max_pow2) {
+        const double cur = os_fft_complexity((double)(int64_t(1) << pow2), (double)nb);
+        if (cur > prev) break;
+        prev = cur;
+        ++pow2;
+    }
+    int64_t nfft = pow2 > max_pow2 ? (int64_t(1) << max_pow2) : (int64_t(1) << (pow2 - 1));
+    if (nfft > nfull) nfft = nextprod2357(nfull);
+    return nfft;
+}
+
+// periodograms.jl:49-50
+int64_t mdsp_frame_count(int64_t len, int64_t n, int64_t noverlap) {
+    if (n <= 0 || noverlap < 0 || noverlap >= n) return -1;
+    return len >= n ? (len - n) / (n - noverlap) + 1 : 0;
+}
+
+// stream_filt.jl:317-322: ceil(((inputlength*L) - phi + 1) / M)
+int64_t mdsp_outputlength(int64_t inputlength, int64_t L, int64_t M, int64_t initial_phi) {
+    if (L <= 0 || M <= 0) return -1;
+    return ceil_div_i128((__int128)inputlength * L - initial_phi + 1, M);
+}
+
+// stream_filt.jl:358-364: round((outputlength*M + phi - d) / L, r), d = M for RoundUp else 1
+int64_t mdsp_inputlength(int64_t outputlength, int64_t L, int64_t M, int64_t initial_phi, int round_up) {
+    if (L <= 0 || M <= 0) return -1;
+    const __int128 num = (__int128)outputlength * M + initial_phi - (round_up ? M : 1);
+    return round_up ? ceil_div_i128(num, L) : floor_div_i128(num, L);
+}
+
+// Filters/filt.jl:490, 504-517
+int mdsp_ols_block_geometry(int64_t nb, int64_t nx, int64_t nfft, int64_t iblock, int64_t* off, int64_t* npadbefore,
+                            int64_t* xstart, int64_t* n, int64_t* nout) {
+    if (nb < 1 || nfft < nb || nx < 0 || iblock < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "bad overlap-save geometry");
+    const int64_t L = std::min<int64_t>(nx, nfft - (nb - 1));
+    if (L <= 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "empty input has no blocks");
+    const int64_t o = 1 + iblock * L;
+    if (o > nx) MDSP_FAIL(MDSP_ERR_ARGUMENT, "block %lld beyond the end of x", (long long)iblock);
+    const int64_t pad = std::max<int64_t>(0, nb - o);
+    const int64_t xs = o - nb + pad + 1;
+    if (off) *off = o;
+    if (npadbefore) *npadbefore = pad;
+    if (xstart) *xstart = xs;
+    if (n) *n = std::min<int64_t>(nfft - pad, nx - xs + 1);
+    if (nout) *nout = std::min<int64_t>(L, nx - o + 1);
+    return MDSP_OK;
+}
+
+// ---- measurement helpers -----------------------------------------------------------------------------
+int mdsp_event_create(void** ev) {
+    if (!ev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "ev is NULL");
+    hipEvent_t e;
+    MDSP_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return MDSP_OK;
+}
+int mdsp_event_destroy(void* ev) {
+    if (ev) MDSP_HIP(hipEventDestroy((hipEvent_t)ev));
+    return MDSP_OK;
+}
+int mdsp_event_record(void* ev, void* stream) {
+    MDSP_HIP(hipEventRecord((hipEvent_t)ev, as_stream(stream)));
+    return MDSP_OK;
+}
+int mdsp_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+    if (!ms) MDSP_FAIL(MDSP_ERR_ARGUMENT, "ms is NULL");
+    MDSP_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
+    MDSP_HIP(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return MDSP_OK;
+}
+
+}  // extern "C"
+
+// float4 grid-stride copy: the on-box HBM yardstick
+__global__ __launch_bounds__(256) void mdsp_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+extern "C" int mdsp_copy_bench(void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
+    if (bytes % 16) MDSP_FAIL(MDSP_ERR_ARGUMENT, "bytes must be a multiple of 16");
+    const size_t n4 = bytes / 16;
+    if (n4 == 0) return MDSP_OK;
+    const int grid = (int)std::min<size_t>((n4 + 255) / 256, (size_t)device_cu_count() * 8);
+    hipLaunchKernelGGL(mdsp_copy_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (float4*)dst_dev,
+                       (const float4*)src_dev, n4);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}

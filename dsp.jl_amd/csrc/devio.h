@@ -1,0 +1,121 @@
+// Device-side streaming I/O through buffer descriptors (SRSRC): 32-bit per-lane byte offsets, hardware
+// bounds checking.  Reads past the end of a signal (and, via an out-of-range sentinel offset, before its
+// start) return 0 and stores there are dropped -- which is exactly the zero padding the reference does by
+// hand for the first / last overlap-save blocks (Filters/filt.jl:505-510) and frame tails.
+//
+// Descriptors are built from wave-uniform values passed through readfirstlane so hipcc keeps them in SGPRs
+// (no waterfall loops, cdna guide T20).  A descriptor addresses at most 2 GiB; callers re-base it per unit of
+// work, so a 4 GiB+ column is fine.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fft_lds.h"
+
+namespace mdsp {
+namespace io {
+
+using fft::cx;
+
+constexpr int OOB = (int)0x80000000;  // byte offset that is out of range for every descriptor built here
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long long bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    long long nb = bytes < 0 ? 0 : (bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes);
+    const unsigned n = __builtin_amdgcn_readfirstlane((unsigned)nb);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)n, 0x00020000);
+}
+
+template <typename T> struct Ld;
+template <> struct Ld<float> {
+    static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, int off) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    }
+    static __device__ __forceinline__ void store(float v, __amdgpu_buffer_rsrc_t r, int off) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
+    }
+};
+template <> struct Ld<double> {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t r, int off) {
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        return __hiloint2double((int)v.y, (int)v.x);
+    }
+    static __device__ __forceinline__ void store(double d, __amdgpu_buffer_rsrc_t r, int off) {
+        u2 v;
+        v.x = (unsigned)__double2loint(d);
+        v.y = (unsigned)__double2hiint(d);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0);
+    }
+};
+template <> struct Ld<cx<float>> {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ cx<float> load(__amdgpu_buffer_rsrc_t r, int off) {
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        return {__uint_as_float(v.x), __uint_as_float(v.y)};
+    }
+    static __device__ __forceinline__ void store(cx<float> c, __amdgpu_buffer_rsrc_t r, int off) {
+        u2 v;
+        v.x = __float_as_uint(c.x);
+        v.y = __float_as_uint(c.y);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0);
+    }
+};
+template <> struct Ld<cx<double>> {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ cx<double> load(__amdgpu_buffer_rsrc_t r, int off) {
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        return {__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z)};
+    }
+    static __device__ __forceinline__ void store(cx<double> c, __amdgpu_buffer_rsrc_t r, int off) {
+        u4 v;
+        v.x = (unsigned)__double2loint(c.x);
+        v.y = (unsigned)__double2hiint(c.x);
+        v.z = (unsigned)__double2loint(c.y);
+        v.w = (unsigned)__double2hiint(c.y);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+    }
+};
+
+// Strided unit I/O: thread t of a T-thread transform owns elements i = t + T*e, e = 0..E-1, of a window that
+// starts `lead` elements BEFORE the first addressable element of the descriptor (lead >= 0, wave-uniform):
+//   * elements with i < lead do not exist (zero padding in front of x / discarded aliased outputs);
+//   * the descriptor is based at window element `lead`... no: it is based at window element 0, i.e. up to `lead`
+//     elements before the array.  Those addresses are never touched: whole-element groups below `lead` are
+//     skipped by wave-uniform branches and the one straddling group uses the OOB sentinel per lane.
+//   * past-the-end elements are handled by the descriptor's num_records (reads 0 / store dropped).
+// All per-element offsets are one VGPR (t*SZ) plus immediates; nothing per-element is loop-invariant state.
+template <typename T, int E, int TT> __device__ __forceinline__ void load_window(T (&out)[E], __amdgpu_buffer_rsrc_t r, int lead, int t) {
+    constexpr int SZ = (int)sizeof(T);
+    int off = t * SZ;
+    asm volatile("" : "+v"(off));  // keep LICM from materialising E offset VGPRs outside the persistent loop
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (TT * e >= lead) {  // uniform: every lane valid (the common case: lead == 0)
+            out[e] = Ld<T>::load(r, off + TT * e * SZ);
+        } else if (TT * (e + 1) <= lead) {  // uniform: every lane in the zero padding
+            out[e] = T{};
+        } else {
+            out[e] = Ld<T>::load(r, (t + TT * e) < lead ? OOB : off + TT * e * SZ);
+        }
+    }
+}
+
+template <typename T, int E, int TT, typename F> __device__ __forceinline__ void store_window(F&& get, __amdgpu_buffer_rsrc_t w, int lead, int t) {
+    constexpr int SZ = (int)sizeof(T);
+    int off = t * SZ;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (TT * e >= lead) {
+            Ld<T>::store(get(e), w, off + TT * e * SZ);
+        } else if (TT * (e + 1) > lead) {
+            Ld<T>::store(get(e), w, (t + TT * e) < lead ? OOB : off + TT * e * SZ);
+        }
+    }
+}
+
+}  // namespace io
+}  // namespace mdsp

@@ -1,0 +1,43 @@
+// Device-side driver for the workgroup FFT of fft_lds.h: runs the P passes with the inter-pass LDS exchanges and
+// the synchronisation they need.
+//
+//  * T == 64 (one wavefront per transform): no s_barrier at all -- DS operations of one wave execute in issue
+//    order, so a scheduling fence is enough.
+//  * T > 64: one __syncthreads() per exchange when the LDS region is double-buffered (NBUF == 2; exchange k uses
+//    buffer k & 1, so a buffer is only rewritten after a barrier that every reader of its previous contents has
+//    passed), two per exchange with a single buffer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "fft_lds.h"
+
+namespace mdsp {
+namespace fft {
+
+template <int T> __device__ __forceinline__ void wg_sync() {
+    if constexpr (T <= 64) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
+
+template <typename C, int PADSHIFT, int NBUF> constexpr int wg_lds_elems() { return NBUF * lds_elems<C::N, PADSHIFT>(); }
+
+// XBASE: index (mod NBUF) of the buffer used by this transform's first exchange.
+template <typename C, int DIR, bool TWREG, int PADSHIFT, int NBUF, int XBASE, int PASS = 0, typename R>
+__device__ __forceinline__ void wg_fft(cx<R> (&v)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], const cx<R>* table, cx<R>* lds) {
+    constexpr int BUF = (XBASE + PASS) % NBUF;
+    cx<R>* region = lds + BUF * lds_elems<C::N, PADSHIFT>();
+    pass_compute<C, DIR, PASS, TWREG, PADSHIFT>(v, t, tw, table, region);
+    if constexpr (PASS < C::P - 1) {
+        wg_sync<C::T>();
+        pass_reload<C, PADSHIFT>(v, t, region);
+        if constexpr (NBUF == 1) wg_sync<C::T>();
+        wg_fft<C, DIR, TWREG, PADSHIFT, NBUF, XBASE, PASS + 1>(v, t, tw, table, lds);
+    }
+}
+
+// Number of exchanges one transform performs.
+template <typename C> constexpr int wg_exchanges() { return C::P - 1; }
+
+}  // namespace fft
+}  // namespace mdsp

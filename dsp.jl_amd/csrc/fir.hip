@@ -1,0 +1,398 @@
+// Stateful polyphase FIR filtering / rational resampling (mdsp_fir_*) and time-domain FIR (mdsp_tdfir_exec).
+//
+// Reference loop being replaced (src/Filters/stream_filt.jl:496-509, and its :409-428 / :452-463 / :541-552 twins):
+//     while inputIdx <= xLen
+//         y[bufIdx += 1] = unsafe_dot(pfb, phiIdx, (history,) x, inputIdx)      util.jl:225-283 (BLAS.dot per sample)
+//         inputIdx += div(phiIdx + M - 1, L);  phiIdx = mod1(phiIdx + mod(M, L), L)
+// The recurrence is serial; its closed form makes every output independent: for 0-based output m
+//     p = (phi0 - 1) + m*M,   phi_m = p mod L (0-based column),   inputIdx_m = d0 + p div L (1-based, as the reference)
+//     y[m] = sum_{i=0}^{tp-1} pfb[i, phi_m] * z[inputIdx_m - 1 + i],     z = [history (tp-1 samples) ; x]
+// FIRStandard is L = M = 1, FIRDecimator L = 1, FIRInterpolator M = 1 (pfb = reversed taps for L = 1), so one
+// kernel serves all four reference kernels.  phi0 / d0 / history are exactly the reference's state and are
+// advanced on the host with the same integer arithmetic (bit-exact, see mdsp_fir_exec).
+//
+// Kernel: each workgroup produces a tile of consecutive outputs of one channel.  The input span of the tile
+// (plus the tp-1 sample history halo) is staged once into LDS with coalesced loads, the transposed filter bank
+// pfbT[i][phi] lives in LDS as well (phase index contiguous: lanes advance by M mod L phases per output, which
+// spreads them over the banks), and every output is a tp-term fused multiply-add chain, oldest sample first.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "common.h"
+#include "fft_lds.h"
+
+using namespace mdsp;
+using mdsp::fft::cx;
+
+namespace {
+
+template <typename R> __device__ __forceinline__ R to_acc(float v, R*) { return (R)v; }
+template <typename R> __device__ __forceinline__ R to_acc(double v, R*) { return (R)v; }
+template <typename R> __device__ __forceinline__ cx<R> to_acc(cx<float> v, cx<R>*) { return {(R)v.x, (R)v.y}; }
+template <typename R> __device__ __forceinline__ cx<R> to_acc(cx<double> v, cx<R>*) { return {(R)v.x, (R)v.y}; }
+template <typename R> __device__ __forceinline__ void fma_acc(R& acc, R h, R x) { acc = fma(x, h, acc); }
+template <typename R> __device__ __forceinline__ void fma_acc(cx<R>& acc, R h, cx<R> x) {
+    acc.x = fma(x.x, h, acc.x);
+    acc.y = fma(x.y, h, acc.y);
+}
+template <typename R> __device__ __forceinline__ R mul_first(R h, R x) { return h * x; }
+template <typename R> __device__ __forceinline__ cx<R> mul_first(R h, cx<R> x) { return {h * x.x, h * x.y}; }
+
+struct FirArgs {
+    const void* x;       // (xlen, nch), ld ldx, storage type XS
+    const void* hist;    // (hl, nch) storage type XS
+    void* y;             // (ycap, nch), ld ldy, type A
+    const void* pfbT;    // tp * L taps (compute real type R), pfbT[i*L + phi]
+    int64_t xlen, ldx, ldy, nout;
+    int64_t phi0m1;      // phi0 - 1
+    int64_t d0;          // input deficit (1-based first input index)
+    int L, M, tp, hl;
+    int tile;            // outputs per workgroup
+    int span;            // LDS samples per tile (upper bound)
+    int pfb_in_lds;
+};
+
+// XS: storage type of x (float, double, cx<float>, cx<double>);  A: accumulate/output type (R or cx<R>)
+template <typename XS, typename A, typename R>
+__global__ __launch_bounds__(256) void polyphase_fir_kernel(FirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    A* zs = reinterpret_cast<A*>(smem);                                  // staged input span (converted to A)
+    R* ps = reinterpret_cast<R*>(smem + (size_t)a.span * sizeof(A));      // pfbT (optional)
+    const int64_t ch = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * a.tile;
+    if (m0 >= a.nout) return;
+    const int cnt = (int)std::min<int64_t>(a.tile, a.nout - m0);
+    const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
+    const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
+    // z-index range of the tile: first = inputIdx(m0) - 1, last = inputIdx(m0+cnt-1) - 1 + tp - 1
+    const int64_t p_first = a.phi0m1 + m0 * a.M;
+    const int64_t p_last = a.phi0m1 + (m0 + cnt - 1) * a.M;
+    const int64_t z_first = a.d0 + p_first / a.L - 1;
+    const int64_t z_last = a.d0 + p_last / a.L - 1 + a.tp - 1;
+    const int nz = (int)(z_last - z_first + 1);
+    for (int k = threadIdx.x; k < nz; k += blockDim.x) {
+        const int64_t zi = z_first + k;  // index into [history ; x]
+        A v{};
+        if (zi < a.hl) v = to_acc(hc[zi], (A*)nullptr);
+        else if (zi - a.hl < a.xlen) v = to_acc(xc[zi - a.hl], (A*)nullptr);
+        zs[k] = v;
+    }
+    const R* pf = static_cast<const R*>(a.pfbT);
+    if (a.pfb_in_lds) {
+        const int np = a.tp * a.L;
+        for (int k = threadIdx.x; k < np; k += blockDim.x) ps[k] = pf[k];
+        pf = ps;
+    }
+    __syncthreads();
+    A* yc = static_cast<A*>(a.y) + ch * a.ldy;
+    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+        const int64_t p = p_first + (int64_t)j * a.M;
+        const int phi = (int)(p % a.L);
+        const int zoff = (int)(a.d0 + p / a.L - 1 - z_first);
+        const A* zp = zs + zoff;
+        const R* hp = pf + phi;
+        A acc = mul_first(hp[0], zp[0]);
+        for (int i = 1; i < a.tp; ++i) fma_acc(acc, hp[(int64_t)i * a.L], zp[i]);
+        yc[m0 + j] = acc;
+    }
+}
+
+// history update (shiftin!, util.jl:299-314): new = last hl samples of [old ; x]
+template <typename XS>
+__global__ __launch_bounds__(256) void shiftin_kernel(const XS* __restrict__ x, const XS* __restrict__ old, XS* __restrict__ neu, int64_t xlen,
+                                                      int64_t ldx, int hl) {
+    const int64_t ch = blockIdx.y;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < hl; k += gridDim.x * blockDim.x) {
+        const int64_t zi = (int64_t)hl + xlen - hl + k;  // index into [old ; x] of new[k]  = xlen + k
+        XS v;
+        if (zi < hl) v = old[ch * hl + zi];
+        else v = x[ch * ldx + (zi - hl)];
+        neu[ch * hl + k] = v;
+    }
+}
+
+int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
+
+}  // namespace
+
+struct mdsp_fir_s {
+    int kind = 0;  // 0 standard, 1 interpolator, 2 decimator, 3 rational
+    int64_t L = 1, M = 1, hlen = 0, tp = 0, hl = 0, nch = 1;
+    int taps_dtype = MDSP_F32, x_dtype = MDSP_F32, out_dtype = MDSP_F32;
+    bool acc_double = false;
+    int64_t phi_idx = 1, input_deficit = 1;  // the reference's 1-based state
+    DevBuf pfbT;
+    DevBuf hist[2];
+    int cur = 0;
+};
+
+namespace {
+
+template <typename XS, typename A, typename R> int fir_launch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
+    // tile size: keep the staged span + filter bank within 64 KiB of LDS
+    const int64_t pfb_bytes = (int64_t)f->tp * f->L * (int64_t)sizeof(R);
+    a.pfb_in_lds = pfb_bytes <= 40 * 1024;
+    int tile = 4096;
+    int64_t span = 0;
+    while (true) {
+        span = ((int64_t)tile * f->M + f->L - 1) / f->L + f->tp + 2;
+        const int64_t bytes = span * (int64_t)sizeof(A) + (a.pfb_in_lds ? pfb_bytes : 0);
+        if (bytes <= 64 * 1024 || tile <= 64) break;
+        tile /= 2;
+    }
+    const int64_t lds_bytes = span * (int64_t)sizeof(A) + (a.pfb_in_lds ? pfb_bytes : 0);
+    if (lds_bytes > 150 * 1024) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "filter too long for the polyphase kernel (tapsPerPhase=%lld)", (long long)f->tp);
+    a.tile = tile;
+    a.span = (int)span;
+    auto kern = polyphase_fir_kernel<XS, A, R>;
+    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const dim3 grid((unsigned)cdiv(a.nout, tile), (unsigned)f->nch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)lds_bytes, st, a);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
+    const bool d = f->acc_double;
+    switch (f->x_dtype) {
+        case MDSP_F32: return d ? fir_launch<float, double, double>(f, a, st) : fir_launch<float, float, float>(f, a, st);
+        case MDSP_F64: return fir_launch<double, double, double>(f, a, st);
+        case MDSP_C32: return d ? fir_launch<cx<float>, cx<double>, double>(f, a, st) : fir_launch<cx<float>, cx<float>, float>(f, a, st);
+        default: return fir_launch<cx<double>, cx<double>, double>(f, a, st);
+    }
+}
+
+template <typename XS> int shiftin_launch(mdsp_fir_s* f, const void* x, int64_t xlen, int64_t ldx, hipStream_t st) {
+    if (f->hl == 0) return MDSP_OK;
+    const int nxt = f->cur ^ 1;
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv(f->hl, 256), 64), (unsigned)f->nch);
+    hipLaunchKernelGGL(shiftin_kernel<XS>, grid, dim3(256), 0, st, (const XS*)x, f->hist[f->cur].as<XS>(), f->hist[nxt].as<XS>(), xlen, ldx, (int)f->hl);
+    MDSP_LAUNCH_CHECK();
+    f->cur = nxt;
+    return MDSP_OK;
+}
+
+int shiftin_dispatch(mdsp_fir_s* f, const void* x, int64_t xlen, int64_t ldx, hipStream_t st) {
+    if (xlen == 0) return MDSP_OK;
+    switch (f->x_dtype) {
+        case MDSP_F32: return shiftin_launch<float>(f, x, xlen, ldx, st);
+        case MDSP_F64: return shiftin_launch<double>(f, x, xlen, ldx, st);
+        case MDSP_C32: return shiftin_launch<cx<float>>(f, x, xlen, ldx, st);
+        default: return shiftin_launch<cx<double>>(f, x, xlen, ldx, st);
+    }
+}
+
+// Julia's round(Int, x): round half to even
+int64_t round_half_even(double v) { return (int64_t)std::nearbyint(v); }
+
+}  // namespace
+
+extern "C" {
+
+int mdsp_fir_create(mdsp_fir* fo, const void* taps_host, int64_t hlen, int64_t L, int64_t M, int taps_dtype, int x_dtype, int64_t nch) {
+    if (!fo) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle pointer is NULL");
+    *fo = nullptr;
+    if (!taps_host || hlen < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "filter taps must be non-empty");
+    if (L < 1 || M < 1) MDSP_FAIL(MDSP_ERR_DOMAIN, "resampling ratio must be positive");
+    if (taps_dtype != MDSP_F32 && taps_dtype != MDSP_F64) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "only real Float32/Float64 taps are supported on the device");
+    if (!dtype_valid(x_dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid x dtype");
+    if (nch < 1 || nch > 65535) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nch must be in [1, 65535]");
+    const int64_t g = gcd64(L, M);  // Rational normalisation (numerator / denominator of L//M)
+    L /= g;
+    M /= g;
+    if (L > (int64_t(1) << 20) || M > (int64_t(1) << 30)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "ratio terms too large");
+    auto f = new mdsp_fir_s();
+    f->L = L;
+    f->M = M;
+    f->hlen = hlen;
+    f->nch = nch;
+    f->taps_dtype = taps_dtype;
+    f->x_dtype = x_dtype;
+    f->kind = (L == 1 && M == 1) ? 0 : (M == 1 ? 1 : (L == 1 ? 2 : 3));
+    f->tp = cdiv(hlen, L);                       // taps2pfb: tapsPerPhase = ceil(hLen / Nphi)   (stream_filt.jl:296)
+    f->hl = f->tp - 1;                           // historyLen (:163,:166,:169,:172)
+    f->acc_double = (taps_dtype == MDSP_F64) || dtype_is_double(x_dtype);  // promote_type(Th, Tx)
+    f->out_dtype = dtype_is_complex(x_dtype) ? (f->acc_double ? MDSP_C64 : MDSP_C32) : (f->acc_double ? MDSP_F64 : MDSP_F32);
+    // pfbT[i*L + c] = pfb[i+1, c+1] with pfb[row, col] = h[(tp-row)*L + col] (1-based rows from the bottom, :300-304)
+    const size_t np = (size_t)(f->tp * L);
+    std::vector<double> pd(np, 0.0);
+    for (int64_t row = 0; row < f->tp; ++row)       // row 0 = top of the matrix
+        for (int64_t col = 0; col < L; ++col) {
+            const int64_t hidx = (f->tp - 1 - row) * L + col;  // bottom row holds h[0..L)
+            double v = 0;
+            if (hidx < hlen) v = taps_dtype == MDSP_F32 ? (double)((const float*)taps_host)[hidx] : ((const double*)taps_host)[hidx];
+            pd[(size_t)(row * L + col)] = v;
+        }
+    int st = MDSP_OK;
+    if (f->acc_double) {
+        st = f->pfbT.reserve(sizeof(double) * np);
+        if (st == MDSP_OK && hipMemcpy(f->pfbT.p, pd.data(), sizeof(double) * np, hipMemcpyHostToDevice) != hipSuccess) st = set_error(MDSP_ERR_DEVICE, "tap upload failed");
+    } else {
+        std::vector<float> pf(np);
+        for (size_t i = 0; i < np; ++i) pf[i] = (float)pd[i];
+        st = f->pfbT.reserve(sizeof(float) * np);
+        if (st == MDSP_OK && hipMemcpy(f->pfbT.p, pf.data(), sizeof(float) * np, hipMemcpyHostToDevice) != hipSuccess) st = set_error(MDSP_ERR_DEVICE, "tap upload failed");
+    }
+    const size_t hbytes = dtype_size(x_dtype) * (size_t)std::max<int64_t>(1, f->hl) * (size_t)nch;
+    for (int b = 0; b < 2 && st == MDSP_OK; ++b) {
+        st = f->hist[b].reserve(hbytes);
+        if (st == MDSP_OK && hipMemset(f->hist[b].p, 0, hbytes) != hipSuccess) st = set_error(MDSP_ERR_DEVICE, "history init failed");
+    }
+    if (st != MDSP_OK) {
+        delete f;
+        return st;
+    }
+    *fo = f;
+    return MDSP_OK;
+}
+
+int mdsp_fir_destroy(mdsp_fir f) {
+    delete f;
+    return MDSP_OK;
+}
+
+int mdsp_fir_reset(mdsp_fir f) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    const size_t hbytes = dtype_size(f->x_dtype) * (size_t)std::max<int64_t>(1, f->hl) * (size_t)f->nch;
+    MDSP_HIP(hipMemset(f->hist[f->cur].p, 0, hbytes));
+    f->phi_idx = 1;
+    f->input_deficit = 1;
+    return MDSP_OK;
+}
+
+int mdsp_fir_setphase(mdsp_fir f, double phi) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (!(phi >= 0)) MDSP_FAIL(MDSP_ERR_DOMAIN, "phi must be >= 0");
+    if (f->kind == 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "setphase! is not defined for a single-rate FIRFilter");
+    if (f->kind == 2) {  // :216-221
+        f->input_deficit += round_half_even(phi);
+    } else {  // :223-229
+        const int64_t q = round_half_even(phi * (double)f->L);
+        f->input_deficit += q / f->L;
+        f->phi_idx = q % f->L + 1;
+    }
+    return MDSP_OK;
+}
+
+int mdsp_fir_timedelay(mdsp_fir f, double* tau) {
+    if (!f || !tau) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    *tau = (f->kind == 1 || f->kind == 3) ? (double)(f->hlen - 1) / (double)(2 * f->L) : (double)(f->hlen - 1) / 2.0;
+    return MDSP_OK;
+}
+
+int mdsp_fir_outputlength(mdsp_fir f, int64_t inputlength, int64_t* outlen) {
+    if (!f || !outlen) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    if (f->kind == 0) *outlen = inputlength;
+    else *outlen = mdsp_outputlength(inputlength - f->input_deficit + 1, f->L, f->M, f->kind == 2 ? 1 : f->phi_idx);
+    return MDSP_OK;
+}
+
+int mdsp_fir_inputlength(mdsp_fir f, int64_t outputlength, int round_up, int64_t* inlen) {
+    if (!f || !inlen) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    if (f->kind == 0) *inlen = outputlength;
+    else *inlen = mdsp_inputlength(outputlength, f->L, f->M, f->kind == 2 ? 1 : f->phi_idx, round_up) + f->input_deficit - 1;
+    return MDSP_OK;
+}
+
+int mdsp_fir_info(mdsp_fir f, int* kind, int64_t* L, int64_t* M, int64_t* taps_per_phase, int64_t* history_len, int* out_dtype) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (kind) *kind = f->kind;
+    if (L) *L = f->L;
+    if (M) *M = f->M;
+    if (taps_per_phase) *taps_per_phase = f->tp;
+    if (history_len) *history_len = f->hl;
+    if (out_dtype) *out_dtype = f->out_dtype;
+    return MDSP_OK;
+}
+
+int mdsp_fir_get_state(mdsp_fir f, int64_t* phi_idx, int64_t* input_deficit, void* history_host) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (phi_idx) *phi_idx = f->phi_idx;
+    if (input_deficit) *input_deficit = f->input_deficit;
+    if (history_host && f->hl > 0) {
+        MDSP_HIP(hipDeviceSynchronize());
+        MDSP_HIP(hipMemcpy(history_host, f->hist[f->cur].p, dtype_size(f->x_dtype) * (size_t)f->hl * (size_t)f->nch, hipMemcpyDeviceToHost));
+    }
+    return MDSP_OK;
+}
+
+int mdsp_fir_set_state(mdsp_fir f, int64_t phi_idx, int64_t input_deficit, const void* history_host) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (phi_idx < 1 || phi_idx > f->L || input_deficit < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "state out of range");
+    f->phi_idx = phi_idx;
+    f->input_deficit = input_deficit;
+    if (history_host && f->hl > 0) {
+        MDSP_HIP(hipDeviceSynchronize());
+        MDSP_HIP(hipMemcpy(f->hist[f->cur].p, history_host, dtype_size(f->x_dtype) * (size_t)f->hl * (size_t)f->nch, hipMemcpyHostToDevice));
+    }
+    return MDSP_OK;
+}
+
+int mdsp_fir_exec(mdsp_fir f, const void* x_dev, int64_t xlen, int64_t ldx, void* y_dev, int64_t ycap, int64_t ldy, int64_t* nwritten,
+                  void* stream) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (xlen < 0 || ycap < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (f->nch > 1 && ldx < xlen) MDSP_FAIL(MDSP_ERR_ARGUMENT, "ldx smaller than xlen");
+    hipStream_t st = as_stream(stream);
+    if (nwritten) *nwritten = 0;
+    if (f->kind != 0 && xlen < f->input_deficit) {  // stream_filt.jl:483-487 (and :443-447, :529-533)
+        MDSP_TRY(shiftin_dispatch(f, x_dev, xlen, ldx, st));
+        f->input_deficit -= xlen;
+        return MDSP_OK;
+    }
+    const int64_t phi0 = f->kind == 2 ? 1 : f->phi_idx;
+    const int64_t d0 = f->kind == 0 ? 1 : f->input_deficit;
+    const int64_t nout = f->kind == 0 ? xlen : mdsp_outputlength(xlen - d0 + 1, f->L, f->M, phi0);
+    if (ycap < nout) MDSP_FAIL(MDSP_ERR_ARGUMENT, "buffer is too small: need %lld, have %lld", (long long)nout, (long long)ycap);
+    if (f->nch > 1 && ldy < nout) MDSP_FAIL(MDSP_ERR_ARGUMENT, "ldy smaller than the output length");
+    if (nout > 0) {
+        if (!x_dev || !y_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+        FirArgs a{};
+        a.x = x_dev;
+        a.hist = f->hist[f->cur].p;
+        a.y = y_dev;
+        a.pfbT = f->pfbT.p;
+        a.xlen = xlen;
+        a.ldx = ldx;
+        a.ldy = ldy;
+        a.nout = nout;
+        a.phi0m1 = phi0 - 1;
+        a.d0 = d0;
+        a.L = (int)f->L;
+        a.M = (int)f->M;
+        a.tp = (int)f->tp;
+        a.hl = (int)f->hl;
+        MDSP_TRY(fir_dispatch(f, a, st));
+    }
+    // state advance: closed form of the loop's final (inputIdx, phiIdx)   (:506-511)
+    const __int128 p_end = (__int128)(phi0 - 1) + (__int128)nout * f->M;
+    const int64_t input_idx_end = d0 + (int64_t)(p_end / f->L);
+    if (f->kind == 1 || f->kind == 3) f->phi_idx = (int64_t)(p_end % f->L) + 1;
+    if (f->kind == 1) f->input_deficit = 1;                              // :465
+    else if (f->kind != 0) f->input_deficit = input_idx_end - xlen;      // :511, :554
+    MDSP_TRY(shiftin_dispatch(f, x_dev, xlen, ldx, st));                 // :512
+    if (nwritten) *nwritten = nout;
+    return MDSP_OK;
+}
+
+// ---- time-domain FIR: filt(b, a::Number, x) / tdfilt (dspbase.jl:95-105) -------------------------------------
+// taps_host: nb REAL taps in the precision of `dtype`; x / y of `dtype`.  Same accumulation order as the TDF-II
+// recursion: oldest sample first, one multiply then a chain of fused multiply-adds.
+int mdsp_tdfir_exec(const void* taps_host, int64_t nb, int dtype, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,
+                    int64_t ldy, void* stream) {
+    if (!taps_host || nb < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "filter vector b must be non-empty");
+    if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype");
+    if (nx < 0 || ncols < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (nx == 0 || ncols == 0) return MDSP_OK;
+    if (ncols > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 columns per call");
+    mdsp_fir f = nullptr;
+    MDSP_TRY(mdsp_fir_create(&f, taps_host, nb, 1, 1, dtype_real_of(dtype), dtype, ncols));
+    int64_t nw = 0;
+    const int rc = mdsp_fir_exec(f, x_dev, nx, ldx, y_dev, nx, ldy, &nw, stream);
+    if (rc == MDSP_OK) (void)hipStreamSynchronize(as_stream(stream));  // the handle's buffers die with it
+    mdsp_fir_destroy(f);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,493 @@
+// Overlap-save FIR filtering / convolution (mdsp_ols_*).
+//
+// Reference loop being replaced (per block, serial, one buffer):  Filters/filt.jl:504-518
+//     fill!(tmp1,0); copyto!(tmp1, npadbefore+1, x, xstart, n)      K1  segment (nb-1 history | L new)
+//     mul!(tmp2, p1, tmp1)                                          F1  rfft
+//     tmp2 .*= filterft                                             K2  spectral multiply (1/nfft folded in)
+//     mul!(tmp1, p2, tmp2)                                          F2  unnormalised brfft
+//     copyto!(out, off, tmp1, nb, min(L, nx-off+1))                 K3  save the L valid samples
+// and its conv twin unsafe_conv_kern_os! (dspbase.jl:583-606, padded edge blocks :441-483).
+//
+// Block geometry (0-based here): block g covers outputs [g*L, g*L+L) and reads x[g*L-(nb-1) .. g*L-(nb-1)+nfft),
+// zero outside [0,nx).  That single rule reproduces npadbefore / n of filt.jl:505-507 for the leading blocks,
+// the trailing clamp, and the pad_before / pad_after / u_deficit arithmetic of the conv edge blocks.
+//
+// Two engines:
+//   FUSED  : one persistent kernel; each workgroup slot packs TWO real blocks into one complex nfft-point FFT
+//            (z = a + i b; linear filtering with real taps keeps them separable), does FFT -> *H -> IFFT in
+//            registers/LDS and stores the valid samples.  HBM traffic = read x once (+ (nb-1)/L overlap, L2) and
+//            write y once.
+//   ROCFFT : K1 -> rocFFT R2C -> K2 -> rocFFT C2R -> K3 over chunks sized to stay in the 256 MiB Infinity Cache.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "devio.h"
+#include "fft_lds.h"
+#include "fft_wg.h"
+#include "hostfft.h"
+#include "rocfft_wrap.h"
+
+using namespace mdsp;
+using mdsp::fft::cx;
+
+namespace {
+
+// ======================================================================================================
+// rocFFT-engine kernels
+// ======================================================================================================
+// K1: unit u = col*nblocks + g  ->  td[(u-u0)*nfft + i]
+template <typename T>
+__global__ __launch_bounds__(256) void ols_segment_kernel(const T* __restrict__ x, T* __restrict__ td, int64_t nx, int64_t ldx,
+                                                          int64_t nblocks, int64_t L, int nb, int nfft, int64_t u0, int64_t nunits) {
+    const int64_t u = u0 + blockIdx.y;
+    if (u >= nunits) return;
+    const int64_t col = u / nblocks, g = u - col * nblocks;
+    const int64_t start = g * L - (nb - 1);
+    const T* xc = x + col * ldx;
+    T* dst = td + (int64_t)blockIdx.y * nfft;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfft; i += gridDim.x * blockDim.x) {
+        const int64_t idx = start + i;
+        T v{};
+        if (idx >= 0 && idx < nx) v = xc[idx];
+        dst[i] = v;
+    }
+}
+
+// K2: fd[b*nspec + k] *= H[k]
+template <typename R>
+__global__ __launch_bounds__(256) void ols_cmul_kernel(cx<R>* __restrict__ fd, const cx<R>* __restrict__ H, int nspec, int64_t count) {
+    const int64_t b = blockIdx.y;
+    if (b >= count) return;
+    cx<R>* row = fd + b * nspec;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nspec; k += gridDim.x * blockDim.x) row[k] = fft::cmul(row[k], H[k]);
+}
+
+// K3: y[col*ldy + g*L + j] = td[(u-u0)*nfft + nb-1 + j]
+template <typename T>
+__global__ __launch_bounds__(256) void ols_save_kernel(const T* __restrict__ td, T* __restrict__ y, int64_t nout, int64_t ldy,
+                                                       int64_t nblocks, int64_t L, int nb, int nfft, int64_t u0, int64_t nunits) {
+    const int64_t u = u0 + blockIdx.y;
+    if (u >= nunits) return;
+    const int64_t col = u / nblocks, g = u - col * nblocks;
+    const int64_t off = g * L;
+    const int64_t cnt = std::min<int64_t>(L, nout - off);
+    const T* src = td + (int64_t)blockIdx.y * nfft + (nb - 1);
+    T* yc = y + col * ldy + off;
+    for (int64_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += (int64_t)gridDim.x * blockDim.x) yc[j] = src[j];
+}
+
+// ======================================================================================================
+// Fused kernel
+// ======================================================================================================
+struct OlsFusedArgs {
+    const void* x;
+    void* y;
+    const void* table;  // N forward roots
+    const void* H;      // N-point filter spectrum, 1/N folded in
+    int64_t nx, nout, ldx, ldy, L;
+    int64_t nblocks;        // per column
+    int64_t units_per_col;  // pairs (real) or blocks (complex)
+    int64_t nunits;         // total
+    int nb;
+};
+
+// Raw samples of one unit as they come from HBM: two real blocks (a, b) or one complex block.
+template <typename R, int E, bool CPLX> struct OlsRaw {
+    std::conditional_t<CPLX, cx<R>, R> a[E];
+    std::conditional_t<CPLX, char, R> b[CPLX ? 1 : E];
+};
+
+template <typename R, int E, int T, bool CPLX>
+__device__ __forceinline__ void ols_issue_loads(OlsRaw<R, E, CPLX>& raw, const OlsFusedArgs& a, int64_t u, int t) {
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    constexpr int64_t SZ = (int64_t)sizeof(TT);
+    const bool live = u < a.nunits;
+    const int64_t col = live ? u / a.units_per_col : 0;
+    const int64_t p = live ? u - col * a.units_per_col : 0;
+    const TT* xc = static_cast<const TT*>(a.x) + col * a.ldx;
+    const int64_t g0 = CPLX ? p : 2 * p;          // first block of the unit
+    const int64_t start = g0 * a.L - (a.nb - 1);  // window start in x; negative for the leading blocks
+    {
+        const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + start, live ? (a.nx - start) * SZ : 0);
+        const int lead = __builtin_amdgcn_readfirstlane((int)(start < 0 ? -start : 0));
+        io::load_window<TT, E, T>(raw.a, r, lead, t);
+    }
+    if constexpr (!CPLX) {
+        const bool haveB = live && (g0 + 1) < a.nblocks;
+        const int64_t startB = start + a.L;
+        const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + startB, haveB ? (a.nx - startB) * SZ : 0);
+        const int lead = __builtin_amdgcn_readfirstlane((int)(startB < 0 ? -startB : 0));
+        io::load_window<TT, E, T>(raw.b, r, lead, t);
+    }
+}
+
+template <typename R, int E, int T, bool CPLX>
+__device__ __forceinline__ void ols_store(const cx<R> (&v)[E], const OlsFusedArgs& a, int64_t u, int t) {
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    constexpr int64_t SZ = (int64_t)sizeof(TT);
+    const bool live = u < a.nunits;
+    const int64_t col = live ? u / a.units_per_col : 0;
+    const int64_t p = live ? u - col * a.units_per_col : 0;
+    const int64_t off0 = (CPLX ? p : 2 * p) * a.L;  // first output of the unit
+    const int lead = a.nb - 1;                      // K3: the first nb-1 samples of a block are aliased -> dropped
+    TT* yc = static_cast<TT*>(a.y) + col * a.ldy;
+    {
+        const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + off0 - lead, live ? (a.nout - off0 + lead) * SZ : 0);
+        if constexpr (CPLX) io::store_window<TT, E, T>([&](int e) { return v[e]; }, w, lead, t);
+        else io::store_window<TT, E, T>([&](int e) { return v[e].x; }, w, lead, t);
+    }
+    if constexpr (!CPLX) {
+        const int64_t offB = off0 + a.L;  // past nout when the unit has no second block: num_records <= 0 drops it
+        const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + offB - lead, (live && offB < a.nout) ? (a.nout - offB + lead) * SZ : 0);
+        io::store_window<TT, E, T>([&](int e) { return v[e].y; }, w, lead, t);
+    }
+}
+
+template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH>
+__global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedArgs a) {
+    using C = fft::Cfg<N, E>;
+    constexpr int T = C::T;
+    static_assert(T % 64 == 0, "a transform must own whole wavefronts (uniform descriptors)");
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
+    __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
+    const int t = threadIdx.x % T;
+    const int slot = threadIdx.x / T;
+    cx<R>* lds = lds_all + slot * REGION;
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+
+    cx<R> tw[NTWA];
+    if constexpr (TWREG) fft::load_twiddles<C, R>(tw, t, table);
+    cx<R> Hr[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) Hr[e] = static_cast<const cx<R>*>(a.H)[t + T * e];
+
+    const int64_t stride = (int64_t)gridDim.x * G;
+    const int64_t niter = (a.nunits + stride - 1) / stride;
+    const int64_t ufirst = (int64_t)blockIdx.x * G + slot;
+    OlsRaw<R, E, CPLX> raw;
+    if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, ufirst, t);
+    for (int64_t it = 0; it < niter; ++it) {
+        const int64_t u = it * stride + ufirst;
+        if constexpr (!PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, u, t);
+        cx<R> v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if constexpr (CPLX) v[e] = raw.a[e];
+            else v[e] = {raw.a[e], raw.b[e]};
+        }
+        // next unit's samples start streaming from HBM while this unit is transformed
+        if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, u + stride, t);
+        fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
+        // spectral multiply (K2): natural order in registers
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = fft::cmul(v[e], Hr[e]);
+        // inverse transform (unnormalised, like plan_brfft / inv(p).p)
+        fft::wg_fft<C, +1, TWREG, PADSHIFT, NBUF, (C::P - 1) % NBUF>(v, t, tw, table, lds);
+        // single buffer: the next iteration's first pass rewrites LDS that slower waves may still be reading
+        if constexpr (C::P > 1 && NBUF == 1) fft::wg_sync<T>();
+        ols_store<R, E, T, CPLX>(v, a, u, t);
+    }
+}
+
+}  // namespace
+
+// ======================================================================================================
+// Plan object
+// ======================================================================================================
+struct mdsp_ols_plan_s {
+    int dtype = MDSP_F32, mode = MDSP_OLS_FILT, engine = MDSP_ENGINE_ROCFFT;
+    int64_t nb = 0, nfft = 0, L = 0;
+    DevBuf H;       // rocFFT engine: nspec (real) or nfft (complex) entries; fused: nfft entries
+    DevBuf table;   // fused: nfft forward roots
+    // rocFFT engine state
+    RocPlan fwd, inv;
+    DevBuf td, fd;
+    int64_t batch = 0;
+    int variant = 0;  // fused kernel variant (tuning knob, MDSP_OLS_VARIANT)
+};
+
+namespace {
+
+bool fused_supported(int dtype, int64_t nfft) {
+    const bool dbl = dtype_is_double(dtype);
+    switch (nfft) {
+        case 256: case 512: case 1024: case 2048: case 4096: return true;
+        case 8192: return !dbl;
+        default: return false;
+    }
+}
+
+template <typename R> int upload_spectrum(mdsp_ols_plan_s* pl, const std::vector<zd>& Hfull, bool half) {
+    const int64_t n = half ? pl->nfft / 2 + 1 : pl->nfft;
+    std::vector<cx<R>> h((size_t)n);
+    for (int64_t k = 0; k < n; ++k) h[(size_t)k] = {(R)Hfull[(size_t)k].real(), (R)Hfull[(size_t)k].imag()};
+    MDSP_TRY(pl->H.reserve(sizeof(cx<R>) * (size_t)n));
+    MDSP_HIP(hipMemcpy(pl->H.p, h.data(), sizeof(cx<R>) * (size_t)n, hipMemcpyHostToDevice));
+    return MDSP_OK;
+}
+
+template <typename R> int upload_table(DevBuf& buf, int64_t n) {
+    std::vector<cx<R>> w((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        const zd r = unit_root(k, n, -1);
+        w[(size_t)k] = {(R)r.real(), (R)r.imag()};
+    }
+    MDSP_TRY(buf.reserve(sizeof(cx<R>) * (size_t)n));
+    MDSP_HIP(hipMemcpy(buf.p, w.data(), sizeof(cx<R>) * (size_t)n, hipMemcpyHostToDevice));
+    return MDSP_OK;
+}
+
+// ---- fused launch ---------------------------------------------------------------------------------------
+template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true>
+int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
+    auto kern = ols_fused_kernel<R, N, E, G, TWREG, PADSHIFT, CPLX, MINW, NBUF, PREFETCH>;
+    constexpr int threads = (N / E) * G;
+    int per_cu = 0;
+    MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
+    if (per_cu < 1) per_cu = 1;
+    const int64_t want = cdiv(a.nunits, G);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cu_count() * per_cu));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, a);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a, int variant, hipStream_t s) {
+    // Geometry: E elements per thread so that a transform owns whole wavefronts (T = N/E >= 64); G transforms
+    // per workgroup so that workgroups have 256 threads where possible.  `variant` selects tuning alternatives
+    // (MDSP_OLS_VARIANT, swept by bench/tune.py); the non-default ones are only built for the headline shape.
+    constexpr bool DBL = sizeof(R) == 8;
+    constexpr int EMAX = DBL ? 8 : 16;
+    constexpr int E = (N / 64 < EMAX) ? N / 64 : EMAX;
+    constexpr int T = N / E;
+    constexpr int G = T >= 256 ? 1 : 256 / T;
+    constexpr int NBUF = T <= 64 ? 1 : 2;
+    constexpr bool TWREG = !DBL;
+    if constexpr (N == 2048 && !CPLX && !DBL) {
+        switch (variant) {
+            //                                    R  N   E  G  TWREG PAD CPLX MINW NBUF PREFETCH
+            case 1: return launch_fused_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, true>(a, s);
+            case 2: return launch_fused_variant<R, N, 16, 2, true, 4, CPLX, 2, 1, true>(a, s);
+            case 3: return launch_fused_variant<R, N, 16, 2, true, 4, CPLX, 2, 2, false>(a, s);
+            case 4: return launch_fused_variant<R, N, 16, 2, true, 5, CPLX, 2, 2, true>(a, s);
+            case 5: return launch_fused_variant<R, N, 16, 2, false, 4, CPLX, 2, 2, true>(a, s);
+            case 6: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true>(a, s);
+            case 7: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 4, 1, true>(a, s);
+            case 8: return launch_fused_variant<R, N, 16, 2, true, 31, CPLX, 2, 2, true>(a, s);
+            default: break;
+        }
+    }
+    return launch_fused_variant<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true>(a, s);
+}
+
+template <typename R, bool CPLX> int launch_fused(int64_t nfft, const OlsFusedArgs& a, int variant, hipStream_t s) {
+    switch (nfft) {
+        case 256: return launch_fused_n<R, 256, CPLX>(a, variant, s);
+        case 512: return launch_fused_n<R, 512, CPLX>(a, variant, s);
+        case 1024: return launch_fused_n<R, 1024, CPLX>(a, variant, s);
+        case 2048: return launch_fused_n<R, 2048, CPLX>(a, variant, s);
+        case 4096: return launch_fused_n<R, 4096, CPLX>(a, variant, s);
+        case 8192:
+            if constexpr (sizeof(R) == 4) return launch_fused_n<R, 8192, CPLX>(a, variant, s);
+        default: break;
+    }
+    MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused overlap-save does not support nfft=%lld", (long long)nfft);
+}
+
+// ---- rocFFT engine --------------------------------------------------------------------------------------
+template <typename R, bool CPLX>
+int exec_rocfft(mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy,
+                hipStream_t s) {
+    using T = std::conditional_t<CPLX, cx<R>, R>;
+    const int64_t nfft = pl->nfft, L = pl->L;
+    const int64_t nblocks = cdiv(nout, L);
+    const int64_t nunits = nblocks * ncols;
+    const int64_t nspec = CPLX ? nfft : nfft / 2 + 1;
+    // chunk so that td + fd stay cache resident (~64 MiB)
+    const int64_t per_unit = (int64_t)sizeof(T) * nfft + (CPLX ? 0 : (int64_t)sizeof(cx<R>) * nspec);
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nunits, (int64_t(64) << 20) / per_unit));
+    if (pl->batch != batch) {
+        MDSP_TRY(pl->td.reserve((size_t)(sizeof(T) * nfft * batch)));
+        if (!CPLX) MDSP_TRY(pl->fd.reserve((size_t)(sizeof(cx<R>) * nspec * batch)));
+        const bool dbl = sizeof(R) == 8;
+        if (CPLX) {
+            MDSP_TRY(pl->fwd.create(FftKind::C2C_FWD, dbl, nfft, batch, true));
+            MDSP_TRY(pl->inv.create(FftKind::C2C_INV, dbl, nfft, batch, true));
+        } else {
+            MDSP_TRY(pl->fwd.create(FftKind::R2C, dbl, nfft, batch, false));
+            MDSP_TRY(pl->inv.create(FftKind::C2R, dbl, nfft, batch, false));
+        }
+        pl->batch = batch;
+    }
+    const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
+    for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
+        const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
+        hipLaunchKernelGGL(ols_segment_kernel<T>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, (const T*)x, pl->td.as<T>(), nx, ldx,
+                           nblocks, L, (int)pl->nb, (int)nfft, u0, nunits);
+        MDSP_LAUNCH_CHECK();
+        if (CPLX) {
+            MDSP_TRY(pl->fwd.exec(pl->td.p, nullptr, s));
+            hipLaunchKernelGGL(ols_cmul_kernel<R>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, pl->td.as<cx<R>>(), pl->H.as<cx<R>>(),
+                               (int)nspec, cnt);
+            MDSP_LAUNCH_CHECK();
+            MDSP_TRY(pl->inv.exec(pl->td.p, nullptr, s));
+        } else {
+            MDSP_TRY(pl->fwd.exec(pl->td.p, pl->fd.p, s));
+            hipLaunchKernelGGL(ols_cmul_kernel<R>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, pl->fd.as<cx<R>>(), pl->H.as<cx<R>>(),
+                               (int)nspec, cnt);
+            MDSP_LAUNCH_CHECK();
+            MDSP_TRY(pl->inv.exec(pl->fd.p, pl->td.p, s));
+        }
+        hipLaunchKernelGGL(ols_save_kernel<T>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, pl->td.as<T>(), (T*)y, nout, ldy, nblocks, L,
+                           (int)pl->nb, (int)nfft, u0, nunits);
+        MDSP_LAUNCH_CHECK();
+    }
+    return MDSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode,
+                         int engine) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    *plan = nullptr;
+    if (!taps_host || nb < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "filter vector b must be non-empty");
+    if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype %d", dtype);
+    if (mode != MDSP_OLS_FILT && mode != MDSP_OLS_CONV) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid mode %d", mode);
+    if (nfft == 0) nfft = mdsp_optimal_fft_len(nb, std::max<int64_t>(nx_hint, 1));
+    if (nfft < nb) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nfft (%lld) must be >= length(b) (%lld)", (long long)nfft, (long long)nb);
+    if (nfft > (int64_t(1) << 24)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft %lld too large", (long long)nfft);
+    int eng = engine;
+    if (eng == MDSP_ENGINE_AUTO) {
+        const char* env = getenv("MDSP_ENGINE");
+        if (env && !strcmp(env, "rocfft")) eng = MDSP_ENGINE_ROCFFT;
+        else if (env && !strcmp(env, "fused")) eng = MDSP_ENGINE_FUSED;
+    }
+    if (eng == MDSP_ENGINE_AUTO) eng = fused_supported(dtype, nfft) ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
+    if (eng == MDSP_ENGINE_FUSED && !fused_supported(dtype, nfft))
+        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft in [256, 8192]; got %lld", (long long)nfft);
+    if (eng != MDSP_ENGINE_FUSED && eng != MDSP_ENGINE_ROCFFT) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid engine %d", engine);
+
+    auto pl = new mdsp_ols_plan_s();
+    pl->dtype = dtype;
+    pl->mode = mode;
+    pl->engine = eng;
+    pl->nb = nb;
+    pl->nfft = nfft;
+    pl->L = nfft - (nb - 1);
+    if (const char* v = getenv("MDSP_OLS_VARIANT")) pl->variant = atoi(v);
+
+    // Filter spectrum in double on the host.  FILT: taps scaled by 1/nfft before the transform (filt.jl:499);
+    // CONV: spectrum scaled by 1/nfft afterwards (dspbase.jl:516).  The scaling is applied in the plan's working
+    // precision at the same place the reference applies it, the transform itself is evaluated in double.
+    const bool cplx = dtype_is_complex(dtype), dbl = dtype_is_double(dtype);
+    std::vector<zd> hp((size_t)nfft, zd(0, 0));
+    for (int64_t i = 0; i < nb; ++i) {
+        zd v;
+        if (dtype == MDSP_F32) v = zd(((const float*)taps_host)[i], 0);
+        else if (dtype == MDSP_F64) v = zd(((const double*)taps_host)[i], 0);
+        else if (dtype == MDSP_C32) v = zd(((const float*)taps_host)[2 * i], ((const float*)taps_host)[2 * i + 1]);
+        else v = zd(((const double*)taps_host)[2 * i], ((const double*)taps_host)[2 * i + 1]);
+        if (mode == MDSP_OLS_FILT) {
+            if (dbl) v = v / (double)nfft;
+            else v = zd((double)((float)v.real() / (float)nfft), (double)((float)v.imag() / (float)nfft));
+        }
+        hp[(size_t)i] = v;
+    }
+    std::vector<zd> Hf = host_fft(hp, -1);
+    if (mode == MDSP_OLS_CONV) {
+        const double sc = 1.0 / (double)nfft;
+        for (auto& h : Hf) h *= sc;
+    }
+    int st = MDSP_OK;
+    const bool half = (eng == MDSP_ENGINE_ROCFFT) && !cplx;
+    st = dbl ? upload_spectrum<double>(pl, Hf, half) : upload_spectrum<float>(pl, Hf, half);
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED) st = dbl ? upload_table<double>(pl->table, nfft) : upload_table<float>(pl->table, nfft);
+    if (st != MDSP_OK) {
+        delete pl;
+        return st;
+    }
+    *plan = pl;
+    return MDSP_OK;
+}
+
+int mdsp_ols_plan_destroy(mdsp_ols_plan plan) {
+    delete plan;
+    return MDSP_OK;
+}
+
+int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len, int* engine_used) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (nfft) *nfft = plan->nfft;
+    if (block_len) *block_len = plan->L;
+    if (engine_used) *engine_used = plan->engine;
+    return MDSP_OK;
+}
+
+int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev, int64_t nout, int64_t ldy,
+                  void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (nx < 0 || ncols < 0 || nout < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (nout > nx + plan->nb - 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nout (%lld) exceeds nx+nb-1", (long long)nout);
+    if (ncols > 1 && (ldx < nx || ldy < nout)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "leading dimension smaller than the column length");
+    if (nout == 0 || ncols == 0) return MDSP_OK;
+    if (!x_dev && nx > 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "x is NULL");
+    if (!y_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
+    if (x_dev == y_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out may not alias x");
+    hipStream_t s = as_stream(stream);
+    const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
+    if (plan->engine == MDSP_ENGINE_ROCFFT) {
+        if (cplx) return dbl ? exec_rocfft<double, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s)
+                             : exec_rocfft<float, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s);
+        return dbl ? exec_rocfft<double, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s)
+                   : exec_rocfft<float, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s);
+    }
+    OlsFusedArgs a;
+    a.x = x_dev;
+    a.y = y_dev;
+    a.table = plan->table.p;
+    a.H = plan->H.p;
+    a.nx = nx;
+    a.nout = nout;
+    a.ldx = ldx;
+    a.ldy = ldy;
+    a.L = plan->L;
+    a.nb = (int)plan->nb;
+    a.nblocks = cdiv(nout, plan->L);
+    a.units_per_col = cplx ? a.nblocks : cdiv(a.nblocks, 2);
+    a.nunits = a.units_per_col * ncols;
+    if (cplx) return dbl ? launch_fused<double, true>(plan->nfft, a, plan->variant, s) : launch_fused<float, true>(plan->nfft, a, plan->variant, s);
+    return dbl ? launch_fused<double, false>(plan->nfft, a, plan->variant, s) : launch_fused<float, false>(plan->nfft, a, plan->variant, s);
+}
+
+int mdsp_ols_segment(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t first_block, int64_t nblocks, void* seg_dev, void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (first_block < 0 || nblocks < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative block range");
+    if (nblocks == 0) return MDSP_OK;
+    hipStream_t s = as_stream(stream);
+    const int64_t nfft = plan->nfft;
+    const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
+    const int64_t total = first_block + nblocks;  // blocks of a single column: unit index == block index
+    const int64_t big = INT64_MAX / 4;
+    for (int64_t b0 = 0; b0 < nblocks; b0 += 32768) {
+        const int64_t cnt = std::min<int64_t>(32768, nblocks - b0);
+#define SEG(TT)                                                                                                                      \
+    hipLaunchKernelGGL(ols_segment_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, (const TT*)x_dev, (TT*)seg_dev + b0 * nfft, nx, \
+                       (int64_t)0, big, plan->L, (int)plan->nb, (int)nfft, first_block + b0, total)
+        switch (plan->dtype) {
+            case MDSP_F32: SEG(float); break;
+            case MDSP_F64: SEG(double); break;
+            case MDSP_C32: SEG(cx<float>); break;
+            default: SEG(cx<double>); break;
+        }
+#undef SEG
+        MDSP_LAUNCH_CHECK();
+    }
+    return MDSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,846 @@
+// Framing, Welch PSD, STFT / spectrogram / periodogram (mdsp_frames, mdsp_welch_*, mdsp_stft_*).
+//
+// Reference loops being replaced (src/periodograms.jl):
+//   K4  ArraySplit getindex :57-69     buf[i] = s[offset+i] * window[i], zero tail up to nfft
+//   F3  mul!(outbuf, plan, sig) :754, :888        rfft (real) / fft (complex), out of place
+//   K5  fft2pow! :142-172              out[i] = muladd(abs2(X[i]), m, out[i]),  m = 1/r or 2/r
+//   K6  fft2oneortwosided! :234-244    raw STFT column, conjugate mirror for real -> two-sided
+//
+// Frame k (0-based) of a channel covers s[k*hop .. k*hop+n), hop = n - noverlap; K = (len-n) div hop + 1 frames
+// (the trailing partial frame is dropped, :49-50).  The window is ALWAYS Float64 in the reference (:250): the
+// product is formed in double and rounded once to the buffer eltype -- done the same way here.
+//
+// Engines:
+//   FUSED  (power-of-two nfft in [256, 8192]):
+//     Welch : persistent kernel; a transform slot packs TWO real frames into one complex FFT (z = w*(a + i b)),
+//             and accumulates |Z[k]|^2 per bin in double in registers.  Since |A[k]|^2 + |B[k]|^2 =
+//             (|Z[k]|^2 + |Z[N-k]|^2)/2, no untangling is needed: the fold happens once in the tiny finalize
+//             kernel.  HBM traffic = the signal, read once (+ overlap re-reads served by L2).
+//     STFT  : window -> FFT -> (|X|^2 * m | X) -> coalesced column store, one kernel.
+//   ROCFFT : K4 kernel -> batched rocFFT -> K5/K6 kernel over cache-sized chunks; any nfft.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "devio.h"
+#include "fft_lds.h"
+#include "fft_wg.h"
+#include "hostfft.h"
+#include "rocfft_wrap.h"
+
+using namespace mdsp;
+using mdsp::fft::cx;
+
+namespace {
+
+template <typename T> struct real_of { using type = T; };
+template <typename R> struct real_of<cx<R>> { using type = R; };
+
+// Float64 window product, rounded once (periodograms.jl:66 `x.buf[i] = x.s[offset+i] * window[i]`)
+__device__ __forceinline__ float win_mul(float s, double w) { return (float)((double)s * w); }
+__device__ __forceinline__ double win_mul(double s, double w) { return s * w; }
+__device__ __forceinline__ cx<float> win_mul(cx<float> s, double w) { return {(float)((double)s.x * w), (float)((double)s.y * w)}; }
+__device__ __forceinline__ cx<double> win_mul(cx<double> s, double w) { return {s.x * w, s.y * w}; }
+
+// ======================================================================================================
+// rocFFT-engine kernels
+// ======================================================================================================
+// K4: frames [f0, f0+count) of channel `ch` (unit u = ch*K + f) -> fr[(u-u0)*nfft + i]
+template <typename T>
+__global__ __launch_bounds__(256) void frame_window_kernel(const T* __restrict__ s, T* __restrict__ fr, const double* __restrict__ win,
+                                                           int64_t lds_, int64_t K, int64_t hop, int n, int nfft, int64_t u0, int64_t nunits) {
+    const int64_t u = u0 + blockIdx.y;
+    if (u >= nunits) return;
+    const int64_t ch = u / K, f = u - ch * K;
+    const T* src = s + ch * lds_ + f * hop;
+    T* dst = fr + (int64_t)blockIdx.y * nfft;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfft; i += gridDim.x * blockDim.x) {
+        T v{};
+        if (i < n) v = win ? win_mul(src[i], win[i]) : src[i];
+        dst[i] = v;
+    }
+}
+
+// K5 (Welch): partial[slice][ch][k] += sum over this chunk's frames of channel ch of |X[k]|^2   (double)
+// grid: (bins/256, nslices, nch).  Frame u of the chunk belongs to slice (u % nslices); deterministic order.
+template <typename R>
+__global__ __launch_bounds__(256) void abs2_accum_kernel(const cx<R>* __restrict__ spec, double* __restrict__ partial, int nspec, int64_t K,
+                                                         int64_t u0, int64_t cnt, int64_t nch) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nspec) return;
+    const int64_t ch = blockIdx.z;
+    // units of this chunk that belong to channel ch: [max(u0, ch*K), min(u0+cnt, (ch+1)*K))
+    const int64_t lo = std::max<int64_t>(u0, ch * K), hi = std::min<int64_t>(u0 + cnt, (ch + 1) * K);
+    double acc = 0;
+    for (int64_t u = lo + blockIdx.y; u < hi; u += gridDim.y) {
+        const cx<R> z = spec[(u - u0) * nspec + k];
+        acc += (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    }
+    if (lo + (int64_t)blockIdx.y < hi) partial[((int64_t)blockIdx.y * nch + ch) * nspec + k] += acc;
+}
+
+// Welch finalize: psd[ch][j] = T( m_j * fold(sum over slices) )
+//   MODE 0: one-sided from half spectrum  (acc has nspec = nfft/2+1 bins)       m = 1/r (DC, Nyquist if even) else 2/r
+//   MODE 1: two-sided from full spectrum  (acc has nfft bins)                   m = 1/r
+//   MODE 2: two-sided from half spectrum  (mirror, periodograms.jl:158-168)     m = 1/r
+//   MODE 3: one-sided from PAIR-PACKED full spectrum: (A[k] + A[N-k])/2
+//   MODE 4: two-sided from PAIR-PACKED full spectrum
+template <typename R, int MODE>
+__global__ __launch_bounds__(256) void welch_finalize_kernel(const double* __restrict__ partial, R* __restrict__ psd, int64_t ldp, int nslices,
+                                                             int64_t nch, int nacc, int nfft, int nout, double r_total) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ch = blockIdx.y;
+    if (j >= nout) return;
+    auto sum_bin = [&](int k) {
+        double a = 0;
+        for (int s = 0; s < nslices; ++s) a += partial[((int64_t)s * nch + ch) * nacc + k];
+        return a;
+    };
+    double v;
+    const double m1 = 1.0 / r_total, m2 = 2.0 / r_total;
+    if (MODE == 0) {
+        v = sum_bin(j) * ((j == 0 || (j == nout - 1 && (nfft % 2 == 0))) ? m1 : m2);
+    } else if (MODE == 1) {
+        v = sum_bin(j) * m1;
+    } else if (MODE == 2) {
+        const int k = j <= nfft / 2 ? j : nfft - j;
+        v = sum_bin(k) * m1;
+    } else {
+        const int k2 = (nfft - j) % nfft;
+        const double a = 0.5 * (sum_bin(j) + sum_bin(k2));
+        if (MODE == 3) v = a * ((j == 0 || (j == nout - 1 && (nfft % 2 == 0))) ? m1 : m2);
+        else v = a * m1;
+    }
+    psd[ch * ldp + j] = (R)v;
+}
+
+// K5/K6 (STFT): column store from a batched spectrum.  PSD: out real; else complex.
+//   HALF: spectrum has nfft/2+1 bins (real input); two-sided output mirrors (conjugate for raw STFT).
+template <typename R, bool PSD, bool HALF>
+__global__ __launch_bounds__(256) void stft_store_kernel(const cx<R>* __restrict__ spec, void* __restrict__ out, int nspec, int nfft, int nout,
+                                                         int64_t K, int64_t ldo, int64_t chs, int64_t u0, int64_t nunits, double r, int onesided) {
+    const int64_t u = u0 + blockIdx.y;
+    if (u >= nunits) return;
+    const int64_t ch = u / K, f = u - ch * K;
+    const cx<R>* z = spec + (int64_t)blockIdx.y * nspec;
+    const R m1 = (R)(1.0 / r), m2 = (R)(2.0 / r);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x) {
+        int k = j;
+        bool conj = false;
+        if (HALF && j > nfft / 2) {
+            k = nfft - j;
+            conj = true;
+        }
+        const cx<R> v = z[k];
+        if (PSD) {
+            const R p = v.x * v.x + v.y * v.y;
+            R m = m1;
+            if (onesided && !(j == 0 || (j == nout - 1 && nfft % 2 == 0))) m = m2;
+            static_cast<R*>(out)[ch * chs + f * ldo + j] = p * m;   // fft2pow! with out == 0: muladd(abs2, m, 0)
+        } else {
+            static_cast<cx<R>*>(out)[ch * chs + f * ldo + j] = conj ? cx<R>{v.x, -v.y} : v;
+        }
+    }
+}
+
+// ======================================================================================================
+// Fused kernels
+// ======================================================================================================
+struct SpecArgs {
+    const void* s;
+    void* out;             // Welch: double partials [slot][ch][N];  STFT: output matrix
+    const void* table;     // N forward roots
+    const double* win;     // n doubles or nullptr
+    int64_t len, lds_, K, hop;
+    int64_t units_per_ch;  // frame pairs (real Welch) or frames
+    int64_t nch;
+    int64_t ldo, chs;      // STFT output strides
+    int n, nout, onesided;
+    double r;
+};
+
+// Load E window values for the thread (zero past n so that the zero tail needs no branch later)
+template <int E, int T> __device__ __forceinline__ void load_window_regs(double (&w)[E], const double* win, int n, int t) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = t + T * e;
+        w[e] = i < n ? (win ? win[i] : 1.0) : 0.0;
+    }
+}
+
+// ---- Welch ------------------------------------------------------------------------------------------------
+template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
+__global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs a) {
+    using C = fft::Cfg<N, E>;
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    constexpr int T = C::T;
+    static_assert(T % 64 == 0, "a transform must own whole wavefronts");
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
+    constexpr int64_t SZ = (int64_t)sizeof(TT);
+    __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
+    const int t = threadIdx.x % T;
+    const int slot = threadIdx.x / T;
+    cx<R>* lds = lds_all + slot * REGION;
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    const int64_t ch = blockIdx.y;
+
+    cx<R> tw[NTWA];
+    if constexpr (TWREG) fft::load_twiddles<C, R>(tw, t, table);
+    std::conditional_t<WIN64, double, R> w[E];
+    {
+        double wd[E];
+        load_window_regs<E, T>(wd, a.win, a.n, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) w[e] = (std::conditional_t<WIN64, double, R>)wd[e];
+    }
+    double acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.0;
+
+    const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
+    const int64_t stride = (int64_t)gridDim.x * G;
+    const int64_t ufirst = (int64_t)blockIdx.x * G + slot;
+    const int64_t niter = (a.units_per_ch + stride - 1) / stride;
+
+    TT ra[E];
+    TT rb[CPLX ? 1 : E];
+    auto issue = [&](int64_t u) {
+        const bool live = u < a.units_per_ch;
+        const int64_t f0 = CPLX ? u : 2 * u;
+        const int64_t start = f0 * a.hop;
+        // a frame never reads past start+n: the descriptor ends there (zero tail) or at the end of the signal
+        const __amdgpu_buffer_rsrc_t r0 = io::make_rsrc(sc + start, live ? std::min<int64_t>(a.n, a.len - start) * SZ : 0);
+        io::load_window<TT, E, T>(ra, r0, 0, t);
+        if constexpr (!CPLX) {
+            const bool haveB = live && (f0 + 1) < a.K;
+            const int64_t startB = start + a.hop;
+            const __amdgpu_buffer_rsrc_t r1 = io::make_rsrc(sc + startB, haveB ? std::min<int64_t>(a.n, a.len - startB) * SZ : 0);
+            io::load_window<TT, E, T>(rb, r1, 0, t);
+        }
+    };
+    if constexpr (PREFETCH) issue(ufirst);
+    for (int64_t it = 0; it < niter; ++it) {
+        const int64_t u = it * stride + ufirst;
+        if constexpr (!PREFETCH) issue(u);
+        cx<R> v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if constexpr (CPLX) {
+                if constexpr (WIN64) v[e] = win_mul(ra[e], (double)w[e]);
+                else v[e] = {ra[e].x * w[e], ra[e].y * w[e]};
+            } else {
+                if constexpr (WIN64) v[e] = {win_mul(ra[e], (double)w[e]), win_mul(rb[e], (double)w[e])};
+                else v[e] = {ra[e] * w[e], rb[e] * w[e]};
+            }
+        }
+        if constexpr (PREFETCH) issue(u + stride);
+        fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
+        // an odd number of exchanges per iteration would re-enter on the buffer that was used last: fence it
+        if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += (double)v[e].x * (double)v[e].x + (double)v[e].y * (double)v[e].y;
+    }
+    // partial[(blockIdx.x*G + slot)][ch][k]
+    double* part = static_cast<double*>(a.out) + (((int64_t)blockIdx.x * G + slot) * a.nch + ch) * N;
+#pragma unroll
+    for (int e = 0; e < E; ++e) part[t + T * e] = acc[e];
+}
+
+// ---- STFT / spectrogram -------------------------------------------------------------------------------------
+// One frame per transform slot (real frames ride with a zero imaginary part).
+template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, bool PSD, int MINW, int NBUF, bool PREFETCH>
+__global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs a) {
+    using C = fft::Cfg<N, E>;
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    constexpr int T = C::T;
+    static_assert(T % 64 == 0, "a transform must own whole wavefronts");
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
+    constexpr int64_t SZ = (int64_t)sizeof(TT);
+    __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
+    const int t = threadIdx.x % T;
+    const int slot = threadIdx.x / T;
+    cx<R>* lds = lds_all + slot * REGION;
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    const int64_t ch = blockIdx.y;
+
+    cx<R> tw[NTWA];
+    if constexpr (TWREG) fft::load_twiddles<C, R>(tw, t, table);
+    double w[E];
+    load_window_regs<E, T>(w, a.win, a.n, t);
+    const bool havewin = a.win != nullptr;
+
+    const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
+    const int64_t stride = (int64_t)gridDim.x * G;
+    const int64_t ufirst = (int64_t)blockIdx.x * G + slot;
+    const int64_t niter = (a.K + stride - 1) / stride;
+    const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
+
+    TT ra[E];
+    auto issue = [&](int64_t f) {
+        const bool live = f < a.K;
+        const int64_t start = f * a.hop;
+        const __amdgpu_buffer_rsrc_t r0 = io::make_rsrc(sc + start, live ? std::min<int64_t>(a.n, a.len - start) * SZ : 0);
+        io::load_window<TT, E, T>(ra, r0, 0, t);
+    };
+    if constexpr (PREFETCH) issue(ufirst);
+    for (int64_t it = 0; it < niter; ++it) {
+        const int64_t f = it * stride + ufirst;
+        if constexpr (!PREFETCH) issue(f);
+        cx<R> v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if constexpr (CPLX) v[e] = havewin ? win_mul(ra[e], w[e]) : ra[e];
+            else v[e] = {havewin ? win_mul(ra[e], w[e]) : ra[e], (R)0};
+        }
+        if constexpr (PREFETCH) issue(f + stride);
+        fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
+        if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
+        // column store: bins k = t + T*e < nout, contiguous across lanes
+        const bool live = f < a.K;
+        if constexpr (PSD) {
+            R* col = static_cast<R*>(a.out) + ch * a.chs + f * a.ldo;
+            const __amdgpu_buffer_rsrc_t wr = io::make_rsrc(col, live ? (int64_t)a.nout * (int64_t)sizeof(R) : 0);
+            io::store_window<R, E, T>(
+                [&](int e) {
+                    const int k = t + T * e;
+                    R m = m1;
+                    if (a.onesided && !(k == 0 || (k == a.nout - 1 && N % 2 == 0))) m = m2;
+                    return (v[e].x * v[e].x + v[e].y * v[e].y) * m;
+                },
+                wr, 0, t);
+        } else {
+            cx<R>* col = static_cast<cx<R>*>(a.out) + ch * a.chs + f * a.ldo;
+            const __amdgpu_buffer_rsrc_t wr = io::make_rsrc(col, live ? (int64_t)a.nout * (int64_t)sizeof(cx<R>) : 0);
+            io::store_window<cx<R>, E, T>([&](int e) { return v[e]; }, wr, 0, t);
+        }
+    }
+}
+
+bool fused_size_ok(int dtype, int64_t nfft) {
+    const bool dbl = dtype_is_double(dtype);
+    switch (nfft) {
+        case 256: case 512: case 1024: case 2048: case 4096: return true;
+        case 8192: return !dbl;
+        default: return false;
+    }
+}
+
+int resolve_engine(int engine, int dtype, int64_t nfft, int* out) {
+    int eng = engine;
+    if (eng == MDSP_ENGINE_AUTO) {
+        const char* env = getenv("MDSP_ENGINE");
+        if (env && !strcmp(env, "rocfft")) eng = MDSP_ENGINE_ROCFFT;
+        else if (env && !strcmp(env, "fused")) eng = MDSP_ENGINE_FUSED;
+    }
+    if (eng == MDSP_ENGINE_AUTO) eng = fused_size_ok(dtype, nfft) ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
+    if (eng == MDSP_ENGINE_FUSED && !fused_size_ok(dtype, nfft))
+        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft in [256, 8192]; got %lld", (long long)nfft);
+    if (eng != MDSP_ENGINE_FUSED && eng != MDSP_ENGINE_ROCFFT) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid engine %d", engine);
+    *out = eng;
+    return MDSP_OK;
+}
+
+template <typename R> int upload_roots(DevBuf& buf, int64_t n) {
+    std::vector<cx<R>> w((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        const zd r = unit_root(k, n, -1);
+        w[(size_t)k] = {(R)r.real(), (R)r.imag()};
+    }
+    MDSP_TRY(buf.reserve(sizeof(cx<R>) * (size_t)n));
+    MDSP_HIP(hipMemcpy(buf.p, w.data(), sizeof(cx<R>) * (size_t)n, hipMemcpyHostToDevice));
+    return MDSP_OK;
+}
+
+int check_split(int64_t n, int64_t noverlap, int64_t nfft) {
+    if (n < 1) MDSP_FAIL(MDSP_ERR_DOMAIN, "n (%lld) must be positive", (long long)n);
+    if (!(0 <= noverlap && noverlap < n))
+        MDSP_FAIL(MDSP_ERR_DOMAIN, "noverlap must be between zero and n (noverlap=%lld, n=%lld)", (long long)noverlap, (long long)n);
+    if (!(nfft >= n)) MDSP_FAIL(MDSP_ERR_DOMAIN, "nfft must be >= n (nfft=%lld, n=%lld)", (long long)nfft, (long long)n);
+    return MDSP_OK;
+}
+
+// geometry shared by the fused launchers
+template <typename R, int N> struct Geo {
+    static constexpr bool DBL = sizeof(R) == 8;
+    static constexpr int EMAX = DBL ? 8 : 16;
+    static constexpr int E = (N / 64 < EMAX) ? N / 64 : EMAX;
+    static constexpr int T = N / E;
+    static constexpr int G = T >= 256 ? 1 : 256 / T;
+    static constexpr int NBUF = T <= 64 ? 1 : 2;
+    static constexpr bool TWREG = !DBL;
+};
+
+template <typename K> int grid_for(K kern, int threads, int64_t work_wgs, int64_t nch, int* grid) {
+    int per_cu = 0;
+    MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = (int64_t)device_cu_count() * per_cu;
+    const int64_t per_ch = std::max<int64_t>(1, resident / std::max<int64_t>(1, nch));
+    *grid = (int)std::max<int64_t>(1, std::min<int64_t>(work_wgs, per_ch));
+    return MDSP_OK;
+}
+
+}  // namespace
+
+// ======================================================================================================
+// mdsp_frames (K4 only)
+// ======================================================================================================
+extern "C" int mdsp_frames(const void* s_dev, int64_t len, int dtype, int64_t n, int64_t noverlap, int64_t nfft, const double* window_host,
+                           int64_t first, int64_t count, void* frames_dev, void* stream) {
+    if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype %d", dtype);
+    MDSP_TRY(check_split(n, noverlap, nfft));
+    const int64_t K = mdsp_frame_count(len, n, noverlap);
+    if (first < 0 || count < 0 || first + count > K) MDSP_FAIL(MDSP_ERR_ARGUMENT, "frame range [%lld,%lld) outside [0,%lld)", (long long)first, (long long)(first + count), (long long)K);
+    if (count == 0) return MDSP_OK;
+    hipStream_t st = as_stream(stream);
+    DevBuf win;
+    if (window_host) {
+        MDSP_TRY(win.reserve(sizeof(double) * (size_t)n));
+        MDSP_HIP(hipMemcpyAsync(win.p, window_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    const int64_t hop = n - noverlap;
+    const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
+    for (int64_t c0 = 0; c0 < count; c0 += 32768) {
+        const int64_t cnt = std::min<int64_t>(32768, count - c0);
+#define FR(TT)                                                                                                                          \
+    hipLaunchKernelGGL(frame_window_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, (const TT*)s_dev, (TT*)frames_dev + c0 * nfft, \
+                       window_host ? win.as<double>() : nullptr, (int64_t)0, K, hop, (int)n, (int)nfft, first + c0, first + count)
+        switch (dtype) {
+            case MDSP_F32: FR(float); break;
+            case MDSP_F64: FR(double); break;
+            case MDSP_C32: FR(cx<float>); break;
+            default: FR(cx<double>); break;
+        }
+#undef FR
+        MDSP_LAUNCH_CHECK();
+    }
+    if (window_host) MDSP_HIP(hipStreamSynchronize(st));  // `win` is freed on return
+    return MDSP_OK;
+}
+
+// ======================================================================================================
+// Welch
+// ======================================================================================================
+struct mdsp_welch_plan_s {
+    int dtype = MDSP_F32, engine = MDSP_ENGINE_ROCFFT, onesided = 1;
+    int64_t n = 0, noverlap = 0, nfft = 0, nout = 0;
+    double r = 1;
+    bool have_win = false;
+    DevBuf win, table, partial;
+    RocPlan fwd;
+    DevBuf fr, spec;
+    int64_t batch = 0;
+    int variant = 0;
+};
+
+namespace {
+
+template <typename R, bool CPLX>
+int welch_exec_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* psd, int64_t ldp, hipStream_t st) {
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    const int64_t nfft = pl->nfft, n = pl->n, hop = pl->n - pl->noverlap;
+    const int64_t K = mdsp_frame_count(len, n, pl->noverlap);
+    const int nspec = (int)(CPLX ? nfft : nfft / 2 + 1);
+    const int64_t nunits = K * nch;
+    const int nslices = 32;
+    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)nslices * (size_t)nch * (size_t)nspec));
+    MDSP_HIP(hipMemsetAsync(pl->partial.p, 0, sizeof(double) * (size_t)nslices * (size_t)nch * (size_t)nspec, st));
+    if (nunits > 0) {
+        const int64_t per_unit = (int64_t)sizeof(TT) * nfft + (int64_t)sizeof(cx<R>) * nspec;
+        const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nunits, (int64_t(64) << 20) / per_unit));
+        if (pl->batch != batch) {
+            MDSP_TRY(pl->fr.reserve((size_t)(sizeof(TT) * nfft * batch)));
+            MDSP_TRY(pl->spec.reserve((size_t)(sizeof(cx<R>) * nspec * batch)));
+            MDSP_TRY(pl->fwd.create(CPLX ? FftKind::C2C_FWD : FftKind::R2C, sizeof(R) == 8, nfft, batch, false));
+            pl->batch = batch;
+        }
+        const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
+        for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
+            const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
+            hipLaunchKernelGGL(frame_window_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
+                               pl->have_win ? pl->win.as<double>() : nullptr, lds_, K, hop, (int)n, (int)nfft, u0, nunits);
+            MDSP_LAUNCH_CHECK();
+            MDSP_TRY(pl->fwd.exec(pl->fr.p, pl->spec.p, st));
+            hipLaunchKernelGGL(abs2_accum_kernel<R>, dim3((unsigned)cdiv(nspec, 256), nslices, (unsigned)nch), dim3(256), 0, st,
+                               pl->spec.as<cx<R>>(), pl->partial.as<double>(), nspec, K, u0, cnt, nch);
+            MDSP_LAUNCH_CHECK();
+        }
+    }
+    const double r_total = (double)K * pl->r;
+    const int nout = (int)pl->nout;
+    const dim3 grid((unsigned)cdiv(nout, 256), (unsigned)nch);
+    if (K == 0) {  // fill!(out, 0); no frames (0 * r would be a division by zero in m)
+        for (int64_t c = 0; c < nch; ++c) MDSP_HIP(hipMemsetAsync((R*)psd + c * ldp, 0, sizeof(R) * (size_t)nout, st));
+        return MDSP_OK;
+    }
+    if (CPLX)
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 1>), grid, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, nch, nspec, (int)nfft, nout, r_total);
+    else if (pl->onesided)
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 0>), grid, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, nch, nspec, (int)nfft, nout, r_total);
+    else
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 2>), grid, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, nch, nspec, (int)nfft, nout, r_total);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+template <typename R, int N, bool CPLX>
+int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, hipStream_t st) {
+    using Gm = Geo<R, N>;
+    constexpr int E = Gm::E, G = Gm::G, NBUF = Gm::NBUF;
+    constexpr bool TWREG = Gm::TWREG;
+    constexpr int threads = (N / E) * G;
+    int grid = 1;
+    const int64_t work = cdiv(a.units_per_ch, G);
+    auto run = [&](auto kern) -> int {
+        MDSP_TRY(grid_for(kern, threads, work, a.nch, &grid));
+        const size_t pbytes = sizeof(double) * (size_t)grid * G * (size_t)a.nch * N;
+        MDSP_TRY(pl->partial.reserve(pbytes));
+        a.out = pl->partial.p;
+        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
+        MDSP_LAUNCH_CHECK();
+        return MDSP_OK;
+    };
+    int rc;
+    if constexpr (N == 4096 && !CPLX && sizeof(R) == 4) {
+        switch (pl->variant) {
+            //                                     R  N   E  G TWREG PAD CPLX MINW NBUF PREF WIN64
+            case 1: rc = run(welch_fused_kernel<R, N, 16, 1, true, 4, CPLX, 2, 2, true, false>); break;
+            case 2: rc = run(welch_fused_kernel<R, N, 16, 1, true, 4, CPLX, 2, 2, false, true>); break;
+            case 3: rc = run(welch_fused_kernel<R, N, 16, 1, false, 4, CPLX, 2, 2, true, true>); break;
+            case 4: rc = run(welch_fused_kernel<R, N, 8, 1, true, 4, CPLX, 2, 2, true, true>); break;
+            case 5: rc = run(welch_fused_kernel<R, N, 16, 1, true, 5, CPLX, 2, 2, true, true>); break;
+            case 6: rc = run(welch_fused_kernel<R, N, 16, 1, true, 4, CPLX, 2, 1, true, true>); break;
+            default: rc = run(welch_fused_kernel<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true, true>); break;
+        }
+    } else {
+        rc = run(welch_fused_kernel<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true, true>);
+    }
+    if (rc != MDSP_OK) return rc;
+    const int nslices = grid * G;
+    const int nout = (int)pl->nout;
+    const double r_total = (double)a.K * pl->r;
+    const dim3 fg((unsigned)cdiv(nout, 256), (unsigned)a.nch);
+    if (CPLX)
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 1>), fg, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, a.nch, N, N, nout, r_total);
+    else if (pl->onesided)
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 3>), fg, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, a.nch, N, N, nout, r_total);
+    else
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 4>), fg, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, a.nch, N, N, nout, r_total);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+template <typename R, bool CPLX>
+int welch_exec_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* psd, int64_t ldp, hipStream_t st) {
+    const int64_t K = mdsp_frame_count(len, pl->n, pl->noverlap);
+    if (K == 0) {
+        for (int64_t c = 0; c < nch; ++c) MDSP_HIP(hipMemsetAsync((R*)psd + c * ldp, 0, sizeof(R) * (size_t)pl->nout, st));
+        return MDSP_OK;
+    }
+    SpecArgs a{};
+    a.s = s;
+    a.table = pl->table.p;
+    a.win = pl->have_win ? pl->win.as<double>() : nullptr;
+    a.len = len;
+    a.lds_ = lds_;
+    a.K = K;
+    a.hop = pl->n - pl->noverlap;
+    a.units_per_ch = CPLX ? K : cdiv(K, 2);
+    a.nch = nch;
+    a.n = (int)pl->n;
+    a.nout = (int)pl->nout;
+    a.onesided = pl->onesided;
+    a.r = pl->r;
+    switch (pl->nfft) {
+        case 256: return welch_launch_n<R, 256, CPLX>(pl, a, psd, ldp, st);
+        case 512: return welch_launch_n<R, 512, CPLX>(pl, a, psd, ldp, st);
+        case 1024: return welch_launch_n<R, 1024, CPLX>(pl, a, psd, ldp, st);
+        case 2048: return welch_launch_n<R, 2048, CPLX>(pl, a, psd, ldp, st);
+        case 4096: return welch_launch_n<R, 4096, CPLX>(pl, a, psd, ldp, st);
+        case 8192:
+            if constexpr (sizeof(R) == 4) return welch_launch_n<R, 8192, CPLX>(pl, a, psd, ldp, st);
+        default: break;
+    }
+    MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused Welch does not support nfft=%lld", (long long)pl->nfft);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdsp_welch_plan_create(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, int64_t nfft, const double* window_host, double r, int onesided,
+                           int dtype, int engine) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    *plan = nullptr;
+    if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype %d", dtype);
+    if (onesided && dtype_is_complex(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "cannot compute one-sided FFT of a complex signal");
+    if (!(nfft >= n)) MDSP_FAIL(MDSP_ERR_DOMAIN, "nfft must be >= n (nfft=%lld, n=%lld)", (long long)nfft, (long long)n);
+    MDSP_TRY(check_split(n, noverlap, nfft));
+    if (!(r > 0)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "normalisation r must be positive");
+    int eng;
+    MDSP_TRY(resolve_engine(engine, dtype, nfft, &eng));
+    auto pl = new mdsp_welch_plan_s();
+    pl->dtype = dtype;
+    pl->engine = eng;
+    pl->onesided = onesided ? 1 : 0;
+    pl->n = n;
+    pl->noverlap = noverlap;
+    pl->nfft = nfft;
+    pl->nout = onesided ? nfft / 2 + 1 : nfft;
+    pl->r = r;
+    if (const char* v = getenv("MDSP_WELCH_VARIANT")) pl->variant = atoi(v);
+    int st = MDSP_OK;
+    if (window_host) {
+        pl->have_win = true;
+        st = pl->win.reserve(sizeof(double) * (size_t)n);
+        if (st == MDSP_OK && hipMemcpy(pl->win.p, window_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
+            st = set_error(MDSP_ERR_DEVICE, "window upload failed");
+    }
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED) st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
+    if (st != MDSP_OK) {
+        delete pl;
+        return st;
+    }
+    *plan = pl;
+    return MDSP_OK;
+}
+
+int mdsp_welch_plan_destroy(mdsp_welch_plan plan) {
+    delete plan;
+    return MDSP_OK;
+}
+
+int mdsp_welch_plan_info(mdsp_welch_plan plan, int64_t* nout, int* engine_used) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (nout) *nout = plan->nout;
+    if (engine_used) *engine_used = plan->engine;
+    return MDSP_OK;
+}
+
+int mdsp_welch_exec(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds_, void* psd_dev, int64_t ldp, void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (len < 0 || nch < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (nch == 0) return MDSP_OK;
+    if (!psd_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
+    if (!s_dev && len > 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "s is NULL");
+    if (nch > 1 && (lds_ < len || ldp < plan->nout)) MDSP_FAIL(MDSP_ERR_DIMENSION, "leading dimension smaller than the column length");
+    if (nch > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 channels per call");
+    hipStream_t st = as_stream(stream);
+    const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
+    if (plan->engine == MDSP_ENGINE_ROCFFT) {
+        if (cplx) return dbl ? welch_exec_rocfft<double, true>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st)
+                             : welch_exec_rocfft<float, true>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st);
+        return dbl ? welch_exec_rocfft<double, false>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st)
+                   : welch_exec_rocfft<float, false>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st);
+    }
+    if (cplx) return dbl ? welch_exec_fused<double, true>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st)
+                         : welch_exec_fused<float, true>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st);
+    return dbl ? welch_exec_fused<double, false>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st)
+               : welch_exec_fused<float, false>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st);
+}
+
+}  // extern "C"
+
+// channel sum (local part of the cross-channel Welch mean)
+template <typename R> __global__ __launch_bounds__(256) void channel_sum_kernel(const R* __restrict__ psd, R* __restrict__ out, int64_t nout, int64_t nch, int64_t ldp) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nout) return;
+    double a = 0;
+    for (int64_t c = 0; c < nch; ++c) a += (double)psd[c * ldp + j];
+    out[j] = (R)a;
+}
+
+extern "C" int mdsp_channel_sum(const void* psd_dev, int64_t nout, int64_t nch, int64_t ldp, int real_dtype, void* sum_dev, void* stream) {
+    if (real_dtype != MDSP_F32 && real_dtype != MDSP_F64) MDSP_FAIL(MDSP_ERR_ARGUMENT, "real dtype expected");
+    if (nout <= 0) return MDSP_OK;
+    const dim3 g((unsigned)cdiv(nout, 256));
+    if (real_dtype == MDSP_F32)
+        hipLaunchKernelGGL(channel_sum_kernel<float>, g, dim3(256), 0, as_stream(stream), (const float*)psd_dev, (float*)sum_dev, nout, nch, ldp);
+    else
+        hipLaunchKernelGGL(channel_sum_kernel<double>, g, dim3(256), 0, as_stream(stream), (const double*)psd_dev, (double*)sum_dev, nout, nch, ldp);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+// ======================================================================================================
+// STFT / spectrogram
+// ======================================================================================================
+struct mdsp_stft_plan_s {
+    int dtype = MDSP_F32, engine = MDSP_ENGINE_ROCFFT, onesided = 1, psd_only = 0;
+    int64_t n = 0, noverlap = 0, nfft = 0, nout = 0;
+    double r = 1;
+    bool have_win = false;
+    DevBuf win, table;
+    RocPlan fwd;
+    DevBuf fr, spec;
+    int64_t batch = 0;
+};
+
+namespace {
+
+template <typename R, bool CPLX>
+int stft_exec_rocfft(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* out, int64_t ldo, int64_t chs, hipStream_t st) {
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    const int64_t nfft = pl->nfft, n = pl->n, hop = pl->n - pl->noverlap;
+    const int64_t K = mdsp_frame_count(len, n, pl->noverlap);
+    const int nspec = (int)(CPLX ? nfft : nfft / 2 + 1);
+    const int64_t nunits = K * nch;
+    if (nunits == 0) return MDSP_OK;
+    const int64_t per_unit = (int64_t)sizeof(TT) * nfft + (int64_t)sizeof(cx<R>) * nspec;
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nunits, (int64_t(64) << 20) / per_unit));
+    if (pl->batch != batch) {
+        MDSP_TRY(pl->fr.reserve((size_t)(sizeof(TT) * nfft * batch)));
+        MDSP_TRY(pl->spec.reserve((size_t)(sizeof(cx<R>) * nspec * batch)));
+        MDSP_TRY(pl->fwd.create(CPLX ? FftKind::C2C_FWD : FftKind::R2C, sizeof(R) == 8, nfft, batch, false));
+        pl->batch = batch;
+    }
+    const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
+    const int nout = (int)pl->nout;
+    for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
+        const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
+        hipLaunchKernelGGL(frame_window_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
+                           pl->have_win ? pl->win.as<double>() : nullptr, lds_, K, hop, (int)n, (int)nfft, u0, nunits);
+        MDSP_LAUNCH_CHECK();
+        MDSP_TRY(pl->fwd.exec(pl->fr.p, pl->spec.p, st));
+        const dim3 g(gx, (unsigned)cnt);
+        if (pl->psd_only)
+            hipLaunchKernelGGL((stft_store_kernel<R, true, !CPLX>), g, dim3(256), 0, st, pl->spec.as<cx<R>>(), out, nspec, (int)nfft, nout, K, ldo, chs, u0,
+                               nunits, pl->r, pl->onesided);
+        else
+            hipLaunchKernelGGL((stft_store_kernel<R, false, !CPLX>), g, dim3(256), 0, st, pl->spec.as<cx<R>>(), out, nspec, (int)nfft, nout, K, ldo, chs, u0,
+                               nunits, pl->r, pl->onesided);
+        MDSP_LAUNCH_CHECK();
+    }
+    return MDSP_OK;
+}
+
+template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, SpecArgs& a, hipStream_t st) {
+    using Gm = Geo<R, N>;
+    constexpr int E = Gm::E, G = Gm::G, NBUF = Gm::NBUF;
+    constexpr bool TWREG = Gm::TWREG;
+    constexpr int threads = (N / E) * G;
+    const int64_t work = cdiv(a.K, G);
+    int grid = 1;
+    auto run = [&](auto kern) -> int {
+        MDSP_TRY(grid_for(kern, threads, work, a.nch, &grid));
+        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
+        MDSP_LAUNCH_CHECK();
+        return MDSP_OK;
+    };
+    if (pl->psd_only) return run(stft_fused_kernel<R, N, E, G, TWREG, 4, CPLX, true, 2, NBUF, true>);
+    return run(stft_fused_kernel<R, N, E, G, TWREG, 4, CPLX, false, 2, NBUF, true>);
+}
+
+template <typename R, bool CPLX>
+int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* out, int64_t ldo, int64_t chs, hipStream_t st) {
+    const int64_t K = mdsp_frame_count(len, pl->n, pl->noverlap);
+    if (K == 0) return MDSP_OK;
+    SpecArgs a{};
+    a.s = s;
+    a.out = out;
+    a.table = pl->table.p;
+    a.win = pl->have_win ? pl->win.as<double>() : nullptr;
+    a.len = len;
+    a.lds_ = lds_;
+    a.K = K;
+    a.hop = pl->n - pl->noverlap;
+    a.units_per_ch = K;
+    a.nch = nch;
+    a.ldo = ldo;
+    a.chs = chs;
+    a.n = (int)pl->n;
+    a.nout = (int)pl->nout;
+    a.onesided = pl->onesided;
+    a.r = pl->r;
+    switch (pl->nfft) {
+        case 256: return stft_launch_n<R, 256, CPLX>(pl, a, st);
+        case 512: return stft_launch_n<R, 512, CPLX>(pl, a, st);
+        case 1024: return stft_launch_n<R, 1024, CPLX>(pl, a, st);
+        case 2048: return stft_launch_n<R, 2048, CPLX>(pl, a, st);
+        case 4096: return stft_launch_n<R, 4096, CPLX>(pl, a, st);
+        case 8192:
+            if constexpr (sizeof(R) == 4) return stft_launch_n<R, 8192, CPLX>(pl, a, st);
+        default: break;
+    }
+    MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused STFT does not support nfft=%lld", (long long)pl->nfft);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdsp_stft_plan_create(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int64_t nfft, const double* window_host, double r, int onesided,
+                          int psd_only, int dtype, int engine) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    *plan = nullptr;
+    if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype %d", dtype);
+    if (onesided && dtype_is_complex(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "cannot compute one-sided FFT of a complex signal");
+    MDSP_TRY(check_split(n, noverlap, nfft));
+    if (psd_only && !(r > 0)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "normalisation r must be positive");
+    int eng;
+    MDSP_TRY(resolve_engine(engine, dtype, nfft, &eng));
+    auto pl = new mdsp_stft_plan_s();
+    pl->dtype = dtype;
+    pl->engine = eng;
+    pl->onesided = onesided ? 1 : 0;
+    pl->psd_only = psd_only ? 1 : 0;
+    pl->n = n;
+    pl->noverlap = noverlap;
+    pl->nfft = nfft;
+    pl->nout = onesided ? nfft / 2 + 1 : nfft;
+    pl->r = r;
+    int st = MDSP_OK;
+    if (window_host) {
+        pl->have_win = true;
+        st = pl->win.reserve(sizeof(double) * (size_t)n);
+        if (st == MDSP_OK && hipMemcpy(pl->win.p, window_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
+            st = set_error(MDSP_ERR_DEVICE, "window upload failed");
+    }
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED) st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
+    if (st != MDSP_OK) {
+        delete pl;
+        return st;
+    }
+    *plan = pl;
+    return MDSP_OK;
+}
+
+int mdsp_stft_plan_destroy(mdsp_stft_plan plan) {
+    delete plan;
+    return MDSP_OK;
+}
+
+int mdsp_stft_plan_info(mdsp_stft_plan plan, int64_t* nout, int* engine_used) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (nout) *nout = plan->nout;
+    if (engine_used) *engine_used = plan->engine;
+    return MDSP_OK;
+}
+
+int mdsp_stft_exec(mdsp_stft_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds_, void* out_dev, int64_t ldo, int64_t chs,
+                   void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (len < 0 || nch < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    const int64_t K = mdsp_frame_count(len, plan->n, plan->noverlap);
+    if (nch == 0 || K == 0) return MDSP_OK;
+    if (!out_dev || !s_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    if (ldo < plan->nout) MDSP_FAIL(MDSP_ERR_DIMENSION, "column stride smaller than the column length");
+    if (nch > 1 && (lds_ < len || chs < ldo * (K - 1) + plan->nout)) MDSP_FAIL(MDSP_ERR_DIMENSION, "channel stride too small");
+    if (nch > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 channels per call");
+    hipStream_t st = as_stream(stream);
+    const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
+    if (plan->engine == MDSP_ENGINE_ROCFFT) {
+        if (cplx) return dbl ? stft_exec_rocfft<double, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
+                             : stft_exec_rocfft<float, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+        return dbl ? stft_exec_rocfft<double, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
+                   : stft_exec_rocfft<float, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+    }
+    if (cplx) return dbl ? stft_exec_fused<double, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
+                         : stft_exec_fused<float, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+    return dbl ? stft_exec_fused<double, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
+               : stft_exec_fused<float, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+}
+
+}  // extern "C"

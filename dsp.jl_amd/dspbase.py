@@ -1,0 +1,228 @@
+"""``filt(b, a, x)``, ``conv``, ``xcorr`` -- the host side of DSP.jl ``src/dspbase.jl`` over libmi355dsp.
+
+Argument checks, promotion rules and algorithm selection follow the reference line by line; the arithmetic runs
+in HIP kernels (time-domain FIR: ``mdsp_tdfir_exec``; FFT convolution: ``mdsp_ols_*``).  Mutating ``f!`` methods are
+spelled ``f_`` here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _dev, _lib
+from ._lib import ArgumentError, UnsupportedError
+
+SMALL_FILT_CUTOFF = 66   # dspbase.jl:3
+_FFT_TYPES = tuple(np.dtype(t) for t in (np.float32, np.float64, np.complex64, np.complex128))   # dspbase.jl:674
+
+
+def optimalfftfiltlength(nb: int, nx: int) -> int:
+    """dspbase.jl:268-291 (evaluated by the C ABI so every host shares one implementation)."""
+    return int(_lib.lib().mdsp_optimal_fft_len(int(nb), int(nx)))
+
+
+def os_fft_complexity(nfft, nb):
+    """dspbase.jl:262."""
+    return (nfft * np.log2(nfft) + nfft) / (nfft - nb + 1)
+
+
+def _host_vec(v) -> np.ndarray:
+    if _dev.is_device_array(v) or hasattr(v, "cpu"):
+        v = v.cpu().numpy()
+    return np.atleast_1d(np.asarray(v))
+
+
+def _compute_dtype(T: np.dtype) -> np.dtype:
+    """Device arithmetic type for a result eltype T: FFT types as they are, everything else in Float64/ComplexF64."""
+    T = np.dtype(T)
+    if T in _FFT_TYPES:
+        return T
+    return np.dtype(np.complex128) if T.kind == "c" else np.dtype(np.float64)
+
+
+def _cast_result(t, T: np.dtype):
+    """Round a device result back to an integer eltype when the reference would have stayed in integers."""
+    T = np.dtype(T)
+    if T.kind in "iu":
+        return t.round().to(_dev.torch_dtype(T))
+    if T.kind == "b":
+        return t.round().to(_dev.torch_dtype(np.int64))
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------------
+# tdfir plumbing shared with Filters.tdfilt
+# ---------------------------------------------------------------------------------------------------------
+def _tdfir(b: np.ndarray, x, T: np.dtype):
+    """Zero-state FIR along the first axis of x with real taps b, result eltype T."""
+    if b.dtype.kind == "c":
+        raise UnsupportedError("complex FIR taps are not accelerated (use DSP.jl on the CPU)")
+    W = _compute_dtype(T)
+    cols, shape = _dev.to_columns(x, W)
+    ncols, nx = cols.shape
+    out = _dev.empty_columns(ncols, nx, W)
+    if nx and ncols:
+        taps = np.ascontiguousarray(b, dtype=np.float32 if W in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64)
+        _lib.check(_lib.lib().mdsp_tdfir_exec(taps.ctypes.data_as(C.c_void_p), len(taps), _dev.md_dtype(W), _dev.ptr(cols), nx, ncols, nx,
+                                              _dev.ptr(out), nx, _dev.stream_ptr()))
+    return _dev.from_columns(_cast_result(out, T), shape, x)
+
+
+def filt(b, a, x):
+    """``filt(b, a, x)`` (dspbase.jl:14-66) for FIR filters (scalar / length-1 ``a``).
+
+    IIR (``length(a) > 1``) is a serial recursion per column and is out of scope for the device path.
+    """
+    bv, av = _host_vec(b), _host_vec(a)
+    xdt = _dev.np_dtype_of(x)
+    if bv.size == 0:
+        raise ArgumentError("filter vector b must be non-empty")
+    if av.size == 0:
+        raise ArgumentError("filter vector a must be non-empty")
+    if av[0] == 0:
+        raise ArgumentError("filter vector a[1] must be nonzero")
+    if av.size > 1:
+        raise UnsupportedError("IIR filt(b, a, x) is a serial recursion; only FIR (scalar a) runs on the device")
+    T = np.result_type(bv.dtype, av.dtype, xdt)
+    if av[0] != 1:                                   # coefficient normalisation, :43-47
+        bv = bv / av[0]
+        T = np.result_type(bv.dtype, xdt)
+    return _tdfir(bv, x, T)
+
+
+def filt_(out, b, a, x):
+    """``filt!(out, b, a, x)`` (dspbase.jl:26-66): size check then write into ``out``."""
+    if tuple(out.shape) != tuple(x.shape):
+        raise ArgumentError(f"output size {tuple(out.shape)} must match input size {tuple(x.shape)}")
+    res = filt(b, a, x)
+    if isinstance(out, np.ndarray):
+        out[...] = res if isinstance(res, np.ndarray) else res.cpu().numpy()
+    else:
+        out.copy_(res if not isinstance(res, np.ndarray) else _dev.torch.from_numpy(res))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# conv
+# ---------------------------------------------------------------------------------------------------------
+class OlsPlan:
+    """Owner of an ``mdsp_ols_plan`` (filter spectrum, rocFFT plans / tables, work buffers in HBM)."""
+
+    def __init__(self, taps: np.ndarray, nfft: int, nx_hint: int, mode: int, engine: int = _lib.ENGINE_AUTO):
+        self.dtype = taps.dtype
+        self._h = C.c_void_p()
+        taps = np.ascontiguousarray(taps)
+        _lib.check(_lib.lib().mdsp_ols_plan_create(C.byref(self._h), taps.ctypes.data_as(C.c_void_p), len(taps), int(nfft), int(nx_hint),
+                                                   _dev.md_dtype(taps.dtype), mode, engine))
+        nf, L, eng = C.c_int64(), C.c_int64(), C.c_int()
+        _lib.check(_lib.lib().mdsp_ols_plan_info(self._h, C.byref(nf), C.byref(L), C.byref(eng)))
+        self.nb, self.nfft, self.block_len, self.engine = len(taps), nf.value, L.value, eng.value
+
+    def exec(self, cols, nout: int):
+        ncols, nx = cols.shape
+        out = _dev.empty_columns(ncols, nout, self.dtype)
+        _lib.check(_lib.lib().mdsp_ols_exec(self._h, _dev.ptr(cols), nx, ncols, nx, _dev.ptr(out), nout, nout, _dev.stream_ptr()))
+        return out
+
+    def segment(self, col, first: int, count: int):
+        """Blocks [first, first+count) of one column as the reference's ``tmp1`` contents, shape (count, nfft)."""
+        seg = _dev.empty_columns(count, self.nfft, self.dtype)
+        _lib.check(_lib.lib().mdsp_ols_segment(self._h, _dev.ptr(col), col.numel(), first, count, _dev.ptr(seg), _dev.stream_ptr()))
+        return seg
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().mdsp_ols_plan_destroy(self._h)
+        except Exception:
+            pass
+
+
+def conv_select_algorithm(nu: int, nv: int, T, algorithm: str = "auto") -> str:
+    """Algorithm choice of ``conv!`` (dspbase.jl:720-743, 1-D)."""
+    T = np.dtype(T)
+    if algorithm == "auto":
+        algorithm = "fast" if T in _FFT_TYPES else "direct"
+    if algorithm == "fast":
+        algorithm = "direct" if nu * nv < 2 ** 16 else "fft"
+    if algorithm == "direct" or nu == 0 or nv == 0:
+        return "direct"
+    if algorithm == "fft":
+        os_nfft = optimalfftfiltlength(min(nu, nv), max(nu, nv))
+        algorithm = "fft_overlapsave" if os_nfft < nu + nv - 1 else "fft_simple"
+    if algorithm not in ("fft_overlapsave", "fft_simple"):
+        raise ArgumentError("algorithm must be :auto, :fast, :direct, :fft, :fft_simple, or :fft_overlapsave")
+    return algorithm
+
+
+def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int = _lib.ENGINE_AUTO):
+    """``conv(u, v; algorithm)`` for vectors (dspbase.jl:709-792).  ``out_len`` > nu+nv-1 zero-fills the tail like
+    ``conv!`` into an oversized ``out`` (:733-735)."""
+    udt, vdt = _dev.np_dtype_of(u), _dev.np_dtype_of(v)
+    if len(u.shape) != 1 or len(v.shape) != 1:
+        raise UnsupportedError("N-d convolution is not accelerated (SURVEY section 8: 1-d only)")
+    T = np.result_type(udt, vdt)
+    nu, nv = int(u.shape[0]), int(v.shape[0])
+    full = max(nu + nv - 1, 0)
+    n_out = full if out_len is None else int(out_len)
+    if n_out < full:
+        raise ArgumentError("output too small for the convolution result")
+    alg = conv_select_algorithm(nu, nv, T, algorithm)
+    W = _compute_dtype(T)
+    like = u
+    if nu == 0 or nv == 0:
+        z = _dev.torch.zeros(n_out, dtype=_dev.torch_dtype(T), device=_dev.device())
+        return z if _dev.is_device_array(like) else z.cpu().numpy()
+    big, small = (u, v) if nu >= nv else (v, u)
+    small_h = _host_vec(small).astype(W)
+    if alg == "direct" and W.kind != "c":
+        # direct sum: zero-state FIR over u extended by nv-1 zeros (dspbase.jl:646-660)
+        cols, _ = _dev.to_columns(big, W)
+        ext = _dev.torch.zeros((1, full), dtype=cols.dtype, device=cols.device)
+        ext[:, :cols.shape[1]] = cols
+        res = _dev.empty_columns(1, full, W)
+        taps = np.ascontiguousarray(small_h)
+        _lib.check(_lib.lib().mdsp_tdfir_exec(taps.ctypes.data_as(C.c_void_p), len(taps), _dev.md_dtype(W), _dev.ptr(ext), full, 1, full,
+                                              _dev.ptr(res), full, _dev.stream_ptr()))
+    else:
+        if alg == "fft_simple":
+            nfft = int(_lib.lib().mdsp_nextfastfft(full))           # _conv_kern_fft!: one transform of nextfastfft(outsize)
+        else:
+            nfft = optimalfftfiltlength(len(small_h), max(nu, nv))
+        plan = OlsPlan(small_h, nfft, max(nu, nv), _lib.OLS_CONV, engine)
+        cols, _ = _dev.to_columns(big, W)
+        res = plan.exec(cols, full)
+    res = _cast_result(res, T)[0]
+    if n_out > full:
+        pad = _dev.torch.zeros(n_out, dtype=res.dtype, device=res.device)
+        pad[:full] = res
+        res = pad
+    return res if _dev.is_device_array(like) else res.cpu().numpy()
+
+
+def conv_(out, u, v, algorithm: str = "auto"):
+    """``conv!(out, u, v; algorithm)``: ``out`` at least nu+nv-1 long; the excess is zeroed."""
+    res = conv(u, v, algorithm, out_len=int(out.shape[0]))
+    if isinstance(out, np.ndarray):
+        out[...] = res if isinstance(res, np.ndarray) else res.cpu().numpy()
+    else:
+        out.copy_(res if not isinstance(res, np.ndarray) else _dev.torch.from_numpy(res))
+    return out
+
+
+def xcorr(u, v=None, padmode: str = "none", scaling: str = "none"):
+    """dspbase.jl:867-898 (vectors)."""
+    v = u if v is None else v
+    su, sv = int(u.shape[0]), int(v.shape[0])
+    if scaling == "biased" and su != sv:
+        raise _lib.DimensionMismatch("scaling only valid for vectors of same length")
+    if padmode not in ("none", "longest"):
+        raise ArgumentError("padmode keyword argument must be either :none or :longest")
+    uh, vh = (a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a) for a in (u, v))
+    if padmode == "longest":
+        n = max(su, sv)
+        uh = np.concatenate([uh, np.zeros(n - su, dtype=uh.dtype)])
+        vh = np.concatenate([vh, np.zeros(n - sv, dtype=vh.dtype)])
+    res = conv(uh, np.conj(vh)[::-1].copy())
+    return res / su if scaling == "biased" else res

@@ -1,0 +1,305 @@
+"""FIR application and polyphase resampling: host side of DSP.jl ``src/Filters/filt.jl:426-555`` and
+``src/Filters/stream_filt.jl`` over libmi355dsp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from fractions import Fraction
+
+import numpy as np
+
+from . import _dev, _lib, design, dspbase
+from ._lib import ArgumentError, DomainError, UnsupportedError
+from .dspbase import SMALL_FILT_CUTOFF, OlsPlan, _cast_result, _compute_dtype, _host_vec, optimalfftfiltlength
+
+_REAL_KINDS = "fiub"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# tdfilt / fftfilt / filt(b, x)   (Filters/filt.jl:426-555)
+# ---------------------------------------------------------------------------------------------------------
+def tdfilt(h, x):
+    """filt.jl:431-433: naive time-domain FIR = ``filt(h, one(H), x)``."""
+    hv = _host_vec(h)
+    return dspbase.filt(hv, np.ones(1, dtype=hv.dtype), x)
+
+
+def tdfilt_(out, h, x):
+    """filt.jl:441-443."""
+    hv = _host_vec(h)
+    return dspbase.filt_(out, hv, np.ones(1, dtype=hv.dtype), x)
+
+
+def _fftfilt(b: np.ndarray, x, nfft: int, engine: int = _lib.ENGINE_AUTO):
+    """filt.jl:479-521 on the device: one overlap-save plan, all columns in one launch sequence."""
+    xdt = _dev.np_dtype_of(x)
+    if b.dtype.kind not in _REAL_KINDS or xdt.kind not in _REAL_KINDS:
+        raise TypeError("fftfilt is defined for real taps and real signals only")      # MethodError in the reference
+    W = np.result_type(b.dtype, xdt)
+    Wc = _compute_dtype(W)
+    cols, shape = _dev.to_columns(x, Wc)
+    ncols, nx = cols.shape
+    if nx == 0 or ncols == 0:
+        return _dev.from_columns(_dev.empty_columns(ncols, nx, Wc), shape, x)
+    if nfft < len(b):
+        raise ArgumentError("nfft must be at least length(b)")
+    plan = OlsPlan(b.astype(Wc), nfft, nx, _lib.OLS_FILT, engine)
+    out = plan.exec(cols, nx)
+    return _dev.from_columns(_cast_result(out, W) if W.kind in "iu" else out, shape, x)
+
+
+def fftfilt(b, x, nfft: int | None = None, engine: int = _lib.ENGINE_AUTO):
+    """``fftfilt(b, x[, nfft])`` (filt.jl:458-461); default nfft = optimalfftfiltlength(length(b), length(x))."""
+    bv = _host_vec(b)
+    if nfft is None:
+        nfft = optimalfftfiltlength(len(bv), int(np.prod(x.shape)))
+    return _fftfilt(bv, x, int(nfft), engine)
+
+
+def fftfilt_(out, b, x, nfft: int | None = None):
+    """``fftfilt!(out, b, x[, nfft])`` (filt.jl:468-476)."""
+    if tuple(out.shape) != tuple(x.shape):
+        raise ArgumentError("out and x must be the same size")
+    return _assign(out, fftfilt(b, x, nfft))
+
+
+def filt(b, x, engine: int = _lib.ENGINE_AUTO):
+    """``filt(b, x)`` (filt.jl:445-446, :525-555): FFT overlap-save when both are real and
+    length(b) > SMALL_FILT_CUTOFF (66), time domain otherwise."""
+    bv = _host_vec(b)
+    xdt = _dev.np_dtype_of(x)
+    if bv.dtype.kind in _REAL_KINDS and xdt.kind in _REAL_KINDS and len(bv) > SMALL_FILT_CUTOFF:
+        return _fftfilt(bv, x, optimalfftfiltlength(len(bv), int(x.shape[0])), engine)
+    return tdfilt(bv, x)
+
+
+def filt_(out, b, x):
+    """``filt!(out, b, x)`` (filt.jl:530-533)."""
+    if tuple(out.shape) != tuple(x.shape):
+        raise ArgumentError("out must be the same size as x")
+    return _assign(out, filt(b, x))
+
+
+def _assign(out, res):
+    if isinstance(out, np.ndarray):
+        out[...] = res if isinstance(res, np.ndarray) else res.cpu().numpy()
+    else:
+        out.copy_(res if not isinstance(res, np.ndarray) else _dev.torch.from_numpy(res))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# FIRFilter (stream_filt.jl:137-210) -- the stateful polyphase filter
+# ---------------------------------------------------------------------------------------------------------
+def outputlength(inputlength: int, ratio, initial_phi: int) -> int:
+    """stream_filt.jl:317-322."""
+    r = Fraction(ratio)
+    return int(_lib.lib().mdsp_outputlength(int(inputlength), r.numerator, r.denominator, int(initial_phi)))
+
+
+def inputlength(outputlength_: int, ratio, initial_phi: int, round_up: bool = False) -> int:
+    """stream_filt.jl:358-364 (RoundDown default, RoundUp with ``round_up=True``)."""
+    r = Fraction(ratio)
+    return int(_lib.lib().mdsp_inputlength(int(outputlength_), r.numerator, r.denominator, int(initial_phi), int(round_up)))
+
+
+class FIRFilter:
+    """``FIRFilter(h, ratio=1)``: single-rate / interpolating / decimating / rational polyphase FIR with persistent
+    state (``phi_idx``, ``input_deficit``, ``history``), exactly the reference's (stream_filt.jl:8-79, :137-178).
+
+    The kernel object lives in libmi355dsp (``mdsp_fir``); it is created at the first ``filt`` call, when the signal
+    eltype and channel count are known.  ``FIRFilter(h, rate::Float64)`` (FIRArbitrary) is not accelerated yet.
+    """
+
+    KINDS = ("FIRStandard", "FIRInterpolator", "FIRDecimator", "FIRRational")
+
+    def __init__(self, h, ratio=1):
+        if isinstance(ratio, float):
+            if not ratio > 0.0:
+                raise DomainError("rate must be greater than 0")
+            raise UnsupportedError("FIRArbitrary (floating-point rate) is not accelerated; SURVEY section 8(f)")
+        self.h = _host_vec(h)
+        if self.h.dtype.kind == "c":
+            raise UnsupportedError("complex FIR taps are not accelerated")
+        if self.h.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            self.h = self.h.astype(np.float64)
+        self.ratio = Fraction(ratio)
+        if self.ratio <= 0:
+            raise DomainError("resampling ratio must be positive")
+        L, M = self.ratio.numerator, self.ratio.denominator
+        self.kind = 0 if (L == 1 and M == 1) else (1 if M == 1 else (2 if L == 1 else 3))
+        self.hLen = len(self.h)
+        self.Nphi = L
+        self.tapsPerphi = -(-self.hLen // L)
+        self.historyLen = self.tapsPerphi - 1
+        self.phi_idx = 1
+        self.input_deficit = 1
+        self._handle = None
+        self._xdtype = None
+        self._nch = None
+        self._history_host = None     # pending history to push into a (re)created handle
+
+    @classmethod
+    def from_ratio(cls, ratio, *args):
+        """``FIRFilter(ratio, args...)`` (stream_filt.jl:207-210): taps from ``resample_filter(ratio, args...)``."""
+        return cls(design.resample_filter(Fraction(ratio), *args), Fraction(ratio))
+
+    # -- reference state API ------------------------------------------------------------------------------
+    @property
+    def kernel(self) -> str:
+        return self.KINDS[self.kind]
+
+    def reset(self):
+        """``reset!`` (stream_filt.jl:247-276)."""
+        self.phi_idx = 1
+        self.input_deficit = 1
+        self._history_host = None
+        if self._handle:
+            _lib.check(_lib.lib().mdsp_fir_reset(self._handle))
+        return self
+
+    def timedelay(self) -> float:
+        """stream_filt.jl:400-403."""
+        if self.kind in (1, 3):
+            return (self.hLen - 1) / (2 * self.Nphi)
+        return (self.hLen - 1) / 2
+
+    def setphase(self, phi: float):
+        """``setphase!`` (stream_filt.jl:216-229); ``round`` is round-half-even as in Julia."""
+        if not phi >= 0:
+            raise DomainError("phi must be >= 0")
+        if self.kind == 0:
+            raise TypeError("setphase! has no method for FIRStandard")
+        if self.kind == 2:
+            self.input_deficit += round(phi)
+        else:
+            throwaway, idx = divmod(round(phi * self.Nphi), self.Nphi)
+            self.input_deficit += throwaway
+            self.phi_idx = idx + 1
+
+    def outputlength(self, inputlength_: int) -> int:
+        """stream_filt.jl:324-338."""
+        if self.kind == 0:
+            return int(inputlength_)
+        return outputlength(inputlength_ - self.input_deficit + 1, self.ratio, 1 if self.kind == 2 else self.phi_idx)
+
+    def inputlength(self, outputlength_: int, round_up: bool = False) -> int:
+        """stream_filt.jl:366-383."""
+        if self.kind == 0:
+            return int(outputlength_)
+        return inputlength(outputlength_, self.ratio, 1 if self.kind == 2 else self.phi_idx, round_up) + self.input_deficit - 1
+
+    @property
+    def history(self) -> np.ndarray:
+        """The reference's ``history`` vector(s): shape (historyLen,) or (historyLen, nch)."""
+        if self._handle is None:
+            return np.zeros(self.historyLen) if self._history_host is None else self._history_host
+        buf = np.zeros((self._nch, max(self.historyLen, 0)), dtype=self._xdtype)
+        if self.historyLen > 0:
+            _lib.check(_lib.lib().mdsp_fir_get_state(self._handle, None, None, buf.ctypes.data_as(C.c_void_p)))
+        return buf[0].copy() if self._nch == 1 else buf.T.copy()
+
+    # -- device handle -------------------------------------------------------------------------------------
+    def _ensure(self, xdtype: np.dtype, nch: int):
+        if self._handle is not None and (self._xdtype != xdtype or self._nch != nch):
+            hist = self.history
+            _lib.lib().mdsp_fir_destroy(self._handle)
+            self._handle = None
+            self._history_host = hist.astype(xdtype) if (hist.ndim == 1 and nch == 1) or (hist.ndim == 2 and hist.shape[1] == nch) else None
+        if self._handle is None:
+            h = C.c_void_p()
+            taps = np.ascontiguousarray(self.h)
+            _lib.check(_lib.lib().mdsp_fir_create(C.byref(h), taps.ctypes.data_as(C.c_void_p), len(taps), self.ratio.numerator,
+                                                  self.ratio.denominator, _dev.md_dtype(taps.dtype), _dev.md_dtype(xdtype), nch))
+            self._handle, self._xdtype, self._nch = h, np.dtype(xdtype), nch
+            od = C.c_int()
+            _lib.check(_lib.lib().mdsp_fir_info(h, None, None, None, None, None, C.byref(od)))
+            self._outdtype = {_lib.F32: np.float32, _lib.F64: np.float64, _lib.C32: np.complex64, _lib.C64: np.complex128}[od.value]
+            if self._history_host is not None and self.historyLen > 0:
+                hh = np.ascontiguousarray(np.atleast_2d(self._history_host.T if self._history_host.ndim == 2 else self._history_host), dtype=xdtype)
+                _lib.check(_lib.lib().mdsp_fir_set_state(h, self.phi_idx, self.input_deficit, hh.ctypes.data_as(C.c_void_p)))
+            self._history_host = None
+
+    def filt(self, x):
+        """``filt(self, x)`` (stream_filt.jl:627-637): filter the next chunk, carrying state.  ``x`` is (n,) or
+        (n, channels); all channels share (phi_idx, input_deficit) and keep their own history."""
+        xdt = _dev.np_dtype_of(x)
+        W = _compute_dtype(xdt)
+        cols, shape = _dev.to_columns(x, W)
+        nch, xlen = cols.shape
+        self._ensure(W, max(nch, 1))
+        _lib.check(_lib.lib().mdsp_fir_set_state(self._handle, self.phi_idx, self.input_deficit, None))
+        ycap = max(self.outputlength(xlen), 0) if xlen >= self.input_deficit or self.kind == 0 else 0
+        out = _dev.empty_columns(nch, ycap, self._outdtype)
+        nw = C.c_int64(0)
+        _lib.check(_lib.lib().mdsp_fir_exec(self._handle, _dev.ptr(cols), xlen, xlen, _dev.ptr(out), ycap, max(ycap, 1), C.byref(nw),
+                                            _dev.stream_ptr()))
+        phi, dfc = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().mdsp_fir_get_state(self._handle, C.byref(phi), C.byref(dfc), None))
+        self.phi_idx, self.input_deficit = phi.value, dfc.value
+        if nw.value != ycap:
+            raise AssertionError("Length of resampled output different from expectation.")     # stream_filt.jl:634
+        return _dev.from_columns(out, shape, x)
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.lib().mdsp_fir_destroy(self._handle)
+        except Exception:
+            pass
+
+
+def filt_stateless(h, x, ratio=1):
+    """``filt(h, x, ratio)`` (stream_filt.jl:663-666)."""
+    return FIRFilter(h, ratio).filt(x)
+
+
+def _undelay(sf: FIRFilter):
+    """``undelay!`` (stream_filt.jl:706-714)."""
+    if sf.kind != 0:
+        sf.setphase(sf.timedelay())
+
+
+def resample(x, rate, h=None, dims: int | None = None):
+    """``resample(x, rate[, h]; dims)`` (stream_filt.jl:688-775) for integer / rational rates.
+
+    Vector ``x``: delay-compensated polyphase resampling to ceil(length(x)*rate) samples.  Array ``x`` with
+    ``dims``: every slice along ``dims`` is resampled independently (``mapslices``) -- on the device all slices are
+    channels of one launch, each starting from the same reset + undelay!-ed state (:768-774).
+    """
+    if isinstance(rate, float):
+        raise UnsupportedError("arbitrary-rate resampling (FIRArbitrary) is not accelerated; SURVEY section 8(f)")
+    rate = Fraction(rate)
+    if h is None:
+        h = design.resample_filter(rate)
+    sf = FIRFilter(h, rate)
+    _undelay(sf)
+    nd = len(x.shape)
+    if nd == 1:
+        n = int(x.shape[0])
+        moved, axis = x, None
+    else:
+        if dims is None:
+            raise TypeError("resample of an array needs the `dims` keyword")
+        axis = dims % nd
+        moved = (x.movedim(axis, 0) if hasattr(x, "movedim") else np.moveaxis(np.asarray(x), axis, 0))
+        n = int(moved.shape[0])
+    out_len = math.ceil(n * rate)                                    # :698 / :762 (exact rational arithmetic)
+    npad = sf.inputlength(out_len, round_up=True)                    # :699 / :763
+    if npad < n:
+        raise ArgumentError("padded length shorter than the input")   # copyto! would throw in the reference
+    xdt = _dev.np_dtype_of(moved)
+    cols, shape = _dev.to_columns(moved, _compute_dtype(xdt))
+    padded = _dev.torch.zeros((cols.shape[0], npad), dtype=cols.dtype, device=cols.device)
+    padded[:, :n] = cols
+    y = sf.filt(padded.t())                                          # (npad, nch) view -> filt -> (nout, nch)
+    if y.shape[0] < out_len:
+        raise AssertionError("Resample output shorter than expected.")   # :722
+    y = y[:out_len]
+    y = y.reshape((out_len,) + tuple(shape[1:]))
+    if axis is not None:
+        y = y.movedim(0, axis)
+    if nd == 1:
+        y = y.reshape(out_len)
+    return y if _dev.is_device_array(x) else y.cpu().numpy()

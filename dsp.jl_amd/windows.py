@@ -1,0 +1,75 @@
+"""Host-side window generators (DSP.jl ``src/windows.jl``): always Float64 vectors, evaluated once per plan."""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import ArgumentError
+
+
+def _cospi(x):
+    """cos(pi x) with the argument reduced exactly before the trig call (Julia's ``cospi``)."""
+    x = np.abs(np.asarray(x, dtype=np.float64)) % 2.0
+    x = np.where(x > 1.0, 2.0 - x, x)
+    flip = x > 0.5
+    x = np.where(flip, 1.0 - x, x)
+    c = np.where(x > 0.25, np.sin(np.pi * (0.5 - x)), np.cos(np.pi * x))
+    return np.where(flip, -c, c)
+
+
+def makewindow(winfunc, n: int, padding: int = 0, zerophase: bool = False) -> np.ndarray:
+    """windows.jl:97-121: sample ``winfunc`` on range(-0.5, 0.5; length=n) (or its zero-phase rotation)."""
+    if n < 0:
+        raise ArgumentError("`n` must be nonnegative")
+    if padding < 0:
+        raise ArgumentError("`padding` must be nonnegative")
+    win = np.zeros(n + padding)
+    if n == 1:
+        win[0] = winfunc(np.zeros(1))[0]
+    elif zerophase:
+        half = n // 2
+        win[: half + 1] = winfunc(np.arange(half + 1) / n)
+        if half:
+            win[-half:] = winfunc(np.arange(-half, 0) / n)
+    elif n > 1:
+        k = np.arange(n)
+        win[:n] = winfunc((2.0 * k - (n - 1)) / (2.0 * (n - 1)))   # correctly rounded -0.5 + k/(n-1)
+    return win
+
+
+def rect(n, padding=0, zerophase=False):
+    """windows.jl:142."""
+    return makewindow(lambda x: np.ones_like(x), n, padding, zerophase)
+
+
+def hanning(n, padding=0, zerophase=False):
+    """windows.jl:181-183."""
+    return makewindow(lambda x: 0.5 * (1.0 + _cospi(2.0 * x)), n, padding, zerophase)
+
+
+hann = hanning
+
+
+def hamming(n, padding=0, zerophase=False):
+    """windows.jl:206-208."""
+    return makewindow(lambda x: 0.46 * _cospi(2.0 * x) + 0.54, n, padding, zerophase)
+
+
+def cosine(n, padding=0, zerophase=False):
+    """windows.jl:289: cospi(x)."""
+    return makewindow(lambda x: _cospi(x), n, padding, zerophase)
+
+
+def bartlett(n, padding=0, zerophase=False):
+    """windows.jl:380-382."""
+    return makewindow(lambda x: 1.0 - np.abs(2.0 * x), n, padding, zerophase)
+
+
+def blackman(n, padding=0, zerophase=False):
+    """windows.jl:455: 0.42 + 0.5 cospi(2x) + 0.08 cospi(4x)."""
+    return makewindow(lambda x: 0.42 + 0.5 * _cospi(2.0 * x) + 0.08 * _cospi(4.0 * x), n, padding, zerophase)
+
+
+def kaiser(n, alpha, padding=0, zerophase=False):
+    """windows.jl:600-605."""
+    scale = 1.0 / np.i0(np.pi * alpha)
+    return makewindow(lambda x: scale * np.i0(np.pi * alpha * np.sqrt(np.clip(1.0 - 4.0 * x * x, 0.0, None))), n, padding, zerophase)

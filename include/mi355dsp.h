@@ -1,0 +1,208 @@
+/*
+ * mi355dsp.h -- C ABI of libmi355dsp.so: DSP.jl's FFT-filtering / spectral-estimation hot path on MI355X.
+ *
+ * DSP.jl (v0.8.5) has no FFI of its own: the hot path leaves Julia only through AbstractFFTs plans
+ * (FFTW) and BLAS.dot.  This header is the boundary a thin Julia `ccall` module (julia/MI355DSP.jl) or the
+ * Python/ctypes host (dsp.jl_amd/) binds instead of those calls; every entry point below names the
+ * reference routine whose inner loop it replaces (paths relative to DSP.jl `src/`).
+ *
+ * Conventions
+ *   - Plain C: pointers, int64 sizes, int status.  Nothing throws or aborts.  0 = MDSP_OK, <0 = error class
+ *     (the host wrapper maps classes to the same exception types DSP.jl raises); mdsp_last_error_string()
+ *     returns a thread-local message.
+ *   - `*_dev` pointers are device (HBM) pointers owned by the caller; `*_host` pointers are host memory read
+ *     during the call.  Handles own plans, work buffers, tables and streaming state.  A handle is
+ *     single-owner; calls are ordered on the `stream` argument (a hipStream_t passed as void*; NULL = the
+ *     null stream).  Distinct handles may be used from distinct host threads.
+ *   - Arrays are column-major: a multi-channel signal is (len, nch) with leading dimension `ld` (elements).
+ *   - Lengths, offsets and phase indices are int64 and follow the reference's 1-based state values where the
+ *     reference exposes them (phi_idx, input_deficit).
+ */
+#ifndef MI355DSP_H
+#define MI355DSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDSP_VERSION 100 /* 0.1.0 */
+
+/* status codes: error classes mirror the Julia exception types of the reference */
+enum {
+    MDSP_OK = 0,
+    MDSP_ERR_ARGUMENT = -1,    /* ArgumentError      (dspbase.jl:28-33, filt.jl:474,531, periodograms.jl:396,564,876, stream_filt.jl:415,490) */
+    MDSP_ERR_DOMAIN = -2,      /* DomainError        (periodograms.jl:44-45,397,565; stream_filt.jl:194,217) */
+    MDSP_ERR_DIMENSION = -3,   /* DimensionMismatch  (periodograms.jl:255,735-737) */
+    MDSP_ERR_ASSERTION = -4,   /* AssertionError     (stream_filt.jl:634,718,722) */
+    MDSP_ERR_UNSUPPORTED = -5, /* valid in DSP.jl but outside this library's scope -> caller falls back to CPU */
+    MDSP_ERR_DEVICE = -6,      /* HIP / rocFFT / RCCL runtime failure */
+    MDSP_ERR_NOMEM = -7
+};
+
+/* element types (fftintype / fftouttype / fftabs2type rules, util.jl:92-104, are applied by the host) */
+enum { MDSP_F32 = 0, MDSP_F64 = 1, MDSP_C32 = 2 /* ComplexF32 */, MDSP_C64 = 3 /* ComplexF64 */ };
+
+/* transform engine */
+enum {
+    MDSP_ENGINE_AUTO = 0,  /* fused in-LDS FFT kernels when the size is supported, rocFFT otherwise */
+    MDSP_ENGINE_FUSED = 1, /* segment/window -> FFT -> epilogue in ONE kernel, FFT held in LDS/registers */
+    MDSP_ENGINE_ROCFFT = 2 /* segmenter / epilogue kernels around cached, batched rocFFT plans */
+};
+
+/* ------------------------------------------------------------------------------------------------------
+ * Library / device
+ * ---------------------------------------------------------------------------------------------------- */
+int mdsp_version(void);
+const char* mdsp_last_error_string(void);
+/* Select the device for the calling thread and create the per-device context (rocFFT setup, plan cache). */
+int mdsp_init(int device);
+int mdsp_shutdown(void);
+int mdsp_device_count(int* count);
+
+/* Device-memory helpers for hosts without their own GPU array type (ctypes tests, the Julia wrapper). */
+int mdsp_malloc(void** dev_ptr, size_t bytes);
+int mdsp_free(void* dev_ptr);
+int mdsp_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int mdsp_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int mdsp_memset(void* dst_dev, int value, size_t bytes, void* stream);
+int mdsp_stream_synchronize(void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Pure index arithmetic (host; bit-exact with the reference)
+ * ---------------------------------------------------------------------------------------------------- */
+/* util.jl:134  nextfastfft(n) = nextprod((2,3,5,7), n) */
+int64_t mdsp_nextfastfft(int64_t n);
+/* dspbase.jl:268-291  optimalfftfiltlength(nb, nx) */
+int64_t mdsp_optimal_fft_len(int64_t nb, int64_t nx);
+/* periodograms.jl:49-50  number of frames of ArraySplit (trailing partial frame dropped) */
+int64_t mdsp_frame_count(int64_t len, int64_t n, int64_t noverlap);
+/* stream_filt.jl:317-322  outputlength(inputlength, L//M, initial_phi) */
+int64_t mdsp_outputlength(int64_t inputlength, int64_t L, int64_t M, int64_t initial_phi);
+/* stream_filt.jl:358-364  inputlength(outputlength, L//M, initial_phi, RoundDown|RoundUp) */
+int64_t mdsp_inputlength(int64_t outputlength, int64_t L, int64_t M, int64_t initial_phi, int round_up);
+/* Overlap-save block geometry of _fftfilt! (Filters/filt.jl:490,504-517) for block `iblock` (0-based):
+ * off (1-based first output), npadbefore, xstart (1-based), n (samples copied), nout (samples saved). */
+int mdsp_ols_block_geometry(int64_t nb, int64_t nx, int64_t nfft, int64_t iblock, int64_t* off,
+                            int64_t* npadbefore, int64_t* xstart, int64_t* n, int64_t* nout);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Overlap-save FIR filtering / convolution
+ *   replaces the block loop of _fftfilt! (Filters/filt.jl:504-518: zero+copy, rfft, .* filterft, brfft, copy)
+ *   and of unsafe_conv_kern_os! (dspbase.jl:546-606) incl. its padded edge blocks (:371-486), N = 1.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct mdsp_ols_plan_s* mdsp_ols_plan;
+enum {
+    MDSP_OLS_FILT = 0, /* y has the length of x; taps pre-scaled by 1/nfft            (filt.jl:499) */
+    MDSP_OLS_CONV = 1  /* y has length nx+nb-1; filter SPECTRUM scaled by 1/nfft (dspbase.jl:516) */
+};
+/* taps_host: nb elements of `dtype` (real taps for MDSP_F32/F64, complex for MDSP_C32/C64).
+ * nfft = 0 selects mdsp_optimal_fft_len(nb, nx_hint). */
+int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb, int64_t nfft, int64_t nx_hint,
+                         int dtype, int mode, int engine);
+int mdsp_ols_plan_destroy(mdsp_ols_plan plan);
+int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len /* L */, int* engine_used);
+/* x_dev: (nx, ncols) ld ldx;  y_dev: (nout, ncols) ld ldy.  nout = nx (filt), nx+nb-1 (conv), or any
+ * 0 <= nout <= nx+nb-1.  x and y must not alias (Filters/filt.jl:438-439). */
+int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,
+                  int64_t nout, int64_t ldy, void* stream);
+/* Segmenter only (K1): materialise blocks [first_block, first_block+nblocks) of column 0 as (nfft, nblocks)
+ * -- the exact contents of `tmp1` before the forward transform (filt.jl:509-510).  For parity tests. */
+int mdsp_ols_segment(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t first_block, int64_t nblocks,
+                     void* seg_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Framing (ArraySplit), Welch, STFT / spectrogram / periodogram
+ *   replaces ArraySplit getindex (periodograms.jl:57-69), mul!(outbuf, plan, sig) (:754,:888),
+ *   fft2pow! (:142-172) and fft2oneortwosided! (:234-244).
+ * ---------------------------------------------------------------------------------------------------- */
+/* K4 only: frames [first, first+count) of one channel as (nfft, count) of the signal's fftintype, windowed
+ * in Float64 and rounded once, zero tail -- bit-identical to the reference's buffer contents. */
+int mdsp_frames(const void* s_dev, int64_t len, int dtype, int64_t n, int64_t noverlap, int64_t nfft,
+                const double* window_host /* n doubles or NULL */, int64_t first, int64_t count, void* frames_dev,
+                void* stream);
+
+typedef struct mdsp_welch_plan_s* mdsp_welch_plan;
+/* dtype: element type of the signal (fftintype already applied).  window_host: n Float64 or NULL.
+ * r = fs * sum(abs2, window) (or fs * n without window), as WelchConfig computes it (periodograms.jl:567-568).
+ * onesided requires a real dtype (ArgumentError otherwise, :564). */
+int mdsp_welch_plan_create(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, int64_t nfft,
+                           const double* window_host, double r, int onesided, int dtype, int engine);
+int mdsp_welch_plan_destroy(mdsp_welch_plan plan);
+int mdsp_welch_plan_info(mdsp_welch_plan plan, int64_t* nout, int* engine_used);
+/* s_dev: (len, nch) ld lds.  psd_dev: (nout, nch) ld ldp of fftabs2type(dtype); nout = nfft/2+1 or nfft.
+ * Each channel gets its own PSD (welch_pgram_helper!, periodograms.jl:746-759). */
+int mdsp_welch_exec(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds,
+                    void* psd_dev, int64_t ldp, void* stream);
+/* Mean over channels of the PSDs produced by the last mdsp_welch_exec on this rank, into mean_dev (nout):
+ * sum over the local channels; the cross-GPU sum (RCCL all-reduce over xGMI) and the 1/total_channels scale
+ * are applied by the host (torch.distributed / ncclAllReduce on the same buffer), see INTEGRATION.md. */
+int mdsp_channel_sum(const void* psd_dev, int64_t nout, int64_t nch, int64_t ldp, int real_dtype,
+                     void* sum_dev, void* stream);
+
+typedef struct mdsp_stft_plan_s* mdsp_stft_plan;
+/* psd_only = 0: raw STFT columns (fftouttype), unnormalised (periodograms.jl:892);
+ * psd_only = 1: spectrogram columns fft2pow!(…, r, onesided, offset) (:890) in fftabs2type.
+ * periodogram(s) (periodograms.jl:393-417) is the single-frame case n = length(s), noverlap = 0, psd_only = 1. */
+int mdsp_stft_plan_create(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int64_t nfft,
+                          const double* window_host, double r, int onesided, int psd_only, int dtype, int engine);
+int mdsp_stft_plan_destroy(mdsp_stft_plan plan);
+int mdsp_stft_plan_info(mdsp_stft_plan plan, int64_t* nout, int* engine_used);
+/* s_dev: (len, nch) ld lds.  out_dev: nch matrices (nout, k) column-major with column stride ldo (>= nout)
+ * and channel stride chs (elements of the output type). */
+int mdsp_stft_exec(mdsp_stft_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds, void* out_dev,
+                   int64_t ldo, int64_t chs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Stateful polyphase FIR (FIRFilter{FIRStandard|FIRInterpolator|FIRDecimator|FIRRational})
+ *   replaces the while loop of filt!(buffer, ::FIRFilter, x) (stream_filt.jl:409-558) and its
+ *   unsafe_dot / BLAS.dot inner products (util.jl:225-283) and shiftin! (util.jl:299-314).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct mdsp_fir_s* mdsp_fir;
+/* taps_host: hlen taps of taps_dtype (MDSP_F32 | MDSP_F64); ratio L/M is reduced to lowest terms.
+ * x_dtype: element type of the input; output type = promote(taps, x).  nch channels share the scalar state
+ * (phi_idx, input_deficit) and keep separate histories, as resample(...; dims) does per slice (:768-774). */
+int mdsp_fir_create(mdsp_fir* f, const void* taps_host, int64_t hlen, int64_t L, int64_t M, int taps_dtype,
+                    int x_dtype, int64_t nch);
+int mdsp_fir_destroy(mdsp_fir f);
+int mdsp_fir_reset(mdsp_fir f);                       /* reset!     stream_filt.jl:247-276 */
+int mdsp_fir_setphase(mdsp_fir f, double phi);        /* setphase!  :216-229 */
+int mdsp_fir_timedelay(mdsp_fir f, double* tau);      /* timedelay  :400-403 */
+int mdsp_fir_outputlength(mdsp_fir f, int64_t inputlength, int64_t* outlen);            /* :324-338 */
+int mdsp_fir_inputlength(mdsp_fir f, int64_t outputlength, int round_up, int64_t* inlen); /* :366-383 */
+int mdsp_fir_info(mdsp_fir f, int* kind /*0 std,1 interp,2 decim,3 rational*/, int64_t* L, int64_t* M,
+                  int64_t* taps_per_phase, int64_t* history_len, int* out_dtype);
+/* state is exactly the reference's: 1-based phi_idx and input_deficit, history (history_len, nch) of x_dtype */
+int mdsp_fir_get_state(mdsp_fir f, int64_t* phi_idx, int64_t* input_deficit, void* history_host);
+int mdsp_fir_set_state(mdsp_fir f, int64_t phi_idx, int64_t input_deficit, const void* history_host);
+/* x_dev: (xlen, nch) ld ldx;  y_dev: (ycap, nch) ld ldy, ycap >= outputlength (ArgumentError otherwise, :490).
+ * *nwritten = samples written per channel (the return value of filt!). */
+int mdsp_fir_exec(mdsp_fir f, const void* x_dev, int64_t xlen, int64_t ldx, void* y_dev, int64_t ycap,
+                  int64_t ldy, int64_t* nwritten, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Time-domain FIR (filt(b, a::Number, x) and the nb <= 66 branch of filt(b, x)):
+ *   replaces _filt_fir! (dspbase.jl:95-105,118-141).  Zero initial state, per column.
+ *   taps_host: nb REAL taps in the real precision of `dtype` (float for MDSP_F32/C32, double for F64/C64);
+ *   x_dev / y_dev: (nx, ncols) of `dtype`.
+ * ---------------------------------------------------------------------------------------------------- */
+int mdsp_tdfir_exec(const void* taps_host, int64_t nb, int dtype, const void* x_dev, int64_t nx, int64_t ncols,
+                    int64_t ldx, void* y_dev, int64_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Measurement helpers (used by bench.py; not part of the drop-in surface)
+ * ---------------------------------------------------------------------------------------------------- */
+/* Times `reps` back-to-back launches of the last exec recorded on a plan with HIP events on `stream`. */
+int mdsp_event_create(void** ev);
+int mdsp_event_destroy(void* ev);
+int mdsp_event_record(void* ev, void* stream);
+int mdsp_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+/* float4 device copy kernel: the on-box achievable-HBM yardstick (bytes read + written = 2*bytes). */
+int mdsp_copy_bench(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355DSP_H */

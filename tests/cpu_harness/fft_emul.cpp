@@ -1,0 +1,102 @@
+// Host emulation of the workgroup FFT in dsp.jl_amd/csrc/fft_lds.h: runs the SAME pass_compute / pass_reload
+// code thread-by-thread (a barrier = the end of a loop over threads) and checks it against a long-double DFT.
+// Built and run by tests/test_fft_core_cpu.py with g++ (no GPU needed).
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../dsp.jl_amd/csrc/fft_lds.h"
+
+using namespace mdsp::fft;
+
+template <typename C, typename R, int DIR, bool TWREG, int PADSHIFT, int PASS>
+static void run_passes(std::vector<cx<R>>& regs, std::vector<cx<R>>& tw, const std::vector<cx<R>>& table, std::vector<cx<R>>& lds) {
+    if constexpr (PASS < C::P) {
+        constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+        for (int t = 0; t < C::T; ++t) {
+            auto& x = *reinterpret_cast<cx<R>(*)[C::E]>(&regs[(size_t)t * C::E]);
+            auto& w = *reinterpret_cast<cx<R>(*)[NTWA]>(&tw[(size_t)t * NTWA]);
+            pass_compute<C, DIR, PASS, TWREG, PADSHIFT>(x, t, w, table.data(), lds.data());
+        }
+        if constexpr (PASS < C::P - 1) {
+            for (int t = 0; t < C::T; ++t) {
+                auto& x = *reinterpret_cast<cx<R>(*)[C::E]>(&regs[(size_t)t * C::E]);
+                pass_reload<C, PADSHIFT>(x, t, lds.data());
+            }
+        }
+        run_passes<C, R, DIR, TWREG, PADSHIFT, PASS + 1>(regs, tw, table, lds);
+    }
+}
+
+template <int N, int E, typename R, int DIR, bool TWREG, int PADSHIFT> static double check() {
+    using C = Cfg<N, E>;
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    std::vector<cx<R>> table(N), regs((size_t)C::T * E), tw((size_t)C::T * NTWA), lds(lds_elems<N, PADSHIFT>());
+    for (int k = 0; k < N; ++k) {
+        const long double a = -2.0L * 3.141592653589793238462643383279502884L * k / N;
+        table[k] = {(R)cosl(a), (R)sinl(a)};
+    }
+    std::vector<std::complex<long double>> in(N), ref(N);
+    srand(1776 + N + E);
+    for (int i = 0; i < N; ++i) in[i] = {(long double)rand() / RAND_MAX - 0.5L, (long double)rand() / RAND_MAX - 0.5L};
+    for (int t = 0; t < C::T; ++t) {
+        for (int e = 0; e < E; ++e) regs[(size_t)t * E + e] = {(R)in[t + C::T * e].real(), (R)in[t + C::T * e].imag()};
+        auto& w = *reinterpret_cast<cx<R>(*)[NTWA]>(&tw[(size_t)t * NTWA]);
+        load_twiddles<C, R>(w, t, table.data());
+    }
+    run_passes<C, R, DIR, TWREG, PADSHIFT, 0>(regs, tw, table, lds);
+    // reference DFT (O(N^2), long double) on the rounded inputs
+    long double maxerr = 0, norm = 0;
+    std::vector<std::complex<long double>> root(N);
+    for (int k = 0; k < N; ++k) {
+        const long double a = (DIR < 0 ? -2.0L : 2.0L) * 3.141592653589793238462643383279502884L * k / N;
+        root[k] = {cosl(a), sinl(a)};
+    }
+    for (int k = 0; k < N; ++k) {
+        std::complex<long double> acc = 0;
+        for (int n = 0; n < N; ++n)
+            acc += std::complex<long double>((R)in[n].real(), (R)in[n].imag()) * root[(size_t)(((long long)n * k) % N)];
+        ref[k] = acc;
+        norm += std::norm(acc);
+    }
+    long double err2 = 0;
+    for (int t = 0; t < C::T; ++t)
+        for (int e = 0; e < E; ++e) {
+            const auto got = std::complex<long double>(regs[(size_t)t * E + e].x, regs[(size_t)t * E + e].y);
+            err2 += std::norm(got - ref[t + C::T * e]);
+        }
+    (void)maxerr;
+    return (double)sqrtl(err2 / norm);
+}
+
+template <int N, int E> static int check_all() {
+    int bad = 0;
+    const double e1 = check<N, E, float, -1, true, 4>();
+    const double e2 = check<N, E, float, +1, false, 5>();
+    const double e3 = check<N, E, double, -1, false, 31>();
+    const double e4 = check<N, E, double, +1, true, 4>();
+    printf("N=%5d E=%2d P=%d radices:", N, E, Cfg<N, E>::P);
+    for (int p = 0; p < Cfg<N, E>::P; ++p) printf(" %d", Cfg<N, E>::radix(p));
+    printf("  relerr f32 fwd %.2e inv %.2e  f64 fwd %.2e inv %.2e\n", e1, e2, e3, e4);
+    if (!(e1 < 2e-6) || !(e2 < 2e-6) || !(e3 < 1e-14) || !(e4 < 1e-14)) bad = 1;
+    return bad;
+}
+
+int main() {
+    int bad = 0;
+    bad |= check_all<16, 16>();
+    bad |= check_all<64, 8>();
+    bad |= check_all<128, 16>();
+    bad |= check_all<256, 16>();
+    bad |= check_all<512, 8>();
+    bad |= check_all<512, 16>();
+    bad |= check_all<1024, 16>();
+    bad |= check_all<2048, 16>();
+    bad |= check_all<2048, 8>();
+    bad |= check_all<4096, 16>();
+    bad |= check_all<8192, 16>();
+    printf(bad ? "FAIL\n" : "OK\n");
+    return bad;
+}
