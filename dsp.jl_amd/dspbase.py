@@ -175,6 +175,11 @@ def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int 
         z = _dev.torch.zeros(n_out, dtype=_dev.torch_dtype(T), device=_dev.device())
         return z if _dev.is_device_array(like) else z.cpu().numpy()
     big, small = (u, v) if nu >= nv else (v, u)
+    if T.kind in "iu":
+        # the reference stays in integer arithmetic (exact); the device computes in Float64, exact below 2^53
+        bound = float(abs(_host_vec(small).astype(np.float64)).max()) * float(_dev.to_columns(big, np.float64)[0].abs().max()) * min(nu, nv)
+        if bound >= 2.0 ** 53:
+            raise UnsupportedError("integer convolution would not be exact in Float64; use DSP.jl on the CPU")
     small_h = _host_vec(small).astype(W)
     if alg == "direct" and W.kind != "c":
         # direct sum: zero-state FIR over u extended by nv-1 zeros (dspbase.jl:646-660)
