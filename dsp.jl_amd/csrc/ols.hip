@@ -259,7 +259,7 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
     // per workgroup so that workgroups have 256 threads where possible.  `variant` selects tuning alternatives
     // (MDSP_OLS_VARIANT, swept by bench/tune.py); the non-default ones are only built for the headline shape.
     constexpr bool DBL = sizeof(R) == 8;
-    constexpr int EMAX = DBL ? 8 : 16;
+    constexpr int EMAX = 8;   // 8 elements/thread: no spills, 2x the rate of 16 on MI355X (profiles/tune_r01)
     constexpr int E = (N / 64 < EMAX) ? N / 64 : EMAX;
     constexpr int T = N / E;
     constexpr int G = T >= 256 ? 1 : 256 / T;
@@ -269,13 +269,17 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
         switch (variant) {
             //                                    R  N   E  G  TWREG PAD CPLX MINW NBUF PREFETCH
             case 1: return launch_fused_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, true>(a, s);
-            case 2: return launch_fused_variant<R, N, 16, 2, true, 4, CPLX, 2, 1, true>(a, s);
-            case 3: return launch_fused_variant<R, N, 16, 2, true, 4, CPLX, 2, 2, false>(a, s);
-            case 4: return launch_fused_variant<R, N, 16, 2, true, 5, CPLX, 2, 2, true>(a, s);
-            case 5: return launch_fused_variant<R, N, 16, 2, false, 4, CPLX, 2, 2, true>(a, s);
-            case 6: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true>(a, s);
-            case 7: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 4, 1, true>(a, s);
-            case 8: return launch_fused_variant<R, N, 16, 2, true, 31, CPLX, 2, 2, true>(a, s);
+            case 2: return launch_fused_variant<R, N, 16, 2, false, 4, CPLX, 2, 2, true>(a, s);
+            case 3: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 3, 2, true>(a, s);
+            case 4: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 4, 2, true>(a, s);
+            case 5: return launch_fused_variant<R, N, 8, 1, false, 4, CPLX, 4, 2, true>(a, s);
+            case 6: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 2, 1, true>(a, s);
+            case 7: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, false>(a, s);
+            case 8: return launch_fused_variant<R, N, 8, 1, true, 3, CPLX, 2, 2, true>(a, s);
+            case 9: return launch_fused_variant<R, N, 8, 1, true, 5, CPLX, 2, 2, true>(a, s);
+            case 10: return launch_fused_variant<R, N, 8, 1, true, 31, CPLX, 2, 2, true>(a, s);
+            case 11: return launch_fused_variant<R, N, 8, 1, false, 4, CPLX, 4, 1, false>(a, s);
+            case 12: return launch_fused_variant<R, N, 8, 1, false, 4, CPLX, 2, 2, true>(a, s);
             default: break;
         }
     }

@@ -364,7 +364,7 @@ int check_split(int64_t n, int64_t noverlap, int64_t nfft) {
 // geometry shared by the fused launchers
 template <typename R, int N> struct Geo {
     static constexpr bool DBL = sizeof(R) == 8;
-    static constexpr int EMAX = DBL ? 8 : 16;
+    static constexpr int EMAX = 8;   // 8 elements/thread: no spills, 2x the rate of 16 on MI355X (profiles/tune_r01)
     static constexpr int E = (N / 64 < EMAX) ? N / 64 : EMAX;
     static constexpr int T = N / E;
     static constexpr int G = T >= 256 ? 1 : 256 / T;
@@ -485,40 +485,42 @@ int welch_exec_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t
     return MDSP_OK;
 }
 
+template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
+int welch_run_variant(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
+    auto kern = welch_fused_kernel<R, N, E, G, TWREG, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, WIN64>;
+    constexpr int threads = (N / E) * G;
+    int grid = 1;
+    MDSP_TRY(grid_for(kern, threads, cdiv(a.units_per_ch, G), a.nch, &grid));
+    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)grid * G * (size_t)a.nch * N));
+    a.out = pl->partial.p;
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
+    MDSP_LAUNCH_CHECK();
+    *nslices = grid * G;
+    return MDSP_OK;
+}
+
 template <typename R, int N, bool CPLX>
 int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, hipStream_t st) {
     using Gm = Geo<R, N>;
-    constexpr int E = Gm::E, G = Gm::G, NBUF = Gm::NBUF;
-    constexpr bool TWREG = Gm::TWREG;
-    constexpr int threads = (N / E) * G;
-    int grid = 1;
-    const int64_t work = cdiv(a.units_per_ch, G);
-    auto run = [&](auto kern) -> int {
-        MDSP_TRY(grid_for(kern, threads, work, a.nch, &grid));
-        const size_t pbytes = sizeof(double) * (size_t)grid * G * (size_t)a.nch * N;
-        MDSP_TRY(pl->partial.reserve(pbytes));
-        a.out = pl->partial.p;
-        hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
-        MDSP_LAUNCH_CHECK();
-        return MDSP_OK;
-    };
-    int rc;
+    int nslices = 0, rc;
     if constexpr (N == 4096 && !CPLX && sizeof(R) == 4) {
-        switch (pl->variant) {
-            //                                     R  N   E  G TWREG PAD CPLX MINW NBUF PREF WIN64
-            case 1: rc = run(welch_fused_kernel<R, N, 16, 1, true, 4, CPLX, 2, 2, true, false>); break;
-            case 2: rc = run(welch_fused_kernel<R, N, 16, 1, true, 4, CPLX, 2, 2, false, true>); break;
-            case 3: rc = run(welch_fused_kernel<R, N, 16, 1, false, 4, CPLX, 2, 2, true, true>); break;
-            case 4: rc = run(welch_fused_kernel<R, N, 8, 1, true, 4, CPLX, 2, 2, true, true>); break;
-            case 5: rc = run(welch_fused_kernel<R, N, 16, 1, true, 5, CPLX, 2, 2, true, true>); break;
-            case 6: rc = run(welch_fused_kernel<R, N, 16, 1, true, 4, CPLX, 2, 1, true, true>); break;
-            default: rc = run(welch_fused_kernel<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true, true>); break;
+        switch (pl->variant) {  // tuning alternatives (MDSP_WELCH_VARIANT), built for the headline shape only
+            //                                  R  N   E  G TWREG PAD CPLX MINW NBUF PREF WIN64
+            case 1: rc = welch_run_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
+            case 2: rc = welch_run_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, false, true>(pl, a, st, &nslices); break;
+            case 3: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true, false>(pl, a, st, &nslices); break;
+            case 4: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, false, true>(pl, a, st, &nslices); break;
+            case 5: rc = welch_run_variant<R, N, 8, 1, false, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
+            case 6: rc = welch_run_variant<R, N, 8, 1, true, 3, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
+            case 7: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 1, true, true>(pl, a, st, &nslices); break;
+            case 8: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 4, 1, true, true>(pl, a, st, &nslices); break;
+            case 9: rc = welch_run_variant<R, N, 8, 1, false, 4, CPLX, 4, 1, false, true>(pl, a, st, &nslices); break;
+            default: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
         }
     } else {
-        rc = run(welch_fused_kernel<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true, true>);
+        rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, 4, CPLX, 2, Gm::NBUF, true, true>(pl, a, st, &nslices);
     }
     if (rc != MDSP_OK) return rc;
-    const int nslices = grid * G;
     const int nout = (int)pl->nout;
     const double r_total = (double)a.K * pl->r;
     const dim3 fg((unsigned)cdiv(nout, 256), (unsigned)a.nch);

@@ -97,6 +97,10 @@ int main() {
     bad |= check_all<2048, 8>();
     bad |= check_all<4096, 16>();
     bad |= check_all<8192, 16>();
+    bad |= check_all<4096, 8>();
+    bad |= check_all<1024, 8>();
+    bad |= check_all<256, 4>();
+    bad |= check_all<8192, 8>();
     printf(bad ? "FAIL\n" : "OK\n");
     return bad;
 }

@@ -42,7 +42,7 @@ def timeit(fn):
 
 res = {"log2n": log2n, "ols": {}, "welch": {}, "stft": {}}
 # ---- overlap-save ----
-ols_variants = [int(v) for v in os.environ.get("TUNE_OLS", "0,1,2,3,4,5,6,7,8").split(",") if v != ""]
+ols_variants = [int(v) for v in os.environ.get("TUNE_OLS", "0,1,2,3,4,5,6,7,8,9,10,11,12").split(",") if v != ""]
 plans = {}
 for v in ols_variants:
     os.environ["MDSP_OLS_VARIANT"] = str(v)
@@ -66,7 +66,7 @@ for k, v in res["ols"].items():
     v["median_ms"] = sorted(v["ms"])[len(v["ms"]) // 2]
 del plans, ref
 # ---- Welch ----
-welch_variants = [int(v) for v in os.environ.get("TUNE_WELCH", "0,1,2,3,4,5,6").split(",") if v != ""]
+welch_variants = [int(v) for v in os.environ.get("TUNE_WELCH", "0,1,2,3,4,5,6,7,8,9").split(",") if v != ""]
 cfgs = {}
 for v in welch_variants:
     os.environ["MDSP_WELCH_VARIANT"] = str(v)
