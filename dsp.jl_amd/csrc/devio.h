@@ -91,15 +91,12 @@ template <typename T, int E, int TT> __device__ __forceinline__ void load_window
     constexpr int SZ = (int)sizeof(T);
     int off = t * SZ;
     asm volatile("" : "+v"(off));  // keep LICM from materialising E offset VGPRs outside the persistent loop
+    if (lead == 0) {               // wave-uniform; the steady state: one VGPR offset + immediates, no per-lane tests
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (TT * e >= lead) {  // uniform: every lane valid (the common case: lead == 0)
-            out[e] = Ld<T>::load(r, off + TT * e * SZ);
-        } else if (TT * (e + 1) <= lead) {  // uniform: every lane in the zero padding
-            out[e] = T{};
-        } else {
-            out[e] = Ld<T>::load(r, (t + TT * e) < lead ? OOB : off + TT * e * SZ);
-        }
+        for (int e = 0; e < E; ++e) out[e] = Ld<T>::load(r, off + TT * e * SZ);
+    } else {                       // leading blocks only: lanes in front of the signal read through the OOB sentinel (-> 0)
+#pragma unroll
+        for (int e = 0; e < E; ++e) out[e] = Ld<T>::load(r, (t + TT * e) < lead ? OOB : off + TT * e * SZ);
     }
 }
 
@@ -107,13 +104,12 @@ template <typename T, int E, int TT, typename F> __device__ __forceinline__ void
     constexpr int SZ = (int)sizeof(T);
     int off = t * SZ;
     asm volatile("" : "+v"(off));
+    if (lead == 0) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (TT * e >= lead) {
-            Ld<T>::store(get(e), w, off + TT * e * SZ);
-        } else if (TT * (e + 1) > lead) {
-            Ld<T>::store(get(e), w, (t + TT * e) < lead ? OOB : off + TT * e * SZ);
-        }
+        for (int e = 0; e < E; ++e) Ld<T>::store(get(e), w, off + TT * e * SZ);
+    } else {                       // branch-free: lanes below `lead` store through the OOB sentinel (dropped)
+#pragma unroll
+        for (int e = 0; e < E; ++e) Ld<T>::store(get(e), w, (t + TT * e) < lead ? OOB : off + TT * e * SZ);
     }
 }
 

@@ -90,6 +90,8 @@ struct OlsFusedArgs {
     int64_t units_per_col;  // pairs (real) or blocks (complex)
     int64_t nunits;         // total
     int nb;
+    int64_t run_len;        // a slot takes runs of run_len consecutive units ...
+    int64_t niter;          // ... runs_per_slot * run_len iterations in total (same for every slot)
 };
 
 // Raw samples of one unit as they come from HBM: two real blocks (a, b) or one complex block.
@@ -98,23 +100,52 @@ template <typename R, int E, bool CPLX> struct OlsRaw {
     std::conditional_t<CPLX, char, R> b[CPLX ? 1 : E];
 };
 
+// Position of a unit inside the (nx, ncols) problem: column, pair/block index within the column, liveness.
+// All wave-uniform (SALU).  Unit schedule: slot s of S walks runs of `run_len` CONSECUTIVE units (run g of slot s
+// starts at unit (g*S + s)*run_len).  With one run per slot (the default) every workgroup streams one contiguous
+// piece of x and y: the nb-1 sample overlap between consecutive blocks and the prefetch of the next unit hit
+// L1/L2, and reads and writes are sequential per workgroup (measured +15 % over a strided schedule).
+struct OlsPos {
+    int64_t col, p;
+    bool live;
+};
+struct OlsWalk {
+    int64_t base, j;   // current unit = base + j
+};
+__device__ __forceinline__ OlsPos ols_pos(const OlsFusedArgs& a, const OlsWalk& w, bool more) {
+    const int64_t u = w.base + w.j;
+    OlsPos q;
+    q.live = more && u < a.nunits;
+    if (a.units_per_col >= a.nunits) {  // single column (the common case): no division at all
+        q.col = 0;
+        q.p = q.live ? u : 0;
+    } else {
+        q.col = q.live ? u / a.units_per_col : 0;
+        q.p = q.live ? u - q.col * a.units_per_col : 0;
+    }
+    return q;
+}
+__device__ __forceinline__ void ols_walk_next(OlsWalk& w, int64_t run_len, int64_t nslots) {
+    if (++w.j == run_len) {
+        w.j = 0;
+        w.base += nslots * run_len;
+    }
+}
+
 template <typename R, int E, int T, bool CPLX>
-__device__ __forceinline__ void ols_issue_loads(OlsRaw<R, E, CPLX>& raw, const OlsFusedArgs& a, int64_t u, int t) {
+__device__ __forceinline__ void ols_issue_loads(OlsRaw<R, E, CPLX>& raw, const OlsFusedArgs& a, OlsPos q, int t) {
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     constexpr int64_t SZ = (int64_t)sizeof(TT);
-    const bool live = u < a.nunits;
-    const int64_t col = live ? u / a.units_per_col : 0;
-    const int64_t p = live ? u - col * a.units_per_col : 0;
-    const TT* xc = static_cast<const TT*>(a.x) + col * a.ldx;
-    const int64_t g0 = CPLX ? p : 2 * p;          // first block of the unit
+    const TT* xc = static_cast<const TT*>(a.x) + q.col * a.ldx;
+    const int64_t g0 = CPLX ? q.p : 2 * q.p;      // first block of the unit
     const int64_t start = g0 * a.L - (a.nb - 1);  // window start in x; negative for the leading blocks
     {
-        const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + start, live ? (a.nx - start) * SZ : 0);
+        const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + start, q.live ? (a.nx - start) * SZ : 0);
         const int lead = __builtin_amdgcn_readfirstlane((int)(start < 0 ? -start : 0));
         io::load_window<TT, E, T>(raw.a, r, lead, t);
     }
     if constexpr (!CPLX) {
-        const bool haveB = live && (g0 + 1) < a.nblocks;
+        const bool haveB = q.live && (g0 + 1) < a.nblocks;
         const int64_t startB = start + a.L;
         const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + startB, haveB ? (a.nx - startB) * SZ : 0);
         const int lead = __builtin_amdgcn_readfirstlane((int)(startB < 0 ? -startB : 0));
@@ -123,23 +154,20 @@ __device__ __forceinline__ void ols_issue_loads(OlsRaw<R, E, CPLX>& raw, const O
 }
 
 template <typename R, int E, int T, bool CPLX>
-__device__ __forceinline__ void ols_store(const cx<R> (&v)[E], const OlsFusedArgs& a, int64_t u, int t) {
+__device__ __forceinline__ void ols_store(const cx<R> (&v)[E], const OlsFusedArgs& a, OlsPos q, int t) {
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     constexpr int64_t SZ = (int64_t)sizeof(TT);
-    const bool live = u < a.nunits;
-    const int64_t col = live ? u / a.units_per_col : 0;
-    const int64_t p = live ? u - col * a.units_per_col : 0;
-    const int64_t off0 = (CPLX ? p : 2 * p) * a.L;  // first output of the unit
-    const int lead = a.nb - 1;                      // K3: the first nb-1 samples of a block are aliased -> dropped
-    TT* yc = static_cast<TT*>(a.y) + col * a.ldy;
+    const int64_t off0 = (CPLX ? q.p : 2 * q.p) * a.L;  // first output of the unit
+    const int lead = a.nb - 1;                          // K3: the first nb-1 samples of a block are aliased -> dropped
+    TT* yc = static_cast<TT*>(a.y) + q.col * a.ldy;
     {
-        const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + off0 - lead, live ? (a.nout - off0 + lead) * SZ : 0);
+        const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + off0 - lead, q.live ? (a.nout - off0 + lead) * SZ : 0);
         if constexpr (CPLX) io::store_window<TT, E, T>([&](int e) { return v[e]; }, w, lead, t);
         else io::store_window<TT, E, T>([&](int e) { return v[e].x; }, w, lead, t);
     }
     if constexpr (!CPLX) {
         const int64_t offB = off0 + a.L;  // past nout when the unit has no second block: num_records <= 0 drops it
-        const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + offB - lead, (live && offB < a.nout) ? (a.nout - offB + lead) * SZ : 0);
+        const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + offB - lead, (q.live && offB < a.nout) ? (a.nout - offB + lead) * SZ : 0);
         io::store_window<TT, E, T>([&](int e) { return v[e].y; }, w, lead, t);
     }
 }
@@ -153,7 +181,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
     __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
     const int t = threadIdx.x % T;
-    const int slot = threadIdx.x / T;
+    const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));  // wave-uniform by construction (T % 64 == 0)
     cx<R>* lds = lds_all + slot * REGION;
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
 
@@ -163,14 +191,15 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
 #pragma unroll
     for (int e = 0; e < E; ++e) Hr[e] = static_cast<const cx<R>*>(a.H)[t + T * e];
 
-    const int64_t stride = (int64_t)gridDim.x * G;
-    const int64_t niter = (a.nunits + stride - 1) / stride;
-    const int64_t ufirst = (int64_t)blockIdx.x * G + slot;
+    const int64_t nslots = (int64_t)gridDim.x * G;
+    OlsWalk walk{((int64_t)blockIdx.x * G + slot) * a.run_len, 0};
+    OlsPos cur = ols_pos(a, walk, a.niter > 0);
     OlsRaw<R, E, CPLX> raw;
-    if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, ufirst, t);
-    for (int64_t it = 0; it < niter; ++it) {
-        const int64_t u = it * stride + ufirst;
-        if constexpr (!PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, u, t);
+    if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, t);
+    for (int64_t it = 0; it < a.niter; ++it) {   // same trip count for every slot (barriers inside)
+        ols_walk_next(walk, a.run_len, nslots);
+        const OlsPos nxt = ols_pos(a, walk, it + 1 < a.niter);
+        if constexpr (!PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, t);
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -178,7 +207,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
             else v[e] = {raw.a[e], raw.b[e]};
         }
         // next unit's samples start streaming from HBM while this unit is transformed
-        if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, u + stride, t);
+        if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, nxt, t);
         fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
         // spectral multiply (K2): natural order in registers
 #pragma unroll
@@ -187,7 +216,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
         fft::wg_fft<C, +1, TWREG, PADSHIFT, NBUF, (C::P - 1) % NBUF>(v, t, tw, table, lds);
         // single buffer: the next iteration's first pass rewrites LDS that slower waves may still be reading
         if constexpr (C::P > 1 && NBUF == 1) fft::wg_sync<T>();
-        ols_store<R, E, T, CPLX>(v, a, u, t);
+        ols_store<R, E, T, CPLX>(v, a, cur, t);
+        cur = nxt;
     }
 }
 
@@ -247,9 +277,16 @@ int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
     if (per_cu < 1) per_cu = 1;
+    if (const char* e = getenv("MDSP_WG_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning knob
     const int64_t want = cdiv(a.nunits, G);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cu_count() * per_cu));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, a);
+    OlsFusedArgs b = a;
+    int64_t runs = 1;                                                  // runs per slot (1 = fully contiguous)
+    if (const char* e = getenv("MDSP_RUNS_PER_SLOT")) runs = std::max(1, atoi(e));
+    const int64_t nslots = (int64_t)grid * G;
+    b.run_len = std::max<int64_t>(1, cdiv(a.nunits, nslots * runs));
+    b.niter = cdiv(cdiv(a.nunits, b.run_len), nslots) * b.run_len;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, b);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
@@ -464,6 +501,8 @@ int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t nco
     a.nblocks = cdiv(nout, plan->L);
     a.units_per_col = cplx ? a.nblocks : cdiv(a.nblocks, 2);
     a.nunits = a.units_per_col * ncols;
+    a.run_len = 1;
+    a.niter = 0;
     if (cplx) return dbl ? launch_fused<double, true>(plan->nfft, a, plan->variant, s) : launch_fused<float, true>(plan->nfft, a, plan->variant, s);
     return dbl ? launch_fused<double, false>(plan->nfft, a, plan->variant, s) : launch_fused<float, false>(plan->nfft, a, plan->variant, s);
 }

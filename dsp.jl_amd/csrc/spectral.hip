@@ -79,6 +79,27 @@ __global__ __launch_bounds__(256) void abs2_accum_kernel(const cx<R>* __restrict
     if (lo + (int64_t)blockIdx.y < hi) partial[((int64_t)blockIdx.y * nch + ch) * nspec + k] += acc;
 }
 
+// Slice reduction: reduced[ch][k] = sum_s partial[s][ch][k], fixed order (deterministic).  32 bins x 8 slice lanes per
+// workgroup so the nslices-long sum is spread over threads instead of being one latency-bound loop per bin.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, double* __restrict__ reduced, int nslices,
+                                                              int64_t nch, int nacc) {
+    __shared__ double sm[8][33];
+    const int bx = threadIdx.x & 31, sy = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + bx;
+    const int64_t ch = blockIdx.y;
+    double a = 0;
+    if (k < nacc)
+        for (int s = sy; s < nslices; s += 8) a += partial[((int64_t)s * nch + ch) * nacc + k];
+    sm[sy][bx] = a;
+    __syncthreads();
+    if (sy == 0 && k < nacc) {
+        double t = sm[0][bx];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += sm[i][bx];
+        reduced[ch * nacc + k] = t;
+    }
+}
+
 // Welch finalize: psd[ch][j] = T( m_j * fold(sum over slices) )
 //   MODE 0: one-sided from half spectrum  (acc has nspec = nfft/2+1 bins)       m = 1/r (DC, Nyquist if even) else 2/r
 //   MODE 1: two-sided from full spectrum  (acc has nfft bins)                   m = 1/r
@@ -156,6 +177,7 @@ struct SpecArgs {
     int64_t nch;
     int64_t ldo, chs;      // STFT output strides
     int n, nout, onesided;
+    int64_t run_len, niter;  // unit schedule: runs of run_len consecutive units per slot, niter iterations per slot
     double r;
 };
 
@@ -180,7 +202,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
     constexpr int64_t SZ = (int64_t)sizeof(TT);
     __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
     const int t = threadIdx.x % T;
-    const int slot = threadIdx.x / T;
+    const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));  // wave-uniform (T % 64 == 0)
     cx<R>* lds = lds_all + slot * REGION;
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
     const int64_t ch = blockIdx.y;
@@ -199,9 +221,18 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
     for (int e = 0; e < E; ++e) acc[e] = 0.0;
 
     const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
-    const int64_t stride = (int64_t)gridDim.x * G;
-    const int64_t ufirst = (int64_t)blockIdx.x * G + slot;
-    const int64_t niter = (a.units_per_ch + stride - 1) / stride;
+    // Unit schedule (wave-uniform): slot s of S walks runs of run_len consecutive units; run g of slot s starts at unit
+    // (g*S + s)*run_len.  Consecutive frames share their n-hop overlap through L1/L2.
+    const int64_t nslots = (int64_t)gridDim.x * G;
+    int64_t wbase = ((int64_t)blockIdx.x * G + slot) * a.run_len, wj = 0;
+    auto unit_cur = [&](bool more) { return (more && wbase + wj < a.units_per_ch) ? wbase + wj : a.units_per_ch; };  // else dead
+    auto walk = [&]() {
+        if (++wj == a.run_len) {
+            wj = 0;
+            wbase += nslots * a.run_len;
+        }
+    };
+    const int64_t niter = a.niter;
 
     TT ra[E];
     TT rb[CPLX ? 1 : E];
@@ -219,9 +250,11 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
             io::load_window<TT, E, T>(rb, r1, 0, t);
         }
     };
-    if constexpr (PREFETCH) issue(ufirst);
+    int64_t u = unit_cur(niter > 0);
+    if constexpr (PREFETCH) issue(u);
     for (int64_t it = 0; it < niter; ++it) {
-        const int64_t u = it * stride + ufirst;
+        walk();
+        const int64_t unext = unit_cur(it + 1 < niter);
         if constexpr (!PREFETCH) issue(u);
         cx<R> v[E];
 #pragma unroll
@@ -234,12 +267,14 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
                 else v[e] = {ra[e] * w[e], rb[e] * w[e]};
             }
         }
-        if constexpr (PREFETCH) issue(u + stride);
+        if constexpr (PREFETCH) issue(unext);
+        u = unext;
         fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
         // an odd number of exchanges per iteration would re-enter on the buffer that was used last: fence it
         if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
+        // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] += (double)v[e].x * (double)v[e].x + (double)v[e].y * (double)v[e].y;
+        for (int e = 0; e < E; ++e) acc[e] += (double)(v[e].x * v[e].x + v[e].y * v[e].y);
     }
     // partial[(blockIdx.x*G + slot)][ch][k]
     double* part = static_cast<double*>(a.out) + (((int64_t)blockIdx.x * G + slot) * a.nch + ch) * N;
@@ -260,7 +295,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
     constexpr int64_t SZ = (int64_t)sizeof(TT);
     __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
     const int t = threadIdx.x % T;
-    const int slot = threadIdx.x / T;
+    const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));  // wave-uniform (T % 64 == 0)
     cx<R>* lds = lds_all + slot * REGION;
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
     const int64_t ch = blockIdx.y;
@@ -272,9 +307,16 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
     const bool havewin = a.win != nullptr;
 
     const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
-    const int64_t stride = (int64_t)gridDim.x * G;
-    const int64_t ufirst = (int64_t)blockIdx.x * G + slot;
-    const int64_t niter = (a.K + stride - 1) / stride;
+    const int64_t nslots = (int64_t)gridDim.x * G;
+    int64_t wbase = ((int64_t)blockIdx.x * G + slot) * a.run_len, wj = 0;
+    auto unit_cur = [&](bool more) { return (more && wbase + wj < a.K) ? wbase + wj : a.K; };
+    auto walk = [&]() {
+        if (++wj == a.run_len) {
+            wj = 0;
+            wbase += nslots * a.run_len;
+        }
+    };
+    const int64_t niter = a.niter;
     const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
 
     TT ra[E];
@@ -284,9 +326,12 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
         const __amdgpu_buffer_rsrc_t r0 = io::make_rsrc(sc + start, live ? std::min<int64_t>(a.n, a.len - start) * SZ : 0);
         io::load_window<TT, E, T>(ra, r0, 0, t);
     };
-    if constexpr (PREFETCH) issue(ufirst);
+    int64_t fcur = unit_cur(niter > 0);
+    if constexpr (PREFETCH) issue(fcur);
     for (int64_t it = 0; it < niter; ++it) {
-        const int64_t f = it * stride + ufirst;
+        const int64_t f = fcur;
+        walk();
+        fcur = unit_cur(it + 1 < niter);
         if constexpr (!PREFETCH) issue(f);
         cx<R> v[E];
 #pragma unroll
@@ -294,7 +339,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
             if constexpr (CPLX) v[e] = havewin ? win_mul(ra[e], w[e]) : ra[e];
             else v[e] = {havewin ? win_mul(ra[e], w[e]) : ra[e], (R)0};
         }
-        if constexpr (PREFETCH) issue(f + stride);
+        if constexpr (PREFETCH) issue(fcur);
         fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
         if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
         // column store: bins k = t + T*e < nout, contiguous across lanes
@@ -372,10 +417,19 @@ template <typename R, int N> struct Geo {
     static constexpr bool TWREG = !DBL;
 };
 
+// runs of consecutive units per slot (default: one run = fully contiguous), identical trip count for every slot
+void set_schedule(SpecArgs& a, int64_t nunits, int64_t nslots) {
+    int64_t runs = 1;
+    if (const char* e = getenv("MDSP_RUNS_PER_SLOT")) runs = std::max(1, atoi(e));
+    a.run_len = std::max<int64_t>(1, cdiv(nunits, nslots * runs));
+    a.niter = cdiv(cdiv(nunits, a.run_len), nslots) * a.run_len;
+}
+
 template <typename K> int grid_for(K kern, int threads, int64_t work_wgs, int64_t nch, int* grid) {
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
     if (per_cu < 1) per_cu = 1;
+    if (const char* e = getenv("MDSP_WG_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning knob
     const int64_t resident = (int64_t)device_cu_count() * per_cu;
     const int64_t per_ch = std::max<int64_t>(1, resident / std::max<int64_t>(1, nch));
     *grid = (int)std::max<int64_t>(1, std::min<int64_t>(work_wgs, per_ch));
@@ -428,7 +482,7 @@ struct mdsp_welch_plan_s {
     int64_t n = 0, noverlap = 0, nfft = 0, nout = 0;
     double r = 1;
     bool have_win = false;
-    DevBuf win, table, partial;
+    DevBuf win, table, partial, reduced;
     RocPlan fwd;
     DevBuf fr, spec;
     int64_t batch = 0;
@@ -493,6 +547,7 @@ int welch_run_variant(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* n
     MDSP_TRY(grid_for(kern, threads, cdiv(a.units_per_ch, G), a.nch, &grid));
     MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)grid * G * (size_t)a.nch * N));
     a.out = pl->partial.p;
+    set_schedule(a, a.units_per_ch, (int64_t)grid * G);
     hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
     MDSP_LAUNCH_CHECK();
     *nslices = grid * G;
@@ -508,28 +563,32 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
             //                                  R  N   E  G TWREG PAD CPLX MINW NBUF PREF WIN64
             case 1: rc = welch_run_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
             case 2: rc = welch_run_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, false, true>(pl, a, st, &nslices); break;
-            case 3: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true, false>(pl, a, st, &nslices); break;
+            case 3: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
             case 4: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, false, true>(pl, a, st, &nslices); break;
             case 5: rc = welch_run_variant<R, N, 8, 1, false, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
             case 6: rc = welch_run_variant<R, N, 8, 1, true, 3, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
             case 7: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 1, true, true>(pl, a, st, &nslices); break;
             case 8: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 4, 1, true, true>(pl, a, st, &nslices); break;
             case 9: rc = welch_run_variant<R, N, 8, 1, false, 4, CPLX, 4, 1, false, true>(pl, a, st, &nslices); break;
-            default: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
+            default: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true, false>(pl, a, st, &nslices); break;
         }
     } else {
-        rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, 4, CPLX, 2, Gm::NBUF, true, true>(pl, a, st, &nslices);
+        rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, 4, CPLX, 2, Gm::NBUF, true, sizeof(R) == 8>(pl, a, st, &nslices);
     }
     if (rc != MDSP_OK) return rc;
     const int nout = (int)pl->nout;
     const double r_total = (double)a.K * pl->r;
+    MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)a.nch * N));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<double>(),
+                       pl->reduced.as<double>(), nslices, a.nch, N);
+    MDSP_LAUNCH_CHECK();
     const dim3 fg((unsigned)cdiv(nout, 256), (unsigned)a.nch);
     if (CPLX)
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 1>), fg, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, a.nch, N, N, nout, r_total);
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 1>), fg, dim3(256), 0, st, pl->reduced.as<double>(), (R*)psd, ldp, 1, a.nch, N, N, nout, r_total);
     else if (pl->onesided)
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 3>), fg, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, a.nch, N, N, nout, r_total);
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 3>), fg, dim3(256), 0, st, pl->reduced.as<double>(), (R*)psd, ldp, 1, a.nch, N, N, nout, r_total);
     else
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 4>), fg, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, a.nch, N, N, nout, r_total);
+        hipLaunchKernelGGL((welch_finalize_kernel<R, 4>), fg, dim3(256), 0, st, pl->reduced.as<double>(), (R*)psd, ldp, 1, a.nch, N, N, nout, r_total);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
@@ -727,6 +786,7 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
     int grid = 1;
     auto run = [&](auto kern) -> int {
         MDSP_TRY(grid_for(kern, threads, work, a.nch, &grid));
+        set_schedule(a, a.K, (int64_t)grid * G);
         hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
         MDSP_LAUNCH_CHECK();
         return MDSP_OK;

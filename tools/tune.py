@@ -87,6 +87,21 @@ for r in range(rounds):
 for k, v in res["welch"].items():
     v["best_GBps"] = round(4.0 * n / (min(v["ms"]) * 1e-3) / 1e9, 1)
     v["median_ms"] = sorted(v["ms"])[len(v["ms"]) // 2]
+# ---- occupancy / schedule knobs (MDSP_WG_PER_CU and MDSP_CHUNK_LOG2 are read at every launch) ----
+res["knobs"] = {}
+os.environ["MDSP_OLS_VARIANT"] = "0"; os.environ["MDSP_WELCH_VARIANT"] = "0"
+p0 = OlsPlan(taps, 2048, n, 0, d.ENGINE_FUSED)
+c0 = d.WelchConfig(n, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=d.ENGINE_FUSED)
+for w in os.environ.get("TUNE_WGS", "1,2,4").split(","):
+    for c in os.environ.get("TUNE_RUNS", "1,2,8,64").split(","):
+        os.environ["MDSP_WG_PER_CU"] = w
+        os.environ["MDSP_RUNS_PER_SLOT"] = c
+        to = [timeit(lambda: _lib.check(lib.mdsp_ols_exec(p0._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream))) for _ in range(rounds)]
+        tw = [timeit(lambda: _lib.check(lib.mdsp_welch_exec(c0._h, x.data_ptr(), n, 1, n, psd.data_ptr(), 2049, stream))) for _ in range(rounds)]
+        res["knobs"][f"wg{w}_chunk{c}"] = {"ols_ms": min(to), "ols_GBps": round(8.0 * n / (min(to) * 1e-3) / 1e9, 1), "welch_ms": min(tw),
+                                          "welch_GBps": round(4.0 * n / (min(tw) * 1e-3) / 1e9, 1)}
+        print("knobs wg", w, "runs_per_slot", c, res["knobs"][f"wg{w}_chunk{c}"])
+del os.environ["MDSP_WG_PER_CU"]; del os.environ["MDSP_RUNS_PER_SLOT"]
 # ---- copy yardstick ----
 cms = [timeit(lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))) for _ in range(5)]
 res["copy_GBps"] = round(2 * 4.0 * n / (min(cms) * 1e-3) / 1e9, 1)
