@@ -1,0 +1,325 @@
+# MI355DSP.jl -- thin Julia host for libmi355dsp.so (the C ABI of include/mi355dsp.h).
+#
+# STATUS: written against the header, NOT executed -- the build image has no Julia.  The same C ABI is exercised
+# by the Python/ctypes host (dsp.jl_amd/) and its GPU parity tests; this file is the `ccall` twin a DSP.jl
+# maintainer would use.  It keeps DSP.jl's names, argument order, defaults, promotion rules and exception types
+# for the hot path (filt / fftfilt / conv / periodogram / welch_pgram / spectrogram / stft / FIRFilter / resample),
+# and does nothing else: no CUDA.jl / AMDGPU.jl array dispatch, every call goes straight to a hand-written HIP
+# kernel through `ccall`.
+#
+# Host arrays in, host arrays out (pinned staging is left to the caller); `DeviceArray` keeps data resident in HBM
+# between calls.  Reference locations are DSP.jl v0.8.5 `src/`.
+module MI355DSP
+
+export DeviceArray, upload, download, filt, fftfilt, tdfilt, conv, periodogram, WelchConfig, welch_pgram,
+       spectrogram, stft, FIRFilter, resample, reset!, setphase!, timedelay, inputlength, outputlength,
+       nextfastfft, optimalfftfiltlength
+
+const lib = get(ENV, "MI355DSP_LIB", joinpath(@__DIR__, "..", "dsp.jl_amd", "libmi355dsp.so"))
+
+# ---------------------------------------------------------------------------------------------- status -> exception
+const MDSP_F32, MDSP_F64, MDSP_C32, MDSP_C64 = Cint(0), Cint(1), Cint(2), Cint(3)
+const ENGINE_AUTO, ENGINE_FUSED, ENGINE_ROCFFT = Cint(0), Cint(1), Cint(2)
+
+struct UnsupportedError <: Exception
+    msg::String
+end
+struct DeviceError <: Exception
+    msg::String
+end
+
+lasterr() = unsafe_string(ccall((:mdsp_last_error_string, lib), Cstring, ()))
+
+function check(status::Cint)
+    status == 0 && return nothing
+    msg = lasterr()
+    status == -1 && throw(ArgumentError(msg))          # dspbase.jl:28-33, filt.jl:474,531, periodograms.jl:396,564,876
+    status == -2 && throw(DomainError(nothing, msg))   # periodograms.jl:44-45,397,565; stream_filt.jl:194,217
+    status == -3 && throw(DimensionMismatch(msg))      # periodograms.jl:255,735-737
+    status == -4 && throw(AssertionError(msg))         # stream_filt.jl:634,718,722
+    status == -5 && throw(UnsupportedError(msg))       # caller should fall back to DSP.jl itself
+    status == -7 && throw(OutOfMemoryError())
+    throw(DeviceError(msg))
+end
+
+mdtype(::Type{Float32}) = MDSP_F32
+mdtype(::Type{Float64}) = MDSP_F64
+mdtype(::Type{ComplexF32}) = MDSP_C32
+mdtype(::Type{ComplexF64}) = MDSP_C64
+
+# element-type rules, util.jl:92-104
+fftintype(::Type{T}) where {T<:Union{Float32,Float64,ComplexF32,ComplexF64}} = T
+fftintype(::Type{T}) where {T<:Real} = Float64
+fftintype(::Type{T}) where {T<:Complex} = ComplexF64
+fftouttype(::Type{T}) where {T<:Union{ComplexF32,ComplexF64}} = T
+fftouttype(::Type{Float32}) = ComplexF32
+fftouttype(::Type{T}) where {T<:Union{Real,Complex}} = ComplexF64
+fftabs2type(::Type{T}) where {T<:Union{Float32,ComplexF32}} = Float32
+fftabs2type(::Type{T}) where {T<:Union{Real,Complex}} = Float64
+
+init(device::Integer=0) = check(ccall((:mdsp_init, lib), Cint, (Cint,), device))
+
+# ---------------------------------------------------------------------------------------------- device memory
+mutable struct DeviceArray{T,N}
+    ptr::Ptr{Cvoid}
+    dims::NTuple{N,Int}
+    function DeviceArray{T}(dims::NTuple{N,Int}) where {T,N}
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:mdsp_malloc, lib), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, prod(dims) * sizeof(T)))
+        a = new{T,N}(p[], dims)
+        finalizer(x -> ccall((:mdsp_free, lib), Cint, (Ptr{Cvoid},), x.ptr), a)
+        a
+    end
+end
+DeviceArray{T}(dims::Int...) where {T} = DeviceArray{T}(dims)
+Base.size(a::DeviceArray) = a.dims
+Base.length(a::DeviceArray) = prod(a.dims)
+Base.eltype(::DeviceArray{T}) where {T} = T
+
+function upload(x::Array{T,N}) where {T,N}
+    d = DeviceArray{T}(size(x))
+    check(ccall((:mdsp_memcpy_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), d.ptr, x, sizeof(x), C_NULL))
+    d
+end
+function download(d::DeviceArray{T,N}) where {T,N}
+    x = Array{T,N}(undef, d.dims)
+    check(ccall((:mdsp_memcpy_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), x, d.ptr, sizeof(x), C_NULL))
+    x
+end
+todevice(x::DeviceArray, ::Type{T}) where {T} = eltype(x) == T ? x : upload(convert(Array{T}, download(x)))
+todevice(x::AbstractArray, ::Type{T}) where {T} = upload(convert(Array{T}, x))
+back(y::DeviceArray, like::DeviceArray) = y
+back(y::DeviceArray, like) = download(y)
+
+# ---------------------------------------------------------------------------------------------- index arithmetic
+nextfastfft(n::Integer) = Int(ccall((:mdsp_nextfastfft, lib), Int64, (Int64,), n))                       # util.jl:134
+optimalfftfiltlength(nb, nx) = Int(ccall((:mdsp_optimal_fft_len, lib), Int64, (Int64, Int64), nb, nx))  # dspbase.jl:268
+framecount(len, n, noverlap) = Int(ccall((:mdsp_frame_count, lib), Int64, (Int64, Int64, Int64), len, n, noverlap))
+outputlength(inlen::Integer, ratio::Union{Integer,Rational}, ϕ::Integer) =                                 # stream_filt.jl:317
+    Int(ccall((:mdsp_outputlength, lib), Int64, (Int64, Int64, Int64, Int64), inlen, numerator(ratio), denominator(ratio), ϕ))
+inputlength(outlen::Integer, ratio::Union{Integer,Rational}, ϕ::Integer, r::RoundingMode=RoundDown) =      # stream_filt.jl:358
+    Int(ccall((:mdsp_inputlength, lib), Int64, (Int64, Int64, Int64, Int64, Cint), outlen, numerator(ratio), denominator(ratio), ϕ,
+              (r == RoundUp || r == RoundFromZero) ? 1 : 0))
+
+const SMALL_FILT_CUTOFF = 66   # dspbase.jl:3
+
+# ---------------------------------------------------------------------------------------------- overlap-save filt / conv
+mutable struct OlsPlan
+    h::Ptr{Cvoid}
+    function OlsPlan(taps::Vector{T}, nfft::Integer, nx::Integer, mode::Integer, engine=ENGINE_AUTO) where {T}
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:mdsp_ols_plan_create, lib), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Cint, Cint),
+                    p, taps, length(taps), nfft, nx, mdtype(T), mode, engine))
+        o = new(p[])
+        finalizer(x -> ccall((:mdsp_ols_plan_destroy, lib), Cint, (Ptr{Cvoid},), x.h), o)
+        o
+    end
+end
+
+function olsexec(plan::OlsPlan, x::DeviceArray{T}, nout::Integer) where {T}
+    nx = size(x, 1); ncols = length(x) ÷ max(nx, 1)
+    y = DeviceArray{T}((nout, size(x)[2:end]...))
+    check(ccall((:mdsp_ols_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}),
+                plan.h, x.ptr, nx, ncols, nx, y.ptr, nout, nout, C_NULL))
+    y
+end
+
+# fftfilt(b, x[, nfft])   Filters/filt.jl:458-461, _fftfilt! :479-521
+function fftfilt(b::AbstractVector{H}, x::Union{AbstractArray{T},DeviceArray{T}},
+                 nfft::Integer=optimalfftfiltlength(length(b), length(x))) where {H<:Real,T<:Real}
+    W = fftintype(promote_type(H, T))
+    xd = todevice(x, W)
+    back(olsexec(OlsPlan(convert(Vector{W}, b), nfft, size(xd, 1), 0), xd, size(xd, 1)), x)
+end
+
+# filt(b, a::Number, x) / tdfilt   dspbase.jl:14-66 (FIR only on the device)
+function filt(b::AbstractVector, a::Number, x::Union{AbstractArray{T},DeviceArray{T}}) where {T}
+    isempty(b) && throw(ArgumentError("filter vector b must be non-empty"))
+    a == 0 && throw(ArgumentError("filter vector a[1] must be nonzero"))
+    W = fftintype(promote_type(eltype(b), typeof(a), T))
+    R = real(W)
+    taps = convert(Vector{R}, a == 1 ? b : b ./ a)
+    xd = todevice(x, W)
+    y = DeviceArray{W}(size(xd))
+    nx = size(xd, 1); ncols = length(xd) ÷ max(nx, 1)
+    check(ccall((:mdsp_tdfir_exec, lib), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                taps, length(taps), mdtype(W), xd.ptr, nx, ncols, nx, y.ptr, nx, C_NULL))
+    back(y, x)
+end
+tdfilt(h::AbstractVector{H}, x) where {H} = filt(h, one(H), x)                      # filt.jl:431
+
+# filt(b, x): FFT path for real taps longer than SMALL_FILT_CUTOFF, time domain otherwise   filt.jl:525-555
+function filt(b::AbstractVector{<:Real}, x::Union{AbstractArray{<:Real},DeviceArray{<:Real}})
+    length(b) > SMALL_FILT_CUTOFF ? fftfilt(b, x, optimalfftfiltlength(length(b), size(x, 1))) : tdfilt(b, x)
+end
+
+# conv(u, v; algorithm)   dspbase.jl:709-792 (vectors; :direct for small / integer inputs stays on the CPU)
+function conv(u::AbstractVector{Tu}, v::AbstractVector{Tv}; algorithm=:auto) where {Tu<:Number,Tv<:Number}
+    T = promote_type(Tu, Tv)
+    W = fftintype(T)
+    nu, nv = length(u), length(v)
+    alg = algorithm
+    alg === :auto && (alg = T <: Union{Float32,Float64,ComplexF32,ComplexF64} ? :fast : :direct)
+    alg === :fast && (alg = nu * nv < 2^16 ? :direct : :fft)
+    (alg === :direct || nu == 0 || nv == 0) && throw(UnsupportedError("direct convolution: use DSP.conv on the CPU"))
+    big, small = nu >= nv ? (u, v) : (v, u)
+    os = optimalfftfiltlength(length(small), length(big))
+    alg === :fft && (alg = os < nu + nv - 1 ? :fft_overlapsave : :fft_simple)
+    alg in (:fft_overlapsave, :fft_simple) ||
+        throw(ArgumentError("algorithm must be :auto, :fast, :direct, :fft, :fft_simple, or :fft_overlapsave"))
+    nfft = alg === :fft_simple ? nextfastfft(nu + nv - 1) : os
+    plan = OlsPlan(convert(Vector{W}, small), nfft, length(big), 1)
+    download(olsexec(plan, todevice(big, W), nu + nv - 1))
+end
+
+# ---------------------------------------------------------------------------------------------- periodograms
+compute_window(::Nothing, n::Int) = (nothing, Float64(n))                               # periodograms.jl:248-257
+function compute_window(window::Function, n::Int)
+    win = window(n)::Vector{Float64}
+    (win, sum(abs2, win))
+end
+function compute_window(window::AbstractVector, n::Int)
+    length(window) == n || throw(DimensionMismatch("length of window must match input"))
+    w = convert(Vector{Float64}, window)
+    (w, sum(abs2, w))
+end
+winptr(::Nothing) = Ptr{Float64}(C_NULL)
+winptr(w::Vector{Float64}) = pointer(w)
+
+struct WelchConfig                                                                        # periodograms.jl:516-587
+    h::Base.RefValue{Ptr{Cvoid}}
+    nsamples::Int; noverlap::Int; onesided::Bool; nfft::Int; fs::Float64
+    freq::AbstractVector; window; r::Float64; intype::DataType; nout::Int
+end
+function WelchConfig(nsamples, ::Type{T}; n::Int=nsamples >> 3, noverlap::Int=n >> 1, onesided::Bool=T <: Real,
+                     nfft::Int=nextfastfft(n), fs::Real=1, window=nothing, engine=ENGINE_AUTO) where {T}
+    onesided && T <: Complex && throw(ArgumentError("cannot compute one-sided FFT of a complex signal"))
+    nfft >= n || throw(DomainError((; nfft, n), "nfft must be >= n"))
+    win, norm2 = compute_window(window, n)
+    r = fs * norm2
+    S = fftintype(T)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve win check(ccall((:mdsp_welch_plan_create, lib), Cint,
+        (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ptr{Float64}, Cdouble, Cint, Cint, Cint),
+        p, n, noverlap, nfft, winptr(win), r, onesided, mdtype(S), engine))
+    nout = onesided ? (nfft >> 1) + 1 : nfft
+    freq = onesided ? (0:nfft>>1) .* (fs / nfft) : vcat(0:(nfft-1)>>1, -(nfft >> 1):-1) .* (fs / nfft)
+    cfg = WelchConfig(p, n, noverlap, onesided, nfft, fs, freq, win, r, S, nout)
+    finalizer(x -> ccall((:mdsp_welch_plan_destroy, lib), Cint, (Ptr{Cvoid},), x[]), p)
+    cfg
+end
+WelchConfig(data::AbstractArray; kw...) = WelchConfig(size(data, ndims(data)), eltype(data); kw...)
+
+# welch_pgram(s, config) -> (power, freq)   periodograms.jl:702-705, :746-759.  Columns of a matrix are channels.
+function welch_pgram(s::Union{AbstractVecOrMat{T},DeviceArray{T}}, config::WelchConfig) where {T<:Number}
+    fftintype(T) == config.intype ||
+        throw(ArgumentError("float(eltype(s)) = $T doesn't match the eltype of the input buffer: $(config.intype)."))
+    sd = todevice(s, config.intype)
+    len = size(sd, 1); nch = length(sd) ÷ max(len, 1)
+    out = DeviceArray{fftabs2type(config.intype)}(nch == 1 && length(size(sd)) == 1 ? (config.nout,) : (config.nout, nch))
+    check(ccall((:mdsp_welch_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                config.h[], sd.ptr, len, nch, len, out.ptr, config.nout, C_NULL))
+    (power = back(out, s), freq = config.freq)
+end
+welch_pgram(s::AbstractVector, n::Int=length(s) >> 3, noverlap::Int=n >> 1; kw...) =
+    welch_pgram(s, WelchConfig(s; n, noverlap, kw...))
+
+# stft / spectrogram / periodogram   periodograms.jl:872-897, :828-837, :393-417
+function stft(s::Union{AbstractVecOrMat{T},DeviceArray{T}}, n::Int=size(s, 1) >> 3, noverlap::Int=n >> 1, psdonly::Bool=false;
+              onesided::Bool=T <: Real, nfft::Int=nextfastfft(n), fs::Real=1, window=nothing, engine=ENGINE_AUTO) where {T}
+    onesided && T <: Complex && throw(ArgumentError("cannot compute one-sided FFT of a complex signal"))
+    win, norm2 = compute_window(window, n)
+    (0 ≤ noverlap < n) || throw(DomainError((; noverlap, n), "noverlap must be between zero and n"))
+    nfft >= n || throw(DomainError((; nfft, n), "nfft must be >= n"))
+    S = fftintype(T)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve win check(ccall((:mdsp_stft_plan_create, lib), Cint,
+        (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ptr{Float64}, Cdouble, Cint, Cint, Cint, Cint),
+        p, n, noverlap, nfft, winptr(win), fs * norm2, onesided, psdonly, mdtype(S), engine))
+    sd = todevice(s, S)
+    len = size(sd, 1); nch = length(sd) ÷ max(len, 1)
+    nout = onesided ? (nfft >> 1) + 1 : nfft
+    k = framecount(len, n, noverlap)
+    out = DeviceArray{psdonly ? fftabs2type(S) : fftouttype(S)}(nch == 1 ? (nout, k) : (nout, k, nch))
+    try
+        k > 0 && check(ccall((:mdsp_stft_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}),
+                             p[], sd.ptr, len, nch, len, out.ptr, nout, nout * k, C_NULL))
+    finally
+        ccall((:mdsp_stft_plan_destroy, lib), Cint, (Ptr{Cvoid},), p[])
+    end
+    back(out, s)
+end
+function spectrogram(s, n::Int=size(s, 1) >> 3, noverlap::Int=n >> 1; onesided::Bool=eltype(s) <: Real,
+                     nfft::Int=nextfastfft(n), fs::Real=1, window=nothing)
+    out = stft(s, n, noverlap, true; onesided, nfft, fs, window)
+    (power = out, freq = onesided ? (0:nfft>>1) .* (fs / nfft) : vcat(0:(nfft-1)>>1, -(nfft >> 1):-1) .* (fs / nfft),
+     time = (n / 2 : n - noverlap : (size(out, 2) - 1) * (n - noverlap) + n / 2) / fs)
+end
+function periodogram(s::AbstractVector{T}; onesided::Bool=T <: Real, nfft::Int=nextfastfft(length(s)), fs::Real=1, window=nothing) where {T}
+    nfft >= length(s) || throw(DomainError((; nfft, n=length(s)), "nfft must be >= n = length(s)"))
+    p = stft(s, length(s), 0, true; onesided, nfft, fs, window)
+    (power = vec(p), freq = onesided ? (0:nfft>>1) .* (fs / nfft) : vcat(0:(nfft-1)>>1, -(nfft >> 1):-1) .* (fs / nfft))
+end
+
+# ---------------------------------------------------------------------------------------------- FIRFilter / resample
+mutable struct FIRFilter                                                                 # stream_filt.jl:137-178
+    h::Ptr{Cvoid}
+    taps::Vector
+    ratio::Rational{Int}
+    xtype::DataType
+    nch::Int
+end
+function FIRFilter(taps::Vector{Th}, ratio::Union{Integer,Rational}=1; xtype::DataType=Th, nch::Integer=1) where {Th<:Union{Float32,Float64}}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    r = convert(Rational{Int}, ratio)
+    check(ccall((:mdsp_fir_create, lib), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Cint, Int64),
+                p, taps, length(taps), numerator(r), denominator(r), mdtype(Th), mdtype(xtype), nch))
+    f = FIRFilter(p[], taps, r, xtype, nch)
+    finalizer(x -> ccall((:mdsp_fir_destroy, lib), Cint, (Ptr{Cvoid},), x.h), f)
+    f
+end
+reset!(f::FIRFilter) = (check(ccall((:mdsp_fir_reset, lib), Cint, (Ptr{Cvoid},), f.h)); f)               # :247-276
+setphase!(f::FIRFilter, ϕ::Real) = check(ccall((:mdsp_fir_setphase, lib), Cint, (Ptr{Cvoid}, Cdouble), f.h, ϕ))  # :216-229
+function timedelay(f::FIRFilter)                                                                           # :400-403
+    τ = Ref{Cdouble}(0)
+    check(ccall((:mdsp_fir_timedelay, lib), Cint, (Ptr{Cvoid}, Ref{Cdouble}), f.h, τ)); τ[]
+end
+function outputlength(f::FIRFilter, inlen::Integer)                                                        # :324-338
+    o = Ref{Int64}(0)
+    check(ccall((:mdsp_fir_outputlength, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Int64}), f.h, inlen, o)); Int(o[])
+end
+function inputlength(f::FIRFilter, outlen::Integer, r::RoundingMode=RoundDown)                             # :366-383
+    o = Ref{Int64}(0)
+    check(ccall((:mdsp_fir_inputlength, lib), Cint, (Ptr{Cvoid}, Int64, Cint, Ref{Int64}), f.h, outlen,
+                (r == RoundUp || r == RoundFromZero) ? 1 : 0, o)); Int(o[])
+end
+
+# filt(f, x): next chunk, state carried on the device   stream_filt.jl:627-637
+function filt(f::FIRFilter, x::Union{AbstractVecOrMat,DeviceArray})
+    xd = todevice(x, f.xtype)
+    xlen = size(xd, 1)
+    ycap = max(outputlength(f, xlen), 0)
+    Ty = promote_type(eltype(f.taps), f.xtype)
+    y = DeviceArray{Ty}(f.nch == 1 ? (ycap,) : (ycap, f.nch))
+    nw = Ref{Int64}(0)
+    check(ccall((:mdsp_fir_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ref{Int64}, Ptr{Cvoid}),
+                f.h, xd.ptr, xlen, xlen, y.ptr, ycap, max(ycap, 1), nw, C_NULL))
+    nw[] == ycap || throw(AssertionError("Length of resampled output different from expectation."))
+    back(y, x)
+end
+
+# resample(x, rate, h)   stream_filt.jl:688-725 (vector) / :747-775 (array, dims = 1: columns are channels)
+function resample(x::AbstractVecOrMat{T}, rate::Union{Integer,Rational}, h::Vector) where {T}
+    S = fftintype(T)
+    nch = size(x, 2)
+    f = FIRFilter(convert(Vector{real(promote_type(eltype(h), S)) == Float32 ? Float32 : Float64}, h), rate; xtype=S, nch)
+    rate == 1 || setphase!(f, timedelay(f))                              # undelay!, :706-714
+    outLen = ceil(Int, size(x, 1) * rate)
+    npad = inputlength(f, outLen, RoundUp)
+    xp = zeros(S, npad, nch); xp[1:size(x, 1), :] .= x                   # _zeropad, :699
+    y = filt(f, ndims(x) == 1 ? vec(xp) : xp)
+    size(y, 1) >= outLen || throw(AssertionError("Resample output shorter than expected."))
+    ndims(x) == 1 ? y[1:outLen] : y[1:outLen, :]
+end
+
+end # module
