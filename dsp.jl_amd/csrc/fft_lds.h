@@ -19,6 +19,13 @@
 #else
 #define MDSP_HD inline
 #endif
+// Make a per-lane integer opaque to the optimiser (device only).  Used to stop LICM from hoisting the LDS twiddle
+// reads of a persistent loop into ~40 extra VGPRs -- the point of the LDS table is to NOT hold them in registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MDSP_OPAQUE_INT(x) asm volatile("" : "+v"(x))
+#else
+#define MDSP_OPAQUE_INT(x) (void)(x)
+#endif
 
 namespace mdsp {
 namespace fft {
@@ -140,7 +147,27 @@ template <int N_, int E_> struct Cfg {
     static constexpr int ntw(int p) { return p == 0 ? 0 : E - E / radix(p); }
     static constexpr int twoff(int p) { return p == 0 ? 0 : twoff(p - 1) + ntw(p - 1); }
     static constexpr int NTW = twoff(P - 1) + ntw(P - 1);
+    // LDS-resident twiddle table (TWMODE 2): pass p >= 1 stores W^{r k stride_p} at  ldsoff(p) + (r-1)*ns(p) + k,
+    // r = 1..radix(p)-1, k = 0..ns(p)-1  (k contiguous: conflict-free reads, r and b become immediate offsets)
+    static constexpr int ldstw(int p) { return p == 0 ? 0 : (radix(p) - 1) * ns(p); }
+    static constexpr int ldsoff(int p) { return p <= 1 ? 0 : ldsoff(p - 1) + ldstw(p - 1); }
+    static constexpr int NTWLDS = P <= 1 ? 1 : ldsoff(P - 1) + ldstw(P - 1);
 };
+
+// twiddle sources
+enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
+
+// Fill the LDS twiddle table cooperatively (T threads of one transform; callers sync afterwards).
+template <typename C, typename R, int PASS = 1> MDSP_HD void fill_lds_twiddles(cx<R>* twl, int t, const cx<R>* table) {
+    if constexpr (PASS < C::P) {
+        constexpr int Ns = C::ns(PASS), Rdx = C::radix(PASS);
+        for (int idx = t; idx < (Rdx - 1) * Ns; idx += C::T) {
+            const int r = idx / Ns + 1, k = idx - (r - 1) * Ns;
+            twl[C::ldsoff(PASS) + idx] = table[(r * k * (C::N / (Ns * Rdx))) & (C::N - 1)];
+        }
+        fill_lds_twiddles<C, R, PASS + 1>(twl, t, table);
+    }
+}
 
 // LDS index padding: one extra element every 2^PADSHIFT elements (PADSHIFT >= 31 disables it)
 template <int PADSHIFT> MDSP_HD int lds_pad(int i) {
@@ -176,7 +203,7 @@ template <typename C, typename R, int PASS = 1> MDSP_HD void load_twiddles(cx<R>
 
 // One Stockham pass on the thread's registers.  Non-final passes scatter their results to `lds`
 // (this transform's region); the final pass leaves X[t + T*e] in x[e].
-template <typename C, int DIR, int PASS, bool TWREG, int PADSHIFT, typename R>
+template <typename C, int DIR, int PASS, int TWMODE, int PADSHIFT, typename R>
 MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], const cx<R>* table, cx<R>* lds) {
     constexpr int Rdx = C::radix(PASS), NB = C::E / Rdx, Ns = C::ns(PASS);
     constexpr bool LAST = PASS == C::P - 1;
@@ -186,9 +213,18 @@ MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 
 #pragma unroll
         for (int r = 0; r < Rdx; ++r) v[r] = x[b + r * NB];
         if constexpr (PASS > 0) {
+            [[maybe_unused]] int kt = (Ns > C::T) ? t : (t & (Ns - 1));   // TW_LDS: k = kt + (T*b mod Ns), see below
+            if constexpr (TWMODE == TW_LDS) MDSP_OPAQUE_INT(kt);
 #pragma unroll
             for (int r = 1; r < Rdx; ++r) {
-                const cx<R> w = TWREG ? tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)] : table[tw_index<C, PASS>(t, b, r)];
+                cx<R> w;
+                if constexpr (TWMODE == TW_REG) w = tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)];
+                else if constexpr (TWMODE == TW_LDS) {
+                    // `table` points at the LDS twiddle table.  k = (t + T*b) mod Ns = kt + KB with kt = t mod Ns (or t when
+                    // Ns > T) and KB = (T*b) mod Ns a compile-time constant (no carry: KB is a multiple of T, kt < T).
+                    const int KB = (C::T * b) & (Ns - 1);   // constant after unrolling
+                    w = table[kt + (C::ldsoff(PASS) + (r - 1) * Ns + KB)];
+                } else w = table[tw_index<C, PASS>(t, b, r)];
                 v[r] = twmul<DIR>(v[r], w);
             }
         }

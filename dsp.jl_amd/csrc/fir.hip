@@ -20,6 +20,7 @@
 #include <numeric>
 
 #include "common.h"
+#include "devio.h"
 #include "fft_lds.h"
 
 using namespace mdsp;
@@ -112,6 +113,115 @@ __global__ __launch_bounds__(256) void shiftin_kernel(const XS* __restrict__ x, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fast path (Float32 taps and real Float32 signal, tapsPerPhase <= 64): "a thread owns P consecutive output residues".
+//
+// Outputs m = q*L + s (round q, residue s) all use phase phi_s = (phi0-1 + s*M) mod L and the z-window that starts at
+// q*M + c_s,  c_s = d0-1 + (phi0-1 + s*M) div L  -- both independent of q.  So a thread keeps the taps of its P residues
+// in registers for the whole kernel, pre-shifted by delta_k = c_{s+k} - c_s (0 <= delta_k <= P-1 when M <= L), and per
+// round reads ONE window of W = TPC+P-1 samples from LDS for its P outputs:  LDS reads per output drop from 2*tp
+// (generic kernel: tap + sample) to W/P, and the FMA chain keeps the oldest-sample-first order.
+// ------------------------------------------------------------------------------------------------------------
+struct FirFastArgs {
+    const float* x;
+    const float* hist;
+    float* y;
+    const float* pfbT;   // tp * L
+    int64_t xlen, ldx, ldy, nout, nrounds;
+    int64_t phi0m1, d0;
+    int L, M, tp, hl;
+    int Q;               // rounds per tile
+    int NP, RL;          // phase groups, round lanes (blockDim.x = NP * RL)
+    int span;            // LDS floats per tile
+};
+
+template <int TPC, int P>
+__global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
+    constexpr int W = TPC + P - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* zs = reinterpret_cast<float*>(smem);
+    const int64_t ch = blockIdx.y;
+    const int g = threadIdx.x % a.NP, r = threadIdx.x / a.NP;
+    const float* xc = a.x + ch * a.ldx;
+    const float* hc = a.hist + ch * (int64_t)a.hl;
+    float* yc = a.y + ch * a.ldy;
+    // per-thread constants: offsets c_k (relative to c of residue 0 of the tile), shifted taps
+    const int s0 = g * P;
+    int coff[P];
+    bool valid[P];
+    float h[P][W];
+    const int64_t cbase = a.d0 - 1;   // c_s = cbase + (phi0m1 + s*M) div L
+    int c0rel = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int s = s0 + k;
+        valid[k] = s < a.L;
+        const int64_t p = a.phi0m1 + (int64_t)(valid[k] ? s : 0) * a.M;
+        const int phi = (int)(p % a.L);
+        const int crel = (int)(p / a.L);           // c_s - cbase
+        if (k == 0) c0rel = crel;
+        const int delta = valid[k] ? crel - c0rel : 0;   // 0..P-1 (M <= L)
+        coff[k] = delta;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int i = j - delta;
+            h[k][j] = (valid[k] && i >= 0 && i < a.tp) ? a.pfbT[(int64_t)i * a.L + phi] : 0.0f;
+        }
+    }
+    (void)coff;
+    const int64_t ntiles = (a.nrounds + a.Q - 1) / a.Q;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t q0 = tile * a.Q;
+        const int nq = (int)std::min<int64_t>(a.Q, a.nrounds - q0);
+        // z range of the tile: [q0*M + cbase, q0*M + cbase + nq*M + M + W)
+        const int64_t z0 = q0 * a.M + cbase;
+        const int nz = nq * a.M + a.M + W;
+        __syncthreads();   // previous tile fully consumed
+        if (z0 >= a.hl) {
+            // steady state: the tile lies inside x.  Descriptor re-based at the tile start (hardware zero fill past the end
+            // of the signal); 8 independent coalesced loads in flight per thread before the LDS writes.
+            const float* src = xc + (z0 - a.hl);
+            const __amdgpu_buffer_rsrc_t rs = io::make_rsrc(src, (a.xlen - (z0 - a.hl)) * 4);
+            const int step = blockDim.x;
+            for (int k2 = threadIdx.x; k2 < nz; k2 += 8 * step) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = io::Ld<float>::load(rs, (k2 + u * step) * 4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k2 + u * step < nz) zs[k2 + u * step] = v[u];
+            }
+        } else {  // the first tile(s) straddle the history
+            for (int k2 = threadIdx.x; k2 < nz; k2 += blockDim.x) {
+                const int64_t zi = z0 + k2;
+                float v = 0.0f;
+                if (zi < a.hl) v = hc[zi];
+                else if (zi - a.hl < a.xlen) v = xc[zi - a.hl];
+                zs[k2] = v;
+            }
+        }
+        __syncthreads();
+        if (valid[0]) {
+            for (int q = r; q < nq; q += a.RL) {
+                const float* zp = zs + q * a.M + c0rel;
+                float acc[P];
+#pragma unroll
+                for (int k = 0; k < P; ++k) acc[k] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const float xv = zp[j];
+#pragma unroll
+                    for (int k = 0; k < P; ++k) acc[k] = fmaf(xv, h[k][j], acc[k]);
+                }
+                const int64_t m = (q0 + q) * a.L + s0;
+#pragma unroll
+                for (int k = 0; k < P; ++k)
+                    if (valid[k] && m + k < a.nout) yc[m + k] = acc[k];
+            }
+        }
+    }
+}
+
 int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 
 }  // namespace
@@ -153,7 +263,64 @@ template <typename XS, typename A, typename R> int fir_launch(mdsp_fir_s* f, Fir
     return MDSP_OK;
 }
 
+template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
+    FirFastArgs b{};
+    b.x = (const float*)a.x;
+    b.hist = (const float*)a.hist;
+    b.y = (float*)a.y;
+    b.pfbT = (const float*)a.pfbT;
+    b.xlen = a.xlen; b.ldx = a.ldx; b.ldy = a.ldy; b.nout = a.nout;
+    b.phi0m1 = a.phi0m1; b.d0 = a.d0;
+    b.L = a.L; b.M = a.M; b.tp = a.tp; b.hl = a.hl;
+    b.nrounds = cdiv(a.nout, (int64_t)a.L);
+    b.NP = (int)cdiv(a.L, P);
+    b.RL = std::max(1, 256 / b.NP);
+    // rounds per tile: LDS budget ~48 KiB, at least RL rounds
+    int lds_kib = 20;
+    if (const char* e = getenv("MDSP_FIR_LDS_KIB")) lds_kib = std::max(4, atoi(e));
+    int Q = (int)std::max<int64_t>(b.RL, ((int64_t)lds_kib * 1024 / 4 - a.M - (TPC + P)) / std::max(1, a.M));
+    Q = std::min(Q, 512);
+    Q = (int)std::min<int64_t>(Q, std::max<int64_t>(b.nrounds, 1));
+    b.Q = Q;
+    b.span = Q * a.M + a.M + TPC + P;
+    const size_t lds_bytes = (size_t)b.span * sizeof(float);
+    auto kern = polyphase_fast_kernel<TPC, P>;
+    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const int64_t ntiles = cdiv(b.nrounds, (int64_t)Q);
+    int wgs = 8;   // measured best on MI355X (profiles/r01c_rows.json): 8 workgroups of ~20 KiB LDS per CU
+    if (const char* e = getenv("MDSP_WG_PER_CU")) wgs = std::max(1, atoi(e));
+    const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
+    const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)f->nch);
+    hipLaunchKernelGGL(kern, grid, dim3(b.NP * b.RL), lds_bytes, st, b);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+// Fast path applies to Float32 taps x real Float32 signal with <= 64 taps per phase and <= 1024 phase groups.
+bool fir_fast_ok(const mdsp_fir_s* f, int P) {
+    if (f->acc_double || f->x_dtype != MDSP_F32 || f->tp > 64) return false;
+    if (getenv("MDSP_FIR_GENERIC")) return false;
+    if (P == 2 && (f->M > f->L || f->L < 2)) return false;
+    return cdiv(f->L, P) <= 256;
+}
+
+template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
+    const int tpc = (int)((f->tp + 7) / 8 * 8);
+    switch (tpc) {
+        case 8: return fir_fast_launch<8, P>(f, a, st);
+        case 16: return fir_fast_launch<16, P>(f, a, st);
+        case 24: return fir_fast_launch<24, P>(f, a, st);
+        case 32: return fir_fast_launch<32, P>(f, a, st);
+        case 40: return fir_fast_launch<40, P>(f, a, st);
+        case 48: return fir_fast_launch<48, P>(f, a, st);
+        case 56: return fir_fast_launch<56, P>(f, a, st);
+        default: return fir_fast_launch<64, P>(f, a, st);
+    }
+}
+
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
+    if (fir_fast_ok(f, 2)) return fir_fast_dispatch<2>(f, a, st);
+    if (fir_fast_ok(f, 1)) return fir_fast_dispatch<1>(f, a, st);
     const bool d = f->acc_double;
     switch (f->x_dtype) {
         case MDSP_F32: return d ? fir_launch<float, double, double>(f, a, st) : fir_launch<float, float, float>(f, a, st);

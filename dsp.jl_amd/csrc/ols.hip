@@ -92,6 +92,7 @@ struct OlsFusedArgs {
     int nb;
     int64_t run_len;        // a slot takes runs of run_len consecutive units ...
     int64_t niter;          // ... runs_per_slot * run_len iterations in total (same for every slot)
+    int ablate;             // profiling aid (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip stores
 };
 
 // Raw samples of one unit as they come from HBM: two real blocks (a, b) or one complex block.
@@ -172,7 +173,7 @@ __device__ __forceinline__ void ols_store(const cx<R> (&v)[E], const OlsFusedArg
     }
 }
 
-template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true>
 __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedArgs a) {
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T;
@@ -186,10 +187,14 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
 
     cx<R> tw[NTWA];
-    if constexpr (TWREG) fft::load_twiddles<C, R>(tw, t, table);
-    cx<R> Hr[E];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_LDS ? C::NTWLDS : 1];
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
+    cx<R> Hr[HREG ? E : 1];
+    if constexpr (HREG) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) Hr[e] = static_cast<const cx<R>*>(a.H)[t + T * e];
+        for (int e = 0; e < E; ++e) Hr[e] = static_cast<const cx<R>*>(a.H)[t + T * e];
+    }
+    const __amdgpu_buffer_rsrc_t hrsrc = io::make_rsrc(a.H, (int64_t)N * (int64_t)sizeof(cx<R>));
 
     const int64_t nslots = (int64_t)gridDim.x * G;
     OlsWalk walk{((int64_t)blockIdx.x * G + slot) * a.run_len, 0};
@@ -199,7 +204,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     for (int64_t it = 0; it < a.niter; ++it) {   // same trip count for every slot (barriers inside)
         ols_walk_next(walk, a.run_len, nslots);
         const OlsPos nxt = ols_pos(a, walk, it + 1 < a.niter);
-        if constexpr (!PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, t);
+        if constexpr (!PREFETCH) { if (!(a.ablate & 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, t); }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -207,16 +212,25 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
             else v[e] = {raw.a[e], raw.b[e]};
         }
         // next unit's samples start streaming from HBM while this unit is transformed
-        if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, nxt, t);
-        fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
+        if constexpr (PREFETCH) { if (!(a.ablate & 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, nxt, t); }
+        if (!(a.ablate & 2)) {
+        fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
         // spectral multiply (K2): natural order in registers
+        if constexpr (HREG) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = fft::cmul(v[e], Hr[e]);
+            for (int e = 0; e < E; ++e) v[e] = fft::cmul(v[e], Hr[e]);
+        } else {  // spectrum streamed from L2 (16 KiB, always resident) instead of living in 2E VGPRs
+            cx<R> hh[E];
+            io::load_window<cx<R>, E, T>(hh, hrsrc, 0, t);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = fft::cmul(v[e], hh[e]);
+        }
         // inverse transform (unnormalised, like plan_brfft / inv(p).p)
-        fft::wg_fft<C, +1, TWREG, PADSHIFT, NBUF, (C::P - 1) % NBUF>(v, t, tw, table, lds);
+        fft::wg_fft<C, +1, TWMODE, PADSHIFT, NBUF, (C::P - 1) % NBUF>(v, t, tw, twsrc, lds);
+        }
         // single buffer: the next iteration's first pass rewrites LDS that slower waves may still be reading
         if constexpr (C::P > 1 && NBUF == 1) fft::wg_sync<T>();
-        ols_store<R, E, T, CPLX>(v, a, cur, t);
+        if (!(a.ablate & 4)) ols_store<R, E, T, CPLX>(v, a, cur, t);
         cur = nxt;
     }
 }
@@ -270,9 +284,9 @@ template <typename R> int upload_table(DevBuf& buf, int64_t n) {
 }
 
 // ---- fused launch ---------------------------------------------------------------------------------------
-template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true, bool HREG = true>
 int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
-    auto kern = ols_fused_kernel<R, N, E, G, TWREG, PADSHIFT, CPLX, MINW, NBUF, PREFETCH>;
+    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG>;
     constexpr int threads = (N / E) * G;
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
@@ -301,22 +315,26 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
     constexpr int T = N / E;
     constexpr int G = T >= 256 ? 1 : 256 / T;
     constexpr int NBUF = T <= 64 ? 1 : 2;
-    constexpr bool TWREG = !DBL;
+    constexpr int TWREG = DBL ? 0 : 1;
     if constexpr (N == 2048 && !CPLX && !DBL) {
         switch (variant) {
-            //                                    R  N   E  G  TWREG PAD CPLX MINW NBUF PREFETCH
-            case 1: return launch_fused_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, true>(a, s);
-            case 2: return launch_fused_variant<R, N, 16, 2, false, 4, CPLX, 2, 2, true>(a, s);
-            case 3: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 3, 2, true>(a, s);
-            case 4: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 4, 2, true>(a, s);
-            case 5: return launch_fused_variant<R, N, 8, 1, false, 4, CPLX, 4, 2, true>(a, s);
-            case 6: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 2, 1, true>(a, s);
-            case 7: return launch_fused_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, false>(a, s);
-            case 8: return launch_fused_variant<R, N, 8, 1, true, 3, CPLX, 2, 2, true>(a, s);
-            case 9: return launch_fused_variant<R, N, 8, 1, true, 5, CPLX, 2, 2, true>(a, s);
-            case 10: return launch_fused_variant<R, N, 8, 1, true, 31, CPLX, 2, 2, true>(a, s);
-            case 11: return launch_fused_variant<R, N, 8, 1, false, 4, CPLX, 4, 1, false>(a, s);
-            case 12: return launch_fused_variant<R, N, 8, 1, false, 4, CPLX, 2, 2, true>(a, s);
+            //                                    R  N   E  G  TW PAD CPLX MINW NBUF PREFETCH     (TW: 0 global, 1 regs, 2 LDS)
+            case 1: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 2, 2, true>(a, s);
+            case 2: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 3, 2, true>(a, s);
+            case 3: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 4, 1, true>(a, s);
+            case 4: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 4, 1, false>(a, s);
+            case 5: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 3, 1, true>(a, s);
+            case 6: return launch_fused_variant<R, N, 8, 1, 1, 4, CPLX, 3, 2, true>(a, s);
+            case 7: return launch_fused_variant<R, N, 8, 1, 1, 3, CPLX, 2, 2, true>(a, s);
+            case 8: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true>(a, s);
+            case 9: return launch_fused_variant<R, N, 16, 1, 2, 4, CPLX, 2, 2, true>(a, s);
+            case 10: return launch_fused_variant<R, N, 16, 1, 2, 4, CPLX, 3, 2, true>(a, s);
+            case 11: return launch_fused_variant<R, N, 16, 2, 2, 4, CPLX, 2, 2, true>(a, s);
+            case 12: return launch_fused_variant<R, N, 16, 2, 2, 4, CPLX, 2, 1, true>(a, s);
+            case 13: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true>(a, s);
+            case 14: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, false>(a, s);
+            case 15: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true, false>(a, s);
+            case 16: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, false>(a, s);
             default: break;
         }
     }
@@ -503,6 +521,8 @@ int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t nco
     a.nunits = a.units_per_col * ncols;
     a.run_len = 1;
     a.niter = 0;
+    a.ablate = 0;
+    if (const char* e = getenv("MDSP_ABLATE")) a.ablate = atoi(e);
     if (cplx) return dbl ? launch_fused<double, true>(plan->nfft, a, plan->variant, s) : launch_fused<float, true>(plan->nfft, a, plan->variant, s);
     return dbl ? launch_fused<double, false>(plan->nfft, a, plan->variant, s) : launch_fused<float, false>(plan->nfft, a, plan->variant, s);
 }

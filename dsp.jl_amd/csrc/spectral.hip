@@ -178,6 +178,7 @@ struct SpecArgs {
     int64_t ldo, chs;      // STFT output strides
     int n, nout, onesided;
     int64_t run_len, niter;  // unit schedule: runs of run_len consecutive units per slot, niter iterations per slot
+    int ablate;              // profiling aid (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip accumulate/stores
     double r;
 };
 
@@ -191,7 +192,7 @@ template <int E, int T> __device__ __forceinline__ void load_window_regs(double 
 }
 
 // ---- Welch ------------------------------------------------------------------------------------------------
-template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
 __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs a) {
     using C = fft::Cfg<N, E>;
     using TT = std::conditional_t<CPLX, cx<R>, R>;
@@ -208,7 +209,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
     const int64_t ch = blockIdx.y;
 
     cx<R> tw[NTWA];
-    if constexpr (TWREG) fft::load_twiddles<C, R>(tw, t, table);
+    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_LDS ? C::NTWLDS : 1];
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
     std::conditional_t<WIN64, double, R> w[E];
     {
         double wd[E];
@@ -255,7 +257,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
     for (int64_t it = 0; it < niter; ++it) {
         walk();
         const int64_t unext = unit_cur(it + 1 < niter);
-        if constexpr (!PREFETCH) issue(u);
+        if constexpr (!PREFETCH) { if (!(a.ablate & 1)) issue(u); }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -267,14 +269,17 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
                 else v[e] = {ra[e] * w[e], rb[e] * w[e]};
             }
         }
-        if constexpr (PREFETCH) issue(unext);
+        if constexpr (PREFETCH) { if (!(a.ablate & 1)) issue(unext); }
         u = unext;
-        fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
+        if (!(a.ablate & 2))
+        fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
         // an odd number of exchanges per iteration would re-enter on the buffer that was used last: fence it
         if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
         // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
+        if (!(a.ablate & 4)) {
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] += (double)(v[e].x * v[e].x + v[e].y * v[e].y);
+        }
     }
     // partial[(blockIdx.x*G + slot)][ch][k]
     double* part = static_cast<double*>(a.out) + (((int64_t)blockIdx.x * G + slot) * a.nch + ch) * N;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
 
 // ---- STFT / spectrogram -------------------------------------------------------------------------------------
 // One frame per transform slot (real frames ride with a zero imaginary part).
-template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, bool PSD, int MINW, int NBUF, bool PREFETCH>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, bool PSD, int MINW, int NBUF, bool PREFETCH>
 __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs a) {
     using C = fft::Cfg<N, E>;
     using TT = std::conditional_t<CPLX, cx<R>, R>;
@@ -301,7 +306,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
     const int64_t ch = blockIdx.y;
 
     cx<R> tw[NTWA];
-    if constexpr (TWREG) fft::load_twiddles<C, R>(tw, t, table);
+    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_LDS ? C::NTWLDS : 1];
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
     double w[E];
     load_window_regs<E, T>(w, a.win, a.n, t);
     const bool havewin = a.win != nullptr;
@@ -340,7 +346,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
             else v[e] = {havewin ? win_mul(ra[e], w[e]) : ra[e], (R)0};
         }
         if constexpr (PREFETCH) issue(fcur);
-        fft::wg_fft<C, -1, TWREG, PADSHIFT, NBUF, 0>(v, t, tw, table, lds);
+        fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
         if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
         // column store: bins k = t + T*e < nout, contiguous across lanes
         const bool live = f < a.K;
@@ -414,11 +420,13 @@ template <typename R, int N> struct Geo {
     static constexpr int T = N / E;
     static constexpr int G = T >= 256 ? 1 : 256 / T;
     static constexpr int NBUF = T <= 64 ? 1 : 2;
-    static constexpr bool TWREG = !DBL;
+    static constexpr int TWREG = DBL ? 0 : 1;
 };
 
 // runs of consecutive units per slot (default: one run = fully contiguous), identical trip count for every slot
 void set_schedule(SpecArgs& a, int64_t nunits, int64_t nslots) {
+    a.ablate = 0;
+    if (const char* e = getenv("MDSP_ABLATE")) a.ablate = atoi(e);
     int64_t runs = 1;
     if (const char* e = getenv("MDSP_RUNS_PER_SLOT")) runs = std::max(1, atoi(e));
     a.run_len = std::max<int64_t>(1, cdiv(nunits, nslots * runs));
@@ -539,9 +547,9 @@ int welch_exec_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t
     return MDSP_OK;
 }
 
-template <typename R, int N, int E, int G, bool TWREG, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
 int welch_run_variant(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
-    auto kern = welch_fused_kernel<R, N, E, G, TWREG, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, WIN64>;
+    auto kern = welch_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, WIN64>;
     constexpr int threads = (N / E) * G;
     int grid = 1;
     MDSP_TRY(grid_for(kern, threads, cdiv(a.units_per_ch, G), a.nch, &grid));
@@ -560,17 +568,18 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
     int nslices = 0, rc;
     if constexpr (N == 4096 && !CPLX && sizeof(R) == 4) {
         switch (pl->variant) {  // tuning alternatives (MDSP_WELCH_VARIANT), built for the headline shape only
-            //                                  R  N   E  G TWREG PAD CPLX MINW NBUF PREF WIN64
-            case 1: rc = welch_run_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
-            case 2: rc = welch_run_variant<R, N, 16, 1, true, 4, CPLX, 2, 2, false, true>(pl, a, st, &nslices); break;
-            case 3: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
-            case 4: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, false, true>(pl, a, st, &nslices); break;
-            case 5: rc = welch_run_variant<R, N, 8, 1, false, 4, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
-            case 6: rc = welch_run_variant<R, N, 8, 1, true, 3, CPLX, 2, 2, true, true>(pl, a, st, &nslices); break;
-            case 7: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 1, true, true>(pl, a, st, &nslices); break;
-            case 8: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 4, 1, true, true>(pl, a, st, &nslices); break;
-            case 9: rc = welch_run_variant<R, N, 8, 1, false, 4, CPLX, 4, 1, false, true>(pl, a, st, &nslices); break;
-            default: rc = welch_run_variant<R, N, 8, 1, true, 4, CPLX, 2, 2, true, false>(pl, a, st, &nslices); break;
+            //                                  R  N   E  G TW PAD CPLX MINW NBUF PREF WIN64      (TW: 0 global, 1 regs, 2 LDS)
+            case 1: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 2, true, false>(pl, a, st, &nslices); break;
+            case 2: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 2, false, false>(pl, a, st, &nslices); break;
+            case 3: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, false>(pl, a, st, &nslices); break;
+            case 4: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, false, false>(pl, a, st, &nslices); break;
+            case 5: rc = welch_run_variant<R, N, 16, 1, 2, 4, CPLX, 2, 1, true, false>(pl, a, st, &nslices); break;
+            case 6: rc = welch_run_variant<R, N, 16, 1, 2, 4, CPLX, 2, 1, false, false>(pl, a, st, &nslices); break;
+            case 7: rc = welch_run_variant<R, N, 16, 1, 1, 5, CPLX, 2, 2, false, false>(pl, a, st, &nslices); break;
+            case 8: rc = welch_run_variant<R, N, 8, 1, 1, 4, CPLX, 4, 2, false, false>(pl, a, st, &nslices); break;
+            case 9: rc = welch_run_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, false, false>(pl, a, st, &nslices); break;
+            case 10: rc = welch_run_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, true, false>(pl, a, st, &nslices); break;
+            default: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, false>(pl, a, st, &nslices); break;
         }
     } else {
         rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, 4, CPLX, 2, Gm::NBUF, true, sizeof(R) == 8>(pl, a, st, &nslices);

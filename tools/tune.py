@@ -102,6 +102,15 @@ for w in os.environ.get("TUNE_WGS", "1,2,4").split(","):
                                           "welch_GBps": round(4.0 * n / (min(tw) * 1e-3) / 1e9, 1)}
         print("knobs wg", w, "runs_per_slot", c, res["knobs"][f"wg{w}_chunk{c}"])
 del os.environ["MDSP_WG_PER_CU"]; del os.environ["MDSP_RUNS_PER_SLOT"]
+# ---- ablations (MDSP_ABLATE: 1 no loads, 2 no transforms, 4 no stores/accumulate) ----
+res["ablate"] = {}
+for ab in os.environ.get("TUNE_ABLATE", "0,1,2,4,3,6,5,7").split(","):
+    os.environ["MDSP_ABLATE"] = ab
+    to = [timeit(lambda: _lib.check(lib.mdsp_ols_exec(p0._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream))) for _ in range(rounds)]
+    tw = [timeit(lambda: _lib.check(lib.mdsp_welch_exec(c0._h, x.data_ptr(), n, 1, n, psd.data_ptr(), 2049, stream))) for _ in range(rounds)]
+    res["ablate"][ab] = {"ols_ms": round(min(to), 4), "welch_ms": round(min(tw), 4)}
+    print("ablate", ab, res["ablate"][ab])
+os.environ["MDSP_ABLATE"] = "0"
 # ---- copy yardstick ----
 cms = [timeit(lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))) for _ in range(5)]
 res["copy_GBps"] = round(2 * 4.0 * n / (min(cms) * 1e-3) / 1e9, 1)
