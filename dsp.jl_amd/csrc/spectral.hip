@@ -547,6 +547,121 @@ int welch_exec_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t
     return MDSP_OK;
 }
 
+// ---- Welch, real input, n == nfft, 50 % overlap (the default `noverlap = n >> 1` and BASELINE config 3) -----------
+// With hop = N/2 the second half of frame a IS the first half of frame b, and the second half of frame b IS the first
+// half of the next unit's frame a.  A slot that walks consecutive units therefore loads every sample exactly ONCE:
+// E loads per thread per unit instead of 2E, and 3E/2 instead of 2E prefetch registers.
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF>
+__global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs a) {
+    using C = fft::Cfg<N, E>;
+    constexpr int T = C::T;
+    constexpr int H = E / 2;
+    static_assert(T % 64 == 0 && E % 2 == 0, "geometry");
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
+    constexpr int64_t SZ = (int64_t)sizeof(R);
+    __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
+    const int t = threadIdx.x % T;
+    const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));
+    cx<R>* lds = lds_all + slot * REGION;
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    const int64_t ch = blockIdx.y;
+
+    cx<R> tw[NTWA];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_LDS ? C::NTWLDS : 1];
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
+    R w[E];
+    {
+        double wd[E];
+        load_window_regs<E, T>(wd, a.win, a.n, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) w[e] = (R)wd[e];
+    }
+    double acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.0;
+
+    const R* sc = static_cast<const R*>(a.s) + ch * a.lds_;
+    const int64_t nslots = (int64_t)gridDim.x * G;
+    int64_t wbase = ((int64_t)blockIdx.x * G + slot) * a.run_len, wj = 0;
+    auto unit_cur = [&](bool more) { return (more && wbase + wj < a.units_per_ch) ? wbase + wj : a.units_per_ch; };
+    auto walk = [&]() {
+        if (++wj == a.run_len) {
+            wj = 0;
+            wbase += nslots * a.run_len;
+        }
+    };
+    const int64_t niter = a.niter;
+    // half-frame h of unit u starts at sample u*N + h*(N/2), h = 0 (a lo), 1 (a hi = b lo), 2 (b hi)
+    auto load_half = [&](R (&dst)[H], int64_t u, int h, bool on) {
+        const int64_t pos = u * N + (int64_t)h * (N / 2);
+        const __amdgpu_buffer_rsrc_t r = io::make_rsrc(sc + pos, on ? std::min<int64_t>(N / 2, a.len - pos) * SZ : 0);
+        io::load_window<R, H, T>(dst, r, 0, t);
+    };
+    R lo[H], ahi[H], bhi[H];
+    int64_t u = unit_cur(niter > 0);
+    {
+        const bool live = u < a.units_per_ch;
+        load_half(lo, u, 0, live);
+        load_half(ahi, u, 1, live);
+        load_half(bhi, u, 2, live && (2 * u + 1) < a.K);
+    }
+    for (int64_t it = 0; it < niter; ++it) {
+        walk();
+        const int64_t unext = unit_cur(it + 1 < niter);
+        const bool haveB = (2 * u + 1) < a.K;   // u live implied (K >= 1) -- a dead unit has all-zero halves anyway
+        cx<R> v[E];
+        if (haveB) {
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                v[e] = {lo[e] * w[e], ahi[e] * w[e]};
+                v[e + H] = {ahi[e] * w[e + H], bhi[e] * w[e + H]};
+            }
+        } else {  // odd frame count: the last unit has no second frame
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                v[e] = {lo[e] * w[e], (R)0};
+                v[e + H] = {ahi[e] * w[e + H], (R)0};
+            }
+        }
+        // next unit: reuse this unit's last half when it is the next frame's first half
+        {
+            const bool nlive = unext < a.units_per_ch;
+            if (unext == u + 1 && nlive) {
+#pragma unroll
+                for (int e = 0; e < H; ++e) lo[e] = bhi[e];
+            } else {
+                load_half(lo, unext, 0, nlive);
+            }
+            load_half(ahi, unext, 1, nlive);
+            load_half(bhi, unext, 2, nlive && (2 * unext + 1) < a.K);
+        }
+        u = unext;
+        fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
+        if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += (double)(v[e].x * v[e].x + v[e].y * v[e].y);
+    }
+    double* part = static_cast<double*>(a.out) + (((int64_t)blockIdx.x * G + slot) * a.nch + ch) * N;
+#pragma unroll
+    for (int e = 0; e < E; ++e) part[t + T * e] = acc[e];
+}
+
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF>
+int welch_run_half(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
+    auto kern = welch_half_kernel<R, N, E, G, TWMODE, PADSHIFT, MINW, NBUF>;
+    constexpr int threads = (N / E) * G;
+    int grid = 1;
+    MDSP_TRY(grid_for(kern, threads, cdiv(a.units_per_ch, G), a.nch, &grid));
+    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)grid * G * (size_t)a.nch * N));
+    a.out = pl->partial.p;
+    set_schedule(a, a.units_per_ch, (int64_t)grid * G);
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
+    MDSP_LAUNCH_CHECK();
+    *nslices = grid * G;
+    return MDSP_OK;
+}
+
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
 int welch_run_variant(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
     auto kern = welch_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, WIN64>;
@@ -565,7 +680,20 @@ int welch_run_variant(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* n
 template <typename R, int N, bool CPLX>
 int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, hipStream_t st) {
     using Gm = Geo<R, N>;
-    int nslices = 0, rc;
+    int nslices = 0, rc = MDSP_OK;
+    const bool half_ok = !CPLX && a.n == N && 2 * a.hop == N && !getenv("MDSP_WELCH_NOHALF");
+    if constexpr (!CPLX && N >= 1024) {
+        if (half_ok && !(N == 4096 && sizeof(R) == 4 && pl->variant >= 1 && pl->variant <= 10)) {
+            constexpr int EH = (N == 4096 && sizeof(R) == 4) ? 16 : Gm::E;
+            constexpr int GH = (N / EH) >= 256 ? 1 : 256 / (N / EH);
+            constexpr int NB = (N / EH) <= 64 ? 1 : 2;
+            if (pl->variant == 11 && N == 4096 && sizeof(R) == 4) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 2>(pl, a, st, &nslices);
+            else if (pl->variant == 12 && N == 4096 && sizeof(R) == 4) rc = welch_run_half<R, N, EH, GH, 2, 4, 2, 1>(pl, a, st, &nslices);
+            else if (pl->variant == 13 && N == 4096 && sizeof(R) == 4) rc = welch_run_half<R, N, 8, 1, 1, 4, 2, 2>(pl, a, st, &nslices);
+            else rc = welch_run_half<R, N, EH, GH, Gm::TWREG, 4, 2, (N == 4096 && sizeof(R) == 4) ? 1 : NB>(pl, a, st, &nslices);
+            goto finalize;
+        }
+    }
     if constexpr (N == 4096 && !CPLX && sizeof(R) == 4) {
         switch (pl->variant) {  // tuning alternatives (MDSP_WELCH_VARIANT), built for the headline shape only
             //                                  R  N   E  G TW PAD CPLX MINW NBUF PREF WIN64      (TW: 0 global, 1 regs, 2 LDS)
@@ -584,6 +712,7 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
     } else {
         rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, 4, CPLX, 2, Gm::NBUF, true, sizeof(R) == 8>(pl, a, st, &nslices);
     }
+finalize:
     if (rc != MDSP_OK) return rc;
     const int nout = (int)pl->nout;
     const double r_total = (double)a.K * pl->r;
