@@ -41,9 +41,41 @@ def pmc(path):
     return out
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and sys.argv[1] != "--traffic":
     if sys.argv[1] == "--pmc":
         print(json.dumps(pmc(sys.argv[2]), indent=1))
     else:
         for r in stats(sys.argv[1]):
             print(f"{r['pct']:6.2f}%  calls={r['calls']:4d}  avg={r['avg_us']:10.2f} us  total={r['total_us']:12.1f} us  {r['kernel']}")
+
+
+def traffic(fetch_db, write_db, out_path):
+    """HBM bytes per launch of the fused kernels from separate --pmc FETCH_SIZE / WRITE_SIZE passes.
+    FETCH_SIZE (KB) is doubled: on gfx950 it tallies 128-B read requests as 64 B (MI355X_MICROARCH.md, HBM section);
+    the float4 copy kernel in the same run is the calibration (reported next to its known byte count)."""
+    f, w = pmc(fetch_db), pmc(write_db)
+
+    def get(d, key, cname):
+        for k, v in d.items():
+            if key in k:
+                return v["counters"].get(cname), k
+        return None, None
+
+    out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024",
+           "workload": "bench.py default (2^30 Float32 samples per launch)"}
+    for name, key in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("welch_fused_generic", "welch_fused_kernel"),
+                      ("copy", "mdsp_copy_kernel")):
+        fv, fk = get(f, key, "FETCH_SIZE")
+        wv, _ = get(w, key, "WRITE_SIZE")
+        if fv is None or wv is None:
+            continue
+        out[f"{name}_kernel"] = fk
+        out[f"{name}_fetch_bytes_corrected"] = int(2 * fv * 1024)
+        out[f"{name}_write_bytes"] = int(wv * 1024)
+        out[f"{name}_bytes_per_launch"] = int(2 * fv * 1024 + wv * 1024)
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--traffic":
+    traffic(sys.argv[2], sys.argv[3], sys.argv[4])
