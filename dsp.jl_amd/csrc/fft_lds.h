@@ -44,6 +44,61 @@ template <int DIR, typename R> MDSP_HD cx<R> twmul(cx<R> a, cx<R> w) { return DI
 // multiply by -i (forward) / +i (inverse)
 template <int DIR, typename R> MDSP_HD cx<R> mul_mi(cx<R> a) { return DIR < 0 ? cx<R>{a.y, -a.x} : cx<R>{-a.y, a.x}; }
 
+// a + mul_mi<DIR>(b)  /  a - mul_mi<DIR>(b)  /  e + h u  /  e - h u   (h real): the shapes the butterflies are made of
+template <int DIR, typename R> MDSP_HD cx<R> add_mi(cx<R> a, cx<R> b) { return cadd(a, mul_mi<DIR>(b)); }
+template <int DIR, typename R> MDSP_HD cx<R> sub_mi(cx<R> a, cx<R> b) { return csub(a, mul_mi<DIR>(b)); }
+template <typename R> MDSP_HD cx<R> caxpy(R h, cx<R> u, cx<R> e) { return {e.x + h * u.x, e.y + h * u.y}; }
+template <typename R> MDSP_HD cx<R> caxmy(R h, cx<R> u, cx<R> e) { return {e.x - h * u.x, e.y - h * u.y}; }
+template <typename R> MDSP_HD cx<R> cscale(R h, cx<R> u) { return {h * u.x, h * u.y}; }
+// lane-wise a b + c on the (re, im) pair (NOT a complex product): the |z|^2 accumulation of the spectral kernels
+template <typename R> MDSP_HD cx<R> lanefma(cx<R> a, cx<R> b, cx<R> c) { return {a.x * b.x + c.x, a.y * b.y + c.y}; }
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDSP_NO_PACKED_F32)
+// ---------------------------------------------------------------------------------- packed-FP32 complex arithmetic
+// gfx950 issues v_pk_{add,mul,fma}_f32 at the rate of their scalar forms, and a complex number IS a (lo, hi) register
+// pair, so every complex add / rotate-by-i / twiddle product below is one or two VOP3P instructions whose op_sel /
+// neg modifiers do the swaps and sign flips for free.  hipcc's SLP vectoriser finds only some of these and pays for
+// the rest with v_mov shuffles (a third of the VALU stream of the fused kernels), hence the explicit forms.
+// Non-volatile asm: the optimiser may still schedule, CSE and delete them.
+typedef float f2v __attribute__((ext_vector_type(2)));
+#define MDSP_PK2(NAME, INSN, MODS)                                                                  \
+    __device__ __forceinline__ cx<float> NAME(cx<float> a, cx<float> b) {                           \
+        f2v d;                                                                                      \
+        asm(INSN " %0, %1, %2 " MODS : "=v"(d) : "v"(f2v{a.x, a.y}), "v"(f2v{b.x, b.y}));           \
+        return {d.x, d.y};                                                                          \
+    }
+#define MDSP_PK3(NAME, INSN, MODS)                                                                  \
+    __device__ __forceinline__ cx<float> NAME(cx<float> a, cx<float> b, cx<float> c) {              \
+        f2v d;                                                                                      \
+        asm(INSN " %0, %1, %2, %3 " MODS : "=v"(d) : "v"(f2v{a.x, a.y}), "v"(f2v{b.x, b.y}), "v"(f2v{c.x, c.y})); \
+        return {d.x, d.y};                                                                          \
+    }
+MDSP_PK2(cadd, "v_pk_add_f32", "")
+MDSP_PK2(csub, "v_pk_add_f32", "neg_lo:[0,1] neg_hi:[0,1]")
+MDSP_PK2(pk_add_ib, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")   // a + i b = (ax - by, ay + bx)
+MDSP_PK2(pk_sub_ib, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")   // a - i b = (ax + by, ay - bx)
+MDSP_PK2(pk_mul, "v_pk_mul_f32", "")
+MDSP_PK2(pk_mul_swap, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,1]")              // (a.y b.x, a.x b.y)
+MDSP_PK2(pk_mul_yy, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0]")                // (a.y b.y, a.y b.x)
+MDSP_PK3(pk_fma, "v_pk_fma_f32", "")                                               // a b + c, lane-wise
+MDSP_PK3(pk_fnma, "v_pk_fma_f32", "neg_lo:[1,0,0] neg_hi:[1,0,0]")                 // c - a b
+MDSP_PK3(pk_cmul_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_lo:[0,0,1]")          // (ax bx - c.x, ax by + c.y)
+MDSP_PK3(pk_cmulc_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_hi:[1,0,0]")         // (ax bx + c.x, -ax by + c.y)
+#undef MDSP_PK2
+#undef MDSP_PK3
+__device__ __forceinline__ cx<float> cmul(cx<float> a, cx<float> w) { return pk_cmul_fin(a, w, pk_mul_yy(a, w)); }
+__device__ __forceinline__ cx<float> cmulc(cx<float> a, cx<float> w) { return pk_cmulc_fin(a, w, pk_mul_yy(a, w)); }
+template <int DIR> __device__ __forceinline__ cx<float> add_mi(cx<float> a, cx<float> b) { return DIR < 0 ? pk_sub_ib(a, b) : pk_add_ib(a, b); }
+template <int DIR> __device__ __forceinline__ cx<float> sub_mi(cx<float> a, cx<float> b) { return DIR < 0 ? pk_add_ib(a, b) : pk_sub_ib(a, b); }
+template <int DIR> __device__ __forceinline__ cx<float> mul_mi(cx<float> a) {
+    return pk_mul_swap(a, DIR < 0 ? cx<float>{1.f, -1.f} : cx<float>{-1.f, 1.f});
+}
+__device__ __forceinline__ cx<float> caxpy(float h, cx<float> u, cx<float> e) { return pk_fma(u, cx<float>{h, h}, e); }
+__device__ __forceinline__ cx<float> caxmy(float h, cx<float> u, cx<float> e) { return pk_fnma(u, cx<float>{h, h}, e); }
+__device__ __forceinline__ cx<float> cscale(float h, cx<float> u) { return pk_mul(u, cx<float>{h, h}); }
+__device__ __forceinline__ cx<float> lanefma(cx<float> a, cx<float> b, cx<float> c) { return pk_fma(a, b, c); }
+#endif
+
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
 
 // ------------------------------------------------------------------------------------------------ butterflies
@@ -55,39 +110,34 @@ template <int DIR, typename R> MDSP_HD void bfly2(cx<R>& a, cx<R>& b) {
 
 // natural-order in, natural-order out
 template <int DIR, typename R> MDSP_HD void bfly4(cx<R>& a0, cx<R>& a1, cx<R>& a2, cx<R>& a3) {
-    const cx<R> t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi<DIR>(csub(a1, a3));
+    const cx<R> t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
     a0 = cadd(t0, t2);
     a2 = csub(t0, t2);
-    a1 = cadd(t1, t3);
-    a3 = csub(t1, t3);
+    a1 = add_mi<DIR>(t1, d);
+    a3 = sub_mi<DIR>(t1, d);
 }
+
+// o W8 / h  and  o W8^3 / (-h)  with W8 = exp(-+ 2 pi i/8) = h (1 -+ i):  o + mul_mi(o)  and  o - mul_mi(o)
+template <int DIR, typename R> MDSP_HD cx<R> w8_1_unscaled(cx<R> o) { return add_mi<DIR>(o, o); }
+template <int DIR, typename R> MDSP_HD cx<R> w8_3_unscaled_neg(cx<R> o) { return sub_mi<DIR>(o, o); }
 
 template <int DIR, typename R> MDSP_HD void bfly8(cx<R> (&v)[8]) {
     constexpr R h = (R)0.70710678118654752440084436210485L;
-    // even / odd radix-4 sub-transforms
+    // even / odd radix-4 sub-transforms: E[k] lands in v[2k], O[k] in v[2k+1]
     bfly4<DIR>(v[0], v[2], v[4], v[6]);
     bfly4<DIR>(v[1], v[3], v[5], v[7]);
-    // odd outputs times W8^k, k = 1,2,3  (W8 = exp(-+ 2 pi i / 8))
-    {
-        const cx<R> o = v[3];  // k = 1:  (1 -+ i)/sqrt2
-        v[3] = DIR < 0 ? cx<R>{(o.x + o.y) * h, (o.y - o.x) * h} : cx<R>{(o.x - o.y) * h, (o.y + o.x) * h};
-    }
-    v[5] = mul_mi<DIR>(v[5]);  // k = 2
-    {
-        const cx<R> o = v[7];  // k = 3:  (-1 -+ i)/sqrt2
-        v[7] = DIR < 0 ? cx<R>{(o.y - o.x) * h, -(o.x + o.y) * h} : cx<R>{-(o.x + o.y) * h, (o.x - o.y) * h};
-    }
-    // after the two bfly4 calls: E[k] sits in v[2k], O[k]*W in v[2k+1]
     const cx<R> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    const cx<R> o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    const cx<R> o0 = v[1], o2 = v[5];
+    const cx<R> u1 = w8_1_unscaled<DIR>(v[3]);       // O[1] W8   =  h u1
+    const cx<R> u3 = w8_3_unscaled_neg<DIR>(v[7]);   // O[3] W8^3 = -h u3
     v[0] = cadd(e0, o0);
-    v[1] = cadd(e1, o1);
-    v[2] = cadd(e2, o2);
-    v[3] = cadd(e3, o3);
     v[4] = csub(e0, o0);
-    v[5] = csub(e1, o1);
-    v[6] = csub(e2, o2);
-    v[7] = csub(e3, o3);
+    v[1] = caxpy(h, u1, e1);
+    v[5] = caxmy(h, u1, e1);
+    v[2] = add_mi<DIR>(e2, o2);                      // O[2] W8^2 = mul_mi(O[2])
+    v[6] = sub_mi<DIR>(e2, o2);
+    v[3] = caxmy(h, u3, e3);
+    v[7] = caxpy(h, u3, e3);
 }
 
 template <int DIR, typename R> MDSP_HD void bfly16(cx<R> (&v)[16]) {
@@ -98,19 +148,16 @@ template <int DIR, typename R> MDSP_HD void bfly16(cx<R> (&v)[16]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) bfly4<DIR>(v[m], v[m + 4], v[m + 8], v[m + 12]);  // y[m][q] in v[m + 4q]
     // twiddles W16^{mq}, forward root w = exp(-2 pi i/16) = (c1, -s1)
-    const cx<R> w1 = {c1, -s1}, w2 = {h, -h}, w3 = {s1, -c1};
-    v[1 + 4 * 1] = twmul<DIR>(v[1 + 4 * 1], w1);           // m=1,q=1 : W^1
-    v[1 + 4 * 2] = twmul<DIR>(v[1 + 4 * 2], w2);           // m=1,q=2 : W^2
-    v[1 + 4 * 3] = twmul<DIR>(v[1 + 4 * 3], w3);           // m=1,q=3 : W^3
-    v[2 + 4 * 1] = twmul<DIR>(v[2 + 4 * 1], w2);           // m=2,q=1 : W^2
-    v[2 + 4 * 2] = mul_mi<DIR>(v[2 + 4 * 2]);              // m=2,q=2 : W^4 = -+i
-    v[2 + 4 * 3] = mul_mi<DIR>(twmul<DIR>(v[2 + 4 * 3], w2));  // m=2,q=3 : W^6 = W^4 W^2
-    v[3 + 4 * 1] = twmul<DIR>(v[3 + 4 * 1], w3);           // m=3,q=1 : W^3
-    v[3 + 4 * 2] = mul_mi<DIR>(twmul<DIR>(v[3 + 4 * 2], w2));  // m=3,q=2 : W^6
-    {
-        const cx<R> t = twmul<DIR>(v[3 + 4 * 3], w1);      // m=3,q=3 : W^9 = -W^1
-        v[3 + 4 * 3] = {-t.x, -t.y};
-    }
+    const cx<R> w1 = {c1, -s1}, w3 = {s1, -c1}, w9 = {-c1, s1};
+    v[1 + 4 * 1] = twmul<DIR>(v[1 + 4 * 1], w1);                          // m=1,q=1 : W^1
+    v[1 + 4 * 2] = cscale(h, w8_1_unscaled<DIR>(v[1 + 4 * 2]));           // m=1,q=2 : W^2 = W8
+    v[1 + 4 * 3] = twmul<DIR>(v[1 + 4 * 3], w3);                          // m=1,q=3 : W^3
+    v[2 + 4 * 1] = cscale(h, w8_1_unscaled<DIR>(v[2 + 4 * 1]));           // m=2,q=1 : W^2
+    v[2 + 4 * 2] = mul_mi<DIR>(v[2 + 4 * 2]);                             // m=2,q=2 : W^4 = -+i
+    v[2 + 4 * 3] = cscale(-h, w8_3_unscaled_neg<DIR>(v[2 + 4 * 3]));      // m=2,q=3 : W^6 = W8^3
+    v[3 + 4 * 1] = twmul<DIR>(v[3 + 4 * 1], w3);                          // m=3,q=1 : W^3
+    v[3 + 4 * 2] = cscale(-h, w8_3_unscaled_neg<DIR>(v[3 + 4 * 2]));      // m=3,q=2 : W^6
+    v[3 + 4 * 3] = twmul<DIR>(v[3 + 4 * 3], w9);                          // m=3,q=3 : W^9 = -W^1
     // outer DFT4 over m for each q; result p lands in slot m=p of the same group: X[4p+q] in v[p + 4q]
 #pragma unroll
     for (int q = 0; q < 4; ++q) bfly4<DIR>(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);

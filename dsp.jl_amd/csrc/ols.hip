@@ -228,8 +228,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
         // inverse transform (unnormalised, like plan_brfft / inv(p).p)
         fft::wg_fft<C, +1, TWMODE, PADSHIFT, NBUF, (C::P - 1) % NBUF>(v, t, tw, twsrc, lds);
         }
-        // single buffer: the next iteration's first pass rewrites LDS that slower waves may still be reading
-        if constexpr (C::P > 1 && NBUF == 1) fft::wg_sync<T>();
+        // no barrier needed here: with one buffer wg_fft ends every exchange with a barrier, with two the 2(P-1)
+        // exchanges of a unit alternate buffers so the next unit's first write is two barriers behind its readers
         if (!(a.ablate & 4)) ols_store<R, E, T, CPLX>(v, a, cur, t);
         cur = nxt;
     }

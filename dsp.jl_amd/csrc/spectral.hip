@@ -274,7 +274,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
         if (!(a.ablate & 2))
         fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
         // an odd number of exchanges per iteration would re-enter on the buffer that was used last: fence it
-        if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
+        if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();  // NBUF == 1: wg_fft already ends every exchange with a barrier
         // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
         if (!(a.ablate & 4)) {
 #pragma unroll
@@ -347,7 +347,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
         }
         if constexpr (PREFETCH) issue(fcur);
         fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
-        if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
+        if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();  // NBUF == 1: wg_fft already ends every exchange with a barrier
         // column store: bins k = t + T*e < nout, contiguous across lanes
         const bool live = f < a.K;
         if constexpr (PSD) {
@@ -577,9 +577,42 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
 #pragma unroll
         for (int e = 0; e < E; ++e) w[e] = (R)wd[e];
     }
-    double acc[E];
+    // Power accumulators.  Float32: (re^2, im^2) pairs fed by one packed FMA per bin, folded into the slot's Float64
+    // partial row every FLUSH units (the reference accumulates in Float32 over ALL frames, periodograms.jl:757; a
+    // run of <= 2 FLUSH same-sign terms per lane keeps this far tighter).  Float64: plain double accumulators.
+    constexpr bool PAIR = sizeof(R) == 4;
+    constexpr int FLUSH = 64;
+    cx<R> accp[PAIR ? E : 1];
+    double acc[PAIR ? 1 : E];
+    if constexpr (PAIR) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] = 0.0;
+        for (int e = 0; e < E; ++e) accp[e] = {(R)0, (R)0};
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.0;
+    }
+    double* part = static_cast<double*>(a.out) + (((int64_t)blockIdx.x * G + slot) * a.nch + ch) * N;
+    const __amdgpu_buffer_rsrc_t prs = io::make_rsrc(part, (int64_t)N * 8);
+    int since = 0;
+    bool first = true;
+    auto flush = [&]() {   // wave-uniform control flow; per-lane state is one laundered byte offset
+        int off = t * 8;
+        asm volatile("" : "+v"(off));
+        if (first) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) io::Ld<double>::store((double)accp[e].x + (double)accp[e].y, prs, off + T * e * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double s = io::Ld<double>::load(prs, off + T * e * 8) + ((double)accp[e].x + (double)accp[e].y);
+                io::Ld<double>::store(s, prs, off + T * e * 8);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) accp[e] = {(R)0, (R)0};
+        first = false;
+        since = 0;
+    };
 
     const R* sc = static_cast<const R*>(a.s) + ch * a.lds_;
     const int64_t nslots = (int64_t)gridDim.x * G;
@@ -637,14 +670,25 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
             load_half(bhi, unext, 2, nlive && (2 * unext + 1) < a.K);
         }
         u = unext;
-        fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
-        if constexpr (C::P > 1 && (NBUF == 1 || ((C::P - 1) % NBUF) != 0)) fft::wg_sync<T>();
+        if (!(a.ablate & 2)) {
+            fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
+            if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();  // NBUF == 1: wg_fft already ends every exchange with a barrier
+        }
+        if constexpr (PAIR) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] += (double)(v[e].x * v[e].x + v[e].y * v[e].y);
+            for (int e = 0; e < E; ++e) accp[e] = fft::lanefma(v[e], v[e], accp[e]);
+            if (++since == FLUSH) flush();
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += (double)(v[e].x * v[e].x + v[e].y * v[e].y);
+        }
     }
-    double* part = static_cast<double*>(a.out) + (((int64_t)blockIdx.x * G + slot) * a.nch + ch) * N;
+    if constexpr (PAIR) {
+        flush();
+    } else {
 #pragma unroll
-    for (int e = 0; e < E; ++e) part[t + T * e] = acc[e];
+        for (int e = 0; e < E; ++e) part[t + T * e] = acc[e];
+    }
 }
 
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF>
@@ -687,10 +731,19 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
             constexpr int EH = (N == 4096 && sizeof(R) == 4) ? 16 : Gm::E;
             constexpr int GH = (N / EH) >= 256 ? 1 : 256 / (N / EH);
             constexpr int NB = (N / EH) <= 64 ? 1 : 2;
-            if (pl->variant == 11 && N == 4096 && sizeof(R) == 4) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 2>(pl, a, st, &nslices);
-            else if (pl->variant == 12 && N == 4096 && sizeof(R) == 4) rc = welch_run_half<R, N, EH, GH, 2, 4, 2, 1>(pl, a, st, &nslices);
-            else if (pl->variant == 13 && N == 4096 && sizeof(R) == 4) rc = welch_run_half<R, N, 8, 1, 1, 4, 2, 2>(pl, a, st, &nslices);
-            else rc = welch_run_half<R, N, EH, GH, Gm::TWREG, 4, 2, (N == 4096 && sizeof(R) == 4) ? 1 : NB>(pl, a, st, &nslices);
+            constexpr int NBH = (N == 4096 && sizeof(R) == 4) ? 1 : NB;
+            bool done = false;
+            if constexpr (N == 4096 && sizeof(R) == 4) {  // tuning alternatives of the headline shape (MDSP_WELCH_VARIANT)
+                done = true;
+                //                                              R  N  E   G  TW PAD MINW NBUF
+                if (pl->variant == 11) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 2>(pl, a, st, &nslices);
+                else if (pl->variant == 12) rc = welch_run_half<R, N, EH, GH, 2, 4, 2, 1>(pl, a, st, &nslices);
+                else if (pl->variant == 13) rc = welch_run_half<R, N, 8, 1, 1, 4, 2, 2>(pl, a, st, &nslices);
+                else if (pl->variant == 14) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 2>(pl, a, st, &nslices);
+                else if (pl->variant == 15) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 1>(pl, a, st, &nslices);
+                else done = false;
+            }
+            if (!done) rc = welch_run_half<R, N, EH, GH, Gm::TWREG, 4, 2, NBH>(pl, a, st, &nslices);
             goto finalize;
         }
     }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profile protocol for the headline bench on the GPU box (run through gpurun from the repo root):
+#   1. rocprofv3 --kernel-trace --stats            -> gpurun_out/prof_stats      (per-kernel durations)
+#   2. rocprofv3 --pmc FETCH_SIZE                  -> gpurun_out/prof_FETCH_SIZE (HBM reads; x2 correction on gfx950)
+#   3. rocprofv3 --pmc WRITE_SIZE                  -> gpurun_out/prof_WRITE_SIZE (HBM writes)
+#   4. rocprofv3 --pmc <SQ counters>               -> gpurun_out/prof_sq         (VALU / LDS activity, bank conflicts)
+# Counter passes are separate runs with --kernel-trace only (never combined with sys/runtime traces).
+# Afterwards, locally:  python tools/prof_summary.py ...  and copy the summaries into profiles/.
+set -u
+REPO="$(pwd)"
+OUT="$REPO/gpurun_out"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline"
+rm -rf "$OUT"/prof_stats "$OUT"/prof_FETCH_SIZE "$OUT"/prof_WRITE_SIZE "$OUT"/prof_sq
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof_stats" -o bench -- $BENCH --steps 10 --warmup 3 > "$OUT/prof_stats.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/prof_$c" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_$c.log" 2>&1
+done
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU \
+    -d "$OUT/prof_sq" -o bench -- $BENCH --steps 3 --warmup 1 > "$OUT/prof_sq.log" 2>&1
+cd "$REPO"
+find "$OUT" -name "*.db" | sort
+grep -h '"metric"' "$OUT/prof_stats.log" | head -1 | cut -c1-400
