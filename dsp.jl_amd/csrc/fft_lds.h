@@ -202,17 +202,37 @@ template <int N_, int E_> struct Cfg {
 };
 
 // twiddle sources
-enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2 };
+enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2, TW_HYB = 3 };
+// TW_HYB: passes whose twiddles depend on few distinct k (Ns <= HYB_NS_MAX: a (radix-1) x Ns table of <= 2 KiB) read
+// them from LDS -- consecutive lanes read consecutive entries, lanes l and l+Ns broadcast -- and only the wide
+// passes keep theirs in VGPRs.  For N = 4096, E = 16 this frees 30 of the 60 twiddle registers.
+constexpr int HYB_NS_MAX = 16;
+template <typename C, int TWMODE, int PASS> constexpr bool tw_pass_in_lds() {
+    return TWMODE == TW_LDS || (TWMODE == TW_HYB && PASS >= 1 && C::ns(PASS) <= HYB_NS_MAX);
+}
+template <typename C, int TWMODE, int PASS> constexpr bool tw_pass_in_regs() {
+    return TWMODE == TW_REG || (TWMODE == TW_HYB && !(PASS >= 1 && C::ns(PASS) <= HYB_NS_MAX));
+}
+// LDS twiddle entries a mode needs (TW_HYB: the leading small-Ns passes only; their ldsoff() are the TW_LDS ones)
+template <typename C, int TWMODE, int PASS = 1> constexpr int tw_lds_entries() {
+    if constexpr (PASS >= C::P) return 1;
+    else if constexpr (tw_pass_in_lds<C, TWMODE, PASS>()) {
+        constexpr int here = C::ldsoff(PASS) + C::ldstw(PASS), rest = tw_lds_entries<C, TWMODE, PASS + 1>();
+        return here > rest ? here : rest;
+    } else return tw_lds_entries<C, TWMODE, PASS + 1>();
+}
 
 // Fill the LDS twiddle table cooperatively (T threads of one transform; callers sync afterwards).
-template <typename C, typename R, int PASS = 1> MDSP_HD void fill_lds_twiddles(cx<R>* twl, int t, const cx<R>* table) {
+template <typename C, typename R, int PASS = 1, int TWMODE = TW_LDS> MDSP_HD void fill_lds_twiddles(cx<R>* twl, int t, const cx<R>* table) {
     if constexpr (PASS < C::P) {
-        constexpr int Ns = C::ns(PASS), Rdx = C::radix(PASS);
-        for (int idx = t; idx < (Rdx - 1) * Ns; idx += C::T) {
-            const int r = idx / Ns + 1, k = idx - (r - 1) * Ns;
-            twl[C::ldsoff(PASS) + idx] = table[(r * k * (C::N / (Ns * Rdx))) & (C::N - 1)];
+        if constexpr (tw_pass_in_lds<C, TWMODE, PASS>()) {
+            constexpr int Ns = C::ns(PASS), Rdx = C::radix(PASS);
+            for (int idx = t; idx < (Rdx - 1) * Ns; idx += C::T) {
+                const int r = idx / Ns + 1, k = idx - (r - 1) * Ns;
+                twl[C::ldsoff(PASS) + idx] = table[(r * k * (C::N / (Ns * Rdx))) & (C::N - 1)];
+            }
         }
-        fill_lds_twiddles<C, R, PASS + 1>(twl, t, table);
+        fill_lds_twiddles<C, R, PASS + 1, TWMODE>(twl, t, table);
     }
 }
 
@@ -237,14 +257,16 @@ template <typename C, int PASS> MDSP_HD int tw_index(int t, int b, int r) {
 }
 
 // Fill the per-thread twiddle registers (loop-invariant for a persistent workgroup).
-template <typename C, typename R, int PASS = 1> MDSP_HD void load_twiddles(cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], int t, const cx<R>* table) {
+template <typename C, typename R, int PASS = 1, int TWMODE = TW_REG> MDSP_HD void load_twiddles(cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], int t, const cx<R>* table) {
     if constexpr (PASS < C::P) {
-        constexpr int Rdx = C::radix(PASS), NB = C::E / Rdx;
+        if constexpr (tw_pass_in_regs<C, TWMODE, PASS>()) {
+            constexpr int Rdx = C::radix(PASS), NB = C::E / Rdx;
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int r = 1; r < Rdx; ++r) tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)] = table[tw_index<C, PASS>(t, b, r)];
-        load_twiddles<C, R, PASS + 1>(tw, t, table);
+                for (int r = 1; r < Rdx; ++r) tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)] = table[tw_index<C, PASS>(t, b, r)];
+        }
+        load_twiddles<C, R, PASS + 1, TWMODE>(tw, t, table);
     }
 }
 
@@ -261,12 +283,13 @@ MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 
         for (int r = 0; r < Rdx; ++r) v[r] = x[b + r * NB];
         if constexpr (PASS > 0) {
             [[maybe_unused]] int kt = (Ns > C::T) ? t : (t & (Ns - 1));   // TW_LDS: k = kt + (T*b mod Ns), see below
-            if constexpr (TWMODE == TW_LDS) MDSP_OPAQUE_INT(kt);
+            constexpr bool IN_LDS = tw_pass_in_lds<C, TWMODE, PASS>(), IN_REGS = tw_pass_in_regs<C, TWMODE, PASS>();
+            if constexpr (IN_LDS) MDSP_OPAQUE_INT(kt);
 #pragma unroll
             for (int r = 1; r < Rdx; ++r) {
                 cx<R> w;
-                if constexpr (TWMODE == TW_REG) w = tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)];
-                else if constexpr (TWMODE == TW_LDS) {
+                if constexpr (IN_REGS) w = tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)];
+                else if constexpr (IN_LDS) {
                     // `table` points at the LDS twiddle table.  k = (t + T*b) mod Ns = kt + KB with kt = t mod Ns (or t when
                     // Ns > T) and KB = (T*b) mod Ns a compile-time constant (no carry: KB is a multiple of T, kt < T).
                     const int KB = (C::T * b) & (Ns - 1);   // constant after unrolling

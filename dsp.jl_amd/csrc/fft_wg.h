@@ -47,6 +47,11 @@ __device__ __forceinline__ const cx<R>* wg_twiddle_setup(cx<R> (&tw)[C::NTW > 0 
         if (slot == 0) fill_lds_twiddles<C, R>(twl, t, table);
         __syncthreads();
         return twl;
+    } else if constexpr (TWMODE == TW_HYB) {
+        load_twiddles<C, R, 1, TW_HYB>(tw, t, table);
+        if (slot == 0) fill_lds_twiddles<C, R, 1, TW_HYB>(twl, t, table);
+        __syncthreads();
+        return twl;
     } else {
         return table;
     }

@@ -187,7 +187,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
 
     cx<R> tw[NTWA];
-    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_LDS ? C::NTWLDS : 1];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
     const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
     cx<R> Hr[HREG ? E : 1];
     if constexpr (HREG) {

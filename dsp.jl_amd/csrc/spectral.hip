@@ -209,7 +209,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
     const int64_t ch = blockIdx.y;
 
     cx<R> tw[NTWA];
-    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_LDS ? C::NTWLDS : 1];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
     const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
     std::conditional_t<WIN64, double, R> w[E];
     {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
     const int64_t ch = blockIdx.y;
 
     cx<R> tw[NTWA];
-    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_LDS ? C::NTWLDS : 1];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
     const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
     double w[E];
     load_window_regs<E, T>(w, a.win, a.n, t);
@@ -568,7 +568,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
     const int64_t ch = blockIdx.y;
 
     cx<R> tw[NTWA];
-    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_LDS ? C::NTWLDS : 1];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
     const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
     R w[E];
     {
@@ -581,7 +581,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
     // partial row every FLUSH units (the reference accumulates in Float32 over ALL frames, periodograms.jl:757; a
     // run of <= 2 FLUSH same-sign terms per lane keeps this far tighter).  Float64: plain double accumulators.
     constexpr bool PAIR = sizeof(R) == 4;
-    constexpr int FLUSH = 64;
+    constexpr bool SCALAR_ACC = MINW >= 3;   // tighter register budget: one Float32 per bin (two scalar FMAs) instead of a pair
+    constexpr int FLUSH = 128;
     cx<R> accp[PAIR ? E : 1];
     double acc[PAIR ? 1 : E];
     if constexpr (PAIR) {
@@ -676,7 +677,10 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
         }
         if constexpr (PAIR) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) accp[e] = fft::lanefma(v[e], v[e], accp[e]);
+            for (int e = 0; e < E; ++e) {
+                if constexpr (SCALAR_ACC) accp[e].x = v[e].x * v[e].x + (v[e].y * v[e].y + accp[e].x);
+                else accp[e] = fft::lanefma(v[e], v[e], accp[e]);
+            }
             if (++since == FLUSH) flush();
         } else {
 #pragma unroll
@@ -741,6 +745,8 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
                 else if (pl->variant == 13) rc = welch_run_half<R, N, 8, 1, 1, 4, 2, 2>(pl, a, st, &nslices);
                 else if (pl->variant == 14) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 2>(pl, a, st, &nslices);
                 else if (pl->variant == 15) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 1>(pl, a, st, &nslices);
+                else if (pl->variant == 16) rc = welch_run_half<R, N, EH, GH, 3, 4, 3, 1>(pl, a, st, &nslices);
+                else if (pl->variant == 17) rc = welch_run_half<R, N, EH, GH, 3, 4, 2, 1>(pl, a, st, &nslices);
                 else done = false;
             }
             if (!done) rc = welch_run_half<R, N, EH, GH, Gm::TWREG, 4, 2, NBH>(pl, a, st, &nslices);
