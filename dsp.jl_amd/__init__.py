@@ -28,17 +28,24 @@ def filt(*args, **kw):
     ``filt(b, x)``             FIR, FFT overlap-save when length(b) > 66 (Filters/filt.jl:445, :525)
     ``filt(f::FIRFilter, x)``  stateful polyphase filter                 (stream_filt.jl:627)
     ``filt(h, x, ratio)``      stateless polyphase filter                (stream_filt.jl:663)
+    ``filt(h, x, rate::float, Nphi=32)``  stateless arbitrary-rate resampler (stream_filt.jl:669)
     """
     if len(args) == 2 and isinstance(args[0], FIRFilter):
         return args[0].filt(args[1])
     if len(args) == 2:
         return _filt_bx(*args, **kw)
-    if len(args) == 3:
+    if len(args) in (3, 4):
         from fractions import Fraction
-        if isinstance(args[2], (int, Fraction)) and not isinstance(args[2], bool) and hasattr(args[1], "shape") and len(getattr(args[1], "shape")) >= 1 \
-                and not hasattr(args[2], "shape"):
+        import numpy as _np
+        third = args[2]
+        scalar_rate = isinstance(third, (int, Fraction, float, _np.floating, _np.integer)) and not isinstance(third, bool)
+        vector_x = hasattr(args[1], "shape") and len(getattr(args[1], "shape")) >= 1
+        if scalar_rate and vector_x:                      # filt(h, x, ratio) / filt(h, x, rate::AbstractFloat, Nphi=32)
+            if len(args) == 4 and not isinstance(third, (float, _np.floating)):
+                raise TypeError("filt(h, x, ratio, Nphi): Nphi is only defined for a floating-point rate")
             return filt_stateless(*args)
-        return _filt_ba(*args)
+        if len(args) == 3:
+            return _filt_ba(*args)
     raise TypeError("filt: no method matching the given arguments")
 
 

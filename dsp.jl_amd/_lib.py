@@ -90,6 +90,18 @@ PROTOTYPES = {
     "mdsp_fir_get_state": (ci, [vp, pi64, pi64, vp]),
     "mdsp_fir_set_state": (ci, [vp, i64, i64, vp]),
     "mdsp_fir_exec": (ci, [vp, vp, i64, i64, vp, i64, i64, pi64, vp]),
+    "mdsp_firarb_create": (ci, [pvp, vp, i64, cd, i64, ci, ci, i64]),
+    "mdsp_firarb_destroy": (ci, [vp]),
+    "mdsp_firarb_reset": (ci, [vp]),
+    "mdsp_firarb_setphase": (ci, [vp, cd]),
+    "mdsp_firarb_timedelay": (ci, [vp, pdbl]),
+    "mdsp_firarb_outputlength": (ci, [vp, i64, pi64]),
+    "mdsp_firarb_inputlength": (ci, [vp, i64, ci, pi64]),
+    "mdsp_firarb_info": (ci, [vp, pi64, pi64, pi64, pint, pdbl]),
+    "mdsp_firarb_get_state": (ci, [vp, pdbl, pdbl, pi64, pi64, pi64, vp]),
+    "mdsp_firarb_set_state": (ci, [vp, cd, i64, vp]),
+    "mdsp_firarb_exec": (ci, [vp, vp, i64, i64, vp, i64, i64, pi64, vp]),
+    "mdsp_arb_trajectory": (ci, [cd, i64, cd, i64, i64, i64, pi64, pdbl, i64, pi64, pdbl, pi64]),
     "mdsp_tdfir_exec": (ci, [vp, i64, ci, vp, i64, i64, i64, vp, i64, vp]),
     "mdsp_event_create": (ci, [pvp]),
     "mdsp_event_destroy": (ci, [vp]),

@@ -17,7 +17,9 @@
 // spreads them over the banks), and every output is a tp-term fused multiply-add chain, oldest sample first.
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <numeric>
+#include <vector>
 
 #include "common.h"
 #include "devio.h"
@@ -39,6 +41,14 @@ template <typename R> __device__ __forceinline__ void fma_acc(cx<R>& acc, R h, c
 }
 template <typename R> __device__ __forceinline__ R mul_first(R h, R x) { return h * x; }
 template <typename R> __device__ __forceinline__ cx<R> mul_first(R h, cx<R> x) { return {h * x.x, h * x.y}; }
+
+// muladd(yUpper, alpha::Float64, yLower) evaluated in Float64 and rounded once to the buffer's element type
+__device__ __forceinline__ float arb_combine(float up, double al, float lo) { return (float)fma((double)up, al, (double)lo); }
+__device__ __forceinline__ double arb_combine(double up, double al, double lo) { return fma(up, al, lo); }
+__device__ __forceinline__ cx<float> arb_combine(cx<float> up, double al, cx<float> lo) {
+    return {(float)fma((double)up.x, al, (double)lo.x), (float)fma((double)up.y, al, (double)lo.y)};
+}
+__device__ __forceinline__ cx<double> arb_combine(cx<double> up, double al, cx<double> lo) { return {fma(up.x, al, lo.x), fma(up.y, al, lo.y)}; }
 
 struct FirArgs {
     const void* x;       // (xlen, nch), ld ldx, storage type XS
@@ -224,6 +234,145 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 
 int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// FIRArbitrary (floating-point rate): polyphase bank + derivative bank with linear interpolation between
+// neighbouring phases (stream_filt.jl:80-134, filt! :579-625).
+//
+// The reference advances a Float64 phase accumulator serially (update! :567-577): phiAcc += Delta; on overflow
+// (dx, phiAcc) = divrem(phiAcc, Nphi), xIdx += dx; alpha = frac(phiAcc), phiIdx = 1 + trunc(phiAcc).  Every step
+// rounds, so the trajectory has no closed form; to stay bit-exact with it the HOST runs the same IEEE operations
+// once per call (arb_trajectory; ~2 ns per output, shared by all channels, cached per (state, length)) and hands the
+// device the exact (xIdx, phiAcc) at every 64th output.  A workgroup replays 64 steps per lane from those anchors
+// with the same operations (v_add_f64 / v_fma_f64 / v_floor_f64 are IEEE-exact) into an LDS record per output, then
+// all threads evaluate   y = muladd(yUpper, alpha, yLower)   (:616) with yLower/yUpper the two tapsPerPhase-term
+// chains (oldest sample first) over the input span staged in LDS.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int ARB_BLK = 64;   // outputs per host anchor
+
+struct ArbStep {              // one update! (stream_filt.jl:567-577), shared by host and device
+    double delta, nphi, inv_nphi;
+    __host__ __device__ inline void operator()(double& acc, int64_t& xidx) const {
+        acc = acc + delta;
+        if (acc >= nphi) {
+            // divrem(acc, nphi): q = floor(acc/nphi) up to one unit, r = acc - q nphi (exact), then fix q
+            double q = floor(acc * inv_nphi);
+            double r = acc - q * nphi;   // q nphi is an exact integer and |r| <= acc is a multiple of ulp(acc): exact with or without FMA
+            if (r < 0.0) {
+                q -= 1.0;
+                r += nphi;
+            } else if (r >= nphi) {
+                q += 1.0;
+                r -= nphi;
+            }
+            xidx += (int64_t)q;
+            acc = r;
+        }
+    }
+};
+
+struct ArbArgs {
+    const void* x;
+    const void* hist;
+    void* y;
+    const void* pfbT;     // tp * Nphi, pfbT[i*Nphi + phi]
+    const void* dpfbT;
+    const int64_t* tab_x; // 1-based xIdx of output 64 b
+    const double* tab_acc;
+    int64_t xlen, ldx, ldy, nout;
+    ArbStep step;
+    int nphi, tp, hl;
+    int tile;             // outputs per workgroup (multiple of ARB_BLK)
+    int span;             // staged samples per tile (0: read [history ; x] straight from global/L2)
+    int taps_in_lds;
+};
+
+struct ArbRec {
+    int xrel;             // xIdx - xIdx(first output of the tile)
+    int phi;              // 0-based phase
+    double alpha;
+};
+
+template <typename XS, typename A, typename R>
+__global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ArbRec* rec = reinterpret_cast<ArbRec*>(smem);
+    A* zs = reinterpret_cast<A*>(smem + (size_t)a.tile * sizeof(ArbRec));
+    R* ps = reinterpret_cast<R*>(smem + (size_t)a.tile * sizeof(ArbRec) + (size_t)a.span * sizeof(A));
+    const int64_t ch = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * a.tile;
+    if (m0 >= a.nout) return;
+    const int cnt = (int)std::min<int64_t>(a.tile, a.nout - m0);
+    const int64_t b0 = m0 / ARB_BLK;
+    const int64_t x_first = a.tab_x[b0];
+    // phase A: replay the recurrence from the host anchors, one lane per 64 outputs
+    if ((int)threadIdx.x * ARB_BLK < cnt) {
+        int64_t xi = a.tab_x[b0 + threadIdx.x];
+        double acc = a.tab_acc[b0 + threadIdx.x];
+        const int base = threadIdx.x * ARB_BLK;
+        const int n = min(ARB_BLK, cnt - base);
+        for (int k = 0; k < n; ++k) {
+            const double fl = floor(acc);
+            rec[base + k] = {(int)(xi - x_first), (int)fl, acc - fl};   // alpha = modf(acc)[1] is exact
+            a.step(acc, xi);
+        }
+    }
+    const R* pf = static_cast<const R*>(a.pfbT);
+    const R* dpf = static_cast<const R*>(a.dpfbT);
+    if (a.taps_in_lds) {
+        const int np = a.tp * a.nphi;
+        for (int k = threadIdx.x; k < np; k += blockDim.x) {
+            ps[k] = pf[k];
+            ps[np + k] = dpf[k];
+        }
+        pf = ps;
+        dpf = ps + np;
+    }
+    __syncthreads();
+    const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
+    const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
+    const int64_t z_first = x_first - 1;                                    // z = [history ; x], output n reads z[n-1 .. n-1+tp)
+    const int64_t nz = (int64_t)rec[cnt - 1].xrel + a.tp;
+    const bool staged = nz <= a.span;                                       // workgroup-uniform
+    auto zload = [&](int64_t zi) -> A {
+        A v{};
+        if (zi < a.hl) v = to_acc(hc[zi], (A*)nullptr);
+        else if (zi - a.hl < a.xlen) v = to_acc(xc[zi - a.hl], (A*)nullptr);
+        return v;
+    };
+    if (staged) {
+        for (int k = threadIdx.x; k < (int)nz; k += blockDim.x) zs[k] = zload(z_first + k);
+        __syncthreads();
+    }
+    A* yc = static_cast<A*>(a.y) + ch * a.ldy;
+    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+        const ArbRec rc = rec[j];
+        const R* hp = pf + rc.phi;
+        const R* dp = dpf + rc.phi;
+        A lo, up;
+        if (staged) {
+            const A* zp = zs + rc.xrel;
+            lo = mul_first(hp[0], zp[0]);
+            up = mul_first(dp[0], zp[0]);
+            for (int i = 1; i < a.tp; ++i) {
+                fma_acc(lo, hp[(int64_t)i * a.nphi], zp[i]);
+                fma_acc(up, dp[(int64_t)i * a.nphi], zp[i]);
+            }
+        } else {
+            const int64_t z0 = z_first + rc.xrel;
+            A z = zload(z0);
+            lo = mul_first(hp[0], z);
+            up = mul_first(dp[0], z);
+            for (int i = 1; i < a.tp; ++i) {
+                z = zload(z0 + i);
+                fma_acc(lo, hp[(int64_t)i * a.nphi], z);
+                fma_acc(up, dp[(int64_t)i * a.nphi], z);
+            }
+        }
+        yc[m0 + j] = arb_combine(up, rc.alpha, lo);
+    }
+}
+
 }  // namespace
 
 struct mdsp_fir_s {
@@ -235,6 +384,23 @@ struct mdsp_fir_s {
     DevBuf pfbT;
     DevBuf hist[2];
     int cur = 0;
+};
+
+
+struct mdsp_firarb_s {
+    mdsp_fir_s base;          // history buffers, dtypes, tp / hl / nch (kind = 4)
+    double rate = 1.0, delta = 0.0;
+    int64_t nphi = 32;
+    // the reference's state (stream_filt.jl:96-104); phi_idx and alpha are functions of phi_acc
+    double phi_acc = 0.0;
+    int64_t input_deficit = 1, x_idx = 1;
+    DevBuf dpfbT;
+    DevBuf tab_x, tab_acc;
+    // trajectory cache: anchors of the last (phi_acc, input_deficit, xlen) evaluated
+    bool cache_valid = false;
+    double c_acc0 = 0.0;
+    int64_t c_def0 = 0, c_xlen = -1, c_nout = 0, c_def_end = 0, c_xidx_end = 0;
+    double c_acc_end = 0.0;
 };
 
 namespace {
@@ -539,6 +705,321 @@ int mdsp_fir_exec(mdsp_fir f, const void* x_dev, int64_t xlen, int64_t ldx, void
     if (f->kind == 1) f->input_deficit = 1;                              // :465
     else if (f->kind != 0) f->input_deficit = input_idx_end - xlen;      // :511, :554
     MDSP_TRY(shiftin_dispatch(f, x_dev, xlen, ldx, st));                 // :512
+    if (nwritten) *nwritten = nout;
+    return MDSP_OK;
+}
+
+// ---- FIRArbitrary host side ---------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// The loop of filt!(buffer, ::FIRFilter{FIRArbitrary}, x) (stream_filt.jl:593-622) without the dot products.
+// Anchors (xIdx, phiAcc) of outputs 0, blk, 2 blk, ... go to ax / aa when given.  Same IEEE operations as the
+// reference, so the trajectory -- and with it the output count and the final state -- is bit-exact.
+void arb_trajectory(double acc, int64_t deficit, const ArbStep& st, int64_t xlen, int64_t blk, std::vector<int64_t>* ax, std::vector<double>* aa,
+                    int64_t* nout, double* acc_end, int64_t* xidx_end) {
+    int64_t n = 0, xi = deficit;
+    while (xi <= xlen) {
+        if (ax && n % blk == 0) {
+            ax->push_back(xi);
+            aa->push_back(acc);
+        }
+        ++n;
+        st(acc, xi);
+    }
+    *nout = n;
+    *acc_end = acc;
+    *xidx_end = xi;
+}
+
+template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, ArbArgs& a, hipStream_t st) {
+    const int64_t taps_bytes = 2 * (int64_t)f->base.tp * f->nphi * (int64_t)sizeof(R);
+    a.taps_in_lds = taps_bytes <= 32 * 1024;
+    // outputs per workgroup: the tile's input span (tile * Delta / Nphi + tp samples) must fit 48 KiB of LDS
+    int tile = 1024;
+    int64_t span = 0;
+    while (true) {
+        span = (int64_t)std::ceil((double)tile * f->delta / (double)f->nphi) + f->base.tp + 4;
+        if (span * (int64_t)sizeof(A) <= 48 * 1024 || tile <= ARB_BLK) break;
+        tile /= 2;
+    }
+    if (span * (int64_t)sizeof(A) > 48 * 1024) span = 0;   // very low rates: outputs are far apart, read through L2 instead
+    a.tile = tile;
+    a.span = (int)span;
+    const size_t lds_bytes = (size_t)tile * sizeof(ArbRec) + (size_t)span * sizeof(A) + (a.taps_in_lds ? (size_t)taps_bytes : 0);
+    auto kern = arbitrary_fir_kernel<XS, A, R>;
+    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const dim3 grid((unsigned)cdiv(a.nout, tile), (unsigned)f->base.nch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+int arb_dispatch(mdsp_firarb_s* f, ArbArgs& a, hipStream_t st) {
+    const bool d = f->base.acc_double;
+    switch (f->base.x_dtype) {
+        case MDSP_F32: return d ? arb_launch<float, double, double>(f, a, st) : arb_launch<float, float, float>(f, a, st);
+        case MDSP_F64: return arb_launch<double, double, double>(f, a, st);
+        case MDSP_C32: return d ? arb_launch<cx<float>, cx<double>, double>(f, a, st) : arb_launch<cx<float>, cx<float>, float>(f, a, st);
+        default: return arb_launch<cx<double>, cx<double>, double>(f, a, st);
+    }
+}
+
+int upload_bank(DevBuf& buf, const std::vector<double>& pd, bool as_double) {
+    if (as_double) {
+        MDSP_TRY(buf.reserve(sizeof(double) * pd.size()));
+        MDSP_HIP(hipMemcpy(buf.p, pd.data(), sizeof(double) * pd.size(), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> pf(pd.size());
+        for (size_t i = 0; i < pd.size(); ++i) pf[i] = (float)pd[i];
+        MDSP_TRY(buf.reserve(sizeof(float) * pf.size()));
+        MDSP_HIP(hipMemcpy(buf.p, pf.data(), sizeof(float) * pf.size(), hipMemcpyHostToDevice));
+    }
+    return MDSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdsp_arb_trajectory(double phi_acc, int64_t input_deficit, double rate, int64_t nphi, int64_t xlen, int64_t block, int64_t* anchors_x,
+                        double* anchors_acc, int64_t anchors_cap, int64_t* nout, double* phi_acc_end, int64_t* input_deficit_end) {
+    if (!(rate > 0.0) || nphi < 1 || xlen < 0 || input_deficit < 1 || block < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid trajectory arguments");
+    if (!nout || !phi_acc_end || !input_deficit_end) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL result pointer");
+    if (xlen < input_deficit) {   // stream_filt.jl:586-590
+        *nout = 0;
+        *phi_acc_end = phi_acc;
+        *input_deficit_end = input_deficit - xlen;
+        return MDSP_OK;
+    }
+    const double delta = (double)nphi / rate;
+    const ArbStep st{delta, (double)nphi, 1.0 / (double)nphi};
+    std::vector<int64_t> ax;
+    std::vector<double> aa;
+    int64_t xe = 0;
+    arb_trajectory(phi_acc, input_deficit, st, xlen, block, anchors_x ? &ax : nullptr, anchors_x ? &aa : nullptr, nout, phi_acc_end, &xe);
+    *input_deficit_end = xe - xlen;
+    if (anchors_x) {
+        if ((int64_t)ax.size() > anchors_cap || !anchors_acc) MDSP_FAIL(MDSP_ERR_ARGUMENT, "anchor buffers too small: need %lld", (long long)ax.size());
+        std::copy(ax.begin(), ax.end(), anchors_x);
+        std::copy(aa.begin(), aa.end(), anchors_acc);
+    }
+    return MDSP_OK;
+}
+
+int mdsp_firarb_create(mdsp_firarb* fo, const void* taps_host, int64_t hlen, double rate, int64_t nphi, int taps_dtype, int x_dtype, int64_t nch) {
+    if (!fo) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle pointer is NULL");
+    *fo = nullptr;
+    if (!(rate > 0.0)) MDSP_FAIL(MDSP_ERR_DOMAIN, "rate must be greater than 0");          // stream_filt.jl:151
+    if (!taps_host || hlen < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "filter taps must be non-empty");
+    if (nphi < 1 || nphi > (int64_t(1) << 20)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "Nphi must be in [1, 2^20]");
+    if (taps_dtype != MDSP_F32 && taps_dtype != MDSP_F64) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "only real Float32/Float64 taps are supported on the device");
+    if (!dtype_valid(x_dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid x dtype");
+    if (nch < 1 || nch > 65535) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nch must be in [1, 65535]");
+    std::unique_ptr<mdsp_firarb_s> f(new mdsp_firarb_s());
+    mdsp_fir_s& b = f->base;
+    b.kind = 4;
+    b.L = nphi;
+    b.M = 1;
+    b.hlen = hlen;
+    b.nch = nch;
+    b.taps_dtype = taps_dtype;
+    b.x_dtype = x_dtype;
+    b.tp = cdiv(hlen, nphi);
+    b.hl = b.tp - 1;
+    b.acc_double = (taps_dtype == MDSP_F64) || dtype_is_double(x_dtype);
+    b.out_dtype = dtype_is_complex(x_dtype) ? (b.acc_double ? MDSP_C64 : MDSP_C32) : (b.acc_double ? MDSP_F64 : MDSP_F32);
+    f->rate = rate;
+    f->nphi = nphi;
+    f->delta = (double)nphi / rate;                                                         // :114
+    // dh = [diff(h); 0] in the taps' own precision (:107), both banks through taps2pfb (:108-109, :294-307)
+    const size_t np = (size_t)(b.tp * nphi);
+    std::vector<double> pd(np, 0.0), dd(np, 0.0);
+    auto tap = [&](int64_t i) -> double { return taps_dtype == MDSP_F32 ? (double)((const float*)taps_host)[i] : ((const double*)taps_host)[i]; };
+    auto dtap = [&](int64_t i) -> double {
+        if (i + 1 >= hlen) return 0.0;
+        if (taps_dtype == MDSP_F32) return (double)(((const float*)taps_host)[i + 1] - ((const float*)taps_host)[i]);
+        return ((const double*)taps_host)[i + 1] - ((const double*)taps_host)[i];
+    };
+    for (int64_t row = 0; row < b.tp; ++row)
+        for (int64_t col = 0; col < nphi; ++col) {
+            const int64_t hidx = (b.tp - 1 - row) * nphi + col;
+            if (hidx < hlen) {
+                pd[(size_t)(row * nphi + col)] = tap(hidx);
+                dd[(size_t)(row * nphi + col)] = dtap(hidx);
+            }
+        }
+    MDSP_TRY(upload_bank(b.pfbT, pd, b.acc_double));
+    MDSP_TRY(upload_bank(f->dpfbT, dd, b.acc_double));
+    const size_t hbytes = dtype_size(x_dtype) * (size_t)std::max<int64_t>(1, b.hl) * (size_t)nch;
+    for (int k = 0; k < 2; ++k) {
+        MDSP_TRY(b.hist[k].reserve(hbytes));
+        MDSP_HIP(hipMemset(b.hist[k].p, 0, hbytes));
+    }
+    *fo = f.release();
+    return MDSP_OK;
+}
+
+int mdsp_firarb_destroy(mdsp_firarb f) {
+    delete f;
+    return MDSP_OK;
+}
+
+int mdsp_firarb_reset(mdsp_firarb f) {   // reset! stream_filt.jl:260-276
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    const mdsp_fir_s& b = f->base;
+    MDSP_HIP(hipMemset(b.hist[b.cur].p, 0, dtype_size(b.x_dtype) * (size_t)std::max<int64_t>(1, b.hl) * (size_t)b.nch));
+    f->phi_acc = 0.0;
+    f->input_deficit = 1;
+    f->x_idx = 1;
+    return MDSP_OK;
+}
+
+int mdsp_firarb_setphase(mdsp_firarb f, double phi) {   // setphase! :231-239
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (!(phi >= 0)) MDSP_FAIL(MDSP_ERR_DOMAIN, "phi must be >= 0");
+    double whole = 0.0;
+    const double frac = std::modf(phi, &whole);
+    f->input_deficit += round_half_even(whole);
+    f->phi_acc = frac * (double)f->nphi;
+    return MDSP_OK;
+}
+
+int mdsp_firarb_timedelay(mdsp_firarb f, double* tau) {   // :400-401
+    if (!f || !tau) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    *tau = (double)(f->base.hlen - 1) / (double)(2 * f->nphi);
+    return MDSP_OK;
+}
+
+int mdsp_firarb_outputlength(mdsp_firarb f, int64_t inputlength, int64_t* outlen) {   // :340-342
+    if (!f || !outlen) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    const double a = (double)(inputlength - f->input_deficit + 1) * f->rate;   // separate statements: no contraction
+    const double b = f->phi_acc / f->delta;
+    const double c = a - b;
+    *outlen = (int64_t)std::ceil(c);
+    return MDSP_OK;
+}
+
+int mdsp_firarb_inputlength(mdsp_firarb f, int64_t outputlength, int round_up, int64_t* inlen) {   // :385-389
+    if (!f || !inlen) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    const int64_t d = round_up ? 1 : 0;
+    const double b = f->phi_acc / f->delta;
+    const double s = (double)(outputlength - d) + b;
+    const double q = s / f->rate;
+    *inlen = (int64_t)std::floor(q) + d + f->input_deficit - 1;
+    return MDSP_OK;
+}
+
+int mdsp_firarb_info(mdsp_firarb f, int64_t* nphi, int64_t* taps_per_phase, int64_t* history_len, int* out_dtype, double* delta) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (nphi) *nphi = f->nphi;
+    if (taps_per_phase) *taps_per_phase = f->base.tp;
+    if (history_len) *history_len = f->base.hl;
+    if (out_dtype) *out_dtype = f->base.out_dtype;
+    if (delta) *delta = f->delta;
+    return MDSP_OK;
+}
+
+int mdsp_firarb_get_state(mdsp_firarb f, double* phi_acc, double* alpha, int64_t* phi_idx, int64_t* input_deficit, int64_t* x_idx,
+                          void* history_host) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    const double fl = std::floor(f->phi_acc);
+    if (phi_acc) *phi_acc = f->phi_acc;
+    if (alpha) *alpha = f->phi_acc - fl;               // modf(phiAcc)[1]  (:576, :238)
+    if (phi_idx) *phi_idx = 1 + (int64_t)fl;           // 1 + Int(foffset) (:577, :237)
+    if (input_deficit) *input_deficit = f->input_deficit;
+    if (x_idx) *x_idx = f->x_idx;
+    const mdsp_fir_s& b = f->base;
+    if (history_host && b.hl > 0) {
+        MDSP_HIP(hipDeviceSynchronize());
+        MDSP_HIP(hipMemcpy(history_host, b.hist[b.cur].p, dtype_size(b.x_dtype) * (size_t)b.hl * (size_t)b.nch, hipMemcpyDeviceToHost));
+    }
+    return MDSP_OK;
+}
+
+int mdsp_firarb_set_state(mdsp_firarb f, double phi_acc, int64_t input_deficit, const void* history_host) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (!(phi_acc >= 0.0) || !(phi_acc < (double)f->nphi) || input_deficit < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "state out of range");
+    f->phi_acc = phi_acc;
+    f->input_deficit = input_deficit;
+    const mdsp_fir_s& b = f->base;
+    if (history_host && b.hl > 0) {
+        MDSP_HIP(hipDeviceSynchronize());
+        MDSP_HIP(hipMemcpy(b.hist[b.cur].p, history_host, dtype_size(b.x_dtype) * (size_t)b.hl * (size_t)b.nch, hipMemcpyHostToDevice));
+    }
+    return MDSP_OK;
+}
+
+int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx, void* y_dev, int64_t ycap, int64_t ldy, int64_t* nwritten,
+                     void* stream) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (xlen < 0 || ycap < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    mdsp_fir_s& b = f->base;
+    if (b.nch > 1 && ldx < xlen) MDSP_FAIL(MDSP_ERR_ARGUMENT, "ldx smaller than xlen");
+    hipStream_t st = as_stream(stream);
+    if (nwritten) *nwritten = 0;
+    if (xlen < f->input_deficit) {   // stream_filt.jl:586-590
+        MDSP_TRY(shiftin_dispatch(&b, x_dev, xlen, ldx, st));
+        f->input_deficit -= xlen;
+        return MDSP_OK;
+    }
+    const ArbStep step{f->delta, (double)f->nphi, 1.0 / (double)f->nphi};
+    const bool hit = f->cache_valid && f->c_acc0 == f->phi_acc && f->c_def0 == f->input_deficit && f->c_xlen == xlen;
+    if (!hit) {
+        std::vector<int64_t> ax;
+        std::vector<double> aa;
+        ax.reserve((size_t)((double)xlen * f->rate / ARB_BLK) + 16);
+        aa.reserve(ax.capacity());
+        int64_t nout = 0, xe = 0;
+        double ae = 0.0;
+        arb_trajectory(f->phi_acc, f->input_deficit, step, xlen, ARB_BLK, &ax, &aa, &nout, &ae, &xe);
+        f->cache_valid = false;
+        MDSP_TRY(f->tab_x.reserve(sizeof(int64_t) * std::max<size_t>(1, ax.size())));
+        MDSP_TRY(f->tab_acc.reserve(sizeof(double) * std::max<size_t>(1, aa.size())));
+        MDSP_HIP(hipStreamSynchronize(st));   // a previous launch on this stream may still read the anchor tables
+        if (!ax.empty()) {
+            MDSP_HIP(hipMemcpy(f->tab_x.p, ax.data(), sizeof(int64_t) * ax.size(), hipMemcpyHostToDevice));
+            MDSP_HIP(hipMemcpy(f->tab_acc.p, aa.data(), sizeof(double) * aa.size(), hipMemcpyHostToDevice));
+        }
+        f->c_acc0 = f->phi_acc;
+        f->c_def0 = f->input_deficit;
+        f->c_xlen = xlen;
+        f->c_nout = nout;
+        f->c_acc_end = ae;
+        f->c_xidx_end = xe;
+        f->c_def_end = xe - xlen;
+        f->cache_valid = true;
+    }
+    const int64_t nout = f->c_nout;
+    // the reference indexes buffer[bufIdx] unchecked beyond allocate_output's outputlength + 1 (:639-655): a short
+    // buffer is a BoundsError there, an ArgumentError here -- raised before anything is written
+    if (ycap < nout) MDSP_FAIL(MDSP_ERR_ARGUMENT, "buffer is too small: need %lld, have %lld", (long long)nout, (long long)ycap);
+    if (b.nch > 1 && ldy < nout) MDSP_FAIL(MDSP_ERR_ARGUMENT, "ldy smaller than the output length");
+    if (nout > 0) {
+        if (!x_dev || !y_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+        ArbArgs a{};
+        a.x = x_dev;
+        a.hist = b.hist[b.cur].p;
+        a.y = y_dev;
+        a.pfbT = b.pfbT.p;
+        a.dpfbT = f->dpfbT.p;
+        a.tab_x = f->tab_x.as<int64_t>();
+        a.tab_acc = f->tab_acc.as<double>();
+        a.xlen = xlen;
+        a.ldx = ldx;
+        a.ldy = ldy;
+        a.nout = nout;
+        a.step = step;
+        a.nphi = (int)f->nphi;
+        a.tp = (int)b.tp;
+        a.hl = (int)b.hl;
+        MDSP_TRY(arb_dispatch(f, a, st));
+    }
+    f->phi_acc = f->c_acc_end;
+    f->x_idx = f->c_xidx_end;
+    f->input_deficit = f->c_def_end;                                       // :619
+    MDSP_TRY(shiftin_dispatch(&b, x_dev, xlen, ldx, st));                  // :620
     if (nwritten) *nwritten = nout;
     return MDSP_OK;
 }

@@ -108,22 +108,45 @@ class FIRFilter:
     """``FIRFilter(h, ratio=1)``: single-rate / interpolating / decimating / rational polyphase FIR with persistent
     state (``phi_idx``, ``input_deficit``, ``history``), exactly the reference's (stream_filt.jl:8-79, :137-178).
 
-    The kernel object lives in libmi355dsp (``mdsp_fir``); it is created at the first ``filt`` call, when the signal
-    eltype and channel count are known.  ``FIRFilter(h, rate::Float64)`` (FIRArbitrary) is not accelerated yet.
+    The kernel object lives in libmi355dsp (``mdsp_fir`` / ``mdsp_firarb``); it is created at the first ``filt`` call,
+    when the signal eltype and channel count are known.
+
+    ``FIRFilter(h, rate::float, Nphi=32)`` is the arbitrary-rate resampler (FIRArbitrary, stream_filt.jl:92-156): state
+    ``phi_accumulator`` (Float64), ``phi_idx``, ``alpha``, ``input_deficit``, ``x_idx``.
     """
 
-    KINDS = ("FIRStandard", "FIRInterpolator", "FIRDecimator", "FIRRational")
+    KINDS = ("FIRStandard", "FIRInterpolator", "FIRDecimator", "FIRRational", "FIRArbitrary")
 
-    def __init__(self, h, ratio=1):
-        if isinstance(ratio, float):
-            if not ratio > 0.0:
-                raise DomainError("rate must be greater than 0")
-            raise UnsupportedError("FIRArbitrary (floating-point rate) is not accelerated; SURVEY section 8(f)")
+    def __init__(self, h, ratio=1, Nphi: int = 32):
         self.h = _host_vec(h)
         if self.h.dtype.kind == "c":
             raise UnsupportedError("complex FIR taps are not accelerated")
         if self.h.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
             self.h = self.h.astype(np.float64)
+        self._handle = None
+        self._xdtype = None
+        self._nch = None
+        self._history_host = None     # pending history to push into a (re)created handle
+        if isinstance(ratio, (float, np.floating)):                 # FIRFilter(h, rate::AbstractFloat, Nphi) :150-156
+            rate = float(ratio)
+            if not rate > 0.0:
+                raise DomainError("rate must be greater than 0")
+            self.kind = 4
+            self.rate = rate
+            self.ratio = rate
+            self.hLen = len(self.h)
+            self.Nphi = int(Nphi)
+            if self.Nphi < 1:
+                raise ArgumentError("Nphi must be positive")
+            self.tapsPerphi = -(-self.hLen // self.Nphi)
+            self.historyLen = self.tapsPerphi - 1
+            self.delta = self.Nphi / rate                           # :114
+            self.phi_accumulator = 0.0
+            self.phi_idx = 1
+            self.alpha = 0.0
+            self.input_deficit = 1
+            self.x_idx = 1
+            return
         self.ratio = Fraction(ratio)
         if self.ratio <= 0:
             raise DomainError("resampling ratio must be positive")
@@ -135,15 +158,20 @@ class FIRFilter:
         self.historyLen = self.tapsPerphi - 1
         self.phi_idx = 1
         self.input_deficit = 1
-        self._handle = None
-        self._xdtype = None
-        self._nch = None
-        self._history_host = None     # pending history to push into a (re)created handle
 
     @classmethod
     def from_ratio(cls, ratio, *args):
-        """``FIRFilter(ratio, args...)`` (stream_filt.jl:207-210): taps from ``resample_filter(ratio, args...)``."""
+        """``FIRFilter(ratio, args...)`` (stream_filt.jl:207-210) / ``FIRFilter(rate::AbstractFloat, Nphi=32, args...)``
+        (:159-162): taps from ``resample_filter``."""
+        if isinstance(ratio, (float, np.floating)):
+            nphi = int(args[0]) if args else 32
+            return cls(design.resample_filter(float(ratio), nphi, *args[1:]), float(ratio), nphi)
         return cls(design.resample_filter(Fraction(ratio), *args), Fraction(ratio))
+
+    def _destroy_handle(self):
+        if self._handle:
+            (_lib.lib().mdsp_firarb_destroy if self.kind == 4 else _lib.lib().mdsp_fir_destroy)(self._handle)
+        self._handle = None
 
     # -- reference state API ------------------------------------------------------------------------------
     @property
@@ -155,22 +183,36 @@ class FIRFilter:
         self.phi_idx = 1
         self.input_deficit = 1
         self._history_host = None
+        if self.kind == 4:                                           # :260-267
+            self.phi_accumulator = 0.0
+            self.alpha = 0.0
+            self.x_idx = 1
+            if self._handle:
+                _lib.check(_lib.lib().mdsp_firarb_reset(self._handle))
+            return self
         if self._handle:
             _lib.check(_lib.lib().mdsp_fir_reset(self._handle))
         return self
 
     def timedelay(self) -> float:
         """stream_filt.jl:400-403."""
-        if self.kind in (1, 3):
+        if self.kind in (1, 3, 4):
             return (self.hLen - 1) / (2 * self.Nphi)
         return (self.hLen - 1) / 2
 
     def setphase(self, phi: float):
-        """``setphase!`` (stream_filt.jl:216-229); ``round`` is round-half-even as in Julia."""
+        """``setphase!`` (stream_filt.jl:216-241); ``round`` is round-half-even as in Julia."""
         if not phi >= 0:
             raise DomainError("phi must be >= 0")
         if self.kind == 0:
             raise TypeError("setphase! has no method for FIRStandard")
+        if self.kind == 4:                                           # :231-239
+            frac, throwaway = math.modf(phi)
+            self.input_deficit += round(throwaway)
+            self.phi_accumulator = frac * self.Nphi
+            self.phi_idx = 1 + math.floor(self.phi_accumulator)
+            self.alpha = math.modf(self.phi_accumulator)[0]
+            return
         if self.kind == 2:
             self.input_deficit += round(phi)
         else:
@@ -179,15 +221,20 @@ class FIRFilter:
             self.phi_idx = idx + 1
 
     def outputlength(self, inputlength_: int) -> int:
-        """stream_filt.jl:324-338."""
+        """stream_filt.jl:324-342."""
         if self.kind == 0:
             return int(inputlength_)
+        if self.kind == 4:                                           # :340-342 (no fused multiply-add: Python floats)
+            return math.ceil((inputlength_ - self.input_deficit + 1) * self.rate - self.phi_accumulator / self.delta)
         return outputlength(inputlength_ - self.input_deficit + 1, self.ratio, 1 if self.kind == 2 else self.phi_idx)
 
     def inputlength(self, outputlength_: int, round_up: bool = False) -> int:
-        """stream_filt.jl:366-383."""
+        """stream_filt.jl:366-389."""
         if self.kind == 0:
             return int(outputlength_)
+        if self.kind == 4:                                           # :385-389
+            d = 1 if round_up else 0
+            return math.floor((outputlength_ - d + self.phi_accumulator / self.delta) / self.rate) + d + self.input_deficit - 1
         return inputlength(outputlength_, self.ratio, 1 if self.kind == 2 else self.phi_idx, round_up) + self.input_deficit - 1
 
     @property
@@ -197,28 +244,38 @@ class FIRFilter:
             return np.zeros(self.historyLen) if self._history_host is None else self._history_host
         buf = np.zeros((self._nch, max(self.historyLen, 0)), dtype=self._xdtype)
         if self.historyLen > 0:
-            _lib.check(_lib.lib().mdsp_fir_get_state(self._handle, None, None, buf.ctypes.data_as(C.c_void_p)))
+            if self.kind == 4:
+                _lib.check(_lib.lib().mdsp_firarb_get_state(self._handle, None, None, None, None, None, buf.ctypes.data_as(C.c_void_p)))
+            else:
+                _lib.check(_lib.lib().mdsp_fir_get_state(self._handle, None, None, buf.ctypes.data_as(C.c_void_p)))
         return buf[0].copy() if self._nch == 1 else buf.T.copy()
 
     # -- device handle -------------------------------------------------------------------------------------
     def _ensure(self, xdtype: np.dtype, nch: int):
         if self._handle is not None and (self._xdtype != xdtype or self._nch != nch):
             hist = self.history
-            _lib.lib().mdsp_fir_destroy(self._handle)
-            self._handle = None
+            self._destroy_handle()
             self._history_host = hist.astype(xdtype) if (hist.ndim == 1 and nch == 1) or (hist.ndim == 2 and hist.shape[1] == nch) else None
         if self._handle is None:
             h = C.c_void_p()
             taps = np.ascontiguousarray(self.h)
-            _lib.check(_lib.lib().mdsp_fir_create(C.byref(h), taps.ctypes.data_as(C.c_void_p), len(taps), self.ratio.numerator,
-                                                  self.ratio.denominator, _dev.md_dtype(taps.dtype), _dev.md_dtype(xdtype), nch))
-            self._handle, self._xdtype, self._nch = h, np.dtype(xdtype), nch
             od = C.c_int()
-            _lib.check(_lib.lib().mdsp_fir_info(h, None, None, None, None, None, C.byref(od)))
+            if self.kind == 4:
+                _lib.check(_lib.lib().mdsp_firarb_create(C.byref(h), taps.ctypes.data_as(C.c_void_p), len(taps), self.rate, self.Nphi,
+                                                         _dev.md_dtype(taps.dtype), _dev.md_dtype(xdtype), nch))
+                _lib.check(_lib.lib().mdsp_firarb_info(h, None, None, None, C.byref(od), None))
+            else:
+                _lib.check(_lib.lib().mdsp_fir_create(C.byref(h), taps.ctypes.data_as(C.c_void_p), len(taps), self.ratio.numerator,
+                                                      self.ratio.denominator, _dev.md_dtype(taps.dtype), _dev.md_dtype(xdtype), nch))
+                _lib.check(_lib.lib().mdsp_fir_info(h, None, None, None, None, None, C.byref(od)))
+            self._handle, self._xdtype, self._nch = h, np.dtype(xdtype), nch
             self._outdtype = {_lib.F32: np.float32, _lib.F64: np.float64, _lib.C32: np.complex64, _lib.C64: np.complex128}[od.value]
             if self._history_host is not None and self.historyLen > 0:
                 hh = np.ascontiguousarray(np.atleast_2d(self._history_host.T if self._history_host.ndim == 2 else self._history_host), dtype=xdtype)
-                _lib.check(_lib.lib().mdsp_fir_set_state(h, self.phi_idx, self.input_deficit, hh.ctypes.data_as(C.c_void_p)))
+                if self.kind == 4:
+                    _lib.check(_lib.lib().mdsp_firarb_set_state(h, self.phi_accumulator, self.input_deficit, hh.ctypes.data_as(C.c_void_p)))
+                else:
+                    _lib.check(_lib.lib().mdsp_fir_set_state(h, self.phi_idx, self.input_deficit, hh.ctypes.data_as(C.c_void_p)))
             self._history_host = None
 
     def filt(self, x):
@@ -229,6 +286,8 @@ class FIRFilter:
         cols, shape = _dev.to_columns(x, W)
         nch, xlen = cols.shape
         self._ensure(W, max(nch, 1))
+        if self.kind == 4:
+            return self._filt_arbitrary(cols, shape, x, nch, xlen)
         _lib.check(_lib.lib().mdsp_fir_set_state(self._handle, self.phi_idx, self.input_deficit, None))
         ycap = max(self.outputlength(xlen), 0) if xlen >= self.input_deficit or self.kind == 0 else 0
         out = _dev.empty_columns(nch, ycap, self._outdtype)
@@ -242,17 +301,31 @@ class FIRFilter:
             raise AssertionError("Length of resampled output different from expectation.")     # stream_filt.jl:634
         return _dev.from_columns(out, shape, x)
 
+    def _filt_arbitrary(self, cols, shape, x, nch, xlen):
+        """``filt(self::FIRFilter{FIRArbitrary}, x)`` (stream_filt.jl:627-637): the buffer holds outputlength + 1 samples
+        (allocate_output :639-655) and is resized to the number actually written."""
+        L = _lib.lib()
+        _lib.check(L.mdsp_firarb_set_state(self._handle, self.phi_accumulator, self.input_deficit, None))
+        ycap = max(self.outputlength(xlen), 0) + 1
+        out = _dev.empty_columns(nch, ycap, self._outdtype)
+        nw = C.c_int64(0)
+        _lib.check(L.mdsp_firarb_exec(self._handle, _dev.ptr(cols), xlen, xlen, _dev.ptr(out), ycap, ycap, C.byref(nw), _dev.stream_ptr()))
+        acc, al = C.c_double(), C.c_double()
+        phi, dfc, xi = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(L.mdsp_firarb_get_state(self._handle, C.byref(acc), C.byref(al), C.byref(phi), C.byref(dfc), C.byref(xi), None))
+        self.phi_accumulator, self.alpha, self.phi_idx, self.input_deficit, self.x_idx = acc.value, al.value, phi.value, dfc.value, xi.value
+        return _dev.from_columns(out[:, :nw.value], (nw.value,) + tuple(shape[1:]), x)
+
     def __del__(self):
         try:
-            if self._handle:
-                _lib.lib().mdsp_fir_destroy(self._handle)
+            self._destroy_handle()
         except Exception:
             pass
 
 
-def filt_stateless(h, x, ratio=1):
-    """``filt(h, x, ratio)`` (stream_filt.jl:663-666)."""
-    return FIRFilter(h, ratio).filt(x)
+def filt_stateless(h, x, ratio=1, Nphi: int = 32):
+    """``filt(h, x, ratio)`` (stream_filt.jl:663-666) / ``filt(h, x, rate::AbstractFloat, Nphi=32)`` (:669-672)."""
+    return FIRFilter(h, ratio, Nphi).filt(x)
 
 
 def _undelay(sf: FIRFilter):
@@ -261,19 +334,24 @@ def _undelay(sf: FIRFilter):
         sf.setphase(sf.timedelay())
 
 
-def resample(x, rate, h=None, dims: int | None = None):
-    """``resample(x, rate[, h]; dims)`` (stream_filt.jl:688-775) for integer / rational rates.
+def resample(x, rate, h=None, dims: int | None = None, Nphi: int = 32):
+    """``resample(x, rate[, h]; dims)`` (stream_filt.jl:688-775): integer / rational rates (polyphase FIRRational &
+    co.) and floating-point rates (``FIRArbitrary`` with ``Nphi`` phases, :692-694, :752-755).
 
     Vector ``x``: delay-compensated polyphase resampling to ceil(length(x)*rate) samples.  Array ``x`` with
     ``dims``: every slice along ``dims`` is resampled independently (``mapslices``) -- on the device all slices are
     channels of one launch, each starting from the same reset + undelay!-ed state (:768-774).
     """
-    if isinstance(rate, float):
-        raise UnsupportedError("arbitrary-rate resampling (FIRArbitrary) is not accelerated; SURVEY section 8(f)")
-    rate = Fraction(rate)
-    if h is None:
-        h = design.resample_filter(rate)
-    sf = FIRFilter(h, rate)
+    if isinstance(rate, (float, np.floating)):
+        rate = float(rate)
+        if h is None:
+            h = design.resample_filter(rate, Nphi)
+        sf = FIRFilter(h, rate, Nphi)
+    else:
+        rate = Fraction(rate)
+        if h is None:
+            h = design.resample_filter(rate)
+        sf = FIRFilter(h, rate)
     _undelay(sf)
     nd = len(x.shape)
     if nd == 1:
@@ -285,7 +363,7 @@ def resample(x, rate, h=None, dims: int | None = None):
         axis = dims % nd
         moved = (x.movedim(axis, 0) if hasattr(x, "movedim") else np.moveaxis(np.asarray(x), axis, 0))
         n = int(moved.shape[0])
-    out_len = math.ceil(n * rate)                                    # :698 / :762 (exact rational arithmetic)
+    out_len = math.ceil(n * rate)                                    # :698 / :762 (exact rational, or Float64 product)
     npad = sf.inputlength(out_len, round_up=True)                    # :699 / :763
     if npad < n:
         raise ArgumentError("padded length shorter than the input")   # copyto! would throw in the reference

@@ -183,6 +183,40 @@ int mdsp_fir_exec(mdsp_fir f, const void* x_dev, int64_t xlen, int64_t ldx, void
                   int64_t ldy, int64_t* nwritten, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Arbitrary-rate resampler (FIRFilter{FIRArbitrary}: rate::AbstractFloat, Nphi phases, linear interpolation
+ * between neighbouring phases through the derivative bank)
+ *   replaces FIRArbitrary / FIRFilter(h, rate, Nphi) (stream_filt.jl:92-156), update! (:567-577) and
+ *   filt!(buffer, ::FIRFilter{FIRArbitrary}, x) (:579-625).  The Float64 phase-accumulator recurrence is evaluated
+ *   with the reference's own IEEE operations (host, once per call, shared by all channels), so the number of
+ *   samples written and the state after every chunk are bit-exact; the dot products run on the device.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct mdsp_firarb_s* mdsp_firarb;
+int mdsp_firarb_create(mdsp_firarb* f, const void* taps_host, int64_t hlen, double rate, int64_t nphi, int taps_dtype,
+                       int x_dtype, int64_t nch);
+int mdsp_firarb_destroy(mdsp_firarb f);
+int mdsp_firarb_reset(mdsp_firarb f);                     /* reset!      stream_filt.jl:260-276 */
+int mdsp_firarb_setphase(mdsp_firarb f, double phi);      /* setphase!   :231-239 */
+int mdsp_firarb_timedelay(mdsp_firarb f, double* tau);    /* timedelay   :400-401 */
+int mdsp_firarb_outputlength(mdsp_firarb f, int64_t inputlength, int64_t* outlen);              /* :340-342 */
+int mdsp_firarb_inputlength(mdsp_firarb f, int64_t outputlength, int round_up, int64_t* inlen); /* :385-389 */
+int mdsp_firarb_info(mdsp_firarb f, int64_t* nphi, int64_t* taps_per_phase, int64_t* history_len, int* out_dtype,
+                     double* delta);
+/* the reference's state: phiAccumulator, alpha = frac(phiAccumulator), phiIdx = 1 + trunc(phiAccumulator) (1-based),
+ * inputDeficit, xIdx (1-based), history (history_len, nch) of x_dtype */
+int mdsp_firarb_get_state(mdsp_firarb f, double* phi_acc, double* alpha, int64_t* phi_idx, int64_t* input_deficit,
+                          int64_t* x_idx, void* history_host);
+int mdsp_firarb_set_state(mdsp_firarb f, double phi_acc, int64_t input_deficit, const void* history_host);
+/* y_dev: (ycap, nch); ycap must hold every sample the loop writes (outputlength(...) + 1 always suffices, which is
+ * what allocate_output reserves, :639-655).  *nwritten = samplesWritten. */
+int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx, void* y_dev, int64_t ycap,
+                     int64_t ldy, int64_t* nwritten, void* stream);
+/* Pure host function (no device): the index trajectory of the loop above.  Writes the (xIdx, phiAccumulator) of
+ * outputs 0, block, 2*block, ... into anchors_* (may be NULL), the number of outputs and the final state. */
+int mdsp_arb_trajectory(double phi_acc, int64_t input_deficit, double rate, int64_t nphi, int64_t xlen, int64_t block,
+                        int64_t* anchors_x, double* anchors_acc, int64_t anchors_cap, int64_t* nout,
+                        double* phi_acc_end, int64_t* input_deficit_end);
+
+/* ------------------------------------------------------------------------------------------------------
  * Time-domain FIR (filt(b, a::Number, x) and the nb <= 66 branch of filt(b, x)):
  *   replaces _filt_fir! (dspbase.jl:95-105,118-141).  Zero initial state, per column.
  *   taps_host: nb REAL taps in the real precision of `dtype` (float for MDSP_F32/C32, double for F64/C64);

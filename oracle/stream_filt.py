@@ -45,10 +45,11 @@ def inputlength_ratio(outputlength: int, ratio: Fraction, initial_phi: int, roun
 class FIRFilter:
     """stream_filt.jl:137-210 with kernels FIRStandard/FIRInterpolator/FIRDecimator/FIRRational (:8-79)."""
 
-    def __init__(self, h, ratio=1):
+    def __init__(self, h, ratio=1, nphi: int = 32):
         h = np.asarray(h)
-        if isinstance(ratio, float):
-            raise NotImplementedError("FIRArbitrary is outside the oracle's scope (SURVEY section 8f)")
+        if isinstance(ratio, (float, np.floating)):
+            self._init_arbitrary(h, float(ratio), int(nphi))
+            return
         ratio = Fraction(ratio)
         self.h = h
         self.ratio = ratio
@@ -79,24 +80,67 @@ class FIRFilter:
             self.history_len = self.taps_per_phi - 1
         self.history = np.zeros(self.history_len, dtype=np.float64)  # :175
 
+    def _init_arbitrary(self, h, rate: float, nphi: int):
+        """FIRArbitrary(h, rate, Nphi) stream_filt.jl:106-134 and FIRFilter(h, rate::AbstractFloat, Nphi) :150-156."""
+        if not rate > 0.0:
+            raise ValueError("DomainError: rate must be greater than 0")      # :151
+        self.kind = "arbitrary"
+        self.h = h
+        self.rate = rate
+        self.ratio = rate
+        self.hlen = len(h)
+        dh = np.concatenate([np.diff(h), np.zeros(1, dtype=h.dtype)]).astype(h.dtype)   # :107 (in eltype(h))
+        self.pfb = taps2pfb(h, nphi)                  # :108
+        self.dpfb = taps2pfb(dh, nphi)                # :109
+        self.taps_per_phi, self.nphi = self.pfb.shape
+        self.phi_acc = 0.0
+        self.phi_idx = 1
+        self.alpha = 0.0
+        self.delta = nphi / rate                      # :114
+        self.input_deficit = 1
+        self.x_idx = 1
+        self.history_len = self.taps_per_phi - 1      # :153
+        self.history = np.zeros(self.history_len, dtype=np.float64)
+
+    def _arb_update(self):
+        """update! stream_filt.jl:567-577."""
+        self.phi_acc += self.delta
+        if self.phi_acc >= self.nphi:
+            dx, self.phi_acc = divmod(self.phi_acc, float(self.nphi))   # both operands positive: divrem == divmod
+            self.x_idx += int(dx)
+        foffset = math.floor(self.phi_acc)
+        self.alpha = self.phi_acc - foffset           # modf: exact fractional part
+        self.phi_idx = 1 + int(foffset)
+
     # -- state -------------------------------------------------------------------------------
     def reset(self):
         """stream_filt.jl:247-276."""
         self.history = np.zeros(self.history_len, dtype=self.history.dtype)
         self.phi_idx = 1
         self.input_deficit = 1
+        if self.kind == "arbitrary":                  # :260-267
+            self.phi_acc = 0.0
+            self.alpha = 0.0
+            self.x_idx = 1
         return self
 
     def timedelay(self) -> float:
         """stream_filt.jl:400-403."""
-        if self.kind in ("rational", "interpolator"):
+        if self.kind in ("rational", "interpolator", "arbitrary"):
             return (self.hlen - 1) / (2 * self.nphi)
         return (self.hlen - 1) / 2
 
     def setphase(self, phi: float):
-        """stream_filt.jl:216-229 (``round`` is round-half-even in both Julia and Python)."""
+        """stream_filt.jl:216-241 (``round`` is round-half-even in both Julia and Python)."""
         if not phi >= 0:
             raise ValueError("DomainError: phi must be >= 0")
+        if self.kind == "arbitrary":                  # :231-239
+            frac, throwaway = math.modf(phi)
+            self.input_deficit += round(throwaway)
+            self.phi_acc = frac * self.nphi
+            self.phi_idx = 1 + math.floor(self.phi_acc)
+            self.alpha = math.modf(self.phi_acc)[0]
+            return
         if self.kind == "decimator":
             self.input_deficit += round(phi)
         elif self.kind in ("interpolator", "rational"):
@@ -109,9 +153,11 @@ class FIRFilter:
 
     # -- lengths -----------------------------------------------------------------------------
     def outputlength(self, inputlength: int) -> int:
-        """stream_filt.jl:324-338."""
+        """stream_filt.jl:324-342."""
         if self.kind == "standard":
             return inputlength
+        if self.kind == "arbitrary":                  # :340-342
+            return math.ceil((inputlength - self.input_deficit + 1) * self.rate - self.phi_acc / self.delta)
         if self.kind == "interpolator":
             return outputlength_ratio(inputlength - self.input_deficit + 1, Fraction(self.ratio.numerator), self.phi_idx)
         if self.kind == "decimator":
@@ -119,9 +165,13 @@ class FIRFilter:
         return outputlength_ratio(inputlength - self.input_deficit + 1, self.ratio, self.phi_idx)
 
     def inputlength(self, outputlength: int, roundup: bool = False) -> int:
-        """stream_filt.jl:366-383."""
+        """stream_filt.jl:366-389."""
         if self.kind == "standard":
             return outputlength
+        if self.kind == "arbitrary":                  # :385-389
+            d = 1 if roundup else 0
+            n = math.floor((outputlength - d + self.phi_acc / self.delta) / self.rate) + d
+            return n + self.input_deficit - 1
         if self.kind == "interpolator":
             n = inputlength_ratio(outputlength, Fraction(self.ratio.numerator), self.phi_idx, roundup)
         elif self.kind == "decimator":
@@ -154,6 +204,22 @@ class FIRFilter:
             self.history = shiftin(hist, x)
             self.input_deficit -= xlen
             return np.empty(0, dtype=T)
+        if self.kind == "arbitrary":                  # filt! :579-625, filt :627-637 (resize! to samplesWritten)
+            self.x_idx = self.input_deficit
+            out = []
+            wide = np.complex128 if np.dtype(T).kind == "c" else np.float64
+            while self.x_idx <= xlen:
+                if self.x_idx < self.taps_per_phi:
+                    ylo = unsafe_dot_mat_hist(self.pfb, self.phi_idx, hist, x, self.x_idx)
+                    yup = unsafe_dot_mat_hist(self.dpfb, self.phi_idx, hist, x, self.x_idx)
+                else:
+                    ylo = unsafe_dot_mat(self.pfb, self.phi_idx, x, self.x_idx)
+                    yup = unsafe_dot_mat(self.dpfb, self.phi_idx, x, self.x_idx)
+                out.append(wide(yup) * self.alpha + wide(ylo))      # muladd(yUpper, alpha::Float64, yLower) :616
+                self._arb_update()
+            self.input_deficit = self.x_idx - xlen
+            self.history = shiftin(hist, x)
+            return np.asarray(out, dtype=wide).astype(T) if out else np.empty(0, dtype=T)
         out_len = self.outputlength(xlen)
         buf = np.empty(out_len, dtype=T)
         buf_idx = 0
@@ -200,14 +266,52 @@ class FIRFilter:
         return buf
 
 
-def filt_stateless(h, x, ratio=1):
-    """stream_filt.jl:663-666."""
-    return FIRFilter(h, ratio).filt(x)
+def filt_stateless(h, x, ratio=1, nphi: int = 32):
+    """stream_filt.jl:663-672."""
+    return FIRFilter(h, ratio, nphi).filt(x)
 
 
-def resample(x, rate, h=None):
-    """stream_filt.jl:688-725 for vectors; ``rate`` int / Fraction."""
+def arb_trajectory(phi_acc: float, input_deficit: int, delta: float, nphi: int, xlen: int):
+    """Index trajectory of filt!(buffer, ::FIRFilter{FIRArbitrary}, x) (stream_filt.jl:593-622) without the dot
+    products: returns (x_idx[], phi_acc[]) of every output plus the final (phi_acc, input_deficit)."""
+    xs, accs = [], []
+    if xlen < input_deficit:
+        return np.zeros(0, np.int64), np.zeros(0), phi_acc, input_deficit - xlen
+    x_idx = input_deficit
+    fn = float(nphi)
+    while x_idx <= xlen:
+        xs.append(x_idx)
+        accs.append(phi_acc)
+        phi_acc += delta
+        if phi_acc >= fn:
+            dx, phi_acc = divmod(phi_acc, fn)
+            x_idx += int(dx)
+    return np.asarray(xs, np.int64), np.asarray(accs), phi_acc, x_idx - xlen
+
+
+def resample_arbitrary(x, rate: float, h=None, nphi: int = 32):
+    """stream_filt.jl:692-704, 717-725 for an AbstractFloat rate."""
     x = np.asarray(x)
+    rate = float(rate)
+    if h is None:
+        h = design.resample_filter(rate, nphi)
+    sf = FIRFilter(h, rate, nphi)
+    sf.setphase(sf.timedelay())                                      # undelay!
+    out_len = math.ceil(len(x) * rate)
+    npad = sf.inputlength(out_len, roundup=True)
+    xp = np.zeros(npad, dtype=x.dtype)
+    xp[:min(len(x), npad)] = x[:npad]
+    y = sf.filt(xp)
+    if not len(y) >= out_len:
+        raise AssertionError("Resample output shorter than expected.")
+    return y[:out_len]
+
+
+def resample(x, rate, h=None, nphi: int = 32):
+    """stream_filt.jl:688-725 for vectors; ``rate`` int / Fraction (rational kernels) or float (FIRArbitrary)."""
+    x = np.asarray(x)
+    if isinstance(rate, (float, np.floating)):
+        return resample_arbitrary(x, float(rate), h, nphi)
     rate = Fraction(rate)
     if h is None:
         h = design.resample_filter(rate)

@@ -152,7 +152,74 @@ def test_argument_errors_raised_before_device_work():
         d.periodogram(np.ones(64), nfft=32)                           # periodograms.jl:397
     with pytest.raises(d.ArgumentError):
         d.conv(np.ones(300), np.ones(300), "quantum")                 # dspbase.jl:754
-    with pytest.raises(d.UnsupportedError):
-        d.FIRFilter(np.ones(8), 1.5)
+    with pytest.raises(d.DomainError):
+        d.FIRFilter(np.ones(8), -1.5)                                 # stream_filt.jl:151
+    with pytest.raises(d.DomainError):
+        d.FIRFilter(np.ones(64), 1.5).setphase(-0.5)                  # stream_filt.jl:232
     with pytest.raises(d.DomainError):
         d.FIRFilter(np.ones(8), 3).setphase(-1.0)                     # stream_filt.jl:224
+
+
+# ---- FIRArbitrary: host-side trajectory and length / phase arithmetic (no device needed) --------------------------
+def _c_trajectory(acc, deficit, rate, nphi, xlen, block=64):
+    import ctypes as C
+    lib = _lib.lib()
+    cap = int(xlen * rate / block) + 16
+    ax = (C.c_int64 * cap)()
+    aa = (C.c_double * cap)()
+    nout, dend, aend = C.c_int64(), C.c_int64(), C.c_double()
+    _lib.check(lib.mdsp_arb_trajectory(acc, deficit, rate, nphi, xlen, block, ax, aa, cap, C.byref(nout), C.byref(aend), C.byref(dend)))
+    na = -(-nout.value // block)
+    return np.array(ax[:na]), np.array(aa[:na]), nout.value, aend.value, dend.value
+
+
+@pytest.mark.parametrize("rate,nphi,acc0,def0,xlen", [
+    (1.1, 32, 0.0, 1, 5000), (0.9802414928649835, 32, 7.25, 3, 1822), (3.141592653589793, 32, 0.0, 1, 1000),
+    (1 / 55.55, 32, 11.0, 5, 35546), (0.012, 32, 0.0, 1, 1000), (2.5, 7, 3.5, 2, 777), (1e-3, 32, 0.0, 40, 50000),
+    (0.5, 32, 0.0, 1, 10), (1.7, 32, 0.0, 12, 5)])
+def test_arbitrary_trajectory_bit_exact_with_oracle(rate, nphi, acc0, def0, xlen):
+    """update! (stream_filt.jl:567-577) replayed by the library vs the oracle's literal loop: anchors, count, final state."""
+    from oracle import stream_filt as osf
+    xs, accs, acc_end, def_end = osf.arb_trajectory(acc0, def0, nphi / rate, nphi, xlen)
+    ax, aa, nout, aend, dend = _c_trajectory(acc0, def0, rate, nphi, xlen)
+    assert nout == len(xs)
+    assert aend == acc_end and dend == def_end           # bit-exact Float64 / integer state
+    assert np.array_equal(ax, xs[::64]) and np.array_equal(aa, accs[::64])
+
+
+def test_arbitrary_reference_length_regressions():
+    """test/resample.jl:96-101 (issue #317): output lengths of resample() at awkward arbitrary rates."""
+    from oracle import design as od
+
+    def resample_len(n, rate):
+        h = od.resample_filter(float(rate), 32)
+        f = d.FIRFilter(h, float(rate))
+        f.setphase(f.timedelay())
+        out_len = int(np.ceil(n * rate))
+        npad = f.inputlength(out_len, round_up=True)
+        _, _, nout, _, _ = _c_trajectory(f.phi_accumulator, f.input_deficit, rate, 32, npad)
+        assert nout >= out_len                             # checked_resample_output! (stream_filt.jl:722)
+        return out_len
+
+    assert resample_len(35546, 1 / 55.55) == 640
+    assert resample_len(1822, 0.9802414928649835) == 1786
+    assert resample_len(16_367_000 * 2, 10_000_000 / 16_367_000) == 20_000_000
+    assert resample_len(1000, 0.012) == 12
+
+
+def test_arbitrary_host_state_matches_oracle():
+    from oracle import stream_filt as osf
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal(640)
+    for rate, nphi in ((1.37, 32), (0.61, 32), (2.2, 20)):
+        o = osf.FIRFilter(h, rate, nphi)
+        p = d.FIRFilter(h, rate, nphi)
+        assert p.kernel == "FIRArbitrary" and p.tapsPerphi == o.taps_per_phi and p.historyLen == o.history_len
+        assert p.timedelay() == o.timedelay() and p.delta == o.delta
+        for phi in (0.0, 0.3, 9.984375, 17.5):
+            o.reset(); p.reset()
+            o.setphase(phi); p.setphase(phi)
+            assert (p.phi_accumulator, p.phi_idx, p.alpha, p.input_deficit) == (o.phi_acc, o.phi_idx, o.alpha, o.input_deficit)
+            for n in (0, 1, 17, 1000, 123457):
+                assert p.outputlength(n) == o.outputlength(n)
+                assert p.inputlength(n) == o.inputlength(n) and p.inputlength(n, round_up=True) == o.inputlength(n, roundup=True)

@@ -501,6 +501,89 @@ def test_firfilter_kernels_and_streaming_state(d, L, M):
     assert (f.phi_idx, f.input_deficit) == (1, 1) and not f.history.any()
 
 
+@pytest.mark.parametrize("rate,nphi", [(1.1, 32), (0.7364, 32), (3.141592653589793, 32), (0.012, 32), (1 / 55.55, 32), (2.2, 20), (0.002, 16)])
+def test_firarbitrary_vs_oracle_and_streaming_state(d, rate, nphi):
+    # test/filt_stream.jl:288-332: naive == stateless == stateful == piecewise.  The Float64 phase accumulator, the
+    # number of samples written and the history must equal the reference's after EVERY chunk, bit for bit.
+    from oracle import stream_filt as osf
+    from oracle import design as odes
+    rng = np.random.default_rng(int(rate * 1000) + nphi)
+    h64 = odes.resample_filter(float(rate), nphi)
+    for Th in (np.float32, np.float64):
+        for Tx in (np.float32, np.float64, np.complex64, np.complex128):
+            h = h64.astype(Th)
+            xlen = int(rng.integers(3000, 4001)) if rate > 0.01 else 40000
+            x = rng.standard_normal(xlen).astype(Tx)
+            if np.dtype(Tx).kind == "c":
+                x = (x + 1j * rng.standard_normal(xlen)).astype(Tx)
+            single = Th == np.float32 and np.dtype(Tx) in (np.dtype(np.float32), np.dtype(np.complex64))
+            tol = 3e-6 if single else 1e-12
+            wide = np.complex128 if np.dtype(Tx).kind == "c" else np.float64
+            o64 = osf.FIRFilter(h, rate, nphi)              # dh = diff(h) is taken in eltype(h) (stream_filt.jl:107) ...
+            o64.h, o64.pfb, o64.dpfb = h.astype(np.float64), o64.pfb.astype(np.float64), o64.dpfb.astype(np.float64)
+            ref = o64.filt(x.astype(wide))                  # ... and only the dot products are evaluated in Float64
+            got = d.filt(h, x, rate, nphi)
+            assert got.shape == ref.shape and got.dtype == np.result_type(Th, Tx)      # samplesWritten is bit-exact
+            assert relerr(got, ref) < tol, (Th, Tx, relerr(got, ref))
+            f, o = d.FIRFilter(h, rate, nphi), osf.FIRFilter(h, rate, nphi)
+            cut = xlen // 3
+            pieces = []
+            for chunk in (x[:cut], x[cut:cut + 1], x[cut + 1:cut + 2], x[cut + 2:]):
+                pieces.append(f.filt(chunk)); oy = o.filt(chunk)
+                assert len(pieces[-1]) == len(oy)
+                assert (f.phi_accumulator, f.phi_idx, f.alpha, f.input_deficit) == (o.phi_acc, o.phi_idx, o.alpha, o.input_deficit)
+                assert np.array_equal(f.history, o.history.astype(Tx))
+            y2 = np.concatenate(pieces)
+            assert y2.shape == ref.shape and relerr(y2, ref) < tol
+    # sample-at-a-time (test/filt_stream.jl:319-325)
+    h = h64; x = rng.standard_normal(300)
+    f, o = d.FIRFilter(h, rate, nphi), osf.FIRFilter(h, rate, nphi)
+    ys, yo = [], []
+    for i in range(len(x)):
+        ys.append(f.filt(x[i:i + 1])); yo.append(o.filt(x[i:i + 1]))
+        assert (f.phi_accumulator, f.input_deficit, len(ys[-1])) == (o.phi_acc, o.input_deficit, len(yo[-1]))
+    ys, yo = np.concatenate(ys), np.concatenate(yo)
+    assert ys.shape == yo.shape and (len(yo) == 0 or relerr(ys, yo) < 1e-12)
+    f.reset()
+    assert (f.phi_accumulator, f.phi_idx, f.alpha, f.input_deficit) == (0.0, 1, 0.0, 1) and not f.history.any()
+
+
+def test_resample_arbitrary_rate(d, torch):
+    # test/resample.jl:74-101: irrational ratio accuracy, Float32 ratio (#302), buffer-length regressions (#317), dims
+    from oracle import stream_filt as osf
+    ratio = 3.141592653589793
+    tx = np.linspace(0, 2, 1000)
+    x = np.sin(2 * np.pi * tx)
+    y = d.resample(x, ratio)
+    ref = osf.resample(x, ratio)
+    assert y.shape == ref.shape == (3142,) and relerr(y, ref) < 1e-12
+    ty = np.arange(len(y)) * ((tx[1] - tx[0]) / ratio)
+    lo = round(len(y) / 3)
+    assert np.abs(y[lo - 1:2 * lo] - np.sin(2 * np.pi * ty)[lo - 1:2 * lo]).max() < 0.00025
+    y32 = d.resample(x, np.float32(ratio))
+    ty = np.arange(len(y32)) * ((tx[1] - tx[0]) / float(np.float32(ratio)))
+    assert np.abs(y32[lo - 1:2 * lo] - np.sin(2 * np.pi * ty)[lo - 1:2 * lo]).max() < 0.00025
+    assert len(d.resample(np.sin(np.arange(1.0, 35547.0)), 1 / 55.55)) == 640
+    assert len(d.resample(np.random.default_rng(0).standard_normal(1822), 0.9802414928649835)) == 1786
+    assert np.array_equal(d.resample(np.zeros(1000), 0.012), np.zeros(12))
+    big = torch.arange(1, 16_367_000 * 2 + 1, device="cuda", dtype=torch.float32)
+    assert d.resample(big, 10_000_000 / 16_367_000).shape == (20_000_000,)
+    del big
+    # array + dims: every slice equals the vector call (test/resample.jl:67-70)
+    A = np.random.default_rng(5).random((3, 50, 4))
+    for dims in range(3):
+        for rate in (1.2, 0.8):
+            got = d.resample(A, rate, dims=dims)
+            want = np.apply_along_axis(lambda v: osf.resample(v, rate), dims, A)
+            assert got.shape == want.shape and relerr(got, want) < 1e-12
+    # Float32 multichannel on the device, long enough for many tiles
+    g = torch.Generator(device="cuda"); g.manual_seed(1776)
+    xx = torch.randn((200000, 3), generator=g, device="cuda", dtype=torch.float32)
+    yy = d.resample(xx, 1.37, dims=0)
+    ref = osf.resample(xx[:, 1].cpu().numpy().astype(np.float64), 1.37)
+    assert yy.shape == (len(ref), 3) and relerr(yy[:, 1].cpu().numpy(), ref) < 3e-6
+
+
 def test_config5_resample_160_147(d, torch):
     # BASELINE config 5 shape (reduced length): 160//147, 5120 taps (32 per phase), 4 channels Float32.
     from oracle import stream_filt as osf
