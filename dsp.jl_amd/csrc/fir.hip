@@ -720,13 +720,35 @@ namespace {
 void arb_trajectory(double acc, int64_t deficit, const ArbStep& st, int64_t xlen, int64_t blk, std::vector<int64_t>* ax, std::vector<double>* aa,
                     int64_t* nout, double* acc_end, int64_t* xidx_end) {
     int64_t n = 0, xi = deficit;
+    const double nphi = st.nphi, nphi2 = 2.0 * st.nphi, nphi3 = 3.0 * st.nphi, nphi4 = 4.0 * st.nphi, delta = st.delta;
     while (xi <= xlen) {
-        if (ax && n % blk == 0) {
+        if (ax) {
             ax->push_back(xi);
             aa->push_back(acc);
         }
-        ++n;
-        st(acc, xi);
+        // one anchor block: the loop-carried chain is add -> compare -> (subtract); q = 1 is the common overflow and
+        // acc - nphi is exact there (Sterbenz), which is what divrem returns
+        const int64_t stop = n + blk;
+        while (n < stop && xi <= xlen) {
+            ++n;
+            const double prev = acc;
+            acc = prev + delta;
+            if (acc >= nphi) {
+                if (acc < nphi2) {
+                    acc -= nphi;
+                    xi += 1;
+                } else if (acc < nphi3) {   // q = 2, 3: same argument (q nphi <= acc < 2 q nphi)
+                    acc -= nphi2;
+                    xi += 2;
+                } else if (acc < nphi4) {
+                    acc -= nphi3;
+                    xi += 3;
+                } else {               // many input samples skipped at once (rate < 1/4): the general divrem
+                    acc = prev;
+                    st(acc, xi);
+                }
+            }
+        }
     }
     *nout = n;
     *acc_end = acc;

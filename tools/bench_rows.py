@@ -96,7 +96,32 @@ if os.environ.get("ROWS_FIR_SWEEP"):
             med, best = timeit(fir)
             print("fir sweep lds_kib", kib, "wg_per_cu", wg, "ms", round(best, 3), "GB/s", round((4 + 4 * 160 / 147) * n * nch / (best * 1e-3) / 1e9, 1), flush=True)
     del os.environ["MDSP_FIR_LDS_KIB"]; del os.environ["MDSP_WG_PER_CU"]
-del x, y
+del y
+# ---------------- next row 1: arbitrary-rate resampler (FIRArbitrary), rate 160/147 as a Float64, Nphi = 32 ----------------
+import time
+rate = 160 / 147
+ha = d.resample_filter(rate, 32).astype(np.float32)
+fa = C.c_void_p()
+_lib.check(lib.mdsp_firarb_create(C.byref(fa), ha.ctypes.data_as(C.c_void_p), len(ha), rate, 32, _lib.F32, _lib.F32, nch))
+ola = C.c_int64(); _lib.check(lib.mdsp_firarb_outputlength(fa, n, C.byref(ola)))
+ya = torch.empty((nch, ola.value + 1), dtype=torch.float32, device="cuda")
+
+
+def arb():
+    _lib.check(lib.mdsp_firarb_reset(fa))
+    _lib.check(lib.mdsp_firarb_exec(fa, x.data_ptr(), n, n, ya.data_ptr(), ola.value + 1, ola.value + 1, C.byref(nw), stream))
+
+
+t0 = time.perf_counter(); arb(); torch.cuda.synchronize(); cold = time.perf_counter() - t0     # includes the serial host recurrence
+med, best = timeit(arb)                                                                       # same (state, length): cached anchors
+res["next1_resample_arbitrary"] = {"rate": rate, "taps": len(ha), "cold_call_s": round(cold, 4), "ms": round(med, 4), "best_ms": round(best, 4),
+                                   "channels": nch, "samples_per_channel": n, "out_per_channel": nw.value,
+                                   "GBps_algorithmic": round((4 + 4 * rate) * n * nch / (best * 1e-3) / 1e9, 1),
+                                   "Gsamples_per_s": round(n * nch / (best * 1e-3) / 1e9, 2),
+                                   "cold_Gsamples_per_s": round(n * nch / cold / 1e9, 2)}
+print("arbitrary", res["next1_resample_arbitrary"], flush=True)
+_lib.check(lib.mdsp_firarb_destroy(fa))
+del x, ya
 torch.cuda.empty_cache()
 
 # ---------------- config 1: time-domain FIR 127 taps, 1e6 Float64 ----------------
