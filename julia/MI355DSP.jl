@@ -322,4 +322,63 @@ function resample(x::AbstractVecOrMat{T}, rate::Union{Integer,Rational}, h::Vect
     ndims(x) == 1 ? y[1:outLen] : y[1:outLen, :]
 end
 
+# ------------------------------------------------------------------------------ FIRArbitrary (floating-point rate)
+mutable struct FIRArbitraryFilter                                                        # stream_filt.jl:92-156
+    h::Ptr{Cvoid}
+    taps::Vector
+    rate::Float64
+    Nϕ::Int
+    xtype::DataType
+    nch::Int
+end
+function FIRFilter(taps::Vector{Th}, rate::AbstractFloat, Nϕ::Integer=32; xtype::DataType=Th, nch::Integer=1) where {Th<:Union{Float32,Float64}}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mdsp_firarb_create, lib), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int64, Cdouble, Int64, Cint, Cint, Int64),
+                p, taps, length(taps), Float64(rate), Nϕ, mdtype(Th), mdtype(xtype), nch))
+    f = FIRArbitraryFilter(p[], taps, Float64(rate), Nϕ, xtype, nch)
+    finalizer(x -> ccall((:mdsp_firarb_destroy, lib), Cint, (Ptr{Cvoid},), x.h), f)
+    f
+end
+reset!(f::FIRArbitraryFilter) = (check(ccall((:mdsp_firarb_reset, lib), Cint, (Ptr{Cvoid},), f.h)); f)            # :260-276
+setphase!(f::FIRArbitraryFilter, ϕ::Real) = check(ccall((:mdsp_firarb_setphase, lib), Cint, (Ptr{Cvoid}, Cdouble), f.h, ϕ))  # :231-239
+function timedelay(f::FIRArbitraryFilter)                                                                          # :400-401
+    τ = Ref{Cdouble}(0)
+    check(ccall((:mdsp_firarb_timedelay, lib), Cint, (Ptr{Cvoid}, Ref{Cdouble}), f.h, τ)); τ[]
+end
+function outputlength(f::FIRArbitraryFilter, inlen::Integer)                                                       # :340-342
+    o = Ref{Int64}(0)
+    check(ccall((:mdsp_firarb_outputlength, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Int64}), f.h, inlen, o)); Int(o[])
+end
+function inputlength(f::FIRArbitraryFilter, outlen::Integer, r::RoundingMode=RoundDown)                            # :385-389
+    o = Ref{Int64}(0)
+    check(ccall((:mdsp_firarb_inputlength, lib), Cint, (Ptr{Cvoid}, Int64, Cint, Ref{Int64}), f.h, outlen,
+                (r == RoundUp || r == RoundFromZero) ? 1 : 0, o)); Int(o[])
+end
+# filt(f, x): buffer of outputlength + 1 samples, resized to samplesWritten (allocate_output :639-655, filt :627-637)
+function filt(f::FIRArbitraryFilter, x::Union{AbstractVecOrMat,DeviceArray})
+    xd = todevice(x, f.xtype)
+    xlen = size(xd, 1)
+    ycap = max(outputlength(f, xlen), 0) + 1
+    Ty = promote_type(eltype(f.taps), f.xtype)
+    y = DeviceArray{Ty}(f.nch == 1 ? (ycap,) : (ycap, f.nch))
+    nw = Ref{Int64}(0)
+    check(ccall((:mdsp_firarb_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ref{Int64}, Ptr{Cvoid}),
+                f.h, xd.ptr, xlen, xlen, y.ptr, ycap, ycap, nw, C_NULL))
+    yh = back(y, x)
+    ndims(yh) == 1 ? yh[1:nw[]] : yh[1:nw[], :]
+end
+# resample(x, rate::AbstractFloat, h, Nϕ = 32)   stream_filt.jl:692-694, :752-755
+function resample(x::AbstractVecOrMat{T}, rate::AbstractFloat, h::Vector, Nϕ::Integer=32) where {T}
+    S = fftintype(T)
+    nch = size(x, 2)
+    f = FIRFilter(convert(Vector{real(promote_type(eltype(h), S)) == Float32 ? Float32 : Float64}, h), rate, Nϕ; xtype=S, nch)
+    setphase!(f, timedelay(f))                                          # undelay!
+    outLen = ceil(Int, size(x, 1) * rate)
+    npad = inputlength(f, outLen, RoundUp)
+    xp = zeros(S, npad, nch); xp[1:size(x, 1), :] .= x
+    y = filt(f, ndims(x) == 1 ? vec(xp) : xp)
+    size(y, 1) >= outLen || throw(AssertionError("Resample output shorter than expected."))   # :722
+    ndims(x) == 1 ? y[1:outLen] : y[1:outLen, :]
+end
+
 end # module
