@@ -70,6 +70,20 @@ def to_columns(x, dtype) -> tuple[torch.Tensor, tuple]:
     return t.contiguous(), shape
 
 
+def as_device(x, dtype) -> torch.Tensor:
+    """``x`` as a device tensor of ``dtype`` with its own shape (no column flattening)."""
+    dev = device()
+    td = torch_dtype(dtype)
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=dev)
+    else:
+        a = np.asarray(x)
+        if a.dtype == np.dtype(object):
+            raise TypeError("non-numeric array")
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if t.dtype == td else t.to(td)
+
+
 def from_columns(t: torch.Tensor, shape: tuple, like):
     """(ncols, n_out) device tensor -> array shaped like the input container (numpy in -> numpy out)."""
     n_out = t.shape[1]

@@ -79,6 +79,13 @@ PROTOTYPES = {
     "mdsp_stft_plan_destroy": (ci, [vp]),
     "mdsp_stft_plan_info": (ci, [vp, pi64, pint]),
     "mdsp_stft_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, vp]),
+    "mdsp_mt_plan_create": (ci, [pvp, i64, i64, vp, i64, vp, ci, ci, ci]),
+    "mdsp_mt_plan_destroy": (ci, [vp]),
+    "mdsp_mt_plan_info": (ci, [vp, pi64, pi64, pint]),
+    "mdsp_mt_psd_exec": (ci, [vp, vp, i64, i64, i64, i64, vp, i64, i64, vp]),
+    "mdsp_mt_spectra_exec": (ci, [vp, vp, i64, i64, ci, vp, vp]),
+    "mdsp_mt_cross_spectra": (ci, [vp, vp, i64, vp, i64, vp, vp]),
+    "mdsp_coherence_from_cs": (ci, [vp, i64, i64, ci, vp, vp]),
     "mdsp_fir_create": (ci, [pvp, vp, i64, i64, i64, ci, ci, i64]),
     "mdsp_fir_destroy": (ci, [vp]),
     "mdsp_fir_reset": (ci, [vp]),

@@ -21,6 +21,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <memory>
+#include <vector>
+
 #include "common.h"
 #include "devio.h"
 #include "fft_lds.h"
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(256) void welch_finalize_kernel(const double* __res
 //   HALF: spectrum has nfft/2+1 bins (real input); two-sided output mirrors (conjugate for raw STFT).
 template <typename R, bool PSD, bool HALF>
 __global__ __launch_bounds__(256) void stft_store_kernel(const cx<R>* __restrict__ spec, void* __restrict__ out, int nspec, int nfft, int nout,
-                                                         int64_t K, int64_t ldo, int64_t chs, int64_t u0, int64_t nunits, double r, int onesided) {
+                                                         int64_t K, int64_t ldo, int64_t chs, int64_t u0, int64_t nunits, double r, int onesided,
+                                                         int accumulate) {
     const int64_t u = u0 + blockIdx.y;
     if (u >= nunits) return;
     const int64_t ch = u / K, f = u - ch * K;
@@ -157,7 +161,8 @@ __global__ __launch_bounds__(256) void stft_store_kernel(const cx<R>* __restrict
             const R p = v.x * v.x + v.y * v.y;
             R m = m1;
             if (onesided && !(j == 0 || (j == nout - 1 && nfft % 2 == 0))) m = m2;
-            static_cast<R*>(out)[ch * chs + f * ldo + j] = p * m;   // fft2pow! with out == 0: muladd(abs2, m, 0)
+            R* o = static_cast<R*>(out) + ch * chs + f * ldo + j;
+            *o = accumulate ? fma(p, m, *o) : p * m;                 // fft2pow!: out = muladd(abs2, m, out)
         } else {
             static_cast<cx<R>*>(out)[ch * chs + f * ldo + j] = conj ? cx<R>{v.x, -v.y} : v;
         }
@@ -179,6 +184,7 @@ struct SpecArgs {
     int n, nout, onesided;
     int64_t run_len, niter;  // unit schedule: runs of run_len consecutive units per slot, niter iterations per slot
     int ablate;              // profiling aid (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip accumulate/stores
+    int accumulate;          // STFT PSD mode: add to the output column instead of overwriting it (multitaper)
     double r;
 };
 
@@ -353,12 +359,15 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
         if constexpr (PSD) {
             R* col = static_cast<R*>(a.out) + ch * a.chs + f * a.ldo;
             const __amdgpu_buffer_rsrc_t wr = io::make_rsrc(col, live ? (int64_t)a.nout * (int64_t)sizeof(R) : 0);
+            R old[E];
+            if (a.accumulate) io::load_window<R, E, T>(old, wr, 0, t);   // wave-uniform branch; the column is this slot's alone
             io::store_window<R, E, T>(
                 [&](int e) {
                     const int k = t + T * e;
                     R m = m1;
                     if (a.onesided && !(k == 0 || (k == a.nout - 1 && N % 2 == 0))) m = m2;
-                    return (v[e].x * v[e].x + v[e].y * v[e].y) * m;
+                    const R p = (v[e].x * v[e].x + v[e].y * v[e].y) * m;
+                    return a.accumulate ? p + old[e] : p;
                 },
                 wr, 0, t);
         } else {
@@ -931,6 +940,8 @@ struct mdsp_stft_plan_s {
     double r = 1;
     bool have_win = false;
     DevBuf win, table;
+    const double* win_ptr = nullptr;   // window used by exec (the plan's own, or one taper of a multitaper plan)
+    int accumulate = 0;                // PSD mode: out += |X|^2 m instead of out = (the taper loop of mt_pgram!, multitaper.jl:240-243)
     RocPlan fwd;
     DevBuf fr, spec;
     int64_t batch = 0;
@@ -959,16 +970,16 @@ int stft_exec_rocfft(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t n
     for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
         const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
         hipLaunchKernelGGL(frame_window_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
-                           pl->have_win ? pl->win.as<double>() : nullptr, lds_, K, hop, (int)n, (int)nfft, u0, nunits);
+                           pl->have_win ? pl->win_ptr : nullptr, lds_, K, hop, (int)n, (int)nfft, u0, nunits);
         MDSP_LAUNCH_CHECK();
         MDSP_TRY(pl->fwd.exec(pl->fr.p, pl->spec.p, st));
         const dim3 g(gx, (unsigned)cnt);
         if (pl->psd_only)
             hipLaunchKernelGGL((stft_store_kernel<R, true, !CPLX>), g, dim3(256), 0, st, pl->spec.as<cx<R>>(), out, nspec, (int)nfft, nout, K, ldo, chs, u0,
-                               nunits, pl->r, pl->onesided);
+                               nunits, pl->r, pl->onesided, pl->accumulate);
         else
             hipLaunchKernelGGL((stft_store_kernel<R, false, !CPLX>), g, dim3(256), 0, st, pl->spec.as<cx<R>>(), out, nspec, (int)nfft, nout, K, ldo, chs, u0,
-                               nunits, pl->r, pl->onesided);
+                               nunits, pl->r, pl->onesided, 0);
         MDSP_LAUNCH_CHECK();
     }
     return MDSP_OK;
@@ -1000,7 +1011,8 @@ int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nc
     a.s = s;
     a.out = out;
     a.table = pl->table.p;
-    a.win = pl->have_win ? pl->win.as<double>() : nullptr;
+    a.win = pl->have_win ? pl->win_ptr : nullptr;
+    a.accumulate = pl->accumulate;
     a.len = len;
     a.lds_ = lds_;
     a.K = K;
@@ -1056,6 +1068,7 @@ int mdsp_stft_plan_create(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int
         st = pl->win.reserve(sizeof(double) * (size_t)n);
         if (st == MDSP_OK && hipMemcpy(pl->win.p, window_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
             st = set_error(MDSP_ERR_DEVICE, "window upload failed");
+        pl->win_ptr = pl->win.as<double>();
     }
     if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED) st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
     if (st != MDSP_OK) {
@@ -1100,6 +1113,252 @@ int mdsp_stft_exec(mdsp_stft_plan plan, const void* s_dev, int64_t len, int64_t 
                          : stft_exec_fused<float, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
     return dbl ? stft_exec_fused<double, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
                : stft_exec_fused<float, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+}
+
+}  // extern "C"
+
+// ======================================================================================================
+// Multitaper (src/multitaper.jl): MTConfig, mt_pgram!, mt_spectrogram!, mt_cross_power_spectra!, mt_coherence!
+// ======================================================================================================
+// The tapers are ntapers windows applied to the SAME frame; mt_pgram! (multitaper.jl:225-245) is the loop
+//     output .= 0;  for taper: fft_input = window[:, taper] .* signal; fft; fft2pow!(output, fft_output, nfft, r[taper], onesided)
+// which is the STFT/PSD pipeline above run once per taper with the accumulate flag set from the second taper on.
+struct mdsp_mt_plan_s {
+    mdsp_stft_plan_s st;          // engine, tables, rocFFT scratch -- window pointer / r / psd_only are re-pointed per taper
+    int64_t ntapers = 0;
+    DevBuf wins;                  // (n, ntapers) Float64, column-major
+    std::vector<double> r;        // inverse normalisation per taper (multitaper.jl:15-17)
+    DevBuf wts;                   // 2 / r  (normalization_weights, :499), Float64
+    DevBuf demeaned;              // scratch for demean = true (:566-570)
+    DevBuf finds;                 // frequency indices of the last cross-spectra call
+};
+
+namespace {
+
+// demeaned[c, :] = signal[c, :] - mean(signal[c, :])   (real signals only: check_onesided_real, :417-422)
+template <typename R> __global__ __launch_bounds__(256) void demean_kernel(const R* __restrict__ s, R* __restrict__ out, int64_t n, int64_t lds_) {
+    __shared__ double red[256];
+    const int64_t ch = blockIdx.x;
+    const R* sc = s + ch * lds_;
+    double a = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) a += (double)sc[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    const R m = (R)(red[0] / (double)n);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) out[ch * n + i] = sc[i] - m;
+}
+
+// cs_inner! (multitaper.jl:602-616) on x_mt[f, taper, ch] with the DC / Nyquist 1/sqrt(2) of :577-580 folded in:
+//   out[l, m, fi] = sum_k w_k x[f, k, l] conj(x[f, k, m])
+template <typename R>
+__global__ __launch_bounds__(256) void cross_spectra_kernel(const cx<R>* __restrict__ x, const double* __restrict__ w, const int64_t* __restrict__ finds,
+                                                            cx<R>* __restrict__ out, int64_t nfreq, int64_t ntapers, int64_t nch, int64_t nfi, int nfft_even) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nch * nch * nfi) return;
+    const int64_t l = idx % nch, m = (idx / nch) % nch, fi = idx / (nch * nch);
+    const int64_t f = finds[fi];
+    const bool edge = f == 0 || (nfft_even && f == nfreq - 1);
+    R ax = 0, ay = 0;
+    for (int64_t k = 0; k < ntapers; ++k) {
+        cx<R> a = x[f + nfreq * (k + ntapers * l)], b = x[f + nfreq * (k + ntapers * m)];
+        if (edge) {   // x_mt[1, :, :] ./= sqrt(2) (and the Nyquist row for even nfft)
+            a = {a.x / (R)1.4142135623730951, a.y / (R)1.4142135623730951};
+            b = {b.x / (R)1.4142135623730951, b.y / (R)1.4142135623730951};
+        }
+        const R wk = (R)w[k];
+        const cx<R> p = fft::cmulc(a, b);   // a * conj(b)
+        ax += wk * p.x;
+        ay += wk * p.y;
+    }
+    out[idx] = {ax, ay};
+}
+
+// coherence_from_cs! (multitaper.jl:704-723)
+template <typename R>
+__global__ __launch_bounds__(256) void coherence_kernel(const cx<R>* __restrict__ cs, R* __restrict__ out, int64_t nch, int64_t nf) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nch * nch * nf) return;
+    const int64_t c1 = idx % nch, c2 = (idx / nch) % nch, f = idx / (nch * nch);
+    if (c1 == c2) {
+        out[idx] = (R)1;
+        return;
+    }
+    const int64_t hi = c1 > c2 ? c1 : c2, lo = c1 > c2 ? c2 : c1;      // the lower triangle is computed, then mirrored
+    const cx<R> v = cs[hi + nch * (lo + nch * f)];
+    const cx<R> d1 = cs[hi + nch * (hi + nch * f)], d2 = cs[lo + nch * (lo + nch * f)];
+    out[idx] = sqrt(v.x * v.x + v.y * v.y) / sqrt(d1.x * d2.x - d1.y * d2.y);
+}
+
+int stft_dispatch(mdsp_stft_plan_s* plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds_, void* out_dev, int64_t ldo, int64_t chs, hipStream_t st) {
+    const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
+    if (plan->engine == MDSP_ENGINE_ROCFFT) {
+        if (cplx) return dbl ? stft_exec_rocfft<double, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
+                             : stft_exec_rocfft<float, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+        return dbl ? stft_exec_rocfft<double, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
+                   : stft_exec_rocfft<float, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+    }
+    if (cplx) return dbl ? stft_exec_fused<double, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
+                         : stft_exec_fused<float, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+    return dbl ? stft_exec_fused<double, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
+               : stft_exec_fused<float, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdsp_mt_plan_create(mdsp_mt_plan* plan, int64_t n, int64_t nfft, const double* tapers_host, int64_t ntapers, const double* r_host, int onesided,
+                        int dtype, int engine) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    *plan = nullptr;
+    if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype %d", dtype);
+    if (onesided && dtype_is_complex(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "cannot compute one-sided FFT of a complex signal");   // :46-47, :115-117
+    if (n <= 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "`n_samples` must be positive");                                                     // :21
+    if (nfft < n) MDSP_FAIL(MDSP_ERR_ARGUMENT, "Must have `nfft >= n_samples`");                                                  // :22
+    if (ntapers <= 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "`ntapers` must be positive");                                                 // :23
+    if (!tapers_host || !r_host) MDSP_FAIL(MDSP_ERR_ARGUMENT, "tapers / r are NULL");
+    for (int64_t k = 0; k < ntapers; ++k)
+        if (!(r_host[k] > 0)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "normalisation r must be positive");
+    int eng;
+    MDSP_TRY(resolve_engine(engine, dtype, nfft, &eng));
+    std::unique_ptr<mdsp_mt_plan_s> pl(new mdsp_mt_plan_s());
+    mdsp_stft_plan_s& st = pl->st;
+    st.dtype = dtype;
+    st.engine = eng;
+    st.onesided = onesided ? 1 : 0;
+    st.n = n;
+    st.noverlap = 0;
+    st.nfft = nfft;
+    st.nout = onesided ? nfft / 2 + 1 : nfft;
+    st.have_win = true;
+    pl->ntapers = ntapers;
+    pl->r.assign(r_host, r_host + ntapers);
+    MDSP_TRY(pl->wins.reserve(sizeof(double) * (size_t)(n * ntapers)));
+    MDSP_HIP(hipMemcpy(pl->wins.p, tapers_host, sizeof(double) * (size_t)(n * ntapers), hipMemcpyHostToDevice));
+    std::vector<double> w((size_t)ntapers);
+    for (int64_t k = 0; k < ntapers; ++k) w[(size_t)k] = 2.0 / r_host[k];
+    MDSP_TRY(pl->wts.reserve(sizeof(double) * (size_t)ntapers));
+    MDSP_HIP(hipMemcpy(pl->wts.p, w.data(), sizeof(double) * (size_t)ntapers, hipMemcpyHostToDevice));
+    if (eng == MDSP_ENGINE_FUSED) MDSP_TRY(dtype_is_double(dtype) ? upload_roots<double>(st.table, nfft) : upload_roots<float>(st.table, nfft));
+    *plan = pl.release();
+    return MDSP_OK;
+}
+
+int mdsp_mt_plan_destroy(mdsp_mt_plan plan) {
+    delete plan;
+    return MDSP_OK;
+}
+
+int mdsp_mt_plan_info(mdsp_mt_plan plan, int64_t* nout, int64_t* ntapers, int* engine_used) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (nout) *nout = plan->st.nout;
+    if (ntapers) *ntapers = plan->ntapers;
+    if (engine_used) *engine_used = plan->st.engine;
+    return MDSP_OK;
+}
+
+int mdsp_mt_psd_exec(mdsp_mt_plan plan, const void* s_dev, int64_t len, int64_t noverlap, int64_t nch, int64_t lds_, void* out_dev, int64_t ldo,
+                     int64_t chs, void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (len < 0 || nch < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    mdsp_stft_plan_s& st = plan->st;
+    if (noverlap < 0 || noverlap >= st.n) MDSP_FAIL(MDSP_ERR_ARGUMENT, "Need `samples_per_window > n_overlap_samples`");   // multitaper.jl:264-266
+    const int64_t K = mdsp_frame_count(len, st.n, noverlap);
+    if (nch == 0 || K == 0) return MDSP_OK;
+    if (!out_dev || !s_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    if (ldo < st.nout) MDSP_FAIL(MDSP_ERR_DIMENSION, "column stride smaller than the column length");
+    if (nch > 1 && (lds_ < len || chs < ldo * (K - 1) + st.nout)) MDSP_FAIL(MDSP_ERR_DIMENSION, "channel stride too small");
+    if (nch > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 channels per call");
+    st.noverlap = noverlap;
+    st.psd_only = 1;
+    for (int64_t k = 0; k < plan->ntapers; ++k) {
+        st.win_ptr = plan->wins.as<double>() + k * st.n;
+        st.r = plan->r[(size_t)k];
+        st.accumulate = k > 0;
+        const int rc = stft_dispatch(&st, s_dev, len, nch, lds_, out_dev, ldo, chs, as_stream(stream));
+        if (rc != MDSP_OK) return rc;
+    }
+    st.accumulate = 0;
+    return MDSP_OK;
+}
+
+int mdsp_mt_spectra_exec(mdsp_mt_plan plan, const void* s_dev, int64_t nch, int64_t lds_, int demean, void* xmt_dev, void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    mdsp_stft_plan_s& st = plan->st;
+    if (dtype_is_complex(st.dtype) || !st.onesided)   // check_onesided_real, multitaper.jl:417-422
+        MDSP_FAIL(MDSP_ERR_ARGUMENT, "Only real data is supported (with the default choice of `onesided=true`) for this operation.");
+    if (nch <= 0) return MDSP_OK;
+    if (!s_dev || !xmt_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    if (nch > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 channels per call");
+    if (nch > 1 && lds_ < st.n) MDSP_FAIL(MDSP_ERR_DIMENSION, "channel stride too small");
+    hipStream_t sm = as_stream(stream);
+    const void* src = s_dev;
+    int64_t ld = lds_;
+    if (demean) {   // mean!(mean_per_channel, signal); demeaned_signal .= signal .- mean_per_channel   (:566-570)
+        const size_t esz = dtype_size(st.dtype);
+        MDSP_TRY(plan->demeaned.reserve(esz * (size_t)(st.n * nch)));
+        if (dtype_is_double(st.dtype))
+            hipLaunchKernelGGL(demean_kernel<double>, dim3((unsigned)nch), dim3(256), 0, sm, (const double*)s_dev, plan->demeaned.as<double>(), st.n, lds_);
+        else
+            hipLaunchKernelGGL(demean_kernel<float>, dim3((unsigned)nch), dim3(256), 0, sm, (const float*)s_dev, plan->demeaned.as<float>(), st.n, lds_);
+        MDSP_LAUNCH_CHECK();
+        src = plan->demeaned.p;
+        ld = st.n;
+    }
+    // x_mt[:, taper, k] = rfft(window[:, taper] .* signal[k, :])   (mt_fft_tapered_multichannel!, :596-600)
+    st.noverlap = 0;
+    st.psd_only = 0;
+    st.accumulate = 0;
+    const size_t csz = dtype_is_double(st.dtype) ? 16 : 8;
+    for (int64_t k = 0; k < plan->ntapers; ++k) {
+        st.win_ptr = plan->wins.as<double>() + k * st.n;
+        char* dst = static_cast<char*>(xmt_dev) + csz * (size_t)(k * st.nout);
+        const int rc = stft_dispatch(&st, src, st.n, nch, ld, dst, st.nout, st.nout * plan->ntapers, sm);
+        if (rc != MDSP_OK) return rc;
+    }
+    return MDSP_OK;
+}
+
+int mdsp_mt_cross_spectra(mdsp_mt_plan plan, const void* xmt_dev, int64_t nch, const int64_t* freq_inds_host, int64_t nfi, void* out_dev, void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    mdsp_stft_plan_s& st = plan->st;
+    if (dtype_is_complex(st.dtype) || !st.onesided)
+        MDSP_FAIL(MDSP_ERR_ARGUMENT, "Only real data is supported (with the default choice of `onesided=true`) for this operation.");
+    if (nch <= 0 || nfi <= 0) return MDSP_OK;
+    if (!xmt_dev || !out_dev || !freq_inds_host) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    for (int64_t i = 0; i < nfi; ++i)
+        if (freq_inds_host[i] < 0 || freq_inds_host[i] >= st.nout) MDSP_FAIL(MDSP_ERR_ARGUMENT, "frequency index out of range");   // @boundscheck :605-606
+    hipStream_t sm = as_stream(stream);
+    MDSP_TRY(plan->finds.reserve(sizeof(int64_t) * (size_t)nfi));
+    MDSP_HIP(hipMemcpyAsync(plan->finds.p, freq_inds_host, sizeof(int64_t) * (size_t)nfi, hipMemcpyHostToDevice, sm));
+    MDSP_HIP(hipStreamSynchronize(sm));   // the host index vector may go away after the call
+    const int64_t total = nch * nch * nfi;
+    const dim3 g((unsigned)cdiv(total, 256));
+    if (dtype_is_double(st.dtype))
+        hipLaunchKernelGGL(cross_spectra_kernel<double>, g, dim3(256), 0, sm, (const cx<double>*)xmt_dev, plan->wts.as<double>(), plan->finds.as<int64_t>(),
+                           (cx<double>*)out_dev, st.nout, plan->ntapers, nch, nfi, (int)(st.nfft % 2 == 0));
+    else
+        hipLaunchKernelGGL(cross_spectra_kernel<float>, g, dim3(256), 0, sm, (const cx<float>*)xmt_dev, plan->wts.as<double>(), plan->finds.as<int64_t>(),
+                           (cx<float>*)out_dev, st.nout, plan->ntapers, nch, nfi, (int)(st.nfft % 2 == 0));
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+int mdsp_coherence_from_cs(const void* cs_dev, int64_t nch, int64_t nf, int real_dtype, void* out_dev, void* stream) {
+    if (real_dtype != MDSP_F32 && real_dtype != MDSP_F64) MDSP_FAIL(MDSP_ERR_ARGUMENT, "real dtype expected");
+    if (nch <= 0 || nf <= 0) return MDSP_OK;
+    if (!cs_dev || !out_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    const dim3 g((unsigned)cdiv(nch * nch * nf, 256));
+    if (real_dtype == MDSP_F64)
+        hipLaunchKernelGGL(coherence_kernel<double>, g, dim3(256), 0, as_stream(stream), (const cx<double>*)cs_dev, (double*)out_dev, nch, nf);
+    else
+        hipLaunchKernelGGL(coherence_kernel<float>, g, dim3(256), 0, as_stream(stream), (const cx<float>*)cs_dev, (float*)out_dev, nch, nf);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
 }
 
 }  // extern "C"

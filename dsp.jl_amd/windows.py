@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ._lib import ArgumentError
+from ._lib import ArgumentError, DomainError
 
 
 def _cospi(x):
@@ -73,3 +73,64 @@ def kaiser(n, alpha, padding=0, zerophase=False):
     """windows.jl:600-605."""
     scale = 1.0 / np.i0(np.pi * alpha)
     return makewindow(lambda x: scale * np.i0(np.pi * alpha * np.sqrt(np.clip(1.0 - 4.0 * x * x, 0.0, None))), n, padding, zerophase)
+
+
+def dpss(n: int, nw: float, ntapers: int | None = None, padding: int = 0, zerophase: bool = False) -> np.ndarray:
+    """``dpss(n, nw, ntapers=ceil(2nw)-1; padding, zerophase)`` (windows.jl:668-726): Slepian tapers, (n, ntapers).
+
+    Host-side table generation like every window here (the reference solves the same symmetric tridiagonal
+    eigenproblem with LAPACK); the first non-zero element of the skew-symmetric tapers is positive (:696-707), the
+    symmetric ones have a positive mean."""
+    import math
+    from scipy.linalg import eigh_tridiagonal
+    if ntapers is None:
+        ntapers = math.ceil(2 * nw) - 1
+    if n % 2 == 1 and zerophase:
+        raise ArgumentError("`dpss` does not currently support odd-length zerophase windows")
+    if zerophase:
+        n += 1
+    if not 0 < ntapers <= n:
+        raise DomainError("ntapers must be in the interval (0, n]")
+    if not 0 <= nw < n / 2:
+        raise DomainError("nw must be in the interval [0, n/2)")
+    v = float(_cospi(np.array([2 * nw / n]))[0])
+    i = np.arange(n, dtype=np.float64)
+    dv = v * ((n - 1) / 2 - i) ** 2
+    k = np.arange(1, n, dtype=np.float64)
+    ev = 0.5 * (k * n - k * k)
+    _, vec = eigh_tridiagonal(dv, ev, select="i", select_range=(n - ntapers, n - 1))
+    rv = np.ascontiguousarray(vec[:, ::-1])
+    for c in range(rv.shape[1]):
+        if c % 2 == 1:
+            if rv[np.flatnonzero(rv[:, c])[0], c] < 0:
+                rv[:, c] = -rv[:, c]
+        elif rv[:, c].sum() < 0:
+            rv[:, c] = -rv[:, c]
+    if zerophase:
+        rv = rv[:-1, :]
+    if padding > 0:
+        rv = np.vstack([rv, np.zeros((padding, ntapers))])
+    if zerophase:
+        rv = np.fft.ifftshift(rv, axes=0)
+    return rv
+
+
+def dpsseig(A: np.ndarray, nw: float) -> np.ndarray:
+    """``dpsseig(A, nw)`` (windows.jl:739-776): concentration ratios of the tapers in ``A`` (host arithmetic)."""
+    from .util import nextfastfft
+    A = np.asarray(A, dtype=np.float64)
+    n = A.shape[0]
+    if not 0 <= nw < n / 2:
+        raise DomainError("nw must be in the interval [0, n/2)")
+    w = nw / n
+    seq = np.empty(n)
+    seq[0] = 1.0
+    seq[1:] = 2 * np.sinc(2 * w * np.arange(1, n))
+    nfft = nextfastfft(2 * n - 1)
+    q = np.empty(A.shape[1])
+    for c in range(A.shape[1]):
+        t = np.zeros(nfft)
+        t[:n] = A[:, c]
+        ac = np.fft.irfft(np.abs(np.fft.rfft(t)) ** 2, nfft) * nfft
+        q[c] = 2 * w * float(np.dot(seq, ac[:n])) / nfft
+    return q

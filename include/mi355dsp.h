@@ -156,6 +156,30 @@ int mdsp_stft_exec(mdsp_stft_plan plan, const void* s_dev, int64_t len, int64_t 
                    int64_t ldo, int64_t chs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Multitaper spectral estimation (src/multitaper.jl)
+ *   plan    = MTConfig (:5-135): frames of n samples, nfft, `ntapers` tapers (n x ntapers, column-major Float64,
+ *             e.g. dpss(n, nw, ntapers)), inverse normalisations r[taper] (fs ./ taper_weights, :127-131)
+ *   psd     = mt_pgram! (:225-245) for every frame of arraysplit(signal, n, noverlap): mt_spectrogram! (:312-330);
+ *             out: (nout, K) per channel, like mdsp_stft_exec with psd_only
+ *   spectra = mt_fft_tapered_multichannel! (:596-600): x_mt[f, taper, channel] of ONE n-sample frame per channel
+ *             (real input, onesided), optionally demeaned per channel (:566-570)
+ *   cross   = cs_inner! (:602-616) incl. the DC / Nyquist 1/sqrt(2) (:577-580): out (nch, nch, nfi) complex
+ *   coherence_from_cs! (:704-723): (nch, nch, nf) complex -> real
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct mdsp_mt_plan_s* mdsp_mt_plan;
+int mdsp_mt_plan_create(mdsp_mt_plan* plan, int64_t n, int64_t nfft, const double* tapers_host, int64_t ntapers,
+                        const double* r_host, int onesided, int dtype, int engine);
+int mdsp_mt_plan_destroy(mdsp_mt_plan plan);
+int mdsp_mt_plan_info(mdsp_mt_plan plan, int64_t* nout, int64_t* ntapers, int* engine_used);
+int mdsp_mt_psd_exec(mdsp_mt_plan plan, const void* s_dev, int64_t len, int64_t noverlap, int64_t nch, int64_t lds,
+                     void* out_dev, int64_t ldo, int64_t chs, void* stream);
+int mdsp_mt_spectra_exec(mdsp_mt_plan plan, const void* s_dev, int64_t nch, int64_t lds, int demean, void* xmt_dev,
+                         void* stream);
+int mdsp_mt_cross_spectra(mdsp_mt_plan plan, const void* xmt_dev, int64_t nch, const int64_t* freq_inds_host /*0-based*/,
+                          int64_t nfi, void* out_dev, void* stream);
+int mdsp_coherence_from_cs(const void* cs_dev, int64_t nch, int64_t nf, int real_dtype, void* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Stateful polyphase FIR (FIRFilter{FIRStandard|FIRInterpolator|FIRDecimator|FIRRational})
  *   replaces the while loop of filt!(buffer, ::FIRFilter, x) (stream_filt.jl:409-558) and its
  *   unsafe_dot / BLAS.dot inner products (util.jl:225-283) and shiftin! (util.jl:299-314).

@@ -15,6 +15,9 @@ Files and the reference tests that consume them:
   resample_x.txt, resample_taps_*.txt, resample_y_*.txt   test/resample.jl:8-24 (MATLAB resample)
   hanning128.txt                      test/windows.jl:55-59
   digitalfilter_hamming_12{8,9}_lowpass[_scaled]_fc0.25_fs1.0.txt   test/filter_design.jl:988-1060 (SciPy firwin)
+  dpss128,4.txt                       test/windows.jl:34-36 (MATLAB dpss)
+  mt_pgram.txt, pmtm_{x,fx,pxx}.txt   test/periodograms.jl:381-440 (MATLAB pmtm)
+  csd_array_multitaper_{frequencies,values_re,values_im}.txt, noise.txt   test/multitaper.jl:254-300 (MNE-Python)
 """
 import os
 import sys
@@ -36,6 +39,8 @@ FILES = [
     "digitalfilter_hamming_128_lowpass_scaled_fc0.25_fs1.0",
     "digitalfilter_hamming_129_lowpass_fc0.25_fs1.0",
     "digitalfilter_hamming_129_lowpass_scaled_fc0.25_fs1.0",
+    "dpss128,4", "mt_pgram", "pmtm_x", "pmtm_fx", "pmtm_pxx",
+    "csd_array_multitaper_frequencies", "csd_array_multitaper_values_re", "csd_array_multitaper_values_im", "noise",
 ]
 
 
@@ -55,7 +60,7 @@ def main():
         sys.exit(f"reference data directory not found: {DATA}")
     arrays = {}
     for name in FILES:
-        key = name.replace(".", "p")
+        key = name.replace(".", "p").replace(",", "_")
         arrays[key] = read_reference_data(name)
         print(f"{name:60s} {arrays[key].shape}")
     np.savez_compressed(OUT, **arrays)

@@ -584,6 +584,142 @@ def test_resample_arbitrary_rate(d, torch):
     assert yy.shape == (len(ref), 3) and relerr(yy[:, 1].cpu().numpy(), ref) < 3e-6
 
 
+# ============================================================================================ multitaper
+@pytest.mark.parametrize("engine", ENGINES, ids=_eng_name)
+def test_mt_pgram_matlab_goldens(d, golden, engine):
+    # test/periodograms.jl:381-440: MATLAB pmtm goldens, config / in-place / keyword forms, Float32
+    s = golden["stft_x"]
+    if engine == 2:                                    # nfft = nextfastfft(5000) = 5000: rocFFT engine only
+        assert isapprox(d.mt_pgram(s, fs=16000, engine=engine).power, golden["mt_pgram"])
+        assert isapprox(d.mt_pgram(s, fs=16000, window=d.dpss(len(s), 4), engine=engine).power, golden["mt_pgram"])
+    x = golden["pmtm_x"]
+    nfft = 2048                                        # nextpow(2, 2000)
+    r = d.mt_pgram(x, fs=1000, nw=4, nfft=nfft, engine=engine)
+    assert isapprox(r.freq, golden["pmtm_fx"]) and isapprox(r.power, golden["pmtm_pxx"])
+    cfg = d.MTConfig(np.float64, len(x), fs=1000, nw=4, nfft=nfft, engine=engine)
+    out = np.zeros(len(cfg.freq))
+    r2 = d.mt_pgram_(out, x, cfg)
+    assert r2.power is out and isapprox(out, golden["pmtm_pxx"]) and isapprox(d.mt_pgram(x, cfg).power, golden["pmtm_pxx"])
+    cfg32 = d.MTConfig(np.float32, len(x), fs=1000, nw=4, nfft=nfft, engine=engine)
+    r32 = d.mt_pgram(x.astype(np.float32), cfg32)
+    assert r32.power.dtype == np.float32 and relerr(r32.power, golden["pmtm_pxx"]) < TOL32
+    with pytest.raises(d.DimensionMismatch):
+        d.mt_pgram(x[:-1], cfg)
+    with pytest.raises(d.DimensionMismatch):
+        d.mt_pgram_(np.zeros(len(cfg.freq) + 1), x, cfg)
+
+
+def test_mtconfig_checks(d):
+    # test/multitaper.jl:10-14
+    with pytest.raises(d.ArgumentError):
+        d.MTConfig(np.float64, 100, nfft=99)
+    with pytest.raises(d.ArgumentError):
+        d.MTConfig(np.float64, 100, fs=-1)
+    with pytest.raises(d.DimensionMismatch):
+        d.MTConfig(np.float64, 100, window=np.random.rand(1, 200))
+    with pytest.raises(d.ArgumentError):
+        d.MTConfig(np.complex128, 100, onesided=True)
+    a = d.dpss_config(np.float64, 1024)                 # :79-91
+    b = d.MTConfig(np.float64, 1024)
+    assert isapprox(a.window, b.window) and a.ntapers == b.ntapers and isapprox(a.r, b.r)
+    c = d.dpss_config(np.float64, 1024, weight_by_evals=True)
+    assert np.abs(c.r - b.r).sum() > 0.1
+
+
+@pytest.mark.parametrize("engine", ENGINES, ids=_eng_name)
+@pytest.mark.parametrize("dt,tol", [(np.float32, TOL32), (np.float64, TOL64), (np.complex64, TOL32), (np.complex128, TOL64)])
+def test_mt_pgram_spectrogram_vs_oracle(d, engine, dt, tol):
+    from oracle import multitaper as omt
+    rng = np.random.default_rng(11)
+    n, cplx = 9000, np.dtype(dt).kind == "c"
+    x = rng.standard_normal(n).astype(dt)
+    if cplx:
+        x = (x + 1j * rng.standard_normal(n)).astype(dt)
+    wide = np.complex128 if cplx else np.float64
+    for spw, nov, nfft, nw in ((1024, 512, 1024, 4), (500, 100, 512 if engine == 1 else 540, 2.5), (256, 255, 256, 3)):
+        got = d.mt_spectrogram(x, spw, nov, fs=7.0, nfft=nfft, nw=nw, engine=engine)
+        P, f, t = omt.mt_spectrogram(x.astype(wide), spw, nov, fs=7.0, nfft=nfft, nw=nw)
+        assert got.power.shape == P.shape and got.power.dtype == np.dtype(dt).type(0).real.dtype
+        assert np.array_equal(got.freq, f) and np.array_equal(got.time, t)
+        assert relerr(got.power, P) < tol
+    two = d.mt_pgram(x[:1024].real.astype(np.float32 if np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64), onesided=False,
+                     engine=engine)
+    ref, _ = omt.mt_pgram(x[:1024].real.astype(np.float64), onesided=False)
+    assert two.power.shape == (1024,) and relerr(two.power, ref) < tol
+
+
+def test_mt_spectrogram_reference_forms(d, golden):
+    # test/periodograms.jl:39-89
+    x0 = golden["spectrogram_x"]
+    sp = d.mt_spectrogram(x0, 256, 128, fs=10)
+    assert np.array_equal(sp.freq, golden["spectrogram_f"]) or isapprox(sp.freq, golden["spectrogram_f"])
+    assert isapprox(sp.time, golden["spectrogram_t"])
+    assert isapprox(sp.power[:, 0], d.mt_pgram(x0[:256], fs=10).power)
+    cfg = d.MTSpectrogramConfig(np.float64, len(x0), 256, 128, fs=10)
+    out = np.zeros((len(cfg.mt_config.freq), len(cfg.time)))
+    assert isapprox(d.mt_spectrogram_(out, x0, cfg).power, sp.power) and isapprox(d.mt_spectrogram(x0, cfg).power, sp.power)
+    assert isapprox(d.mt_spectrogram_(out, x0, 256, 128, fs=10).power, sp.power)
+    cfg32 = d.MTSpectrogramConfig(np.float32, len(x0), 256, 128, fs=10)
+    assert relerr(d.mt_spectrogram(x0.astype(np.float32), cfg32).power, sp.power) < TOL32
+    mc = d.MTConfig(np.float64, 256, fs=10)
+    assert isapprox(d.mt_spectrogram(x0, mc, 128).power, sp.power)
+    with pytest.raises(d.DimensionMismatch):
+        d.mt_spectrogram_(np.zeros((out.shape[0], out.shape[1] + 1)), x0, cfg)
+    with pytest.raises(d.DimensionMismatch):
+        d.mt_spectrogram_(out, np.concatenate([x0, x0]), cfg)
+
+
+@pytest.mark.parametrize("engine", ENGINES, ids=_eng_name)
+def test_mt_cross_spectra_and_coherence(d, golden, engine):
+    # test/multitaper.jl:254-335 (MNE-Python goldens) and :96-250 (synthetic coherence properties)
+    from oracle import multitaper as omt
+    fs, n = 1000.0, 1024
+    t = np.arange(n) / fs
+    sin1, sin2 = np.sin(np.pi * 2 * 12.0 * t), np.sin(np.pi * (2 * 12.0 * t + 1))
+    noise = golden["noise"]
+    sig = np.vstack([sin1, sin2])
+    mc = d.dpss_config(np.float64, n, fs=fs, keep_only_large_evals=True, weight_by_evals=True, engine=engine)
+    cfg = d.MTCrossSpectraConfig(2, mc, demean=True)
+    res = d.mt_cross_power_spectra(sig, cfg)
+    ref = (golden["csd_array_multitaper_values_re"] + 1j * golden["csd_array_multitaper_values_im"]).reshape((2, 2, 512), order="F")
+    assert isapprox(res.freq[1:], golden["csd_array_multitaper_frequencies"]) and isapprox(res.power[:, :, 1:], ref)
+    out = np.zeros((2, 2, len(cfg.freq)), dtype=np.complex128)
+    assert isapprox(d.mt_cross_power_spectra_(out, sig, cfg).power, res.power)
+    mc32 = d.dpss_config(np.float32, n, fs=fs, keep_only_large_evals=True, weight_by_evals=True, engine=engine)
+    r32 = d.mt_cross_power_spectra(sig.astype(np.float32), d.MTCrossSpectraConfig(2, mc32, demean=True))
+    assert r32.power.dtype == np.complex64 and relerr(r32.power, res.power) < 2e-5
+    with pytest.raises(d.DimensionMismatch):
+        d.mt_cross_power_spectra_(np.zeros((3, 2, len(cfg.freq)), dtype=np.complex128), sig, cfg)
+    with pytest.raises(d.DimensionMismatch):
+        d.mt_cross_power_spectra(np.vstack([sig, sig]), cfg)
+    # MNE coherence reference value
+    noisy = np.vstack([sin1, sin1 + 3 * noise])
+    ccfg = d.MTCoherenceConfig(2, mc, freq_range=(10, 15), demean=True)
+    coh = d.mt_coherence(noisy, ccfg)
+    assert all(10 <= f <= 15 for f in coh.freq)
+    c = coh.coherence
+    assert abs(c.mean(axis=2)[1, 0] - 0.982356762670818) < 1e-10
+    assert np.array_equal(c, c.transpose(1, 0, 2)) and np.all(c[0, 0] == 1) and np.all(c[1, 1] == 1)
+    # one channel: cross spectra == mt_pgram
+    x = sin1 + 3 * noise
+    cs = d.mt_cross_power_spectra(x[None, :], fs=fs, engine=engine)
+    p = d.mt_pgram(x, fs=fs, engine=engine)
+    assert isapprox(cs.freq, p.freq) and isapprox(cs.power[0, 0].real, p.power)
+    with pytest.raises(d.ArgumentError):
+        d.mt_cross_power_spectra(x[None, :].astype(complex), fs=fs)
+    # against the oracle with three channels, a frequency band, no demeaning, Float32 and Float64
+    rng = np.random.default_rng(4)
+    several = np.vstack([sin1, sin2, rng.random(n) * 2 - 1])
+    for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
+        got = d.mt_coherence(several.astype(dt), fs=fs, freq_range=(10, 15), engine=engine)
+        ref, f = omt.mt_coherence(several, fs=fs, freq_range=(10, 15))
+        assert got.coherence.shape == ref.shape == (3, 3, len(f)) and got.coherence.dtype == dt
+        assert relerr(got.coherence, ref) < tol
+        gcs = d.mt_cross_power_spectra(several.astype(dt), fs=fs, demean=True, engine=engine)
+        rcs, _ = omt.mt_cross_power_spectra(several, fs=fs, demean=True)
+        assert relerr(gcs.power, rcs) < tol
+
+
 def test_config5_resample_160_147(d, torch):
     # BASELINE config 5 shape (reduced length): 160//147, 5120 taps (32 per phase), 4 channels Float32.
     from oracle import stream_filt as osf

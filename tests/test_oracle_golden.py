@@ -363,3 +363,66 @@ def test_config5_lengths():
     assert math.ceil(2 ** 28 * Fraction(160, 147)) == 292174646
     pfb = sf.taps2pfb(np.arange(1, 10), 4)
     assert np.array_equal(pfb, [[9, 0, 0, 0], [5, 6, 7, 8], [1, 2, 3, 4]])     # stream_filt.jl:286-292
+
+
+# ---- multitaper (src/multitaper.jl) and dpss (windows.jl:668-776): oracle pinned to the reference's MATLAB / MNE goldens ----
+def test_dpss_matlab_golden(golden):
+    from oracle import windows as ow
+    d1 = ow.dpss(128, 4)
+    assert isapprox(d1, golden["dpss128_4"])                                     # test/windows.jl:34-36
+    lam = [0.9999999997159923, 0.9999999731146645, 0.9999988168667646, 0.9999680890685374, 0.9994167543397652,
+           0.9925560207018469, 0.9368556668429153]
+    assert isapprox(ow.dpsseig(d1, 4), np.array(lam))                            # test/windows.jl:39-42
+    z = ow.dpss(8, 2, 1, zerophase=True)[:, 0]
+    assert np.array_equal(z, np.fft.ifftshift(ow.dpss(9, 2, 1)[:8, 0]))          # test/windows.jl:171
+    with pytest.raises(ValueError):
+        ow.dpss(9, 2, 1, zerophase=True)                                         # test/windows.jl:173
+
+
+def test_mt_pgram_matlab_goldens(golden):
+    from oracle import multitaper as omt, windows as ow
+    s = golden["stft_x"]
+    p, _ = omt.mt_pgram(s, fs=16000)
+    assert isapprox(p, golden["mt_pgram"])                                       # test/periodograms.jl:385
+    p, _ = omt.mt_pgram(s, fs=16000, window=ow.dpss(len(s), 4))
+    assert isapprox(p, golden["mt_pgram"])                                       # :386
+    x = golden["pmtm_x"]
+    p, f = omt.mt_pgram(x, fs=1000, nw=4, nfft=omt.nextpow2(len(x)))
+    assert isapprox(f, golden["pmtm_fx"]) and isapprox(p, golden["pmtm_pxx"])    # :416-418
+
+
+def test_mt_spectrogram_first_column_is_mt_pgram(golden):
+    from oracle import multitaper as omt
+    x0 = golden["spectrogram_x"]
+    P, f, t = omt.mt_spectrogram(x0, 256, 128, fs=10)
+    assert np.array_equal(f, golden["spectrogram_f"]) or isapprox(f, golden["spectrogram_f"])
+    assert isapprox(t, golden["spectrogram_t"])                                  # test/periodograms.jl:39-41
+    assert isapprox(P[:, 0], omt.mt_pgram(x0[:256], fs=10)[0])                   # :42
+    for n_samples in range(20, 101, 20):                                         # test/multitaper.jl:16-19
+        for spw in range(20, 101, 20):
+            for ov in range(0, spw, 20):
+                cfg = omt.MTSpectrogramConfig(n_samples, omt.MTConfig(np.float64, spw), ov)
+                from oracle.periodograms import arraysplit
+                assert len(cfg.time) == len(arraysplit(np.arange(1, n_samples + 1), spw, ov))
+
+
+def test_mt_cross_spectra_and_coherence_mne_goldens(golden):
+    from oracle import multitaper as omt
+    fs, n = 1000.0, 1024
+    t = np.arange(n) / fs
+    sig = np.vstack([np.sin(np.pi * 2 * 12.0 * t), np.sin(np.pi * (2 * 12.0 * t + 1))])
+    mc = omt.dpss_config(np.float64, n, fs=fs, keep_only_large_evals=True, weight_by_evals=True)
+    cs, fr = omt.mt_cross_power_spectra(sig, omt.MTCrossSpectraConfig(2, mc, demean=True))
+    ref = (golden["csd_array_multitaper_values_re"] + 1j * golden["csd_array_multitaper_values_im"]).reshape((2, 2, 512), order="F")
+    assert isapprox(fr[1:], golden["csd_array_multitaper_frequencies"])          # test/multitaper.jl:281
+    assert isapprox(cs[:, :, 1:], ref)                                           # :282
+    noisy = np.vstack([sig[0], sig[0] + 3 * golden["noise"]])
+    coh, f = omt.mt_coherence(noisy, omt.MTCrossSpectraConfig(2, mc, demean=True, freq_range=(10, 15)))
+    assert all(10 <= x <= 15 for x in f)
+    assert abs(coh.mean(axis=2)[1, 0] - 0.982356762670818) < 1e-12               # :270-272 (MNE reference value)
+    x = sig[0] + 3 * golden["noise"]                                             # :308-316: cross spectra of one channel == mt_pgram
+    cs1, f1 = omt.mt_cross_power_spectra(x[None, :], fs=fs)
+    pg, fg = omt.mt_pgram(x, fs=fs)
+    assert isapprox(f1, fg) and isapprox(cs1[0, 0].real, pg)
+    with pytest.raises(ValueError):
+        omt.mt_cross_power_spectra(x[None, :].astype(complex), fs=fs)            # :333
