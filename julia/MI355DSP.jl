@@ -381,4 +381,34 @@ function resample(x::AbstractVecOrMat{T}, rate::AbstractFloat, h::Vector, Nϕ::I
     ndims(x) == 1 ? y[1:outLen] : y[1:outLen, :]
 end
 
+# ------------------------------------------------------------------------------------------------ multitaper
+# MTConfig{T}(n_samples; ...) keeps DSP.jl's own constructor (host: dpss, r, freq); the device plan mirrors it.
+mutable struct MTPlan
+    h::Ptr{Cvoid}
+    nout::Int
+end
+function MTPlan(::Type{T}, window::Matrix{Float64}, r::Vector{Float64}, nfft::Integer, onesided::Bool) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mdsp_mt_plan_create, lib), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Cint, Cint, Cint),
+                p, size(window, 1), nfft, window, size(window, 2), r, onesided, mdtype(T), 0))
+    pl = MTPlan(p[], onesided ? nfft >> 1 + 1 : nfft)
+    finalizer(x -> ccall((:mdsp_mt_plan_destroy, lib), Cint, (Ptr{Cvoid},), x.h), pl)
+    pl
+end
+# mt_pgram!(output, signal, config) / mt_spectrogram!(destination, signal, config)   multitaper.jl:225-245, :312-330
+function mt_psd!(out::DeviceArray, pl::MTPlan, s::DeviceArray, noverlap::Integer=0)
+    check(ccall((:mdsp_mt_psd_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}),
+                pl.h, s.ptr, size(s, 1), noverlap, size(s, 2), size(s, 1), out.ptr, pl.nout, size(out, 1) * size(out, 2), C_NULL))
+    out
+end
+# mt_cross_power_spectra!(output, signal, config)   multitaper.jl:551-585 (signal: samples x channels on the device)
+function mt_cross!(out::DeviceArray, xmt::DeviceArray, pl::MTPlan, s::DeviceArray, freq_inds::Vector{Int64}, demean::Bool)
+    nch = size(s, 2)
+    check(ccall((:mdsp_mt_spectra_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}),
+                pl.h, s.ptr, nch, size(s, 1), demean, xmt.ptr, C_NULL))
+    check(ccall((:mdsp_mt_cross_spectra, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                pl.h, xmt.ptr, nch, freq_inds .- 1, length(freq_inds), out.ptr, C_NULL))
+    out
+end
+
 end # module
