@@ -15,7 +15,7 @@ from .design import resample_filter, kaiserord  # noqa: F401
 from .dspbase import conv, conv_, xcorr, optimalfftfiltlength, os_fft_complexity, SMALL_FILT_CUTOFF  # noqa: F401
 from .dspbase import filt as _filt_ba, filt_ as _filt_ba_
 from .filters import (FIRFilter, fftfilt, fftfilt_, tdfilt, tdfilt_, resample, inputlength, outputlength,  # noqa: F401
-                      filt as _filt_bx, filt_ as _filt_bx_, filt_stateless)
+                      filt as _filt_bx, filt_ as _filt_bx_, filt_stateless, DF2TFilter, filtfilt)
 from .multitaper import (MTConfig, MTSpectrogramConfig, MTCrossSpectraConfig, MTCoherenceConfig, CrossPowerSpectra, Coherence,  # noqa: F401
                          coherence, dpss_config, mt_pgram, mt_pgram_, mt_spectrogram, mt_spectrogram_, mt_cross_power_spectra,
                          mt_cross_power_spectra_, mt_coherence, mt_coherence_)
@@ -30,10 +30,11 @@ def filt(*args, **kw):
     ``filt(b, a, x)``          time-domain FIR, scalar ``a``            (dspbase.jl:14)
     ``filt(b, x)``             FIR, FFT overlap-save when length(b) > 66 (Filters/filt.jl:445, :525)
     ``filt(f::FIRFilter, x)``  stateful polyphase filter                 (stream_filt.jl:627)
+    ``filt(f::DF2TFilter, x)`` stateful FIR filter (TDF-II state)        (Filters/filt.jl:153)
     ``filt(h, x, ratio)``      stateless polyphase filter                (stream_filt.jl:663)
     ``filt(h, x, rate::float, Nphi=32)``  stateless arbitrary-rate resampler (stream_filt.jl:669)
     """
-    if len(args) == 2 and isinstance(args[0], FIRFilter):
+    if len(args) == 2 and isinstance(args[0], (FIRFilter, DF2TFilter)):
         return args[0].filt(args[1])
     if len(args) == 2:
         return _filt_bx(*args, **kw)

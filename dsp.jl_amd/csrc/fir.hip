@@ -42,6 +42,9 @@ template <typename R> __device__ __forceinline__ void fma_acc(cx<R>& acc, R h, c
 template <typename R> __device__ __forceinline__ R mul_first(R h, R x) { return h * x; }
 template <typename R> __device__ __forceinline__ cx<R> mul_first(R h, cx<R> x) { return {h * x.x, h * x.y}; }
 
+// 2 a - b  (extrapolate_signal!)
+template <typename R> __device__ __forceinline__ R sub2(R a, R b) { return (R)2 * a - b; }
+template <typename R> __device__ __forceinline__ cx<R> sub2(cx<R> a, cx<R> b) { return {(R)2 * a.x - b.x, (R)2 * a.y - b.y}; }
 // muladd(yUpper, alpha::Float64, yLower) evaluated in Float64 and rounded once to the buffer's element type
 __device__ __forceinline__ float arb_combine(float up, double al, float lo) { return (float)fma((double)up, al, (double)lo); }
 __device__ __forceinline__ double arb_combine(double up, double al, double lo) { return fma(up, al, lo); }
@@ -370,6 +373,89 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
             }
         }
         yc[m0 + j] = arb_combine(up, rc.alpha, lo);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Stateful time-domain FIR: DF2TFilter{PolynomialRatio} with a = [1] (Filters/filt.jl:153-181) advanced by
+// _filt_fir! (dspbase.jl:95-105).  The state si[0..nb-2] is the TDF-II register file, NOT an input history:
+//     y[n]   = fma(x[n], b0, fma(x[n-1], b1, ... start))            start = si0[n]                (n <  nb-1)
+//                                                                       = b[nb-1] * x[n-nb+1]      (n >= nb-1)
+//     si'[j] = fma(x[N-1], b[j+1], fma(x[N-2], b[j+2], ... start))  start = si0[j+N]              (N <= nb-2-j)
+//                                                                       = b[nb-1] * x[N-1-(nb-2-j)] otherwise
+// -- the same innermost-first accumulation order the serial recursion produces, so outputs and state agree with
+// the reference to the last fused-multiply-add.
+// ------------------------------------------------------------------------------------------------------------
+template <typename A, typename R>
+__global__ __launch_bounds__(256) void tdfir_state_out_kernel(const A* __restrict__ x, const A* __restrict__ si0, A* __restrict__ y, const R* __restrict__ b,
+                                                              int64_t nx, int64_t ldx, int64_t ldy, int nb) {
+    const int64_t col = blockIdx.y;
+    const A* xc = x + col * ldx;
+    const A* sc = si0 + col * (int64_t)(nb - 1);
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < nx; n += (int64_t)gridDim.x * blockDim.x) {
+        A acc;
+        int k;
+        if (n < nb - 1) {
+            acc = sc[n];
+            k = (int)n;
+        } else {
+            acc = mul_first(b[nb - 1], xc[n - (nb - 1)]);
+            k = nb - 2;
+        }
+        for (; k >= 0; --k) fma_acc(acc, b[k], xc[n - k]);
+        y[col * ldy + n] = acc;
+    }
+}
+
+// one workgroup per column; every thread first computes its new registers (reading the OLD state), then all write
+template <typename A, typename R>
+__global__ __launch_bounds__(256) void tdfir_state_next_kernel(const A* __restrict__ x, A* __restrict__ si, const R* __restrict__ b, int64_t N, int64_t ldx,
+                                                               int nb) {
+    constexpr int MAXPER = 16;   // nb - 1 <= 256 * MAXPER
+    const int64_t col = blockIdx.x;
+    const A* xc = x + col * ldx;
+    A* sc = si + col * (int64_t)(nb - 1);
+    A res[MAXPER];
+#pragma unroll
+    for (int q = 0; q < MAXPER; ++q) {
+        const int j = threadIdx.x + 256 * q;
+        if (j >= nb - 1) break;
+        const int span = nb - 2 - j;             // largest m with b[j+1+m] defined
+        A acc;
+        int64_t m;
+        if (N <= span) {
+            acc = sc[j + N];
+            m = N - 1;
+        } else {
+            acc = mul_first(b[nb - 1], xc[N - 1 - span]);
+            m = span - 1;
+        }
+        for (; m >= 0; --m) fma_acc(acc, b[j + 1 + m], xc[N - 1 - m]);
+        res[q] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MAXPER; ++q) {
+        const int j = threadIdx.x + 256 * q;
+        if (j >= nb - 1) break;
+        sc[j] = res[q];
+    }
+}
+
+// extrapolate_signal! (Filters/filt.jl:243-257): out = [2 x[1] .- x[pad+1:-1:2]; x; 2 x[end] .- x[end-1:-1:end-pad]]
+template <typename A>
+__global__ __launch_bounds__(256) void extrapolate_kernel(const A* __restrict__ x, A* __restrict__ out, int64_t n, int64_t ldx, int64_t ldo, int64_t pad) {
+    const int64_t col = blockIdx.y;
+    const A* xc = x + col * ldx;
+    A* oc = out + col * ldo;
+    const int64_t total = n + 2 * pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        A v;
+        if (i < pad) v = sub2(xc[0], xc[pad - i]);                     // 1-based: out[i] = 2 sig[1] - sig[2 + pad - i]
+        else if (i < pad + n) v = xc[i - pad];
+        else v = sub2(xc[n - 1], xc[n - 1 - (i - pad - n + 1)]);     // out[n + pad + i'] = 2 sig[n] - sig[n - i']
+        oc[i] = v;
     }
 }
 
@@ -1044,6 +1130,73 @@ int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx
     MDSP_TRY(shiftin_dispatch(&b, x_dev, xlen, ldx, st));                  // :620
     if (nwritten) *nwritten = nout;
     return MDSP_OK;
+}
+
+// ---- stateful time-domain FIR (DF2TFilter with FIR coefficients) and filtfilt's odd extension --------------------
+}  // extern "C"
+
+namespace {
+
+template <typename A, typename R>
+int tdfir_state_run(const void* taps_host, int64_t nb, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t ldy, void* si, hipStream_t st) {
+    DevBuf bdev;
+    MDSP_TRY(bdev.reserve(sizeof(R) * (size_t)nb));
+    MDSP_HIP(hipMemcpyAsync(bdev.p, taps_host, sizeof(R) * (size_t)nb, hipMemcpyHostToDevice, st));
+    if (nx > 0) {
+        const dim3 g((unsigned)std::min<int64_t>(cdiv(nx, 256), 4096), (unsigned)ncols);
+        hipLaunchKernelGGL((tdfir_state_out_kernel<A, R>), g, dim3(256), 0, st, (const A*)x, (const A*)si, (A*)y, bdev.as<R>(), nx, ldx, ldy, (int)nb);
+        MDSP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((tdfir_state_next_kernel<A, R>), dim3((unsigned)ncols), dim3(256), 0, st, (const A*)x, (A*)si, bdev.as<R>(), nx, ldx, (int)nb);
+        MDSP_LAUNCH_CHECK();
+    }
+    MDSP_HIP(hipStreamSynchronize(st));   // the tap buffer dies with this call
+    return MDSP_OK;
+}
+
+template <typename A> int extrapolate_run(const void* x, int64_t n, int64_t ncols, int64_t ldx, void* out, int64_t ldo, int64_t pad, hipStream_t st) {
+    const dim3 g((unsigned)std::min<int64_t>(cdiv(n + 2 * pad, 256), 65535), (unsigned)ncols);
+    hipLaunchKernelGGL(extrapolate_kernel<A>, g, dim3(256), 0, st, (const A*)x, (A*)out, n, ldx, ldo, pad);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdsp_tdfir_state_exec(const void* taps_host, int64_t nb, int dtype, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,
+                          int64_t ldy, void* si_dev, void* stream) {
+    if (!taps_host || nb < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "filter vector b must be non-empty");
+    if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype");
+    if (nx < 0 || ncols < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (nb < 2) MDSP_FAIL(MDSP_ERR_ARGUMENT, "a one-tap filter has no state; scale the signal instead");   // mul!(out, x, b[1]), filt.jl:163
+    if (nb - 1 > 256 * 16) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "stateful time-domain FIR supports at most 4097 taps");
+    if (nx == 0 || ncols == 0) return MDSP_OK;
+    if (ncols > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 columns per call");
+    if (!x_dev || !y_dev || !si_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case MDSP_F32: return tdfir_state_run<float, float>(taps_host, nb, x_dev, nx, ncols, ldx, y_dev, ldy, si_dev, st);
+        case MDSP_F64: return tdfir_state_run<double, double>(taps_host, nb, x_dev, nx, ncols, ldx, y_dev, ldy, si_dev, st);
+        case MDSP_C32: return tdfir_state_run<cx<float>, float>(taps_host, nb, x_dev, nx, ncols, ldx, y_dev, ldy, si_dev, st);
+        default: return tdfir_state_run<cx<double>, double>(taps_host, nb, x_dev, nx, ncols, ldx, y_dev, ldy, si_dev, st);
+    }
+}
+
+int mdsp_extrapolate(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int dtype, int64_t pad, void* out_dev, int64_t ldo, void* stream) {
+    if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype");
+    if (n < 1 || pad < 0 || pad > n - 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "pad_length must be in [0, length(x) - 1]");     // sig[2 + pad - i] must exist
+    if (ldo < n + 2 * pad) MDSP_FAIL(MDSP_ERR_ARGUMENT, "output is incorrectly sized");                               // filt.jl:245
+    if (ncols <= 0) return MDSP_OK;
+    if (ncols > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 columns per call");
+    if (!x_dev || !out_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    hipStream_t st = as_stream(stream);
+    switch (dtype) {
+        case MDSP_F32: return extrapolate_run<float>(x_dev, n, ncols, ldx, out_dev, ldo, pad, st);
+        case MDSP_F64: return extrapolate_run<double>(x_dev, n, ncols, ldx, out_dev, ldo, pad, st);
+        case MDSP_C32: return extrapolate_run<cx<float>>(x_dev, n, ncols, ldx, out_dev, ldo, pad, st);
+        default: return extrapolate_run<cx<double>>(x_dev, n, ncols, ldx, out_dev, ldo, pad, st);
+    }
 }
 
 // ---- time-domain FIR: filt(b, a::Number, x) / tdfilt (dspbase.jl:95-105) -------------------------------------

@@ -381,3 +381,95 @@ def resample(x, rate, h=None, dims: int | None = None, Nphi: int = 32):
     if nd == 1:
         y = y.reshape(out_len)
     return y if _dev.is_device_array(x) else y.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Stateful FIR filtering (DF2TFilter) and zero-phase FIR filtering (filtfilt)   Filters/filt.jl:122-181, :296-338
+# ---------------------------------------------------------------------------------------------------------
+class DF2TFilter:
+    """``DF2TFilter(PolynomialRatio(b, [1]), [T], coldims=())`` for FIR coefficients: a filter object carrying the
+    TDF-II state ``state`` of shape ``(length(b) - 1, coldims...)`` between calls (filt.jl:122-181).
+
+    ``DF2TFilter(b)`` / ``DF2TFilter(b, a)`` with scalar or length-1 ``a``; an IIR ``a`` is a serial recursion and is
+    left to DSP.jl's CPU code (``UnsupportedError``)."""
+
+    def __init__(self, b, a=1.0, dtype=None, coldims=()):
+        bv, av = _host_vec(b), _host_vec(a)
+        if bv.size == 0 or av.size == 0:
+            raise ArgumentError("filter coefficients must be non-empty")
+        if av.size > 1:
+            raise UnsupportedError("IIR DF2TFilter is a serial recursion; only FIR coefficients run on the device")
+        if av[0] == 0:
+            raise ArgumentError("filter vector a[1] must be nonzero")
+        if bv.dtype.kind == "c":
+            raise UnsupportedError("complex FIR taps are not accelerated")
+        if av[0] != 1:
+            bv = bv / av[0]                                             # PolynomialRatio normalises by a[1]
+        self.b = bv if bv.dtype in (np.dtype(np.float32), np.dtype(np.float64)) else bv.astype(np.float64)
+        T = np.result_type(self.b.dtype, dtype) if dtype is not None else self.b.dtype   # zeros(promote_type(T, V), ...), :150
+        self._T = _compute_dtype(T)
+        self.state = _dev.torch.zeros((len(self.b) - 1,) + tuple(coldims), dtype=_dev.torch_dtype(self._T), device=_dev.device())
+
+    def filt(self, x):
+        """``filt(f, x)`` = ``filt!(similar(x, promote_type(...)), f, x)`` (filt.jl:153-181)."""
+        if tuple(x.shape[1:]) != tuple(self.state.shape[1:]):
+            raise ArgumentError("state size must match x")              # :158
+        xdt = _dev.np_dtype_of(x)
+        W = _compute_dtype(np.result_type(self.b.dtype, xdt, self._T))
+        cols, shape = _dev.to_columns(x, W)
+        ncols, nx = cols.shape
+        nb = len(self.b)
+        if nb == 1:                                                     # mul!(out, x, b[1]), :163
+            return _dev.from_columns(cols * float(self.b[0]), shape, x)
+        if self._T != W:                                                # a wider signal eltype widens the state for good
+            self.state = self.state.to(_dev.torch_dtype(W))
+            self._T = W
+        out = _dev.empty_columns(ncols, nx, W)
+        if nx and ncols:
+            si = self.state.reshape(nb - 1, -1).t().contiguous()        # (ncols, nb-1): one register file per column
+            taps = np.ascontiguousarray(self.b, dtype=np.float32 if W in (np.dtype(np.float32), np.dtype(np.complex64)) else np.float64)
+            _lib.check(_lib.lib().mdsp_tdfir_state_exec(taps.ctypes.data_as(C.c_void_p), nb, _dev.md_dtype(W), _dev.ptr(cols), nx, ncols, nx,
+                                                        _dev.ptr(out), nx, _dev.ptr(si), _dev.stream_ptr()))
+            self.state = si.t().reshape(self.state.shape).contiguous()
+        return _dev.from_columns(out, shape, x)
+
+
+def filtfilt(b, *args):
+    """``filtfilt(b, x)`` / ``filtfilt(b, a, x)`` with scalar or length-1 ``a`` (filt.jl:301-338): zero-phase FIR
+    filtering -- odd-symmetric extension by ``length(b)-1`` samples, one pass with ``conv(b, reverse(b))``, trim."""
+    if len(args) == 2:
+        a, x = args
+        av = _host_vec(a)
+        if av.size != 1:
+            raise UnsupportedError("IIR filtfilt is a serial recursion; only FIR coefficients run on the device")
+        bv = _host_vec(b)
+        if av[0] != 1:
+            bv = bv / av[0]                                             # :331-333
+    elif len(args) == 1:
+        x = args[0]
+        bv = _host_vec(b)
+    else:
+        raise TypeError("filtfilt(b, x) or filtfilt(b, a, x)")
+    if bv.dtype.kind == "c":
+        raise UnsupportedError("complex FIR taps are not accelerated")
+    nb = len(bv)
+    n = int(x.shape[0])
+    if nb - 1 > n - 1:
+        raise ArgumentError("the signal must be longer than the filter order")   # sig[2 + pad_length - i] is a BoundsError in the reference
+    # newb = conv(b, reverse(b)), built as the reference builds it: causal half by filt!, mirrored (:309-314)
+    bw = bv.astype(np.float64) if bv.dtype.kind != "f" else bv
+    rev = bw[::-1].copy()
+    half = np.array([np.dot(bw[:k + 1][::-1], rev[:k + 1]) for k in range(nb)], dtype=bw.dtype)
+    newb = np.concatenate([half, half[nb - 2::-1] if nb > 1 else half[:0]])
+    xdt = _dev.np_dtype_of(x)
+    W = _compute_dtype(np.result_type(bw.dtype, xdt))
+    cols, shape = _dev.to_columns(x, W)
+    ncols = cols.shape[0]
+    ext = _dev.empty_columns(ncols, n + 2 * (nb - 1), W)
+    if ncols and n:
+        _lib.check(_lib.lib().mdsp_extrapolate(_dev.ptr(cols), n, ncols, n, _dev.md_dtype(W), nb - 1, _dev.ptr(ext), n + 2 * (nb - 1),
+                                               _dev.stream_ptr()))
+    y = filt(newb, ext.t())                                             # filt!(extrapolated, newb, extrapolated), :322
+    y = y[2 * nb - 2:]                                                  # drop garbage at start, :325
+    res = y.reshape((n,) + tuple(shape[1:]))
+    return res if _dev.is_device_array(x) else res.cpu().numpy()

@@ -249,6 +249,16 @@ int mdsp_arb_trajectory(double phi_acc, int64_t input_deficit, double rate, int6
 int mdsp_tdfir_exec(const void* taps_host, int64_t nb, int dtype, const void* x_dev, int64_t nx, int64_t ncols,
                     int64_t ldx, void* y_dev, int64_t ldy, void* stream);
 
+/* Stateful time-domain FIR: filt!(out, f::DF2TFilter{<:PolynomialRatio}, x) with FIR coefficients (Filters/filt.jl:153-181)
+ *   advancing the TDF-II state exactly as _filt_fir!(out, b, x, si, col) does (dspbase.jl:95-105).
+ *   si_dev: (nb-1, ncols) of `dtype`, read as the initial state and overwritten with the final one. */
+int mdsp_tdfir_state_exec(const void* taps_host, int64_t nb, int dtype, const void* x_dev, int64_t nx, int64_t ncols,
+                          int64_t ldx, void* y_dev, int64_t ldy, void* si_dev, void* stream);
+/* extrapolate_signal! (Filters/filt.jl:243-257), the odd-symmetric extension filtfilt applies per column:
+ *   out (n + 2 pad, ncols) = [2 x[1] .- x[pad+1:-1:2]; x; 2 x[end] .- x[end-1:-1:end-pad]] */
+int mdsp_extrapolate(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int dtype, int64_t pad, void* out_dev,
+                     int64_t ldo, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Measurement helpers (used by bench.py; not part of the drop-in surface)
  * ---------------------------------------------------------------------------------------------------- */

@@ -87,6 +87,22 @@ def _filt_iir(b, a, x):
     return out
 
 
+def _filt_iir_state(b, a, x, si0):
+    """dspbase.jl:69-92 with an initial state (used by iir_filtfilt); b, a zero-padded to equal length."""
+    silen = len(b) - 1
+    si = np.array(si0, dtype=x.dtype, copy=True)
+    out = np.empty_like(x)
+    for i in range(len(x)):
+        xi = x[i]
+        val = xi * b[0] + (si[0] if silen else 0)
+        out[i] = val
+        for j in range(silen - 1):
+            si[j] = val * (-a[j + 1]) + (xi * b[j + 1] + si[j + 1])
+        if silen:
+            si[silen - 1] = xi * b[silen] - a[silen] * val
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # FFT length selection, dspbase.jl:262-291
 # ---------------------------------------------------------------------------------------------

@@ -584,6 +584,60 @@ def test_resample_arbitrary_rate(d, torch):
     assert yy.shape == (len(ref), 3) and relerr(yy[:, 1].cpu().numpy(), ref) < 3e-6
 
 
+def test_df2tfilter_fir_streaming_state(d):
+    # Filters/filt.jl:153-181 with FIR coefficients: outputs AND the TDF-II state after every chunk match _filt_fir!
+    # (dspbase.jl:95-105); chunked == one-shot (test/filt.jl "DF2TFilter" streaming checks)
+    from oracle import filt as of
+    from oracle.dspbase import filt_ba
+    rng = np.random.default_rng(21)
+    for nb in (2, 5, 12, 67, 300):
+        for Tb, Tx in ((np.float64, np.float64), (np.float32, np.float32), (np.float64, np.complex128), (np.float32, np.complex64),
+                       (np.float32, np.float64)):
+            b = rng.standard_normal(nb).astype(Tb)
+            x = rng.standard_normal((400, 3)).astype(Tx)
+            if np.dtype(Tx).kind == "c":
+                x = (x + 1j * rng.standard_normal((400, 3))).astype(Tx)
+            single = np.result_type(Tb, Tx) in (np.dtype(np.float32), np.dtype(np.complex64))
+            tol = 2e-6 if single else 1e-13
+            f, o = d.DF2TFilter(b, dtype=Tx, coldims=(3,)), of.DF2TFilterFIR(b, dtype=Tx, coldims=(3,))   # DF2TFilter(coef, V, coldims), filt.jl:149
+            ys, yo = [], []
+            for chunk in (x[:50], x[50:51], x[51:53], x[53:]):
+                ys.append(d.filt(f, chunk)); yo.append(o.filt(chunk))
+                st = f.state.cpu().numpy()
+                assert st.shape == o.state.shape and relerr(st, o.state) < tol
+            y = np.concatenate(ys)
+            assert y.dtype == np.result_type(Tb, Tx) and relerr(y, np.concatenate(yo)) < tol
+            wide = np.complex128 if np.dtype(Tx).kind == "c" else np.float64
+            assert relerr(y, filt_ba(b.astype(np.float64), np.ones(1), x.astype(wide))) < tol
+    f = d.DF2TFilter(rng.standard_normal(8))
+    x = rng.standard_normal(64)
+    y = np.concatenate([d.filt(f, x[i:i + 1]) for i in range(64)])               # one sample at a time
+    assert relerr(y, filt_ba(f.b, np.ones(1), x)) < 1e-13
+    with pytest.raises(d.ArgumentError):
+        d.filt(d.DF2TFilter(np.ones(4), coldims=(2,)), np.ones((10, 3)))           # filt.jl:158
+    with pytest.raises(d.UnsupportedError):
+        d.DF2TFilter(np.ones(3), np.array([1.0, 0.5]))
+
+
+def test_fir_filtfilt(d, golden):
+    # test/filt.jl:334-339: filtfilt(b, x) == iir_filtfilt(b, [1], x), filtfilt(b, [2.0], x) == iir_filtfilt(b, [2], x)
+    from oracle import filt as of
+    rng = np.random.default_rng(8)
+    for b in (rng.standard_normal(10), np.arange(1.0, 11.0)):
+        for x in (rng.standard_normal(100), rng.standard_normal((100, 2)), rng.standard_normal(10)):
+            assert isapprox(d.filtfilt(b, x), of.iir_filtfilt(b, [1.0], x))
+            assert isapprox(d.filtfilt(b, [2.0], x), of.iir_filtfilt(b, [2.0], x))
+    # long filter -> the overlap-save path inside filt(newb, extrapolated); Float32; complex signal with real taps
+    b = _lowpass_taps(129, np.float64)
+    x = golden["spectrogram_x"]
+    assert relerr(d.filtfilt(b, x), of.filtfilt(b, x)) < 1e-12
+    assert relerr(d.filtfilt(b.astype(np.float32), x.astype(np.float32)), of.filtfilt(b, x)) < TOL32
+    z = x[:250] + 1j * x[250:500]
+    assert relerr(d.filtfilt(b[:31] / b[:31].sum(), z), of.filtfilt(b[:31] / b[:31].sum(), z)) < 1e-12
+    with pytest.raises(d.UnsupportedError):
+        d.filtfilt(np.ones(3), np.array([1.0, 0.5]), x)
+
+
 # ============================================================================================ multitaper
 @pytest.mark.parametrize("engine", ENGINES, ids=_eng_name)
 def test_mt_pgram_matlab_goldens(d, golden, engine):
