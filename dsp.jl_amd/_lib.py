@@ -79,6 +79,7 @@ PROTOTYPES = {
     "mdsp_stft_plan_destroy": (ci, [vp]),
     "mdsp_stft_plan_info": (ci, [vp, pi64, pint]),
     "mdsp_stft_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, vp]),
+    "mdsp_hilbert": (ci, [vp, i64, i64, i64, ci, vp, i64, vp]),
     "mdsp_tdfir_state_exec": (ci, [vp, i64, ci, vp, i64, i64, i64, vp, i64, vp, vp]),
     "mdsp_extrapolate": (ci, [vp, i64, i64, i64, ci, i64, vp, i64, vp]),
     "mdsp_mt_plan_create": (ci, [pvp, i64, i64, vp, i64, vp, ci, ci, ci]),

@@ -1362,3 +1362,92 @@ int mdsp_coherence_from_cs(const void* cs_dev, int64_t nch, int64_t nf, int real
 }
 
 }  // extern "C"
+
+// ======================================================================================================
+// hilbert(x) (src/util.jl:31-87): analytic signal along the first dimension
+//   X = rfft(x);  X[2 : N/2 + isodd(N)] *= 2;  X[N/2 + 2 : N] = 0;  out = bfft(X) / N
+// Whole-column transforms of arbitrary length: batched rocFFT (R2C, then an in-place inverse C2C).
+// ======================================================================================================
+namespace {
+
+template <typename R>
+__global__ __launch_bounds__(256) void hilbert_spectrum_kernel(const cx<R>* __restrict__ half, cx<R>* __restrict__ full, int64_t n, int64_t nspec, int64_t ncols) {
+    const int64_t col = blockIdx.y;
+    const cx<R>* h = half + col * nspec;
+    cx<R>* f = full + col * n;
+    const int64_t last2 = n / 2 + (n & 1);   // 1-based indices 2 .. N/2 + isodd(N) are doubled
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        cx<R> v = {(R)0, (R)0};
+        if (i < nspec) {
+            v = h[i];
+            if (i >= 1 && i < last2) v = {v.x * (R)2, v.y * (R)2};
+        }
+        f[i] = v;
+    }
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void hilbert_scale_kernel(const cx<R>* __restrict__ in, cx<R>* __restrict__ out, int64_t n, int64_t ldo, double inv_n) {
+    const int64_t col = blockIdx.y;
+    const R s = (R)inv_n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cx<R> v = in[col * n + i];
+        out[col * ldo + i] = {v.x * s, v.y * s};
+    }
+}
+
+template <typename R> int hilbert_run(const void* x, int64_t n, int64_t ncols, int64_t ldx, void* out, int64_t ldo, hipStream_t st) {
+    const int64_t nspec = n / 2 + 1;
+    // columns are processed in batches whose intermediates stay within ~256 MiB
+    const int64_t per_col = (int64_t)sizeof(R) * n + (int64_t)sizeof(cx<R>) * (nspec + n);
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(ncols, (int64_t(256) << 20) / per_col));
+    DevBuf xin, half, full;
+    RocPlan fwd, inv;
+    MDSP_TRY(half.reserve(sizeof(cx<R>) * (size_t)(nspec * batch)));
+    MDSP_TRY(full.reserve(sizeof(cx<R>) * (size_t)(n * batch)));
+    const bool packed = ldx == n;
+    if (!packed) MDSP_TRY(xin.reserve(sizeof(R) * (size_t)(n * batch)));
+    MDSP_TRY(fwd.create(FftKind::R2C, sizeof(R) == 8, n, batch, false));
+    MDSP_TRY(inv.create(FftKind::C2C_INV, sizeof(R) == 8, n, batch, true));
+    const unsigned gx = (unsigned)std::min<int64_t>(cdiv(n, 256), 4096);
+    for (int64_t c0 = 0; c0 < ncols; c0 += batch) {
+        const int64_t cnt = std::min<int64_t>(batch, ncols - c0);
+        const R* src = static_cast<const R*>(x) + c0 * ldx;
+        if (!packed) {
+            MDSP_HIP(hipMemcpy2DAsync(xin.p, sizeof(R) * (size_t)n, src, sizeof(R) * (size_t)ldx, sizeof(R) * (size_t)n, (size_t)cnt, hipMemcpyDeviceToDevice, st));
+            src = xin.as<R>();
+        }
+        if (cnt < batch) {   // the plans are built for `batch` columns: clear what the tail batch does not fill
+            MDSP_HIP(hipMemsetAsync(full.p, 0, sizeof(cx<R>) * (size_t)(n * batch), st));
+            if (packed) {     // the tail batch must not read past the caller's buffer
+                MDSP_TRY(xin.reserve(sizeof(R) * (size_t)(n * batch)));
+                MDSP_HIP(hipMemsetAsync(xin.p, 0, sizeof(R) * (size_t)(n * batch), st));
+                MDSP_HIP(hipMemcpyAsync(xin.p, src, sizeof(R) * (size_t)(n * cnt), hipMemcpyDeviceToDevice, st));
+                src = xin.as<R>();
+            }
+        }
+        MDSP_TRY(fwd.exec(const_cast<R*>(src), half.p, st));
+        hipLaunchKernelGGL(hilbert_spectrum_kernel<R>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, half.as<cx<R>>(), full.as<cx<R>>(), n, nspec, cnt);
+        MDSP_LAUNCH_CHECK();
+        MDSP_TRY(inv.exec(full.p, full.p, st));
+        hipLaunchKernelGGL(hilbert_scale_kernel<R>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, full.as<cx<R>>(), static_cast<cx<R>*>(out) + c0 * ldo, n, ldo,
+                           1.0 / (double)n);
+        MDSP_LAUNCH_CHECK();
+    }
+    MDSP_HIP(hipStreamSynchronize(st));   // plans and scratch die with this call
+    return MDSP_OK;
+}
+
+}  // namespace
+
+extern "C" int mdsp_hilbert(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int real_dtype, void* out_dev, int64_t ldo, void* stream) {
+    if (real_dtype != MDSP_F32 && real_dtype != MDSP_F64) MDSP_FAIL(MDSP_ERR_ARGUMENT, "hilbert is defined for real signals");
+    if (n < 0 || ncols < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (n == 0 || ncols == 0) return MDSP_OK;
+    if (!x_dev || !out_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    if (ldx < n || ldo < n) MDSP_FAIL(MDSP_ERR_DIMENSION, "column stride smaller than the column length");
+    if (ncols > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 columns per call");
+    MDSP_TRY(rocfft_ensure_setup());
+    return real_dtype == MDSP_F64 ? hilbert_run<double>(x_dev, n, ncols, ldx, out_dev, ldo, as_stream(stream))
+                                  : hilbert_run<float>(x_dev, n, ncols, ldx, out_dev, ldo, as_stream(stream));
+}

@@ -231,3 +231,21 @@ def xcorr(u, v=None, padmode: str = "none", scaling: str = "none"):
         vh = np.concatenate([vh, np.zeros(n - sv, dtype=vh.dtype)])
     res = conv(uh, np.conj(vh)[::-1].copy())
     return res / su if scaling == "biased" else res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# hilbert (src/util.jl:31-87)
+# ---------------------------------------------------------------------------------------------------------
+def hilbert(x):
+    """``hilbert(x)``: analytic representation ``x + j H{x}`` of a real signal along the first dimension."""
+    xdt = _dev.np_dtype_of(x)
+    if xdt.kind == "c":
+        raise TypeError("hilbert is defined for real signals")             # MethodError in the reference
+    from . import util
+    S = util.fftintype(xdt)
+    cols, shape = _dev.to_columns(x, S)
+    ncols, n = cols.shape
+    out = _dev.empty_columns(ncols, n, util.fftouttype(S))
+    if n and ncols:
+        _lib.check(_lib.lib().mdsp_hilbert(_dev.ptr(cols), n, ncols, n, _dev.md_dtype(S), _dev.ptr(out), n, _dev.stream_ptr()))
+    return _dev.from_columns(out, shape, x)

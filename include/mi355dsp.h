@@ -259,6 +259,10 @@ int mdsp_tdfir_state_exec(const void* taps_host, int64_t nb, int dtype, const vo
 int mdsp_extrapolate(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int dtype, int64_t pad, void* out_dev,
                      int64_t ldo, void* stream);
 
+/* hilbert(x) (src/util.jl:31-87): analytic signal of every real column, out (n, ncols) complex of the same precision */
+int mdsp_hilbert(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int real_dtype, void* out_dev, int64_t ldo,
+                 void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Measurement helpers (used by bench.py; not part of the drop-in surface)
  * ---------------------------------------------------------------------------------------------------- */

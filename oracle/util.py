@@ -127,3 +127,16 @@ def shiftin(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     out[:alen - blen] = a[blen:]
     out[alen - blen:] = b
     return out
+
+
+def hilbert(x):
+    """util.jl:31-87: analytic signal along the first dimension (rfft, double the positive bins, zero the negative
+    ones, unnormalised inverse, divide by N)."""
+    x = np.asarray(x)
+    T = fftintype(x.dtype)
+    xs = x.astype(T)
+    N = xs.shape[0]
+    X = np.zeros(xs.shape, dtype=np.complex128)
+    X[: (N >> 1) + 1] = np.fft.rfft(xs.astype(np.float64), axis=0)
+    X[1: N // 2 + (N & 1)] *= 2
+    return (np.fft.ifft(X, axis=0)).astype(fftouttype(T))

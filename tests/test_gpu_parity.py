@@ -638,6 +638,30 @@ def test_fir_filtfilt(d, golden):
         d.filtfilt(np.ones(3), np.array([1.0, 0.5]), x)
 
 
+def test_hilbert(d):
+    # test/util.jl:4-50
+    from oracle import util as ou
+    t = np.arange(0, 2, 1 / 256)
+    a = np.stack([np.sin(np.pi * t), np.cos(np.pi * t), np.sin(2 * np.pi * t), np.cos(2 * np.pi * t)], axis=1)
+    h = np.stack([d.hilbert(a[:, k]) for k in range(4)], axis=1)
+    assert isapprox(h.real, a) and isapprox(np.abs(h), np.ones(a.shape))
+    ang = np.angle(h)
+    assert isapprox(ang[:256, 0], np.arange(-np.pi / 2, np.pi / 2 - np.pi / 512, np.pi / 256))
+    assert isapprox(ang[:256, 1], np.arange(0, np.pi - np.pi / 512, np.pi / 256))
+    assert isapprox(ang[:128, 2], np.arange(-np.pi / 2, np.pi / 2 - np.pi / 256, np.pi / 128))
+    assert isapprox(h[:, 1].imag, a[:, 0])
+    assert isapprox(h, d.hilbert(a))                                   # 2-D input, :49
+    h2 = d.hilbert(np.concatenate([np.ones(10), np.zeros(9)]))        # odd length, :41-44
+    assert isapprox(h2, ou.hilbert(np.concatenate([np.ones(10), np.zeros(9)])))
+    r = np.arange(1, 21)
+    assert np.array_equal(d.hilbert(r), d.hilbert(r.astype(np.float64)))   # :46
+    rng = np.random.default_rng(2)
+    for n, dt, tol in ((1000, np.float64, 1e-12), (4097, np.float32, TOL32), (30030, np.float64, 1e-12)):
+        x = rng.standard_normal((n, 3)).astype(dt)
+        got = d.hilbert(x)
+        assert got.dtype == (np.complex64 if dt == np.float32 else np.complex128) and relerr(got, ou.hilbert(x.astype(np.float64))) < tol
+
+
 # ============================================================================================ multitaper
 @pytest.mark.parametrize("engine", ENGINES, ids=_eng_name)
 def test_mt_pgram_matlab_goldens(d, golden, engine):
