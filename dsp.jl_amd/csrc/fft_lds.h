@@ -201,6 +201,57 @@ template <int N_, int E_> struct Cfg {
     static constexpr int NTWLDS = P <= 1 ? 1 : ldsoff(P - 1) + ldstw(P - 1);
 };
 
+// ------------------------------------------------------------------------------------------------ lane permutations
+// Which butterfly a thread computes in a pass is free as long as reads and writes agree: thread t runs butterflies
+// j = perm_p(t) + T*b of pass p, where perm_p permutes the low six bits of t (inside the wavefront, so global
+// accesses stay coalesced).  tools/lds_perm_search.py picks, per geometry, the bit permutations (and padding) that
+// minimise LDS bank conflicts under the MI355X banking rules (ds_write_b64: 16-lane groups / 32 banks; ds_read_b64:
+// 32-lane groups / 64 banks): N = 4096, E = 16 becomes conflict-free with one element of padding per 32
+// (192 array cycles per transform and wave instead of 256), N = 2048, E = 8 drops from 224 to 160.
+// Measured on MI355X (profiles/r01e_tune_lanes.json): the permuted schedules lose to identity lanes + the same padding,
+// because the permuted pass-0 ownership also permutes the lanes of the global loads / stores (same cache lines per
+// wave, but no longer ascending by lane) -- that costs more than the saved LDS cycles.  They stay available as tuning
+// variants (PERMUTE template flags); the defaults use identity lanes with pad shift 5.
+// The first and the last pass share their permutation so a transform's input and output ownership coincide:
+// thread t holds X[io_lane(t) + T*e] before the first and after the last pass.
+template <int N, int E> struct LanePerm {
+    static constexpr bool any = false;
+    static constexpr int src(int, int bit) { return bit; }
+    static constexpr int padshift = 4;
+};
+template <> struct LanePerm<2048, 8> {   // radices 8 8 8 4
+    static constexpr bool any = true;
+    static constexpr int src(int pass, int bit) {
+        constexpr int A[6] = {0, 4, 1, 2, 3, 5}, B[6] = {0, 1, 2, 4, 5, 3};
+        return (pass == 0 || pass == 3) ? A[bit] : (pass == 1 ? B[bit] : bit);
+    }
+    static constexpr int padshift = 5;
+};
+template <> struct LanePerm<4096, 16> {  // radices 16 16 16
+    static constexpr bool any = true;
+    static constexpr int src(int pass, int bit) {
+        constexpr int A[6] = {4, 0, 1, 2, 3, 5};
+        return (pass == 0 || pass == 2) ? A[bit] : bit;
+    }
+    static constexpr int padshift = 5;
+};
+// PERMUTE = false reproduces the identity mapping (kernels that were not re-tuned, and the host emulation's baseline)
+template <typename C, int PASS, bool PERMUTE> MDSP_HD int lane_perm(int t) {
+    using LP = LanePerm<C::N, C::E>;
+    if constexpr (!PERMUTE || !LP::any || C::T < 64) return t;
+    else {
+        int out = t & ~63;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) out |= ((t >> LP::src(PASS, d)) & 1) << d;
+        return out;
+    }
+}
+template <typename C, bool PERMUTE> MDSP_HD int io_lane(int t) {
+    static_assert(!PERMUTE || !LanePerm<C::N, C::E>::any || LanePerm<C::N, C::E>::src(0, 0) == LanePerm<C::N, C::E>::src(C::P - 1, 0),
+                  "first and last pass must share their lane permutation");
+    return lane_perm<C, 0, PERMUTE>(t);
+}
+
 // twiddle sources
 enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2, TW_HYB = 3 };
 // TW_HYB: passes whose twiddles depend on few distinct k (Ns <= HYB_NS_MAX: a (radix-1) x Ns table of <= 2 KiB) read
@@ -257,25 +308,28 @@ template <typename C, int PASS> MDSP_HD int tw_index(int t, int b, int r) {
 }
 
 // Fill the per-thread twiddle registers (loop-invariant for a persistent workgroup).
-template <typename C, typename R, int PASS = 1, int TWMODE = TW_REG> MDSP_HD void load_twiddles(cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], int t, const cx<R>* table) {
+template <typename C, typename R, int PASS = 1, int TWMODE = TW_REG, bool PERMUTE = false>
+MDSP_HD void load_twiddles(cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], int t, const cx<R>* table) {
     if constexpr (PASS < C::P) {
         if constexpr (tw_pass_in_regs<C, TWMODE, PASS>()) {
             constexpr int Rdx = C::radix(PASS), NB = C::E / Rdx;
+            const int tp = lane_perm<C, PASS, PERMUTE>(t);
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int r = 1; r < Rdx; ++r) tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)] = table[tw_index<C, PASS>(t, b, r)];
+                for (int r = 1; r < Rdx; ++r) tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)] = table[tw_index<C, PASS>(tp, b, r)];
         }
-        load_twiddles<C, R, PASS + 1, TWMODE>(tw, t, table);
+        load_twiddles<C, R, PASS + 1, TWMODE, PERMUTE>(tw, t, table);
     }
 }
 
 // One Stockham pass on the thread's registers.  Non-final passes scatter their results to `lds`
 // (this transform's region); the final pass leaves X[t + T*e] in x[e].
-template <typename C, int DIR, int PASS, int TWMODE, int PADSHIFT, typename R>
-MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], const cx<R>* table, cx<R>* lds) {
+template <typename C, int DIR, int PASS, int TWMODE, int PADSHIFT, bool PERMUTE = false, typename R>
+MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t_raw, const cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], const cx<R>* table, cx<R>* lds) {
     constexpr int Rdx = C::radix(PASS), NB = C::E / Rdx, Ns = C::ns(PASS);
     constexpr bool LAST = PASS == C::P - 1;
+    const int t = lane_perm<C, PASS, PERMUTE>(t_raw);   // the butterflies this thread owns in this pass
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         cx<R> v[Rdx];
@@ -312,7 +366,8 @@ MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 
 }
 
 // After the barrier that follows a non-final pass: fetch the operands of the next pass.
-template <typename C, int PADSHIFT, typename R> MDSP_HD void pass_reload(cx<R> (&x)[C::E], int t, const cx<R>* lds) {
+template <typename C, int PADSHIFT, int NEXT = 1, bool PERMUTE = false, typename R> MDSP_HD void pass_reload(cx<R> (&x)[C::E], int t_raw, const cx<R>* lds) {
+    const int t = lane_perm<C, NEXT, PERMUTE>(t_raw);   // operands of the pass that follows
     if constexpr (PADSHIFT >= 31 || C::T % (1 << (PADSHIFT >= 31 ? 0 : PADSHIFT)) == 0) {
         const int base = lds_pad<PADSHIFT>(t);
 #pragma unroll

@@ -23,25 +23,31 @@ template <int T> __device__ __forceinline__ void wg_sync() {
 template <typename C, int PADSHIFT, int NBUF> constexpr int wg_lds_elems() { return NBUF * lds_elems<C::N, PADSHIFT>(); }
 
 // XBASE: index (mod NBUF) of the buffer used by this transform's first exchange.
-template <typename C, int DIR, int TWMODE, int PADSHIFT, int NBUF, int XBASE, int PASS = 0, typename R>
+template <typename C, int DIR, int TWMODE, int PADSHIFT, int NBUF, int XBASE, int PASS = 0, bool PERMUTE = false, typename R>
 __device__ __forceinline__ void wg_fft(cx<R> (&v)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], const cx<R>* table, cx<R>* lds) {
     constexpr int BUF = (XBASE + PASS) % NBUF;
     cx<R>* region = lds + BUF * lds_elems<C::N, PADSHIFT>();
-    pass_compute<C, DIR, PASS, TWMODE, PADSHIFT>(v, t, tw, table, region);
+    pass_compute<C, DIR, PASS, TWMODE, PADSHIFT, PERMUTE>(v, t, tw, table, region);
     if constexpr (PASS < C::P - 1) {
         wg_sync<C::T>();
-        pass_reload<C, PADSHIFT>(v, t, region);
+        pass_reload<C, PADSHIFT, PASS + 1, PERMUTE>(v, t, region);
         if constexpr (NBUF == 1) wg_sync<C::T>();
-        wg_fft<C, DIR, TWMODE, PADSHIFT, NBUF, XBASE, PASS + 1>(v, t, tw, table, lds);
+        wg_fft<C, DIR, TWMODE, PADSHIFT, NBUF, XBASE, PASS + 1, PERMUTE>(v, t, tw, table, lds);
     }
+}
+// lane-permuted transform (fft_lds.h "lane permutations"): thread t holds X[io_lane<C, true>(t) + T*e] before and after
+template <typename C, int DIR, int TWMODE, int PADSHIFT, int NBUF, int XBASE, typename R>
+__device__ __forceinline__ void wg_fft_perm(cx<R> (&v)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], const cx<R>* table, cx<R>* lds) {
+    wg_fft<C, DIR, TWMODE, PADSHIFT, NBUF, XBASE, 0, true>(v, t, tw, table, lds);
 }
 
 // Twiddle source setup for a kernel: registers (loaded once per persistent workgroup), an LDS-resident table shared
 // by the workgroup's transform slots, or the global root table.  Returns the pointer pass_compute() should use.
-template <typename C, int TWMODE, typename R>
+template <typename C, int TWMODE, bool PERMUTE = false, typename R>
 __device__ __forceinline__ const cx<R>* wg_twiddle_setup(cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], cx<R>* twl, int t, int slot, const cx<R>* table) {
+    static_assert(!PERMUTE || TWMODE == TW_REG || TWMODE == TW_GLOBAL, "lane permutations are wired for register / global twiddles");
     if constexpr (TWMODE == TW_REG) {
-        load_twiddles<C, R>(tw, t, table);
+        load_twiddles<C, R, 1, TW_REG, PERMUTE>(tw, t, table);
         return table;
     } else if constexpr (TWMODE == TW_LDS) {
         if (slot == 0) fill_lds_twiddles<C, R>(twl, t, table);

@@ -173,7 +173,7 @@ __device__ __forceinline__ void ols_store(const cx<R> (&v)[E], const OlsFusedArg
     }
 }
 
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, bool PERM = false>
 __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedArgs a) {
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T;
@@ -182,17 +182,18 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
     __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
     const int t = threadIdx.x % T;
+    const int ti = fft::io_lane<C, PERM>(t);   // this thread owns elements ti + T*e of a unit (ti == t unless lane-permuted)
     const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));  // wave-uniform by construction (T % 64 == 0)
     cx<R>* lds = lds_all + slot * REGION;
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
 
     cx<R> tw[NTWA];
     __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
-    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE, PERM>(tw, twl, t, slot, table);
     cx<R> Hr[HREG ? E : 1];
     if constexpr (HREG) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) Hr[e] = static_cast<const cx<R>*>(a.H)[t + T * e];
+        for (int e = 0; e < E; ++e) Hr[e] = static_cast<const cx<R>*>(a.H)[ti + T * e];
     }
     const __amdgpu_buffer_rsrc_t hrsrc = io::make_rsrc(a.H, (int64_t)N * (int64_t)sizeof(cx<R>));
 
@@ -200,11 +201,11 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     OlsWalk walk{((int64_t)blockIdx.x * G + slot) * a.run_len, 0};
     OlsPos cur = ols_pos(a, walk, a.niter > 0);
     OlsRaw<R, E, CPLX> raw;
-    if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, t);
+    if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti);
     for (int64_t it = 0; it < a.niter; ++it) {   // same trip count for every slot (barriers inside)
         ols_walk_next(walk, a.run_len, nslots);
         const OlsPos nxt = ols_pos(a, walk, it + 1 < a.niter);
-        if constexpr (!PREFETCH) { if (!(a.ablate & 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, t); }
+        if constexpr (!PREFETCH) { if (!(a.ablate & 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti); }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -212,25 +213,25 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
             else v[e] = {raw.a[e], raw.b[e]};
         }
         // next unit's samples start streaming from HBM while this unit is transformed
-        if constexpr (PREFETCH) { if (!(a.ablate & 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, nxt, t); }
+        if constexpr (PREFETCH) { if (!(a.ablate & 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, nxt, ti); }
         if (!(a.ablate & 2)) {
-        fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
+        fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0, 0, PERM>(v, t, tw, twsrc, lds);
         // spectral multiply (K2): natural order in registers
         if constexpr (HREG) {
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = fft::cmul(v[e], Hr[e]);
         } else {  // spectrum streamed from L2 (16 KiB, always resident) instead of living in 2E VGPRs
             cx<R> hh[E];
-            io::load_window<cx<R>, E, T>(hh, hrsrc, 0, t);
+            io::load_window<cx<R>, E, T>(hh, hrsrc, 0, ti);
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = fft::cmul(v[e], hh[e]);
         }
         // inverse transform (unnormalised, like plan_brfft / inv(p).p)
-        fft::wg_fft<C, +1, TWMODE, PADSHIFT, NBUF, (C::P - 1) % NBUF>(v, t, tw, twsrc, lds);
+        fft::wg_fft<C, +1, TWMODE, PADSHIFT, NBUF, (C::P - 1) % NBUF, 0, PERM>(v, t, tw, twsrc, lds);
         }
         // no barrier needed here: with one buffer wg_fft ends every exchange with a barrier, with two the 2(P-1)
         // exchanges of a unit alternate buffers so the next unit's first write is two barriers behind its readers
-        if (!(a.ablate & 4)) ols_store<R, E, T, CPLX>(v, a, cur, t);
+        if (!(a.ablate & 4)) ols_store<R, E, T, CPLX>(v, a, cur, ti);
         cur = nxt;
     }
 }
@@ -284,9 +285,10 @@ template <typename R> int upload_table(DevBuf& buf, int64_t n) {
 }
 
 // ---- fused launch ---------------------------------------------------------------------------------------
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true, bool HREG = true>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true, bool HREG = true,
+          bool PERM = false>
 int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
-    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG>;
+    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG, PERM>;
     constexpr int threads = (N / E) * G;
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
@@ -318,25 +320,23 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
     constexpr int TWREG = DBL ? 0 : 1;
     if constexpr (N == 2048 && !CPLX && !DBL) {
         switch (variant) {
-            //                                    R  N   E  G  TW PAD CPLX MINW NBUF PREFETCH     (TW: 0 global, 1 regs, 2 LDS)
-            case 1: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 2, 2, true>(a, s);
-            case 2: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 3, 2, true>(a, s);
-            case 3: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 4, 1, true>(a, s);
-            case 4: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 4, 1, false>(a, s);
-            case 5: return launch_fused_variant<R, N, 8, 1, 2, 4, CPLX, 3, 1, true>(a, s);
-            case 6: return launch_fused_variant<R, N, 8, 1, 1, 4, CPLX, 3, 2, true>(a, s);
-            case 7: return launch_fused_variant<R, N, 8, 1, 1, 3, CPLX, 2, 2, true>(a, s);
-            case 8: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true>(a, s);
-            case 9: return launch_fused_variant<R, N, 16, 1, 2, 4, CPLX, 2, 2, true>(a, s);
-            case 10: return launch_fused_variant<R, N, 16, 1, 2, 4, CPLX, 3, 2, true>(a, s);
-            case 11: return launch_fused_variant<R, N, 16, 2, 2, 4, CPLX, 2, 2, true>(a, s);
-            case 12: return launch_fused_variant<R, N, 16, 2, 2, 4, CPLX, 2, 1, true>(a, s);
-            case 13: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true>(a, s);
-            case 14: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, false>(a, s);
-            case 15: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true, false>(a, s);
-            case 16: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, false>(a, s);
+            //                                    R  N   E  G  TW PAD CPLX MINW NBUF PREF HREG PERM   (TW: 0 global, 1 regs, 2 LDS)
+            case 1: return launch_fused_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, true, true, false>(a, s);   // identity lanes, pad 4 (previous default)
+            case 2: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, false>(a, s);   // identity lanes, pad 5 (= default)
+            case 10: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, true>(a, s);   // permuted lanes, pad 5
+            case 3: return launch_fused_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, true, true, true>(a, s);    // permuted lanes, pad 4
+            case 4: return launch_fused_variant<R, N, 8, 1, 1, 3, CPLX, 2, 2, true, true, false>(a, s);
+            case 5: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 3, 2, true, true, true>(a, s);
+            case 6: return launch_fused_variant<R, N, 8, 1, 0, 5, CPLX, 2, 2, true, true, true>(a, s);    // global twiddles
+            case 7: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 1, true, true, true>(a, s);    // single LDS buffer
+            case 8: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, false, true, true>(a, s);   // no prefetch
+            case 9: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true, false, false>(a, s);  // E = 16
             default: break;
         }
+        // default: identity lanes, one pad element per 32 (conflict-free ds_read_b64, 2-way on the first scatter only).  The
+        // lane-permuted schedule (variant 10) has fewer LDS conflicts still, but its permuted global accesses cost more
+        // than the LDS cycles it saves (measured 3.8 vs 4.2 TB/s, profiles/r01e_tune_lanes.json).
+        return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, false>(a, s);
     }
     return launch_fused_variant<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true>(a, s);
 }

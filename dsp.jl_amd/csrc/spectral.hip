@@ -172,6 +172,10 @@ __global__ __launch_bounds__(256) void stft_store_kernel(const cx<R>* __restrict
 // ======================================================================================================
 // Fused kernels
 // ======================================================================================================
+// LDS padding of the workgroup FFT: one element per 2^shift.  4 everywhere except the two headline geometries, where 5 measured
+// faster (Welch nfft = 4096 E = 16: +5 %; overlap-save nfft = 2048: +3 %; the STFT nfft = 1024 kernel loses 7 % with 5).
+template <typename R> constexpr int pad_default() { return 4; }
+
 struct SpecArgs {
     const void* s;
     void* out;             // Welch: double partials [slot][ch][N];  STFT: output matrix
@@ -560,7 +564,7 @@ int welch_exec_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t
 // With hop = N/2 the second half of frame a IS the first half of frame b, and the second half of frame b IS the first
 // half of the next unit's frame a.  A slot that walks consecutive units therefore loads every sample exactly ONCE:
 // E loads per thread per unit instead of 2E, and 3E/2 instead of 2E prefetch registers.
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF, bool PERM = false>
 __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs a) {
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T;
@@ -570,7 +574,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
     constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
     constexpr int64_t SZ = (int64_t)sizeof(R);
     __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
-    const int t = threadIdx.x % T;
+    const int traw = threadIdx.x % T;
+    const int t = fft::io_lane<C, PERM>(traw);   // element / bin ownership: t + T*e (== traw unless lane-permuted)
     const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));
     cx<R>* lds = lds_all + slot * REGION;
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
@@ -578,7 +583,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
 
     cx<R> tw[NTWA];
     __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
-    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE, PERM>(tw, twl, traw, slot, table);
     R w[E];
     {
         double wd[E];
@@ -681,7 +686,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
         }
         u = unext;
         if (!(a.ablate & 2)) {
-            fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
+            fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0, 0, PERM>(v, traw, tw, twsrc, lds);
             if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();  // NBUF == 1: wg_fft already ends every exchange with a barrier
         }
         if constexpr (PAIR) {
@@ -704,9 +709,9 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
     }
 }
 
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF, bool PERM = false>
 int welch_run_half(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
-    auto kern = welch_half_kernel<R, N, E, G, TWMODE, PADSHIFT, MINW, NBUF>;
+    auto kern = welch_half_kernel<R, N, E, G, TWMODE, PADSHIFT, MINW, NBUF, PERM>;
     constexpr int threads = (N / E) * G;
     int grid = 1;
     MDSP_TRY(grid_for(kern, threads, cdiv(a.units_per_ch, G), a.nch, &grid));
@@ -740,7 +745,7 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
     int nslices = 0, rc = MDSP_OK;
     const bool half_ok = !CPLX && a.n == N && 2 * a.hop == N && !getenv("MDSP_WELCH_NOHALF");
     if constexpr (!CPLX && N >= 1024) {
-        if (half_ok && !(N == 4096 && sizeof(R) == 4 && pl->variant >= 1 && pl->variant <= 10)) {
+        if (half_ok && !(N == 4096 && sizeof(R) == 4 && pl->variant >= 1 && pl->variant <= 9)) {
             constexpr int EH = (N == 4096 && sizeof(R) == 4) ? 16 : Gm::E;
             constexpr int GH = (N / EH) >= 256 ? 1 : 256 / (N / EH);
             constexpr int NB = (N / EH) <= 64 ? 1 : 2;
@@ -749,7 +754,11 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
             if constexpr (N == 4096 && sizeof(R) == 4) {  // tuning alternatives of the headline shape (MDSP_WELCH_VARIANT)
                 done = true;
                 //                                              R  N  E   G  TW PAD MINW NBUF
-                if (pl->variant == 11) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 2>(pl, a, st, &nslices);
+                if (pl->variant == 10) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 1>(pl, a, st, &nslices);        // identity lanes, pad 4 (previous default)
+                else if (pl->variant == 11) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 2>(pl, a, st, &nslices);
+                else if (pl->variant == 18) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, false>(pl, a, st, &nslices);   // identity lanes, pad 5
+                else if (pl->variant == 19) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 2, true>(pl, a, st, &nslices);    // permuted, two LDS buffers
+                else if (pl->variant == 20) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, true>(pl, a, st, &nslices);    // permuted lanes, pad 5
                 else if (pl->variant == 12) rc = welch_run_half<R, N, EH, GH, 2, 4, 2, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 13) rc = welch_run_half<R, N, 8, 1, 1, 4, 2, 2>(pl, a, st, &nslices);
                 else if (pl->variant == 14) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 2>(pl, a, st, &nslices);
@@ -758,7 +767,12 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
                 else if (pl->variant == 17) rc = welch_run_half<R, N, EH, GH, 3, 4, 2, 1>(pl, a, st, &nslices);
                 else done = false;
             }
-            if (!done) rc = welch_run_half<R, N, EH, GH, Gm::TWREG, 4, 2, NBH>(pl, a, st, &nslices);
+            if (!done) {
+                if constexpr (N == 4096 && sizeof(R) == 4)   // identity lanes, pad 5; the conflict-free lane-permuted schedule is variant 20
+                    rc = welch_run_half<R, N, EH, GH, 1, 5, 2, NBH, false>(pl, a, st, &nslices);
+                else
+                    rc = welch_run_half<R, N, EH, GH, Gm::TWREG, pad_default<R>(), 2, NBH>(pl, a, st, &nslices);
+            }
             goto finalize;
         }
     }
@@ -778,7 +792,7 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
             default: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, false>(pl, a, st, &nslices); break;
         }
     } else {
-        rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, 4, CPLX, 2, Gm::NBUF, true, sizeof(R) == 8>(pl, a, st, &nslices);
+        rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, pad_default<R>(), CPLX, 2, Gm::NBUF, true, sizeof(R) == 8>(pl, a, st, &nslices);
     }
 finalize:
     if (rc != MDSP_OK) return rc;
@@ -999,8 +1013,8 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
         MDSP_LAUNCH_CHECK();
         return MDSP_OK;
     };
-    if (pl->psd_only) return run(stft_fused_kernel<R, N, E, G, TWREG, 4, CPLX, true, 2, NBUF, true>);
-    return run(stft_fused_kernel<R, N, E, G, TWREG, 4, CPLX, false, 2, NBUF, true>);
+    if (pl->psd_only) return run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, true, 2, NBUF, true>);
+    return run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, false, 2, NBUF, true>);
 }
 
 template <typename R, bool CPLX>

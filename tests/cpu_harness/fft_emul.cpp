@@ -12,26 +12,26 @@
 
 using namespace mdsp::fft;
 
-template <typename C, typename R, int DIR, int TWREG, int PADSHIFT, int PASS>
+template <typename C, typename R, int DIR, int TWREG, int PADSHIFT, int PASS, bool PERMUTE = false>
 static void run_passes(std::vector<cx<R>>& regs, std::vector<cx<R>>& tw, const std::vector<cx<R>>& table, std::vector<cx<R>>& lds) {
     if constexpr (PASS < C::P) {
         constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
         for (int t = 0; t < C::T; ++t) {
             auto& x = *reinterpret_cast<cx<R>(*)[C::E]>(&regs[(size_t)t * C::E]);
             auto& w = *reinterpret_cast<cx<R>(*)[NTWA]>(&tw[(size_t)t * NTWA]);
-            pass_compute<C, DIR, PASS, TWREG, PADSHIFT>(x, t, w, table.data(), lds.data());
+            pass_compute<C, DIR, PASS, TWREG, PADSHIFT, PERMUTE>(x, t, w, table.data(), lds.data());
         }
         if constexpr (PASS < C::P - 1) {
             for (int t = 0; t < C::T; ++t) {
                 auto& x = *reinterpret_cast<cx<R>(*)[C::E]>(&regs[(size_t)t * C::E]);
-                pass_reload<C, PADSHIFT>(x, t, lds.data());
+                pass_reload<C, PADSHIFT, PASS + 1, PERMUTE>(x, t, lds.data());
             }
         }
-        run_passes<C, R, DIR, TWREG, PADSHIFT, PASS + 1>(regs, tw, table, lds);
+        run_passes<C, R, DIR, TWREG, PADSHIFT, PASS + 1, PERMUTE>(regs, tw, table, lds);
     }
 }
 
-template <int N, int E, typename R, int DIR, int TWREG, int PADSHIFT> static double check() {
+template <int N, int E, typename R, int DIR, int TWREG, int PADSHIFT, bool PERMUTE = false> static double check() {
     using C = Cfg<N, E>;
     constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
     std::vector<cx<R>> table(N), regs((size_t)C::T * E), tw((size_t)C::T * NTWA), lds(lds_elems<N, PADSHIFT>());
@@ -43,13 +43,14 @@ template <int N, int E, typename R, int DIR, int TWREG, int PADSHIFT> static dou
     srand(1776 + N + E);
     for (int i = 0; i < N; ++i) in[i] = {(long double)rand() / RAND_MAX - 0.5L, (long double)rand() / RAND_MAX - 0.5L};
     for (int t = 0; t < C::T; ++t) {
-        for (int e = 0; e < E; ++e) regs[(size_t)t * E + e] = {(R)in[t + C::T * e].real(), (R)in[t + C::T * e].imag()};
+        const int ti = io_lane<C, PERMUTE>(t);   // thread t owns X[io_lane(t) + T*e] before the first and after the last pass
+        for (int e = 0; e < E; ++e) regs[(size_t)t * E + e] = {(R)in[ti + C::T * e].real(), (R)in[ti + C::T * e].imag()};
         auto& w = *reinterpret_cast<cx<R>(*)[NTWA]>(&tw[(size_t)t * NTWA]);
-        load_twiddles<C, R>(w, t, table.data());
+        load_twiddles<C, R, 1, TW_REG, PERMUTE>(w, t, table.data());
     }
     std::vector<cx<R>> twl(C::NTWLDS);
     for (int t = 0; t < C::T; ++t) fill_lds_twiddles<C, R>(twl.data(), t, table.data());
-    run_passes<C, R, DIR, TWREG, PADSHIFT, 0>(regs, tw, TWREG == TW_LDS ? twl : table, lds);
+    run_passes<C, R, DIR, TWREG, PADSHIFT, 0, PERMUTE>(regs, tw, TWREG == TW_LDS ? twl : table, lds);
     // reference DFT (O(N^2), long double) on the rounded inputs
     long double maxerr = 0, norm = 0;
     std::vector<std::complex<long double>> root(N);
@@ -68,7 +69,7 @@ template <int N, int E, typename R, int DIR, int TWREG, int PADSHIFT> static dou
     for (int t = 0; t < C::T; ++t)
         for (int e = 0; e < E; ++e) {
             const auto got = std::complex<long double>(regs[(size_t)t * E + e].x, regs[(size_t)t * E + e].y);
-            err2 += std::norm(got - ref[t + C::T * e]);
+            err2 += std::norm(got - ref[io_lane<C, PERMUTE>(t) + C::T * e]);
         }
     (void)maxerr;
     return (double)sqrtl(err2 / norm);
@@ -79,7 +80,14 @@ template <int N, int E> static int check_all() {
     const double e1 = std::max(check<N, E, float, -1, 1, 4>(), check<N, E, float, -1, 2, 4>());
     const double e2 = check<N, E, float, +1, 0, 5>();
     const double e3 = std::max(check<N, E, double, -1, 0, 31>(), check<N, E, double, +1, 2, 3>());
-    const double e4 = check<N, E, double, +1, 1, 4>();
+    double e4 = check<N, E, double, +1, 1, 4>();
+    if constexpr (LanePerm<N, E>::any) {   // the lane-permuted schedule (register / global twiddles, the geometry's own padding)
+        constexpr int PS = LanePerm<N, E>::padshift;
+        e4 = std::max(e4, std::max(check<N, E, double, +1, 1, PS, true>(), check<N, E, double, -1, 0, PS, true>()));
+        const double ep = std::max(check<N, E, float, -1, 1, PS, true>(), check<N, E, float, +1, 1, PS, true>());
+        if (!(ep < 2e-6)) bad = 1;
+        printf("N=%5d E=%2d lane-permuted schedule, pad shift %d: f32 %.2e\n", N, E, PS, ep);
+    }
     printf("N=%5d E=%2d P=%d radices:", N, E, Cfg<N, E>::P);
     for (int p = 0; p < Cfg<N, E>::P; ++p) printf(" %d", Cfg<N, E>::radix(p));
     printf("  relerr f32 fwd %.2e inv %.2e  f64 fwd %.2e inv %.2e\n", e1, e2, e3, e4);
