@@ -278,11 +278,10 @@ struct ArbArgs {
     const void* x;
     const void* hist;
     void* y;
-    const void* pfbT;     // tp * Nphi, pfbT[i*Nphi + phi]
-    const void* dpfbT;
+    const void* taps2;    // tp * Nphi pairs (pfb, dpfb), taps2[i*Nphi + phi]
     const int64_t* tab_x; // 1-based xIdx of output 64 b
     const double* tab_acc;
-    int64_t xlen, ldx, ldy, nout;
+    int64_t xlen, ldx, ldy, nout, nch;
     ArbStep step;
     int nphi, tp, hl;
     int tile;             // outputs per workgroup (multiple of ARB_BLK)
@@ -296,19 +295,22 @@ struct ArbRec {
     double alpha;
 };
 
+template <typename R> struct Tap2 {   // (pfb, dpfb) of one (tap, phase): one 8 / 16-byte LDS read feeds both chains
+    R p, d;
+};
+
 template <typename XS, typename A, typename R>
 __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ArbRec* rec = reinterpret_cast<ArbRec*>(smem);
     A* zs = reinterpret_cast<A*>(smem + (size_t)a.tile * sizeof(ArbRec));
-    R* ps = reinterpret_cast<R*>(smem + (size_t)a.tile * sizeof(ArbRec) + (size_t)a.span * sizeof(A));
-    const int64_t ch = blockIdx.y;
+    Tap2<R>* ps = reinterpret_cast<Tap2<R>*>(smem + (size_t)a.tile * sizeof(ArbRec) + (size_t)a.span * sizeof(A));
     const int64_t m0 = (int64_t)blockIdx.x * a.tile;
     if (m0 >= a.nout) return;
     const int cnt = (int)std::min<int64_t>(a.tile, a.nout - m0);
     const int64_t b0 = m0 / ARB_BLK;
     const int64_t x_first = a.tab_x[b0];
-    // phase A: replay the recurrence from the host anchors, one lane per 64 outputs
+    // phase A (once per tile, shared by every channel): replay the recurrence from the host anchors, one lane per 64 outputs
     if ((int)threadIdx.x * ARB_BLK < cnt) {
         int64_t xi = a.tab_x[b0 + threadIdx.x];
         double acc = a.tab_acc[b0 + threadIdx.x];
@@ -320,62 +322,63 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
             a.step(acc, xi);
         }
     }
-    const R* pf = static_cast<const R*>(a.pfbT);
-    const R* dpf = static_cast<const R*>(a.dpfbT);
+    const Tap2<R>* pf = static_cast<const Tap2<R>*>(a.taps2);
     if (a.taps_in_lds) {
         const int np = a.tp * a.nphi;
-        for (int k = threadIdx.x; k < np; k += blockDim.x) {
-            ps[k] = pf[k];
-            ps[np + k] = dpf[k];
-        }
+        for (int k = threadIdx.x; k < np; k += blockDim.x) ps[k] = pf[k];
         pf = ps;
-        dpf = ps + np;
     }
     __syncthreads();
-    const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
-    const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
     const int64_t z_first = x_first - 1;                                    // z = [history ; x], output n reads z[n-1 .. n-1+tp)
     const int64_t nz = (int64_t)rec[cnt - 1].xrel + a.tp;
     const bool staged = nz <= a.span;                                       // workgroup-uniform
-    auto zload = [&](int64_t zi) -> A {
-        A v{};
-        if (zi < a.hl) v = to_acc(hc[zi], (A*)nullptr);
-        else if (zi - a.hl < a.xlen) v = to_acc(xc[zi - a.hl], (A*)nullptr);
-        return v;
-    };
-    if (staged) {
-        for (int k = threadIdx.x; k < (int)nz; k += blockDim.x) zs[k] = zload(z_first + k);
-        __syncthreads();
-    }
-    A* yc = static_cast<A*>(a.y) + ch * a.ldy;
-    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
-        const ArbRec rc = rec[j];
-        const R* hp = pf + rc.phi;
-        const R* dp = dpf + rc.phi;
-        A lo, up;
+    for (int64_t ch = blockIdx.y; ch < a.nch; ch += gridDim.y) {
+        const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
+        const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
+        auto zload = [&](int64_t zi) -> A {
+            A v{};
+            if (zi < a.hl) v = to_acc(hc[zi], (A*)nullptr);
+            else if (zi - a.hl < a.xlen) v = to_acc(xc[zi - a.hl], (A*)nullptr);
+            return v;
+        };
         if (staged) {
-            const A* zp = zs + rc.xrel;
-            lo = mul_first(hp[0], zp[0]);
-            up = mul_first(dp[0], zp[0]);
-            for (int i = 1; i < a.tp; ++i) {
-                fma_acc(lo, hp[(int64_t)i * a.nphi], zp[i]);
-                fma_acc(up, dp[(int64_t)i * a.nphi], zp[i]);
-            }
-        } else {
-            const int64_t z0 = z_first + rc.xrel;
-            A z = zload(z0);
-            lo = mul_first(hp[0], z);
-            up = mul_first(dp[0], z);
-            for (int i = 1; i < a.tp; ++i) {
-                z = zload(z0 + i);
-                fma_acc(lo, hp[(int64_t)i * a.nphi], z);
-                fma_acc(up, dp[(int64_t)i * a.nphi], z);
-            }
+            __syncthreads();   // the previous channel's readers are done with zs
+            for (int k = threadIdx.x; k < (int)nz; k += blockDim.x) zs[k] = zload(z_first + k);
+            __syncthreads();
         }
-        yc[m0 + j] = arb_combine(up, rc.alpha, lo);
+        A* yc = static_cast<A*>(a.y) + ch * a.ldy;
+        for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+            const ArbRec rc = rec[j];
+            const Tap2<R>* hp = pf + rc.phi;
+            A lo, up;
+            if (staged) {
+                const A* zp = zs + rc.xrel;
+                Tap2<R> t = hp[0];
+                lo = mul_first(t.p, zp[0]);
+                up = mul_first(t.d, zp[0]);
+                for (int i = 1; i < a.tp; ++i) {
+                    t = hp[(int64_t)i * a.nphi];
+                    const A z = zp[i];
+                    fma_acc(lo, t.p, z);
+                    fma_acc(up, t.d, z);
+                }
+            } else {
+                const int64_t z0 = z_first + rc.xrel;
+                A z = zload(z0);
+                Tap2<R> t = hp[0];
+                lo = mul_first(t.p, z);
+                up = mul_first(t.d, z);
+                for (int i = 1; i < a.tp; ++i) {
+                    z = zload(z0 + i);
+                    t = hp[(int64_t)i * a.nphi];
+                    fma_acc(lo, t.p, z);
+                    fma_acc(up, t.d, z);
+                }
+            }
+            yc[m0 + j] = arb_combine(up, rc.alpha, lo);
+        }
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------
 // Stateful time-domain FIR: DF2TFilter{PolynomialRatio} with a = [1] (Filters/filt.jl:153-181) advanced by
@@ -480,7 +483,6 @@ struct mdsp_firarb_s {
     // the reference's state (stream_filt.jl:96-104); phi_idx and alpha are functions of phi_acc
     double phi_acc = 0.0;
     int64_t input_deficit = 1, x_idx = 1;
-    DevBuf dpfbT;
     DevBuf tab_x, tab_acc;
     // trajectory cache: anchors of the last (phi_acc, input_deficit, xlen) evaluated
     bool cache_valid = false;
@@ -848,7 +850,7 @@ template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, 
     int tile = 1024;
     int64_t span = 0;
     while (true) {
-        span = (int64_t)std::ceil((double)tile * f->delta / (double)f->nphi) + f->base.tp + 4;
+        span = ((int64_t)std::ceil((double)tile * f->delta / (double)f->nphi) + f->base.tp + 4 + 3) & ~int64_t(3);   // multiple of 4: the tap pairs that follow stay 16-byte aligned
         if (span * (int64_t)sizeof(A) <= 48 * 1024 || tile <= ARB_BLK) break;
         tile /= 2;
     }
@@ -858,7 +860,10 @@ template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, 
     const size_t lds_bytes = (size_t)tile * sizeof(ArbRec) + (size_t)span * sizeof(A) + (a.taps_in_lds ? (size_t)taps_bytes : 0);
     auto kern = arbitrary_fir_kernel<XS, A, R>;
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const dim3 grid((unsigned)cdiv(a.nout, tile), (unsigned)f->base.nch);
+    // channels share a tile's replayed trajectory: loop over them inside the workgroup unless there are too few tiles to fill the GPU
+    const int64_t tiles = cdiv(a.nout, tile);
+    const unsigned gy = (unsigned)std::min<int64_t>(f->base.nch, std::max<int64_t>(1, cdiv((int64_t)device_cu_count() * 8, tiles)));
+    const dim3 grid((unsigned)tiles, gy);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
@@ -958,8 +963,12 @@ int mdsp_firarb_create(mdsp_firarb* fo, const void* taps_host, int64_t hlen, dou
                 dd[(size_t)(row * nphi + col)] = dtap(hidx);
             }
         }
-    MDSP_TRY(upload_bank(b.pfbT, pd, b.acc_double));
-    MDSP_TRY(upload_bank(f->dpfbT, dd, b.acc_double));
+    std::vector<double> both(2 * np);
+    for (size_t i = 0; i < np; ++i) {
+        both[2 * i] = pd[i];
+        both[2 * i + 1] = dd[i];
+    }
+    MDSP_TRY(upload_bank(b.pfbT, both, b.acc_double));   // interleaved (pfb, dpfb) pairs
     const size_t hbytes = dtype_size(x_dtype) * (size_t)std::max<int64_t>(1, b.hl) * (size_t)nch;
     for (int k = 0; k < 2; ++k) {
         MDSP_TRY(b.hist[k].reserve(hbytes));
@@ -1110,8 +1119,8 @@ int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx
         a.x = x_dev;
         a.hist = b.hist[b.cur].p;
         a.y = y_dev;
-        a.pfbT = b.pfbT.p;
-        a.dpfbT = f->dpfbT.p;
+        a.taps2 = b.pfbT.p;
+        a.nch = b.nch;
         a.tab_x = f->tab_x.as<int64_t>();
         a.tab_acc = f->tab_acc.as<double>();
         a.xlen = xlen;
