@@ -64,7 +64,10 @@ def to_columns(x, dtype) -> tuple[torch.Tensor, tuple]:
     if t.dim() == 0:
         raise _lib.ArgumentError("expected at least a vector")
     n = shape[0]
-    t = t.reshape(n, -1).t()              # (ncols, n) view; Julia's trailing dims are flattened like CartesianIndices
+    ncols = 1
+    for k in shape[1:]:
+        ncols *= int(k)
+    t = t.reshape(n, ncols).t()           # (ncols, n) view; Julia's trailing dims are flattened like CartesianIndices
     if t.dtype != td:
         t = t.to(td)
     return t.contiguous(), shape

@@ -17,7 +17,9 @@
 // spreads them over the banks), and every output is a tp-term fused multiply-add chain, oldest sample first.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -1146,19 +1148,36 @@ int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx
 
 namespace {
 
+// Device copy of the taps of the most recent stateful filter: a streaming caller passes the same coefficients chunk after
+// chunk (often one sample at a time), so the upload -- and any allocation -- happens once per filter, not once per call.
+struct TapCache {
+    std::mutex mu;
+    std::vector<unsigned char> host;
+    DevBuf dev;
+};
+TapCache& tap_cache() {
+    static TapCache c;
+    return c;
+}
+
 template <typename A, typename R>
 int tdfir_state_run(const void* taps_host, int64_t nb, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t ldy, void* si, hipStream_t st) {
-    DevBuf bdev;
-    MDSP_TRY(bdev.reserve(sizeof(R) * (size_t)nb));
-    MDSP_HIP(hipMemcpyAsync(bdev.p, taps_host, sizeof(R) * (size_t)nb, hipMemcpyHostToDevice, st));
+    TapCache& tc = tap_cache();
+    std::lock_guard<std::mutex> lock(tc.mu);
+    const size_t bytes = sizeof(R) * (size_t)nb;
+    if (tc.host.size() != bytes || std::memcmp(tc.host.data(), taps_host, bytes) != 0) {
+        MDSP_HIP(hipDeviceSynchronize());   // earlier launches may still read the previous coefficients
+        MDSP_TRY(tc.dev.reserve(bytes));
+        MDSP_HIP(hipMemcpy(tc.dev.p, taps_host, bytes, hipMemcpyHostToDevice));
+        tc.host.assign((const unsigned char*)taps_host, (const unsigned char*)taps_host + bytes);
+    }
     if (nx > 0) {
         const dim3 g((unsigned)std::min<int64_t>(cdiv(nx, 256), 4096), (unsigned)ncols);
-        hipLaunchKernelGGL((tdfir_state_out_kernel<A, R>), g, dim3(256), 0, st, (const A*)x, (const A*)si, (A*)y, bdev.as<R>(), nx, ldx, ldy, (int)nb);
+        hipLaunchKernelGGL((tdfir_state_out_kernel<A, R>), g, dim3(256), 0, st, (const A*)x, (const A*)si, (A*)y, tc.dev.as<R>(), nx, ldx, ldy, (int)nb);
         MDSP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((tdfir_state_next_kernel<A, R>), dim3((unsigned)ncols), dim3(256), 0, st, (const A*)x, (A*)si, bdev.as<R>(), nx, ldx, (int)nb);
+        hipLaunchKernelGGL((tdfir_state_next_kernel<A, R>), dim3((unsigned)ncols), dim3(256), 0, st, (const A*)x, (A*)si, tc.dev.as<R>(), nx, ldx, (int)nb);
         MDSP_LAUNCH_CHECK();
     }
-    MDSP_HIP(hipStreamSynchronize(st));   // the tap buffer dies with this call
     return MDSP_OK;
 }
 

