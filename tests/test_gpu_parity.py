@@ -701,6 +701,102 @@ def test_edge_cases_empty_and_tiny_inputs(d):
     assert d.resample(np.arange(10.0), Fraction(1, 1), np.ones(1)).shape == (10,)
 
 
+def test_fuzz_differential_against_oracle(d):
+    # seeded random configurations of every entry point on the path, each compared with the oracle; sizes kept small so
+    # the whole sweep costs a few seconds, shapes deliberately ragged (odd lengths, nfft > n, hop 1, many short columns)
+    from oracle import dspbase as odsp, filt as of, periodograms as opg, stream_filt as osf, windows as ow
+    rng = np.random.default_rng(20260925)
+
+    def sig(n, dt, cols=()):
+        x = rng.standard_normal((n,) + cols)
+        if np.dtype(dt).kind == "c":
+            x = x + 1j * rng.standard_normal((n,) + cols)
+        return x.astype(dt)
+
+    def tol_of(*dts):
+        return 8e-6 if any(np.dtype(t) in (np.dtype(np.float32), np.dtype(np.complex64)) for t in dts) else 1e-11
+
+    wide = lambda a: a.astype(np.complex128 if a.dtype.kind == "c" else np.float64)
+    # --- filt / fftfilt / conv
+    for _ in range(40):
+        nb = int(rng.integers(1, 400)); nx = int(rng.integers(1, 6000))
+        dt = [np.float32, np.float64][int(rng.integers(2))]
+        cols = [(), (int(rng.integers(1, 5)),)][int(rng.integers(2))]
+        b, x = sig(nb, dt), sig(nx, dt, cols)
+        ref = of.filt(wide(b), wide(x))
+        got = d.filt(b, x)
+        assert got.shape == x.shape and got.dtype == dt and np.allclose(got, ref, rtol=tol_of(dt), atol=tol_of(dt) * np.abs(ref).max()), (nb, nx, dt, cols)
+        if nb > 1:
+            nfft = int(2 ** rng.integers(int(np.ceil(np.log2(nb))) + (0 if nb & (nb - 1) == 0 else 0), 14))
+            if nfft >= nb:
+                got = d.fftfilt(b, x, nfft)
+                assert np.allclose(got, ref, rtol=tol_of(dt), atol=tol_of(dt) * np.abs(ref).max()), (nb, nx, nfft)
+        if not cols:
+            v = sig(int(rng.integers(1, 300)), dt)
+            for alg in ("direct", "fft", "auto"):
+                got = d.conv(x, v, alg)
+                refc = np.convolve(wide(x), wide(v))
+                assert got.shape == refc.shape and np.allclose(got, refc, rtol=tol_of(dt), atol=tol_of(dt) * np.abs(refc).max()), (alg, nx)
+    # --- welch / stft / spectrogram / periodogram
+    wins = (None, ow.hanning, ow.hamming, "array")
+    for _ in range(40):
+        dt = [np.float32, np.float64, np.complex64, np.complex128][int(rng.integers(4))]
+        n = int(rng.integers(2, 700)); noverlap = int(rng.integers(0, n)); length = int(rng.integers(n, 9 * n + 50))
+        nfft = [n, n + int(rng.integers(0, 50)), int(2 ** np.ceil(np.log2(n)))][int(rng.integers(3))]
+        w = wins[int(rng.integers(len(wins)))]
+        w = rng.random(n) + 0.1 if isinstance(w, str) else w
+        cplx = np.dtype(dt).kind == "c"
+        onesided = False if cplx else bool(rng.integers(2))
+        x = sig(length, dt)
+        tol = tol_of(dt) * 4
+        kw = dict(nfft=nfft, fs=float(rng.uniform(0.5, 3)), window=w, onesided=onesided)
+        got = d.welch_pgram(x, n, noverlap, **kw)
+        ref = opg.welch_pgram(wide(x), n, noverlap, **kw)
+        assert got.power.shape == ref.power.shape and np.allclose(got.power, ref.power, rtol=tol, atol=tol * ref.power.max()), ("welch", n, noverlap, nfft, dt)
+        assert np.allclose(got.freq, ref.freq)
+        gs = d.stft(x, n, noverlap, **kw)
+        rs = opg.stft(wide(x), n, noverlap, **kw)
+        assert gs.shape == rs.shape and np.allclose(gs, rs, rtol=tol, atol=tol * np.abs(rs).max()), ("stft", n, noverlap, nfft, dt)
+        gp = d.spectrogram(x, n, noverlap, **kw)
+        rp = opg.spectrogram(wide(x), n, noverlap, **kw)
+        assert gp.power.shape == rp.power.shape and np.allclose(gp.power, rp.power, rtol=tol, atol=tol * rp.power.max()) and np.allclose(gp.time, rp.time)
+        pg = d.periodogram(x[:n], nfft=nfft, fs=kw["fs"], window=w, onesided=onesided)
+        rg = opg.periodogram(wide(x[:n]), nfft=nfft, fs=kw["fs"], window=w, onesided=onesided)
+        assert np.allclose(pg.power, rg.power, rtol=tol, atol=tol * rg.power.max())
+    # --- polyphase FIRFilter (rational) and FIRArbitrary with ragged chunking; state compared after every chunk
+    for _ in range(30):
+        L, M = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+        ratio = Fraction(L, M)
+        dt = [np.float32, np.float64, np.complex64, np.complex128][int(rng.integers(4))]
+        h = rng.standard_normal(int(rng.integers(1, 200))).astype([np.float32, np.float64][int(rng.integers(2))])
+        x = sig(int(rng.integers(1, 1500)), dt)
+        tol = tol_of(dt, h.dtype)
+        f, o = d.FIRFilter(h, ratio), osf.FIRFilter(h, ratio)
+        pos = 0
+        while pos < len(x):
+            step = int(rng.integers(0, 400))
+            y, yo = f.filt(x[pos:pos + step]), o.filt(x[pos:pos + step])
+            pos += step
+            assert y.shape == yo.shape and (f.phi_idx, f.input_deficit) == (o.phi_idx, o.input_deficit), (L, M, pos)
+            if yo.size:
+                assert np.allclose(y, yo, rtol=tol, atol=tol * max(1e-30, np.abs(yo).max())), (L, M, pos, dt)
+    for _ in range(15):
+        rate = float(rng.uniform(0.05, 4.0)); nphi = int(rng.integers(2, 40))
+        dt = [np.float32, np.float64][int(rng.integers(2))]
+        h = rng.standard_normal(int(rng.integers(nphi, 12 * nphi))).astype(dt)
+        x = sig(int(rng.integers(1, 1500)), dt)
+        tol = tol_of(dt)
+        f, o = d.FIRFilter(h, rate, nphi), osf.FIRFilter(h, rate, nphi)
+        pos = 0
+        while pos < len(x):
+            step = int(rng.integers(0, 400))
+            y, yo = f.filt(x[pos:pos + step]), o.filt(x[pos:pos + step])
+            pos += step
+            assert y.shape == yo.shape and (f.phi_accumulator, f.input_deficit) == (o.phi_acc, o.input_deficit), (rate, nphi, pos)
+            if yo.size:
+                assert np.allclose(y, yo, rtol=tol * 4, atol=tol * 4 * max(1e-30, np.abs(yo).max())), (rate, nphi, pos, dt)
+
+
 # ============================================================================================ multitaper
 @pytest.mark.parametrize("engine", ENGINES, ids=_eng_name)
 def test_mt_pgram_matlab_goldens(d, golden, engine):
