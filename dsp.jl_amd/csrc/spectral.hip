@@ -318,8 +318,16 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
     cx<R> tw[NTWA];
     __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
     const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
-    double w[E];
-    load_window_regs<E, T>(w, a.win, a.n, t);
+    // window in the working precision: Float32 frames are multiplied by the Float32-rounded window (one rounding more than the
+    // reference's Float64 product rounded once, periodograms.jl:62 -- 6e-8 relative, far inside the Float32 FFT's own error),
+    // which halves the window registers and drops four conversions per sample from the VALU stream
+    R w[E];
+    {
+        double wd[E];
+        load_window_regs<E, T>(wd, a.win, a.n, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) w[e] = (R)wd[e];
+    }
     const bool havewin = a.win != nullptr;
 
     const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
@@ -352,8 +360,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            if constexpr (CPLX) v[e] = havewin ? win_mul(ra[e], w[e]) : ra[e];
-            else v[e] = {havewin ? win_mul(ra[e], w[e]) : ra[e], (R)0};
+            if constexpr (CPLX) v[e] = havewin ? cx<R>{ra[e].x * w[e], ra[e].y * w[e]} : ra[e];
+            else v[e] = {havewin ? ra[e] * w[e] : ra[e], (R)0};
         }
         if constexpr (PREFETCH) issue(fcur);
         fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
@@ -1013,6 +1021,26 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
         MDSP_LAUNCH_CHECK();
         return MDSP_OK;
     };
+    if constexpr (N == 1024 && sizeof(R) == 4 && CPLX) {   // tuning alternatives of the config-4 shape (MDSP_STFT_VARIANT)
+        // default for this shape: one wavefront per transform (E = 16, T = 64, four transforms per workgroup, no s_barrier
+        // at all) -- measured 7-11 % faster than the two-wave E = 8 geometry (variant 9).  Variants 2-4: global twiddles.
+        static const int variant = getenv("MDSP_STFT_VARIANT") ? atoi(getenv("MDSP_STFT_VARIANT")) : 1;
+        if (variant >= 1 && variant <= 4) {
+            constexpr int E2 = 16, G2 = 4, T2 = 64;
+            const int64_t work2 = cdiv(a.K, G2);
+            auto run2 = [&](auto kern) -> int {
+                MDSP_TRY(grid_for(kern, T2 * G2, work2, a.nch, &grid));
+                set_schedule(a, a.K, (int64_t)grid * G2);
+                hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(T2 * G2), 0, st, a);
+                MDSP_LAUNCH_CHECK();
+                return MDSP_OK;
+            };
+            if (variant == 1) return pl->psd_only ? run2(stft_fused_kernel<R, N, E2, G2, 1, 4, CPLX, true, 2, 1, true>) : run2(stft_fused_kernel<R, N, E2, G2, 1, 4, CPLX, false, 2, 1, true>);
+            if (variant == 2) return pl->psd_only ? run2(stft_fused_kernel<R, N, E2, G2, 0, 4, CPLX, true, 2, 1, true>) : run2(stft_fused_kernel<R, N, E2, G2, 0, 4, CPLX, false, 2, 1, true>);
+            if (variant == 3) return pl->psd_only ? run2(stft_fused_kernel<R, N, E2, G2, 0, 5, CPLX, true, 2, 1, true>) : run2(stft_fused_kernel<R, N, E2, G2, 0, 5, CPLX, false, 2, 1, true>);
+            return pl->psd_only ? run2(stft_fused_kernel<R, N, E2, G2, 0, 4, CPLX, true, 3, 1, true>) : run2(stft_fused_kernel<R, N, E2, G2, 0, 4, CPLX, false, 3, 1, true>);
+        }
+    }
     if (pl->psd_only) return run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, true, 2, NBUF, true>);
     return run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, false, 2, NBUF, true>);
 }
