@@ -193,6 +193,16 @@ def main():
         ms = C.c_float()
         _lib.check(lib.mdsp_event_elapsed_ms(c0, c1, C.byref(ms)))
         copy_gbs = 3 * 2 * n * 4 / (ms.value * 1e-3) / 1e9
+        # read-only yardstick (float4 loads summed, nothing written): what a 4 B/sample reader like the Welch kernel could reach
+        os.environ["MDSP_COPY_MODE"] = "4"
+        _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))
+        _lib.check(lib.mdsp_event_record(c0, stream))
+        for _ in range(3):
+            _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))
+        _lib.check(lib.mdsp_event_record(c1, stream))
+        _lib.check(lib.mdsp_event_elapsed_ms(c0, c1, C.byref(ms)))
+        read_gbs = 3 * n * 4 / (ms.value * 1e-3) / 1e9
+        del os.environ["MDSP_COPY_MODE"]
         ols_gbs = 8.0 * n / (ols_ms * 1e-3) / 1e9
         welch_gbs = 4.0 * n / (welch_ms * 1e-3) / 1e9
         traffic = None
@@ -223,7 +233,7 @@ def main():
                        "samples_per_gpu": n, "engine": {1: "fused", 2: "rocfft"}[plan.engine], "stages_ms": {"filt": round(ols_ms, 4), "welch": round(welch_ms, 4)},
                        "stage_Gsamples_per_s": {"filt": round(n / ols_ms / 1e6, 2), "welch": round(n / welch_ms / 1e6, 2)}},
             "roofline": roof,
-            "kernels": {"other": welch_roof, "copy_float4_GBps": round(copy_gbs, 1)},
+            "kernels": {"other": welch_roof, "copy_float4_GBps": round(copy_gbs, 1), "read_float4_GBps": round(read_gbs, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -215,19 +215,68 @@ int mdsp_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
 
 }  // extern "C"
 
-// float4 grid-stride copy: the on-box HBM yardstick
+// float4 grid-stride copy: the on-box HBM yardstick.  MDSP_COPY_MODE selects experiments on the access pattern
+// (1: four independent float4 per thread and iteration, 2: nontemporal loads/stores, 3: one contiguous chunk per workgroup,
+// 4: read-only sum (no stores), 5: write-only fill); MDSP_COPY_WGS = workgroups per CU (default 8).
 __global__ __launch_bounds__(256) void mdsp_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void mdsp_copy4_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void mdsp_copy_nt_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src) + i);
+        __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(dst) + i);
+    }
+}
+
+__global__ __launch_bounds__(256) void mdsp_copy_chunk_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4) {
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void mdsp_read_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float4 acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = src[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345678f) dst[0] = acc;   // keeps the loads alive
+}
+
+__global__ __launch_bounds__(256) void mdsp_fill_kernel(float4* __restrict__ dst, const float4* __restrict__, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = v;
 }
 
 extern "C" int mdsp_copy_bench(void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
     if (bytes % 16) MDSP_FAIL(MDSP_ERR_ARGUMENT, "bytes must be a multiple of 16");
     const size_t n4 = bytes / 16;
     if (n4 == 0) return MDSP_OK;
-    const int grid = (int)std::min<size_t>((n4 + 255) / 256, (size_t)device_cu_count() * 8);
-    hipLaunchKernelGGL(mdsp_copy_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (float4*)dst_dev,
-                       (const float4*)src_dev, n4);
+    const int mode = getenv("MDSP_COPY_MODE") ? atoi(getenv("MDSP_COPY_MODE")) : 0;
+    const int wgs = getenv("MDSP_COPY_WGS") ? std::max(1, atoi(getenv("MDSP_COPY_WGS"))) : 8;
+    const int grid = (int)std::min<size_t>((n4 + 255) / 256, (size_t)device_cu_count() * wgs);
+    auto kern = mode == 1 ? mdsp_copy4_kernel : mode == 2 ? mdsp_copy_nt_kernel : mode == 3 ? mdsp_copy_chunk_kernel : mode == 4 ? mdsp_read_kernel
+                                                                                                     : mode == 5 ? mdsp_fill_kernel : mdsp_copy_kernel;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, as_stream(stream), (float4*)dst_dev, (const float4*)src_dev, n4);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
