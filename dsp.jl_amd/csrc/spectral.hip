@@ -732,183 +732,6 @@ int welch_run_half(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nsli
     return MDSP_OK;
 }
 
-// ---- Welch half-overlap kernel, two transform slots per workgroup in a fixed antiphase ----------------------------
-// The exchange phases of a transform (LDS stores draining, s_barrier, LDS loads returning) leave its waves without
-// VALU work, and two independent workgroups per CU cover each other's gaps only by chance (measured: 59 % VALU
-// utilisation, 1.29x over one workgroup).  Here one 512-thread workgroup owns BOTH transforms resident on the CU
-// and runs them one phase apart, every phase ending in the workgroup barrier the exchange needs anyway:
-//     phase 0: window + pass 0 + scatter     phase 1: gather        phase 2: pass 1 + scatter     phase 3: gather + pass 2 + |Z|^2
-//     slot A:    0   1   2   3   0   1 ...
-//     slot B:        0   1   2   3   0 ...
-// so in every interval one slot computes while the other waits for LDS (1 and 3-head are pure latency), and each SIMD
-// (one wave of A, one of B) always has VALU work to issue.
-template <typename R, int N, int E, int PADSHIFT, int TWMODE = fft::TW_REG>
-__global__ __launch_bounds__((N / E) * 2, 2) void welch_pipe_kernel(SpecArgs a) {
-    using C = fft::Cfg<N, E>;
-    static_assert(C::P == 3 && sizeof(R) == 4 && C::T % 64 == 0 && E % 2 == 0, "built for the nfft = 4096, E = 16 Float32 geometry");
-    constexpr int T = C::T, H = E / 2, G = 2;
-    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
-    constexpr int REGION = fft::lds_elems<N, PADSHIFT>();
-    constexpr int64_t SZ = (int64_t)sizeof(R);
-    constexpr int FLUSH = 128;
-    __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
-    const int t = threadIdx.x % T;
-    const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));
-    cx<R>* lds = lds_all + slot * REGION;
-    const cx<R>* table = static_cast<const cx<R>*>(a.table);
-    const int64_t ch = blockIdx.y;
-
-    cx<R> tw[NTWA];
-    __shared__ __attribute__((aligned(16))) cx<R> twl[TWMODE == fft::TW_HYB ? fft::tw_lds_entries<C, TWMODE>() : 1];
-    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);   // TW_HYB: pass 1 reads its 15 roots from LDS
-    R w[E];
-    {
-        double wd[E];
-        load_window_regs<E, T>(wd, a.win, a.n, t);
-#pragma unroll
-        for (int e = 0; e < E; ++e) w[e] = (R)wd[e];
-    }
-    cx<R> accp[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) accp[e] = {(R)0, (R)0};
-    double* part = static_cast<double*>(a.out) + (((int64_t)blockIdx.x * G + slot) * a.nch + ch) * N;
-    const __amdgpu_buffer_rsrc_t prs = io::make_rsrc(part, (int64_t)N * 8);
-    int since = 0;
-    bool first = true;
-    auto flush = [&]() {
-        int off = t * 8;
-        asm volatile("" : "+v"(off));
-        if (first) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) io::Ld<double>::store((double)accp[e].x + (double)accp[e].y, prs, off + T * e * 8);
-        } else {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const double s = io::Ld<double>::load(prs, off + T * e * 8) + ((double)accp[e].x + (double)accp[e].y);
-                io::Ld<double>::store(s, prs, off + T * e * 8);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) accp[e] = {(R)0, (R)0};
-        first = false;
-        since = 0;
-    };
-
-    const R* sc = static_cast<const R*>(a.s) + ch * a.lds_;
-    const int64_t nslots = (int64_t)gridDim.x * G;
-    int64_t wbase = ((int64_t)blockIdx.x * G + slot) * a.run_len, wj = 0;
-    auto unit_cur = [&](bool more) { return (more && wbase + wj < a.units_per_ch) ? wbase + wj : a.units_per_ch; };
-    auto walk = [&]() {
-        if (++wj == a.run_len) {
-            wj = 0;
-            wbase += nslots * a.run_len;
-        }
-    };
-    const int64_t niter = a.niter;
-    auto load_half = [&](R (&dst)[H], int64_t u, int h, bool on) {
-        const int64_t pos = u * N + (int64_t)h * (N / 2);
-        const __amdgpu_buffer_rsrc_t r = io::make_rsrc(sc + pos, on ? std::min<int64_t>(N / 2, a.len - pos) * SZ : 0);
-        io::load_window<R, H, T>(dst, r, 0, t);
-    };
-    R lo[H], ahi[H], bhi[H];
-    int64_t u = unit_cur(niter > 0);
-    {
-        const bool live = u < a.units_per_ch;
-        load_half(lo, u, 0, live);
-        load_half(ahi, u, 1, live);
-        load_half(bhi, u, 2, live && (2 * u + 1) < a.K);
-    }
-    cx<R> v[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = {(R)0, (R)0};
-    int64_t it = 0;
-    auto phase0 = [&]() {   // window the prefetched halves, start the next unit's loads, first pass + scatter
-        walk();
-        const int64_t unext = unit_cur(it + 1 < niter);
-        const bool haveB = (2 * u + 1) < a.K;
-        if (haveB) {
-#pragma unroll
-            for (int e = 0; e < H; ++e) {
-                v[e] = {lo[e] * w[e], ahi[e] * w[e]};
-                v[e + H] = {ahi[e] * w[e + H], bhi[e] * w[e + H]};
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < H; ++e) {
-                v[e] = {lo[e] * w[e], (R)0};
-                v[e + H] = {ahi[e] * w[e + H], (R)0};
-            }
-        }
-        const bool nlive = unext < a.units_per_ch;
-        if (unext == u + 1 && nlive) {
-#pragma unroll
-            for (int e = 0; e < H; ++e) lo[e] = bhi[e];
-        } else {
-            load_half(lo, unext, 0, nlive);
-        }
-        load_half(ahi, unext, 1, nlive);
-        load_half(bhi, unext, 2, nlive && (2 * unext + 1) < a.K);
-        u = unext;
-        ++it;
-        fft::pass_compute<C, -1, 0, TWMODE, PADSHIFT>(v, t, tw, twsrc, lds);
-    };
-    auto phase1 = [&]() {   // gather; the Float64 fold rides here, where v is dead
-        if (since >= FLUSH) flush();
-        fft::pass_reload<C, PADSHIFT, 1>(v, t, lds);
-    };
-    auto phase2 = [&]() { fft::pass_compute<C, -1, 1, TWMODE, PADSHIFT>(v, t, tw, twsrc, lds); };
-    auto phase3 = [&]() {   // gather, last pass, |Z|^2
-        fft::pass_reload<C, PADSHIFT, 2>(v, t, lds);
-        fft::pass_compute<C, -1, 2, TWMODE, PADSHIFT>(v, t, tw, twsrc, lds);
-#pragma unroll
-        for (int e = 0; e < E; ++e) accp[e] = fft::lanefma(v[e], v[e], accp[e]);
-        ++since;
-    };
-    // two straight-line schedules, one interval apart; both execute 4 niter + 1 workgroup barriers
-    if (slot == 0) {
-        for (int64_t i = 0; i < niter; ++i) {
-            phase0();
-            __syncthreads();
-            phase1();
-            __syncthreads();
-            phase2();
-            __syncthreads();
-            phase3();
-            __syncthreads();
-        }
-        __syncthreads();
-    } else {
-        for (int64_t i = 0; i < niter; ++i) {
-            if (i > 0) phase3();
-            __syncthreads();
-            phase0();
-            __syncthreads();
-            phase1();
-            __syncthreads();
-            phase2();
-            __syncthreads();
-        }
-        if (niter > 0) phase3();
-        __syncthreads();
-    }
-    flush();
-}
-
-template <typename R, int N, int E, int PADSHIFT, int TWMODE = fft::TW_REG>
-int welch_run_pipe(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
-    auto kern = welch_pipe_kernel<R, N, E, PADSHIFT, TWMODE>;
-    constexpr int threads = (N / E) * 2;
-    int grid = 1;
-    MDSP_TRY(grid_for(kern, threads, cdiv(a.units_per_ch, 2), a.nch, &grid));
-    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)grid * 2 * (size_t)a.nch * N));
-    a.out = pl->partial.p;
-    set_schedule(a, a.units_per_ch, (int64_t)grid * 2);
-    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
-    MDSP_LAUNCH_CHECK();
-    *nslices = grid * 2;
-    return MDSP_OK;
-}
-
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
 int welch_run_variant(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
     auto kern = welch_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, WIN64>;
@@ -945,8 +768,6 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
                 else if (pl->variant == 19) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 2, true>(pl, a, st, &nslices);    // permuted, two LDS buffers
                 else if (pl->variant == 20) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, true>(pl, a, st, &nslices);    // permuted lanes, pad 5
                 else if (pl->variant == 21) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 2, false>(pl, a, st, &nslices);   // identity lanes, pad 5, two LDS buffers
-                else if (pl->variant == 22) rc = welch_run_pipe<R, N, 16, 5>(pl, a, st, &nslices);                       // two slots per workgroup in antiphase
-                else if (pl->variant == 23) rc = welch_run_pipe<R, N, 16, 5, fft::TW_HYB>(pl, a, st, &nslices);
                 else if (pl->variant == 12) rc = welch_run_half<R, N, EH, GH, 2, 4, 2, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 13) rc = welch_run_half<R, N, 8, 1, 1, 4, 2, 2>(pl, a, st, &nslices);
                 else if (pl->variant == 14) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 2>(pl, a, st, &nslices);
