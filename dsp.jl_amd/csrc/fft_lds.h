@@ -79,6 +79,8 @@ MDSP_PK2(pk_add_ib, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
 MDSP_PK2(pk_sub_ib, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")   // a - i b = (ax + by, ay - bx)
 MDSP_PK2(pk_mul, "v_pk_mul_f32", "")
 MDSP_PK2(pk_mul_swap, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,1]")              // (a.y b.x, a.x b.y)
+MDSP_PK2(pk_mul_blo, "v_pk_mul_f32", "op_sel_hi:[1,0]")                          // (a.x b.x, a.y b.x): both lanes times b's low half
+MDSP_PK2(pk_mul_bhi, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,1]")              // (a.x b.y, a.y b.y): both lanes times b's high half
 MDSP_PK2(pk_mul_yy, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0]")                // (a.y b.y, a.y b.x)
 MDSP_PK3(pk_fma, "v_pk_fma_f32", "")                                               // a b + c, lane-wise
 MDSP_PK3(pk_fnma, "v_pk_fma_f32", "neg_lo:[1,0,0] neg_hi:[1,0,0]")                 // c - a b

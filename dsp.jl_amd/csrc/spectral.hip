@@ -668,10 +668,22 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
         const bool haveB = (2 * u + 1) < a.K;   // u live implied (K >= 1) -- a dead unit has all-zero halves anyway
         cx<R> v[E];
         if (haveB) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (PAIR) {   // one packed multiply per bin: (lo, ahi) w_e and (ahi, bhi) w_{e+H}, the window half picked by op_sel
 #pragma unroll
-            for (int e = 0; e < H; ++e) {
-                v[e] = {lo[e] * w[e], ahi[e] * w[e]};
-                v[e + H] = {ahi[e] * w[e + H], bhi[e] * w[e + H]};
+                for (int e = 0; e < H; ++e) {
+                    const cx<R> wp = {w[e], w[e + H]};
+                    v[e] = fft::pk_mul_blo(cx<R>{lo[e], ahi[e]}, wp);
+                    v[e + H] = fft::pk_mul_bhi(cx<R>{ahi[e], bhi[e]}, wp);
+                }
+            } else
+#endif
+            {
+#pragma unroll
+                for (int e = 0; e < H; ++e) {
+                    v[e] = {lo[e] * w[e], ahi[e] * w[e]};
+                    v[e + H] = {ahi[e] * w[e + H], bhi[e] * w[e + H]};
+                }
             }
         } else {  // odd frame count: the last unit has no second frame
 #pragma unroll
