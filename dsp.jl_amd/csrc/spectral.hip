@@ -390,6 +390,130 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
     }
 }
 
+// ---- STFT / spectrogram of REAL signals: two frames per complex transform ----------------------------------------------
+// z = w (a + i b) with a, b two consecutive frames; after the forward transform the two spectra are untangled with the
+// mirror bin,  A[k] = (Z[k] + conj(Z[N-k])) / 2,  B[k] = (Z[k] - conj(Z[N-k])) / (2i),  for the nfft/2+1 non-redundant
+// bins.  Z[N-k] lives in another thread (bin N-k = (T-t) + T (E-1-e)), so the spectrum takes one more trip through LDS
+// -- one exchange instead of a second transform's P-1 exchanges and all of its butterflies.
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool PSD, int MINW, int NBUF>
+__global__ __launch_bounds__((N / E) * G, MINW) void stft_pair_kernel(SpecArgs a) {
+    using C = fft::Cfg<N, E>;
+    constexpr int T = C::T, H = E / 2;
+    static_assert(T % 64 == 0 && E % 2 == 0, "a transform must own whole wavefronts");
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
+    constexpr int64_t SZ = (int64_t)sizeof(R);
+    __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
+    const int t = threadIdx.x % T;
+    const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));
+    cx<R>* lds = lds_all + slot * REGION;
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    const int64_t ch = blockIdx.y;
+
+    cx<R> tw[NTWA];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, slot, table);
+    R w[E];
+    {
+        double wd[E];
+        load_window_regs<E, T>(wd, a.win, a.n, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) w[e] = (R)wd[e];
+    }
+    const R* sc = static_cast<const R*>(a.s) + ch * a.lds_;
+    const int64_t nslots = (int64_t)gridDim.x * G;
+    int64_t wbase = ((int64_t)blockIdx.x * G + slot) * a.run_len, wj = 0;
+    auto unit_cur = [&](bool more) { return (more && wbase + wj < a.units_per_ch) ? wbase + wj : a.units_per_ch; };
+    auto walk = [&]() {
+        if (++wj == a.run_len) {
+            wj = 0;
+            wbase += nslots * a.run_len;
+        }
+    };
+    const int64_t niter = a.niter;
+    const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
+    using OT = std::conditional_t<PSD, R, cx<R>>;
+
+    R ra[E], rb[E];
+    auto issue = [&](int64_t u) {   // frames 2u and 2u+1 (the second one may not exist)
+        const int64_t fa = 2 * u, fb = 2 * u + 1;
+        const int64_t sa = fa * a.hop, sb = fb * a.hop;
+        const __amdgpu_buffer_rsrc_t r0 = io::make_rsrc(sc + sa, fa < a.K ? std::min<int64_t>(a.n, a.len - sa) * SZ : 0);
+        const __amdgpu_buffer_rsrc_t r1 = io::make_rsrc(sc + sb, fb < a.K ? std::min<int64_t>(a.n, a.len - sb) * SZ : 0);
+        io::load_window<R, E, T>(ra, r0, 0, t);
+        io::load_window<R, E, T>(rb, r1, 0, t);
+    };
+    int64_t ucur = unit_cur(niter > 0);
+    issue(ucur);
+    for (int64_t it = 0; it < niter; ++it) {
+        const int64_t u = ucur;
+        walk();
+        ucur = unit_cur(it + 1 < niter);
+        cx<R> v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = {ra[e] * w[e], rb[e] * w[e]};   // w == 1 beyond... load_window_regs gives 1 without a window, 0 past n
+        issue(ucur);
+        fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
+        // mirror exchange through the (now idle) first LDS buffer: natural order, so both the writes and the descending reads
+        // are contiguous across lanes
+        if constexpr (C::P > 1 && NBUF > 1) fft::wg_sync<T>();   // the last gather of the transform may still be reading buffer (P-2) % NBUF
+        {
+            const int base = fft::lds_pad<PADSHIFT>(t);
+#pragma unroll
+            for (int e = 0; e < E; ++e) lds[base + fft::lds_padc<PADSHIFT>(T * e)] = v[e];
+        }
+        fft::wg_sync<T>();
+        const int64_t fa = 2 * u, fb = 2 * u + 1;
+        const bool liveA = fa < a.K, liveB = fb < a.K;
+        OT* colA = static_cast<OT*>(a.out) + ch * a.chs + fa * a.ldo;
+        OT* colB = static_cast<OT*>(a.out) + ch * a.chs + fb * a.ldo;
+        const __amdgpu_buffer_rsrc_t wa = io::make_rsrc(colA, liveA ? (int64_t)a.nout * (int64_t)sizeof(OT) : 0);
+        const __amdgpu_buffer_rsrc_t wb = io::make_rsrc(colB, liveB ? (int64_t)a.nout * (int64_t)sizeof(OT) : 0);
+        auto emit = [&](int k, cx<R> z, cx<R> p) {   // bin k <= N/2 of both frames from Z[k] = z and Z[N-k] = p
+            const cx<R> A = {(z.x + p.x) * (R)0.5, (z.y - p.y) * (R)0.5};
+            const cx<R> B = {(z.y + p.y) * (R)0.5, (p.x - z.x) * (R)0.5};
+            const int off = k * (int)sizeof(OT);
+            if constexpr (PSD) {
+                R m = m1;
+                if (a.onesided && !(k == 0 || (k == N / 2 && N % 2 == 0))) m = m2;
+                R pa = (A.x * A.x + A.y * A.y) * m, pb = (B.x * B.x + B.y * B.y) * m;
+                if (a.accumulate) {   // multitaper: fft2pow! adds this taper's power to the column (wave-uniform branch)
+                    pa += io::Ld<R>::load(wa, off);
+                    pb += io::Ld<R>::load(wb, off);
+                }
+                io::Ld<R>::store(pa, wa, off);
+                io::Ld<R>::store(pb, wb, off);
+                if (!a.onesided && k != 0 && k != N / 2) {   // real signal, two-sided output: the mirrored bin carries the same power
+                    const int offm = (N - k) * (int)sizeof(OT);
+                    io::Ld<R>::store(pa, wa, offm);
+                    io::Ld<R>::store(pb, wb, offm);
+                }
+            } else {
+                io::Ld<cx<R>>::store(A, wa, off);
+                io::Ld<cx<R>>::store(B, wb, off);
+                if (!a.onesided && k != 0 && k != N / 2) {   // fft2oneortwosided!: out[N-k] = conj(out[k])
+                    const int offm = (N - k) * (int)sizeof(OT);
+                    io::Ld<cx<R>>::store(cx<R>{A.x, -A.y}, wa, offm);
+                    io::Ld<cx<R>>::store(cx<R>{B.x, -B.y}, wb, offm);
+                }
+            }
+        };
+        // bins k = t + T e, e < E/2, are <= N/2 - 1 + ... (k < N/2); their mirrors N - k sit at index (N - t) - T e
+        {
+            const int mbase = fft::lds_pad<PADSHIFT>((N - t) & (N - 1));   // t == 0: bin 0 mirrors itself (index 0)
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                cx<R> p;
+                if (e == 0) p = lds[mbase];
+                else p = lds[fft::lds_pad<PADSHIFT>(N - t - T * e)];
+                emit(t + T * e, v[e], p);
+            }
+            if (t == 0) emit(N / 2, v[H], v[H]);   // the Nyquist bin is thread 0's element E/2 and its own mirror
+        }
+        if constexpr (C::P > 1) fft::wg_sync<T>();   // the next transform's first scatter reuses this buffer
+    }
+}
+
 bool fused_size_ok(int dtype, int64_t nfft) {
     const bool dbl = dtype_is_double(dtype);
     switch (nfft) {
@@ -1052,6 +1176,23 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
             if (variant == 2) return pl->psd_only ? run2(stft_fused_kernel<R, N, E2, G2, 0, 4, CPLX, true, 2, 1, true>) : run2(stft_fused_kernel<R, N, E2, G2, 0, 4, CPLX, false, 2, 1, true>);
             if (variant == 3) return pl->psd_only ? run2(stft_fused_kernel<R, N, E2, G2, 0, 5, CPLX, true, 2, 1, true>) : run2(stft_fused_kernel<R, N, E2, G2, 0, 5, CPLX, false, 2, 1, true>);
             return pl->psd_only ? run2(stft_fused_kernel<R, N, E2, G2, 0, 4, CPLX, true, 3, 1, true>) : run2(stft_fused_kernel<R, N, E2, G2, 0, 4, CPLX, false, 3, 1, true>);
+        }
+    }
+    if constexpr (!CPLX) {
+        // real signals: two frames per transform (stft_pair_kernel); MDSP_STFT_NOPAIR=1 keeps the one-frame-per-transform kernel
+        static const bool nopair = getenv("MDSP_STFT_NOPAIR") != nullptr;
+        if (!nopair && a.n <= N) {
+            const int64_t units = cdiv(a.K, 2);
+            a.units_per_ch = units;
+            auto runp = [&](auto kern) -> int {
+                MDSP_TRY(grid_for(kern, threads, cdiv(units, G), a.nch, &grid));
+                set_schedule(a, units, (int64_t)grid * G);
+                hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
+                MDSP_LAUNCH_CHECK();
+                return MDSP_OK;
+            };
+            if (pl->psd_only) return runp(stft_pair_kernel<R, N, E, G, TWREG, pad_default<R>(), true, 2, NBUF>);
+            return runp(stft_pair_kernel<R, N, E, G, TWREG, pad_default<R>(), false, 2, NBUF>);
         }
     }
     if (pl->psd_only) return run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, true, 2, NBUF, true>);
