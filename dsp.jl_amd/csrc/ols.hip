@@ -312,18 +312,24 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
     // per workgroup so that workgroups have 256 threads where possible.  `variant` selects tuning alternatives
     // (MDSP_OLS_VARIANT, swept by bench/tune.py); the non-default ones are only built for the headline shape.
     constexpr bool DBL = sizeof(R) == 8;
-    constexpr int EMAX = 8;   // 8 elements/thread: no spills, 2x the rate of 16 on MI355X (profiles/tune_r01)
+    // Elements per thread.  Float32, nfft >= 1024: 16 -- half as many waves per transform (one wave at 1024: no s_barrier at
+    // all), measured 6-10 % faster than 8 at nfft = 2048 once the packed-FP32 butterflies removed the register spills
+    // (profiles/r01i_tune_e16.json).  Float64 and small transforms: 8.
+    constexpr int EMAX = (!DBL && N >= 1024) ? 16 : 8;
     constexpr int E = (N / 64 < EMAX) ? N / 64 : EMAX;
     constexpr int T = N / E;
     constexpr int G = T >= 256 ? 1 : 256 / T;
-    constexpr int NBUF = T <= 64 ? 1 : 2;
+    constexpr int NBUF = (T <= 64 || E == 16) ? 1 : 2;
     constexpr int TWREG = DBL ? 0 : 1;
     if constexpr (N == 2048 && !CPLX && !DBL) {
         switch (variant) {
             //                                    R  N   E  G  TW PAD CPLX MINW NBUF PREF HREG PERM   (TW: 0 global, 1 regs, 2 LDS)
             case 1: return launch_fused_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, true, true, false>(a, s);   // identity lanes, pad 4 (previous default)
-            case 2: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, false>(a, s);   // identity lanes, pad 5 (= default)
+            case 2: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, false>(a, s);   // identity lanes, pad 5 (best E = 8 form)
             case 10: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, true>(a, s);   // permuted lanes, pad 5
+            case 11: return launch_fused_variant<R, N, 16, 2, 1, 5, CPLX, 2, 1, true, true, false>(a, s);  // E = 16: two waves per transform
+            case 12: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true, true, false>(a, s);  // (= default)
+            case 13: return launch_fused_variant<R, N, 16, 2, 1, 5, CPLX, 2, 2, true, true, false>(a, s);
             case 3: return launch_fused_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, true, true, true>(a, s);    // permuted lanes, pad 4
             case 4: return launch_fused_variant<R, N, 8, 1, 1, 3, CPLX, 2, 2, true, true, false>(a, s);
             case 5: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 3, 2, true, true, true>(a, s);
@@ -333,10 +339,9 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
             case 9: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true, false, false>(a, s);  // E = 16
             default: break;
         }
-        // default: identity lanes, one pad element per 32 (conflict-free ds_read_b64, 2-way on the first scatter only).  The
-        // lane-permuted schedule (variant 10) has fewer LDS conflicts still, but its permuted global accesses cost more
-        // than the LDS cycles it saves (measured 3.8 vs 4.2 TB/s, profiles/r01e_tune_lanes.json).
-        return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, false>(a, s);
+        // default: the generic E = 16 geometry below (variant 12).  Variant 2 is the best E = 8 form (identity lanes, one pad
+        // element per 32); the lane-permuted schedule (variant 10) has fewer LDS conflicts still, but its permuted global accesses
+        // cost more than the LDS cycles it saves (3.8 vs 4.2 TB/s, profiles/r01e_tune_lanes.json).
     }
     return launch_fused_variant<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true>(a, s);
 }

@@ -560,7 +560,11 @@ int check_split(int64_t n, int64_t noverlap, int64_t nfft) {
 // geometry shared by the fused launchers
 template <typename R, int N> struct Geo {
     static constexpr bool DBL = sizeof(R) == 8;
-    static constexpr int EMAX = 8;   // 8 elements/thread: no spills, 2x the rate of 16 on MI355X (profiles/tune_r01)
+    // 8 elements per thread in general; nfft = 1024 in Float32 takes 16 so that a transform is ONE wavefront (no s_barrier)
+#ifndef MDSP_GEO_E1024
+#define MDSP_GEO_E1024 16
+#endif
+    static constexpr int EMAX = (N == 1024 && !DBL) ? MDSP_GEO_E1024 : 8;
     static constexpr int E = (N / 64 < EMAX) ? N / 64 : EMAX;
     static constexpr int T = N / E;
     static constexpr int G = T >= 256 ? 1 : 256 / T;
