@@ -797,6 +797,35 @@ def test_fuzz_differential_against_oracle(d):
                 assert np.allclose(y, yo, rtol=tol * 4, atol=tol * 4 * max(1e-30, np.abs(yo).max())), (rate, nphi, pos, dt)
 
 
+def test_streams_beyond_2_32_samples(d, torch):
+    # 64-bit positions end to end: a 2^32 + 12345-sample Float32 stream (16 GiB in, 16 GiB out) -- the layout is sized for 288 GB
+    from oracle import dspbase as odsp, periodograms as opg, windows as ow
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip("needs ~60 GB of HBM")
+    n = 2 ** 32 + 12345
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    x = torch.empty(n, device="cuda", dtype=torch.float32)
+    for i in range(0, n, 2 ** 28):
+        x[i:i + 2 ** 28] = torch.randn(min(2 ** 28, n - i), generator=g, device="cuda")
+    b = _lowpass_taps(256, np.float32)
+    y = d.fftfilt(b, x, 2048)
+    assert y.shape == (n,)
+    for s in (0, 2 ** 31 - 300, 2 ** 31 + 77, 2 ** 32 - 500, n - 700):
+        lo = max(0, s - 255)
+        ref = odsp.filt_ba(b.astype(np.float64), 1.0, x[lo:s + 600].cpu().numpy().astype(np.float64))[s - lo:]
+        assert relerr(y[s:s + 600].cpu().numpy(), ref) < TOL32, s
+    del y
+    p = d.welch_pgram(x, 4096, 2048, window=d.hanning).power
+    assert d.frame_count(n, 4096, 2048) == (n - 4096) // 2048 + 1 == 2097157
+    assert abs(float(p[5:2040].mean()) / 2 - 1) < 5e-3                       # one-sided PSD of unit white noise at fs = 1
+    seg = x[n - 2 ** 20:]
+    ref = opg.welch_pgram(seg.cpu().numpy().astype(np.float64), 4096, 2048, window=ow.hanning).power
+    assert relerr(d.welch_pgram(seg, 4096, 2048, window=d.hanning).power.cpu().numpy(), ref) < TOL32
+    m = 2 ** 31 + 1001
+    z = d.resample(x[:m], Fraction(3, 2), d.resample_filter(Fraction(3, 2)).astype(np.float32))
+    assert z.shape[0] == math.ceil(m * Fraction(3, 2))
+
+
 # ============================================================================================ multitaper
 @pytest.mark.parametrize("engine", ENGINES, ids=_eng_name)
 def test_mt_pgram_matlab_goldens(d, golden, engine):
