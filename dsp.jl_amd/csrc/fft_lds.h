@@ -186,8 +186,9 @@ template <int N_, int E_> struct Cfg {
     static constexpr int N = N_, E = E_, T = N_ / E_;
     static constexpr int LOGN = ilog2(N_), LOGE = ilog2(E_);
     static_assert((1 << LOGN) == N_ && (1 << LOGE) == E_, "power of two sizes only");
-    static_assert(E_ >= 2 && E_ <= 16 && N_ >= E_, "unsupported elements-per-thread");
-    static constexpr int P = (LOGN + LOGE - 1) / LOGE;  // passes
+    static_assert(E_ >= 2 && E_ <= 64 && N_ >= E_, "unsupported elements-per-thread");
+    static constexpr int LOGR = LOGE < 4 ? LOGE : 4;    // register butterflies stop at radix 16; E > 16 runs E/16 of them per pass
+    static constexpr int P = (LOGN + LOGR - 1) / LOGR;  // passes
     // spread the log2 radices as evenly as possible, larger radices first
     static constexpr int logradix(int p) { return LOGN / P + (p < LOGN % P ? 1 : 0); }
     static constexpr int radix(int p) { return 1 << logradix(p); }
