@@ -892,12 +892,12 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
     using Gm = Geo<R, N>;
     int nslices = 0, rc = MDSP_OK;
     const bool half_ok = !CPLX && a.n == N && 2 * a.hop == N && !getenv("MDSP_WELCH_NOHALF");
-    if constexpr (!CPLX && N >= 1024) {
+    if constexpr (!CPLX && N >= 256) {
         if (half_ok && !(N == 4096 && sizeof(R) == 4 && pl->variant >= 1 && pl->variant <= 9)) {
-            constexpr int EH = (N == 4096 && sizeof(R) == 4) ? 16 : Gm::E;
+            constexpr int EH = (N >= 2048 && sizeof(R) == 4) ? 16 : Gm::E;   // Float32, nfft >= 1024: 16 elements per thread (Geo does 1024)
             constexpr int GH = (N / EH) >= 256 ? 1 : 256 / (N / EH);
             constexpr int NB = (N / EH) <= 64 ? 1 : 2;
-            constexpr int NBH = (N == 4096 && sizeof(R) == 4) ? 1 : NB;
+            constexpr int NBH = (EH == 16) ? 1 : NB;
             bool done = false;
             if constexpr (N == 4096 && sizeof(R) == 4) {  // tuning alternatives of the headline shape (MDSP_WELCH_VARIANT)
                 done = true;
