@@ -189,6 +189,8 @@ struct SpecArgs {
     int64_t run_len, niter;  // unit schedule: runs of run_len consecutive units per slot, niter iterations per slot
     int ablate;              // profiling aid (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip accumulate/stores
     int accumulate;          // STFT PSD mode: add to the output column instead of overwriting it (multitaper)
+    int ntapers;             // > 0: multitaper PSD in one launch (stft_pair_kernel<MT>): win holds ntapers windows of n doubles, rinv their 1/r
+    const double* rinv;
     double r;
 };
 
@@ -395,7 +397,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
 // mirror bin,  A[k] = (Z[k] + conj(Z[N-k])) / 2,  B[k] = (Z[k] - conj(Z[N-k])) / (2i),  for the nfft/2+1 non-redundant
 // bins.  Z[N-k] lives in another thread (bin N-k = (T-t) + T (E-1-e)), so the spectrum takes one more trip through LDS
 // -- one exchange instead of a second transform's P-1 exchanges and all of its butterflies.
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool PSD, int MINW, int NBUF>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool PSD, int MINW, int NBUF, bool MT = false>
 __global__ __launch_bounds__((N / E) * G, MINW) void stft_pair_kernel(SpecArgs a) {
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T, H = E / 2;
@@ -449,6 +451,70 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_pair_kernel(SpecArgs a
         const int64_t u = ucur;
         walk();
         ucur = unit_cur(it + 1 < niter);
+        if constexpr (MT && PSD) {
+            // multitaper PSD (mt_pgram!, multitaper.jl:239-243): the frame pair stays in registers while every taper is applied,
+            // transformed, untangled and accumulated; one store per bin at the end
+            static_assert(PSD, "multitaper accumulates powers");
+            R pa[H], pb[H], pna = (R)0, pnb = (R)0;
+#pragma unroll
+            for (int e = 0; e < H; ++e) pa[e] = pb[e] = (R)0;
+            const int mbase = fft::lds_pad<PADSHIFT>((N - t) & (N - 1));
+            for (int k = 0; k < a.ntapers; ++k) {
+                const double* wk = a.win + (int64_t)k * a.n;
+                cx<R> v[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = t + T * e;
+                    const R wv = i < a.n ? (R)wk[i] : (R)0;
+                    v[e] = {ra[e] * wv, rb[e] * wv};
+                }
+                fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
+                if constexpr (C::P > 1 && NBUF > 1) fft::wg_sync<T>();
+                {
+                    const int base = fft::lds_pad<PADSHIFT>(t);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) lds[base + fft::lds_padc<PADSHIFT>(T * e)] = v[e];
+                }
+                fft::wg_sync<T>();
+                const double rk = a.rinv[k];
+                const R k1 = (R)rk, k2 = (R)(2.0 * rk);
+                auto power = [&](cx<R> z, cx<R> p, R m, R& qa, R& qb) {
+                    const cx<R> A = {(z.x + p.x) * (R)0.5, (z.y - p.y) * (R)0.5};
+                    const cx<R> B = {(z.y + p.y) * (R)0.5, (p.x - z.x) * (R)0.5};
+                    qa += (A.x * A.x + A.y * A.y) * m;
+                    qb += (B.x * B.x + B.y * B.y) * m;
+                };
+#pragma unroll
+                for (int e = 0; e < H; ++e) {
+                    const cx<R> p = e == 0 ? lds[mbase] : lds[fft::lds_pad<PADSHIFT>(N - t - T * e)];
+                    const bool dc = (t + T * e) == 0;
+                    power(v[e], p, (a.onesided && !dc) ? k2 : k1, pa[e], pb[e]);
+                }
+                if (t == 0) power(v[H], v[H], k1, pna, pnb);       // Nyquist (nfft even): weight 1/r in both layouts
+                if constexpr (C::P > 1) fft::wg_sync<T>();
+            }
+            issue(ucur);
+            const int64_t fa = 2 * u, fb = 2 * u + 1;
+            R* colA = static_cast<R*>(a.out) + ch * a.chs + fa * a.ldo;
+            R* colB = static_cast<R*>(a.out) + ch * a.chs + fb * a.ldo;
+            const __amdgpu_buffer_rsrc_t wa = io::make_rsrc(colA, fa < a.K ? (int64_t)a.nout * (int64_t)sizeof(R) : 0);
+            const __amdgpu_buffer_rsrc_t wb = io::make_rsrc(colB, fb < a.K ? (int64_t)a.nout * (int64_t)sizeof(R) : 0);
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                const int kb = t + T * e;
+                io::Ld<R>::store(pa[e], wa, kb * (int)sizeof(R));
+                io::Ld<R>::store(pb[e], wb, kb * (int)sizeof(R));
+                if (!a.onesided && kb != 0) {
+                    io::Ld<R>::store(pa[e], wa, (N - kb) * (int)sizeof(R));
+                    io::Ld<R>::store(pb[e], wb, (N - kb) * (int)sizeof(R));
+                }
+            }
+            if (t == 0) {
+                io::Ld<R>::store(pna, wa, (N / 2) * (int)sizeof(R));
+                io::Ld<R>::store(pnb, wb, (N / 2) * (int)sizeof(R));
+            }
+            continue;
+        }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = {ra[e] * w[e], rb[e] * w[e]};   // w == 1 beyond... load_window_regs gives 1 without a window, 0 past n
@@ -1105,6 +1171,8 @@ struct mdsp_stft_plan_s {
     DevBuf win, table;
     const double* win_ptr = nullptr;   // window used by exec (the plan's own, or one taper of a multitaper plan)
     int accumulate = 0;                // PSD mode: out += |X|^2 m instead of out = (the taper loop of mt_pgram!, multitaper.jl:240-243)
+    int mt_ntapers = 0;                // > 0: all tapers in one launch where the kernel supports it (real input, fused engine)
+    const double* mt_rinv = nullptr;
     RocPlan fwd;
     DevBuf fr, spec;
     int64_t batch = 0;
@@ -1195,6 +1263,7 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
                 MDSP_LAUNCH_CHECK();
                 return MDSP_OK;
             };
+            if (pl->psd_only && a.ntapers > 0) return runp(stft_pair_kernel<R, N, E, G, TWREG, pad_default<R>(), true, 2, NBUF, true>);
             if (pl->psd_only) return runp(stft_pair_kernel<R, N, E, G, TWREG, pad_default<R>(), true, 2, NBUF>);
             return runp(stft_pair_kernel<R, N, E, G, TWREG, pad_default<R>(), false, 2, NBUF>);
         }
@@ -1213,6 +1282,8 @@ int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nc
     a.table = pl->table.p;
     a.win = pl->have_win ? pl->win_ptr : nullptr;
     a.accumulate = pl->accumulate;
+    a.ntapers = pl->mt_ntapers;
+    a.rinv = pl->mt_rinv;
     a.len = len;
     a.lds_ = lds_;
     a.K = K;
@@ -1329,6 +1400,7 @@ struct mdsp_mt_plan_s {
     DevBuf wins;                  // (n, ntapers) Float64, column-major
     std::vector<double> r;        // inverse normalisation per taper (multitaper.jl:15-17)
     DevBuf wts;                   // 2 / r  (normalization_weights, :499), Float64
+    DevBuf rinv;                  // 1 / r, Float64 (in-kernel taper loop)
     DevBuf demeaned;              // scratch for demean = true (:566-570)
     DevBuf finds;                 // frequency indices of the last cross-spectra call
 };
@@ -1443,6 +1515,9 @@ int mdsp_mt_plan_create(mdsp_mt_plan* plan, int64_t n, int64_t nfft, const doubl
     for (int64_t k = 0; k < ntapers; ++k) w[(size_t)k] = 2.0 / r_host[k];
     MDSP_TRY(pl->wts.reserve(sizeof(double) * (size_t)ntapers));
     MDSP_HIP(hipMemcpy(pl->wts.p, w.data(), sizeof(double) * (size_t)ntapers, hipMemcpyHostToDevice));
+    for (int64_t k = 0; k < ntapers; ++k) w[(size_t)k] = 1.0 / r_host[k];
+    MDSP_TRY(pl->rinv.reserve(sizeof(double) * (size_t)ntapers));
+    MDSP_HIP(hipMemcpy(pl->rinv.p, w.data(), sizeof(double) * (size_t)ntapers, hipMemcpyHostToDevice));
     if (eng == MDSP_ENGINE_FUSED) MDSP_TRY(dtype_is_double(dtype) ? upload_roots<double>(st.table, nfft) : upload_roots<float>(st.table, nfft));
     *plan = pl.release();
     return MDSP_OK;
@@ -1475,6 +1550,19 @@ int mdsp_mt_psd_exec(mdsp_mt_plan plan, const void* s_dev, int64_t len, int64_t 
     if (nch > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 channels per call");
     st.noverlap = noverlap;
     st.psd_only = 1;
+    // real signals on the fused engine: every taper inside one launch (the frame pair stays in registers); otherwise one
+    // pass per taper with the accumulate flag
+    if (st.engine == MDSP_ENGINE_FUSED && !dtype_is_complex(st.dtype) && !getenv("MDSP_MT_PASSES") && !getenv("MDSP_STFT_NOPAIR")) {
+        st.win_ptr = plan->wins.as<double>();
+        st.r = plan->r[0];
+        st.accumulate = 0;
+        st.mt_ntapers = (int)plan->ntapers;
+        st.mt_rinv = plan->rinv.as<double>();
+        const int rc = stft_dispatch(&st, s_dev, len, nch, lds_, out_dev, ldo, chs, as_stream(stream));
+        st.mt_ntapers = 0;
+        st.mt_rinv = nullptr;
+        return rc;
+    }
     for (int64_t k = 0; k < plan->ntapers; ++k) {
         st.win_ptr = plan->wins.as<double>() + k * st.n;
         st.r = plan->r[(size_t)k];
