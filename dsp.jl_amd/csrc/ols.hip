@@ -320,7 +320,10 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
     constexpr int T = N / E;
     constexpr int G = T >= 256 ? 1 : 256 / T;
     constexpr int NBUF = (T <= 64 || E == 16) ? 1 : 2;
-    constexpr int TWREG = DBL ? 0 : 1;
+#ifndef MDSP_TW_F64
+#define MDSP_TW_F64 1
+#endif
+    constexpr int TWREG = DBL ? MDSP_TW_F64 : 1;   // Float64 twiddles: 1 = registers, 0 = global table
     if constexpr (N == 2048 && !CPLX && !DBL) {
         switch (variant) {
             //                                    R  N   E  G  TW PAD CPLX MINW NBUF PREF HREG PERM   (TW: 0 global, 1 regs, 2 LDS)

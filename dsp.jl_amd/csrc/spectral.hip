@@ -635,7 +635,10 @@ template <typename R, int N> struct Geo {
     static constexpr int T = N / E;
     static constexpr int G = T >= 256 ? 1 : 256 / T;
     static constexpr int NBUF = T <= 64 ? 1 : 2;
-    static constexpr int TWREG = DBL ? 0 : 1;
+#ifndef MDSP_TW_F64
+#define MDSP_TW_F64 1
+#endif
+    static constexpr int TWREG = DBL ? MDSP_TW_F64 : 1;   // Float64 twiddles: 1 = registers, 0 = global table
 };
 
 // runs of consecutive units per slot (default: one run = fully contiguous), identical trip count for every slot
