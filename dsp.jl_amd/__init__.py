@@ -10,7 +10,8 @@ from ._lib import ArgumentError, DeviceError, DimensionMismatch, DomainError, Un
 from ._lib import ENGINE_AUTO, ENGINE_FUSED, ENGINE_ROCFFT  # noqa: F401
 from .util import nextfastfft, fftintype, fftouttype, fftabs2type  # noqa: F401
 from . import windows, design  # noqa: F401
-from .windows import hanning, hann, hamming, rect, bartlett, cosine, blackman, kaiser, dpss, dpsseig  # noqa: F401
+from .windows import (hanning, hann, hamming, rect, bartlett, cosine, blackman, kaiser, dpss, dpsseig, tukey, lanczos, triang,  # noqa: F401
+                      gaussian, bartlett_hann, blackmanharris, nuttall, flattop)
 from .design import resample_filter, kaiserord  # noqa: F401
 from .dspbase import conv, conv_, xcorr, hilbert, optimalfftfiltlength, os_fft_complexity, SMALL_FILT_CUTOFF  # noqa: F401
 from .dspbase import filt as _filt_ba, filt_ as _filt_ba_
@@ -19,7 +20,7 @@ from .filters import (FIRFilter, fftfilt, fftfilt_, tdfilt, tdfilt_, resample, i
 from .multitaper import (MTConfig, MTSpectrogramConfig, MTCrossSpectraConfig, MTCoherenceConfig, CrossPowerSpectra, Coherence,  # noqa: F401
                          coherence, dpss_config, mt_pgram, mt_pgram_, mt_spectrogram, mt_spectrogram_, mt_cross_power_spectra,
                          mt_cross_power_spectra_, mt_coherence, mt_coherence_)
-from .periodograms import (Periodogram, Spectrogram, WelchConfig, arraysplit, periodogram, welch_pgram, welch_pgram_,  # noqa: F401
+from .periodograms import (Periodogram, Spectrogram, WelchConfig, arraysplit, fftshift, periodogram, welch_pgram, welch_pgram_,  # noqa: F401
                            spectrogram, stft, power, freq, time, frame_count)
 from .channels import channel_shard, welch_channel_mean  # noqa: F401
 

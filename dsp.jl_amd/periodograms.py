@@ -45,6 +45,23 @@ def time(p):
     return p.time
 
 
+def _is_twosided_freq(f: np.ndarray) -> bool:
+    """``fftfreq`` layout (a ``Frequencies`` object with negative bins) as opposed to ``rfftfreq`` / already shifted."""
+    f = np.asarray(f)
+    return f.size > 1 and bool(np.any(np.diff(f) < 0))
+
+
+def fftshift(p):
+    """``fftshift(p::Periodogram)`` / ``fftshift(p::Spectrogram)`` (periodograms.jl:331-333, :778-780): centre the zero
+    frequency of a two-sided estimate; one-sided (and already shifted) ones are returned as they are."""
+    if not _is_twosided_freq(p.freq):
+        return p
+    xp = _dev.torch if _dev.is_device_array(p.power) else np
+    power = xp.fft.fftshift(p.power, 0)        # frequency is the first axis of both layouts
+    f = np.fft.fftshift(p.freq)
+    return Spectrogram(power, f, p.time) if isinstance(p, Spectrogram) else Periodogram(power, f)
+
+
 def compute_window(window, n: int):
     """periodograms.jl:248-257 -> (Float64 window or None, norm2)."""
     if window is None:

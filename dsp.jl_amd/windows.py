@@ -66,13 +66,79 @@ def bartlett(n, padding=0, zerophase=False):
 
 def blackman(n, padding=0, zerophase=False):
     """windows.jl:455: 0.42 + 0.5 cospi(2x) + 0.08 cospi(4x)."""
-    return makewindow(lambda x: 0.42 + 0.5 * _cospi(2.0 * x) + 0.08 * _cospi(4.0 * x), n, padding, zerophase)
+    return makewindow(lambda x: 0.5 * _cospi(2.0 * x) + (0.08 * _cospi(4.0 * x) + 0.42), n, padding, zerophase)
 
 
 def kaiser(n, alpha, padding=0, zerophase=False):
     """windows.jl:600-605."""
     scale = 1.0 / np.i0(np.pi * alpha)
     return makewindow(lambda x: scale * np.i0(np.pi * alpha * np.sqrt(np.clip(1.0 - 4.0 * x * x, 0.0, None))), n, padding, zerophase)
+
+
+def tukey(n, alpha, padding=0, zerophase=False):
+    """windows.jl:245-263."""
+    if not 0 <= alpha <= 1:
+        raise DomainError("α must be in the range [0, 1].")
+    if abs(alpha) <= np.finfo(np.float64).eps:
+        return rect(n, padding, zerophase)
+
+    def f(x):
+        lo = 0.5 * (1 + _cospi(2 / alpha * (x + (1 - alpha) / 2)))
+        hi = 0.5 * (1 + _cospi(2 / alpha * (x - (1 - alpha) / 2)))
+        return np.where(x <= -(1 - alpha) / 2, lo, np.where(x <= (1 - alpha) / 2, 1.0, hi))
+    return makewindow(f, n, padding, zerophase)
+
+
+def lanczos(n, padding=0, zerophase=False):
+    """windows.jl:314-316."""
+    return makewindow(lambda x: np.sinc(2 * x), n, padding, zerophase)
+
+
+def triang(n, padding=0, zerophase=False):
+    """windows.jl:350-357."""
+    m = n + 1 if zerophase else n
+    scale = 2 * (m - 1) / m if m % 2 == 0 else 2 * (m - 1) / (m + 1)
+    return makewindow(lambda x: -scale * np.abs(x) + 1, n, padding, zerophase)
+
+
+def gaussian(n, sigma, padding=0, zerophase=False):
+    """windows.jl:405-408."""
+    if not sigma > 0:
+        raise DomainError("σ must be positive")
+    return makewindow(lambda x: np.exp(-0.5 * (x / sigma) ** 2), n, padding, zerophase)
+
+
+def bartlett_hann(n, padding=0, zerophase=False):
+    """windows.jl:429-434."""
+    return makewindow(lambda x: 0.38 * _cospi(2 * x) + (-0.48 * np.abs(x) + 0.62), n, padding, zerophase)
+
+
+def blackmanharris(n, term=4, padding=0, zerophase=False):
+    """windows.jl:503-517."""
+    if term == 4:
+        a0, a1, a2, a3 = 0.35875, 0.48829, 0.14128, 0.01168
+        return makewindow(lambda x: a1 * _cospi(2 * x) + (a2 * _cospi(4 * x) + (a3 * _cospi(6 * x) + a0)), n, padding, zerophase)
+    if term == 3:
+        a0, a1, a2 = 0.42323, 0.49755, 0.07922
+        return makewindow(lambda x: a1 * _cospi(2 * x) + (a2 * _cospi(4 * x) + a0), n, padding, zerophase)
+    raise ArgumentError("`term` must be either 3 or 4")
+
+
+def nuttall(n, term=4, padding=0, zerophase=False):
+    """windows.jl:556-570."""
+    if term == 4:
+        a0, a1, a2, a3 = 0.3635819, 0.4891775, 0.1365995, 0.0106411
+        return makewindow(lambda x: a1 * _cospi(2 * x) + (a2 * _cospi(4 * x) + (a3 * _cospi(6 * x) + a0)), n, padding, zerophase)
+    if term == 3:
+        a0, a1, a2 = 0.4243801, 0.4973406, 0.0782793
+        return makewindow(lambda x: a1 * _cospi(2 * x) + (a2 * _cospi(4 * x) + a0), n, padding, zerophase)
+    raise ArgumentError("`term` must be either 3 or 4")
+
+
+def flattop(n, padding=0, zerophase=False):
+    """windows.jl:640-645."""
+    a0, a1, a2, a3, a4 = 0.21557895, 0.41663158, 0.277263158, 0.083578947, 0.006947368
+    return makewindow(lambda x: a1 * _cospi(2 * x) + (a2 * _cospi(4 * x) + (a3 * _cospi(6 * x) + (a4 * _cospi(8 * x) + a0))), n, padding, zerophase)
 
 
 def dpss(n: int, nw: float, ntapers: int | None = None, padding: int = 0, zerophase: bool = False) -> np.ndarray:

@@ -16,6 +16,7 @@ Files and the reference tests that consume them:
   hanning128.txt                      test/windows.jl:55-59
   digitalfilter_hamming_12{8,9}_lowpass[_scaled]_fc0.25_fs1.0.txt   test/filter_design.jl:988-1060 (SciPy firwin)
   dpss128,4.txt                       test/windows.jl:34-36 (MATLAB dpss)
+  {hamming,triang,bartlett,bartlett_hann,blackman,blackmanharris_*,nuttall_*,kaiser,flattop,gaussian,tukey,lanczos,cosine}128*.txt   test/windows.jl:45-128
   mt_pgram.txt, pmtm_{x,fx,pxx}.txt   test/periodograms.jl:381-440 (MATLAB pmtm)
   csd_array_multitaper_{frequencies,values_re,values_im}.txt, noise.txt   test/multitaper.jl:254-300 (MNE-Python)
 """
@@ -41,6 +42,8 @@ FILES = [
     "digitalfilter_hamming_129_lowpass_scaled_fc0.25_fs1.0",
     "dpss128,4", "mt_pgram", "pmtm_x", "pmtm_fx", "pmtm_pxx",
     "csd_array_multitaper_frequencies", "csd_array_multitaper_values_re", "csd_array_multitaper_values_im", "noise",
+    "hamming128", "triang128", "bartlett128", "bartlett_hann128", "blackman128", "blackmanharris_3term_128", "blackmanharris_4term_128",
+    "nuttall_3term_128", "nuttall_4term_128", "kaiser128,0.4", "flattop", "gaussian128,0.2", "tukey128,0.4", "lanczos128", "cosine128",
 ]
 
 

@@ -223,3 +223,26 @@ def test_arbitrary_host_state_matches_oracle():
             for n in (0, 1, 17, 1000, 123457):
                 assert p.outputlength(n) == o.outputlength(n)
                 assert p.inputlength(n) == o.inputlength(n) and p.inputlength(n, round_up=True) == o.inputlength(n, roundup=True)
+
+
+def test_window_generators_match_reference_goldens(golden):
+    """test/windows.jl:45-128: every window the host can generate against the reference's MATLAB / regression vectors."""
+    from conftest import isapprox
+    assert np.array_equal(d.rect(128), np.ones(128))
+    pairs = [(d.hanning(128), "hanning128"), (d.hann(128), "hanning128"), (d.hamming(128), "hamming128"), (d.triang(128), "triang128"),
+             (d.bartlett(128), "bartlett128"), (d.bartlett_hann(128), "bartlett_hann128"), (d.blackman(128), "blackman128"),
+             (d.blackmanharris(128, 3), "blackmanharris_3term_128"), (d.blackmanharris(128), "blackmanharris_4term_128"),
+             (d.nuttall(128, 3), "nuttall_3term_128"), (d.nuttall(128), "nuttall_4term_128"), (d.kaiser(128, 0.4 / np.pi), "kaiser128_0p4"),
+             (d.flattop(128), "flattop"), (d.gaussian(128, 0.2), "gaussian128_0p2"), (d.tukey(128, 0.4), "tukey128_0p4"),
+             (d.lanczos(128), "lanczos128"), (d.cosine(128), "cosine128")]
+    for got, key in pairs:
+        assert isapprox(got, golden[key]), key
+    assert isapprox(d.triang(5), d.bartlett(7)[1:6])
+    assert d.blackman(128).min() == 0.0
+    assert np.array_equal(d.tukey(128, 0), d.rect(128))
+    with pytest.raises(d.ArgumentError):
+        d.blackmanharris(128, 2)
+    with pytest.raises(d.ArgumentError):
+        d.nuttall(128, 2)
+    with pytest.raises(d.DomainError):
+        d.tukey(128, 1.5)

@@ -662,6 +662,22 @@ def test_hilbert(d):
         assert got.dtype == (np.complex64 if dt == np.float32 else np.complex128) and relerr(got, ou.hilbert(x.astype(np.float64))) < tol
 
 
+def test_fftshift_of_estimates(d):
+    # test/periodograms.jl:239-260
+    data = np.arange(1.0, 101.0)
+    p = d.periodogram(data); ps = d.fftshift(p)
+    assert np.array_equal(p.power, ps.power) and np.allclose(p.freq, ps.freq)
+    pp = d.fftshift(ps)
+    assert np.array_equal(pp.power, ps.power) and np.array_equal(pp.freq, ps.freq)
+    p = d.periodogram(data, onesided=False)
+    assert np.array_equal(np.fft.fftshift(p.power), d.fftshift(p).power) and np.array_equal(np.fft.fftshift(p.freq), d.fftshift(p).freq)
+    sp = d.spectrogram(data); sps = d.fftshift(sp)
+    assert np.array_equal(sp.power, sps.power) and np.allclose(sp.freq, sps.freq)
+    sp = d.spectrogram(data, onesided=False)
+    assert np.array_equal(np.fft.fftshift(sp.power, 0), d.fftshift(sp).power) and np.array_equal(np.fft.fftshift(sp.freq), d.fftshift(sp).freq)
+    assert np.array_equal(d.fftshift(sp).time, sp.time)
+
+
 def test_edge_cases_empty_and_tiny_inputs(d):
     # what the reference does for degenerate shapes (test/dsp.jl:42-49, test/filt.jl, periodograms.jl:49-50, stream_filt.jl:483-487)
     from oracle import dspbase as odsp, filt as of, periodograms as opg, stream_filt as osf
