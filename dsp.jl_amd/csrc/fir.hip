@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "devio.h"
+#include "arb_scan.h"
 #include "fft_lds.h"
 
 using namespace mdsp;
@@ -253,13 +254,20 @@ int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 // all threads evaluate   y = muladd(yUpper, alpha, yLower)   (:616) with yLower/yUpper the two tapsPerPhase-term
 // chains (oldest sample first) over the input span staged in LDS.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int ARB_BLK = 64;   // outputs per host anchor
+constexpr int ARB_BLK = 32;   // outputs per host anchor (16 bytes of anchor per block: 0.5 B of extra traffic per output)
 
 struct ArbStep {              // one update! (stream_filt.jl:567-577), shared by host and device
     double delta, nphi, inv_nphi;
     __host__ __device__ inline void operator()(double& acc, int64_t& xidx) const {
         acc = acc + delta;
         if (acc >= nphi) {
+            if (acc < 2.0 * nphi) {
+                // q = 1, the common overflow: nphi <= acc < 2 nphi makes acc - nphi exact (Sterbenz), which is what divrem
+                // returns -- and keeps floor / multiply / compare-and-fix off the loop-carried chain
+                acc -= nphi;
+                xidx += 1;
+                return;
+            }
             // divrem(acc, nphi): q = floor(acc/nphi) up to one unit, r = acc - q nphi (exact), then fix q
             double q = floor(acc * inv_nphi);
             double r = acc - q * nphi;   // q nphi is an exact integer and |r| <= acc is a multiple of ulp(acc): exact with or without FMA
@@ -281,7 +289,7 @@ struct ArbArgs {
     const void* hist;
     void* y;
     const void* taps2;    // tp * Nphi pairs (pfb, dpfb), taps2[i*Nphi + phi]
-    const int64_t* tab_x; // 1-based xIdx of output 64 b
+    const int64_t* tab_x; // 1-based xIdx of output ARB_BLK b
     const double* tab_acc;
     int64_t xlen, ldx, ldy, nout, nch;
     ArbStep step;
@@ -297,22 +305,68 @@ struct ArbRec {
     double alpha;
 };
 
-template <typename R> struct Tap2 {   // (pfb, dpfb) of one (tap, phase): one 8 / 16-byte LDS read feeds both chains
+// rec[] is written by phase A with a lane stride of ARB_BLK records: one pad record per ARB_BLK keeps those 16-byte stores
+// off a single bank group
+__host__ __device__ constexpr int arb_rec_slot(int j) { return j + j / ARB_BLK; }
+
+template <typename R> struct alignas(2 * sizeof(R)) Tap2 {   // (pfb, dpfb) of one (tap, phase): one 8 / 16-byte LDS read feeds both chains
     R p, d;
 };
 
-template <typename XS, typename A, typename R>
+// One tile of outputs for one group of NCH channels.  `pf` is either the LDS copy of the tap pairs or the global
+// table (the caller branches, so each copy of this body sees one address space and the LDS copy compiles to
+// ds_read_b64); the samples of the NCH channels are interleaved in LDS, zs[k * NCH + c], so one tap-pair read and one
+// NCH-wide sample read feed 2 NCH FMAs: 4 + 8 / NCH bytes of LDS traffic per tap and output instead of 12.
+template <typename A, typename R, int NCH>
+__device__ __forceinline__ void arb_tile_staged(const ArbRec* rec, const Tap2<R>* __restrict__ pf, const A* zs, A* const (&yc)[NCH], int nc, int cnt,
+                                                int tp, int nphi) {
+    struct alignas(sizeof(A) * NCH <= 16 ? sizeof(A) * NCH : 16) ZV {
+        A v[NCH];
+    };
+    const ZV* zv = reinterpret_cast<const ZV*>(zs);
+    for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+        const ArbRec rc = rec[arb_rec_slot(j)];
+        const Tap2<R>* hq = pf + rc.phi;
+        const ZV* zp = zv + rc.xrel;
+        A lo[NCH], up[NCH];
+        {
+            const Tap2<R> t = *hq;
+            const ZV z = zp[0];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                lo[c] = mul_first(t.p, z.v[c]);
+                up[c] = mul_first(t.d, z.v[c]);
+            }
+        }
+#pragma unroll 8
+        for (int i = 1; i < tp; ++i) {
+            hq += nphi;
+            const Tap2<R> t = *hq;
+            const ZV z = zp[i];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                fma_acc(lo[c], t.p, z.v[c]);
+                fma_acc(up[c], t.d, z.v[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (c < nc) yc[c][j] = arb_combine(up[c], rc.alpha, lo[c]);
+    }
+}
+
+template <typename XS, typename A, typename R, int NCH>
 __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ArbRec* rec = reinterpret_cast<ArbRec*>(smem);
-    A* zs = reinterpret_cast<A*>(smem + (size_t)a.tile * sizeof(ArbRec));
-    Tap2<R>* ps = reinterpret_cast<Tap2<R>*>(smem + (size_t)a.tile * sizeof(ArbRec) + (size_t)a.span * sizeof(A));
+    A* zs = reinterpret_cast<A*>(smem + (size_t)arb_rec_slot(a.tile) * sizeof(ArbRec));
+    Tap2<R>* ps = reinterpret_cast<Tap2<R>*>(smem + (size_t)arb_rec_slot(a.tile) * sizeof(ArbRec) + (size_t)a.span * NCH * sizeof(A));
     const int64_t m0 = (int64_t)blockIdx.x * a.tile;
     if (m0 >= a.nout) return;
     const int cnt = (int)std::min<int64_t>(a.tile, a.nout - m0);
     const int64_t b0 = m0 / ARB_BLK;
     const int64_t x_first = a.tab_x[b0];
-    // phase A (once per tile, shared by every channel): replay the recurrence from the host anchors, one lane per 64 outputs
+    // phase A (once per tile, shared by every channel): replay the recurrence from the host anchors, one lane per ARB_BLK outputs
     if ((int)threadIdx.x * ARB_BLK < cnt) {
         int64_t xi = a.tab_x[b0 + threadIdx.x];
         double acc = a.tab_acc[b0 + threadIdx.x];
@@ -320,64 +374,66 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
         const int n = min(ARB_BLK, cnt - base);
         for (int k = 0; k < n; ++k) {
             const double fl = floor(acc);
-            rec[base + k] = {(int)(xi - x_first), (int)fl, acc - fl};   // alpha = modf(acc)[1] is exact
+            rec[arb_rec_slot(base + k)] = {(int)(xi - x_first), (int)fl, acc - fl};   // alpha = modf(acc)[1] is exact
             a.step(acc, xi);
         }
     }
-    const Tap2<R>* pf = static_cast<const Tap2<R>*>(a.taps2);
+    const Tap2<R>* pg = static_cast<const Tap2<R>*>(a.taps2);
     if (a.taps_in_lds) {
         const int np = a.tp * a.nphi;
-        for (int k = threadIdx.x; k < np; k += blockDim.x) ps[k] = pf[k];
-        pf = ps;
+        for (int k = threadIdx.x; k < np; k += blockDim.x) ps[k] = pg[k];
     }
     __syncthreads();
     const int64_t z_first = x_first - 1;                                    // z = [history ; x], output n reads z[n-1 .. n-1+tp)
-    const int64_t nz = (int64_t)rec[cnt - 1].xrel + a.tp;
+    const int64_t nz = (int64_t)rec[arb_rec_slot(cnt - 1)].xrel + a.tp;
     const bool staged = nz <= a.span;                                       // workgroup-uniform
-    for (int64_t ch = blockIdx.y; ch < a.nch; ch += gridDim.y) {
-        const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
-        const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
-        auto zload = [&](int64_t zi) -> A {
+    for (int64_t c0 = (int64_t)blockIdx.y * NCH; c0 < a.nch; c0 += (int64_t)gridDim.y * NCH) {
+        const int nc = (int)std::min<int64_t>(NCH, a.nch - c0);
+        auto zload = [&](int64_t ch, int64_t zi) -> A {
+            const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
+            const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
             A v{};
             if (zi < a.hl) v = to_acc(hc[zi], (A*)nullptr);
             else if (zi - a.hl < a.xlen) v = to_acc(xc[zi - a.hl], (A*)nullptr);
             return v;
         };
         if (staged) {
-            __syncthreads();   // the previous channel's readers are done with zs
-            for (int k = threadIdx.x; k < (int)nz; k += blockDim.x) zs[k] = zload(z_first + k);
-            __syncthreads();
-        }
-        A* yc = static_cast<A*>(a.y) + ch * a.ldy;
-        for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
-            const ArbRec rc = rec[j];
-            const Tap2<R>* hp = pf + rc.phi;
-            A lo, up;
-            if (staged) {
-                const A* zp = zs + rc.xrel;
-                Tap2<R> t = hp[0];
-                lo = mul_first(t.p, zp[0]);
-                up = mul_first(t.d, zp[0]);
-                for (int i = 1; i < a.tp; ++i) {
-                    t = hp[(int64_t)i * a.nphi];
-                    const A z = zp[i];
-                    fma_acc(lo, t.p, z);
-                    fma_acc(up, t.d, z);
-                }
-            } else {
-                const int64_t z0 = z_first + rc.xrel;
-                A z = zload(z0);
-                Tap2<R> t = hp[0];
-                lo = mul_first(t.p, z);
-                up = mul_first(t.d, z);
-                for (int i = 1; i < a.tp; ++i) {
-                    z = zload(z0 + i);
-                    t = hp[(int64_t)i * a.nphi];
-                    fma_acc(lo, t.p, z);
-                    fma_acc(up, t.d, z);
+            __syncthreads();   // the previous channel group's readers are done with zs
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c < nc) {
+                    for (int k = threadIdx.x; k < (int)nz; k += blockDim.x) zs[k * NCH + c] = zload(c0 + c, z_first + k);
+                } else {
+                    for (int k = threadIdx.x; k < (int)nz; k += blockDim.x) zs[k * NCH + c] = A{};
                 }
             }
-            yc[m0 + j] = arb_combine(up, rc.alpha, lo);
+            __syncthreads();
+            A* yc[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) yc[c] = static_cast<A*>(a.y) + (c0 + (c < nc ? c : 0)) * a.ldy + m0;
+            if (a.taps_in_lds) arb_tile_staged<A, R, NCH>(rec, ps, zs, yc, nc, cnt, a.tp, a.nphi);
+            else arb_tile_staged<A, R, NCH>(rec, pg, zs, yc, nc, cnt, a.tp, a.nphi);
+        } else {
+            const Tap2<R>* pf = a.taps_in_lds ? ps : pg;
+            for (int c = 0; c < nc; ++c) {
+                A* yc = static_cast<A*>(a.y) + (c0 + c) * a.ldy;
+                for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+                    const ArbRec rc = rec[arb_rec_slot(j)];
+                    const Tap2<R>* hp = pf + rc.phi;
+                    const int64_t z0 = z_first + rc.xrel;
+                    A z = zload(c0 + c, z0);
+                    Tap2<R> t = hp[0];
+                    A lo = mul_first(t.p, z);
+                    A up = mul_first(t.d, z);
+                    for (int i = 1; i < a.tp; ++i) {
+                        z = zload(c0 + c, z0 + i);
+                        t = hp[(int64_t)i * a.nphi];
+                        fma_acc(lo, t.p, z);
+                        fma_acc(up, t.d, z);
+                    }
+                    yc[m0 + j] = arb_combine(up, rc.alpha, lo);
+                }
+            }
         }
     }
 }
@@ -486,11 +542,13 @@ struct mdsp_firarb_s {
     double phi_acc = 0.0;
     int64_t input_deficit = 1, x_idx = 1;
     DevBuf tab_x, tab_acc;
+    DevBuf scan_t0, scan_wide, scan_E, scan_mind, scan_cb, scan_res;   // work space of the parallel trajectory scan (arb_scan.h)
     // trajectory cache: anchors of the last (phi_acc, input_deficit, xlen) evaluated
     bool cache_valid = false;
     double c_acc0 = 0.0;
     int64_t c_def0 = 0, c_xlen = -1, c_nout = 0, c_def_end = 0, c_xidx_end = 0;
     double c_acc_end = 0.0;
+    int64_t n_scanned = 0, n_serial = 0;   // trajectories evaluated by the device scan / the serial host loop
 };
 
 namespace {
@@ -807,11 +865,12 @@ namespace {
 // The loop of filt!(buffer, ::FIRFilter{FIRArbitrary}, x) (stream_filt.jl:593-622) without the dot products.
 // Anchors (xIdx, phiAcc) of outputs 0, blk, 2 blk, ... go to ax / aa when given.  Same IEEE operations as the
 // reference, so the trajectory -- and with it the output count and the final state -- is bit-exact.
+// kstop: stop after that many outputs (a multiple of blk) with the state of output kstop -- the pilot of the parallel scan.
 void arb_trajectory(double acc, int64_t deficit, const ArbStep& st, int64_t xlen, int64_t blk, std::vector<int64_t>* ax, std::vector<double>* aa,
-                    int64_t* nout, double* acc_end, int64_t* xidx_end) {
+                    int64_t* nout, double* acc_end, int64_t* xidx_end, int64_t kstop = INT64_MAX) {
     int64_t n = 0, xi = deficit;
     const double nphi = st.nphi, nphi2 = 2.0 * st.nphi, nphi3 = 3.0 * st.nphi, nphi4 = 4.0 * st.nphi, delta = st.delta;
-    while (xi <= xlen) {
+    while (xi <= xlen && n < kstop) {
         if (ax) {
             ax->push_back(xi);
             aa->push_back(acc);
@@ -845,30 +904,270 @@ void arb_trajectory(double acc, int64_t deficit, const ArbStep& st, int64_t xlen
     *xidx_end = xi;
 }
 
-template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, ArbArgs& a, hipStream_t st) {
-    const int64_t taps_bytes = 2 * (int64_t)f->base.tp * f->nphi * (int64_t)sizeof(R);
-    a.taps_in_lds = taps_bytes <= 32 * 1024;
-    // outputs per workgroup: the tile's input span (tile * Delta / Nphi + tp samples) must fit 48 KiB of LDS
-    int tile = 1024;
-    int64_t span = 0;
-    while (true) {
-        span = ((int64_t)std::ceil((double)tile * f->delta / (double)f->nphi) + f->base.tp + 4 + 3) & ~int64_t(3);   // multiple of 4: the tap pairs that follow stay 16-byte aligned
-        if (span * (int64_t)sizeof(A) <= 48 * 1024 || tile <= ARB_BLK) break;
-        tile /= 2;
+// ---- parallel trajectory scan (arb_scan.h): kernels and drivers ------------------------------------------------
+static_assert(arbscan::BLK == ARB_BLK, "the scan's block is the anchor block");
+
+__global__ __launch_bounds__(256) void arb_scan_tables_kernel(arbscan::ScanArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < a.nb) arbscan::scan_tables_body(a, b);
+}
+template <typename TIn> __global__ __launch_bounds__(256) void arb_scan_compose_kernel(arbscan::Grid G, const TIn* in, int64_t n, int64_t* out, int64_t ng) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ng) arbscan::scan_compose_body(G, in, n, out, g);
+}
+__global__ void arb_scan_top_kernel(arbscan::Grid G, const int64_t* in, int64_t n, int64_t* Eout) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) arbscan::scan_top_body(G, in, n, Eout);
+}
+template <typename TIn>
+__global__ __launch_bounds__(256) void arb_scan_expand_kernel(arbscan::Grid G, const TIn* in, int64_t n, const int64_t* Ecoarse, int64_t* Efine, int64_t ng) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ng) arbscan::scan_expand_body(G, in, n, Ecoarse, Efine, g);
+}
+__global__ __launch_bounds__(256) void arb_scan_finalize_kernel(arbscan::ScanArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < a.nb) arbscan::scan_finalize_body(a, b);
+}
+
+struct ScanLayout {
+    std::vector<int64_t> n;      // elements per level: n[0] blocks, n[l+1] = ceil(n[l] / FAN); the last level is scanned serially
+    std::vector<int64_t> woff;   // wide tables of level l >= 1 start at woff[l] (int64 elements)
+    std::vector<int64_t> eoff;   // E of level l starts at eoff[l]
+    int64_t wide_total = 0, e_total = 0;
+};
+ScanLayout scan_layout(int64_t nb, int R) {
+    ScanLayout L;
+    L.n.push_back(nb);
+    do L.n.push_back(cdiv(L.n.back(), (int64_t)arbscan::FAN));
+    while (L.n.back() > 1024);
+    L.woff.assign(L.n.size(), 0);
+    L.eoff.assign(L.n.size(), 0);
+    for (size_t l = 0; l < L.n.size(); ++l) {
+        L.eoff[l] = L.e_total;
+        L.e_total += L.n[l];
+        if (l >= 1) {
+            L.woff[l] = L.wide_total;
+            L.wide_total += L.n[l] * R;
+        }
     }
-    if (span * (int64_t)sizeof(A) > 48 * 1024) span = 0;   // very low rates: outputs are far apart, read through L2 instead
+    return L;
+}
+
+// One pass of the scan: tables -> up-sweep -> serial top -> down-sweep -> finalize.  device = false runs the same bodies in
+// host loops (CPU tests of the arithmetic; the product path always passes true).
+int scan_pass(const arbscan::ScanArgs& a, const ScanLayout& L, int64_t* wide, int64_t* Eall, bool device, hipStream_t st) {
+    using namespace arbscan;
+    const int nl = (int)L.n.size() - 1;   // top level
+    const auto blocks = [](int64_t n) { return dim3((unsigned)cdiv(n, (int64_t)256)); };
+    if (device) {
+        hipLaunchKernelGGL(arb_scan_tables_kernel, blocks(a.nb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(arb_scan_compose_kernel<int32_t>, blocks(L.n[1]), dim3(256), 0, st, a.G, (const int32_t*)a.t0, L.n[0], wide + L.woff[1], L.n[1]);
+        for (int l = 2; l <= nl; ++l)
+            hipLaunchKernelGGL(arb_scan_compose_kernel<int64_t>, blocks(L.n[l]), dim3(256), 0, st, a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1],
+                               wide + L.woff[l], L.n[l]);
+        hipLaunchKernelGGL(arb_scan_top_kernel, dim3(1), dim3(64), 0, st, a.G, (const int64_t*)(wide + L.woff[nl]), L.n[nl], Eall + L.eoff[nl]);
+        for (int l = nl; l >= 2; --l)
+            hipLaunchKernelGGL(arb_scan_expand_kernel<int64_t>, blocks(L.n[l]), dim3(256), 0, st, a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1],
+                               (const int64_t*)(Eall + L.eoff[l]), Eall + L.eoff[l - 1], L.n[l]);
+        hipLaunchKernelGGL(arb_scan_expand_kernel<int32_t>, blocks(L.n[1]), dim3(256), 0, st, a.G, (const int32_t*)a.t0, L.n[0], (const int64_t*)(Eall + L.eoff[1]),
+                           Eall + L.eoff[0], L.n[1]);
+        hipLaunchKernelGGL(arb_scan_finalize_kernel, blocks(a.nb), dim3(256), 0, st, a);
+        MDSP_LAUNCH_CHECK();
+        return MDSP_OK;
+    }
+    for (int64_t b = 0; b < a.nb; ++b) scan_tables_body(a, b);
+    for (int64_t g = 0; g < L.n[1]; ++g) scan_compose_body(a.G, (const int32_t*)a.t0, L.n[0], wide + L.woff[1], g);
+    for (int l = 2; l <= nl; ++l)
+        for (int64_t g = 0; g < L.n[l]; ++g) scan_compose_body(a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1], wide + L.woff[l], g);
+    scan_top_body(a.G, wide + L.woff[nl], L.n[nl], Eall + L.eoff[nl]);
+    for (int l = nl; l >= 2; --l)
+        for (int64_t g = 0; g < L.n[l]; ++g) scan_expand_body(a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1], Eall + L.eoff[l], Eall + L.eoff[l - 1], g);
+    for (int64_t g = 0; g < L.n[1]; ++g) scan_expand_body(a.G, (const int32_t*)a.t0, L.n[0], Eall + L.eoff[1], Eall + L.eoff[0], g);
+    for (int64_t b = 0; b < a.nb; ++b) scan_finalize_body(a, b);
+    return MDSP_OK;
+}
+
+// What the scan needs from the serial pilot: anchors of the first `pilot` outputs, the exact state of output `pilot`
+// on the grid, the slope of the rounding drift, and how many blocks can still follow.
+struct ScanSetup {
+    arbscan::Grid G;
+    std::vector<int64_t> ax;
+    std::vector<double> aa;
+    uint64_t As = 0;
+    int64_t xs = 0, k0 = 0, nb = 0;
+    double sigma = 0.0;
+};
+// false: not applicable (short stream, recurrence outside the integer model) -- the caller runs the serial loop
+bool scan_setup(double acc, int64_t deficit, const ArbStep& st, int64_t nphi, int64_t xlen, int64_t pilot, ScanSetup& S) {
+    using namespace arbscan;
+    if (pilot < 2 * BLK || pilot % BLK) return false;
+    if (!make_grid(st.delta, nphi, S.G)) return false;
+    int64_t n = 0, xe = 0;
+    double ae = 0.0;
+    arb_trajectory(acc, deficit, st, xlen, BLK, &S.ax, &S.aa, &n, &ae, &xe, pilot);
+    if (n < pilot || xe > xlen) return false;   // the stream ends inside the pilot
+    if (!to_grid(S.G, ae, S.As)) return false;
+    S.xs = xe;
+    S.k0 = pilot;
+    // drift slope over outputs BLK .. pilot (both on the grid):  E = U(pilot) - U(BLK) - (pilot - BLK) D
+    uint64_t A1 = 0;
+    if (!to_grid(S.G, S.aa[1], A1)) return false;
+    const __int128 U1 = (__int128)A1 + (__int128)S.G.N * S.ax[1], U0 = (__int128)S.As + (__int128)S.G.N * xe;
+    const __int128 E = U0 - U1 - (__int128)(pilot - BLK) * (__int128)S.G.D;
+    S.sigma = (double)E / (double)(pilot - BLK);
+    // outputs that can follow output k0: xIdx first exceeds xlen after about ((xlen + 1 - xs) N - As) / D updates; two spare blocks
+    const __int128 room = (__int128)(xlen + 1 - xe) * (__int128)S.G.N;
+    const __int128 kmax = room / (__int128)S.G.D + 2;
+    if (kmax > ((__int128)1 << 40)) return false;
+    S.nb = (int64_t)kmax / BLK + 2;
+    return true;
+}
+
+// Host emulation of the whole scan (same integer bodies as the kernels), for the CPU tests.  Returns false when the caller
+// has to fall back to the serial loop.
+bool arb_scan_host(double acc, int64_t deficit, const ArbStep& st, int64_t nphi, int64_t xlen, int64_t pilot, std::vector<int64_t>& ax,
+                   std::vector<double>& aa, int64_t* nout, double* acc_end, int64_t* xidx_end, int* passes) {
+    using namespace arbscan;
+    ScanSetup S;
+    if (!scan_setup(acc, deficit, st, nphi, xlen, pilot, S)) return false;
+    const ScanLayout L = scan_layout(S.nb, S.G.R);
+    const int64_t nanch = S.k0 / BLK + S.nb;
+    ax = S.ax;
+    aa = S.aa;
+    ax.resize((size_t)nanch);
+    aa.resize((size_t)nanch);
+    std::vector<int32_t> t0((size_t)S.nb * S.G.R);
+    std::vector<uint32_t> mind((size_t)S.nb);
+    std::vector<int64_t> cb((size_t)S.nb), wide((size_t)L.wide_total), Eall((size_t)L.e_total), res(4, 0);
+    ScanArgs a{};
+    a.G = S.G;
+    a.As = S.As;
+    a.xs = S.xs;
+    a.k0 = S.k0;
+    a.xlen = xlen;
+    a.nb = S.nb;
+    a.sigma = S.sigma;
+    a.t0 = t0.data();
+    a.mind = mind.data();
+    a.cb = cb.data();
+    a.E = Eall.data() + L.eoff[0];
+    a.baseA = reinterpret_cast<uint64_t*>(aa.data() + S.k0 / BLK);
+    a.baseW = ax.data() + S.k0 / BLK;
+    a.tab_x = ax.data();
+    a.tab_acc = aa.data();
+    a.result = res.data();
+    for (int pass = 0; pass < 2; ++pass) {
+        a.pass = pass;
+        std::fill(res.begin(), res.end(), 0);
+        scan_pass(a, L, wide.data(), Eall.data(), false, nullptr);
+        if (passes) *passes = pass + 1;
+        if (!(res[0] & 1)) break;
+    }
+    if ((res[0] & 1) || !(res[0] & 2)) return false;
+    *nout = res[1];
+    *xidx_end = res[2];
+    std::memcpy(acc_end, &res[3], 8);
+    ax.resize((size_t)cdiv(*nout, (int64_t)BLK));
+    aa.resize(ax.size());
+    return true;
+}
+
+// Device scan for one call: pilot on the host, everything else on the stream; the anchors are written straight into the
+// filter's device tables.  false: fall back to the serial loop (nothing the caller relies on has been modified).
+int arb_scan_device(mdsp_firarb_s* f, const ArbStep& step, int64_t xlen, int64_t pilot, hipStream_t st, bool* used, int64_t* nout, double* acc_end,
+                    int64_t* xidx_end) {
+    using namespace arbscan;
+    *used = false;
+    ScanSetup S;
+    if (!scan_setup(f->phi_acc, f->input_deficit, step, f->nphi, xlen, pilot, S)) return MDSP_OK;
+    const ScanLayout L = scan_layout(S.nb, S.G.R);
+    const int64_t nanch = S.k0 / BLK + S.nb;
+    MDSP_TRY(f->tab_x.reserve(sizeof(int64_t) * (size_t)nanch));
+    MDSP_TRY(f->tab_acc.reserve(sizeof(double) * (size_t)nanch));
+    MDSP_TRY(f->scan_t0.reserve(sizeof(int32_t) * (size_t)S.nb * S.G.R));
+    MDSP_TRY(f->scan_mind.reserve(sizeof(uint32_t) * (size_t)S.nb));
+    MDSP_TRY(f->scan_cb.reserve(sizeof(int64_t) * (size_t)S.nb));
+    MDSP_TRY(f->scan_wide.reserve(sizeof(int64_t) * (size_t)L.wide_total));
+    MDSP_TRY(f->scan_E.reserve(sizeof(int64_t) * (size_t)L.e_total));
+    MDSP_TRY(f->scan_res.reserve(sizeof(int64_t) * 4));
+    MDSP_HIP(hipStreamSynchronize(st));   // a previous launch on this stream may still read the anchor tables
+    MDSP_HIP(hipMemcpy(f->tab_x.p, S.ax.data(), sizeof(int64_t) * S.ax.size(), hipMemcpyHostToDevice));
+    MDSP_HIP(hipMemcpy(f->tab_acc.p, S.aa.data(), sizeof(double) * S.aa.size(), hipMemcpyHostToDevice));
+    ScanArgs a{};
+    a.G = S.G;
+    a.As = S.As;
+    a.xs = S.xs;
+    a.k0 = S.k0;
+    a.xlen = xlen;
+    a.nb = S.nb;
+    a.sigma = S.sigma;
+    a.t0 = f->scan_t0.as<int32_t>();
+    a.mind = f->scan_mind.as<uint32_t>();
+    a.cb = f->scan_cb.as<int64_t>();
+    a.E = f->scan_E.as<int64_t>() + L.eoff[0];
+    a.baseA = reinterpret_cast<uint64_t*>(f->tab_acc.as<double>() + S.k0 / BLK);
+    a.baseW = f->tab_x.as<int64_t>() + S.k0 / BLK;
+    a.tab_x = f->tab_x.as<int64_t>();
+    a.tab_acc = f->tab_acc.as<double>();
+    a.result = f->scan_res.as<int64_t>();
+    int64_t res[4] = {0, 0, 0, 0};
+    for (int pass = 0; pass < 2; ++pass) {
+        a.pass = pass;
+        MDSP_HIP(hipMemsetAsync(f->scan_res.p, 0, sizeof(res), st));
+        MDSP_TRY(scan_pass(a, L, f->scan_wide.as<int64_t>(), f->scan_E.as<int64_t>(), true, st));
+        MDSP_HIP(hipMemcpyAsync(res, f->scan_res.p, sizeof(res), hipMemcpyDeviceToHost, st));
+        MDSP_HIP(hipStreamSynchronize(st));
+        if (!(res[0] & 1)) break;
+    }
+    if ((res[0] & 1) || !(res[0] & 2)) return MDSP_OK;   // ambiguous twice, or no end found: serial loop
+    *nout = res[1];
+    *xidx_end = res[2];
+    std::memcpy(acc_end, &res[3], 8);
+    *used = true;
+    return MDSP_OK;
+}
+
+template <typename XS, typename A, typename R, int NCH> int arb_launch_n(mdsp_firarb_s* f, ArbArgs& a, int tile, int64_t span, hipStream_t st) {
+    const int64_t taps_bytes = 2 * (int64_t)f->base.tp * f->nphi * (int64_t)sizeof(R);
     a.tile = tile;
     a.span = (int)span;
-    const size_t lds_bytes = (size_t)tile * sizeof(ArbRec) + (size_t)span * sizeof(A) + (a.taps_in_lds ? (size_t)taps_bytes : 0);
-    auto kern = arbitrary_fir_kernel<XS, A, R>;
+    const size_t lds_bytes = (size_t)arb_rec_slot(tile) * sizeof(ArbRec) + (size_t)span * NCH * sizeof(A) + (a.taps_in_lds ? (size_t)taps_bytes : 0);
+    auto kern = arbitrary_fir_kernel<XS, A, R, NCH>;
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    // channels share a tile's replayed trajectory: loop over them inside the workgroup unless there are too few tiles to fill the GPU
+    // channels share a tile's replayed trajectory (and, NCH at a time, its tap reads): loop over the channel groups inside the
+    // workgroup unless there are too few tiles to fill the GPU
     const int64_t tiles = cdiv(a.nout, tile);
-    const unsigned gy = (unsigned)std::min<int64_t>(f->base.nch, std::max<int64_t>(1, cdiv((int64_t)device_cu_count() * 8, tiles)));
+    const int64_t groups = cdiv(f->base.nch, NCH);
+    const unsigned gy = (unsigned)std::min<int64_t>(groups, std::max<int64_t>(1, cdiv((int64_t)device_cu_count() * 8, tiles)));
     const dim3 grid((unsigned)tiles, gy);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
+}
+
+template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, ArbArgs& a, hipStream_t st) {
+    const int64_t taps_bytes = 2 * (int64_t)f->base.tp * f->nphi * (int64_t)sizeof(R);
+    a.taps_in_lds = taps_bytes <= 32 * 1024;
+    const int nch_max = getenv("MDSP_ARB_NCH") ? atoi(getenv("MDSP_ARB_NCH")) : 4;   // tuning knob
+    // channels per group: the most whose workgroup (trajectory records + interleaved input span of tile * Delta / Nphi + tp
+    // samples per channel + tap pairs) stays within 44 KiB of LDS, i.e. leaves >= 3 workgroups per CU; measured on MI355X,
+    // larger footprints lose more to occupancy than the shared tap reads save
+    int nchg = f->base.nch >= 3 ? 4 : (int)std::max<int64_t>(1, f->base.nch);
+    nchg = std::min(nchg, nch_max >= 4 ? 4 : nch_max >= 2 ? 2 : 1);
+    int tile = 1024;
+    int64_t span = 0;
+    const auto span_of = [&](int t) { return ((int64_t)std::ceil((double)t * f->delta / (double)f->nphi) + f->base.tp + 4 + 3) & ~int64_t(3); };   // multiple of 4: the tap pairs that follow stay 16-byte aligned
+    const int64_t fixed = (int64_t)arb_rec_slot(1024) * (int64_t)sizeof(ArbRec) + (a.taps_in_lds ? taps_bytes : 0);
+    span = span_of(tile);
+    while (nchg > 1 && fixed + span * nchg * (int64_t)sizeof(A) > 44 * 1024) nchg /= 2;
+    if (nchg == 1) {   // one channel at a time: shrink the tile until its span fits 48 KiB
+        while ((span = span_of(tile)) * (int64_t)sizeof(A) > 48 * 1024 && tile > ARB_BLK) tile /= 2;
+        if (span * (int64_t)sizeof(A) > 48 * 1024) span = 0;   // very low rates: outputs are far apart, read through L2 instead
+    }
+    switch (nchg) {
+        case 4: return arb_launch_n<XS, A, R, 4>(f, a, tile, span, st);
+        case 2: return arb_launch_n<XS, A, R, 2>(f, a, tile, span, st);
+        default: return arb_launch_n<XS, A, R, 1>(f, a, tile, span, st);
+    }
 }
 
 int arb_dispatch(mdsp_firarb_s* f, ArbArgs& a, hipStream_t st) {
@@ -920,6 +1219,39 @@ int mdsp_arb_trajectory(double phi_acc, int64_t input_deficit, double rate, int6
         std::copy(ax.begin(), ax.end(), anchors_x);
         std::copy(aa.begin(), aa.end(), anchors_acc);
     }
+    return MDSP_OK;
+}
+
+// Host emulation of the device's parallel trajectory scan (same integer code, arb_scan.h): for the CPU tests.  *used = 0
+// when the scan does not apply (short stream, recurrence outside the integer model, ambiguous twice) -- the product then
+// runs the serial loop, and so should the caller.
+int mdsp_arb_trajectory_scan(double phi_acc, int64_t input_deficit, double rate, int64_t nphi, int64_t xlen, int64_t pilot, int64_t* anchors_x,
+                             double* anchors_acc, int64_t anchors_cap, int64_t* nout, double* phi_acc_end, int64_t* input_deficit_end, int* used,
+                             int* passes) {
+    if (!(rate > 0.0) || nphi < 1 || xlen < 0 || input_deficit < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid trajectory arguments");
+    if (!nout || !phi_acc_end || !input_deficit_end || !used) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL result pointer");
+    *used = 0;
+    if (xlen < input_deficit) return MDSP_OK;
+    const double delta = (double)nphi / rate;
+    const ArbStep st{delta, (double)nphi, 1.0 / (double)nphi};
+    std::vector<int64_t> ax;
+    std::vector<double> aa;
+    int64_t xe = 0;
+    if (!arb_scan_host(phi_acc, input_deficit, st, nphi, xlen, pilot, ax, aa, nout, phi_acc_end, &xe, passes)) return MDSP_OK;
+    *input_deficit_end = xe - xlen;
+    if (anchors_x) {
+        if ((int64_t)ax.size() > anchors_cap || !anchors_acc) MDSP_FAIL(MDSP_ERR_ARGUMENT, "anchor buffers too small: need %lld", (long long)ax.size());
+        std::copy(ax.begin(), ax.end(), anchors_x);
+        std::copy(aa.begin(), aa.end(), anchors_acc);
+    }
+    *used = 1;
+    return MDSP_OK;
+}
+
+int mdsp_firarb_scan_stats(mdsp_firarb f, int64_t* scanned, int64_t* serial) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (scanned) *scanned = f->n_scanned;
+    if (serial) *serial = f->n_serial;
     return MDSP_OK;
 }
 
@@ -1086,20 +1418,34 @@ int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx
     const ArbStep step{f->delta, (double)f->nphi, 1.0 / (double)f->nphi};
     const bool hit = f->cache_valid && f->c_acc0 == f->phi_acc && f->c_def0 == f->input_deficit && f->c_xlen == xlen;
     if (!hit) {
-        std::vector<int64_t> ax;
-        std::vector<double> aa;
-        ax.reserve((size_t)((double)xlen * f->rate / ARB_BLK) + 16);
-        aa.reserve(ax.capacity());
         int64_t nout = 0, xe = 0;
         double ae = 0.0;
-        arb_trajectory(f->phi_acc, f->input_deficit, step, xlen, ARB_BLK, &ax, &aa, &nout, &ae, &xe);
+        bool scanned = false;
         f->cache_valid = false;
-        MDSP_TRY(f->tab_x.reserve(sizeof(int64_t) * std::max<size_t>(1, ax.size())));
-        MDSP_TRY(f->tab_acc.reserve(sizeof(double) * std::max<size_t>(1, aa.size())));
-        MDSP_HIP(hipStreamSynchronize(st));   // a previous launch on this stream may still read the anchor tables
-        if (!ax.empty()) {
-            MDSP_HIP(hipMemcpy(f->tab_x.p, ax.data(), sizeof(int64_t) * ax.size(), hipMemcpyHostToDevice));
-            MDSP_HIP(hipMemcpy(f->tab_acc.p, aa.data(), sizeof(double) * aa.size(), hipMemcpyHostToDevice));
+        // long streams: the recurrence is evaluated in parallel on the device, bit for bit (arb_scan.h); MDSP_ARB_SCAN=0 and
+        // MDSP_ARB_SCAN_MIN (outputs) are test / tuning knobs
+        const char* es = getenv("MDSP_ARB_SCAN");
+        const char* em = getenv("MDSP_ARB_SCAN_MIN");
+        const int64_t scan_min = em ? atoll(em) : (int64_t)1 << 19;
+        const int64_t pilot = std::min<int64_t>(65536, std::max<int64_t>(2 * ARB_BLK, (scan_min / 4) & ~int64_t(ARB_BLK - 1)));
+        if (!(es && atoi(es) == 0) && (double)xlen * f->rate >= (double)scan_min)
+            MDSP_TRY(arb_scan_device(f, step, xlen, pilot, st, &scanned, &nout, &ae, &xe));
+        if (scanned) {
+            ++f->n_scanned;
+        } else {
+            std::vector<int64_t> ax;
+            std::vector<double> aa;
+            ax.reserve((size_t)((double)xlen * f->rate / ARB_BLK) + 16);
+            aa.reserve(ax.capacity());
+            arb_trajectory(f->phi_acc, f->input_deficit, step, xlen, ARB_BLK, &ax, &aa, &nout, &ae, &xe);
+            MDSP_TRY(f->tab_x.reserve(sizeof(int64_t) * std::max<size_t>(1, ax.size())));
+            MDSP_TRY(f->tab_acc.reserve(sizeof(double) * std::max<size_t>(1, aa.size())));
+            MDSP_HIP(hipStreamSynchronize(st));   // a previous launch on this stream may still read the anchor tables
+            if (!ax.empty()) {
+                MDSP_HIP(hipMemcpy(f->tab_x.p, ax.data(), sizeof(int64_t) * ax.size(), hipMemcpyHostToDevice));
+                MDSP_HIP(hipMemcpy(f->tab_acc.p, aa.data(), sizeof(double) * aa.size(), hipMemcpyHostToDevice));
+            }
+            ++f->n_serial;
         }
         f->c_acc0 = f->phi_acc;
         f->c_def0 = f->input_deficit;

@@ -187,6 +187,47 @@ def test_arbitrary_trajectory_bit_exact_with_oracle(rate, nphi, acc0, def0, xlen
     assert np.array_equal(ax, xs[::64]) and np.array_equal(aa, accs[::64])
 
 
+def _c_trajectory_scan(acc, deficit, rate, nphi, xlen, pilot):
+    import ctypes as C
+    lib = _lib.lib()
+    cap = int(xlen * rate / 32) + 64
+    ax = np.zeros(cap, np.int64)
+    aa = np.zeros(cap, np.float64)
+    nout, dend, aend, used, passes = C.c_int64(), C.c_int64(), C.c_double(), C.c_int(), C.c_int()
+    _lib.check(lib.mdsp_arb_trajectory_scan(acc, deficit, rate, nphi, xlen, pilot, ax.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            aa.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(nout), C.byref(aend), C.byref(dend),
+                                            C.byref(used), C.byref(passes)))
+    na = -(-nout.value // 32)
+    return bool(used.value), passes.value, ax[:na], aa[:na], nout.value, aend.value, dend.value
+
+
+def test_arbitrary_parallel_scan_is_bit_exact():
+    """The device's parallel evaluation of update! (integer image of the IEEE operations + scan of the roundings,
+    csrc/arb_scan.h), run through its host emulation, against the serial loop: every anchor, the output count and the final
+    state, over up/down-sampling rates, non-power-of-two Nphi, off-grid initial phases, exactly representable rates
+    (positions on the wrap point) and a three-level scan."""
+    rng = np.random.default_rng(5)
+    rates = [160 / 147, 147 / 160, 0.3721, 1.5, 2.7, 1.0000001, 0.99, 3.3, 0.2, 1 / 3, 2 / 3, 6.5, 0.13, 5.99, 1.0, 2.0, 0.5, 4 / 3, np.pi / 3]
+    rates += list(np.exp(rng.uniform(np.log(0.13), np.log(6.9), 12)))
+    scanned = 0
+    cases = []
+    for rate in rates:
+        for nphi in (32, 48, 7):
+            cases.append((rate, nphi, int(rng.integers(60000, 120000) / max(rate, 1)), int(rng.choice([64, 1024, 4096]))))
+    cases.append((1.5, 32, 6_000_000, 65536))           # 9e6 outputs: 281k blocks, three scan levels
+    for rate, nphi, xlen, pilot in cases:
+        acc = float(rng.uniform(0, nphi)) if rng.random() < 0.7 else 0.0
+        deficit = int(rng.integers(1, 5))
+        ax, aa, nout, aend, dend = _c_trajectory(acc, deficit, rate, nphi, xlen, block=32)
+        used, passes, sx, sa, snout, saend, sdend = _c_trajectory_scan(acc, deficit, rate, nphi, xlen, pilot)
+        if not used:
+            continue
+        scanned += 1
+        assert (snout, saend, sdend) == (nout, aend, dend), (rate, nphi, xlen)
+        assert np.array_equal(sx, ax) and np.array_equal(sa, aa), (rate, nphi, xlen)
+    assert scanned >= len(cases) - 3                     # the scan certifies itself on (almost) every case
+
+
 def test_arbitrary_reference_length_regressions():
     """test/resample.jl:96-101 (issue #317): output lengths of resample() at awkward arbitrary rates."""
     from oracle import design as od

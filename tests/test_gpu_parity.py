@@ -548,6 +548,43 @@ def test_firarbitrary_vs_oracle_and_streaming_state(d, rate, nphi):
     assert (f.phi_accumulator, f.phi_idx, f.alpha, f.input_deficit) == (0.0, 1, 0.0, 1) and not f.history.any()
 
 
+@pytest.mark.parametrize("rate,nphi", [(160 / 147, 32), (0.7071067811865476, 32), (2.7, 48), (1.5, 32), (4 / 3, 32), (0.3721, 20)])
+def test_firarbitrary_device_trajectory_scan_is_bit_exact(d, rate, nphi, monkeypatch):
+    """Streams of >= 2^19 outputs evaluate update! (stream_filt.jl:567-577) in parallel on the device (csrc/arb_scan.h).  Output
+    count, final phase accumulator / input deficit and every output sample must equal those of the serial recurrence."""
+    import ctypes as C
+    from dsp_jl_amd import _lib
+    from oracle import design as odes
+    lib = _lib.lib()
+    rng = np.random.default_rng(int(rate * 977) + nphi)
+    h = odes.resample_filter(float(rate), nphi).astype(np.float32)
+    xlen = int(600000 / rate) + 999
+    x = rng.standard_normal(2 * xlen).astype(np.float32)
+
+    def run(scan):
+        monkeypatch.setenv("MDSP_ARB_SCAN", "1" if scan else "0")
+        f = d.FIRFilter(h, rate, nphi)
+        f.setphase(f.timedelay())                       # an initial phase that is NOT on the recurrence's grid
+        start = (f.phi_accumulator, f.input_deficit)
+        ys, states = [], []
+        for chunk in (x[:xlen], x[xlen:]):             # the second chunk starts from the state the first one left
+            ys.append(f.filt(chunk))
+            states.append((f.phi_accumulator, f.phi_idx, f.alpha, f.input_deficit, len(ys[-1])))
+        sc, se = C.c_int64(), C.c_int64()
+        _lib.check(lib.mdsp_firarb_scan_stats(f._handle, C.byref(sc), C.byref(se)))
+        return start, ys, states, (sc.value, se.value)
+
+    start, ys, states, counts = run(True)
+    start0, ys0, states0, counts0 = run(False)
+    assert counts == (2, 0) and counts0 == (0, 2)       # both chunks went through the scan / the serial loop
+    assert start == start0 and states == states0
+    assert all(np.array_equal(a, b) for a, b in zip(ys, ys0))
+    # and the serial library loop itself is pinned to the oracle's literal recurrence in tests/test_abi_cpu.py
+    nout, dend, aend = C.c_int64(), C.c_int64(), C.c_double()
+    _lib.check(lib.mdsp_arb_trajectory(start[0], start[1], rate, nphi, xlen, 32, None, None, 0, C.byref(nout), C.byref(aend), C.byref(dend)))
+    assert (aend.value, dend.value, nout.value) == (states[0][0], states[0][3], states[0][4])
+
+
 def test_resample_arbitrary_rate(d, torch):
     # test/resample.jl:74-101: irrational ratio accuracy, Float32 ratio (#302), buffer-length regressions (#317), dims
     from oracle import stream_filt as osf
