@@ -13,7 +13,7 @@ from . import windows, design  # noqa: F401
 from .windows import (hanning, hann, hamming, rect, bartlett, cosine, blackman, kaiser, dpss, dpsseig, tukey, lanczos, triang,  # noqa: F401
                       gaussian, bartlett_hann, blackmanharris, nuttall, flattop)
 from .design import resample_filter, kaiserord  # noqa: F401
-from .dspbase import conv, conv_, xcorr, hilbert, optimalfftfiltlength, os_fft_complexity, SMALL_FILT_CUTOFF  # noqa: F401
+from .dspbase import conv, conv_, conv_separable, xcorr, hilbert, optimalfftfiltlength, os_fft_complexity, SMALL_FILT_CUTOFF  # noqa: F401
 from .dspbase import filt as _filt_ba, filt_ as _filt_ba_
 from .filters import (FIRFilter, fftfilt, fftfilt_, tdfilt, tdfilt_, resample, inputlength, outputlength,  # noqa: F401
                       filt as _filt_bx, filt_ as _filt_bx_, filt_stateless, DF2TFilter, filtfilt)

@@ -366,48 +366,83 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
     const int cnt = (int)std::min<int64_t>(a.tile, a.nout - m0);
     const int64_t b0 = m0 / ARB_BLK;
     const int64_t x_first = a.tab_x[b0];
-    // phase A (once per tile, shared by every channel): replay the recurrence from the host anchors, one lane per ARB_BLK outputs
-    if ((int)threadIdx.x * ARB_BLK < cnt) {
-        int64_t xi = a.tab_x[b0 + threadIdx.x];
-        double acc = a.tab_acc[b0 + threadIdx.x];
-        const int base = threadIdx.x * ARB_BLK;
-        const int n = min(ARB_BLK, cnt - base);
-        for (int k = 0; k < n; ++k) {
-            const double fl = floor(acc);
-            rec[arb_rec_slot(base + k)] = {(int)(xi - x_first), (int)fl, acc - fl};   // alpha = modf(acc)[1] is exact
-            a.step(acc, xi);
-        }
-    }
-    const Tap2<R>* pg = static_cast<const Tap2<R>*>(a.taps2);
-    if (a.taps_in_lds) {
-        const int np = a.tp * a.nphi;
-        for (int k = threadIdx.x; k < np; k += blockDim.x) ps[k] = pg[k];
-    }
-    __syncthreads();
     const int64_t z_first = x_first - 1;                                    // z = [history ; x], output n reads z[n-1 .. n-1+tp)
-    const int64_t nz = (int64_t)rec[arb_rec_slot(cnt - 1)].xrel + a.tp;
-    const bool staged = nz <= a.span;                                       // workgroup-uniform
-    for (int64_t c0 = (int64_t)blockIdx.y * NCH; c0 < a.nch; c0 += (int64_t)gridDim.y * NCH) {
-        const int nc = (int)std::min<int64_t>(NCH, a.nch - c0);
-        auto zload = [&](int64_t ch, int64_t zi) -> A {
-            const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
-            const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
-            A v{};
-            if (zi < a.hl) v = to_acc(hc[zi], (A*)nullptr);
-            else if (zi - a.hl < a.xlen) v = to_acc(xc[zi - a.hl], (A*)nullptr);
-            return v;
-        };
-        if (staged) {
-            __syncthreads();   // the previous channel group's readers are done with zs
+    const int tid = threadIdx.x;
+    auto zload = [&](int64_t ch, int64_t zi) -> A {   // branch-free: the loads of a staging batch all issue before the first wait
+        const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
+        const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
+        const int64_t xi = zi - a.hl;
+        const bool in_hist = zi < a.hl, ok = in_hist || xi < a.xlen;
+        const XS* p = in_hist ? hc + zi : xc + (xi < a.xlen ? xi : 0);
+        const A v = to_acc(*p, (A*)nullptr);
+        return ok ? v : A{};
+    };
+    // stage z[z_first .. z_first + count) of the channel group at c0 into zs, interleaved; `lanes` threads starting at `first`
+    auto stage = [&](int64_t c0, int nc, int first, int lanes, int count) {
+        constexpr int RB = 4;   // RB * NCH independent loads in flight per thread
+        for (int k0 = first; k0 < count; k0 += RB * lanes) {
+            A v[RB][NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c < nc) {
-                    for (int k = threadIdx.x; k < (int)nz; k += blockDim.x) zs[k * NCH + c] = zload(c0 + c, z_first + k);
-                } else {
-                    for (int k = threadIdx.x; k < (int)nz; k += blockDim.x) zs[k * NCH + c] = A{};
+            for (int r = 0; r < RB; ++r) {
+                const int k = k0 + r * lanes;
+                const int64_t zi = z_first + (k < count ? k : count - 1);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) v[r][c] = zload(c0 + (c < nc ? c : 0), zi);
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int k = k0 + r * lanes;
+                if (k < count) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) zs[k * NCH + c] = c < nc ? v[r][c] : A{};
                 }
             }
-            __syncthreads();
+        }
+    };
+    const Tap2<R>* pg = static_cast<const Tap2<R>*>(a.taps2);
+    const int64_t c_first = (int64_t)blockIdx.y * NCH;
+    // Prologue, wave-specialised so that its two latency chains overlap: wave 0 replays the recurrence from the anchors (phase A,
+    // once per tile, shared by every channel; one lane per ARB_BLK outputs), waves 1..3 meanwhile copy the tap pairs and stage the
+    // first channel group's samples (the whole span: its exact extent is only known after phase A).
+    if (tid < 64) {
+        if (tid * ARB_BLK < cnt) {
+            int64_t xi = a.tab_x[b0 + tid];
+            double acc = a.tab_acc[b0 + tid];
+            const int base = tid * ARB_BLK;
+            const int n = min(ARB_BLK, cnt - base);
+            for (int k = 0; k < n; ++k) {
+                const double fl = floor(acc);
+                rec[arb_rec_slot(base + k)] = {(int)(xi - x_first), (int)fl, acc - fl};   // alpha = modf(acc)[1] is exact
+                a.step(acc, xi);
+            }
+        }
+    } else {
+        const int lanes = (int)blockDim.x - 64, u = tid - 64;
+        if (a.taps_in_lds) {
+            const int np = a.tp * a.nphi;
+            constexpr int RB = 4;
+            for (int k0 = u; k0 < np; k0 += RB * lanes) {
+                Tap2<R> v[RB];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) v[r] = pg[min(k0 + r * lanes, np - 1)];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    if (k0 + r * lanes < np) ps[k0 + r * lanes] = v[r];
+            }
+        }
+        if (a.span > 0 && c_first < a.nch) stage(c_first, (int)std::min<int64_t>(NCH, a.nch - c_first), u, lanes, a.span);
+    }
+    __syncthreads();
+    const int64_t nz = (int64_t)rec[arb_rec_slot(cnt - 1)].xrel + a.tp;
+    const bool staged = nz <= a.span;                                       // workgroup-uniform
+    for (int64_t c0 = c_first; c0 < a.nch; c0 += (int64_t)gridDim.y * NCH) {
+        const int nc = (int)std::min<int64_t>(NCH, a.nch - c0);
+        if (staged) {
+            if (c0 != c_first) {
+                __syncthreads();   // the previous channel group's readers are done with zs
+                stage(c0, nc, tid, (int)blockDim.x, (int)nz);
+                __syncthreads();
+            }
             A* yc[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) yc[c] = static_cast<A*>(a.y) + (c0 + (c < nc ? c : 0)) * a.ldy + m0;
@@ -1154,9 +1189,11 @@ template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, 
     int nchg = f->base.nch >= 3 ? 4 : (int)std::max<int64_t>(1, f->base.nch);
     nchg = std::min(nchg, nch_max >= 4 ? 4 : nch_max >= 2 ? 2 : 1);
     int tile = 1024;
+    if (const char* e = getenv("MDSP_ARB_TILE")) tile = std::min(64 * ARB_BLK, std::max(ARB_BLK, atoi(e) / ARB_BLK * ARB_BLK));   // tuning knob (one wave replays the tile)
+    const int tile0 = tile;
     int64_t span = 0;
     const auto span_of = [&](int t) { return ((int64_t)std::ceil((double)t * f->delta / (double)f->nphi) + f->base.tp + 4 + 3) & ~int64_t(3); };   // multiple of 4: the tap pairs that follow stay 16-byte aligned
-    const int64_t fixed = (int64_t)arb_rec_slot(1024) * (int64_t)sizeof(ArbRec) + (a.taps_in_lds ? taps_bytes : 0);
+    const int64_t fixed = (int64_t)arb_rec_slot(tile0) * (int64_t)sizeof(ArbRec) + (a.taps_in_lds ? taps_bytes : 0);
     span = span_of(tile);
     while (nchg > 1 && fixed + span * nchg * (int64_t)sizeof(A) > 44 * 1024) nchg /= 2;
     if (nchg == 1) {   // one channel at a time: shrink the tile until its span fits 48 KiB

@@ -27,6 +27,8 @@ struct RocPlan {
     void destroy();
     // Contiguous batches: real side distance n, hermitian side distance n/2+1, complex side distance n.
     int create(FftKind kind, bool is_double, int64_t n, int64_t batch, bool inplace);
+    // One N-d transform (N <= 3), lens[0] fastest, default contiguous layouts (Hermitian side: lens[0]/2 + 1 along dimension 0).
+    int create_nd(FftKind kind, bool is_double, int ndim, const int64_t* lens, bool inplace);
     int exec(void* in, void* out, hipStream_t stream);
 };
 

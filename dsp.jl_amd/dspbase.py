@@ -157,11 +157,16 @@ def conv_select_algorithm(nu: int, nv: int, T, algorithm: str = "auto") -> str:
 
 
 def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int = _lib.ENGINE_AUTO):
-    """``conv(u, v; algorithm)`` for vectors (dspbase.jl:709-792).  ``out_len`` > nu+nv-1 zero-fills the tail like
-    ``conv!`` into an oversized ``out`` (:733-735)."""
+    """``conv(u, v; algorithm)`` (dspbase.jl:709-792): vectors here, arrays in ``_conv_nd``, ``conv(u, v, A)`` with a matrix
+    ``A`` is the separable form (:801-818).  ``out_len`` > nu+nv-1 zero-fills the tail like ``conv!`` into an oversized
+    ``out`` (:733-735)."""
+    if not isinstance(algorithm, str):                  # conv(u, transpose(v), A): the third positional argument is the matrix
+        return conv_separable(u, v, algorithm)
     udt, vdt = _dev.np_dtype_of(u), _dev.np_dtype_of(v)
     if len(u.shape) != 1 or len(v.shape) != 1:
-        raise UnsupportedError("N-d convolution is not accelerated (SURVEY section 8: 1-d only)")
+        if out_len is not None:
+            raise ArgumentError("out_len is a vector argument")
+        return _conv_nd(u, v, algorithm)
     T = np.result_type(udt, vdt)
     nu, nv = int(u.shape[0]), int(v.shape[0])
     full = max(nu + nv - 1, 0)
@@ -204,6 +209,65 @@ def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int 
         pad[:full] = res
         res = pad
     return res if _dev.is_device_array(like) else res.cpu().numpy()
+
+
+def _conv_nd(u, v, algorithm: str = "auto"):
+    """``conv(u, v; algorithm)`` for arrays (dspbase.jl:709-792).  Operands of different rank are promoted with trailing
+    singleton dimensions (:784-792).  :direct (chosen by the reference for integer eltypes and for length(u) length(v) <
+    2^16) is the convolution sum on the device; every FFT algorithm is one N-d transform of the padded output
+    (``_conv_kern_fft!``, :611-644 -- :fft_overlapsave computes the same sums block-wise)."""
+    udt, vdt = _dev.np_dtype_of(u), _dev.np_dtype_of(v)
+    T = np.result_type(udt, vdt)
+    nd = max(len(u.shape), len(v.shape))
+    su = tuple(int(k) for k in u.shape) + (1,) * (nd - len(u.shape))
+    sv = tuple(int(k) for k in v.shape) + (1,) * (nd - len(v.shape))
+    so = tuple(max(a + b - 1, 0) for a, b in zip(su, sv))
+    like = u
+    if algorithm not in ("auto", "fast", "direct", "fft", "fft_simple", "fft_overlapsave"):
+        raise ArgumentError("algorithm must be :auto, :fast, :direct, :fft, :fft_simple, or :fft_overlapsave")
+    nu, nv = int(np.prod(su)), int(np.prod(sv))
+    if nu == 0 or nv == 0:
+        z = _dev.torch.zeros(so, dtype=_dev.torch_dtype(T), device=_dev.device())
+        return z if _dev.is_device_array(like) else z.cpu().numpy()
+    alg = algorithm
+    if alg == "auto":
+        alg = "fast" if T in _FFT_TYPES else "direct"
+    if alg == "fast":
+        alg = "direct" if nu * nv < 2 ** 16 else "fft"
+    W = _compute_dtype(T)
+    ud = _dev.as_device(u, W).reshape(su).contiguous()
+    vd = _dev.as_device(v, W).reshape(sv).contiguous()
+    if T.kind in "iu":
+        bound = float(ud.abs().max()) * float(vd.abs().max()) * min(nu, nv)
+        if bound >= 2.0 ** 53:
+            raise UnsupportedError("integer convolution would not be exact in Float64; use DSP.jl on the CPU")
+    out = _dev.torch.empty(so, dtype=ud.dtype, device=ud.device)
+    # C-ordered (row-major) arrays are column-major arrays with the dimensions reversed; convolution treats every
+    # dimension alike, so only the size vectors are reversed
+    csu = (C.c_int64 * nd)(*reversed(su))
+    csv = (C.c_int64 * nd)(*reversed(sv))
+    fn = _lib.lib().mdsp_convnd_direct if alg == "direct" else _lib.lib().mdsp_convnd_fft
+    _lib.check(fn(_dev.ptr(ud), csu, _dev.ptr(vd), csv, nd, _dev.md_dtype(W), _dev.ptr(out), _dev.stream_ptr()))
+    res = out
+    if T.kind in "iu":
+        res = _dev.torch.round(res).to(_dev.torch_dtype(T))
+    elif res.dtype != _dev.torch_dtype(T):
+        res = res.to(_dev.torch_dtype(T))
+    return res if _dev.is_device_array(like) else res.cpu().numpy()
+
+
+def conv_separable(u, v, A):
+    """``conv(u, transpose(v), A)`` (dspbase.jl:801-818): 2-D convolution of the matrix ``A`` with the separable kernel
+    ``u * transpose(v)`` -- evaluated as the 2-D convolution with that rank-one kernel."""
+    if len(u.shape) != 1 or len(v.shape) != 1 or len(A.shape) != 2:
+        raise ArgumentError("conv(u, v', A) takes two vectors and a matrix")
+    T = np.result_type(_dev.np_dtype_of(u), _dev.np_dtype_of(v), _dev.np_dtype_of(A))
+    W = _compute_dtype(T) if T in _FFT_TYPES else np.dtype(np.float64)
+    ud, vd = _dev.as_device(u, W), _dev.as_device(v, W)
+    kern = ud.reshape(-1, 1) * vd.reshape(1, -1)
+    res = _conv_nd(_dev.as_device(A, W), kern, "fft_simple")
+    res = res if res.dtype == _dev.torch_dtype(T) else (_dev.torch.round(res) if T.kind in "iu" else res).to(_dev.torch_dtype(T))
+    return res if _dev.is_device_array(A) else res.cpu().numpy()
 
 
 def conv_(out, u, v, algorithm: str = "auto"):

@@ -250,6 +250,21 @@ int mdsp_arb_trajectory_scan(double phi_acc, int64_t input_deficit, double rate,
 int mdsp_firarb_scan_stats(mdsp_firarb f, int64_t* scanned, int64_t* serial);
 
 /* ------------------------------------------------------------------------------------------------------
+ * N-dimensional convolution: conv(u, v) / conv!(out, u, v) for arrays (dspbase.jl:709-792).
+ *   u_dev / v_dev: column-major arrays (first dimension fastest) of sizes su[ndim] / sv[ndim], both of `dtype`;
+ *   out_dev: column-major, sizes su[d] + sv[d] - 1.
+ *   mdsp_convnd_fft    replaces _conv_kern_fft! (dspbase.jl:611-644): per-dimension zero-padding to
+ *                      nextfastfft(outsize), one N-d transform per operand (real transforms for real dtypes),
+ *                      product, inverse, crop -- and stands in for unsafe_conv_kern_os! (:490-609), which evaluates
+ *                      the same sums block-wise.  At most three dimensions with extent > 1 (rocFFT).
+ *   mdsp_convnd_direct replaces _conv_td! (dspbase.jl:646-660): the convolution sum, any ndim <= 8.
+ * ---------------------------------------------------------------------------------------------------- */
+int mdsp_convnd_fft(const void* u_dev, const int64_t* su, const void* v_dev, const int64_t* sv, int ndim, int dtype,
+                    void* out_dev, void* stream);
+int mdsp_convnd_direct(const void* u_dev, const int64_t* su, const void* v_dev, const int64_t* sv, int ndim, int dtype,
+                       void* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Time-domain FIR (filt(b, a::Number, x) and the nb <= 66 branch of filt(b, x)):
  *   replaces _filt_fir! (dspbase.jl:95-105,118-141).  Zero initial state, per column.
  *   taps_host: nb REAL taps in the real precision of `dtype` (float for MDSP_F32/C32, double for F64/C64);

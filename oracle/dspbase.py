@@ -270,6 +270,72 @@ def conv(u, v, algorithm: str = "auto", out_len: int | None = None):
     return res
 
 
+# ---------------------------------------------------------------------------------------------
+# conv for arrays, dspbase.jl:611-660, :709-818
+# ---------------------------------------------------------------------------------------------
+def _conv_td_nd(u, v, T):
+    """_conv_td! (dspbase.jl:646-660): out[n + m] += u[m] v[n] over all index pairs."""
+    so = tuple(a + b - 1 for a, b in zip(u.shape, v.shape))
+    out = np.zeros(so, dtype=T)
+    small, big = (u, v) if u.size <= v.size else (v, u)
+    for m in np.ndindex(*small.shape):
+        sl = tuple(slice(i, i + n) for i, n in zip(m, big.shape))
+        out[sl] += small[m] * big.astype(T)
+    return out
+
+
+def _conv_kern_fft_nd(u, v, T):
+    """_conv_kern_fft! (dspbase.jl:611-644): one N-d (r)fft of nextfastfft(outsize) per dimension."""
+    so = tuple(a + b - 1 for a, b in zip(u.shape, v.shape))
+    nffts = tuple(nextfastfft(n) for n in so)
+    up = np.zeros(nffts, dtype=T); up[tuple(slice(0, n) for n in u.shape)] = u
+    vp = np.zeros(nffts, dtype=T); vp[tuple(slice(0, n) for n in v.shape)] = v
+    if np.dtype(T).kind == "c":
+        raw = sfft.ifftn(sfft.fftn(up) * sfft.fftn(vp))
+    else:
+        # Julia's rfft halves the FIRST dimension; numpy's rfftn the last -- the transform is the same set of sums
+        raw = sfft.irfftn(sfft.rfftn(up) * sfft.rfftn(vp), nffts)
+    return raw[tuple(slice(0, n) for n in so)].astype(T)
+
+
+def conv_nd(u, v, algorithm: str = "auto"):
+    """``conv(u, v; algorithm)`` for arrays (dspbase.jl:709-792), trailing-singleton promotion of :784-792 included.
+    :fft_overlapsave is evaluated by the single-transform kernel (same sums; the block geometry is a CPU memory device)."""
+    u = np.asarray(u)
+    v = np.asarray(v)
+    nd = max(u.ndim, v.ndim)
+    u = u.reshape(u.shape + (1,) * (nd - u.ndim))
+    v = v.reshape(v.shape + (1,) * (nd - v.ndim))
+    T = np.result_type(u.dtype, v.dtype)
+    so = tuple(max(a + b - 1, 0) for a, b in zip(u.shape, v.shape))
+    if algorithm not in ("auto", "fast", "direct", "fft", "fft_simple", "fft_overlapsave"):
+        raise ValueError("algorithm must be :auto, :fast, :direct, :fft, :fft_simple, or :fft_overlapsave")
+    if u.size == 0 or v.size == 0:
+        return np.zeros(so, dtype=T)
+    alg = algorithm
+    if alg == "auto":
+        alg = "fast" if T in FFT_TYPES else "direct"
+    if alg == "fast":
+        alg = "direct" if u.size * v.size < 2 ** 16 else "fft"
+    if alg == "direct":
+        return _conv_td_nd(u, v, T)
+    Tf = T if T in FFT_TYPES else np.result_type(T, np.float64)
+    res = _conv_kern_fft_nd(u.astype(Tf), v.astype(Tf), Tf)
+    return np.round(res).astype(T) if T.kind in "iu" else res
+
+
+def conv_separable(u, v, A):
+    """``conv(u, transpose(v), A)`` (dspbase.jl:801-818): fft sizes m, n exactly (no nextfastfft)."""
+    u = np.asarray(u); v = np.asarray(v); A = np.asarray(A)
+    T = np.result_type(u.dtype, v.dtype, A.dtype)
+    m, n = len(u) + A.shape[0] - 1, len(v) + A.shape[1] - 1
+    B = np.zeros((m, n), dtype=np.result_type(T, np.float64)); B[:A.shape[0], :A.shape[1]] = A
+    uf = sfft.fft(np.concatenate([u, np.zeros(m - len(u))]))
+    vf = sfft.fft(np.concatenate([v, np.zeros(n - len(v))]))
+    Cm = sfft.ifft2(sfft.fft2(B) * (uf[:, None] * vf[None, :]))
+    return Cm if T.kind == "c" else Cm.real
+
+
 def xcorr(u, v=None, padmode: str = "none", scaling: str = "none"):
     """dspbase.jl:867-898."""
     u = np.asarray(u)

@@ -1047,3 +1047,56 @@ def test_channel_mean_single_rank(d, torch):
     mean = d.welch_channel_mean(S, cfg)
     per = d.welch_pgram(S.t(), cfg).power                                               # (nout, nch)
     assert float((mean.double() - per.double().mean(dim=1)).norm() / mean.double().norm()) < 1e-6
+
+
+def test_array_convolution(d, torch):
+    """conv(u, v) for arrays (dspbase.jl:709-818): the reference's literal tables (test/dsp.jl:130-268), algorithm equivalence
+    (:169-171), integer exactness, rank promotion, the separable form, and random operands against the oracle in every dtype."""
+    import conv_cases as cc
+    from oracle import dspbase as odsp
+    for alg in ("auto", "direct", "fft_simple", "fft", "fft_overlapsave", "fast"):
+        for a, b, e in ((cc.A2, cc.B2, cc.EXP2), (cc.B2, cc.A2, cc.EXP2), (cc.A3, cc.B3, cc.EXP3), (cc.A2.astype(np.int32), cc.B2, cc.EXP2)):
+            got = d.conv(a, b, algorithm=alg)
+            assert got.dtype == np.result_type(a.dtype, b.dtype) and np.array_equal(got, e), alg
+        fa, fb = cc.A2.astype(np.float64), cc.B2.astype(np.float64)
+        assert np.allclose(d.conv(fa, fb, algorithm=alg), cc.EXP2, rtol=1e-13, atol=1e-13)
+        assert np.allclose(d.conv(cc.A2.astype(np.float32), cc.B2, algorithm=alg), cc.EXP2, rtol=1e-6, atol=1e-6)       # :164
+        got = d.conv(fa + 1j, fb + 0j, algorithm=alg)
+        assert np.allclose(got.real, cc.EXP2, atol=1e-12) and np.allclose(got.imag, cc.IM_EXP2, atol=1e-12)
+    with pytest.raises(d.ArgumentError):
+        d.conv(cc.A2, cc.B2, algorithm="quantum")                                                                     # :172
+    # separable (test/dsp.jl:203-226)
+    got = d.conv(cc.SEP_U.astype(np.float64), cc.SEP_V.astype(np.float64), cc.SEP_A.astype(np.float64))
+    assert got.shape == cc.SEP_EXP.shape and np.allclose(got, cc.SEP_EXP, rtol=1e-12)
+    assert np.array_equal(d.conv(cc.SEP_U, cc.SEP_V, cc.SEP_A), cc.SEP_EXP)
+    # rank promotion and the 6-d case (test/dsp.jl:256-268)
+    a, b = cc.promoted_case()
+    exp = np.stack([odsp.conv_nd(a[:, :, 0], b) * n for n in range(1, 7)], axis=2)
+    assert np.array_equal(d.conv(a, b), exp) and np.array_equal(d.conv(b, a), exp)
+    assert np.allclose(d.conv(a, b.astype(np.float64)), exp) and np.allclose(d.conv(b.astype(np.float64), a), exp)
+    ones6 = np.ones((2,) * 6)
+    assert np.array_equal(d.conv(ones6, np.ones((1,) * 6)), ones6)
+    # empty operands (dspbase.jl:730)
+    assert d.conv(np.zeros((0, 3)), np.ones((2, 2))).shape == (1, 4) and not d.conv(np.zeros((0, 3)), np.ones((2, 2))).any()
+    # random operands, every dtype, direct and FFT against the oracle
+    rng = np.random.default_rng(11)
+    for T, tol in ((np.float32, 2e-6), (np.float64, 1e-13), (np.complex64, 2e-6), (np.complex128, 1e-13)):
+        for su, sv in (((37, 21), (5, 9)), ((8, 13, 11), (3, 4, 2)), ((130, 75), (33, 20)), ((5, 1, 17), (2, 6, 1)), ((64,), (9, 3))):
+            u = rng.standard_normal(su).astype(T); v = rng.standard_normal(sv).astype(T)
+            if np.dtype(T).kind == "c":
+                u = (u + 1j * rng.standard_normal(su)).astype(T); v = (v + 1j * rng.standard_normal(sv)).astype(T)
+            wide = np.complex128 if np.dtype(T).kind == "c" else np.float64
+            ref = odsp.conv_nd(u.astype(wide), v.astype(wide), "direct")
+            for alg in ("direct", "fft_simple", "auto"):
+                got = d.conv(u, v, algorithm=alg)
+                assert got.dtype == T and got.shape == ref.shape and relerr(got, ref) < tol, (T, su, sv, alg, relerr(got, ref))
+    # device tensors in -> device tensor out; a large image against a small kernel (one 2-d transform of the padded output)
+    img = rng.standard_normal((1500, 2000)).astype(np.float32); ker = rng.standard_normal((31, 17)).astype(np.float32)
+    got = d.conv(torch.from_numpy(img).cuda(), torch.from_numpy(ker).cuda())
+    assert isinstance(got, torch.Tensor) and got.is_cuda and tuple(got.shape) == (1530, 2016)
+    ref = odsp.conv_nd(img.astype(np.float64), ker.astype(np.float64), "fft_simple")
+    assert relerr(got.cpu().numpy(), ref) < 3e-6
+    # linearity and the delta kernel at full size: conv(x, delta shifted) is a shifted copy, bit for bit up to FFT rounding
+    delta = np.zeros((3, 4), dtype=np.float32); delta[2, 1] = 1
+    sh = d.conv(img, delta)
+    assert relerr(sh[2:2 + 1500, 1:1 + 2000], img) < 2e-6 and np.abs(sh[:2]).max() < 1e-4

@@ -426,3 +426,25 @@ def test_mt_cross_spectra_and_coherence_mne_goldens(golden):
     assert isapprox(f1, fg) and isapprox(cs1[0, 0].real, pg)
     with pytest.raises(ValueError):
         omt.mt_cross_power_spectra(x[None, :].astype(complex), fs=fs)            # :333
+
+
+def test_oracle_array_convolution_known_answers():
+    """oracle.dspbase.conv_nd / conv_separable against the literal tables of test/dsp.jl:130-268."""
+    import conv_cases as cc
+    from oracle import dspbase as odsp
+    for alg in ("auto", "direct", "fft_simple", "fft"):
+        assert np.array_equal(odsp.conv_nd(cc.A2, cc.B2, alg), cc.EXP2) and np.array_equal(odsp.conv_nd(cc.B2, cc.A2, alg), cc.EXP2)
+        assert np.array_equal(odsp.conv_nd(cc.A3, cc.B3, alg), cc.EXP3)
+        fa, fb = cc.A2.astype(np.float64), cc.B2.astype(np.float64)
+        assert np.allclose(odsp.conv_nd(fa, fb, alg), cc.EXP2, rtol=1e-13, atol=1e-13)
+        got = odsp.conv_nd(fa + 1j, fb + 0j, alg)
+        assert np.allclose(got.real, cc.EXP2, atol=1e-12) and np.allclose(got.imag, cc.IM_EXP2, atol=1e-12)
+    assert np.allclose(odsp.conv_separable(cc.SEP_U.astype(float), cc.SEP_V.astype(float), cc.SEP_A.astype(float)), cc.SEP_EXP, rtol=1e-12)
+    a, b = cc.promoted_case()
+    exp = np.stack([odsp.conv_nd(a[:, :, 0], b) * n for n in range(1, 7)], axis=2)
+    assert np.array_equal(odsp.conv_nd(a, b), exp) and np.array_equal(odsp.conv_nd(b, a), exp)
+    ones6 = np.ones((2,) * 6)
+    assert np.array_equal(odsp.conv_nd(ones6, np.ones((1,) * 6)), ones6)                      # test/dsp.jl:256-259
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal((9, 14, 5)), rng.standard_normal((4, 3, 6))
+    assert np.allclose(odsp.conv_nd(u, v, "direct"), odsp.conv_nd(u, v, "fft_simple"), rtol=1e-12, atol=1e-12)   # test/dsp.jl:169-171
