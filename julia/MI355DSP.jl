@@ -172,6 +172,37 @@ function conv(u::AbstractVector{Tu}, v::AbstractVector{Tv}; algorithm=:auto) whe
     download(olsexec(plan, todevice(big, W), nu + nv - 1))
 end
 
+# conv(u, v; algorithm) for arrays   dspbase.jl:709-792: _conv_kern_fft! (:611-644) / _conv_td! (:646-660) on the device.
+# Julia arrays are column-major, which is the layout the C ABI takes: sizes are passed as they are.
+function conv(u::AbstractArray{Tu,N}, v::AbstractArray{Tv,N}; algorithm=:auto) where {Tu<:Number,Tv<:Number,N}
+    T = promote_type(Tu, Tv)
+    W = T <: Union{Float32,Float64,ComplexF32,ComplexF64} ? T : (T <: Complex ? ComplexF64 : Float64)
+    so = size(u) .+ size(v) .- 1
+    (isempty(u) || isempty(v)) && return zeros(T, max.(so, 0))
+    alg = algorithm
+    alg === :auto && (alg = T === W ? :fast : :direct)
+    alg === :fast && (alg = length(u) * length(v) < 2^16 ? :direct : :fft)
+    alg in (:direct, :fft, :fft_simple, :fft_overlapsave) ||
+        throw(ArgumentError("algorithm must be :auto, :fast, :direct, :fft, :fft_simple, or :fft_overlapsave"))
+    ud, vd, out = todevice(u, W), todevice(v, W), DeviceArray{W}(so)
+    entry = alg === :direct ? :mdsp_convnd_direct : :mdsp_convnd_fft
+    su, sv = collect(Int64, size(u)), collect(Int64, size(v))
+    if entry === :mdsp_convnd_direct
+        check(ccall((:mdsp_convnd_direct, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Int64}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}),
+                    ud.ptr, su, vd.ptr, sv, N, mdtype(W), out.ptr, C_NULL))
+    else
+        check(ccall((:mdsp_convnd_fft, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Int64}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}),
+                    ud.ptr, su, vd.ptr, sv, N, mdtype(W), out.ptr, C_NULL))
+    end
+    res = download(out)
+    T === W ? res : round.(T, res)                     # integer eltypes: exact in Float64 below 2^53
+end
+# rank promotion with trailing singleton dimensions   dspbase.jl:784-792
+function conv(A::AbstractArray{<:Number,M}, B::AbstractArray{<:Number,N}; kwargs...) where {M,N}
+    M < N ? conv(reshape(A, size(A)..., ntuple(_ -> 1, N - M)...), B; kwargs...) :
+            conv(A, reshape(B, size(B)..., ntuple(_ -> 1, M - N)...); kwargs...)
+end
+
 # ---------------------------------------------------------------------------------------------- periodograms
 compute_window(::Nothing, n::Int) = (nothing, Float64(n))                               # periodograms.jl:248-257
 function compute_window(window::Function, n::Int)
