@@ -55,6 +55,8 @@ win, norm2 = compute_window(d.hanning, 1024)
 K = d.frame_count(n, 1024, 768)
 for name, psd, outdt, bps in ((("stft", 0, torch.complex64, 40.0), ("spectrogram", 1, torch.float32, 24.0)) if nch else ()):
     for eng, ename in ((d.ENGINE_FUSED, "fused"), (d.ENGINE_ROCFFT, "rocfft")):
+        if os.environ.get("ROWS_ENGINE", ename) != ename:
+            continue
         plan = _StftPlan(1024, 768, 1024, win, 1.0 * norm2, False, psd, np.complex64, eng)
         out = torch.empty((nch, K, 1024), dtype=outdt, device="cuda")
         f = lambda: _lib.check(lib.mdsp_stft_exec(plan._h, s.data_ptr(), n, nch, n, out.data_ptr(), 1024, K * 1024, stream))
@@ -66,6 +68,8 @@ for name, psd, outdt, bps in ((("stft", 0, torch.complex64, 40.0), ("spectrogram
         del out, plan
 del s, z
 torch.cuda.empty_cache()
+if os.environ.get("ROWS_ONLY") == "stft":
+    sys.exit(0)
 
 # ---------------- config 5: polyphase resampler 160//147 ----------------
 nch, n = 4, 1 << (28 - scale)
