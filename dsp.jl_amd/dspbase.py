@@ -283,6 +283,8 @@ def conv_(out, u, v, algorithm: str = "auto"):
 def xcorr(u, v=None, padmode: str = "none", scaling: str = "none"):
     """dspbase.jl:867-898 (vectors)."""
     v = u if v is None else v
+    if len(u.shape) != 1 or len(v.shape) != 1:
+        raise TypeError("xcorr only supports vectors")       # MethodError in the reference (test/dsp.jl:347)
     su, sv = int(u.shape[0]), int(v.shape[0])
     if scaling == "biased" and su != sv:
         raise _lib.DimensionMismatch("scaling only valid for vectors of same length")

@@ -35,3 +35,20 @@ def promoted_case():
     a = np.stack([np.full((3, 3), n) for n in range(1, 7)], axis=2)
     b = np.ones((2, 2), dtype=np.int64)
     return a, b
+
+
+# test/dsp.jl:317-360 ("xcorr"): (u, v, keyword arguments, expected)
+XCORR = [
+    ([1, 2], [3, 4], {}, [4, 11, 6]),
+    ([1, 2, 3], [4, 5], {}, [5, 14, 23, 12]),
+    ([1, 2, 3], [4, 5], {"padmode": "longest"}, [0, 5, 14, 23, 12]),
+    ([1, 2, 3], [4, 5], {"padmode": "none"}, [5, 14, 23, 12]),
+    ([1, 2], [3, 4, 5], {}, [5, 14, 11, 6]),
+    ([1, 2], [3, 4, 5], {"padmode": "longest"}, [5, 14, 11, 6, 0]),
+    ([1.0j], [1.0j], {}, [1]),
+    (np.array([1, 2, 3]) * 1.0j, np.array([4, 5], dtype=np.complex128), {}, np.array([5, 14, 23, 12]) * 1j),
+    (np.array([1, 2]) * 1.0j, np.array([3, 4, 5], dtype=np.complex128), {}, np.array([5, 14, 11, 6]) * 1j),
+    (np.array([1, 2, 3], dtype=np.complex128), np.array([4, 5]) * 1.0j, {}, -np.array([5, 14, 23, 12]) * 1j),
+    (np.array([1, 2, 3]) * 1.0j, np.array([4, 5]) * 1.0j, {}, [5, 14, 23, 12]),
+    ([1, 2], [3, 4], {"scaling": "biased"}, [2.0, 5.5, 3.0]),
+]

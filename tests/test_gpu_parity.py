@@ -1100,3 +1100,31 @@ def test_array_convolution(d, torch):
     delta = np.zeros((3, 4), dtype=np.float32); delta[2, 1] = 1
     sh = d.conv(img, delta)
     assert relerr(sh[2:2 + 1500, 1:1 + 2000], img) < 2e-6 and np.abs(sh[:2]).max() < 1e-4
+
+
+def test_xcorr(d, torch):
+    """xcorr (dspbase.jl:867-898): the reference's literal answers (test/dsp.jl:317-360), its argument errors, and long random
+    vectors (overlap-save convolution underneath) against the oracle."""
+    import conv_cases as cc
+    from oracle import dspbase as odsp
+    for u, v, kw, exp in cc.XCORR:
+        got = d.xcorr(np.asarray(u), np.asarray(v), **kw)
+        assert np.shape(got) == np.shape(exp) and np.allclose(got, exp, atol=1e-12), (u, v, kw, got)
+    assert np.array_equal(d.xcorr(np.array([1, 2, 3]), np.array([4, 5])), [5, 14, 23, 12])          # integers stay exact integers
+    with pytest.raises(d.ArgumentError):
+        d.xcorr(np.array([1]), np.array([2]), padmode="bug")
+    with pytest.raises(d.DimensionMismatch):
+        d.xcorr(np.array([1]), np.array([2, 3]), scaling="biased")
+    with pytest.raises(TypeError):
+        d.xcorr(np.ones((2, 2)), np.ones((2, 2)))                                                   # MethodError: vectors only
+    rng = np.random.default_rng(21)
+    for T, tol in ((np.float32, 3e-6), (np.float64, 1e-12), (np.complex64, 3e-6), (np.complex128, 1e-12)):
+        u = rng.standard_normal(70001).astype(T); v = rng.standard_normal(513).astype(T)
+        if np.dtype(T).kind == "c":
+            u = (u + 1j * rng.standard_normal(len(u))).astype(T); v = (v + 1j * rng.standard_normal(len(v))).astype(T)
+        wide = np.complex128 if np.dtype(T).kind == "c" else np.float64
+        for kw in ({}, {"padmode": "longest"}):
+            ref = odsp.xcorr(u.astype(wide), v.astype(wide), **kw)
+            got = d.xcorr(u, v, **kw)
+            assert got.dtype == T and got.shape == ref.shape and relerr(got, ref) < tol, (T, kw, relerr(got, ref))
+        assert relerr(d.xcorr(u), odsp.xcorr(u.astype(wide))) < tol                                  # autocorrelation

@@ -448,3 +448,15 @@ def test_oracle_array_convolution_known_answers():
     rng = np.random.default_rng(0)
     u, v = rng.standard_normal((9, 14, 5)), rng.standard_normal((4, 3, 6))
     assert np.allclose(odsp.conv_nd(u, v, "direct"), odsp.conv_nd(u, v, "fft_simple"), rtol=1e-12, atol=1e-12)   # test/dsp.jl:169-171
+
+
+def test_oracle_xcorr_known_answers():
+    """oracle.dspbase.xcorr against test/dsp.jl:317-360."""
+    import conv_cases as cc
+    from oracle import dspbase as odsp
+    for u, v, kw, exp in cc.XCORR:
+        assert np.allclose(odsp.xcorr(np.asarray(u), np.asarray(v), **kw), exp, atol=1e-13), (u, v, kw)
+    with pytest.raises(ValueError):
+        odsp.xcorr(np.array([1]), np.array([2]), padmode="bug")
+    with pytest.raises(ValueError):
+        odsp.xcorr(np.array([1]), np.array([2, 3]), scaling="biased")
