@@ -11,6 +11,7 @@
 //
 // Arrays are column-major (first dimension fastest), as Julia stores them.
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -118,55 +119,94 @@ __global__ __launch_bounds__(256) void direct_nd_kernel(const T* __restrict__ bi
 
 dim3 grid_for(int64_t n) { return dim3((unsigned)std::min<int64_t>(cdiv(n, (int64_t)256), (int64_t)device_cu_count() * 32)); }
 
-int nd_plan(RocPlan& p, FftKind kind, bool dbl, const Dims& n, bool inplace) { return p.create_nd(kind, dbl, n.nd, n.d, inplace); }
+// Transforms and work buffers of the most recent padded sizes, per dtype: repeated convolutions of same-sized operands (image
+// batches, sliding kernels) pay plan creation and allocation once.  One entry per dtype, guarded by a mutex; a call holds
+// the lock for its duration (the buffers are shared state), so concurrent callers of one dtype serialise.
+struct ConvCache {
+    std::mutex mu;
+    Dims n{};
+    bool valid = false;
+    RocPlan fwd, inv;
+    DevBuf pad, a, b;
+    hipStream_t last = nullptr;   // stream of the previous call: a call on another stream waits for it before reusing the buffers
+    bool used = false;
+    int enter(hipStream_t st) {
+        if (used && last != st) MDSP_HIP(hipStreamSynchronize(last));
+        last = st;
+        used = true;
+        return MDSP_OK;
+    }
+};
+ConvCache& conv_cache(int dtype) {
+    static ConvCache c[4];
+    return c[dtype - MDSP_F32];
+}
+bool same_dims(const Dims& x, const Dims& y) {
+    if (x.nd != y.nd) return false;
+    for (int d = 0; d < x.nd; ++d)
+        if (x.d[d] != y.d[d]) return false;
+    return true;
+}
 
-template <typename R> int conv_fft_real(const R* u, const Dims& su, const R* v, const Dims& sv, R* out, const Dims& so, const Dims& n, hipStream_t st) {
+template <typename R> int conv_fft_real(int dtype, const R* u, const Dims& su, const R* v, const Dims& sv, R* out, const Dims& so, const Dims& n, hipStream_t st) {
     // out-of-place real transforms with rocFFT's default contiguous layouts: real (n0, n1, ..), Hermitian (n0/2 + 1, n1, ..)
     const int64_t h0 = n.d[0] / 2 + 1;
     int64_t rest = 1;
     for (int d = 1; d < n.nd; ++d) rest *= n.d[d];
     const int64_t nspec = h0 * rest, total = n.count();
-    DevBuf pad, a, b;
-    MDSP_TRY(pad.reserve(sizeof(R) * (size_t)total));
-    MDSP_TRY(a.reserve(sizeof(cx<R>) * (size_t)nspec));
-    MDSP_TRY(b.reserve(sizeof(cx<R>) * (size_t)nspec));
-    RocPlan fwd, inv;
-    MDSP_TRY(nd_plan(fwd, FftKind::R2C, sizeof(R) == 8, n, false));
-    MDSP_TRY(nd_plan(inv, FftKind::C2R, sizeof(R) == 8, n, false));
-    hipLaunchKernelGGL(pad_nd_kernel<R>, grid_for(total), dim3(256), 0, st, u, su, pad.as<R>(), n, n.d[0]);
+    ConvCache& c = conv_cache(dtype);
+    std::lock_guard<std::mutex> lk(c.mu);
+    MDSP_TRY(c.enter(st));
+    if (!c.valid || !same_dims(c.n, n)) {
+        c.valid = false;
+        MDSP_HIP(hipStreamSynchronize(st));   // a previous call on this stream may still use the buffers about to be replaced
+        MDSP_TRY(c.pad.reserve(sizeof(R) * (size_t)total));
+        MDSP_TRY(c.a.reserve(sizeof(cx<R>) * (size_t)nspec));
+        MDSP_TRY(c.b.reserve(sizeof(cx<R>) * (size_t)nspec));
+        MDSP_TRY(c.fwd.create_nd(FftKind::R2C, sizeof(R) == 8, n.nd, n.d, false));
+        MDSP_TRY(c.inv.create_nd(FftKind::C2R, sizeof(R) == 8, n.nd, n.d, false));
+        c.n = n;
+        c.valid = true;
+    }
+    hipLaunchKernelGGL(pad_nd_kernel<R>, grid_for(total), dim3(256), 0, st, u, su, c.pad.as<R>(), n, n.d[0]);
     MDSP_LAUNCH_CHECK();
-    MDSP_TRY(fwd.exec(pad.p, a.p, st));
-    hipLaunchKernelGGL(pad_nd_kernel<R>, grid_for(total), dim3(256), 0, st, v, sv, pad.as<R>(), n, n.d[0]);
+    MDSP_TRY(c.fwd.exec(c.pad.p, c.a.p, st));
+    hipLaunchKernelGGL(pad_nd_kernel<R>, grid_for(total), dim3(256), 0, st, v, sv, c.pad.as<R>(), n, n.d[0]);
     MDSP_LAUNCH_CHECK();
-    MDSP_TRY(fwd.exec(pad.p, b.p, st));
-    hipLaunchKernelGGL(spectrum_product_kernel<R>, grid_for(nspec), dim3(256), 0, st, a.as<cx<R>>(), b.as<cx<R>>(), nspec, (R)(1.0 / (double)total));
+    MDSP_TRY(c.fwd.exec(c.pad.p, c.b.p, st));
+    hipLaunchKernelGGL(spectrum_product_kernel<R>, grid_for(nspec), dim3(256), 0, st, c.a.as<cx<R>>(), c.b.as<cx<R>>(), nspec, (R)(1.0 / (double)total));
     MDSP_LAUNCH_CHECK();
-    MDSP_TRY(inv.exec(a.p, pad.p, st));
-    hipLaunchKernelGGL(crop_nd_kernel<R>, grid_for(so.count()), dim3(256), 0, st, pad.as<R>(), n, n.d[0], out, so);
+    MDSP_TRY(c.inv.exec(c.a.p, c.pad.p, st));
+    hipLaunchKernelGGL(crop_nd_kernel<R>, grid_for(so.count()), dim3(256), 0, st, c.pad.as<R>(), n, n.d[0], out, so);
     MDSP_LAUNCH_CHECK();
-    MDSP_HIP(hipStreamSynchronize(st));   // the work buffers die with this frame
-    return MDSP_OK;
+    return MDSP_OK;   // stream-ordered: the cached buffers are only reused by later launches on a stream the next call synchronises with
 }
 
-template <typename R> int conv_fft_complex(const cx<R>* u, const Dims& su, const cx<R>* v, const Dims& sv, cx<R>* out, const Dims& so, const Dims& n, hipStream_t st) {
+template <typename R> int conv_fft_complex(int dtype, const cx<R>* u, const Dims& su, const cx<R>* v, const Dims& sv, cx<R>* out, const Dims& so, const Dims& n, hipStream_t st) {
     const int64_t total = n.count();
-    DevBuf a, b;
-    MDSP_TRY(a.reserve(sizeof(cx<R>) * (size_t)total));
-    MDSP_TRY(b.reserve(sizeof(cx<R>) * (size_t)total));
-    RocPlan fwd, inv;
-    MDSP_TRY(nd_plan(fwd, FftKind::C2C_FWD, sizeof(R) == 8, n, true));
-    MDSP_TRY(nd_plan(inv, FftKind::C2C_INV, sizeof(R) == 8, n, true));
-    hipLaunchKernelGGL(pad_nd_kernel<cx<R>>, grid_for(total), dim3(256), 0, st, u, su, a.as<cx<R>>(), n, n.d[0]);
-    hipLaunchKernelGGL(pad_nd_kernel<cx<R>>, grid_for(total), dim3(256), 0, st, v, sv, b.as<cx<R>>(), n, n.d[0]);
+    ConvCache& c = conv_cache(dtype);
+    std::lock_guard<std::mutex> lk(c.mu);
+    MDSP_TRY(c.enter(st));
+    if (!c.valid || !same_dims(c.n, n)) {
+        c.valid = false;
+        MDSP_HIP(hipStreamSynchronize(st));
+        MDSP_TRY(c.a.reserve(sizeof(cx<R>) * (size_t)total));
+        MDSP_TRY(c.b.reserve(sizeof(cx<R>) * (size_t)total));
+        MDSP_TRY(c.fwd.create_nd(FftKind::C2C_FWD, sizeof(R) == 8, n.nd, n.d, true));
+        MDSP_TRY(c.inv.create_nd(FftKind::C2C_INV, sizeof(R) == 8, n.nd, n.d, true));
+        c.n = n;
+        c.valid = true;
+    }
+    hipLaunchKernelGGL(pad_nd_kernel<cx<R>>, grid_for(total), dim3(256), 0, st, u, su, c.a.as<cx<R>>(), n, n.d[0]);
+    hipLaunchKernelGGL(pad_nd_kernel<cx<R>>, grid_for(total), dim3(256), 0, st, v, sv, c.b.as<cx<R>>(), n, n.d[0]);
     MDSP_LAUNCH_CHECK();
-    MDSP_TRY(fwd.exec(a.p, a.p, st));
-    MDSP_TRY(fwd.exec(b.p, b.p, st));
-    hipLaunchKernelGGL(spectrum_product_kernel<R>, grid_for(total), dim3(256), 0, st, a.as<cx<R>>(), b.as<cx<R>>(), total, (R)(1.0 / (double)total));
+    MDSP_TRY(c.fwd.exec(c.a.p, c.a.p, st));
+    MDSP_TRY(c.fwd.exec(c.b.p, c.b.p, st));
+    hipLaunchKernelGGL(spectrum_product_kernel<R>, grid_for(total), dim3(256), 0, st, c.a.as<cx<R>>(), c.b.as<cx<R>>(), total, (R)(1.0 / (double)total));
     MDSP_LAUNCH_CHECK();
-    MDSP_TRY(inv.exec(a.p, a.p, st));
-    hipLaunchKernelGGL(crop_nd_kernel<cx<R>>, grid_for(so.count()), dim3(256), 0, st, a.as<cx<R>>(), n, n.d[0], out, so);
+    MDSP_TRY(c.inv.exec(c.a.p, c.a.p, st));
+    hipLaunchKernelGGL(crop_nd_kernel<cx<R>>, grid_for(so.count()), dim3(256), 0, st, c.a.as<cx<R>>(), n, n.d[0], out, so);
     MDSP_LAUNCH_CHECK();
-    MDSP_HIP(hipStreamSynchronize(st));
     return MDSP_OK;
 }
 
@@ -211,10 +251,10 @@ int mdsp_convnd_fft(const void* u_dev, const int64_t* su, const void* v_dev, con
     MDSP_TRY(rocfft_ensure_setup());
     hipStream_t st = as_stream(stream);
     switch (dtype) {
-        case MDSP_F32: return conv_fft_real<float>((const float*)u_dev, uc, (const float*)v_dev, vc, (float*)out_dev, oc, n, st);
-        case MDSP_F64: return conv_fft_real<double>((const double*)u_dev, uc, (const double*)v_dev, vc, (double*)out_dev, oc, n, st);
-        case MDSP_C32: return conv_fft_complex<float>((const cx<float>*)u_dev, uc, (const cx<float>*)v_dev, vc, (cx<float>*)out_dev, oc, n, st);
-        default: return conv_fft_complex<double>((const cx<double>*)u_dev, uc, (const cx<double>*)v_dev, vc, (cx<double>*)out_dev, oc, n, st);
+        case MDSP_F32: return conv_fft_real<float>(dtype, (const float*)u_dev, uc, (const float*)v_dev, vc, (float*)out_dev, oc, n, st);
+        case MDSP_F64: return conv_fft_real<double>(dtype, (const double*)u_dev, uc, (const double*)v_dev, vc, (double*)out_dev, oc, n, st);
+        case MDSP_C32: return conv_fft_complex<float>(dtype, (const cx<float>*)u_dev, uc, (const cx<float>*)v_dev, vc, (cx<float>*)out_dev, oc, n, st);
+        default: return conv_fft_complex<double>(dtype, (const cx<double>*)u_dev, uc, (const cx<double>*)v_dev, vc, (cx<double>*)out_dev, oc, n, st);
     }
 }
 

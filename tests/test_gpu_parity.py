@@ -877,6 +877,30 @@ def test_streams_beyond_2_32_samples(d, torch):
     m = 2 ** 31 + 1001
     z = d.resample(x[:m], Fraction(3, 2), d.resample_filter(Fraction(3, 2)).astype(np.float32))
     assert z.shape[0] == math.ceil(m * Fraction(3, 2))
+    del z
+    # FIRArbitrary with more than 2^32 OUTPUTS: the device's parallel trajectory scan (134 M anchor blocks, four scan levels)
+    # against the serial recurrence for the count and the final state; one-shot against two-chunk streaming for the samples
+    import ctypes as C
+    from dsp_jl_amd import _lib
+    rate = 2.0003
+    h = d.resample_filter(rate, 32).astype(np.float32)
+    f = d.FIRFilter(h, rate)
+    y1 = f.filt(x[:m])
+    assert y1.shape[0] > 2 ** 32
+    nout, dend, aend = C.c_int64(), C.c_int64(), C.c_double()
+    _lib.check(_lib.lib().mdsp_arb_trajectory(0.0, 1, rate, 32, m, 32, None, None, 0, C.byref(nout), C.byref(aend), C.byref(dend)))
+    assert (y1.shape[0], f.phi_accumulator, f.input_deficit) == (nout.value, aend.value, dend.value)
+    sc, se = C.c_int64(), C.c_int64()
+    _lib.check(_lib.lib().mdsp_firarb_scan_stats(f._handle, C.byref(sc), C.byref(se)))
+    assert (sc.value, se.value) == (1, 0)
+    tail = y1[-(2 ** 20):].clone()
+    del y1
+    g2 = d.FIRFilter(h, rate)
+    cut = 2 ** 30 + 12345
+    na = g2.filt(x[:cut]).shape[0]
+    yb = g2.filt(x[cut:m])
+    assert na + yb.shape[0] == nout.value and (g2.phi_accumulator, g2.input_deficit) == (aend.value, dend.value)
+    assert torch.equal(yb[-(2 ** 20):], tail)
 
 
 # ============================================================================================ multitaper
