@@ -114,6 +114,7 @@ PROTOTYPES = {
     "mdsp_arb_trajectory": (ci, [cd, i64, cd, i64, i64, i64, pi64, pdbl, i64, pi64, pdbl, pi64]),
     "mdsp_arb_trajectory_scan": (ci, [cd, i64, cd, i64, i64, i64, pi64, pdbl, i64, pi64, pdbl, pi64, pint, pint]),
     "mdsp_firarb_scan_stats": (ci, [vp, pi64, pi64]),
+    "mdsp_arb_replay_check": (ci, [cd, cd, i64, i64, pi64]),
     "mdsp_convnd_fft": (ci, [vp, pi64, vp, pi64, ci, ci, vp, vp]),
     "mdsp_convnd_direct": (ci, [vp, pi64, vp, pi64, ci, ci, vp, vp]),
     "mdsp_tdfir_exec": (ci, [vp, i64, ci, vp, i64, i64, i64, vp, i64, vp]),

@@ -46,7 +46,8 @@
 namespace mdsp {
 namespace arbscan {
 
-constexpr int BLK = 32;        // updates per block = outputs per anchor (ARB_BLK in fir.hip)
+constexpr int BLK = 32;        // updates per scan block
+constexpr int ANCH = 16;       // outputs per anchor (ARB_BLK in fir.hip): two anchors per block, the second from finalize's own replay
 constexpr int RMAX = 16;       // table entries: residues of E modulo 2^(J+1), J <= 3
 constexpr int FAN = 64;        // tables composed per thread in one scan level
 
@@ -216,10 +217,10 @@ struct ScanArgs {
     uint32_t* mind;            // clamped threshold distance of the block's candidates
     int64_t* cb;               // offset the block's candidates were built around
     int64_t* E;                // in (pass 1): E of the previous scan; out: E at the block start
-    uint64_t* baseA;           // unrounded state at the block start (aliases the anchor tables until finalize)
+    uint64_t* baseA;           // unrounded state at the block start, at [2 b] (aliases the block's first anchor slot until finalize)
     int64_t* baseW;
     // finalize
-    int64_t* tab_x;            // anchors, indexed by k / BLK
+    int64_t* tab_x;            // anchors, indexed by k / ANCH
     double* tab_acc;
     int64_t* result;           // [0] status bits (1: ambiguous block, 2: end found), [1] nout, [2] xIdx_end, [3] bits of phi_acc_end
 };
@@ -230,8 +231,8 @@ MDSP_HD void scan_tables_body(const ScanArgs& a, int64_t b) {
     uint64_t A0;
     int64_t W0;
     base_at(G, a.As, (uint64_t)b * BLK, A0, W0);
-    a.baseA[b] = A0;
-    a.baseW[b] = W0;
+    a.baseA[2 * b] = A0;
+    a.baseW[2 * b] = W0;
     const int64_t c = a.pass == 0 ? predicted_offset(G, a.sigma, b * BLK) : round_offset(G, a.E[b]);
     a.cb[b] = c;
     uint64_t Ac[RMAX], Ab = add_mod(G, A0, c);
@@ -294,7 +295,7 @@ MDSP_HD void scan_finalize_body(const ScanArgs& a, int64_t b) {
     // block of a second pass whose first pass was right)
     if (!(dE >= 0 && dE < G.R) && (uint64_t)a.mind[b] <= margin) status |= 1;
     // exact position: unrounded + E  (may wrap: E is not small compared with the distance to the wrap point)
-    int64_t v = (int64_t)a.baseA[b] + E, W = a.baseW[b];
+    int64_t v = (int64_t)a.baseA[2 * b] + E, W = a.baseW[2 * b];
     const int64_t n = (int64_t)G.N;
     while (v >= n) {
         v -= n;
@@ -307,13 +308,17 @@ MDSP_HD void scan_finalize_body(const ScanArgs& a, int64_t b) {
     uint64_t A = (uint64_t)v;
     const int64_t kb = a.k0 + b * BLK;
     int64_t xi = a.xs + W;
-    a.tab_x[kb / BLK] = xi;
-    a.tab_acc[kb / BLK] = from_grid(G, A);
+    a.tab_x[kb / ANCH] = xi;
+    a.tab_acc[kb / ANCH] = from_grid(G, A);
     if (xi <= a.xlen) {
         for (int i = 1; i <= BLK; ++i) {
             int64_t Wn = 0;
             step(G, A, Wn);
             xi += Wn;
+            if (i == ANCH) {   // the block's second anchor (state of output kb + ANCH); harmless if that output does not exist
+                a.tab_x[kb / ANCH + 1] = xi;
+                a.tab_acc[kb / ANCH + 1] = from_grid(G, A);
+            }
             if (xi > a.xlen) {
                 status |= 2;
                 a.result[1] = kb + i;

@@ -16,6 +16,7 @@
 // pfbT[i][phi] lives in LDS as well (phase index contiguous: lanes advance by M mod L phases per output, which
 // spreads them over the banks), and every output is a tp-term fused multiply-add chain, oldest sample first.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -254,10 +255,24 @@ int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 // all threads evaluate   y = muladd(yUpper, alpha, yLower)   (:616) with yLower/yUpper the two tapsPerPhase-term
 // chains (oldest sample first) over the input span staged in LDS.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int ARB_BLK = 32;   // outputs per host anchor (16 bytes of anchor per block: 0.5 B of extra traffic per output)
+constexpr int ARB_BLK = 16;   // outputs per anchor (16 bytes each: 1 B of extra traffic per output); one lane of wave 0 replays one block
 
 struct ArbStep {              // one update! (stream_filt.jl:567-577), shared by host and device
     double delta, nphi, inv_nphi;
+    double c1, c2;            // qd nphi and (qd + 1) nphi, qd = floor(delta / nphi): the only two quotients an update can produce
+    int64_t qd;
+    static ArbStep make(double delta, double nphi) {
+        ArbStep s{};
+        s.delta = delta;
+        s.nphi = nphi;
+        s.inv_nphi = 1.0 / nphi;
+        const double rd = std::fmod(delta, nphi);   // exact
+        s.qd = (int64_t)((delta - rd) / nphi);       // exact: delta - rd is a multiple of nphi
+        s.c1 = (double)s.qd * nphi;
+        s.c2 = (double)(s.qd + 1) * nphi;
+        return s;
+    }
+    // The reference's form, operation by operation.
     __host__ __device__ inline void operator()(double& acc, int64_t& xidx) const {
         acc = acc + delta;
         if (acc >= nphi) {
@@ -282,6 +297,15 @@ struct ArbStep {              // one update! (stream_filt.jl:567-577), shared by
             acc = r;
         }
     }
+    // Branch-free equivalent for the device replay.  s = fl(acc + delta) lies in [delta, nphi + delta], so the quotient of
+    // divrem(s, nphi) is qd or qd + 1 (none when qd = 0 and s < nphi); for a quotient q >= 1, q nphi <= s < (q + 1) nphi <= 2 q nphi
+    // makes s - q nphi exact (Sterbenz) -- the exact remainder divrem returns.  Valid while qd nphi < 2^53.
+    __host__ __device__ inline void fast(double& acc, int64_t& xidx) const {
+        const double s = acc + delta;
+        const bool big = s >= c2;
+        acc = s - (big ? c2 : c1);
+        xidx += qd + (big ? 1 : 0);
+    }
 };
 
 struct ArbArgs {
@@ -297,6 +321,7 @@ struct ArbArgs {
     int tile;             // outputs per workgroup (multiple of ARB_BLK)
     int span;             // staged samples per tile (0: read [history ; x] straight from global/L2)
     int taps_in_lds;
+    long long* prof;      // profiling only (MDSP_ARB_PROF): 8 clock64() stamps per workgroup
     int ablate;           // profiling only (MDSP_ABLATE): 1 no phase-A replay, 2 one tap instead of tp, 4 no staging loads, 8 no tap copy
 };
 
@@ -375,9 +400,14 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
     if (m0 >= a.nout) return;
     const int cnt = (int)std::min<int64_t>(a.tile, a.nout - m0);
     const int64_t b0 = m0 / ARB_BLK;
+    const int tid = threadIdx.x;
+    auto stamp = [&](int k) {
+        if (a.prof && tid == 0) a.prof[(int64_t)blockIdx.x * 8 + k] = clock64();
+    };
+    stamp(0);
     const int64_t x_first = a.tab_x[b0];
     const int64_t z_first = x_first - 1;                                    // z = [history ; x], output n reads z[n-1 .. n-1+tp)
-    const int tid = threadIdx.x;
+    if (a.prof && tid == 0) a.prof[(int64_t)blockIdx.x * 8 + 1] = clock64() + (x_first & 0);
     auto zload = [&](int64_t ch, int64_t zi) -> A {   // branch-free: the loads of a staging batch all issue before the first wait
         const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
         const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
@@ -423,9 +453,10 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
             for (int k = 0; k < n; ++k) {
                 const double fl = floor(acc);
                 rec[arb_rec_slot(base + k)] = {(int)(xi - x_first), (int)fl, acc - fl};   // alpha = modf(acc)[1] is exact
-                if (!(a.ablate & 1)) a.step(acc, xi);
+                if (!(a.ablate & 1)) a.step.fast(acc, xi);
             }
         }
+        stamp(2);
     } else {
         const int lanes = (int)blockDim.x - 64, u = tid - 64;
         if (a.taps_in_lds && !(a.ablate & 8)) {
@@ -443,6 +474,7 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
         if (a.span > 0 && c_first < a.nch && !(a.ablate & 4)) stage(c_first, (int)std::min<int64_t>(NCH, a.nch - c_first), u, lanes, a.span);
     }
     __syncthreads();
+    stamp(3);
     const int64_t nz = (int64_t)rec[arb_rec_slot(cnt - 1)].xrel + a.tp;
     const bool staged = nz <= a.span;                                       // workgroup-uniform
     for (int64_t c0 = c_first; c0 < a.nch; c0 += (int64_t)gridDim.y * NCH) {
@@ -459,6 +491,7 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
             const int tpe = (a.ablate & 2) ? 1 : a.tp;
             if (a.taps_in_lds) arb_tile_staged<A, R, NCH>(rec, ps, zs, yc, nc, cnt, tpe, a.nphi);
             else arb_tile_staged<A, R, NCH>(rec, pg, zs, yc, nc, cnt, tpe, a.nphi);
+            stamp(4);
         } else {
             const Tap2<R>* pf = a.taps_in_lds ? ps : pg;
             for (int c = 0; c < nc; ++c) {
@@ -481,6 +514,145 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
                 }
             }
         }
+    }
+    __syncthreads();
+    stamp(5);
+}
+
+// Persistent, software-pipelined form of the kernel above for the common case (tap pairs in LDS, a tile's input span of at most
+// PIPE_RB * 256 samples): a workgroup walks tiles blockIdx.x, + gridDim.x, ... of ONE channel group (blockIdx.y) and, while it
+// evaluates tile i, (a) holds tile i+1's samples in flight from HBM in registers, written to the other LDS buffer after the
+// compute, (b) has wave 0 replay tile i+1's trajectory into the other record buffer first, and (c) loads the anchors of tile
+// i+2.  One barrier per tile; no global-memory latency on the critical path after the first tile.
+constexpr int PIPE_RB = 6;
+
+template <typename XS, typename A, typename R, int NCH>
+__global__ __launch_bounds__(256) void arbitrary_fir_pipe_kernel(ArbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int rec_bytes = arb_rec_slot(a.tile) * (int)sizeof(ArbRec), zs_bytes = a.span * NCH * (int)sizeof(A);
+    // buffer b of the records / samples (plain offsets from the LDS base, so every access stays a DS instruction)
+    auto rec_buf = [&](int b) { return reinterpret_cast<ArbRec*>(smem + b * rec_bytes); };
+    auto zs_buf = [&](int b) { return reinterpret_cast<A*>(smem + 2 * rec_bytes + b * zs_bytes); };
+    Tap2<R>* ps = reinterpret_cast<Tap2<R>*>(smem + 2 * rec_bytes + 2 * zs_bytes);
+    const int tid = threadIdx.x;
+    const int64_t ntile = (a.nout + a.tile - 1) / a.tile;
+    const int64_t c0 = (int64_t)blockIdx.y * NCH;
+    const int nc = (int)std::min<int64_t>(NCH, a.nch - c0);
+    const int bpt = a.tile / ARB_BLK;   // anchor blocks per tile
+    // the span of one tile: PIPE_RB * NCH independent loads per thread, RAW values (clamped addresses); validity and conversion
+    // are applied when the values are written to LDS, after the compute -- nothing may consume them earlier
+    auto issue = [&](XS (&v)[PIPE_RB][NCH], int64_t z_first) {
+#pragma unroll
+        for (int r = 0; r < PIPE_RB; ++r) {
+            const int k = tid + r * 256;
+            const int64_t zi = z_first + (k < a.span ? k : a.span - 1);
+            const int64_t xi = zi - a.hl;
+            const bool in_hist = zi < a.hl;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int64_t ch = c0 + (c < nc ? c : 0);
+                const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
+                const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
+                v[r][c] = *(in_hist ? hc + zi : xc + (xi < a.xlen ? xi : 0));
+            }
+        }
+    };
+    auto commit = [&](const XS (&v)[PIPE_RB][NCH], int64_t z_first, A* zs) {
+#pragma unroll
+        for (int r = 0; r < PIPE_RB; ++r) {
+            const int k = tid + r * 256;
+            if (k < a.span) {
+                const int64_t zi = z_first + k;
+                const bool ok = zi < a.hl || zi - a.hl < a.xlen;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) zs[k * NCH + c] = (ok && c < nc) ? to_acc(v[r][c], (A*)nullptr) : A{};
+            }
+        }
+    };
+    auto tile_count = [&](int64_t t) { return (int)std::min<int64_t>(a.tile, a.nout - t * a.tile); };
+    // wave 0, lane l: replay anchor block l of tile t from (xi, acc) into rec
+    auto replay = [&](ArbRec* rec, int64_t t, int64_t x_first, int64_t xi, double acc) {
+        const int cnt = tile_count(t), base = tid * ARB_BLK;
+        if (base < cnt) {
+            const int n = min(ARB_BLK, cnt - base);
+            for (int k = 0; k < n; ++k) {
+                const double fl = floor(acc);
+                rec[arb_rec_slot(base + k)] = {(int)(xi - x_first), (int)fl, acc - fl};
+                a.step.fast(acc, xi);
+            }
+        }
+    };
+    // ---- prologue: taps, tile t0 in full, anchors of tile t0 + stride -------------------------------------------------------
+    const int64_t stride = gridDim.x;
+    int64_t t = blockIdx.x;
+    if (t >= ntile) return;
+    {
+        const Tap2<R>* pg = static_cast<const Tap2<R>*>(a.taps2);
+        const int np = a.tp * a.nphi;
+        for (int k = tid; k < np; k += 256) ps[k] = pg[k];
+    }
+    int64_t xf_cur = a.tab_x[t * bpt];
+    int64_t xf_next = t + stride < ntile ? a.tab_x[(t + stride) * bpt] : 0;
+    int64_t anx = 0;
+    double ana = 0.0;
+    {
+        XS v[PIPE_RB][NCH];
+        issue(v, xf_cur - 1);
+        if (tid < 64) {
+            const bool live = tid * ARB_BLK < tile_count(t);
+            const int64_t xi = live ? a.tab_x[t * bpt + tid] : 0;
+            const double acc = live ? a.tab_acc[t * bpt + tid] : 0.0;
+            if (t + stride < ntile && tid * ARB_BLK < tile_count(t + stride)) {
+                anx = a.tab_x[(t + stride) * bpt + tid];
+                ana = a.tab_acc[(t + stride) * bpt + tid];
+            }
+            replay(rec_buf(0), t, xf_cur, xi, acc);
+        }
+        commit(v, xf_cur - 1, zs_buf(0));
+    }
+    __syncthreads();
+    // ---- steady state ---------------------------------------------------------------------------------------------------
+    for (int i = 0; t < ntile; ++i, t += stride) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        const int64_t tn = t + stride, tnn = tn + stride;
+        const bool have_next = tn < ntile;
+        XS v[PIPE_RB][NCH];
+        int64_t xf_nn = 0;
+        if (have_next) {
+            // order matters for s_waitcnt (counters retire in order): the anchor loads of the tile after next go first, so the
+            // copy into the loop-carried registers below waits for them only, not for the sample loads issued after them
+            int64_t xi = 0, anx_new = 0;
+            double acc = 0.0, ana_new = 0.0;
+            if (tid < 64) {
+                xi = anx;
+                acc = ana;
+                if (tnn < ntile && tid * ARB_BLK < tile_count(tnn)) {   // consumed one iteration later
+                    anx_new = a.tab_x[tnn * bpt + tid];
+                    ana_new = a.tab_acc[tnn * bpt + tid];
+                }
+            }
+            if (tnn < ntile) xf_nn = a.tab_x[tnn * bpt];
+            __builtin_amdgcn_sched_barrier(0);
+            issue(v, xf_next - 1);
+            if (tid < 64) {
+                replay(rec_buf(nxt), tn, xf_next, xi, acc);
+                anx = anx_new;
+                ana = ana_new;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the loads above stay in flight across the compute below
+        {
+            const int cnt = tile_count(t);
+            A* yc[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) yc[c] = static_cast<A*>(a.y) + (c0 + (c < nc ? c : 0)) * a.ldy + t * a.tile;
+            arb_tile_staged<A, R, NCH>(rec_buf(cur), ps, zs_buf(cur), yc, nc, cnt, a.tp, a.nphi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (have_next) commit(v, xf_next - 1, zs_buf(nxt));
+        xf_cur = xf_next;
+        xf_next = xf_nn;
+        __syncthreads();
     }
 }
 
@@ -588,6 +760,7 @@ struct mdsp_firarb_s {
     double phi_acc = 0.0;
     int64_t input_deficit = 1, x_idx = 1;
     DevBuf tab_x, tab_acc;
+    DevBuf prof;   // MDSP_ARB_PROF: per-workgroup clock stamps of the filtering kernel
     DevBuf scan_t0, scan_wide, scan_E, scan_mind, scan_cb, scan_res;   // work space of the parallel trajectory scan (arb_scan.h)
     // trajectory cache: anchors of the last (phi_acc, input_deficit, xlen) evaluated
     bool cache_valid = false;
@@ -951,7 +1124,7 @@ void arb_trajectory(double acc, int64_t deficit, const ArbStep& st, int64_t xlen
 }
 
 // ---- parallel trajectory scan (arb_scan.h): kernels and drivers ------------------------------------------------
-static_assert(arbscan::BLK == ARB_BLK, "the scan's block is the anchor block");
+static_assert(arbscan::ANCH == ARB_BLK && arbscan::BLK == 2 * ARB_BLK, "two anchors per scan block");
 
 __global__ __launch_bounds__(256) void arb_scan_tables_kernel(arbscan::ScanArgs a) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1049,15 +1222,15 @@ bool scan_setup(double acc, int64_t deficit, const ArbStep& st, int64_t nphi, in
     if (!make_grid(st.delta, nphi, S.G)) return false;
     int64_t n = 0, xe = 0;
     double ae = 0.0;
-    arb_trajectory(acc, deficit, st, xlen, BLK, &S.ax, &S.aa, &n, &ae, &xe, pilot);
+    arb_trajectory(acc, deficit, st, xlen, ANCH, &S.ax, &S.aa, &n, &ae, &xe, pilot);
     if (n < pilot || xe > xlen) return false;   // the stream ends inside the pilot
     if (!to_grid(S.G, ae, S.As)) return false;
     S.xs = xe;
     S.k0 = pilot;
     // drift slope over outputs BLK .. pilot (both on the grid):  E = U(pilot) - U(BLK) - (pilot - BLK) D
     uint64_t A1 = 0;
-    if (!to_grid(S.G, S.aa[1], A1)) return false;
-    const __int128 U1 = (__int128)A1 + (__int128)S.G.N * S.ax[1], U0 = (__int128)S.As + (__int128)S.G.N * xe;
+    if (!to_grid(S.G, S.aa[BLK / ANCH], A1)) return false;
+    const __int128 U1 = (__int128)A1 + (__int128)S.G.N * S.ax[BLK / ANCH], U0 = (__int128)S.As + (__int128)S.G.N * xe;
     const __int128 E = U0 - U1 - (__int128)(pilot - BLK) * (__int128)S.G.D;
     S.sigma = (double)E / (double)(pilot - BLK);
     // outputs that can follow output k0: xIdx first exceeds xlen after about ((xlen + 1 - xs) N - As) / D updates; two spare blocks
@@ -1076,7 +1249,7 @@ bool arb_scan_host(double acc, int64_t deficit, const ArbStep& st, int64_t nphi,
     ScanSetup S;
     if (!scan_setup(acc, deficit, st, nphi, xlen, pilot, S)) return false;
     const ScanLayout L = scan_layout(S.nb, S.G.R);
-    const int64_t nanch = S.k0 / BLK + S.nb;
+    const int64_t nanch = S.k0 / ANCH + 2 * S.nb;
     ax = S.ax;
     aa = S.aa;
     ax.resize((size_t)nanch);
@@ -1096,8 +1269,8 @@ bool arb_scan_host(double acc, int64_t deficit, const ArbStep& st, int64_t nphi,
     a.mind = mind.data();
     a.cb = cb.data();
     a.E = Eall.data() + L.eoff[0];
-    a.baseA = reinterpret_cast<uint64_t*>(aa.data() + S.k0 / BLK);
-    a.baseW = ax.data() + S.k0 / BLK;
+    a.baseA = reinterpret_cast<uint64_t*>(aa.data() + S.k0 / ANCH);
+    a.baseW = ax.data() + S.k0 / ANCH;
     a.tab_x = ax.data();
     a.tab_acc = aa.data();
     a.result = res.data();
@@ -1112,7 +1285,7 @@ bool arb_scan_host(double acc, int64_t deficit, const ArbStep& st, int64_t nphi,
     *nout = res[1];
     *xidx_end = res[2];
     std::memcpy(acc_end, &res[3], 8);
-    ax.resize((size_t)cdiv(*nout, (int64_t)BLK));
+    ax.resize((size_t)cdiv(*nout, (int64_t)ANCH));
     aa.resize(ax.size());
     return true;
 }
@@ -1126,7 +1299,7 @@ int arb_scan_device(mdsp_firarb_s* f, const ArbStep& step, int64_t xlen, int64_t
     ScanSetup S;
     if (!scan_setup(f->phi_acc, f->input_deficit, step, f->nphi, xlen, pilot, S)) return MDSP_OK;
     const ScanLayout L = scan_layout(S.nb, S.G.R);
-    const int64_t nanch = S.k0 / BLK + S.nb;
+    const int64_t nanch = S.k0 / ANCH + 2 * S.nb;
     MDSP_TRY(f->tab_x.reserve(sizeof(int64_t) * (size_t)nanch));
     MDSP_TRY(f->tab_acc.reserve(sizeof(double) * (size_t)nanch));
     MDSP_TRY(f->scan_t0.reserve(sizeof(int32_t) * (size_t)S.nb * S.G.R));
@@ -1150,8 +1323,8 @@ int arb_scan_device(mdsp_firarb_s* f, const ArbStep& step, int64_t xlen, int64_t
     a.mind = f->scan_mind.as<uint32_t>();
     a.cb = f->scan_cb.as<int64_t>();
     a.E = f->scan_E.as<int64_t>() + L.eoff[0];
-    a.baseA = reinterpret_cast<uint64_t*>(f->tab_acc.as<double>() + S.k0 / BLK);
-    a.baseW = f->tab_x.as<int64_t>() + S.k0 / BLK;
+    a.baseA = reinterpret_cast<uint64_t*>(f->tab_acc.as<double>() + S.k0 / ANCH);
+    a.baseW = f->tab_x.as<int64_t>() + S.k0 / ANCH;
     a.tab_x = f->tab_x.as<int64_t>();
     a.tab_acc = f->tab_acc.as<double>();
     a.result = f->scan_res.as<int64_t>();
@@ -1185,7 +1358,44 @@ template <typename XS, typename A, typename R, int NCH> int arb_launch_n(mdsp_fi
     const int64_t groups = cdiv(f->base.nch, NCH);
     const unsigned gy = (unsigned)std::min<int64_t>(groups, std::max<int64_t>(1, cdiv((int64_t)device_cu_count() * 8, tiles)));
     const dim3 grid((unsigned)tiles, gy);
+    const bool prof = getenv("MDSP_ARB_PROF") != nullptr && gy == 1;
+    if (prof) {
+        MDSP_TRY(f->prof.reserve(sizeof(long long) * 8 * (size_t)tiles));
+        MDSP_HIP(hipMemsetAsync(f->prof.p, 0, sizeof(long long) * 8 * (size_t)tiles, st));
+        a.prof = f->prof.as<long long>();
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+    MDSP_LAUNCH_CHECK();
+    if (prof) {   // phase durations (shader clocks) averaged over the workgroups of the middle half of the launch
+        std::vector<long long> h((size_t)tiles * 8);
+        MDSP_HIP(hipStreamSynchronize(st));
+        MDSP_HIP(hipMemcpy(h.data(), f->prof.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        double sum[5] = {0, 0, 0, 0, 0};
+        int64_t n = 0;
+        long long tmin = LLONG_MAX, tmax = 0;
+        for (int64_t t = 0; t < tiles; ++t) {
+            tmin = std::min(tmin, h[t * 8]);
+            tmax = std::max(tmax, h[t * 8 + 5]);
+        }
+        for (int64_t t = tiles / 4; t < tiles * 3 / 4; ++t, ++n)
+            for (int k = 0; k < 5; ++k) sum[k] += (double)(h[t * 8 + k + 1] - h[t * 8 + (k == 2 ? 1 : k)]);
+        fprintf(stderr, "[MDSP_ARB_PROF] tiles %lld, kernel span %lld clk; per workgroup (clk): x_first load %.0f, replay(wave0) %.0f, prologue->barrier %.0f, compute %.0f, drain %.0f\n",
+                (long long)tiles, tmax - tmin, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
+    }
+    return MDSP_OK;
+}
+
+template <typename XS, typename A, typename R, int NCH> int arb_launch_pipe(mdsp_firarb_s* f, ArbArgs& a, int tile, int64_t span, int64_t lds_bytes, hipStream_t st) {
+    a.tile = tile;
+    a.span = (int)span;
+    auto kern = arbitrary_fir_pipe_kernel<XS, A, R, NCH>;
+    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const int64_t tiles = cdiv(a.nout, (int64_t)tile), groups = cdiv(f->base.nch, (int64_t)NCH);
+    int per_cu = (int)std::max<int64_t>(1, (int64_t)(160 * 1024) / lds_bytes);
+    if (const char* e = getenv("MDSP_WG_PER_CU")) per_cu = std::max(1, atoi(e));
+    const int64_t slots = (int64_t)device_cu_count() * per_cu;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, slots / groups));
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)groups), dim3(256), (size_t)lds_bytes, st, a);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
@@ -1211,6 +1421,17 @@ template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, 
     if (nchg == 1) {   // one channel at a time: shrink the tile until its span fits 48 KiB
         while ((span = span_of(tile)) * (int64_t)sizeof(A) > 48 * 1024 && tile > ARB_BLK) tile /= 2;
         if (span * (int64_t)sizeof(A) > 48 * 1024) span = 0;   // very low rates: outputs are far apart, read through L2 instead
+    }
+    // persistent pipelined kernel (opt-in, MDSP_ARB_PIPE=1: measured SLOWER than the one-tile-per-workgroup kernel, see DESIGN.md
+    // 4.7): tap pairs in LDS, the tile's span within PIPE_RB batches, two record + two sample buffers within 80 KiB
+    const int64_t pipe_lds = 2 * (int64_t)arb_rec_slot(tile) * (int64_t)sizeof(ArbRec) + 2 * span * nchg * (int64_t)sizeof(A) + taps_bytes;
+    const char* ep = getenv("MDSP_ARB_PIPE");
+    if (ep && atoi(ep) == 1 && a.taps_in_lds && !a.ablate && span > 0 && span <= PIPE_RB * 256 && tile == 1024 && pipe_lds <= 80 * 1024) {
+        switch (nchg) {
+            case 4: return arb_launch_pipe<XS, A, R, 4>(f, a, tile, span, pipe_lds, st);
+            case 2: return arb_launch_pipe<XS, A, R, 2>(f, a, tile, span, pipe_lds, st);
+            default: return arb_launch_pipe<XS, A, R, 1>(f, a, tile, span, pipe_lds, st);
+        }
     }
     switch (nchg) {
         case 4: return arb_launch_n<XS, A, R, 4>(f, a, tile, span, st);
@@ -1257,7 +1478,7 @@ int mdsp_arb_trajectory(double phi_acc, int64_t input_deficit, double rate, int6
         return MDSP_OK;
     }
     const double delta = (double)nphi / rate;
-    const ArbStep st{delta, (double)nphi, 1.0 / (double)nphi};
+    const ArbStep st = ArbStep::make(delta, (double)nphi);
     std::vector<int64_t> ax;
     std::vector<double> aa;
     int64_t xe = 0;
@@ -1282,7 +1503,7 @@ int mdsp_arb_trajectory_scan(double phi_acc, int64_t input_deficit, double rate,
     *used = 0;
     if (xlen < input_deficit) return MDSP_OK;
     const double delta = (double)nphi / rate;
-    const ArbStep st{delta, (double)nphi, 1.0 / (double)nphi};
+    const ArbStep st = ArbStep::make(delta, (double)nphi);
     std::vector<int64_t> ax;
     std::vector<double> aa;
     int64_t xe = 0;
@@ -1294,6 +1515,26 @@ int mdsp_arb_trajectory_scan(double phi_acc, int64_t input_deficit, double rate,
         std::copy(aa.begin(), aa.end(), anchors_acc);
     }
     *used = 1;
+    return MDSP_OK;
+}
+
+// Test helper: number of updates (out of nsteps from phi_acc) at which the branch-free update of the device replay
+// (ArbStep::fast) differs from the reference-form update (ArbStep::operator()) in phase or in index increment.
+int mdsp_arb_replay_check(double phi_acc, double rate, int64_t nphi, int64_t nsteps, int64_t* mismatches) {
+    if (!(rate > 0.0) || nphi < 1 || nsteps < 0 || !mismatches) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid arguments");
+    const ArbStep st = ArbStep::make((double)nphi / rate, (double)nphi);
+    double a1 = phi_acc, a2 = phi_acc;
+    int64_t x1 = 0, x2 = 0, bad = 0;
+    for (int64_t k = 0; k < nsteps; ++k) {
+        st(a1, x1);
+        st.fast(a2, x2);
+        if (a1 != a2 || x1 != x2) {
+            ++bad;
+            a2 = a1;
+            x2 = x1;
+        }
+    }
+    *mismatches = bad;
     return MDSP_OK;
 }
 
@@ -1464,7 +1705,7 @@ int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx
         f->input_deficit -= xlen;
         return MDSP_OK;
     }
-    const ArbStep step{f->delta, (double)f->nphi, 1.0 / (double)f->nphi};
+    const ArbStep step = ArbStep::make(f->delta, (double)f->nphi);
     const bool hit = f->cache_valid && f->c_acc0 == f->phi_acc && f->c_def0 == f->input_deficit && f->c_xlen == xlen;
     if (!hit) {
         int64_t nout = 0, xe = 0;
@@ -1476,7 +1717,7 @@ int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx
         const char* es = getenv("MDSP_ARB_SCAN");
         const char* em = getenv("MDSP_ARB_SCAN_MIN");
         const int64_t scan_min = em ? atoll(em) : (int64_t)1 << 19;
-        const int64_t pilot = std::min<int64_t>(65536, std::max<int64_t>(2 * ARB_BLK, (scan_min / 4) & ~int64_t(ARB_BLK - 1)));
+        const int64_t pilot = std::min<int64_t>(65536, std::max<int64_t>(2 * arbscan::BLK, (scan_min / 4) & ~int64_t(arbscan::BLK - 1)));
         if (!(es && atoi(es) == 0) && (double)xlen * f->rate >= (double)scan_min)
             MDSP_TRY(arb_scan_device(f, step, xlen, pilot, st, &scanned, &nout, &ae, &xe));
         if (scanned) {

@@ -242,12 +242,14 @@ int mdsp_arb_trajectory(double phi_acc, int64_t input_deficit, double rate, int6
 /* For streams of >= 2^19 outputs mdsp_firarb_exec evaluates that same recurrence in parallel on the device, bit for bit
  * (integer image of the IEEE operations + a multi-level scan of the rounding, dsp.jl_amd/csrc/arb_scan.h), after a
  * serial pilot of `pilot` outputs; it falls back to the serial loop when its self-check cannot certify the result.
- * mdsp_arb_trajectory_scan is the host emulation of that device code (anchors every 32 outputs; *used = 0: the scan
+ * mdsp_arb_trajectory_scan is the host emulation of that device code (anchors every 16 outputs; *used = 0: the scan
  * does not apply to these arguments); mdsp_firarb_scan_stats counts how each trajectory of a filter was evaluated. */
 int mdsp_arb_trajectory_scan(double phi_acc, int64_t input_deficit, double rate, int64_t nphi, int64_t xlen, int64_t pilot,
                              int64_t* anchors_x, double* anchors_acc, int64_t anchors_cap, int64_t* nout,
                              double* phi_acc_end, int64_t* input_deficit_end, int* used, int* passes);
 int mdsp_firarb_scan_stats(mdsp_firarb f, int64_t* scanned, int64_t* serial);
+/* test helper (host): updates at which the device replay's branch-free form of update! differs from the reference form */
+int mdsp_arb_replay_check(double phi_acc, double rate, int64_t nphi, int64_t nsteps, int64_t* mismatches);
 
 /* ------------------------------------------------------------------------------------------------------
  * N-dimensional convolution: conv(u, v) / conv!(out, u, v) for arrays (dspbase.jl:709-792).

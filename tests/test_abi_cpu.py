@@ -190,14 +190,14 @@ def test_arbitrary_trajectory_bit_exact_with_oracle(rate, nphi, acc0, def0, xlen
 def _c_trajectory_scan(acc, deficit, rate, nphi, xlen, pilot):
     import ctypes as C
     lib = _lib.lib()
-    cap = int(xlen * rate / 32) + 64
+    cap = int(xlen * rate / 16) + 64
     ax = np.zeros(cap, np.int64)
     aa = np.zeros(cap, np.float64)
     nout, dend, aend, used, passes = C.c_int64(), C.c_int64(), C.c_double(), C.c_int(), C.c_int()
     _lib.check(lib.mdsp_arb_trajectory_scan(acc, deficit, rate, nphi, xlen, pilot, ax.ctypes.data_as(C.POINTER(C.c_int64)),
                                             aa.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(nout), C.byref(aend), C.byref(dend),
                                             C.byref(used), C.byref(passes)))
-    na = -(-nout.value // 32)
+    na = -(-nout.value // 16)
     return bool(used.value), passes.value, ax[:na], aa[:na], nout.value, aend.value, dend.value
 
 
@@ -218,7 +218,7 @@ def test_arbitrary_parallel_scan_is_bit_exact():
     for rate, nphi, xlen, pilot in cases:
         acc = float(rng.uniform(0, nphi)) if rng.random() < 0.7 else 0.0
         deficit = int(rng.integers(1, 5))
-        ax, aa, nout, aend, dend = _c_trajectory(acc, deficit, rate, nphi, xlen, block=32)
+        ax, aa, nout, aend, dend = _c_trajectory(acc, deficit, rate, nphi, xlen, block=16)
         used, passes, sx, sa, snout, saend, sdend = _c_trajectory_scan(acc, deficit, rate, nphi, xlen, pilot)
         if not used:
             continue
@@ -226,6 +226,21 @@ def test_arbitrary_parallel_scan_is_bit_exact():
         assert (snout, saend, sdend) == (nout, aend, dend), (rate, nphi, xlen)
         assert np.array_equal(sx, ax) and np.array_equal(sa, aa), (rate, nphi, xlen)
     assert scanned >= len(cases) - 3                     # the scan certifies itself on (almost) every case
+
+
+def test_arbitrary_device_replay_update_is_exact():
+    """The branch-free update the device replays between anchors (two candidate quotients, Sterbenz-exact remainder) against
+    the reference-form update (stream_filt.jl:567-577), step by step: up- and down-sampling, large skips, odd Nphi."""
+    import ctypes as C
+    lib = _lib.lib()
+    rng = np.random.default_rng(9)
+    rates = [160 / 147, 147 / 160, 0.3721, 1.5, 2.7, 6.5, 0.13, 0.012, 1 / 55.55, 0.002, 1.0, 2.0, 0.5, 1e-4, 31.7, 1 - 2 ** -40, 1 + 2 ** -40]
+    rates += list(np.exp(rng.uniform(np.log(1e-3), np.log(30), 40)))
+    for rate in rates:
+        for nphi in (32, 7, 48, 1):
+            bad = C.c_int64(-1)
+            _lib.check(lib.mdsp_arb_replay_check(float(rng.uniform(0, nphi)), float(rate), nphi, 200000, C.byref(bad)))
+            assert bad.value == 0, (rate, nphi)
 
 
 def test_arbitrary_reference_length_regressions():
