@@ -519,143 +519,6 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
     stamp(5);
 }
 
-// Persistent, software-pipelined form of the kernel above for the common case (tap pairs in LDS, a tile's input span of at most
-// PIPE_RB * 256 samples): a workgroup walks tiles blockIdx.x, + gridDim.x, ... of ONE channel group (blockIdx.y) and, while it
-// evaluates tile i, (a) holds tile i+1's samples in flight from HBM in registers, written to the other LDS buffer after the
-// compute, (b) has wave 0 replay tile i+1's trajectory into the other record buffer first, and (c) loads the anchors of tile
-// i+2.  One barrier per tile; no global-memory latency on the critical path after the first tile.
-constexpr int PIPE_RB = 6;
-
-template <typename XS, typename A, typename R, int NCH>
-__global__ __launch_bounds__(256) void arbitrary_fir_pipe_kernel(ArbArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int rec_bytes = arb_rec_slot(a.tile) * (int)sizeof(ArbRec), zs_bytes = a.span * NCH * (int)sizeof(A);
-    // buffer b of the records / samples (plain offsets from the LDS base, so every access stays a DS instruction)
-    auto rec_buf = [&](int b) { return reinterpret_cast<ArbRec*>(smem + b * rec_bytes); };
-    auto zs_buf = [&](int b) { return reinterpret_cast<A*>(smem + 2 * rec_bytes + b * zs_bytes); };
-    Tap2<R>* ps = reinterpret_cast<Tap2<R>*>(smem + 2 * rec_bytes + 2 * zs_bytes);
-    const int tid = threadIdx.x;
-    const int64_t ntile = (a.nout + a.tile - 1) / a.tile;
-    const int64_t c0 = (int64_t)blockIdx.y * NCH;
-    const int nc = (int)std::min<int64_t>(NCH, a.nch - c0);
-    const int bpt = a.tile / ARB_BLK;   // anchor blocks per tile
-    // the span of one tile: PIPE_RB * NCH independent loads per thread, RAW values (clamped addresses); validity and conversion
-    // are applied when the values are written to LDS, after the compute -- nothing may consume them earlier
-    auto issue = [&](XS (&v)[PIPE_RB][NCH], int64_t z_first) {
-#pragma unroll
-        for (int r = 0; r < PIPE_RB; ++r) {
-            const int k = tid + r * 256;
-            const int64_t zi = z_first + (k < a.span ? k : a.span - 1);
-            const int64_t xi = zi - a.hl;
-            const bool in_hist = zi < a.hl;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int64_t ch = c0 + (c < nc ? c : 0);
-                const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
-                const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
-                v[r][c] = *(in_hist ? hc + zi : xc + (xi < a.xlen ? xi : 0));
-            }
-        }
-    };
-    auto commit = [&](const XS (&v)[PIPE_RB][NCH], int64_t z_first, A* zs) {
-#pragma unroll
-        for (int r = 0; r < PIPE_RB; ++r) {
-            const int k = tid + r * 256;
-            if (k < a.span) {
-                const int64_t zi = z_first + k;
-                const bool ok = zi < a.hl || zi - a.hl < a.xlen;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) zs[k * NCH + c] = (ok && c < nc) ? to_acc(v[r][c], (A*)nullptr) : A{};
-            }
-        }
-    };
-    auto tile_count = [&](int64_t t) { return (int)std::min<int64_t>(a.tile, a.nout - t * a.tile); };
-    // wave 0, lane l: replay anchor block l of tile t from (xi, acc) into rec
-    auto replay = [&](ArbRec* rec, int64_t t, int64_t x_first, int64_t xi, double acc) {
-        const int cnt = tile_count(t), base = tid * ARB_BLK;
-        if (base < cnt) {
-            const int n = min(ARB_BLK, cnt - base);
-            for (int k = 0; k < n; ++k) {
-                const double fl = floor(acc);
-                rec[arb_rec_slot(base + k)] = {(int)(xi - x_first), (int)fl, acc - fl};
-                a.step.fast(acc, xi);
-            }
-        }
-    };
-    // ---- prologue: taps, tile t0 in full, anchors of tile t0 + stride -------------------------------------------------------
-    const int64_t stride = gridDim.x;
-    int64_t t = blockIdx.x;
-    if (t >= ntile) return;
-    {
-        const Tap2<R>* pg = static_cast<const Tap2<R>*>(a.taps2);
-        const int np = a.tp * a.nphi;
-        for (int k = tid; k < np; k += 256) ps[k] = pg[k];
-    }
-    int64_t xf_cur = a.tab_x[t * bpt];
-    int64_t xf_next = t + stride < ntile ? a.tab_x[(t + stride) * bpt] : 0;
-    int64_t anx = 0;
-    double ana = 0.0;
-    {
-        XS v[PIPE_RB][NCH];
-        issue(v, xf_cur - 1);
-        if (tid < 64) {
-            const bool live = tid * ARB_BLK < tile_count(t);
-            const int64_t xi = live ? a.tab_x[t * bpt + tid] : 0;
-            const double acc = live ? a.tab_acc[t * bpt + tid] : 0.0;
-            if (t + stride < ntile && tid * ARB_BLK < tile_count(t + stride)) {
-                anx = a.tab_x[(t + stride) * bpt + tid];
-                ana = a.tab_acc[(t + stride) * bpt + tid];
-            }
-            replay(rec_buf(0), t, xf_cur, xi, acc);
-        }
-        commit(v, xf_cur - 1, zs_buf(0));
-    }
-    __syncthreads();
-    // ---- steady state ---------------------------------------------------------------------------------------------------
-    for (int i = 0; t < ntile; ++i, t += stride) {
-        const int cur = i & 1, nxt = cur ^ 1;
-        const int64_t tn = t + stride, tnn = tn + stride;
-        const bool have_next = tn < ntile;
-        XS v[PIPE_RB][NCH];
-        int64_t xf_nn = 0;
-        if (have_next) {
-            // order matters for s_waitcnt (counters retire in order): the anchor loads of the tile after next go first, so the
-            // copy into the loop-carried registers below waits for them only, not for the sample loads issued after them
-            int64_t xi = 0, anx_new = 0;
-            double acc = 0.0, ana_new = 0.0;
-            if (tid < 64) {
-                xi = anx;
-                acc = ana;
-                if (tnn < ntile && tid * ARB_BLK < tile_count(tnn)) {   // consumed one iteration later
-                    anx_new = a.tab_x[tnn * bpt + tid];
-                    ana_new = a.tab_acc[tnn * bpt + tid];
-                }
-            }
-            if (tnn < ntile) xf_nn = a.tab_x[tnn * bpt];
-            __builtin_amdgcn_sched_barrier(0);
-            issue(v, xf_next - 1);
-            if (tid < 64) {
-                replay(rec_buf(nxt), tn, xf_next, xi, acc);
-                anx = anx_new;
-                ana = ana_new;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the loads above stay in flight across the compute below
-        {
-            const int cnt = tile_count(t);
-            A* yc[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) yc[c] = static_cast<A*>(a.y) + (c0 + (c < nc ? c : 0)) * a.ldy + t * a.tile;
-            arb_tile_staged<A, R, NCH>(rec_buf(cur), ps, zs_buf(cur), yc, nc, cnt, a.tp, a.nphi);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (have_next) commit(v, xf_next - 1, zs_buf(nxt));
-        xf_cur = xf_next;
-        xf_next = xf_nn;
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // Stateful time-domain FIR: DF2TFilter{PolynomialRatio} with a = [1] (Filters/filt.jl:153-181) advanced by
 // _filt_fir! (dspbase.jl:95-105).  The state si[0..nb-2] is the TDF-II register file, NOT an input history:
@@ -1385,21 +1248,6 @@ template <typename XS, typename A, typename R, int NCH> int arb_launch_n(mdsp_fi
     return MDSP_OK;
 }
 
-template <typename XS, typename A, typename R, int NCH> int arb_launch_pipe(mdsp_firarb_s* f, ArbArgs& a, int tile, int64_t span, int64_t lds_bytes, hipStream_t st) {
-    a.tile = tile;
-    a.span = (int)span;
-    auto kern = arbitrary_fir_pipe_kernel<XS, A, R, NCH>;
-    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const int64_t tiles = cdiv(a.nout, (int64_t)tile), groups = cdiv(f->base.nch, (int64_t)NCH);
-    int per_cu = (int)std::max<int64_t>(1, (int64_t)(160 * 1024) / lds_bytes);
-    if (const char* e = getenv("MDSP_WG_PER_CU")) per_cu = std::max(1, atoi(e));
-    const int64_t slots = (int64_t)device_cu_count() * per_cu;
-    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, slots / groups));
-    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)groups), dim3(256), (size_t)lds_bytes, st, a);
-    MDSP_LAUNCH_CHECK();
-    return MDSP_OK;
-}
-
 template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, ArbArgs& a, hipStream_t st) {
     const int64_t taps_bytes = 2 * (int64_t)f->base.tp * f->nphi * (int64_t)sizeof(R);
     a.taps_in_lds = taps_bytes <= 32 * 1024;
@@ -1421,17 +1269,6 @@ template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, 
     if (nchg == 1) {   // one channel at a time: shrink the tile until its span fits 48 KiB
         while ((span = span_of(tile)) * (int64_t)sizeof(A) > 48 * 1024 && tile > ARB_BLK) tile /= 2;
         if (span * (int64_t)sizeof(A) > 48 * 1024) span = 0;   // very low rates: outputs are far apart, read through L2 instead
-    }
-    // persistent pipelined kernel (opt-in, MDSP_ARB_PIPE=1: measured SLOWER than the one-tile-per-workgroup kernel, see DESIGN.md
-    // 4.7): tap pairs in LDS, the tile's span within PIPE_RB batches, two record + two sample buffers within 80 KiB
-    const int64_t pipe_lds = 2 * (int64_t)arb_rec_slot(tile) * (int64_t)sizeof(ArbRec) + 2 * span * nchg * (int64_t)sizeof(A) + taps_bytes;
-    const char* ep = getenv("MDSP_ARB_PIPE");
-    if (ep && atoi(ep) == 1 && a.taps_in_lds && !a.ablate && span > 0 && span <= PIPE_RB * 256 && tile == 1024 && pipe_lds <= 80 * 1024) {
-        switch (nchg) {
-            case 4: return arb_launch_pipe<XS, A, R, 4>(f, a, tile, span, pipe_lds, st);
-            case 2: return arb_launch_pipe<XS, A, R, 2>(f, a, tile, span, pipe_lds, st);
-            default: return arb_launch_pipe<XS, A, R, 1>(f, a, tile, span, pipe_lds, st);
-        }
     }
     switch (nchg) {
         case 4: return arb_launch_n<XS, A, R, 4>(f, a, tile, span, st);
