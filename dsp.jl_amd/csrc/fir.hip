@@ -1099,7 +1099,7 @@ bool scan_setup(double acc, int64_t deficit, const ArbStep& st, int64_t nphi, in
     // outputs that can follow output k0: xIdx first exceeds xlen after about ((xlen + 1 - xs) N - As) / D updates; two spare blocks
     const __int128 room = (__int128)(xlen + 1 - xe) * (__int128)S.G.N;
     const __int128 kmax = room / (__int128)S.G.D + 2;
-    if (kmax > ((__int128)1 << 40)) return false;
+    if (kmax > ((__int128)1 << 33)) return false;   // scan work space is ~40 B per 32 outputs: keep it within a few GiB, longer streams go serial
     S.nb = (int64_t)kmax / BLK + 2;
     return true;
 }

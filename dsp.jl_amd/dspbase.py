@@ -14,6 +14,10 @@ from . import _dev, _lib
 from ._lib import ArgumentError, UnsupportedError
 
 SMALL_FILT_CUTOFF = 66   # dspbase.jl:3
+# Integer operands whose sums stay below this are convolved by Float64 FFTs and rounded: the transform's relative error (~1e-15 log2 n)
+# times the bound is orders of magnitude below 1/2, so the integers are exact (the reference's :direct sum is O(nu nv)).
+_INT_FFT_BOUND = 2.0 ** 36
+
 _FFT_TYPES = tuple(np.dtype(t) for t in (np.float32, np.float64, np.complex64, np.complex128))   # dspbase.jl:674
 
 
@@ -185,6 +189,8 @@ def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int 
         bound = float(abs(_host_vec(small).astype(np.float64)).max()) * float(_dev.to_columns(big, np.float64)[0].abs().max()) * min(nu, nv)
         if bound >= 2.0 ** 53:
             raise UnsupportedError("integer convolution would not be exact in Float64; use DSP.jl on the CPU")
+        if alg == "direct" and algorithm == "auto" and nu * nv >= 2 ** 16 and bound < _INT_FFT_BOUND:
+            alg = conv_select_algorithm(nu, nv, np.float64, "fft")   # same integers, O(n log n): the FFT's error stays far below 1/2
     small_h = _host_vec(small).astype(W)
     if alg == "direct" and W.kind != "c":
         # direct sum: zero-state FIR over u extended by nv-1 zeros (dspbase.jl:646-660)
@@ -241,6 +247,8 @@ def _conv_nd(u, v, algorithm: str = "auto"):
         bound = float(ud.abs().max()) * float(vd.abs().max()) * min(nu, nv)
         if bound >= 2.0 ** 53:
             raise UnsupportedError("integer convolution would not be exact in Float64; use DSP.jl on the CPU")
+        if alg == "direct" and algorithm == "auto" and nu * nv >= 2 ** 16 and bound < _INT_FFT_BOUND and sum(1 for a, b in zip(su, sv) if a > 1 or b > 1) <= 3:
+            alg = "fft"                                               # exact after rounding, O(n log n) instead of O(nu nv)
     out = _dev.torch.empty(so, dtype=ud.dtype, device=ud.device)
     # C-ordered (row-major) arrays are column-major arrays with the dimensions reversed; convolution treats every
     # dimension alike, so only the size vectors are reversed

@@ -1152,3 +1152,20 @@ def test_xcorr(d, torch):
             got = d.xcorr(u, v, **kw)
             assert got.dtype == T and got.shape == ref.shape and relerr(got, ref) < tol, (T, kw, relerr(got, ref))
         assert relerr(d.xcorr(u), odsp.xcorr(u.astype(wide))) < tol                                  # autocorrelation
+
+
+def test_integer_convolution_large_operands_exact(d):
+    """Integer eltypes: the reference sums in integers (:direct, O(nu nv)); for large operands the device convolves by Float64 FFTs
+    and rounds -- the integers must come out exact (and the explicit :direct keyword must agree)."""
+    rng = np.random.default_rng(33)
+    u = rng.integers(-1000, 1000, 70000); v = rng.integers(-1000, 1000, 900)
+    ref = np.convolve(u, v)
+    got = d.conv(u, v)
+    assert got.dtype == np.int64 and np.array_equal(got, ref)
+    assert np.array_equal(d.conv(u.astype(np.int32), v.astype(np.int32)), ref)
+    assert np.array_equal(d.conv(u[:3000], v, algorithm="direct"), np.convolve(u[:3000], v))
+    a = rng.integers(-50, 50, (300, 260)); b = rng.integers(-50, 50, (24, 31))
+    from oracle import dspbase as odsp
+    ref2 = odsp.conv_nd(a, b, "direct")
+    assert np.array_equal(d.conv(a, b), ref2) and np.array_equal(d.conv(b, a), ref2)
+    assert np.array_equal(d.conv(a[:40, :50], b, algorithm="direct"), odsp.conv_nd(a[:40, :50], b, "direct"))
