@@ -150,6 +150,7 @@ struct FirFastArgs {
     int Q;               // rounds per tile
     int NP, RL;          // phase groups, round lanes (blockDim.x = NP * RL)
     int span;            // LDS floats per tile
+    unsigned char gmap[256];   // thread -> phase group (a permutation of 0..NP-1 per round lane): see fir_lane_map
 };
 
 template <int TPC, int P>
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* zs = reinterpret_cast<float*>(smem);
     const int64_t ch = blockIdx.y;
-    const int g = threadIdx.x % a.NP, r = threadIdx.x / a.NP;
+    const int g = a.gmap[threadIdx.x], r = threadIdx.x / a.NP;
     const float* xc = a.x + ch * a.ldx;
     const float* hc = a.hist + ch * (int64_t)a.hl;
     float* yc = a.y + ch * a.ldy;
@@ -222,13 +223,25 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
             for (int q = r; q < nq; q += a.RL) {
                 const float* zp = zs + q * a.M + c0rel;
                 float acc[P];
+                if constexpr (P == 2) {   // both residues in one v_pk_fma_f32 per tap (sample broadcast by op_sel)
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+                    f2v a2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int k = 0; k < P; ++k) acc[k] = 0.0f;
+                    for (int j = 0; j < W; ++j) {
+                        const float xv = zp[j];
+                        a2 = __builtin_elementwise_fma(f2v{xv, xv}, f2v{h[0][j], h[1][j]}, a2);
+                    }
+                    acc[0] = a2.x;
+                    acc[1] = a2.y;
+                } else {
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
-                    const float xv = zp[j];
+                    for (int k = 0; k < P; ++k) acc[k] = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < P; ++k) acc[k] = fmaf(xv, h[k][j], acc[k]);
+                    for (int j = 0; j < W; ++j) {
+                        const float xv = zp[j];
+#pragma unroll
+                        for (int k = 0; k < P; ++k) acc[k] = fmaf(xv, h[k][j], acc[k]);
+                    }
                 }
                 const int64_t m = (q0 + q) * a.L + s0;
 #pragma unroll
@@ -659,6 +672,54 @@ template <typename XS, typename A, typename R> int fir_launch(mdsp_fir_s* f, Fir
     return MDSP_OK;
 }
 
+// Which phase group each thread of the fast kernel owns.  A thread's LDS reads are at (round) M + c_g + j, c_g = (phi0-1 + g P M)
+// div L: with groups in thread order, the 32 lanes of a ds_read_b32 group span ~32 P M / L addresses and collide two ways
+// whenever that exceeds 32 (160//147: 1.88 LDS cycles per access instead of 1, 45 % of the kernel's LDS cycles measured as
+// bank conflicts).  Any assignment of groups to lanes is legal (the taps live in registers, stores stay inside the same
+// L-sample row), so the host picks, per 32-lane group, phase groups with distinct banks (greedy), keeps the identity when
+// that is not better, and passes the table in the kernel arguments.
+template <int P> void fir_lane_map(FirFastArgs& b) {
+    const int NP = b.NP, nthreads = b.NP * b.RL;
+    std::vector<int> c0(NP), ident(nthreads), greedy(nthreads);
+    for (int g = 0; g < NP; ++g) c0[g] = (int)((b.phi0m1 + (int64_t)g * P * b.M) / b.L);
+    const auto cycles = [&](const std::vector<int>& tab) {
+        int total = 0;
+        for (int w0 = 0; w0 < nthreads; w0 += 32) {
+            int cnt[32] = {0}, addr[32][32];
+            int worst = 1;
+            for (int t = w0; t < std::min(w0 + 32, nthreads); ++t) {
+                const int a = (t / NP) * b.M + c0[tab[t]], bank = a & 31;
+                bool seen = false;
+                for (int i = 0; i < cnt[bank]; ++i) seen = seen || addr[bank][i] == a;
+                if (!seen) addr[bank][cnt[bank]++] = a;
+                worst = std::max(worst, cnt[bank]);
+            }
+            total += worst;
+        }
+        return total;
+    };
+    std::vector<std::vector<char>> used(b.RL, std::vector<char>(NP, 0));
+    for (int t = 0; t < nthreads; ++t) ident[t] = t % NP;
+    for (int w0 = 0; w0 < nthreads; w0 += 32) {
+        bool bank_used[32] = {false};
+        for (int t = w0; t < std::min(w0 + 32, nthreads); ++t) {
+            const int r = t / NP;
+            int pick = -1, any = -1;
+            for (int g = 0; g < NP && pick < 0; ++g) {
+                if (used[r][g]) continue;
+                if (any < 0) any = g;
+                if (!bank_used[(r * b.M + c0[g]) & 31]) pick = g;
+            }
+            if (pick < 0) pick = any;
+            used[r][pick] = 1;
+            bank_used[(r * b.M + c0[pick]) & 31] = true;
+            greedy[t] = pick;
+        }
+    }
+    const std::vector<int>& best = cycles(greedy) < cycles(ident) && !getenv("MDSP_FIR_IDENTITY_LANES") ? greedy : ident;
+    for (int t = 0; t < 256; ++t) b.gmap[t] = (unsigned char)(t < nthreads ? best[t] : 0);
+}
+
 template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
     FirFastArgs b{};
     b.x = (const float*)a.x;
@@ -671,6 +732,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
     b.nrounds = cdiv(a.nout, (int64_t)a.L);
     b.NP = (int)cdiv(a.L, P);
     b.RL = std::max(1, 256 / b.NP);
+    fir_lane_map<P>(b);
     // rounds per tile: LDS budget ~48 KiB, at least RL rounds
     int lds_kib = 20;
     if (const char* e = getenv("MDSP_FIR_LDS_KIB")) lds_kib = std::max(4, atoi(e));
@@ -683,7 +745,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
     auto kern = polyphase_fast_kernel<TPC, P>;
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const int64_t ntiles = cdiv(b.nrounds, (int64_t)Q);
-    int wgs = 8;   // measured best on MI355X (profiles/r01c_rows.json): 8 workgroups of ~20 KiB LDS per CU
+    int wgs = 5;   // resident workgroups per CU (94 VGPRs x 4 waves, ~20 KiB LDS); 8 / 5 / 4 measured 2.64 / 2.59 / 2.67 ms on config 5
     if (const char* e = getenv("MDSP_WG_PER_CU")) wgs = std::max(1, atoi(e));
     const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)f->nch);
@@ -696,7 +758,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
 bool fir_fast_ok(const mdsp_fir_s* f, int P) {
     if (f->acc_double || f->x_dtype != MDSP_F32 || f->tp > 64) return false;
     if (getenv("MDSP_FIR_GENERIC")) return false;
-    if (P == 2 && (f->M > f->L || f->L < 2)) return false;
+    if (P >= 2 && (f->M > f->L || f->L < P)) return false;
     return cdiv(f->L, P) <= 256;
 }
 

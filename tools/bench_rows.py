@@ -47,7 +47,7 @@ g = torch.Generator(device="cuda"); g.manual_seed(1776)
 
 # ---------------- config 4: STFT / spectrogram ----------------
 nch, n = 8, 1 << (26 - scale)
-if os.environ.get("ROWS_SKIP_STFT"):
+if os.environ.get("ROWS_SKIP_STFT") or os.environ.get("ROWS_ONLY") == "fir":
     nch = 0
 z = torch.randn((max(nch, 1), n if nch else 8, 2), generator=g, device="cuda", dtype=torch.float32) * math.sqrt(0.5)
 s = torch.view_as_complex(z)                                    # (nch, n) C64: channel = contiguous column
@@ -101,6 +101,8 @@ if os.environ.get("ROWS_FIR_SWEEP"):
             print("fir sweep lds_kib", kib, "wg_per_cu", wg, "ms", round(best, 3), "GB/s", round((4 + 4 * 160 / 147) * n * nch / (best * 1e-3) / 1e9, 1), flush=True)
     del os.environ["MDSP_FIR_LDS_KIB"]; del os.environ["MDSP_WG_PER_CU"]
 del y
+if os.environ.get("ROWS_ONLY") == "fir":
+    sys.exit(0)
 # ---------------- next row 1: arbitrary-rate resampler (FIRArbitrary), rate 160/147 as a Float64, Nphi = 32 ----------------
 import time
 rate = 160 / 147
