@@ -1169,3 +1169,32 @@ def test_integer_convolution_large_operands_exact(d):
     ref2 = odsp.conv_nd(a, b, "direct")
     assert np.array_equal(d.conv(a, b), ref2) and np.array_equal(d.conv(b, a), ref2)
     assert np.array_equal(d.conv(a[:40, :50], b, algorithm="direct"), odsp.conv_nd(a[:40, :50], b, "direct"))
+
+
+def test_time_axis_split_of_one_stream(d, torch):
+    """SURVEY 8e "next": one stream split along time over ranks.  Three "ranks" are evaluated one after another on this GPU; the
+    frame-count-weighted sum of their PSDs and the concatenation of their filter outputs must equal the whole-stream results."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(3_000_000).astype(np.float32)
+    n, nov = 4096, 2048
+    K = d.frame_count(len(x), n, nov)
+    whole = d.welch_pgram(x, n, nov, window=d.hanning).power
+    acc = np.zeros_like(whole, dtype=np.float64)
+    world = 3
+    for r in range(world):
+        frames = d.frame_shard(K, r, world)
+        lo, hi = d.frame_span(frames, n, nov)
+        acc += d.welch_time_split(torch.from_numpy(x[lo:hi]).cuda(), K, n, nov, window=d.hanning).cpu().numpy().astype(np.float64)
+    assert relerr(acc, whole.astype(np.float64)) < 3e-6
+    empty = d.welch_time_split(torch.from_numpy(x[:100]).cuda(), K, n, nov, window=d.hanning)       # a rank without a full frame contributes zeros
+    assert empty.shape == whole.shape and not empty.any()
+    b = _lowpass_taps(256, np.float32)
+    yw = d.filt(b, x)
+    per = -(-len(x) // world)
+    parts = []
+    for r in range(world):
+        olo, ohi = r * per, min(len(x), (r + 1) * per)
+        slo, shi = d.filt_time_split_span(olo, ohi, len(b))
+        parts.append(d.filt_time_split(b, x[slo:shi], olo - slo))
+    y = np.concatenate(parts)
+    assert y.shape == yw.shape and relerr(y, yw) < 3e-6
