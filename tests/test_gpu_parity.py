@@ -1198,3 +1198,36 @@ def test_time_axis_split_of_one_stream(d, torch):
         parts.append(d.filt_time_split(b, x[slo:shi], olo - slo))
     y = np.concatenate(parts)
     assert y.shape == yw.shape and relerr(y, yw) < 3e-6
+
+
+@pytest.mark.parametrize("Tx", [np.float32, np.float64, np.complex64, np.complex128])
+def test_firarbitrary_channel_groups_every_dtype(d, Tx):
+    """The arbitrary-rate kernel evaluates up to four channels per pass over the taps (samples interleaved in LDS; 4-, 8- and 16-byte
+    sample groups use different LDS read widths and lane orders).  Every channel of a multi-channel call must equal the
+    single-channel call bit for bit, and the oracle within tolerance -- short and long filters, 2..9 channels."""
+    from oracle import stream_filt as osf
+    rng = np.random.default_rng(5 + np.dtype(Tx).itemsize)
+    cplx = np.dtype(Tx).kind == "c"
+    single = np.dtype(Tx) in (np.dtype(np.float32), np.dtype(np.complex64))
+    for rate, nphi, ntaps in ((1.37, 32, 32 * 6), (0.81, 32, 32 * 12), (2.2, 16, 16 * 40), (1.0884, 32, 1185)):
+        Th = np.float32 if single else np.float64
+        h = (rng.standard_normal(ntaps) / ntaps).astype(Th)
+        for nch in (2, 3, 4, 5, 9):
+            xlen = 3000 + 17 * nch
+            x = rng.standard_normal((xlen, nch)).astype(Tx)
+            if cplx:
+                x = (x + 1j * rng.standard_normal((xlen, nch))).astype(Tx)
+            f = d.FIRFilter(h, rate, nphi)
+            y = f.filt(x)
+            state = (f.phi_accumulator, f.input_deficit)
+            assert y.shape[1] == nch
+            for c in range(nch):
+                g = d.FIRFilter(h, rate, nphi)
+                yc = g.filt(np.ascontiguousarray(x[:, c]))
+                assert (g.phi_accumulator, g.input_deficit) == state
+                assert np.array_equal(y[:, c], yc), (Tx, rate, nch, c)
+            o = osf.FIRFilter(h, rate, nphi)
+            wide = np.complex128 if cplx else np.float64
+            o.h, o.pfb, o.dpfb = h.astype(np.float64), o.pfb.astype(np.float64), o.dpfb.astype(np.float64)
+            ref = o.filt(x[:, nch - 1].astype(wide))
+            assert relerr(y[:, nch - 1], ref) < (3e-6 if single else 1e-12)
