@@ -225,9 +225,12 @@ struct ScanArgs {
     int64_t* result;           // [0] status bits (1: ambiguous block, 2: end found), [1] nout, [2] xIdx_end, [3] bits of phi_acc_end
 };
 
-// K1: tables of block b
-MDSP_HD void scan_tables_body(const ScanArgs& a, int64_t b) {
+// K1: tables of block b.  RC = the table size as a compile-time constant (device: candidates live in registers), 0 = read it
+// from the grid (host emulation).
+template <int RC = 0> MDSP_HD void scan_tables_body(const ScanArgs& a, int64_t b) {
     const Grid& G = a.G;
+    constexpr int CAP = RC ? RC : RMAX;
+    const int R = RC ? RC : G.R;
     uint64_t A0;
     int64_t W0;
     base_at(G, a.As, (uint64_t)b * BLK, A0, W0);
@@ -235,10 +238,13 @@ MDSP_HD void scan_tables_body(const ScanArgs& a, int64_t b) {
     a.baseW[2 * b] = W0;
     const int64_t c = a.pass == 0 ? predicted_offset(G, a.sigma, b * BLK) : round_offset(G, a.E[b]);
     a.cb[b] = c;
-    uint64_t Ac[RMAX], Ab = add_mod(G, A0, c);
+    uint64_t Ac[CAP], Ab = add_mod(G, A0, c);
     int64_t Wd = 0;
-    int32_t T[RMAX];
-    for (int e = 0; e < G.R; ++e) {
+    int32_t T[CAP];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e < R; ++e) {
         const uint64_t v = Ab + (uint64_t)e;
         Ac[e] = v >= G.N ? v - G.N : v;
         T[e] = 0;
@@ -247,21 +253,39 @@ MDSP_HD void scan_tables_body(const ScanArgs& a, int64_t b) {
     for (int k = 0; k < BLK; ++k) {
         const uint64_t d = threshold_distance(G, Ab);
         md = d < md ? d : md;
-        for (int e = 0; e < G.R; ++e) T[e] += (int32_t)step(G, Ac[e], Wd);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int e = 0; e < R; ++e) T[e] += (int32_t)step(G, Ac[e], Wd);
         base_step(G, Ab, Wd);
     }
-    for (int e = 0; e < G.R; ++e) a.t0[b * G.R + e] = T[e];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e < R; ++e) a.t0[b * R + e] = T[e];
     a.mind[b] = md > 0xffffffffull ? 0xffffffffu : (uint32_t)md;
 }
 
 // K2 up: out[g] = in[FAN g] then in[FAN g + 1] then ...   (tables are R consecutive entries; wide sums above level 0)
-template <typename TIn> MDSP_HD void scan_compose_body(const Grid& G, const TIn* in, int64_t n, int64_t* out, int64_t g) {
-    int64_t acc[RMAX];
-    for (int e = 0; e < G.R; ++e) acc[e] = 0;
+template <int RC, typename TIn> MDSP_HD void scan_compose_body(const Grid& G, const TIn* in, int64_t n, int64_t* out, int64_t g) {
+    constexpr int CAP = RC ? RC : RMAX;
+    const int R = RC ? RC : G.R;
+    int64_t acc[CAP];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e < R; ++e) acc[e] = 0;
     const int64_t lo = g * FAN, hi = lo + FAN < n ? lo + FAN : n;
-    for (int64_t t = lo; t < hi; ++t)
-        for (int e = 0; e < G.R; ++e) acc[e] += (int64_t)in[t * G.R + ((e + acc[e]) & (G.R - 1))];
-    for (int e = 0; e < G.R; ++e) out[g * G.R + e] = acc[e];
+    for (int64_t t = lo; t < hi; ++t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int e = 0; e < R; ++e) acc[e] += (int64_t)in[t * R + ((e + acc[e]) & (R - 1))];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e < R; ++e) out[g * R + e] = acc[e];
 }
 
 // K2 top: serial over the coarsest level

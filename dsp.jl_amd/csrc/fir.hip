@@ -1051,13 +1051,22 @@ void arb_trajectory(double acc, int64_t deficit, const ArbStep& st, int64_t xlen
 // ---- parallel trajectory scan (arb_scan.h): kernels and drivers ------------------------------------------------
 static_assert(arbscan::ANCH == ARB_BLK && arbscan::BLK == 2 * ARB_BLK, "two anchors per scan block");
 
-__global__ __launch_bounds__(256) void arb_scan_tables_kernel(arbscan::ScanArgs a) {
+template <int RC> __global__ __launch_bounds__(256) void arb_scan_tables_kernel(arbscan::ScanArgs a) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < a.nb) arbscan::scan_tables_body(a, b);
+    if (b < a.nb) arbscan::scan_tables_body<RC>(a, b);
 }
-template <typename TIn> __global__ __launch_bounds__(256) void arb_scan_compose_kernel(arbscan::Grid G, const TIn* in, int64_t n, int64_t* out, int64_t ng) {
+template <int RC, typename TIn> __global__ __launch_bounds__(256) void arb_scan_compose_kernel(arbscan::Grid G, const TIn* in, int64_t n, int64_t* out, int64_t ng) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < ng) arbscan::scan_compose_body(G, in, n, out, g);
+    if (g < ng) arbscan::scan_compose_body<RC>(G, in, n, out, g);
+}
+template <typename TIn> void launch_compose(const arbscan::Grid& G, const TIn* in, int64_t n, int64_t* out, int64_t ng, hipStream_t st) {
+    const dim3 grid((unsigned)cdiv(ng, (int64_t)256));
+    switch (G.R) {
+        case 2: hipLaunchKernelGGL((arb_scan_compose_kernel<2, TIn>), grid, dim3(256), 0, st, G, in, n, out, ng); break;
+        case 4: hipLaunchKernelGGL((arb_scan_compose_kernel<4, TIn>), grid, dim3(256), 0, st, G, in, n, out, ng); break;
+        case 8: hipLaunchKernelGGL((arb_scan_compose_kernel<8, TIn>), grid, dim3(256), 0, st, G, in, n, out, ng); break;
+        default: hipLaunchKernelGGL((arb_scan_compose_kernel<16, TIn>), grid, dim3(256), 0, st, G, in, n, out, ng); break;
+    }
 }
 __global__ void arb_scan_top_kernel(arbscan::Grid G, const int64_t* in, int64_t n, int64_t* Eout) {
     if (blockIdx.x == 0 && threadIdx.x == 0) arbscan::scan_top_body(G, in, n, Eout);
@@ -1103,11 +1112,15 @@ int scan_pass(const arbscan::ScanArgs& a, const ScanLayout& L, int64_t* wide, in
     const int nl = (int)L.n.size() - 1;   // top level
     const auto blocks = [](int64_t n) { return dim3((unsigned)cdiv(n, (int64_t)256)); };
     if (device) {
-        hipLaunchKernelGGL(arb_scan_tables_kernel, blocks(a.nb), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(arb_scan_compose_kernel<int32_t>, blocks(L.n[1]), dim3(256), 0, st, a.G, (const int32_t*)a.t0, L.n[0], wide + L.woff[1], L.n[1]);
+        switch (a.G.R) {   // table size 2^(J+1) as a template argument: the candidates stay in registers
+            case 2: hipLaunchKernelGGL(arb_scan_tables_kernel<2>, blocks(a.nb), dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL(arb_scan_tables_kernel<4>, blocks(a.nb), dim3(256), 0, st, a); break;
+            case 8: hipLaunchKernelGGL(arb_scan_tables_kernel<8>, blocks(a.nb), dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL(arb_scan_tables_kernel<16>, blocks(a.nb), dim3(256), 0, st, a); break;
+        }
+        launch_compose<int32_t>(a.G, (const int32_t*)a.t0, L.n[0], wide + L.woff[1], L.n[1], st);
         for (int l = 2; l <= nl; ++l)
-            hipLaunchKernelGGL(arb_scan_compose_kernel<int64_t>, blocks(L.n[l]), dim3(256), 0, st, a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1],
-                               wide + L.woff[l], L.n[l]);
+            launch_compose<int64_t>(a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1], wide + L.woff[l], L.n[l], st);
         hipLaunchKernelGGL(arb_scan_top_kernel, dim3(1), dim3(64), 0, st, a.G, (const int64_t*)(wide + L.woff[nl]), L.n[nl], Eall + L.eoff[nl]);
         for (int l = nl; l >= 2; --l)
             hipLaunchKernelGGL(arb_scan_expand_kernel<int64_t>, blocks(L.n[l]), dim3(256), 0, st, a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1],
@@ -1118,10 +1131,10 @@ int scan_pass(const arbscan::ScanArgs& a, const ScanLayout& L, int64_t* wide, in
         MDSP_LAUNCH_CHECK();
         return MDSP_OK;
     }
-    for (int64_t b = 0; b < a.nb; ++b) scan_tables_body(a, b);
-    for (int64_t g = 0; g < L.n[1]; ++g) scan_compose_body(a.G, (const int32_t*)a.t0, L.n[0], wide + L.woff[1], g);
+    for (int64_t b = 0; b < a.nb; ++b) scan_tables_body<0>(a, b);
+    for (int64_t g = 0; g < L.n[1]; ++g) scan_compose_body<0>(a.G, (const int32_t*)a.t0, L.n[0], wide + L.woff[1], g);
     for (int l = 2; l <= nl; ++l)
-        for (int64_t g = 0; g < L.n[l]; ++g) scan_compose_body(a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1], wide + L.woff[l], g);
+        for (int64_t g = 0; g < L.n[l]; ++g) scan_compose_body<0>(a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1], wide + L.woff[l], g);
     scan_top_body(a.G, wide + L.woff[nl], L.n[nl], Eall + L.eoff[nl]);
     for (int l = nl; l >= 2; --l)
         for (int64_t g = 0; g < L.n[l]; ++g) scan_expand_body(a.G, (const int64_t*)(wide + L.woff[l - 1]), L.n[l - 1], Eall + L.eoff[l], Eall + L.eoff[l - 1], g);
