@@ -1211,11 +1211,18 @@ int stft_exec_rocfft(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t n
     }
     const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
     const int nout = (int)pl->nout;
+    const bool direct = !pl->psd_only && nout == nspec && ldo == nout && (nch == 1 || chs == K * (int64_t)nout) && !getenv("MDSP_STFT_NODIRECT");
     for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
         const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
         hipLaunchKernelGGL(frame_window_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
                            pl->have_win ? pl->win_ptr : nullptr, lds_, K, hop, (int)n, (int)nfft, u0, nunits);
         MDSP_LAUNCH_CHECK();
+        // raw STFT whose output matrix has exactly the batched transform's layout (contiguous columns of nspec bins, channels
+        // back to back): full batches are transformed straight into it, one pass over the spectra less
+        if (direct && cnt == batch) {
+            MDSP_TRY(pl->fwd.exec(pl->fr.p, static_cast<cx<R>*>(out) + u0 * nout, st));
+            continue;
+        }
         MDSP_TRY(pl->fwd.exec(pl->fr.p, pl->spec.p, st));
         const dim3 g(gx, (unsigned)cnt);
         if (pl->psd_only)
