@@ -221,6 +221,11 @@ def main():
         welch_roof = {"bound": "hbm", "kernel": "welch_fused_kernel (+finalize; 4 B/sample)", "achieved": round(welch_gbs, 1),
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(welch_gbs / HBM_PEAK_GBS, 4),
                       "traffic": kern_traffic.get("welch_fused_bytes_per_launch"), "ms_per_launch": round(welch_ms, 4)}
+        # the Welch kernel's other roof: 5 N log2 N flop per 4096-point transform of 4096 new samples, against the packed-FP32
+        # add/multiply rate (butterflies are adds, not FMAs): 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz (boost; the kernel is
+        # power-throttled to ~1.8 GHz)
+        welch_tflops = 5.0 * 4096 * 12 * (n / 4096) / (welch_ms * 1e-3) / 1e12
+        welch_roof["valu"] = {"achieved": round(welch_tflops, 1), "peak": 78.6, "unit": "TFLOP/s (packed f32 add/mul)", "frac": round(welch_tflops / 78.6, 4)}
         if not dominant_is_ols:
             roof, welch_roof = welch_roof, roof
         out = {
