@@ -100,6 +100,15 @@ template <typename T, int E, int TT> __device__ __forceinline__ void load_window
     }
 }
 
+// elements e = E0 .. E-1 only (the tail of a window whose head is already in registers)
+template <typename T, int E, int TT, int E0> __device__ __forceinline__ void load_window_tail(T (&out)[E], __amdgpu_buffer_rsrc_t r, int t) {
+    constexpr int SZ = (int)sizeof(T);
+    int off = t * SZ;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int e = E0; e < E; ++e) out[e] = Ld<T>::load(r, off + TT * e * SZ);
+}
+
 template <typename T, int E, int TT, typename F> __device__ __forceinline__ void store_window(F&& get, __amdgpu_buffer_rsrc_t w, int lead, int t) {
     constexpr int SZ = (int)sizeof(T);
     int off = t * SZ;
