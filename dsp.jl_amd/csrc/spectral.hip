@@ -1316,6 +1316,19 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
             return runp(stft_pair_kernel<R, N, E, G, TWREG, pad_default<R>(), false, 2, NBUF>);
         }
     }
+    if constexpr (CPLX && sizeof(R) == 4) {   // complex Float32 frames that advance by whole elements: overlap stays in registers
+        constexpr int T = N / E;
+        const int shift = (!getenv("MDSP_STFT_NOSHIFT") && a.n == N && a.hop % T == 0 && a.hop / T < E) ? (int)(a.hop / T) : 0;
+#define MDSP_STFT_GEN(S) \
+    (pl->psd_only ? run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, true, 2, NBUF, true, S>) \
+                  : run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, false, 2, NBUF, true, S>))
+        if constexpr (E > 4) {
+            if (shift == 1) return MDSP_STFT_GEN(1);
+            if (shift == 2) return MDSP_STFT_GEN(2);
+            if (shift == 4) return MDSP_STFT_GEN(4);
+        }
+#undef MDSP_STFT_GEN
+    }
     if (pl->psd_only) return run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, true, 2, NBUF, true>);
     return run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, false, 2, NBUF, true>);
 }
