@@ -214,7 +214,9 @@ template <int E, int T> __device__ __forceinline__ void load_window_regs(double 
 }
 
 // ---- Welch ------------------------------------------------------------------------------------------------
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
+// SHIFT > 0 (complex signals; host guarantees n == N and hop == SHIFT * T): the samples a frame shares with its predecessor stay
+// in registers, shifted by SHIFT elements per frame -- see stft_fused_kernel.
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64, int SHIFT = 0>
 __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs a) {
     using C = fft::Cfg<N, E>;
     using TT = std::conditional_t<CPLX, cx<R>, R>;
@@ -260,12 +262,24 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
 
     TT ra[E];
     TT rb[CPLX ? 1 : E];
+    int64_t held = -2;   // SHIFT: frame whose raw samples ra[] holds
     auto issue = [&](int64_t u) {
         const bool live = u < a.units_per_ch;
         const int64_t f0 = CPLX ? u : 2 * u;
         const int64_t start = f0 * a.hop;
         // a frame never reads past start+n: the descriptor ends there (zero tail) or at the end of the signal
         const __amdgpu_buffer_rsrc_t r0 = io::make_rsrc(sc + start, live ? std::min<int64_t>(a.n, a.len - start) * SZ : 0);
+        if constexpr (SHIFT > 0) {
+            static_assert(CPLX && SHIFT < E, "frame-overlap reuse is wired for complex signals");
+            if (live && u == held + 1) {   // wave-uniform: the next frame of the same run
+#pragma unroll
+                for (int e = 0; e < E - SHIFT; ++e) ra[e] = ra[e + SHIFT];
+                io::load_window_tail<TT, E, T, E - SHIFT>(ra, r0, t);
+                held = u;
+                return;
+            }
+            held = live ? u : -2;
+        }
         io::load_window<TT, E, T>(ra, r0, 0, t);
         if constexpr (!CPLX) {
             const bool haveB = live && (f0 + 1) < a.K;
@@ -967,9 +981,9 @@ int welch_run_half(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nsli
     return MDSP_OK;
 }
 
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool WIN64, int SHIFT = 0>
 int welch_run_variant(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
-    auto kern = welch_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, WIN64>;
+    auto kern = welch_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, WIN64, SHIFT>;
     constexpr int threads = (N / E) * G;
     int grid = 1;
     MDSP_TRY(grid_for(kern, threads, cdiv(a.units_per_ch, G), a.nch, &grid));
@@ -1036,7 +1050,16 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
             default: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, false>(pl, a, st, &nslices); break;
         }
     } else {
-        rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, pad_default<R>(), CPLX, 2, Gm::NBUF, true, sizeof(R) == 8>(pl, a, st, &nslices);
+        bool done = false;
+        if constexpr (CPLX && sizeof(R) == 4 && Gm::E > 4) {   // complex Float32 frames advancing by whole elements: overlap stays in registers
+            constexpr int T = N / Gm::E;
+            const int shift = (!getenv("MDSP_STFT_NOSHIFT") && a.n == N && a.hop % T == 0 && a.hop / T < Gm::E) ? (int)(a.hop / T) : 0;
+            done = shift == 1 || shift == 2 || shift == 4;
+            if (shift == 1) rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, pad_default<R>(), CPLX, 2, Gm::NBUF, true, false, 1>(pl, a, st, &nslices);
+            else if (shift == 2) rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, pad_default<R>(), CPLX, 2, Gm::NBUF, true, false, 2>(pl, a, st, &nslices);
+            else if (shift == 4) rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, pad_default<R>(), CPLX, 2, Gm::NBUF, true, false, 4>(pl, a, st, &nslices);
+        }
+        if (!done) rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, pad_default<R>(), CPLX, 2, Gm::NBUF, true, sizeof(R) == 8>(pl, a, st, &nslices);
     }
 finalize:
     if (rc != MDSP_OK) return rc;
