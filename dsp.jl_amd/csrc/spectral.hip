@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1768,19 +1769,49 @@ __global__ __launch_bounds__(256) void hilbert_scale_kernel(const cx<R>* __restr
     }
 }
 
+// Transforms and scratch of the most recent (length, batch) per precision: plan creation for a 2^20-point column costs ~15 ms,
+// the transform itself tens of microseconds.  A call holds the entry's lock; a call on another stream first waits for the
+// previous user's stream.
+struct HilbertCache {
+    std::mutex mu;
+    int64_t n = 0, batch = 0;
+    RocPlan fwd, inv;
+    DevBuf xin, half, full;
+    hipStream_t last = nullptr;
+    bool used = false;
+};
+HilbertCache& hilbert_cache(bool dbl) {
+    static HilbertCache c[2];
+    return c[dbl ? 1 : 0];
+}
+
 template <typename R> int hilbert_run(const void* x, int64_t n, int64_t ncols, int64_t ldx, void* out, int64_t ldo, hipStream_t st) {
     const int64_t nspec = n / 2 + 1;
     // columns are processed in batches whose intermediates stay within ~256 MiB
     const int64_t per_col = (int64_t)sizeof(R) * n + (int64_t)sizeof(cx<R>) * (nspec + n);
     const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(ncols, (int64_t(256) << 20) / per_col));
-    DevBuf xin, half, full;
-    RocPlan fwd, inv;
-    MDSP_TRY(half.reserve(sizeof(cx<R>) * (size_t)(nspec * batch)));
-    MDSP_TRY(full.reserve(sizeof(cx<R>) * (size_t)(n * batch)));
+    HilbertCache& hc = hilbert_cache(sizeof(R) == 8);
+    std::lock_guard<std::mutex> lk(hc.mu);
+    if (hc.used && hc.last != st) MDSP_HIP(hipStreamSynchronize(hc.last));
+    hc.last = st;
+    hc.used = true;
+    DevBuf& xin = hc.xin;
+    DevBuf& half = hc.half;
+    DevBuf& full = hc.full;
+    RocPlan& fwd = hc.fwd;
+    RocPlan& inv = hc.inv;
     const bool packed = ldx == n;
+    if (hc.n != n || hc.batch != batch) {
+        hc.n = hc.batch = 0;
+        MDSP_HIP(hipStreamSynchronize(st));   // an earlier call on this stream may still use the buffers about to be replaced
+        MDSP_TRY(half.reserve(sizeof(cx<R>) * (size_t)(nspec * batch)));
+        MDSP_TRY(full.reserve(sizeof(cx<R>) * (size_t)(n * batch)));
+        MDSP_TRY(fwd.create(FftKind::R2C, sizeof(R) == 8, n, batch, false));
+        MDSP_TRY(inv.create(FftKind::C2C_INV, sizeof(R) == 8, n, batch, true));
+        hc.n = n;
+        hc.batch = batch;
+    }
     if (!packed) MDSP_TRY(xin.reserve(sizeof(R) * (size_t)(n * batch)));
-    MDSP_TRY(fwd.create(FftKind::R2C, sizeof(R) == 8, n, batch, false));
-    MDSP_TRY(inv.create(FftKind::C2C_INV, sizeof(R) == 8, n, batch, true));
     const unsigned gx = (unsigned)std::min<int64_t>(cdiv(n, 256), 4096);
     for (int64_t c0 = 0; c0 < ncols; c0 += batch) {
         const int64_t cnt = std::min<int64_t>(batch, ncols - c0);
@@ -1806,8 +1837,7 @@ template <typename R> int hilbert_run(const void* x, int64_t n, int64_t ncols, i
                            1.0 / (double)n);
         MDSP_LAUNCH_CHECK();
     }
-    MDSP_HIP(hipStreamSynchronize(st));   // plans and scratch die with this call
-    return MDSP_OK;
+    return MDSP_OK;   // stream-ordered: the cached scratch is next touched by launches on this stream, or after the wait above
 }
 
 }  // namespace

@@ -1,6 +1,7 @@
 """Host-side FIR tap generators needed as *inputs* of the hot path (DSP.jl ``src/Filters/design.jl``)."""
 from __future__ import annotations
 
+import functools
 import math
 from fractions import Fraction
 
@@ -37,7 +38,21 @@ def lowpass_firwindow(w, window, fs=2, scale=True) -> np.ndarray:
 
 
 def resample_filter(rate, *args) -> np.ndarray:
-    """design.jl:683-720.  Rational/integer ``rate`` -> (rel_bw=1.0, attenuation=60); float -> (Nphi=32, rel_bw, att)."""
+    """design.jl:683-720.  Rational/integer ``rate`` -> (rel_bw=1.0, attenuation=60); float -> (Nphi=32, rel_bw, att).
+    The design (a Kaiser window of a few thousand points) is memoised per argument tuple: ``resample(x, rate)`` redesigns the same
+    filter on every call."""
+    try:
+        return _resample_filter_cached(rate if isinstance(rate, float) else Fraction(rate), tuple(args)).copy()
+    except TypeError:           # unhashable argument: design without the memo
+        return _resample_filter(rate, *args)
+
+
+@functools.lru_cache(maxsize=32)
+def _resample_filter_cached(rate, args):
+    return _resample_filter(rate, *args)
+
+
+def _resample_filter(rate, *args) -> np.ndarray:
     if isinstance(rate, float):
         nphi = int(args[0]) if len(args) > 0 else 32
         rel_bw = args[1] if len(args) > 1 else 1.0

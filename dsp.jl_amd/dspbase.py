@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _dev, _lib
+from . import _dev, _lib, _plancache
 from ._lib import ArgumentError, UnsupportedError
 
 SMALL_FILT_CUTOFF = 66   # dspbase.jl:3
@@ -206,7 +206,8 @@ def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int 
             nfft = int(_lib.lib().mdsp_nextfastfft(full))           # _conv_kern_fft!: one transform of nextfastfft(outsize)
         else:
             nfft = optimalfftfiltlength(len(small_h), max(nu, nv))
-        plan = OlsPlan(small_h, nfft, max(nu, nv), _lib.OLS_CONV, engine)
+        plan = _plancache.plans.get(("ols", _plancache.ctx_key(), _plancache.array_key(small_h), int(nfft), _lib.OLS_CONV, engine),
+                                    lambda: OlsPlan(small_h, nfft, max(nu, nv), _lib.OLS_CONV, engine))
         cols, _ = _dev.to_columns(big, W)
         res = plan.exec(cols, full)
     res = _cast_result(res, T)[0]

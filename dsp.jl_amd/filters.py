@@ -9,7 +9,7 @@ from fractions import Fraction
 
 import numpy as np
 
-from . import _dev, _lib, design, dspbase
+from . import _dev, _lib, _plancache, design, dspbase
 from ._lib import ArgumentError, DomainError, UnsupportedError
 from .dspbase import SMALL_FILT_CUTOFF, OlsPlan, _cast_result, _compute_dtype, _host_vec, optimalfftfiltlength
 
@@ -44,7 +44,9 @@ def _fftfilt(b: np.ndarray, x, nfft: int, engine: int = _lib.ENGINE_AUTO):
         return _dev.from_columns(_dev.empty_columns(ncols, nx, Wc), shape, x)
     if nfft < len(b):
         raise ArgumentError("nfft must be at least length(b)")
-    plan = OlsPlan(b.astype(Wc), nfft, nx, _lib.OLS_FILT, engine)
+    taps = b.astype(Wc)
+    plan = _plancache.plans.get(("ols", _plancache.ctx_key(), _plancache.array_key(taps), int(nfft), _lib.OLS_FILT, engine),
+                                lambda: OlsPlan(taps, nfft, nx, _lib.OLS_FILT, engine))
     out = plan.exec(cols, nx)
     return _dev.from_columns(_cast_result(out, W) if W.kind in "iu" else out, shape, x)
 

@@ -11,7 +11,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from . import _dev, _lib, util
+from . import _dev, _lib, _plancache, util
 from ._lib import ArgumentError, DimensionMismatch, DomainError
 
 
@@ -152,7 +152,8 @@ def stft(s, n: int | None = None, noverlap: int | None = None, psdonly: bool = F
     cols, shape = _dev.to_columns(s, S)
     nch = cols.shape[0]
     k = frame_count(length, n, noverlap)
-    plan = _StftPlan(n, noverlap, nfft, win, fs * norm2, onesided, psdonly, S, engine)
+    plan = _plancache.plans.get(("stft", _plancache.ctx_key(), n, noverlap, nfft, _plancache.window_key(window), float(fs), onesided, bool(psdonly), np.dtype(S).str, engine),
+                                lambda: _StftPlan(n, noverlap, nfft, win, fs * norm2, onesided, psdonly, S, engine))
     out = _dev.torch.zeros((nch, k, plan.nout), dtype=_dev.torch_dtype(T), device=cols.device)     # zeros(...), :881
     if k and nch:
         _lib.check(_lib.lib().mdsp_stft_exec(plan._h, _dev.ptr(cols), length, nch, length, _dev.ptr(out), plan.nout, k * plan.nout,
@@ -263,7 +264,12 @@ def welch_pgram(s, n=None, noverlap=None, *, config: WelchConfig | None = None, 
         length = int(s.shape[0])
         n = length >> 3 if n is None else int(n)
         noverlap = n >> 1 if noverlap is None else int(noverlap)
-        config = WelchConfig(length, sdt, n=n, noverlap=noverlap, **kw)
+        if "window" in kw:      # without it the constructor warns (deprecated default) on every call, like the reference
+            key = ("welch", _plancache.ctx_key(), np.dtype(sdt).str, n, noverlap, kw.get("nfft"), kw.get("onesided"), float(kw.get("fs", 1)),
+                   _plancache.window_key(kw["window"]), kw.get("engine", _lib.ENGINE_AUTO))
+            config = _plancache.plans.get(key, lambda: WelchConfig(length, sdt, n=n, noverlap=noverlap, **kw))
+        else:
+            config = WelchConfig(length, sdt, n=n, noverlap=noverlap, **kw)
     if util.fftintype(sdt) != config.intype:
         raise ArgumentError(f"float(eltype(s)) = {util.fftintype(sdt)} doesn't match the eltype of the input buffer: {config.intype}.")
     cols, shape = _dev.to_columns(s, config.intype)
