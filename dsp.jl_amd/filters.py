@@ -344,16 +344,21 @@ def resample(x, rate, h=None, dims: int | None = None, Nphi: int = 32):
     ``dims``: every slice along ``dims`` is resampled independently (``mapslices``) -- on the device all slices are
     channels of one launch, each starting from the same reset + undelay!-ed state (:768-774).
     """
+    # resample() always starts from a reset, undelay!-ed filter (:696, :768-774), so the filter object -- polyphase banks in HBM,
+    # history buffers -- is reused across calls with the same taps and rate (LRU, _plancache) instead of being rebuilt each time
     if isinstance(rate, (float, np.floating)):
         rate = float(rate)
         if h is None:
             h = design.resample_filter(rate, Nphi)
-        sf = FIRFilter(h, rate, Nphi)
+        key = ("resample", _plancache.ctx_key(), _plancache.array_key(_host_vec(h)), rate, int(Nphi))
+        sf = _plancache.plans.get(key, lambda: FIRFilter(h, rate, Nphi))
     else:
         rate = Fraction(rate)
         if h is None:
             h = design.resample_filter(rate)
-        sf = FIRFilter(h, rate)
+        key = ("resample", _plancache.ctx_key(), _plancache.array_key(_host_vec(h)), rate, 0)
+        sf = _plancache.plans.get(key, lambda: FIRFilter(h, rate))
+    sf.reset()
     _undelay(sf)
     nd = len(x.shape)
     if nd == 1:
