@@ -12,7 +12,7 @@ from collections import OrderedDict
 
 
 class PlanCache:
-    def __init__(self, maxsize: int = 16):
+    def __init__(self, maxsize: int = 8):
         self._d: OrderedDict = OrderedDict()
         self._lock = threading.Lock()
         self.maxsize = maxsize
