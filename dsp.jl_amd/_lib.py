@@ -10,7 +10,8 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355dsp.so")
+# MDSP_LIB_TAG selects an experimental build made by `python dsp.jl_amd/build.py --tag T --cflags "..."` (tools/io_policy_sweep.sh)
+LIB_PATH = os.path.join(HERE, "libmi355dsp" + ("_" + os.environ["MDSP_LIB_TAG"] if os.environ.get("MDSP_LIB_TAG") else "") + ".so")
 
 # ---- status codes / dtype / engine enums (mirror include/mi355dsp.h) -----------------------------------
 OK, ERR_ARGUMENT, ERR_DOMAIN, ERR_DIMENSION, ERR_ASSERTION, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7

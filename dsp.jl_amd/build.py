@@ -58,7 +58,13 @@ def _compile(src: str, force: bool, verbose: bool) -> tuple[str, bool]:
     return obj, True
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tag: str = "", cflags: str = "") -> str:
+    """tag / cflags: an experimental variant (extra -D flags) built next to the product library as libmi355dsp_<tag>.so."""
+    global OBJ, LIB, CFLAGS
+    if tag:
+        OBJ = os.path.join(HERE, "csrc", "_obj_" + tag)
+        LIB = os.path.join(HERE, f"libmi355dsp_{tag}.so")
+        CFLAGS = CFLAGS + cflags.split()
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}")
     os.makedirs(OBJ, exist_ok=True)
@@ -76,4 +82,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    def _opt(name):
+        return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else ""
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, tag=_opt("--tag"), cflags=_opt("--cflags")))

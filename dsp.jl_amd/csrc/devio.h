@@ -19,6 +19,14 @@ using fft::cx;
 
 constexpr int OOB = (int)0x80000000;  // byte offset that is out of range for every descriptor built here
 
+// Cache policy (the `aux` immediate of the buffer instructions: bit 0 sc0, bit 1 nt, bit 4 sc1) of the streaming loads / stores.
+#ifndef MDSP_IO_AUX_LOAD
+#define MDSP_IO_AUX_LOAD 0
+#endif
+#ifndef MDSP_IO_AUX_STORE
+#define MDSP_IO_AUX_STORE 0
+#endif
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long long bytes) {
     const unsigned long long a = (unsigned long long)base;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
@@ -31,42 +39,42 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
 template <typename T> struct Ld;
 template <> struct Ld<float> {
     static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, int off) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, MDSP_IO_AUX_LOAD));
     }
     static __device__ __forceinline__ void store(float v, __amdgpu_buffer_rsrc_t r, int off) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, MDSP_IO_AUX_STORE);
     }
 };
 template <> struct Ld<double> {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t r, int off) {
-        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, MDSP_IO_AUX_LOAD);
         return __hiloint2double((int)v.y, (int)v.x);
     }
     static __device__ __forceinline__ void store(double d, __amdgpu_buffer_rsrc_t r, int off) {
         u2 v;
         v.x = (unsigned)__double2loint(d);
         v.y = (unsigned)__double2hiint(d);
-        __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, MDSP_IO_AUX_STORE);
     }
 };
 template <> struct Ld<cx<float>> {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ cx<float> load(__amdgpu_buffer_rsrc_t r, int off) {
-        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, MDSP_IO_AUX_LOAD);
         return {__uint_as_float(v.x), __uint_as_float(v.y)};
     }
     static __device__ __forceinline__ void store(cx<float> c, __amdgpu_buffer_rsrc_t r, int off) {
         u2 v;
         v.x = __float_as_uint(c.x);
         v.y = __float_as_uint(c.y);
-        __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, MDSP_IO_AUX_STORE);
     }
 };
 template <> struct Ld<cx<double>> {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ cx<double> load(__amdgpu_buffer_rsrc_t r, int off) {
-        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, MDSP_IO_AUX_LOAD);
         return {__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z)};
     }
     static __device__ __forceinline__ void store(cx<double> c, __amdgpu_buffer_rsrc_t r, int off) {
@@ -75,7 +83,7 @@ template <> struct Ld<cx<double>> {
         v.y = (unsigned)__double2hiint(c.x);
         v.z = (unsigned)__double2loint(c.y);
         v.w = (unsigned)__double2hiint(c.y);
-        __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, MDSP_IO_AUX_STORE);
     }
 };
 
