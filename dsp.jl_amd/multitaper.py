@@ -13,7 +13,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from . import _dev, _lib, util, windows
+from . import _dev, _lib, _plancache, util, windows
 from ._lib import ArgumentError, DimensionMismatch
 from .periodograms import Periodogram, Spectrogram, frame_count
 
@@ -124,10 +124,14 @@ def mt_pgram(s, config: MTConfig | None = None, *, onesided: bool | None = None,
     ``mt_pgram(signal, config::MTConfig)`` (multitaper.jl:177-245)."""
     if len(s.shape) != 1:
         raise ArgumentError("mt_pgram expects a vector")
-    if config is None:
+    if config is None:   # the keyword form builds its config on every call: keep the most recent ones (tapers in HBM, transforms)
         n = int(s.shape[0])
-        config = MTConfig(_signal_T(s), n, fs=fs, nfft=util.nextfastfft(n) if nfft is None else nfft, window=window, nw=nw,
-                          ntapers=math.ceil(2 * nw) - 1 if ntapers is None else ntapers, onesided=onesided, engine=engine)
+        nfft_ = util.nextfastfft(n) if nfft is None else nfft
+        ntap = math.ceil(2 * nw) - 1 if ntapers is None else ntapers
+        key = ("mt", _plancache.ctx_key(), np.dtype(_signal_T(s)).str, n, float(fs), nfft_, _plancache.window_key(window), float(nw), ntap,
+               onesided, engine)
+        config = _plancache.plans.get(key, lambda: MTConfig(_signal_T(s), n, fs=fs, nfft=nfft_, window=window, nw=nw, ntapers=ntap,
+                                                           onesided=onesided, engine=engine))
     if int(s.shape[0]) != config.n_samples:
         raise DimensionMismatch(f"Expected `signal` to be of length `config.n_samples`; got {int(s.shape[0])} and {config.n_samples}")   # :230-233
     out, _ = _psd(config, s, 0)
@@ -189,7 +193,12 @@ def mt_spectrogram(signal, *args, **kw) -> Spectrogram:
     else:
         n = args[0] if len(args) > 0 else length >> 3
         n_overlap = args[1] if len(args) > 1 else n >> 1
-        config = MTSpectrogramConfig(_signal_T(signal), length, n, n_overlap, **kw)
+        try:
+            key = ("mtspec", _plancache.ctx_key(), np.dtype(_signal_T(signal)).str, length, int(n), int(n_overlap),
+                   tuple(sorted((k, _plancache.window_key(v) if k == "window" else v) for k, v in kw.items())))
+            config = _plancache.plans.get(key, lambda: MTSpectrogramConfig(_signal_T(signal), length, n, n_overlap, **kw))
+        except TypeError:       # an unhashable keyword value: no caching
+            config = MTSpectrogramConfig(_signal_T(signal), length, n, n_overlap, **kw)
     if length != config.n_samples:
         raise DimensionMismatch(f"Expected `signal` to be of length `config.n_samples`; got {length} and {config.n_samples}")   # :318-321
     mc = config.mt_config

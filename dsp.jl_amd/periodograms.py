@@ -6,6 +6,7 @@ signatures, defaults, checks and normalisation; framing, windowing, the transfor
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import warnings
 from dataclasses import dataclass
 
@@ -67,14 +68,24 @@ def compute_window(window, n: int):
     if window is None:
         return None, float(n)
     if callable(window):
-        win = np.ascontiguousarray(window(n), dtype=np.float64)
-        return win, float(np.sum(win * win))
+        try:
+            return _window_of(window, int(n))          # memoised: a 65536-point hanning costs a millisecond of host time per call
+        except TypeError:                              # unhashable callable
+            win = np.ascontiguousarray(window(n), dtype=np.float64)
+            return win, float(np.sum(win * win))
     win = np.asarray(window.cpu() if hasattr(window, "cpu") else window)
     if len(win) != n:
         raise DimensionMismatch("length of window must match input")
     if win.dtype.kind == "c":
         raise _lib.UnsupportedError("complex windows are not accelerated")
     win = np.ascontiguousarray(win, dtype=np.float64)
+    return win, float(np.sum(win * win))
+
+
+@functools.lru_cache(maxsize=16)
+def _window_of(window, n: int):
+    win = np.ascontiguousarray(window(n), dtype=np.float64)
+    win.setflags(write=False)                          # shared between calls
     return win, float(np.sum(win * win))
 
 

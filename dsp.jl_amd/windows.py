@@ -1,6 +1,8 @@
 """Host-side window generators (DSP.jl ``src/windows.jl``): always Float64 vectors, evaluated once per plan."""
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from ._lib import ArgumentError, DomainError
@@ -142,6 +144,20 @@ def flattop(n, padding=0, zerophase=False):
 
 
 def dpss(n: int, nw: float, ntapers: int | None = None, padding: int = 0, zerophase: bool = False) -> np.ndarray:
+    """Memoised front of ``_dpss`` (the tridiagonal eigenproblem costs tens of milliseconds at n = 2^14, and ``mt_pgram(s)`` /
+    ``mt_spectrogram(s, n)`` ask for the same tapers on every call); returns a fresh copy."""
+    try:
+        return _dpss_cached(int(n), float(nw), None if ntapers is None else int(ntapers), int(padding), bool(zerophase)).copy()
+    except TypeError:
+        return _dpss(n, nw, ntapers, padding, zerophase)
+
+
+@functools.lru_cache(maxsize=16)
+def _dpss_cached(n, nw, ntapers, padding, zerophase):
+    return _dpss(n, nw, ntapers, padding, zerophase)
+
+
+def _dpss(n: int, nw: float, ntapers: int | None = None, padding: int = 0, zerophase: bool = False) -> np.ndarray:
     """``dpss(n, nw, ntapers=ceil(2nw)-1; padding, zerophase)`` (windows.jl:668-726): Slepian tapers, (n, ntapers).
 
     Host-side table generation like every window here (the reference solves the same symmetric tridiagonal

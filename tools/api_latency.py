@@ -16,6 +16,12 @@ import dsp_jl_amd as d
 x = torch.randn(1 << 20, device="cuda", dtype=torch.float32)
 b = np.random.default_rng(0).standard_normal(256).astype(np.float32)
 h = d.resample_filter(Fraction(3, 2)).astype(np.float32)
+xc = torch.randn(1 << 20, device="cuda", dtype=torch.complex64)
+img = torch.randn((512, 512), device="cuda", dtype=torch.float32)
+ker = torch.randn((9, 9), device="cuda", dtype=torch.float32)
+df = d.DF2TFilter(b[:64])
+ff = d.FIRFilter(h, Fraction(3, 2))
+cfg = d.WelchConfig(1 << 20, np.float32, n=4096, noverlap=2048, window=d.hanning)
 calls = {
     "filt(b[256], x[2^20])": lambda: d.filt(b, x),
     "filt(b[16], x[2^20]) (time domain)": lambda: d.filt(b[:16], x),
@@ -25,6 +31,16 @@ calls = {
     "resample(x[2^20], 1.2345)": lambda: d.resample(x, 1.2345),
     "conv(x[2^20], b[256])": lambda: d.conv(x, torch.from_numpy(b).cuda()),
     "hilbert(x[2^20])": lambda: d.hilbert(x),
+    "periodogram(x[2^16])": lambda: d.periodogram(x[:1 << 16], window=d.hanning),
+    "stft(xc[2^20], 1024, 768)": lambda: d.stft(xc, 1024, 768, window=d.hanning),
+    "xcorr(x[2^16], b[256])": lambda: d.xcorr(x[:1 << 16], torch.from_numpy(b).cuda()),
+    "filtfilt(b[256], x[2^20])": lambda: d.filtfilt(b, x),
+    "mt_pgram(x[2^14])": lambda: d.mt_pgram(x[:1 << 14]),
+    "mt_spectrogram(x[2^20], 1024, 512)": lambda: d.mt_spectrogram(x, 1024, 512),
+    "conv(img[512x512], k[9x9])": lambda: d.conv(img, ker),
+    "DF2TFilter(b[64]).filt(x[2^16])": lambda: df.filt(x[:1 << 16]),
+    "FIRFilter(3//2).filt(x[2^20]) (held object)": lambda: ff.filt(x),
+    "welch_pgram(x, config) (held object)": lambda: d.welch_pgram(x, cfg),
 }
 res = {}
 for name, fn in calls.items():
