@@ -288,7 +288,13 @@ def _cs_config(signal, config, kw):
     if dt.kind == "c":
         raise ArgumentError("Only real data is supported (with the default choice of `onesided=true`) for this operation.")
     T = dt if dt.kind == "f" else np.dtype(np.float64)
-    return MTCrossSpectraConfig(T, int(signal.shape[0]), int(signal.shape[1]), **kw)
+    nch, ns = int(signal.shape[0]), int(signal.shape[1])
+    try:                        # keyword form: keep the most recent configs (tapers, transforms, work buffers) alive
+        key = ("mtcs", _plancache.ctx_key(), np.dtype(T).str, nch, ns,
+               tuple(sorted((k, _plancache.window_key(v) if k == "window" else (tuple(v) if isinstance(v, (list, tuple)) else v)) for k, v in kw.items())))
+        return _plancache.plans.get(key, lambda: MTCrossSpectraConfig(T, nch, ns, **kw))
+    except TypeError:           # an unhashable keyword value: no caching
+        return MTCrossSpectraConfig(T, nch, ns, **kw)
 
 
 def mt_cross_power_spectra(signal, config: MTCrossSpectraConfig | None = None, **kw) -> CrossPowerSpectra:
