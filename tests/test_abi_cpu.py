@@ -302,3 +302,36 @@ def test_window_generators_match_reference_goldens(golden):
         d.nuttall(128, 2)
     with pytest.raises(d.DomainError):
         d.tukey(128, 1.5)
+
+
+def test_plan_cache_lru_semantics():
+    """dsp.jl_amd/_plancache.py: most-recently-used retention, eviction order, content keys of arrays and windows."""
+    from dsp_jl_amd import _plancache as pc
+    c = pc.PlanCache(maxsize=3)
+    made = []
+
+    def make(tag):
+        made.append(tag)
+        return object()
+
+    a = c.get("a", lambda: make("a"))
+    assert c.get("a", lambda: make("a2")) is a and made == ["a"] and (c.hits, c.misses) == (1, 1)
+    c.get("b", lambda: make("b")); c.get("c", lambda: make("c"))
+    c.get("a", lambda: make("a3"))                       # refresh a: b is now the oldest
+    c.get("d", lambda: make("d"))                        # evicts b
+    assert made == ["a", "b", "c", "d"]
+    c.get("b", lambda: make("b2"))                       # rebuilt, evicts c
+    assert made[-1] == "b2" and c.get("a", lambda: make("a4")) is a
+    c.clear()
+    assert c.get("a", lambda: make("a5")) is not a
+    x = np.arange(6, dtype=np.float32)
+    assert pc.array_key(x) == pc.array_key(x.copy()) and pc.array_key(x) != pc.array_key(x.astype(np.float64))
+    assert pc.array_key(x) != pc.array_key(x.reshape(2, 3)) and pc.array_key(x) != pc.array_key(x[::-1])
+    assert pc.window_key(None) is None and pc.window_key(d.hanning) is d.hanning and pc.window_key(x) == pc.array_key(x)
+    # memoised designs return fresh arrays with identical contents
+    h1, h2 = d.resample_filter(1.2345), d.resample_filter(1.2345)
+    assert h1 is not h2 and np.array_equal(h1, h2)
+    h1[0] = 123.0
+    assert d.resample_filter(1.2345)[0] != 123.0
+    t1 = d.dpss(64, 4); t1[0, 0] = 9.0
+    assert d.dpss(64, 4)[0, 0] != 9.0
