@@ -261,11 +261,12 @@ int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 //
 // The reference advances a Float64 phase accumulator serially (update! :567-577): phiAcc += Delta; on overflow
 // (dx, phiAcc) = divrem(phiAcc, Nphi), xIdx += dx; alpha = frac(phiAcc), phiIdx = 1 + trunc(phiAcc).  Every step
-// rounds, so the trajectory has no closed form; to stay bit-exact with it the HOST runs the same IEEE operations
-// once per call (arb_trajectory; ~2 ns per output, shared by all channels, cached per (state, length)) and hands the
-// device the exact (xIdx, phiAcc) at every 64th output.  A workgroup replays 64 steps per lane from those anchors
-// with the same operations (v_add_f64 / v_fma_f64 / v_floor_f64 are IEEE-exact) into an LDS record per output, then
-// all threads evaluate   y = muladd(yUpper, alpha, yLower)   (:616) with yLower/yUpper the two tapsPerPhase-term
+// rounds, so the index sequence depends on the accumulated roundings.  To stay bit-exact with it, anchors -- the exact
+// (xIdx, phiAcc) of every ARB_BLK-th output -- are produced either by the same IEEE operations run serially on the host
+// (arb_trajectory, short streams) or by the parallel integer evaluation of arb_scan.h on the device (long streams), cached
+// per (state, length) and shared by all channels.  Wave 0 of a workgroup replays ARB_BLK updates per lane from those anchors
+// (v_add_f64 / v_floor_f64 are IEEE-exact; ArbStep::fast) into an LDS record per output, then all threads evaluate
+//   y = muladd(yUpper, alpha, yLower)   (:616) with yLower/yUpper the two tapsPerPhase-term
 // chains (oldest sample first) over the input span staged in LDS.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int ARB_BLK = 16;   // outputs per anchor (16 bytes each: 1 B of extra traffic per output); one lane of wave 0 replays one block
