@@ -247,6 +247,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Gsamples/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                                   # rank 0 may still be printing / measuring its yardsticks: leave together
         dist.destroy_process_group()
 
 
