@@ -41,7 +41,7 @@ class PlanCache:
 def array_key(a):
     """Hashable identity of a host array's contents."""
     import numpy as np
-    a = np.ascontiguousarray(a)
+    a = np.ascontiguousarray(a.cpu() if hasattr(a, "cpu") else a)
     return (a.dtype.str, a.shape, a.tobytes())
 
 
@@ -49,7 +49,7 @@ def window_key(window):
     """Windows are functions (hashable as they are), None, or vectors (keyed by content)."""
     if window is None or callable(window):
         return window
-    return array_key(window)
+    return array_key(window.cpu() if hasattr(window, "cpu") else window)   # device tensors are keyed by their host copy
 
 
 def ctx_key():
