@@ -335,3 +335,39 @@ def test_plan_cache_lru_semantics():
     assert d.resample_filter(1.2345)[0] != 123.0
     t1 = d.dpss(64, 4); t1[0, 0] = 9.0
     assert d.dpss(64, 4)[0, 0] != 9.0
+
+
+def test_time_split_helpers_cover_every_frame_and_sample_once():
+    """frame_shard / frame_span / filt_time_split_span (SURVEY 8e "next"): the shards partition the frames, neighbouring spans overlap
+    by n - hop samples, a span holds exactly its frames, and filter halos are nb - 1 samples (clipped at the stream start)."""
+    rng = np.random.default_rng(12)
+    for _ in range(300):
+        n = int(rng.integers(2, 400)); nov = int(rng.integers(0, n)); hop = n - nov
+        length = int(rng.integers(n, 20000)); world = int(rng.integers(1, 9))
+        K = opg.frame_count(length, n, nov)
+        shards = [d.frame_shard(K, r, world) for r in range(world)]
+        assert [k for sh in shards for k in sh] == list(range(K))
+        prev_hi = None
+        for sh in shards:
+            lo, hi = d.frame_span(sh, n, nov)
+            if len(sh) == 0:
+                assert (lo, hi) == (0, 0)
+                continue
+            assert hi <= length and opg.frame_count(hi - lo, n, nov) == len(sh) and lo == sh.start * hop
+            if prev_hi is not None:
+                assert prev_hi - lo == n - hop
+            prev_hi = hi
+        nb = int(rng.integers(1, 300)); lo = int(rng.integers(0, length)); hi = int(rng.integers(lo, length + 1))
+        slo, shi = d.filt_time_split_span(lo, hi, nb)
+        assert shi == hi and slo == max(0, lo - (nb - 1))
+
+
+def test_arbitrary_scan_declines_what_it_cannot_model():
+    """Rates outside the integer model (more than three rounding bits, more than eight input samples per output) and streams that end
+    inside the pilot are reported as not handled -- the product then runs the serial loop."""
+    for rate, xlen in ((9.5, 50000), (0.05, 2_000_000), (1.1, 100)):
+        used, passes, *_ = _c_trajectory_scan(0.3, 1, rate, 32, xlen, 1024)
+        assert not used
+    used, passes, sx, sa, snout, saend, sdend = _c_trajectory_scan(0.3, 1, 6.9, 32, 30000, 1024)
+    ax, aa, nout, aend, dend = _c_trajectory(0.3, 1, 6.9, 32, 30000, block=16)
+    assert used and (snout, saend, sdend) == (nout, aend, dend) and np.array_equal(sx, ax) and np.array_equal(sa, aa)
