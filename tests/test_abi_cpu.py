@@ -228,6 +228,28 @@ def test_arbitrary_parallel_scan_is_bit_exact():
     assert scanned >= len(cases) - 3                     # the scan certifies itself on (almost) every case
 
 
+def test_argument_errors_of_the_array_paths_come_before_device_work():
+    """conv for arrays / separable conv / xcorr: the reference's argument errors (dspbase.jl:754, :872-880; test/dsp.jl:172, :347-356)
+    are raised on the host, before anything needs a device."""
+    with pytest.raises(d.ArgumentError):
+        d.conv(np.ones((2, 2)), np.ones((2, 2)), algorithm="quantum")
+    with pytest.raises(d.ArgumentError):
+        d.conv(np.ones((2, 2)), np.ones(2), np.ones((2, 2)))             # conv(u, v', A) takes two vectors and a matrix
+    with pytest.raises(TypeError):
+        d.xcorr(np.ones((2, 2)), np.ones((2, 2)))
+    with pytest.raises(d.ArgumentError):
+        d.xcorr(np.ones(2), np.ones(2), padmode="bug")
+    with pytest.raises(d.DimensionMismatch):
+        d.xcorr(np.ones(1), np.ones(2), scaling="biased")
+    if _lib.device_count() == 0:
+        with pytest.raises(d.DeviceError):
+            d.conv(np.ones((2, 2)), np.ones((2, 2)))
+        with pytest.raises(d.DeviceError):
+            d.hilbert(np.ones(8))
+        with pytest.raises(d.DeviceError):
+            d.resample(np.ones(64), 1.5)
+
+
 def test_arbitrary_device_replay_update_is_exact():
     """The branch-free update the device replays between anchors (two candidate quotients, Sterbenz-exact remainder) against
     the reference-form update (stream_filt.jl:567-577), step by step: up- and down-sampling, large skips, odd Nphi."""
