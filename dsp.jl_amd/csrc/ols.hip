@@ -40,13 +40,13 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void ols_segment_kernel(const T* __restrict__ x, T* __restrict__ td, int64_t nx, int64_t ldx,
                                                           int64_t nblocks, int64_t L, int nb, int nfft, int64_t u0, int64_t nunits) {
-    const int64_t u = u0 + blockIdx.y;
+    const int64_t u = u0 + blockIdx.x;
     if (u >= nunits) return;
     const int64_t col = u / nblocks, g = u - col * nblocks;
     const int64_t start = g * L - (nb - 1);
     const T* xc = x + col * ldx;
-    T* dst = td + (int64_t)blockIdx.y * nfft;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfft; i += gridDim.x * blockDim.x) {
+    T* dst = td + (int64_t)blockIdx.x * nfft;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nfft; i += gridDim.y * blockDim.x) {
         const int64_t idx = start + i;
         T v{};
         if (idx >= 0 && idx < nx) v = xc[idx];
@@ -57,24 +57,24 @@ __global__ __launch_bounds__(256) void ols_segment_kernel(const T* __restrict__ 
 // K2: fd[b*nspec + k] *= H[k]
 template <typename R>
 __global__ __launch_bounds__(256) void ols_cmul_kernel(cx<R>* __restrict__ fd, const cx<R>* __restrict__ H, int nspec, int64_t count) {
-    const int64_t b = blockIdx.y;
+    const int64_t b = blockIdx.x;
     if (b >= count) return;
     cx<R>* row = fd + b * nspec;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nspec; k += gridDim.x * blockDim.x) row[k] = fft::cmul(row[k], H[k]);
+    for (int k = blockIdx.y * blockDim.x + threadIdx.x; k < nspec; k += gridDim.y * blockDim.x) row[k] = fft::cmul(row[k], H[k]);
 }
 
 // K3: y[col*ldy + g*L + j] = td[(u-u0)*nfft + nb-1 + j]
 template <typename T>
 __global__ __launch_bounds__(256) void ols_save_kernel(const T* __restrict__ td, T* __restrict__ y, int64_t nout, int64_t ldy,
                                                        int64_t nblocks, int64_t L, int nb, int nfft, int64_t u0, int64_t nunits) {
-    const int64_t u = u0 + blockIdx.y;
+    const int64_t u = u0 + blockIdx.x;
     if (u >= nunits) return;
     const int64_t col = u / nblocks, g = u - col * nblocks;
     const int64_t off = g * L;
     const int64_t cnt = std::min<int64_t>(L, nout - off);
-    const T* src = td + (int64_t)blockIdx.y * nfft + (nb - 1);
+    const T* src = td + (int64_t)blockIdx.x * nfft + (nb - 1);
     T* yc = y + col * ldy + off;
-    for (int64_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += (int64_t)gridDim.x * blockDim.x) yc[j] = src[j];
+    for (int64_t j = blockIdx.y * blockDim.x + threadIdx.x; j < cnt; j += (int64_t)gridDim.y * blockDim.x) yc[j] = src[j];
 }
 
 // ======================================================================================================
@@ -392,23 +392,23 @@ int exec_rocfft(mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, i
     const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
     for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
         const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
-        hipLaunchKernelGGL(ols_segment_kernel<T>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, (const T*)x, pl->td.as<T>(), nx, ldx,
+        hipLaunchKernelGGL(ols_segment_kernel<T>, dim3((unsigned)cnt, gx), dim3(256), 0, s, (const T*)x, pl->td.as<T>(), nx, ldx,
                            nblocks, L, (int)pl->nb, (int)nfft, u0, nunits);
         MDSP_LAUNCH_CHECK();
         if (CPLX) {
             MDSP_TRY(pl->fwd.exec(pl->td.p, nullptr, s));
-            hipLaunchKernelGGL(ols_cmul_kernel<R>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, pl->td.as<cx<R>>(), pl->H.as<cx<R>>(),
+            hipLaunchKernelGGL(ols_cmul_kernel<R>, dim3((unsigned)cnt, gx), dim3(256), 0, s, pl->td.as<cx<R>>(), pl->H.as<cx<R>>(),
                                (int)nspec, cnt);
             MDSP_LAUNCH_CHECK();
             MDSP_TRY(pl->inv.exec(pl->td.p, nullptr, s));
         } else {
             MDSP_TRY(pl->fwd.exec(pl->td.p, pl->fd.p, s));
-            hipLaunchKernelGGL(ols_cmul_kernel<R>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, pl->fd.as<cx<R>>(), pl->H.as<cx<R>>(),
+            hipLaunchKernelGGL(ols_cmul_kernel<R>, dim3((unsigned)cnt, gx), dim3(256), 0, s, pl->fd.as<cx<R>>(), pl->H.as<cx<R>>(),
                                (int)nspec, cnt);
             MDSP_LAUNCH_CHECK();
             MDSP_TRY(pl->inv.exec(pl->fd.p, pl->td.p, s));
         }
-        hipLaunchKernelGGL(ols_save_kernel<T>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, pl->td.as<T>(), (T*)y, nout, ldy, nblocks, L,
+        hipLaunchKernelGGL(ols_save_kernel<T>, dim3((unsigned)cnt, gx), dim3(256), 0, s, pl->td.as<T>(), (T*)y, nout, ldy, nblocks, L,
                            (int)pl->nb, (int)nfft, u0, nunits);
         MDSP_LAUNCH_CHECK();
     }
@@ -548,7 +548,7 @@ int mdsp_ols_segment(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t 
     for (int64_t b0 = 0; b0 < nblocks; b0 += 32768) {
         const int64_t cnt = std::min<int64_t>(32768, nblocks - b0);
 #define SEG(TT)                                                                                                                      \
-    hipLaunchKernelGGL(ols_segment_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, s, (const TT*)x_dev, (TT*)seg_dev + b0 * nfft, nx, \
+    hipLaunchKernelGGL(ols_segment_kernel<TT>, dim3((unsigned)cnt, gx), dim3(256), 0, s, (const TT*)x_dev, (TT*)seg_dev + b0 * nfft, nx, \
                        (int64_t)0, big, plan->L, (int)plan->nb, (int)nfft, first_block + b0, total)
         switch (plan->dtype) {
             case MDSP_F32: SEG(float); break;

@@ -63,12 +63,12 @@ __device__ __forceinline__ cx<double> win_mul(cx<double> s, double w) { return {
 template <typename T>
 __global__ __launch_bounds__(256) void frame_window_kernel(const T* __restrict__ s, T* __restrict__ fr, const double* __restrict__ win,
                                                            int64_t lds_, int64_t K, int64_t hop, int n, int nfft, int64_t u0, int64_t nunits) {
-    const int64_t u = u0 + blockIdx.y;
+    const int64_t u = u0 + blockIdx.x;
     if (u >= nunits) return;
     const int64_t ch = u / K, f = u - ch * K;
     const T* src = s + ch * lds_ + f * hop;
-    T* dst = fr + (int64_t)blockIdx.y * nfft;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfft; i += gridDim.x * blockDim.x) {
+    T* dst = fr + (int64_t)blockIdx.x * nfft;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nfft; i += gridDim.y * blockDim.x) {
         T v{};
         if (i < n) v = win ? win_mul(src[i], win[i]) : src[i];
         dst[i] = v;
@@ -155,12 +155,12 @@ template <typename R, bool PSD, bool HALF>
 __global__ __launch_bounds__(256) void stft_store_kernel(const cx<R>* __restrict__ spec, void* __restrict__ out, int nspec, int nfft, int nout,
                                                          int64_t K, int64_t ldo, int64_t chs, int64_t u0, int64_t nunits, double r, int onesided,
                                                          int accumulate) {
-    const int64_t u = u0 + blockIdx.y;
+    const int64_t u = u0 + blockIdx.x;
     if (u >= nunits) return;
     const int64_t ch = u / K, f = u - ch * K;
-    const cx<R>* z = spec + (int64_t)blockIdx.y * nspec;
+    const cx<R>* z = spec + (int64_t)blockIdx.x * nspec;
     const R m1 = (R)(1.0 / r), m2 = (R)(2.0 / r);
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += gridDim.x * blockDim.x) {
+    for (int j = blockIdx.y * blockDim.x + threadIdx.x; j < nout; j += gridDim.y * blockDim.x) {
         int k = j;
         bool conj = false;
         if (HALF && j > nfft / 2) {
@@ -726,7 +726,7 @@ extern "C" int mdsp_frames(const void* s_dev, int64_t len, int dtype, int64_t n,
     for (int64_t c0 = 0; c0 < count; c0 += 32768) {
         const int64_t cnt = std::min<int64_t>(32768, count - c0);
 #define FR(TT)                                                                                                                          \
-    hipLaunchKernelGGL(frame_window_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, (const TT*)s_dev, (TT*)frames_dev + c0 * nfft, \
+    hipLaunchKernelGGL(frame_window_kernel<TT>, dim3((unsigned)cnt, gx), dim3(256), 0, st, (const TT*)s_dev, (TT*)frames_dev + c0 * nfft, \
                        window_host ? win.as<double>() : nullptr, (int64_t)0, K, hop, (int)n, (int)nfft, first + c0, first + count)
         switch (dtype) {
             case MDSP_F32: FR(float); break;
@@ -780,7 +780,7 @@ int welch_exec_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t
         const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
         for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
             const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
-            hipLaunchKernelGGL(frame_window_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
+            hipLaunchKernelGGL(frame_window_kernel<TT>, dim3((unsigned)cnt, gx), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
                                pl->have_win ? pl->win.as<double>() : nullptr, lds_, K, hop, (int)n, (int)nfft, u0, nunits);
             MDSP_LAUNCH_CHECK();
             MDSP_TRY(pl->fwd.exec(pl->fr.p, pl->spec.p, st));
@@ -1254,7 +1254,7 @@ int stft_exec_rocfft(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t n
     const bool direct = !pl->psd_only && nout == nspec && ldo == nout && (nch == 1 || chs == K * (int64_t)nout) && !getenv("MDSP_STFT_NODIRECT");
     for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
         const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
-        hipLaunchKernelGGL(frame_window_kernel<TT>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
+        hipLaunchKernelGGL(frame_window_kernel<TT>, dim3((unsigned)cnt, gx), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
                            pl->have_win ? pl->win_ptr : nullptr, lds_, K, hop, (int)n, (int)nfft, u0, nunits);
         MDSP_LAUNCH_CHECK();
         // raw STFT whose output matrix has exactly the batched transform's layout (contiguous columns of nspec bins, channels
@@ -1264,7 +1264,7 @@ int stft_exec_rocfft(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t n
             continue;
         }
         MDSP_TRY(pl->fwd.exec(pl->fr.p, pl->spec.p, st));
-        const dim3 g(gx, (unsigned)cnt);
+        const dim3 g((unsigned)cnt, gx);
         if (pl->psd_only)
             hipLaunchKernelGGL((stft_store_kernel<R, true, !CPLX>), g, dim3(256), 0, st, pl->spec.as<cx<R>>(), out, nspec, (int)nfft, nout, K, ldo, chs, u0,
                                nunits, pl->r, pl->onesided, pl->accumulate);
@@ -1745,11 +1745,11 @@ namespace {
 
 template <typename R>
 __global__ __launch_bounds__(256) void hilbert_spectrum_kernel(const cx<R>* __restrict__ half, cx<R>* __restrict__ full, int64_t n, int64_t nspec, int64_t ncols) {
-    const int64_t col = blockIdx.y;
+    const int64_t col = blockIdx.x;
     const cx<R>* h = half + col * nspec;
     cx<R>* f = full + col * n;
     const int64_t last2 = n / 2 + (n & 1);   // 1-based indices 2 .. N/2 + isodd(N) are doubled
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.y * blockDim.x) {
         cx<R> v = {(R)0, (R)0};
         if (i < nspec) {
             v = h[i];
@@ -1761,9 +1761,9 @@ __global__ __launch_bounds__(256) void hilbert_spectrum_kernel(const cx<R>* __re
 
 template <typename R>
 __global__ __launch_bounds__(256) void hilbert_scale_kernel(const cx<R>* __restrict__ in, cx<R>* __restrict__ out, int64_t n, int64_t ldo, double inv_n) {
-    const int64_t col = blockIdx.y;
+    const int64_t col = blockIdx.x;
     const R s = (R)inv_n;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.y * blockDim.x) {
         const cx<R> v = in[col * n + i];
         out[col * ldo + i] = {v.x * s, v.y * s};
     }
@@ -1830,10 +1830,10 @@ template <typename R> int hilbert_run(const void* x, int64_t n, int64_t ncols, i
             }
         }
         MDSP_TRY(fwd.exec(const_cast<R*>(src), half.p, st));
-        hipLaunchKernelGGL(hilbert_spectrum_kernel<R>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, half.as<cx<R>>(), full.as<cx<R>>(), n, nspec, cnt);
+        hipLaunchKernelGGL(hilbert_spectrum_kernel<R>, dim3((unsigned)cnt, gx), dim3(256), 0, st, half.as<cx<R>>(), full.as<cx<R>>(), n, nspec, cnt);
         MDSP_LAUNCH_CHECK();
         MDSP_TRY(inv.exec(full.p, full.p, st));
-        hipLaunchKernelGGL(hilbert_scale_kernel<R>, dim3(gx, (unsigned)cnt), dim3(256), 0, st, full.as<cx<R>>(), static_cast<cx<R>*>(out) + c0 * ldo, n, ldo,
+        hipLaunchKernelGGL(hilbert_scale_kernel<R>, dim3((unsigned)cnt, gx), dim3(256), 0, st, full.as<cx<R>>(), static_cast<cx<R>*>(out) + c0 * ldo, n, ldo,
                            1.0 / (double)n);
         MDSP_LAUNCH_CHECK();
     }

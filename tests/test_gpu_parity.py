@@ -1231,3 +1231,27 @@ def test_firarbitrary_channel_groups_every_dtype(d, Tx):
             o.h, o.pfb, o.dpfb = h.astype(np.float64), o.pfb.astype(np.float64), o.dpfb.astype(np.float64)
             ref = o.filt(x[:, nch - 1].astype(wide))
             assert relerr(y[:, nch - 1], ref) < (3e-6 if single else 1e-12)
+
+
+def test_rocfft_engine_more_than_65535_units_per_chunk(d, torch):
+    # Small transforms on long signals put > 65535 blocks / frames in one rocFFT-engine chunk (the block index rides on gridDim.x,
+    # whose limit is 2^31 - 1; gridDim.y stops at 65535): conv(f32[4M], f32[12]) -> nfft 64, ~75k blocks; welch / stft with n ~ 100.
+    from oracle import dspbase as odsp, periodograms as opg, windows as ow
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(4_000_000).astype(np.float32)
+    b = rng.standard_normal(12).astype(np.float32)
+    y = d.fftfilt(b, x, 64, engine=d.ENGINE_ROCFFT)
+    m = 3_990_000
+    ref_tail = odsp.filt_ba(b.astype(np.float64), 1.0, x[m - 11:].astype(np.float64))[11:]
+    assert relerr(y[m:], ref_tail) < TOL32
+    assert relerr(y[:5000], odsp.filt_ba(b.astype(np.float64), 1.0, x[:5000].astype(np.float64))) < TOL32
+    s = rng.standard_normal(9_000_000).astype(np.float32)
+    for n, nov, nfft in ((128, 64, 128), (100, 0, 120)):
+        got = d.welch_pgram(s, n, nov, nfft=nfft, window=d.hanning, engine=d.ENGINE_ROCFFT).power
+        assert relerr(got, opg.welch_pgram(s, n, nov, nfft=nfft, window=ow.hanning, dtype=np.float64).power) < TOL32, (n, nov)
+    S = d.stft(torch.from_numpy(s).cuda(), 100, 0, nfft=120, window=d.hanning, engine=d.ENGINE_ROCFFT)
+    K = d.frame_count(len(s), 100, 0)
+    assert S.shape == (61, K) and K > 65535
+    for f0 in (0, 65534, K - 3):
+        ref = opg.stft(s[f0 * 100:(f0 + 3) * 100], 100, 0, nfft=120, window=ow.hanning, dtype=np.float64)
+        assert relerr(S[:, f0:f0 + 3].cpu().numpy(), ref) < TOL32, f0
