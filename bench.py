@@ -194,15 +194,13 @@ def main():
         _lib.check(lib.mdsp_event_elapsed_ms(c0, c1, C.byref(ms)))
         copy_gbs = 3 * 2 * n * 4 / (ms.value * 1e-3) / 1e9
         # read-only yardstick (float4 loads summed, nothing written): what a 4 B/sample reader like the Welch kernel could reach
-        os.environ["MDSP_COPY_MODE"] = "4"
-        _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))
+        _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), n * 4, 4, 8, stream))
         _lib.check(lib.mdsp_event_record(c0, stream))
         for _ in range(3):
-            _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))
+            _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), n * 4, 4, 8, stream))
         _lib.check(lib.mdsp_event_record(c1, stream))
         _lib.check(lib.mdsp_event_elapsed_ms(c0, c1, C.byref(ms)))
         read_gbs = 3 * n * 4 / (ms.value * 1e-3) / 1e9
-        del os.environ["MDSP_COPY_MODE"]
         ols_gbs = 8.0 * n / (ols_ms * 1e-3) / 1e9
         welch_gbs = 4.0 * n / (welch_ms * 1e-3) / 1e9
         traffic = None

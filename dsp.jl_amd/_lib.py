@@ -52,6 +52,8 @@ PROTOTYPES = {
     "mdsp_last_error_string": (C.c_char_p, []),
     "mdsp_init": (ci, [ci]),
     "mdsp_shutdown": (ci, []),
+    "mdsp_reload_tunables": (ci, []),
+    "mdsp_debug_knobs": (ci, []),
     "mdsp_device_count": (ci, [pint]),
     "mdsp_malloc": (ci, [pvp, C.c_size_t]),
     "mdsp_free": (ci, [vp]),
@@ -124,6 +126,7 @@ PROTOTYPES = {
     "mdsp_event_record": (ci, [vp, vp]),
     "mdsp_event_elapsed_ms": (ci, [vp, vp, C.POINTER(C.c_float)]),
     "mdsp_copy_bench": (ci, [vp, vp, C.c_size_t, vp]),
+    "mdsp_copy_bench_mode": (ci, [vp, vp, C.c_size_t, ci, ci, vp]),
 }
 
 _lock = threading.Lock()
@@ -158,6 +161,16 @@ def lib() -> C.CDLL:
                 fn.argtypes = args
             _lib = handle
     return _lib
+
+
+def set_tunable(name: str, value) -> None:
+    """Set (or, with None, clear) a tuning variable in the environment AND make the library re-read it: libmi355dsp reads its
+    environment once (mdsp_init / first use), never on exec or plan paths.  Tuning tools only."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    check(lib().mdsp_reload_tunables())
 
 
 def check(status: int) -> None:

@@ -19,15 +19,69 @@ int set_error(int code, const char* fmt, ...) {
 void clear_error() { g_err.clear(); }
 
 int device_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    static int cus[64] = {0};          // per device: a process may drive several GPUs
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        cus[dev] = n > 0 ? n : 256;
     }
-    return cus;
+    return cus[dev];
+}
+
+// ---- tunables: the environment is read here and nowhere else ---------------------------------------------
+static Tunables g_tun;
+static std::once_flag g_tun_once;
+static std::mutex g_tun_mu;
+
+static void read_tunables_locked() {
+    Tunables t;
+    auto geti = [](const char* name, int def) {
+        const char* e = getenv(name);
+        return e && *e ? atoi(e) : def;
+    };
+    if (const char* e = getenv("MDSP_ENGINE")) {
+        if (!strcmp(e, "rocfft")) t.engine = MDSP_ENGINE_ROCFFT;
+        else if (!strcmp(e, "fused")) t.engine = MDSP_ENGINE_FUSED;
+    }
+    t.wg_per_cu = std::max(0, geti("MDSP_WG_PER_CU", 0));
+    t.runs_per_slot = std::max(1, geti("MDSP_RUNS_PER_SLOT", 1));
+    t.ols_variant = geti("MDSP_OLS_VARIANT", 0);
+    t.welch_variant = geti("MDSP_WELCH_VARIANT", 0);
+    t.stft_variant = geti("MDSP_STFT_VARIANT", 1);
+    t.rocfft_chunk_mib = std::max(1, geti("MDSP_ROCFFT_CHUNK_MIB", 192));
+    t.fir_lds_kib = std::max(4, geti("MDSP_FIR_LDS_KIB", 20));
+    t.arb_nch = geti("MDSP_ARB_NCH", 4);
+    t.arb_tile = std::max(0, geti("MDSP_ARB_TILE", 0));
+    t.arb_scan = geti("MDSP_ARB_SCAN", 1);
+    if (const char* e = getenv("MDSP_ARB_SCAN_MIN")) t.arb_scan_min = atoll(e);
+    t.host_chunk_mib = std::max(1, geti("MDSP_HOST_CHUNK_MIB", 64));
+#ifdef MDSP_DEBUG_KNOBS
+    t.ablate = geti("MDSP_ABLATE", 0);
+    t.welch_nohalf = getenv("MDSP_WELCH_NOHALF") != nullptr;
+    t.stft_noshift = getenv("MDSP_STFT_NOSHIFT") != nullptr;
+    t.stft_nopair = getenv("MDSP_STFT_NOPAIR") != nullptr;
+    t.stft_nodirect = getenv("MDSP_STFT_NODIRECT") != nullptr;
+    t.fir_generic = getenv("MDSP_FIR_GENERIC") != nullptr;
+    t.fir_identity_lanes = getenv("MDSP_FIR_IDENTITY_LANES") != nullptr;
+    t.mt_passes = getenv("MDSP_MT_PASSES") != nullptr;
+    t.arb_prof = getenv("MDSP_ARB_PROF") != nullptr;
+#endif
+    g_tun = t;
+}
+const Tunables& tunables() {
+    std::call_once(g_tun_once, [] {
+        std::lock_guard<std::mutex> lk(g_tun_mu);
+        read_tunables_locked();
+    });
+    return g_tun;
+}
+void reload_tunables() {
+    (void)tunables();
+    std::lock_guard<std::mutex> lk(g_tun_mu);
+    read_tunables_locked();
 }
 
 // ---- pure index arithmetic ---------------------------------------------------------------------------
@@ -92,10 +146,24 @@ int mdsp_init(int device) {
     if (n <= 0) MDSP_FAIL(MDSP_ERR_DEVICE, "no HIP device visible: libmi355dsp has no CPU fallback");
     if (device < 0 || device >= n) MDSP_FAIL(MDSP_ERR_ARGUMENT, "device %d out of range [0,%d)", device, n);
     MDSP_HIP(hipSetDevice(device));
+    (void)tunables();   // the environment is read once, here (or on first use)
     return MDSP_OK;
 }
 
 int mdsp_shutdown(void) { return MDSP_OK; }
+
+int mdsp_reload_tunables(void) {
+    reload_tunables();
+    return MDSP_OK;
+}
+
+int mdsp_debug_knobs(void) {
+#ifdef MDSP_DEBUG_KNOBS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int mdsp_malloc(void** dev_ptr, size_t bytes) {
     if (!dev_ptr) MDSP_FAIL(MDSP_ERR_ARGUMENT, "dev_ptr is NULL");
@@ -267,16 +335,20 @@ __global__ __launch_bounds__(256) void mdsp_fill_kernel(float4* __restrict__ dst
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = v;
 }
 
-extern "C" int mdsp_copy_bench(void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
+extern "C" int mdsp_copy_bench_mode(void* dst_dev, const void* src_dev, size_t bytes, int mode, int wgs, void* stream) {
     if (bytes % 16) MDSP_FAIL(MDSP_ERR_ARGUMENT, "bytes must be a multiple of 16");
     const size_t n4 = bytes / 16;
     if (n4 == 0) return MDSP_OK;
-    const int mode = getenv("MDSP_COPY_MODE") ? atoi(getenv("MDSP_COPY_MODE")) : 0;
-    const int wgs = getenv("MDSP_COPY_WGS") ? std::max(1, atoi(getenv("MDSP_COPY_WGS"))) : 8;
+    if (mode < 0 || mode > 5) MDSP_FAIL(MDSP_ERR_ARGUMENT, "copy mode %d out of range [0,5]", mode);
+    if (wgs < 1) wgs = 8;
     const int grid = (int)std::min<size_t>((n4 + 255) / 256, (size_t)device_cu_count() * wgs);
     auto kern = mode == 1 ? mdsp_copy4_kernel : mode == 2 ? mdsp_copy_nt_kernel : mode == 3 ? mdsp_copy_chunk_kernel : mode == 4 ? mdsp_read_kernel
                                                                                                      : mode == 5 ? mdsp_fill_kernel : mdsp_copy_kernel;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, as_stream(stream), (float4*)dst_dev, (const float4*)src_dev, n4);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
+}
+
+extern "C" int mdsp_copy_bench(void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
+    return mdsp_copy_bench_mode(dst_dev, src_dev, bytes, 0, 8, stream);
 }

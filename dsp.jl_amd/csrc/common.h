@@ -90,7 +90,40 @@ inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// device properties (cached per process)
+// device properties (cached per device)
 int device_cu_count();
+
+// ---------------------------------------------------------------- tunables
+// Optional tuning variables (DESIGN.md section 5 "Tuning knobs") are read from the environment ONCE -- by mdsp_init(), or on
+// first use -- into this struct; exec / plan paths only ever look at the struct.  mdsp_reload_tunables() re-reads them
+// (tools/tune.py sweeps variants inside one process).  None changes results beyond rounding.
+struct Tunables {
+    int engine = MDSP_ENGINE_AUTO;      // MDSP_ENGINE=fused|rocfft : engine of plans created with MDSP_ENGINE_AUTO
+    int wg_per_cu = 0;                  // MDSP_WG_PER_CU           : persistent-grid workgroups per CU (0 = occupancy query / kernel default)
+    int runs_per_slot = 1;              // MDSP_RUNS_PER_SLOT       : contiguous runs per transform slot
+    int ols_variant = 0, welch_variant = 0, stft_variant = 1;   // MDSP_{OLS,WELCH,STFT}_VARIANT : alternative kernel instantiations
+    int rocfft_chunk_mib = 192;         // MDSP_ROCFFT_CHUNK_MIB    : intermediates per rocFFT-engine chunk
+    int fir_lds_kib = 20;               // MDSP_FIR_LDS_KIB         : staging tile of the fast polyphase kernel
+    int arb_nch = 4, arb_tile = 0;      // MDSP_ARB_NCH / _TILE     : FIRArbitrary channels per group / outputs per workgroup (0 = default)
+    int arb_scan = 1;                   // MDSP_ARB_SCAN=0          : serial host recurrence only
+    int64_t arb_scan_min = (int64_t)1 << 19;   // MDSP_ARB_SCAN_MIN : outputs from which the device scan is used
+    int host_chunk_mib = 64;            // MDSP_HOST_CHUNK_MIB      : pinned staging chunk of the host-pointer entry points
+#ifdef MDSP_DEBUG_KNOBS
+    // Profiling / bisecting switches: only in builds made with -DMDSP_DEBUG_KNOBS (build.py --tag dbg --cflags -DMDSP_DEBUG_KNOBS).
+    int ablate = 0;                     // MDSP_ABLATE: 1 skip HBM loads, 2 skip transforms, 4 skip stores / accumulation (results are garbage)
+    bool welch_nohalf = false, stft_noshift = false, stft_nopair = false, stft_nodirect = false, fir_generic = false,
+         fir_identity_lanes = false, mt_passes = false, arb_prof = false;
+#endif
+};
+const Tunables& tunables();
+void reload_tunables();
+
+#ifdef MDSP_DEBUG_KNOBS
+#define MDSP_DBG(field) (::mdsp::tunables().field)
+#define MDSP_ABLATED(a, bit) (((a).ablate & (bit)) != 0)
+#else
+#define MDSP_DBG(field) 0
+#define MDSP_ABLATED(a, bit) false
+#endif
 
 }  // namespace mdsp

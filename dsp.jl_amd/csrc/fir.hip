@@ -467,13 +467,13 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
             for (int k = 0; k < n; ++k) {
                 const double fl = floor(acc);
                 rec[arb_rec_slot(base + k)] = {(int)(xi - x_first), (int)fl, acc - fl};   // alpha = modf(acc)[1] is exact
-                if (!(a.ablate & 1)) a.step.fast(acc, xi);
+                if (!MDSP_ABLATED(a, 1)) a.step.fast(acc, xi);
             }
         }
         stamp(2);
     } else {
         const int lanes = (int)blockDim.x - 64, u = tid - 64;
-        if (a.taps_in_lds && !(a.ablate & 8)) {
+        if (a.taps_in_lds && !MDSP_ABLATED(a, 8)) {
             const int np = a.tp * a.nphi;
             constexpr int RB = 4;
             for (int k0 = u; k0 < np; k0 += RB * lanes) {
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
                     if (k0 + r * lanes < np) ps[k0 + r * lanes] = v[r];
             }
         }
-        if (a.span > 0 && c_first < a.nch && !(a.ablate & 4)) stage(c_first, (int)std::min<int64_t>(NCH, a.nch - c_first), u, lanes, a.span);
+        if (a.span > 0 && c_first < a.nch && !MDSP_ABLATED(a, 4)) stage(c_first, (int)std::min<int64_t>(NCH, a.nch - c_first), u, lanes, a.span);
     }
     __syncthreads();
     stamp(3);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
             A* yc[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) yc[c] = static_cast<A*>(a.y) + (c0 + (c < nc ? c : 0)) * a.ldy + m0;
-            const int tpe = (a.ablate & 2) ? 1 : a.tp;
+            const int tpe = MDSP_ABLATED(a, 2) ? 1 : a.tp;
             if (a.taps_in_lds) arb_tile_staged<A, R, NCH>(rec, ps, zs, yc, nc, cnt, tpe, a.nphi);
             else arb_tile_staged<A, R, NCH>(rec, pg, zs, yc, nc, cnt, tpe, a.nphi);
             stamp(4);
@@ -717,7 +717,7 @@ template <int P> void fir_lane_map(FirFastArgs& b) {
             greedy[t] = pick;
         }
     }
-    const std::vector<int>& best = cycles(greedy) < cycles(ident) && !getenv("MDSP_FIR_IDENTITY_LANES") ? greedy : ident;
+    const std::vector<int>& best = cycles(greedy) < cycles(ident) && !MDSP_DBG(fir_identity_lanes) ? greedy : ident;
     for (int t = 0; t < 256; ++t) b.gmap[t] = (unsigned char)(t < nthreads ? best[t] : 0);
 }
 
@@ -735,8 +735,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
     b.RL = std::max(1, 256 / b.NP);
     fir_lane_map<P>(b);
     // rounds per tile: LDS budget ~48 KiB, at least RL rounds
-    int lds_kib = 20;
-    if (const char* e = getenv("MDSP_FIR_LDS_KIB")) lds_kib = std::max(4, atoi(e));
+    const int lds_kib = tunables().fir_lds_kib;
     int Q = (int)std::max<int64_t>(b.RL, ((int64_t)lds_kib * 1024 / 4 - a.M - (TPC + P)) / std::max(1, a.M));
     Q = std::min(Q, 512);
     Q = (int)std::min<int64_t>(Q, std::max<int64_t>(b.nrounds, 1));
@@ -747,7 +746,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const int64_t ntiles = cdiv(b.nrounds, (int64_t)Q);
     int wgs = 5;   // resident workgroups per CU (94 VGPRs x 4 waves, ~20 KiB LDS); 8 / 5 / 4 measured 2.64 / 2.59 / 2.67 ms on config 5
-    if (const char* e = getenv("MDSP_WG_PER_CU")) wgs = std::max(1, atoi(e));
+    if (tunables().wg_per_cu > 0) wgs = tunables().wg_per_cu;
     const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)f->nch);
     hipLaunchKernelGGL(kern, grid, dim3(b.NP * b.RL), lds_bytes, st, b);
@@ -758,7 +757,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
 // Fast path applies to Float32 taps x real Float32 signal with <= 64 taps per phase and <= 1024 phase groups.
 bool fir_fast_ok(const mdsp_fir_s* f, int P) {
     if (f->acc_double || f->x_dtype != MDSP_F32 || f->tp > 64) return false;
-    if (getenv("MDSP_FIR_GENERIC")) return false;
+    if (MDSP_DBG(fir_generic)) return false;
     if (P >= 2 && (f->M > f->L || f->L < P)) return false;
     return cdiv(f->L, P) <= 256;
 }
@@ -1297,7 +1296,7 @@ template <typename XS, typename A, typename R, int NCH> int arb_launch_n(mdsp_fi
     const int64_t groups = cdiv(f->base.nch, NCH);
     const unsigned gy = (unsigned)std::min<int64_t>(groups, std::max<int64_t>(1, cdiv((int64_t)device_cu_count() * 8, tiles)));
     const dim3 grid((unsigned)tiles, gy);
-    const bool prof = getenv("MDSP_ARB_PROF") != nullptr && gy == 1;
+    const bool prof = MDSP_DBG(arb_prof) && gy == 1;
     if (prof) {
         MDSP_TRY(f->prof.reserve(sizeof(long long) * 8 * (size_t)tiles));
         MDSP_HIP(hipMemsetAsync(f->prof.p, 0, sizeof(long long) * 8 * (size_t)tiles, st));
@@ -1327,15 +1326,15 @@ template <typename XS, typename A, typename R, int NCH> int arb_launch_n(mdsp_fi
 template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, ArbArgs& a, hipStream_t st) {
     const int64_t taps_bytes = 2 * (int64_t)f->base.tp * f->nphi * (int64_t)sizeof(R);
     a.taps_in_lds = taps_bytes <= 32 * 1024;
-    a.ablate = getenv("MDSP_ABLATE") ? atoi(getenv("MDSP_ABLATE")) : 0;
-    const int nch_max = getenv("MDSP_ARB_NCH") ? atoi(getenv("MDSP_ARB_NCH")) : 4;   // tuning knob
+    a.ablate = MDSP_DBG(ablate);
+    const int nch_max = tunables().arb_nch;   // tuning knob
     // channels per group: the most whose workgroup (trajectory records + interleaved input span of tile * Delta / Nphi + tp
     // samples per channel + tap pairs) stays within 44 KiB of LDS, i.e. leaves >= 3 workgroups per CU; measured on MI355X,
     // larger footprints lose more to occupancy than the shared tap reads save
     int nchg = f->base.nch >= 3 ? 4 : (int)std::max<int64_t>(1, f->base.nch);
     nchg = std::min(nchg, nch_max >= 4 ? 4 : nch_max >= 2 ? 2 : 1);
     int tile = 1024;
-    if (const char* e = getenv("MDSP_ARB_TILE")) tile = std::min(64 * ARB_BLK, std::max(ARB_BLK, atoi(e) / ARB_BLK * ARB_BLK));   // tuning knob (one wave replays the tile)
+    if (tunables().arb_tile > 0) tile = std::min(64 * ARB_BLK, std::max(ARB_BLK, tunables().arb_tile / ARB_BLK * ARB_BLK));   // tuning knob (one wave replays the tile)
     const int tile0 = tile;
     int64_t span = 0;
     const auto span_of = [&](int t) { return ((int64_t)std::ceil((double)t * f->delta / (double)f->nphi) + f->base.tp + 4 + 3) & ~int64_t(3); };   // multiple of 4: the tap pairs that follow stay 16-byte aligned
@@ -1627,11 +1626,9 @@ int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx
         f->cache_valid = false;
         // long streams: the recurrence is evaluated in parallel on the device, bit for bit (arb_scan.h); MDSP_ARB_SCAN=0 and
         // MDSP_ARB_SCAN_MIN (outputs) are test / tuning knobs
-        const char* es = getenv("MDSP_ARB_SCAN");
-        const char* em = getenv("MDSP_ARB_SCAN_MIN");
-        const int64_t scan_min = em ? atoll(em) : (int64_t)1 << 19;
+        const int64_t scan_min = tunables().arb_scan_min;
         const int64_t pilot = std::min<int64_t>(65536, std::max<int64_t>(2 * arbscan::BLK, (scan_min / 4) & ~int64_t(arbscan::BLK - 1)));
-        if (!(es && atoi(es) == 0) && (double)xlen * f->rate >= (double)scan_min)
+        if (tunables().arb_scan != 0 && (double)xlen * f->rate >= (double)scan_min)
             MDSP_TRY(arb_scan_device(f, step, xlen, pilot, st, &scanned, &nout, &ae, &xe));
         if (scanned) {
             ++f->n_scanned;

@@ -92,7 +92,7 @@ struct OlsFusedArgs {
     int nb;
     int64_t run_len;        // a slot takes runs of run_len consecutive units ...
     int64_t niter;          // ... runs_per_slot * run_len iterations in total (same for every slot)
-    int ablate;             // profiling aid (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip stores
+    int ablate;             // profiling aid, -DMDSP_DEBUG_KNOBS builds only (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip stores
 };
 
 // Raw samples of one unit as they come from HBM: two real blocks (a, b) or one complex block.
@@ -205,7 +205,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     for (int64_t it = 0; it < a.niter; ++it) {   // same trip count for every slot (barriers inside)
         ols_walk_next(walk, a.run_len, nslots);
         const OlsPos nxt = ols_pos(a, walk, it + 1 < a.niter);
-        if constexpr (!PREFETCH) { if (!(a.ablate & 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti); }
+        if constexpr (!PREFETCH) { if (!MDSP_ABLATED(a, 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti); }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -213,8 +213,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
             else v[e] = {raw.a[e], raw.b[e]};
         }
         // next unit's samples start streaming from HBM while this unit is transformed
-        if constexpr (PREFETCH) { if (!(a.ablate & 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, nxt, ti); }
-        if (!(a.ablate & 2)) {
+        if constexpr (PREFETCH) { if (!MDSP_ABLATED(a, 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, nxt, ti); }
+        if (!MDSP_ABLATED(a, 2)) {
         fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0, 0, PERM>(v, t, tw, twsrc, lds);
         // spectral multiply (K2): natural order in registers
         if constexpr (HREG) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
         }
         // no barrier needed here: with one buffer wg_fft ends every exchange with a barrier, with two the 2(P-1)
         // exchanges of a unit alternate buffers so the next unit's first write is two barriers behind its readers
-        if (!(a.ablate & 4)) ols_store<R, E, T, CPLX>(v, a, cur, ti);
+        if (!MDSP_ABLATED(a, 4)) ols_store<R, E, T, CPLX>(v, a, cur, ti);
         cur = nxt;
     }
 }
@@ -293,12 +293,11 @@ int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
     if (per_cu < 1) per_cu = 1;
-    if (const char* e = getenv("MDSP_WG_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning knob
+    if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
     const int64_t want = cdiv(a.nunits, G);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cu_count() * per_cu));
     OlsFusedArgs b = a;
-    int64_t runs = 1;                                                  // runs per slot (1 = fully contiguous)
-    if (const char* e = getenv("MDSP_RUNS_PER_SLOT")) runs = std::max(1, atoi(e));
+    const int64_t runs = tunables().runs_per_slot;                     // runs per slot (1 = fully contiguous)
     const int64_t nslots = (int64_t)grid * G;
     b.run_len = std::max<int64_t>(1, cdiv(a.nunits, nslots * runs));
     b.niter = cdiv(cdiv(a.nunits, b.run_len), nslots) * b.run_len;
@@ -430,11 +429,7 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     if (nfft < nb) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nfft (%lld) must be >= length(b) (%lld)", (long long)nfft, (long long)nb);
     if (nfft > (int64_t(1) << 24)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft %lld too large", (long long)nfft);
     int eng = engine;
-    if (eng == MDSP_ENGINE_AUTO) {
-        const char* env = getenv("MDSP_ENGINE");
-        if (env && !strcmp(env, "rocfft")) eng = MDSP_ENGINE_ROCFFT;
-        else if (env && !strcmp(env, "fused")) eng = MDSP_ENGINE_FUSED;
-    }
+    if (eng == MDSP_ENGINE_AUTO) eng = tunables().engine;
     if (eng == MDSP_ENGINE_AUTO) eng = fused_supported(dtype, nfft) ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
     if (eng == MDSP_ENGINE_FUSED && !fused_supported(dtype, nfft))
         MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft in [256, 8192]; got %lld", (long long)nfft);
@@ -447,7 +442,7 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     pl->nb = nb;
     pl->nfft = nfft;
     pl->L = nfft - (nb - 1);
-    if (const char* v = getenv("MDSP_OLS_VARIANT")) pl->variant = atoi(v);
+    pl->variant = tunables().ols_variant;
 
     // Filter spectrum in double on the host.  FILT: taps scaled by 1/nfft before the transform (filt.jl:499);
     // CONV: spectrum scaled by 1/nfft afterwards (dspbase.jl:516).  The scaling is applied in the plan's working
@@ -530,8 +525,7 @@ int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t nco
     a.nunits = a.units_per_col * ncols;
     a.run_len = 1;
     a.niter = 0;
-    a.ablate = 0;
-    if (const char* e = getenv("MDSP_ABLATE")) a.ablate = atoi(e);
+    a.ablate = MDSP_DBG(ablate);
     if (cplx) return dbl ? launch_fused<double, true>(plan->nfft, a, plan->variant, s) : launch_fused<float, true>(plan->nfft, a, plan->variant, s);
     return dbl ? launch_fused<double, false>(plan->nfft, a, plan->variant, s) : launch_fused<float, false>(plan->nfft, a, plan->variant, s);
 }

@@ -40,11 +40,7 @@ namespace {
 // Intermediates (windowed frames + spectra) of one rocFFT-engine chunk: small enough to stay in the 256 MiB Infinity Cache
 // between the three kernels that touch them, large enough that each launch fills the GPU.  MDSP_ROCFFT_CHUNK_MIB overrides.
 inline int64_t rocfft_chunk_bytes() {
-    static const int64_t v = [] {
-        const char* e = getenv("MDSP_ROCFFT_CHUNK_MIB");
-        return (int64_t)std::max(1, e ? atoi(e) : 192) << 20;   // swept 32..1024 MiB on config 4: 192 is 14 % faster than 64 (tools/rocfft_chunk_sweep.sh)
-    }();
-    return v;
+    return (int64_t)tunables().rocfft_chunk_mib << 20;   // default 192; swept 32..1024 MiB on config 4: 192 is 14 % faster than 64 (tools/rocfft_chunk_sweep.sh)
 }
 
 template <typename T> struct real_of { using type = T; };
@@ -294,7 +290,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
     for (int64_t it = 0; it < niter; ++it) {
         walk();
         const int64_t unext = unit_cur(it + 1 < niter);
-        if constexpr (!PREFETCH) { if (!(a.ablate & 1)) issue(u); }
+        if constexpr (!PREFETCH) { if (!MDSP_ABLATED(a, 1)) issue(u); }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -306,14 +302,14 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_fused_kernel(SpecArgs
                 else v[e] = {ra[e] * w[e], rb[e] * w[e]};
             }
         }
-        if constexpr (PREFETCH) { if (!(a.ablate & 1)) issue(unext); }
+        if constexpr (PREFETCH) { if (!MDSP_ABLATED(a, 1)) issue(unext); }
         u = unext;
-        if (!(a.ablate & 2))
+        if (!MDSP_ABLATED(a, 2))
         fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0>(v, t, tw, twsrc, lds);
         // an odd number of exchanges per iteration would re-enter on the buffer that was used last: fence it
         if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();  // NBUF == 1: wg_fft already ends every exchange with a barrier
         // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
-        if (!(a.ablate & 4)) {
+        if (!MDSP_ABLATED(a, 4)) {
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] += (double)(v[e].x * v[e].x + v[e].y * v[e].y);
         }
@@ -632,11 +628,7 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 
 int resolve_engine(int engine, int dtype, int64_t nfft, int* out) {
     int eng = engine;
-    if (eng == MDSP_ENGINE_AUTO) {
-        const char* env = getenv("MDSP_ENGINE");
-        if (env && !strcmp(env, "rocfft")) eng = MDSP_ENGINE_ROCFFT;
-        else if (env && !strcmp(env, "fused")) eng = MDSP_ENGINE_FUSED;
-    }
+    if (eng == MDSP_ENGINE_AUTO) eng = tunables().engine;
     if (eng == MDSP_ENGINE_AUTO) eng = fused_size_ok(dtype, nfft) ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
     if (eng == MDSP_ENGINE_FUSED && !fused_size_ok(dtype, nfft))
         MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft in [256, 8192]; got %lld", (long long)nfft);
@@ -684,10 +676,8 @@ template <typename R, int N> struct Geo {
 
 // runs of consecutive units per slot (default: one run = fully contiguous), identical trip count for every slot
 void set_schedule(SpecArgs& a, int64_t nunits, int64_t nslots) {
-    a.ablate = 0;
-    if (const char* e = getenv("MDSP_ABLATE")) a.ablate = atoi(e);
-    int64_t runs = 1;
-    if (const char* e = getenv("MDSP_RUNS_PER_SLOT")) runs = std::max(1, atoi(e));
+    a.ablate = MDSP_DBG(ablate);
+    const int64_t runs = tunables().runs_per_slot;
     a.run_len = std::max<int64_t>(1, cdiv(nunits, nslots * runs));
     a.niter = cdiv(cdiv(nunits, a.run_len), nslots) * a.run_len;
 }
@@ -696,7 +686,7 @@ template <typename K> int grid_for(K kern, int threads, int64_t work_wgs, int64_
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
     if (per_cu < 1) per_cu = 1;
-    if (const char* e = getenv("MDSP_WG_PER_CU")) per_cu = std::max(1, atoi(e));   // tuning knob
+    if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
     const int64_t resident = (int64_t)device_cu_count() * per_cu;
     const int64_t per_ch = std::max<int64_t>(1, resident / std::max<int64_t>(1, nch));
     *grid = (int)std::max<int64_t>(1, std::min<int64_t>(work_wgs, per_ch));
@@ -943,7 +933,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
             load_half(bhi, unext, 2, nlive && (2 * unext + 1) < a.K);
         }
         u = unext;
-        if (!(a.ablate & 2)) {
+        if (!MDSP_ABLATED(a, 2)) {
             fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0, 0, PERM>(v, traw, tw, twsrc, lds);
             if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();  // NBUF == 1: wg_fft already ends every exchange with a barrier
         }
@@ -1001,7 +991,7 @@ template <typename R, int N, bool CPLX>
 int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, hipStream_t st) {
     using Gm = Geo<R, N>;
     int nslices = 0, rc = MDSP_OK;
-    const bool half_ok = !CPLX && a.n == N && 2 * a.hop == N && !getenv("MDSP_WELCH_NOHALF");
+    const bool half_ok = !CPLX && a.n == N && 2 * a.hop == N && !MDSP_DBG(welch_nohalf);
     if constexpr (!CPLX && N >= 256) {
         if (half_ok && !(N == 4096 && sizeof(R) == 4 && pl->variant >= 1 && pl->variant <= 9)) {
             constexpr int EH = (N >= 2048 && sizeof(R) == 4) ? 16 : Gm::E;   // Float32, nfft >= 1024: 16 elements per thread (Geo does 1024)
@@ -1054,7 +1044,7 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
         bool done = false;
         if constexpr (CPLX && sizeof(R) == 4 && Gm::E > 4) {   // complex Float32 frames advancing by whole elements: overlap stays in registers
             constexpr int T = N / Gm::E;
-            const int shift = (!getenv("MDSP_STFT_NOSHIFT") && a.n == N && a.hop % T == 0 && a.hop / T < Gm::E) ? (int)(a.hop / T) : 0;
+            const int shift = (!MDSP_DBG(stft_noshift) && a.n == N && a.hop % T == 0 && a.hop / T < Gm::E) ? (int)(a.hop / T) : 0;
             done = shift == 1 || shift == 2 || shift == 4;
             if (shift == 1) rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, pad_default<R>(), CPLX, 2, Gm::NBUF, true, false, 1>(pl, a, st, &nslices);
             else if (shift == 2) rc = welch_run_variant<R, N, Gm::E, Gm::G, Gm::TWREG, pad_default<R>(), CPLX, 2, Gm::NBUF, true, false, 2>(pl, a, st, &nslices);
@@ -1139,7 +1129,7 @@ int mdsp_welch_plan_create(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, i
     pl->nfft = nfft;
     pl->nout = onesided ? nfft / 2 + 1 : nfft;
     pl->r = r;
-    if (const char* v = getenv("MDSP_WELCH_VARIANT")) pl->variant = atoi(v);
+    pl->variant = tunables().welch_variant;
     int st = MDSP_OK;
     if (window_host) {
         pl->have_win = true;
@@ -1251,7 +1241,7 @@ int stft_exec_rocfft(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t n
     }
     const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
     const int nout = (int)pl->nout;
-    const bool direct = !pl->psd_only && nout == nspec && ldo == nout && (nch == 1 || chs == K * (int64_t)nout) && !getenv("MDSP_STFT_NODIRECT");
+    const bool direct = !pl->psd_only && nout == nspec && ldo == nout && (nch == 1 || chs == K * (int64_t)nout) && !MDSP_DBG(stft_nodirect);
     for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
         const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
         hipLaunchKernelGGL(frame_window_kernel<TT>, dim3((unsigned)cnt, gx), dim3(256), 0, st, (const TT*)s, pl->fr.as<TT>(),
@@ -1293,7 +1283,7 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
     if constexpr (N == 1024 && sizeof(R) == 4 && CPLX) {   // tuning alternatives of the config-4 shape (MDSP_STFT_VARIANT)
         // default for this shape: one wavefront per transform (E = 16, T = 64, four transforms per workgroup, no s_barrier
         // at all) -- measured 7-11 % faster than the two-wave E = 8 geometry (variant 9).  Variants 2-4: global twiddles.
-        static const int variant = getenv("MDSP_STFT_VARIANT") ? atoi(getenv("MDSP_STFT_VARIANT")) : 1;
+        const int variant = tunables().stft_variant;
         if (variant >= 1 && variant <= 4) {
             constexpr int E2 = 16, G2 = 4, T2 = 64;
             const int64_t work2 = cdiv(a.K, G2);
@@ -1306,7 +1296,7 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
             };
             if (variant == 1) {
                 // register reuse of the overlapping samples when a frame advances by a whole number of elements per thread
-                const int shift = (!getenv("MDSP_STFT_NOSHIFT") && a.n == N && a.hop % T2 == 0) ? (int)(a.hop / T2) : 0;
+                const int shift = (!MDSP_DBG(stft_noshift) && a.n == N && a.hop % T2 == 0) ? (int)(a.hop / T2) : 0;
 #define MDSP_STFT_V1(S) (pl->psd_only ? run2(stft_fused_kernel<R, N, E2, G2, 1, 4, CPLX, true, 2, 1, true, S>) : run2(stft_fused_kernel<R, N, E2, G2, 1, 4, CPLX, false, 2, 1, true, S>))
                 switch (shift) {
                     case 1: return MDSP_STFT_V1(1);
@@ -1324,7 +1314,7 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
     }
     if constexpr (!CPLX) {
         // real signals: two frames per transform (stft_pair_kernel); MDSP_STFT_NOPAIR=1 keeps the one-frame-per-transform kernel
-        static const bool nopair = getenv("MDSP_STFT_NOPAIR") != nullptr;
+        const bool nopair = MDSP_DBG(stft_nopair);
         if (!nopair && a.n <= N) {
             const int64_t units = cdiv(a.K, 2);
             a.units_per_ch = units;
@@ -1342,7 +1332,7 @@ template <typename R, int N, bool CPLX> int stft_launch_n(mdsp_stft_plan_s* pl, 
     }
     if constexpr (CPLX && sizeof(R) == 4) {   // complex Float32 frames that advance by whole elements: overlap stays in registers
         constexpr int T = N / E;
-        const int shift = (!getenv("MDSP_STFT_NOSHIFT") && a.n == N && a.hop % T == 0 && a.hop / T < E) ? (int)(a.hop / T) : 0;
+        const int shift = (!MDSP_DBG(stft_noshift) && a.n == N && a.hop % T == 0 && a.hop / T < E) ? (int)(a.hop / T) : 0;
 #define MDSP_STFT_GEN(S) \
     (pl->psd_only ? run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, true, 2, NBUF, true, S>) \
                   : run(stft_fused_kernel<R, N, E, G, TWREG, pad_default<R>(), CPLX, false, 2, NBUF, true, S>))
@@ -1637,7 +1627,7 @@ int mdsp_mt_psd_exec(mdsp_mt_plan plan, const void* s_dev, int64_t len, int64_t 
     st.psd_only = 1;
     // real signals on the fused engine: every taper inside one launch (the frame pair stays in registers); otherwise one
     // pass per taper with the accumulate flag
-    if (st.engine == MDSP_ENGINE_FUSED && !dtype_is_complex(st.dtype) && !getenv("MDSP_MT_PASSES") && !getenv("MDSP_STFT_NOPAIR")) {
+    if (st.engine == MDSP_ENGINE_FUSED && !dtype_is_complex(st.dtype) && !MDSP_DBG(mt_passes) && !MDSP_DBG(stft_nopair)) {
         st.win_ptr = plan->wins.as<double>();
         st.r = plan->r[0];
         st.accumulate = 0;

@@ -60,6 +60,12 @@ const char* mdsp_last_error_string(void);
 /* Select the device for the calling thread and create the per-device context (rocFFT setup, plan cache). */
 int mdsp_init(int device);
 int mdsp_shutdown(void);
+/* Optional tuning variables (MDSP_ENGINE, MDSP_*_VARIANT, MDSP_WG_PER_CU, ... -- DESIGN.md section 5) are read from the environment once,
+ * by mdsp_init() or on first use; exec and plan paths never call getenv.  mdsp_reload_tunables() re-reads them (tuning sweeps inside one
+ * process).  mdsp_debug_knobs() is 1 only for a library built with -DMDSP_DEBUG_KNOBS, the only builds in which the profiling switches
+ * (MDSP_ABLATE, MDSP_WELCH_NOHALF, MDSP_STFT_NOSHIFT / _NOPAIR / _NODIRECT, MDSP_FIR_GENERIC, ...) exist at all. */
+int mdsp_reload_tunables(void);
+int mdsp_debug_knobs(void);
 int mdsp_device_count(int* count);
 
 /* Device-memory helpers for hosts without their own GPU array type (ctypes tests, the Julia wrapper). */
@@ -299,6 +305,9 @@ int mdsp_event_record(void* ev, void* stream);
 int mdsp_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
 /* float4 device copy kernel: the on-box achievable-HBM yardstick (bytes read + written = 2*bytes). */
 int mdsp_copy_bench(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+/* The same yardstick with an explicit access pattern: mode 0 float4 copy (grid-stride), 1 four float loads/stores, 2 nontemporal float4,
+ * 3 one contiguous chunk per workgroup, 4 read-only (float4 loads summed), 5 write-only; wgs = workgroups per CU (< 1: 8). */
+int mdsp_copy_bench_mode(void* dst_dev, const void* src_dev, size_t bytes, int mode, int wgs, void* stream);
 
 #ifdef __cplusplus
 }

@@ -393,3 +393,27 @@ def test_arbitrary_scan_declines_what_it_cannot_model():
     used, passes, sx, sa, snout, saend, sdend = _c_trajectory_scan(0.3, 1, 6.9, 32, 30000, 1024)
     ax, aa, nout, aend, dend = _c_trajectory(0.3, 1, 6.9, 32, 30000, block=16)
     assert used and (snout, saend, sdend) == (nout, aend, dend) and np.array_equal(sx, ax) and np.array_equal(sa, aa)
+
+
+def test_environment_is_read_in_one_place_and_debug_knobs_are_compiled_out():
+    """exec / plan paths never call getenv (tunables are read once, in api_core.hip), and the profiling
+    switches (MDSP_ABLATE, ...) do not exist in the product build."""
+    import glob
+    import re
+    from dsp_jl_amd import _lib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "csrc")
+    offenders = []
+    for path in glob.glob(os.path.join(csrc, "*")):
+        if os.path.isdir(path) or os.path.basename(path) == "api_core.hip":
+            continue
+        if re.search(r"\bgetenv\s*\(", open(path, errors="replace").read()):
+            offenders.append(os.path.basename(path))
+    assert not offenders, offenders
+    lib = _lib.lib()
+    assert lib.mdsp_debug_knobs() == 0
+    os.environ["MDSP_ABLATE"] = "7"
+    try:
+        assert lib.mdsp_reload_tunables() == 0 and lib.mdsp_debug_knobs() == 0
+    finally:
+        del os.environ["MDSP_ABLATE"]
+        lib.mdsp_reload_tunables()

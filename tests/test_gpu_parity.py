@@ -562,7 +562,7 @@ def test_firarbitrary_device_trajectory_scan_is_bit_exact(d, rate, nphi, monkeyp
     x = rng.standard_normal(2 * xlen).astype(np.float32)
 
     def run(scan):
-        monkeypatch.setenv("MDSP_ARB_SCAN", "1" if scan else "0")
+        _lib.set_tunable("MDSP_ARB_SCAN", "1" if scan else "0")
         f = d.FIRFilter(h, rate, nphi)
         f.setphase(f.timedelay())                       # an initial phase that is NOT on the recurrence's grid
         start = (f.phi_accumulator, f.input_deficit)

@@ -34,20 +34,20 @@ for rate in rates:
         import time
         cold = {}
         for scan in ("1", "0"):
-            os.environ["MDSP_ARB_SCAN"] = scan
+            _lib.set_tunable("MDSP_ARB_SCAN", scan)
             fc = C.c_void_p()
             _lib.check(lib.mdsp_firarb_create(C.byref(fc), ha.ctypes.data_as(C.c_void_p), len(ha), rate, 32, _lib.F32, _lib.F32, nch))
             torch.cuda.synchronize(); t0 = time.perf_counter()
             _lib.check(lib.mdsp_firarb_exec(fc, x.data_ptr(), n, n, ya.data_ptr(), ola.value + 1, ola.value + 1, C.byref(nw), stream))
             torch.cuda.synchronize(); cold[scan] = time.perf_counter() - t0
             _lib.check(lib.mdsp_firarb_destroy(fc))
-        os.environ["MDSP_ARB_SCAN"] = "1"
+        _lib.set_tunable("MDSP_ARB_SCAN", "1")
         print(f"rate={rate:.4f} nch={nch} cold call: scan {cold['1']*1e3:.2f} ms, serial {cold['0']*1e3:.2f} ms  ({nw.value} outputs/channel)", flush=True)
         out[f"rate={rate:.4f} nch={nch} cold_ms"] = {"scan": round(cold["1"] * 1e3, 3), "serial": round(cold["0"] * 1e3, 3), "outputs": nw.value}
         for g in (1, 2, 4):
             if g > max(nch, 1) and g > 1:
                 continue
-            os.environ["MDSP_ARB_NCH"] = str(g)
+            _lib.set_tunable("MDSP_ARB_NCH", str(g))
 
             def arb():
                 _lib.check(lib.mdsp_firarb_reset(fa))

@@ -96,10 +96,10 @@ print("resample", res["config5_resample_160_147"], flush=True)
 if os.environ.get("ROWS_FIR_SWEEP"):
     for kib in (8, 12, 20, 32, 48):
         for wg in (2, 4, 8):
-            os.environ["MDSP_FIR_LDS_KIB"] = str(kib); os.environ["MDSP_WG_PER_CU"] = str(wg)
+            _lib.set_tunable("MDSP_FIR_LDS_KIB", str(kib)); _lib.set_tunable("MDSP_WG_PER_CU", str(wg))
             med, best = timeit(fir)
             print("fir sweep lds_kib", kib, "wg_per_cu", wg, "ms", round(best, 3), "GB/s", round((4 + 4 * 160 / 147) * n * nch / (best * 1e-3) / 1e9, 1), flush=True)
-    del os.environ["MDSP_FIR_LDS_KIB"]; del os.environ["MDSP_WG_PER_CU"]
+    _lib.set_tunable("MDSP_FIR_LDS_KIB", None); _lib.set_tunable("MDSP_WG_PER_CU", None)
 del y
 if os.environ.get("ROWS_ONLY") == "fir":
     sys.exit(0)

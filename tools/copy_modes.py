@@ -12,8 +12,7 @@ for log2n in (28, 30):
     x=torch.randn(n, device="cuda"); y=torch.empty_like(x)
     for mode in (0,1,2,3,4,5):
         for wgs in (4,8,16,32):
-            os.environ["MDSP_COPY_MODE"]=str(mode); os.environ["MDSP_COPY_WGS"]=str(wgs)
-            f=lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n*4, st))
+            f=lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), n*4, mode, wgs, st))
             f(); torch.cuda.synchronize(); ts=[]
             for _ in range(5):
                 _lib.check(lib.mdsp_event_record(e0, st)); f(); _lib.check(lib.mdsp_event_record(e1, st))

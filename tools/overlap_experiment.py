@@ -65,9 +65,9 @@ res = {"samples": n}
 ref = None
 for wg in ("default", "1", "2", "3"):
     if wg == "default":
-        os.environ.pop("MDSP_WG_PER_CU", None)
+        _lib.set_tunable("MDSP_WG_PER_CU", None)
     else:
-        os.environ["MDSP_WG_PER_CU"] = wg
+        _lib.set_tunable("MDSP_WG_PER_CU", wg)
     res[f"wg_per_cu={wg}"] = {"back_to_back_ms": timed(serial), "two_streams_ms": timed(overlapped),
                               "filt_alone_ms": timed(lambda: ols(torch.cuda.current_stream())), "welch_alone_ms": timed(lambda: welch(torch.cuda.current_stream()))}
     print(wg, res[f"wg_per_cu={wg}"], flush=True)

@@ -45,9 +45,9 @@ res = {"log2n": log2n, "ols": {}, "welch": {}, "stft": {}}
 ols_variants = [int(v) for v in os.environ.get("TUNE_OLS", "0,1,2,3,4,5,6,7,8,9,10,11,12").split(",") if v != ""]
 plans = {}
 for v in ols_variants:
-    os.environ["MDSP_OLS_VARIANT"] = str(v)
+    _lib.set_tunable("MDSP_OLS_VARIANT", str(v))
     plans[("fused", v)] = OlsPlan(taps, 2048, n, 0, d.ENGINE_FUSED)
-os.environ["MDSP_OLS_VARIANT"] = "0"
+_lib.set_tunable("MDSP_OLS_VARIANT", "0")
 plans[("rocfft", 0)] = OlsPlan(taps, 2048, n, 0, d.ENGINE_ROCFFT)
 ref = None
 for key, p in plans.items():
@@ -69,9 +69,9 @@ del plans, ref
 welch_variants = [int(v) for v in os.environ.get("TUNE_WELCH", "0,1,2,3,4,5,6,7,8,9").split(",") if v != ""]
 cfgs = {}
 for v in welch_variants:
-    os.environ["MDSP_WELCH_VARIANT"] = str(v)
+    _lib.set_tunable("MDSP_WELCH_VARIANT", str(v))
     cfgs[("fused", v)] = d.WelchConfig(n, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=d.ENGINE_FUSED)
-os.environ["MDSP_WELCH_VARIANT"] = "0"
+_lib.set_tunable("MDSP_WELCH_VARIANT", "0")
 cfgs[("rocfft", 0)] = d.WelchConfig(n, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=d.ENGINE_ROCFFT)
 psd = torch.empty(2049, dtype=torch.float32, device="cuda")
 ref = None
@@ -89,28 +89,29 @@ for k, v in res["welch"].items():
     v["median_ms"] = sorted(v["ms"])[len(v["ms"]) // 2]
 # ---- occupancy / schedule knobs (MDSP_WG_PER_CU and MDSP_CHUNK_LOG2 are read at every launch) ----
 res["knobs"] = {}
-os.environ["MDSP_OLS_VARIANT"] = "0"; os.environ["MDSP_WELCH_VARIANT"] = "0"
+_lib.set_tunable("MDSP_OLS_VARIANT", "0"); _lib.set_tunable("MDSP_WELCH_VARIANT", "0")
 p0 = OlsPlan(taps, 2048, n, 0, d.ENGINE_FUSED)
 c0 = d.WelchConfig(n, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=d.ENGINE_FUSED)
 for w in os.environ.get("TUNE_WGS", "1,2,4").split(","):
     for c in os.environ.get("TUNE_RUNS", "1,2,8,64").split(","):
-        os.environ["MDSP_WG_PER_CU"] = w
-        os.environ["MDSP_RUNS_PER_SLOT"] = c
+        _lib.set_tunable("MDSP_WG_PER_CU", w)
+        _lib.set_tunable("MDSP_RUNS_PER_SLOT", c)
         to = [timeit(lambda: _lib.check(lib.mdsp_ols_exec(p0._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream))) for _ in range(rounds)]
         tw = [timeit(lambda: _lib.check(lib.mdsp_welch_exec(c0._h, x.data_ptr(), n, 1, n, psd.data_ptr(), 2049, stream))) for _ in range(rounds)]
         res["knobs"][f"wg{w}_chunk{c}"] = {"ols_ms": min(to), "ols_GBps": round(8.0 * n / (min(to) * 1e-3) / 1e9, 1), "welch_ms": min(tw),
                                           "welch_GBps": round(4.0 * n / (min(tw) * 1e-3) / 1e9, 1)}
         print("knobs wg", w, "runs_per_slot", c, res["knobs"][f"wg{w}_chunk{c}"])
-del os.environ["MDSP_WG_PER_CU"]; del os.environ["MDSP_RUNS_PER_SLOT"]
+_lib.set_tunable("MDSP_WG_PER_CU", None); _lib.set_tunable("MDSP_RUNS_PER_SLOT", None)
 # ---- ablations (MDSP_ABLATE: 1 no loads, 2 no transforms, 4 no stores/accumulate) ----
 res["ablate"] = {}
-for ab in os.environ.get("TUNE_ABLATE", "0,1,2,4,3,6,5,7").split(","):
-    os.environ["MDSP_ABLATE"] = ab
+# only in a -DMDSP_DEBUG_KNOBS build:  python dsp.jl_amd/build.py --tag dbg --cflags -DMDSP_DEBUG_KNOBS ; MDSP_LIB_TAG=dbg python tools/tune.py
+for ab in (os.environ.get("TUNE_ABLATE", "0,1,2,4,3,6,5,7").split(",") if lib.mdsp_debug_knobs() else []):
+    _lib.set_tunable("MDSP_ABLATE", ab)
     to = [timeit(lambda: _lib.check(lib.mdsp_ols_exec(p0._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream))) for _ in range(rounds)]
     tw = [timeit(lambda: _lib.check(lib.mdsp_welch_exec(c0._h, x.data_ptr(), n, 1, n, psd.data_ptr(), 2049, stream))) for _ in range(rounds)]
     res["ablate"][ab] = {"ols_ms": round(min(to), 4), "welch_ms": round(min(tw), 4)}
     print("ablate", ab, res["ablate"][ab])
-os.environ["MDSP_ABLATE"] = "0"
+_lib.set_tunable("MDSP_ABLATE", "0")
 # ---- copy yardstick ----
 cms = [timeit(lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))) for _ in range(5)]
 res["copy_GBps"] = round(2 * 4.0 * n / (min(cms) * 1e-3) / 1e9, 1)
