@@ -22,6 +22,7 @@ from .multitaper import (MTConfig, MTSpectrogramConfig, MTCrossSpectraConfig, MT
                          mt_cross_power_spectra_, mt_coherence, mt_coherence_)
 from .periodograms import (Periodogram, Spectrogram, WelchConfig, arraysplit, fftshift, periodogram, welch_pgram, welch_pgram_,  # noqa: F401
                            spectrogram, stft, power, freq, time, frame_count)
+from .comm import Comm  # noqa: F401
 from .channels import (channel_shard, welch_channel_mean, frame_shard, frame_span, welch_time_split,  # noqa: F401
                        filt_time_split_span, filt_time_split)
 

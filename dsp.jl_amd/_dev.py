@@ -48,6 +48,21 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+HOST_PIPELINE_MIN_BYTES = 32 << 20   # numpy inputs at least this large take the library's host-pointer pipeline (pinned, chunked, overlapped)
+
+
+def host_columns(x, dtype):
+    """``x`` as HOST columns for the host-pointer entry points: a C-contiguous (ncols, n) numpy view of ``dtype`` WITHOUT copying, or
+    None when ``x`` is not a large numpy array whose columns are already contiguous (1-d, or 2-d in Fortran order like a Julia matrix)."""
+    if not isinstance(x, np.ndarray) or x.dtype != np.dtype(dtype) or x.nbytes < HOST_PIPELINE_MIN_BYTES:
+        return None
+    if x.ndim == 1 and x.flags.c_contiguous:
+        return x.reshape(1, -1)
+    if x.ndim == 2 and x.flags.f_contiguous:
+        return x.T
+    return None
+
+
 def to_columns(x, dtype) -> tuple[torch.Tensor, tuple]:
     """Return a C-contiguous (ncols, n) device tensor of ``dtype`` holding the columns of ``x`` (shape (n, cols...)),
     plus the original shape."""
@@ -102,3 +117,13 @@ def empty_columns(ncols: int, n: int, dtype) -> torch.Tensor:
 
 def ptr(t: torch.Tensor) -> int:
     return t.data_ptr()
+
+
+def tensor_view(ptr_: int, count: int, dtype, dev=None) -> torch.Tensor:
+    """A 1-d tensor VIEW of ``count`` elements of ``dtype`` at device address ``ptr_`` (memory owned by the library)."""
+    dt = np.dtype(dtype)
+
+    class _Iface:
+        __cuda_array_interface__ = {"shape": (int(count),), "typestr": dt.str, "data": (int(ptr_), False), "version": 3, "strides": None}
+
+    return torch.as_tensor(_Iface(), device=dev if dev is not None else device())

@@ -18,6 +18,8 @@ OK, ERR_ARGUMENT, ERR_DOMAIN, ERR_DIMENSION, ERR_ASSERTION, ERR_UNSUPPORTED, ERR
 F32, F64, C32, C64 = 0, 1, 2, 3
 ENGINE_AUTO, ENGINE_FUSED, ENGINE_ROCFFT = 0, 1, 2
 OLS_FILT, OLS_CONV = 0, 1
+HOST_PINNED = 1
+COMM_ID_BYTES = 128
 
 
 class ArgumentError(ValueError):
@@ -71,12 +73,31 @@ PROTOTYPES = {
     "mdsp_ols_plan_destroy": (ci, [vp]),
     "mdsp_ols_plan_info": (ci, [vp, pi64, pi64, pint]),
     "mdsp_ols_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, vp]),
+    "mdsp_ols_exec_range": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, i64, vp]),
+    "mdsp_ols_exec_host": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, ci]),
     "mdsp_ols_segment": (ci, [vp, vp, i64, i64, i64, vp, vp]),
     "mdsp_frames": (ci, [vp, i64, ci, i64, i64, i64, pdbl, i64, i64, vp, vp]),
     "mdsp_welch_plan_create": (ci, [pvp, i64, i64, i64, pdbl, cd, ci, ci, ci]),
     "mdsp_welch_plan_destroy": (ci, [vp]),
     "mdsp_welch_plan_info": (ci, [vp, pi64, pint]),
     "mdsp_welch_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, vp]),
+    "mdsp_welch_reset": (ci, [vp]),
+    "mdsp_welch_accumulate": (ci, [vp, vp, i64, i64, i64, vp]),
+    "mdsp_welch_frames_accumulated": (ci, [vp, pi64]),
+    "mdsp_welch_finalize": (ci, [vp, i64, vp, i64, vp]),
+    "mdsp_welch_accumulator": (ci, [vp, pvp, pi64]),
+    "mdsp_welch_exec_host": (ci, [vp, vp, i64, i64, i64, vp, i64, ci]),
+    "mdsp_comm_unique_id": (ci, [vp]),
+    "mdsp_comm_init_rank": (ci, [pvp, vp, ci, ci]),
+    "mdsp_comm_destroy": (ci, [vp]),
+    "mdsp_comm_info": (ci, [vp, pint, pint]),
+    "mdsp_allreduce_sum": (ci, [vp, vp, i64, ci, vp]),
+    "mdsp_welch_mean_allreduce": (ci, [vp, vp, i64, i64, i64, vp, vp, vp]),
+    "mdsp_welch_allreduce": (ci, [vp, vp, vp]),
+    "mdsp_host_alloc": (ci, [pvp, C.c_size_t]),
+    "mdsp_host_free": (ci, [vp]),
+    "mdsp_host_register": (ci, [vp, C.c_size_t]),
+    "mdsp_host_unregister": (ci, [vp]),
     "mdsp_channel_sum": (ci, [vp, i64, i64, i64, ci, vp, vp]),
     "mdsp_stft_plan_create": (ci, [pvp, i64, i64, i64, pdbl, cd, ci, ci, ci, ci]),
     "mdsp_stft_plan_destroy": (ci, [vp]),

@@ -22,20 +22,45 @@ def channel_shard(nch_total: int, rank: int, world: int) -> range:
     return range(lo, min(lo + per, nch_total))
 
 
-def welch_channel_mean(cols: torch.Tensor, config: WelchConfig, nch_total: int | None = None, group=None) -> torch.Tensor:
+def _allreduce_sum(t: torch.Tensor, comm=None, group=None) -> torch.Tensor:
+    """The one transport of the path: in-place sum over ranks.  ``comm`` (dsp_jl_amd.Comm: RCCL through the C ABI,
+    ``mdsp_allreduce_sum``) when given; otherwise an initialised ``torch.distributed`` group (backend "nccl" IS RCCL on ROCm;
+    "gloo" in the CPU tests); single process: nothing to do."""
+    if comm is not None:
+        if comm.nranks > 1:
+            comm.allreduce_sum(t)
+    elif torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
+    return t
+
+
+def _local_channel_sum(psd: torch.Tensor, nout: int, T) -> torch.Tensor:
+    """Sum over this rank's channels on the device (``mdsp_channel_sum``); a rank without channels contributes zeros."""
+    tot = torch.zeros(nout, dtype=_dev.torch_dtype(T), device=psd.device)
+    if psd.shape[0] > 0:
+        _lib.check(_lib.lib().mdsp_channel_sum(_dev.ptr(psd), nout, psd.shape[0], nout, _dev.md_dtype(T), _dev.ptr(tot), _dev.stream_ptr()))
+    return tot
+
+
+def welch_channel_mean(cols: torch.Tensor, config: WelchConfig, nch_total: int | None = None, group=None, comm=None) -> torch.Tensor:
     """Mean over ALL channels (across ranks) of the per-channel Welch PSDs.
 
-    ``cols``: this rank's channels as a C-contiguous (nch_local, len) device tensor.  Local sum on the device
-    (``mdsp_channel_sum``), one all-reduce(sum) of ``nout`` values over xGMI, then the 1/nch scale.
+    ``cols``: this rank's channels as a C-contiguous (nch_local, len) device tensor (may have 0 rows).  With ``comm`` (a
+    ``dsp_jl_amd.Comm``) the whole reduction is ONE C-ABI call, ``mdsp_welch_mean_allreduce``: local sum on the device, one
+    ``ncclAllReduce(sum)`` of ``nout`` values over xGMI, the 1/nch scale.  Without it the same three steps run here with
+    ``torch.distributed`` as the transport.
     """
-    psd = _welch_exec(cols, config)                                   # (nch_local, nout)
+    nloc = int(cols.shape[0])
+    psd = _welch_exec(cols, config) if nloc > 0 else cols.new_zeros((0, config.nout))                   # (nch_local, nout)
     T = util.fftabs2type(config.intype)
-    tot = torch.empty(config.nout, dtype=_dev.torch_dtype(T), device=cols.device)
-    _lib.check(_lib.lib().mdsp_channel_sum(_dev.ptr(psd), config.nout, psd.shape[0], config.nout, _dev.md_dtype(T), _dev.ptr(tot),
-                                           _dev.stream_ptr()))
-    n_all = psd.shape[0] if nch_total is None else nch_total
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
-        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM, group=group)
+    n_all = nloc if nch_total is None else int(nch_total)
+    if comm is not None:
+        mean = torch.empty(config.nout, dtype=_dev.torch_dtype(T), device=cols.device)
+        _lib.check(_lib.lib().mdsp_welch_mean_allreduce(config._h, _dev.ptr(psd) if nloc else None, nloc, config.nout, n_all, _dev.ptr(mean),
+                                                        comm._h, _dev.stream_ptr()))
+        return mean
+    tot = _local_channel_sum(psd, config.nout, T)
+    _allreduce_sum(tot, None, group)
     return tot / n_all
 
 
@@ -57,26 +82,21 @@ def frame_span(frames: range, n: int, noverlap: int) -> tuple[int, int]:
     return frames.start * hop, (frames.stop - 1) * hop + n
 
 
-def welch_time_split(x_slice, nframes_total: int, n: int, noverlap: int, group=None, **kw) -> torch.Tensor:
+def welch_time_split(x_slice, nframes_total: int, n: int, noverlap: int, group=None, comm=None, **kw) -> torch.Tensor:
     """Welch PSD of one stream whose frames are split over ranks.  ``x_slice``: this rank's samples (``frame_span`` of its
-    ``frame_shard``; may be empty).  Every rank evaluates the reference's frames of its range, the per-rank means are
-    recombined with their frame counts by one all-reduce(sum) of ``nout`` values: sum_r K_r P_r / K -- the same frames and the
-    same normalisation as ``welch_pgram`` of the whole stream (periodograms.jl:746-759)."""
+    ``frame_shard``; may be empty).  Every rank adds the reference's frames of its range to a Welch plan's Float64 |X|^2 sums
+    (``mdsp_welch_accumulate``), the sums are added over ranks by one all-reduce, and every rank forms the PSD with the TOTAL frame
+    count (``mdsp_welch_finalize``) -- the same frames and the same normalisation as ``welch_pgram`` of the whole stream
+    (periodograms.jl:746-759)."""
     length = int(x_slice.shape[0])
     sdt = _dev.np_dtype_of(x_slice)
-    k_local = 0 if length < n else (length - n) // (n - noverlap) + 1
-    T = util.fftabs2type(util.fftintype(sdt))
-    if k_local > 0:
-        cfg = WelchConfig(length, sdt, n=n, noverlap=noverlap, **kw)
-        cols, _ = _dev.to_columns(x_slice, cfg.intype)
-        tot = _welch_exec(cols, cfg)[0] * float(k_local)
-    else:
-        nfft = int(kw.get("nfft", util.nextfastfft(n)))
-        onesided = kw.get("onesided", sdt.kind != "c")
-        tot = torch.zeros(nfft // 2 + 1 if onesided else nfft, dtype=_dev.torch_dtype(T), device=_dev.device())
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
-        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM, group=group)
-    return tot / float(nframes_total)
+    cfg = WelchConfig(max(length, n), sdt, n=n, noverlap=noverlap, **kw)
+    cols, _ = _dev.to_columns(x_slice, cfg.intype)                # (1, length); a rank without frames passes an empty slice
+    cfg.reset()
+    cfg.accumulate(cols)
+    acc = cfg.accumulator()
+    _allreduce_sum(acc, comm, group)
+    return cfg.finalize(int(nframes_total))[0]
 
 
 def filt_time_split_span(lo: int, hi: int, nb: int) -> tuple[int, int]:

@@ -27,6 +27,7 @@
 #include "fft_wg.h"
 #include "hostfft.h"
 #include "rocfft_wrap.h"
+#include "ols_plan.h"
 
 using namespace mdsp;
 using mdsp::fft::cx;
@@ -88,7 +89,8 @@ struct OlsFusedArgs {
     int64_t nx, nout, ldx, ldy, L;
     int64_t nblocks;        // per column
     int64_t units_per_col;  // pairs (real) or blocks (complex)
-    int64_t nunits;         // total
+    int64_t nunits;         // total (one past the last unit of this launch)
+    int64_t u_begin;        // first unit of this launch (0 unless a block range is executed, mdsp_ols_exec_range)
     int nb;
     int64_t run_len;        // a slot takes runs of run_len consecutive units ...
     int64_t niter;          // ... runs_per_slot * run_len iterations in total (same for every slot)
@@ -198,7 +200,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     const __amdgpu_buffer_rsrc_t hrsrc = io::make_rsrc(a.H, (int64_t)N * (int64_t)sizeof(cx<R>));
 
     const int64_t nslots = (int64_t)gridDim.x * G;
-    OlsWalk walk{((int64_t)blockIdx.x * G + slot) * a.run_len, 0};
+    OlsWalk walk{a.u_begin + ((int64_t)blockIdx.x * G + slot) * a.run_len, 0};
     OlsPos cur = ols_pos(a, walk, a.niter > 0);
     OlsRaw<R, E, CPLX> raw;
     if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti);
@@ -241,17 +243,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
 // ======================================================================================================
 // Plan object
 // ======================================================================================================
-struct mdsp_ols_plan_s {
-    int dtype = MDSP_F32, mode = MDSP_OLS_FILT, engine = MDSP_ENGINE_ROCFFT;
-    int64_t nb = 0, nfft = 0, L = 0;
-    DevBuf H;       // rocFFT engine: nspec (real) or nfft (complex) entries; fused: nfft entries
-    DevBuf table;   // fused: nfft forward roots
-    // rocFFT engine state
-    RocPlan fwd, inv;
-    DevBuf td, fd;
-    int64_t batch = 0;
-    int variant = 0;  // fused kernel variant (tuning knob, MDSP_OLS_VARIANT)
-};
+// struct mdsp_ols_plan_s: ols_plan.h (shared with hostpath.hip)
 
 namespace {
 
@@ -294,13 +286,14 @@ int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
     if (per_cu < 1) per_cu = 1;
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
-    const int64_t want = cdiv(a.nunits, G);
+    const int64_t todo = a.nunits - a.u_begin;
+    const int64_t want = cdiv(todo, G);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)device_cu_count() * per_cu));
     OlsFusedArgs b = a;
     const int64_t runs = tunables().runs_per_slot;                     // runs per slot (1 = fully contiguous)
     const int64_t nslots = (int64_t)grid * G;
-    b.run_len = std::max<int64_t>(1, cdiv(a.nunits, nslots * runs));
-    b.niter = cdiv(cdiv(a.nunits, b.run_len), nslots) * b.run_len;
+    b.run_len = std::max<int64_t>(1, cdiv(todo, nslots * runs));
+    b.niter = cdiv(cdiv(todo, b.run_len), nslots) * b.run_len;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, b);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
@@ -366,15 +359,15 @@ template <typename R, bool CPLX> int launch_fused(int64_t nfft, const OlsFusedAr
 // ---- rocFFT engine --------------------------------------------------------------------------------------
 template <typename R, bool CPLX>
 int exec_rocfft(mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy,
-                hipStream_t s) {
+                hipStream_t s, int64_t u_begin = 0, int64_t u_end = -1) {
     using T = std::conditional_t<CPLX, cx<R>, R>;
     const int64_t nfft = pl->nfft, L = pl->L;
     const int64_t nblocks = cdiv(nout, L);
-    const int64_t nunits = nblocks * ncols;
+    const int64_t nunits = u_end >= 0 ? std::min(u_end, nblocks * ncols) : nblocks * ncols;   // unit = block (no pair packing in this engine)
     const int64_t nspec = CPLX ? nfft : nfft / 2 + 1;
     // chunk so that td + fd stay cache resident (~64 MiB)
     const int64_t per_unit = (int64_t)sizeof(T) * nfft + (CPLX ? 0 : (int64_t)sizeof(cx<R>) * nspec);
-    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nunits, (int64_t(64) << 20) / per_unit));
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nblocks * ncols, (int64_t(64) << 20) / per_unit));
     if (pl->batch != batch) {
         MDSP_TRY(pl->td.reserve((size_t)(sizeof(T) * nfft * batch)));
         if (!CPLX) MDSP_TRY(pl->fd.reserve((size_t)(sizeof(cx<R>) * nspec * batch)));
@@ -389,7 +382,7 @@ int exec_rocfft(mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, i
         pl->batch = batch;
     }
     const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
-    for (int64_t u0 = 0; u0 < nunits; u0 += batch) {
+    for (int64_t u0 = u_begin; u0 < nunits; u0 += batch) {
         const int64_t cnt = std::min<int64_t>(batch, nunits - u0);
         hipLaunchKernelGGL(ols_segment_kernel<T>, dim3((unsigned)cnt, gx), dim3(256), 0, s, (const T*)x, pl->td.as<T>(), nx, ldx,
                            nblocks, L, (int)pl->nb, (int)nfft, u0, nunits);
@@ -491,23 +484,20 @@ int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len, in
     return MDSP_OK;
 }
 
-int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev, int64_t nout, int64_t ldy,
-                  void* stream) {
-    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
-    if (nx < 0 || ncols < 0 || nout < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
-    if (nout > nx + plan->nb - 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nout (%lld) exceeds nx+nb-1", (long long)nout);
-    if (ncols > 1 && (ldx < nx || ldy < nout)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "leading dimension smaller than the column length");
-    if (nout == 0 || ncols == 0) return MDSP_OK;
-    if (!x_dev && nx > 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "x is NULL");
-    if (!y_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
-    if (x_dev == y_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out may not alias x");
-    hipStream_t s = as_stream(stream);
+// blocks [g_begin, g_end) of every column's block grid (g_end < 0: all).  x / y may be "virtual" bases: only the elements those blocks
+// touch are dereferenced (mdsp_ols_exec_range).
+static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev, int64_t nout, int64_t ldy,
+                         int64_t g_begin, int64_t g_end, hipStream_t s) {
     const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
+    const int64_t nblocks = cdiv(nout, plan->L);
+    if (g_end < 0 || g_end > nblocks) g_end = nblocks;
+    if (g_begin >= g_end) return MDSP_OK;
     if (plan->engine == MDSP_ENGINE_ROCFFT) {
-        if (cplx) return dbl ? exec_rocfft<double, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s)
-                             : exec_rocfft<float, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s);
-        return dbl ? exec_rocfft<double, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s)
-                   : exec_rocfft<float, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s);
+        const int64_t ub = g_begin, ue = (g_begin == 0 && g_end == nblocks) ? -1 : g_end;
+        if (cplx) return dbl ? exec_rocfft<double, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s, ub, ue)
+                             : exec_rocfft<float, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s, ub, ue);
+        return dbl ? exec_rocfft<double, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s, ub, ue)
+                   : exec_rocfft<float, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s, ub, ue);
     }
     OlsFusedArgs a;
     a.x = x_dev;
@@ -520,14 +510,53 @@ int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t nco
     a.ldy = ldy;
     a.L = plan->L;
     a.nb = (int)plan->nb;
-    a.nblocks = cdiv(nout, plan->L);
-    a.units_per_col = cplx ? a.nblocks : cdiv(a.nblocks, 2);
-    a.nunits = a.units_per_col * ncols;
+    a.nblocks = g_end;                     // blocks past the range do not exist for this launch (second block of the last pair)
+    a.units_per_col = cplx ? nblocks : cdiv(nblocks, 2);
+    a.nunits = (g_end == nblocks) ? a.units_per_col * ncols : (cplx ? g_end : cdiv(g_end, 2));   // ranges: single column (checked by the caller)
+    a.u_begin = cplx ? g_begin : g_begin / 2;
     a.run_len = 1;
     a.niter = 0;
     a.ablate = MDSP_DBG(ablate);
     if (cplx) return dbl ? launch_fused<double, true>(plan->nfft, a, plan->variant, s) : launch_fused<float, true>(plan->nfft, a, plan->variant, s);
     return dbl ? launch_fused<double, false>(plan->nfft, a, plan->variant, s) : launch_fused<float, false>(plan->nfft, a, plan->variant, s);
+}
+
+int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev, int64_t nout, int64_t ldy,
+                  void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (nx < 0 || ncols < 0 || nout < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (nout > nx + plan->nb - 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nout (%lld) exceeds nx+nb-1", (long long)nout);
+    if (ncols > 1 && (ldx < nx || ldy < nout)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "leading dimension smaller than the column length");
+    if (nout == 0 || ncols == 0) return MDSP_OK;
+    if (!x_dev && nx > 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "x is NULL");
+    if (!y_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
+    if (x_dev == y_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out may not alias x");
+    return ols_exec_core(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, 0, -1, as_stream(stream));
+}
+
+int mdsp_ols_exec_range(mdsp_ols_plan plan, const void* xs_dev, int64_t xs_first, int64_t xs_len, int64_t nx, void* ys_dev, int64_t first_block,
+                        int64_t nblocks_range, int64_t nout, void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (nx < 0 || nout < 0 || xs_first < 0 || xs_len < 0 || first_block < 0 || nblocks_range < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (nout > nx + plan->nb - 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nout (%lld) exceeds nx+nb-1", (long long)nout);
+    const int64_t L = plan->L, nb = plan->nb, nblocks = cdiv(nout, L);
+    const int64_t g0 = first_block, g1 = std::min(nblocks, first_block + nblocks_range);
+    if (g0 >= g1) return MDSP_OK;
+    if (!dtype_is_complex(plan->dtype) && (g0 & 1)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "first_block must be even (two real blocks share a transform)");
+    // samples the blocks read: [g0 L - (nb-1), g1 L) clipped to the signal
+    const int64_t need_lo = std::max<int64_t>(0, g0 * L - (nb - 1)), need_hi = std::min(nx, g1 * L);
+    if (need_hi > need_lo && (xs_first > need_lo || xs_first + xs_len < need_hi))
+        MDSP_FAIL(MDSP_ERR_ARGUMENT, "the slice [%lld, %lld) does not cover the samples [%lld, %lld) that blocks [%lld, %lld) read", (long long)xs_first,
+                  (long long)(xs_first + xs_len), (long long)need_lo, (long long)need_hi, (long long)g0, (long long)g1);
+    if (!xs_dev && need_hi > need_lo) MDSP_FAIL(MDSP_ERR_ARGUMENT, "x is NULL");
+    if (!ys_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
+    const size_t esz = dtype_size(plan->dtype);
+    // virtual bases of the whole column: x[0] and y[0]; only [need_lo, need_hi) and [g0 L, min(nout, g1 L)) are dereferenced
+    const char* xv = static_cast<const char*>(xs_dev) - (ptrdiff_t)xs_first * (ptrdiff_t)esz;
+    char* yv = static_cast<char*>(ys_dev) - (ptrdiff_t)(g0 * L) * (ptrdiff_t)esz;
+    const int64_t nx_eff = std::min(nx, xs_first + xs_len);      // nothing past the slice is read (hardware zero fill past nx_eff is never reached)
+    const int64_t nout_eff = std::min(nout, g1 * L);
+    return ols_exec_core(plan, xv, nx_eff, 1, nx_eff, yv, nout_eff, nout_eff, g0, g1, as_stream(stream));
 }
 
 int mdsp_ols_segment(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t first_block, int64_t nblocks, void* seg_dev, void* stream) {

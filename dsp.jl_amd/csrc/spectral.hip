@@ -31,6 +31,7 @@
 #include "fft_wg.h"
 #include "hostfft.h"
 #include "rocfft_wrap.h"
+#include "welch_plan.h"
 
 using namespace mdsp;
 using mdsp::fft::cx;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void abs2_accum_kernel(const cx<R>* __restrict
 // Slice reduction: reduced[ch][k] = sum_s partial[s][ch][k], fixed order (deterministic).  32 bins x 8 slice lanes per
 // workgroup so the nslices-long sum is spread over threads instead of being one latency-bound loop per bin.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, double* __restrict__ reduced, int nslices,
-                                                              int64_t nch, int nacc) {
+                                                              int64_t nch, int nacc, int accumulate) {
     __shared__ double sm[8][33];
     const int bx = threadIdx.x & 31, sy = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + bx;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
         double t = sm[0][bx];
 #pragma unroll
         for (int i = 1; i < 8; ++i) t += sm[i][bx];
-        reduced[ch * nacc + k] = t;
+        reduced[ch * nacc + k] = accumulate ? reduced[ch * nacc + k] + t : t;   // accumulate: a further slice of the same stream
     }
 }
 
@@ -734,30 +735,26 @@ extern "C" int mdsp_frames(const void* s_dev, int64_t len, int dtype, int64_t n,
 // ======================================================================================================
 // Welch
 // ======================================================================================================
-struct mdsp_welch_plan_s {
-    int dtype = MDSP_F32, engine = MDSP_ENGINE_ROCFFT, onesided = 1;
-    int64_t n = 0, noverlap = 0, nfft = 0, nout = 0;
-    double r = 1;
-    bool have_win = false;
-    DevBuf win, table, partial, reduced;
-    RocPlan fwd;
-    DevBuf fr, spec;
-    int64_t batch = 0;
-    int variant = 0;
-};
+// struct mdsp_welch_plan_s: welch_plan.h (shared with comm.hip / hostpath.hip)
 
 namespace {
 
 template <typename R, bool CPLX>
-int welch_exec_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* psd, int64_t ldp, hipStream_t st) {
+int welch_accumulate_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, hipStream_t st) {
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     const int64_t nfft = pl->nfft, n = pl->n, hop = pl->n - pl->noverlap;
     const int64_t K = mdsp_frame_count(len, n, pl->noverlap);
     const int nspec = (int)(CPLX ? nfft : nfft / 2 + 1);
     const int64_t nunits = K * nch;
     const int nslices = 32;
-    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)nslices * (size_t)nch * (size_t)nspec));
-    MDSP_HIP(hipMemsetAsync(pl->partial.p, 0, sizeof(double) * (size_t)nslices * (size_t)nch * (size_t)nspec, st));
+    pl->acc_nslices = nslices;
+    pl->acc_nacc = nspec;
+    pl->acc_mode = CPLX ? 1 : (pl->onesided ? 0 : 2);
+    if (pl->acc_fresh) {
+        MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)nslices * (size_t)nch * (size_t)nspec));
+        MDSP_HIP(hipMemsetAsync(pl->partial.p, 0, sizeof(double) * (size_t)nslices * (size_t)nch * (size_t)nspec, st));
+        pl->acc_fresh = false;
+    }
     if (nunits > 0) {
         const int64_t per_unit = (int64_t)sizeof(TT) * nfft + (int64_t)sizeof(cx<R>) * nspec;
         const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nunits, rocfft_chunk_bytes() / per_unit));
@@ -779,19 +776,29 @@ int welch_exec_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t
             MDSP_LAUNCH_CHECK();
         }
     }
-    const double r_total = (double)K * pl->r;
+    return MDSP_OK;
+}
+
+// psd[ch][j] = T( m_j * fold(accumulated |X|^2 sums) ), m from r_total = K_total * fs * sum(w^2)  (periodograms.jl:751, :142-172)
+template <typename R> int welch_finalize(mdsp_welch_plan_s* pl, int64_t K_total, int64_t nch, void* psd, int64_t ldp, hipStream_t st) {
     const int nout = (int)pl->nout;
-    const dim3 grid((unsigned)cdiv(nout, 256), (unsigned)nch);
-    if (K == 0) {  // fill!(out, 0); no frames (0 * r would be a division by zero in m)
+    if (K_total <= 0) {  // fill!(out, 0); no frames (0 * r would be a division by zero in m)
         for (int64_t c = 0; c < nch; ++c) MDSP_HIP(hipMemsetAsync((R*)psd + c * ldp, 0, sizeof(R) * (size_t)nout, st));
         return MDSP_OK;
     }
-    if (CPLX)
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 1>), grid, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, nch, nspec, (int)nfft, nout, r_total);
-    else if (pl->onesided)
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 0>), grid, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, nch, nspec, (int)nfft, nout, r_total);
-    else
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 2>), grid, dim3(256), 0, st, pl->partial.as<double>(), (R*)psd, ldp, nslices, nch, nspec, (int)nfft, nout, r_total);
+    const double r_total = (double)K_total * pl->r;
+    const dim3 grid((unsigned)cdiv(nout, 256), (unsigned)nch);
+    const double* acc = pl->acc_ptr();
+    const int ns = pl->acc_nslices, na = pl->acc_nacc, nfft = (int)pl->nfft;
+#define MDSP_FIN(MODE) hipLaunchKernelGGL((welch_finalize_kernel<R, MODE>), grid, dim3(256), 0, st, acc, (R*)psd, ldp, ns, nch, na, nfft, nout, r_total)
+    switch (pl->acc_mode) {
+        case 0: MDSP_FIN(0); break;
+        case 1: MDSP_FIN(1); break;
+        case 2: MDSP_FIN(2); break;
+        case 3: MDSP_FIN(3); break;
+        default: MDSP_FIN(4); break;
+    }
+#undef MDSP_FIN
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
@@ -988,7 +995,7 @@ int welch_run_variant(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* n
 }
 
 template <typename R, int N, bool CPLX>
-int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, hipStream_t st) {
+int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
     using Gm = Geo<R, N>;
     int nslices = 0, rc = MDSP_OK;
     const bool half_ok = !CPLX && a.n == N && 2 * a.hop == N && !MDSP_DBG(welch_nohalf);
@@ -1054,28 +1061,30 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, void* psd, int64_t ldp, h
     }
 finalize:
     if (rc != MDSP_OK) return rc;
-    const int nout = (int)pl->nout;
-    const double r_total = (double)a.K * pl->r;
+    // fold the slots' partial rows into the plan's Float64 accumulator (added to what earlier slices of the stream left there)
     MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)a.nch * N));
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<double>(),
-                       pl->reduced.as<double>(), nslices, a.nch, N);
+                       pl->reduced.as<double>(), nslices, a.nch, N, pl->acc_fresh ? 0 : 1);
     MDSP_LAUNCH_CHECK();
-    const dim3 fg((unsigned)cdiv(nout, 256), (unsigned)a.nch);
-    if (CPLX)
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 1>), fg, dim3(256), 0, st, pl->reduced.as<double>(), (R*)psd, ldp, 1, a.nch, N, N, nout, r_total);
-    else if (pl->onesided)
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 3>), fg, dim3(256), 0, st, pl->reduced.as<double>(), (R*)psd, ldp, 1, a.nch, N, N, nout, r_total);
-    else
-        hipLaunchKernelGGL((welch_finalize_kernel<R, 4>), fg, dim3(256), 0, st, pl->reduced.as<double>(), (R*)psd, ldp, 1, a.nch, N, N, nout, r_total);
-    MDSP_LAUNCH_CHECK();
+    pl->acc_fresh = false;
+    pl->acc_nslices = 1;
+    pl->acc_nacc = N;
+    pl->acc_mode = CPLX ? 1 : (pl->onesided ? 3 : 4);
     return MDSP_OK;
 }
 
 template <typename R, bool CPLX>
-int welch_exec_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* psd, int64_t ldp, hipStream_t st) {
+int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, hipStream_t st) {
     const int64_t K = mdsp_frame_count(len, pl->n, pl->noverlap);
     if (K == 0) {
-        for (int64_t c = 0; c < nch; ++c) MDSP_HIP(hipMemsetAsync((R*)psd + c * ldp, 0, sizeof(R) * (size_t)pl->nout, st));
+        if (pl->acc_fresh) {   // nothing to add; make the accumulator exist (zeros) so that a later finalize / all-reduce is defined
+            MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)nch * (size_t)pl->nfft));
+            MDSP_HIP(hipMemsetAsync(pl->reduced.p, 0, sizeof(double) * (size_t)nch * (size_t)pl->nfft, st));
+            pl->acc_fresh = false;
+            pl->acc_nslices = 1;
+            pl->acc_nacc = (int)pl->nfft;
+            pl->acc_mode = CPLX ? 1 : (pl->onesided ? 3 : 4);
+        }
         return MDSP_OK;
     }
     SpecArgs a{};
@@ -1093,13 +1102,13 @@ int welch_exec_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, int64_t 
     a.onesided = pl->onesided;
     a.r = pl->r;
     switch (pl->nfft) {
-        case 256: return welch_launch_n<R, 256, CPLX>(pl, a, psd, ldp, st);
-        case 512: return welch_launch_n<R, 512, CPLX>(pl, a, psd, ldp, st);
-        case 1024: return welch_launch_n<R, 1024, CPLX>(pl, a, psd, ldp, st);
-        case 2048: return welch_launch_n<R, 2048, CPLX>(pl, a, psd, ldp, st);
-        case 4096: return welch_launch_n<R, 4096, CPLX>(pl, a, psd, ldp, st);
+        case 256: return welch_launch_n<R, 256, CPLX>(pl, a, st);
+        case 512: return welch_launch_n<R, 512, CPLX>(pl, a, st);
+        case 1024: return welch_launch_n<R, 1024, CPLX>(pl, a, st);
+        case 2048: return welch_launch_n<R, 2048, CPLX>(pl, a, st);
+        case 4096: return welch_launch_n<R, 4096, CPLX>(pl, a, st);
         case 8192:
-            if constexpr (sizeof(R) == 4) return welch_launch_n<R, 8192, CPLX>(pl, a, psd, ldp, st);
+            if constexpr (sizeof(R) == 4) return welch_launch_n<R, 8192, CPLX>(pl, a, st);
         default: break;
     }
     MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused Welch does not support nfft=%lld", (long long)pl->nfft);
@@ -1158,26 +1167,76 @@ int mdsp_welch_plan_info(mdsp_welch_plan plan, int64_t* nout, int* engine_used) 
     return MDSP_OK;
 }
 
-int mdsp_welch_exec(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds_, void* psd_dev, int64_t ldp, void* stream) {
+static int welch_check_args(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds_) {
     if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
     if (len < 0 || nch < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
-    if (nch == 0) return MDSP_OK;
-    if (!psd_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
-    if (!s_dev && len > 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "s is NULL");
-    if (nch > 1 && (lds_ < len || ldp < plan->nout)) MDSP_FAIL(MDSP_ERR_DIMENSION, "leading dimension smaller than the column length");
+    if (!s_dev && len > 0 && nch > 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "s is NULL");
+    if (nch > 1 && lds_ < len) MDSP_FAIL(MDSP_ERR_DIMENSION, "leading dimension smaller than the column length");
     if (nch > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 channels per call");
+    return MDSP_OK;
+}
+
+int mdsp_welch_reset(mdsp_welch_plan plan) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    plan->acc_fresh = true;
+    plan->acc_frames = 0;
+    plan->acc_nch = 0;
+    return MDSP_OK;
+}
+
+int mdsp_welch_accumulate(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds_, void* stream) {
+    MDSP_TRY(welch_check_args(plan, s_dev, len, nch, lds_));
+    if (nch == 0) return MDSP_OK;
+    if (!plan->acc_fresh && plan->acc_nch != nch)
+        MDSP_FAIL(MDSP_ERR_DIMENSION, "accumulating %lld channels into sums of %lld channels (mdsp_welch_reset first)", (long long)nch, (long long)plan->acc_nch);
     hipStream_t st = as_stream(stream);
     const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
+    int rc;
     if (plan->engine == MDSP_ENGINE_ROCFFT) {
-        if (cplx) return dbl ? welch_exec_rocfft<double, true>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st)
-                             : welch_exec_rocfft<float, true>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st);
-        return dbl ? welch_exec_rocfft<double, false>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st)
-                   : welch_exec_rocfft<float, false>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st);
+        if (cplx) rc = dbl ? welch_accumulate_rocfft<double, true>(plan, s_dev, len, nch, lds_, st) : welch_accumulate_rocfft<float, true>(plan, s_dev, len, nch, lds_, st);
+        else rc = dbl ? welch_accumulate_rocfft<double, false>(plan, s_dev, len, nch, lds_, st) : welch_accumulate_rocfft<float, false>(plan, s_dev, len, nch, lds_, st);
+    } else {
+        if (cplx) rc = dbl ? welch_accumulate_fused<double, true>(plan, s_dev, len, nch, lds_, st) : welch_accumulate_fused<float, true>(plan, s_dev, len, nch, lds_, st);
+        else rc = dbl ? welch_accumulate_fused<double, false>(plan, s_dev, len, nch, lds_, st) : welch_accumulate_fused<float, false>(plan, s_dev, len, nch, lds_, st);
     }
-    if (cplx) return dbl ? welch_exec_fused<double, true>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st)
-                         : welch_exec_fused<float, true>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st);
-    return dbl ? welch_exec_fused<double, false>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st)
-               : welch_exec_fused<float, false>(plan, s_dev, len, nch, lds_, psd_dev, ldp, st);
+    if (rc != MDSP_OK) return rc;
+    plan->acc_nch = nch;
+    plan->acc_frames += mdsp_frame_count(len, plan->n, plan->noverlap);
+    return MDSP_OK;
+}
+
+int mdsp_welch_frames_accumulated(mdsp_welch_plan plan, int64_t* frames_per_channel) {
+    if (!plan || !frames_per_channel) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    *frames_per_channel = plan->acc_frames;
+    return MDSP_OK;
+}
+
+int mdsp_welch_accumulator(mdsp_welch_plan plan, void** acc_dev, int64_t* count) {
+    if (!plan || !acc_dev || !count) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    if (plan->acc_fresh) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nothing accumulated since the last mdsp_welch_reset");
+    *acc_dev = plan->acc_ptr();
+    *count = (int64_t)plan->acc_nslices * plan->acc_nch * plan->acc_nacc;
+    return MDSP_OK;
+}
+
+int mdsp_welch_finalize(mdsp_welch_plan plan, int64_t frames_total, void* psd_dev, int64_t ldp, void* stream) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (!psd_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
+    if (plan->acc_fresh) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nothing accumulated since the last mdsp_welch_reset");
+    if (plan->acc_nch > 1 && ldp < plan->nout) MDSP_FAIL(MDSP_ERR_DIMENSION, "leading dimension smaller than the column length");
+    const int64_t K = frames_total > 0 ? frames_total : plan->acc_frames;
+    return dtype_is_double(plan->dtype) ? welch_finalize<double>(plan, K, plan->acc_nch, psd_dev, ldp, as_stream(stream))
+                                        : welch_finalize<float>(plan, K, plan->acc_nch, psd_dev, ldp, as_stream(stream));
+}
+
+int mdsp_welch_exec(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds_, void* psd_dev, int64_t ldp, void* stream) {
+    MDSP_TRY(welch_check_args(plan, s_dev, len, nch, lds_));
+    if (nch == 0) return MDSP_OK;
+    if (!psd_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
+    if (nch > 1 && ldp < plan->nout) MDSP_FAIL(MDSP_ERR_DIMENSION, "leading dimension smaller than the column length");
+    MDSP_TRY(mdsp_welch_reset(plan));
+    MDSP_TRY(mdsp_welch_accumulate(plan, s_dev, len, nch, lds_, stream));
+    return mdsp_welch_finalize(plan, 0, psd_dev, ldp, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,25 @@
+// The Welch plan object (opaque behind the C ABI), shared by spectral.hip (kernels), comm.hip (all-reduce of its accumulators)
+// and hostpath.hip (host-pointer pipeline).
+#pragma once
+
+#include "common.h"
+#include "rocfft_wrap.h"
+
+struct mdsp_welch_plan_s {
+    int dtype = MDSP_F32, engine = MDSP_ENGINE_ROCFFT, onesided = 1;
+    int64_t n = 0, noverlap = 0, nfft = 0, nout = 0;
+    double r = 1;
+    bool have_win = false;
+    mdsp::DevBuf win, table, partial, reduced;
+    mdsp::RocPlan fwd;
+    mdsp::DevBuf fr, spec;
+    int64_t batch = 0;
+    int variant = 0;
+    // Float64 sums of |X[k]|^2 over the frames accumulated since the last reset (mdsp_welch_reset / _accumulate / _finalize):
+    //   fused engine : `reduced`, acc_nslices = 1, acc_nacc = nfft bins per channel (pair-packed full spectrum for real signals)
+    //   rocFFT engine: `partial`, acc_nslices = 32 deterministic slices, acc_nacc = nspec bins per channel
+    bool acc_fresh = true;       // nothing accumulated yet: the next accumulate overwrites instead of adding
+    int64_t acc_nch = 0, acc_frames = 0;
+    int acc_nslices = 1, acc_nacc = 0, acc_mode = 0;   // welch_finalize_kernel MODE
+    double* acc_ptr() const { return engine == MDSP_ENGINE_ROCFFT ? partial.as<double>() : reduced.as<double>(); }
+};

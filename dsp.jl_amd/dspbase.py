@@ -129,6 +129,14 @@ class OlsPlan:
         _lib.check(_lib.lib().mdsp_ols_exec(self._h, _dev.ptr(cols), nx, ncols, nx, _dev.ptr(out), nout, nout, _dev.stream_ptr()))
         return out
 
+    def exec_host(self, cols: np.ndarray, nout: int) -> np.ndarray:
+        """Filter HOST columns ((ncols, nx) C-contiguous numpy of the plan's dtype) through the pinned, chunked
+        H2D || kernel || D2H pipeline of ``mdsp_ols_exec_host``; bit-identical to ``exec`` on a device copy."""
+        ncols, nx = cols.shape
+        out = np.empty((ncols, nout), dtype=self.dtype)
+        _lib.check(_lib.lib().mdsp_ols_exec_host(self._h, cols.ctypes.data_as(C.c_void_p), nx, ncols, nx, out.ctypes.data_as(C.c_void_p), nout, nout, 0))
+        return out
+
     def segment(self, col, first: int, count: int):
         """Blocks [first, first+count) of one column as the reference's ``tmp1`` contents, shape (count, nfft)."""
         seg = _dev.empty_columns(count, self.nfft, self.dtype)

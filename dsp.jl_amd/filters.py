@@ -38,6 +38,16 @@ def _fftfilt(b: np.ndarray, x, nfft: int, engine: int = _lib.ENGINE_AUTO):
         raise TypeError("fftfilt is defined for real taps and real signals only")      # MethodError in the reference
     W = np.result_type(b.dtype, xdt)
     Wc = _compute_dtype(W)
+    hcols = _dev.host_columns(x, Wc) if W == Wc else None
+    if hcols is not None:              # large host array: the library's pinned, chunked H2D || kernel || D2H pipeline, no torch copy
+        if nfft < len(b):
+            raise ArgumentError("nfft must be at least length(b)")
+        taps = b.astype(Wc)
+        _dev.device()
+        plan = _plancache.plans.get(("ols", _plancache.ctx_key(), _plancache.array_key(taps), int(nfft), _lib.OLS_FILT, engine),
+                                    lambda: OlsPlan(taps, nfft, hcols.shape[1], _lib.OLS_FILT, engine))
+        out = plan.exec_host(hcols, hcols.shape[1])
+        return out[0] if x.ndim == 1 else out.T
     cols, shape = _dev.to_columns(x, Wc)
     ncols, nx = cols.shape
     if nx == 0 or ncols == 0:

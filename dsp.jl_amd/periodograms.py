@@ -247,6 +247,47 @@ class WelchConfig:
         _lib.check(_lib.lib().mdsp_welch_plan_info(self._h, C.byref(no), C.byref(eng)))
         self.nout, self.engine = no.value, eng.value
 
+    # -- streaming form: welch_pgram of a stream handed over slice by slice (mdsp_welch_reset / _accumulate / _finalize) --------------
+    def reset(self):
+        _lib.check(_lib.lib().mdsp_welch_reset(self._h))
+        self._acc_dev = None
+        return self
+
+    def accumulate(self, cols):
+        """Add the frames of ``cols`` ((nch, len) device columns of ``intype``: whole frames; consecutive slices of one stream overlap by
+        n - hop samples) to the plan's Float64 sums."""
+        nch, length = cols.shape
+        self._acc_dev = cols.device
+        _lib.check(_lib.lib().mdsp_welch_accumulate(self._h, _dev.ptr(cols), length, nch, length, _dev.stream_ptr()))
+        return self
+
+    def frames_accumulated(self) -> int:
+        k = C.c_int64()
+        _lib.check(_lib.lib().mdsp_welch_frames_accumulated(self._h, C.byref(k)))
+        return k.value
+
+    def accumulator(self):
+        """The plan's Float64 accumulator as a device tensor VIEW (what a collective sums over ranks)."""
+        p, cnt = C.c_void_p(), C.c_int64()
+        _lib.check(_lib.lib().mdsp_welch_accumulator(self._h, C.byref(p), C.byref(cnt)))
+        return _dev.tensor_view(p.value, cnt.value, np.float64, self._acc_dev)
+
+    def finalize(self, frames_total: int = 0, nch: int = 1):
+        """(nch, nout) PSDs from the accumulated sums; ``frames_total`` = K of the whole stream (0: the frames accumulated here)."""
+        T = util.fftabs2type(self.intype)
+        out = _dev.empty_columns(nch, self.nout, T)
+        _lib.check(_lib.lib().mdsp_welch_finalize(self._h, int(frames_total), _dev.ptr(out), self.nout, _dev.stream_ptr()))
+        return out
+
+    def exec_host(self, s: np.ndarray):
+        """``welch_pgram`` of HOST columns ((nch, len) C-contiguous numpy of ``intype``) through the pinned, chunked H2D || kernel
+        pipeline of ``mdsp_welch_exec_host``; returns a (nch, nout) numpy array."""
+        nch, length = s.shape
+        out = np.empty((nch, self.nout), dtype=util.fftabs2type(self.intype))
+        _lib.check(_lib.lib().mdsp_welch_exec_host(self._h, s.ctypes.data_as(C.c_void_p), length, nch, length, out.ctypes.data_as(C.c_void_p),
+                                                   self.nout, 0))
+        return out
+
     def __del__(self):
         try:
             if self._h:
@@ -283,6 +324,10 @@ def welch_pgram(s, n=None, noverlap=None, *, config: WelchConfig | None = None, 
             config = WelchConfig(length, sdt, n=n, noverlap=noverlap, **kw)
     if util.fftintype(sdt) != config.intype:
         raise ArgumentError(f"float(eltype(s)) = {util.fftintype(sdt)} doesn't match the eltype of the input buffer: {config.intype}.")
+    hcols = _dev.host_columns(s, config.intype)
+    if hcols is not None:              # large host array: mdsp_welch_exec_host (pinned, chunked H2D || kernel), no torch copy
+        out = config.exec_host(hcols)
+        return Periodogram(out[0] if s.ndim == 1 else out.T, config.freq)
     cols, shape = _dev.to_columns(s, config.intype)
     out = _welch_exec(cols, config)
     res = out.t() if len(shape) > 1 else out[0]

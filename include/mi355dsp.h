@@ -114,6 +114,13 @@ int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len /* 
  * 0 <= nout <= nx+nb-1.  x and y must not alias (Filters/filt.jl:438-439). */
 int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,
                   int64_t nout, int64_t ldy, void* stream);
+/* Blocks [first_block, first_block + nblocks_range) of the SAME block grid mdsp_ols_exec uses for one column of nx samples /
+ * nout outputs, from a slice of the signal: xs_dev holds x[xs_first .. xs_first + xs_len) and must cover the samples those blocks
+ * read, [first_block L - (nb-1), (first_block + nblocks_range) L) clipped to [0, nx); ys_dev[0..] receives the outputs from
+ * first_block L on.  first_block must be even for real dtypes.  Building block of mdsp_ols_exec_host and of a time-axis split
+ * of one stream over GPUs (no collective: overlap-save blocks are independent, Filters/filt.jl:504-518). */
+int mdsp_ols_exec_range(mdsp_ols_plan plan, const void* xs_dev, int64_t xs_first, int64_t xs_len, int64_t nx, void* ys_dev,
+                        int64_t first_block, int64_t nblocks_range, int64_t nout, void* stream);
 /* Segmenter only (K1): materialise blocks [first_block, first_block+nblocks) of column 0 as (nfft, nblocks)
  * -- the exact contents of `tmp1` before the forward transform (filt.jl:509-510).  For parity tests. */
 int mdsp_ols_segment(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t first_block, int64_t nblocks,
@@ -142,11 +149,63 @@ int mdsp_welch_plan_info(mdsp_welch_plan plan, int64_t* nout, int* engine_used);
  * Each channel gets its own PSD (welch_pgram_helper!, periodograms.jl:746-759). */
 int mdsp_welch_exec(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds,
                     void* psd_dev, int64_t ldp, void* stream);
-/* Mean over channels of the PSDs produced by the last mdsp_welch_exec on this rank, into mean_dev (nout):
- * sum over the local channels; the cross-GPU sum (RCCL all-reduce over xGMI) and the 1/total_channels scale
- * are applied by the host (torch.distributed / ncclAllReduce on the same buffer), see INTEGRATION.md. */
-int mdsp_channel_sum(const void* psd_dev, int64_t nout, int64_t nch, int64_t ldp, int real_dtype,
-                     void* sum_dev, void* stream);
+/* Streaming form of the same computation -- mdsp_welch_exec IS reset + accumulate + finalize.  The plan owns Float64 sums of
+ * |X[k]|^2 over every frame accumulated since the last reset; a long stream may be handed over slice by slice (each slice: whole
+ * frames, i.e. consecutive slices overlap by n - hop samples), by several ranks (mdsp_welch_allreduce), or from host memory
+ * (mdsp_welch_exec_host).  finalize forms psd = fold(sums) / (K fs sum(w^2)) with K = frames_total (0: the frames accumulated here),
+ * periodograms.jl:751-757.  All slices of one accumulation must have the same channel count. */
+int mdsp_welch_reset(mdsp_welch_plan plan);
+int mdsp_welch_accumulate(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds, void* stream);
+int mdsp_welch_frames_accumulated(mdsp_welch_plan plan, int64_t* frames_per_channel);
+int mdsp_welch_finalize(mdsp_welch_plan plan, int64_t frames_total, void* psd_dev, int64_t ldp, void* stream);
+/* The accumulator itself (Float64, `count` values, layout private to the engine): what a caller-side collective would sum over ranks. */
+int mdsp_welch_accumulator(mdsp_welch_plan plan, void** acc_dev, int64_t* count);
+/* Local part of the cross-channel mean: sum over nch rows (ld ldp) of nout values, in `real_dtype`, into sum_dev (nout). */
+int mdsp_channel_sum(const void* psd_dev, int64_t nout, int64_t nch, int64_t ldp, int real_dtype, void* sum_dev,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, channels sharded over ranks, RCCL over xGMI for the ONE collective of the path.
+ *   The reference loops over columns / channels serially (Filters/filt.jl:504, stream_filt.jl:768 `mapslices`); here rank r owns
+ *   a contiguous block of channels and runs the single-GPU entry points on them -- no data-path collective -- and only the
+ *   cross-channel Welch mean needs an exchange: an all-reduce (sum) of nout values.
+ *   Bootstrap: rank 0 calls mdsp_comm_unique_id and ships the 128 bytes to the other ranks by whatever the host has (MPI.jl bcast,
+ *   a shared file, torch.distributed's store); every rank then calls mdsp_comm_init_rank (collective) after mdsp_init(device).
+ *   librccl is bound at run time; without it these entries return MDSP_ERR_DEVICE and everything else keeps working.
+ * ---------------------------------------------------------------------------------------------------- */
+#define MDSP_COMM_ID_BYTES 128
+typedef struct mdsp_comm_s* mdsp_comm;
+int mdsp_comm_unique_id(void* id128 /* MDSP_COMM_ID_BYTES, host */);
+int mdsp_comm_init_rank(mdsp_comm* comm, const void* id128, int rank, int nranks);
+int mdsp_comm_destroy(mdsp_comm comm);
+int mdsp_comm_info(mdsp_comm comm, int* rank, int* nranks);
+/* in-place sum over ranks of `count` Float32 / Float64 values (ncclAllReduce on `stream`) */
+int mdsp_allreduce_sum(mdsp_comm comm, void* buf_dev, int64_t count, int real_dtype, void* stream);
+/* Cross-channel Welch mean: psd_dev = this rank's per-channel PSDs (nch_local rows of ld ldp, plan's nout bins, fftabs2type);
+ * mean_dev (nout) = (1 / nch_total) * sum over the channels of ALL ranks.  comm == NULL or a 1-rank communicator: local mean. */
+int mdsp_welch_mean_allreduce(mdsp_welch_plan plan, const void* psd_dev, int64_t nch_local, int64_t ldp, int64_t nch_total,
+                              void* mean_dev, mdsp_comm comm, void* stream);
+/* ONE stream split along time over ranks: sums the plans' Float64 accumulators and frame counts over ranks in place; a following
+ * mdsp_welch_finalize(plan, 0, ...) gives every rank the PSD of the whole stream.  Synchronises `stream`. */
+int mdsp_welch_allreduce(mdsp_welch_plan plan, mdsp_comm comm, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Host-array entry points: DSP.jl's own call shape (host Arrays in, host Arrays out; Filters/filt.jl:458-476,
+ * periodograms.jl:647-744) as a chunked H2D || kernel || D2H pipeline on two internal streams with page-locked double buffers.
+ * Synchronous (results are in the host arrays on return); PCIe-bound -- see DESIGN.md section 5 for the measured rates.
+ *   flags: MDSP_HOST_PINNED = the caller's arrays are already page-locked (mdsp_host_alloc / mdsp_host_register): no staging copies.
+ *   Chunk size: MDSP_HOST_CHUNK_MIB (default 64).  Results are bit-identical to the device-resident calls for overlap-save
+ *   (same block grid) and equal up to Float64 summation order for Welch.
+ * ---------------------------------------------------------------------------------------------------- */
+#define MDSP_HOST_PINNED 1
+int mdsp_host_alloc(void** host_ptr, size_t bytes);      /* hipHostMalloc */
+int mdsp_host_free(void* host_ptr);
+int mdsp_host_register(void* host_ptr, size_t bytes);    /* hipHostRegister: page-lock an existing allocation (e.g. a Julia Array) */
+int mdsp_host_unregister(void* host_ptr);
+int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64_t ncols, int64_t ldx, void* y_host, int64_t nout,
+                       int64_t ldy, int flags);
+int mdsp_welch_exec_host(mdsp_welch_plan plan, const void* s_host, int64_t len, int64_t nch, int64_t lds, void* psd_host,
+                         int64_t ldp, int flags);
 
 typedef struct mdsp_stft_plan_s* mdsp_stft_plan;
 /* psd_only = 0: raw STFT columns (fftouttype), unnormalised (periodograms.jl:892);

@@ -1,0 +1,211 @@
+"""GPU tests of the boundary pieces added in round 2 (run with -m gpu on an MI355X):
+
+  * the RCCL communicator behind the C ABI (mdsp_comm_*, mdsp_welch_mean_allreduce, mdsp_welch_allreduce) with one rank -- the box
+    has one GPU; the world-2 logic of the same product functions runs under gloo in tests/test_dist_gloo.py;
+  * the streaming Welch protocol (reset / accumulate / finalize) against the one-shot call and the oracle;
+  * block-range overlap-save (mdsp_ols_exec_range): bit-identical to the whole-signal call;
+  * the host-pointer pipelines (mdsp_ols_exec_host / mdsp_welch_exec_host), pageable and page-locked arrays, both engines.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 5e-6
+
+
+@pytest.fixture(scope="module")
+def d():
+    import dsp_jl_amd as dd
+    from dsp_jl_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device")
+    _lib.check(_lib.lib().mdsp_init(0))
+    return dd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    return t
+
+
+def _taps(n, dtype):
+    from oracle import design, windows
+    return design.digitalfilter_lowpass_firwindow(0.25, windows.hamming(n)).astype(dtype)
+
+
+def test_rccl_communicator_behind_the_c_abi_single_rank(d, torch):
+    from dsp_jl_amd import _lib, _dev
+    comm = d.Comm.single()                                  # ncclGetUniqueId + ncclCommInitRank(1 rank) inside libmi355dsp
+    assert (comm.rank, comm.nranks) == (0, 1)
+    r, n = C.c_int(-1), C.c_int(-1)
+    _lib.check(_lib.lib().mdsp_comm_info(comm._h, C.byref(r), C.byref(n)))
+    assert (r.value, n.value) == (0, 1)
+    for dt in (torch.float32, torch.float64):
+        t = torch.arange(5000, device="cuda", dtype=dt) * 0.25
+        ref = t.clone()
+        comm.allreduce_sum(t)                               # a real ncclAllReduce launch on the current stream
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref)
+    # cross-channel Welch mean through ONE C-ABI call == mean of the per-channel PSDs
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    S = torch.randn((6, 50000), generator=g, device="cuda", dtype=torch.float32)
+    cfg = d.WelchConfig(50000, np.float32, n=1024, noverlap=512, window=d.hanning)
+    mean = d.welch_channel_mean(S, cfg, comm=comm)
+    per = d.welch_pgram(S.t(), cfg).power
+    assert float((mean.double() - per.double().mean(dim=1)).norm() / mean.double().norm()) < 1e-6
+    assert torch.allclose(mean, d.welch_channel_mean(S, cfg), rtol=1e-6, atol=0)   # and == the torch.distributed-transport form on one rank
+    half = d.welch_channel_mean(S[:3], cfg, nch_total=6, comm=comm)           # a rank holding 3 of 6 channels contributes sum/6
+    assert float((half.double() - per[:, :3].double().sum(dim=1) / 6).norm() / half.double().norm()) < 1e-6
+    none = d.welch_channel_mean(S[:0], cfg, nch_total=6, comm=comm)           # a rank without channels contributes zeros
+    assert float(none.abs().max()) == 0.0
+    # time split on one rank == whole-stream PSD (accumulate -> all-reduce of the Float64 sums -> finalize with the total frame count)
+    x = S[0]
+    K = d.frame_count(x.numel(), 1024, 512)
+    p = d.welch_time_split(x, K, 1024, 512, window=d.hanning, comm=comm)
+    assert float((p.double() - per[:, 0].double()).norm() / per[:, 0].double().norm()) < 1e-6
+    cfg.reset(); cfg.accumulate(S[:1].contiguous())
+    _lib.check(_lib.lib().mdsp_welch_allreduce(cfg._h, comm._h, _dev.stream_ptr()))
+    assert cfg.frames_accumulated() == K
+    comm.close()
+    with pytest.raises(d.ArgumentError):
+        d.Comm(b"x" * 5, 0, 1)
+
+
+@pytest.mark.parametrize("engine", [1, 2], ids=["fused", "rocfft"])
+@pytest.mark.parametrize("dt,tol", [(np.float32, TOL32), (np.float64, 1e-12), (np.complex64, TOL32)])
+def test_welch_streaming_accumulate_equals_one_shot(d, torch, engine, dt, tol):
+    from oracle import periodograms as opg, windows as ow
+    rng = np.random.default_rng(11)
+    n, nov, L = 512, 384, 200_000
+    hop = n - nov
+    x = rng.standard_normal((2, L)).astype(dt) if np.dtype(dt).kind != "c" else (rng.standard_normal((2, L)) + 1j * rng.standard_normal((2, L))).astype(dt)
+    xd = torch.from_numpy(x).cuda()
+    cfg = d.WelchConfig(L, dt, n=n, noverlap=nov, window=d.hanning, engine=engine)
+    K = d.frame_count(L, n, nov)
+    one = d.welch_pgram(xd.t(), cfg).power                      # (nout, 2)
+    cfg.reset()
+    cuts = [0, 1, 7, 300, 301, K // 2, K]                      # uneven slices of whole frames, including single-frame slices
+    for k0, k1 in zip(cuts[:-1], cuts[1:]):
+        cfg.accumulate(xd[:, k0 * hop:(k1 - 1) * hop + n].contiguous())
+    assert cfg.frames_accumulated() == K
+    st = cfg.finalize(nch=2).t()
+    assert float((st.double() - one.double()).norm() / one.double().norm()) < (1e-6 if np.dtype(dt).itemsize in (4, 8) and np.dtype(dt) != np.float64 else 1e-13)
+    for c in range(2):
+        ref = opg.welch_pgram(x[c], n, nov, window=ow.hanning, dtype=np.float64).power
+        assert relerr(st[:, c].cpu().numpy(), ref) < tol
+    # finalize with an explicit total: a rank that saw half the frames of a stream twice as long
+    assert float((cfg.finalize(2 * K, nch=2).t().double() * 2 - st.double()).norm() / st.double().norm()) < 1e-6
+    with pytest.raises(d.DimensionMismatch):
+        cfg.accumulate(xd[:1, :n * 4].contiguous())             # channel count changed without a reset
+
+
+@pytest.mark.parametrize("engine", [1, 2], ids=["fused", "rocfft"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64])
+def test_ols_block_range_is_bit_identical(d, torch, engine, dt):
+    from dsp_jl_amd import _lib, _dev
+    from dsp_jl_amd.dspbase import OlsPlan
+    rng = np.random.default_rng(3)
+    nb, nfft, nx = 97, 512, 100_003
+    L = nfft - nb + 1
+    rdt = np.float32 if dt in (np.float32, np.complex64) else np.float64
+    b = _taps(nb, rdt)
+    x = rng.standard_normal(nx).astype(rdt) if np.dtype(dt).kind != "c" else (rng.standard_normal(nx) + 1j * rng.standard_normal(nx)).astype(dt)
+    taps = b.astype(dt)
+    plan = OlsPlan(taps, nfft, nx, _lib.OLS_FILT, engine)
+    xd = torch.from_numpy(x).cuda()
+    whole = plan.exec(xd.view(1, -1), nx)[0]
+    nblocks = -(-nx // L)
+    got = torch.empty_like(whole)
+    for g0, cnt in ((0, 2), (2, 40), (42, 2), (44, nblocks)):       # even starts; the last range is clipped to the grid
+        g1 = min(nblocks, g0 + cnt)
+        lo, hi = max(0, g0 * L - (nb - 1)), min(nx, g1 * L)
+        o0, o1 = g0 * L, min(nx, g1 * L)
+        xs = xd[lo:hi].clone()                                   # a slice that holds nothing but what the blocks read
+        ys = torch.empty(o1 - o0, dtype=xd.dtype, device="cuda")
+        _lib.check(_lib.lib().mdsp_ols_exec_range(plan._h, _dev.ptr(xs), lo, hi - lo, nx, _dev.ptr(ys), g0, cnt, nx, _dev.stream_ptr()))
+        got[o0:o1] = ys
+    assert torch.equal(got, whole)
+    if np.dtype(dt).kind != "c":
+        with pytest.raises(d.ArgumentError):                     # odd first block: two real blocks share a transform
+            _lib.check(_lib.lib().mdsp_ols_exec_range(plan._h, _dev.ptr(xd), 0, nx, nx, _dev.ptr(got), 1, 2, nx, _dev.stream_ptr()))
+    with pytest.raises(d.ArgumentError):                         # slice does not cover what the blocks read
+        _lib.check(_lib.lib().mdsp_ols_exec_range(plan._h, _dev.ptr(xd), 5000, 100, nx, _dev.ptr(got), 2, 4, nx, _dev.stream_ptr()))
+
+
+@pytest.mark.parametrize("engine", [1, 2], ids=["fused", "rocfft"])
+def test_host_pipeline_overlap_save(d, torch, engine, monkeypatch):
+    """mdsp_ols_exec_host: chunked, double-buffered H2D || kernel || D2H; bit-identical to the device-resident call."""
+    from dsp_jl_amd import _lib
+    from dsp_jl_amd.dspbase import OlsPlan
+    from oracle import dspbase as odsp
+    rng = np.random.default_rng(5)
+    _lib.set_tunable("MDSP_HOST_CHUNK_MIB", 1)                  # many chunks on a modest array: both lanes, drains, the last partial chunk
+    try:
+        for dt, nx, ncols in ((np.float32, 3_000_017, 1), (np.float64, 700_001, 3)):
+            b = _taps(256, dt)
+            x = rng.standard_normal((ncols, nx)).astype(dt)
+            plan = OlsPlan(b, 2048, nx, _lib.OLS_FILT, engine)
+            dev = plan.exec(torch.from_numpy(x).cuda(), nx).cpu().numpy()
+            host = plan.exec_host(x, nx)                         # pageable numpy memory: staged through pinned buffers
+            assert np.array_equal(host, dev)
+            ref = odsp.filt_ba(b.astype(np.float64), 1.0, x[ncols - 1, :50000].astype(np.float64))
+            assert relerr(host[ncols - 1, :50000], ref) < (TOL32 if dt == np.float32 else 1e-12)
+            # page-locked arrays: no staging copies (MDSP_HOST_PINNED)
+            nbytes = x.nbytes
+            pin_in, pin_out = C.c_void_p(), C.c_void_p()
+            _lib.check(_lib.lib().mdsp_host_alloc(C.byref(pin_in), nbytes)); _lib.check(_lib.lib().mdsp_host_alloc(C.byref(pin_out), nbytes))
+            try:
+                xin = np.ctypeslib.as_array(C.cast(pin_in, C.POINTER(C.c_byte)), shape=(nbytes,)).view(dt).reshape(ncols, nx)
+                yout = np.ctypeslib.as_array(C.cast(pin_out, C.POINTER(C.c_byte)), shape=(nbytes,)).view(dt).reshape(ncols, nx)
+                xin[...] = x
+                _lib.check(_lib.lib().mdsp_ols_exec_host(plan._h, pin_in, nx, ncols, nx, pin_out, nx, nx, _lib.HOST_PINNED))
+                assert np.array_equal(yout, dev)
+            finally:
+                _lib.lib().mdsp_host_free(pin_in); _lib.lib().mdsp_host_free(pin_out)
+        # conv mode: nout = nx + nb - 1 (tail blocks read past the end of x)
+        b = _taps(256, np.float32); x = rng.standard_normal(1_000_000).astype(np.float32)
+        plan = OlsPlan(b, 2048, len(x), _lib.OLS_CONV, engine)
+        nout = len(x) + 255
+        dev = plan.exec(torch.from_numpy(x).cuda().view(1, -1), nout).cpu().numpy()
+        assert np.array_equal(plan.exec_host(x.reshape(1, -1), nout), dev)
+    finally:
+        _lib.set_tunable("MDSP_HOST_CHUNK_MIB", None)
+    # the numpy API takes this path on its own for large host arrays (>= 32 MiB): results equal the device-array call
+    x = rng.standard_normal(9_000_000).astype(np.float32); b = _taps(256, np.float32)
+    y_host = d.fftfilt(b, x, 2048, engine=engine)
+    assert isinstance(y_host, np.ndarray) and np.array_equal(y_host, d.fftfilt(b, torch.from_numpy(x).cuda(), 2048, engine=engine).cpu().numpy())
+    X = np.asfortranarray(rng.standard_normal((5_000_000, 2)).astype(np.float32))   # a Julia-layout (column-major) matrix
+    Y = d.fftfilt(b, X, 2048, engine=engine)
+    assert Y.shape == X.shape and np.array_equal(Y[:, 1], d.fftfilt(b, np.ascontiguousarray(X[:, 1]), 2048, engine=engine))
+
+
+@pytest.mark.parametrize("engine", [1, 2], ids=["fused", "rocfft"])
+def test_host_pipeline_welch(d, torch, engine):
+    from dsp_jl_amd import _lib
+    from oracle import periodograms as opg, windows as ow
+    rng = np.random.default_rng(9)
+    _lib.set_tunable("MDSP_HOST_CHUNK_MIB", 1)
+    try:
+        for dt, L, nch, n, nov, nfft in ((np.float32, 2_500_000, 1, 4096, 2048, 4096), (np.float32, 400_000, 3, 1000, 300, 1024), (np.float64, 300_000, 2, 512, 384, 512)):
+            s = rng.standard_normal((nch, L)).astype(dt)
+            cfg = d.WelchConfig(L, dt, n=n, noverlap=nov, nfft=nfft, window=d.hanning, engine=engine)
+            host = cfg.exec_host(s)
+            dev = d.welch_pgram(torch.from_numpy(s).cuda().t(), cfg).power.t().cpu().numpy()
+            assert host.shape == dev.shape == (nch, cfg.nout)
+            assert relerr(host, dev) < (1e-6 if dt == np.float32 else 1e-13)
+            ref = opg.welch_pgram(s[nch - 1], n, nov, nfft=nfft, window=ow.hanning, dtype=np.float64).power
+            assert relerr(host[nch - 1], ref) < (TOL32 if dt == np.float32 else 1e-12)
+        short = rng.standard_normal((1, 100)).astype(np.float32)         # shorter than one frame: fill!(out, 0)
+        cfg = d.WelchConfig(100, np.float32, n=256, noverlap=128, window=d.hanning, engine=engine)
+        assert np.array_equal(cfg.exec_host(short), np.zeros((1, 129), np.float32))
+    finally:
+        _lib.set_tunable("MDSP_HOST_CHUNK_MIB", None)
+    s = rng.standard_normal(9_000_000).astype(np.float32)                # numpy API: large host arrays take the pipeline
+    p = d.welch_pgram(s, 4096, 2048, window=d.hanning, engine=engine).power
+    assert isinstance(p, np.ndarray) and relerr(p, d.welch_pgram(torch.from_numpy(s).cuda(), 4096, 2048, window=d.hanning, engine=engine).power.cpu().numpy()) < 1e-6
