@@ -1,27 +1,44 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the hot path on MI355X.
+"""bench.py -- benchmark of the hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--config filtwelch|stft|resample]
+                                                   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Metric (BASELINE.json): "Gsamples/s filt+welch, 1 Gsample Float32 stream".  One step = one pass of the hot path over
-one 2^30-sample Float32 stream per GPU, already resident in HBM:
-    y = fftfilt(b, x)          256-tap overlap-save FIR           (BASELINE config 2, Filters/filt.jl:479-521)
-    P = welch_pgram(x)         nfft = 4096, hanning, 50 % overlap   (BASELINE config 3, periodograms.jl:746-759)
-    mean over channels         one RCCL all-reduce of 2049 floats   (only for N > 1: one channel (stream) per GPU)
-value = (2^30 samples x N) / step time, i.e. input samples that went through BOTH filt and Welch per second.
+--config filtwelch (default; the BASELINE.json metric "Gsamples/s filt+welch, 1 Gsample Float32 stream"):
+    one step = one pass of the hot path over one 2^30-sample Float32 stream per GPU, already resident in HBM:
+        y = fftfilt(b, x)          256-tap overlap-save FIR             (BASELINE config 2, Filters/filt.jl:479-521)
+        P = welch_pgram(x)         nfft = 4096, hanning, 50 % overlap   (BASELINE config 3, periodograms.jl:746-759)
+        mean over channels         one RCCL all-reduce of 2049 floats   (N > 1: one channel (stream) per GPU)
+    value = (2^30 samples x N) / step time, i.e. input samples that went through BOTH filt and Welch per second.
+--config stft      BASELINE config 4: stft nfft = 1024, hop = 256, ComplexF32; 8 channels x 2^26 samples per GPU (64 channels on 8 GPUs);
+                   channels are independent: NO collective (periodograms.jl:872-897 is per-vector).
+--config resample  BASELINE config 5: FIRFilter 160//147, 5120 taps (32 per phase), Float32; 4 channels x 2^28 samples per GPU
+                   (32 channels on 8 GPUs) + one RCCL all-reduce for the cross-channel average of the last output block.
+
+The collective goes through the library's own communicator (mdsp_comm_* / mdsp_welch_mean_allreduce: RCCL behind the C ABI, the
+entry points a Julia host binds); torch.distributed ("nccl" = RCCL) carries the bootstrap id, the barrier and the max-over-ranks
+of the timing, and is the fallback transport should the library communicator fail to initialise (reported in `config.collective`).
 
 The JSON line also carries
-    roofline      for the dominant kernel (the fused overlap-save kernel): algorithmic bytes (8 B/sample: 4 read + 4
-                  written) / its mean launch duration, measured live with HIP events on the launch stream;
-                  `traffic` = measured HBM bytes per launch from profiles/pmc_*.json (rocprofv3 --pmc passes) if present.
-    kernels       the same for the Welch kernel (4 B/sample) and the on-box float4 copy yardstick.
-    cpu_baseline  the CPU oracle (numpy/scipy restatement of DSP.jl's algorithm, 1 thread) timed on a bounded sample.
+    roofline      the dominant kernel: algorithmic bytes / its mean launch duration, measured live with HIP events on
+                  the launch stream; `traffic` = HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -- measured
+                  live by re-running this script under rocprofv3 (N = 1, rocprofv3 on PATH), else the committed profiles/pmc_latest.json;
+                  `traffic_source` says which.
+    kernels       the other kernel of the step, the float4 copy / read yardsticks, and (N = 1) the remaining SURVEY section-8 rows at their
+                  single-GPU shares: stft, spectrogram, resample, firarb -- each with ms, algorithmic GB/s and frac of 8 TB/s.
+    host_path     (N = 1) the host-pointer entry points (mdsp_*_exec_host: pinned double buffers, H2D || kernel || D2H): PCIe-inclusive
+                  rates on a bounded sample, reported SEPARATELY -- never part of `value`.
+    cpu_baseline  the CPU oracle (numpy/scipy restatement of DSP.jl's algorithm; kind "port") timed on a bounded sample: 1 thread
+                  (`value`), all cores (`multi`), and the line-faithful per-block loop (`faithful`).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -30,6 +47,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured float4-copy rate
+METRIC = "Gsamples/s filt+welch, 1 Gsample Float32 stream; achieved HBM GB/s vs roofline"
 
 
 def parse():
@@ -37,10 +55,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2n", type=int, default=30, help="stream length per GPU = 2^log2n samples (BASELINE: 30)")
+    ap.add_argument("--config", choices=["filtwelch", "stft", "resample"], default="filtwelch")
+    ap.add_argument("--log2n", type=int, default=0, help="samples per channel = 2^log2n (default: 30 / 26 / 28 by config, BASELINE sizes)")
     ap.add_argument("--engine", choices=["auto", "fused", "rocfft"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=29, help="CPU baseline sample = 2^k samples")
+    ap.add_argument("--no-rows", action="store_true", help="skip the other section-8 rows (kernels.stft / spectrogram / resample / firarb)")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
+    ap.add_argument("--host-log2n", type=int, default=28)
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run under rocprofv3 for roofline.traffic")
+    ap.add_argument("--dry", action="store_true", help="CPU dry mode (tests): gloo, no device work; exercises sharding, the collective and the JSON schema")
     return ap.parse_args()
 
 
@@ -49,52 +73,286 @@ def lowpass_taps(n):
     return d.design.lowpass_firwindow(0.25, d.hamming(n), fs=1.0).astype("float32")
 
 
-def cpu_baseline(log2n: int):
-    """Oracle timed on the host (1 thread): same workload, bounded sample."""
+def resample_taps():
     import numpy as np
+    from fractions import Fraction
+    import dsp_jl_amd as d
+    h = d.resample_filter(Fraction(160, 147))
+    return (np.concatenate([h, np.zeros(5120 - len(h))]) if len(h) < 5120 else h[:5120]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(log2n: int):
+    """Oracle timed on the host, same workload, bounded sample: 1 thread, all cores, and the line-faithful block loop."""
+    import numpy as np
+    import scipy.fft as sfft
     from oracle import filt as ofilt, periodograms as opg, windows as ow
     try:
         import threadpoolctl
         ctl = threadpoolctl.threadpool_limits(1)
     except Exception:
         ctl = None
-    n = 1 << log2n
-    seg = min(n, 1 << 24)              # the stream is walked in 2^24-sample segments to bound host memory (~1.5 GB)
-    rng = np.random.default_rng(1776)
+    ncores = os.cpu_count() or 1
     b = np.asarray(lowpass_taps(256))
     nb, nfft = 256, 2048
     L = nfft - nb + 1
-    import scipy.fft as sfft
     H = sfft.rfft(np.concatenate([b / np.float32(nfft), np.zeros(nfft - nb, np.float32)]))
-    t_filt = t_welch = 0.0
-    for s0 in range(0, n, seg):
-        x = rng.standard_normal(seg, dtype=np.float32)
-        # vectorised form of the oracle's block loop (same algorithm: rfft -> *H -> irfft per 2048-point block), batched
-        t0 = time.perf_counter()
-        xp = np.concatenate([np.zeros(nb - 1, np.float32), x, np.zeros(nfft, np.float32)])
-        nblk = -(-seg // L)
-        y = np.empty(nblk * L, np.float32)
-        CH = 2048
-        for k0 in range(0, nblk, CH):
-            k1 = min(nblk, k0 + CH)
-            idx = (np.arange(k0, k1) * L)[:, None] + np.arange(nfft)[None, :]
-            blk = sfft.irfft(sfft.rfft(xp[idx], axis=1, workers=1) * H, nfft, axis=1, workers=1) * np.float32(nfft)
-            y[k0 * L:k1 * L] = blk[:, nb - 1:].reshape(-1)
-        t_filt += time.perf_counter() - t0
-        if s0 == 0:  # spot-check the batched form against the line-faithful oracle on a prefix
-            ref = ofilt._fftfilt(b, x[:20000], nfft)
-            assert np.allclose(y[:20000], ref, rtol=1e-4, atol=1e-5)
-        t0 = time.perf_counter()
-        opg.welch_pgram(x, 4096, 2048, window=ow.hanning)
-        t_welch += time.perf_counter() - t0
-        del xp, y
-    if ctl is not None:
-        ctl.restore_original_limits() if hasattr(ctl, "restore_original_limits") else None
-    return {"value": round(n / (t_filt + t_welch) / 1e9, 5), "unit": "Gsamples/s", "cores": 1, "kind": "port",
-            "sample": f"2^{log2n} Float32 samples in 2^24-sample segments: overlap-save filt {t_filt:.2f}s + welch {t_welch:.2f}s, numpy/scipy(pocketfft) "
-                      f"restatement of DSP.jl (not DSP.jl/FFTW), host has {os.cpu_count()} cores"}
+
+    def run(n, workers):
+        seg = min(n, 1 << 24)          # the stream is walked in 2^24-sample segments to bound host memory (~1.5 GB)
+        rng = np.random.default_rng(1776)
+        t_filt = t_welch = 0.0
+        with sfft.set_workers(workers):
+            for s0 in range(0, n, seg):
+                x = rng.standard_normal(seg, dtype=np.float32)
+                # vectorised form of the oracle's block loop (same algorithm: rfft -> *H -> irfft per 2048-point block), batched
+                t0 = time.perf_counter()
+                xp = np.concatenate([np.zeros(nb - 1, np.float32), x, np.zeros(nfft, np.float32)])
+                nblk = -(-seg // L)
+                y = np.empty(nblk * L, np.float32)
+                CH = 2048
+                for k0 in range(0, nblk, CH):
+                    k1 = min(nblk, k0 + CH)
+                    idx = (np.arange(k0, k1) * L)[:, None] + np.arange(nfft)[None, :]
+                    blk = sfft.irfft(sfft.rfft(xp[idx], axis=1) * H, nfft, axis=1) * np.float32(nfft)
+                    y[k0 * L:k1 * L] = blk[:, nb - 1:].reshape(-1)
+                t_filt += time.perf_counter() - t0
+                if s0 == 0:  # spot-check the batched form against the line-faithful oracle on a prefix
+                    ref = ofilt._fftfilt(b, x[:20000], nfft)
+                    assert np.allclose(y[:20000], ref, rtol=1e-4, atol=1e-5)
+                t0 = time.perf_counter()
+                opg.welch_pgram(x, 4096, 2048, window=ow.hanning)
+                t_welch += time.perf_counter() - t0
+                del xp, y
+        return t_filt, t_welch
+
+    n = 1 << log2n
+    tf1, tw1 = run(n, 1)
+    tfm, twm = run(n, ncores)
+    # the line-faithful oracle (one Python iteration per 2048-point block, exactly Filters/filt.jl:504-518) on a smaller sample
+    nf = 1 << min(log2n, 24)
+    xf = np.random.default_rng(1776).standard_normal(nf, dtype=np.float32)
+    t0 = time.perf_counter()
+    ofilt._fftfilt(b, xf, nfft)
+    t_faith_filt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    opg.welch_pgram(xf, 4096, 2048, window=ow.hanning, sequential=True)
+    t_faith_welch = time.perf_counter() - t0
+    if ctl is not None and hasattr(ctl, "restore_original_limits"):
+        ctl.restore_original_limits()
+    return {"value": round(n / (tf1 + tw1) / 1e9, 5), "unit": "Gsamples/s", "cores": 1, "kind": "port",
+            "sample": f"2^{log2n} Float32 samples in 2^24-sample segments: overlap-save filt {tf1:.2f}s + welch {tw1:.2f}s, numpy/scipy(pocketfft) "
+                      f"restatement of DSP.jl (not DSP.jl/FFTW; the filt leg is the block loop vectorised over 2048 blocks per call), host has {ncores} cores",
+            "multi": {"value": round(n / (tfm + twm) / 1e9, 5), "cores": ncores,
+                      "sample": f"same sample, scipy.fft.set_workers({ncores}): filt {tfm:.2f}s + welch {twm:.2f}s"},
+            "faithful": {"value": round(nf / (t_faith_filt + t_faith_welch) / 1e9, 5), "cores": 1,
+                         "sample": f"2^{min(log2n, 24)} samples through the line-faithful oracle (one Python iteration per block / frame, frame-by-frame "
+                                   f"Float32 accumulation): filt {t_faith_filt:.2f}s + welch {t_faith_welch:.2f}s"}}
 
 
+# ------------------------------------------------------------------------------------------------------------------ helpers
+class Timer:
+    """HIP events on the launch stream (torch.cuda.Event would only see torch's current stream; these are recorded on the
+    stream handed to the library)."""
+
+    def __init__(self, lib, _lib, stream):
+        self.lib, self._lib, self.stream = lib, _lib, stream
+
+    def ev(self):
+        e = C.c_void_p()
+        self._lib.check(self.lib.mdsp_event_create(C.byref(e)))
+        return e
+
+    def rec(self, e):
+        self._lib.check(self.lib.mdsp_event_record(e, self.stream))
+
+    def ms(self, a, b):
+        v = C.c_float()
+        self._lib.check(self.lib.mdsp_event_elapsed_ms(a, b, C.byref(v)))
+        return v.value
+
+    def time(self, fn, reps=5):
+        import torch
+        fn()
+        torch.cuda.synchronize()
+        a, b = self.ev(), self.ev()
+        ts = []
+        for _ in range(reps):
+            self.rec(a); fn(); self.rec(b)
+            torch.cuda.synchronize()
+            ts.append(self.ms(a, b))
+        ts.sort()
+        return ts[len(ts) // 2], ts[0]
+
+
+def roof(kernel, ms, alg_bytes, traffic=None, extra=None):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+         "traffic": traffic, "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def committed_traffic():
+    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(p))
+        return d, f"profiles/pmc_latest.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py @ {d.get('commit', 'round-1 HEAD a2de93b')}; NOT measured in this run)"
+    except Exception:
+        return {}, None
+
+
+def live_traffic(args):
+    """Re-run this script (2 steps, no extras) under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel-trace only, as
+    MI355X_MICROARCH.md prescribes) and return HBM bytes per launch of the fused kernels.  FETCH_SIZE is doubled (gfx950 correction)."""
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prof_summary
+    tmp = tempfile.mkdtemp(prefix="mdsp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(tmp, ctr)
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "bench", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2",
+               "--warmup", "1", "--no-cpu-baseline", "--no-rows", "--no-host", "--no-live-pmc", "--config", args.config, "--engine", args.engine]
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)           # our own child process group only
+                return None, f"rocprofv3 --pmc {ctr} pass timed out"
+        except Exception as e:
+            return None, f"rocprofv3 failed to start: {e}"
+        dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+        if not dbs:
+            return None, f"rocprofv3 --pmc {ctr} produced no database (rc {p.returncode})"
+        try:
+            out[ctr] = prof_summary.pmc(dbs[0])
+        except Exception as e:
+            return None, f"cannot read the {ctr} database: {e}"
+    res = {}
+    for key, pat in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("stft", "stft_fused_kernel"), ("resample", "polyphase_fast_kernel"),
+                     ("copy", "mdsp_copy_kernel")):
+        f = next((v["counters"].get("FETCH_SIZE") for k, v in out["FETCH_SIZE"].items() if pat in k), None)
+        w = next((v["counters"].get("WRITE_SIZE") for k, v in out["WRITE_SIZE"].items() if pat in k), None)
+        if f is not None and w is not None:
+            res[f"{key}_bytes_per_launch"] = int(2 * f * 1024 + w * 1024)
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res, "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes of this command, 2 steps); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH correction)"
+
+
+# ------------------------------------------------------------------------------------------------------------------ rows / host path
+def measure_rows(tm, lib, _lib, d, stream):
+    """The remaining SURVEY section-8 rows at their single-GPU shares (device-resident, HIP events): config 4 stft / spectrogram
+    (8 ch x 2^26 ComplexF32, nfft 1024, hop 256), config 5 resample 160//147 (4 ch x 2^28 Float32), (f)1 FIRArbitrary at the same shape."""
+    import numpy as np
+    import torch
+    from dsp_jl_amd.periodograms import _StftPlan, compute_window
+    rows = {}
+    g = torch.Generator(device="cuda"); g.manual_seed(1776)
+    nch, n = 8, 1 << 26
+    s = torch.view_as_complex(torch.randn((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) * math.sqrt(0.5))
+    win, norm2 = compute_window(d.hanning, 1024)
+    K = d.frame_count(n, 1024, 768)
+    for name, psd, outdt, bps in (("stft", 0, torch.complex64, 40.0), ("spectrogram", 1, torch.float32, 24.0)):
+        plan = _StftPlan(1024, 768, 1024, win, 1.0 * norm2, False, psd, np.complex64, d.ENGINE_FUSED)
+        out = torch.empty((nch, K, 1024), dtype=outdt, device="cuda")
+        med, best = tm.time(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, s.data_ptr(), n, nch, n, out.data_ptr(), 1024, K * 1024, stream)))
+        rows[name] = roof(f"stft_fused_kernel ({name}, config 4 share: 8 ch x 2^26 ComplexF32, {bps:.0f} B/sample)", med, bps * n * nch,
+                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
+        del out, plan
+    del s
+    torch.cuda.empty_cache()
+    nch, n = 4, 1 << 28
+    h = resample_taps()
+    x = torch.randn((nch, n), generator=g, device="cuda", dtype=torch.float32)
+    fh = C.c_void_p()
+    _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), 160, 147, _lib.F32, _lib.F32, nch))
+    ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, n, C.byref(ol)))
+    y = torch.empty((nch, ol.value + 1), dtype=torch.float32, device="cuda")
+    nw = C.c_int64()
+
+    def fir():
+        _lib.check(lib.mdsp_fir_reset(fh))
+        _lib.check(lib.mdsp_fir_exec(fh, x.data_ptr(), n, n, y.data_ptr(), ol.value, ol.value + 1, C.byref(nw), stream))
+
+    med, best = tm.time(fir)
+    rows["resample"] = roof("polyphase_fast_kernel (config 5 share: 4 ch x 2^28 Float32, 160//147, 8.354 B/sample)", med, (4 + 4 * 160 / 147) * n * nch,
+                            extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
+    _lib.check(lib.mdsp_fir_destroy(fh))
+    rate = 160 / 147
+    ha = d.resample_filter(rate, 32).astype(np.float32)
+    fa = C.c_void_p()
+    _lib.check(lib.mdsp_firarb_create(C.byref(fa), ha.ctypes.data_as(C.c_void_p), len(ha), rate, 32, _lib.F32, _lib.F32, nch))
+    ola = C.c_int64(); _lib.check(lib.mdsp_firarb_outputlength(fa, n, C.byref(ola)))
+    ya = y if ola.value + 1 <= y.shape[1] else torch.empty((nch, ola.value + 1), dtype=torch.float32, device="cuda")
+    ld = ya.shape[1]
+
+    def arb():
+        _lib.check(lib.mdsp_firarb_reset(fa))
+        _lib.check(lib.mdsp_firarb_exec(fa, x.data_ptr(), n, n, ya.data_ptr(), ola.value + 1, ld, C.byref(nw), stream))
+
+    med, best = tm.time(arb)
+    rows["firarb"] = roof("arbitrary_fir_kernel (row f1: 4 ch x 2^28 Float32, rate 160/147 as Float64, warm trajectory)", med, (4 + 4 * rate) * n * nch,
+                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
+    _lib.check(lib.mdsp_firarb_destroy(fa))
+    del x, y, ya
+    torch.cuda.empty_cache()
+    return rows
+
+
+def measure_host_path(lib, _lib, d, log2n):
+    """mdsp_ols_exec_host / mdsp_welch_exec_host on a bounded sample: pageable numpy arrays (staged) and page-locked arrays."""
+    import numpy as np
+    from dsp_jl_amd.dspbase import OlsPlan
+    n = 1 << log2n
+    rng = np.random.default_rng(1776)
+    x = rng.standard_normal(n, dtype=np.float32)
+    plan = OlsPlan(np.asarray(lowpass_taps(256)), 2048, n, _lib.OLS_FILT, d.ENGINE_AUTO)
+    cfg = d.WelchConfig(n, np.float32, n=4096, noverlap=2048, window=d.hanning)
+    res = {"sample": f"2^{log2n} Float32 samples (bounded sample of the headline workload); wall clock of the synchronous call, PCIe included",
+           "unit": "Gsamples/s", "note": "reported separately: never part of `value`"}
+
+    def wall(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    y = np.empty_like(x)
+    psd = np.empty(cfg.nout, np.float32)
+    xp, yp, pp = x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), psd.ctypes.data_as(C.c_void_p)
+    t = wall(lambda: _lib.check(lib.mdsp_ols_exec_host(plan._h, xp, n, 1, n, yp, n, n, 0)))
+    res["filt_pageable"] = {"Gsamples_per_s": round(n / t / 1e9, 3), "GBps_pcie_both_ways": round(8.0 * n / t / 1e9, 1)}
+    t = wall(lambda: _lib.check(lib.mdsp_welch_exec_host(cfg._h, xp, n, 1, n, pp, cfg.nout, 0)))
+    res["welch_pageable"] = {"Gsamples_per_s": round(n / t / 1e9, 3), "GBps_pcie_h2d": round(4.0 * n / t / 1e9, 1)}
+    pin_in, pin_out = C.c_void_p(), C.c_void_p()
+    _lib.check(lib.mdsp_host_alloc(C.byref(pin_in), n * 4)); _lib.check(lib.mdsp_host_alloc(C.byref(pin_out), n * 4))
+    try:
+        C.memmove(pin_in, xp, n * 4)
+        t = wall(lambda: _lib.check(lib.mdsp_ols_exec_host(plan._h, pin_in, n, 1, n, pin_out, n, n, _lib.HOST_PINNED)))
+        res["filt_pinned"] = {"Gsamples_per_s": round(n / t / 1e9, 3), "GBps_pcie_both_ways": round(8.0 * n / t / 1e9, 1)}
+        t = wall(lambda: _lib.check(lib.mdsp_welch_exec_host(cfg._h, pin_in, n, 1, n, pp, cfg.nout, _lib.HOST_PINNED)))
+        res["welch_pinned"] = {"Gsamples_per_s": round(n / t / 1e9, 3), "GBps_pcie_h2d": round(4.0 * n / t / 1e9, 1)}
+    finally:
+        lib.mdsp_host_free(pin_in); lib.mdsp_host_free(pin_out)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     import torch
@@ -102,6 +360,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry:
+        return dry_main(args, world, rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -110,51 +370,127 @@ def main():
         torch.cuda.set_device(0)
     import numpy as np
     import dsp_jl_amd as d
-    from dsp_jl_amd import _lib, _dev
+    from dsp_jl_amd import _lib
     from dsp_jl_amd.dspbase import OlsPlan
     lib = _lib.lib()
     _lib.check(lib.mdsp_init(local if world > 1 else 0))
     eng = {"auto": d.ENGINE_AUTO, "fused": d.ENGINE_FUSED, "rocfft": d.ENGINE_ROCFFT}[args.engine]
-
-    n = 1 << args.log2n
     dev = torch.device("cuda", torch.cuda.current_device())
-    g = torch.Generator(device=dev)
-    g.manual_seed(1776 + rank)                          # seed 1776 = test/runtests.jl:20; one independent stream per GPU
-    x = torch.randn(n, generator=g, device=dev, dtype=torch.float32)
-    t = torch.arange(n, device=dev, dtype=torch.float32)
-    x += 0.5 * torch.sin((2 * np.pi * 0.1234) * t)      # BASELINE.md config 3 line (phase accuracy is irrelevant here)
-    del t
-    xc = x.view(1, n)                                   # one column = one channel, contiguous
-    y = torch.empty_like(xc)
-    taps = lowpass_taps(256)
-    plan = OlsPlan(np.asarray(taps), 2048, n, _lib.OLS_FILT, eng)
-    cfg = d.WelchConfig(n, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=eng)
-    psd = torch.empty((1, cfg.nout), dtype=torch.float32, device=dev)
-    mean = torch.empty(cfg.nout, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    tm = Timer(lib, _lib, stream)
 
-    def ev():
-        import ctypes as C
-        e = C.c_void_p()
-        _lib.check(lib.mdsp_event_create(C.byref(e)))
-        return e
+    # the library's RCCL communicator (C ABI); torch.distributed is the fallback transport
+    comm, collective = None, "none (1 GPU)"
+    if world > 1:
+        try:
+            comm = d.Comm.from_torch_distributed()
+            collective = "mdsp_comm (RCCL ncclAllReduce behind the C ABI)"
+        except Exception as e:  # pragma: no cover - needs > 1 GPU
+            comm, collective = None, f"torch.distributed nccl (mdsp_comm init failed: {e})"
+        flags = torch.tensor([1.0 if comm is not None else 0.0], device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)          # all ranks must agree on the transport
+        if float(flags.item()) < 1.0 and comm is not None:
+            comm.close(); comm = None
+            collective = "torch.distributed nccl (mdsp_comm unavailable on some rank)"
 
-    import ctypes as C
+    g = torch.Generator(device=dev)
+    g.manual_seed(1776 + rank)                          # seed 1776 = test/runtests.jl:20; independent data per GPU
 
-    def step(evt):
-        a, b_, c = evt
-        _lib.check(lib.mdsp_event_record(a, stream))
-        _lib.check(lib.mdsp_ols_exec(plan._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream))
-        _lib.check(lib.mdsp_event_record(b_, stream))
-        _lib.check(lib.mdsp_welch_exec(cfg._h, x.data_ptr(), n, 1, n, psd.data_ptr(), cfg.nout, stream))
-        _lib.check(lib.mdsp_event_record(c, stream))
-        _lib.check(lib.mdsp_channel_sum(psd.data_ptr(), cfg.nout, 1, cfg.nout, _lib.F32, mean.data_ptr(), stream))
-        if world > 1:
-            dist.all_reduce(mean, op=dist.ReduceOp.SUM)          # RCCL over xGMI: 2049 floats
-        mean.mul_(1.0 / world)
+    if args.config == "filtwelch":
+        log2n = args.log2n or 30
+        n = 1 << log2n
+        x = torch.randn(n, generator=g, device=dev, dtype=torch.float32)
+        t = torch.arange(n, device=dev, dtype=torch.float32)
+        x += 0.5 * torch.sin((2 * np.pi * 0.1234) * t)      # BASELINE.md config 3 line (phase accuracy is irrelevant here)
+        del t
+        y = torch.empty(n, dtype=torch.float32, device=dev)
+        plan = OlsPlan(np.asarray(lowpass_taps(256)), 2048, n, _lib.OLS_FILT, eng)
+        cfg = d.WelchConfig(n, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=eng)
+        psd = torch.empty((1, cfg.nout), dtype=torch.float32, device=dev)
+        mean = torch.empty(cfg.nout, dtype=torch.float32, device=dev)
+        units_per_rank = n
 
-    evs = [(ev(), ev(), ev()) for _ in range(args.steps)]        # HIP events on the launch stream, created up front
-    scratch = (ev(), ev(), ev())
+        def step(evt):
+            a, b_, c = evt
+            tm.rec(a)
+            _lib.check(lib.mdsp_ols_exec(plan._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream))
+            tm.rec(b_)
+            _lib.check(lib.mdsp_welch_exec(cfg._h, x.data_ptr(), n, 1, n, psd.data_ptr(), cfg.nout, stream))
+            tm.rec(c)
+            if comm is not None or world == 1:   # local channel sum -> RCCL all-reduce of 2049 floats over xGMI -> 1/nch: ONE C-ABI call
+                _lib.check(lib.mdsp_welch_mean_allreduce(cfg._h, psd.data_ptr(), 1, cfg.nout, world, mean.data_ptr(), comm._h if comm else None, stream))
+            else:
+                _lib.check(lib.mdsp_channel_sum(psd.data_ptr(), cfg.nout, 1, cfg.nout, _lib.F32, mean.data_ptr(), stream))
+                dist.all_reduce(mean, op=dist.ReduceOp.SUM)
+                mean.mul_(1.0 / world)
+        names = ("filt", "welch")
+        alg = (8.0 * n, 4.0 * n)
+        kern = ("ols_fused_kernel (overlap-save filt, 8 B/sample)", "welch_half_kernel (+reduce+finalize; 4 B/sample)")
+        workload = (f"filt(256-tap overlap-save, nfft=2048) + welch_pgram(nfft=4096, hanning, 50% overlap) per 2^{log2n}-sample Float32 stream; "
+                    "one stream (channel) per GPU; RCCL all-reduce of the 2049-bin PSD for N>1")
+        metric, dtype, engine_used = METRIC, "f32", {1: "fused", 2: "rocfft"}[plan.engine]
+    elif args.config == "stft":
+        from dsp_jl_amd.periodograms import _StftPlan, compute_window
+        log2n = args.log2n or 26
+        nch, n = 8, 1 << log2n
+        s = torch.view_as_complex(torch.randn((nch, n, 2), generator=g, device=dev, dtype=torch.float32) * math.sqrt(0.5))
+        win, norm2 = compute_window(d.hanning, 1024)
+        K = d.frame_count(n, 1024, 768)
+        plan = _StftPlan(1024, 768, 1024, win, 1.0 * norm2, False, 0, np.complex64, eng)
+        out = torch.empty((nch, K, 1024), dtype=torch.complex64, device=dev)
+        units_per_rank = nch * n
+
+        def step(evt):
+            a, b_, c = evt
+            tm.rec(a)
+            _lib.check(lib.mdsp_stft_exec(plan._h, s.data_ptr(), n, nch, n, out.data_ptr(), 1024, K * 1024, stream))
+            tm.rec(b_)
+            tm.rec(c)                            # channels are independent: no collective on this path
+        names = ("stft", "none")
+        alg = (40.0 * n * nch, 0.0)
+        kern = ("stft_fused_kernel (config 4: 8 + 8*1024/256 = 40 B/sample)", "-")
+        workload = (f"stft(nfft=1024, hop=256, hanning, two-sided) of {nch} channels x 2^{log2n} ComplexF32 samples per GPU -> {nch} x (1024 x {K}) ComplexF32; "
+                    f"channel c of {nch}*N on rank c div {nch}; no collective")
+        metric, dtype, engine_used = "Gsamples/s stft nfft=1024 hop=256 ComplexF32, 8 channels x 64 Msample per GPU (BASELINE config 4)", "c64(f32 pairs)", "fused" if eng != d.ENGINE_ROCFFT else "rocfft"
+    else:
+        log2n = args.log2n or 28
+        nch, n = 4, 1 << log2n
+        h = resample_taps()
+        x = torch.randn((nch, n), generator=g, device=dev, dtype=torch.float32)
+        fh = C.c_void_p()
+        _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), 160, 147, _lib.F32, _lib.F32, nch))
+        ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, n, C.byref(ol)))
+        y = torch.empty((nch, ol.value), dtype=torch.float32, device=dev)
+        nw = C.c_int64()
+        TAIL = 1024
+        avg = torch.empty(TAIL, dtype=torch.float32, device=dev)
+        units_per_rank = nch * n
+
+        def step(evt):
+            a, b_, c = evt
+            tm.rec(a)
+            _lib.check(lib.mdsp_fir_reset(fh))
+            _lib.check(lib.mdsp_fir_exec(fh, x.data_ptr(), n, n, y.data_ptr(), ol.value, ol.value, C.byref(nw), stream))
+            tm.rec(b_)
+            # "RCCL avg" (BASELINE config 5): cross-channel average of the last output block -- local sum over this rank's channels,
+            # one all-reduce of 1024 floats, 1/nch_total
+            tail = y[:, ol.value - TAIL:]
+            _lib.check(lib.mdsp_channel_sum(tail.data_ptr(), TAIL, nch, ol.value, _lib.F32, avg.data_ptr(), stream))
+            if comm is not None:
+                _lib.check(lib.mdsp_allreduce_sum(comm._h, avg.data_ptr(), TAIL, _lib.F32, stream))
+            elif world > 1:
+                dist.all_reduce(avg, op=dist.ReduceOp.SUM)
+            avg.mul_(1.0 / (nch * world))
+            tm.rec(c)
+        names = ("resample", "channel average + all-reduce")
+        alg = ((4 + 4 * 160 / 147) * n * nch, 0.0)
+        kern = ("polyphase_fast_kernel (config 5: 4 + 4*160/147 = 8.354 B/input sample)", "-")
+        workload = (f"resample 160//147 (FIRFilter, 5120 taps = 32 per phase) of {nch} channels x 2^{log2n} Float32 samples per GPU -> {ol.value} outputs per channel; "
+                    "RCCL all-reduce (1024 floats) for the cross-channel average of the last output block")
+        metric, dtype, engine_used = "Gsamples/s FIRFilter polyphase resample 160//147, 32 taps/phase, Float32, 4 channels x 256 Msample per GPU (BASELINE config 5)", "f32", "hip"
+
+    evs = [(tm.ev(), tm.ev(), tm.ev()) for _ in range(args.steps)]        # HIP events on the launch stream, created up front
+    scratch = (tm.ev(), tm.ev(), tm.ev())
     for _ in range(args.warmup):
         step(scratch)
     torch.cuda.synchronize()
@@ -169,83 +505,117 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t_ols = t_welch = 0.0
-    for a, b_, c in evs:
-        ms = C.c_float()
-        _lib.check(lib.mdsp_event_elapsed_ms(a, b_, C.byref(ms))); t_ols += ms.value
-        _lib.check(lib.mdsp_event_elapsed_ms(b_, c, C.byref(ms))); t_welch += ms.value
+    t_a = sum(tm.ms(a, b_) for a, b_, _ in evs) / max(1, args.steps)
+    t_b = sum(tm.ms(b_, c) for _, b_, c in evs) / max(1, args.steps)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        ols_ms = t_ols / args.steps
-        welch_ms = t_welch / args.steps
-        # on-box copy yardstick (float4 copy kernel, 2 x 4 GiB moved)
-        c0, c1 = ev(), ev()
-        _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))
-        _lib.check(lib.mdsp_event_record(c0, stream))
-        for _ in range(3):
-            _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))
-        _lib.check(lib.mdsp_event_record(c1, stream))
-        ms = C.c_float()
-        _lib.check(lib.mdsp_event_elapsed_ms(c0, c1, C.byref(ms)))
-        copy_gbs = 3 * 2 * n * 4 / (ms.value * 1e-3) / 1e9
-        # read-only yardstick (float4 loads summed, nothing written): what a 4 B/sample reader like the Welch kernel could reach
-        _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), n * 4, 4, 8, stream))
-        _lib.check(lib.mdsp_event_record(c0, stream))
-        for _ in range(3):
-            _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), n * 4, 4, 8, stream))
-        _lib.check(lib.mdsp_event_record(c1, stream))
-        _lib.check(lib.mdsp_event_elapsed_ms(c0, c1, C.byref(ms)))
-        read_gbs = 3 * n * 4 / (ms.value * 1e-3) / 1e9
-        ols_gbs = 8.0 * n / (ols_ms * 1e-3) / 1e9
-        welch_gbs = 4.0 * n / (welch_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        kern_traffic = {}
-        if os.path.exists(pmc):
-            try:
-                kern_traffic = json.load(open(pmc))
-                traffic = kern_traffic.get("ols_fused_bytes_per_launch")
-            except Exception:
-                pass
-        dominant_is_ols = ols_ms >= welch_ms
-        roof = {"bound": "hbm", "kernel": "ols_fused_kernel (overlap-save filt, 8 B/sample)", "achieved": round(ols_gbs, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ols_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "ms_per_launch": round(ols_ms, 4)}
-        welch_roof = {"bound": "hbm", "kernel": "welch_fused_kernel (+finalize; 4 B/sample)", "achieved": round(welch_gbs, 1),
-                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(welch_gbs / HBM_PEAK_GBS, 4),
-                      "traffic": kern_traffic.get("welch_fused_bytes_per_launch"), "ms_per_launch": round(welch_ms, 4)}
-        # the Welch kernel's other roof: 5 N log2 N flop per 4096-point transform of 4096 new samples, against the packed-FP32
-        # add/multiply rate (butterflies are adds, not FMAs): 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz (boost; the kernel is
-        # power-throttled to ~1.8 GHz)
-        welch_tflops = 5.0 * 4096 * 12 * (n / 4096) / (welch_ms * 1e-3) / 1e12
-        welch_roof["valu"] = {"achieved": round(welch_tflops, 1), "peak": 78.6, "unit": "TFLOP/s (packed f32 add/mul)", "frac": round(welch_tflops / 78.6, 4)}
-        if not dominant_is_ols:
-            roof, welch_roof = welch_roof, roof
         out = {
-            "metric": "Gsamples/s filt+welch, 1 Gsample Float32 stream; achieved HBM GB/s vs roofline",
-            "value": round(n * world / dt * args.steps / 1e9, 3), "unit": "Gsamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "filt(256-tap overlap-save, nfft=2048) + welch_pgram(nfft=4096, hanning, 50% overlap) per "
-                                   f"2^{args.log2n}-sample Float32 stream; one stream (channel) per GPU; RCCL all-reduce of the 2049-bin PSD for N>1",
-                       "samples_per_gpu": n, "engine": {1: "fused", 2: "rocfft"}[plan.engine], "stages_ms": {"filt": round(ols_ms, 4), "welch": round(welch_ms, 4)},
-                       "stage_Gsamples_per_s": {"filt": round(n / ols_ms / 1e6, 2), "welch": round(n / welch_ms / 1e6, 2)}},
-            "roofline": roof,
-            "kernels": {"other": welch_roof, "copy_float4_GBps": round(copy_gbs, 1), "read_float4_GBps": round(read_gbs, 1)},
+            "metric": metric,
+            "value": round(units_per_rank * world / dt * args.steps / 1e9, 3), "unit": "Gsamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "name": args.config, "samples_per_gpu": units_per_rank, "engine": engine_used, "collective": collective,
+                       "stages_ms": {names[0]: round(t_a, 4), names[1]: round(t_b, 4)}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        traffic, traffic_source = committed_traffic()
+        if world == 1 and not args.no_live_pmc:
+            try:
+                live, src = live_traffic(args)
+            except Exception as e:  # pragma: no cover
+                live, src = None, f"live PMC pass failed: {e}"
+            if live:
+                traffic, traffic_source = live, src
+            else:
+                traffic_source = f"{traffic_source}; live pass unavailable ({src})"
+        tkey = {"filtwelch": ("ols_fused_bytes_per_launch", "welch_fused_bytes_per_launch"), "stft": ("stft_bytes_per_launch", None),
+                "resample": ("resample_bytes_per_launch", None)}[args.config]
+        main_roof = roof(kern[0], t_a, alg[0], traffic.get(tkey[0]) if traffic else None, {"traffic_source": traffic_source})
+        kernels = {}
+        if args.config == "filtwelch":
+            other = roof(kern[1], t_b, alg[1], traffic.get(tkey[1]) if traffic else None, {"traffic_source": traffic_source})
+            # the Welch kernel's other roof: 5 N log2 N flop per 4096-point transform of 4096 new samples against the packed-FP32 add/multiply
+            # rate (butterflies are adds, not FMAs): 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz
+            tfl = 5.0 * 4096 * 12 * (units_per_rank / 4096) / (t_b * 1e-3) / 1e12
+            other["valu"] = {"achieved": round(tfl, 1), "peak": 78.6, "unit": "TFLOP/s (packed f32 add/mul)", "frac": round(tfl / 78.6, 4)}
+            if t_b > t_a:            # `roofline` is the dominant (longer) kernel of the step
+                main_roof, other = other, main_roof
+            kernels["other"] = other
+            out["config"]["stage_Gsamples_per_s"] = {"filt": round(units_per_rank / t_a / 1e6, 2), "welch": round(units_per_rank / t_b / 1e6, 2)}
+            # on-box yardsticks: float4 copy (2 x 4 GiB moved) and read-only stream
+            nb = units_per_rank * 4
+            med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), nb, stream)), reps=3)
+            kernels["copy_float4_GBps"] = round(2 * nb / med / 1e6, 1)
+            med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 4, 8, stream)), reps=3)
+            kernels["read_float4_GBps"] = round(nb / med / 1e6, 1)
+        out["roofline"] = main_roof
+        if world == 1 and not args.no_rows and args.config == "filtwelch":
+            del x, y
+            torch.cuda.empty_cache()
+            try:
+                kernels.update(measure_rows(tm, lib, _lib, d, stream))
+            except Exception as e:  # pragma: no cover
+                kernels["rows_error"] = str(e)
+        out["kernels"] = kernels
+        if world == 1 and not args.no_host and args.config == "filtwelch":
+            try:
+                out["host_path"] = measure_host_path(lib, _lib, d, args.host_log2n)
+            except Exception as e:  # pragma: no cover
+                out["host_path"] = {"error": str(e)}
+        if world == 1 and not args.no_cpu_baseline and args.config == "filtwelch":
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_log2n)
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "Gsamples/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+        out["commit"] = git_head()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                                   # rank 0 may still be printing / measuring its yardsticks: leave together
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+
+
+def dry_main(args, world, rank):
+    """CPU dry mode: the launcher contract (env, gloo rendezvous on 127.0.0.1, barrier + max-over-ranks timing, rank-0 JSON line), the
+    channel sharding and the collective call pattern of each --config with world_size ranks and NO device work.  tests/test_bench_dry.py
+    runs it with 2 ranks; it measures nothing (value = null)."""
+    import torch
+    import torch.distributed as dist
+    import dsp_jl_amd as d
+    if world > 1:
+        dist.init_process_group("gloo")
+    per_gpu = {"filtwelch": 1, "stft": 8, "resample": 4}[args.config]
+    nch_total = per_gpu * world
+    mine = d.channel_shard(nch_total, rank, world)
+    assert len(mine) == per_gpu                                     # weak scaling: fixed channels per GPU
+    nred = {"filtwelch": 2049, "stft": 0, "resample": 1024}[args.config]
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if nred:
+            v = torch.full((nred,), float(len(mine)), dtype=torch.float32)   # stands for the local channel sum
+            if world > 1:
+                dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            v.mul_(1.0 / nch_total)
+            assert abs(float(v[0]) - 1.0) < 1e-6                    # every channel counted exactly once
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC if args.config == "filtwelch" else f"dry:{args.config}", "value": None, "unit": "Gsamples/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tt.item()) / max(1, args.steps) * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry mode)",
+                          "config": {"workload": f"dry run of --config {args.config}", "name": args.config, "channels_total": nch_total,
+                                     "channels_per_gpu": per_gpu, "collective": "gloo (dry)", "allreduce_floats": nred}}), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

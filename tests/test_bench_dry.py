@@ -1,0 +1,44 @@
+"""bench.py's launcher contract under torch.distributed.run with 2 ranks on CPU (gloo, --dry): every --config shards its channels
+8 / 4 / 1 per rank, issues its collective and prints ONE JSON line from rank 0 with the driver's schema.  The CPU baseline legs (1 thread,
+all cores, line-faithful) are exercised on a tiny sample."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("config,per_gpu,nred", [("filtwelch", 1, 2049), ("stft", 8, 0), ("resample", 4, 1024)])
+def test_bench_dry_two_ranks(config, per_gpu, nred):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", config, "--dry"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["channels_per_gpu"] == per_gpu and out["config"]["channels_total"] == 2 * per_gpu and out["config"]["allreduce_floats"] == nred
+
+
+def test_cpu_baseline_variants_small_sample():
+    sys.path.insert(0, ROOT)
+    import bench
+    cb = bench.cpu_baseline(18)
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["multi"]["cores"] == (os.cpu_count() or 1) and cb["multi"]["value"] > 0
+    assert cb["faithful"]["value"] > 0 and "line-faithful" in cb["faithful"]["sample"]
