@@ -142,6 +142,11 @@ PROTOTYPES = {
     "mdsp_convnd_fft": (ci, [vp, pi64, vp, pi64, ci, ci, vp, vp]),
     "mdsp_convnd_direct": (ci, [vp, pi64, vp, pi64, ci, ci, vp, vp]),
     "mdsp_tdfir_exec": (ci, [vp, i64, ci, vp, i64, i64, i64, vp, i64, vp]),
+    "mdsp_ols_plan_cached": (ci, [pvp, vp, i64, i64, i64, ci, ci, ci, vp]),
+    "mdsp_welch_plan_cached": (ci, [pvp, i64, i64, i64, pdbl, cd, ci, ci, ci, vp]),
+    "mdsp_stft_plan_cached": (ci, [pvp, i64, i64, i64, pdbl, cd, ci, ci, ci, ci, vp]),
+    "mdsp_plan_cache_stats": (ci, [pi64, pi64, pi64]),
+    "mdsp_plan_cache_clear": (ci, []),
     "mdsp_event_create": (ci, [pvp]),
     "mdsp_event_destroy": (ci, [vp]),
     "mdsp_event_record": (ci, [vp, vp]),

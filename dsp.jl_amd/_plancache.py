@@ -53,10 +53,11 @@ def window_key(window):
 
 
 def ctx_key():
-    """Plans own work buffers: one cached plan per (thread, stream) so that concurrent callers never share one."""
+    """Plans own work buffers in ONE device's HBM: one cached plan per (device, thread, stream) so that concurrent callers never share
+    one and a plan is never reused after torch.cuda.set_device() moved the caller to another GPU (the default stream is 0 on every device)."""
     from . import _dev
-    _dev.device()                      # DeviceError without a GPU, before anything else touches the runtime
-    return (threading.get_ident(), _dev.stream_ptr())
+    dev = _dev.device()                # DeviceError without a GPU, before anything else touches the runtime
+    return (dev.index, threading.get_ident(), _dev.stream_ptr())
 
 
 plans = PlanCache()

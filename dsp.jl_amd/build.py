@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "libmi355dsp.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-SOURCES = ["api_core.hip", "rocfft_wrap.hip", "ols.hip", "spectral.hip", "fir.hip", "convnd.hip", "comm.hip", "hostpath.hip"]
+SOURCES = ["api_core.hip", "rocfft_wrap.hip", "ols.hip", "spectral.hip", "fir.hip", "convnd.hip", "comm.hip", "hostpath.hip", "plancache.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
           "-Wno-implicit-fallthrough", "-ffp-contract=on", f"-I{ROCM}/include"]
 LDFLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", f"-L{ROCM}/lib", "-lrocfft", "-ldl", "-lpthread", f"-Wl,-rpath,{ROCM}/lib"]   # librccl is bound at run time (comm.hip)

@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _dev, _lib, _plancache
+from . import _dev, _lib, _plancache, util
 from ._lib import ArgumentError, UnsupportedError
 
 SMALL_FILT_CUTOFF = 66   # dspbase.jl:3
@@ -88,10 +88,9 @@ def filt(b, a, x):
         raise ArgumentError("filter vector a[1] must be nonzero")
     if av.size > 1:
         raise UnsupportedError("IIR filt(b, a, x) is a serial recursion; only FIR (scalar a) runs on the device")
-    T = np.result_type(bv.dtype, av.dtype, xdt)
-    if av[0] != 1:                                   # coefficient normalisation, :43-47
+    T = util.promote_type(bv.dtype, av.dtype, xdt)   # eltype of `out`, fixed BEFORE the normalisation (dspbase.jl:14-15): Float32 taps and
+    if av[0] != 1:                                   # signal with an integer `a` stay Float32.  Coefficient normalisation, :43-47
         bv = bv / av[0]
-        T = np.result_type(bv.dtype, xdt)
     return _tdfir(bv, x, T)
 
 
@@ -113,12 +112,21 @@ def filt_(out, b, a, x):
 class OlsPlan:
     """Owner of an ``mdsp_ols_plan`` (filter spectrum, rocFFT plans / tables, work buffers in HBM)."""
 
-    def __init__(self, taps: np.ndarray, nfft: int, nx_hint: int, mode: int, engine: int = _lib.ENGINE_AUTO):
+    def __init__(self, taps: np.ndarray, nfft: int, nx_hint: int, mode: int, engine: int = _lib.ENGINE_AUTO, cached: bool = False):
+        """``cached``: borrow the plan from the library's own LRU (``mdsp_ols_plan_cached``: keyed by device, thread, stream and the
+        contents of ``taps``) instead of owning a fresh one -- the per-call path of ``filt(b, x)`` / ``conv(u, v)``.  A borrowed plan
+        is for immediate use; it is never destroyed from here."""
         self.dtype = taps.dtype
         self._h = C.c_void_p()
+        self._owned = not cached
         taps = np.ascontiguousarray(taps)
-        _lib.check(_lib.lib().mdsp_ols_plan_create(C.byref(self._h), taps.ctypes.data_as(C.c_void_p), len(taps), int(nfft), int(nx_hint),
-                                                   _dev.md_dtype(taps.dtype), mode, engine))
+        if cached:
+            _dev.device()
+            _lib.check(_lib.lib().mdsp_ols_plan_cached(C.byref(self._h), taps.ctypes.data_as(C.c_void_p), len(taps), int(nfft), int(nx_hint),
+                                                       _dev.md_dtype(taps.dtype), mode, engine, _dev.stream_ptr()))
+        else:
+            _lib.check(_lib.lib().mdsp_ols_plan_create(C.byref(self._h), taps.ctypes.data_as(C.c_void_p), len(taps), int(nfft), int(nx_hint),
+                                                       _dev.md_dtype(taps.dtype), mode, engine))
         nf, L, eng = C.c_int64(), C.c_int64(), C.c_int()
         _lib.check(_lib.lib().mdsp_ols_plan_info(self._h, C.byref(nf), C.byref(L), C.byref(eng)))
         self.nb, self.nfft, self.block_len, self.engine = len(taps), nf.value, L.value, eng.value
@@ -145,7 +153,7 @@ class OlsPlan:
 
     def __del__(self):
         try:
-            if self._h:
+            if self._h and self._owned:
                 _lib.lib().mdsp_ols_plan_destroy(self._h)
         except Exception:
             pass
@@ -179,7 +187,7 @@ def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int 
         if out_len is not None:
             raise ArgumentError("out_len is a vector argument")
         return _conv_nd(u, v, algorithm)
-    T = np.result_type(udt, vdt)
+    T = util.promote_type(udt, vdt)
     nu, nv = int(u.shape[0]), int(v.shape[0])
     full = max(nu + nv - 1, 0)
     n_out = full if out_len is None else int(out_len)
@@ -214,8 +222,7 @@ def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int 
             nfft = int(_lib.lib().mdsp_nextfastfft(full))           # _conv_kern_fft!: one transform of nextfastfft(outsize)
         else:
             nfft = optimalfftfiltlength(len(small_h), max(nu, nv))
-        plan = _plancache.plans.get(("ols", _plancache.ctx_key(), _plancache.array_key(small_h), int(nfft), _lib.OLS_CONV, engine),
-                                    lambda: OlsPlan(small_h, nfft, max(nu, nv), _lib.OLS_CONV, engine))
+        plan = OlsPlan(small_h, nfft, max(nu, nv), _lib.OLS_CONV, engine, cached=True)     # the library's own plan LRU (mdsp_ols_plan_cached)
         cols, _ = _dev.to_columns(big, W)
         res = plan.exec(cols, full)
     res = _cast_result(res, T)[0]
@@ -232,7 +239,7 @@ def _conv_nd(u, v, algorithm: str = "auto"):
     2^16) is the convolution sum on the device; every FFT algorithm is one N-d transform of the padded output
     (``_conv_kern_fft!``, :611-644 -- :fft_overlapsave computes the same sums block-wise)."""
     udt, vdt = _dev.np_dtype_of(u), _dev.np_dtype_of(v)
-    T = np.result_type(udt, vdt)
+    T = util.promote_type(udt, vdt)
     nd = max(len(u.shape), len(v.shape))
     su = tuple(int(k) for k in u.shape) + (1,) * (nd - len(u.shape))
     sv = tuple(int(k) for k in v.shape) + (1,) * (nd - len(v.shape))
@@ -278,7 +285,7 @@ def conv_separable(u, v, A):
     ``u * transpose(v)`` -- evaluated as the 2-D convolution with that rank-one kernel."""
     if len(u.shape) != 1 or len(v.shape) != 1 or len(A.shape) != 2:
         raise ArgumentError("conv(u, v', A) takes two vectors and a matrix")
-    T = np.result_type(_dev.np_dtype_of(u), _dev.np_dtype_of(v), _dev.np_dtype_of(A))
+    T = util.promote_type(_dev.np_dtype_of(u), _dev.np_dtype_of(v), _dev.np_dtype_of(A))
     W = _compute_dtype(T) if T in _FFT_TYPES else np.dtype(np.float64)
     ud, vd = _dev.as_device(u, W), _dev.as_device(v, W)
     kern = ud.reshape(-1, 1) * vd.reshape(1, -1)

@@ -9,7 +9,7 @@ from fractions import Fraction
 
 import numpy as np
 
-from . import _dev, _lib, _plancache, design, dspbase
+from . import _dev, _lib, _plancache, design, dspbase, util
 from ._lib import ArgumentError, DomainError, UnsupportedError
 from .dspbase import SMALL_FILT_CUTOFF, OlsPlan, _cast_result, _compute_dtype, _host_vec, optimalfftfiltlength
 
@@ -36,7 +36,7 @@ def _fftfilt(b: np.ndarray, x, nfft: int, engine: int = _lib.ENGINE_AUTO):
     xdt = _dev.np_dtype_of(x)
     if b.dtype.kind not in _REAL_KINDS or xdt.kind not in _REAL_KINDS:
         raise TypeError("fftfilt is defined for real taps and real signals only")      # MethodError in the reference
-    W = np.result_type(b.dtype, xdt)
+    W = util.promote_type(b.dtype, xdt)
     Wc = _compute_dtype(W)
     hcols = _dev.host_columns(x, Wc) if W == Wc else None
     if hcols is not None:              # large host array: the library's pinned, chunked H2D || kernel || D2H pipeline, no torch copy
@@ -44,8 +44,7 @@ def _fftfilt(b: np.ndarray, x, nfft: int, engine: int = _lib.ENGINE_AUTO):
             raise ArgumentError("nfft must be at least length(b)")
         taps = b.astype(Wc)
         _dev.device()
-        plan = _plancache.plans.get(("ols", _plancache.ctx_key(), _plancache.array_key(taps), int(nfft), _lib.OLS_FILT, engine),
-                                    lambda: OlsPlan(taps, nfft, hcols.shape[1], _lib.OLS_FILT, engine))
+        plan = OlsPlan(taps, nfft, hcols.shape[1], _lib.OLS_FILT, engine, cached=True)
         out = plan.exec_host(hcols, hcols.shape[1])
         return out[0] if x.ndim == 1 else out.T
     cols, shape = _dev.to_columns(x, Wc)
@@ -55,8 +54,7 @@ def _fftfilt(b: np.ndarray, x, nfft: int, engine: int = _lib.ENGINE_AUTO):
     if nfft < len(b):
         raise ArgumentError("nfft must be at least length(b)")
     taps = b.astype(Wc)
-    plan = _plancache.plans.get(("ols", _plancache.ctx_key(), _plancache.array_key(taps), int(nfft), _lib.OLS_FILT, engine),
-                                lambda: OlsPlan(taps, nfft, nx, _lib.OLS_FILT, engine))
+    plan = OlsPlan(taps, nfft, nx, _lib.OLS_FILT, engine, cached=True)     # the library's own plan LRU (mdsp_ols_plan_cached)
     out = plan.exec(cols, nx)
     return _dev.from_columns(_cast_result(out, W) if W.kind in "iu" else out, shape, x)
 
@@ -423,7 +421,7 @@ class DF2TFilter:
         if av[0] != 1:
             bv = bv / av[0]                                             # PolynomialRatio normalises by a[1]
         self.b = bv if bv.dtype in (np.dtype(np.float32), np.dtype(np.float64)) else bv.astype(np.float64)
-        T = np.result_type(self.b.dtype, dtype) if dtype is not None else self.b.dtype   # zeros(promote_type(T, V), ...), :150
+        T = util.promote_type(self.b.dtype, dtype) if dtype is not None else self.b.dtype   # zeros(promote_type(T, V), ...), :150
         self._T = _compute_dtype(T)
         self.state = _dev.torch.zeros((len(self.b) - 1,) + tuple(coldims), dtype=_dev.torch_dtype(self._T), device=_dev.device())
 
@@ -432,7 +430,7 @@ class DF2TFilter:
         if tuple(x.shape[1:]) != tuple(self.state.shape[1:]):
             raise ArgumentError("state size must match x")              # :158
         xdt = _dev.np_dtype_of(x)
-        W = _compute_dtype(np.result_type(self.b.dtype, xdt, self._T))
+        W = _compute_dtype(util.promote_type(self.b.dtype, xdt, self._T))
         cols, shape = _dev.to_columns(x, W)
         ncols, nx = cols.shape
         nb = len(self.b)
@@ -479,7 +477,7 @@ def filtfilt(b, *args):
     half = np.array([np.dot(bw[:k + 1][::-1], rev[:k + 1]) for k in range(nb)], dtype=bw.dtype)
     newb = np.concatenate([half, half[nb - 2::-1] if nb > 1 else half[:0]])
     xdt = _dev.np_dtype_of(x)
-    W = _compute_dtype(np.result_type(bw.dtype, xdt))
+    W = _compute_dtype(util.promote_type(bw.dtype, xdt))
     cols, shape = _dev.to_columns(x, W)
     ncols = cols.shape[0]
     ext = _dev.empty_columns(ncols, n + 2 * (nb - 1), W)

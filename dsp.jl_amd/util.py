@@ -51,3 +51,32 @@ def fftfreq(n: int, fs=1.0) -> np.ndarray:
     k = np.arange(n)
     k[k > (n - 1) // 2] -= n
     return k * (fs / n)
+
+
+def promote_type(*dts) -> np.dtype:
+    """Julia's ``promote_type`` for the element types of this path (Bool, Int*, UInt*, Float16/32/64 and their Complex forms).
+
+    It is NOT ``np.result_type``: an integer never widens a float (``promote_type(Float32, Int64) == Float32``, numpy says float64), so
+    ``filt(b::Vector{Float32}, 1, x::Vector{Float32})`` stays Float32 as in the reference (dspbase.jl:26-31, 775-777).  Mixed signedness
+    follows Julia: the unsigned type wins at equal size, the larger type otherwise."""
+    dts = [np.dtype(d) for d in dts]
+    if not dts:
+        raise TypeError("promote_type needs at least one type")
+    cplx = any(d.kind == "c" for d in dts)
+    reals = [np.dtype(np.float32) if d == _C32 else np.dtype(np.float64) if d == _C64 else d for d in dts]
+    floats = [d for d in reals if d.kind == "f"]
+    if floats:
+        r = max(floats, key=lambda d: d.itemsize)
+    else:
+        ints = [d for d in reals if d.kind in "iu"]
+        if not ints:
+            r = np.dtype(np.bool_)
+        else:
+            size = max(d.itemsize for d in ints)
+            unsigned_wins = any(d.kind == "u" and d.itemsize == size for d in ints)
+            r = np.dtype(("u" if unsigned_wins else "i") + str(size))
+    if not cplx:
+        return r
+    if r == np.dtype(np.float32) or r == np.dtype(np.float16):
+        return _C32
+    return _C64            # Complex{Int} has no numpy twin: the device computes those in ComplexF64 and rounds (dspbase._cast_result)

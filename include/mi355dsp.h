@@ -355,6 +355,23 @@ int mdsp_hilbert(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int r
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Plan cache inside the library: the per-call fast path for hosts that mirror DSP.jl's function-style entry points one-to-one
+ * (filt(b, x), conv(u, v), welch_pgram(s, n, noverlap), stft / spectrogram / periodogram build their FFTW plans on every call;
+ * a device plan costs ~1 ms, the call ~45 us).  Same arguments as the matching *_plan_create plus the stream the plan will run on;
+ * the key is (device, calling thread, stream, every argument, CONTENTS of taps / window).  The returned handle is BORROWED: never
+ * destroy it; it stays valid until MDSP_PLAN_CACHE_SIZE further distinct cached requests, or mdsp_plan_cache_clear().
+ * ---------------------------------------------------------------------------------------------------- */
+#define MDSP_PLAN_CACHE_SIZE 16
+int mdsp_ols_plan_cached(mdsp_ols_plan* plan, const void* taps_host, int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode,
+                         int engine, void* stream);
+int mdsp_welch_plan_cached(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, int64_t nfft, const double* window_host, double r,
+                           int onesided, int dtype, int engine, void* stream);
+int mdsp_stft_plan_cached(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int64_t nfft, const double* window_host, double r,
+                          int onesided, int psd_only, int dtype, int engine, void* stream);
+int mdsp_plan_cache_stats(int64_t* entries, int64_t* hits, int64_t* misses);
+int mdsp_plan_cache_clear(void);
+
+/* ------------------------------------------------------------------------------------------------------
  * Measurement helpers (used by bench.py; not part of the drop-in surface)
  * ---------------------------------------------------------------------------------------------------- */
 /* Times `reps` back-to-back launches of the last exec recorded on a plan with HIP events on `stream`. */

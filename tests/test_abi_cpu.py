@@ -417,3 +417,14 @@ def test_environment_is_read_in_one_place_and_debug_knobs_are_compiled_out():
     finally:
         del os.environ["MDSP_ABLATE"]
         lib.mdsp_reload_tunables()
+
+
+def test_promote_type_follows_julia_not_numpy():
+    """ADVICE r1: filt(b::Float32, 1, x::Float32) must stay Float32 (numpy's result_type says float64)."""
+    from dsp_jl_amd import util
+    P = util.promote_type
+    f4, f8, c8, c16, i8, i4, u8, u4, b1 = (np.dtype(t) for t in (np.float32, np.float64, np.complex64, np.complex128, np.int64, np.int32, np.uint64, np.uint32, np.bool_))
+    assert P(f4, i8, f4) == f4 and P(f4, i8) == f4 and P(i8, f8) == f8 and P(f4, f8) == f8
+    assert P(c8, i8) == c8 and P(c8, f8) == c16 and P(f4, c8) == c8 and P(c16, f4) == c16
+    assert P(i8, i4) == i8 and P(i4, u4) == u4 and P(i8, u4) == i8 and P(i8, u8) == u8 and P(b1, i4) == i4 and P(b1, b1) == b1
+    assert P(np.float16, i8) == np.dtype(np.float16) and P(np.float16, f4) == f4

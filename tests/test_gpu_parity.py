@@ -1255,3 +1255,20 @@ def test_rocfft_engine_more_than_65535_units_per_chunk(d, torch):
     for f0 in (0, 65534, K - 3):
         ref = opg.stft(s[f0 * 100:(f0 + 3) * 100], 100, 0, nfft=120, window=ow.hanning, dtype=np.float64)
         assert relerr(S[:, f0:f0 + 3].cpu().numpy(), ref) < TOL32, f0
+
+
+def test_result_eltypes_follow_julia_promotion(d):
+    # promote_type, not numpy's result_type -- an integer never widens a float (dspbase.jl:14-15, :775-777)
+    rng = np.random.default_rng(2)
+    b32 = rng.standard_normal(5).astype(np.float32); x32 = rng.standard_normal(300).astype(np.float32)
+    y = d.filt(b32, 1, x32)
+    assert y.dtype == np.float32                                         # filt(b::Float32, 1::Int, x::Float32) -> Float32
+    assert d.filt(b32, 1.0, x32).dtype == np.float64                     # a Float64 `a` does promote (promote_type(Float32, Float64))
+    assert d.filt(b32, np.float32(2), x32).dtype == np.float32
+    assert np.allclose(d.filt(b32, 2, x32), y / 2, rtol=1e-6)
+    assert d.conv(np.arange(1, 40), x32).dtype == np.float32             # conv(Int vector, Float32 vector) -> Float32
+    assert d.conv(np.arange(1, 40), x32.astype(np.float64)).dtype == np.float64
+    assert d.fftfilt(np.arange(1.0, 100.0).astype(np.float32), x32).dtype == np.float32
+    assert d.filt(np.array([2, 4]), 2, np.array([1, 2, 3])).dtype == np.int64
+    f = d.DF2TFilter(b32)
+    assert f.filt(x32).dtype == np.float32
