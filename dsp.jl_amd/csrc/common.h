@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -117,6 +118,11 @@ struct Tunables {
 };
 const Tunables& tunables();
 void reload_tunables();
+
+// ---------------------------------------------------------------- library-wide LRU of device objects (plancache.hip)
+// key = plan_cache_key(kind, stream) [device, calling thread, stream] + whatever else the object depends on, appended by the caller.
+std::string plan_cache_key(char kind, void* stream);
+int plan_cache_get(const std::string& key, void** out, const std::function<int(void**)>& make, std::function<void(void*)> destroy);
 
 #ifdef MDSP_DEBUG_KNOBS
 #define MDSP_DBG(field) (::mdsp::tunables().field)

@@ -877,14 +877,17 @@ int mdsp_fir_destroy(mdsp_fir f) {
     return MDSP_OK;
 }
 
-int mdsp_fir_reset(mdsp_fir f) {
+static int fir_reset_on(mdsp_fir f, hipStream_t st, bool async) {
     if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
     const size_t hbytes = dtype_size(f->x_dtype) * (size_t)std::max<int64_t>(1, f->hl) * (size_t)f->nch;
-    MDSP_HIP(hipMemset(f->hist[f->cur].p, 0, hbytes));
+    if (async) MDSP_HIP(hipMemsetAsync(f->hist[f->cur].p, 0, hbytes, st));   // stream-ordered: the caller's next exec runs on the same stream
+    else MDSP_HIP(hipMemset(f->hist[f->cur].p, 0, hbytes));
     f->phi_idx = 1;
     f->input_deficit = 1;
     return MDSP_OK;
 }
+
+int mdsp_fir_reset(mdsp_fir f) { return fir_reset_on(f, nullptr, false); }
 
 int mdsp_fir_setphase(mdsp_fir f, double phi) {
     if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
@@ -1694,34 +1697,34 @@ int mdsp_firarb_exec(mdsp_firarb f, const void* x_dev, int64_t xlen, int64_t ldx
 
 namespace {
 
-// Device copy of the taps of the most recent stateful filter: a streaming caller passes the same coefficients chunk after
-// chunk (often one sample at a time), so the upload -- and any allocation -- happens once per filter, not once per call.
-struct TapCache {
-    std::mutex mu;
-    std::vector<unsigned char> host;
-    DevBuf dev;
-};
-TapCache& tap_cache() {
-    static TapCache c;
-    return c;
-}
-
+// Device copies of the taps of the recently used stateful filters: a streaming caller passes the same coefficients chunk after chunk
+// (often one sample at a time), so the upload -- and any allocation -- happens once per filter, not once per call.  Entries live in the
+// library's LRU (plancache.hip), keyed by (device, thread, stream, tap bytes): filters with different taps that alternate each keep
+// their buffer, nothing synchronises the device, and no lock is held across a launch.
 template <typename A, typename R>
 int tdfir_state_run(const void* taps_host, int64_t nb, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t ldy, void* si, hipStream_t st) {
-    TapCache& tc = tap_cache();
-    std::lock_guard<std::mutex> lock(tc.mu);
     const size_t bytes = sizeof(R) * (size_t)nb;
-    if (tc.host.size() != bytes || std::memcmp(tc.host.data(), taps_host, bytes) != 0) {
-        MDSP_HIP(hipDeviceSynchronize());   // earlier launches may still read the previous coefficients
-        MDSP_TRY(tc.dev.reserve(bytes));
-        MDSP_HIP(hipMemcpy(tc.dev.p, taps_host, bytes, hipMemcpyHostToDevice));
-        tc.host.assign((const unsigned char*)taps_host, (const unsigned char*)taps_host + bytes);
-    }
+    std::string key = plan_cache_key('t', st);
+    key.append(static_cast<const char*>(taps_host), bytes);
+    void* h = nullptr;
+    MDSP_TRY(plan_cache_get(key, &h,
+                            [&](void** out) -> int {
+                                auto buf = new DevBuf();
+                                int rc = buf->reserve(bytes);
+                                if (rc == MDSP_OK && hipMemcpyAsync(buf->p, taps_host, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+                                    rc = set_error(MDSP_ERR_DEVICE, "tap upload failed");
+                                if (rc == MDSP_OK && hipStreamSynchronize(st) != hipSuccess) rc = set_error(MDSP_ERR_DEVICE, "tap upload failed");   // taps_host may be freed on return
+                                if (rc != MDSP_OK) { delete buf; return rc; }
+                                *out = buf;
+                                return MDSP_OK;
+                            },
+                            [](void* p) { delete static_cast<DevBuf*>(p); }));
+    const R* taps = static_cast<DevBuf*>(h)->as<R>();
     if (nx > 0) {
         const dim3 g((unsigned)std::min<int64_t>(cdiv(nx, 256), 4096), (unsigned)ncols);
-        hipLaunchKernelGGL((tdfir_state_out_kernel<A, R>), g, dim3(256), 0, st, (const A*)x, (const A*)si, (A*)y, tc.dev.as<R>(), nx, ldx, ldy, (int)nb);
+        hipLaunchKernelGGL((tdfir_state_out_kernel<A, R>), g, dim3(256), 0, st, (const A*)x, (const A*)si, (A*)y, taps, nx, ldx, ldy, (int)nb);
         MDSP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((tdfir_state_next_kernel<A, R>), dim3((unsigned)ncols), dim3(256), 0, st, (const A*)x, (A*)si, tc.dev.as<R>(), nx, ldx, (int)nb);
+        hipLaunchKernelGGL((tdfir_state_next_kernel<A, R>), dim3((unsigned)ncols), dim3(256), 0, st, (const A*)x, (A*)si, taps, nx, ldx, (int)nb);
         MDSP_LAUNCH_CHECK();
     }
     return MDSP_OK;
@@ -1783,13 +1786,19 @@ int mdsp_tdfir_exec(const void* taps_host, int64_t nb, int dtype, const void* x_
     if (nx < 0 || ncols < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
     if (nx == 0 || ncols == 0) return MDSP_OK;
     if (ncols > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 columns per call");
-    mdsp_fir f = nullptr;
-    MDSP_TRY(mdsp_fir_create(&f, taps_host, nb, 1, 1, dtype_real_of(dtype), dtype, ncols));
+    // The filter object (device taps, history) comes from the library's LRU, keyed by (device, thread, stream, taps, dtype, columns):
+    // repeated filt(b, 1, x) / tdfilt / direct-conv calls allocate and upload nothing, and nothing synchronises the caller's stream.
+    std::string key = plan_cache_key('f', stream);
+    key.append(reinterpret_cast<const char*>(&dtype), sizeof(dtype));
+    key.append(reinterpret_cast<const char*>(&ncols), sizeof(ncols));
+    key.append(static_cast<const char*>(taps_host), (size_t)nb * dtype_size(dtype_real_of(dtype)));
+    void* h = nullptr;
+    MDSP_TRY(plan_cache_get(key, &h, [&](void** out) { return mdsp_fir_create(reinterpret_cast<mdsp_fir*>(out), taps_host, nb, 1, 1, dtype_real_of(dtype), dtype, ncols); },
+                            [](void* p) { (void)mdsp_fir_destroy(static_cast<mdsp_fir>(p)); }));
+    mdsp_fir f = static_cast<mdsp_fir>(h);
+    MDSP_TRY(fir_reset_on(f, as_stream(stream), true));   // zero initial state: every call is a fresh filt(b, a, x)
     int64_t nw = 0;
-    const int rc = mdsp_fir_exec(f, x_dev, nx, ldx, y_dev, nx, ldy, &nw, stream);
-    if (rc == MDSP_OK) (void)hipStreamSynchronize(as_stream(stream));  // the handle's buffers die with it
-    mdsp_fir_destroy(f);
-    return rc;
+    return mdsp_fir_exec(f, x_dev, nx, ldx, y_dev, nx, ldy, &nw, stream);
 }
 
 }  // extern "C"

@@ -42,7 +42,10 @@ Cache& cache() {
 void put(std::string& k, const void* p, size_t n) { k.append(static_cast<const char*>(p), n); }
 template <typename T> void put(std::string& k, T v) { put(k, &v, sizeof(v)); }
 
-std::string base_key(char kind, void* stream) {
+}  // namespace
+
+namespace mdsp {
+std::string plan_cache_key(char kind, void* stream) {
     std::string k(1, kind);
     int dev = -1;
     (void)hipGetDevice(&dev);
@@ -51,9 +54,16 @@ std::string base_key(char kind, void* stream) {
     put(k, stream);
     return k;
 }
+}  // namespace mdsp
 
-// find or create; `make` builds a new plan into *out
-int get(const std::string& key, void** out, const std::function<int(void**)>& make, std::function<void(void*)> destroy) {
+namespace {
+std::string base_key(char kind, void* stream) { return plan_cache_key(kind, stream); }
+
+}  // namespace
+
+namespace mdsp {
+// find or create; `make` builds a new object into *out
+int plan_cache_get(const std::string& key, void** out, const std::function<int(void**)>& make, std::function<void(void*)> destroy) {
     Cache& c = cache();
     {
         std::lock_guard<std::mutex> lk(c.mu);
@@ -81,6 +91,12 @@ int get(const std::string& key, void** out, const std::function<int(void**)>& ma
     for (auto& e : evicted) e.destroy(e.handle);   // hipFree inside synchronises with any launch still using the buffers
     *out = h;
     return MDSP_OK;
+}
+}  // namespace mdsp
+
+namespace {
+int get(const std::string& key, void** out, const std::function<int(void**)>& make, std::function<void(void*)> destroy) {
+    return plan_cache_get(key, out, make, std::move(destroy));
 }
 
 size_t real_size(int dtype) { return dtype_is_double(dtype) ? 8 : 4; }

@@ -209,3 +209,73 @@ def test_host_pipeline_welch(d, torch, engine):
     s = rng.standard_normal(9_000_000).astype(np.float32)                # numpy API: large host arrays take the pipeline
     p = d.welch_pgram(s, 4096, 2048, window=d.hanning, engine=engine).power
     assert isinstance(p, np.ndarray) and relerr(p, d.welch_pgram(torch.from_numpy(s).cuda(), 4096, 2048, window=d.hanning, engine=engine).power.cpu().numpy()) < 1e-6
+
+
+def test_library_plan_cache(d, torch):
+    """mdsp_*_plan_cached: the per-call fast path behind the C ABI (what the Julia twin's filt(b, x) / welch_pgram(s, n, noverlap) bind)."""
+    from dsp_jl_amd import _lib, _dev
+    lib = _lib.lib()
+    _lib.check(lib.mdsp_plan_cache_clear())
+    st = _dev.stream_ptr()
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(100).astype(np.float32)
+    h1, h2, h3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(lib.mdsp_ols_plan_cached(C.byref(h1), b.ctypes.data_as(C.c_void_p), 100, 0, 10 ** 6, _lib.F32, _lib.OLS_FILT, 0, st))
+    _lib.check(lib.mdsp_ols_plan_cached(C.byref(h2), b.copy().ctypes.data_as(C.c_void_p), 100, 0, 10 ** 6, _lib.F32, _lib.OLS_FILT, 0, st))
+    assert h1.value == h2.value                                  # same contents -> same plan
+    b2 = b.copy(); b2[7] += 1
+    _lib.check(lib.mdsp_ols_plan_cached(C.byref(h3), b2.ctypes.data_as(C.c_void_p), 100, 0, 10 ** 6, _lib.F32, _lib.OLS_FILT, 0, st))
+    assert h3.value != h1.value                                  # one tap differs -> another plan
+    w = d.hanning(512)
+    wp = w.ctypes.data_as(C.POINTER(C.c_double))
+    p1, p2, p3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(lib.mdsp_welch_plan_cached(C.byref(p1), 512, 256, 512, wp, float((w * w).sum()), 1, _lib.F32, 0, st))
+    _lib.check(lib.mdsp_welch_plan_cached(C.byref(p2), 512, 256, 512, wp, float((w * w).sum()), 1, _lib.F32, 0, st))
+    _lib.check(lib.mdsp_stft_plan_cached(C.byref(p3), 512, 256, 512, wp, float((w * w).sum()), 1, 1, _lib.F32, 0, st))
+    assert p1.value == p2.value and p3.value not in (None, p1.value)
+    e, hit, miss = C.c_int64(), C.c_int64(), C.c_int64()
+    _lib.check(lib.mdsp_plan_cache_stats(C.byref(e), C.byref(hit), C.byref(miss)))
+    assert (e.value, hit.value >= 2, miss.value >= 4) == (4, True, True)
+    # a borrowed plan computes what an owned one does
+    x = torch.randn(200_000, device="cuda")
+    y1 = torch.empty_like(x); y2 = torch.empty_like(x)
+    _lib.check(lib.mdsp_ols_exec(h1, x.data_ptr(), x.numel(), 1, x.numel(), y1.data_ptr(), x.numel(), x.numel(), st))
+    own = C.c_void_p()
+    _lib.check(lib.mdsp_ols_plan_create(C.byref(own), b.ctypes.data_as(C.c_void_p), 100, 0, 10 ** 6, _lib.F32, _lib.OLS_FILT, 0))
+    _lib.check(lib.mdsp_ols_exec(own, x.data_ptr(), x.numel(), 1, x.numel(), y2.data_ptr(), x.numel(), x.numel(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    lib.mdsp_ols_plan_destroy(own)
+    # eviction: more distinct requests than MDSP_PLAN_CACHE_SIZE keep the cache bounded
+    for k in range(20):
+        bk = b.copy(); bk[0] = k
+        hk = C.c_void_p()
+        _lib.check(lib.mdsp_ols_plan_cached(C.byref(hk), bk.ctypes.data_as(C.c_void_p), 100, 0, 10 ** 6, _lib.F32, _lib.OLS_FILT, 0, st))
+    _lib.check(lib.mdsp_plan_cache_stats(C.byref(e), None, None))
+    assert e.value == 16
+    _lib.check(lib.mdsp_plan_cache_clear())
+    _lib.check(lib.mdsp_plan_cache_stats(C.byref(e), None, None))
+    assert e.value == 0
+    # the Python per-call path rides on it: repeated filt(b, x) hits
+    xb = rng.standard_normal(50_000).astype(np.float32); bb = rng.standard_normal(200).astype(np.float32)
+    r1 = d.filt(bb, xb); r2 = d.filt(bb, xb)
+    _lib.check(lib.mdsp_plan_cache_stats(C.byref(e), C.byref(hit), C.byref(miss)))
+    assert np.array_equal(r1, r2) and e.value == 1
+
+
+def test_alternating_stateful_filters_and_repeated_tdfilt(d, torch):
+    """ADVICE r1: two DF2TFilter objects with different taps that alternate (no device-wide synchronisation, each keeps its device taps);
+    repeated filt(b, 1, x) reuses its cached filter object and stays a fresh zero-state filter every call."""
+    from oracle import dspbase as odsp
+    rng = np.random.default_rng(4)
+    b1, b2 = rng.standard_normal(9), rng.standard_normal(30)
+    f1, f2 = d.DF2TFilter(b1), d.DF2TFilter(b2)
+    x = rng.standard_normal(4000)
+    y1, y2 = [], []
+    for k in range(0, 4000, 500):
+        y1.append(f1.filt(x[k:k + 500])); y2.append(f2.filt(x[k:k + 500]))
+    assert relerr(np.concatenate(y1), odsp.filt_ba(b1, 1.0, x)) < 1e-12
+    assert relerr(np.concatenate(y2), odsp.filt_ba(b2, 1.0, x)) < 1e-12
+    for _ in range(3):
+        assert relerr(d.filt(b1, 1.0, x), odsp.filt_ba(b1, 1.0, x)) < 1e-12     # state never leaks from one call into the next
+        assert relerr(d.filt(b2, 1.0, x[:100]), odsp.filt_ba(b2, 1.0, x[:100])) < 1e-12
