@@ -574,8 +574,11 @@ def test_firarbitrary_device_trajectory_scan_is_bit_exact(d, rate, nphi, monkeyp
         _lib.check(lib.mdsp_firarb_scan_stats(f._handle, C.byref(sc), C.byref(se)))
         return start, ys, states, (sc.value, se.value)
 
-    start, ys, states, counts = run(True)
-    start0, ys0, states0, counts0 = run(False)
+    try:
+        start, ys, states, counts = run(True)
+        start0, ys0, states0, counts0 = run(False)
+    finally:
+        _lib.set_tunable("MDSP_ARB_SCAN", None)       # the library reads its environment once: put the default back for the tests that follow
     assert counts == (2, 0) and counts0 == (0, 2)       # both chunks went through the scan / the serial loop
     assert start == start0 and states == states0
     assert all(np.array_equal(a, b) for a, b in zip(ys, ys0))
