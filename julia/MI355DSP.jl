@@ -7,13 +7,16 @@
 # and does nothing else: no CUDA.jl / AMDGPU.jl array dispatch, every call goes straight to a hand-written HIP
 # kernel through `ccall`.
 #
-# Host arrays in, host arrays out (pinned staging is left to the caller); `DeviceArray` keeps data resident in HBM
-# between calls.  Reference locations are DSP.jl v0.8.5 `src/`.
+# Host `Array`s go through the library's host-pointer pipelines (mdsp_ols_exec_host / mdsp_welch_exec_host: pinned double buffers,
+# H2D || kernel || D2H on two streams; `pin!` page-locks an Array so the DMA engines use it directly); `DeviceArray` keeps data
+# resident in HBM between calls.  The function-style calls take their plans from the library's own LRU (mdsp_*_plan_cached), the
+# multi-GPU part is `Comm` (RCCL behind the C ABI).  Reference locations are DSP.jl v0.8.5 `src/`.
 module MI355DSP
 
 export DeviceArray, upload, download, filt, fftfilt, tdfilt, conv, periodogram, WelchConfig, welch_pgram,
        spectrogram, stft, FIRFilter, resample, reset!, setphase!, timedelay, inputlength, outputlength,
-       nextfastfft, optimalfftfiltlength
+       nextfastfft, optimalfftfiltlength, Comm, welch_channel_mean, welch_reset!, welch_accumulate!, welch_finalize, welch_allreduce!,
+       pin!, unpin!
 
 const lib = get(ENV, "MI355DSP_LIB", joinpath(@__DIR__, "..", "dsp.jl_amd", "libmi355dsp.so"))
 
@@ -124,12 +127,44 @@ function olsexec(plan::OlsPlan, x::DeviceArray{T}, nout::Integer) where {T}
     y
 end
 
+# The function-style entry points build a plan per call in the reference (cheap FFTW plans); here the plan comes from the LIBRARY's LRU
+# (mdsp_ols_plan_cached: keyed by device, thread, stream and the contents of the taps) -- ~45 us per call instead of ~1 ms.  The handle is
+# borrowed: no finalizer, never destroyed from here.
+function cached_ols_plan(taps::Vector{T}, nfft::Integer, nx::Integer, mode::Integer, engine=ENGINE_AUTO) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mdsp_ols_plan_cached, lib), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Cint, Cint, Ptr{Cvoid}),
+                p, taps, length(taps), nfft, nx, mdtype(T), mode, engine, C_NULL))
+    p[]
+end
+
+# page-lock an existing Array (hipHostRegister) so that the host pipelines DMA straight from / into it
+pin!(x::Array) = (check(ccall((:mdsp_host_register, lib), Cint, (Ptr{Cvoid}, Csize_t), x, sizeof(x))); x)
+unpin!(x::Array) = (check(ccall((:mdsp_host_unregister, lib), Cint, (Ptr{Cvoid},), x)); x)
+const HOST_PINNED = Cint(1)
+
 # fftfilt(b, x[, nfft])   Filters/filt.jl:458-461, _fftfilt! :479-521
-function fftfilt(b::AbstractVector{H}, x::Union{AbstractArray{T},DeviceArray{T}},
-                 nfft::Integer=optimalfftfiltlength(length(b), length(x))) where {H<:Real,T<:Real}
+# Device arrays: one launch sequence on resident data.  Host Arrays: the chunked H2D || kernel || D2H pipeline (same block grid, so
+# both return bit-identical results).
+function fftfilt(b::AbstractVector{H}, x::DeviceArray{T}, nfft::Integer=optimalfftfiltlength(length(b), length(x))) where {H<:Real,T<:Real}
     W = fftintype(promote_type(H, T))
     xd = todevice(x, W)
-    back(olsexec(OlsPlan(convert(Vector{W}, b), nfft, size(xd, 1), 0), xd, size(xd, 1)), x)
+    nx = size(xd, 1); ncols = length(xd) ÷ max(nx, 1)
+    plan = cached_ols_plan(convert(Vector{W}, b), nfft, nx, 0)
+    y = DeviceArray{W}(size(xd))
+    check(ccall((:mdsp_ols_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}),
+                plan, xd.ptr, nx, ncols, nx, y.ptr, nx, nx, C_NULL))
+    y
+end
+function fftfilt(b::AbstractVector{H}, x::AbstractArray{T}, nfft::Integer=optimalfftfiltlength(length(b), length(x));
+                 pinned::Bool=false) where {H<:Real,T<:Real}
+    W = fftintype(promote_type(H, T))
+    xh = convert(Array{W}, x)                                  # column-major (n, cols...): exactly the layout the C ABI takes
+    nx = size(xh, 1); ncols = length(xh) ÷ max(nx, 1)
+    plan = cached_ols_plan(convert(Vector{W}, b), nfft, nx, 0)
+    y = similar(xh)
+    check(ccall((:mdsp_ols_exec_host, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Cint),
+                plan, xh, nx, ncols, nx, y, nx, nx, pinned ? HOST_PINNED : Cint(0)))
+    y
 end
 
 # filt(b, a::Number, x) / tdfilt   dspbase.jl:14-66 (FIR only on the device)
@@ -168,8 +203,12 @@ function conv(u::AbstractVector{Tu}, v::AbstractVector{Tv}; algorithm=:auto) whe
     alg in (:fft_overlapsave, :fft_simple) ||
         throw(ArgumentError("algorithm must be :auto, :fast, :direct, :fft, :fft_simple, or :fft_overlapsave"))
     nfft = alg === :fft_simple ? nextfastfft(nu + nv - 1) : os
-    plan = OlsPlan(convert(Vector{W}, small), nfft, length(big), 1)
-    download(olsexec(plan, todevice(big, W), nu + nv - 1))
+    bigd = todevice(big, W)
+    plan = cached_ols_plan(convert(Vector{W}, small), nfft, length(big), 1)
+    y = DeviceArray{W}((nu + nv - 1,))
+    check(ccall((:mdsp_ols_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}),
+                plan, bigd.ptr, length(big), 1, length(big), y.ptr, nu + nv - 1, nu + nv - 1, C_NULL))
+    download(y)
 end
 
 # conv(u, v; algorithm) for arrays   dspbase.jl:709-792: _conv_kern_fft! (:611-644) / _conv_td! (:646-660) on the device.
@@ -254,6 +293,71 @@ function welch_pgram(s::Union{AbstractVecOrMat{T},DeviceArray{T}}, config::Welch
 end
 welch_pgram(s::AbstractVector, n::Int=length(s) >> 3, noverlap::Int=n >> 1; kw...) =
     welch_pgram(s, WelchConfig(s; n, noverlap, kw...))
+
+# Host Arrays: mdsp_welch_exec_host (time chunks of whole frames through pinned double buffers; Float64 sums accumulate in the plan)
+function welch_pgram(s::Array{T}, config::WelchConfig; pinned::Bool=false) where {T<:Union{Float32,Float64,ComplexF32,ComplexF64}}
+    T == config.intype || throw(ArgumentError("float(eltype(s)) = $T doesn't match the eltype of the input buffer: $(config.intype)."))
+    len = size(s, 1); nch = length(s) ÷ max(len, 1)
+    out = Array{fftabs2type(T)}(undef, ndims(s) == 1 ? (config.nout,) : (config.nout, nch))
+    check(ccall((:mdsp_welch_exec_host, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Cint),
+                config.h[], s, len, nch, len, out, config.nout, pinned ? HOST_PINNED : Cint(0)))
+    (power = out, freq = config.freq)
+end
+
+# Streaming form (mdsp_welch_exec IS reset + accumulate + finalize): a stream handed over slice by slice -- each slice whole frames,
+# consecutive slices overlapping by n - hop samples -- or by several ranks (welch_allreduce!).   periodograms.jl:746-759
+welch_reset!(c::WelchConfig) = (check(ccall((:mdsp_welch_reset, lib), Cint, (Ptr{Cvoid},), c.h[])); c)
+function welch_accumulate!(c::WelchConfig, s::DeviceArray)
+    len = size(s, 1); nch = length(s) ÷ max(len, 1)
+    check(ccall((:mdsp_welch_accumulate, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}), c.h[], s.ptr, len, nch, len, C_NULL))
+    c
+end
+function welch_finalize(c::WelchConfig, nch::Integer=1; frames_total::Integer=0)
+    out = DeviceArray{fftabs2type(c.intype)}((c.nout, nch))
+    check(ccall((:mdsp_welch_finalize, lib), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}), c.h[], frames_total, out.ptr, c.nout, C_NULL))
+    out
+end
+
+# ---------------------------------------------------------------------------------------------- multi-GPU (one process per GPU)
+# The reference loops over columns / channels serially (Filters/filt.jl:504; `mapslices` stream_filt.jl:768).  Here rank r owns a
+# contiguous block of channels and runs the single-GPU methods on them; the ONLY collective is the all-reduce of an nout-value PSD for
+# the cross-channel Welch mean -- RCCL over xGMI, behind the C ABI.  Bootstrap: rank 0 makes the 128-byte id, the host ships it
+# (e.g. `MPI.Bcast!(id, 0, comm)` or a shared file), every rank calls Comm(id, rank, nranks) after init(device).
+mutable struct Comm
+    h::Ptr{Cvoid}
+    rank::Int
+    nranks::Int
+end
+function unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:mdsp_comm_unique_id, lib), Cint, (Ptr{UInt8},), id))
+    id
+end
+function Comm(id::Vector{UInt8}, rank::Integer, nranks::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mdsp_comm_init_rank, lib), Cint, (Ref{Ptr{Cvoid}}, Ptr{UInt8}, Cint, Cint), p, id, rank, nranks))
+    c = Comm(p[], rank, nranks)
+    finalizer(x -> ccall((:mdsp_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.h), c)
+    c
+end
+channel_shard(nch::Integer, rank::Integer, nranks::Integer) = (per = cld(nch, nranks); (min(rank * per, nch) + 1):min((rank + 1) * per, nch))
+
+# mean over ALL channels (across ranks) of the per-channel Welch PSDs: local sum on the device -> ncclAllReduce(sum) of nout values ->
+# 1/nch_total, one C-ABI call.  `s`: this rank's channels as columns.
+function welch_channel_mean(s::DeviceArray{T}, config::WelchConfig, nch_total::Integer, comm::Union{Comm,Nothing}=nothing) where {T}
+    len = size(s, 1); nloc = length(s) ÷ max(len, 1)
+    R = fftabs2type(config.intype)
+    psd = DeviceArray{R}((config.nout, max(nloc, 1)))
+    nloc > 0 && check(ccall((:mdsp_welch_exec, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                            config.h[], s.ptr, len, nloc, len, psd.ptr, config.nout, C_NULL))
+    mean = DeviceArray{R}((config.nout,))
+    check(ccall((:mdsp_welch_mean_allreduce, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                config.h[], psd.ptr, nloc, config.nout, nch_total, mean.ptr, comm === nothing ? C_NULL : comm.h, C_NULL))
+    mean
+end
+# one stream split along time over ranks: after welch_accumulate! on every rank's slice, sum the Float64 accumulators and frame counts
+welch_allreduce!(c::WelchConfig, comm::Comm) =
+    (check(ccall((:mdsp_welch_allreduce, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), c.h[], comm.h, C_NULL)); c)
 
 # stft / spectrogram / periodogram   periodograms.jl:872-897, :828-837, :393-417
 function stft(s::Union{AbstractVecOrMat{T},DeviceArray{T}}, n::Int=size(s, 1) >> 3, noverlap::Int=n >> 1, psdonly::Bool=false;

@@ -428,3 +428,16 @@ def test_promote_type_follows_julia_not_numpy():
     assert P(c8, i8) == c8 and P(c8, f8) == c16 and P(f4, c8) == c8 and P(c16, f4) == c16
     assert P(i8, i4) == i8 and P(i4, u4) == u4 and P(i8, u4) == i8 and P(i8, u8) == u8 and P(b1, i4) == i4 and P(b1, b1) == b1
     assert P(np.float16, i8) == np.dtype(np.float16) and P(np.float16, f4) == f4
+
+
+def test_julia_twin_binds_only_exported_symbols_with_matching_arity():
+    """julia/MI355DSP.jl cannot be run here (no Julia in the image): at least every `ccall((:sym, lib), Cint, (types...), args...)` must name
+    an exported symbol and declare as many argument types as the ctypes prototype of the same entry point."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "MI355DSP.jl")).read()
+    calls = re.findall(r"ccall\(\(:(mdsp_[a-z0-9_]+), lib\),\s*([A-Za-z0-9]+),\s*\(([^()]*(?:\{[^{}]*\}[^()]*)*)\)", src)
+    assert len(calls) >= 55
+    lib = _lib.lib()
+    for name, _ret, types in calls:
+        assert name in _lib.PROTOTYPES and hasattr(lib, name), name
+        n = len([t for t in types.split(",") if t.strip()])
+        assert n == len(_lib.PROTOTYPES[name][1]), (name, n, len(_lib.PROTOTYPES[name][1]))
