@@ -238,10 +238,23 @@ template <> struct LanePerm<4096, 16> {  // radices 16 16 16
     }
     static constexpr int padshift = 5;
 };
-// PERMUTE = false reproduces the identity mapping (kernels that were not re-tuned, and the host emulation's baseline)
-template <typename C, int PASS, bool PERMUTE> MDSP_HD int lane_perm(int t) {
+// PERMUTE = 0 reproduces the identity mapping (kernels that were not re-tuned, and the host emulation's baseline), 1 the
+// bank-conflict permutations above.
+//
+// PERMUTE = 2, "wave-private last exchange" (N = 4096, E = 16, T = 256, radices 16 16 16): passes 1 and 2 run butterfly
+// j = nibble_swap(t) = (t mod 16) * 16 + t div 16.  With that ownership the 16 operands of a pass-2 butterfly are produced by the 16
+// lanes of ONE 16-lane row of one wavefront (writer lane l, output r  ->  reader lane (l div 16) * 16 + r, operand l mod 16: a 16 x 16
+// transpose inside each row), so the second exchange needs no s_barrier at all -- a wave's DS operations execute in order -- and only the
+// first exchange (all-to-all between the four waves) keeps its barrier.  Input ownership stays t + T*e (coalesced loads); the OUTPUT
+// ownership becomes nibble_swap(t) + T*e, which is why this mode is used where outputs are reduced, not stored (Welch).
+template <typename C> constexpr bool wave_private_ok() { return C::N == 4096 && C::E == 16 && C::P == 3; }
+template <typename C, int PASS, int PERMUTE> MDSP_HD int lane_perm(int t) {
     using LP = LanePerm<C::N, C::E>;
-    if constexpr (!PERMUTE || !LP::any || C::T < 64) return t;
+    if constexpr (PERMUTE == 2) {
+        static_assert(wave_private_ok<C>(), "wave-private exchange is wired for N = 4096, E = 16");
+        if constexpr (PASS == 0) return t;
+        else return ((t & 15) << 4) | ((t >> 4) & 15);
+    } else if constexpr (!PERMUTE || !LP::any || C::T < 64) return t;
     else {
         int out = t & ~63;
 #pragma unroll
@@ -249,11 +262,16 @@ template <typename C, int PASS, bool PERMUTE> MDSP_HD int lane_perm(int t) {
         return out;
     }
 }
-template <typename C, bool PERMUTE> MDSP_HD int io_lane(int t) {
-    static_assert(!PERMUTE || !LanePerm<C::N, C::E>::any || LanePerm<C::N, C::E>::src(0, 0) == LanePerm<C::N, C::E>::src(C::P - 1, 0),
+template <typename C, int PERMUTE> MDSP_HD int io_lane(int t) {
+    static_assert(PERMUTE != 1 || !LanePerm<C::N, C::E>::any || LanePerm<C::N, C::E>::src(0, 0) == LanePerm<C::N, C::E>::src(C::P - 1, 0),
                   "first and last pass must share their lane permutation");
     return lane_perm<C, 0, PERMUTE>(t);
 }
+// ownership AFTER the last pass: thread t holds X[out_lane(t) + T*e]  (== io_lane(t) except in the wave-private mode)
+template <typename C, int PERMUTE> MDSP_HD int out_lane(int t) { return lane_perm<C, C::P - 1, PERMUTE>(t); }
+// wave-private exchange: element (row-local lane a, slot b) of wavefront w, 16-lane row q lives at  w*4*272 + q*272 + a*17 + b
+// (17 = one element of padding per 16: ds_write_b64 from 16 contiguous lanes and ds_read_b64 from 32 are both conflict-free)
+MDSP_HD int wave_private_base(int t_raw) { return (t_raw >> 6) * (4 * 272) + ((t_raw >> 4) & 3) * 272; }
 
 // twiddle sources
 enum { TW_GLOBAL = 0, TW_REG = 1, TW_LDS = 2, TW_HYB = 3 };
@@ -311,7 +329,7 @@ template <typename C, int PASS> MDSP_HD int tw_index(int t, int b, int r) {
 }
 
 // Fill the per-thread twiddle registers (loop-invariant for a persistent workgroup).
-template <typename C, typename R, int PASS = 1, int TWMODE = TW_REG, bool PERMUTE = false>
+template <typename C, typename R, int PASS = 1, int TWMODE = TW_REG, int PERMUTE = false>
 MDSP_HD void load_twiddles(cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], int t, const cx<R>* table) {
     if constexpr (PASS < C::P) {
         if constexpr (tw_pass_in_regs<C, TWMODE, PASS>()) {
@@ -328,7 +346,7 @@ MDSP_HD void load_twiddles(cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], int t, const cx
 
 // One Stockham pass on the thread's registers.  Non-final passes scatter their results to `lds`
 // (this transform's region); the final pass leaves X[t + T*e] in x[e].
-template <typename C, int DIR, int PASS, int TWMODE, int PADSHIFT, bool PERMUTE = false, typename R>
+template <typename C, int DIR, int PASS, int TWMODE, int PADSHIFT, int PERMUTE = false, typename R>
 MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t_raw, const cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], const cx<R>* table, cx<R>* lds) {
     constexpr int Rdx = C::radix(PASS), NB = C::E / Rdx, Ns = C::ns(PASS);
     constexpr bool LAST = PASS == C::P - 1;
@@ -359,6 +377,10 @@ MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t_raw, const cx<R> (&tw)[C::NTW 
         if constexpr (LAST) {
 #pragma unroll
             for (int r = 0; r < Rdx; ++r) x[b + r * NB] = v[r];
+        } else if constexpr (PERMUTE == 2 && PASS == C::P - 2) {   // wave-private transpose: writer (lane a of its row, output r) -> slot a*17 + r
+            const int base = wave_private_base(t_raw) + (t_raw & 15) * 17;
+#pragma unroll
+            for (int r = 0; r < Rdx; ++r) lds[base + r] = v[r];
         } else {
             const int j = t + C::T * b;
             const int base = lds_pad<PADSHIFT>((j / Ns) * (Ns * Rdx) + (j & (Ns - 1)));
@@ -369,9 +391,13 @@ MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t_raw, const cx<R> (&tw)[C::NTW 
 }
 
 // After the barrier that follows a non-final pass: fetch the operands of the next pass.
-template <typename C, int PADSHIFT, int NEXT = 1, bool PERMUTE = false, typename R> MDSP_HD void pass_reload(cx<R> (&x)[C::E], int t_raw, const cx<R>* lds) {
+template <typename C, int PADSHIFT, int NEXT = 1, int PERMUTE = false, typename R> MDSP_HD void pass_reload(cx<R> (&x)[C::E], int t_raw, const cx<R>* lds) {
     const int t = lane_perm<C, NEXT, PERMUTE>(t_raw);   // operands of the pass that follows
-    if constexpr (PADSHIFT >= 31 || C::T % (1 << (PADSHIFT >= 31 ? 0 : PADSHIFT)) == 0) {
+    if constexpr (PERMUTE == 2 && NEXT == C::P - 1) {   // wave-private transpose: reader lane c of its row takes operand e from slot e*17 + c
+        const int base = wave_private_base(t_raw) + (t_raw & 15);
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) x[e] = lds[base + 17 * e];
+    } else if constexpr (PADSHIFT >= 31 || C::T % (1 << (PADSHIFT >= 31 ? 0 : PADSHIFT)) == 0) {
         const int base = lds_pad<PADSHIFT>(t);
 #pragma unroll
         for (int e = 0; e < C::E; ++e) x[e] = lds[base + lds_padc<PADSHIFT>(C::T * e)];

@@ -23,13 +23,19 @@ template <int T> __device__ __forceinline__ void wg_sync() {
 template <typename C, int PADSHIFT, int NBUF> constexpr int wg_lds_elems() { return NBUF * lds_elems<C::N, PADSHIFT>(); }
 
 // XBASE: index (mod NBUF) of the buffer used by this transform's first exchange.
-template <typename C, int DIR, int TWMODE, int PADSHIFT, int NBUF, int XBASE, int PASS = 0, bool PERMUTE = false, typename R>
+template <typename C, int DIR, int TWMODE, int PADSHIFT, int NBUF, int XBASE, int PASS = 0, int PERMUTE = false, typename R>
 __device__ __forceinline__ void wg_fft(cx<R> (&v)[C::E], int t, const cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], const cx<R>* table, cx<R>* lds) {
     constexpr int BUF = (XBASE + PASS) % NBUF;
     cx<R>* region = lds + BUF * lds_elems<C::N, PADSHIFT>();
     pass_compute<C, DIR, PASS, TWMODE, PADSHIFT, PERMUTE>(v, t, tw, table, region);
     if constexpr (PASS < C::P - 1) {
-        wg_sync<C::T>();
+        // PERMUTE == 2: the last exchange stays inside each wavefront (fft_lds.h) -- a scheduling fence instead of an s_barrier.  That mode
+        // needs NBUF == 2 (exchange 0 in buffer 0, the private one in buffer 1) and the CALLER puts one workgroup barrier between two
+        // transforms (buffer 0 is rewritten by the next transform's first pass).
+        constexpr bool PRIVATE = PERMUTE == 2 && PASS == C::P - 2;
+        static_assert(PERMUTE != 2 || (NBUF == 2 && lds_elems<C::N, PADSHIFT>() >= 4 * 4 * 272), "wave-private exchange uses the second LDS buffer (pad shift 4)");
+        if constexpr (PRIVATE) wg_sync<64>();
+        else wg_sync<C::T>();
         pass_reload<C, PADSHIFT, PASS + 1, PERMUTE>(v, t, region);
         if constexpr (NBUF == 1) wg_sync<C::T>();
         wg_fft<C, DIR, TWMODE, PADSHIFT, NBUF, XBASE, PASS + 1, PERMUTE>(v, t, tw, table, lds);
@@ -43,7 +49,7 @@ __device__ __forceinline__ void wg_fft_perm(cx<R> (&v)[C::E], int t, const cx<R>
 
 // Twiddle source setup for a kernel: registers (loaded once per persistent workgroup), an LDS-resident table shared
 // by the workgroup's transform slots, or the global root table.  Returns the pointer pass_compute() should use.
-template <typename C, int TWMODE, bool PERMUTE = false, typename R>
+template <typename C, int TWMODE, int PERMUTE = false, typename R>
 __device__ __forceinline__ const cx<R>* wg_twiddle_setup(cx<R> (&tw)[C::NTW > 0 ? C::NTW : 1], cx<R>* twl, int t, int slot, const cx<R>* table) {
     static_assert(!PERMUTE || TWMODE == TW_REG || TWMODE == TW_GLOBAL, "lane permutations are wired for register / global twiddles");
     if constexpr (TWMODE == TW_REG) {

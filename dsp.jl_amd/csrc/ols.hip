@@ -175,7 +175,7 @@ __device__ __forceinline__ void ols_store(const cx<R> (&v)[E], const OlsFusedArg
     }
 }
 
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, bool PERM = false>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, int PERM = false>
 __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedArgs a) {
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T;
@@ -278,7 +278,7 @@ template <typename R> int upload_table(DevBuf& buf, int64_t n) {
 
 // ---- fused launch ---------------------------------------------------------------------------------------
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true, bool HREG = true,
-          bool PERM = false>
+          int PERM = false>
 int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
     auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG, PERM>;
     constexpr int threads = (N / E) * G;
@@ -333,13 +333,34 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
             case 7: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 1, true, true, true>(a, s);    // single LDS buffer
             case 8: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, false, true, true>(a, s);   // no prefetch
             case 9: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true, false, false>(a, s);  // E = 16
+            // register diets for three / four resident workgroups per CU: MINW caps the allocation at 168 / 128 VGPRs
+            case 14: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 3, 1, true, true, false>(a, s);   // registers only, capped at 168
+            case 15: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, true, false, false>(a, s);  // hybrid twiddles + spectrum from L2
+            case 16: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, true, true, false>(a, s);   // hybrid twiddles, spectrum in registers
+            case 17: return launch_fused_variant<R, N, 16, 2, 2, 4, CPLX, 4, 1, true, false, false>(a, s);  // LDS twiddles + spectrum from L2, capped at 128
+            case 18: return launch_fused_variant<R, N, 16, 2, 2, 4, CPLX, 3, 1, true, false, false>(a, s);  // LDS twiddles + spectrum from L2, capped at 168
+            case 19: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, false, false, false>(a, s); // hybrid, L2 spectrum, no prefetch
+            case 23: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 4, 1, false, false, false>(a, s); // same, capped at 128 VGPRs (four workgroups)
+            case 24: return launch_fused_variant<R, N, 16, 2, 0, 4, CPLX, 4, 1, false, false, false>(a, s); // global twiddles, L2 spectrum, no prefetch, 128
+            case 25: return launch_fused_variant<R, N, 16, 2, 3, 5, CPLX, 3, 1, false, false, false>(a, s); // 19 with pad 5
+            case 26: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, false, true, false>(a, s);  // hybrid, spectrum in registers, no prefetch
+            case 27: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 3, 1, false, false, false>(a, s); // register twiddles, L2 spectrum, no prefetch
+            case 28: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, false, true, false>(a, s);  // default geometry minus the prefetch
             default: break;
         }
-        // default: the generic E = 16 geometry below (variant 12).  Variant 2 is the best E = 8 form (identity lanes, one pad
+            case 0: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, false, true, false>(a, s);   // DEFAULT (= 26): hybrid twiddles (pass-1 table
+            // in LDS, 30 VGPRs less), filter spectrum in registers, no software prefetch: 165 VGPRs -> three workgroups per CU.  12-round
+            // interleaved A/B on two boxes (profiles/r02e_ols_ab.json): 1.98 ms vs 2.03 (28: registers only, no prefetch) vs 2.17 (12: the
+            // round-1 default with prefetch).  Variant 2 is the best E = 8 form (identity lanes, one pad
         // element per 32); the lane-permuted schedule (variant 10) has fewer LDS conflicts still, but its permuted global accesses
         // cost more than the LDS cycles it saves (3.8 vs 4.2 TB/s, profiles/r01e_tune_lanes.json).
     }
-    return launch_fused_variant<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true>(a, s);
+    // Software prefetch of the next unit's samples: OFF by default.  Measured on MI355X (profiles/r02c_tune.json, 2^30 Float32, nfft 2048):
+    // the same geometry without the prefetch is 14 % faster (1.85 vs 2.16 ms) -- the 32 registers it frees matter less than the issue
+    // pattern: loads at the top of the iteration park the wave while its partner workgroup on the SIMD computes, which puts the two
+    // resident workgroups in antiphase on their own.  MDSP_OLS_PREFETCH=1 restores the prefetching form (tools/bench_matrix.py sweeps both).
+    if (tunables().ols_prefetch == 1) return launch_fused_variant<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, true>(a, s);
+    return launch_fused_variant<R, N, E, G, TWREG, 4, CPLX, 2, NBUF, false>(a, s);
 }
 
 template <typename R, bool CPLX> int launch_fused(int64_t nfft, const OlsFusedArgs& a, int variant, hipStream_t s) {

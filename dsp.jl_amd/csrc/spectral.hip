@@ -807,7 +807,10 @@ template <typename R> int welch_finalize(mdsp_welch_plan_s* pl, int64_t K_total,
 // With hop = N/2 the second half of frame a IS the first half of frame b, and the second half of frame b IS the first
 // half of the next unit's frame a.  A slot that walks consecutive units therefore loads every sample exactly ONCE:
 // E loads per thread per unit instead of 2E, and 3E/2 instead of 2E prefetch registers.
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF, bool PERM = false>
+// PREF = false: no software prefetch -- the unit's two new halves are loaded at the top of its iteration and are dead before the transform
+// starts, which frees 16 of the 24 sample registers; latency is covered by a third resident workgroup per CU instead (measured on the
+// overlap-save kernel: +11 % over the prefetching two-workgroup form, profiles/r02b_tune.json).
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF, int PERM = false, bool PREF = true>
 __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs a) {
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T;
@@ -818,7 +821,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
     constexpr int64_t SZ = (int64_t)sizeof(R);
     __shared__ __attribute__((aligned(16))) cx<R> lds_all[G * REGION];
     const int traw = threadIdx.x % T;
-    const int t = fft::io_lane<C, PERM>(traw);   // element / bin ownership: t + T*e (== traw unless lane-permuted)
+    const int t = fft::io_lane<C, PERM>(traw);     // sample / window ownership before the transform: t + T*e (== traw unless lane-permuted)
+    const int tout = fft::out_lane<C, PERM>(traw);  // bin ownership after it (== t except with the wave-private exchange, PERM == 2)
     const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));
     cx<R>* lds = lds_all + slot * REGION;
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
@@ -854,7 +858,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
     int since = 0;
     bool first = true;
     auto flush = [&]() {   // wave-uniform control flow; per-lane state is one laundered byte offset
-        int off = t * 8;
+        int off = tout * 8;
         asm volatile("" : "+v"(off));
         if (first) {
 #pragma unroll
@@ -891,7 +895,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
     };
     R lo[H], ahi[H], bhi[H];
     int64_t u = unit_cur(niter > 0);
-    {
+    bool have_lo = false;   // PREF = false: lo[] already holds the first half of unit u (carried over from the previous unit)
+    if constexpr (PREF) {
         const bool live = u < a.units_per_ch;
         load_half(lo, u, 0, live);
         load_half(ahi, u, 1, live);
@@ -901,6 +906,12 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
         walk();
         const int64_t unext = unit_cur(it + 1 < niter);
         const bool haveB = (2 * u + 1) < a.K;   // u live implied (K >= 1) -- a dead unit has all-zero halves anyway
+        if constexpr (!PREF) {
+            const bool live = u < a.units_per_ch;
+            if (!have_lo) load_half(lo, u, 0, live);
+            load_half(ahi, u, 1, live);
+            load_half(bhi, u, 2, live && haveB);
+        }
         cx<R> v[E];
         if (haveB) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -928,7 +939,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
             }
         }
         // next unit: reuse this unit's last half when it is the next frame's first half
-        {
+        if constexpr (PREF) {
             const bool nlive = unext < a.units_per_ch;
             if (unext == u + 1 && nlive) {
 #pragma unroll
@@ -938,9 +949,18 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
             }
             load_half(ahi, unext, 1, nlive);
             load_half(bhi, unext, 2, nlive && (2 * unext + 1) < a.K);
+        } else {
+            have_lo = unext == u + 1 && unext < a.units_per_ch;   // wave-uniform
+            if (have_lo) {
+#pragma unroll
+                for (int e = 0; e < H; ++e) lo[e] = bhi[e];
+            }
         }
         u = unext;
         if (!MDSP_ABLATED(a, 2)) {
+            // wave-private last exchange: the workgroup barrier that protects buffer 0 sits HERE, a whole transform after its readers
+            // passed it -- nobody waits at it in steady state
+            if constexpr (PERM == 2) __syncthreads();
             fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0, 0, PERM>(v, traw, tw, twsrc, lds);
             if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();  // NBUF == 1: wg_fft already ends every exchange with a barrier
         }
@@ -960,13 +980,13 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
         flush();
     } else {
 #pragma unroll
-        for (int e = 0; e < E; ++e) part[t + T * e] = acc[e];
+        for (int e = 0; e < E; ++e) part[tout + T * e] = acc[e];
     }
 }
 
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF, bool PERM = false>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF, int PERM = false, bool PREF = true>
 int welch_run_half(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
-    auto kern = welch_half_kernel<R, N, E, G, TWMODE, PADSHIFT, MINW, NBUF, PERM>;
+    auto kern = welch_half_kernel<R, N, E, G, TWMODE, PADSHIFT, MINW, NBUF, PERM, PREF>;
     constexpr int threads = (N / E) * G;
     int grid = 1;
     MDSP_TRY(grid_for(kern, threads, cdiv(a.units_per_ch, G), a.nch, &grid));
@@ -1015,6 +1035,13 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 19) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 2, true>(pl, a, st, &nslices);    // permuted, two LDS buffers
                 else if (pl->variant == 20) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, true>(pl, a, st, &nslices);    // permuted lanes, pad 5
                 else if (pl->variant == 21) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 2, false>(pl, a, st, &nslices);   // identity lanes, pad 5, two LDS buffers
+                else if (pl->variant == 22) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 2, 2>(pl, a, st, &nslices);       // wave-private last exchange (one real barrier per transform)
+                // no software prefetch, register diets for a third workgroup per CU
+                else if (pl->variant == 23) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, 0, false>(pl, a, st, &nslices);   // registers, no prefetch (still two workgroups)
+                else if (pl->variant == 24) rc = welch_run_half<R, N, EH, GH, 3, 5, 3, 1, 0, false>(pl, a, st, &nslices);   // hybrid twiddles, scalar accumulators, <= 168 VGPRs
+                else if (pl->variant == 25) rc = welch_run_half<R, N, EH, GH, 3, 4, 3, 1, 0, false>(pl, a, st, &nslices);   // same, pad 4
+                else if (pl->variant == 26) rc = welch_run_half<R, N, EH, GH, 2, 5, 3, 1, 0, false>(pl, a, st, &nslices);   // LDS twiddles
+                else if (pl->variant == 27) rc = welch_run_half<R, N, EH, GH, 3, 5, 3, 1, 0, true>(pl, a, st, &nslices);    // hybrid + prefetch (= 16 with pad 5)
                 else if (pl->variant == 12) rc = welch_run_half<R, N, EH, GH, 2, 4, 2, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 13) rc = welch_run_half<R, N, 8, 1, 1, 4, 2, 2>(pl, a, st, &nslices);
                 else if (pl->variant == 14) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 2>(pl, a, st, &nslices);

@@ -12,7 +12,7 @@
 
 using namespace mdsp::fft;
 
-template <typename C, typename R, int DIR, int TWREG, int PADSHIFT, int PASS, bool PERMUTE = false>
+template <typename C, typename R, int DIR, int TWREG, int PADSHIFT, int PASS, int PERMUTE = false>
 static void run_passes(std::vector<cx<R>>& regs, std::vector<cx<R>>& tw, const std::vector<cx<R>>& table, std::vector<cx<R>>& lds) {
     if constexpr (PASS < C::P) {
         constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
@@ -31,7 +31,7 @@ static void run_passes(std::vector<cx<R>>& regs, std::vector<cx<R>>& tw, const s
     }
 }
 
-template <int N, int E, typename R, int DIR, int TWREG, int PADSHIFT, bool PERMUTE = false> static double check() {
+template <int N, int E, typename R, int DIR, int TWREG, int PADSHIFT, int PERMUTE = false> static double check() {
     using C = Cfg<N, E>;
     constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
     std::vector<cx<R>> table(N), regs((size_t)C::T * E), tw((size_t)C::T * NTWA), lds(lds_elems<N, PADSHIFT>());
@@ -69,7 +69,7 @@ template <int N, int E, typename R, int DIR, int TWREG, int PADSHIFT, bool PERMU
     for (int t = 0; t < C::T; ++t)
         for (int e = 0; e < E; ++e) {
             const auto got = std::complex<long double>(regs[(size_t)t * E + e].x, regs[(size_t)t * E + e].y);
-            err2 += std::norm(got - ref[io_lane<C, PERMUTE>(t) + C::T * e]);
+            err2 += std::norm(got - ref[out_lane<C, PERMUTE>(t) + C::T * e]);   // == io_lane except in the wave-private mode
         }
     (void)maxerr;
     return (double)sqrtl(err2 / norm);
@@ -87,6 +87,12 @@ template <int N, int E> static int check_all() {
         const double ep = std::max(check<N, E, float, -1, 1, PS, true>(), check<N, E, float, +1, 1, PS, true>());
         if (!(ep < 2e-6)) bad = 1;
         printf("N=%5d E=%2d lane-permuted schedule, pad shift %d: f32 %.2e\n", N, E, PS, ep);
+    }
+    if constexpr (wave_private_ok<Cfg<N, E>>()) {   // PERMUTE = 2: the last exchange stays inside each wavefront (pad shift 4: region = 4 x 4 x 272)
+        const double ew = std::max(std::max(check<N, E, float, -1, 1, 4, 2>(), check<N, E, float, +1, 1, 4, 2>()), check<N, E, float, -1, 0, 4, 2>());
+        const double ed = std::max(check<N, E, double, -1, 1, 4, 2>(), check<N, E, double, +1, 0, 4, 2>());
+        if (!(ew < 2e-6) || !(ed < 1e-14)) bad = 1;
+        printf("N=%5d E=%2d wave-private last exchange: f32 %.2e f64 %.2e\n", N, E, ew, ed);
     }
     printf("N=%5d E=%2d P=%d radices:", N, E, Cfg<N, E>::P);
     for (int p = 0; p < Cfg<N, E>::P; ++p) printf(" %d", Cfg<N, E>::radix(p));

@@ -57,9 +57,18 @@ for dt in (np.float32, np.float64, np.complex64, np.complex128):
             y = torch.empty_like(x)
             ms = timeit(lambda: _lib.check(lib.mdsp_ols_exec(p._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream)))
             row["filt"] = round(n / ms / 1e6, 1)
+            if os.environ.get("MATRIX_PREFETCH"):      # the same plan with the software prefetch switched on (MDSP_OLS_PREFETCH is read at launch)
+                _lib.set_tunable("MDSP_OLS_PREFETCH", 1)
+                ms = timeit(lambda: _lib.check(lib.mdsp_ols_exec(p._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream)))
+                _lib.set_tunable("MDSP_OLS_PREFETCH", None)
+                row["filt_prefetch"] = round(n / ms / 1e6, 1)
             del y, p
         except Exception as e:
             row["filt"] = str(e)[:40]
+        if os.environ.get("MATRIX_ONLY") == "filt":
+            res[f"{name}_{nfft}"] = row
+            print(name, nfft, row, flush=True)
+            continue
         cfg = d.WelchConfig(n, dt, n=nfft, noverlap=nfft // 2, window=d.hanning, engine=d.ENGINE_FUSED)
         psd = torch.empty(cfg.nout, dtype=TD[rdt], device="cuda")
         ms = timeit(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, x.data_ptr(), n, 1, n, psd.data_ptr(), cfg.nout, stream)))

@@ -112,6 +112,16 @@ for ab in (os.environ.get("TUNE_ABLATE", "0,1,2,4,3,6,5,7").split(",") if lib.md
     res["ablate"][ab] = {"ols_ms": round(min(to), 4), "welch_ms": round(min(tw), 4)}
     print("ablate", ab, res["ablate"][ab])
 _lib.set_tunable("MDSP_ABLATE", "0")
+# ---- power / DVFS probe: the same two launches on an all-zero stream (no toggling data: MI355X_MICROARCH.md "DVFS give-back") ----
+if os.environ.get("TUNE_ZERO"):
+    xz = torch.zeros_like(x)
+    to = [timeit(lambda: _lib.check(lib.mdsp_ols_exec(p0._h, xz.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream))) for _ in range(rounds)]
+    tw = [timeit(lambda: _lib.check(lib.mdsp_welch_exec(c0._h, xz.data_ptr(), n, 1, n, psd.data_ptr(), 2049, stream))) for _ in range(rounds)]
+    tor = [timeit(lambda: _lib.check(lib.mdsp_ols_exec(p0._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream))) for _ in range(rounds)]
+    twr = [timeit(lambda: _lib.check(lib.mdsp_welch_exec(c0._h, x.data_ptr(), n, 1, n, psd.data_ptr(), 2049, stream))) for _ in range(rounds)]
+    res["zero_input"] = {"ols_ms_zeros": min(to), "ols_ms_random": min(tor), "welch_ms_zeros": min(tw), "welch_ms_random": min(twr)}
+    print("zero-input probe", res["zero_input"])
+    del xz
 # ---- copy yardstick ----
 cms = [timeit(lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, stream))) for _ in range(5)]
 res["copy_GBps"] = round(2 * 4.0 * n / (min(cms) * 1e-3) / 1e9, 1)
