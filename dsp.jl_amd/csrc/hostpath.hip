@@ -163,7 +163,11 @@ int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64
     // blocks per chunk: ~host_chunk_mib of input, even, at least 2
     int64_t bpc = std::max<int64_t>(2, ((int64_t)tunables().host_chunk_mib << 20) / (int64_t)(L * (int64_t)esz));
     bpc &= ~int64_t(1);
-    const size_t in_cap = (size_t)(bpc * L + nb - 1) * esz, out_cap = (size_t)(bpc * L) * esz;
+    // Partitioned plans (long filters) have no block-range entry: a chunk is filtered as a signal of its own that starts nb-1 samples early
+    // (zero initial state), and the nb-1 warm-up outputs are dropped -- equal to the device-resident call up to rounding, not bit for bit.
+    const bool halo = plan->partitions > 1;
+    if (halo) bpc = std::max<int64_t>(bpc, 4 * cdiv(nb, L));   // keep the re-filtered halo below a quarter of a chunk
+    const size_t in_cap = (size_t)(bpc * L + nb - 1) * esz, out_cap = (size_t)(bpc * L + (halo ? nb - 1 : 0)) * esz;
 
     Pipe* pp = pipe_for_device();
     std::lock_guard<std::mutex> lk(pp->mu);
@@ -201,14 +205,15 @@ int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64
                 hipError_t e = hipStreamWaitEvent(ln.s, pp->lane[(chunk & 1) ^ 1].kdone, 0);
                 if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "stream wait failed: %s", hipGetErrorString(e)); break; }
             }
-            rc = mdsp_ols_exec_range(plan, ln.din.p, lo, hi > lo ? hi - lo : 0, nx, ln.dout.p, g0, g1 - g0, nout, ln.s);
+            if (halo) rc = mdsp_ols_exec(plan, ln.din.p, hi > lo ? hi - lo : 0, 1, hi > lo ? hi - lo : 0, ln.dout.p, o1 - lo, o1 - lo, ln.s);
+            else rc = mdsp_ols_exec_range(plan, ln.din.p, lo, hi > lo ? hi - lo : 0, nx, ln.dout.p, g0, g1 - g0, nout, ln.s);
             if (rc != MDSP_OK) break;
             if (serial_exec) {
                 hipError_t e = hipEventRecord(ln.kdone, ln.s);
                 if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "event record failed: %s", hipGetErrorString(e)); break; }
             }
             void* dst = pinned ? (void*)(yc + (size_t)o0 * esz) : ln.hout.p;
-            hipError_t e = hipMemcpyAsync(dst, ln.dout.p, outb, hipMemcpyDeviceToHost, ln.s);
+            hipError_t e = hipMemcpyAsync(dst, static_cast<const char*>(ln.dout.p) + (halo ? (size_t)(o0 - lo) * esz : 0), outb, hipMemcpyDeviceToHost, ln.s);
             if (e == hipSuccess) e = hipEventRecord(ln.done, ln.s);
             if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "D2H copy failed: %s", hipGetErrorString(e)); break; }
             ln.out_dst = yc + (size_t)o0 * esz;

@@ -238,6 +238,133 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     }
 }
 
+// ======================================================================================================
+// Partitioned overlap-save for long filters (fused engine, requested nfft beyond the in-LDS transform sizes)
+// ======================================================================================================
+// optimalfftfiltlength (dspbase.jl:268-291) asks for nfft = 16384 ... 2^20 once the filter has more than ~1100 taps: one block no longer fits
+// a workgroup's LDS.  The same linear convolution is evaluated with a UNIFORMLY PARTITIONED filter instead: h = [h_0 | h_1 | ... | h_{P-1}],
+// B taps each, N = 2B-point transforms,
+//     X_m = FFT(x[(m-1)B .. (m+1)B)),     Y_m = sum_p X_{m-p} H_p,     y[mB .. (m+1)B) = IFFT(Y_m)[B .. 2B)
+// (H_p = FFT([h_p, 0...]) / N).  A slot walks CONSECUTIVE blocks and keeps the last P-1 input spectra in REGISTERS (a frequency-domain delay
+// line): one forward and one inverse transform per block whatever P is, every sample read from HBM once (the 50 % window overlap and nothing
+// else comes from L2).  Real signals: a slot walks TWO runs of blocks at once, run A in the real and run B in the imaginary part -- with
+// real taps the two never mix (the packing of ols_fused_kernel, but across runs instead of neighbouring blocks, because a delay line shifts
+// by one block per step).  Each run is preceded by P-1 warm-up blocks that only fill the delay line (negative blocks are all zero padding).
+struct UpolsArgs {
+    const void* x;
+    void* y;
+    const void* table;   // N forward roots
+    const void* Hp;      // P spectra of N bins, 1/N folded in
+    int64_t nx, nout, ldx, ldy;
+    int64_t nblocks;     // per column: ceil(nout / B)
+    int64_t run_len;     // blocks per run; slot s of S owns blocks [s*R*run_len, (s+1)*R*run_len), R = 2 runs (real) or 1 (complex)
+};
+
+template <typename R, int N, int E, int P, int TWMODE, int PADSHIFT, bool CPLX, int MINW>
+__global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
+    using C = fft::Cfg<N, E>;
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    constexpr int T = C::T, B = N / 2, H = E / 2;
+    constexpr int64_t SZ = (int64_t)sizeof(TT);
+    static_assert(T % 64 == 0 && P >= 2 && P <= 4, "geometry");
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    __shared__ __attribute__((aligned(16))) cx<R> lds[fft::wg_lds_elems<C, PADSHIFT, 1>()];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
+    const int t = threadIdx.x;
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    cx<R> tw[NTWA];
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, 0, table);
+    const __amdgpu_buffer_rsrc_t hrsrc = io::make_rsrc(a.Hp, (int64_t)P * N * (int64_t)sizeof(cx<R>));
+    const int64_t col = blockIdx.y;
+    const TT* xc = static_cast<const TT*>(a.x) + col * a.ldx;
+    TT* yc = static_cast<TT*>(a.y) + col * a.ldy;
+    constexpr int RUNS = CPLX ? 1 : 2;
+    const int64_t first = (int64_t)blockIdx.x * RUNS * a.run_len;   // run A: [first, first + run_len), run B: the run_len blocks after it
+
+    cx<R> zp[P - 1][E];   // delay line: zp[q] = spectrum of the block q + 1 steps back
+#pragma unroll
+    for (int q = 0; q < P - 1; ++q)
+#pragma unroll
+        for (int e = 0; e < E; ++e) zp[q][e] = {(R)0, (R)0};
+
+    // window of block m of this column: x[(m-1)B .. (m+1)B), zero outside [0, nx)
+    auto load_block = [&](TT (&dst)[E], int64_t m, bool on) {
+        const int64_t start = (m - 1) * B;
+        const bool live = on && m >= 0 && start < a.nx;
+        const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + start, live ? (a.nx - start) * SZ : 0);
+        const int lead = __builtin_amdgcn_readfirstlane((int)(live && start < 0 ? -start : 0));
+        io::load_window<TT, E, T>(dst, r, lead, t);
+    };
+    for (int64_t k = -(P - 1); k < a.run_len; ++k) {   // same trip count for every workgroup (barriers inside)
+        const int64_t mA = first + k, mB = first + a.run_len + k;
+        // blocks in front of a run's first block only feed the delay line; blocks at / past nblocks produce nothing (and run B may be empty)
+        const bool onA = first < a.nblocks && mA < a.nblocks, onB = !CPLX && (first + a.run_len) < a.nblocks && mB < a.nblocks;
+        cx<R> v[E];
+        {
+            TT ra[E];
+            load_block(ra, mA, onA);
+            if constexpr (CPLX) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = ra[e];
+            } else {
+                TT rb[E];
+                load_block(rb, mB, onB);
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = {ra[e], rb[e]};
+            }
+        }
+        fft::wg_fft<C, -1, TWMODE, PADSHIFT, 1, 0>(v, t, tw, twsrc, lds);
+        if (k >= 0) {   // wave-uniform
+            cx<R> y[E];
+            {
+                cx<R> hh[E];
+                io::load_window<cx<R>, E, T>(hh, hrsrc, 0, t);
+#pragma unroll
+                for (int e = 0; e < E; ++e) y[e] = fft::cmul(v[e], hh[e]);
+            }
+#pragma unroll
+            for (int q = 0; q < P - 1; ++q) {
+                cx<R> hh[E];
+                const __amdgpu_buffer_rsrc_t hq = io::make_rsrc(static_cast<const cx<R>*>(a.Hp) + (int64_t)(q + 1) * N, (int64_t)N * (int64_t)sizeof(cx<R>));
+                io::load_window<cx<R>, E, T>(hh, hq, 0, t);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const cx<R> pr = fft::cmul(zp[q][e], hh[e]);
+                    y[e] = fft::cadd(y[e], pr);
+                }
+            }
+            fft::wg_fft<C, +1, TWMODE, PADSHIFT, 1, 0>(y, t, tw, twsrc, lds);
+            // valid outputs: the upper half of the window, i.e. elements e >= E/2 of every thread (t + T*e >= B)
+            {
+                const int64_t o = mA * B;
+                const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + o, (onA && o < a.nout) ? (a.nout - o) * SZ : 0);
+                int off = t * (int)SZ;
+                asm volatile("" : "+v"(off));
+#pragma unroll
+                for (int e = 0; e < H; ++e) {
+                    if constexpr (CPLX) io::Ld<TT>::store(y[e + H], w, off + T * e * (int)SZ);
+                    else io::Ld<TT>::store(y[e + H].x, w, off + T * e * (int)SZ);
+                }
+            }
+            if constexpr (!CPLX) {
+                const int64_t o = mB * B;
+                const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + o, (onB && o < a.nout) ? (a.nout - o) * SZ : 0);
+                int off = t * (int)SZ;
+                asm volatile("" : "+v"(off));
+#pragma unroll
+                for (int e = 0; e < H; ++e) io::Ld<TT>::store(y[e + H].y, w, off + T * e * (int)SZ);
+            }
+        }
+        // shift the delay line
+#pragma unroll
+        for (int q = P - 2; q > 0; --q)
+#pragma unroll
+            for (int e = 0; e < E; ++e) zp[q][e] = zp[q - 1][e];
+#pragma unroll
+        for (int e = 0; e < E; ++e) zp[0][e] = v[e];
+    }
+}
+
 }  // namespace
 
 // ======================================================================================================
@@ -254,6 +381,33 @@ bool fused_supported(int dtype, int64_t nfft) {
         case 8192: return !dbl;
         default: return false;
     }
+}
+
+// Execution geometry of the fused engine for a requested (reference) nfft:
+//   * the transform sizes it holds in LDS run as they are;
+//   * beyond them (filters of ~1100 taps and more, where optimalfftfiltlength returns 16384 ... 2^20) the SAME convolution is re-blocked:
+//     one block of the largest in-LDS size while the filter covers at most half of it, else a uniformly partitioned filter
+//     (upols_fused_kernel) with B = N/2 taps per partition and at most four partitions.
+// Returns false when the fused engine cannot run the request (non power-of-two sizes, filters beyond 4 partitions).
+bool fused_geometry(int dtype, int64_t nb, int64_t nfft_req, int64_t* exec_nfft, int* partitions) {
+    *partitions = 1;
+    *exec_nfft = nfft_req;
+    if (fused_supported(dtype, nfft_req)) return true;
+    const int64_t nmax = dtype_is_double(dtype) ? 4096 : 8192;
+    if (nfft_req <= nmax || (nfft_req & (nfft_req - 1)) != 0) return false;   // small or mixed-radix sizes: not this engine
+    if (nb - 1 <= nmax / 2) {
+        *exec_nfft = nmax;
+        return true;
+    }
+    for (int64_t n = 4096; n <= nmax; n *= 2) {
+        const int64_t parts = cdiv(nb, n / 2);
+        if (parts <= 4) {
+            *exec_nfft = n;
+            *partitions = (int)std::max<int64_t>(2, parts);
+            return true;
+        }
+    }
+    return false;
 }
 
 template <typename R> int upload_spectrum(mdsp_ols_plan_s* pl, const std::vector<zd>& Hfull, bool half) {
@@ -346,14 +500,13 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
             case 26: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, false, true, false>(a, s);  // hybrid, spectrum in registers, no prefetch
             case 27: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 3, 1, false, false, false>(a, s); // register twiddles, L2 spectrum, no prefetch
             case 28: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, false, true, false>(a, s);  // default geometry minus the prefetch
-            default: break;
+            // DEFAULT (= 26): hybrid twiddles (pass-1 table in LDS, 30 VGPRs less), filter spectrum in registers, no software prefetch:
+            // 165 VGPRs -> three workgroups per CU.  12-round interleaved A/B on two boxes (profiles/r02e_ols_ab.json): 1.98 ms vs 2.03
+            // (28: registers only, no prefetch) vs 2.17 (12: the round-1 default with prefetch).  Variant 2 is the best E = 8 form; the
+            // lane-permuted schedule (10) has fewer LDS conflicts still, but its permuted global accesses cost more than the LDS cycles it
+            // saves (3.8 vs 4.2 TB/s, profiles/r01e_tune_lanes.json).
+            default: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, false, true, false>(a, s);
         }
-            case 0: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, false, true, false>(a, s);   // DEFAULT (= 26): hybrid twiddles (pass-1 table
-            // in LDS, 30 VGPRs less), filter spectrum in registers, no software prefetch: 165 VGPRs -> three workgroups per CU.  12-round
-            // interleaved A/B on two boxes (profiles/r02e_ols_ab.json): 1.98 ms vs 2.03 (28: registers only, no prefetch) vs 2.17 (12: the
-            // round-1 default with prefetch).  Variant 2 is the best E = 8 form (identity lanes, one pad
-        // element per 32); the lane-permuted schedule (variant 10) has fewer LDS conflicts still, but its permuted global accesses
-        // cost more than the LDS cycles it saves (3.8 vs 4.2 TB/s, profiles/r01e_tune_lanes.json).
     }
     // Software prefetch of the next unit's samples: OFF by default.  Measured on MI355X (profiles/r02c_tune.json, 2^30 Float32, nfft 2048):
     // the same geometry without the prefetch is 14 % faster (1.85 vs 2.16 ms) -- the 32 registers it frees matter less than the issue
@@ -375,6 +528,51 @@ template <typename R, bool CPLX> int launch_fused(int64_t nfft, const OlsFusedAr
         default: break;
     }
     MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused overlap-save does not support nfft=%lld", (long long)nfft);
+}
+
+// ---- partitioned launch ------------------------------------------------------------------------------------
+template <typename R, int N, int E, int P, bool CPLX>
+int launch_upols_np(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, hipStream_t s) {
+    constexpr bool DBL = sizeof(R) == 8;
+    constexpr int TW = DBL ? 1 : fft::TW_HYB;       // Float32: pass-1 twiddles from LDS (30 VGPRs less next to the delay line)
+    auto kern = upols_fused_kernel<R, N, E, P, TW, 4, CPLX, 2>;
+    constexpr int threads = N / E, B = N / 2, RUNS = CPLX ? 1 : 2;
+    UpolsArgs a;
+    a.x = x; a.y = y; a.table = pl->table.p; a.Hp = pl->H.p;
+    a.nx = nx; a.nout = nout; a.ldx = ldx; a.ldy = ldy;
+    a.nblocks = cdiv(nout, (int64_t)B);
+    int per_cu = 0;
+    MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
+    if (per_cu < 1) per_cu = 1;
+    if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
+    // persistent grid; runs of at least 16 (P - 1) blocks keep the warm-up blocks of a run below ~6 % of its work
+    const int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * per_cu / std::max<int64_t>(1, ncols));
+    const int64_t by_work = std::max<int64_t>(1, a.nblocks / (RUNS * 16 * (P - 1)));
+    const int64_t slots = std::min(resident, by_work);
+    a.run_len = cdiv(a.nblocks, slots * RUNS);
+    const int64_t grid = cdiv(a.nblocks, a.run_len * RUNS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ncols), dim3(threads), 0, s, a);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+template <typename R, int N, int E, bool CPLX>
+int launch_upols_n(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, hipStream_t s) {
+    switch (pl->partitions) {
+        case 2: return launch_upols_np<R, N, E, 2, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
+        case 3: return launch_upols_np<R, N, E, 3, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
+        case 4: return launch_upols_np<R, N, E, 4, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
+        default: break;
+    }
+    MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "partitioned overlap-save supports 2..4 partitions, got %d", pl->partitions);
+}
+template <typename R, bool CPLX>
+int launch_upols(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, hipStream_t s) {
+    constexpr bool DBL = sizeof(R) == 8;
+    if (pl->nfft == 4096) return launch_upols_n<R, 4096, DBL ? 8 : 16, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
+    if constexpr (!DBL) {
+        if (pl->nfft == 8192) return launch_upols_n<R, 8192, 16, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
+    }
+    MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "partitioned overlap-save does not support nfft=%lld", (long long)pl->nfft);
 }
 
 // ---- rocFFT engine --------------------------------------------------------------------------------------
@@ -444,24 +642,73 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     if (nfft > (int64_t(1) << 24)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft %lld too large", (long long)nfft);
     int eng = engine;
     if (eng == MDSP_ENGINE_AUTO) eng = tunables().engine;
-    if (eng == MDSP_ENGINE_AUTO) eng = fused_supported(dtype, nfft) ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
-    if (eng == MDSP_ENGINE_FUSED && !fused_supported(dtype, nfft))
-        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft in [256, 8192]; got %lld", (long long)nfft);
+    int64_t exec_nfft = nfft;
+    int parts = 1;
+    const bool fused_ok = fused_geometry(dtype, nb, nfft, &exec_nfft, &parts);
+    if (eng == MDSP_ENGINE_AUTO) eng = fused_ok ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
+    if (eng == MDSP_ENGINE_FUSED && !fused_ok)
+        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft >= 256 and filters of at most %d taps; got nfft=%lld, %lld taps",
+                  dtype_is_double(dtype) ? 8192 : 16384, (long long)nfft, (long long)nb);
     if (eng != MDSP_ENGINE_FUSED && eng != MDSP_ENGINE_ROCFFT) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid engine %d", engine);
+    if (eng != MDSP_ENGINE_FUSED) {
+        exec_nfft = nfft;
+        parts = 1;
+    }
 
     auto pl = new mdsp_ols_plan_s();
     pl->dtype = dtype;
     pl->mode = mode;
     pl->engine = eng;
     pl->nb = nb;
-    pl->nfft = nfft;
-    pl->L = nfft - (nb - 1);
+    pl->ref_nfft = nfft;
+    pl->ref_L = nfft - (nb - 1);
+    pl->partitions = parts;
+    pl->nfft = exec_nfft;
+    pl->L = parts > 1 ? exec_nfft / 2 : exec_nfft - (nb - 1);
     pl->variant = tunables().ols_variant;
+    nfft = exec_nfft;   // from here on: the transform size that executes
 
     // Filter spectrum in double on the host.  FILT: taps scaled by 1/nfft before the transform (filt.jl:499);
     // CONV: spectrum scaled by 1/nfft afterwards (dspbase.jl:516).  The scaling is applied in the plan's working
     // precision at the same place the reference applies it, the transform itself is evaluated in double.
     const bool cplx = dtype_is_complex(dtype), dbl = dtype_is_double(dtype);
+    if (parts > 1) {   // P spectra of the zero-padded partitions h_p = h[pB .. (p+1)B), 1/N folded in (both modes: one scaling per partition)
+        const int64_t B = nfft / 2;
+        std::vector<zd> Hall((size_t)(parts * nfft));
+        for (int p = 0; p < parts; ++p) {
+            std::vector<zd> hpart((size_t)nfft, zd(0, 0));
+            for (int64_t i = 0; i < B && p * B + i < nb; ++i) {
+                const int64_t j = p * B + i;
+                zd v;
+                if (dtype == MDSP_F32) v = zd(((const float*)taps_host)[j], 0);
+                else if (dtype == MDSP_F64) v = zd(((const double*)taps_host)[j], 0);
+                else if (dtype == MDSP_C32) v = zd(((const float*)taps_host)[2 * j], ((const float*)taps_host)[2 * j + 1]);
+                else v = zd(((const double*)taps_host)[2 * j], ((const double*)taps_host)[2 * j + 1]);
+                hpart[(size_t)i] = v / (double)nfft;
+            }
+            const std::vector<zd> Hq = host_fft(hpart, -1);
+            std::copy(Hq.begin(), Hq.end(), Hall.begin() + (size_t)p * (size_t)nfft);
+        }
+        int stp = MDSP_OK;
+        if (dbl) {
+            std::vector<cx<double>> h(Hall.size());
+            for (size_t k = 0; k < Hall.size(); ++k) h[k] = {Hall[k].real(), Hall[k].imag()};
+            stp = pl->H.reserve(sizeof(cx<double>) * h.size());
+            if (stp == MDSP_OK && hipMemcpy(pl->H.p, h.data(), sizeof(cx<double>) * h.size(), hipMemcpyHostToDevice) != hipSuccess) stp = set_error(MDSP_ERR_DEVICE, "spectrum upload failed");
+        } else {
+            std::vector<cx<float>> h(Hall.size());
+            for (size_t k = 0; k < Hall.size(); ++k) h[k] = {(float)Hall[k].real(), (float)Hall[k].imag()};
+            stp = pl->H.reserve(sizeof(cx<float>) * h.size());
+            if (stp == MDSP_OK && hipMemcpy(pl->H.p, h.data(), sizeof(cx<float>) * h.size(), hipMemcpyHostToDevice) != hipSuccess) stp = set_error(MDSP_ERR_DEVICE, "spectrum upload failed");
+        }
+        if (stp == MDSP_OK) stp = dbl ? upload_table<double>(pl->table, nfft) : upload_table<float>(pl->table, nfft);
+        if (stp != MDSP_OK) {
+            delete pl;
+            return stp;
+        }
+        *plan = pl;
+        return MDSP_OK;
+    }
     std::vector<zd> hp((size_t)nfft, zd(0, 0));
     for (int64_t i = 0; i < nb; ++i) {
         zd v;
@@ -499,9 +746,17 @@ int mdsp_ols_plan_destroy(mdsp_ols_plan plan) {
 
 int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len, int* engine_used) {
     if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
-    if (nfft) *nfft = plan->nfft;
-    if (block_len) *block_len = plan->L;
+    if (nfft) *nfft = plan->ref_nfft;          // the reference's geometry: what optimalfftfiltlength / the caller chose
+    if (block_len) *block_len = plan->ref_L;
     if (engine_used) *engine_used = plan->engine;
+    return MDSP_OK;
+}
+
+int mdsp_ols_plan_geometry(mdsp_ols_plan plan, int64_t* exec_nfft, int64_t* exec_block_len, int* partitions) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (exec_nfft) *exec_nfft = plan->nfft;
+    if (exec_block_len) *exec_block_len = plan->L;
+    if (partitions) *partitions = plan->partitions;
     return MDSP_OK;
 }
 
@@ -511,6 +766,12 @@ static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int6
                          int64_t g_begin, int64_t g_end, hipStream_t s) {
     const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
     const int64_t nblocks = cdiv(nout, plan->L);
+    if (plan->partitions > 1) {   // long filters: uniformly partitioned overlap-save (whole columns only)
+        if (g_begin != 0 || (g_end >= 0 && g_end < nblocks)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "block ranges are not available for partitioned plans");
+        if (ncols > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 columns per call");
+        if (cplx) return dbl ? launch_upols<double, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s) : launch_upols<float, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s);
+        return dbl ? launch_upols<double, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s) : launch_upols<float, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s);
+    }
     if (g_end < 0 || g_end > nblocks) g_end = nblocks;
     if (g_begin >= g_end) return MDSP_OK;
     if (plan->engine == MDSP_ENGINE_ROCFFT) {
@@ -560,6 +821,7 @@ int mdsp_ols_exec_range(mdsp_ols_plan plan, const void* xs_dev, int64_t xs_first
     if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
     if (nx < 0 || nout < 0 || xs_first < 0 || xs_len < 0 || first_block < 0 || nblocks_range < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
     if (nout > nx + plan->nb - 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nout (%lld) exceeds nx+nb-1", (long long)nout);
+    if (plan->partitions > 1) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "block ranges are not available for partitioned plans (filters longer than half the largest in-LDS transform)");
     const int64_t L = plan->L, nb = plan->nb, nblocks = cdiv(nout, L);
     const int64_t g0 = first_block, g1 = std::min(nblocks, first_block + nblocks_range);
     if (g0 >= g1) return MDSP_OK;
@@ -585,7 +847,7 @@ int mdsp_ols_segment(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t 
     if (first_block < 0 || nblocks < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative block range");
     if (nblocks == 0) return MDSP_OK;
     hipStream_t s = as_stream(stream);
-    const int64_t nfft = plan->nfft;
+    const int64_t nfft = plan->ref_nfft;          // the REFERENCE's blocks (tmp1 of Filters/filt.jl:504-510), whatever geometry executes
     const int gx = (int)std::min<int64_t>(cdiv(nfft, 256), 8);
     const int64_t total = first_block + nblocks;  // blocks of a single column: unit index == block index
     const int64_t big = INT64_MAX / 4;
@@ -593,7 +855,7 @@ int mdsp_ols_segment(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t 
         const int64_t cnt = std::min<int64_t>(32768, nblocks - b0);
 #define SEG(TT)                                                                                                                      \
     hipLaunchKernelGGL(ols_segment_kernel<TT>, dim3((unsigned)cnt, gx), dim3(256), 0, s, (const TT*)x_dev, (TT*)seg_dev + b0 * nfft, nx, \
-                       (int64_t)0, big, plan->L, (int)plan->nb, (int)nfft, first_block + b0, total)
+                       (int64_t)0, big, plan->ref_L, (int)plan->nb, (int)nfft, first_block + b0, total)
         switch (plan->dtype) {
             case MDSP_F32: SEG(float); break;
             case MDSP_F64: SEG(double); break;

@@ -6,7 +6,9 @@
 
 struct mdsp_ols_plan_s {
     int dtype = MDSP_F32, mode = MDSP_OLS_FILT, engine = MDSP_ENGINE_ROCFFT;
-    int64_t nb = 0, nfft = 0, L = 0;
+    int64_t nb = 0, nfft = 0, L = 0;      // nfft / L: the geometry that EXECUTES (== the reference's unless the fused engine re-blocked a long filter)
+    int64_t ref_nfft = 0, ref_L = 0;     // what the caller / optimalfftfiltlength asked for (plan_info, mdsp_ols_segment: the reference's tmp1 blocks)
+    int partitions = 1;                  // > 1: uniformly partitioned overlap-save (upols_fused_kernel): nfft = 2 B, `partitions` spectra in H
     mdsp::DevBuf H;       // rocFFT engine: nspec (real) or nfft (complex) entries; fused: nfft entries
     mdsp::DevBuf table;   // fused: nfft forward roots
     // rocFFT engine state

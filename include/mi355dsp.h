@@ -110,6 +110,11 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
                          int dtype, int mode, int engine);
 int mdsp_ols_plan_destroy(mdsp_ols_plan plan);
 int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len /* L */, int* engine_used);
+/* What actually executes.  mdsp_ols_plan_info reports the REFERENCE's geometry (the nfft optimalfftfiltlength / the caller chose, dspbase.jl:268-291);
+ * the fused engine runs it as it is up to nfft = 8192 (4096 in Float64).  Longer filters -- ~1100 taps and more, where the reference asks for
+ * nfft = 16384 ... 2^20 -- are re-blocked: one block of the largest in-LDS transform while the filter covers at most half of it, else a
+ * uniformly partitioned filter (2..4 partitions of exec_nfft/2 taps, spectra of the last blocks kept in registers).  Same outputs within rounding. */
+int mdsp_ols_plan_geometry(mdsp_ols_plan plan, int64_t* exec_nfft, int64_t* exec_block_len, int* partitions);
 /* x_dev: (nx, ncols) ld ldx;  y_dev: (nout, ncols) ld ldy.  nout = nx (filt), nx+nb-1 (conv), or any
  * 0 <= nout <= nx+nb-1.  x and y must not alias (Filters/filt.jl:438-439). */
 int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,

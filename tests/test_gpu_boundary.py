@@ -279,3 +279,61 @@ def test_alternating_stateful_filters_and_repeated_tdfilt(d, torch):
     for _ in range(3):
         assert relerr(d.filt(b1, 1.0, x), odsp.filt_ba(b1, 1.0, x)) < 1e-12     # state never leaks from one call into the next
         assert relerr(d.filt(b2, 1.0, x[:100]), odsp.filt_ba(b2, 1.0, x[:100])) < 1e-12
+
+
+@pytest.mark.parametrize("dt,nb,expect", [(np.float32, 1500, (8192, 6693, 1)), (np.float32, 5120, (4096, 2048, 3)), (np.float32, 7000, (4096, 2048, 4)),
+                                          (np.float32, 12000, (8192, 4096, 3)), (np.float64, 3000, (4096, 2048, 2)), (np.float64, 1800, (4096, 2297, 1)),
+                                          (np.complex64, 5000, (4096, 2048, 3))])
+def test_long_filters_are_reblocked_by_the_fused_engine(d, torch, dt, nb, expect):
+    """VERDICT r1 'missing 4': optimalfftfiltlength (dspbase.jl:268-291) asks for nfft = 16384 ... 2^20 once the filter has more than ~1100 taps;
+    the fused engine evaluates the same convolution with the largest in-LDS block, or a uniformly partitioned filter (2..4 partitions, delay
+    line of spectra in registers) -- against the oracle's own overlap-save at the REFERENCE's nfft, filt and conv, several columns."""
+    from dsp_jl_amd import _lib
+    from dsp_jl_amd.dspbase import OlsPlan
+    from oracle import filt as ofilt, dspbase as odsp
+    rng = np.random.default_rng(nb)
+    cplx = np.dtype(dt).kind == "c"
+    rdt = np.float32 if dt in (np.float32, np.complex64) else np.float64
+    b = (rng.standard_normal(nb) / np.sqrt(nb)).astype(rdt)      # no taper: the first outputs of a short signal are O(1), not rounding-level
+    nx = 400_000 + 137
+    x = rng.standard_normal((nx, 2)).astype(rdt)
+    if cplx:
+        x = (x + 1j * rng.standard_normal((nx, 2))).astype(dt)
+    nfft_ref = d.optimalfftfiltlength(nb, nx)
+    assert nfft_ref > (4096 if rdt == np.float64 else 8192)
+    plan = OlsPlan(b.astype(dt), nfft_ref, nx, _lib.OLS_FILT, d.ENGINE_FUSED)
+    assert (plan.nfft, plan.block_len, plan.engine) == (nfft_ref, nfft_ref - nb + 1, d.ENGINE_FUSED)     # plan_info: the reference's geometry
+    en, el, ep = C.c_int64(), C.c_int64(), C.c_int()
+    _lib.check(_lib.lib().mdsp_ols_plan_geometry(plan._h, C.byref(en), C.byref(el), C.byref(ep)))
+    assert (en.value, el.value, ep.value) == expect
+    tol = TOL32 if rdt == np.float32 else 1e-12
+    xd = torch.from_numpy(x).cuda()
+    y = plan.exec(xd.t().contiguous(), nx).t().cpu().numpy()
+    for c in range(2):
+        xc = x[:, c].astype(np.complex128 if cplx else np.float64)
+        ref = odsp.filt_ba(b.astype(np.float64), 1.0, xc) if not cplx else (odsp.filt_ba(b.astype(np.float64), 1.0, xc.real) + 1j * odsp.filt_ba(b.astype(np.float64), 1.0, xc.imag))
+        assert relerr(y[:, c], ref) < tol, c
+        # the edges carry the zero padding and the clamped last block
+        assert relerr(y[:3000, c], ref[:3000]) < 5 * tol and relerr(y[-3000:, c], ref[-3000:]) < 5 * tol
+    if not cplx:
+        # through the API: filt(b, x) picks the same plan; the rocFFT engine runs the reference's own block size; conv adds the tail
+        got = d.filt(b, xd[:, 0])
+        assert relerr(got.cpu().numpy(), ofilt.fftfilt(b.astype(np.float64), x[:, 0].astype(np.float64))) < tol
+        roc = d.fftfilt(b, xd[:, 0], nfft_ref, engine=d.ENGINE_ROCFFT)
+        assert relerr(got.cpu().numpy(), roc.cpu().numpy()) < 2 * tol
+        cv = d.conv(xd[:, 1], torch.from_numpy(b).cuda())
+        assert cv.shape == (nx + nb - 1,)
+        assert relerr(cv.cpu().numpy(), odsp.conv(x[:, 1].astype(np.float64), b.astype(np.float64))) < tol
+        # host-pointer pipeline on a re-blocked plan (halo chunks for the partitioned ones)
+        _lib.set_tunable("MDSP_HOST_CHUNK_MIB", 1)
+        try:
+            yh = plan.exec_host(np.ascontiguousarray(x.T), nx)
+        finally:
+            _lib.set_tunable("MDSP_HOST_CHUNK_MIB", None)
+        assert relerr(yh.T, y) < 2e-6 if rdt == np.float32 else relerr(yh.T, y) < 1e-13
+    # short signals: fewer blocks than one run, fewer samples than one block
+    for n_small in (1, 100, 2049, 5000):
+        xs = x[:n_small, 0]
+        got = plan.exec(torch.from_numpy(np.ascontiguousarray(xs)).cuda().view(1, -1), n_small)[0].cpu().numpy()
+        ref = odsp.filt_ba(b.astype(np.float64), 1.0, xs.real.astype(np.float64)) + (1j * odsp.filt_ba(b.astype(np.float64), 1.0, xs.imag.astype(np.float64)) if cplx else 0)
+        assert relerr(got, ref) < 5 * tol, n_small
