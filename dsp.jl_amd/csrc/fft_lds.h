@@ -407,5 +407,123 @@ template <typename C, int PADSHIFT, int NEXT = 1, int PERMUTE = false, typename 
     }
 }
 
+
+// ================================================================================================ mixed-radix transforms (runtime N)
+// nextfastfft (util.jl:134) returns 7-smooth sizes -- 1000, 1536, 3000 ... -- and periodogram / welch_pgram / stft use them by default
+// (nfft = nextfastfft(n), periodograms.jl:393, :560, :872).  The register-resident Stockham above needs E | N with one radix set per
+// geometry; for everything else the transform runs entirely through LDS: every pass reads its operands from one buffer and scatters its
+// results into the other (Stockham autosort, natural order in, natural order out), radices 16 / 8 / 4 / 2 / 3 / 5 / 7 chosen per pass at run
+// time, any thread count.  Slower per point than the register form, but fused all the same: the frame is windowed into LDS straight
+// from the signal and the spectrum is consumed from LDS, so HBM sees the signal once and the output once.
+template <typename R> MDSP_HD void bfly3f(cx<R>& a0, cx<R>& a1, cx<R>& a2) {   // forward: w = exp(-2 pi i / 3)
+    constexpr R s = (R)0.86602540378443864676372317075294L;
+    const cx<R> t1 = cadd(a1, a2), d = csub(a1, a2);
+    const cx<R> t2 = {a0.x - (R)0.5 * t1.x, a0.y - (R)0.5 * t1.y};
+    const cx<R> t3 = mul_mi<-1>(cscale(s, d));   // -i (sqrt(3)/2) (a1 - a2)
+    a0 = cadd(a0, t1);
+    a1 = cadd(t2, t3);
+    a2 = csub(t2, t3);
+}
+template <typename R> MDSP_HD void bfly5f(cx<R> (&v)[5]) {
+    constexpr R c1 = (R)0.30901699437494742410229341718282L, c2 = (R)-0.80901699437494742410229341718282L;
+    constexpr R s1 = (R)0.95105651629515357211643933337938L, s2 = (R)0.58778525229247312916870595463907L;
+    const cx<R> t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const cx<R> m1 = {v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y};
+    const cx<R> m2 = {v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y};
+    const cx<R> n1 = mul_mi<-1>(cx<R>{s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y});   // -i n1
+    const cx<R> n2 = mul_mi<-1>(cx<R>{s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y});
+    v[0] = cadd(v[0], cadd(t1, t2));
+    v[1] = cadd(m1, n1);
+    v[4] = csub(m1, n1);
+    v[2] = cadd(m2, n2);
+    v[3] = csub(m2, n2);
+}
+template <typename R> MDSP_HD void bfly7f(cx<R> (&v)[7]) {
+    constexpr R c1 = (R)0.62348980185873353052500488400424L, c2 = (R)-0.22252093395631440428890256449679L, c3 = (R)-0.90096886790241912623610231950745L;
+    constexpr R s1 = (R)0.78183148246802980870844452667406L, s2 = (R)0.97492791218182360701813168299393L, s3 = (R)0.43388373911755812047576833284836L;
+    const cx<R> t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
+    const cx<R> u1 = csub(v[1], v[6]), u2 = csub(v[2], v[5]), u3 = csub(v[3], v[4]);
+    const cx<R> m1 = {v[0].x + c1 * t1.x + c2 * t2.x + c3 * t3.x, v[0].y + c1 * t1.y + c2 * t2.y + c3 * t3.y};
+    const cx<R> m2 = {v[0].x + c2 * t1.x + c3 * t2.x + c1 * t3.x, v[0].y + c2 * t1.y + c3 * t2.y + c1 * t3.y};
+    const cx<R> m3 = {v[0].x + c3 * t1.x + c1 * t2.x + c2 * t3.x, v[0].y + c3 * t1.y + c1 * t2.y + c2 * t3.y};
+    const cx<R> n1 = mul_mi<-1>(cx<R>{s1 * u1.x + s2 * u2.x + s3 * u3.x, s1 * u1.y + s2 * u2.y + s3 * u3.y});
+    const cx<R> n2 = mul_mi<-1>(cx<R>{s2 * u1.x - s3 * u2.x - s1 * u3.x, s2 * u1.y - s3 * u2.y - s1 * u3.y});
+    const cx<R> n3 = mul_mi<-1>(cx<R>{s3 * u1.x - s1 * u2.x + s2 * u3.x, s3 * u1.y - s1 * u2.y + s2 * u3.y});
+    v[0] = cadd(v[0], cadd(t1, cadd(t2, t3)));
+    v[1] = cadd(m1, n1);
+    v[6] = csub(m1, n1);
+    v[2] = cadd(m2, n2);
+    v[5] = csub(m2, n2);
+    v[3] = cadd(m3, n3);
+    v[4] = csub(m3, n3);
+}
+template <int RDX, typename R> MDSP_HD void gen_bfly(cx<R> (&v)[RDX]) {
+    if constexpr (RDX == 3) bfly3f(v[0], v[1], v[2]);
+    else if constexpr (RDX == 5) bfly5f(v);
+    else if constexpr (RDX == 7) bfly7f(v);
+    else bfly<RDX, -1>(v);
+}
+
+// LDS index padding of the mixed-radix buffers: one element per 16 (first-pass scatters have stride = radix elements)
+MDSP_HD int gen_pad(int i) { return i + (i >> 4); }
+MDSP_HD constexpr int gen_lds_elems(int n) { return n + (n >> 4) + 1; }
+
+// Radix schedule of a 7-smooth N: 16s and 8s first, then 4 / 2, then 7, 5, 3 (radix[] and ns[] have room for MDSP_GEN_MAXP passes).
+// Returns the number of passes, 0 if N has another prime factor or needs more passes than that.
+#define MDSP_GEN_MAXP 8
+MDSP_HD int gen_schedule(int n, int* radix, int* ns) {
+    int p = 0, rest = n, acc = 1;
+    const int order[7] = {16, 8, 4, 2, 7, 5, 3};
+    for (int k = 0; k < 7; ++k) {
+        const int r = order[k];
+        while (rest % r == 0 && rest > 1) {
+            if (r == 16 && rest == 32) break;   // 32 = 8 * 4, not 16 * 2
+            if (p == MDSP_GEN_MAXP) return 0;
+            radix[p] = r;
+            ns[p] = acc;
+            acc *= r;
+            rest /= r;
+            ++p;
+        }
+    }
+    return rest == 1 ? p : 0;
+}
+
+// One forward pass of radix RDX over the whole transform by T threads (thread t takes butterflies t, t + T, ...):
+//   v[q] = in[j + (N/RDX) q] * w^(q k stride),  k = j mod Ns, stride = N / (Ns RDX);   out[(j div Ns) Ns RDX + k + Ns q'] = DFT_RDX(v)[q']
+// roots[k] = exp(-2 pi i k / N), k < N.  divm = ceil(2^24 / Ns): j div Ns == (j * divm) >> 24 (64-bit product) for every j < N / RDX -- exact
+// because j * Ns < 2^24 for N <= 8192 (checked exhaustively by the host harness for every size it runs).
+template <int RDX, typename R>
+MDSP_HD void gen_pass(const cx<R>* in, cx<R>* out, const cx<R>* roots, int N, int Ns, unsigned divm, int t, int T) {
+    const int nbf = N / RDX, stride = N / (Ns * RDX);
+    for (int j = t; j < nbf; j += T) {
+        cx<R> v[RDX];
+#pragma unroll
+        for (int q = 0; q < RDX; ++q) v[q] = in[gen_pad(j + nbf * q)];
+        const int hi = Ns == 1 ? j : (int)(((unsigned long long)(unsigned)j * divm) >> 24);
+        const int k = j - hi * Ns;
+        if (Ns > 1) {
+            const int idx = k * stride;   // q * idx < N for q < RDX: no reduction needed
+#pragma unroll
+            for (int q = 1; q < RDX; ++q) v[q] = cmul(v[q], roots[q * idx]);
+        }
+        gen_bfly<RDX>(v);
+        const int base = hi * Ns * RDX + k;
+#pragma unroll
+        for (int q = 0; q < RDX; ++q) out[gen_pad(base + Ns * q)] = v[q];
+    }
+}
+template <typename R> MDSP_HD void gen_pass_dispatch(int radix, const cx<R>* in, cx<R>* out, const cx<R>* roots, int N, int Ns, unsigned divm, int t, int T) {
+    switch (radix) {
+        case 16: gen_pass<16>(in, out, roots, N, Ns, divm, t, T); break;
+        case 8: gen_pass<8>(in, out, roots, N, Ns, divm, t, T); break;
+        case 4: gen_pass<4>(in, out, roots, N, Ns, divm, t, T); break;
+        case 2: gen_pass<2>(in, out, roots, N, Ns, divm, t, T); break;
+        case 7: gen_pass<7>(in, out, roots, N, Ns, divm, t, T); break;
+        case 5: gen_pass<5>(in, out, roots, N, Ns, divm, t, T); break;
+        default: gen_pass<3>(in, out, roots, N, Ns, divm, t, T); break;
+    }
+}
+
 }  // namespace fft
 }  // namespace mdsp

@@ -618,6 +618,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_pair_kernel(SpecArgs a
     }
 }
 
+#include "spectral_gen.h"
+
 bool fused_size_ok(int dtype, int64_t nfft) {
     const bool dbl = dtype_is_double(dtype);
     switch (nfft) {
@@ -630,9 +632,11 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 int resolve_engine(int engine, int dtype, int64_t nfft, int* out) {
     int eng = engine;
     if (eng == MDSP_ENGINE_AUTO) eng = tunables().engine;
-    if (eng == MDSP_ENGINE_AUTO) eng = fused_size_ok(dtype, nfft) ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
-    if (eng == MDSP_ENGINE_FUSED && !fused_size_ok(dtype, nfft))
-        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft in [256, 8192]; got %lld", (long long)nfft);
+    // fused: the register-resident power-of-two sizes, and the mixed-radix LDS kernel for the other 7-smooth sizes nextfastfft returns
+    const bool fused_ok = fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft);
+    if (eng == MDSP_ENGINE_AUTO) eng = fused_ok ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
+    if (eng == MDSP_ENGINE_FUSED && !fused_ok)
+        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports nfft = 2^a 3^b 5^c 7^d up to %d; got %lld", dtype_is_double(dtype) ? 4096 : 8192, (long long)nfft);
     if (eng != MDSP_ENGINE_FUSED && eng != MDSP_ENGINE_ROCFFT) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid engine %d", engine);
     *out = eng;
     return MDSP_OK;
@@ -1128,6 +1132,24 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
     a.nout = (int)pl->nout;
     a.onesided = pl->onesided;
     a.r = pl->r;
+    if (!fused_size_ok(pl->dtype, pl->nfft)) {   // mixed-radix sizes: everything through LDS (spectral_gen.h), same Float64 accumulator protocol
+        GenArgs g{};
+        g.s = s; g.roots = pl->table.p; g.win = a.win;
+        g.len = len; g.lds_ = lds_; g.K = K; g.hop = a.hop; g.nch = nch; g.units_per_ch = a.units_per_ch;
+        g.n = a.n; g.N = (int)pl->nfft; g.nout = a.nout; g.onesided = a.onesided; g.r = a.r;
+        int64_t nslots = 0;
+        MDSP_TRY((gen_launch<R, CPLX, 0>(g, nch, st, &nslots, &pl->partial)));
+        const int N = (int)pl->nfft;
+        MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)nch * (size_t)N));
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)nch), dim3(256), 0, st, pl->partial.as<double>(),
+                           pl->reduced.as<double>(), (int)nslots, nch, N, pl->acc_fresh ? 0 : 1);
+        MDSP_LAUNCH_CHECK();
+        pl->acc_fresh = false;
+        pl->acc_nslices = 1;
+        pl->acc_nacc = N;
+        pl->acc_mode = CPLX ? 1 : (pl->onesided ? 3 : 4);
+        return MDSP_OK;
+    }
     switch (pl->nfft) {
         case 256: return welch_launch_n<R, 256, CPLX>(pl, a, st);
         case 512: return welch_launch_n<R, 512, CPLX>(pl, a, st);
@@ -1457,6 +1479,15 @@ int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nc
     a.nout = (int)pl->nout;
     a.onesided = pl->onesided;
     a.r = pl->r;
+    if (!fused_size_ok(pl->dtype, pl->nfft)) {   // mixed-radix sizes (spectral_gen.h); multitaper plans come here once per taper (accumulate)
+        GenArgs g{};
+        g.s = s; g.out = out; g.roots = pl->table.p; g.win = a.win;
+        g.len = len; g.lds_ = lds_; g.K = K; g.hop = a.hop; g.nch = nch; g.ldo = ldo; g.chs = chs;
+        g.units_per_ch = CPLX ? K : cdiv(K, 2);
+        g.n = a.n; g.N = (int)pl->nfft; g.nout = a.nout; g.onesided = a.onesided; g.psd = pl->psd_only; g.accumulate = pl->accumulate; g.r = a.r;
+        int64_t nslots = 0;
+        return gen_launch<R, CPLX, 1>(g, nch, st, &nslots, nullptr);
+    }
     switch (pl->nfft) {
         case 256: return stft_launch_n<R, 256, CPLX>(pl, a, st);
         case 512: return stft_launch_n<R, 512, CPLX>(pl, a, st);
@@ -1713,7 +1744,7 @@ int mdsp_mt_psd_exec(mdsp_mt_plan plan, const void* s_dev, int64_t len, int64_t 
     st.psd_only = 1;
     // real signals on the fused engine: every taper inside one launch (the frame pair stays in registers); otherwise one
     // pass per taper with the accumulate flag
-    if (st.engine == MDSP_ENGINE_FUSED && !dtype_is_complex(st.dtype) && !MDSP_DBG(mt_passes) && !MDSP_DBG(stft_nopair)) {
+    if (st.engine == MDSP_ENGINE_FUSED && fused_size_ok(st.dtype, st.nfft) && !dtype_is_complex(st.dtype) && !MDSP_DBG(mt_passes) && !MDSP_DBG(stft_nopair)) {
         st.win_ptr = plan->wins.as<double>();
         st.r = plan->r[0];
         st.accumulate = 0;

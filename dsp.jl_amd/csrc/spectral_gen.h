@@ -1,0 +1,176 @@
+// Mixed-radix fused spectral kernel (included by spectral.hip inside its anonymous namespace): Welch / STFT / spectrogram / periodogram for
+// the transform sizes nextfastfft (util.jl:134) produces besides powers of two -- 2^a 3^b 5^c 7^d, e.g. 1000, 1536, 3000 -- which DSP.jl
+// uses by default (nfft = nextfastfft(n): periodograms.jl:393, :560, :872).  One persistent kernel:
+//
+//   window the frame(s) into LDS straight from the signal  ->  mixed-radix Stockham passes LDS <-> LDS (fft_lds.h "mixed-radix transforms")
+//   ->  consume the natural-order spectrum from LDS:  |Z|^2 into per-slot Float64 sums (Welch)  or  the output column (STFT / PSD).
+//
+// Real signals ride two frames per transform (z = w (a + i b)); Welch needs no untangling (|A|^2 + |B|^2 = (|Z[k]|^2 + |Z[N-k]|^2) / 2, folded by
+// welch_finalize_kernel modes 3 / 4), the STFT modes untangle A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / (2i) while reading
+// the spectrum back from LDS.  HBM traffic = the signal once (+ frame overlap from L2) and the output once: the algorithmic bytes of SURVEY 8d,
+// against ~9x that for the K4 -> rocFFT -> K5/K6 pipeline these sizes used to take.
+#pragma once
+
+struct GenArgs {
+    const void* s;
+    void* out;             // Welch: double partials [slot][ch][N];  STFT: output matrices
+    const void* roots;     // N forward roots
+    const double* win;     // n doubles or nullptr
+    int64_t len, lds_, K, hop, nch, ldo, chs;
+    int64_t units_per_ch;  // frames (complex signals) or frame pairs (real signals)
+    int64_t per_slot;      // consecutive units per transform slot (same trip count for every slot)
+    int n, N, nout, onesided, psd, accumulate;
+    int P, T;              // passes, threads per transform slot (256 / T slots per workgroup)
+    int radix[MDSP_GEN_MAXP], ns[MDSP_GEN_MAXP];
+    unsigned divm[MDSP_GEN_MAXP];
+    double r;
+};
+
+constexpr int GEN_EMAX = 32;   // bins per thread in the Welch accumulator (N <= 8192 with T = 256)
+
+// 7-smooth size the mixed-radix kernel takes: not one of the register-resident power-of-two sizes, two padded LDS buffers per slot
+inline bool gen_size_ok(int dtype, int64_t nfft) {
+    if (nfft < 2 || nfft > (dtype_is_double(dtype) ? 4096 : 8192)) return false;
+    int radix[MDSP_GEN_MAXP], ns[MDSP_GEN_MAXP];
+    return fft::gen_schedule((int)nfft, radix, ns) > 0;
+}
+
+template <typename R, bool CPLX, int MODE>   // MODE 0: Welch sums, 1: STFT columns (raw or PSD)
+__global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
+    const int T = a.T, N = a.N;
+    const int slot = threadIdx.x / T, t = threadIdx.x - slot * T, G = 256 / T;
+    const int region = fft::gen_lds_elems(N);
+    cx<R>* bufA = reinterpret_cast<cx<R>*>(gen_smem) + (size_t)slot * 2 * region;
+    cx<R>* bufB = bufA + region;
+    const cx<R>* roots = static_cast<const cx<R>*>(a.roots);
+    const int64_t ch = blockIdx.y;
+    const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
+    const int64_t gslot = (int64_t)blockIdx.x * G + slot;
+    const int64_t u0 = gslot * a.per_slot;
+
+    double acc[MODE == 0 ? GEN_EMAX : 1];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < GEN_EMAX; ++i) acc[i] = 0.0;
+    }
+    for (int64_t it = 0; it < a.per_slot; ++it) {
+        const int64_t u = u0 + it;
+        const bool live = u < a.units_per_ch;
+        const int64_t f0 = CPLX ? u : 2 * u;
+        const bool haveB = !CPLX && live && (f0 + 1) < a.K;
+        // K4 (periodograms.jl:57-69): frame * window in Float64, rounded once, zero tail; frames lie wholly inside the signal by construction
+        const TT* fa = sc + f0 * a.hop;
+        for (int i = t; i < N; i += T) {
+            cx<R> z = {(R)0, (R)0};
+            if (live && i < a.n) {
+                const double w = a.win ? a.win[i] : 1.0;
+                if constexpr (CPLX) z = a.win ? win_mul(fa[i], w) : fa[i];
+                else {
+                    z.x = a.win ? win_mul(fa[i], w) : fa[i];
+                    if (haveB) z.y = a.win ? win_mul(fa[i + a.hop], w) : fa[i + a.hop];
+                }
+            }
+            bufA[fft::gen_pad(i)] = z;
+        }
+        __syncthreads();
+        cx<R>*src = bufA, *dst = bufB;
+        for (int p = 0; p < a.P; ++p) {
+            fft::gen_pass_dispatch(a.radix[p], src, dst, roots, N, a.ns[p], a.divm[p], t, T);
+            __syncthreads();
+            cx<R>* tmp = src;
+            src = dst;
+            dst = tmp;
+        }
+        if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
+#pragma unroll
+            for (int i = 0; i < GEN_EMAX; ++i) {
+                const int k = t + T * i;
+                if (k < N && live) {
+                    const cx<R> z = src[fft::gen_pad(k)];
+                    acc[i] += (double)(z.x * z.x + z.y * z.y);
+                }
+            }
+        } else if (live) {
+            const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
+            const int64_t o0 = ch * a.chs + f0 * a.ldo;
+            for (int j = t; j < a.nout; j += T) {
+                if constexpr (CPLX) {   // two-sided only (a complex signal has no one-sided form, periodograms.jl:876)
+                    const cx<R> z = src[fft::gen_pad(j)];
+                    if (a.psd) {
+                        R* o = static_cast<R*>(a.out) + o0 + j;
+                        const R pw = z.x * z.x + z.y * z.y;
+                        *o = a.accumulate ? fma(pw, m1, *o) : pw * m1;       // fft2pow!: out = muladd(abs2, m, out)
+                    } else static_cast<cx<R>*>(a.out)[o0 + j] = z;
+                } else {
+                    const bool mirror = j > N / 2;                              // real -> two-sided: X[N-k] = conj(X[k]) (fft2oneortwosided!, :234-244)
+                    const int k = mirror ? N - j : j;
+                    const cx<R> zk = src[fft::gen_pad(k)], zm = src[fft::gen_pad(k == 0 ? 0 : N - k)];
+                    cx<R> A = {(R)0.5 * (zk.x + zm.x), (R)0.5 * (zk.y - zm.y)};   // (Z[k] + conj Z[N-k]) / 2
+                    cx<R> B = {(R)0.5 * (zk.y + zm.y), (R)0.5 * (zm.x - zk.x)};   // (Z[k] - conj Z[N-k]) / (2i)
+                    if (a.psd) {
+                        R m = m1;
+                        if (a.onesided && !(j == 0 || (j == a.nout - 1 && N % 2 == 0))) m = m2;
+                        R* o = static_cast<R*>(a.out) + o0 + j;
+                        const R pa = A.x * A.x + A.y * A.y;
+                        *o = a.accumulate ? fma(pa, m, *o) : pa * m;
+                        if (haveB) {
+                            const R pb = B.x * B.x + B.y * B.y;
+                            o[a.ldo] = a.accumulate ? fma(pb, m, o[a.ldo]) : pb * m;
+                        }
+                    } else {
+                        if (mirror) {
+                            A.y = -A.y;
+                            B.y = -B.y;
+                        }
+                        cx<R>* o = static_cast<cx<R>*>(a.out) + o0 + j;
+                        *o = A;
+                        if (haveB) o[a.ldo] = B;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the spectrum buffer may be the one the next frame is windowed into
+    }
+    if constexpr (MODE == 0) {
+        double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)N;
+#pragma unroll
+        for (int i = 0; i < GEN_EMAX; ++i) {
+            const int k = t + T * i;
+            if (k < N) part[k] = acc[i];
+        }
+    }
+}
+
+// geometry + schedule shared by the two launchers; returns the slot count through *nslots
+template <typename R, bool CPLX, int MODE>
+int gen_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial) {
+    a.P = fft::gen_schedule(a.N, a.radix, a.ns);
+    if (a.P <= 0) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%d has a prime factor other than 2, 3, 5, 7", a.N);
+    for (int p = 0; p < a.P; ++p) a.divm[p] = (unsigned)(((1u << 24) + a.ns[p] - 1) / a.ns[p]);
+    // threads per transform: enough that a thread owns at most GEN_EMAX bins and most lanes have a butterfly in the widest-radix pass
+    int T = 64;
+    while (T < 256 && (a.N > T * 16)) T *= 2;
+    a.T = T;
+    const int G = 256 / T;
+    const size_t lds_bytes = (size_t)G * 2 * (size_t)fft::gen_lds_elems(a.N) * sizeof(cx<R>);
+    auto kern = gen_spectral_kernel<R, CPLX, MODE>;
+    if (lds_bytes > 160 * 1024) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%d does not fit the LDS in this precision", a.N);
+    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int per_cu = 0;
+    MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
+    const int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * per_cu / std::max<int64_t>(1, nch));
+    const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(cdiv(a.units_per_ch, G), resident));
+    *nslots = wgs * G;
+    a.per_slot = cdiv(a.units_per_ch, *nslots);
+    if (MODE == 0) {
+        MDSP_TRY(partial->reserve(sizeof(double) * (size_t)(*nslots) * (size_t)nch * (size_t)a.N));
+        a.out = partial->p;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, (unsigned)nch), dim3(256), lds_bytes, st, a);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}

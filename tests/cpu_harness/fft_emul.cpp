@@ -101,8 +101,52 @@ template <int N, int E> static int check_all() {
     return bad;
 }
 
+// mixed-radix transforms (runtime N, everything through LDS): gen_schedule + gen_pass thread by thread against the long-double DFT, and the
+// multiply-shift division of gen_pass checked for every butterfly index
+template <typename R> static int check_gen(int N, int T, double tol) {
+    int radix[MDSP_GEN_MAXP], ns[MDSP_GEN_MAXP];
+    const int P = gen_schedule(N, radix, ns);
+    if (P == 0) { printf("gen N=%d: no schedule\n", N); return 1; }
+    std::vector<cx<R>> roots(N), a(gen_lds_elems(N)), b(gen_lds_elems(N));
+    for (int k = 0; k < N; ++k) {
+        const long double ang = -2.0L * 3.141592653589793238462643383279502884L * k / N;
+        roots[k] = {(R)cosl(ang), (R)sinl(ang)};
+    }
+    std::vector<std::complex<long double>> in(N);
+    srand(99 + N);
+    for (int i = 0; i < N; ++i) {
+        in[i] = {(long double)(R)((double)rand() / RAND_MAX - 0.5), (long double)(R)((double)rand() / RAND_MAX - 0.5)};
+        a[gen_pad(i)] = {(R)in[i].real(), (R)in[i].imag()};
+    }
+    cx<R>*src = a.data(), *dst = b.data();
+    for (int p = 0; p < P; ++p) {
+        const unsigned divm = (unsigned)(((1u << 24) + ns[p] - 1) / ns[p]);
+        for (int j = 0; j < N / radix[p]; ++j)
+            if (ns[p] > 1 && (int)(((unsigned long long)(unsigned)j * divm) >> 24) != j / ns[p]) { printf("gen N=%d pass %d: division by %d wrong at j=%d\n", N, p, ns[p], j); return 1; }
+        for (int t = 0; t < T; ++t) gen_pass_dispatch(radix[p], src, dst, roots.data(), N, ns[p], divm, t, T);
+        std::swap(src, dst);
+    }
+    long double err2 = 0, norm = 0;
+    for (int k = 0; k < N; ++k) {
+        std::complex<long double> acc = 0;
+        for (int n = 0; n < N; ++n) {
+            const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)(((long long)n * k) % N) / N;
+            acc += in[n] * std::complex<long double>(cosl(ang), sinl(ang));
+        }
+        err2 += std::norm(std::complex<long double>(src[gen_pad(k)].x, src[gen_pad(k)].y) - acc);
+        norm += std::norm(acc);
+    }
+    const double e = (double)sqrtl(err2 / norm);
+    printf("gen N=%5d T=%3d passes %d radices:", N, T, P);
+    for (int p = 0; p < P; ++p) printf(" %d", radix[p]);
+    printf("  relerr %.2e\n", e);
+    return e < tol ? 0 : 1;
+}
+
 int main() {
     int bad = 0;
+    for (int N : {18, 30, 100, 120, 1000, 1536, 3000, 768, 1500, 2000, 2401, 625, 6561, 7000, 8000, 6, 7, 5, 3, 2, 64, 4096, 7680})
+        bad |= check_gen<float>(N, N > 2000 ? 256 : 64, 3e-6) | check_gen<double>(N, 128, 2e-14);
     bad |= check_all<16, 16>();
     bad |= check_all<64, 8>();
     bad |= check_all<128, 16>();

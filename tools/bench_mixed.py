@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Spectral estimators at nextfastfft sizes that are not powers of two (VERDICT r1 'missing 3'): fused engine (mixed-radix LDS kernel) against the
+rocFFT engine these sizes took before, next to the neighbouring power of two.  2^27 samples, Float32 / ComplexF32.  Writes gpurun_out/mixed.json."""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import dsp_jl_amd as d
+from dsp_jl_amd import _lib
+from dsp_jl_amd.periodograms import _StftPlan, compute_window
+
+lib = _lib.lib()
+_lib.check(lib.mdsp_init(0))
+stream = torch.cuda.current_stream().cuda_stream
+g = torch.Generator(device="cuda"); g.manual_seed(1776)
+n = 1 << int(os.environ.get("MIXED_LOG2N", "27"))
+
+
+def ev():
+    e = C.c_void_p(); _lib.check(lib.mdsp_event_create(C.byref(e))); return e
+
+
+e0, e1 = ev(), ev()
+
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        _lib.check(lib.mdsp_event_record(e0, stream)); fn(); _lib.check(lib.mdsp_event_record(e1, stream))
+        torch.cuda.synchronize()
+        ms = C.c_float(); _lib.check(lib.mdsp_event_elapsed_ms(e0, e1, C.byref(ms))); ts.append(ms.value)
+    return sorted(ts)[len(ts) // 2]
+
+
+res = {}
+xr = torch.randn(n, generator=g, device="cuda", dtype=torch.float32)
+xc = torch.complex(xr[: n // 2].clone(), torch.randn(n // 2, generator=g, device="cuda", dtype=torch.float32))
+for nfft in (1000, 1024, 1536, 2048, 3000, 4096, 6000, 8000):
+    row = {}
+    for eng, ename in ((d.ENGINE_FUSED, "fused"), (d.ENGINE_ROCFFT, "rocfft")):
+        # Welch, 50 % overlap, real Float32: 4 B / sample
+        cfg = d.WelchConfig(n, np.float32, n=nfft, noverlap=nfft // 2, nfft=nfft, window=d.hanning, engine=eng)
+        psd = torch.empty(cfg.nout, dtype=torch.float32, device="cuda")
+        ms = timeit(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xr.data_ptr(), n, 1, n, psd.data_ptr(), cfg.nout, stream)))
+        row[f"welch50_{ename}"] = {"ms": round(ms, 4), "Gsamples_per_s": round(n / ms / 1e6, 1), "GBps_algorithmic": round(4.0 * n / ms / 1e6, 1)}
+        # stft ComplexF32, 75 % overlap (config-4 shape): 8 + 8 * 4 = 40 B / sample
+        m = n // 2
+        win, norm2 = compute_window(d.hanning, nfft)
+        hop = nfft // 4
+        K = d.frame_count(m, nfft, nfft - hop)
+        plan = _StftPlan(nfft, nfft - hop, nfft, win, norm2, False, 0, np.complex64, eng)
+        out = torch.empty((K, nfft), dtype=torch.complex64, device="cuda")
+        ms = timeit(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, xc.data_ptr(), m, 1, m, out.data_ptr(), nfft, K * nfft, stream)))
+        row[f"stft75_c64_{ename}"] = {"ms": round(ms, 4), "Gsamples_per_s": round(m / ms / 1e6, 1), "GBps_algorithmic": round(40.0 * m / ms / 1e6, 1)}
+        # spectrogram real Float32, 50 % overlap, one-sided: 4 + 4 * (nfft/2+1) / (nfft/2) ~ 8 B / sample
+        plan = _StftPlan(nfft, nfft // 2, nfft, win, norm2, True, 1, np.float32, eng)
+        K = d.frame_count(n, nfft, nfft // 2)
+        out = torch.empty((K, plan.nout), dtype=torch.float32, device="cuda")
+        ms = timeit(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, xr.data_ptr(), n, 1, n, out.data_ptr(), plan.nout, K * plan.nout, stream)))
+        row[f"spectrogram50_f32_{ename}"] = {"ms": round(ms, 4), "Gsamples_per_s": round(n / ms / 1e6, 1),
+                                             "GBps_algorithmic": round((4.0 + 4.0 * plan.nout / (nfft // 2)) * n / ms / 1e6, 1)}
+        del out, plan, psd, cfg
+    res[str(nfft)] = row
+    print(nfft, {k: v["GBps_algorithmic"] for k, v in row.items()}, flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "mixed.json"), "w"), indent=1)
