@@ -464,6 +464,21 @@ template <int RDX, typename R> MDSP_HD void gen_bfly(cx<R> (&v)[RDX]) {
     else bfly<RDX, -1>(v);
 }
 
+// LDS accesses of the runtime-indexed buffers: cx<R> is only R-aligned, so a plain access compiles to two 4-byte DS operations (32-bank
+// rules, 2-way conflicts on every consecutive-element access: SQ_LDS_BANK_CONFLICT was 50 % of the LDS cycles).  The buffers ARE 2R-aligned:
+// say so, and every access is one ds_read_b64 / ds_write_b64 (b128 for Float64).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename R> struct alignas(2 * sizeof(R)) cxa { R x, y; };
+template <typename R> __device__ __forceinline__ cx<R> ld2(const cx<R>* p) {
+    const cxa<R> v = *reinterpret_cast<const cxa<R>*>(p);
+    return {v.x, v.y};
+}
+template <typename R> __device__ __forceinline__ void st2(cx<R>* p, cx<R> v) { *reinterpret_cast<cxa<R>*>(p) = cxa<R>{v.x, v.y}; }
+#else
+template <typename R> MDSP_HD cx<R> ld2(const cx<R>* p) { return *p; }
+template <typename R> MDSP_HD void st2(cx<R>* p, cx<R> v) { *p = v; }
+#endif
+
 // LDS index padding of the mixed-radix buffers: one element per 16 (first-pass scatters have stride = radix elements)
 MDSP_HD int gen_pad(int i) { return i + (i >> 4); }
 MDSP_HD constexpr int gen_lds_elems(int n) { return n + (n >> 4) + 1; }
@@ -496,21 +511,43 @@ MDSP_HD int gen_schedule(int n, int* radix, int* ns) {
 template <int RDX, typename R>
 MDSP_HD void gen_pass(const cx<R>* in, cx<R>* out, const cx<R>* roots, int N, int Ns, unsigned divm, int t, int T) {
     const int nbf = N / RDX, stride = N / (Ns * RDX);
-    for (int j = t; j < nbf; j += T) {
-        cx<R> v[RDX];
+    // U butterflies per trip (predicated): their LDS reads and twiddle fetches are all in flight before the first butterfly is evaluated
+    constexpr int U = RDX >= 16 ? 1 : 2;
+    for (int j0 = t; j0 < nbf; j0 += U * T) {
+        cx<R> v[U][RDX];
+        int hi[U], k[U];
 #pragma unroll
-        for (int q = 0; q < RDX; ++q) v[q] = in[gen_pad(j + nbf * q)];
-        const int hi = Ns == 1 ? j : (int)(((unsigned long long)(unsigned)j * divm) >> 24);
-        const int k = j - hi * Ns;
-        if (Ns > 1) {
-            const int idx = k * stride;   // q * idx < N for q < RDX: no reduction needed
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * T;
+            const bool on = j < nbf;
+            const int jj = on ? j : t;   // a valid index for the idle half: nothing is stored for it
 #pragma unroll
-            for (int q = 1; q < RDX; ++q) v[q] = cmul(v[q], roots[q * idx]);
+            for (int q = 0; q < RDX; ++q) v[u][q] = ld2(in + gen_pad(jj + nbf * q));
+            hi[u] = Ns == 1 ? jj : (int)(((unsigned long long)(unsigned)jj * divm) >> 24);
+            k[u] = jj - hi[u] * Ns;
         }
-        gen_bfly<RDX>(v);
-        const int base = hi * Ns * RDX + k;
+        if (Ns > 1) {
+            cx<R> w[U][RDX];
 #pragma unroll
-        for (int q = 0; q < RDX; ++q) out[gen_pad(base + Ns * q)] = v[q];
+            for (int u = 0; u < U; ++u) {
+                const int idx = k[u] * stride;   // q * idx < N for q < RDX: no reduction needed
+#pragma unroll
+                for (int q = 1; q < RDX; ++q) w[u][q] = ld2(roots + q * idx);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 1; q < RDX; ++q) v[u][q] = cmul(v[u][q], w[u][q]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            gen_bfly<RDX>(v[u]);
+            if (j0 + u * T < nbf) {
+                const int base = hi[u] * Ns * RDX + k[u];
+#pragma unroll
+                for (int q = 0; q < RDX; ++q) st2(out + gen_pad(base + Ns * q), v[u][q]);
+            }
+        }
     }
 }
 template <typename R> MDSP_HD void gen_pass_dispatch(int radix, const cx<R>* in, cx<R>* out, const cx<R>* roots, int N, int Ns, unsigned divm, int t, int T) {

@@ -629,12 +629,16 @@ bool fused_size_ok(int dtype, int64_t nfft) {
     }
 }
 
-int resolve_engine(int engine, int dtype, int64_t nfft, int* out) {
+// kind: 0 = Welch (sums of |X|^2), 1 = STFT / spectrogram / periodogram columns
+int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) {
     int eng = engine;
     if (eng == MDSP_ENGINE_AUTO) eng = tunables().engine;
     // fused: the register-resident power-of-two sizes, and the mixed-radix LDS kernel for the other 7-smooth sizes nextfastfft returns
     const bool fused_ok = fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft);
-    if (eng == MDSP_ENGINE_AUTO) eng = fused_ok ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
+    // AUTO takes the mixed-radix kernel where it measured faster than the rocFFT pipeline (profiles/r02g_mixed.json, 2^27 samples): Welch and
+    // real-signal columns up to 4096 points (1.4-3x), complex columns above (1.6x); elsewhere the two are within 20 % and rocFFT is kept.
+    const bool gen_wins = fused_size_ok(dtype, nfft) || (gen_size_ok(dtype, nfft) && ((nfft <= 4096) == (kind == 0 || !dtype_is_complex(dtype))));
+    if (eng == MDSP_ENGINE_AUTO) eng = gen_wins ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
     if (eng == MDSP_ENGINE_FUSED && !fused_ok)
         MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports nfft = 2^a 3^b 5^c 7^d up to %d; got %lld", dtype_is_double(dtype) ? 4096 : 8192, (long long)nfft);
     if (eng != MDSP_ENGINE_FUSED && eng != MDSP_ENGINE_ROCFFT) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid engine %d", engine);
@@ -1177,7 +1181,7 @@ int mdsp_welch_plan_create(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, i
     MDSP_TRY(check_split(n, noverlap, nfft));
     if (!(r > 0)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "normalisation r must be positive");
     int eng;
-    MDSP_TRY(resolve_engine(engine, dtype, nfft, &eng));
+    MDSP_TRY(resolve_engine(engine, dtype, nfft, &eng, 0));
     auto pl = new mdsp_welch_plan_s();
     pl->dtype = dtype;
     pl->engine = eng;

@@ -21,12 +21,13 @@ struct GenArgs {
     int64_t per_slot;      // consecutive units per transform slot (same trip count for every slot)
     int n, N, nout, onesided, psd, accumulate;
     int P, T;              // passes, threads per transform slot (256 / T slots per workgroup)
+    int roots_in_lds;      // the root table is staged into LDS behind the transform buffers
     int radix[MDSP_GEN_MAXP], ns[MDSP_GEN_MAXP];
     unsigned divm[MDSP_GEN_MAXP];
     double r;
 };
 
-constexpr int GEN_EMAX = 32;   // bins per thread in the Welch accumulator (N <= 8192 with T = 256)
+// bins per thread in the Welch accumulator: 16 up to N = 4096 with T = 256, 32 beyond (template parameter EMAX)
 
 // 7-smooth size the mixed-radix kernel takes: not one of the register-resident power-of-two sizes, two padded LDS buffers per slot
 inline bool gen_size_ok(int dtype, int64_t nfft) {
@@ -35,7 +36,7 @@ inline bool gen_size_ok(int dtype, int64_t nfft) {
     return fft::gen_schedule((int)nfft, radix, ns) > 0;
 }
 
-template <typename R, bool CPLX, int MODE>   // MODE 0: Welch sums, 1: STFT columns (raw or PSD)
+template <typename R, bool CPLX, int MODE, int GEN_EMAX>   // MODE 0: Welch sums, 1: STFT columns (raw or PSD)
 __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
@@ -45,6 +46,12 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
     cx<R>* bufA = reinterpret_cast<cx<R>*>(gen_smem) + (size_t)slot * 2 * region;
     cx<R>* bufB = bufA + region;
     const cx<R>* roots = static_cast<const cx<R>*>(a.roots);
+    if (a.roots_in_lds) {   // the root table (N entries) staged once per workgroup: twiddle fetches become LDS reads instead of scattered L1 / L2 hits
+        cx<R>* twl = reinterpret_cast<cx<R>*>(gen_smem) + (size_t)G * 2 * region;
+        for (int i = threadIdx.x; i < N; i += 256) fft::st2(twl + i, roots[i]);
+        roots = twl;
+        __syncthreads();
+    }
     const int64_t ch = blockIdx.y;
     const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
     const int64_t gslot = (int64_t)blockIdx.x * G + slot;
@@ -62,17 +69,28 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
         const bool haveB = !CPLX && live && (f0 + 1) < a.K;
         // K4 (periodograms.jl:57-69): frame * window in Float64, rounded once, zero tail; frames lie wholly inside the signal by construction
         const TT* fa = sc + f0 * a.hop;
-        for (int i = t; i < N; i += T) {
-            cx<R> z = {(R)0, (R)0};
-            if (live && i < a.n) {
-                const double w = a.win ? a.win[i] : 1.0;
-                if constexpr (CPLX) z = a.win ? win_mul(fa[i], w) : fa[i];
-                else {
-                    z.x = a.win ? win_mul(fa[i], w) : fa[i];
-                    if (haveB) z.y = a.win ? win_mul(fa[i + a.hop], w) : fa[i + a.hop];
+        constexpr int LU = 8;   // loads of LU elements per thread are in flight together
+        for (int i0 = t; i0 < N; i0 += LU * T) {
+            TT ra[LU], rb[CPLX ? 1 : LU];
+            std::conditional_t<sizeof(R) == 4, float, double> w[LU];   // Float32 signals: window rounded to Float32 first (as welch_half_kernel / stft_pair_kernel do)
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * T;
+                const bool on = live && i < a.n;
+                ra[u] = on ? fa[i] : TT{};
+                if constexpr (!CPLX) rb[u] = (on && haveB) ? fa[i + a.hop] : TT{};
+                w[u] = (on && a.win) ? (std::conditional_t<sizeof(R) == 4, float, double>)a.win[i] : 1;
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * T;
+                if (i < N) {
+                    cx<R> z;
+                    if constexpr (CPLX) z = {ra[u].x * w[u], ra[u].y * w[u]};
+                    else z = {ra[u] * w[u], rb[u] * w[u]};
+                    fft::st2(bufA + fft::gen_pad(i), z);
                 }
             }
-            bufA[fft::gen_pad(i)] = z;
         }
         __syncthreads();
         cx<R>*src = bufA, *dst = bufB;
@@ -88,7 +106,7 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
             for (int i = 0; i < GEN_EMAX; ++i) {
                 const int k = t + T * i;
                 if (k < N && live) {
-                    const cx<R> z = src[fft::gen_pad(k)];
+                    const cx<R> z = fft::ld2(src + fft::gen_pad(k));
                     acc[i] += (double)(z.x * z.x + z.y * z.y);
                 }
             }
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
             const int64_t o0 = ch * a.chs + f0 * a.ldo;
             for (int j = t; j < a.nout; j += T) {
                 if constexpr (CPLX) {   // two-sided only (a complex signal has no one-sided form, periodograms.jl:876)
-                    const cx<R> z = src[fft::gen_pad(j)];
+                    const cx<R> z = fft::ld2(src + fft::gen_pad(j));
                     if (a.psd) {
                         R* o = static_cast<R*>(a.out) + o0 + j;
                         const R pw = z.x * z.x + z.y * z.y;
@@ -106,7 +124,7 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
                 } else {
                     const bool mirror = j > N / 2;                              // real -> two-sided: X[N-k] = conj(X[k]) (fft2oneortwosided!, :234-244)
                     const int k = mirror ? N - j : j;
-                    const cx<R> zk = src[fft::gen_pad(k)], zm = src[fft::gen_pad(k == 0 ? 0 : N - k)];
+                    const cx<R> zk = fft::ld2(src + fft::gen_pad(k)), zm = fft::ld2(src + fft::gen_pad(k == 0 ? 0 : N - k));
                     cx<R> A = {(R)0.5 * (zk.x + zm.x), (R)0.5 * (zk.y - zm.y)};   // (Z[k] + conj Z[N-k]) / 2
                     cx<R> B = {(R)0.5 * (zk.y + zm.y), (R)0.5 * (zm.x - zk.x)};   // (Z[k] - conj Z[N-k]) / (2i)
                     if (a.psd) {
@@ -144,22 +162,32 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
 }
 
 // geometry + schedule shared by the two launchers; returns the slot count through *nslots
-template <typename R, bool CPLX, int MODE>
-int gen_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial) {
+template <typename R, bool CPLX, int MODE, int EMAX>
+int gen_launch_e(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial) {
     a.P = fft::gen_schedule(a.N, a.radix, a.ns);
     if (a.P <= 0) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%d has a prime factor other than 2, 3, 5, 7", a.N);
     for (int p = 0; p < a.P; ++p) a.divm[p] = (unsigned)(((1u << 24) + a.ns[p] - 1) / a.ns[p]);
     // threads per transform: enough that a thread owns at most GEN_EMAX bins and most lanes have a butterfly in the widest-radix pass
-    int T = 64;
-    while (T < 256 && (a.N > T * 16)) T *= 2;
+    // Passes are latency chains (LDS read -> twiddle -> butterfly -> LDS write): as many threads per transform as it has butterflies in its
+    // widest pass, so a thread walks one or two of them per pass
+    // Threads per transform: a thread walks two butterflies per trip (fft_lds.h gen_pass), so T ~ N / 8 keeps every lane busy in the radix-4 /
+    // radix-5 passes without a second trip; the Welch form also needs N / T <= EMAX bins per thread.
+    int T = a.N <= 512 ? 64 : (a.N <= 1024 ? 128 : 256);
+    while (T < 256 && a.N > T * EMAX) T *= 2;
     a.T = T;
     const int G = 256 / T;
-    const size_t lds_bytes = (size_t)G * 2 * (size_t)fft::gen_lds_elems(a.N) * sizeof(cx<R>);
-    auto kern = gen_spectral_kernel<R, CPLX, MODE>;
+    size_t lds_bytes = (size_t)G * 2 * (size_t)fft::gen_lds_elems(a.N) * sizeof(cx<R>);
+    a.roots_in_lds = lds_bytes + (size_t)a.N * sizeof(cx<R>) <= 80 * 1024 ? 1 : 0;   // keeps two workgroups per CU
+    if (a.roots_in_lds) lds_bytes += (size_t)a.N * sizeof(cx<R>);
+    auto kern = gen_spectral_kernel<R, CPLX, MODE, EMAX>;
     if (lds_bytes > 160 * 1024) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%d does not fit the LDS in this precision", a.N);
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    int per_cu = 0;
-    MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds_bytes));
+    // resident workgroups per CU from the kernel's own resources (the occupancy query answered HALF of what the hardware admits for these
+    // kernels: one workgroup per CU for the Welch form at 242 VGPRs, two for the STFT form at 119 -- profiles/r02h_gen_pmc.json)
+    hipFuncAttributes fa{};
+    MDSP_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
+    const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8);
+    int per_cu = std::min<int>({8, 512 / regs, (int)((size_t)160 * 1024 / std::max<size_t>(lds_bytes, 1))});
     if (per_cu < 1) per_cu = 1;
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
     const int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * per_cu / std::max<int64_t>(1, nch));
@@ -173,4 +201,9 @@ int gen_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf*
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs, (unsigned)nch), dim3(256), lds_bytes, st, a);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
+}
+template <typename R, bool CPLX, int MODE>
+int gen_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial) {
+    if (MODE == 0 && a.N > 4096) return gen_launch_e<R, CPLX, MODE, 32>(a, nch, st, nslots, partial);
+    return gen_launch_e<R, CPLX, MODE, 16>(a, nch, st, nslots, partial);
 }
