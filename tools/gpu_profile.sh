@@ -11,7 +11,7 @@ REPO="$(pwd)"
 OUT="$REPO/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-live-pmc --no-host"   # the step kernels AND the section-8 rows (stft, spectrogram, resample, firarb) in one process
 rm -rf "$OUT"/prof_stats "$OUT"/prof_FETCH_SIZE "$OUT"/prof_WRITE_SIZE "$OUT"/prof_sq
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof_stats" -o bench -- $BENCH --steps 10 --warmup 3 > "$OUT/prof_stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -22,3 +22,9 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 cd "$REPO"
 find "$OUT" -name "*.db" | sort
 grep -h '"metric"' "$OUT/prof_stats.log" | head -1 | cut -c1-400
+# condensed summaries (copy the ones to keep into profiles/)
+python tools/prof_summary.py "$(find "$OUT/prof_stats" -name '*.db' | head -1)" > "$OUT/kernel_stats.txt" 2>/dev/null
+python tools/prof_summary.py --pmc "$(find "$OUT/prof_sq" -name '*.db' | head -1)" > "$OUT/pmc_sq.json" 2>/dev/null
+python tools/prof_summary.py --traffic "$(find "$OUT/prof_FETCH_SIZE" -name '*.db' | head -1)" "$(find "$OUT/prof_WRITE_SIZE" -name '*.db' | head -1)" "$OUT/pmc_traffic.json" > /dev/null 2>&1
+python tools/pmc_brief.py "$OUT/pmc_sq.json" > "$OUT/pmc_brief.txt" 2>/dev/null
+head -30 "$OUT/kernel_stats.txt"; cat "$OUT/pmc_brief.txt"

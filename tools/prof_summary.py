@@ -64,7 +64,8 @@ def traffic(fetch_db, write_db, out_path):
     out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024",
            "workload": "bench.py default (2^30 Float32 samples per launch)"}
     for name, key in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("welch_fused_generic", "welch_fused_kernel"),
-                      ("copy", "mdsp_copy_kernel")):
+                      ("stft", "stft_fused_kernel<float, 1024, 16, 4, 1, 4, true, false"), ("spectrogram", "stft_fused_kernel<float, 1024, 16, 4, 1, 4, true, true"),
+                      ("resample", "polyphase_fast_kernel"), ("firarb", "arbitrary_fir_kernel"), ("copy", "mdsp_copy_kernel")):
         fv, fk = get(f, key, "FETCH_SIZE")
         wv, _ = get(w, key, "WRITE_SIZE")
         if fv is None or wv is None:
@@ -73,6 +74,11 @@ def traffic(fetch_db, write_db, out_path):
         out[f"{name}_fetch_bytes_corrected"] = int(2 * fv * 1024)
         out[f"{name}_write_bytes"] = int(wv * 1024)
         out[f"{name}_bytes_per_launch"] = int(2 * fv * 1024 + wv * 1024)
+    try:
+        import subprocess
+        out["commit"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        out["commit"] = None
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
