@@ -225,7 +225,7 @@ def live_traffic(args):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(tmp, ctr)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "bench", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2",
-               "--warmup", "1", "--no-cpu-baseline", "--no-rows", "--no-host", "--no-live-pmc", "--config", args.config, "--engine", args.engine]
+               "--warmup", "1", "--no-cpu-baseline", "--no-host", "--no-live-pmc", "--config", args.config, "--engine", args.engine] + (["--no-rows"] if args.no_rows else [])
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
@@ -243,8 +243,8 @@ def live_traffic(args):
         except Exception as e:
             return None, f"cannot read the {ctr} database: {e}"
     res = {}
-    for key, pat in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("stft", "stft_fused_kernel"), ("resample", "polyphase_fast_kernel"),
-                     ("copy", "mdsp_copy_kernel")):
+    for key, pat in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("stft", "true, false, 2, 1, true, 4>"),
+                     ("spectrogram", "true, true, 2, 1, true, 4>"), ("resample", "polyphase_fast_kernel"), ("firarb", "arbitrary_fir_kernel"), ("copy", "mdsp_copy_kernel")):
         f = next((v["counters"].get("FETCH_SIZE") for k, v in out["FETCH_SIZE"].items() if pat in k), None)
         w = next((v["counters"].get("WRITE_SIZE") for k, v in out["WRITE_SIZE"].items() if pat in k), None)
         if f is not None and w is not None:
@@ -557,6 +557,10 @@ def main():
             torch.cuda.empty_cache()
             try:
                 kernels.update(measure_rows(tm, lib, _lib, d, stream))
+                for key in ("stft", "spectrogram", "resample", "firarb"):
+                    if key in kernels and traffic:
+                        kernels[key]["traffic"] = traffic.get(f"{key}_bytes_per_launch")
+                        kernels[key]["traffic_source"] = traffic_source
             except Exception as e:  # pragma: no cover
                 kernels["rows_error"] = str(e)
         out["kernels"] = kernels
