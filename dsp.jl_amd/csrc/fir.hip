@@ -233,6 +233,16 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
                     }
                     acc[0] = a2.x;
                     acc[1] = a2.y;
+                } else if constexpr (P == 4) {   // four residues: two packed FMAs per tap, W / 4 LDS reads per output instead of W / 2
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+                    f2v a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        const float xv = zp[j];
+                        a01 = __builtin_elementwise_fma(f2v{xv, xv}, f2v{h[0][j], h[1][j]}, a01);
+                        a23 = __builtin_elementwise_fma(f2v{xv, xv}, f2v{h[2][j], h[3][j]}, a23);
+                    }
+                    acc[0] = a01.x; acc[1] = a01.y; acc[2] = a23.x; acc[3] = a23.y;
                 } else {
 #pragma unroll
                     for (int k = 0; k < P; ++k) acc[k] = 0.0f;
@@ -745,7 +755,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
     auto kern = polyphase_fast_kernel<TPC, P>;
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const int64_t ntiles = cdiv(b.nrounds, (int64_t)Q);
-    int wgs = 5;   // resident workgroups per CU (94 VGPRs x 4 waves, ~20 KiB LDS); 8 / 5 / 4 measured 2.64 / 2.59 / 2.67 ms on config 5
+    int wgs = P >= 4 ? 2 : 5;   // resident workgroups per CU (P = 2: 94 VGPRs x 4 waves, ~20 KiB LDS; 8 / 5 / 4 measured 2.64 / 2.59 / 2.67 ms on config 5; P = 4: 228 VGPRs)
     if (tunables().wg_per_cu > 0) wgs = tunables().wg_per_cu;
     const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)f->nch);
@@ -777,6 +787,7 @@ template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStrea
 }
 
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
+    if (tunables().fir_p == 4 && f->tp <= 32 && fir_fast_ok(f, 4)) return fir_fast_dispatch<4>(f, a, st);   // tuning: four residues per thread
     if (fir_fast_ok(f, 2)) return fir_fast_dispatch<2>(f, a, st);
     if (fir_fast_ok(f, 1)) return fir_fast_dispatch<1>(f, a, st);
     const bool d = f->acc_double;
