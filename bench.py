@@ -551,6 +551,9 @@ def main():
             kernels["copy_float4_GBps"] = round(2 * nb / med / 1e6, 1)
             med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 4, 8, stream)), reps=3)
             kernels["read_float4_GBps"] = round(nb / med / 1e6, 1)
+            # the best 1:1 copy this box does (MI355X_MICROARCH.md quotes 6.29 TB/s): nontemporal float4, four workgroups per CU
+            med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 2, 4, stream)), reps=3)
+            kernels["copy_float4_nontemporal_4wg_GBps"] = round(2 * nb / med / 1e6, 1)
         out["roofline"] = main_roof
         if world == 1 and not args.no_rows and args.config == "filtwelch":
             del x, y
