@@ -382,16 +382,29 @@ def main():
     # the library's RCCL communicator (C ABI); torch.distributed is the fallback transport
     comm, collective = None, "none (1 GPU)"
     if world > 1:
+        # 1. a LOCAL probe on every rank (binds librccl, ncclGetUniqueId needs no communicator), 2. agree, 3. only then the collective init:
+        #    a rank that cannot load RCCL must not leave the others waiting inside ncclCommInitRank
         try:
-            comm = d.Comm.from_torch_distributed()
-            collective = "mdsp_comm (RCCL ncclAllReduce behind the C ABI)"
-        except Exception as e:  # pragma: no cover - needs > 1 GPU
-            comm, collective = None, f"torch.distributed nccl (mdsp_comm init failed: {e})"
-        flags = torch.tensor([1.0 if comm is not None else 0.0], device=dev)
-        dist.all_reduce(flags, op=dist.ReduceOp.MIN)          # all ranks must agree on the transport
-        if float(flags.item()) < 1.0 and comm is not None:
-            comm.close(); comm = None
-            collective = "torch.distributed nccl (mdsp_comm unavailable on some rank)"
+            my_id, err = d.Comm.unique_id(), ""
+        except Exception as e:  # pragma: no cover - needs a broken RCCL
+            my_id, err = None, str(e)
+        flags = torch.tensor([1.0 if my_id is not None else 0.0], device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        if float(flags.item()) >= 1.0:
+            box = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            try:
+                comm = d.Comm(box[0], rank, world)
+                collective = "mdsp_comm (RCCL ncclAllReduce behind the C ABI)"
+            except Exception as e:  # pragma: no cover - needs > 1 GPU
+                comm, collective = None, f"torch.distributed nccl (mdsp_comm init failed: {e})"
+            flags = torch.tensor([1.0 if comm is not None else 0.0], device=dev)
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)          # all ranks must agree on the transport
+            if float(flags.item()) < 1.0 and comm is not None:
+                comm.close(); comm = None
+                collective = "torch.distributed nccl (mdsp_comm unavailable on some rank)"
+        else:
+            collective = f"torch.distributed nccl (RCCL probe failed on some rank{': ' + err if err else ''})"
 
     g = torch.Generator(device=dev)
     g.manual_seed(1776 + rank)                          # seed 1776 = test/runtests.jl:20; independent data per GPU
