@@ -94,6 +94,16 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // device properties (cached per device)
 int device_cu_count();
 
+// Transform slots per workgroup.  A transform of T > 64 threads synchronises its waves with s_barrier, and s_barrier spans the WORKGROUP:
+// two 128-thread transforms in one 256-thread workgroup wait for each other at every exchange although they share nothing.  One transform
+// per workgroup whenever barriers are real (T >= 128); several one-wave transforms (wave-level fences only) still share a workgroup.
+// Measured on the headline overlap-save shape, 12 interleaved rounds on two boxes (profiles/r02l_ols_decoupled.json): 1.85 / 1.78 ms
+// against 2.04 / 1.96 for the same kernel with two transforms per workgroup.  -DMDSP_COUPLED_SLOTS=1 restores the round-1 grouping.
+#ifndef MDSP_COUPLED_SLOTS
+#define MDSP_COUPLED_SLOTS 0
+#endif
+constexpr int slots_per_workgroup(int T) { return MDSP_COUPLED_SLOTS ? (T >= 256 ? 1 : 256 / T) : (T >= 128 ? 1 : 256 / T); }
+
 // ---------------------------------------------------------------- tunables
 // Optional tuning variables (DESIGN.md section 5 "Tuning knobs") are read from the environment ONCE -- by mdsp_init(), or on
 // first use -- into this struct; exec / plan paths only ever look at the struct.  mdsp_reload_tunables() re-reads them

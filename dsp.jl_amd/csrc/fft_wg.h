@@ -12,6 +12,10 @@
 
 #include "fft_lds.h"
 
+#ifndef MDSP_FFT_SETPRIO
+#define MDSP_FFT_SETPRIO 0   // 1: raise the wave priority across every inter-pass exchange (tools: build.py --tag prio --cflags -DMDSP_FFT_SETPRIO=1)
+#endif
+
 namespace mdsp {
 namespace fft {
 
@@ -34,10 +38,16 @@ __device__ __forceinline__ void wg_fft(cx<R> (&v)[C::E], int t, const cx<R> (&tw
         // transforms (buffer 0 is rewritten by the next transform's first pass).
         constexpr bool PRIVATE = PERMUTE == 2 && PASS == C::P - 2;
         static_assert(PERMUTE != 2 || (NBUF == 2 && lds_elems<C::N, PADSHIFT>() >= 4 * 4 * 272), "wave-private exchange uses the second LDS buffer (pad shift 4)");
+#if MDSP_FFT_SETPRIO
+        __builtin_amdgcn_s_setprio(1);   // experiment: the exchange (latency chain: barrier, LDS reads) outranks the partner wave's butterflies
+#endif
         if constexpr (PRIVATE) wg_sync<64>();
         else wg_sync<C::T>();
         pass_reload<C, PADSHIFT, PASS + 1, PERMUTE>(v, t, region);
         if constexpr (NBUF == 1) wg_sync<C::T>();
+#if MDSP_FFT_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         wg_fft<C, DIR, TWMODE, PADSHIFT, NBUF, XBASE, PASS + 1, PERMUTE>(v, t, tw, table, lds);
     }
 }

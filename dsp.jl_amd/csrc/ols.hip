@@ -464,7 +464,7 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
     constexpr int EMAX = (!DBL && N >= 1024) ? 16 : 8;
     constexpr int E = (N / 64 < EMAX) ? N / 64 : EMAX;
     constexpr int T = N / E;
-    constexpr int G = T >= 256 ? 1 : 256 / T;
+    constexpr int G = slots_per_workgroup(T);
     constexpr int NBUF = (T <= 64 || E == 16) ? 1 : 2;
 #ifndef MDSP_TW_F64
 #define MDSP_TW_F64 1
@@ -500,12 +500,19 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
             case 26: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, false, true, false>(a, s);  // hybrid, spectrum in registers, no prefetch
             case 27: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 3, 1, false, false, false>(a, s); // register twiddles, L2 spectrum, no prefetch
             case 28: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, false, true, false>(a, s);  // default geometry minus the prefetch
-            // DEFAULT (= 26): hybrid twiddles (pass-1 table in LDS, 30 VGPRs less), filter spectrum in registers, no software prefetch:
-            // 165 VGPRs -> three workgroups per CU.  12-round interleaved A/B on two boxes (profiles/r02e_ols_ab.json): 1.98 ms vs 2.03
-            // (28: registers only, no prefetch) vs 2.17 (12: the round-1 default with prefetch).  Variant 2 is the best E = 8 form; the
+            case 29: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 3, 1, false, true, false>(a, s);  // the default with ONE transform per (128-thread)
+            // workgroup: the two transforms of a 256-thread workgroup share every s_barrier although they exchange nothing
+            case 30: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, false, true, false>(a, s);  // 28 with one transform per workgroup
+            case 31: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 4, 1, false, false, false>(a, s); // 23 (<= 128 VGPRs, spectrum from L2) with one transform per workgroup
+            case 32: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 3, 1, false, false, false>(a, s); // 19 with one transform per workgroup
+            case 33: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, true, false>(a, s);   // 12 (prefetch) with one transform per workgroup
+            // DEFAULT (= 30): register twiddles, filter spectrum in registers, no software prefetch, ONE transform per 128-thread workgroup
+            // (191 VGPRs, four workgroups of two waves per CU).  12-round interleaved A/B on two boxes (profiles/r02l_ols_decoupled.json,
+            // r02e_ols_ab.json): 1.85 / 1.78 ms vs 1.93 / 1.86 (29: hybrid twiddles, 3 waves per SIMD) vs 2.05 / 1.97 (26: the same kernel
+            // with two transforms per workgroup) vs 2.17 (12: the round-1 default, prefetch).  Variant 2 is the best E = 8 form; the
             // lane-permuted schedule (10) has fewer LDS conflicts still, but its permuted global accesses cost more than the LDS cycles it
             // saves (3.8 vs 4.2 TB/s, profiles/r01e_tune_lanes.json).
-            default: return launch_fused_variant<R, N, 16, 2, 3, 4, CPLX, 3, 1, false, true, false>(a, s);
+            default: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, false, true, false>(a, s);
         }
     }
     // Software prefetch of the next unit's samples: OFF by default.  Measured on MI355X (profiles/r02c_tune.json, 2^30 Float32, nfft 2048):

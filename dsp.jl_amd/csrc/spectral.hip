@@ -675,7 +675,7 @@ template <typename R, int N> struct Geo {
     static constexpr int EMAX = (N == 1024 && !DBL) ? MDSP_GEO_E1024 : 8;
     static constexpr int E = (N / 64 < EMAX) ? N / 64 : EMAX;
     static constexpr int T = N / E;
-    static constexpr int G = T >= 256 ? 1 : 256 / T;
+    static constexpr int G = slots_per_workgroup(T);
     static constexpr int NBUF = T <= 64 ? 1 : 2;
 #ifndef MDSP_TW_F64
 #define MDSP_TW_F64 1
@@ -1030,7 +1030,7 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
     if constexpr (!CPLX && N >= 256) {
         if (half_ok && !(N == 4096 && sizeof(R) == 4 && pl->variant >= 1 && pl->variant <= 9)) {
             constexpr int EH = (N >= 2048 && sizeof(R) == 4) ? 16 : Gm::E;   // Float32, nfft >= 1024: 16 elements per thread (Geo does 1024)
-            constexpr int GH = (N / EH) >= 256 ? 1 : 256 / (N / EH);
+            constexpr int GH = slots_per_workgroup(N / EH);
             constexpr int NB = (N / EH) <= 64 ? 1 : 2;
             constexpr int NBH = (EH == 16) ? 1 : NB;
             bool done = false;
