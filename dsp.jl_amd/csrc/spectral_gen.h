@@ -41,14 +41,21 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
     const int T = a.T, N = a.N;
-    const int slot = threadIdx.x / T, t = threadIdx.x - slot * T, G = 256 / T;
+    const int slot = threadIdx.x / T, t = threadIdx.x - slot * T, G = blockDim.x / T;
+    // A transform's waves synchronise with s_barrier, which spans the workgroup: one transform per workgroup when T >= 128 (the launcher's
+    // choice), and one-wave transforms (T == 64: several per workgroup) need only a scheduling fence -- a wave's DS operations execute in order.
+    const bool one_wave = T <= 64;
+    auto sync = [&]() {
+        if (one_wave) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+    };
     const int region = fft::gen_lds_elems(N);
     cx<R>* bufA = reinterpret_cast<cx<R>*>(gen_smem) + (size_t)slot * 2 * region;
     cx<R>* bufB = bufA + region;
     const cx<R>* roots = static_cast<const cx<R>*>(a.roots);
     if (a.roots_in_lds) {   // the root table (N entries) staged once per workgroup: twiddle fetches become LDS reads instead of scattered L1 / L2 hits
         cx<R>* twl = reinterpret_cast<cx<R>*>(gen_smem) + (size_t)G * 2 * region;
-        for (int i = threadIdx.x; i < N; i += 256) fft::st2(twl + i, roots[i]);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) fft::st2(twl + i, roots[i]);
         roots = twl;
         __syncthreads();
     }
@@ -92,11 +99,11 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
                 }
             }
         }
-        __syncthreads();
+        sync();
         cx<R>*src = bufA, *dst = bufB;
         for (int p = 0; p < a.P; ++p) {
             fft::gen_pass_dispatch(a.radix[p], src, dst, roots, N, a.ns[p], a.divm[p], t, T);
-            __syncthreads();
+            sync();
             cx<R>* tmp = src;
             src = dst;
             dst = tmp;
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
                 }
             }
         }
-        __syncthreads();   // the spectrum buffer may be the one the next frame is windowed into
+        sync();   // the spectrum buffer may be the one the next frame is windowed into
     }
     if constexpr (MODE == 0) {
         double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)N;
@@ -175,7 +182,8 @@ int gen_launch_e(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBu
     int T = a.N <= 512 ? 64 : (a.N <= 1024 ? 128 : 256);
     while (T < 256 && a.N > T * EMAX) T *= 2;
     a.T = T;
-    const int G = 256 / T;
+    const int G = T <= 64 ? 4 : 1;   // several one-wave transforms per workgroup; otherwise one transform per workgroup (no barrier coupling)
+    const int threads = T * G;
     size_t lds_bytes = (size_t)G * 2 * (size_t)fft::gen_lds_elems(a.N) * sizeof(cx<R>);
     a.roots_in_lds = lds_bytes + (size_t)a.N * sizeof(cx<R>) <= 80 * 1024 ? 1 : 0;   // keeps two workgroups per CU
     if (a.roots_in_lds) lds_bytes += (size_t)a.N * sizeof(cx<R>);
@@ -187,7 +195,7 @@ int gen_launch_e(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBu
     hipFuncAttributes fa{};
     MDSP_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
     const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8);
-    int per_cu = std::min<int>({8, 512 / regs, (int)((size_t)160 * 1024 / std::max<size_t>(lds_bytes, 1))});
+    int per_cu = std::min<int>({32 / (threads / 64), (512 / regs) * 4 / (threads / 64), (int)((size_t)160 * 1024 / std::max<size_t>(lds_bytes, 1))});
     if (per_cu < 1) per_cu = 1;
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
     const int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * per_cu / std::max<int64_t>(1, nch));
@@ -198,7 +206,7 @@ int gen_launch_e(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBu
         MDSP_TRY(partial->reserve(sizeof(double) * (size_t)(*nslots) * (size_t)nch * (size_t)a.N));
         a.out = partial->p;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, (unsigned)nch), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, (unsigned)nch), dim3(threads), lds_bytes, st, a);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
