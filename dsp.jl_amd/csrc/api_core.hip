@@ -152,7 +152,10 @@ int mdsp_init(int device) {
     return MDSP_OK;
 }
 
-int mdsp_shutdown(void) { return MDSP_OK; }
+int mdsp_shutdown(void) {
+    (void)mdsp_plan_cache_clear();   // borrowed plans die here: a host calls this once, after its last use of the library
+    return MDSP_OK;
+}
 
 int mdsp_reload_tunables(void) {
     reload_tunables();

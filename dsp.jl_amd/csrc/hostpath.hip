@@ -109,12 +109,12 @@ struct Pipe {
 // one pipeline per device, created on first use (host entry points are synchronous; concurrent callers serialise here)
 Pipe* pipe_for_device() {
     static std::mutex mu;
-    static std::unique_ptr<Pipe> pipes[64];
+    static Pipe* pipes[64] = {nullptr};   // never destroyed: streams / pinned buffers must not be released from a static destructor, after the HIP runtime
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     std::lock_guard<std::mutex> lk(mu);
-    if (!pipes[dev]) pipes[dev] = std::make_unique<Pipe>();
-    return pipes[dev].get();
+    if (!pipes[dev]) pipes[dev] = new Pipe();
+    return pipes[dev];
 }
 
 }  // namespace

@@ -382,3 +382,33 @@ def test_mixed_radix_sizes_run_fused(d, torch, dt, tol, nfft):
     roc = d.stft(xd[:L], n, nov, nfft=nfft, window=d.hanning, engine=d.ENGINE_ROCFFT)
     fus = d.stft(xd[:L], n, nov, nfft=nfft, window=d.hanning, engine=d.ENGINE_FUSED)
     assert float((roc - fus).abs().max() / fus.abs().max()) < 20 * tol
+
+
+def test_host_pipelines_with_padded_leading_dimensions(d, torch):
+    """Columns of a larger host matrix (ld > column length) through the host-pointer entry points: only the columns' own samples travel."""
+    from dsp_jl_amd import _lib
+    from dsp_jl_amd.dspbase import OlsPlan
+    from oracle import dspbase as odsp, periodograms as opg, windows as ow
+    lib = _lib.lib()
+    rng = np.random.default_rng(21)
+    nx, ld, ncols = 300_001, 300_100, 3
+    X = rng.standard_normal((ncols, ld)).astype(np.float32)            # rows = Julia columns, ld = 300100
+    b = _taps(200, np.float32)
+    plan = OlsPlan(b, 1024, nx, _lib.OLS_FILT, d.ENGINE_AUTO)
+    Y = np.full((ncols, ld), 7.0, np.float32)
+    _lib.set_tunable("MDSP_HOST_CHUNK_MIB", 1)
+    try:
+        _lib.check(lib.mdsp_ols_exec_host(plan._h, X.ctypes.data_as(C.c_void_p), nx, ncols, ld, Y.ctypes.data_as(C.c_void_p), nx, ld, 0))
+        cfg = d.WelchConfig(nx, np.float32, n=1024, noverlap=512, window=d.hanning)
+        P = np.full((ncols, cfg.nout + 5), -1.0, np.float32)
+        _lib.check(lib.mdsp_welch_exec_host(cfg._h, X.ctypes.data_as(C.c_void_p), nx, ncols, ld, P.ctypes.data_as(C.c_void_p), cfg.nout + 5, 0))
+    finally:
+        _lib.set_tunable("MDSP_HOST_CHUNK_MIB", None)
+    assert np.all(Y[:, nx:] == 7.0) and np.all(P[:, cfg.nout:] == -1.0)          # nothing outside the columns is touched
+    for c in range(ncols):
+        assert relerr(Y[c, :nx], odsp.filt_ba(b.astype(np.float64), 1.0, X[c, :nx].astype(np.float64))) < TOL32
+        assert relerr(P[c, :cfg.nout], opg.welch_pgram(X[c, :nx], 1024, 512, window=ow.hanning, dtype=np.float64).power) < TOL32
+    with pytest.raises(d.ArgumentError):
+        _lib.check(lib.mdsp_ols_exec_host(plan._h, X.ctypes.data_as(C.c_void_p), nx, ncols, nx - 1, Y.ctypes.data_as(C.c_void_p), nx, ld, 0))
+    with pytest.raises(d.DimensionMismatch):
+        _lib.check(lib.mdsp_welch_exec_host(cfg._h, X.ctypes.data_as(C.c_void_p), nx, ncols, nx - 1, P.ctypes.data_as(C.c_void_p), cfg.nout, 0))
