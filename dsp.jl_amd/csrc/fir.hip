@@ -755,7 +755,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
     auto kern = polyphase_fast_kernel<TPC, P>;
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const int64_t ntiles = cdiv(b.nrounds, (int64_t)Q);
-    int wgs = P >= 4 ? 2 : 5;   // resident workgroups per CU (P = 2: 94 VGPRs x 4 waves, ~20 KiB LDS; 8 / 5 / 4 measured 2.64 / 2.59 / 2.67 ms on config 5; P = 4: 228 VGPRs)
+    int wgs = P >= 4 ? 2 : (P == 3 ? 3 : 5);   // resident workgroups per CU (P = 2: 94 VGPRs x 4 waves, ~20 KiB LDS; 8 / 5 / 4 measured 2.64 / 2.59 / 2.67 ms on config 5; P = 4: 228 VGPRs)
     if (tunables().wg_per_cu > 0) wgs = tunables().wg_per_cu;
     const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)f->nch);
@@ -788,6 +788,7 @@ template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStrea
 
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
     if (tunables().fir_p == 4 && f->tp <= 32 && fir_fast_ok(f, 4)) return fir_fast_dispatch<4>(f, a, st);   // tuning: four residues per thread
+    if (tunables().fir_p == 3 && f->tp <= 32 && fir_fast_ok(f, 3)) return fir_fast_dispatch<3>(f, a, st);   // tuning: three residues per thread
     if (fir_fast_ok(f, 2)) return fir_fast_dispatch<2>(f, a, st);
     if (fir_fast_ok(f, 1)) return fir_fast_dispatch<1>(f, a, st);
     const bool d = f->acc_double;
