@@ -175,7 +175,54 @@ __device__ __forceinline__ void ols_store(const cx<R> (&v)[E], const OlsFusedArg
     }
 }
 
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, int PERM = false>
+// Staged store of a unit of REAL Float32 blocks ("a store path decoupled from ..."): after the inverse transform a thread holds
+// outputs i = t + T e -- one 4-byte store per lane, 256 contiguous bytes per wave instruction, at an odd element offset (L = nfft - nb + 1).
+// With the transform removed those stores alone take 1.89 ms per 2^30 samples (2.3 TB/s) against 0.82 ms for the loads and 5.2 TB/s for a float4
+// write stream (profiles/r02o_ablation.json): the store PATTERN, not HBM, bounded the kernel.  Here the unit's 2 L valid outputs -- which are
+// CONTIGUOUS in y: block a then block b -- go through the (now idle) exchange buffer: ds_write_b32 in thread order, one barrier, ds_read_b128,
+// and every lane stores 16 bytes: 1 KiB contiguous per wave instruction.  Only units that lie wholly inside the output take this path.
+template <typename R, int E, int T, int N>
+__device__ __forceinline__ void ols_store_staged(const cx<R> (&v)[E], const OlsFusedArgs& a, OlsPos q, int t, float* S) {
+    static_assert(sizeof(R) == 4, "staged stores are wired for Float32");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lead = a.nb - 1, L = (int)a.L, twoL = 2 * L;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int j = t + T * e - lead;
+        if (j >= 0) {
+            S[j] = v[e].x;
+            S[L + j] = v[e].y;
+        }
+    }
+    fft::wg_sync<T>();
+    constexpr int NV = (2 * N + 4 * T - 1) / (4 * T);   // float4 vectors per thread (2 L <= 2 N floats)
+    f4 r[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int idx = 4 * (t + T * c);
+        r[c] = idx + 4 <= ((twoL + 3) & ~3) ? *reinterpret_cast<const f4*>(S + idx) : f4{0.f, 0.f, 0.f, 0.f};   // S is 16-byte aligned, idx a multiple of 4
+    }
+    fft::wg_sync<T>();   // the buffer is the next unit's first exchange
+    const int64_t off0 = 2 * q.p * a.L;
+    float* yc = static_cast<float*>(a.y) + q.col * a.ldy + off0;
+    const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc, (int64_t)twoL * 4);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int idx = 4 * (t + T * c);
+        if (idx + 4 <= twoL) {
+            u4 d;
+            d.x = __float_as_uint(r[c].x); d.y = __float_as_uint(r[c].y); d.z = __float_as_uint(r[c].z); d.w = __float_as_uint(r[c].w);
+            __builtin_amdgcn_raw_buffer_store_b128(d, w, idx * 4, 0, MDSP_IO_AUX_STORE);
+        } else if (idx < twoL) {   // the one vector that straddles the end of the unit (2 L is not a multiple of 4)
+            io::Ld<float>::store(r[c].x, w, idx * 4);
+            if (idx + 1 < twoL) io::Ld<float>::store(r[c].y, w, idx * 4 + 4);
+            if (idx + 2 < twoL) io::Ld<float>::store(r[c].z, w, idx * 4 + 8);
+        }
+    }
+}
+
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, int PERM = false, bool STAGE = false>
 __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedArgs a) {
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T;
@@ -233,7 +280,14 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
         }
         // no barrier needed here: with one buffer wg_fft ends every exchange with a barrier, with two the 2(P-1)
         // exchanges of a unit alternate buffers so the next unit's first write is two barriers behind its readers
-        if (!MDSP_ABLATED(a, 4)) ols_store<R, E, T, CPLX>(v, a, cur, ti);
+        if (!MDSP_ABLATED(a, 4)) {
+            if constexpr (STAGE && !CPLX && sizeof(R) == 4 && (G == 1 || T == 64) && NBUF == 1 && !PERM) {
+                // wave-uniform (workgroup-uniform: one transform per workgroup, or one-wave transforms): both blocks exist and lie inside y
+                const bool whole = cur.live && (2 * cur.p + 1) < a.nblocks && (2 * cur.p + 2) * a.L <= a.nout;
+                if (whole) ols_store_staged<R, E, T, N>(v, a, cur, ti, reinterpret_cast<float*>(lds));
+                else ols_store<R, E, T, CPLX>(v, a, cur, ti);
+            } else ols_store<R, E, T, CPLX>(v, a, cur, ti);
+        }
         cur = nxt;
     }
 }
@@ -432,9 +486,9 @@ template <typename R> int upload_table(DevBuf& buf, int64_t n) {
 
 // ---- fused launch ---------------------------------------------------------------------------------------
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true, bool HREG = true,
-          int PERM = false>
+          int PERM = false, bool STAGE = false>
 int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
-    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG, PERM>;
+    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG, PERM, STAGE>;
     constexpr int threads = (N / E) * G;
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
@@ -506,6 +560,8 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
             case 31: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 4, 1, false, false, false>(a, s); // 23 (<= 128 VGPRs, spectrum from L2) with one transform per workgroup
             case 32: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 3, 1, false, false, false>(a, s); // 19 with one transform per workgroup
             case 33: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, true, false>(a, s);   // 12 (prefetch) with one transform per workgroup
+            case 34: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, false, true, false, true>(a, s);   // 30 + outputs staged through LDS, 16-byte stores
+            case 35: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 3, 1, false, true, false, true>(a, s);   // 29 + staged stores
             // DEFAULT (= 30): register twiddles, filter spectrum in registers, no software prefetch, ONE transform per 128-thread workgroup
             // (191 VGPRs, four workgroups of two waves per CU).  12-round interleaved A/B on two boxes (profiles/r02l_ols_decoupled.json,
             // r02e_ols_ab.json): 1.85 / 1.78 ms vs 1.93 / 1.86 (29: hybrid twiddles, 3 waves per SIMD) vs 2.05 / 1.97 (26: the same kernel
