@@ -60,6 +60,7 @@ static void read_tunables_locked() {
     t.host_chunk_mib = std::max(1, geti("MDSP_HOST_CHUNK_MIB", 64));
     t.ols_prefetch = geti("MDSP_OLS_PREFETCH", 0);
     t.fir_p = geti("MDSP_FIR_P", 0);
+    t.fir_mm = geti("MDSP_FIR_MM", -1);
 #ifdef MDSP_DEBUG_KNOBS
     t.ablate = geti("MDSP_ABLATE", 0);
     t.welch_nohalf = getenv("MDSP_WELCH_NOHALF") != nullptr;

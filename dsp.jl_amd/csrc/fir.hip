@@ -262,6 +262,215 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Matrix-core path (Float32 taps and real Float32 signal, L >= 16): the polyphase bank as the B operand of v_mfma_f32_16x16x4_f32.
+//
+// The register-tap kernel above is bound by the LDS and the vector ALU: P = 2 residues share one window (16.5 ds_read_b32 and
+// 16.5 v_pk_fma_f32 per output; 68 % LDS-array busy, and v_pk_fma_f32 issues at the v_fma_f32 rate, 16 FMA/clk/SIMD), more residues
+// per thread cost VGPRs and occupancy (P = 4: 228 VGPRs, slower) -- 2.5 ms on BASELINE config 5 against an HBM floor of 1.9.
+// Outputs of the same residue s in different rounds q share their taps, and neighbouring residues read windows that start delta_j =
+// c_{s0+j} - c_{s0} <= j samples apart: for 16 rounds x 16 residues,
+//      Y[q][j] = sum_k  X[q][k] * H[k][j],    X[q][k] = z[q M + c_{s0} + k],    H[k][j] = pfb[phase_j][k - delta_j]  (0 outside the bank)
+// is a (16 x K)(K x 16) product with K = tp + delta_15 -- what the f32 matrix instruction computes, four k per issue, at 4x the
+// vector FMA rate and with the VALU left free.  Its arithmetic is bit for bit a k-ordered fmaf chain (one rounding per product,
+// no wider accumulator; /opt/skills/guides/cdna_hip_programming.md section 3), i.e. exactly the oldest-sample-first chain of the
+// register-tap kernel: the zero taps add exact zeros and the two kernels agree bit for bit (tests/test_gpu_boundary.py).
+// This is not a GEMM reshaping of the problem: no operand is materialised or reordered in memory, X is the staged signal tile
+// itself (lane l reads z[(q0 + l%16) M + c + 4 t + l/16], one ds_read_b32 per MFMA), H lives in T VGPRs per wave for the whole
+// kernel (lane l: tap k = 4 t + l/16 of residue j = l%16), and the roofline that bounds the kernel stays HBM.
+//   wave  = one block of 16 residues, all 64 rounds of the tile as four independent accumulators
+//   tile  = 64 rounds = 64 M input samples staged in LDS; the 64 L outputs go back through the same LDS (row pitch 16 NB + 4) and
+//           leave as one contiguous run of 16-byte stores
+// ------------------------------------------------------------------------------------------------------------
+struct FirMArgs {
+    const float* x;
+    const float* hist;
+    float* y;
+    const float* pfbT;           // tp * L
+    int64_t xlen, ldx, ldy, nout, nrounds;
+    int64_t d0;
+    int L, M, hl, tp;
+    int NB;                      // blocks of 16 residues
+    int Lp;                      // row pitch of the output tile in LDS (floats): 16 NB + 4
+    int bufsz;                   // floats per LDS tile buffer (three of them)
+    int nd, ns;                  // waves that issue the LDS-DMA / that store, after the NB multiplying waves
+    unsigned lmagic;             // ceil(2^32 / L): quotient by L of anything below 2^32 / L by multiply-high
+    int phi0m1;                  // phi0 - 1: residue s has phase (phi0-1 + s M) mod L and window start (phi0-1 + s M) div L
+};
+
+typedef int mm_i4 __attribute__((ext_vector_type(4)));
+// 64 consecutive dwords of a raw buffer straight into LDS (no VGPRs, no ds_write pass): lane l moves the dword at byte offset voff
+// to lds_byte + 4 l.  Issued by hand: the compiler's wait-count bookkeeping makes every later ds_read wait for a DMA it knows of
+// (it cannot tell the two tile buffers apart), which would serialise the next tile's loads with this tile's products.  M0 carries
+// the LDS address and is the compiler's to use, so it is saved and restored inside the statement.
+__device__ __forceinline__ void mm_dma64(mm_i4 rsrc, unsigned lds_byte, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
+}
+// 256 consecutive dwords, 16 bytes per lane (lane l: byte offset voff -> lds_byte + 16 l).  A 16-byte access that crosses the end of
+// the buffer is dropped whole, so the caller uses this form only for granules that lie inside the signal.
+__device__ __forceinline__ void mm_dma256(mm_i4 rsrc, unsigned lds_byte, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ mm_i4 mm_rsrc(const void* base, long long bytes) {   // raw buffer: zero fill past `bytes`
+    const unsigned long long p = (unsigned long long)base;
+    const long long nb = bytes < 0 ? 0 : (bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes);
+    return mm_i4{(int)__builtin_amdgcn_readfirstlane((unsigned)p), (int)(__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xffffu),
+                 (int)__builtin_amdgcn_readfirstlane((unsigned)nb), 0x00020000};
+}
+typedef float mm_f4 __attribute__((ext_vector_type(4)));
+
+template <int T>   // k-steps of four taps
+__global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
+    constexpr int Q = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* zs = reinterpret_cast<float*>(smem);   // three tile buffers
+    const int64_t ch = blockIdx.y;
+    const float* xc = a.x + ch * a.ldx;
+    const float* hc = a.hist + ch * (int64_t)a.hl;
+    float* yc = a.y + ch * a.ldy;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int lj = lane & 15, lk = lane >> 4;
+    // Wave roles: waves 0 .. NB-1 multiply (one block of 16 residues each), the next nd waves issue the LDS-DMA of the samples, the
+    // last ns waves store the outputs.  The memory waves work through the whole tile period beside the MFMAs -- a wave that first
+    // moved data and then multiplied would hold up its SIMD's matrix pipe (measured: 2 000 - 6 000 clocks of DMA issue / store
+    // issue per tile, against 4 600 of MFMA) -- and no wave waits on a vmcnt that mixes loads with younger stores.
+    const bool is_comp = wave < a.NB, is_dma = wave >= a.NB && wave < a.NB + a.nd, is_store = wave >= a.NB + a.nd;
+    // H: this wave's taps, for the whole kernel
+    float hreg[T];
+    int c0 = 0;
+    if (is_comp) {
+        const int s0 = 16 * wave, sj = s0 + lj;
+        const unsigned p0 = (unsigned)(a.phi0m1 + s0 * a.M), pj = (unsigned)(a.phi0m1 + sj * a.M);
+        c0 = (int)__umulhi(p0, a.lmagic);
+        const int cj = (int)__umulhi(pj, a.lmagic), phase = (int)pj - cj * a.L, delta = cj - c0;
+        const bool valid = sj < a.L;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int i = 4 * t + lk - delta;
+            hreg[t] = (valid && i >= 0 && i < a.tp) ? a.pfbT[(int64_t)i * a.L + phase] : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) hreg[t] = 0.0f;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the taps are in (their first use must not look like a pending load inside the tile loop)
+    const int64_t cbase = a.d0 - 1;
+    constexpr int wtail = 4 * T + 4;   // samples read past a window start
+    const int64_t ntiles = (a.nrounds + Q - 1) / Q;
+    // Software pipeline over tiles, three LDS buffers in rotation.  In iteration t:
+    //   buffer t+1 receives the NEXT tile's samples by LDS-DMA (no registers, no ds_write pass), issued right after the barrier;
+    //   buffer t-1 holds the PREVIOUS tile's outputs, which leave as coalesced stores while this tile is multiplied;
+    //   buffer t   feeds the products, and takes the accumulators afterwards (one more barrier).
+    // The first tile(s), which straddle the history, are filled by ordinary loads (all waves).
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)zs;
+    const auto dma_ok = [&](int64_t tile) { return tile < ntiles && tile * Q * a.M + cbase >= a.hl; };
+    const auto dma = [&](int64_t tile, int buf) {
+        if (!is_dma || !dma_ok(tile)) return;
+        const int64_t q0 = tile * Q, z0 = q0 * a.M + cbase;
+        const int nz = (int)std::min<int64_t>(Q, a.nrounds - q0) * a.M + a.M + wtail;
+        const mm_i4 rs = mm_rsrc(xc + (z0 - a.hl), (a.xlen - (z0 - a.hl)) * 4);   // re-based at the tile start: zero fill past the signal
+        const int inside = (int)std::min<int64_t>(nz, a.xlen - (z0 - a.hl));   // samples of the tile that exist
+        for (int i = wave - a.NB; 256 * i < nz; i += a.nd) {   // granules of 256 samples, round-robin over the DMA waves
+            const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + 256 * i) * 4u;
+            if (256 * (i + 1) <= inside) mm_dma256(rs, dst, (256 * i + 4 * lane) * 4);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mm_dma64(rs, dst + 256u * j, (256 * i + 64 * j + lane) * 4);
+            }
+        }
+    };
+    // the outputs of a tile, m = q0 L .., are contiguous in y: coalesced 16-byte stores (dword-aligned; global memory takes them
+    // unaligned) by the storing waves, four LDS reads in flight per thread
+    const int st0 = (int)threadIdx.x - 64 * (a.NB + a.nd), stn = 64 * a.ns;
+    const auto copy_out = [&](int64_t tile, const float* zo) {
+        if (!is_store) return;
+        const int64_t q0 = tile * Q, mbase = q0 * a.L;
+        const int total = (int)std::min<int64_t>(std::min<int64_t>(Q, a.nrounds - q0) * a.L, a.nout - mbase);
+        float* yo = yc + mbase;
+        if (a.L % 4 == 0) {
+            const int n4 = total / 4;
+            for (int i4 = st0; i4 < n4; i4 += 4 * stn) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = 4 * std::min(i4 + u * stn, n4 - 1), row = (int)__umulhi((unsigned)idx, a.lmagic), col = idx - row * a.L;
+                    v[u] = *reinterpret_cast<const float4*>(zo + row * a.Lp + col);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i4 + u * stn < n4) __builtin_memcpy(yo + 4 * (i4 + u * stn), &v[u], sizeof(float4));
+            }
+            for (int idx = (total & ~3) + st0; idx < total; idx += stn) {
+                const int row = (int)__umulhi((unsigned)idx, a.lmagic), col = idx - row * a.L;
+                yo[idx] = zo[row * a.Lp + col];
+            }
+        } else {
+            for (int idx = st0; idx < total; idx += stn) {
+                const int row = (int)__umulhi((unsigned)idx, a.lmagic), col = idx - row * a.L;
+                yo[idx] = zo[row * a.Lp + col];
+            }
+        }
+    };
+    // Which round a row of the 16 x 16 product is: with odd M, the 16 EVEN (then the 16 odd) rounds of a 32-round span put the
+    // 2 x 16 A-operand reads of a ds_read_b32 lane group on 32 different banks (16 consecutive rounds collide two ways).
+    const int ra = (a.M & 1) ? 2 : 1;
+    const auto rbase = [&](int c) { return (a.M & 1) ? 32 * (c >> 1) + (c & 1) : 16 * c; };
+    int cur = 0, prv = 2, nxt = 1;
+    int64_t prev_tile = -1;
+    dma(blockIdx.x, 0);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t q0 = tile * Q;
+        const int nq = (int)std::min<int64_t>(Q, a.nrounds - q0);
+        const int64_t z0 = q0 * a.M + cbase;
+        const int nz = nq * a.M + a.M + wtail;
+        float* zt = zs + cur * a.bufsz;   // this tile: input during the products, output tile [Q][Lp] afterwards
+        if (dma_ok(tile)) {
+            if (is_dma) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of the tile has landed
+        } else {  // the first tile(s) straddle the history
+            for (int k2 = threadIdx.x; k2 < nz; k2 += blockDim.x) {
+                const int64_t zi = z0 + k2;
+                float v = 0.0f;
+                if (zi < a.hl) v = hc[zi];
+                else if (zi - a.hl < a.xlen) v = xc[zi - a.hl];
+                zt[k2] = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+        }
+        __syncthreads();   // tile t is in; the outputs of t-1 are complete in their buffer; the buffer of t-2 has been read out
+        dma(tile + gridDim.x, nxt);
+        if (prev_tile >= 0) copy_out(prev_tile, zs + prv * a.bufsz);
+        mm_f4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mm_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (is_comp) {
+            const float* ap[4];   // A operand: row = lane % 16 (a round), k = lane / 16
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ap[c] = zt + (ra * lj + rbase(c)) * a.M + c0 + lk;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[c][4 * t], hreg[t], acc[c], 0, 0, 0);
+        }
+        __syncthreads();   // every wave is done with the input tile: the output tile takes its place
+        if (is_comp) {
+            // D: register r of lane l is row 4 (l / 16) + r, column l % 16
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zt[(ra * (4 * lk + r) + rbase(c)) * a.Lp + 16 * wave + lj] = acc[c][r];
+        }
+        prev_tile = tile;
+        const int fre = prv;
+        prv = cur; cur = nxt; nxt = fre;
+    }
+    __syncthreads();
+    if (prev_tile >= 0) copy_out(prev_tile, zs + prv * a.bufsz);
+}
+
 int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 
 
@@ -786,7 +995,81 @@ template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStrea
     }
 }
 
+// ---- matrix-core kernel, host side ------------------------------------------------------------------------------
+// Shapes it is built for: Float32 x Float32, 16 <= L <= 224 (up to 14 multiplying waves, one block of 16 residues each, and at least two memory waves), a 64-round tile that
+// fits the LDS, at most 80 window positions per block, and rounds (lane stride M samples) that spread over the LDS banks.
+int64_t fir_mm_steps(const mdsp_fir_s* f) {   // k-steps of four window positions: tp + max delta_15
+    return cdiv(f->tp + ((f->L - 1) + 15 * f->M) / f->L, (int64_t)4);
+}
+int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : 20; }
+int64_t fir_mm_bufsz(const mdsp_fir_s* f) {   // floats per tile buffer: the staged samples, later the [64][16 NB + 4] outputs; 256-dword DMA granules
+    const int64_t Q = 64, NB = cdiv(f->L, (int64_t)16), T = fir_mm_tsel(fir_mm_steps(f));
+    return cdiv(std::max<int64_t>(Q * f->M + f->M + 4 * T + 4, Q * (16 * NB + 4)), (int64_t)256) * 256;
+}
+size_t fir_mm_lds_bytes(const mdsp_fir_s* f) {
+    return 3 * (size_t)fir_mm_bufsz(f) * sizeof(float);   // three tile buffers
+}
+// memory waves beside the NB multiplying ones (16 waves per workgroup at most): DMA issue, output stores
+void fir_mm_roles(int NB, int* nd, int* ns) {
+    const int extra = 16 - NB;
+    *nd = extra >= 6 ? 2 : 1;
+    *ns = std::max(1, std::min(4, extra - *nd));
+}
+bool fir_mm_shape_ok(const mdsp_fir_s* f) {
+    if (f->acc_double || f->x_dtype != MDSP_F32 || f->taps_dtype != MDSP_F32) return false;
+    if (f->L < 16 || f->L > 224 || f->M % 4 == 0 || fir_mm_steps(f) > 20) return false;   // 14 multiplying waves + 2 memory waves
+    return fir_mm_lds_bytes(f) <= 150 * 1024;
+}
+
+template <int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
+    FirMArgs b{};
+    b.x = (const float*)a.x;
+    b.hist = (const float*)a.hist;
+    b.y = (float*)a.y;
+    b.pfbT = (const float*)a.pfbT;
+    b.xlen = a.xlen; b.ldx = a.ldx; b.ldy = a.ldy; b.nout = a.nout;
+    b.d0 = a.d0;
+    b.L = a.L; b.M = a.M; b.hl = a.hl; b.tp = a.tp;
+    b.nrounds = cdiv(a.nout, (int64_t)a.L);
+    b.NB = (int)cdiv((int64_t)a.L, (int64_t)16);
+    b.Lp = 16 * b.NB + 4;
+    b.lmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)a.L - 1) / (uint64_t)a.L);
+    b.phi0m1 = (int)a.phi0m1;
+    b.bufsz = (int)fir_mm_bufsz(f);
+    fir_mm_roles(b.NB, &b.nd, &b.ns);
+    const size_t lds_bytes = fir_mm_lds_bytes(f);
+    const int nw = b.NB + b.nd + b.ns;
+    auto kern = polyphase_mfma_kernel<T>;
+    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const int64_t ntiles = cdiv(b.nrounds, (int64_t)64);
+    int wgs = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(160 * 1024) / (int64_t)(lds_bytes + 256), 32 / nw));
+    if (tunables().wg_per_cu > 0) wgs = tunables().wg_per_cu;
+    const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
+    const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)f->nch);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds_bytes, st, b);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+int fir_mm_dispatch_t(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
+    switch (fir_mm_tsel(fir_mm_steps(f))) {
+        case 4: return fir_mm_launch<4>(f, a, st);
+        case 8: return fir_mm_launch<8>(f, a, st);
+        case 12: return fir_mm_launch<12>(f, a, st);
+        case 16: return fir_mm_launch<16>(f, a, st);
+        default: return fir_mm_launch<20>(f, a, st);
+    }
+}
+
+// where the matrix-core kernel is used: the shape fits, and (unless forced) there are enough 64-round tiles to fill the device
+bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
+    if (tunables().fir_mm == 0 || !fir_mm_shape_ok(f)) return false;
+    if (tunables().fir_mm == 1) return true;
+    return cdiv(cdiv(a.nout, (int64_t)a.L), (int64_t)64) * f->nch >= 2 * device_cu_count();
+}
+
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
+    if (fir_mm_use(f, a)) return fir_mm_dispatch_t(f, a, st);
     if (tunables().fir_p == 4 && f->tp <= 32 && fir_fast_ok(f, 4)) return fir_fast_dispatch<4>(f, a, st);   // tuning: four residues per thread
     if (tunables().fir_p == 3 && f->tp <= 32 && fir_fast_ok(f, 3)) return fir_fast_dispatch<3>(f, a, st);   // tuning: three residues per thread
     if (fir_fast_ok(f, 2)) return fir_fast_dispatch<2>(f, a, st);

@@ -412,3 +412,51 @@ def test_host_pipelines_with_padded_leading_dimensions(d, torch):
         _lib.check(lib.mdsp_ols_exec_host(plan._h, X.ctypes.data_as(C.c_void_p), nx, ncols, nx - 1, Y.ctypes.data_as(C.c_void_p), nx, ld, 0))
     with pytest.raises(d.DimensionMismatch):
         _lib.check(lib.mdsp_welch_exec_host(cfg._h, X.ctypes.data_as(C.c_void_p), nx, ncols, nx - 1, P.ctypes.data_as(C.c_void_p), cfg.nout, 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,M,ntaps", [(160, 147, 5120), (160, 147, 5921), (23, 17, 300), (16, 9, 129), (17, 35, 1100), (37, 2, 400), (250, 249, 4000), (14, 9, 64)])
+def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M, ntaps):
+    # The matrix-core kernel (v_mfma_f32_16x16x4_f32: 16 rounds x 16 residues, a k-ordered fmaf chain) and the register-tap kernel sum
+    # each output in the same order: bit-identical outputs and states, for any phase / deficit the stream is cut at, with ragged tails
+    # (nout not a multiple of L, L not a multiple of 16), several channels on an odd leading dimension, and against the oracle.
+    from fractions import Fraction
+    from dsp_jl_amd import _lib
+    from oracle import stream_filt as osf
+    lib = _lib.lib()
+    rng = np.random.default_rng(L * 1000 + M)
+    h = (rng.standard_normal(ntaps) / np.sqrt(ntaps / L)).astype(np.float32)
+    nch, n = 3, 200_003
+    g = torch.Generator(device="cuda"); g.manual_seed(L + M)
+    x = torch.randn((nch, n), generator=g, device="cuda", dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    cuts = (0, 1, 777, 100_000, n)
+    outs = {}
+    try:
+        for sg in (0, 1):
+            _lib.set_tunable("MDSP_FIR_MM", sg)
+            fh = C.c_void_p()
+            _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, _lib.F32, _lib.F32, nch))
+            pieces, states = [], []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, b - a, C.byref(ol)))
+                ldy = ol.value + 1
+                y = torch.full((nch, ldy), float("nan"), dtype=torch.float32, device="cuda")
+                nw = C.c_int64()
+                _lib.check(lib.mdsp_fir_exec(fh, x[:, a:].data_ptr(), b - a, n, y.data_ptr(), ol.value, ldy, C.byref(nw), stream))
+                torch.cuda.synchronize()
+                assert nw.value == ol.value
+                assert torch.isnan(y[:, ol.value:]).all() and not torch.isnan(y[:, :ol.value]).any()
+                pieces.append(y[:, :ol.value].clone())
+                phi, dfc = C.c_int64(), C.c_int64()
+                _lib.check(lib.mdsp_fir_get_state(fh, C.byref(phi), C.byref(dfc), None))
+                states.append((phi.value, dfc.value))
+            outs[sg] = (torch.cat(pieces, dim=1), states)
+            _lib.check(lib.mdsp_fir_destroy(fh))
+    finally:
+        _lib.set_tunable("MDSP_FIR_MM", None)
+    assert outs[0][1] == outs[1][1]
+    assert torch.equal(outs[0][0], outs[1][0])
+    m = 20_000
+    ref = osf.FIRFilter(h.astype(np.float64), Fraction(L, M)).filt(x[1, :m].cpu().numpy().astype(np.float64))
+    assert relerr(outs[1][0][1, :len(ref)].cpu().numpy(), ref) < 2e-6

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""A/B of the polyphase kernels on BASELINE config 5's single-GPU share (160//147, 5120 taps, 4 channels x 2^28 Float32):
+register-tap kernel (MDSP_FIR_MM=0) against the matrix-core kernel (MDSP_FIR_MM=1), interleaved rounds in one process.
+Writes gpurun_out/tune_fir.json.   TUNE_FIR="mm,wg_per_cu,p;..."  TUNE_LOG2N=28  TUNE_RATIO=160/147  TUNE_TAPS=5120"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import dsp_jl_amd as d
+from dsp_jl_amd import _lib
+from fractions import Fraction
+
+lib = _lib.lib()
+_lib.check(lib.mdsp_init(0))
+log2n = int(os.environ.get("TUNE_LOG2N", "28"))
+rounds = int(os.environ.get("TUNE_ROUNDS", "5"))
+nch, n = int(os.environ.get("TUNE_NCH", "4")), 1 << log2n
+L, M = (int(v) for v in os.environ.get("TUNE_RATIO", "160/147").split("/"))
+variants = [tuple(int(t) for t in v.split(",")) for v in os.environ.get("TUNE_FIR", "0,0,0;1,0,0;1,2,0;1,1,0").split(";")]
+g = torch.Generator(device="cuda"); g.manual_seed(1776)
+x = torch.randn((nch, n), generator=g, device="cuda", dtype=torch.float32)
+stream = torch.cuda.current_stream().cuda_stream
+h = np.asarray(d.resample_filter(Fraction(L, M)), dtype=np.float32)
+ntaps = int(os.environ.get("TUNE_TAPS", "5120" if (L, M) == (160, 147) else "0"))   # config 5: 5120 taps = 32 per phase
+if ntaps:
+    h = np.concatenate([h, np.zeros(ntaps - len(h), np.float32)]) if len(h) < ntaps else h[:ntaps].copy()
+fh = C.c_void_p()
+_lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, _lib.F32, _lib.F32, nch))
+ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, n, C.byref(ol)))
+ldy = ol.value + int(os.environ.get("TUNE_LDPAD", "0"))
+y = torch.empty((nch, ldy), dtype=torch.float32, device="cuda")
+nw = C.c_int64()
+
+
+def ev():
+    e = C.c_void_p(); _lib.check(lib.mdsp_event_create(C.byref(e))); return e
+
+
+e0, e1 = ev(), ev()
+
+
+def run():
+    _lib.check(lib.mdsp_fir_reset(fh))
+    _lib.check(lib.mdsp_fir_exec(fh, x.data_ptr(), n, n, y.data_ptr(), ol.value, ldy, C.byref(nw), stream))
+
+
+def select(v):
+    _lib.set_tunable("MDSP_FIR_MM", str(v[0])); _lib.set_tunable("MDSP_WG_PER_CU", str(v[1])); _lib.set_tunable("MDSP_FIR_P", str(v[2]))
+
+
+def timeit():
+    run(); torch.cuda.synchronize()
+    _lib.check(lib.mdsp_event_record(e0, stream)); run(); _lib.check(lib.mdsp_event_record(e1, stream))
+    ms = C.c_float(); _lib.check(lib.mdsp_event_elapsed_ms(e0, e1, C.byref(ms)))
+    return ms.value
+
+
+res = {"log2n": log2n, "nch": nch, "ratio": f"{L}//{M}", "taps": len(h), "nout": ol.value, "variants": {}}
+ref = None
+for v in variants:
+    select(v); y.zero_(); run(); torch.cuda.synchronize()
+    if ref is None:
+        ref = y.clone()
+    key = "mm={} wg_per_cu={} p={}".format(*v[:3])
+    res["variants"][key] = {"maxdiff_vs_first": float((y - ref).abs().max()), "ms": []}
+for r in range(rounds):
+    for v in variants:
+        select(v)
+        res["variants"]["mm={} wg_per_cu={} p={}".format(*v[:3])]["ms"].append(round(timeit(), 4))
+bytes_alg = (4 + 4 * L / M) * n * nch
+for k, e in res["variants"].items():
+    e["median_ms"] = float(np.median(e["ms"]))
+    e["GBps"] = round(bytes_alg / e["median_ms"] / 1e6, 1)
+    print(k, e["median_ms"], "ms", e["GBps"], "GB/s  maxdiff", e["maxdiff_vs_first"], flush=True)
+select((-1, 0, 0)); _lib.set_tunable("MDSP_FIR_MM", None); _lib.set_tunable("MDSP_WG_PER_CU", None); _lib.set_tunable("MDSP_FIR_P", None)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "tune_fir.json"), "w"), indent=1)
