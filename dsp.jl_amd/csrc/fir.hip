@@ -292,7 +292,7 @@ struct FirMArgs {
     int L, M, hl, tp;
     int NB;                      // blocks of 16 residues
     int Lp;                      // row pitch of the output tile in LDS (floats): 16 NB + 4
-    int bufsz;                   // floats per LDS tile buffer (three of them)
+    int bufsz;                   // floats per LDS sample buffer (two of them, then two output buffers)
     int nd, ns;                  // waves that issue the LDS-DMA / that store, after the NB multiplying waves
     unsigned lmagic;             // ceil(2^32 / L): quotient by L of anything below 2^32 / L by multiply-high
     int phi0m1;                  // phi0 - 1: residue s has phase (phi0-1 + s M) mod L and window start (phi0-1 + s M) div L
@@ -327,7 +327,7 @@ template <int T>   // k-steps of four taps
 __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     constexpr int Q = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* zs = reinterpret_cast<float*>(smem);   // three tile buffers
+    float* zs = reinterpret_cast<float*>(smem);   // two sample buffers of bufsz floats, then two output buffers [Q][Lp]
     const int64_t ch = blockIdx.y;
     const float* xc = a.x + ch * a.ldx;
     const float* hc = a.hist + ch * (int64_t)a.hl;
@@ -361,10 +361,11 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     const int64_t cbase = a.d0 - 1;
     constexpr int wtail = 4 * T + 4;   // samples read past a window start
     const int64_t ntiles = (a.nrounds + Q - 1) / Q;
-    // Software pipeline over tiles, three LDS buffers in rotation.  In iteration t:
-    //   buffer t+1 receives the NEXT tile's samples by LDS-DMA (no registers, no ds_write pass), issued right after the barrier;
-    //   buffer t-1 holds the PREVIOUS tile's outputs, which leave as coalesced stores while this tile is multiplied;
-    //   buffer t   feeds the products, and takes the accumulators afterwards (one more barrier).
+    // Software pipeline over tiles with ONE barrier per tile.  LDS holds two sample buffers and two output buffers; in iteration t
+    //   sample buffer t+1 receives the NEXT tile by LDS-DMA (no registers, no ds_write pass), issued right after the barrier;
+    //   sample buffer t   feeds the products, and every multiplying wave writes its 64 x 16 outputs into output buffer t as soon
+    //                     as its own MFMAs are done (nobody else touches that block of columns);
+    //   output buffer t-1 leaves as coalesced stores.
     // The first tile(s), which straddle the history, are filled by ordinary loads (all waves).
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)zs;
     const auto dma_ok = [&](int64_t tile) { return tile < ntiles && tile * Q * a.M + cbase >= a.hl; };
@@ -419,34 +420,38 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     // 2 x 16 A-operand reads of a ds_read_b32 lane group on 32 different banks (16 consecutive rounds collide two ways).
     const int ra = (a.M & 1) ? 2 : 1;
     const auto rbase = [&](int c) { return (a.M & 1) ? 32 * (c >> 1) + (c & 1) : 16 * c; };
-    int cur = 0, prv = 2, nxt = 1;
+    float* zout = zs + 2 * a.bufsz;
+    const int osz = Q * a.Lp;
+    int cur = 0;
     int64_t prev_tile = -1;
     dma(blockIdx.x, 0);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, cur ^= 1) {
         const int64_t q0 = tile * Q;
         const int nq = (int)std::min<int64_t>(Q, a.nrounds - q0);
         const int64_t z0 = q0 * a.M + cbase;
         const int nz = nq * a.M + a.M + wtail;
-        float* zt = zs + cur * a.bufsz;   // this tile: input during the products, output tile [Q][Lp] afterwards
+        const float* zt = zs + cur * a.bufsz;   // this tile's samples
+        float* zo = zout + cur * osz;           // this tile's outputs
         if (dma_ok(tile)) {
             if (is_dma) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of the tile has landed
         } else {  // the first tile(s) straddle the history
+            float* zw = zs + cur * a.bufsz;
             for (int k2 = threadIdx.x; k2 < nz; k2 += blockDim.x) {
                 const int64_t zi = z0 + k2;
                 float v = 0.0f;
                 if (zi < a.hl) v = hc[zi];
                 else if (zi - a.hl < a.xlen) v = xc[zi - a.hl];
-                zt[k2] = v;
+                zw[k2] = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);
         }
-        __syncthreads();   // tile t is in; the outputs of t-1 are complete in their buffer; the buffer of t-2 has been read out
-        dma(tile + gridDim.x, nxt);
-        if (prev_tile >= 0) copy_out(prev_tile, zs + prv * a.bufsz);
-        mm_f4 acc[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = mm_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();   // tile t is in; the outputs of t-1 are complete; the other sample buffer and the other output buffer are free
+        dma(tile + gridDim.x, cur ^ 1);
+        if (prev_tile >= 0) copy_out(prev_tile, zout + (cur ^ 1) * osz);
         if (is_comp) {
+            mm_f4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mm_f4{0.0f, 0.0f, 0.0f, 0.0f};
             const float* ap[4];   // A operand: row = lane % 16 (a round), k = lane / 16
 #pragma unroll
             for (int c = 0; c < 4; ++c) ap[c] = zt + (ra * lj + rbase(c)) * a.M + c0 + lk;
@@ -454,21 +459,16 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[c][4 * t], hreg[t], acc[c], 0, 0, 0);
-        }
-        __syncthreads();   // every wave is done with the input tile: the output tile takes its place
-        if (is_comp) {
             // D: register r of lane l is row 4 (l / 16) + r, column l % 16
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zt[(ra * (4 * lk + r) + rbase(c)) * a.Lp + 16 * wave + lj] = acc[c][r];
+                for (int r = 0; r < 4; ++r) zo[(ra * (4 * lk + r) + rbase(c)) * a.Lp + 16 * wave + lj] = acc[c][r];
         }
         prev_tile = tile;
-        const int fre = prv;
-        prv = cur; cur = nxt; nxt = fre;
     }
     __syncthreads();
-    if (prev_tile >= 0) copy_out(prev_tile, zs + prv * a.bufsz);
+    if (prev_tile >= 0) copy_out(prev_tile, zout + (cur ^ 1) * osz);
 }
 
 int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
@@ -1002,12 +1002,13 @@ int64_t fir_mm_steps(const mdsp_fir_s* f) {   // k-steps of four window position
     return cdiv(f->tp + ((f->L - 1) + 15 * f->M) / f->L, (int64_t)4);
 }
 int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : 20; }
-int64_t fir_mm_bufsz(const mdsp_fir_s* f) {   // floats per tile buffer: the staged samples, later the [64][16 NB + 4] outputs; 256-dword DMA granules
-    const int64_t Q = 64, NB = cdiv(f->L, (int64_t)16), T = fir_mm_tsel(fir_mm_steps(f));
-    return cdiv(std::max<int64_t>(Q * f->M + f->M + 4 * T + 4, Q * (16 * NB + 4)), (int64_t)256) * 256;
+int64_t fir_mm_bufsz(const mdsp_fir_s* f) {   // floats per sample buffer: 64 rounds + the window tail, in 256-dword DMA granules
+    const int64_t Q = 64, T = fir_mm_tsel(fir_mm_steps(f));
+    return cdiv(Q * f->M + f->M + 4 * T + 4, (int64_t)256) * 256;
 }
-size_t fir_mm_lds_bytes(const mdsp_fir_s* f) {
-    return 3 * (size_t)fir_mm_bufsz(f) * sizeof(float);   // three tile buffers
+size_t fir_mm_lds_bytes(const mdsp_fir_s* f) {   // two sample buffers, two output buffers [64][16 NB + 4]
+    const int64_t NB = cdiv(f->L, (int64_t)16);
+    return (size_t)(2 * fir_mm_bufsz(f) + 2 * 64 * (16 * NB + 4)) * sizeof(float);
 }
 // memory waves beside the NB multiplying ones (16 waves per workgroup at most): DMA issue, output stores
 void fir_mm_roles(int NB, int* nd, int* ns) {
@@ -1018,7 +1019,7 @@ void fir_mm_roles(int NB, int* nd, int* ns) {
 bool fir_mm_shape_ok(const mdsp_fir_s* f) {
     if (f->acc_double || f->x_dtype != MDSP_F32 || f->taps_dtype != MDSP_F32) return false;
     if (f->L < 16 || f->L > 224 || f->M % 4 == 0 || fir_mm_steps(f) > 20) return false;   // 14 multiplying waves + 2 memory waves
-    return fir_mm_lds_bytes(f) <= 150 * 1024;
+    return fir_mm_lds_bytes(f) <= 160 * 1024;
 }
 
 template <int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
@@ -1042,7 +1043,7 @@ template <int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, hipStream_t 
     auto kern = polyphase_mfma_kernel<T>;
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const int64_t ntiles = cdiv(b.nrounds, (int64_t)64);
-    int wgs = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(160 * 1024) / (int64_t)(lds_bytes + 256), 32 / nw));
+    int wgs = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(160 * 1024) / (int64_t)lds_bytes, 32 / nw));
     if (tunables().wg_per_cu > 0) wgs = tunables().wg_per_cu;
     const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)f->nch);
