@@ -244,7 +244,7 @@ def live_traffic(args):
             return None, f"cannot read the {ctr} database: {e}"
     res = {}
     for key, pat in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("stft", "true, false, 2, 1, true, 4>"),
-                     ("spectrogram", "true, true, 2, 1, true, 4>"), ("resample", "polyphase_fast_kernel"), ("firarb", "arbitrary_fir_kernel"), ("copy", "mdsp_copy_kernel")):
+                     ("spectrogram", "true, true, 2, 1, true, 4>"), ("resample", "polyphase_"), ("firarb", "arbitrary_fir_kernel"), ("copy", "mdsp_copy_kernel")):
         f = next((v["counters"].get("FETCH_SIZE") for k, v in out["FETCH_SIZE"].items() if pat in k), None)
         w = next((v["counters"].get("WRITE_SIZE") for k, v in out["WRITE_SIZE"].items() if pat in k), None)
         if f is not None and w is not None:
@@ -289,7 +289,7 @@ def measure_rows(tm, lib, _lib, d, stream):
         _lib.check(lib.mdsp_fir_exec(fh, x.data_ptr(), n, n, y.data_ptr(), ol.value, ol.value + 1, C.byref(nw), stream))
 
     med, best = tm.time(fir)
-    rows["resample"] = roof("polyphase_fast_kernel (config 5 share: 4 ch x 2^28 Float32, 160//147, 8.354 B/sample)", med, (4 + 4 * 160 / 147) * n * nch,
+    rows["resample"] = roof("polyphase_mfma_kernel (config 5 share: 4 ch x 2^28 Float32, 160//147, 8.354 B/sample)", med, (4 + 4 * 160 / 147) * n * nch,
                             extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
     _lib.check(lib.mdsp_fir_destroy(fh))
     rate = 160 / 147
@@ -497,7 +497,7 @@ def main():
             tm.rec(c)
         names = ("resample", "channel average + all-reduce")
         alg = ((4 + 4 * 160 / 147) * n * nch, 0.0)
-        kern = ("polyphase_fast_kernel (config 5: 4 + 4*160/147 = 8.354 B/input sample)", "-")
+        kern = ("polyphase_mfma_kernel (config 5: 4 + 4*160/147 = 8.354 B/input sample)", "-")
         workload = (f"resample 160//147 (FIRFilter, 5120 taps = 32 per phase) of {nch} channels x 2^{log2n} Float32 samples per GPU -> {ol.value} outputs per channel; "
                     "RCCL all-reduce (1024 floats) for the cross-channel average of the last output block")
         metric, dtype, engine_used = "Gsamples/s FIRFilter polyphase resample 160//147, 32 taps/phase, Float32, 4 channels x 256 Msample per GPU (BASELINE config 5)", "f32", "hip"

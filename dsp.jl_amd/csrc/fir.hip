@@ -278,9 +278,15 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 // This is not a GEMM reshaping of the problem: no operand is materialised or reordered in memory, X is the staged signal tile
 // itself (lane l reads z[(q0 + l%16) M + c + 4 t + l/16], one ds_read_b32 per MFMA), H lives in T VGPRs per wave for the whole
 // kernel (lane l: tap k = 4 t + l/16 of residue j = l%16), and the roofline that bounds the kernel stays HBM.
-//   wave  = one block of 16 residues, all 64 rounds of the tile as four independent accumulators
-//   tile  = 64 rounds = 64 M input samples staged in LDS; the 64 L outputs go back through the same LDS (row pitch 16 NB + 4) and
-//           leave as one contiguous run of 16-byte stores
+//   tile   = 64 rounds = 64 M input samples + the window tail, staged in LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPRs, no
+//            ds_write pass); its 64 L outputs go through an LDS output buffer (row pitch 16 NB + 4) and leave as one contiguous
+//            run of 16-byte stores
+//   waves  = NB multiplying waves (one block of 16 residues each, the 64 rounds as four independent accumulators), then nd waves
+//            that only issue the DMA of the next tile and ns waves that only store the previous tile's outputs: the memory
+//            waves work through the whole tile period beside the MFMAs, one s_barrier per tile
+//   LDS    = two sample buffers + two output buffers (config 5: 2 x 38 KiB + 2 x 41 KiB = 158 KiB, one workgroup of 16 waves per CU)
+// Measured on BASELINE config 5 (4 ch x 2^28, 160//147, 5120 taps): 1.86 ms = 4.8 TB/s of algorithmic traffic, the device-copy
+// rate of this GPU, against 2.4 - 2.5 ms for the register-tap kernel (profiles/r02q_*).
 // ------------------------------------------------------------------------------------------------------------
 struct FirMArgs {
     const float* x;

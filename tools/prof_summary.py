@@ -65,7 +65,7 @@ def traffic(fetch_db, write_db, out_path):
            "workload": "bench.py default (2^30 Float32 samples per launch)"}
     for name, key in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("welch_fused_generic", "welch_fused_kernel"),
                       ("stft", "stft_fused_kernel<float, 1024, 16, 4, 1, 4, true, false"), ("spectrogram", "stft_fused_kernel<float, 1024, 16, 4, 1, 4, true, true"),
-                      ("resample", "polyphase_fast_kernel"), ("firarb", "arbitrary_fir_kernel"), ("copy", "mdsp_copy_kernel")):
+                      ("resample", "polyphase_"), ("firarb", "arbitrary_fir_kernel"), ("copy", "mdsp_copy_kernel")):
         fv, fk = get(f, key, "FETCH_SIZE")
         wv, _ = get(w, key, "WRITE_SIZE")
         if fv is None or wv is None:
