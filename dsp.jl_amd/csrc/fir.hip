@@ -293,15 +293,17 @@ struct FirMArgs {
     const float* hist;
     float* y;
     const float* pfbT;           // tp * L
-    int64_t xlen, ldx, ldy, nout, nrounds;
+    int64_t xlen, ldx, ldy, nout;
+    int64_t nrows;               // rows of Lr outputs in this call: ceil(nout / Lr)
     int64_t d0;
-    int L, M, hl, tp;
-    int NB;                      // blocks of 16 residues
-    int Lp;                      // row pitch of the output tile in LDS (floats): 16 NB + 4
+    int L, M, hl, tp;            // the filter's ratio L // M
+    int Lr, Mr;                  // a ROW = RB rounds = Lr = RB L consecutive outputs, Mr = RB M input samples (RB = 1 when L >= 16)
+    int NB, NG;                  // blocks of 16 columns (outputs of a row); groups of 64 rows per tile: NB NG multiplying waves
+    int Lp;                      // row pitch of the output buffer in LDS (floats): Lr when NB = 1 (contiguous outputs), else 16 NB + 4
     int bufsz;                   // floats per LDS sample buffer (two of them, then two output buffers)
-    int nd, ns;                  // waves that issue the LDS-DMA / that store, after the NB multiplying waves
-    unsigned lmagic;             // ceil(2^32 / L): quotient by L of anything below 2^32 / L by multiply-high
-    int phi0m1;                  // phi0 - 1: residue s has phase (phi0-1 + s M) mod L and window start (phi0-1 + s M) div L
+    int nd, ns;                  // waves that issue the LDS-DMA / that store, after the multiplying waves
+    unsigned lmagic, rmagic;     // ceil(2^32 / L), ceil(2^32 / Lr): quotients of small numbers by multiply-high
+    int phi0m1;                  // phi0 - 1: output j of a row has phase (phi0-1 + j M) mod L and window start (phi0-1 + j M) div L
 };
 
 typedef int mm_i4 __attribute__((ext_vector_type(4)));
@@ -331,29 +333,31 @@ typedef float mm_f4 __attribute__((ext_vector_type(4)));
 
 template <int T>   // k-steps of four taps
 __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
-    constexpr int Q = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* zs = reinterpret_cast<float*>(smem);   // two sample buffers of bufsz floats, then two output buffers [Q][Lp]
+    const int Q = 64 * a.NG;                      // rows per tile
     const int64_t ch = blockIdx.y;
     const float* xc = a.x + ch * a.ldx;
     const float* hc = a.hist + ch * (int64_t)a.hl;
     float* yc = a.y + ch * a.ldy;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lj = lane & 15, lk = lane >> 4;
-    // Wave roles: waves 0 .. NB-1 multiply (one block of 16 residues each), the next nd waves issue the LDS-DMA of the samples, the
-    // last ns waves store the outputs.  The memory waves work through the whole tile period beside the MFMAs -- a wave that first
-    // moved data and then multiplied would hold up its SIMD's matrix pipe (measured: 2 000 - 6 000 clocks of DMA issue / store
-    // issue per tile, against 4 600 of MFMA) -- and no wave waits on a vmcnt that mixes loads with younger stores.
-    const bool is_comp = wave < a.NB, is_dma = wave >= a.NB && wave < a.NB + a.nd, is_store = wave >= a.NB + a.nd;
+    // Wave roles: the first NB NG waves multiply (wave w: column block w % NB, rows 64 (w / NB) ..), the next nd waves issue the LDS-DMA
+    // of the samples, the last ns waves store the outputs.  The memory waves work through the whole tile period beside the MFMAs -- a
+    // wave that first moved data and then multiplied would hold up its SIMD's matrix pipe (measured: 2 000 - 6 000 clocks of DMA
+    // issue / store issue per tile, against 4 600 of MFMA) -- and no wave waits on a vmcnt that mixes loads with younger stores.
+    const int ncomp = a.NB * a.NG;
+    const bool is_comp = wave < ncomp, is_dma = wave >= ncomp && wave < ncomp + a.nd, is_store = wave >= ncomp + a.nd;
+    const int wb = wave % a.NB, wg = wave / a.NB;
     // H: this wave's taps, for the whole kernel
     float hreg[T];
     int c0 = 0;
     if (is_comp) {
-        const int s0 = 16 * wave, sj = s0 + lj;
+        const int s0 = 16 * wb, sj = s0 + lj;
         const unsigned p0 = (unsigned)(a.phi0m1 + s0 * a.M), pj = (unsigned)(a.phi0m1 + sj * a.M);
-        c0 = (int)__umulhi(p0, a.lmagic);
-        const int cj = (int)__umulhi(pj, a.lmagic), phase = (int)pj - cj * a.L, delta = cj - c0;
-        const bool valid = sj < a.L;
+        c0 = a.L == 1 ? (int)p0 : (int)__umulhi(p0, a.lmagic);   // (ceil(2^32 / 1) does not fit the magic)
+        const int cj = a.L == 1 ? (int)pj : (int)__umulhi(pj, a.lmagic), phase = (int)pj - cj * a.L, delta = cj - c0;
+        const bool valid = sj < a.Lr;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int i = 4 * t + lk - delta;
@@ -366,22 +370,22 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the taps are in (their first use must not look like a pending load inside the tile loop)
     const int64_t cbase = a.d0 - 1;
     constexpr int wtail = 4 * T + 4;   // samples read past a window start
-    const int64_t ntiles = (a.nrounds + Q - 1) / Q;
+    const int64_t ntiles = (a.nrows + Q - 1) / Q;
     // Software pipeline over tiles with ONE barrier per tile.  LDS holds two sample buffers and two output buffers; in iteration t
     //   sample buffer t+1 receives the NEXT tile by LDS-DMA (no registers, no ds_write pass), issued right after the barrier;
     //   sample buffer t   feeds the products, and every multiplying wave writes its 64 x 16 outputs into output buffer t as soon
-    //                     as its own MFMAs are done (nobody else touches that block of columns);
+    //                     as its own MFMAs are done (nobody else touches those rows and columns);
     //   output buffer t-1 leaves as coalesced stores.
     // The first tile(s), which straddle the history, are filled by ordinary loads (all waves).
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)zs;
-    const auto dma_ok = [&](int64_t tile) { return tile < ntiles && tile * Q * a.M + cbase >= a.hl; };
+    const auto dma_ok = [&](int64_t tile) { return tile < ntiles && tile * Q * a.Mr + cbase >= a.hl; };
     const auto dma = [&](int64_t tile, int buf) {
         if (!is_dma || !dma_ok(tile)) return;
-        const int64_t q0 = tile * Q, z0 = q0 * a.M + cbase;
-        const int nz = (int)std::min<int64_t>(Q, a.nrounds - q0) * a.M + a.M + wtail;
+        const int64_t q0 = tile * Q, z0 = q0 * a.Mr + cbase;
+        const int nz = (int)std::min<int64_t>(Q, a.nrows - q0) * a.Mr + a.Mr + wtail;
         const mm_i4 rs = mm_rsrc(xc + (z0 - a.hl), (a.xlen - (z0 - a.hl)) * 4);   // re-based at the tile start: zero fill past the signal
         const int inside = (int)std::min<int64_t>(nz, a.xlen - (z0 - a.hl));   // samples of the tile that exist
-        for (int i = wave - a.NB; 256 * i < nz; i += a.nd) {   // granules of 256 samples, round-robin over the DMA waves
+        for (int i = wave - ncomp; 256 * i < nz; i += a.nd) {   // granules of 256 samples, round-robin over the DMA waves
             const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + 256 * i) * 4u;
             if (256 * (i + 1) <= inside) mm_dma256(rs, dst, (256 * i + 4 * lane) * 4);
             else {
@@ -390,21 +394,22 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
             }
         }
     };
-    // the outputs of a tile, m = q0 L .., are contiguous in y: coalesced 16-byte stores (dword-aligned; global memory takes them
+    // the outputs of a tile, m = q0 Lr .., are contiguous in y: coalesced 16-byte stores (dword-aligned; global memory takes them
     // unaligned) by the storing waves, four LDS reads in flight per thread
-    const int st0 = (int)threadIdx.x - 64 * (a.NB + a.nd), stn = 64 * a.ns;
+    const int st0 = (int)threadIdx.x - 64 * (ncomp + a.nd), stn = 64 * a.ns;
     const auto copy_out = [&](int64_t tile, const float* zo) {
         if (!is_store) return;
-        const int64_t q0 = tile * Q, mbase = q0 * a.L;
-        const int total = (int)std::min<int64_t>(std::min<int64_t>(Q, a.nrounds - q0) * a.L, a.nout - mbase);
+        const int64_t q0 = tile * Q, mbase = q0 * a.Lr;
+        const int total = (int)std::min<int64_t>(std::min<int64_t>(Q, a.nrows - q0) * a.Lr, a.nout - mbase);
         float* yo = yc + mbase;
-        if (a.L % 4 == 0) {
+        const bool flat = a.Lp == a.Lr;   // rows without padding: the buffer IS the run of outputs
+        if (flat || a.Lr % 4 == 0) {
             const int n4 = total / 4;
             for (int i4 = st0; i4 < n4; i4 += 4 * stn) {
                 float4 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int idx = 4 * std::min(i4 + u * stn, n4 - 1), row = (int)__umulhi((unsigned)idx, a.lmagic), col = idx - row * a.L;
+                    const int idx = 4 * std::min(i4 + u * stn, n4 - 1), row = flat ? 0 : (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * a.Lr;
                     v[u] = *reinterpret_cast<const float4*>(zo + row * a.Lp + col);
                 }
 #pragma unroll
@@ -412,20 +417,20 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                     if (i4 + u * stn < n4) __builtin_memcpy(yo + 4 * (i4 + u * stn), &v[u], sizeof(float4));
             }
             for (int idx = (total & ~3) + st0; idx < total; idx += stn) {
-                const int row = (int)__umulhi((unsigned)idx, a.lmagic), col = idx - row * a.L;
+                const int row = flat ? 0 : (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * a.Lr;
                 yo[idx] = zo[row * a.Lp + col];
             }
         } else {
             for (int idx = st0; idx < total; idx += stn) {
-                const int row = (int)__umulhi((unsigned)idx, a.lmagic), col = idx - row * a.L;
+                const int row = (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * a.Lr;
                 yo[idx] = zo[row * a.Lp + col];
             }
         }
     };
-    // Which round a row of the 16 x 16 product is: with odd M, the 16 EVEN (then the 16 odd) rounds of a 32-round span put the
-    // 2 x 16 A-operand reads of a ds_read_b32 lane group on 32 different banks (16 consecutive rounds collide two ways).
-    const int ra = (a.M & 1) ? 2 : 1;
-    const auto rbase = [&](int c) { return (a.M & 1) ? 32 * (c >> 1) + (c & 1) : 16 * c; };
+    // Which row of the tile a row of the 16 x 16 product is: with odd Mr, the 16 EVEN (then the 16 odd) rows of a 32-row span put the
+    // 2 x 16 A-operand reads of a ds_read_b32 lane group on 32 different banks (16 consecutive rows collide two ways).
+    const int ra = (a.Mr & 1) ? 2 : 1;
+    const auto rbase = [&](int c) { return 64 * wg + ((a.Mr & 1) ? 32 * (c >> 1) + (c & 1) : 16 * c); };
     float* zout = zs + 2 * a.bufsz;
     const int osz = Q * a.Lp;
     int cur = 0;
@@ -433,9 +438,9 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     dma(blockIdx.x, 0);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, cur ^= 1) {
         const int64_t q0 = tile * Q;
-        const int nq = (int)std::min<int64_t>(Q, a.nrounds - q0);
-        const int64_t z0 = q0 * a.M + cbase;
-        const int nz = nq * a.M + a.M + wtail;
+        const int nq = (int)std::min<int64_t>(Q, a.nrows - q0);
+        const int64_t z0 = q0 * a.Mr + cbase;
+        const int nz = nq * a.Mr + a.Mr + wtail;
         const float* zt = zs + cur * a.bufsz;   // this tile's samples
         float* zo = zout + cur * osz;           // this tile's outputs
         if (dma_ok(tile)) {
@@ -458,18 +463,20 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
             mm_f4 acc[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = mm_f4{0.0f, 0.0f, 0.0f, 0.0f};
-            const float* ap[4];   // A operand: row = lane % 16 (a round), k = lane / 16
+            const float* ap[4];   // A operand: row = lane % 16, k = lane / 16
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ap[c] = zt + (ra * lj + rbase(c)) * a.M + c0 + lk;
+            for (int c = 0; c < 4; ++c) ap[c] = zt + (ra * lj + rbase(c)) * a.Mr + c0 + lk;
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[c][4 * t], hreg[t], acc[c], 0, 0, 0);
             // D: register r of lane l is row 4 (l / 16) + r, column l % 16
+            if (16 * wb + lj < a.Lr) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zo[(ra * (4 * lk + r) + rbase(c)) * a.Lp + 16 * wave + lj] = acc[c][r];
+                    for (int r = 0; r < 4; ++r) zo[(ra * (4 * lk + r) + rbase(c)) * a.Lp + 16 * wb + lj] = acc[c][r];
+            }
         }
         prev_tile = tile;
     }
@@ -1002,33 +1009,59 @@ template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStrea
 }
 
 // ---- matrix-core kernel, host side ------------------------------------------------------------------------------
-// Shapes it is built for: Float32 x Float32, 16 <= L <= 224 (up to 14 multiplying waves, one block of 16 residues each, and at least two memory waves), a 64-round tile that
-// fits the LDS, at most 80 window positions per block, and rounds (lane stride M samples) that spread over the LDS banks.
-int64_t fir_mm_steps(const mdsp_fir_s* f) {   // k-steps of four window positions: tp + max delta_15
-    return cdiv(f->tp + ((f->L - 1) + 15 * f->M) / f->L, (int64_t)4);
+// Shapes it is built for: Float32 x Float32, L <= 192, at most 128 window positions per block of 16 outputs, a tile that fits the LDS.
+// For L < 16 a row of the product is RB whole rounds (Lr = RB L <= 16 consecutive outputs, Mr = RB M samples): the columns of a
+// row still repeat their phases from row to row, which is all the kernel needs; RB is chosen so that rows (lane stride Mr samples)
+// spread over the LDS banks (odd Mr: conflict-free).
+struct FirMGeo {
+    bool ok = false;
+    int RB = 1, Lr = 0, Mr = 0, NB = 0, NG = 1, T = 0, Lp = 0, nd = 1, ns = 1;
+    int64_t bufsz = 0;
+    size_t lds_bytes = 0;
+};
+int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : 32; }
+FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
+    FirMGeo g;
+    if (f->acc_double || f->x_dtype != MDSP_F32 || f->taps_dtype != MDSP_F32) return g;
+    if (f->L > 192 || f->M > 4096) return g;
+    if (f->L < 16) {   // rounds per row: most outputs per LDS cycle of the A-operand reads (16 rows x 2 taps per ds_read_b32 lane group)
+        double best = -1;
+        for (int rb = 1; rb * f->L <= 16; ++rb) {
+            const int64_t mr = rb * f->M;
+            int worst = 1;
+            if (!(mr & 1)) {   // odd strides are conflict-free with the even / odd row order of the kernel
+                int cnt[32] = {0};
+                for (int i = 0; i < 16; ++i)
+                    for (int k = 0; k < 2; ++k) worst = std::max(worst, ++cnt[(int)((i * mr + k) & 31)]);
+            }
+            const double score = (double)(rb * f->L) / worst + 1e-3 * rb;
+            if (score > best) { best = score; g.RB = rb; }
+        }
+    }
+    g.Lr = g.RB * (int)f->L;
+    g.Mr = g.RB * (int)f->M;
+    g.NB = (int)cdiv((int64_t)g.Lr, (int64_t)16);
+    const int64_t steps = cdiv(f->tp + ((f->L - 1) + (int64_t)(std::min(g.Lr, 16) - 1) * f->M) / f->L, (int64_t)4);   // tp + max delta within a block
+    if (steps > 32) return g;
+    g.T = fir_mm_tsel(steps);
+    g.Lp = g.NB == 1 ? g.Lr : 16 * g.NB + 4;
+    for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {   // the largest tile (64 NG rows) that leaves four memory waves and fits the LDS
+        const int64_t bufsz = cdiv((int64_t)64 * ng * g.Mr + g.Mr + 4 * g.T + 4, (int64_t)256) * 256;
+        const size_t bytes = (size_t)(2 * bufsz + 2 * 64 * ng * g.Lp) * sizeof(float);
+        if (bytes <= 160 * 1024) {
+            g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true;
+            break;
+        }
+    }
+    if (!g.ok) return g;
+    const int extra = 16 - g.NB * g.NG;   // memory waves beside the multiplying ones (16 waves per workgroup at most)
+    g.nd = extra >= 6 ? 2 : 1;
+    g.ns = std::max(1, std::min(4, extra - g.nd));
+    return g;
 }
-int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : 20; }
-int64_t fir_mm_bufsz(const mdsp_fir_s* f) {   // floats per sample buffer: 64 rounds + the window tail, in 256-dword DMA granules
-    const int64_t Q = 64, T = fir_mm_tsel(fir_mm_steps(f));
-    return cdiv(Q * f->M + f->M + 4 * T + 4, (int64_t)256) * 256;
-}
-size_t fir_mm_lds_bytes(const mdsp_fir_s* f) {   // two sample buffers, two output buffers [64][16 NB + 4]
-    const int64_t NB = cdiv(f->L, (int64_t)16);
-    return (size_t)(2 * fir_mm_bufsz(f) + 2 * 64 * (16 * NB + 4)) * sizeof(float);
-}
-// memory waves beside the NB multiplying ones (16 waves per workgroup at most): DMA issue, output stores
-void fir_mm_roles(int NB, int* nd, int* ns) {
-    const int extra = 16 - NB;
-    *nd = extra >= 6 ? 2 : 1;
-    *ns = std::max(1, std::min(4, extra - *nd));
-}
-bool fir_mm_shape_ok(const mdsp_fir_s* f) {
-    if (f->acc_double || f->x_dtype != MDSP_F32 || f->taps_dtype != MDSP_F32) return false;
-    if (f->L < 16 || f->L > 224 || f->M % 4 == 0 || fir_mm_steps(f) > 20) return false;   // 14 multiplying waves + 2 memory waves
-    return fir_mm_lds_bytes(f) <= 160 * 1024;
-}
+bool fir_mm_shape_ok(const mdsp_fir_s* f) { return fir_mm_geo(f).ok; }
 
-template <int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
+template <int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
     FirMArgs b{};
     b.x = (const float*)a.x;
     b.hist = (const float*)a.hist;
@@ -1037,42 +1070,45 @@ template <int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, hipStream_t 
     b.xlen = a.xlen; b.ldx = a.ldx; b.ldy = a.ldy; b.nout = a.nout;
     b.d0 = a.d0;
     b.L = a.L; b.M = a.M; b.hl = a.hl; b.tp = a.tp;
-    b.nrounds = cdiv(a.nout, (int64_t)a.L);
-    b.NB = (int)cdiv((int64_t)a.L, (int64_t)16);
-    b.Lp = 16 * b.NB + 4;
+    b.Lr = g.Lr; b.Mr = g.Mr; b.NB = g.NB; b.NG = g.NG; b.Lp = g.Lp; b.nd = g.nd; b.ns = g.ns;
+    b.nrows = cdiv(a.nout, (int64_t)g.Lr);
     b.lmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)a.L - 1) / (uint64_t)a.L);
+    b.rmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)g.Lr - 1) / (uint64_t)g.Lr);
     b.phi0m1 = (int)a.phi0m1;
-    b.bufsz = (int)fir_mm_bufsz(f);
-    fir_mm_roles(b.NB, &b.nd, &b.ns);
-    const size_t lds_bytes = fir_mm_lds_bytes(f);
-    const int nw = b.NB + b.nd + b.ns;
+    b.bufsz = (int)g.bufsz;
+    const int nw = g.NB * g.NG + g.nd + g.ns;
     auto kern = polyphase_mfma_kernel<T>;
-    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const int64_t ntiles = cdiv(b.nrounds, (int64_t)64);
-    int wgs = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(160 * 1024) / (int64_t)lds_bytes, 32 / nw));
+    if (g.lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+    const int64_t ntiles = cdiv(b.nrows, (int64_t)64 * g.NG);
+    int wgs = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(160 * 1024) / (int64_t)g.lds_bytes, 32 / nw));
     if (tunables().wg_per_cu > 0) wgs = tunables().wg_per_cu;
     const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)f->nch);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds_bytes, st, b);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * nw), g.lds_bytes, st, b);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
 
 int fir_mm_dispatch_t(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
-    switch (fir_mm_tsel(fir_mm_steps(f))) {
-        case 4: return fir_mm_launch<4>(f, a, st);
-        case 8: return fir_mm_launch<8>(f, a, st);
-        case 12: return fir_mm_launch<12>(f, a, st);
-        case 16: return fir_mm_launch<16>(f, a, st);
-        default: return fir_mm_launch<20>(f, a, st);
+    const FirMGeo g = fir_mm_geo(f);
+    switch (g.T) {
+        case 4: return fir_mm_launch<4>(f, a, g, st);
+        case 8: return fir_mm_launch<8>(f, a, g, st);
+        case 12: return fir_mm_launch<12>(f, a, g, st);
+        case 16: return fir_mm_launch<16>(f, a, g, st);
+        case 20: return fir_mm_launch<20>(f, a, g, st);
+        case 24: return fir_mm_launch<24>(f, a, g, st);
+        default: return fir_mm_launch<32>(f, a, g, st);
     }
 }
 
 // where the matrix-core kernel is used: the shape fits, and (unless forced) there are enough 64-round tiles to fill the device
 bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
-    if (tunables().fir_mm == 0 || !fir_mm_shape_ok(f)) return false;
+    if (tunables().fir_mm == 0) return false;
+    const FirMGeo g = fir_mm_geo(f);
+    if (!g.ok) return false;
     if (tunables().fir_mm == 1) return true;
-    return cdiv(cdiv(a.nout, (int64_t)a.L), (int64_t)64) * f->nch >= 2 * device_cu_count();
+    return cdiv(cdiv(a.nout, (int64_t)g.Lr), (int64_t)64 * g.NG) * f->nch >= 2 * device_cu_count();
 }
 
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
