@@ -1272,6 +1272,19 @@ int mdsp_fir_info(mdsp_fir f, int* kind, int64_t* L, int64_t* M, int64_t* taps_p
     return MDSP_OK;
 }
 
+int mdsp_fir_kernel_path(mdsp_fir f, int64_t xlen, int* path) {
+    if (!f || !path) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
+    if (xlen < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    const int64_t phi0 = f->kind == 2 ? 1 : f->phi_idx;
+    const int64_t d0 = f->kind == 0 ? 1 : f->input_deficit;
+    FirArgs a{};
+    a.nout = f->kind == 0 ? xlen : (xlen < d0 ? 0 : mdsp_outputlength(xlen - d0 + 1, f->L, f->M, phi0));
+    a.L = (int)f->L;
+    a.M = (int)f->M;
+    *path = fir_mm_use(f, a) ? 2 : (fir_fast_ok(f, 2) || fir_fast_ok(f, 1)) ? 1 : 0;
+    return MDSP_OK;
+}
+
 int mdsp_fir_get_state(mdsp_fir f, int64_t* phi_idx, int64_t* input_deficit, void* history_host) {
     if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
     if (phi_idx) *phi_idx = f->phi_idx;

@@ -461,3 +461,30 @@ def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M,
     m = 20_000
     ref = osf.FIRFilter(h.astype(np.float64), Fraction(L, M)).filt(x[1, :m].cpu().numpy().astype(np.float64))
     assert relerr(outs[1][0][1, :len(ref)].cpu().numpy(), ref) < 2e-6
+
+
+@pytest.mark.gpu
+def test_polyphase_kernel_choice(d, torch):
+    # BASELINE config 5's shape runs on the matrix-core kernel, short chunks of the same filter on the register-tap kernel, Float64 on
+    # the generic one -- a silent fallback would show up here, not as a slow benchmark.
+    from dsp_jl_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+
+    def path(h, L, M, x_dtype, nch, xlen):
+        fh = C.c_void_p()
+        tdt = _lib.F32 if h.dtype == np.float32 else _lib.F64
+        _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, tdt, x_dtype, nch))
+        p = C.c_int(-1)
+        _lib.check(lib.mdsp_fir_kernel_path(fh, xlen, C.byref(p)))
+        _lib.check(lib.mdsp_fir_destroy(fh))
+        return p.value
+
+    h = rng.standard_normal(5120).astype(np.float32)
+    assert path(h, 160, 147, _lib.F32, 4, 2 ** 28) == 2
+    assert path(h, 160, 147, _lib.F32, 4, 10_000) == 1
+    assert path(h.astype(np.float64), 160, 147, _lib.F64, 4, 2 ** 28) == 0
+    assert path(h, 160, 147, _lib.C32, 4, 2 ** 28) == 0
+    assert path(rng.standard_normal(48).astype(np.float32), 2, 1, _lib.F32, 1, 2 ** 26) == 2      # interpolation by 2: a row is 7 rounds
+    assert path(rng.standard_normal(64).astype(np.float32), 1, 2, _lib.F32, 1, 2 ** 26) == 2      # decimation by 2
+    assert path(rng.standard_normal(4000).astype(np.float32), 250, 249, _lib.F32, 1, 2 ** 26) == 1  # L > 192
