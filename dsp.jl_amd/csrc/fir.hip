@@ -289,20 +289,20 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 // rate of this GPU, against 2.4 - 2.5 ms for the register-tap kernel (profiles/r02q_*).
 // ------------------------------------------------------------------------------------------------------------
 struct FirMArgs {
-    const float* x;
-    const float* hist;
-    float* y;
-    const float* pfbT;           // tp * L
+    const void* x;               // (xlen, nch) samples: R or (R, R) pairs
+    const void* hist;
+    void* y;
+    const void* pfbT;            // tp * L taps of type R
     int64_t xlen, ldx, ldy, nout;
     int64_t nrows;               // rows of Lr outputs in this call: ceil(nout / Lr)
     int64_t d0;
     int L, M, hl, tp;            // the filter's ratio L // M
     int Lr, Mr;                  // a ROW = RB rounds = Lr = RB L consecutive outputs, Mr = RB M input samples (RB = 1 when L >= 16)
-    int NB, NG;                  // blocks of 16 columns (outputs of a row); groups of 64 rows per tile: NB NG multiplying waves
-    int Lp;                      // row pitch of the output buffer in LDS (floats): Lr when NB = 1 (contiguous outputs), else 16 NB + 4
-    int bufsz;                   // floats per LDS sample buffer (two of them, then two output buffers)
+    int NB, NG;                  // blocks of 16 columns (outputs of a row); groups of 16 CH rows per tile: NB NG multiplying waves
+    int Lp;                      // row pitch of the output buffer in LDS (R elements): Lr CS when NB = 1 (contiguous outputs), else 16 NB CS + 16 bytes
+    int bufsz;                   // dwords per LDS sample buffer (two of them, then two output buffers)
     int nd, ns;                  // waves that issue the LDS-DMA / that store, after the multiplying waves
-    unsigned lmagic, rmagic;     // ceil(2^32 / L), ceil(2^32 / Lr): quotients of small numbers by multiply-high
+    unsigned lmagic, rmagic;     // ceil(2^32 / L), ceil(2^32 / (Lr CS)): quotients of small numbers by multiply-high
     int phi0m1;                  // phi0 - 1: output j of a row has phase (phi0-1 + j M) mod L and window start (phi0-1 + j M) div L
 };
 
@@ -329,30 +329,47 @@ __device__ __forceinline__ mm_i4 mm_rsrc(const void* base, long long bytes) {   
     return mm_i4{(int)__builtin_amdgcn_readfirstlane((unsigned)p), (int)(__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xffffu),
                  (int)__builtin_amdgcn_readfirstlane((unsigned)nb), 0x00020000};
 }
-typedef float mm_f4 __attribute__((ext_vector_type(4)));
+// the matrix instruction per element type: D (16 x 16) += A (16 x 4) B (4 x 16); lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16]
+template <typename R> struct Mm;
+template <> struct Mm<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lk, int r) { return 4 * lk + r; }   // D register r of lane l: row 4 (l / 16) + r, column l % 16
+};
+template <> struct Mm<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lk, int r) { return lk + 4 * r; }   // D register r of lane l: row (l / 16) + 4 r, column l % 16
+};
 
-template <int T>   // k-steps of four taps
+// R: Float32 / Float64 arithmetic (signal and taps of that type); CS: 1 real signal, 2 complex signal (interleaved pairs: the two parts
+// are two products against the same taps); CH: 16-row chunks per multiplying wave (independent accumulators); T: k-steps of four taps
+template <typename R, int CS, int CH, int T>
 __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
+    typedef typename Mm<R>::acc_t acc_t;
+    constexpr int DW = (int)(sizeof(R) / 4) * CS;   // dwords per sample
+    constexpr int VW = 16 / (int)sizeof(R);         // R elements per 16-byte store
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* zs = reinterpret_cast<float*>(smem);   // two sample buffers of bufsz floats, then two output buffers [Q][Lp]
-    const int Q = 64 * a.NG;                      // rows per tile
+    R* zs = reinterpret_cast<R*>(smem);            // two sample buffers of bufsz dwords, then two output buffers [Q][Lp]
+    const int Q = 16 * CH * a.NG;                  // rows per tile
     const int64_t ch = blockIdx.y;
-    const float* xc = a.x + ch * a.ldx;
-    const float* hc = a.hist + ch * (int64_t)a.hl;
-    float* yc = a.y + ch * a.ldy;
+    const R* xc = static_cast<const R*>(a.x) + ch * a.ldx * CS;
+    const R* hc = static_cast<const R*>(a.hist) + ch * (int64_t)a.hl * CS;
+    R* yc = static_cast<R*>(a.y) + ch * a.ldy * CS;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lj = lane & 15, lk = lane >> 4;
-    // Wave roles: the first NB NG waves multiply (wave w: column block w % NB, rows 64 (w / NB) ..), the next nd waves issue the LDS-DMA
-    // of the samples, the last ns waves store the outputs.  The memory waves work through the whole tile period beside the MFMAs -- a
-    // wave that first moved data and then multiplied would hold up its SIMD's matrix pipe (measured: 2 000 - 6 000 clocks of DMA
-    // issue / store issue per tile, against 4 600 of MFMA) -- and no wave waits on a vmcnt that mixes loads with younger stores.
+    // Wave roles: the first NB NG waves multiply (wave w: column block w % NB, rows 16 CH (w / NB) ..), the next nd waves issue the
+    // LDS-DMA of the samples, the last ns waves store the outputs.  The memory waves work through the whole tile period beside the
+    // MFMAs -- a wave that first moved data and then multiplied would hold up its SIMD's matrix pipe (measured: 2 000 - 6 000 clocks
+    // of DMA issue / store issue per tile, against 4 600 of MFMA) -- and no wave waits on a vmcnt that mixes loads with younger stores.
     const int ncomp = a.NB * a.NG;
     const bool is_comp = wave < ncomp, is_dma = wave >= ncomp && wave < ncomp + a.nd, is_store = wave >= ncomp + a.nd;
     const int wb = wave % a.NB, wg = wave / a.NB;
     // H: this wave's taps, for the whole kernel
-    float hreg[T];
+    R hreg[T];
     int c0 = 0;
     if (is_comp) {
+        const R* pf = static_cast<const R*>(a.pfbT);
         const int s0 = 16 * wb, sj = s0 + lj;
         const unsigned p0 = (unsigned)(a.phi0m1 + s0 * a.M), pj = (unsigned)(a.phi0m1 + sj * a.M);
         c0 = a.L == 1 ? (int)p0 : (int)__umulhi(p0, a.lmagic);   // (ceil(2^32 / 1) does not fit the magic)
@@ -361,11 +378,11 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int i = 4 * t + lk - delta;
-            hreg[t] = (valid && i >= 0 && i < a.tp) ? a.pfbT[(int64_t)i * a.L + phase] : 0.0f;
+            hreg[t] = (valid && i >= 0 && i < a.tp) ? pf[(int64_t)i * a.L + phase] : (R)0;
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < T; ++t) hreg[t] = 0.0f;
+        for (int t = 0; t < T; ++t) hreg[t] = (R)0;
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the taps are in (their first use must not look like a pending load inside the tile loop)
     const int64_t cbase = a.d0 - 1;
@@ -373,19 +390,19 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     const int64_t ntiles = (a.nrows + Q - 1) / Q;
     // Software pipeline over tiles with ONE barrier per tile.  LDS holds two sample buffers and two output buffers; in iteration t
     //   sample buffer t+1 receives the NEXT tile by LDS-DMA (no registers, no ds_write pass), issued right after the barrier;
-    //   sample buffer t   feeds the products, and every multiplying wave writes its 64 x 16 outputs into output buffer t as soon
-    //                     as its own MFMAs are done (nobody else touches those rows and columns);
+    //   sample buffer t   feeds the products, and every multiplying wave writes its outputs into output buffer t as soon as its
+    //                     own MFMAs are done (nobody else touches those rows and columns);
     //   output buffer t-1 leaves as coalesced stores.
     // The first tile(s), which straddle the history, are filled by ordinary loads (all waves).
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)zs;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) R*)zs;
     const auto dma_ok = [&](int64_t tile) { return tile < ntiles && tile * Q * a.Mr + cbase >= a.hl; };
     const auto dma = [&](int64_t tile, int buf) {
         if (!is_dma || !dma_ok(tile)) return;
         const int64_t q0 = tile * Q, z0 = q0 * a.Mr + cbase;
-        const int nz = (int)std::min<int64_t>(Q, a.nrows - q0) * a.Mr + a.Mr + wtail;
-        const mm_i4 rs = mm_rsrc(xc + (z0 - a.hl), (a.xlen - (z0 - a.hl)) * 4);   // re-based at the tile start: zero fill past the signal
-        const int inside = (int)std::min<int64_t>(nz, a.xlen - (z0 - a.hl));   // samples of the tile that exist
-        for (int i = wave - ncomp; 256 * i < nz; i += a.nd) {   // granules of 256 samples, round-robin over the DMA waves
+        const int nzd = ((int)std::min<int64_t>(Q, a.nrows - q0) * a.Mr + a.Mr + wtail) * DW;   // dwords of the tile
+        const mm_i4 rs = mm_rsrc(xc + (z0 - a.hl) * CS, (a.xlen - (z0 - a.hl)) * 4 * DW);   // re-based at the tile start: zero fill past the signal
+        const int inside = (int)std::min<int64_t>(nzd, (a.xlen - (z0 - a.hl)) * DW);   // dwords of the tile that exist
+        for (int i = wave - ncomp; 256 * i < nzd; i += a.nd) {   // granules of 256 dwords, round-robin over the DMA waves
             const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + 256 * i) * 4u;
             if (256 * (i + 1) <= inside) mm_dma256(rs, dst, (256 * i + 4 * lane) * 4);
             else {
@@ -394,44 +411,46 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
             }
         }
     };
-    // the outputs of a tile, m = q0 Lr .., are contiguous in y: coalesced 16-byte stores (dword-aligned; global memory takes them
-    // unaligned) by the storing waves, four LDS reads in flight per thread
+    // the outputs of a tile, m = q0 Lr .., are contiguous in y: coalesced 16-byte stores (element-aligned; global memory takes them
+    // unaligned) by the storing waves, four LDS reads in flight per thread.  Indices count R elements.
     const int st0 = (int)threadIdx.x - 64 * (ncomp + a.nd), stn = 64 * a.ns;
-    const auto copy_out = [&](int64_t tile, const float* zo) {
+    const int lrc = a.Lr * CS;
+    const auto copy_out = [&](int64_t tile, const R* zo) {
         if (!is_store) return;
         const int64_t q0 = tile * Q, mbase = q0 * a.Lr;
-        const int total = (int)std::min<int64_t>(std::min<int64_t>(Q, a.nrows - q0) * a.Lr, a.nout - mbase);
-        float* yo = yc + mbase;
-        const bool flat = a.Lp == a.Lr;   // rows without padding: the buffer IS the run of outputs
-        if (flat || a.Lr % 4 == 0) {
-            const int n4 = total / 4;
-            for (int i4 = st0; i4 < n4; i4 += 4 * stn) {
-                float4 v[4];
+        const int total = (int)std::min<int64_t>(std::min<int64_t>(Q, a.nrows - q0) * a.Lr, a.nout - mbase) * CS;
+        R* yo = yc + mbase * CS;
+        typedef R vec_t __attribute__((ext_vector_type(VW)));
+        const bool flat = a.Lp == lrc;   // rows without padding: the buffer IS the run of outputs
+        if (flat || lrc % VW == 0) {
+            const int nv = total / VW;
+            for (int iv = st0; iv < nv; iv += 4 * stn) {
+                vec_t v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int idx = 4 * std::min(i4 + u * stn, n4 - 1), row = flat ? 0 : (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * a.Lr;
-                    v[u] = *reinterpret_cast<const float4*>(zo + row * a.Lp + col);
+                    const int idx = VW * std::min(iv + u * stn, nv - 1), row = flat ? 0 : (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * lrc;
+                    v[u] = *reinterpret_cast<const vec_t*>(zo + row * a.Lp + col);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (i4 + u * stn < n4) __builtin_memcpy(yo + 4 * (i4 + u * stn), &v[u], sizeof(float4));
+                    if (iv + u * stn < nv) __builtin_memcpy(yo + VW * (iv + u * stn), &v[u], sizeof(vec_t));
             }
-            for (int idx = (total & ~3) + st0; idx < total; idx += stn) {
-                const int row = flat ? 0 : (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * a.Lr;
+            for (int idx = nv * VW + st0; idx < total; idx += stn) {
+                const int row = flat ? 0 : (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * lrc;
                 yo[idx] = zo[row * a.Lp + col];
             }
         } else {
             for (int idx = st0; idx < total; idx += stn) {
-                const int row = (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * a.Lr;
+                const int row = (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * lrc;
                 yo[idx] = zo[row * a.Lp + col];
             }
         }
     };
     // Which row of the tile a row of the 16 x 16 product is: with odd Mr, the 16 EVEN (then the 16 odd) rows of a 32-row span put the
-    // 2 x 16 A-operand reads of a ds_read_b32 lane group on 32 different banks (16 consecutive rows collide two ways).
+    // 2 x 16 A-operand reads of a lane group on 32 different banks (16 consecutive rows collide two ways).
     const int ra = (a.Mr & 1) ? 2 : 1;
-    const auto rbase = [&](int c) { return 64 * wg + ((a.Mr & 1) ? 32 * (c >> 1) + (c & 1) : 16 * c); };
-    float* zout = zs + 2 * a.bufsz;
+    const auto rbase = [&](int c) { return 16 * CH * wg + ((a.Mr & 1) ? 32 * (c >> 1) + (c & 1) : 16 * c); };
+    R* zout = zs + 2 * (a.bufsz / (int)(sizeof(R) / 4));
     const int osz = Q * a.Lp;
     int cur = 0;
     int64_t prev_tile = -1;
@@ -441,17 +460,18 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
         const int nq = (int)std::min<int64_t>(Q, a.nrows - q0);
         const int64_t z0 = q0 * a.Mr + cbase;
         const int nz = nq * a.Mr + a.Mr + wtail;
-        const float* zt = zs + cur * a.bufsz;   // this tile's samples
-        float* zo = zout + cur * osz;           // this tile's outputs
+        const R* zt = zs + cur * (a.bufsz / (int)(sizeof(R) / 4));   // this tile's samples
+        R* zo = zout + cur * osz;                                      // this tile's outputs
         if (dma_ok(tile)) {
             if (is_dma) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of the tile has landed
         } else {  // the first tile(s) straddle the history
-            float* zw = zs + cur * a.bufsz;
-            for (int k2 = threadIdx.x; k2 < nz; k2 += blockDim.x) {
-                const int64_t zi = z0 + k2;
-                float v = 0.0f;
-                if (zi < a.hl) v = hc[zi];
-                else if (zi - a.hl < a.xlen) v = xc[zi - a.hl];
+            R* zw = zs + cur * (a.bufsz / (int)(sizeof(R) / 4));
+            for (int k2 = threadIdx.x; k2 < nz * CS; k2 += blockDim.x) {
+                const int64_t zi = z0 + k2 / CS;
+                const int part = k2 % CS;
+                R v = (R)0;
+                if (zi < a.hl) v = hc[zi * CS + part];
+                else if (zi - a.hl < a.xlen) v = xc[(zi - a.hl) * CS + part];
                 zw[k2] = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -460,22 +480,27 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
         dma(tile + gridDim.x, cur ^ 1);
         if (prev_tile >= 0) copy_out(prev_tile, zout + (cur ^ 1) * osz);
         if (is_comp) {
-            mm_f4 acc[4];
+            acc_t acc[CS][CH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mm_f4{0.0f, 0.0f, 0.0f, 0.0f};
-            const float* ap[4];   // A operand: row = lane % 16, k = lane / 16
+            for (int p = 0; p < CS; ++p)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ap[c] = zt + (ra * lj + rbase(c)) * a.Mr + c0 + lk;
+                for (int c = 0; c < CH; ++c) acc[p][c] = acc_t{(R)0, (R)0, (R)0, (R)0};
+            const R* ap[CH];   // A operand: row = lane % 16, k = lane / 16
+#pragma unroll
+            for (int c = 0; c < CH; ++c) ap[c] = zt + ((ra * lj + rbase(c)) * a.Mr + c0 + lk) * CS;
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[c][4 * t], hreg[t], acc[c], 0, 0, 0);
-            // D: register r of lane l is row 4 (l / 16) + r, column l % 16
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[t], acc[p][c]);
             if (16 * wb + lj < a.Lr) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) zo[(ra * (4 * lk + r) + rbase(c)) * a.Lp + 16 * wb + lj] = acc[c][r];
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int p = 0; p < CS; ++p) zo[(ra * Mm<R>::row(lk, r) + rbase(c)) * a.Lp + (16 * wb + lj) * CS + p] = acc[p][c][r];
             }
         }
         prev_tile = tile;
@@ -1009,22 +1034,28 @@ template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStrea
 }
 
 // ---- matrix-core kernel, host side ------------------------------------------------------------------------------
-// Shapes it is built for: Float32 x Float32, L <= 192, at most 128 window positions per block of 16 outputs, a tile that fits the LDS.
+// Shapes it is built for: Float32 taps x Float32 / ComplexF32 signals, and Float64 arithmetic on Float64 / ComplexF64 signals; L <= 192,
+// at most 128 window positions per block of 16 outputs, a tile that fits the LDS.
 // For L < 16 a row of the product is RB whole rounds (Lr = RB L <= 16 consecutive outputs, Mr = RB M samples): the columns of a
 // row still repeat their phases from row to row, which is all the kernel needs; RB is chosen so that rows (lane stride Mr samples)
 // spread over the LDS banks (odd Mr: conflict-free).
 struct FirMGeo {
     bool ok = false;
+    int esz = 4, CS = 1, CH = 4;   // bytes of R; parts per sample; 16-row chunks per multiplying wave
     int RB = 1, Lr = 0, Mr = 0, NB = 0, NG = 1, T = 0, Lp = 0, nd = 1, ns = 1;
-    int64_t bufsz = 0;
+    int64_t bufsz = 0;             // dwords per sample buffer
     size_t lds_bytes = 0;
 };
 int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : 32; }
 FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     FirMGeo g;
-    if (f->acc_double || f->x_dtype != MDSP_F32 || f->taps_dtype != MDSP_F32) return g;
+    // element type: signal and compute type must agree (Float32 taps x Float32 samples, or Float64 arithmetic on Float64 samples)
+    if (f->acc_double != dtype_is_double(f->x_dtype)) return g;
+    g.esz = f->acc_double ? 8 : 4;
+    g.CS = dtype_is_complex(f->x_dtype) ? 2 : 1;
+    g.CH = (g.esz == 4 && g.CS == 1) ? 4 : 2;
     if (f->L > 192 || f->M > 4096) return g;
-    if (f->L < 16) {   // rounds per row: most outputs per LDS cycle of the A-operand reads (16 rows x 2 taps per ds_read_b32 lane group)
+    if (f->L < 16) {   // rounds per row: most outputs per LDS cycle of the A-operand reads (16 rows x 2 taps per lane group)
         double best = -1;
         for (int rb = 1; rb * f->L <= 16; ++rb) {
             const int64_t mr = rb * f->M;
@@ -1044,10 +1075,11 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     const int64_t steps = cdiv(f->tp + ((f->L - 1) + (int64_t)(std::min(g.Lr, 16) - 1) * f->M) / f->L, (int64_t)4);   // tp + max delta within a block
     if (steps > 32) return g;
     g.T = fir_mm_tsel(steps);
-    g.Lp = g.NB == 1 ? g.Lr : 16 * g.NB + 4;
-    for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {   // the largest tile (64 NG rows) that leaves four memory waves and fits the LDS
-        const int64_t bufsz = cdiv((int64_t)64 * ng * g.Mr + g.Mr + 4 * g.T + 4, (int64_t)256) * 256;
-        const size_t bytes = (size_t)(2 * bufsz + 2 * 64 * ng * g.Lp) * sizeof(float);
+    g.Lp = g.NB == 1 ? g.Lr * g.CS : 16 * g.NB * g.CS + 16 / g.esz;
+    const int rows = 16 * g.CH, dw = g.esz / 4 * g.CS;
+    for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
+        const int64_t bufsz = cdiv(((int64_t)rows * ng * g.Mr + g.Mr + 4 * g.T + 4) * dw, (int64_t)256) * 256;
+        const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
         if (bytes <= 160 * 1024) {
             g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true;
             break;
@@ -1061,25 +1093,25 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
 }
 bool fir_mm_shape_ok(const mdsp_fir_s* f) { return fir_mm_geo(f).ok; }
 
-template <int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
+template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
     FirMArgs b{};
-    b.x = (const float*)a.x;
-    b.hist = (const float*)a.hist;
-    b.y = (float*)a.y;
-    b.pfbT = (const float*)a.pfbT;
+    b.x = a.x;
+    b.hist = a.hist;
+    b.y = a.y;
+    b.pfbT = a.pfbT;
     b.xlen = a.xlen; b.ldx = a.ldx; b.ldy = a.ldy; b.nout = a.nout;
     b.d0 = a.d0;
     b.L = a.L; b.M = a.M; b.hl = a.hl; b.tp = a.tp;
     b.Lr = g.Lr; b.Mr = g.Mr; b.NB = g.NB; b.NG = g.NG; b.Lp = g.Lp; b.nd = g.nd; b.ns = g.ns;
     b.nrows = cdiv(a.nout, (int64_t)g.Lr);
     b.lmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)a.L - 1) / (uint64_t)a.L);
-    b.rmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)g.Lr - 1) / (uint64_t)g.Lr);
+    b.rmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)(g.Lr * CS) - 1) / (uint64_t)(g.Lr * CS));
     b.phi0m1 = (int)a.phi0m1;
     b.bufsz = (int)g.bufsz;
     const int nw = g.NB * g.NG + g.nd + g.ns;
-    auto kern = polyphase_mfma_kernel<T>;
+    auto kern = polyphase_mfma_kernel<R, CS, CH, T>;
     if (g.lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-    const int64_t ntiles = cdiv(b.nrows, (int64_t)64 * g.NG);
+    const int64_t ntiles = cdiv(b.nrows, (int64_t)16 * CH * g.NG);
     int wgs = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(160 * 1024) / (int64_t)g.lds_bytes, 32 / nw));
     if (tunables().wg_per_cu > 0) wgs = tunables().wg_per_cu;
     const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch));
@@ -1089,17 +1121,21 @@ template <int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGe
     return MDSP_OK;
 }
 
-int fir_mm_dispatch_t(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
-    const FirMGeo g = fir_mm_geo(f);
+template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
     switch (g.T) {
-        case 4: return fir_mm_launch<4>(f, a, g, st);
-        case 8: return fir_mm_launch<8>(f, a, g, st);
-        case 12: return fir_mm_launch<12>(f, a, g, st);
-        case 16: return fir_mm_launch<16>(f, a, g, st);
-        case 20: return fir_mm_launch<20>(f, a, g, st);
-        case 24: return fir_mm_launch<24>(f, a, g, st);
-        default: return fir_mm_launch<32>(f, a, g, st);
+        case 4: return fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
+        case 8: return fir_mm_launch<R, CS, CH, 8>(f, a, g, st);
+        case 12: return fir_mm_launch<R, CS, CH, 12>(f, a, g, st);
+        case 16: return fir_mm_launch<R, CS, CH, 16>(f, a, g, st);
+        case 20: return fir_mm_launch<R, CS, CH, 20>(f, a, g, st);
+        case 24: return fir_mm_launch<R, CS, CH, 24>(f, a, g, st);
+        default: return fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
     }
+}
+int fir_mm_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
+    const FirMGeo g = fir_mm_geo(f);
+    if (g.esz == 4) return g.CS == 1 ? fir_mm_dispatch_t<float, 1, 4>(f, a, g, st) : fir_mm_dispatch_t<float, 2, 2>(f, a, g, st);
+    return g.CS == 1 ? fir_mm_dispatch_t<double, 1, 2>(f, a, g, st) : fir_mm_dispatch_t<double, 2, 2>(f, a, g, st);
 }
 
 // where the matrix-core kernel is used: the shape fits, and (unless forced) there are enough 64-round tiles to fill the device
@@ -1108,11 +1144,11 @@ bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
     const FirMGeo g = fir_mm_geo(f);
     if (!g.ok) return false;
     if (tunables().fir_mm == 1) return true;
-    return cdiv(cdiv(a.nout, (int64_t)g.Lr), (int64_t)64 * g.NG) * f->nch >= 2 * device_cu_count();
+    return cdiv(cdiv(a.nout, (int64_t)g.Lr), (int64_t)16 * g.CH * g.NG) * f->nch >= 2 * device_cu_count();
 }
 
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
-    if (fir_mm_use(f, a)) return fir_mm_dispatch_t(f, a, st);
+    if (fir_mm_use(f, a)) return fir_mm_dispatch(f, a, st);
     if (tunables().fir_p == 4 && f->tp <= 32 && fir_fast_ok(f, 4)) return fir_fast_dispatch<4>(f, a, st);   // tuning: four residues per thread
     if (tunables().fir_p == 3 && f->tp <= 32 && fir_fast_ok(f, 3)) return fir_fast_dispatch<3>(f, a, st);   // tuning: three residues per thread
     if (fir_fast_ok(f, 2)) return fir_fast_dispatch<2>(f, a, st);

@@ -415,21 +415,27 @@ def test_host_pipelines_with_padded_leading_dimensions(d, torch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "c32", "f64", "c64"])
 @pytest.mark.parametrize("L,M,ntaps", [(160, 147, 5120), (160, 147, 5921), (23, 17, 300), (16, 9, 129), (17, 35, 1100), (37, 2, 400), (250, 249, 4000), (14, 9, 64),
                                            (2, 1, 49), (1, 2, 31), (3, 2, 73), (2, 3, 61), (4, 1, 97), (1, 4, 40), (5, 3, 101), (1, 1, 33), (7, 4, 120), (25, 24, 700), (192, 191, 6000)])
-def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M, ntaps):
-    # The matrix-core kernel (v_mfma_f32_16x16x4_f32: 16 rounds x 16 residues, a k-ordered fmaf chain) and the register-tap kernel sum
-    # each output in the same order: bit-identical outputs and states, for any phase / deficit the stream is cut at, with ragged tails
-    # (nout not a multiple of L, L not a multiple of 16), several channels on an odd leading dimension, and against the oracle.
+def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M, ntaps, dt):
+    # The matrix-core kernel (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64: 16 rows x 16 outputs, a k-ordered fmaf chain) and the
+    # register-tap / generic kernels sum each output in the same order: bit-identical Float32 outputs (Float64: to rounding) and
+    # identical states, for any phase / deficit the stream is cut at, with ragged tails (nout not a multiple of L, L not a multiple
+    # of 16), several channels on an odd leading dimension, real and complex signals, and against the oracle.
     from fractions import Fraction
     from dsp_jl_amd import _lib
     from oracle import stream_filt as osf
     lib = _lib.lib()
+    tdt, hdt, ldt_h, ldt_x, tol = {"f32": (torch.float32, np.float32, _lib.F32, _lib.F32, 2e-6), "c32": (torch.complex64, np.float32, _lib.F32, _lib.C32, 2e-6),
+                                   "f64": (torch.float64, np.float64, _lib.F64, _lib.F64, 1e-13), "c64": (torch.complex128, np.float64, _lib.F64, _lib.C64, 1e-13)}[dt]
+    if dt != "f32" and (L, M) in ((160, 147), (250, 249), (192, 191)) and ntaps != 5120:
+        pytest.skip("the large shapes are run once per dtype")
     rng = np.random.default_rng(L * 1000 + M)
-    h = (rng.standard_normal(ntaps) / np.sqrt(ntaps / L)).astype(np.float32)
+    h = (rng.standard_normal(ntaps) / np.sqrt(ntaps / L)).astype(hdt)
     nch, n = 3, 200_003
     g = torch.Generator(device="cuda"); g.manual_seed(L + M)
-    x = torch.randn((nch, n), generator=g, device="cuda", dtype=torch.float32)
+    x = torch.randn((nch, n), generator=g, device="cuda", dtype=tdt)
     stream = torch.cuda.current_stream().cuda_stream
     cuts = (0, 1, 777, 100_000, n)
     outs = {}
@@ -437,17 +443,18 @@ def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M,
         for sg in (0, 1):
             _lib.set_tunable("MDSP_FIR_MM", sg)
             fh = C.c_void_p()
-            _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, _lib.F32, _lib.F32, nch))
+            _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, ldt_h, ldt_x, nch))
             pieces, states = [], []
             for a, b in zip(cuts[:-1], cuts[1:]):
                 ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, b - a, C.byref(ol)))
                 ldy = ol.value + 1
-                y = torch.full((nch, ldy), float("nan"), dtype=torch.float32, device="cuda")
+                y = torch.full((nch, ldy), complex(float("nan"), float("nan")) if tdt.is_complex else float("nan"), dtype=tdt, device="cuda")
                 nw = C.c_int64()
                 _lib.check(lib.mdsp_fir_exec(fh, x[:, a:].data_ptr(), b - a, n, y.data_ptr(), ol.value, ldy, C.byref(nw), stream))
                 torch.cuda.synchronize()
                 assert nw.value == ol.value
-                assert torch.isnan(y[:, ol.value:]).all() and not torch.isnan(y[:, :ol.value]).any()
+                assert torch.isnan(torch.view_as_real(y[:, ol.value:]) if y.is_complex() else y[:, ol.value:]).all()
+                assert not torch.isnan(torch.view_as_real(y[:, :ol.value]) if y.is_complex() else y[:, :ol.value]).any()
                 pieces.append(y[:, :ol.value].clone())
                 phi, dfc = C.c_int64(), C.c_int64()
                 _lib.check(lib.mdsp_fir_get_state(fh, C.byref(phi), C.byref(dfc), None))
@@ -457,16 +464,20 @@ def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M,
     finally:
         _lib.set_tunable("MDSP_FIR_MM", None)
     assert outs[0][1] == outs[1][1]
-    assert torch.equal(outs[0][0], outs[1][0])
+    if dt in ("f32", "c32"):
+        assert torch.equal(outs[0][0], outs[1][0])
+    else:
+        assert relerr(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy()) < 1e-14
     m = 20_000
-    ref = osf.FIRFilter(h.astype(np.float64), Fraction(L, M)).filt(x[1, :m].cpu().numpy().astype(np.float64))
-    assert relerr(outs[1][0][1, :len(ref)].cpu().numpy(), ref) < 2e-6
+    xr = x[1, :m].cpu().numpy()
+    ref = osf.FIRFilter(h.astype(np.float64), Fraction(L, M)).filt(xr.astype(np.complex128 if np.iscomplexobj(xr) else np.float64))
+    assert relerr(outs[1][0][1, :len(ref)].cpu().numpy(), ref) < tol
 
 
 @pytest.mark.gpu
 def test_polyphase_kernel_choice(d, torch):
     # BASELINE config 5's shape runs on the matrix-core kernel, short chunks of the same filter on the register-tap kernel, Float64 on
-    # the generic one -- a silent fallback would show up here, not as a slow benchmark.
+    # the matrix-core kernel in Float64, mixed precisions on the generic one -- a silent fallback would show up here, not as a slow benchmark.
     from dsp_jl_amd import _lib
     lib = _lib.lib()
     rng = np.random.default_rng(5)
@@ -483,8 +494,9 @@ def test_polyphase_kernel_choice(d, torch):
     h = rng.standard_normal(5120).astype(np.float32)
     assert path(h, 160, 147, _lib.F32, 4, 2 ** 28) == 2
     assert path(h, 160, 147, _lib.F32, 4, 10_000) == 1
-    assert path(h.astype(np.float64), 160, 147, _lib.F64, 4, 2 ** 28) == 0
-    assert path(h, 160, 147, _lib.C32, 4, 2 ** 28) == 0
+    assert path(h.astype(np.float64), 160, 147, _lib.F64, 4, 2 ** 28) == 2      # Float64 on v_mfma_f64_16x16x4_f64
+    assert path(h, 160, 147, _lib.C32, 4, 2 ** 28) == 2                         # complex signal: two products against the same taps
+    assert path(h.astype(np.float64), 160, 147, _lib.F32, 4, 2 ** 28) == 0      # Float64 taps on a Float32 signal: generic kernel
     assert path(rng.standard_normal(48).astype(np.float32), 2, 1, _lib.F32, 1, 2 ** 26) == 2      # interpolation by 2: a row is 7 rounds
     assert path(rng.standard_normal(64).astype(np.float32), 1, 2, _lib.F32, 1, 2 ** 26) == 2      # decimation by 2
     assert path(rng.standard_normal(4000).astype(np.float32), 250, 249, _lib.F32, 1, 2 ** 26) == 1  # L > 192

@@ -23,17 +23,21 @@ nch, n = int(os.environ.get("TUNE_NCH", "4")), 1 << log2n
 L, M = (int(v) for v in os.environ.get("TUNE_RATIO", "160/147").split("/"))
 variants = [tuple(int(t) for t in v.split(",")) for v in os.environ.get("TUNE_FIR", "0,0,0;1,0,0;1,2,0;1,1,0").split(";")]
 g = torch.Generator(device="cuda"); g.manual_seed(1776)
-x = torch.randn((nch, n), generator=g, device="cuda", dtype=torch.float32)
+DT = os.environ.get("TUNE_DTYPE", "f32")   # f32 | f64 | c32 | c64 (complex signal, real taps)
+tdt, xdt, ydt, esz, lt, lx = {"f32": (torch.float32, np.float32, torch.float32, 4, _lib.F32, _lib.F32), "f64": (torch.float64, np.float64, torch.float64, 8, _lib.F64, _lib.F64),
+                              "c32": (torch.complex64, np.float32, torch.complex64, 8, _lib.F32, _lib.C32),
+                              "c64": (torch.complex128, np.float64, torch.complex128, 16, _lib.F64, _lib.C64)}[DT]
+x = torch.randn((nch, n), generator=g, device="cuda", dtype=tdt)
 stream = torch.cuda.current_stream().cuda_stream
-h = np.asarray(d.resample_filter(Fraction(L, M)), dtype=np.float32)
+h = np.asarray(d.resample_filter(Fraction(L, M)), dtype=xdt)
 ntaps = int(os.environ.get("TUNE_TAPS", "5120" if (L, M) == (160, 147) else "0"))   # config 5: 5120 taps = 32 per phase
 if ntaps:
-    h = np.concatenate([h, np.zeros(ntaps - len(h), np.float32)]) if len(h) < ntaps else h[:ntaps].copy()
+    h = np.concatenate([h, np.zeros(ntaps - len(h), xdt)]) if len(h) < ntaps else h[:ntaps].copy()
 fh = C.c_void_p()
-_lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, _lib.F32, _lib.F32, nch))
+_lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, lt, lx, nch))
 ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, n, C.byref(ol)))
 ldy = ol.value + int(os.environ.get("TUNE_LDPAD", "0"))
-y = torch.empty((nch, ldy), dtype=torch.float32, device="cuda")
+y = torch.empty((nch, ldy), dtype=ydt, device="cuda")
 nw = C.c_int64()
 
 
@@ -60,7 +64,7 @@ def timeit():
     return ms.value
 
 
-res = {"log2n": log2n, "nch": nch, "ratio": f"{L}//{M}", "taps": len(h), "nout": ol.value, "variants": {}}
+res = {"dtype": DT, "log2n": log2n, "nch": nch, "ratio": f"{L}//{M}", "taps": len(h), "nout": ol.value, "variants": {}}
 ref = None
 for v in variants:
     select(v); y.zero_(); run(); torch.cuda.synchronize()
@@ -68,11 +72,12 @@ for v in variants:
         ref = y.clone()
     key = "mm={} wg_per_cu={} p={}".format(*v[:3])
     res["variants"][key] = {"maxdiff_vs_first": float((y - ref).abs().max()), "ms": []}
+    del_ref = None
 for r in range(rounds):
     for v in variants:
         select(v)
         res["variants"]["mm={} wg_per_cu={} p={}".format(*v[:3])]["ms"].append(round(timeit(), 4))
-bytes_alg = (4 + 4 * L / M) * n * nch
+bytes_alg = (esz + esz * L / M) * n * nch
 for k, e in res["variants"].items():
     e["median_ms"] = float(np.median(e["ms"]))
     e["GBps"] = round(bytes_alg / e["median_ms"] / 1e6, 1)
