@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Matrix-core path (Float32 taps and real Float32 signal, L >= 16): the polyphase bank as the B operand of v_mfma_f32_16x16x4_f32.
+// Matrix-core path: the polyphase bank as the B operand of v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 (Float32 taps on Float32 /
+// ComplexF32 signals, Float64 arithmetic on Float64 / ComplexF64 signals; any ratio with L <= 192).
 //
 // The register-tap kernel above is bound by the LDS and the vector ALU: P = 2 residues share one window (16.5 ds_read_b32 and
 // 16.5 v_pk_fma_f32 per output; 68 % LDS-array busy, and v_pk_fma_f32 issues at the v_fma_f32 rate, 16 FMA/clk/SIMD), more residues
@@ -285,8 +286,9 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 //            that only issue the DMA of the next tile and ns waves that only store the previous tile's outputs: the memory
 //            waves work through the whole tile period beside the MFMAs, one s_barrier per tile
 //   LDS    = two sample buffers + two output buffers (config 5: 2 x 38 KiB + 2 x 41 KiB = 158 KiB, one workgroup of 16 waves per CU)
+// For L < 16 a row of the product is RB whole rounds (RB L <= 16 consecutive outputs, RB M samples): see fir_mm_geo().
 // Measured on BASELINE config 5 (4 ch x 2^28, 160//147, 5120 taps): 1.86 ms = 4.8 TB/s of algorithmic traffic, the device-copy
-// rate of this GPU, against 2.4 - 2.5 ms for the register-tap kernel (profiles/r02q_*).
+// rate of this GPU, against 2.4 - 2.5 ms for the register-tap kernel (profiles/r02q_*); other ratios and types: DESIGN.md section 4.6.
 // ------------------------------------------------------------------------------------------------------------
 struct FirMArgs {
     const void* x;               // (xlen, nch) samples: R or (R, R) pairs
