@@ -120,7 +120,7 @@ struct Tunables {
     int64_t arb_scan_min = (int64_t)1 << 19;   // MDSP_ARB_SCAN_MIN : outputs from which the device scan is used
     int host_chunk_mib = 64;            // MDSP_HOST_CHUNK_MIB      : pinned staging chunk of the host-pointer entry points
     int fir_p = 0;                      // MDSP_FIR_P=4             : four output residues per thread in the fast polyphase kernel (default 2)
-    int fir_mm = -1;                    // MDSP_FIR_MM=0|1          : matrix-core polyphase kernel off / wherever the shape fits (-1: where it pays)
+    int fir_mm = -1;                    // MDSP_FIR_MM=0            : matrix-core polyphase kernel off (default: wherever the shape fits)
     int ols_prefetch = 0;               // MDSP_OLS_PREFETCH=1      : overlap-save kernel with software prefetch of the next unit (default: off)
 #ifdef MDSP_DEBUG_KNOBS
     // Profiling / bisecting switches: only in builds made with -DMDSP_DEBUG_KNOBS (build.py --tag dbg --cflags -DMDSP_DEBUG_KNOBS).

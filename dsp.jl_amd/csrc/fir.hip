@@ -1140,13 +1140,11 @@ int fir_mm_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
     return g.CS == 1 ? fir_mm_dispatch_t<double, 1, 2>(f, a, g, st) : fir_mm_dispatch_t<double, 2, 2>(f, a, g, st);
 }
 
-// where the matrix-core kernel is used: the shape fits, and (unless forced) there are enough 64-round tiles to fill the device
+// where the matrix-core kernel is used: wherever the shape fits -- it is the faster kernel from 2^16 samples (0.019 against 0.042 ms,
+// one channel 2//1) to 2^28 (profiles/r02r_tune_fir); MDSP_FIR_MM=0 turns it off
 bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
-    if (tunables().fir_mm == 0) return false;
-    const FirMGeo g = fir_mm_geo(f);
-    if (!g.ok) return false;
-    if (tunables().fir_mm == 1) return true;
-    return cdiv(cdiv(a.nout, (int64_t)g.Lr), (int64_t)16 * g.CH * g.NG) * f->nch >= 2 * device_cu_count();
+    (void)a;
+    return tunables().fir_mm != 0 && fir_mm_geo(f).ok;
 }
 
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {

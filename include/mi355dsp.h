@@ -269,8 +269,8 @@ int mdsp_fir_inputlength(mdsp_fir f, int64_t outputlength, int round_up, int64_t
 int mdsp_fir_info(mdsp_fir f, int* kind /*0 std,1 interp,2 decim,3 rational*/, int64_t* L, int64_t* M,
                   int64_t* taps_per_phase, int64_t* history_len, int* out_dtype);
 /* Which kernel mdsp_fir_exec would run for a chunk of `xlen` samples in the filter's current state: 0 generic polyphase kernel
- * (any dtype), 1 register-tap kernel (Float32, <= 64 taps per phase), 2 matrix-core kernel (Float32; rows of 16 outputs on
- * v_mfma_f32_16x16x4_f32, bit-identical to 1).  Diagnostics / tests: the choice never changes results beyond the sign of a zero. */
+ * (any dtype), 1 register-tap kernel (Float32, <= 64 taps per phase), 2 matrix-core kernel (rows of 16 outputs on
+ * v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64; Float32 results bit-identical to 0 / 1).  Diagnostics / tests: the choice never changes results beyond the sign of a zero. */
 int mdsp_fir_kernel_path(mdsp_fir f, int64_t xlen, int* path);
 /* state is exactly the reference's: 1-based phi_idx and input_deficit, history (history_len, nch) of x_dtype */
 int mdsp_fir_get_state(mdsp_fir f, int64_t* phi_idx, int64_t* input_deficit, void* history_host);
