@@ -1037,7 +1037,7 @@ template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStrea
 
 // ---- matrix-core kernel, host side ------------------------------------------------------------------------------
 // Shapes it is built for: Float32 taps x Float32 / ComplexF32 signals, and Float64 arithmetic on Float64 / ComplexF64 signals; L <= 192,
-// at most 128 window positions per block of 16 outputs, a tile that fits the LDS.
+// at most 256 (Float64: 128) window positions per block of 16 outputs, a tile that fits the LDS.
 // For L < 16 a row of the product is RB whole rounds (Lr = RB L <= 16 consecutive outputs, Mr = RB M samples): the columns of a
 // row still repeat their phases from row to row, which is all the kernel needs; RB is chosen so that rows (lane stride Mr samples)
 // spread over the LDS banks (odd Mr: conflict-free).
@@ -1048,7 +1048,7 @@ struct FirMGeo {
     int64_t bufsz = 0;             // dwords per sample buffer
     size_t lds_bytes = 0;
 };
-int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : 32; }
+int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : steps <= 32 ? 32 : steps <= 48 ? 48 : 64; }
 FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     FirMGeo g;
     // element type: signal and compute type must agree (Float32 taps x Float32 samples, or Float64 arithmetic on Float64 samples)
@@ -1075,7 +1075,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     g.Mr = g.RB * (int)f->M;
     g.NB = (int)cdiv((int64_t)g.Lr, (int64_t)16);
     const int64_t steps = cdiv(f->tp + ((f->L - 1) + (int64_t)(std::min(g.Lr, 16) - 1) * f->M) / f->L, (int64_t)4);   // tp + max delta within a block
-    if (steps > 32) return g;
+    if (steps > (g.esz == 8 ? 32 : 64)) return g;   // taps live in registers: T (Float64: 2 T) VGPRs
     g.T = fir_mm_tsel(steps);
     g.Lp = g.NB == 1 ? g.Lr * g.CS : 16 * g.NB * g.CS + 16 / g.esz;
     const int rows = 16 * g.CH, dw = g.esz / 4 * g.CS;
@@ -1131,7 +1131,10 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
         case 16: return fir_mm_launch<R, CS, CH, 16>(f, a, g, st);
         case 20: return fir_mm_launch<R, CS, CH, 20>(f, a, g, st);
         case 24: return fir_mm_launch<R, CS, CH, 24>(f, a, g, st);
-        default: return fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
+        case 32: return fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
+        default:
+            if constexpr (sizeof(R) == 4) return g.T == 48 ? fir_mm_launch<R, CS, CH, 48>(f, a, g, st) : fir_mm_launch<R, CS, CH, 64>(f, a, g, st);
+            else return fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
     }
 }
 int fir_mm_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
