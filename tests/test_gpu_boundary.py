@@ -500,3 +500,59 @@ def test_polyphase_kernel_choice(d, torch):
     assert path(rng.standard_normal(48).astype(np.float32), 2, 1, _lib.F32, 1, 2 ** 26) == 2      # interpolation by 2: a row is 7 rounds
     assert path(rng.standard_normal(64).astype(np.float32), 1, 2, _lib.F32, 1, 2 ** 26) == 2      # decimation by 2
     assert path(rng.standard_normal(4000).astype(np.float32), 250, 249, _lib.F32, 1, 2 ** 26) == 1  # L > 192
+
+
+@pytest.mark.gpu
+def test_polyphase_matrix_core_kernel_fuzz(d, torch):
+    # Random ratios, tap counts, start phases and chunkings: the matrix-core kernel against the register-tap / generic kernels
+    # (bit for bit in Float32) and the filter state after every chunk.
+    from math import gcd
+    from dsp_jl_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(20260925)
+    stream = torch.cuda.current_stream().cuda_stream
+    tried = used = 0
+    try:
+        for it in range(60):
+            L = int(rng.integers(1, 200)); M = int(rng.integers(1, 260))
+            g0 = gcd(L, M); L //= g0; M //= g0
+            tp = int(rng.integers(1, 70))
+            ntaps = int(max(1, tp * L - rng.integers(0, L)))
+            h = rng.standard_normal(ntaps).astype(np.float32)
+            nch = int(rng.integers(1, 4))
+            n = int(rng.integers(1, 60_000))
+            cplx = bool(rng.integers(0, 2))
+            tdt = torch.complex64 if cplx else torch.float32
+            x = torch.randn((nch, n), device="cuda", dtype=tdt)
+            cuts = sorted({0, n, *[int(c) for c in rng.integers(0, n + 1, size=3)]})
+            phi = float(rng.random()) if rng.integers(0, 2) else None
+            res = {}
+            for mm in (0, 1):
+                _lib.set_tunable("MDSP_FIR_MM", mm)
+                fh = C.c_void_p()
+                _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, _lib.F32, _lib.C32 if cplx else _lib.F32, nch))
+                if phi is not None and not (L == 1 and M == 1):
+                    _lib.check(lib.mdsp_fir_setphase(fh, phi))
+                pth = C.c_int(-1); _lib.check(lib.mdsp_fir_kernel_path(fh, n, C.byref(pth)))
+                if mm == 1:
+                    tried += 1; used += pth.value == 2
+                pieces, states = [], []
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, b - a, C.byref(ol)))
+                    y = torch.zeros((nch, ol.value + 3), dtype=tdt, device="cuda")
+                    nw = C.c_int64()
+                    _lib.check(lib.mdsp_fir_exec(fh, x[:, a:].data_ptr(), b - a, n, y.data_ptr(), ol.value, ol.value + 3, C.byref(nw), stream))
+                    torch.cuda.synchronize()
+                    assert nw.value == ol.value and not y[:, ol.value:].abs().any()
+                    pieces.append(y[:, :ol.value].clone())
+                    p_, d_ = C.c_int64(), C.c_int64()
+                    _lib.check(lib.mdsp_fir_get_state(fh, C.byref(p_), C.byref(d_), None))
+                    states.append((p_.value, d_.value))
+                res[mm] = (torch.cat(pieces, dim=1) if pieces else None, states)
+                _lib.check(lib.mdsp_fir_destroy(fh))
+            assert res[0][1] == res[1][1], (L, M, ntaps)
+            if res[0][0] is not None:
+                assert torch.equal(res[0][0], res[1][0]), (L, M, ntaps, nch, n, cplx, cuts)
+    finally:
+        _lib.set_tunable("MDSP_FIR_MM", None)
+    assert used >= tried // 2          # most random shapes fit the matrix-core kernel
