@@ -419,6 +419,11 @@ function timedelay(f::FIRFilter)                                                
     τ = Ref{Cdouble}(0)
     check(ccall((:mdsp_fir_timedelay, lib), Cint, (Ptr{Cvoid}, Ref{Cdouble}), f.h, τ)); τ[]
 end
+# which device kernel a chunk of `n` samples would take: 0 generic, 1 register-tap, 2 matrix-core (diagnostics; results do not depend on it)
+function kernel_path(f::FIRFilter, n::Integer)
+    p = Ref{Cint}(-1)
+    check(ccall((:mdsp_fir_kernel_path, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Cint}), f.h, n, p)); Int(p[])
+end
 function outputlength(f::FIRFilter, inlen::Integer)                                                        # :324-338
     o = Ref{Int64}(0)
     check(ccall((:mdsp_fir_outputlength, lib), Cint, (Ptr{Cvoid}, Int64, Ref{Int64}), f.h, inlen, o)); Int(o[])
