@@ -24,6 +24,8 @@
 #include <numeric>
 #include <vector>
 
+#include <atomic>
+
 #include "common.h"
 #include "devio.h"
 #include "arb_scan.h"
@@ -623,9 +625,12 @@ template <typename R> struct alignas(2 * sizeof(R)) Tap2 {   // (pfb, dpfb) of o
 __device__ const unsigned char ARB_B128_ORDER[32] = {0,  1,  2,  3,  16, 17, 18, 19, 20, 21, 22, 23, 4,  5,  6,  7,
                                                      24, 25, 26, 27, 8,  9,  10, 11, 12, 13, 14, 15, 28, 29, 30, 31};
 
-template <typename A, typename R, int NCH>
-__device__ __forceinline__ void arb_tile_staged(const ArbRec* rec, const Tap2<R>* __restrict__ pf, const A* zs, A* const (&yc)[NCH], int nc, int cnt,
-                                                int tp, int nphi) {
+// NPHI: the number of phases when it is known at compile time (32, the reference's default: the tap reads of an unrolled batch
+// then differ by immediate offsets from one address register instead of one register and one v_add each), 0: run-time nphi
+template <typename A, typename R, int NCH, int NPHI>
+__device__ __forceinline__ void arb_tile_staged_n(const ArbRec* rec, const Tap2<R>* __restrict__ pf, const A* zs, A* const (&yc)[NCH], int nc, int cnt,
+                                                  int tp, int nphi_rt) {
+    const int nphi = NPHI ? NPHI : nphi_rt;
     struct alignas(sizeof(A) * NCH <= 16 ? sizeof(A) * NCH : 16) ZV {
         A v[NCH];
     };
@@ -648,8 +653,7 @@ __device__ __forceinline__ void arb_tile_staged(const ArbRec* rec, const Tap2<R>
         }
 #pragma unroll 8
         for (int i = 1; i < tp; ++i) {
-            hq += nphi;
-            const Tap2<R> t = *hq;
+            const Tap2<R> t = hq[i * nphi];
             const ZV z = zp[i];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -661,6 +665,12 @@ __device__ __forceinline__ void arb_tile_staged(const ArbRec* rec, const Tap2<R>
         for (int c = 0; c < NCH; ++c)
             if (c < nc) yc[c][j] = arb_combine(up[c], rc.alpha, lo[c]);
     }
+}
+template <typename A, typename R, int NCH>
+__device__ __forceinline__ void arb_tile_staged(const ArbRec* rec, const Tap2<R>* __restrict__ pf, const A* zs, A* const (&yc)[NCH], int nc, int cnt,
+                                                int tp, int nphi) {
+    if (nphi == 32) arb_tile_staged_n<A, R, NCH, 32>(rec, pf, zs, yc, nc, cnt, tp, nphi);
+    else arb_tile_staged_n<A, R, NCH, 0>(rec, pf, zs, yc, nc, cnt, tp, nphi);
 }
 
 template <typename XS, typename A, typename R, int NCH>
@@ -1112,7 +1122,14 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
     b.bufsz = (int)g.bufsz;
     const int nw = g.NB * g.NG + g.nd + g.ns;
     auto kern = polyphase_mfma_kernel<R, CS, CH, T>;
-    if (g.lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+    static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB
+    int dev = 0;
+    MDSP_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(lds_opt_in.load(std::memory_order_acquire) & bit)) {
+        MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_opt_in.fetch_or(bit, std::memory_order_release);
+    }
     const int64_t ntiles = cdiv(b.nrows, (int64_t)16 * CH * g.NG);
     int wgs = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(160 * 1024) / (int64_t)g.lds_bytes, 32 / nw));
     if (tunables().wg_per_cu > 0) wgs = tunables().wg_per_cu;
