@@ -1099,8 +1099,12 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     }
     if (!g.ok) return g;
     const int extra = 16 - g.NB * g.NG;   // memory waves beside the multiplying ones (16 waves per workgroup at most)
-    g.nd = extra >= 6 ? 2 : 1;
-    g.ns = std::max(1, std::min(4, extra - g.nd));
+    g.nd = extra >= 4 ? 2 : 1;
+    g.ns = std::max(1, std::min(f->L >= f->M ? 2 : 4, extra - g.nd));   // measured: two store waves when the ratio is >= 1 (160//147 1.94 -> 1.87 ms, 2//1 1.01 -> 0.93), four below (1//2 0.48 -> 0.45)
+    if (tunables().fir_mm_nd > 0 && tunables().fir_mm_ns > 0 && tunables().fir_mm_nd + tunables().fir_mm_ns <= extra) {   // tuning knobs
+        g.nd = tunables().fir_mm_nd;
+        g.ns = tunables().fir_mm_ns;
+    }
     return g;
 }
 bool fir_mm_shape_ok(const mdsp_fir_s* f) { return fir_mm_geo(f).ok; }

@@ -55,6 +55,7 @@ def run():
 
 def select(v):
     _lib.set_tunable("MDSP_FIR_MM", str(v[0])); _lib.set_tunable("MDSP_WG_PER_CU", str(v[1])); _lib.set_tunable("MDSP_FIR_P", str(v[2]))
+    _lib.set_tunable("MDSP_FIR_MM_ND", str(v[3]) if len(v) > 3 else "0"); _lib.set_tunable("MDSP_FIR_MM_NS", str(v[4]) if len(v) > 4 else "0")
 
 
 def timeit():
@@ -70,13 +71,13 @@ for v in variants:
     select(v); y.zero_(); run(); torch.cuda.synchronize()
     if ref is None:
         ref = y.clone()
-    key = "mm={} wg_per_cu={} p={}".format(*v[:3])
+    key = "mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "")
     res["variants"][key] = {"maxdiff_vs_first": float((y - ref).abs().max()), "ms": []}
     del_ref = None
 for r in range(rounds):
     for v in variants:
         select(v)
-        res["variants"]["mm={} wg_per_cu={} p={}".format(*v[:3])]["ms"].append(round(timeit(), 4))
+        res["variants"]["mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "")]["ms"].append(round(timeit(), 4))
 bytes_alg = (esz + esz * L / M) * n * nch
 for k, e in res["variants"].items():
     e["median_ms"] = float(np.median(e["ms"]))
