@@ -310,6 +310,31 @@ def measure_rows(tm, lib, _lib, d, stream):
     _lib.check(lib.mdsp_firarb_destroy(fa))
     del x, y, ya
     torch.cuda.empty_cache()
+    # the same resampler on the other signal types (DSP.jl's default is Float64), and two small ratios: 4 channels x 2^26 samples
+    n2 = 1 << 26
+    for name, tdt, hdt, lt, lx, esz, (L, M) in (("resample_f64", torch.float64, np.float64, _lib.F64, _lib.F64, 8, (160, 147)),
+                                                ("resample_c32", torch.complex64, np.float32, _lib.F32, _lib.C32, 8, (160, 147)),
+                                                ("interp2_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (2, 1)),
+                                                ("decim2_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (1, 2))):
+        from fractions import Fraction
+        hh = resample_taps().astype(hdt) if (L, M) == (160, 147) else np.asarray(d.resample_filter(Fraction(L, M)), dtype=hdt)
+        xx = torch.randn((nch, n2), generator=g, device="cuda", dtype=tdt)
+        f2 = C.c_void_p()
+        _lib.check(lib.mdsp_fir_create(C.byref(f2), hh.ctypes.data_as(C.c_void_p), len(hh), L, M, lt, lx, nch))
+        o2 = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(f2, n2, C.byref(o2)))
+        yy = torch.empty((nch, o2.value + 1), dtype=tdt, device="cuda")
+        pth = C.c_int(-1); _lib.check(lib.mdsp_fir_kernel_path(f2, n2, C.byref(pth)))
+
+        def fir2():
+            _lib.check(lib.mdsp_fir_reset(f2))
+            _lib.check(lib.mdsp_fir_exec(f2, xx.data_ptr(), n2, n2, yy.data_ptr(), o2.value, o2.value + 1, C.byref(nw), stream))
+
+        med, best = tm.time(fir2)
+        rows[name] = roof(f"{('generic', 'register-tap', 'matrix-core')[pth.value]} polyphase kernel ({L}//{M}, {len(hh)} taps, 4 ch x 2^26 {str(tdt).split('.')[-1]}, {esz * (1 + L / M):.2f} B/sample)",
+                          med, esz * (1 + L / M) * n2 * nch, extra={"Gsamples_per_s": round(n2 * nch / med / 1e6, 2), "best_ms": round(best, 4)})
+        _lib.check(lib.mdsp_fir_destroy(f2))
+        del xx, yy
+    torch.cuda.empty_cache()
     return rows
 
 
