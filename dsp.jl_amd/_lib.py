@@ -123,6 +123,7 @@ PROTOTYPES = {
     "mdsp_fir_inputlength": (ci, [vp, i64, ci, pi64]),
     "mdsp_fir_info": (ci, [vp, pint, pi64, pi64, pi64, pi64, pint]),
     "mdsp_fir_kernel_path": (ci, [vp, i64, pint]),
+    "mdsp_fir_mm_geometry": (ci, [i64, i64, i64, ci, ci, pi64]),
     "mdsp_fir_get_state": (ci, [vp, pi64, pi64, vp]),
     "mdsp_fir_set_state": (ci, [vp, i64, i64, vp]),
     "mdsp_fir_exec": (ci, [vp, vp, i64, i64, vp, i64, i64, pi64, vp]),

@@ -1332,6 +1332,26 @@ int mdsp_fir_info(mdsp_fir f, int* kind, int64_t* L, int64_t* M, int64_t* taps_p
     return MDSP_OK;
 }
 
+int mdsp_fir_mm_geometry(int64_t L, int64_t M, int64_t hlen, int taps_dtype, int x_dtype, int64_t* out12) {
+    if (!out12) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
+    if (L < 1 || M < 1 || hlen < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "L, M, hlen must be positive");
+    if ((taps_dtype != MDSP_F32 && taps_dtype != MDSP_F64) || !dtype_valid(x_dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype");
+    const int64_t g0 = gcd64(L, M);
+    mdsp_fir_s f;   // no device objects are touched: pure geometry
+    f.L = L / g0;
+    f.M = M / g0;
+    f.hlen = hlen;
+    f.tp = cdiv(hlen, f.L);
+    f.hl = f.tp - 1;
+    f.taps_dtype = taps_dtype;
+    f.x_dtype = x_dtype;
+    f.acc_double = (taps_dtype == MDSP_F64) || dtype_is_double(x_dtype);
+    const FirMGeo g = fir_mm_geo(&f);
+    const int64_t v[12] = {g.ok ? 1 : 0, g.RB, g.Lr, g.Mr, g.NB, g.NG, g.T, g.CH, g.CS, g.nd, g.ns, (int64_t)g.lds_bytes};
+    for (int i = 0; i < 12; ++i) out12[i] = v[i];
+    return MDSP_OK;
+}
+
 int mdsp_fir_kernel_path(mdsp_fir f, int64_t xlen, int* path) {
     if (!f || !path) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
     if (xlen < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");

@@ -441,3 +441,51 @@ def test_julia_twin_binds_only_exported_symbols_with_matching_arity():
         assert name in _lib.PROTOTYPES and hasattr(lib, name), name
         n = len([t for t in types.split(",") if t.strip()])
         assert n == len(_lib.PROTOTYPES[name][1]), (name, n, len(_lib.PROTOTYPES[name][1]))
+
+
+def test_matrix_core_polyphase_geometry_is_consistent():
+    # mdsp_fir_mm_geometry is the host arithmetic that sizes the matrix-core polyphase kernel (rows of RB rounds, blocks of 16 outputs,
+    # k-steps, LDS buffers, wave roles): pure integer code, checked here without a device over random ratios and tap counts.
+    import ctypes as C
+    from math import gcd
+    from dsp_jl_amd import _lib
+    lib = _lib.lib()
+    out = (C.c_int64 * 12)()
+
+    def geo(L, M, hlen, tdt, xdt):
+        _lib.check(lib.mdsp_fir_mm_geometry(L, M, hlen, tdt, xdt, out))
+        return list(out)
+
+    assert geo(160, 147, 5120, _lib.F32, _lib.F32) == [1, 1, 160, 147, 10, 1, 12, 4, 1, 2, 2, 161792]      # BASELINE config 5
+    assert geo(320, 294, 5120, _lib.F32, _lib.F32)[:5] == [1, 1, 160, 147, 10]                             # ratios are reduced first
+    g = geo(2, 1, 75, _lib.F32, _lib.F32)
+    assert g[0] == 1 and g[1] == 7 and g[2] == 14 and g[3] == 7                                             # a row is 7 rounds: odd sample stride
+    assert geo(250, 249, 4000, _lib.F32, _lib.F32)[0] == 0                                                  # L > 192
+    assert geo(160, 147, 5120, _lib.F64, _lib.F32)[0] == 0                                                  # Float64 taps on a Float32 signal
+    assert geo(160, 147, 5120, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
+    assert geo(1, 2, 64 * 4 + 1, _lib.F32, _lib.F32)[0] == 0                                                # more than 256 window positions
+    rng = np.random.default_rng(42)
+    fits = 0
+    for _ in range(3000):
+        L, M = int(rng.integers(1, 260)), int(rng.integers(1, 700))
+        hlen = int(rng.integers(1, 9000))
+        tdt = [_lib.F32, _lib.F64][int(rng.integers(0, 2))]
+        xdt = [_lib.F32, _lib.F64, _lib.C32, _lib.C64][int(rng.integers(0, 4))]
+        ok, RB, Lr, Mr, NB, NG, T, CH, CS, nd, ns, lds = geo(L, M, hlen, tdt, xdt)
+        g0 = gcd(L, M); Lq, Mq = L // g0, M // g0
+        dbl = tdt == _lib.F64 or xdt in (_lib.F64, _lib.C64)
+        if not ok:
+            continue
+        fits += 1
+        tp = -(-hlen // Lq)
+        assert dbl == (xdt in (_lib.F64, _lib.C64))                       # compute type == signal type
+        assert Lq <= 192 and Lr == RB * Lq and Mr == RB * Mq and (RB == 1 if Lq >= 16 else Lr <= 16)
+        assert NB == -(-Lr // 16) and 1 <= NG <= 8 and NB * NG + nd + ns <= 16 and nd >= 1 and ns >= 1
+        assert CS == (2 if xdt in (_lib.C32, _lib.C64) else 1) and CH == (4 if (not dbl and CS == 1) else 2)
+        dmax = ((Lq - 1) + (min(Lr, 16) - 1) * Mq) // Lq
+        assert 4 * T >= tp + dmax and T <= (32 if dbl else 64)           # every tap of every column of a block has a k-step
+        esz = 8 if dbl else 4
+        rows = 16 * CH * NG
+        need = 2 * 4 * (-(-((rows * Mr + Mr + 4 * T + 4) * (esz // 4) * CS) // 256) * 256) + 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + 16 // esz) * esz
+        assert lds == need <= 160 * 1024
+    assert fits > 300
