@@ -452,8 +452,9 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     };
     // Which row of the tile a row of the 16 x 16 product is: with odd Mr, the 16 EVEN (then the 16 odd) rows of a 32-row span put the
     // 2 x 16 A-operand reads of a lane group on 32 different banks (16 consecutive rows collide two ways).
-    const int ra = (a.Mr & 1) ? 2 : 1;
-    const auto rbase = [&](int c) { return 16 * CH * wg + ((a.Mr & 1) ? 32 * (c >> 1) + (c & 1) : 16 * c); };
+    const bool eo = CH >= 2 && (a.Mr & 1);   // (a single 16-row chunk per wave keeps consecutive rows)
+    const int ra = eo ? 2 : 1;
+    const auto rbase = [&](int c) { return 16 * CH * wg + (eo ? 32 * (c >> 1) + (c & 1) : 16 * c); };
     R* zout = zs + 2 * (a.bufsz / (int)(sizeof(R) / 4));
     const int osz = Q * a.Lp;
     int cur = 0;
@@ -1065,7 +1066,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     if (f->acc_double != dtype_is_double(f->x_dtype)) return g;
     g.esz = f->acc_double ? 8 : 4;
     g.CS = dtype_is_complex(f->x_dtype) ? 2 : 1;
-    g.CH = (g.esz == 4 && g.CS == 1) ? 4 : 2;
+    const int chmax = (g.esz == 4 && g.CS == 1) ? 4 : 2;   // 16-row chunks per multiplying wave: fewer when the tile would not fit the LDS
     if (f->L > 192 || f->M > 4096) return g;
     if (f->L < 16) {   // rounds per row: most outputs per LDS cycle of the A-operand reads (16 rows x 2 taps per lane group)
         double best = -1;
@@ -1088,13 +1089,17 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     if (steps > (g.esz == 8 ? 32 : 64)) return g;   // taps live in registers: T (Float64: 2 T) VGPRs
     g.T = fir_mm_tsel(steps);
     g.Lp = g.NB == 1 ? g.Lr * g.CS : 16 * g.NB * g.CS + 16 / g.esz;
-    const int rows = 16 * g.CH, dw = g.esz / 4 * g.CS;
-    for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
-        const int64_t bufsz = cdiv(((int64_t)rows * ng * g.Mr + g.Mr + 4 * g.T + 4) * dw, (int64_t)256) * 256;
-        const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
-        if (bytes <= 160 * 1024) {
-            g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true;
-            break;
+    const int dw = g.esz / 4 * g.CS;
+    int best_rows = 0;
+    for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
+        const int rows = 16 * ch;
+        for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {
+            const int64_t bufsz = cdiv(((int64_t)rows * ng * g.Mr + g.Mr + 4 * g.T + 4) * dw, (int64_t)256) * 256;
+            const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
+            if (bytes <= 160 * 1024) {
+                if (rows * ng > best_rows) { best_rows = rows * ng; g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; }
+                break;
+            }
         }
     }
     if (!g.ok) return g;
@@ -1160,8 +1165,10 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
 }
 int fir_mm_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
     const FirMGeo g = fir_mm_geo(f);
-    if (g.esz == 4) return g.CS == 1 ? fir_mm_dispatch_t<float, 1, 4>(f, a, g, st) : fir_mm_dispatch_t<float, 2, 2>(f, a, g, st);
-    return g.CS == 1 ? fir_mm_dispatch_t<double, 1, 2>(f, a, g, st) : fir_mm_dispatch_t<double, 2, 2>(f, a, g, st);
+    if (g.esz == 4 && g.CS == 1) return g.CH == 4 ? fir_mm_dispatch_t<float, 1, 4>(f, a, g, st) : g.CH == 2 ? fir_mm_dispatch_t<float, 1, 2>(f, a, g, st) : fir_mm_dispatch_t<float, 1, 1>(f, a, g, st);
+    if (g.esz == 4) return g.CH == 2 ? fir_mm_dispatch_t<float, 2, 2>(f, a, g, st) : fir_mm_dispatch_t<float, 2, 1>(f, a, g, st);
+    if (g.CS == 1) return g.CH == 2 ? fir_mm_dispatch_t<double, 1, 2>(f, a, g, st) : fir_mm_dispatch_t<double, 1, 1>(f, a, g, st);
+    return g.CH == 2 ? fir_mm_dispatch_t<double, 2, 2>(f, a, g, st) : fir_mm_dispatch_t<double, 2, 1>(f, a, g, st);
 }
 
 // where the matrix-core kernel is used: wherever the shape fits -- it is the faster kernel from 2^16 samples (0.019 against 0.042 ms,

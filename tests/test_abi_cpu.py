@@ -463,6 +463,8 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     assert geo(250, 249, 4000, _lib.F32, _lib.F32)[0] == 0                                                  # L > 192
     assert geo(160, 147, 5120, _lib.F64, _lib.F32)[0] == 0                                                  # Float64 taps on a Float32 signal
     assert geo(160, 147, 5120, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
+    assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:8] == [1, 1, 147, 160, 10, 1, 16, 2]                    # 48 kHz -> 44.1 kHz: 32 rows per wave fit
+    assert geo(160, 441, 16001, _lib.F32, _lib.F32)[7] == 2                                                 # 44.1 kHz -> 16 kHz
     assert geo(1, 2, 64 * 4 + 1, _lib.F32, _lib.F32)[0] == 0                                                # more than 256 window positions
     rng = np.random.default_rng(42)
     fits = 0
@@ -481,7 +483,7 @@ def test_matrix_core_polyphase_geometry_is_consistent():
         assert dbl == (xdt in (_lib.F64, _lib.C64))                       # compute type == signal type
         assert Lq <= 192 and Lr == RB * Lq and Mr == RB * Mq and (RB == 1 if Lq >= 16 else Lr <= 16)
         assert NB == -(-Lr // 16) and 1 <= NG <= 8 and NB * NG + nd + ns <= 16 and nd >= 1 and ns >= 1
-        assert CS == (2 if xdt in (_lib.C32, _lib.C64) else 1) and CH == (4 if (not dbl and CS == 1) else 2)
+        assert CS == (2 if xdt in (_lib.C32, _lib.C64) else 1) and CH in ((4, 2, 1) if (not dbl and CS == 1) else (2, 1))
         dmax = ((Lq - 1) + (min(Lr, 16) - 1) * Mq) // Lq
         assert 4 * T >= tp + dmax and T <= (32 if dbl else 64)           # every tap of every column of a block has a k-step
         esz = 8 if dbl else 4
