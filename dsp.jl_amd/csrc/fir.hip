@@ -305,6 +305,7 @@ struct FirMArgs {
     int NB, NG;                  // blocks of 16 columns (outputs of a row); groups of 16 CH rows per tile: NB NG multiplying waves
     int Lp;                      // row pitch of the output buffer in LDS (R elements): Lr CS when NB = 1 (contiguous outputs), else 16 NB CS + 16 bytes
     int bufsz;                   // dwords per LDS sample buffer (two of them, then two output buffers)
+    int pitch;                   // 0: the samples of a tile are staged as one run (row r starts at r Mr); else every row is staged on its own, pitch dwords apart
     int nd, ns;                  // waves that issue the LDS-DMA / that store, after the multiplying waves
     unsigned lmagic, rmagic;     // ceil(2^32 / L), ceil(2^32 / (Lr CS)): quotients of small numbers by multiply-high
     int phi0m1;                  // phi0 - 1: output j of a row has phase (phi0-1 + j M) mod L and window start (phi0-1 + j M) div L
@@ -400,18 +401,37 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     // The first tile(s), which straddle the history, are filled by ordinary loads (all waves).
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) R*)zs;
     const auto dma_ok = [&](int64_t tile) { return tile < ntiles && tile * Q * a.Mr + cbase >= a.hl; };
+    // Row-staged tiles (pitch != 0): when the sample stride of a row, Mr, is a multiple of 8 the 16 rows of an A operand would sit on
+    // 2 - 8 banks of a linear tile (147//160: all on one); every row is then DMA-ed on its own -- its Mr samples and the window tail
+    // again -- to rows pitch = 256 g + 4 dwords apart (two-way conflicts at worst); the duplicates come from L2.
+    const int rgran = a.pitch ? (a.pitch - 4) / 256 : 0;                    // 256-dword granules per row
+    const int zpitch = a.pitch ? a.pitch / (int)(sizeof(R) / 4) : a.Mr * CS;   // R elements between rows
     const auto dma = [&](int64_t tile, int buf) {
         if (!is_dma || !dma_ok(tile)) return;
         const int64_t q0 = tile * Q, z0 = q0 * a.Mr + cbase;
-        const int nzd = ((int)std::min<int64_t>(Q, a.nrows - q0) * a.Mr + a.Mr + wtail) * DW;   // dwords of the tile
+        const int nq = (int)std::min<int64_t>(Q, a.nrows - q0);
         const mm_i4 rs = mm_rsrc(xc + (z0 - a.hl) * CS, (a.xlen - (z0 - a.hl)) * 4 * DW);   // re-based at the tile start: zero fill past the signal
-        const int inside = (int)std::min<int64_t>(nzd, (a.xlen - (z0 - a.hl)) * DW);   // dwords of the tile that exist
-        for (int i = wave - ncomp; 256 * i < nzd; i += a.nd) {   // granules of 256 dwords, round-robin over the DMA waves
-            const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + 256 * i) * 4u;
-            if (256 * (i + 1) <= inside) mm_dma256(rs, dst, (256 * i + 4 * lane) * 4);
-            else {
+        const int64_t exist = (a.xlen - (z0 - a.hl)) * DW;                     // dwords of the signal from the tile start on
+        if (a.pitch == 0) {
+            const int nzd = (nq * a.Mr + a.Mr + wtail) * DW;   // dwords of the tile
+            for (int i = wave - ncomp; 256 * i < nzd; i += a.nd) {   // granules of 256 dwords, round-robin over the DMA waves
+                const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + 256 * i) * 4u;
+                if (256 * (int64_t)(i + 1) <= exist) mm_dma256(rs, dst, (256 * i + 4 * lane) * 4);
+                else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mm_dma64(rs, dst + 256u * j, (256 * i + 64 * j + lane) * 4);
+                    for (int j = 0; j < 4; ++j) mm_dma64(rs, dst + 256u * j, (256 * i + 64 * j + lane) * 4);
+                }
+            }
+        } else {
+            for (int i = wave - ncomp; i < nq * rgran; i += a.nd) {   // (row, granule) pairs
+                const int row = i / rgran, gr = i - row * rgran;
+                const int src = row * a.Mr * DW + 256 * gr;                     // dwords from the tile start
+                const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + row * a.pitch + 256 * gr) * 4u;
+                if (src + 256 <= exist) mm_dma256(rs, dst, (src + 4 * lane) * 4);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mm_dma64(rs, dst + 256u * j, (src + 64 * j + lane) * 4);
+                }
             }
         }
     };
@@ -452,7 +472,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     };
     // Which row of the tile a row of the 16 x 16 product is: with odd Mr, the 16 EVEN (then the 16 odd) rows of a 32-row span put the
     // 2 x 16 A-operand reads of a lane group on 32 different banks (16 consecutive rows collide two ways).
-    const bool eo = CH >= 2 && (a.Mr & 1);   // (a single 16-row chunk per wave keeps consecutive rows)
+    const bool eo = CH >= 2 && (a.Mr & 1) && a.pitch == 0;   // (a single 16-row chunk per wave keeps consecutive rows)
     const int ra = eo ? 2 : 1;
     const auto rbase = [&](int c) { return 16 * CH * wg + (eo ? 32 * (c >> 1) + (c & 1) : 16 * c); };
     R* zout = zs + 2 * (a.bufsz / (int)(sizeof(R) / 4));
@@ -471,13 +491,15 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
             if (is_dma) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of the tile has landed
         } else {  // the first tile(s) straddle the history
             R* zw = zs + cur * (a.bufsz / (int)(sizeof(R) / 4));
-            for (int k2 = threadIdx.x; k2 < nz * CS; k2 += blockDim.x) {
-                const int64_t zi = z0 + k2 / CS;
-                const int part = k2 % CS;
+            const int rowlen = a.pitch ? (a.Mr + wtail) * CS : nz * CS, nrow = a.pitch ? nq : 1;   // R elements per staged row; rows
+            for (int k2 = threadIdx.x; k2 < rowlen * nrow; k2 += blockDim.x) {
+                const int row = k2 / rowlen, e = k2 - row * rowlen;
+                const int64_t zi = z0 + (int64_t)row * a.Mr + e / CS;
+                const int part = e % CS;
                 R v = (R)0;
                 if (zi < a.hl) v = hc[zi * CS + part];
                 else if (zi - a.hl < a.xlen) v = xc[(zi - a.hl) * CS + part];
-                zw[k2] = v;
+                zw[row * zpitch + e] = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);
         }
@@ -492,7 +514,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                 for (int c = 0; c < CH; ++c) acc[p][c] = acc_t{(R)0, (R)0, (R)0, (R)0};
             const R* ap[CH];   // A operand: row = lane % 16, k = lane / 16
 #pragma unroll
-            for (int c = 0; c < CH; ++c) ap[c] = zt + ((ra * lj + rbase(c)) * a.Mr + c0 + lk) * CS;
+            for (int c = 0; c < CH; ++c) ap[c] = zt + (ra * lj + rbase(c)) * zpitch + (c0 + lk) * CS;
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -1057,6 +1079,7 @@ struct FirMGeo {
     int esz = 4, CS = 1, CH = 4;   // bytes of R; parts per sample; 16-row chunks per multiplying wave
     int RB = 1, Lr = 0, Mr = 0, NB = 0, NG = 1, T = 0, Lp = 0, nd = 1, ns = 1;
     int64_t bufsz = 0;             // dwords per sample buffer
+    int pitch = 0;                 // dwords between separately staged rows (0: one linear run per tile)
     size_t lds_bytes = 0;
 };
 int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : steps <= 32 ? 32 : steps <= 48 ? 48 : 64; }
@@ -1090,14 +1113,18 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     g.T = fir_mm_tsel(steps);
     g.Lp = g.NB == 1 ? g.Lr * g.CS : 16 * g.NB * g.CS + 16 / g.esz;
     const int dw = g.esz / 4 * g.CS;
+    // rows (lane stride Mr samples) on a linear tile hit 32 / gcd(Mr dw, 32) banks: stage the rows separately from four-way conflicts on
+    const bool rowmode = tunables().fir_mm_rows == 1 || (tunables().fir_mm_rows != 0 && std::gcd((int64_t)g.Mr * dw, (int64_t)32) >= 8);
+    const int wtail = 4 * g.T + 4;
+    const int pitch = rowmode ? (int)cdiv((int64_t)(g.Mr + wtail) * dw, (int64_t)256) * 256 + 4 : 0;
     int best_rows = 0;
     for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
         const int rows = 16 * ch;
         for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {
-            const int64_t bufsz = cdiv(((int64_t)rows * ng * g.Mr + g.Mr + 4 * g.T + 4) * dw, (int64_t)256) * 256;
+            const int64_t bufsz = rowmode ? cdiv((int64_t)rows * ng * pitch, (int64_t)256) * 256 : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
             const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
             if (bytes <= 160 * 1024) {
-                if (rows * ng > best_rows) { best_rows = rows * ng; g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; }
+                if (rows * ng > best_rows) { best_rows = rows * ng; g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; g.pitch = pitch; }
                 break;
             }
         }
@@ -1129,6 +1156,7 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
     b.rmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)(g.Lr * CS) - 1) / (uint64_t)(g.Lr * CS));
     b.phi0m1 = (int)a.phi0m1;
     b.bufsz = (int)g.bufsz;
+    b.pitch = g.pitch;
     const int nw = g.NB * g.NG + g.nd + g.ns;
     auto kern = polyphase_mfma_kernel<R, CS, CH, T>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB

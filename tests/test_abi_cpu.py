@@ -463,7 +463,7 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     assert geo(250, 249, 4000, _lib.F32, _lib.F32)[0] == 0                                                  # L > 192
     assert geo(160, 147, 5120, _lib.F64, _lib.F32)[0] == 0                                                  # Float64 taps on a Float32 signal
     assert geo(160, 147, 5120, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
-    assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:8] == [1, 1, 147, 160, 10, 1, 16, 2]                    # 48 kHz -> 44.1 kHz: 32 rows per wave fit
+    assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:7] == [1, 1, 147, 160, 10, 1, 16]                       # 48 kHz -> 44.1 kHz (rows staged one by one: M = 160 is a multiple of 32)
     assert geo(160, 441, 16001, _lib.F32, _lib.F32)[7] == 2                                                 # 44.1 kHz -> 16 kHz
     assert geo(1, 2, 64 * 4 + 1, _lib.F32, _lib.F32)[0] == 0                                                # more than 256 window positions
     rng = np.random.default_rng(42)
@@ -488,6 +488,10 @@ def test_matrix_core_polyphase_geometry_is_consistent():
         assert 4 * T >= tp + dmax and T <= (32 if dbl else 64)           # every tap of every column of a block has a k-step
         esz = 8 if dbl else 4
         rows = 16 * CH * NG
-        need = 2 * 4 * (-(-((rows * Mr + Mr + 4 * T + 4) * (esz // 4) * CS) // 256) * 256) + 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + 16 // esz) * esz
+        dw = (esz // 4) * CS
+        rowmode = gcd(Mr * dw, 32) >= 8                                   # rows staged one by one when a linear tile would put them on <= 4 banks
+        pitch = -(-((Mr + 4 * T + 4) * dw) // 256) * 256 + 4
+        buf = -(-(rows * pitch) // 256) * 256 if rowmode else -(-((rows * Mr + Mr + 4 * T + 4) * dw) // 256) * 256
+        need = 2 * 4 * buf + 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + 16 // esz) * esz
         assert lds == need <= 160 * 1024
     assert fits > 300
