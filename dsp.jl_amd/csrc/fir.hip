@@ -305,6 +305,7 @@ struct FirMArgs {
     int NB, NG;                  // blocks of 16 columns (outputs of a row); groups of 16 CH rows per tile: NB NG multiplying waves
     int Lp;                      // row pitch of the output buffer in LDS (R elements): Lr CS when NB = 1 (contiguous outputs), else 16 NB CS + 16 bytes
     int bufsz;                   // dwords per LDS sample buffer (two of them, then two output buffers)
+    int steps;                   // k-steps of four taps when they do not fit registers (template T = 0): the taps are then fetched per tile
     int pitch;                   // 0: the samples of a tile are staged as one run (row r starts at r Mr); else every row is staged on its own, pitch dwords apart
     int nd, ns;                  // waves that issue the LDS-DMA / that store, after the multiplying waves
     unsigned lmagic, rmagic;     // ceil(2^32 / L), ceil(2^32 / (Lr CS)): quotients of small numbers by multiply-high
@@ -370,28 +371,32 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     const int ncomp = a.NB * a.NG;
     const bool is_comp = wave < ncomp, is_dma = wave >= ncomp && wave < ncomp + a.nd, is_store = wave >= ncomp + a.nd;
     const int wb = wave % a.NB, wg = wave / a.NB;
-    // H: this wave's taps, for the whole kernel
-    R hreg[T];
-    int c0 = 0;
+    // H: this wave's taps, in registers for the whole kernel (T k-steps) -- or, for filters too long for that (T = 0), fetched from the
+    // bank in L2 for every tile (a dword per lane and k-step, beside the four to eight MFMAs it feeds)
+    constexpr int TR = T ? T : 1;
+    const int steps = T ? T : a.steps;
+    R hreg[TR];
+    int c0 = 0, tap_phase = 0, tap_delta = 0;
+    bool tap_valid = false;
+    const R* pf = static_cast<const R*>(a.pfbT);
     if (is_comp) {
-        const R* pf = static_cast<const R*>(a.pfbT);
         const int s0 = 16 * wb, sj = s0 + lj;
         const unsigned p0 = (unsigned)(a.phi0m1 + s0 * a.M), pj = (unsigned)(a.phi0m1 + sj * a.M);
         c0 = a.L == 1 ? (int)p0 : (int)__umulhi(p0, a.lmagic);   // (ceil(2^32 / 1) does not fit the magic)
-        const int cj = a.L == 1 ? (int)pj : (int)__umulhi(pj, a.lmagic), phase = (int)pj - cj * a.L, delta = cj - c0;
-        const bool valid = sj < a.Lr;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int i = 4 * t + lk - delta;
-            hreg[t] = (valid && i >= 0 && i < a.tp) ? pf[(int64_t)i * a.L + phase] : (R)0;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < T; ++t) hreg[t] = (R)0;
+        const int cj = a.L == 1 ? (int)pj : (int)__umulhi(pj, a.lmagic);
+        tap_phase = (int)pj - cj * a.L;
+        tap_delta = cj - c0;
+        tap_valid = sj < a.Lr;
     }
+    const auto tap = [&](int t) -> R {   // H[k = 4 t + lane / 16][j = lane % 16]
+        const int i = 4 * t + lk - tap_delta;
+        return (tap_valid && i >= 0 && i < a.tp) ? pf[(int64_t)i * a.L + tap_phase] : (R)0;
+    };
+#pragma unroll
+    for (int t = 0; t < TR; ++t) hreg[t] = (T && is_comp) ? tap(t) : (R)0;
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the taps are in (their first use must not look like a pending load inside the tile loop)
     const int64_t cbase = a.d0 - 1;
-    constexpr int wtail = 4 * T + 4;   // samples read past a window start
+    const int wtail = 4 * steps + 4;   // samples read past a window start
     const int64_t ntiles = (a.nrows + Q - 1) / Q;
     // Software pipeline over tiles with ONE barrier per tile.  LDS holds two sample buffers and two output buffers; in iteration t
     //   sample buffer t+1 receives the NEXT tile by LDS-DMA (no registers, no ds_write pass), issued right after the barrier;
@@ -515,12 +520,26 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
             const R* ap[CH];   // A operand: row = lane % 16, k = lane / 16
 #pragma unroll
             for (int c = 0; c < CH; ++c) ap[c] = zt + (ra * lj + rbase(c)) * zpitch + (c0 + lk) * CS;
+            if constexpr (T != 0) {
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+                for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int c = 0; c < CH; ++c)
+                    for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[t], acc[p][c]);
+                        for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[t], acc[p][c]);
+            } else {
+                for (int t0 = 0; t0 < steps; t0 += 8) {   // steps is a multiple of 8: eight tap fetches in flight
+                    R h[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) h[u] = tap(t0 + u);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+#pragma unroll
+                            for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+                }
+            }
             if (16 * wb + lj < a.Lr) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
@@ -1077,7 +1096,7 @@ template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStrea
 struct FirMGeo {
     bool ok = false;
     int esz = 4, CS = 1, CH = 4;   // bytes of R; parts per sample; 16-row chunks per multiplying wave
-    int RB = 1, Lr = 0, Mr = 0, NB = 0, NG = 1, T = 0, Lp = 0, nd = 1, ns = 1;
+    int RB = 1, Lr = 0, Mr = 0, NB = 0, NG = 1, T = 0, steps = 0, Lp = 0, nd = 1, ns = 1;   // T = 0: `steps` k-steps with the taps fetched per tile
     int64_t bufsz = 0;             // dwords per sample buffer
     int pitch = 0;                 // dwords between separately staged rows (0: one linear run per tile)
     size_t lds_bytes = 0;
@@ -1109,23 +1128,37 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     g.Mr = g.RB * (int)f->M;
     g.NB = (int)cdiv((int64_t)g.Lr, (int64_t)16);
     const int64_t steps = cdiv(f->tp + ((f->L - 1) + (int64_t)(std::min(g.Lr, 16) - 1) * f->M) / f->L, (int64_t)4);   // tp + max delta within a block
-    if (steps > (g.esz == 8 ? 32 : 64)) return g;   // taps live in registers: T (Float64: 2 T) VGPRs
-    g.T = fir_mm_tsel(steps);
+    if (steps > 1024) return g;
+    if (steps > (g.esz == 8 ? 32 : 64)) {   // the taps do not fit registers (T, Float64 2 T, VGPRs): fetched per tile
+        g.T = 0;
+        g.steps = (int)cdiv(steps, (int64_t)8) * 8;
+    } else {
+        g.T = fir_mm_tsel(steps);
+        g.steps = g.T;
+    }
     g.Lp = g.NB == 1 ? g.Lr * g.CS : 16 * g.NB * g.CS + 16 / g.esz;
     const int dw = g.esz / 4 * g.CS;
-    // rows (lane stride Mr samples) on a linear tile hit 32 / gcd(Mr dw, 32) banks: stage the rows separately from four-way conflicts on
-    const bool rowmode = tunables().fir_mm_rows == 1 || (tunables().fir_mm_rows != 0 && std::gcd((int64_t)g.Mr * dw, (int64_t)32) >= 8);
-    const int wtail = 4 * g.T + 4;
-    const int pitch = rowmode ? (int)cdiv((int64_t)(g.Mr + wtail) * dw, (int64_t)256) * 256 + 4 : 0;
-    int best_rows = 0;
-    for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
-        const int rows = 16 * ch;
-        for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {
-            const int64_t bufsz = rowmode ? cdiv((int64_t)rows * ng * pitch, (int64_t)256) * 256 : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
-            const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
-            if (bytes <= 160 * 1024) {
-                if (rows * ng > best_rows) { best_rows = rows * ng; g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; g.pitch = pitch; }
-                break;
+    // Rows (lane stride Mr samples) of a linear tile hit 32 / gcd(Mr dw, 32) banks.  From four-way conflicts on, staging the rows one by
+    // one (pitch 256 g + 4 dwords: two-way conflicts) is the alternative -- unless the window tail it duplicates per row (long filters)
+    // shrinks the tile too much: the larger of (rows per tile) / (conflict ways) decides.
+    const int wtail = 4 * g.steps + 4;
+    const int64_t gb = std::gcd((int64_t)g.Mr * dw, (int64_t)32);
+    const int rpitch = (int)cdiv((int64_t)(g.Mr + wtail) * dw, (int64_t)256) * 256 + 4;
+    double best_score = -1;
+    for (int mode = 0; mode < 2; ++mode) {   // 0: one linear run per tile, 1: row by row
+        if (mode == 1 && (tunables().fir_mm_rows == 0 || (tunables().fir_mm_rows < 0 && gb < 8))) continue;
+        if (mode == 0 && tunables().fir_mm_rows == 1) continue;
+        const double ways = mode ? 2.0 : std::max(1.0, (double)gb / 2);
+        for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
+            const int rows = 16 * ch;
+            for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {
+                const int64_t bufsz = mode ? cdiv((int64_t)rows * ng * rpitch, (int64_t)256) * 256 : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
+                const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
+                if (bytes <= 160 * 1024) {
+                    const double score = rows * ng / ways + 1e-3 * ch;
+                    if (score > best_score) { best_score = score; g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; g.pitch = mode ? rpitch : 0; }
+                    break;
+                }
             }
         }
     }
@@ -1157,6 +1190,7 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
     b.phi0m1 = (int)a.phi0m1;
     b.bufsz = (int)g.bufsz;
     b.pitch = g.pitch;
+    b.steps = g.steps;
     const int nw = g.NB * g.NG + g.nd + g.ns;
     auto kern = polyphase_mfma_kernel<R, CS, CH, T>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB
@@ -1179,6 +1213,7 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
 
 template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
     switch (g.T) {
+        case 0: return fir_mm_launch<R, CS, CH, 0>(f, a, g, st);
         case 4: return fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
         case 8: return fir_mm_launch<R, CS, CH, 8>(f, a, g, st);
         case 12: return fir_mm_launch<R, CS, CH, 12>(f, a, g, st);
@@ -1382,7 +1417,7 @@ int mdsp_fir_mm_geometry(int64_t L, int64_t M, int64_t hlen, int taps_dtype, int
     f.x_dtype = x_dtype;
     f.acc_double = (taps_dtype == MDSP_F64) || dtype_is_double(x_dtype);
     const FirMGeo g = fir_mm_geo(&f);
-    const int64_t v[12] = {g.ok ? 1 : 0, g.RB, g.Lr, g.Mr, g.NB, g.NG, g.T, g.CH, g.CS, g.nd, g.ns, (int64_t)g.lds_bytes};
+    const int64_t v[12] = {g.ok ? 1 : 0, g.RB, g.Lr, g.Mr, g.NB, g.NG, g.steps, g.CH, g.CS, g.nd, g.ns, (int64_t)g.lds_bytes};
     for (int i = 0; i < 12; ++i) out12[i] = v[i];
     return MDSP_OK;
 }

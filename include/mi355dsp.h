@@ -273,7 +273,7 @@ int mdsp_fir_info(mdsp_fir f, int* kind /*0 std,1 interp,2 decim,3 rational*/, i
  * v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64; Float32 results bit-identical to 0 / 1).  Diagnostics / tests: the choice never changes results beyond the sign of a zero. */
 int mdsp_fir_kernel_path(mdsp_fir f, int64_t xlen, int* path);
 /* Geometry the matrix-core kernel would use for a filter of hlen taps at ratio L // M (pure host arithmetic, no device):
- * out12 = {fits, rounds per row RB, outputs per row Lr = RB L, samples per row Mr = RB M, column blocks NB, row groups NG, k-steps T,
+ * out12 = {fits, rounds per row RB, outputs per row Lr = RB L, samples per row Mr = RB M, column blocks NB, row groups NG, k-steps of four taps (in registers up to 64, Float64 32; beyond that fetched per tile),
  * 16-row chunks per wave CH, parts per sample CS, DMA waves, store waves, LDS bytes}.  Diagnostics / tests. */
 int mdsp_fir_mm_geometry(int64_t L, int64_t M, int64_t hlen, int taps_dtype, int x_dtype, int64_t* out12);
 /* state is exactly the reference's: 1-based phi_idx and input_deficit, history (history_len, nch) of x_dtype */

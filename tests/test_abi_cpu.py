@@ -465,7 +465,8 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     assert geo(160, 147, 5120, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
     assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:7] == [1, 1, 147, 160, 10, 1, 16]                       # 48 kHz -> 44.1 kHz (rows staged one by one: M = 160 is a multiple of 32)
     assert geo(160, 441, 16001, _lib.F32, _lib.F32)[7] == 2                                                 # 44.1 kHz -> 16 kHz
-    assert geo(1, 2, 64 * 4 + 1, _lib.F32, _lib.F32)[0] == 0                                                # more than 256 window positions
+    assert geo(1, 2, 64 * 4 + 1, _lib.F32, _lib.F32)[6] == 72                                               # more than 256 window positions: taps fetched per tile
+    assert geo(1, 2, 5000, _lib.F32, _lib.F32)[0] == 0                                                      # more than 4096 window positions
     rng = np.random.default_rng(42)
     fits = 0
     for _ in range(3000):
@@ -485,13 +486,15 @@ def test_matrix_core_polyphase_geometry_is_consistent():
         assert NB == -(-Lr // 16) and 1 <= NG <= 8 and NB * NG + nd + ns <= 16 and nd >= 1 and ns >= 1
         assert CS == (2 if xdt in (_lib.C32, _lib.C64) else 1) and CH in ((4, 2, 1) if (not dbl and CS == 1) else (2, 1))
         dmax = ((Lq - 1) + (min(Lr, 16) - 1) * Mq) // Lq
-        assert 4 * T >= tp + dmax and T <= (32 if dbl else 64)           # every tap of every column of a block has a k-step
+        assert 4 * T >= tp + dmax and T <= 1024 and (T <= (32 if dbl else 64) or T % 8 == 0)   # every tap of every column of a block has a k-step
         esz = 8 if dbl else 4
         rows = 16 * CH * NG
         dw = (esz // 4) * CS
-        rowmode = gcd(Mr * dw, 32) >= 8                                   # rows staged one by one when a linear tile would put them on <= 4 banks
-        pitch = -(-((Mr + 4 * T + 4) * dw) // 256) * 256 + 4
-        buf = -(-(rows * pitch) // 256) * 256 if rowmode else -(-((rows * Mr + Mr + 4 * T + 4) * dw) // 256) * 256
-        need = 2 * 4 * buf + 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + 16 // esz) * esz
+        pitch = -(-((Mr + 4 * T + 4) * dw) // 256) * 256 + 4               # rows staged one by one (sample strides that are multiples of 8) ...
+        lin = -(-((rows * Mr + Mr + 4 * T + 4) * dw) // 256) * 256           # ... or the tile as one run
+        obuf = 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + 16 // esz) * esz
+        need = 2 * 4 * lin + obuf
+        if gcd(Mr * dw, 32) >= 8 and lds != need:
+            need = 2 * 4 * (-(-(rows * pitch) // 256) * 256) + obuf
         assert lds == need <= 160 * 1024
     assert fits > 300
