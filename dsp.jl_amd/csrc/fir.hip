@@ -302,7 +302,8 @@ struct FirMArgs {
     int64_t d0;
     int L, M, hl, tp;            // the filter's ratio L // M
     int Lr, Mr;                  // a ROW = RB rounds = Lr = RB L consecutive outputs, Mr = RB M input samples (RB = 1 when L >= 16)
-    int NB, NG;                  // blocks of 16 columns (outputs of a row); groups of 16 CH rows per tile: NB NG multiplying waves
+    int NB, NG;                  // blocks of 16 columns (outputs of a row); groups of 16 CH rows per tile
+    int NBW;                     // multiplying waves per row group: wave w takes the column blocks w % NBW, w % NBW + NBW, .. (more than one only with T = 0)
     int Lp;                      // row pitch of the output buffer in LDS (R elements): Lr CS when NB = 1 (contiguous outputs), else 16 NB CS + 16 bytes
     int bufsz;                   // dwords per LDS sample buffer (two of them, then two output buffers)
     int steps;                   // k-steps of four taps when they do not fit registers (template T = 0): the taps are then fetched per tile
@@ -368,26 +369,28 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     // LDS-DMA of the samples, the last ns waves store the outputs.  The memory waves work through the whole tile period beside the
     // MFMAs -- a wave that first moved data and then multiplied would hold up its SIMD's matrix pipe (measured: 2 000 - 6 000 clocks
     // of DMA issue / store issue per tile, against 4 600 of MFMA) -- and no wave waits on a vmcnt that mixes loads with younger stores.
-    const int ncomp = a.NB * a.NG;
+    const int ncomp = a.NBW * a.NG;
     const bool is_comp = wave < ncomp, is_dma = wave >= ncomp && wave < ncomp + a.nd, is_store = wave >= ncomp + a.nd;
-    const int wb = wave % a.NB, wg = wave / a.NB;
+    const int wb0 = wave % a.NBW, wg = wave / a.NBW;
     // H: this wave's taps, in registers for the whole kernel (T k-steps) -- or, for filters too long for that (T = 0), fetched from the
     // bank in L2 for every tile (a dword per lane and k-step, beside the four to eight MFMAs it feeds)
     constexpr int TR = T ? T : 1;
     const int steps = T ? T : a.steps;
     R hreg[TR];
-    int c0 = 0, tap_phase = 0, tap_delta = 0;
+    int wb = wb0, c0 = 0, tap_phase = 0, tap_delta = 0;
     bool tap_valid = false;
     const R* pf = static_cast<const R*>(a.pfbT);
-    if (is_comp) {
-        const int s0 = 16 * wb, sj = s0 + lj;
+    const auto block_setup = [&](int b) {   // window start of column block b and this lane's column of it
+        wb = b;
+        const int s0 = 16 * b, sj = s0 + lj;
         const unsigned p0 = (unsigned)(a.phi0m1 + s0 * a.M), pj = (unsigned)(a.phi0m1 + sj * a.M);
         c0 = a.L == 1 ? (int)p0 : (int)__umulhi(p0, a.lmagic);   // (ceil(2^32 / 1) does not fit the magic)
         const int cj = a.L == 1 ? (int)pj : (int)__umulhi(pj, a.lmagic);
         tap_phase = (int)pj - cj * a.L;
         tap_delta = cj - c0;
         tap_valid = sj < a.Lr;
-    }
+    };
+    if (is_comp) block_setup(wb0);
     const auto tap = [&](int t) -> R {   // H[k = 4 t + lane / 16][j = lane % 16]
         const int i = 4 * t + lk - tap_delta;
         return (tap_valid && i >= 0 && i < a.tp) ? pf[(int64_t)i * a.L + tap_phase] : (R)0;
@@ -512,41 +515,44 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
         dma(tile + gridDim.x, cur ^ 1);
         if (prev_tile >= 0) copy_out(prev_tile, zout + (cur ^ 1) * osz);
         if (is_comp) {
-            acc_t acc[CS][CH];
+            for (int b = wb0; b < a.NB; b += a.NBW) {   // (one block per wave unless T = 0)
+                if (T == 0 && a.NBW < a.NB) block_setup(b);
+                acc_t acc[CS][CH];
 #pragma unroll
-            for (int p = 0; p < CS; ++p)
+                for (int p = 0; p < CS; ++p)
 #pragma unroll
-                for (int c = 0; c < CH; ++c) acc[p][c] = acc_t{(R)0, (R)0, (R)0, (R)0};
-            const R* ap[CH];   // A operand: row = lane % 16, k = lane / 16
+                    for (int c = 0; c < CH; ++c) acc[p][c] = acc_t{(R)0, (R)0, (R)0, (R)0};
+                const R* ap[CH];   // A operand: row = lane % 16, k = lane / 16
 #pragma unroll
-            for (int c = 0; c < CH; ++c) ap[c] = zt + (ra * lj + rbase(c)) * zpitch + (c0 + lk) * CS;
-            if constexpr (T != 0) {
+                for (int c = 0; c < CH; ++c) ap[c] = zt + (ra * lj + rbase(c)) * zpitch + (c0 + lk) * CS;
+                if constexpr (T != 0) {
 #pragma unroll
-                for (int t = 0; t < T; ++t)
-#pragma unroll
-                    for (int c = 0; c < CH; ++c)
-#pragma unroll
-                        for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[t], acc[p][c]);
-            } else {
-                for (int t0 = 0; t0 < steps; t0 += 8) {   // steps is a multiple of 8: eight tap fetches in flight
-                    R h[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) h[u] = tap(t0 + u);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
+                    for (int t = 0; t < T; ++t)
 #pragma unroll
                         for (int c = 0; c < CH; ++c)
 #pragma unroll
-                            for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+                            for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[t], acc[p][c]);
+                } else {
+                    for (int t0 = 0; t0 < steps; t0 += 8) {   // steps is a multiple of 8: eight tap fetches in flight
+                        R h[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) h[u] = tap(t0 + u);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+#pragma unroll
+                            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+                    }
                 }
-            }
-            if (16 * wb + lj < a.Lr) {
+                if (16 * wb + lj < a.Lr) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c)
+                    for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int p = 0; p < CS; ++p) zo[(ra * Mm<R>::row(lk, r) + rbase(c)) * a.Lp + (16 * wb + lj) * CS + p] = acc[p][c][r];
+                            for (int p = 0; p < CS; ++p) zo[(ra * Mm<R>::row(lk, r) + rbase(c)) * a.Lp + (16 * wb + lj) * CS + p] = acc[p][c][r];
+                }
             }
         }
         prev_tile = tile;
@@ -1088,15 +1094,16 @@ template <int P> int fir_fast_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStrea
 }
 
 // ---- matrix-core kernel, host side ------------------------------------------------------------------------------
-// Shapes it is built for: Float32 taps x Float32 / ComplexF32 signals, and Float64 arithmetic on Float64 / ComplexF64 signals; L <= 192,
-// at most 256 (Float64: 128) window positions per block of 16 outputs, a tile that fits the LDS.
+// Shapes it is built for: Float32 taps x Float32 / ComplexF32 signals, and Float64 arithmetic on Float64 / ComplexF64 signals; L <= 1024,
+// a tile that fits the LDS.  Up to 12 column blocks (L <= 192) and 256 (Float64: 128) window positions per block the taps of a wave's block
+// live in registers; beyond either, a wave fetches the taps of its block(s) from L2 for every tile.
 // For L < 16 a row of the product is RB whole rounds (Lr = RB L <= 16 consecutive outputs, Mr = RB M samples): the columns of a
 // row still repeat their phases from row to row, which is all the kernel needs; RB is chosen so that rows (lane stride Mr samples)
 // spread over the LDS banks (odd Mr: conflict-free).
 struct FirMGeo {
     bool ok = false;
     int esz = 4, CS = 1, CH = 4;   // bytes of R; parts per sample; 16-row chunks per multiplying wave
-    int RB = 1, Lr = 0, Mr = 0, NB = 0, NG = 1, T = 0, steps = 0, Lp = 0, nd = 1, ns = 1;   // T = 0: `steps` k-steps with the taps fetched per tile
+    int RB = 1, Lr = 0, Mr = 0, NB = 0, NBW = 0, NG = 1, T = 0, steps = 0, Lp = 0, nd = 1, ns = 1;   // T = 0: `steps` k-steps with the taps fetched per tile
     int64_t bufsz = 0;             // dwords per sample buffer
     int pitch = 0;                 // dwords between separately staged rows (0: one linear run per tile)
     size_t lds_bytes = 0;
@@ -1109,7 +1116,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     g.esz = f->acc_double ? 8 : 4;
     g.CS = dtype_is_complex(f->x_dtype) ? 2 : 1;
     const int chmax = (g.esz == 4 && g.CS == 1) ? 4 : 2;   // 16-row chunks per multiplying wave: fewer when the tile would not fit the LDS
-    if (f->L > 192 || f->M > 4096) return g;
+    if (f->L > 1024 || f->M > 4096) return g;
     if (f->L < 16) {   // rounds per row: most outputs per LDS cycle of the A-operand reads (16 rows x 2 taps per lane group)
         double best = -1;
         for (int rb = 1; rb * f->L <= 16; ++rb) {
@@ -1128,8 +1135,10 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     g.Mr = g.RB * (int)f->M;
     g.NB = (int)cdiv((int64_t)g.Lr, (int64_t)16);
     const int64_t steps = cdiv(f->tp + ((f->L - 1) + (int64_t)(std::min(g.Lr, 16) - 1) * f->M) / f->L, (int64_t)4);   // tp + max delta within a block
-    if (steps > 1024) return g;
-    if (steps > (g.esz == 8 ? 32 : 64)) {   // the taps do not fit registers (T, Float64 2 T, VGPRs): fetched per tile
+    if (steps > 1024 || (int64_t)(f->L + (int64_t)(g.Lr + 16) * f->M) * f->L >= ((int64_t)1 << 32)) return g;   // (the multiply-high quotients stay exact)
+    g.NBW = std::min(g.NB, 12);   // more than 12 column blocks (L > 192): a wave takes several, with their taps fetched per tile
+    if (g.NBW < g.NB) g.NBW = (int)cdiv((int64_t)g.NB, cdiv((int64_t)g.NB, (int64_t)12));   // as even as it gets
+    if (steps > (g.esz == 8 ? 32 : 64) || g.NBW < g.NB) {   // the taps do not fit registers (T, Float64 2 T, VGPRs): fetched per tile
         g.T = 0;
         g.steps = (int)cdiv(steps, (int64_t)8) * 8;
     } else {
@@ -1151,7 +1160,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
         const double ways = mode ? 2.0 : std::max(1.0, (double)gb / 2);
         for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
             const int rows = 16 * ch;
-            for (int ng = std::min(8, 12 / g.NB); ng >= 1; --ng) {
+            for (int ng = std::min(8, 12 / g.NBW); ng >= 1; --ng) {
                 const int64_t bufsz = mode ? cdiv((int64_t)rows * ng * rpitch, (int64_t)256) * 256 : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
                 const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
                 if (bytes <= 160 * 1024) {
@@ -1163,7 +1172,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
         }
     }
     if (!g.ok) return g;
-    const int extra = 16 - g.NB * g.NG;   // memory waves beside the multiplying ones (16 waves per workgroup at most)
+    const int extra = 16 - g.NBW * g.NG;   // memory waves beside the multiplying ones (16 waves per workgroup at most)
     g.nd = extra >= 4 ? 2 : 1;
     g.ns = std::max(1, std::min(f->L >= f->M ? 2 : 4, extra - g.nd));   // measured: two store waves when the ratio is >= 1 (160//147 1.94 -> 1.87 ms, 2//1 1.01 -> 0.93), four below (1//2 0.48 -> 0.45)
     if (tunables().fir_mm_nd > 0 && tunables().fir_mm_ns > 0 && tunables().fir_mm_nd + tunables().fir_mm_ns <= extra) {   // tuning knobs
@@ -1183,7 +1192,7 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
     b.xlen = a.xlen; b.ldx = a.ldx; b.ldy = a.ldy; b.nout = a.nout;
     b.d0 = a.d0;
     b.L = a.L; b.M = a.M; b.hl = a.hl; b.tp = a.tp;
-    b.Lr = g.Lr; b.Mr = g.Mr; b.NB = g.NB; b.NG = g.NG; b.Lp = g.Lp; b.nd = g.nd; b.ns = g.ns;
+    b.Lr = g.Lr; b.Mr = g.Mr; b.NB = g.NB; b.NBW = g.NBW; b.NG = g.NG; b.Lp = g.Lp; b.nd = g.nd; b.ns = g.ns;
     b.nrows = cdiv(a.nout, (int64_t)g.Lr);
     b.lmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)a.L - 1) / (uint64_t)a.L);
     b.rmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)(g.Lr * CS) - 1) / (uint64_t)(g.Lr * CS));
@@ -1191,7 +1200,7 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
     b.bufsz = (int)g.bufsz;
     b.pitch = g.pitch;
     b.steps = g.steps;
-    const int nw = g.NB * g.NG + g.nd + g.ns;
+    const int nw = g.NBW * g.NG + g.nd + g.ns;
     auto kern = polyphase_mfma_kernel<R, CS, CH, T>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB
     int dev = 0;
@@ -1238,7 +1247,13 @@ int fir_mm_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
 // one channel 2//1) to 2^28 (profiles/r02r_tune_fir); MDSP_FIR_MM=0 turns it off
 bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
     (void)a;
-    return tunables().fir_mm != 0 && fir_mm_geo(f).ok;
+    if (tunables().fir_mm == 0) return false;
+    const FirMGeo g = fir_mm_geo(f);
+    if (!g.ok) return false;
+    // L > 192 (several column blocks per wave, small tiles): measured slower than the register-tap kernel where that one applies
+    // (Float32, 441//160: 1.1 against 2.3 TB/s) and 4 - 5x faster than the generic kernel everything else would take (Float64: 0.26 -> 1.2)
+    if (g.NBW < g.NB && tunables().fir_mm != 1 && fir_fast_ok(f, 2)) return false;
+    return true;
 }
 
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {

@@ -460,7 +460,8 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     assert geo(320, 294, 5120, _lib.F32, _lib.F32)[:5] == [1, 1, 160, 147, 10]                             # ratios are reduced first
     g = geo(2, 1, 75, _lib.F32, _lib.F32)
     assert g[0] == 1 and g[1] == 7 and g[2] == 14 and g[3] == 7                                             # a row is 7 rounds: odd sample stride
-    assert geo(250, 249, 4000, _lib.F32, _lib.F32)[0] == 0                                                  # L > 192
+    assert geo(250, 249, 4000, _lib.F32, _lib.F32)[:5] == [1, 1, 250, 249, 16]                              # L > 192: two column blocks per wave
+    assert geo(2000, 1999, 40000, _lib.F32, _lib.F32)[0] == 0                                               # L > 1024
     assert geo(160, 147, 5120, _lib.F64, _lib.F32)[0] == 0                                                  # Float64 taps on a Float32 signal
     assert geo(160, 147, 5120, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
     assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:7] == [1, 1, 147, 160, 10, 1, 16]                       # 48 kHz -> 44.1 kHz (rows staged one by one: M = 160 is a multiple of 32)
@@ -470,7 +471,7 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     rng = np.random.default_rng(42)
     fits = 0
     for _ in range(3000):
-        L, M = int(rng.integers(1, 260)), int(rng.integers(1, 700))
+        L, M = int(rng.integers(1, 1100)), int(rng.integers(1, 700))
         hlen = int(rng.integers(1, 9000))
         tdt = [_lib.F32, _lib.F64][int(rng.integers(0, 2))]
         xdt = [_lib.F32, _lib.F64, _lib.C32, _lib.C64][int(rng.integers(0, 4))]
@@ -482,8 +483,9 @@ def test_matrix_core_polyphase_geometry_is_consistent():
         fits += 1
         tp = -(-hlen // Lq)
         assert dbl == (xdt in (_lib.F64, _lib.C64))                       # compute type == signal type
-        assert Lq <= 192 and Lr == RB * Lq and Mr == RB * Mq and (RB == 1 if Lq >= 16 else Lr <= 16)
-        assert NB == -(-Lr // 16) and 1 <= NG <= 8 and NB * NG + nd + ns <= 16 and nd >= 1 and ns >= 1
+        assert Lq <= 1024 and Lr == RB * Lq and Mr == RB * Mq and (RB == 1 if Lq >= 16 else Lr <= 16)
+        NBW = NB if NB <= 12 else -(-NB // -(-NB // 12))                 # multiplying waves per row group (several column blocks each when L > 192)
+        assert NB == -(-Lr // 16) and 1 <= NG <= 8 and NBW * NG + nd + ns <= 16 and nd >= 1 and ns >= 1
         assert CS == (2 if xdt in (_lib.C32, _lib.C64) else 1) and CH in ((4, 2, 1) if (not dbl and CS == 1) else (2, 1))
         dmax = ((Lq - 1) + (min(Lr, 16) - 1) * Mq) // Lq
         assert 4 * T >= tp + dmax and T <= 1024 and (T <= (32 if dbl else 64) or T % 8 == 0)   # every tap of every column of a block has a k-step

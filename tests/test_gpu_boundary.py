@@ -417,7 +417,7 @@ def test_host_pipelines_with_padded_leading_dimensions(d, torch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["f32", "c32", "f64", "c64"])
 @pytest.mark.parametrize("L,M,ntaps", [(160, 147, 5120), (160, 147, 5921), (23, 17, 300), (16, 9, 129), (17, 35, 1100), (37, 2, 400), (250, 249, 4000), (14, 9, 64),
-                                           (2, 1, 49), (1, 2, 31), (3, 2, 73), (2, 3, 61), (4, 1, 97), (1, 4, 40), (5, 3, 101), (1, 1, 33), (7, 4, 120), (25, 24, 700), (192, 191, 6000), (1, 4, 193), (1, 3, 170), (2, 5, 400), (147, 160, 5881), (160, 441, 16001), (20, 441, 2200), (1, 8, 441), (80, 441, 16001), (1, 1, 300)])
+                                           (2, 1, 49), (1, 2, 31), (3, 2, 73), (2, 3, 61), (4, 1, 97), (1, 4, 40), (5, 3, 101), (1, 1, 33), (7, 4, 120), (25, 24, 700), (192, 191, 6000), (1, 4, 193), (1, 3, 170), (2, 5, 400), (147, 160, 5881), (160, 441, 16001), (20, 441, 2200), (1, 8, 441), (80, 441, 16001), (1, 1, 300), (441, 160, 16001), (320, 147, 9000), (1000, 999, 30000)])
 def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M, ntaps, dt):
     # The matrix-core kernel (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64: 16 rows x 16 outputs, a k-ordered fmaf chain) and the
     # register-tap / generic kernels sum each output in the same order: bit-identical Float32 outputs (Float64: to rounding) and
@@ -429,7 +429,7 @@ def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M,
     lib = _lib.lib()
     tdt, hdt, ldt_h, ldt_x, tol = {"f32": (torch.float32, np.float32, _lib.F32, _lib.F32, 2e-6), "c32": (torch.complex64, np.float32, _lib.F32, _lib.C32, 2e-6),
                                    "f64": (torch.float64, np.float64, _lib.F64, _lib.F64, 1e-13), "c64": (torch.complex128, np.float64, _lib.F64, _lib.C64, 1e-13)}[dt]
-    if dt != "f32" and (L, M) in ((160, 147), (250, 249), (192, 191), (160, 441), (80, 441)) and ntaps != 5120:
+    if dt != "f32" and (L, M) in ((160, 147), (250, 249), (192, 191), (160, 441), (80, 441), (441, 160), (1000, 999)) and ntaps != 5120:
         pytest.skip("the large shapes are run once per dtype")
     rng = np.random.default_rng(L * 1000 + M)
     h = (rng.standard_normal(ntaps) / np.sqrt(ntaps / L)).astype(hdt)
@@ -499,7 +499,9 @@ def test_polyphase_kernel_choice(d, torch):
     assert path(h.astype(np.float64), 160, 147, _lib.F32, 4, 2 ** 28) == 0      # Float64 taps on a Float32 signal: generic kernel
     assert path(rng.standard_normal(48).astype(np.float32), 2, 1, _lib.F32, 1, 2 ** 26) == 2      # interpolation by 2: a row is 7 rounds
     assert path(rng.standard_normal(64).astype(np.float32), 1, 2, _lib.F32, 1, 2 ** 26) == 2      # decimation by 2
-    assert path(rng.standard_normal(4000).astype(np.float32), 250, 249, _lib.F32, 1, 2 ** 26) == 1  # L > 192
+    assert path(rng.standard_normal(4000).astype(np.float32), 250, 249, _lib.F32, 1, 2 ** 26) == 1  # L > 192 in Float32: the register-tap kernel is the faster one
+    assert path(rng.standard_normal(4000), 250, 249, _lib.F64, 1, 2 ** 26) == 2                     # ... in Float64 the matrix cores (several column blocks per wave)
+    assert path(rng.standard_normal(40000).astype(np.float32), 2000, 1999, _lib.F32, 1, 2 ** 26) == 0  # L > 1024
 
 
 @pytest.mark.gpu
@@ -514,7 +516,7 @@ def test_polyphase_matrix_core_kernel_fuzz(d, torch):
     tried = used = 0
     try:
         for it in range(60):
-            L = int(rng.integers(1, 200)); M = int(rng.integers(1, 260))
+            L = int(rng.integers(1, 500)); M = int(rng.integers(1, 260))
             g0 = gcd(L, M); L //= g0; M //= g0
             tp = int(rng.integers(1, 70))
             ntaps = int(max(1, tp * L - rng.integers(0, L)))
