@@ -1138,7 +1138,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     if (steps > 1024 || (int64_t)(f->L + (int64_t)(g.Lr + 16) * f->M) * f->L >= ((int64_t)1 << 32)) return g;   // (the multiply-high quotients stay exact)
     g.NBW = std::min(g.NB, 12);   // more than 12 column blocks (L > 192): a wave takes several, with their taps fetched per tile
     if (g.NBW < g.NB) g.NBW = (int)cdiv((int64_t)g.NB, cdiv((int64_t)g.NB, (int64_t)12));   // as even as it gets
-    if (steps > (g.esz == 8 ? 32 : 64) || g.NBW < g.NB) {   // the taps do not fit registers (T, Float64 2 T, VGPRs): fetched per tile
+    if (steps > (g.esz == 8 ? (g.CS == 2 ? 24 : 32) : (g.CS == 2 ? 64 : 48)) || g.NBW < g.NB) {   // (beyond: too many registers -- measured: ComplexF64 at T = 32 and Float32 at T = 64 spill and lose 40 - 50 %)   // the taps do not fit registers (T, Float64 2 T, VGPRs): fetched per tile
         g.T = 0;
         g.steps = (int)cdiv(steps, (int64_t)8) * 8;
     } else {
@@ -1147,24 +1147,29 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     }
     g.Lp = g.NB == 1 ? g.Lr * g.CS : 16 * g.NB * g.CS + 16 / g.esz;
     const int dw = g.esz / 4 * g.CS;
-    // Rows (lane stride Mr samples) of a linear tile hit 32 / gcd(Mr dw, 32) banks.  From four-way conflicts on, staging the rows one by
-    // one (pitch 256 g + 4 dwords: two-way conflicts) is the alternative -- unless the window tail it duplicates per row (long filters)
-    // shrinks the tile too much: the larger of (rows per tile) / (conflict ways) decides.
+    // Rows (lane stride Mr samples) of a linear tile hit banks / gcd(Mr dw, banks) places.  From four-way conflicts on, staging the rows
+    // one by one (pitch 256 g + 4 dwords: two-way conflicts in Float32, none in Float64) is the alternative -- unless the window tail it
+    // duplicates per row (long filters) shrinks the tile too much.
     const int wtail = 4 * g.steps + 4;
-    const int64_t gb = std::gcd((int64_t)g.Mr * dw, (int64_t)32);
+    // conflict ways of the 16 rows of an A operand: 4-byte reads see 32 banks, 8-byte reads 64; rows s dwords apart land on banks / gcd(s, banks) places
+    const int banks = g.esz == 8 ? 64 : 32;
+    const auto ways_of = [&](int64_t s) { return (double)std::max<int64_t>(1, 16 / std::min<int64_t>(16, banks / std::gcd(s, (int64_t)banks))); };
     const int rpitch = (int)cdiv((int64_t)(g.Mr + wtail) * dw, (int64_t)256) * 256 + 4;
+    const double ways_lin = ((g.Mr * dw) & 1) ? 1.0 : ways_of((int64_t)g.Mr * dw), ways_row = ways_of(rpitch);
+    // cost per row of outputs ~ max(1, 0.2 ways) [the A-operand reads keep the LDS about 20 % busy when conflict-free] + 32 / rows [one
+    // barrier and pipeline turn-around per tile, worth about 32 rows]: the staging mode and tile with the smallest cost
     double best_score = -1;
     for (int mode = 0; mode < 2; ++mode) {   // 0: one linear run per tile, 1: row by row
-        if (mode == 1 && (tunables().fir_mm_rows == 0 || (tunables().fir_mm_rows < 0 && gb < 8))) continue;
+        if (mode == 1 && (tunables().fir_mm_rows == 0 || (tunables().fir_mm_rows < 0 && ways_lin < 4))) continue;
         if (mode == 0 && tunables().fir_mm_rows == 1) continue;
-        const double ways = mode ? 2.0 : std::max(1.0, (double)gb / 2);
+        const double ways = mode ? ways_row : ways_lin;
         for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
             const int rows = 16 * ch;
             for (int ng = std::min(8, 12 / g.NBW); ng >= 1; --ng) {
                 const int64_t bufsz = mode ? cdiv((int64_t)rows * ng * rpitch, (int64_t)256) * 256 : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
                 const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
                 if (bytes <= 160 * 1024) {
-                    const double score = rows * ng / ways + 1e-3 * ch;
+                    const double score = 1.0 / (std::max(1.0, 0.2 * ways) + 32.0 / (rows * ng)) + 1e-6 * ch;
                     if (score > best_score) { best_score = score; g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; g.pitch = mode ? rpitch : 0; }
                     break;
                 }

@@ -466,7 +466,7 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     assert geo(160, 147, 5120, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
     assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:7] == [1, 1, 147, 160, 10, 1, 16]                       # 48 kHz -> 44.1 kHz (rows staged one by one: M = 160 is a multiple of 32)
     assert geo(160, 441, 16001, _lib.F32, _lib.F32)[7] == 2                                                 # 44.1 kHz -> 16 kHz
-    assert geo(1, 2, 64 * 4 + 1, _lib.F32, _lib.F32)[6] == 72                                               # more than 256 window positions: taps fetched per tile
+    assert geo(1, 2, 48 * 4 + 1, _lib.F32, _lib.F32)[6] == 56                                               # more than 192 window positions: taps fetched per tile
     assert geo(1, 2, 5000, _lib.F32, _lib.F32)[0] == 0                                                      # more than 4096 window positions
     rng = np.random.default_rng(42)
     fits = 0
@@ -496,7 +496,7 @@ def test_matrix_core_polyphase_geometry_is_consistent():
         lin = -(-((rows * Mr + Mr + 4 * T + 4) * dw) // 256) * 256           # ... or the tile as one run
         obuf = 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + 16 // esz) * esz
         need = 2 * 4 * lin + obuf
-        if gcd(Mr * dw, 32) >= 8 and lds != need:
+        if lds != need:                                                    # rows staged one by one (bank-hostile sample strides)
             need = 2 * 4 * (-(-(rows * pitch) // 256) * 256) + obuf
         assert lds == need <= 160 * 1024
     assert fits > 300
