@@ -1159,6 +1159,9 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     // cost per row of outputs ~ max(1, 0.2 ways) [the A-operand reads keep the LDS about 20 % busy when conflict-free] + 32 / rows [one
     // barrier and pipeline turn-around per tile, worth about 32 rows]: the staging mode and tile with the smallest cost
     double best_score = -1;
+    for (int pad = 1; pad >= 0 && !g.ok; --pad) {   // (a last resort: output rows without their 16 bytes of padding -- ComplexF64 at 160//147 then fits exactly)
+    if (g.NB > 1) g.Lp = 16 * g.NB * g.CS + (pad ? 16 / g.esz : 0);
+    else if (!pad) break;
     for (int mode = 0; mode < 2; ++mode) {   // 0: one linear run per tile, 1: row by row
         if (mode == 1 && (tunables().fir_mm_rows == 0 || (tunables().fir_mm_rows < 0 && ways_lin < 4))) continue;
         if (mode == 0 && tunables().fir_mm_rows == 1) continue;
@@ -1175,6 +1178,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
                 }
             }
         }
+    }
     }
     if (!g.ok) return g;
     const int extra = 16 - g.NBW * g.NG;   // memory waves beside the multiplying ones (16 waves per workgroup at most)

@@ -463,7 +463,8 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     assert geo(250, 249, 4000, _lib.F32, _lib.F32)[:5] == [1, 1, 250, 249, 16]                              # L > 192: two column blocks per wave
     assert geo(2000, 1999, 40000, _lib.F32, _lib.F32)[0] == 0                                               # L > 1024
     assert geo(160, 147, 5120, _lib.F64, _lib.F32)[0] == 0                                                  # Float64 taps on a Float32 signal
-    assert geo(160, 147, 5120, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
+    assert geo(160, 147, 5120, _lib.F64, _lib.C64)[-1] == 160 * 1024                                        # ComplexF64: 16 rows per wave, unpadded output rows: exactly the LDS
+    assert geo(147, 160, 5881, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
     assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:7] == [1, 1, 147, 160, 10, 1, 16]                       # 48 kHz -> 44.1 kHz (rows staged one by one: M = 160 is a multiple of 32)
     assert geo(160, 441, 16001, _lib.F32, _lib.F32)[7] == 2                                                 # 44.1 kHz -> 16 kHz
     assert geo(1, 2, 48 * 4 + 1, _lib.F32, _lib.F32)[6] == 56                                               # more than 192 window positions: taps fetched per tile
@@ -494,9 +495,9 @@ def test_matrix_core_polyphase_geometry_is_consistent():
         dw = (esz // 4) * CS
         pitch = -(-((Mr + 4 * T + 4) * dw) // 256) * 256 + 4               # rows staged one by one (sample strides that are multiples of 8) ...
         lin = -(-((rows * Mr + Mr + 4 * T + 4) * dw) // 256) * 256           # ... or the tile as one run
-        obuf = 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + 16 // esz) * esz
-        need = 2 * 4 * lin + obuf
-        if lds != need:                                                    # rows staged one by one (bank-hostile sample strides)
-            need = 2 * 4 * (-(-(rows * pitch) // 256) * 256) + obuf
-        assert lds == need <= 160 * 1024
+        def total(padded, rowwise):
+            ibuf = -(-(rows * pitch) // 256) * 256 if rowwise else lin
+            return 2 * 4 * ibuf + 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + (16 // esz if padded else 0)) * esz
+        need = next((v for v in (total(True, False), total(True, True), total(False, False), total(False, True)) if v == lds), None)
+        assert need is not None and lds <= 160 * 1024
     assert fits > 300
