@@ -269,13 +269,14 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 // ComplexF32 signals, Float64 arithmetic on Float64 / ComplexF64 signals; any ratio with L <= 192).
 //
 // The register-tap kernel above is bound by the LDS and the vector ALU: P = 2 residues share one window (16.5 ds_read_b32 and
-// 16.5 v_pk_fma_f32 per output; 68 % LDS-array busy, and v_pk_fma_f32 issues at the v_fma_f32 rate, 16 FMA/clk/SIMD), more residues
-// per thread cost VGPRs and occupancy (P = 4: 228 VGPRs, slower) -- 2.5 ms on BASELINE config 5 against an HBM floor of 1.9.
+// 16.5 v_pk_fma_f32 per output; 68 % LDS-array busy, the packed FMAs at 8 - 10 clocks each between their LDS reads against 4.4 in
+// isolation), more residues per thread cost VGPRs and occupancy (P = 4: 228 VGPRs, slower) -- 2.5 ms on BASELINE config 5 against an
+// HBM floor of 1.6 - 1.9.
 // Outputs of the same residue s in different rounds q share their taps, and neighbouring residues read windows that start delta_j =
 // c_{s0+j} - c_{s0} <= j samples apart: for 16 rounds x 16 residues,
 //      Y[q][j] = sum_k  X[q][k] * H[k][j],    X[q][k] = z[q M + c_{s0} + k],    H[k][j] = pfb[phase_j][k - delta_j]  (0 outside the bank)
-// is a (16 x K)(K x 16) product with K = tp + delta_15 -- what the f32 matrix instruction computes, four k per issue, at 4x the
-// vector FMA rate and with the VALU left free.  Its arithmetic is bit for bit a k-ordered fmaf chain (one rounding per product,
+// is a (16 x K)(K x 16) product with K = tp + delta_15 -- what the f32 matrix instruction computes, four k per issue: 1024 multiply-adds
+// per operand read from LDS, at the vector unit's peak FMA rate, and with the VALU left free.  Its arithmetic is bit for bit a k-ordered fmaf chain (one rounding per product,
 // no wider accumulator; /opt/skills/guides/cdna_hip_programming.md section 3), i.e. exactly the oldest-sample-first chain of the
 // register-tap kernel: the zero taps add exact zeros and the two kernels agree bit for bit (tests/test_gpu_boundary.py).
 // This is not a GEMM reshaping of the problem: no operand is materialised or reordered in memory, X is the staged signal tile
