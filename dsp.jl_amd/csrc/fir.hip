@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 
 // ------------------------------------------------------------------------------------------------------------
 // Matrix-core path: the polyphase bank as the B operand of v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 (Float32 taps on Float32 /
-// ComplexF32 signals, Float64 arithmetic on Float64 / ComplexF64 signals; any ratio with L <= 192).
+// ComplexF32 signals, Float64 arithmetic on Float64 / ComplexF64 signals; any ratio with L <= 1024 and filters of any length).
 //
 // The register-tap kernel above is bound by the LDS and the vector ALU: P = 2 residues share one window (16.5 ds_read_b32 and
 // 16.5 v_pk_fma_f32 per output; 68 % LDS-array busy, the packed FMAs at 8 - 10 clocks each between their LDS reads against 4.4 in
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 // c_{s0+j} - c_{s0} <= j samples apart: for 16 rounds x 16 residues,
 //      Y[q][j] = sum_k  X[q][k] * H[k][j],    X[q][k] = z[q M + c_{s0} + k],    H[k][j] = pfb[phase_j][k - delta_j]  (0 outside the bank)
 // is a (16 x K)(K x 16) product with K = tp + delta_15 -- what the f32 matrix instruction computes, four k per issue: 1024 multiply-adds
-// per operand read from LDS, at the vector unit's peak FMA rate, and with the VALU left free.  Its arithmetic is bit for bit a k-ordered fmaf chain (one rounding per product,
-// no wider accumulator; /opt/skills/guides/cdna_hip_programming.md section 3), i.e. exactly the oldest-sample-first chain of the
+// per operand read from LDS, at the vector unit's peak FMA rate, and with the VALU left free.  Its arithmetic is bit for bit a k-ordered
+// fmaf chain (one rounding per product, no wider accumulator; /opt/skills/guides/cdna_hip_programming.md section 3), i.e. exactly the oldest-sample-first chain of the
 // register-tap kernel: the zero taps add exact zeros and the two kernels agree bit for bit (tests/test_gpu_boundary.py).
 // This is not a GEMM reshaping of the problem: no operand is materialised or reordered in memory, X is the staged signal tile
 // itself (lane l reads z[(q0 + l%16) M + c + 4 t + l/16], one ds_read_b32 per MFMA), H lives in T VGPRs per wave for the whole
@@ -289,7 +289,10 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 //            that only issue the DMA of the next tile and ns waves that only store the previous tile's outputs: the memory
 //            waves work through the whole tile period beside the MFMAs, one s_barrier per tile
 //   LDS    = two sample buffers + two output buffers (config 5: 2 x 38 KiB + 2 x 41 KiB = 158 KiB, one workgroup of 16 waves per CU)
-// For L < 16 a row of the product is RB whole rounds (RB L <= 16 consecutive outputs, RB M samples): see fir_mm_geo().
+// Variations, all chosen by fir_mm_geo(): for L < 16 a row of the product is RB whole rounds (RB L <= 16 consecutive outputs, RB M
+// samples) and several groups of rows share a tile; 2 or 1 chunks of 16 rows per wave when the tile would not fit; rows staged one by
+// one (padded pitch) when their sample stride is bank-hostile; taps fetched from L2 per tile when they do not fit registers (long
+// filters, or several column blocks per wave for L > 192).
 // Measured on BASELINE config 5 (4 ch x 2^28, 160//147, 5120 taps): 1.86 ms = 4.8 TB/s of algorithmic traffic, the device-copy
 // rate of this GPU, against 2.4 - 2.5 ms for the register-tap kernel (profiles/r02q_*); other ratios and types: DESIGN.md section 4.6.
 // ------------------------------------------------------------------------------------------------------------
