@@ -1172,7 +1172,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
         const double ways = mode ? ways_row : ways_lin;
         for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
             const int rows = 16 * ch;
-            for (int ng = std::min(8, 12 / g.NBW); ng >= 1; --ng) {
+            for (int ng = std::min(tunables().fir_mm_ng > 0 ? tunables().fir_mm_ng : 8, 12 / g.NBW); ng >= 1; --ng) {
                 const int64_t bufsz = mode ? cdiv((int64_t)rows * ng * rpitch, (int64_t)256) * 256 : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
                 const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
                 if (bytes <= 160 * 1024) {
