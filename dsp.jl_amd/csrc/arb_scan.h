@@ -38,9 +38,9 @@
 #include <cstdint>
 
 #if defined(__HIPCC__)
-#define MDSP_HD __host__ __device__ inline
+#define ARBSCAN_HD __host__ __device__ inline
 #else
-#define MDSP_HD inline
+#define ARBSCAN_HD inline
 #endif
 
 namespace mdsp {
@@ -60,7 +60,7 @@ struct Grid {
     int nthr;
 };
 
-MDSP_HD int bitlen64(uint64_t v) {
+ARBSCAN_HD int bitlen64(uint64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return v ? 64 - __clzll((long long)v) : 0;
 #else
@@ -103,10 +103,10 @@ inline bool to_grid(const Grid& G, double acc, uint64_t& A) {
     return A < G.N;
 }
 
-MDSP_HD double from_grid(const Grid& G, uint64_t A) { return ldexp((double)A, G.gexp); }   // exact: A is a representable multiple
+ARBSCAN_HD double from_grid(const Grid& G, uint64_t A) { return ldexp((double)A, G.gexp); }   // exact: A is a representable multiple
 
 // one update on the grid; returns eps = S' - S
-MDSP_HD int64_t step(const Grid& G, uint64_t& A, int64_t& W) {
+ARBSCAN_HD int64_t step(const Grid& G, uint64_t& A, int64_t& W) {
     uint64_t S = A + G.D;
     const uint64_t S0 = S;
     if (S >> 53) {
@@ -125,7 +125,7 @@ MDSP_HD int64_t step(const Grid& G, uint64_t& A, int64_t& W) {
 }
 
 // one update of the unrounded trajectory
-MDSP_HD void base_step(const Grid& G, uint64_t& A0, int64_t& W0) {
+ARBSCAN_HD void base_step(const Grid& G, uint64_t& A0, int64_t& W0) {
     A0 += G.rd;
     W0 += (int64_t)G.qd;
     if (A0 >= G.N) {
@@ -135,7 +135,7 @@ MDSP_HD void base_step(const Grid& G, uint64_t& A0, int64_t& W0) {
 }
 
 // circular distance of A to the nearest binade threshold / the wrap point
-MDSP_HD uint64_t threshold_distance(const Grid& G, uint64_t A) {
+ARBSCAN_HD uint64_t threshold_distance(const Grid& G, uint64_t A) {
     uint64_t d = A < G.N - A ? A : G.N - A;
     for (int i = 0; i < G.nthr; ++i) {
         const uint64_t t = G.thr[i];
@@ -146,7 +146,7 @@ MDSP_HD uint64_t threshold_distance(const Grid& G, uint64_t A) {
 }
 
 // (hi:lo) / n with hi < n: quotient and remainder by shift-subtract
-MDSP_HD void divmod128(uint64_t hi, uint64_t lo, uint64_t n, uint64_t& q, uint64_t& r) {
+ARBSCAN_HD void divmod128(uint64_t hi, uint64_t lo, uint64_t n, uint64_t& q, uint64_t& r) {
     uint64_t rem = hi, quo = 0;
     for (int i = 63; i >= 0; --i) {
         const uint64_t top = rem >> 63;
@@ -161,7 +161,7 @@ MDSP_HD void divmod128(uint64_t hi, uint64_t lo, uint64_t n, uint64_t& q, uint64
     r = rem;
 }
 
-MDSP_HD void mul64(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
+ARBSCAN_HD void mul64(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
 #if defined(__HIP_DEVICE_COMPILE__)
     hi = __umul64hi(a, b);
     lo = a * b;
@@ -173,7 +173,7 @@ MDSP_HD void mul64(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
 }
 
 // unrounded state after n updates from (As, 0):  As + n D = W N + A
-MDSP_HD void base_at(const Grid& G, uint64_t As, uint64_t n, uint64_t& A, int64_t& W) {
+ARBSCAN_HD void base_at(const Grid& G, uint64_t As, uint64_t n, uint64_t& A, int64_t& W) {
     uint64_t hi, lo;
     mul64(n, G.rd, hi, lo);
     const uint64_t lo2 = lo + As;
@@ -184,7 +184,7 @@ MDSP_HD void base_at(const Grid& G, uint64_t As, uint64_t n, uint64_t& A, int64_
     W = (int64_t)(n * G.qd + q);
 }
 
-MDSP_HD uint64_t add_mod(const Grid& G, uint64_t A, int64_t c) {   // (A + c) mod N, |c| << 2^62
+ARBSCAN_HD uint64_t add_mod(const Grid& G, uint64_t A, int64_t c) {   // (A + c) mod N, |c| << 2^62
     int64_t v = (int64_t)A + c;
     const int64_t n = (int64_t)G.N;
     if (v >= n || v < 0) {
@@ -197,11 +197,11 @@ MDSP_HD uint64_t add_mod(const Grid& G, uint64_t A, int64_t c) {   // (A + c) mo
 // Offset the tables of block b are built around: the predicted E (a multiple of R), so that the true position stays
 // within a few units of the simulated candidates however far E has drifted (E is very nearly linear in k: the
 // rounding pattern is quasi-periodic).  pass 0: slope from a serial pilot; pass 1: the E of a previous scan.
-MDSP_HD int64_t predicted_offset(const Grid& G, double sigma, int64_t k) {
+ARBSCAN_HD int64_t predicted_offset(const Grid& G, double sigma, int64_t k) {
     const double c = sigma * (double)k / (double)G.R;
     return (int64_t)llrint(c) * (int64_t)G.R;
 }
-MDSP_HD int64_t round_offset(const Grid& G, int64_t E) { return (E >> (G.J + 1)) << (G.J + 1); }
+ARBSCAN_HD int64_t round_offset(const Grid& G, int64_t E) { return (E >> (G.J + 1)) << (G.J + 1); }
 
 struct ScanArgs {
     Grid G;
@@ -227,7 +227,7 @@ struct ScanArgs {
 
 // K1: tables of block b.  RC = the table size as a compile-time constant (device: candidates live in registers), 0 = read it
 // from the grid (host emulation).
-template <int RC = 0> MDSP_HD void scan_tables_body(const ScanArgs& a, int64_t b) {
+template <int RC = 0> ARBSCAN_HD void scan_tables_body(const ScanArgs& a, int64_t b) {
     const Grid& G = a.G;
     constexpr int CAP = RC ? RC : RMAX;
     const int R = RC ? RC : G.R;
@@ -267,7 +267,7 @@ template <int RC = 0> MDSP_HD void scan_tables_body(const ScanArgs& a, int64_t b
 }
 
 // K2 up: out[g] = in[FAN g] then in[FAN g + 1] then ...   (tables are R consecutive entries; wide sums above level 0)
-template <int RC, typename TIn> MDSP_HD void scan_compose_body(const Grid& G, const TIn* in, int64_t n, int64_t* out, int64_t g) {
+template <int RC, typename TIn> ARBSCAN_HD void scan_compose_body(const Grid& G, const TIn* in, int64_t n, int64_t* out, int64_t g) {
     constexpr int CAP = RC ? RC : RMAX;
     const int R = RC ? RC : G.R;
     int64_t acc[CAP];
@@ -289,7 +289,7 @@ template <int RC, typename TIn> MDSP_HD void scan_compose_body(const Grid& G, co
 }
 
 // K2 top: serial over the coarsest level
-MDSP_HD void scan_top_body(const Grid& G, const int64_t* in, int64_t n, int64_t* Eout) {
+ARBSCAN_HD void scan_top_body(const Grid& G, const int64_t* in, int64_t n, int64_t* Eout) {
     int64_t E = 0;
     for (int64_t t = 0; t < n; ++t) {
         Eout[t] = E;
@@ -298,7 +298,7 @@ MDSP_HD void scan_top_body(const Grid& G, const int64_t* in, int64_t n, int64_t*
 }
 
 // K2 down: E at the starts of the fine elements of group g from the group's own start
-template <typename TIn> MDSP_HD void scan_expand_body(const Grid& G, const TIn* in, int64_t n, const int64_t* Ecoarse, int64_t* Efine, int64_t g) {
+template <typename TIn> ARBSCAN_HD void scan_expand_body(const Grid& G, const TIn* in, int64_t n, const int64_t* Ecoarse, int64_t* Efine, int64_t g) {
     int64_t E = Ecoarse[g];
     const int64_t lo = g * FAN, hi = lo + FAN < n ? lo + FAN : n;
     for (int64_t t = lo; t < hi; ++t) {
@@ -308,7 +308,7 @@ template <typename TIn> MDSP_HD void scan_expand_body(const Grid& G, const TIn* 
 }
 
 // K3: exact anchor of block b; the block that contains the end of the stream replays its updates and reports the end state
-MDSP_HD void scan_finalize_body(const ScanArgs& a, int64_t b) {
+ARBSCAN_HD void scan_finalize_body(const ScanArgs& a, int64_t b) {
     const Grid& G = a.G;
     const int64_t E = a.E[b], dE = E - a.cb[b];
     const uint64_t absd = (uint64_t)(dE < 0 ? -dE : dE);
