@@ -75,3 +75,25 @@ def test_matrix_form_from_a_mid_stream_state():
     full = matrix_form(h, L, M, x)
     assert len(full) == len(y1) + len(y2)
     assert np.max(np.abs(full - np.concatenate([y1, y2]))) <= 1e-12 * np.max(np.abs(full))
+
+
+def test_matrix_form_random_shapes():
+    rng = np.random.default_rng(2026)
+    done = 0
+    out = (C.c_int64 * 12)()
+    while done < 40:
+        L, M = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+        tp = int(rng.integers(1, 90))
+        g0 = gcd(L, M)
+        ntaps = max(1, tp * (L // g0) - int(rng.integers(0, L // g0)))
+        _lib.check(_lib.lib().mdsp_fir_mm_geometry(L, M, ntaps, _lib.F64, _lib.F64, out))
+        if not out[0]:
+            continue
+        h = rng.standard_normal(ntaps)
+        x = rng.standard_normal(int(rng.integers(1, 2500)))
+        ref = osf.FIRFilter(h, Fraction(L, M)).filt(x)
+        got = matrix_form(h, L, M, x)
+        assert got.shape == ref.shape, (L, M, ntaps, len(x))
+        if len(ref):
+            assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), (L, M, ntaps, len(x))
+        done += 1
