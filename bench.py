@@ -150,6 +150,51 @@ def cpu_baseline(log2n: int):
                                    f"Float32 accumulation): filt {t_faith_filt:.2f}s + welch {t_faith_welch:.2f}s"}}
 
 
+def cpu_baseline_config(config: str, log2n: int):
+    """CPU baseline of the --config stft / resample lines: the oracle (numpy restatement of DSP.jl, one thread) on a bounded single-channel
+    sample of the same workload; for the resampler also SciPy's compiled polyphase routine as a second opinion."""
+    import numpy as np
+    from fractions import Fraction
+    try:
+        import threadpoolctl
+        ctl = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        ctl = None
+    ncores = os.cpu_count() or 1
+    n = 1 << log2n
+    rng = np.random.default_rng(1776)
+    if config == "resample":
+        from oracle import stream_filt as osf
+        h = resample_taps()
+        x = rng.standard_normal(n, dtype=np.float32)
+        t0 = time.perf_counter()
+        y = osf.FIRFilter(h, Fraction(160, 147)).filt(x)
+        t = time.perf_counter() - t0
+        res = {"value": round(n / t / 1e9, 6), "unit": "Gsamples/s", "cores": 1, "kind": "port",
+               "sample": f"one channel of 2^{log2n} Float32 samples, 160//147, 5120 taps: oracle FIRFilter.filt (numpy restatement of stream_filt.jl:476-515, "
+                         f"not DSP.jl/BLAS) {t:.2f}s -> {len(y)} outputs; host has {ncores} cores"}
+        try:
+            import scipy.signal as ss
+            t0 = time.perf_counter()
+            ss.upfirdn(h, x, 160, 147)
+            t2 = time.perf_counter() - t0
+            res["compiled"] = {"value": round(n / t2 / 1e9, 6), "cores": 1, "sample": f"same sample through scipy.signal.upfirdn (compiled polyphase loop, different edge handling): {t2:.2f}s"}
+        except Exception as e:  # pragma: no cover
+            res["compiled"] = {"value": None, "sample": f"scipy.signal.upfirdn failed: {e}"}
+    else:
+        from oracle import periodograms as opg, windows as ow
+        s = (rng.standard_normal(n, dtype=np.float32) + 1j * rng.standard_normal(n, dtype=np.float32)).astype(np.complex64)
+        t0 = time.perf_counter()
+        S = opg.stft(s, 1024, 768, window=ow.hanning, onesided=False)
+        t = time.perf_counter() - t0
+        res = {"value": round(n / t / 1e9, 6), "unit": "Gsamples/s", "cores": 1, "kind": "port",
+               "sample": f"one channel of 2^{log2n} ComplexF32 samples, nfft 1024, hop 256: oracle stft (numpy / pocketfft restatement of periodograms.jl:872-897, "
+                         f"not DSP.jl/FFTW) {t:.2f}s -> {S.shape[1]} columns; host has {ncores} cores"}
+    if ctl is not None and hasattr(ctl, "restore_original_limits"):
+        ctl.restore_original_limits()
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------------------ helpers
 class Timer:
     """HIP events on the launch stream (torch.cuda.Event would only see torch's current stream; these are recorded on the
@@ -610,9 +655,9 @@ def main():
                 out["host_path"] = measure_host_path(lib, _lib, d, args.host_log2n)
             except Exception as e:  # pragma: no cover
                 out["host_path"] = {"error": str(e)}
-        if world == 1 and not args.no_cpu_baseline and args.config == "filtwelch":
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_log2n)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_log2n) if args.config == "filtwelch" else cpu_baseline_config(args.config, min(args.cpu_log2n, 23))
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "Gsamples/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         out["commit"] = git_head()
