@@ -2,7 +2,10 @@
 """bench.py -- benchmark of the hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--config filtwelch|stft|resample]
-                                                   (N > 1: launched by torch.distributed.run, one rank per GPU)
+        N > 1: one rank per GPU.  Either the caller launches the ranks (python -m torch.distributed.run --nproc-per-node N ... bench.py
+        --gpus N: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or -- when no launcher environment is present --
+        this script launches them ITSELF (re-exec under torch.distributed.run on 127.0.0.1).  Fewer than N visible devices: exit code 2 and
+        no JSON line (never an `n_gpus: 1` line for --gpus 8).
 
 --config filtwelch (default; the BASELINE.json metric "Gsamples/s filt+welch, 1 Gsample Float32 stream"):
     one step = one pass of the hot path over one 2^30-sample Float32 stream per GPU, already resident in HBM:
@@ -52,7 +55,7 @@ METRIC = "Gsamples/s filt+welch, 1 Gsample Float32 stream; achieved HBM GB/s vs 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE when launched by torchrun, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["filtwelch", "stft", "resample"], default="filtwelch")
@@ -230,6 +233,21 @@ class Timer:
         return ts[len(ts) // 2], ts[0]
 
 
+class Marks:
+    """Row markers for the profiler: before each measured row, one mdsp_fill_kernel launch with (100 + row index) workgroups on the launch stream
+    (tools/prof_summary.py rows() cuts the dispatch list at them).  ~2 us each, always outside the timed regions."""
+    ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32")
+
+    def __init__(self, lib, _lib, stream):
+        import torch
+        self.lib, self._lib, self.stream = lib, _lib, stream
+        self.buf = torch.empty(16 * 256 * (100 + len(self.ROWS)) // 4, dtype=torch.float32, device="cuda")
+
+    def __call__(self, row):
+        nwg = 100 + self.ROWS.index(row)
+        self._lib.check(self.lib.mdsp_copy_bench_mode(self.buf.data_ptr(), self.buf.data_ptr(), 16 * 256 * nwg, 5, 8, self.stream))
+
+
 def roof(kernel, ms, alg_bytes, traffic=None, extra=None):
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -283,23 +301,17 @@ def live_traffic(args):
         dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
         if not dbs:
             return None, f"rocprofv3 --pmc {ctr} produced no database (rc {p.returncode})"
-        try:
-            out[ctr] = prof_summary.pmc(dbs[0])
-        except Exception as e:
-            return None, f"cannot read the {ctr} database: {e}"
-    res = {}
-    for key, pat in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("stft", "true, false, 2, 1, true, 4>"),
-                     ("spectrogram", "true, true, 2, 1, true, 4>"), ("resample", "polyphase_"), ("firarb", "arbitrary_fir_kernel"), ("copy", "mdsp_copy_kernel")):
-        f = next((v["counters"].get("FETCH_SIZE") for k, v in out["FETCH_SIZE"].items() if pat in k), None)
-        w = next((v["counters"].get("WRITE_SIZE") for k, v in out["WRITE_SIZE"].items() if pat in k), None)
-        if f is not None and w is not None:
-            res[f"{key}_bytes_per_launch"] = int(2 * f * 1024 + w * 1024)
+        out[ctr] = dbs[0]
+    try:
+        res = prof_summary.traffic_rows(out["FETCH_SIZE"], out["WRITE_SIZE"])     # per bench row (marker-separated), dominant kernel of the row
+    except Exception as e:
+        return None, f"cannot read the PMC databases: {e}"
     shutil.rmtree(tmp, ignore_errors=True)
-    return res, "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes of this command, 2 steps); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH correction)"
+    return res, "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes of this command, 2 steps); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH correction); each row's dispatches are separated by marker launches, so a row reports its OWN launch shape"
 
 
 # ------------------------------------------------------------------------------------------------------------------ rows / host path
-def measure_rows(tm, lib, _lib, d, stream):
+def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
     """The remaining SURVEY section-8 rows at their single-GPU shares (device-resident, HIP events): config 4 stft / spectrogram
     (8 ch x 2^26 ComplexF32, nfft 1024, hop 256), config 5 resample 160//147 (4 ch x 2^28 Float32), (f)1 FIRArbitrary at the same shape."""
     import numpy as np
@@ -314,6 +326,7 @@ def measure_rows(tm, lib, _lib, d, stream):
     for name, psd, outdt, bps in (("stft", 0, torch.complex64, 40.0), ("spectrogram", 1, torch.float32, 24.0)):
         plan = _StftPlan(1024, 768, 1024, win, 1.0 * norm2, False, psd, np.complex64, d.ENGINE_FUSED)
         out = torch.empty((nch, K, 1024), dtype=outdt, device="cuda")
+        mark(name)
         med, best = tm.time(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, s.data_ptr(), n, nch, n, out.data_ptr(), 1024, K * 1024, stream)))
         rows[name] = roof(f"stft_fused_kernel ({name}, config 4 share: 8 ch x 2^26 ComplexF32, {bps:.0f} B/sample)", med, bps * n * nch,
                           extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
@@ -333,6 +346,7 @@ def measure_rows(tm, lib, _lib, d, stream):
         _lib.check(lib.mdsp_fir_reset(fh))
         _lib.check(lib.mdsp_fir_exec(fh, x.data_ptr(), n, n, y.data_ptr(), ol.value, ol.value + 1, C.byref(nw), stream))
 
+    mark("resample")
     med, best = tm.time(fir)
     rows["resample"] = roof("polyphase_mfma_kernel (config 5 share: 4 ch x 2^28 Float32, 160//147, 8.354 B/sample)", med, (4 + 4 * 160 / 147) * n * nch,
                             extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
@@ -349,6 +363,7 @@ def measure_rows(tm, lib, _lib, d, stream):
         _lib.check(lib.mdsp_firarb_reset(fa))
         _lib.check(lib.mdsp_firarb_exec(fa, x.data_ptr(), n, n, ya.data_ptr(), ola.value + 1, ld, C.byref(nw), stream))
 
+    mark("firarb")
     med, best = tm.time(arb)
     rows["firarb"] = roof("arbitrary_fir_kernel (row f1: 4 ch x 2^28 Float32, rate 160/147 as Float64, warm trajectory)", med, (4 + 4 * rate) * n * nch,
                           extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
@@ -374,6 +389,7 @@ def measure_rows(tm, lib, _lib, d, stream):
             _lib.check(lib.mdsp_fir_reset(f2))
             _lib.check(lib.mdsp_fir_exec(f2, xx.data_ptr(), n2, n2, yy.data_ptr(), o2.value, o2.value + 1, C.byref(nw), stream))
 
+        mark(name)
         med, best = tm.time(fir2)
         rows[name] = roof(f"{('generic', 'register-tap', 'matrix-core')[pth.value]} polyphase kernel ({L}//{M}, {len(hh)} taps, 4 ch x 2^26 {str(tdt).split('.')[-1]}, {esz * (1 + L / M):.2f} B/sample)",
                           med, esz * (1 + L / M) * n2 * nch, extra={"Gsamples_per_s": round(n2 * nch / med / 1e6, 2), "best_ms": round(best, 4)})
@@ -423,15 +439,55 @@ def measure_host_path(lib, _lib, d, log2n):
 
 
 # ------------------------------------------------------------------------------------------------------------------ main
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher environment: start the N ranks ourselves (one process per GPU) under torch.distributed.run, rendezvous on
+    127.0.0.1, same command line; the children see WORLD_SIZE and take the normal path.  Returns the launcher's exit code."""
+    if not args.dry:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) visible; refusing to print a line for fewer GPUs than asked", file=sys.stderr, flush=True)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if args.gpus is None:
+        args.gpus = world
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if not launched and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if launched and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} contradicts the launcher's WORLD_SIZE={world}", file=sys.stderr, flush=True)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
     if args.dry:
         return dry_main(args, world, rank)
+    if world > 1 and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) visible", file=sys.stderr, flush=True)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -506,6 +562,7 @@ def main():
                 _lib.check(lib.mdsp_channel_sum(psd.data_ptr(), cfg.nout, 1, cfg.nout, _lib.F32, mean.data_ptr(), stream))
                 dist.all_reduce(mean, op=dist.ReduceOp.SUM)
                 mean.mul_(1.0 / world)
+        coll = lambda: (psd.sum(0, dtype=torch.float64), mean, float(world))     # (this rank's contribution, the collective's result, divisor)
         names = ("filt", "welch")
         alg = (8.0 * n, 4.0 * n)
         kern = ("ols_fused_kernel (overlap-save filt, 8 B/sample)", "welch_half_kernel (+reduce+finalize; 4 B/sample)")
@@ -529,6 +586,7 @@ def main():
             _lib.check(lib.mdsp_stft_exec(plan._h, s.data_ptr(), n, nch, n, out.data_ptr(), 1024, K * 1024, stream))
             tm.rec(b_)
             tm.rec(c)                            # channels are independent: no collective on this path
+        coll = None
         names = ("stft", "none")
         alg = (40.0 * n * nch, 0.0)
         kern = ("stft_fused_kernel (config 4: 8 + 8*1024/256 = 40 B/sample)", "-")
@@ -565,6 +623,7 @@ def main():
                 dist.all_reduce(avg, op=dist.ReduceOp.SUM)
             avg.mul_(1.0 / (nch * world))
             tm.rec(c)
+        coll = lambda: (y[:, ol.value - TAIL:].sum(0, dtype=torch.float64), avg, float(nch * world))
         names = ("resample", "channel average + all-reduce")
         alg = ((4 + 4 * 160 / 147) * n * nch, 0.0)
         kern = ("polyphase_mfma_kernel (config 5: 4 + 4*160/147 = 8.354 B/input sample)", "-")
@@ -572,6 +631,8 @@ def main():
                     "RCCL all-reduce (1024 floats) for the cross-channel average of the last output block")
         metric, dtype, engine_used = "Gsamples/s FIRFilter polyphase resample 160//147, 32 taps/phase, Float32, 4 channels x 256 Msample per GPU (BASELINE config 5)", "f32", "hip"
 
+    mark = Marks(lib, _lib, stream)
+    mark("step")
     evs = [(tm.ev(), tm.ev(), tm.ev()) for _ in range(args.steps)]        # HIP events on the launch stream, created up front
     scratch = (tm.ev(), tm.ev(), tm.ev())
     for _ in range(args.warmup):
@@ -595,6 +656,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
+    # self-check of the step's collective (outside the timed region): every rank's contribution is gathered over a DIFFERENT transport
+    # (torch.distributed all_gather), summed in Float64 on each rank, and compared with what the step's own all-reduce left behind
+    collective_check, collective_failed = "n/a (no collective on this path)", False
+    if coll is not None:
+        contrib, result, div = coll()
+        if world > 1:
+            parts = [torch.empty_like(contrib) for _ in range(world)]
+            dist.all_gather(parts, contrib)
+            want = torch.stack(parts).sum(0) / div
+        else:
+            want = contrib / div
+        err = float((result.to(torch.float64) - want).norm() / want.norm().clamp_min(1e-300))
+        bad = torch.tensor([0.0 if err < 1e-5 else 1.0], device=dev)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        collective_failed = float(bad.item()) != 0.0
+        collective_check = (f"FAILED (rank 0 relative error {err:.3e})" if collective_failed else
+                            "ok" if world > 1 else "ok (1 rank: local channel sum only, nothing crossed a link)")
+
     if rank == 0:
         out = {
             "metric": metric,
@@ -602,6 +682,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "samples_per_gpu": units_per_rank, "engine": engine_used, "collective": collective,
+                       "collective_check": collective_check,
                        "stages_ms": {names[0]: round(t_a, 4), names[1]: round(t_b, 4)}},
         }
         traffic, traffic_source = committed_traffic()
@@ -630,6 +711,7 @@ def main():
             out["config"]["stage_Gsamples_per_s"] = {"filt": round(units_per_rank / t_a / 1e6, 2), "welch": round(units_per_rank / t_b / 1e6, 2)}
             # on-box yardsticks: float4 copy (2 x 4 GiB moved) and read-only stream
             nb = units_per_rank * 4
+            mark("yardsticks")
             med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), nb, stream)), reps=3)
             kernels["copy_float4_GBps"] = round(2 * nb / med / 1e6, 1)
             med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 4, 8, stream)), reps=3)
@@ -642,8 +724,8 @@ def main():
             del x, y
             torch.cuda.empty_cache()
             try:
-                kernels.update(measure_rows(tm, lib, _lib, d, stream))
-                for key in ("stft", "spectrogram", "resample", "firarb"):
+                kernels.update(measure_rows(tm, lib, _lib, d, stream, mark))
+                for key in ("stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32"):
                     if key in kernels and traffic:
                         kernels[key]["traffic"] = traffic.get(f"{key}_bytes_per_launch")
                         kernels[key]["traffic_source"] = traffic_source
@@ -667,6 +749,8 @@ def main():
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
+    if collective_failed:
+        sys.exit(3)
 
 
 def dry_main(args, world, rank):
@@ -698,12 +782,25 @@ def dry_main(args, world, rank):
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    # the same self-check as the device path: rank-dependent contributions, all-reduce against an all_gather + Float64 sum
+    check = "n/a (no collective on this path)"
+    if nred:
+        contrib = (torch.arange(nred, dtype=torch.float64) + 1.0) * (rank + 1) * len(mine)
+        red = contrib.to(torch.float32)
+        want = contrib
+        if world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            parts = [torch.empty_like(contrib) for _ in range(world)]
+            dist.all_gather(parts, contrib)
+            want = torch.stack(parts).sum(0)
+        err = float((red.to(torch.float64) / nch_total - want / nch_total).norm() / (want / nch_total).norm())
+        check = "ok" if err < 1e-5 else f"FAILED ({err:.3e})"
     if rank == 0:
         print(json.dumps({"metric": METRIC if args.config == "filtwelch" else f"dry:{args.config}", "value": None, "unit": "Gsamples/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tt.item()) / max(1, args.steps) * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry mode)",
                           "config": {"workload": f"dry run of --config {args.config}", "name": args.config, "channels_total": nch_total,
-                                     "channels_per_gpu": per_gpu, "collective": "gloo (dry)", "allreduce_floats": nred}}), flush=True)
+                                     "channels_per_gpu": per_gpu, "collective": "gloo (dry)", "collective_check": check, "allreduce_floats": nred}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

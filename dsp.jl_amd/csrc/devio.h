@@ -117,6 +117,25 @@ template <typename T, int E, int TT, int E0> __device__ __forceinline__ void loa
     for (int e = E0; e < E; ++e) out[e] = Ld<T>::load(r, off + TT * e * SZ);
 }
 
+// Stores of elements ES .. E-1 of a window whose first `lead` elements are dropped, with ES = lead div TT known at compile time: elements above
+// ES are plain stores (one VGPR offset + immediates), element ES drops its lanes t < lead - ES TT through the OOB sentinel, elements below ES
+// issue nothing at all.
+template <typename T, int E, int TT, int ES, typename F> __device__ __forceinline__ void store_window_from(F&& get, __amdgpu_buffer_rsrc_t w, int rem, int t, int off) {
+    constexpr int SZ = (int)sizeof(T);
+    Ld<T>::store(get(ES), w, t < rem ? OOB : off + TT * ES * SZ);
+#pragma unroll
+    for (int e = ES + 1; e < E; ++e) Ld<T>::store(get(e), w, off + TT * e * SZ);
+}
+template <typename T, int E, int TT, int ES, typename F> __device__ __forceinline__ void store_window_switch(F&& get, __amdgpu_buffer_rsrc_t w, int es, int rem, int t, int off) {
+    if constexpr (ES < E) {
+        if (es == ES) store_window_from<T, E, TT, ES>(get, w, rem, t, off);
+        else store_window_switch<T, E, TT, ES + 1>(get, w, es, rem, t, off);
+    }
+}
+
+#ifndef MDSP_IO_STORE_SWITCH
+#define MDSP_IO_STORE_SWITCH 1   // 0: the round-2 form (one compare + select per element and store)
+#endif
 template <typename T, int E, int TT, typename F> __device__ __forceinline__ void store_window(F&& get, __amdgpu_buffer_rsrc_t w, int lead, int t) {
     constexpr int SZ = (int)sizeof(T);
     int off = t * SZ;
@@ -124,6 +143,13 @@ template <typename T, int E, int TT, typename F> __device__ __forceinline__ void
     if (lead == 0) {
 #pragma unroll
         for (int e = 0; e < E; ++e) Ld<T>::store(get(e), w, off + TT * e * SZ);
+    } else if (MDSP_IO_STORE_SWITCH && (TT & (TT - 1)) == 0) {
+        // `lead` is wave-uniform (and loop-invariant in the overlap-save kernels: nb - 1): which elements lie wholly below it is a scalar
+        // decision, so the per-element compare + select of the branch-free form (2 VALU operations per store, 8 % of the overlap-save
+        // kernel's vector instructions) shrinks to ONE select for the element that straddles `lead`, and the dropped elements cost no
+        // VMEM slot either.  The chain of wave-uniform compares runs on the scalar unit.
+        const int es = __builtin_amdgcn_readfirstlane(lead / TT), rem = __builtin_amdgcn_readfirstlane(lead - (lead / TT) * TT);
+        store_window_switch<T, E, TT, 0>(get, w, es, rem, t, off);   // es >= E: the whole window is dropped
     } else {                       // branch-free: lanes below `lead` store through the OOB sentinel (dropped)
 #pragma unroll
         for (int e = 0; e < E; ++e) Ld<T>::store(get(e), w, (t + TT * e) < lead ? OOB : off + TT * e * SZ);

@@ -52,6 +52,15 @@ template <typename R> MDSP_HD cx<R> caxmy(R h, cx<R> u, cx<R> e) { return {e.x -
 template <typename R> MDSP_HD cx<R> cscale(R h, cx<R> u) { return {h * u.x, h * u.y}; }
 // lane-wise a b + c on the (re, im) pair (NOT a complex product): the |z|^2 accumulation of the spectral kernels
 template <typename R> MDSP_HD cx<R> lanefma(cx<R> a, cx<R> b, cx<R> c) { return {a.x * b.x + c.x, a.y * b.y + c.y}; }
+// both halves of a times ONE half of the pair w (a real window pair {w_lo, w_hi}), optionally +- c: the window folded into the first butterfly stage
+template <typename R> MDSP_HD cx<R> wmul_hi(cx<R> a, cx<R> w) { return {a.x * w.y, a.y * w.y}; }
+template <typename R> MDSP_HD cx<R> wfma_lo(cx<R> a, cx<R> w, cx<R> c) { return {a.x * w.x + c.x, a.y * w.x + c.y}; }
+template <typename R> MDSP_HD cx<R> wfms_lo(cx<R> a, cx<R> w, cx<R> c) { return {a.x * w.x - c.x, a.y * w.x - c.y}; }
+// products with COMPILE-TIME constants (the W16 / W8 roots inside the butterflies); the packed Float32 forms keep the constant in an SGPR pair
+template <int DIR, typename R> MDSP_HD cx<R> twmul_k(cx<R> a, cx<R> w) { return twmul<DIR>(a, w); }
+template <typename R> MDSP_HD cx<R> cscale_k(R h, cx<R> u) { return cscale(h, u); }
+template <typename R> MDSP_HD cx<R> caxpy_k(R h, cx<R> u, cx<R> e) { return caxpy(h, u, e); }
+template <typename R> MDSP_HD cx<R> caxmy_k(R h, cx<R> u, cx<R> e) { return caxmy(h, u, e); }
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDSP_NO_PACKED_F32)
 // ---------------------------------------------------------------------------------- packed-FP32 complex arithmetic
@@ -99,6 +108,50 @@ __device__ __forceinline__ cx<float> caxpy(float h, cx<float> u, cx<float> e) { 
 __device__ __forceinline__ cx<float> caxmy(float h, cx<float> u, cx<float> e) { return pk_fnma(u, cx<float>{h, h}, e); }
 __device__ __forceinline__ cx<float> cscale(float h, cx<float> u) { return pk_mul(u, cx<float>{h, h}); }
 __device__ __forceinline__ cx<float> lanefma(cx<float> a, cx<float> b, cx<float> c) { return pk_fma(a, b, c); }
+__device__ __forceinline__ cx<float> wmul_hi(cx<float> a, cx<float> w) { return pk_mul_bhi(a, w); }
+__device__ __forceinline__ cx<float> wfma_lo(cx<float> a, cx<float> w, cx<float> c) {
+    f2v d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(f2v{a.x, a.y}), "v"(f2v{w.x, w.y}), "v"(f2v{c.x, c.y}));
+    return {d.x, d.y};
+}
+__device__ __forceinline__ cx<float> wfms_lo(cx<float> a, cx<float> w, cx<float> c) {
+    f2v d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(f2v{a.x, a.y}), "v"(f2v{w.x, w.y}), "v"(f2v{c.x, c.y}));
+    return {d.x, d.y};
+}
+// Constant operands from SGPR pairs (VOP3P takes one scalar source): the butterflies' roots cost neither VGPRs nor the v_mov_b64 that
+// re-materialised them in front of every use (9 per radix-16 butterfly in the round-2 ISA).  -DMDSP_FFT_SGPR_CONST=0 restores the VGPR forms.
+#ifndef MDSP_FFT_SGPR_CONST
+#define MDSP_FFT_SGPR_CONST 1
+#endif
+#if MDSP_FFT_SGPR_CONST
+#define MDSP_PK2S(NAME, INSN, MODS)                                                                 \
+    __device__ __forceinline__ cx<float> NAME(cx<float> a, cx<float> k) {                           \
+        f2v d;                                                                                      \
+        asm(INSN " %0, %1, %2 " MODS : "=v"(d) : "v"(f2v{a.x, a.y}), "s"(f2v{k.x, k.y}));           \
+        return {d.x, d.y};                                                                          \
+    }
+#define MDSP_PK3S(NAME, INSN, MODS)                                                                 \
+    __device__ __forceinline__ cx<float> NAME(cx<float> a, cx<float> k, cx<float> c) {              \
+        f2v d;                                                                                      \
+        asm(INSN " %0, %1, %2, %3 " MODS : "=v"(d) : "v"(f2v{a.x, a.y}), "s"(f2v{k.x, k.y}), "v"(f2v{c.x, c.y})); \
+        return {d.x, d.y};                                                                          \
+    }
+MDSP_PK2S(pks_mul, "v_pk_mul_f32", "")
+MDSP_PK2S(pks_mul_yy, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0]")
+MDSP_PK3S(pks_fma, "v_pk_fma_f32", "")
+MDSP_PK3S(pks_fnma, "v_pk_fma_f32", "neg_lo:[1,0,0] neg_hi:[1,0,0]")
+MDSP_PK3S(pks_cmul_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_lo:[0,0,1]")
+MDSP_PK3S(pks_cmulc_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_hi:[1,0,0]")
+#undef MDSP_PK2S
+#undef MDSP_PK3S
+template <int DIR> __device__ __forceinline__ cx<float> twmul_k(cx<float> a, cx<float> w) {
+    return DIR < 0 ? pks_cmul_fin(a, w, pks_mul_yy(a, w)) : pks_cmulc_fin(a, w, pks_mul_yy(a, w));
+}
+__device__ __forceinline__ cx<float> cscale_k(float h, cx<float> u) { return pks_mul(u, cx<float>{h, h}); }
+__device__ __forceinline__ cx<float> caxpy_k(float h, cx<float> u, cx<float> e) { return pks_fma(u, cx<float>{h, h}, e); }
+__device__ __forceinline__ cx<float> caxmy_k(float h, cx<float> u, cx<float> e) { return pks_fnma(u, cx<float>{h, h}, e); }
+#endif
 #endif
 
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
@@ -134,32 +187,30 @@ template <int DIR, typename R> MDSP_HD void bfly8(cx<R> (&v)[8]) {
     const cx<R> u3 = w8_3_unscaled_neg<DIR>(v[7]);   // O[3] W8^3 = -h u3
     v[0] = cadd(e0, o0);
     v[4] = csub(e0, o0);
-    v[1] = caxpy(h, u1, e1);
-    v[5] = caxmy(h, u1, e1);
+    v[1] = caxpy_k(h, u1, e1);
+    v[5] = caxmy_k(h, u1, e1);
     v[2] = add_mi<DIR>(e2, o2);                      // O[2] W8^2 = mul_mi(O[2])
     v[6] = sub_mi<DIR>(e2, o2);
-    v[3] = caxmy(h, u3, e3);
-    v[7] = caxpy(h, u3, e3);
+    v[3] = caxmy_k(h, u3, e3);
+    v[7] = caxpy_k(h, u3, e3);
 }
 
-template <int DIR, typename R> MDSP_HD void bfly16(cx<R> (&v)[16]) {
-    // n = m + 4 s, k = 4 p + q :  X[4p+q] = sum_m W4^{mp} W16^{mq} ( sum_s v[m+4s] W4^{sq} )
+// everything of the radix-16 butterfly after the four inner DFT4s: v[m + 4q] = y[m][q] in, natural order out
+template <int DIR, typename R> MDSP_HD void bfly16_tail(cx<R> (&v)[16]) {
     constexpr R c1 = (R)0.92387953251128675612818318939679L;  // cos(pi/8)
     constexpr R s1 = (R)0.38268343236508977172845998403040L;  // sin(pi/8)
     constexpr R h = (R)0.70710678118654752440084436210485L;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) bfly4<DIR>(v[m], v[m + 4], v[m + 8], v[m + 12]);  // y[m][q] in v[m + 4q]
     // twiddles W16^{mq}, forward root w = exp(-2 pi i/16) = (c1, -s1)
     const cx<R> w1 = {c1, -s1}, w3 = {s1, -c1}, w9 = {-c1, s1};
-    v[1 + 4 * 1] = twmul<DIR>(v[1 + 4 * 1], w1);                          // m=1,q=1 : W^1
-    v[1 + 4 * 2] = cscale(h, w8_1_unscaled<DIR>(v[1 + 4 * 2]));           // m=1,q=2 : W^2 = W8
-    v[1 + 4 * 3] = twmul<DIR>(v[1 + 4 * 3], w3);                          // m=1,q=3 : W^3
-    v[2 + 4 * 1] = cscale(h, w8_1_unscaled<DIR>(v[2 + 4 * 1]));           // m=2,q=1 : W^2
-    v[2 + 4 * 2] = mul_mi<DIR>(v[2 + 4 * 2]);                             // m=2,q=2 : W^4 = -+i
-    v[2 + 4 * 3] = cscale(-h, w8_3_unscaled_neg<DIR>(v[2 + 4 * 3]));      // m=2,q=3 : W^6 = W8^3
-    v[3 + 4 * 1] = twmul<DIR>(v[3 + 4 * 1], w3);                          // m=3,q=1 : W^3
-    v[3 + 4 * 2] = cscale(-h, w8_3_unscaled_neg<DIR>(v[3 + 4 * 2]));      // m=3,q=2 : W^6
-    v[3 + 4 * 3] = twmul<DIR>(v[3 + 4 * 3], w9);                          // m=3,q=3 : W^9 = -W^1
+    v[1 + 4 * 1] = twmul_k<DIR>(v[1 + 4 * 1], w1);                          // m=1,q=1 : W^1
+    v[1 + 4 * 2] = cscale_k(h, w8_1_unscaled<DIR>(v[1 + 4 * 2]));           // m=1,q=2 : W^2 = W8
+    v[1 + 4 * 3] = twmul_k<DIR>(v[1 + 4 * 3], w3);                          // m=1,q=3 : W^3
+    v[2 + 4 * 1] = cscale_k(h, w8_1_unscaled<DIR>(v[2 + 4 * 1]));           // m=2,q=1 : W^2
+    v[2 + 4 * 2] = mul_mi<DIR>(v[2 + 4 * 2]);                               // m=2,q=2 : W^4 = -+i
+    v[2 + 4 * 3] = cscale_k(-h, w8_3_unscaled_neg<DIR>(v[2 + 4 * 3]));      // m=2,q=3 : W^6 = W8^3
+    v[3 + 4 * 1] = twmul_k<DIR>(v[3 + 4 * 1], w3);                          // m=3,q=1 : W^3
+    v[3 + 4 * 2] = cscale_k(-h, w8_3_unscaled_neg<DIR>(v[3 + 4 * 2]));      // m=3,q=2 : W^6
+    v[3 + 4 * 3] = twmul_k<DIR>(v[3 + 4 * 3], w9);                          // m=3,q=3 : W^9 = -W^1
     // outer DFT4 over m for each q; result p lands in slot m=p of the same group: X[4p+q] in v[p + 4q]
 #pragma unroll
     for (int q = 0; q < 4; ++q) bfly4<DIR>(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -171,6 +222,31 @@ template <int DIR, typename R> MDSP_HD void bfly16(cx<R> (&v)[16]) {
     v[b] = t;
     MDSP_SWAP(1, 4) MDSP_SWAP(2, 8) MDSP_SWAP(3, 12) MDSP_SWAP(6, 9) MDSP_SWAP(7, 13) MDSP_SWAP(11, 14)
 #undef MDSP_SWAP
+}
+
+template <int DIR, typename R> MDSP_HD void bfly16(cx<R> (&v)[16]) {
+    // n = m + 4 s, k = 4 p + q :  X[4p+q] = sum_m W4^{mp} W16^{mq} ( sum_s v[m+4s] W4^{sq} )
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bfly4<DIR>(v[m], v[m + 4], v[m + 8], v[m + 12]);  // y[m][q] in v[m + 4q]
+    bfly16_tail<DIR>(v);
+}
+
+// The same butterfly on WINDOWED input with the window folded into the first add/subtract stage:
+//     x[e] = q[e] w[e],  x[e + 8] = f[e] w[e + 8],  e = 0..7,   wp[e] = {w[e], w[e + 8]}  (real window values as a pair)
+// a + b with a = q w_lo, b = f w_hi is one product and one FMA, a - b one more FMA: 3 operations per pair instead of 2 products + 2 additions
+// (8 packed operations less per butterfly).  Rounding differs from "window, then transform" by one fused rounding per term.
+template <int DIR, typename R> MDSP_HD void bfly16_win(const cx<R> (&q)[8], const cx<R> (&f)[8], const cx<R> (&wp)[8], cx<R> (&v)[16]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const cx<R> p0 = wmul_hi(f[m], wp[m]), p1 = wmul_hi(f[m + 4], wp[m + 4]);
+        const cx<R> t0 = wfma_lo(q[m], wp[m], p0), t1 = wfms_lo(q[m], wp[m], p0);              // x[m] +- x[m+8]
+        const cx<R> t2 = wfma_lo(q[m + 4], wp[m + 4], p1), d = wfms_lo(q[m + 4], wp[m + 4], p1);  // x[m+4] +- x[m+12]
+        v[m] = cadd(t0, t2);
+        v[m + 8] = csub(t0, t2);
+        v[m + 4] = add_mi<DIR>(t1, d);
+        v[m + 12] = sub_mi<DIR>(t1, d);
+    }
+    bfly16_tail<DIR>(v);
 }
 
 template <int RDX, int DIR, typename R> MDSP_HD void bfly(cx<R> (&v)[RDX]) {
@@ -388,6 +464,18 @@ MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t_raw, const cx<R> (&tw)[C::NTW 
             for (int r = 0; r < Rdx; ++r) lds[base + lds_padc<PADSHIFT>(r * Ns)] = v[r];
         }
     }
+}
+
+// Pass 0 of a forward E = 16 transform whose input is q[e] w[e] (e < 8), f[e] w[e + 8]: the window rides in the butterfly's first stage
+// (bfly16_win); results are scattered exactly as pass_compute<.., PASS = 0> does.  Identity lanes only.
+template <typename C, int PADSHIFT, typename R>
+MDSP_HD void pass0_windowed(const cx<R> (&q)[8], const cx<R> (&f)[8], const cx<R> (&wp)[8], int t, cx<R>* lds) {
+    static_assert(C::E == 16 && C::radix(0) == 16 && C::P > 1, "E = 16 geometries with a radix-16 first pass");
+    cx<R> v[16];
+    bfly16_win<-1>(q, f, wp, v);
+    const int base = lds_pad<PADSHIFT>(t * 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[base + lds_padc<PADSHIFT>(r)] = v[r];
 }
 
 // After the barrier that follows a non-final pass: fetch the operands of the next pass.

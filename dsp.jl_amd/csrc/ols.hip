@@ -21,6 +21,13 @@
 #include <algorithm>
 #include <cstdlib>
 
+// The butterflies' constant roots stay in VGPRs here: these kernels run both transform directions next to the filter spectrum and already
+// use all 106 SGPRs -- with the roots in SGPR pairs (fft_lds.h) hipcc spills 14 more SGPRs into VGPR lanes and reads them back inside the
+// loop (18 v_readlane per unit in the headline instantiation), which costs more than the 10 VGPRs it frees (occupancy unchanged).
+#ifndef MDSP_FFT_SGPR_CONST
+#define MDSP_FFT_SGPR_CONST 0
+#endif
+
 #include "common.h"
 #include "devio.h"
 #include "fft_lds.h"

@@ -992,6 +992,143 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
     }
 }
 
+// ---- the same path, Float32, 16 elements per thread, with the instruction diet of round 3 ---------------------------------------------
+// The round-2 loop issued ~420 VALU instructions per thread and unit for 335 of arithmetic.  What went:
+//   * the samples of a unit live in PAIRS: Q[e] = (frame a, frame b)[t + T e] for the first half-frame, F[e] for the second -- exactly the
+//     (re, im) operands of the packed first stage, so no v_mov builds them.  Frame b's first half IS frame a's second half: it is loaded a
+//     second time (an L1/L2 hit, a VMEM slot instead of VALU work), predicated on the unit HAVING a frame b -- the odd last frame needs no
+//     branch and no zeroing in the loop;
+//   * the half-frame a unit hands to its successor (b's second half = the next a's first half) is not copied: the pair that holds it BECOMES
+//     the successor's Q, and the successor packs z = b + i a instead of a + i b (|Z[k]|^2 + |Z[N-k]|^2 is symmetric in a <-> b, and k <-> N-k is
+//     folded by the finalize kernel anyway), so the roles of the two pair arrays and of their halves alternate from unit to unit (loop unrolled x2);
+//   * the window rides in the first butterfly stage (fft::bfly16_win: 8 packed operations less), and the butterflies' constant roots come
+//     from SGPR pairs (fft_lds.h, MDSP_FFT_SGPR_CONST).
+template <int N, int PADSHIFT, int NBUF>
+__global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
+    using R = float;
+    constexpr int E = 16, H = 8;
+    using C = fft::Cfg<N, E>;
+    constexpr int T = C::T;
+    static_assert(T % 64 == 0 && T >= 128, "one transform per workgroup");
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
+    __shared__ __attribute__((aligned(16))) cx<R> lds[REGION];
+    const int t = threadIdx.x;
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    const int64_t ch = blockIdx.y;
+
+    cx<R> tw[NTWA];
+    fft::load_twiddles<C, R, 1, fft::TW_REG, false>(tw, t, table);
+    cx<R> wp[H];   // {w[t + T e], w[t + T (e + 8)]}
+    {
+        double wd[E];
+        load_window_regs<E, T>(wd, a.win, a.n, t);
+#pragma unroll
+        for (int e = 0; e < H; ++e) wp[e] = {(R)wd[e], (R)wd[e + H]};
+    }
+    constexpr int FLUSH = 128;
+    cx<R> accp[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) accp[e] = {(R)0, (R)0};
+    double* part = static_cast<double*>(a.out) + ((int64_t)blockIdx.x * a.nch + ch) * N;
+    const __amdgpu_buffer_rsrc_t prs = io::make_rsrc(part, (int64_t)N * 8);
+    int since = 0;
+    bool first = true;
+    auto flush = [&]() {
+        int off = t * 8;
+        asm volatile("" : "+v"(off));
+        if (first) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) io::Ld<double>::store((double)accp[e].x + (double)accp[e].y, prs, off + T * e * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double s = io::Ld<double>::load(prs, off + T * e * 8) + ((double)accp[e].x + (double)accp[e].y);
+                io::Ld<double>::store(s, prs, off + T * e * 8);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) accp[e] = {(R)0, (R)0};
+        first = false;
+        since = 0;
+    };
+
+    const R* sc = static_cast<const R*>(a.s) + ch * a.lds_;
+    const int64_t nslots = (int64_t)gridDim.x;
+    int64_t wbase = (int64_t)blockIdx.x * a.run_len, wj = 0;
+    auto unit_cur = [&](bool more) { return (more && wbase + wj < a.units_per_ch) ? wbase + wj : a.units_per_ch; };
+    auto walk = [&]() {
+        if (++wj == a.run_len) {
+            wj = 0;
+            wbase += nslots * a.run_len;
+        }
+    };
+    // half-frame h of unit u starts at sample u N + h N/2: h = 0 (a lo), 1 (a hi = b lo), 2 (b hi); `on` false -> all zeros
+    auto half_rsrc = [&](int64_t u, int h, bool on) {
+        const int64_t pos = u * N + (int64_t)h * (N / 2);
+        return io::make_rsrc(sc + pos, on ? std::min<int64_t>(N / 2, a.len - pos) * 4 : 0);
+    };
+    // component selectors: XA = true -> frame a rides in .x (z = a + i b), false -> in .y (z = b + i a)
+    auto ld8 = [&](cx<R> (&dst)[H], bool to_x, const __amdgpu_buffer_rsrc_t r) {
+        int off = t * 4;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int e = 0; e < H; ++e) {
+            const R s = io::Ld<R>::load(r, off + T * e * 4);
+            if (to_x) dst[e].x = s;
+            else dst[e].y = s;
+        }
+    };
+    // all four half-frame streams of unit u: Q = (a lo | b lo), F = (a hi | b hi); `carry`: a lo is already in Q (handed over by the predecessor)
+    auto load_unit = [&](cx<R> (&Q)[H], cx<R> (&F)[H], bool xa, int64_t u, bool carry) {
+        const bool live = u < a.units_per_ch, haveB = live && (2 * u + 1) < a.K;
+        if (!carry) ld8(Q, xa, half_rsrc(u, 0, live));
+        ld8(Q, !xa, half_rsrc(u, 1, haveB));
+        ld8(F, xa, half_rsrc(u, 1, live));
+        ld8(F, !xa, half_rsrc(u, 2, haveB));
+    };
+    cx<R> P1[H], P2[H];
+    int64_t u = unit_cur(a.niter > 0);
+    load_unit(P1, P2, true, u, false);
+    auto unit = [&](cx<R> (&Q)[H], cx<R> (&F)[H], bool xa, bool more) {
+        walk();
+        const int64_t unext = unit_cur(more);
+        fft::pass0_windowed<C, PADSHIFT>(Q, F, wp, t, lds);   // consumes Q and F
+        // the successor: F's frame-b-second-half component is its frame a's first half when it follows directly (roles and halves swap)
+        const bool carry = unext == u + 1 && unext < a.units_per_ch;   // wave-uniform
+        load_unit(F, Q, !xa, unext, carry);
+        u = unext;
+        cx<R> v[E];
+        fft::wg_sync<T>();
+        fft::pass_reload<C, PADSHIFT, 1, 0>(v, t, lds);
+        if constexpr (NBUF == 1) fft::wg_sync<T>();
+        fft::wg_fft<C, -1, fft::TW_REG, PADSHIFT, NBUF, 0, 1, 0>(v, t, tw, table, lds);
+        if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();
+#pragma unroll
+        for (int e = 0; e < E; ++e) accp[e] = fft::lanefma(v[e], v[e], accp[e]);
+        if (++since == FLUSH) flush();
+    };
+    for (int64_t it = 0; it < a.niter; it += 2) {   // same trip count for every slot (barriers inside)
+        unit(P1, P2, true, it + 1 < a.niter);
+        if (it + 1 < a.niter) unit(P2, P1, false, it + 2 < a.niter);
+    }
+    flush();
+}
+
+template <int N, int PADSHIFT, int NBUF> int welch_run_half3(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
+    auto kern = welch_half3_kernel<N, PADSHIFT, NBUF>;
+    constexpr int threads = N / 16;
+    int grid = 1;
+    MDSP_TRY(grid_for(kern, threads, a.units_per_ch, a.nch, &grid));
+    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)grid * (size_t)a.nch * N));
+    a.out = pl->partial.p;
+    set_schedule(a, a.units_per_ch, (int64_t)grid);
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
+    MDSP_LAUNCH_CHECK();
+    *nslices = grid;
+    return MDSP_OK;
+}
+
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF, int PERM = false, bool PREF = true>
 int welch_run_half(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
     auto kern = welch_half_kernel<R, N, E, G, TWMODE, PADSHIFT, MINW, NBUF, PERM, PREF>;
@@ -1056,6 +1193,9 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 15) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 16) rc = welch_run_half<R, N, EH, GH, 3, 4, 3, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 17) rc = welch_run_half<R, N, EH, GH, 3, 4, 2, 1>(pl, a, st, &nslices);
+                else if (pl->variant == 30) rc = welch_run_half3<N, 5, 1>(pl, a, st, &nslices);   // round 3: paired samples, branch-free, window in the first stage
+                else if (pl->variant == 31) rc = welch_run_half3<N, 5, 2>(pl, a, st, &nslices);   // ... with two LDS buffers (one barrier per exchange)
+                else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
                 else done = false;
             }
             if (!done) {

@@ -143,8 +143,65 @@ template <typename R> static int check_gen(int N, int T, double tol) {
     return e < tol ? 0 : 1;
 }
 
+// Windowed first pass (pass0_windowed / bfly16_win: the window folded into the butterfly's first stage) followed by the ordinary passes, with the
+// sample pairing of welch_half3_kernel: q[e] = (frame A, frame B)[t + T e] for e < 8, f[e] = the same for e + 8, wp[e] = {w[e], w[e + 8]};
+// `swap` exchanges the two components (z = b + i a).  Checked against the long-double DFT of w (a + i b).
+template <int N, typename R, int PADSHIFT> static double check_windowed(bool swap) {
+    using C = Cfg<N, 16>;
+    constexpr int E = 16, T = C::T, NTWA = C::NTW > 0 ? C::NTW : 1;
+    std::vector<cx<R>> table(N), regs((size_t)T * E), tw((size_t)T * NTWA), lds(lds_elems<N, PADSHIFT>());
+    for (int k = 0; k < N; ++k) {
+        const long double a = -2.0L * 3.141592653589793238462643383279502884L * k / N;
+        table[k] = {(R)cosl(a), (R)sinl(a)};
+    }
+    std::vector<R> fa(N), fb(N), w(N);
+    srand(4242 + N);
+    for (int i = 0; i < N; ++i) {
+        fa[i] = (R)((double)rand() / RAND_MAX - 0.5);
+        fb[i] = (R)((double)rand() / RAND_MAX - 0.5);
+        w[i] = (R)(0.5 - 0.5 * cos(2.0 * 3.14159265358979323846 * i / (N - 1)));
+    }
+    for (int t = 0; t < T; ++t) {
+        cx<R> q[8], f[8], wp[8];
+        for (int e = 0; e < 8; ++e) {
+            const int i0 = t + T * e, i1 = t + T * (e + 8);
+            q[e] = swap ? cx<R>{fb[i0], fa[i0]} : cx<R>{fa[i0], fb[i0]};
+            f[e] = swap ? cx<R>{fb[i1], fa[i1]} : cx<R>{fa[i1], fb[i1]};
+            wp[e] = {w[i0], w[i1]};
+        }
+        pass0_windowed<C, PADSHIFT>(q, f, wp, t, lds.data());
+        auto& ww = *reinterpret_cast<cx<R>(*)[NTWA]>(&tw[(size_t)t * NTWA]);
+        load_twiddles<C, R, 1, TW_REG, false>(ww, t, table.data());
+    }
+    for (int t = 0; t < T; ++t) {
+        auto& x = *reinterpret_cast<cx<R>(*)[E]>(&regs[(size_t)t * E]);
+        pass_reload<C, PADSHIFT, 1, false>(x, t, lds.data());
+    }
+    run_passes<C, R, -1, TW_REG, PADSHIFT, 1, false>(regs, tw, table, lds);
+    long double err2 = 0, norm = 0;
+    for (int k = 0; k < N; ++k) {
+        std::complex<long double> acc = 0;
+        for (int n = 0; n < N; ++n) {
+            const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)(((long long)n * k) % N) / N;
+            const std::complex<long double> z = swap ? std::complex<long double>(fb[n], fa[n]) : std::complex<long double>(fa[n], fb[n]);
+            acc += (long double)w[n] * z * std::complex<long double>(cosl(ang), sinl(ang));
+        }
+        const cx<R> g = regs[(size_t)(k % T) * E + k / T];
+        err2 += std::norm(std::complex<long double>(g.x, g.y) - acc);
+        norm += std::norm(acc);
+    }
+    return (double)sqrtl(err2 / norm);
+}
+
 int main() {
     int bad = 0;
+    {
+        const double e1 = std::max(check_windowed<4096, float, 5>(false), check_windowed<4096, float, 5>(true));
+        const double e2 = std::max(check_windowed<2048, float, 5>(false), check_windowed<1024, float, 4>(true));
+        const double e3 = check_windowed<4096, double, 5>(false);
+        printf("windowed first pass (bfly16_win): f32 4096 %.2e, 2048 / 1024 %.2e, f64 %.2e\n", e1, e2, e3);
+        if (!(e1 < 2e-6) || !(e2 < 2e-6) || !(e3 < 1e-14)) bad = 1;
+    }
     for (int N : {18, 30, 100, 120, 1000, 1536, 3000, 768, 1500, 2000, 2401, 625, 6561, 7000, 8000, 6, 7, 5, 3, 2, 64, 4096, 7680})
         bad |= check_gen<float>(N, N > 2000 ? 256 : 64, 3e-6) | check_gen<double>(N, 128, 2e-14);
     bad |= check_all<16, 16>();

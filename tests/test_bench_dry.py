@@ -33,6 +33,39 @@ def test_bench_dry_two_ranks(config, per_gpu, nred):
         assert key in out
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["config"]["channels_per_gpu"] == per_gpu and out["config"]["channels_total"] == 2 * per_gpu and out["config"]["allreduce_floats"] == nred
+    assert out["config"]["collective_check"] == ("ok" if nred else "n/a (no collective on this path)")
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 --dry` with NO launcher around it (the form the driver's single-command BENCH uses) starts two ranks itself and
+    reports n_gpus 2; the step's collective is cross-checked against an all_gather + Float64 sum (`collective_check`)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["channels_total"] == 2 and out["config"]["collective_check"] == "ok"
+
+
+def test_bench_refuses_fewer_devices_than_asked():
+    """Without --dry, --gpus 8 on a box with fewer than 8 devices exits non-zero and prints NO JSON line (never `n_gpus: 1` for --gpus 8)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("this box really has 8 devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "--gpus 8" in r.stderr
+
+
+def test_bench_refuses_a_contradicting_launcher():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "contradicts" in r.stderr
 
 
 def test_cpu_baseline_variants_small_sample():

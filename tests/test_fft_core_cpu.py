@@ -13,4 +13,4 @@ def test_fft_passes_on_the_host(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:]
-    assert "wave-private last exchange" in r.stdout and "gen N= 3000" in r.stdout
+    assert "wave-private last exchange" in r.stdout and "gen N= 3000" in r.stdout and "windowed first pass" in r.stdout

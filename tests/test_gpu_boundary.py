@@ -558,3 +558,38 @@ def test_polyphase_matrix_core_kernel_fuzz(d, torch):
     finally:
         _lib.set_tunable("MDSP_FIR_MM", None)
     assert used >= tried // 2          # most random shapes fit the matrix-core kernel
+
+
+@pytest.mark.parametrize("variant", [30, 31, 32])
+def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
+    """welch_half3_kernel (paired samples, role-swapping units, window folded into the first butterfly stage, frame b's first half loaded a
+    second time under the unit's have-frame-b predicate): every frame count parity, the odd last frame, one to three frames, several
+    channels, a stream long enough for the Float64 fold (FLUSH = 128 units) and for slots that walk several runs -- against the oracle and
+    against the round-2 kernel (same frames, same accumulators; only the rounding of the first stage differs)."""
+    from dsp_jl_amd import _lib
+    from oracle import periodograms as opg, windows as ow
+    rng = np.random.default_rng(300 + variant)
+    try:
+        for length in (4096, 6144, 8191, 8192, 10240, 12288, 100_000, 4096 * 700 + 2048, (1 << 23) + 4097):
+            s = (rng.standard_normal(length) + 0.5 * np.sin(2 * np.pi * 0.1234 * np.arange(length))).astype(np.float32)
+            _lib.set_tunable("MDSP_WELCH_VARIANT", str(variant))
+            cfg = d.WelchConfig(length, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=d.ENGINE_FUSED)
+            got = d.welch_pgram(s, cfg).power
+            again = d.welch_pgram(s, cfg).power
+            _lib.set_tunable("MDSP_WELCH_VARIANT", "18")      # the round-2 default form (identity lanes, pad 5), explicitly
+            old = d.welch_pgram(s, d.WelchConfig(length, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=d.ENGINE_FUSED)).power
+            assert np.array_equal(got, again)                                           # deterministic: config reuse is bit-identical
+            if length <= 4096 * 700 + 2048:
+                ref = opg.welch_pgram(s, 4096, 2048, window=ow.hanning, dtype=np.float64).power
+                assert relerr(got, ref) < TOL32, (variant, length, relerr(got, ref))
+            assert relerr(got, old.astype(np.float64)) < 1e-6, (variant, length, relerr(got, old.astype(np.float64)))
+        # several channels in one launch == channel by channel
+        _lib.set_tunable("MDSP_WELCH_VARIANT", str(variant))
+        S = rng.standard_normal((50_000, 3)).astype(np.float32)
+        cfg = d.WelchConfig(50_000, np.float32, n=4096, noverlap=2048, window=d.hamming, engine=d.ENGINE_FUSED)
+        P = d.welch_pgram(S, cfg).power
+        for c in range(3):
+            assert np.array_equal(P[:, c], d.welch_pgram(S[:, c].copy(), cfg).power)
+            assert relerr(P[:, c], opg.welch_pgram(S[:, c], 4096, 2048, window=ow.hamming, dtype=np.float64).power) < TOL32
+    finally:
+        _lib.set_tunable("MDSP_WELCH_VARIANT", None)

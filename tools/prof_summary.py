@@ -41,6 +41,76 @@ def pmc(path):
     return out
 
 
+# bench.py launches a marker before every measured row: mdsp_fill_kernel with (MARK_BASE + row index) workgroups.  Dispatches between two markers
+# belong to the row of the first, so a row's counters never mix with another row's dispatches of the same template instantiation.
+MARK_KERNEL, MARK_BASE = "mdsp_fill_kernel", 100
+ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32")
+
+
+def rows(path, min_ns=20000):
+    """Per bench row: the kernels dispatched in that row's marker segment with their mean counter values -> {row: {kernel: {...}}}.
+    Databases of commands without markers come back as the single row "unmarked"."""
+    db = sqlite3.connect(path)
+    q = db.execute("select dispatch_id, kernel_name, counter_name, value, duration, grid_size, workgroup_size, lds_block_size, vgpr_count, accum_vgpr_count, start "
+                   "from counters_collection order by start, dispatch_id").fetchall()
+    out, row = {}, "unmarked"
+    for did, kn, cn, v, dur, grid, wg, lds, vg, ag, _ in q:
+        if MARK_KERNEL in kn:
+            i = grid // max(1, wg) - MARK_BASE
+            row = ROWS[i] if 0 <= i < len(ROWS) else f"row{i}"
+            continue
+        if dur < min_ns:
+            continue
+        e = out.setdefault(row, {}).setdefault(short(kn), {"dispatches": set(), "ns": {}, "vgpr": vg, "agpr": ag, "lds": lds, "grid": grid, "wg": wg, "sum": {}})
+        e["dispatches"].add(did)
+        e["ns"][did] = dur
+        e["sum"][cn] = e["sum"].get(cn, 0.0) + v
+    for r in out.values():
+        for e in r.values():
+            n = len(e["dispatches"])
+            e["counters"] = {c: t / n for c, t in e.pop("sum").items()}
+            e["avg_ns"] = round(sum(e.pop("ns").values()) / n, 0)
+            e["dispatches"] = n
+    return out
+
+
+def dominant(rowd, pat=""):
+    """The kernel of a row with the largest time share (optionally restricted to names containing `pat`)."""
+    c = [(e["avg_ns"] * e["dispatches"], k) for k, e in rowd.items() if pat in k]
+    return max(c)[1] if c else None
+
+
+ROW_KERNELS = (("ols_fused", "step", "ols_fused_kernel"), ("welch_fused", "step", "welch_half_kernel"), ("copy", "yardsticks", "mdsp_copy_kernel"),
+               ("stft", "stft", "stft_"), ("spectrogram", "spectrogram", "stft_"), ("resample", "resample", "polyphase_"), ("firarb", "firarb", "arbitrary_fir_kernel"),
+               ("resample_f64", "resample_f64", "polyphase_"), ("resample_c32", "resample_c32", "polyphase_"), ("interp2_f32", "interp2_f32", "polyphase_"),
+               ("decim2_f32", "decim2_f32", "polyphase_"))
+
+
+def traffic_rows(fetch_db, write_db):
+    """HBM bytes per launch of each row's dominant kernel from separate --pmc FETCH_SIZE / WRITE_SIZE passes of a marker-carrying bench.py run
+    (FETCH_SIZE doubled: gfx950 correction, calibrated on the float4 copy of the same run)."""
+    f, w = rows(fetch_db), rows(write_db)
+    out = {}
+    for name, row, pat in ROW_KERNELS:
+        fr, wr = f.get(row) or f.get("unmarked") or {}, w.get(row) or w.get("unmarked") or {}
+        k = dominant(fr, pat)
+        if k is None or k not in wr:
+            continue
+        fv, wv = fr[k]["counters"].get("FETCH_SIZE"), wr[k]["counters"].get("WRITE_SIZE")
+        if fv is None or wv is None:
+            continue
+        out[f"{name}_kernel"] = k
+        out[f"{name}_fetch_bytes_corrected"] = int(2 * fv * 1024)
+        out[f"{name}_write_bytes"] = int(wv * 1024)
+        out[f"{name}_bytes_per_launch"] = int(2 * fv * 1024 + wv * 1024)
+    return out
+
+
+if __name__ == "__main__" and sys.argv[1] == "--rows":
+    r = rows(sys.argv[2])
+    print(json.dumps(r, indent=1))
+    sys.exit(0)
+
 if __name__ == "__main__" and sys.argv[1] != "--traffic":
     if sys.argv[1] == "--pmc":
         print(json.dumps(pmc(sys.argv[2]), indent=1))
@@ -53,27 +123,10 @@ def traffic(fetch_db, write_db, out_path):
     """HBM bytes per launch of the fused kernels from separate --pmc FETCH_SIZE / WRITE_SIZE passes.
     FETCH_SIZE (KB) is doubled: on gfx950 it tallies 128-B read requests as 64 B (MI355X_MICROARCH.md, HBM section);
     the float4 copy kernel in the same run is the calibration (reported next to its known byte count)."""
-    f, w = pmc(fetch_db), pmc(write_db)
-
-    def get(d, key, cname):
-        for k, v in d.items():
-            if key in k:
-                return v["counters"].get(cname), k
-        return None, None
-
-    out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024",
-           "workload": "bench.py default (2^30 Float32 samples per launch)"}
-    for name, key in (("ols_fused", "ols_fused_kernel"), ("welch_fused", "welch_half_kernel"), ("welch_fused_generic", "welch_fused_kernel"),
-                      ("stft", "stft_fused_kernel<float, 1024, 16, 4, 1, 4, true, false"), ("spectrogram", "stft_fused_kernel<float, 1024, 16, 4, 1, 4, true, true"),
-                      ("resample", "polyphase_"), ("firarb", "arbitrary_fir_kernel"), ("copy", "mdsp_copy_kernel")):
-        fv, fk = get(f, key, "FETCH_SIZE")
-        wv, _ = get(w, key, "WRITE_SIZE")
-        if fv is None or wv is None:
-            continue
-        out[f"{name}_kernel"] = fk
-        out[f"{name}_fetch_bytes_corrected"] = int(2 * fv * 1024)
-        out[f"{name}_write_bytes"] = int(wv * 1024)
-        out[f"{name}_bytes_per_launch"] = int(2 * fv * 1024 + wv * 1024)
+    out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; rows separated by "
+                     "bench.py's marker dispatches (tools/prof_summary.py rows())",
+           "workload": "bench.py default (2^30 Float32 samples per launch; rows at their section-8 sizes)"}
+    out.update(traffic_rows(fetch_db, write_db))
     try:
         import subprocess
         out["commit"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
