@@ -29,7 +29,7 @@ The JSON line also carries
                   `traffic_source` says which.
     kernels       the other kernel of the step, the float4 copy / read yardsticks, and (N = 1) the remaining SURVEY section-8 rows at their
                   single-GPU shares: stft, spectrogram, resample, firarb -- each with ms, algorithmic GB/s and frac of 8 TB/s.
-    host_path     (N = 1) the host-pointer entry points (mdsp_*_exec_host: pinned double buffers, H2D || kernel || D2H): PCIe-inclusive
+    host_path     (N = 1) the host-pointer entry points (mdsp_{ols,welch,stft,fir}_exec_host: three-stage H2D || kernel || D2H pipeline): PCIe-inclusive
                   rates on a bounded sample, reported SEPARATELY -- never part of `value`.
     cpu_baseline  the CPU oracle (numpy/scipy restatement of DSP.jl's algorithm; kind "port") timed on a bounded sample: 1 thread
                   (`value`), all cores (`multi`), and the line-faithful per-block loop (`faithful`).
@@ -365,8 +365,19 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
 
     mark("firarb")
     med, best = tm.time(arb)
+    # the kernel's other roof: two dot products of tapsPerPhi terms per output (pfb and its derivative bank, stream_filt.jl:596-616) against the
+    # measured packed-FMA issue rate (profiles/r02t_valu_rate.txt: v_pk_fma_f32 at 4.40 clocks per wave instruction = 29.1 FMA lanes per clock and
+    # SIMD with four waves per SIMD; 1024 SIMDs, 2.4 GHz)
+    tpp = -(-len(ha) // 32)
+    fma = 2.0 * tpp * ola.value * nch
+    tfl = 2.0 * fma / (med * 1e-3) / 1e12
+    peak = 2.0 * 29.1 * 1024 * 2.4e9 / 1e12
     rows["firarb"] = roof("arbitrary_fir_kernel (row f1: 4 ch x 2^28 Float32, rate 160/147 as Float64, warm trajectory)", med, (4 + 4 * rate) * n * nch,
-                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
+                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4),
+                                 "valu": {"achieved": round(tfl, 1), "peak": round(peak, 1), "unit": "TFLOP/s (v_pk_fma_f32 issue rate, measured)", "frac": round(tfl / peak, 4),
+                                          "fma_per_output": 2 * tpp,
+                                          "note": "FMA issue alone is not the bound either: the SQ counters show the vector unit 70 % busy, most of it LDS-operand "
+                                                  "fetch and address arithmetic around each FMA (DESIGN.md section 4.7)"}})
     _lib.check(lib.mdsp_firarb_destroy(fa))
     del x, y, ya
     torch.cuda.empty_cache()
@@ -435,6 +446,50 @@ def measure_host_path(lib, _lib, d, log2n):
         res["welch_pinned"] = {"Gsamples_per_s": round(n / t / 1e9, 3), "GBps_pcie_h2d": round(4.0 * n / t / 1e9, 1)}
     finally:
         lib.mdsp_host_free(pin_in); lib.mdsp_host_free(pin_out)
+    del x, y
+    # the other two hot entries from host memory (round 3): config 4's stft (output 4x the input: the D2H direction is the bound) and
+    # config 5's resampler, page-locked arrays, bounded single-channel samples
+    try:
+        from fractions import Fraction
+        from dsp_jl_amd.periodograms import _StftPlan, compute_window
+        ns = 1 << (log2n - 3)
+        win, norm2 = compute_window(d.hanning, 1024)
+        sp = _StftPlan(1024, 768, 1024, win, 1.0 * norm2, False, 0, np.complex64, d.ENGINE_AUTO)
+        K = d.frame_count(ns, 1024, 768)
+        pi, po = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.mdsp_host_alloc(C.byref(pi), ns * 8)); _lib.check(lib.mdsp_host_alloc(C.byref(po), K * 1024 * 8))
+        try:
+            sig = (rng.standard_normal(ns, dtype=np.float32) + 1j * rng.standard_normal(ns, dtype=np.float32)).astype(np.complex64)
+            C.memmove(pi, sig.ctypes.data_as(C.c_void_p), ns * 8)
+            t = wall(lambda: _lib.check(lib.mdsp_stft_exec_host(sp._h, pi, ns, 1, ns, po, 1024, K * 1024, _lib.HOST_PINNED)))
+            res["stft_pinned"] = {"Gsamples_per_s": round(ns / t / 1e9, 3), "GBps_pcie_d2h": round(8.0 * K * 1024 / t / 1e9, 1), "GBps_pcie_h2d": round(8.0 * ns / t / 1e9, 1),
+                                  "sample": f"one channel of 2^{log2n - 3} ComplexF32 samples, nfft 1024, hop 256 -> {K} columns"}
+        finally:
+            lib.mdsp_host_free(pi); lib.mdsp_host_free(po)
+        nr = 1 << (log2n - 1)
+        h = resample_taps()
+        fh = C.c_void_p()
+        _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), 160, 147, _lib.F32, _lib.F32, 1))
+        ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, nr, C.byref(ol)))
+        pi, po = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.mdsp_host_alloc(C.byref(pi), nr * 4)); _lib.check(lib.mdsp_host_alloc(C.byref(po), (ol.value + 1) * 4))
+        try:
+            xr = rng.standard_normal(nr, dtype=np.float32)
+            C.memmove(pi, xr.ctypes.data_as(C.c_void_p), nr * 4)
+            nw = C.c_int64()
+
+            def fir_host():
+                _lib.check(lib.mdsp_fir_reset(fh))
+                _lib.check(lib.mdsp_fir_exec_host(fh, pi, nr, nr, po, ol.value, ol.value + 1, C.byref(nw), _lib.HOST_PINNED))
+
+            t = wall(fir_host)
+            res["resample_pinned"] = {"Gsamples_per_s": round(nr / t / 1e9, 3), "GBps_pcie_both_ways": round(4.0 * (nr + ol.value) / t / 1e9, 1),
+                                      "sample": f"one channel of 2^{log2n - 1} Float32 samples, 160//147, 5120 taps -> {ol.value} outputs"}
+        finally:
+            lib.mdsp_host_free(pi); lib.mdsp_host_free(po)
+            lib.mdsp_fir_destroy(fh)
+    except Exception as e:  # pragma: no cover
+        res["rows_error"] = str(e)
     return res
 
 

@@ -104,6 +104,7 @@ PROTOTYPES = {
     "mdsp_stft_plan_destroy": (ci, [vp]),
     "mdsp_stft_plan_info": (ci, [vp, pi64, pint]),
     "mdsp_stft_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, vp]),
+    "mdsp_stft_exec_host": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, ci]),
     "mdsp_hilbert": (ci, [vp, i64, i64, i64, ci, vp, i64, vp]),
     "mdsp_tdfir_state_exec": (ci, [vp, i64, ci, vp, i64, i64, i64, vp, i64, vp, vp]),
     "mdsp_extrapolate": (ci, [vp, i64, i64, i64, ci, i64, vp, i64, vp]),
@@ -127,6 +128,7 @@ PROTOTYPES = {
     "mdsp_fir_get_state": (ci, [vp, pi64, pi64, vp]),
     "mdsp_fir_set_state": (ci, [vp, i64, i64, vp]),
     "mdsp_fir_exec": (ci, [vp, vp, i64, i64, vp, i64, i64, pi64, vp]),
+    "mdsp_fir_exec_host": (ci, [vp, vp, i64, i64, vp, i64, i64, pi64, ci]),
     "mdsp_firarb_create": (ci, [pvp, vp, i64, cd, i64, ci, ci, i64]),
     "mdsp_firarb_destroy": (ci, [vp]),
     "mdsp_firarb_reset": (ci, [vp]),

@@ -2,6 +2,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "hostpipe.h"
 
 namespace mdsp {
 
@@ -159,6 +160,7 @@ int mdsp_init(int device) {
 
 int mdsp_shutdown(void) {
     (void)mdsp_plan_cache_clear();   // borrowed plans die here: a host calls this once, after its last use of the library
+    hostpipe::release_all();          // device and page-locked staging buffers of the host-array pipelines
     return MDSP_OK;
 }
 

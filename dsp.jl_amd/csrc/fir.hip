@@ -27,6 +27,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "hostpipe.h"
 #include "devio.h"
 #include "arb_scan.h"
 #include "fft_lds.h"
@@ -1531,6 +1532,47 @@ int mdsp_fir_exec(mdsp_fir f, const void* x_dev, int64_t xlen, int64_t ldx, void
     MDSP_TRY(shiftin_dispatch(f, x_dev, xlen, ldx, st));                 // :512
     if (nwritten) *nwritten = nout;
     return MDSP_OK;
+}
+
+// filt(::FIRFilter, x) / resample(x, ratio, h) of host arrays (stream_filt.jl:627-637, :688-775): the stream goes through the filter in time
+// chunks of all channels -- exactly the reference's streaming use of a FIRFilter, whose state (phase index, input deficit, history) the object
+// carries from chunk to chunk, so the chunked result is the one-shot result bit for bit and the filter ends in the same state.
+int mdsp_fir_exec_host(mdsp_fir f, const void* x_host, int64_t xlen, int64_t ldx, void* y_host, int64_t ycap, int64_t ldy, int64_t* nwritten,
+                       int flags) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    if (xlen < 0 || ycap < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (f->nch > 1 && ldx < xlen) MDSP_FAIL(MDSP_ERR_ARGUMENT, "ldx smaller than xlen");
+    if (nwritten) *nwritten = 0;
+    int64_t total = 0;
+    MDSP_TRY(mdsp_fir_outputlength(f, xlen, &total));
+    if (ycap < total) MDSP_FAIL(MDSP_ERR_ARGUMENT, "buffer is too small: need %lld, have %lld", (long long)total, (long long)ycap);
+    if (f->nch > 1 && ldy < total) MDSP_FAIL(MDSP_ERR_ARGUMENT, "ldy smaller than the output length");
+    if (xlen == 0) return MDSP_OK;
+    if (!x_host || (total > 0 && !y_host)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    const bool pinned = (flags & MDSP_HOST_PINNED) != 0;
+    const size_t esz = dtype_size(f->x_dtype), osz = dtype_size(f->out_dtype);
+    const int64_t nch = f->nch;
+    // samples per channel and chunk: ~host_chunk_mib of input and output together
+    const double per_sample = (double)esz + (double)osz * (double)f->L / (double)f->M;
+    const int64_t cl_max = std::max<int64_t>(4096, (int64_t)((double)((int64_t)tunables().host_chunk_mib << 20) / per_sample / (double)nch));
+    const int64_t ocap = (int64_t)(((__int128)cl_max * f->L) / f->M) + 2;      // outputs of a chunk never exceed ceil(cl L / M) + 1
+    hostpipe::Session ss((size_t)cl_max * (size_t)nch * esz, (size_t)ocap * (size_t)nch * osz, pinned);
+    int rc = ss.status();
+    int64_t done = 0;
+    for (int64_t x0 = 0; x0 < xlen && rc == MDSP_OK; x0 += cl_max) {
+        hostpipe::Lane* ln = nullptr;
+        if ((rc = ss.acquire(&ln)) != MDSP_OK) break;
+        const int64_t cl = std::min(cl_max, xlen - x0);
+        if ((rc = ss.upload(ln, static_cast<const char*>(x_host) + (size_t)x0 * esz, (size_t)ldx * esz, (size_t)cl * esz, (size_t)nch)) != MDSP_OK) break;
+        int64_t nw = 0;
+        if ((rc = mdsp_fir_exec(f, ln->din.p, cl, cl, ln->dout.p, ocap, ocap, &nw, ss.kstream())) != MDSP_OK) break;
+        rc = ss.download(ln, static_cast<char*>(y_host) + (size_t)done * osz, (size_t)ldy * osz, (size_t)nw * osz, (size_t)nch, 0, (size_t)ocap * osz);
+        done += nw;
+    }
+    rc = ss.finish(rc);
+    if (rc == MDSP_OK && done != total) rc = set_error(MDSP_ERR_ASSERTION, "chunked filtering wrote %lld outputs, the closed form says %lld", (long long)done, (long long)total);
+    if (nwritten) *nwritten = done;
+    return rc;
 }
 
 // ---- FIRArbitrary host side ---------------------------------------------------------------------------------

@@ -1,27 +1,25 @@
-// Host-pointer entry points (mdsp_ols_exec_host, mdsp_welch_exec_host): the reference's own call shape -- every DSP.jl entry takes
-// host Arrays (Filters/filt.jl:458-476, periodograms.jl:647-744) -- as a chunked, double-buffered pipeline
-//
-//     lane 0:  [stage chunk 0] H2D  kernel  D2H [drain]      [stage chunk 2] H2D  kernel  D2H ...
-//     lane 1:                  [stage chunk 1] H2D  kernel  D2H [drain]      [stage chunk 3] ...
-//
-// Two lanes, each with its own HIP stream, device buffers and page-locked staging buffers: while one lane's kernel and D2H run,
-// the other lane's H2D is in flight (PCIe is full duplex) and the host thread stages / drains with a small team of memcpy threads.
+// Host-pointer entry points (mdsp_ols_exec_host, mdsp_welch_exec_host; mdsp_stft_exec_host and mdsp_fir_exec_host live next to their plans in
+// spectral.hip / fir.hip): the reference's own call shape -- every DSP.jl entry takes host Arrays (Filters/filt.jl:458-476,
+// periodograms.jl:647-744) -- on the chunked three-stage pipeline of hostpipe.h: one stream per PCIe direction plus one for the kernels, three
+// lanes of buffers, so that chunk k's D2H, chunk k+1's kernels and chunk k+2's H2D are in flight together.
 // Callers whose arrays are ALREADY page-locked (mdsp_host_alloc / mdsp_host_register) pass MDSP_HOST_PINNED and skip the staging
 // copies: the DMA engines then read and write the caller's memory directly.
 //
-// These calls are PCIe-bound (~50-60 GB/s per direction against 4-5 TB/s for the kernels): they exist so that a drop-in caller can
-// hand over host arrays at all, and bench.py --host reports their rate separately from the device-resident `value`.
+// These calls are PCIe-bound (~55 GB/s per direction against 4-5 TB/s for the kernels): they exist so that a drop-in caller can
+// hand over host arrays at all, and bench.py reports their rate separately from the device-resident `value`.
 #include <algorithm>
 #include <memory>
 #include <thread>
 
 #include "common.h"
+#include "hostpipe.h"
 #include "ols_plan.h"
 #include "welch_plan.h"
 
 using namespace mdsp;
 
-namespace {
+namespace mdsp {
+namespace hostpipe {
 
 // memcpy split over a few threads (one thread moves ~10 GB/s; PCIe 5 x16 moves ~55 GB/s per direction)
 void par_memcpy(void* dst, const void* src, size_t bytes) {
@@ -44,80 +42,180 @@ void par_memcpy(void* dst, const void* src, size_t bytes) {
     for (auto& t : th) t.join();
 }
 
-struct PinBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    ~PinBuf() { release(); }
-    void release() {
-        if (p) (void)hipHostFree(p);
+namespace {
+// rows x row bytes between pitched host arrays (dense on one side)
+void par_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t row, size_t rows) {
+    if (rows == 0 || row == 0) return;
+    if (dpitch == row && spitch == row) return par_memcpy(dst, src, row * rows);
+    if (row >= (size_t(1) << 20) || rows < 8) {
+        for (size_t r = 0; r < rows; ++r) par_memcpy((char*)dst + r * dpitch, (const char*)src + r * spitch, row);
+        return;
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nt = std::min<size_t>({size_t(8), (size_t)hw, rows});
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nt; ++i)
+        th.emplace_back([=] { for (size_t r = i; r < rows; r += nt) memcpy((char*)dst + r * dpitch, (const char*)src + r * spitch, row); });
+    for (size_t r = 0; r < rows; r += nt) memcpy((char*)dst + r * dpitch, (const char*)src + r * spitch, row);
+    for (auto& t : th) t.join();
+}
+}  // namespace
+
+void PinBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+int PinBuf::reserve(size_t n) {
+    if (n <= bytes) return MDSP_OK;
+    release();
+    hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+    if (e != hipSuccess) {
         p = nullptr;
-        bytes = 0;
+        return set_error(MDSP_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
     }
-    int reserve(size_t n) {
-        if (n <= bytes) return MDSP_OK;
-        release();
-        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
-        if (e != hipSuccess) {
-            p = nullptr;
-            return set_error(MDSP_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
-        }
-        bytes = n;
-        return MDSP_OK;
-    }
-};
-
-struct Lane {
-    hipStream_t s = nullptr;
-    hipEvent_t done = nullptr, kdone = nullptr;   // chunk finished (after its D2H) / its kernels finished
-    DevBuf din, dout;
-    PinBuf hin, hout;
-    // output of the chunk in flight on this lane: where it goes once `done` has fired
-    void* out_dst = nullptr;
-    size_t out_bytes = 0;
-    bool busy = false;
-    ~Lane() {
-        if (done) (void)hipEventDestroy(done);
-        if (kdone) (void)hipEventDestroy(kdone);
-        if (s) (void)hipStreamDestroy(s);
-    }
-    int init() {
-        if (!s) MDSP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        if (!done) MDSP_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        if (!kdone) MDSP_HIP(hipEventCreateWithFlags(&kdone, hipEventDisableTiming));
-        return MDSP_OK;
-    }
-    // wait for the chunk in flight and hand its output to the caller's array
-    int drain(bool pinned) {
-        if (!busy) return MDSP_OK;
-        MDSP_HIP(hipEventSynchronize(done));
-        if (!pinned && out_bytes) par_memcpy(out_dst, hout.p, out_bytes);
-        busy = false;
-        out_bytes = 0;
-        return MDSP_OK;
-    }
-};
-
-struct Pipe {
-    Lane lane[2];
-    std::mutex mu;
-    int init() {
-        MDSP_TRY(lane[0].init());
-        return lane[1].init();
-    }
-};
-
-// one pipeline per device, created on first use (host entry points are synchronous; concurrent callers serialise here)
-Pipe* pipe_for_device() {
-    static std::mutex mu;
-    static Pipe* pipes[64] = {nullptr};   // never destroyed: streams / pinned buffers must not be released from a static destructor, after the HIP runtime
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!pipes[dev]) pipes[dev] = new Pipe();
-    return pipes[dev];
+    bytes = n;
+    return MDSP_OK;
 }
 
+struct Pipe {
+    Lane lane[NL];
+    hipStream_t s_up = nullptr, s_k = nullptr, s_down = nullptr;
+    std::mutex mu;
+    int init() {
+        if (!s_up) MDSP_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+        if (!s_k) MDSP_HIP(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
+        if (!s_down) MDSP_HIP(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+        for (Lane& ln : lane) {
+            if (!ln.up) MDSP_HIP(hipEventCreateWithFlags(&ln.up, hipEventDisableTiming));
+            if (!ln.kd) MDSP_HIP(hipEventCreateWithFlags(&ln.kd, hipEventDisableTiming));
+            if (!ln.down) MDSP_HIP(hipEventCreateWithFlags(&ln.down, hipEventDisableTiming));
+        }
+        return MDSP_OK;
+    }
+    void release() {   // buffers only: streams and events are a few hundred bytes and stay for the next use
+        for (Lane& ln : lane) {
+            ln.din.release(); ln.dout.release(); ln.hin.release(); ln.hout.release();
+        }
+    }
+};
+
+namespace {
+std::mutex g_mu;
+Pipe* g_pipes[64] = {nullptr};   // never destroyed from a static destructor (after the HIP runtime); mdsp_shutdown releases the buffers
+
+// one pipeline per device, created on first use
+Pipe* pipe_for_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_pipes[dev]) g_pipes[dev] = new Pipe();
+    return g_pipes[dev];
+}
 }  // namespace
+
+void release_all() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Pipe* p : g_pipes)
+        if (p) {
+            std::lock_guard<std::mutex> lk2(p->mu);
+            (void)hipStreamSynchronize(p->s_up);
+            (void)hipStreamSynchronize(p->s_k);
+            (void)hipStreamSynchronize(p->s_down);
+            p->release();
+        }
+}
+
+Session::Session(size_t in_cap, size_t out_cap, bool pinned) : p_(pipe_for_device()), pinned_(pinned) {
+    p_->mu.lock();
+    rc_ = p_->init();
+    for (Lane& ln : p_->lane) {
+        ln.busy = ln.has_out = false;
+        if (rc_ == MDSP_OK) rc_ = ln.din.reserve(in_cap);
+        if (rc_ == MDSP_OK && out_cap) rc_ = ln.dout.reserve(out_cap);
+        if (rc_ == MDSP_OK && !pinned) rc_ = ln.hin.reserve(in_cap);
+        if (rc_ == MDSP_OK && !pinned && out_cap) rc_ = ln.hout.reserve(out_cap);
+    }
+}
+Session::~Session() { p_->mu.unlock(); }
+hipStream_t Session::kstream() const { return p_->s_k; }
+
+int Session::drain(Lane& ln) {
+    if (!ln.busy) return MDSP_OK;
+    MDSP_HIP(hipEventSynchronize(ln.has_out ? ln.down : ln.kd));
+    if (ln.has_out && !pinned_) par_memcpy2d(ln.out_dst, ln.out_pitch, ln.hout.p, ln.out_row, ln.out_row, ln.out_rows);
+    ln.busy = ln.has_out = false;
+    return MDSP_OK;
+}
+
+int Session::acquire(Lane** out) {
+    Lane& ln = p_->lane[next_++ % NL];
+    MDSP_TRY(drain(ln));
+    *out = &ln;
+    return MDSP_OK;
+}
+
+int Session::upload(Lane* ln, const void* src, size_t spitch, size_t row, size_t rows) {
+    if (row * rows) {
+        if (!pinned_) {
+            par_memcpy2d(ln->hin.p, row, src, spitch, row, rows);
+            src = ln->hin.p;
+            spitch = row;
+        }
+        if (spitch == row || rows == 1) MDSP_HIP(hipMemcpyAsync(ln->din.p, src, row * rows, hipMemcpyHostToDevice, p_->s_up));
+        else MDSP_HIP(hipMemcpy2DAsync(ln->din.p, row, src, spitch, row, rows, hipMemcpyHostToDevice, p_->s_up));
+    }
+    MDSP_HIP(hipEventRecord(ln->up, p_->s_up));
+    MDSP_HIP(hipStreamWaitEvent(p_->s_k, ln->up, 0));
+    ln->busy = true;   // from here on the lane has work in flight (finish() synchronises the streams on error)
+    return MDSP_OK;
+}
+
+int Session::download(Lane* ln, void* dst, size_t dpitch, size_t row, size_t rows, size_t dev_off, size_t dev_pitch) {
+    MDSP_HIP(hipEventRecord(ln->kd, p_->s_k));
+    MDSP_HIP(hipStreamWaitEvent(p_->s_down, ln->kd, 0));
+    ln->busy = true;
+    if (row * rows) {
+        const char* dsrc = static_cast<const char*>(ln->dout.p) + dev_off;
+        void* hdst = pinned_ ? dst : ln->hout.p;
+        const size_t hpitch = pinned_ ? dpitch : row;
+        if ((hpitch == row && dev_pitch == row) || rows == 1) MDSP_HIP(hipMemcpyAsync(hdst, dsrc, row * rows, hipMemcpyDeviceToHost, p_->s_down));
+        else MDSP_HIP(hipMemcpy2DAsync(hdst, hpitch, dsrc, dev_pitch, row, rows, hipMemcpyDeviceToHost, p_->s_down));
+    }
+    MDSP_HIP(hipEventRecord(ln->down, p_->s_down));
+    ln->has_out = true;
+    ln->out_dst = dst;
+    ln->out_pitch = dpitch;
+    ln->out_row = row;
+    ln->out_rows = rows;
+    return MDSP_OK;
+}
+
+int Session::no_download(Lane* ln) {
+    MDSP_HIP(hipEventRecord(ln->kd, p_->s_k));
+    ln->busy = true;
+    ln->has_out = false;
+    return MDSP_OK;
+}
+
+int Session::finish(int rc) {
+    if (rc == MDSP_OK) {
+        for (int i = 0; i < NL; ++i) {   // oldest first
+            const int r2 = drain(p_->lane[(next_ + i) % NL]);
+            if (rc == MDSP_OK) rc = r2;
+        }
+    }
+    if (rc != MDSP_OK) {   // leave no work behind on the streams
+        (void)hipStreamSynchronize(p_->s_up);
+        (void)hipStreamSynchronize(p_->s_k);
+        (void)hipStreamSynchronize(p_->s_down);
+        for (Lane& ln : p_->lane) ln.busy = ln.has_out = false;
+    }
+    return rc;
+}
+
+}  // namespace hostpipe
+}  // namespace mdsp
 
 extern "C" {
 
@@ -151,7 +249,6 @@ int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64
     if (nx < 0 || ncols < 0 || nout < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
     const int64_t L = plan->L, nb = plan->nb;
     const int dtype = plan->dtype;
-    const bool serial_exec = plan->engine == MDSP_ENGINE_ROCFFT;   // that engine's transforms share the plan's work buffers: one at a time
     if (nout > nx + nb - 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nout (%lld) exceeds nx+nb-1", (long long)nout);
     if (ncols > 1 && (ldx < nx || ldy < nout)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "leading dimension smaller than the column length");
     if (nout == 0 || ncols == 0) return MDSP_OK;
@@ -169,68 +266,26 @@ int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64
     if (halo) bpc = std::max<int64_t>(bpc, 4 * cdiv(nb, L));   // keep the re-filtered halo below a quarter of a chunk
     const size_t in_cap = (size_t)(bpc * L + nb - 1) * esz, out_cap = (size_t)(bpc * L + (halo ? nb - 1 : 0)) * esz;
 
-    Pipe* pp = pipe_for_device();
-    std::lock_guard<std::mutex> lk(pp->mu);
-    MDSP_TRY(pp->init());
-    for (Lane& ln : pp->lane) {
-        MDSP_TRY(ln.din.reserve(in_cap));
-        MDSP_TRY(ln.dout.reserve(out_cap));
-        if (!pinned) {
-            MDSP_TRY(ln.hin.reserve(in_cap));
-            MDSP_TRY(ln.hout.reserve(out_cap));
-        }
-    }
-    int rc = MDSP_OK;
-    int64_t chunk = 0;
+    hostpipe::Session ss(in_cap, out_cap, pinned);
+    int rc = ss.status();
     for (int64_t col = 0; col < ncols && rc == MDSP_OK; ++col) {
         const char* xc = static_cast<const char*>(x_host) + (size_t)(col * ldx) * esz;
         char* yc = static_cast<char*>(y_host) + (size_t)(col * ldy) * esz;
-        for (int64_t g0 = 0; g0 < nblocks && rc == MDSP_OK; g0 += bpc, ++chunk) {
-            Lane& ln = pp->lane[chunk & 1];
-            if ((rc = ln.drain(pinned)) != MDSP_OK) break;           // this lane's previous chunk (two chunks ago)
+        for (int64_t g0 = 0; g0 < nblocks && rc == MDSP_OK; g0 += bpc) {
+            hostpipe::Lane* ln = nullptr;
+            if ((rc = ss.acquire(&ln)) != MDSP_OK) break;
             const int64_t g1 = std::min(nblocks, g0 + bpc);
             const int64_t lo = std::max<int64_t>(0, g0 * L - (nb - 1)), hi = std::min(nx, g1 * L);
             const int64_t o0 = g0 * L, o1 = std::min(nout, g1 * L);
             const size_t inb = hi > lo ? (size_t)(hi - lo) * esz : 0, outb = (size_t)(o1 - o0) * esz;
-            const void* src = xc + (size_t)lo * esz;
-            if (inb) {
-                if (!pinned) {
-                    par_memcpy(ln.hin.p, src, inb);
-                    src = ln.hin.p;
-                }
-                hipError_t e = hipMemcpyAsync(ln.din.p, src, inb, hipMemcpyHostToDevice, ln.s);
-                if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "H2D copy failed: %s", hipGetErrorString(e)); break; }
-            }
-            if (serial_exec && chunk > 0) {
-                hipError_t e = hipStreamWaitEvent(ln.s, pp->lane[(chunk & 1) ^ 1].kdone, 0);
-                if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "stream wait failed: %s", hipGetErrorString(e)); break; }
-            }
-            if (halo) rc = mdsp_ols_exec(plan, ln.din.p, hi > lo ? hi - lo : 0, 1, hi > lo ? hi - lo : 0, ln.dout.p, o1 - lo, o1 - lo, ln.s);
-            else rc = mdsp_ols_exec_range(plan, ln.din.p, lo, hi > lo ? hi - lo : 0, nx, ln.dout.p, g0, g1 - g0, nout, ln.s);
+            if ((rc = ss.upload(ln, xc + (size_t)lo * esz, inb, inb, 1)) != MDSP_OK) break;
+            if (halo) rc = mdsp_ols_exec(plan, ln->din.p, hi > lo ? hi - lo : 0, 1, hi > lo ? hi - lo : 0, ln->dout.p, o1 - lo, o1 - lo, ss.kstream());
+            else rc = mdsp_ols_exec_range(plan, ln->din.p, lo, hi > lo ? hi - lo : 0, nx, ln->dout.p, g0, g1 - g0, nout, ss.kstream());
             if (rc != MDSP_OK) break;
-            if (serial_exec) {
-                hipError_t e = hipEventRecord(ln.kdone, ln.s);
-                if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "event record failed: %s", hipGetErrorString(e)); break; }
-            }
-            void* dst = pinned ? (void*)(yc + (size_t)o0 * esz) : ln.hout.p;
-            hipError_t e = hipMemcpyAsync(dst, static_cast<const char*>(ln.dout.p) + (halo ? (size_t)(o0 - lo) * esz : 0), outb, hipMemcpyDeviceToHost, ln.s);
-            if (e == hipSuccess) e = hipEventRecord(ln.done, ln.s);
-            if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "D2H copy failed: %s", hipGetErrorString(e)); break; }
-            ln.out_dst = yc + (size_t)o0 * esz;
-            ln.out_bytes = outb;
-            ln.busy = true;
+            rc = ss.download(ln, yc + (size_t)o0 * esz, outb, outb, 1, halo ? (size_t)(o0 - lo) * esz : 0, outb);
         }
     }
-    for (Lane& ln : pp->lane) {
-        const int r2 = ln.drain(pinned);
-        if (rc == MDSP_OK) rc = r2;
-    }
-    if (rc != MDSP_OK) {   // leave no work behind on the lanes
-        (void)hipStreamSynchronize(pp->lane[0].s);
-        (void)hipStreamSynchronize(pp->lane[1].s);
-        pp->lane[0].busy = pp->lane[1].busy = false;
-    }
-    return rc;
+    return ss.finish(rc);
 }
 
 // welch_pgram of host arrays ((len, nch) column-major, ld lds_host): time chunks of whole frames for all channels at once; each
@@ -250,64 +305,27 @@ int mdsp_welch_exec_host(mdsp_welch_plan plan, const void* s_host, int64_t len, 
     // frames per chunk: ~host_chunk_mib over all channels
     const int64_t fpc = std::max<int64_t>(2, (((int64_t)tunables().host_chunk_mib << 20) / (int64_t)esz / nch - n) / hop + 1) & ~int64_t(1);
     const int64_t cl_max = (fpc - 1) * hop + n;                 // samples per channel per chunk
-    const size_t in_cap = (size_t)cl_max * (size_t)nch * esz;
+    const size_t in_cap = (size_t)cl_max * (size_t)nch * esz, psd_bytes = (size_t)nch * (size_t)plan->nout * rsz;
 
-    Pipe* pp = pipe_for_device();
-    std::lock_guard<std::mutex> lk(pp->mu);
-    MDSP_TRY(pp->init());
-    for (Lane& ln : pp->lane) {
-        MDSP_TRY(ln.din.reserve(in_cap));
-        if (!pinned) MDSP_TRY(ln.hin.reserve(in_cap));
-    }
-    MDSP_TRY(mdsp_welch_reset(plan));
-    // The accumulators live in the plan, so the chunks' kernels must run in order on ONE stream (lane 0's); the copies of the next chunk
-    // run on the other lane's stream and overlap them.
-    hipStream_t ks = pp->lane[0].s;
-    hipEvent_t kdone[2] = {pp->lane[0].kdone, pp->lane[1].kdone};   // kernel of the chunk that used buffer b has finished
-    bool used[2] = {false, false};
-    int rc = MDSP_OK;
-    int64_t chunk = 0;
-    for (int64_t k0 = 0; k0 < K && rc == MDSP_OK; k0 += fpc, ++chunk) {
-        const int b = (int)(chunk & 1);
-        Lane& ln = pp->lane[b];
+    hostpipe::Session ss(in_cap, psd_bytes, pinned);
+    int rc = ss.status();
+    if (rc == MDSP_OK) rc = mdsp_welch_reset(plan);
+    hostpipe::Lane* ln = nullptr;
+    // the accumulators live in the plan: the chunks' kernels run in order on the pipeline's kernel stream while the next chunks upload
+    for (int64_t k0 = 0; k0 < K && rc == MDSP_OK; k0 += fpc) {
+        if ((rc = ss.acquire(&ln)) != MDSP_OK) break;
         const int64_t k1 = std::min(K, k0 + fpc), cl = (k1 - k0 - 1) * hop + n;
-        if (used[b]) MDSP_HIP(hipEventSynchronize(kdone[b]));   // the kernel that read this buffer two chunks ago
-        const char* src = static_cast<const char*>(s_host) + (size_t)(k0 * hop) * esz;
-        size_t spitch = (size_t)lds_host * esz;
-        if (!pinned) {   // gather the channel slices into the staging buffer (contiguous rows of cl samples)
-            for (int64_t c = 0; c < nch; ++c) par_memcpy((char*)ln.hin.p + (size_t)(c * cl) * esz, src + (size_t)c * spitch, (size_t)cl * esz);
-            src = (const char*)ln.hin.p;
-            spitch = (size_t)cl * esz;
-        }
-        hipStream_t cs = pp->lane[1].s;                         // copy stream
-        hipError_t e = hipMemcpy2DAsync(ln.din.p, (size_t)cl * esz, src, spitch, (size_t)cl * esz, (size_t)nch, hipMemcpyHostToDevice, cs);
-        hipEvent_t copied = nullptr;
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&copied, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(copied, cs);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ks, copied, 0);
-        if (copied) (void)hipEventDestroy(copied);              // destruction is deferred until the event has completed
-        if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "H2D copy failed: %s", hipGetErrorString(e)); break; }
-        rc = mdsp_welch_accumulate(plan, ln.din.p, cl, nch, cl, ks);
-        if (rc != MDSP_OK) break;
-        e = hipEventRecord(kdone[b], ks);
-        if (e != hipSuccess) { rc = set_error(MDSP_ERR_DEVICE, "event record failed: %s", hipGetErrorString(e)); break; }
-        used[b] = true;
+        // the channel slices land as contiguous rows of cl samples
+        if ((rc = ss.upload(ln, static_cast<const char*>(s_host) + (size_t)(k0 * hop) * esz, (size_t)lds_host * esz, (size_t)cl * esz, (size_t)nch)) != MDSP_OK) break;
+        if ((rc = mdsp_welch_accumulate(plan, ln->din.p, cl, nch, cl, ss.kstream())) != MDSP_OK) break;
+        rc = ss.no_download(ln);
     }
-    if (rc == MDSP_OK && K == 0) rc = mdsp_welch_accumulate(plan, pp->lane[0].din.p, 0, nch, 0, ks);   // no frames: zero PSD (fill!(out, 0))
-    if (rc == MDSP_OK) {
-        DevBuf& pd = pp->lane[0].dout;
-        rc = pd.reserve((size_t)nch * (size_t)plan->nout * rsz);
-        if (rc == MDSP_OK) rc = mdsp_welch_finalize(plan, 0, pd.p, plan->nout, ks);
-        if (rc == MDSP_OK) {
-            hipError_t e = hipMemcpy2DAsync(psd_host, (size_t)ldp * rsz, pd.p, (size_t)plan->nout * rsz, (size_t)plan->nout * rsz, (size_t)nch,
-                                            hipMemcpyDeviceToHost, ks);
-            if (e != hipSuccess) rc = set_error(MDSP_ERR_DEVICE, "D2H copy failed: %s", hipGetErrorString(e));
-        }
-    }
-    (void)hipStreamSynchronize(pp->lane[1].s);
-    hipError_t e = hipStreamSynchronize(ks);
-    if (rc == MDSP_OK && e != hipSuccess) rc = set_error(MDSP_ERR_DEVICE, "stream synchronize failed: %s", hipGetErrorString(e));
-    return rc;
+    if (rc == MDSP_OK) rc = ss.acquire(&ln);
+    if (rc == MDSP_OK) rc = ss.upload(ln, nullptr, 0, 0, 0);
+    if (rc == MDSP_OK && K == 0) rc = mdsp_welch_accumulate(plan, ln->din.p, 0, nch, 0, ss.kstream());   // no frames: zero PSD (fill!(out, 0))
+    if (rc == MDSP_OK) rc = mdsp_welch_finalize(plan, 0, ln->dout.p, plan->nout, ss.kstream());
+    if (rc == MDSP_OK) rc = ss.download(ln, psd_host, (size_t)ldp * rsz, (size_t)plan->nout * rsz, (size_t)nch, 0, (size_t)plan->nout * rsz);
+    return ss.finish(rc);
 }
 
 }  // extern "C"

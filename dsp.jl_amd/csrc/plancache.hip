@@ -7,12 +7,18 @@
 // the key is everything the plan depends on -- device, calling thread, stream, sizes, dtype, engine, mode and the CONTENTS of the taps /
 // window -- so a hit is exactly the plan a fresh create would have produced.
 //
-// Ownership: a cached handle is BORROWED.  It must not be passed to mdsp_*_plan_destroy, and it stays valid until MDSP_PLAN_CACHE_SIZE
-// further distinct cached-plan requests have been made by the same thread (then the least recently used entry is destroyed), or until
-// mdsp_plan_cache_clear().  Entries are per (thread, stream): two host threads never share a cached plan's work buffers.
+// Ownership: a cached handle is BORROWED.  It must not be passed to mdsp_*_plan_destroy.  The cache is partitioned BY CALLING THREAD: every
+// thread has its own two LRU lists -- one of MDSP_PLAN_CACHE_SIZE user-visible plans ('o' overlap-save, 'w' Welch, 's' STFT), one of the same
+// size for the objects the library caches for itself ('f' per-call FIR filters, 't' tap uploads of the stateful FIR entry points) -- and only
+// that thread's own requests of the same class ever evict from them.  So a borrowed handle stays valid until the thread that borrowed it has
+// made MDSP_PLAN_CACHE_SIZE further DISTINCT cached-plan requests, whatever other threads do, and the library's internal objects can never
+// push a user's plan out.  (Round 2 kept one global list: misses of other threads, or this thread's own internal entries, could destroy a plan
+// between its lookup and its use.)  mdsp_plan_cache_clear() destroys every thread's entries: call it only while no other thread is inside the
+// library.  The lists of threads that have exited stay until then (at most 2 x MDSP_PLAN_CACHE_SIZE small objects per thread).
 #include <functional>
 #include <list>
 #include <thread>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -28,16 +34,22 @@ struct Entry {
     std::function<void(void*)> destroy;
 };
 
+struct PerThread {
+    std::list<Entry> user, internal;   // front = most recently used
+};
+
 struct Cache {
-    std::mutex mu;
-    std::list<Entry> lru;   // front = most recently used
+    std::mutex mu;                                         // guards the map and the lists (held for list surgery only, never across device work)
+    std::unordered_map<std::thread::id, PerThread> by_thread;
     int64_t hits = 0, misses = 0;
 };
 
 Cache& cache() {
-    static Cache c;
-    return c;
+    static Cache* c = new Cache();   // never destroyed: no device calls from static destructors at process exit
+    return *c;
 }
+
+bool is_internal(const std::string& key) { return !key.empty() && (key[0] == 'f' || key[0] == 't'); }
 
 void put(std::string& k, const void* p, size_t n) { k.append(static_cast<const char*>(p), n); }
 template <typename T> void put(std::string& k, T v) { put(k, &v, sizeof(v)); }
@@ -62,14 +74,18 @@ std::string base_key(char kind, void* stream) { return plan_cache_key(kind, stre
 }  // namespace
 
 namespace mdsp {
-// find or create; `make` builds a new object into *out
+// find or create; `make` builds a new object into *out.  Only the calling thread's list of the key's class is searched and evicted from.
 int plan_cache_get(const std::string& key, void** out, const std::function<int(void**)>& make, std::function<void(void*)> destroy) {
     Cache& c = cache();
+    const std::thread::id me = std::this_thread::get_id();
+    const bool internal = is_internal(key);
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        for (auto it = c.lru.begin(); it != c.lru.end(); ++it)
+        PerThread& pt = c.by_thread[me];
+        std::list<Entry>& lru = internal ? pt.internal : pt.user;
+        for (auto it = lru.begin(); it != lru.end(); ++it)
             if (it->key == key) {
-                c.lru.splice(c.lru.begin(), c.lru, it);
+                lru.splice(lru.begin(), lru, it);
                 ++c.hits;
                 *out = it->handle;
                 return MDSP_OK;
@@ -81,11 +97,12 @@ int plan_cache_get(const std::string& key, void** out, const std::function<int(v
     {
         std::lock_guard<std::mutex> lk(c.mu);
         ++c.misses;
-        c.lru.push_front(Entry{key, h, std::move(destroy)});
-        // evict the least recently used entries of THIS thread's keys beyond the capacity (keys carry the thread: count all, evict oldest)
-        while (c.lru.size() > kCapacity) {
-            evicted.push_back(std::move(c.lru.back()));
-            c.lru.pop_back();
+        PerThread& pt = c.by_thread[me];
+        std::list<Entry>& lru = internal ? pt.internal : pt.user;
+        lru.push_front(Entry{key, h, std::move(destroy)});
+        while (lru.size() > kCapacity) {   // this thread's least recently used entries of this class
+            evicted.push_back(std::move(lru.back()));
+            lru.pop_back();
         }
     }
     for (auto& e : evicted) e.destroy(e.handle);   // hipFree inside synchronises with any launch still using the buffers
@@ -158,7 +175,10 @@ int mdsp_stft_plan_cached(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int
 int mdsp_plan_cache_stats(int64_t* entries, int64_t* hits, int64_t* misses) {
     Cache& c = cache();
     std::lock_guard<std::mutex> lk(c.mu);
-    if (entries) *entries = (int64_t)c.lru.size();
+    if (entries) {
+        *entries = 0;
+        for (auto& kv : c.by_thread) *entries += (int64_t)(kv.second.user.size() + kv.second.internal.size());
+    }
     if (hits) *hits = c.hits;
     if (misses) *misses = c.misses;
     return MDSP_OK;
@@ -169,7 +189,11 @@ int mdsp_plan_cache_clear(void) {
     std::list<Entry> all;
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        all.swap(c.lru);
+        for (auto& kv : c.by_thread) {
+            all.splice(all.end(), kv.second.user);
+            all.splice(all.end(), kv.second.internal);
+        }
+        c.by_thread.clear();
     }
     for (auto& e : all) e.destroy(e.handle);
     return MDSP_OK;

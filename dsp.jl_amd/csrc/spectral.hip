@@ -32,6 +32,7 @@
 #include "hostfft.h"
 #include "rocfft_wrap.h"
 #include "welch_plan.h"
+#include "hostpipe.h"
 
 using namespace mdsp;
 using mdsp::fft::cx;
@@ -1090,6 +1091,18 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
     cx<R> P1[H], P2[H];
     int64_t u = unit_cur(a.niter > 0);
     load_unit(P1, P2, true, u, false);
+#ifdef MDSP_WELCH_PROF
+    unsigned long long prof_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0, prof_units = 0, prof_t0 = 0;
+#define MDSP_STAMP(k)                                                                   \
+    do {                                                                                \
+        unsigned long long now_;                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) : : "memory"); \
+        prof_sum[k] += now_ - prof_last;                                                \
+        prof_last = now_;                                                               \
+    } while (0)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last) : : "memory");
+    prof_t0 = prof_last;
+#endif
     auto unit = [&](cx<R> (&Q)[H], cx<R> (&F)[H], bool xa, bool more) {
         walk();
         const int64_t unext = unit_cur(more);
@@ -1099,6 +1112,34 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
         load_unit(F, Q, !xa, unext, carry);
         u = unext;
         cx<R> v[E];
+#ifdef MDSP_WELCH_PROF
+        // phase timeline of one unit (debug builds: build.py --tag prof --cflags -DMDSP_WELCH_PROF): shader-clock stamps at the phase boundaries,
+        // summed per wave; s_memtime needs lgkmcnt(0), which every boundary here waits for anyway (barriers, first use of the reloaded operands)
+        static_assert(C::P == 3 && NBUF == 1, "the phase profile is wired for three passes and one LDS buffer");
+        MDSP_STAMP(1);   // pass 0: butterflies + LDS writes done, next unit's loads issued
+        fft::wg_sync<T>();
+        MDSP_STAMP(2);   // barrier 1
+        fft::pass_reload<C, PADSHIFT, 1, 0>(v, t, lds);
+        MDSP_STAMP(3);   // operands of pass 1 back from LDS
+        fft::wg_sync<T>();
+        MDSP_STAMP(4);   // barrier 2
+        fft::pass_compute<C, -1, 1, fft::TW_REG, PADSHIFT, 0>(v, t, tw, table, lds);
+        MDSP_STAMP(5);   // pass 1 + LDS writes
+        fft::wg_sync<T>();
+        MDSP_STAMP(6);   // barrier 3
+        fft::pass_reload<C, PADSHIFT, 2, 0>(v, t, lds);
+        MDSP_STAMP(7);   // operands of pass 2
+        fft::wg_sync<T>();
+        MDSP_STAMP(8);   // barrier 4
+        fft::pass_compute<C, -1, 2, fft::TW_REG, PADSHIFT, 0>(v, t, tw, table, lds);
+#pragma unroll
+        for (int e = 0; e < E; ++e) accp[e] = fft::lanefma(v[e], v[e], accp[e]);
+        asm volatile("" :: "v"(accp[0].x), "v"(accp[E - 1].y));
+        MDSP_STAMP(9);   // pass 2 + |Z|^2
+        if (++since == FLUSH) flush();
+        MDSP_STAMP(0);   // (flush); also the start of the next unit
+        ++prof_units;
+#else
         fft::wg_sync<T>();
         fft::pass_reload<C, PADSHIFT, 1, 0>(v, t, lds);
         if constexpr (NBUF == 1) fft::wg_sync<T>();
@@ -1107,12 +1148,22 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e) accp[e] = fft::lanefma(v[e], v[e], accp[e]);
         if (++since == FLUSH) flush();
+#endif
     };
     for (int64_t it = 0; it < a.niter; it += 2) {   // same trip count for every slot (barriers inside)
         unit(P1, P2, true, it + 1 < a.niter);
         if (it + 1 < a.niter) unit(P2, P1, false, it + 2 < a.niter);
     }
     flush();
+#ifdef MDSP_WELCH_PROF
+    if (a.rinv && (threadIdx.x & 63) == 0) {   // one record per wave: 10 phase sums, units, total clocks  (a.rinv: the profile buffer in these builds)
+        unsigned long long* rec = (unsigned long long*)a.rinv + ((size_t)blockIdx.x * (T / 64) + threadIdx.x / 64) * 12;
+        for (int k = 0; k < 10; ++k) rec[k] = prof_sum[k];
+        rec[10] = prof_units;
+        rec[11] = prof_last - prof_t0;
+    }
+#undef MDSP_STAMP
+#endif
 }
 
 template <int N, int PADSHIFT, int NBUF> int welch_run_half3(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
@@ -1123,8 +1174,40 @@ template <int N, int PADSHIFT, int NBUF> int welch_run_half3(mdsp_welch_plan_s* 
     MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)grid * (size_t)a.nch * N));
     a.out = pl->partial.p;
     set_schedule(a, a.units_per_ch, (int64_t)grid);
+#ifdef MDSP_WELCH_PROF
+    static DevBuf profbuf;
+    const size_t nrec = (size_t)grid * (threads / 64);
+    MDSP_TRY(profbuf.reserve(nrec * 12 * 8));
+    a.rinv = a.nch == 1 ? static_cast<const double*>(profbuf.p) : nullptr;
+    hipEvent_t e0, e1;
+    MDSP_HIP(hipEventCreate(&e0)); MDSP_HIP(hipEventCreate(&e1));
+    MDSP_HIP(hipEventRecord(e0, st));
+#endif
     hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
     MDSP_LAUNCH_CHECK();
+#ifdef MDSP_WELCH_PROF
+    MDSP_HIP(hipEventRecord(e1, st));
+    MDSP_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    MDSP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (a.rinv) {   // debug build only: one line per launch
+        std::vector<unsigned long long> h(nrec * 12);
+        MDSP_HIP(hipMemcpy(h.data(), profbuf.p, nrec * 12 * 8, hipMemcpyDeviceToHost));
+        double sum[10] = {0}, units = 0, tot = 0, totmax = 0;
+        for (size_t r = 0; r < nrec; ++r) {
+            for (int k = 0; k < 10; ++k) sum[k] += (double)h[r * 12 + k];
+            units += (double)h[r * 12 + 10];
+            tot += (double)h[r * 12 + 11];
+            totmax = std::max(totmax, (double)h[r * 12 + 11]);
+        }
+        static const char* nm[10] = {"flush+loop", "pass0+ldsW", "barrier1", "reload1", "barrier2", "pass1+ldsW", "barrier3", "reload2", "barrier4", "pass2+acc"};
+        fprintf(stderr, "WELCHPROF grid %d x %d waves, %.4f ms, %.0f units/wave, clocks/unit %.0f (max-wave total %.0f clocks -> %.3f GHz):", grid, threads / 64, ms,
+                units / nrec, tot / units, totmax, totmax / (ms * 1e6));
+        for (int k = 1; k <= 9; ++k) fprintf(stderr, " %s %.0f", nm[k], sum[k] / units);
+        fprintf(stderr, " %s %.0f\n", nm[0], sum[0] / units);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+#endif
     *nslices = grid;
     return MDSP_OK;
 }
@@ -1194,7 +1277,9 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 16) rc = welch_run_half<R, N, EH, GH, 3, 4, 3, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 17) rc = welch_run_half<R, N, EH, GH, 3, 4, 2, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 30) rc = welch_run_half3<N, 5, 1>(pl, a, st, &nslices);   // round 3: paired samples, branch-free, window in the first stage
+#ifndef MDSP_WELCH_PROF
                 else if (pl->variant == 31) rc = welch_run_half3<N, 5, 2>(pl, a, st, &nslices);   // ... with two LDS buffers (one barrier per exchange)
+#endif
                 else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
                 else done = false;
             }
@@ -1720,6 +1805,43 @@ int mdsp_stft_exec(mdsp_stft_plan plan, const void* s_dev, int64_t len, int64_t 
                          : stft_exec_fused<float, true>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
     return dbl ? stft_exec_fused<double, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st)
                : stft_exec_fused<float, false>(plan, s_dev, len, nch, lds_, out_dev, ldo, chs, st);
+}
+
+// stft / spectrogram of host arrays (periodograms.jl:872-897 takes a host vector and returns a host matrix): channel by channel, runs of whole
+// frames.  Chunk c of a channel holds frames [k0, k1): their samples [k0 hop, (k1-1) hop + n) go up, their columns come down -- every frame is the
+// same frame the device-resident call transforms, so the two agree bit for bit.  The output is 2-8x the input (40 B per sample at config 4), which is
+// why the chunk is sized by its OUTPUT and why the pipeline keeps the D2H stream busy while the next chunk uploads (hostpipe.h).
+int mdsp_stft_exec_host(mdsp_stft_plan plan, const void* s_host, int64_t len, int64_t nch, int64_t lds_, void* out_host, int64_t ldo, int64_t chs,
+                        int flags) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    if (len < 0 || nch < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
+    if (plan->accumulate || plan->mt_ntapers > 0) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "multitaper plans have no host-array entry");
+    const int64_t n = plan->n, hop = plan->n - plan->noverlap, nout = plan->nout;
+    const int64_t K = mdsp_frame_count(len, n, plan->noverlap);
+    if (nch == 0 || K == 0) return MDSP_OK;
+    if (!out_host || !s_host) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
+    if (ldo < nout) MDSP_FAIL(MDSP_ERR_DIMENSION, "column stride smaller than the column length");
+    if (nch > 1 && (lds_ < len || chs < ldo * (K - 1) + nout)) MDSP_FAIL(MDSP_ERR_DIMENSION, "channel stride too small");
+    const bool pinned = (flags & MDSP_HOST_PINNED) != 0;
+    const size_t esz = dtype_size(plan->dtype);
+    const size_t osz = plan->psd_only ? dtype_size(dtype_real_of(plan->dtype)) : dtype_size(dtype_complex_of(plan->dtype));
+    const int64_t fpc = std::max<int64_t>(1, ((int64_t)tunables().host_chunk_mib << 20) / (int64_t)(nout * (int64_t)osz));   // frames per chunk
+    const size_t in_cap = (size_t)((fpc - 1) * hop + n) * esz, out_cap = (size_t)fpc * (size_t)nout * osz;
+    hostpipe::Session ss(in_cap, out_cap, pinned);
+    int rc = ss.status();
+    for (int64_t c = 0; c < nch && rc == MDSP_OK; ++c) {
+        const char* sc = static_cast<const char*>(s_host) + (size_t)(c * lds_) * esz;
+        char* oc = static_cast<char*>(out_host) + (size_t)(c * chs) * osz;
+        for (int64_t k0 = 0; k0 < K && rc == MDSP_OK; k0 += fpc) {
+            hostpipe::Lane* ln = nullptr;
+            if ((rc = ss.acquire(&ln)) != MDSP_OK) break;
+            const int64_t k1 = std::min(K, k0 + fpc), cl = (k1 - k0 - 1) * hop + n;
+            if ((rc = ss.upload(ln, sc + (size_t)(k0 * hop) * esz, (size_t)cl * esz, (size_t)cl * esz, 1)) != MDSP_OK) break;
+            if ((rc = mdsp_stft_exec(plan, ln->din.p, cl, 1, cl, ln->dout.p, nout, nout * (k1 - k0), ss.kstream())) != MDSP_OK) break;
+            rc = ss.download(ln, oc + (size_t)(k0 * ldo) * osz, (size_t)ldo * osz, (size_t)nout * osz, (size_t)(k1 - k0), 0, (size_t)nout * osz);
+        }
+    }
+    return ss.finish(rc);
 }
 
 }  // extern "C"

@@ -293,6 +293,22 @@ class FIRFilter:
         (n, channels); all channels share (phi_idx, input_deficit) and keep their own history."""
         xdt = _dev.np_dtype_of(x)
         W = _compute_dtype(xdt)
+        hcols = _dev.host_columns(x, W) if self.kind != 4 else None
+        if hcols is not None:              # large host array: mdsp_fir_exec_host (time chunks through the stateful filter, H2D || kernel || D2H)
+            nch, xlen = hcols.shape
+            self._ensure(W, max(nch, 1))
+            _lib.check(_lib.lib().mdsp_fir_set_state(self._handle, self.phi_idx, self.input_deficit, None))
+            ycap = max(self.outputlength(xlen), 0) if xlen >= self.input_deficit or self.kind == 0 else 0
+            outh = np.empty((nch, ycap), dtype=self._outdtype)
+            nw = C.c_int64(0)
+            _lib.check(_lib.lib().mdsp_fir_exec_host(self._handle, hcols.ctypes.data_as(C.c_void_p), xlen, xlen, outh.ctypes.data_as(C.c_void_p), ycap,
+                                                     max(ycap, 1), C.byref(nw), 0))
+            phi, dfc = C.c_int64(), C.c_int64()
+            _lib.check(_lib.lib().mdsp_fir_get_state(self._handle, C.byref(phi), C.byref(dfc), None))
+            self.phi_idx, self.input_deficit = phi.value, dfc.value
+            if nw.value != ycap:
+                raise AssertionError("Length of resampled output different from expectation.")     # stream_filt.jl:634
+            return outh[0] if x.ndim == 1 else outh.T
         cols, shape = _dev.to_columns(x, W)
         nch, xlen = cols.shape
         self._ensure(W, max(nch, 1))

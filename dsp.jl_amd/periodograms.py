@@ -160,11 +160,19 @@ def stft(s, n: int | None = None, noverlap: int | None = None, psdonly: bool = F
     _check_split(n, noverlap, nfft)                                                   # ArraySplit checks, :44-45
     S = util.fftintype(sdt)
     T = util.fftabs2type(S) if psdonly else util.fftouttype(S)
-    cols, shape = _dev.to_columns(s, S)
-    nch = cols.shape[0]
     k = frame_count(length, n, noverlap)
     plan = _plancache.plans.get(("stft", _plancache.ctx_key(), n, noverlap, nfft, _plancache.window_key(window), float(fs), onesided, bool(psdonly), np.dtype(S).str, engine),
                                 lambda: _StftPlan(n, noverlap, nfft, win, fs * norm2, onesided, psdonly, S, engine))
+    hcols = _dev.host_columns(s, S)
+    if hcols is not None and k > 0:    # large host array: mdsp_stft_exec_host (chunked H2D || kernel || D2H, the output never lives on the device whole)
+        nch = hcols.shape[0]
+        outh = np.empty((nch, k, plan.nout), dtype=T)
+        _lib.check(_lib.lib().mdsp_stft_exec_host(plan._h, hcols.ctypes.data_as(C.c_void_p), length, nch, length, outh.ctypes.data_as(C.c_void_p),
+                                                  plan.nout, k * plan.nout, 0))
+        res = outh.transpose(2, 1, 0)
+        return res[:, :, 0] if s.ndim == 1 else res
+    cols, shape = _dev.to_columns(s, S)
+    nch = cols.shape[0]
     out = _dev.torch.zeros((nch, k, plan.nout), dtype=_dev.torch_dtype(T), device=cols.device)     # zeros(...), :881
     if k and nch:
         _lib.check(_lib.lib().mdsp_stft_exec(plan._h, _dev.ptr(cols), length, nch, length, _dev.ptr(out), plan.nout, k * plan.nout,

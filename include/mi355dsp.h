@@ -196,7 +196,9 @@ int mdsp_welch_allreduce(mdsp_welch_plan plan, mdsp_comm comm, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Host-array entry points: DSP.jl's own call shape (host Arrays in, host Arrays out; Filters/filt.jl:458-476,
- * periodograms.jl:647-744) as a chunked H2D || kernel || D2H pipeline on two internal streams with page-locked double buffers.
+ * periodograms.jl:647-744, :872-897, stream_filt.jl:627-637, :688-775) as a chunked H2D || kernel || D2H pipeline: one internal stream per
+ * PCIe direction plus one for the kernels, three lanes of device (and, for pageable arrays, page-locked staging) buffers, so that chunk k's
+ * download, chunk k+1's kernels and chunk k+2's upload are in flight together (full duplex).
  * Synchronous (results are in the host arrays on return); PCIe-bound -- see DESIGN.md section 5 for the measured rates.
  *   flags: MDSP_HOST_PINNED = the caller's arrays are already page-locked (mdsp_host_alloc / mdsp_host_register): no staging copies.
  *   Chunk size: MDSP_HOST_CHUNK_MIB (default 64).  Results are bit-identical to the device-resident calls for overlap-save
@@ -211,6 +213,8 @@ int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64
                        int64_t ldy, int flags);
 int mdsp_welch_exec_host(mdsp_welch_plan plan, const void* s_host, int64_t len, int64_t nch, int64_t lds, void* psd_host,
                          int64_t ldp, int flags);
+/* stft / spectrogram / periodogram of host arrays (mdsp_stft_exec with host pointers, periodograms.jl:872-897): channel by channel in runs of
+ * whole frames, the chunk sized by its OUTPUT (2-8x the input); bit-identical to the device-resident call.  Declared after mdsp_stft_plan below. */
 
 typedef struct mdsp_stft_plan_s* mdsp_stft_plan;
 /* psd_only = 0: raw STFT columns (fftouttype), unnormalised (periodograms.jl:892);
@@ -224,6 +228,9 @@ int mdsp_stft_plan_info(mdsp_stft_plan plan, int64_t* nout, int* engine_used);
  * and channel stride chs (elements of the output type). */
 int mdsp_stft_exec(mdsp_stft_plan plan, const void* s_dev, int64_t len, int64_t nch, int64_t lds, void* out_dev,
                    int64_t ldo, int64_t chs, void* stream);
+/* the same with host arrays (see "Host-array entry points" above); flags: MDSP_HOST_PINNED */
+int mdsp_stft_exec_host(mdsp_stft_plan plan, const void* s_host, int64_t len, int64_t nch, int64_t lds, void* out_host,
+                        int64_t ldo, int64_t chs, int flags);
 
 /* ------------------------------------------------------------------------------------------------------
  * Multitaper spectral estimation (src/multitaper.jl)
@@ -283,6 +290,11 @@ int mdsp_fir_set_state(mdsp_fir f, int64_t phi_idx, int64_t input_deficit, const
  * *nwritten = samples written per channel (the return value of filt!). */
 int mdsp_fir_exec(mdsp_fir f, const void* x_dev, int64_t xlen, int64_t ldx, void* y_dev, int64_t ycap,
                   int64_t ldy, int64_t* nwritten, void* stream);
+/* filt(::FIRFilter, x) / resample of host arrays (stream_filt.jl:627-637, :688-775): the stream passes through the filter in time chunks of
+ * all channels, the filter state carried from chunk to chunk exactly as in the reference's streaming use -- the result and the final state
+ * are those of ONE mdsp_fir_exec over the whole stream, bit for bit.  ycap >= mdsp_fir_outputlength(f, xlen).  flags: MDSP_HOST_PINNED */
+int mdsp_fir_exec_host(mdsp_fir f, const void* x_host, int64_t xlen, int64_t ldx, void* y_host, int64_t ycap,
+                       int64_t ldy, int64_t* nwritten, int flags);
 
 /* ------------------------------------------------------------------------------------------------------
  * Arbitrary-rate resampler (FIRFilter{FIRArbitrary}: rate::AbstractFloat, Nphi phases, linear interpolation
@@ -372,7 +384,9 @@ int mdsp_hilbert(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int r
  * (filt(b, x), conv(u, v), welch_pgram(s, n, noverlap), stft / spectrogram / periodogram build their FFTW plans on every call;
  * a device plan costs ~1 ms, the call ~45 us).  Same arguments as the matching *_plan_create plus the stream the plan will run on;
  * the key is (device, calling thread, stream, every argument, CONTENTS of taps / window).  The returned handle is BORROWED: never
- * destroy it; it stays valid until MDSP_PLAN_CACHE_SIZE further distinct cached requests, or mdsp_plan_cache_clear().
+ * destroy it.  The cache is partitioned by calling thread (and the library's own cached objects live in separate lists), so the handle
+ * stays valid until THE SAME THREAD has made MDSP_PLAN_CACHE_SIZE further distinct cached requests, whatever other threads do, or until
+ * mdsp_plan_cache_clear() -- which destroys every thread's entries and must not race with other threads' library calls.
  * ---------------------------------------------------------------------------------------------------- */
 #define MDSP_PLAN_CACHE_SIZE 16
 int mdsp_ols_plan_cached(mdsp_ols_plan* plan, const void* taps_host, int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode,

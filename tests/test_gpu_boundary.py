@@ -263,6 +263,54 @@ def test_library_plan_cache(d, torch):
     assert np.array_equal(r1, r2) and e.value == 1
 
 
+def test_library_plan_cache_is_partitioned_by_thread_and_class(d, torch):
+    """ADVICE r2 (medium): a borrowed plan must survive other threads' misses and the library's own cached objects.  Thread A borrows a plan;
+    thread B then requests 3 x MDSP_PLAN_CACHE_SIZE distinct plans, and thread A itself runs 2 x MDSP_PLAN_CACHE_SIZE per-call FIR filters
+    with distinct taps (the library caches an internal 'f' object for each) -- A's plan is still the same live handle and still filters."""
+    import threading
+    from dsp_jl_amd import _lib, _dev
+    lib = _lib.lib()
+    _lib.check(lib.mdsp_plan_cache_clear())
+    st = _dev.stream_ptr()
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(100).astype(np.float32)
+    hA = C.c_void_p()
+    _lib.check(lib.mdsp_ols_plan_cached(C.byref(hA), b.ctypes.data_as(C.c_void_p), 100, 0, 10 ** 6, _lib.F32, _lib.OLS_FILT, 0, st))
+    x = torch.randn(100_000, device="cuda")
+    y0 = torch.empty_like(x)
+    _lib.check(lib.mdsp_ols_exec(hA, x.data_ptr(), x.numel(), 1, x.numel(), y0.data_ptr(), x.numel(), x.numel(), st))
+    torch.cuda.synchronize()
+    errs = []
+
+    def other():
+        try:
+            torch.cuda.set_device(0)
+            for k in range(48):
+                bk = b.copy(); bk[3] = 100 + k
+                hk = C.c_void_p()
+                _lib.check(lib.mdsp_ols_plan_cached(C.byref(hk), bk.ctypes.data_as(C.c_void_p), 100, 0, 10 ** 6, _lib.F32, _lib.OLS_FILT, 0, st))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = threading.Thread(target=other); th.start(); th.join()
+    assert not errs, errs
+    xs = rng.standard_normal(3000)
+    for k in range(32):                                   # this thread's own internal entries (one cached FIR object per distinct b)
+        bk = rng.standard_normal(12)
+        d.filt(bk, 1.0, xs)
+    e = C.c_int64()
+    _lib.check(lib.mdsp_plan_cache_stats(C.byref(e), None, None))
+    assert e.value <= 16 + 16 + 16                        # A's user list (1) + A's internal list (<= 16) + B's user list (16)
+    h2 = C.c_void_p()
+    _lib.check(lib.mdsp_ols_plan_cached(C.byref(h2), b.ctypes.data_as(C.c_void_p), 100, 0, 10 ** 6, _lib.F32, _lib.OLS_FILT, 0, st))
+    assert h2.value == hA.value                           # a hit on the very same object: nobody evicted it
+    y1 = torch.empty_like(x)
+    _lib.check(lib.mdsp_ols_exec(hA, x.data_ptr(), x.numel(), 1, x.numel(), y1.data_ptr(), x.numel(), x.numel(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    _lib.check(lib.mdsp_plan_cache_clear())
+
+
 def test_alternating_stateful_filters_and_repeated_tdfilt(d, torch):
     """ADVICE r1: two DF2TFilter objects with different taps that alternate (no device-wide synchronisation, each keeps its device taps);
     repeated filt(b, 1, x) reuses its cached filter object and stays a fresh zero-state filter every call."""
@@ -593,3 +641,145 @@ def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
             assert relerr(P[:, c], opg.welch_pgram(S[:, c], 4096, 2048, window=ow.hamming, dtype=np.float64).power) < TOL32
     finally:
         _lib.set_tunable("MDSP_WELCH_VARIANT", None)
+
+
+@pytest.mark.parametrize("engine", [1, 2], ids=["fused", "rocfft"])
+def test_host_pipeline_stft(d, torch, engine):
+    """mdsp_stft_exec_host: stft / spectrogram of host arrays in runs of whole frames on the three-stage pipeline -- the same frames the
+    device-resident call transforms, so the columns are bit-identical; strided output matrices (ldo > nout), several channels with a
+    leading dimension, page-locked arrays, the numpy API's own use of it, and the oracle."""
+    from dsp_jl_amd import _lib
+    from dsp_jl_amd.periodograms import _StftPlan, compute_window
+    from oracle import periodograms as opg, windows as ow
+    rng = np.random.default_rng(21)
+    lib = _lib.lib()
+    _lib.set_tunable("MDSP_HOST_CHUNK_MIB", 1)
+    try:
+        for sdt, L, nch, n, nov, nfft, psd in ((np.complex64, 600_000, 2, 1024, 768, 1024, 0), (np.float32, 900_001, 1, 512, 256, 512, 1),
+                                              (np.float64, 200_000, 3, 300, 100, 512, 0), (np.float32, 700_000, 2, 1000, 250, 1000, 1)):
+            cplx = np.dtype(sdt).kind == "c"
+            s = rng.standard_normal((nch, L + 7)).astype(sdt)        # rows longer than the signal: lds > len
+            if cplx:
+                s = (s + 1j * rng.standard_normal((nch, L + 7))).astype(sdt)
+            win, norm2 = compute_window(d.hanning, n)
+            plan = _StftPlan(n, nov, nfft, win, 1.0 * norm2, not cplx, psd, sdt, engine)
+            K = d.frame_count(L, n, nov)
+            single = sdt in (np.float32, np.complex64)
+            odt = (np.float32 if single else np.float64) if psd else (np.complex64 if single else np.complex128)
+            ldo = plan.nout + 3
+            dev_s = torch.from_numpy(s).cuda()
+            dev_out = torch.zeros((nch, K, ldo), dtype=getattr(torch, np.dtype(odt).name), device="cuda")
+            _lib.check(lib.mdsp_stft_exec(plan._h, dev_s.data_ptr(), L, nch, L + 7, dev_out.data_ptr(), ldo, K * ldo, None))
+            torch.cuda.synchronize()
+            host_out = np.zeros((nch, K, ldo), dtype=odt)
+            _lib.check(lib.mdsp_stft_exec_host(plan._h, s.ctypes.data_as(C.c_void_p), L, nch, L + 7, host_out.ctypes.data_as(C.c_void_p), ldo, K * ldo, 0))
+            assert np.array_equal(host_out, dev_out.cpu().numpy()), (sdt, n)
+            # page-locked arrays
+            pin_in, pin_out = C.c_void_p(), C.c_void_p()
+            _lib.check(lib.mdsp_host_alloc(C.byref(pin_in), s.nbytes)); _lib.check(lib.mdsp_host_alloc(C.byref(pin_out), host_out.nbytes))
+            try:
+                C.memmove(pin_in, s.ctypes.data_as(C.c_void_p), s.nbytes)
+                C.memset(pin_out, 0, host_out.nbytes)
+                _lib.check(lib.mdsp_stft_exec_host(plan._h, pin_in, L, nch, L + 7, pin_out, ldo, K * ldo, _lib.HOST_PINNED))
+                got = np.ctypeslib.as_array(C.cast(pin_out, C.POINTER(C.c_byte)), shape=(host_out.nbytes,)).view(odt).reshape(nch, K, ldo)
+                assert np.array_equal(got, host_out)
+            finally:
+                lib.mdsp_host_free(pin_in); lib.mdsp_host_free(pin_out)
+            # the oracle on the last channel (a few columns spread over the chunks)
+            sig = s[nch - 1, :L]
+            if psd:
+                ref = opg.spectrogram(sig.astype(np.float64 if not cplx else np.complex128), n, nov, nfft=nfft, window=ow.hanning, onesided=not cplx).power
+            else:
+                ref = opg.stft(sig.astype(np.float64 if not cplx else np.complex128), n, nov, nfft=nfft, window=ow.hanning, onesided=not cplx)
+            got = host_out[nch - 1, :, :plan.nout].T
+            assert relerr(got, ref) < (TOL32 if single else 1e-12)
+        # shorter than one frame: nothing is written
+        z = np.full((1, 5, 10), 7.0, np.float32)
+        win, norm2 = compute_window(d.hanning, 256)
+        plan = _StftPlan(256, 128, 256, win, norm2, True, 1, np.float32, engine)
+        _lib.check(lib.mdsp_stft_exec_host(plan._h, rng.standard_normal(100).astype(np.float32).ctypes.data_as(C.c_void_p), 100, 1, 100, z.ctypes.data_as(C.c_void_p), 129, 129, 0))
+        assert np.all(z == 7.0)
+    finally:
+        _lib.set_tunable("MDSP_HOST_CHUNK_MIB", None)
+    # numpy API: large host arrays take the pipeline on their own
+    s = (rng.standard_normal(5_000_000) + 1j * rng.standard_normal(5_000_000)).astype(np.complex64)
+    S_host = d.stft(s, 1024, 768, window=d.hanning, engine=engine)
+    S_dev = d.stft(torch.from_numpy(s).cuda(), 1024, 768, window=d.hanning, engine=engine)
+    assert isinstance(S_host, np.ndarray) and S_host.shape == tuple(S_dev.shape) and np.array_equal(S_host, S_dev.cpu().numpy())
+    x = rng.standard_normal(9_000_000).astype(np.float32)
+    P = d.spectrogram(x, 512, 256, window=d.hanning, engine=engine)
+    Pd = d.spectrogram(torch.from_numpy(x).cuda(), 512, 256, window=d.hanning, engine=engine)
+    assert isinstance(P.power, np.ndarray) and np.array_equal(P.power, Pd.power.cpu().numpy()) and np.array_equal(P.time, Pd.time)
+
+
+def test_host_pipeline_polyphase_filter(d, torch):
+    """mdsp_fir_exec_host: a host stream through the stateful polyphase filter in time chunks of all channels -- output and final state are those
+    of ONE device-resident mdsp_fir_exec (bit for bit), for rational / interpolating / decimating / single-rate filters, Float32 and Float64,
+    with a non-trivial initial state, page-locked arrays, and the numpy API (FIRFilter.filt / resample)."""
+    from fractions import Fraction
+    from dsp_jl_amd import _lib
+    from oracle import stream_filt as osf, design as odes
+    rng = np.random.default_rng(33)
+    lib = _lib.lib()
+    _lib.set_tunable("MDSP_HOST_CHUNK_MIB", 1)
+    try:
+        for dt, ld, (L, M), nch, n in ((np.float32, _lib.F32, (160, 147), 2, 1_200_003), (np.float64, _lib.F64, (3, 2), 1, 500_000), (np.float32, _lib.F32, (1, 4), 3, 900_000),
+                                       (np.float32, _lib.F32, (2, 1), 1, 400_001), (np.float32, _lib.F32, (1, 1), 2, 300_000)):
+            h = np.asarray(odes.resample_filter(Fraction(L, M)) if (L, M) != (1, 1) else _taps(48, np.float64), dtype=dt)
+            x = rng.standard_normal((nch, n + 5)).astype(dt)          # ldx > xlen
+            res = {}
+            for mode in ("dev", "host", "pinned"):
+                f = C.c_void_p()
+                _lib.check(lib.mdsp_fir_create(C.byref(f), h.ctypes.data_as(C.c_void_p), len(h), L, M, ld, ld, nch))
+                # a non-trivial state: run a short prefix first (device call), then the stream
+                pre = torch.from_numpy(np.ascontiguousarray(x[:, :1000])).cuda()
+                ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(f, 1000, C.byref(ol)))
+                ypre = torch.empty((nch, ol.value + 1), dtype=pre.dtype, device="cuda")
+                nw = C.c_int64()
+                _lib.check(lib.mdsp_fir_exec(f, pre.data_ptr(), 1000, 1000, ypre.data_ptr(), ol.value, ol.value + 1, C.byref(nw), None))
+                rest = n - 1000
+                _lib.check(lib.mdsp_fir_outputlength(f, rest, C.byref(ol)))
+                ldy = ol.value + 2
+                if mode == "dev":
+                    xd = torch.from_numpy(x).cuda()
+                    yd = torch.zeros((nch, ldy), dtype=xd.dtype, device="cuda")
+                    _lib.check(lib.mdsp_fir_exec(f, xd.data_ptr() + 1000 * x.itemsize, rest, n + 5, yd.data_ptr(), ol.value, ldy, C.byref(nw), None))
+                    torch.cuda.synchronize()
+                    y = yd.cpu().numpy()
+                elif mode == "host":
+                    y = np.zeros((nch, ldy), dtype=dt)
+                    _lib.check(lib.mdsp_fir_exec_host(f, C.c_void_p(x.ctypes.data + 1000 * x.itemsize), rest, n + 5, y.ctypes.data_as(C.c_void_p), ol.value, ldy, C.byref(nw), 0))
+                else:
+                    pin_in, pin_out = C.c_void_p(), C.c_void_p()
+                    _lib.check(lib.mdsp_host_alloc(C.byref(pin_in), x.nbytes)); _lib.check(lib.mdsp_host_alloc(C.byref(pin_out), nch * ldy * x.itemsize))
+                    C.memmove(pin_in, x.ctypes.data_as(C.c_void_p), x.nbytes)
+                    C.memset(pin_out, 0, nch * ldy * x.itemsize)
+                    _lib.check(lib.mdsp_fir_exec_host(f, C.c_void_p(pin_in.value + 1000 * x.itemsize), rest, n + 5, pin_out, ol.value, ldy, C.byref(nw), _lib.HOST_PINNED))
+                    y = np.ctypeslib.as_array(C.cast(pin_out, C.POINTER(C.c_byte)), shape=(nch * ldy * x.itemsize,)).view(dt).reshape(nch, ldy).copy()
+                    lib.mdsp_host_free(pin_in); lib.mdsp_host_free(pin_out)
+                assert nw.value == ol.value
+                phi, dfc = C.c_int64(), C.c_int64()
+                hl = C.c_int64(); _lib.check(lib.mdsp_fir_info(f, None, None, None, None, C.byref(hl), None))
+                hist = np.zeros((nch, max(hl.value, 1)), dtype=dt)
+                _lib.check(lib.mdsp_fir_get_state(f, C.byref(phi), C.byref(dfc), hist.ctypes.data_as(C.c_void_p)))
+                res[mode] = (y, phi.value, dfc.value, hist)
+                _lib.check(lib.mdsp_fir_destroy(f))
+            for mode in ("host", "pinned"):
+                assert np.array_equal(res[mode][0], res["dev"][0]), (L, M, mode)
+                assert res[mode][1:3] == res["dev"][1:3] and np.array_equal(res[mode][3], res["dev"][3]), (L, M, mode)
+            # the oracle on channel 0 (prefix + stream through one oracle filter)
+            of = osf.FIRFilter(h.astype(np.float64), Fraction(L, M))
+            of.filt(x[0, :1000].astype(np.float64))
+            ref = of.filt(x[0, 1000:n].astype(np.float64))
+            assert relerr(res["host"][0][0, :len(ref)], ref) < (2e-6 if dt == np.float32 else 1e-12)
+    finally:
+        _lib.set_tunable("MDSP_HOST_CHUNK_MIB", None)
+    # numpy API: a large host array through FIRFilter.filt and resample
+    x = rng.standard_normal(9_000_000).astype(np.float32)
+    ratio = Fraction(160, 147)
+    h = np.asarray(d.resample_filter(ratio), dtype=np.float32)
+    y_host = d.FIRFilter(h, ratio).filt(x)
+    y_dev = d.FIRFilter(h, ratio).filt(torch.from_numpy(x).cuda())
+    assert isinstance(y_host, np.ndarray) and np.array_equal(y_host, y_dev.cpu().numpy())
+    r_host = d.resample(x, ratio)
+    assert np.array_equal(r_host, d.resample(torch.from_numpy(x).cuda(), ratio).cpu().numpy())

@@ -118,7 +118,9 @@ def test_config4_stft_8x2p26_vs_oracle(d, torch):
 def test_config5_resample_4x2p28_vs_oracle(d, torch):
     """stream_filt.jl:476-515 / :688-725 at one GPU's share of config 5: 4 channels x 2^28 Float32 -> 292174646 outputs each.
     600-output oracle windows (Float64; the state of the reference's loop at the window start from the oracle's closed form) at
-    the start, inside a tile, across tile boundaries of the kernel (33 rounds x 160 outputs), where the output byte offset
+    the start, inside a tile, across tile boundaries of the matrix-core kernel that runs this shape (rows x outputs per row from
+    mdsp_fir_mm_geometry: 64 rows x 160 outputs; tiles are grid-strided over workgroups, so seams deep in the stream belong to
+    different workgroups than their neighbours) and of the retired register-tap kernel (33 x 160), where the output byte offset
     crosses 2^30 / 2^32 (channel 3), at pseudo-random depths, and at the very end (zero-padded tail, stream_filt.jl:699)."""
     from oracle import design as odes
     lg = int(os.environ.get("MDSP_TEST_C5_LOG2", 28))
@@ -132,10 +134,21 @@ def test_config5_resample_4x2p28_vs_oracle(d, torch):
     nout = fz.resample_output_length(n, ratio)
     assert lg != 28 or nout == 292174646
     assert y.shape == (nout, nch) and y.dtype == torch.float32
-    tile = 33 * 160
+    import ctypes as C
+    from dsp_jl_amd import _lib
+    geo = (C.c_int64 * 12)()
+    _lib.check(_lib.lib().mdsp_fir_mm_geometry(160, 147, len(h), _lib.F32, _lib.F32, geo))
+    fits, RB, Lr, Mr, NB, NG, steps, CH = list(geo)[:8]
+    assert fits and Lr == 160
+    tile = int(Lr * 16 * CH * NG)                  # outputs per tile of polyphase_mfma_kernel (config 5: 64 rows x 160 = 10240)
+    assert lg != 28 or tile == 10240
+    old_tile = 33 * 160                            # the register-tap kernel's tile (kept: its seams are ordinary positions now)
     rng = np.random.default_rng(1776)
-    spots = [0, 1, tile // 2, tile - 300, 7 * tile - 300, (nout // tile // 2) * tile - 300, (nout // tile) * tile - 300,
+    ntiles = nout // tile
+    spots = [0, 1, tile // 2, tile - 300, 2 * tile - 300, 7 * tile - 300, 255 * tile - 300, 256 * tile - 300, 257 * tile - 300, 1023 * tile - 300,
+             (ntiles // 2) * tile - 300, (ntiles - 1) * tile - 300, ntiles * tile - 300, old_tile - 300, 7 * old_tile - 300,
              2 ** 28 - 300, 2 ** 30 - 3 * nout - 300, nout - 600]      # 2^30 - 3 nout: channel 3's output crosses byte offset 2^32
+    spots += [int(k) * tile - 300 for k in rng.integers(1, max(2, ntiles), size=6)]     # seams at pseudo-random depths
     spots += [int(v) for v in rng.integers(0, nout - 600, size=12)]
     worst = 0.0
     for c in (0, 3):
