@@ -229,7 +229,55 @@ __device__ __forceinline__ void ols_store_staged(const cx<R> (&v)[E], const OlsF
     }
 }
 
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, int PERM = false, bool STAGE = false>
+// ---- LDS-DMA staging of the NEXT unit's samples (round 3) ----------------------------------------------------------------------------
+// Without a prefetch a unit's wave parks ~2 us on its loads at the top of every iteration, and with four two-wave workgroups per CU only
+// ~25 KiB per CU are outstanding on average: the read side of the kernel is capped by bytes in flight (bandwidth = outstanding / latency),
+// not by HBM.  A register prefetch costs the VGPRs that pay for the fourth workgroup (round 2 measured it slower).  buffer_load ... lds costs
+// none: the contiguous span of the next unit -- its two real blocks overlap by nb - 1 samples, so it is ONE run of L + N samples -- goes from
+// HBM straight into a 2 N-sample LDS buffer while this unit is transformed, and the next iteration starts with ds_reads instead of a trip to
+// memory.  Hand-issued (the compiler would make every later ds_read wait for a DMA it knows about); M0 holds the LDS address and is saved
+// and restored inside the statement.
+typedef int dma_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_i4 dma_rsrc(const void* base, long long bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    const long long nb = bytes < 0 ? 0 : (bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes);
+    return dma_i4{(int)__builtin_amdgcn_readfirstlane((unsigned)p), (int)(__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xffffu),
+                  (int)__builtin_amdgcn_readfirstlane((unsigned)nb), 0x00020000};
+}
+// 256 consecutive dwords, 16 bytes per lane: byte offset voff -> lds_byte + 16 lane
+__device__ __forceinline__ void dma256(dma_i4 rsrc, unsigned lds_byte, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
+}
+// 64 consecutive dwords, 4 bytes per lane (the tail of a span: lanes past the descriptor's end move nothing that is read)
+__device__ __forceinline__ void dma64(dma_i4 rsrc, unsigned lds_byte, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
+}
+// A unit whose L + N samples lie wholly inside the column (both blocks exist, no zero padding in front or behind) is staged; the handful of
+// edge units of a column keep the direct loads (hardware zero fill).
+__device__ __forceinline__ bool ols_unit_interior(const OlsFusedArgs& a, OlsPos q, int N) {
+    const int64_t g0 = 2 * q.p, start = g0 * a.L - (a.nb - 1);
+    return q.live && (g0 + 1) < a.nblocks && start >= 0 && start + a.L + N <= a.nx;
+}
+// issue the DMA of unit q's span into `stage` (T threads = T / 64 waves share the granules)
+template <int T> __device__ __forceinline__ void ols_dma_issue(const OlsFusedArgs& a, OlsPos q, int N, float* stage, int tid) {
+    const float* xc = static_cast<const float*>(a.x) + q.col * a.ldx;
+    const int64_t start = 2 * q.p * a.L - (a.nb - 1);
+    const int span = (int)a.L + N;                                  // floats
+    const dma_i4 r = dma_rsrc(xc + start, (long long)span * 4);
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)stage;   // LDS byte address of the staging buffer
+    const int wave = __builtin_amdgcn_readfirstlane(tid / 64), lane = tid & 63;
+    constexpr int NW = T / 64;
+    const int nfull = span / 256;
+    for (int g = wave; g < nfull; g += NW) dma256(r, base + (unsigned)g * 1024u, g * 1024 + lane * 16);
+    const int ntail = (span - nfull * 256 + 63) / 64;               // 64-dword granules behind the last full one
+    for (int g = wave; g < ntail; g += NW) dma64(r, base + (unsigned)nfull * 1024u + (unsigned)g * 256u, nfull * 1024 + g * 256 + lane * 4);
+}
+
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, int PERM = false, bool STAGE = false, bool XDMA = false>
 __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedArgs a) {
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T;
@@ -257,11 +305,31 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
     OlsWalk walk{a.u_begin + ((int64_t)blockIdx.x * G + slot) * a.run_len, 0};
     OlsPos cur = ols_pos(a, walk, a.niter > 0);
     OlsRaw<R, E, CPLX> raw;
+    constexpr bool DMA = XDMA && !CPLX && sizeof(R) == 4 && G == 1 && !PERM && !PREFETCH && C::P > 1;
+    __shared__ __attribute__((aligned(16))) float stage[DMA ? 2 * N : 4];   // the staged span: L + N <= 2 N samples
+    [[maybe_unused]] bool cur_staged = false;
+    if constexpr (DMA) {
+        cur_staged = ols_unit_interior(a, cur, N);                           // wave-uniform
+        if (cur_staged) ols_dma_issue<T>(a, cur, N, stage, threadIdx.x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if constexpr (PREFETCH) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti);
     for (int64_t it = 0; it < a.niter; ++it) {   // same trip count for every slot (barriers inside)
         ols_walk_next(walk, a.run_len, nslots);
         const OlsPos nxt = ols_pos(a, walk, it + 1 < a.niter);
-        if constexpr (!PREFETCH) { if (!MDSP_ABLATED(a, 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti); }
+        if constexpr (DMA) {
+            // every wave waited for its share of this unit's DMA before it left the previous iteration (or the prologue): after the barrier
+            // the whole span is in `stage`
+            fft::wg_sync<T>();
+            if (cur_staged) {
+                const int L = (int)a.L;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    raw.a[e] = stage[ti + T * e];
+                    raw.b[e] = stage[L + ti + T * e];
+                }
+            } else if (!MDSP_ABLATED(a, 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti);
+        } else if constexpr (!PREFETCH) { if (!MDSP_ABLATED(a, 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti); }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -271,6 +339,19 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
         // next unit's samples start streaming from HBM while this unit is transformed
         if constexpr (PREFETCH) { if (!MDSP_ABLATED(a, 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, nxt, ti); }
         if (!MDSP_ABLATED(a, 2)) {
+        if constexpr (DMA) {
+            // the forward transform's first pass, by hand: behind its exchange barrier every wave has read `stage`, so the NEXT unit's span
+            // may start to overwrite it -- a whole unit (two transforms) ahead of its use
+            constexpr int BUF0 = 0;
+            cx<R>* region = lds + BUF0 * fft::lds_elems<C::N, PADSHIFT>();
+            fft::pass_compute<C, -1, 0, TWMODE, PADSHIFT, PERM>(v, t, tw, twsrc, region);
+            fft::wg_sync<T>();
+            cur_staged = ols_unit_interior(a, nxt, N);
+            if (cur_staged) ols_dma_issue<T>(a, nxt, N, stage, threadIdx.x);
+            fft::pass_reload<C, PADSHIFT, 1, PERM>(v, t, region);
+            if constexpr (NBUF == 1) fft::wg_sync<T>();
+            fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0, 1, PERM>(v, t, tw, twsrc, lds);
+        } else
         fft::wg_fft<C, -1, TWMODE, PADSHIFT, NBUF, 0, 0, PERM>(v, t, tw, twsrc, lds);
         // spectral multiply (K2): natural order in registers
         if constexpr (HREG) {
@@ -287,6 +368,8 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
         }
         // no barrier needed here: with one buffer wg_fft ends every exchange with a barrier, with two the 2(P-1)
         // exchanges of a unit alternate buffers so the next unit's first write is two barriers behind its readers
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next unit's span has landed (issued two transforms ago); BEFORE this
+                                                                              // unit's stores, which the counter would otherwise make us wait for as well
         if (!MDSP_ABLATED(a, 4)) {
             if constexpr (STAGE && !CPLX && sizeof(R) == 4 && (G == 1 || T == 64) && NBUF == 1 && !PERM) {
                 // wave-uniform (workgroup-uniform: one transform per workgroup, or one-wave transforms): both blocks exist and lie inside y
@@ -493,9 +576,9 @@ template <typename R> int upload_table(DevBuf& buf, int64_t n) {
 
 // ---- fused launch ---------------------------------------------------------------------------------------
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true, bool HREG = true,
-          int PERM = false, bool STAGE = false>
+          int PERM = false, bool STAGE = false, bool XDMA = false>
 int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
-    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG, PERM, STAGE>;
+    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG, PERM, STAGE, XDMA>;
     constexpr int threads = (N / E) * G;
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
@@ -569,6 +652,8 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
             case 33: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, true, false>(a, s);   // 12 (prefetch) with one transform per workgroup
             case 34: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, false, true, false, true>(a, s);   // 30 + outputs staged through LDS, 16-byte stores
             case 35: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 3, 1, false, true, false, true>(a, s);   // 29 + staged stores
+            case 36: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, false, true, false, false, true>(a, s);   // 30 + the next unit's span staged in LDS by DMA
+            case 37: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 3, 1, false, true, false, false, true>(a, s);   // 29 (hybrid twiddles, <= 168 VGPRs) + DMA staging
             // DEFAULT (= 30): register twiddles, filter spectrum in registers, no software prefetch, ONE transform per 128-thread workgroup
             // (191 VGPRs, four workgroups of two waves per CU).  12-round interleaved A/B on two boxes (profiles/r02l_ols_decoupled.json,
             // r02e_ols_ab.json): 1.85 / 1.78 ms vs 1.93 / 1.86 (29: hybrid twiddles, 3 waves per SIMD) vs 2.05 / 1.97 (26: the same kernel

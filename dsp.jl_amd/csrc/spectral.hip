@@ -1004,7 +1004,13 @@ __global__ __launch_bounds__((N / E) * G, MINW) void welch_half_kernel(SpecArgs 
 //     folded by the finalize kernel anyway), so the roles of the two pair arrays and of their halves alternate from unit to unit (loop unrolled x2);
 //   * the window rides in the first butterfly stage (fft::bfly16_win: 8 packed operations less), and the butterflies' constant roots come
 //     from SGPR pairs (fft_lds.h, MDSP_FFT_SGPR_CONST).
-template <int N, int PADSHIFT, int NBUF>
+//   * DEEP: the samples of the next TWO units are in flight instead of one.  The phase profile of the one-deep form (profiles/r03b_welch_phases.txt)
+//     showed a wave parked ~1000 of a unit's ~5250 clocks in front of the first butterfly stage, waiting for loads it had issued one unit
+//     (~3300 clocks, 1.5 us) earlier: with two workgroups per CU and one unit (16 KiB) in flight per workgroup -- and only between issue
+//     and arrival -- a CU keeps ~20 KiB outstanding, and Little's law (bytes in flight = bandwidth x latency, ~2 us under load) caps the
+//     kernel near 3 TB/s whatever the arithmetic does.  Two register sets alternate; the half-frame hand-over is replaced by a third
+//     (L2-hit) load so that a unit's pairs do not depend on its predecessor's registers.
+template <int N, int PADSHIFT, int NBUF, bool DEEP = false>
 __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
     using R = float;
     constexpr int E = 16, H = 8;
@@ -1103,14 +1109,8 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last) : : "memory");
     prof_t0 = prof_last;
 #endif
-    auto unit = [&](cx<R> (&Q)[H], cx<R> (&F)[H], bool xa, bool more) {
-        walk();
-        const int64_t unext = unit_cur(more);
-        fft::pass0_windowed<C, PADSHIFT>(Q, F, wp, t, lds);   // consumes Q and F
-        // the successor: F's frame-b-second-half component is its frame a's first half when it follows directly (roles and halves swap)
-        const bool carry = unext == u + 1 && unext < a.units_per_ch;   // wave-uniform
-        load_unit(F, Q, !xa, unext, carry);
-        u = unext;
+    // everything of a unit after its first pass (whose results are on their way to LDS) and after the prefetch has been issued
+    auto tail = [&]() {
         cx<R> v[E];
 #ifdef MDSP_WELCH_PROF
         // phase timeline of one unit (debug builds: build.py --tag prof --cflags -DMDSP_WELCH_PROF): shader-clock stamps at the phase boundaries,
@@ -1150,9 +1150,39 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
         if (++since == FLUSH) flush();
 #endif
     };
-    for (int64_t it = 0; it < a.niter; it += 2) {   // same trip count for every slot (barriers inside)
-        unit(P1, P2, true, it + 1 < a.niter);
-        if (it + 1 < a.niter) unit(P2, P1, false, it + 2 < a.niter);
+    if constexpr (!DEEP) {
+        auto unit = [&](cx<R> (&Q)[H], cx<R> (&F)[H], bool xa, bool more) {
+            walk();
+            const int64_t unext = unit_cur(more);
+            fft::pass0_windowed<C, PADSHIFT>(Q, F, wp, t, lds);   // consumes Q and F
+            // the successor: F's frame-b-second-half component is its frame a's first half when it follows directly (roles and halves swap)
+            const bool carry = unext == u + 1 && unext < a.units_per_ch;   // wave-uniform
+            load_unit(F, Q, !xa, unext, carry);
+            u = unext;
+            tail();
+        };
+        for (int64_t it = 0; it < a.niter; it += 2) {   // same trip count for every slot (barriers inside)
+            unit(P1, P2, true, it + 1 < a.niter);
+            if (it + 1 < a.niter) unit(P2, P1, false, it + 2 < a.niter);
+        }
+    } else {
+        // two register sets, both with frame a in .x; a set is refilled with the unit TWO ahead as soon as the first stage has consumed it
+        cx<R> P3[H], P4[H];
+        int64_t taken = 1;   // (P1, P2) hold the slot's first unit
+        auto take = [&]() {
+            walk();
+            return unit_cur(taken++ < a.niter);
+        };
+        load_unit(P3, P4, true, take(), false);
+        auto unit_deep = [&](cx<R> (&Q)[H], cx<R> (&F)[H]) {
+            fft::pass0_windowed<C, PADSHIFT>(Q, F, wp, t, lds);
+            load_unit(Q, F, true, take(), false);
+            tail();
+        };
+        for (int64_t it = 0; it < a.niter; it += 2) {
+            unit_deep(P1, P2);
+            if (it + 1 < a.niter) unit_deep(P3, P4);
+        }
     }
     flush();
 #ifdef MDSP_WELCH_PROF
@@ -1166,8 +1196,8 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
 #endif
 }
 
-template <int N, int PADSHIFT, int NBUF> int welch_run_half3(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
-    auto kern = welch_half3_kernel<N, PADSHIFT, NBUF>;
+template <int N, int PADSHIFT, int NBUF, bool DEEP = false> int welch_run_half3(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
+    auto kern = welch_half3_kernel<N, PADSHIFT, NBUF, DEEP>;
     constexpr int threads = N / 16;
     int grid = 1;
     MDSP_TRY(grid_for(kern, threads, a.units_per_ch, a.nch, &grid));
@@ -1281,6 +1311,8 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 31) rc = welch_run_half3<N, 5, 2>(pl, a, st, &nslices);   // ... with two LDS buffers (one barrier per exchange)
 #endif
                 else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
+                else if (pl->variant == 33) rc = welch_run_half3<N, 5, 1, true>(pl, a, st, &nslices);   // ... two units in flight (two register sets)
+                else if (pl->variant == 34) rc = welch_run_half3<N, 4, 1, true>(pl, a, st, &nslices);
                 else done = false;
             }
             if (!done) {

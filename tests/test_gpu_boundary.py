@@ -608,7 +608,7 @@ def test_polyphase_matrix_core_kernel_fuzz(d, torch):
     assert used >= tried // 2          # most random shapes fit the matrix-core kernel
 
 
-@pytest.mark.parametrize("variant", [30, 31, 32])
+@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34])
 def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
     """welch_half3_kernel (paired samples, role-swapping units, window folded into the first butterfly stage, frame b's first half loaded a
     second time under the unit's have-frame-b predicate): every frame count parity, the odd last frame, one to three frames, several
@@ -783,3 +783,43 @@ def test_host_pipeline_polyphase_filter(d, torch):
     assert isinstance(y_host, np.ndarray) and np.array_equal(y_host, y_dev.cpu().numpy())
     r_host = d.resample(x, ratio)
     assert np.array_equal(r_host, d.resample(torch.from_numpy(x).cuda(), ratio).cpu().numpy())
+
+
+@pytest.mark.parametrize("variant", [36, 37])
+def test_overlap_save_lds_dma_staging_is_bit_identical(d, torch, variant):
+    """ols_fused_kernel<..., XDMA>: the next unit's span goes HBM -> LDS by buffer_load ... lds while this unit is transformed.  Only WHERE the
+    samples wait changes, so outputs must equal the direct-load kernel bit for bit: signals of every edge shape (shorter than a block, one unit,
+    an odd block count, leading zero padding, the clamped tail), several columns (units of different columns alternate in a slot), conv mode
+    (blocks past the end of x), block ranges from a slice (mdsp_ols_exec_range), and a long stream whose slots walk many interior units."""
+    from dsp_jl_amd import _lib
+    from dsp_jl_amd.dspbase import OlsPlan
+    from oracle import dspbase as odsp
+    rng = np.random.default_rng(360 + variant)
+    lib = _lib.lib()
+    b = _taps(256, np.float32)
+    try:
+        for nx, ncols, mode in ((100, 1, _lib.OLS_FILT), (1793, 1, _lib.OLS_FILT), (3586, 1, _lib.OLS_FILT), (3587, 2, _lib.OLS_FILT), (10_000, 3, _lib.OLS_FILT),
+                                (1_000_003, 1, _lib.OLS_FILT), (700_001, 2, _lib.OLS_CONV), ((1 << 24) + 12345, 1, _lib.OLS_FILT), (3_000_000, 5, _lib.OLS_FILT)):
+            x = torch.from_numpy(rng.standard_normal((ncols, nx)).astype(np.float32)).cuda()
+            nout = nx if mode == _lib.OLS_FILT else nx + 255
+            _lib.set_tunable("MDSP_OLS_VARIANT", "0")
+            ref = OlsPlan(b, 2048, nx, mode, d.ENGINE_FUSED).exec(x, nout)
+            _lib.set_tunable("MDSP_OLS_VARIANT", str(variant))
+            plan = OlsPlan(b, 2048, nx, mode, d.ENGINE_FUSED)
+            got = plan.exec(x, nout)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (variant, nx, ncols, mode)
+            assert torch.equal(plan.exec(x, nout), ref)                       # and again: the staging buffer carries nothing over between launches
+            if nx == 1_000_003:
+                want = odsp.filt_ba(b.astype(np.float64), 1.0, x[0, :60000].cpu().numpy().astype(np.float64))
+                assert relerr(got[0, :60000].cpu().numpy(), want) < TOL32
+                # a block range from a slice of the signal (host pipeline / time-axis split): blocks [100, 300) of the same grid
+                L, g0, g1 = 1793, 100, 300
+                lo, hi = g0 * L - 255, g1 * L
+                xs = x[0, lo:hi].contiguous()
+                ys = torch.empty(hi - g0 * L, dtype=torch.float32, device="cuda")
+                _lib.check(lib.mdsp_ols_exec_range(plan._h, xs.data_ptr(), lo, hi - lo, nx, ys.data_ptr(), g0, g1 - g0, nx, None))
+                torch.cuda.synchronize()
+                assert torch.equal(ys, ref[0, g0 * L:hi])
+    finally:
+        _lib.set_tunable("MDSP_OLS_VARIANT", None)
