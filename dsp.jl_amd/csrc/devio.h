@@ -156,5 +156,33 @@ template <typename T, int E, int TT, typename F> __device__ __forceinline__ void
     }
 }
 
+// ---- LDS-DMA (buffer_load ... lds): global memory straight into LDS, no VGPRs, no ds_write pass ---------------------------------------
+// Hand-issued: the compiler's wait-count bookkeeping would make every later ds_read wait for a DMA it knows about (it cannot tell LDS regions
+// apart), which defeats a prefetch.  M0 carries the LDS address and belongs to the compiler, so it is saved and restored inside the statement.
+// The issuing wave orders its own LDS reads behind a DMA with s_waitcnt vmcnt (DMA operations retire in issue order with the wave's other
+// vector-memory operations); other waves additionally need a barrier.
+typedef int dma_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_i4 dma_rsrc(const void* base, long long bytes) {   // raw buffer: nothing past `bytes` is moved
+    const unsigned long long p = (unsigned long long)base;
+    const long long nb = bytes < 0 ? 0 : (bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes);
+    return dma_i4{(int)__builtin_amdgcn_readfirstlane((unsigned)p), (int)(__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xffffu),
+                  (int)__builtin_amdgcn_readfirstlane((unsigned)nb), 0x00020000};
+}
+// 256 consecutive dwords, 16 bytes per lane: byte offset voff (+ lane * 16 inside it) -> lds_byte + 16 lane
+__device__ __forceinline__ void dma256(dma_i4 rsrc, unsigned lds_byte, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
+}
+// 64 consecutive dwords, 4 bytes per lane
+__device__ __forceinline__ void dma64(dma_i4 rsrc, unsigned lds_byte, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
+}
+template <typename T> __device__ __forceinline__ unsigned lds_byte_address(T* p) {   // LDS byte address of a __shared__ object
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)p;
+}
+
 }  // namespace io
 }  // namespace mdsp

@@ -468,14 +468,17 @@ MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t_raw, const cx<R> (&tw)[C::NTW 
 
 // Pass 0 of a forward E = 16 transform whose input is q[e] w[e] (e < 8), f[e] w[e + 8]: the window rides in the butterfly's first stage
 // (bfly16_win); results are scattered exactly as pass_compute<.., PASS = 0> does.  Identity lanes only.
+template <typename C, int PADSHIFT, typename R> MDSP_HD void pass0_scatter(const cx<R> (&v)[16], int t, cx<R>* lds) {
+    const int base = lds_pad<PADSHIFT>(t * 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[base + lds_padc<PADSHIFT>(r)] = v[r];
+}
 template <typename C, int PADSHIFT, typename R>
 MDSP_HD void pass0_windowed(const cx<R> (&q)[8], const cx<R> (&f)[8], const cx<R> (&wp)[8], int t, cx<R>* lds) {
     static_assert(C::E == 16 && C::radix(0) == 16 && C::P > 1, "E = 16 geometries with a radix-16 first pass");
     cx<R> v[16];
     bfly16_win<-1>(q, f, wp, v);
-    const int base = lds_pad<PADSHIFT>(t * 16);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lds[base + lds_padc<PADSHIFT>(r)] = v[r];
+    pass0_scatter<C, PADSHIFT>(v, t, lds);
 }
 
 // After the barrier that follows a non-final pass: fetch the operands of the next pass.

@@ -237,25 +237,10 @@ __device__ __forceinline__ void ols_store_staged(const cx<R> (&v)[E], const OlsF
 // HBM straight into a 2 N-sample LDS buffer while this unit is transformed, and the next iteration starts with ds_reads instead of a trip to
 // memory.  Hand-issued (the compiler would make every later ds_read wait for a DMA it knows about); M0 holds the LDS address and is saved
 // and restored inside the statement.
-typedef int dma_i4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ dma_i4 dma_rsrc(const void* base, long long bytes) {
-    const unsigned long long p = (unsigned long long)base;
-    const long long nb = bytes < 0 ? 0 : (bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes);
-    return dma_i4{(int)__builtin_amdgcn_readfirstlane((unsigned)p), (int)(__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) & 0xffffu),
-                  (int)__builtin_amdgcn_readfirstlane((unsigned)nb), 0x00020000};
-}
-// 256 consecutive dwords, 16 bytes per lane: byte offset voff -> lds_byte + 16 lane
-__device__ __forceinline__ void dma256(dma_i4 rsrc, unsigned lds_byte, int voff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
-}
-// 64 consecutive dwords, 4 bytes per lane (the tail of a span: lanes past the descriptor's end move nothing that is read)
-__device__ __forceinline__ void dma64(dma_i4 rsrc, unsigned lds_byte, int voff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_byte), "v"(voff), "s"(rsrc) : "memory");
-}
+using io::dma_i4;
+using io::dma_rsrc;
+using io::dma256;
+using io::dma64;
 // A unit whose L + N samples lie wholly inside the column (both blocks exist, no zero padding in front or behind) is staged; the handful of
 // edge units of a column keep the direct loads (hardware zero fill).
 __device__ __forceinline__ bool ols_unit_interior(const OlsFusedArgs& a, OlsPos q, int N) {
@@ -268,7 +253,7 @@ template <int T> __device__ __forceinline__ void ols_dma_issue(const OlsFusedArg
     const int64_t start = 2 * q.p * a.L - (a.nb - 1);
     const int span = (int)a.L + N;                                  // floats
     const dma_i4 r = dma_rsrc(xc + start, (long long)span * 4);
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)stage;   // LDS byte address of the staging buffer
+    const unsigned base = io::lds_byte_address(stage);
     const int wave = __builtin_amdgcn_readfirstlane(tid / 64), lane = tid & 63;
     constexpr int NW = T / 64;
     const int nfull = span / 256;

@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
     int64_t u = unit_cur(a.niter > 0);
     load_unit(P1, P2, true, u, false);
 #ifdef MDSP_WELCH_PROF
-    unsigned long long prof_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0, prof_units = 0, prof_t0 = 0;
+    unsigned long long prof_sum[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0, prof_units = 0, prof_t0 = 0;
 #define MDSP_STAMP(k)                                                                   \
     do {                                                                                \
         unsigned long long now_;                                                        \
@@ -1154,7 +1154,20 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
         auto unit = [&](cx<R> (&Q)[H], cx<R> (&F)[H], bool xa, bool more) {
             walk();
             const int64_t unext = unit_cur(more);
+#ifdef MDSP_WELCH_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MDSP_STAMP(10);   // this unit's samples have arrived
+            {
+                cx<R> v0[16];
+                fft::bfly16_win<-1>(Q, F, wp, v0);
+                asm volatile("" :: "v"(v0[0].x), "v"(v0[15].y));
+                MDSP_STAMP(11);   // first pass: arithmetic
+                fft::pass0_scatter<C, PADSHIFT>(v0, t, lds);
+                MDSP_STAMP(12);   // first pass: LDS writes retired
+            }
+#else
             fft::pass0_windowed<C, PADSHIFT>(Q, F, wp, t, lds);   // consumes Q and F
+#endif
             // the successor: F's frame-b-second-half component is its frame a's first half when it follows directly (roles and halves swap)
             const bool carry = unext == u + 1 && unext < a.units_per_ch;   // wave-uniform
             load_unit(F, Q, !xa, unext, carry);
@@ -1175,7 +1188,20 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
         };
         load_unit(P3, P4, true, take(), false);
         auto unit_deep = [&](cx<R> (&Q)[H], cx<R> (&F)[H]) {
+#ifdef MDSP_WELCH_PROF
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // this unit's 32 loads are the older half of what is in flight
+            MDSP_STAMP(10);
+            {
+                cx<R> v0[16];
+                fft::bfly16_win<-1>(Q, F, wp, v0);
+                asm volatile("" :: "v"(v0[0].x), "v"(v0[15].y));
+                MDSP_STAMP(11);
+                fft::pass0_scatter<C, PADSHIFT>(v0, t, lds);
+                MDSP_STAMP(12);
+            }
+#else
             fft::pass0_windowed<C, PADSHIFT>(Q, F, wp, t, lds);
+#endif
             load_unit(Q, F, true, take(), false);
             tail();
         };
@@ -1187,13 +1213,167 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
     flush();
 #ifdef MDSP_WELCH_PROF
     if (a.rinv && (threadIdx.x & 63) == 0) {   // one record per wave: 10 phase sums, units, total clocks  (a.rinv: the profile buffer in these builds)
-        unsigned long long* rec = (unsigned long long*)a.rinv + ((size_t)blockIdx.x * (T / 64) + threadIdx.x / 64) * 12;
-        for (int k = 0; k < 10; ++k) rec[k] = prof_sum[k];
-        rec[10] = prof_units;
-        rec[11] = prof_last - prof_t0;
+        unsigned long long* rec = (unsigned long long*)a.rinv + ((size_t)blockIdx.x * (T / 64) + threadIdx.x / 64) * 16;
+        for (int k = 0; k < 13; ++k) rec[k] = prof_sum[k];
+        rec[13] = prof_units;
+        rec[14] = prof_last - prof_t0;
     }
 #undef MDSP_STAMP
 #endif
+}
+
+// ---- the same path with the samples staged in LDS by DMA (round 3) ----------------------------------------------------------------------
+// Phase profile of welch_half3_kernel (profiles/r03c_welch_phases.txt): of a unit's ~5300 clocks a wave spends ~700 ISSUING its 32
+// buffer_load_dword (a wave instruction moves 256 bytes, and the four waves of a workgroup reach the load burst together) and ~800 waiting for
+// them, however early they were issued (two units ahead changes nothing) -- 28 % of the unit in a load path built from 4-byte-per-lane
+// instructions.  Here a unit's two new half-frames (2 x 8 KiB) arrive by buffer_load_dwordx4 ... lds: four DMA instructions per wave and unit
+// instead of 32 loads, no VGPRs, issued two units ahead.  Half-frame k of the channel lives in ring slot k mod 5 (5 x 8 KiB next to the 33 KiB
+// exchange buffer: two workgroups per CU still fit); unit u reads half-frames 2u, 2u+1, 2u+2 as the (frame a, frame b) pairs of the first stage
+// and, once every wave is past the first exchange barrier (all reads of the two oldest slots done), its waves refill those two slots with the
+// half-frames of unit u+2.  Every wave issues the same number of DMA instructions per unit (a zero-size descriptor for half-frames that do not
+// exist), so "all but the newest batch have landed" is the constant s_waitcnt vmcnt(4), placed in front of an exchange barrier that exists
+// anyway: the pipeline adds no barrier.  One contiguous run of units per slot (the default schedule); other schedules take welch_half3_kernel.
+template <int N, int PADSHIFT>
+__global__ __launch_bounds__(N / 16, 2) void welch_half4_kernel(SpecArgs a) {
+    using R = float;
+    constexpr int E = 16, H = 8, NBUF = 1, NSLOT = 5;
+    using C = fft::Cfg<N, E>;
+    constexpr int T = C::T, NW = T / 64;
+    constexpr int HALF = N / 2;                      // samples per half-frame
+    constexpr int GRAN = HALF / 256;                 // 1 KiB DMA granules per half-frame
+    static_assert(T % 64 == 0 && T >= 128 && C::P == 3 && GRAN % NW == 0, "geometry");
+    constexpr int GPW = GRAN / NW;                   // granules per wave and half-frame
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int REGION = fft::wg_lds_elems<C, PADSHIFT, NBUF>();
+    __shared__ __attribute__((aligned(16))) cx<R> lds[REGION];
+    __shared__ __attribute__((aligned(16))) R ring[NSLOT * HALF];
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t / 64), lane = t & 63;
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    const int64_t ch = blockIdx.y;
+
+    cx<R> tw[NTWA];
+    fft::load_twiddles<C, R, 1, fft::TW_REG, false>(tw, t, table);
+    cx<R> wp[H];
+    {
+        double wd[E];
+        load_window_regs<E, T>(wd, a.win, a.n, t);
+#pragma unroll
+        for (int e = 0; e < H; ++e) wp[e] = {(R)wd[e], (R)wd[e + H]};
+    }
+    constexpr int FLUSH = 128;
+    cx<R> accp[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) accp[e] = {(R)0, (R)0};
+    double* part = static_cast<double*>(a.out) + ((int64_t)blockIdx.x * a.nch + ch) * N;
+    const __amdgpu_buffer_rsrc_t prs = io::make_rsrc(part, (int64_t)N * 8);
+    int since = 0;
+    bool first = true;
+    auto flush = [&]() {
+        int off = t * 8;
+        asm volatile("" : "+v"(off));
+        if (first) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) io::Ld<double>::store((double)accp[e].x + (double)accp[e].y, prs, off + T * e * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double s = io::Ld<double>::load(prs, off + T * e * 8) + ((double)accp[e].x + (double)accp[e].y);
+                io::Ld<double>::store(s, prs, off + T * e * 8);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) accp[e] = {(R)0, (R)0};
+        first = false;
+        since = 0;
+    };
+
+    const R* sc = static_cast<const R*>(a.s) + ch * a.lds_;
+    // this slot's units: u0 .. u0 + cnt - 1 (consecutive; run_len covers the slot's whole share), dead iterations behind them
+    const int64_t u0 = (int64_t)blockIdx.x * a.run_len;
+    const int64_t uend = std::min<int64_t>(u0 + a.run_len, a.units_per_ch);           // one past this slot's last live unit
+    // half-frame k (of the channel) is wanted by this slot iff it belongs to a frame of one of its units: k in [2 u0, klast]
+    const int64_t klast = uend > u0 ? 2 * (uend - 1) + (((2 * (uend - 1) + 1) < a.K) ? 2 : 1) : -1;
+    const unsigned ring0 = io::lds_byte_address(ring);
+    // this wave's share of half-frame k -> ring slot k mod NSLOT (always GPW instructions: an unwanted half-frame moves nothing)
+    auto dma_half = [&](int64_t k, int slot) {
+        const bool want = k >= 2 * u0 && k <= klast;
+        const io::dma_i4 r = io::dma_rsrc(sc + k * HALF, want ? (long long)HALF * 4 : 0);
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+            const int gr = wave * GPW + g;
+            io::dma256(r, ring0 + (unsigned)slot * (unsigned)(HALF * 4) + (unsigned)gr * 1024u, gr * 1024 + lane * 16);
+        }
+    };
+    // prologue: unit u0 (three half-frames) and unit u0 + 1 (two more) -- slots 0 .. 4; then only the newest batch (GPW x 2) may be outstanding
+    dma_half(2 * u0, 0); dma_half(2 * u0 + 1, 1); dma_half(2 * u0 + 2, 2);
+    dma_half(2 * u0 + 3, 3); dma_half(2 * u0 + 4, 4);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * GPW) : "memory");
+    __syncthreads();
+    int s0 = 0;                                      // ring slot of half-frame 2 u (wave-uniform)
+    int64_t u = u0;
+    for (int64_t it = 0; it < a.niter; ++it, ++u) {  // same trip count for every slot (barriers inside)
+        const bool live = u < uend, haveB = live && (2 * u + 1) < a.K;
+        const int s1 = s0 + 1 >= NSLOT ? s0 + 1 - NSLOT : s0 + 1, s2 = s0 + 2 >= NSLOT ? s0 + 2 - NSLOT : s0 + 2;
+        cx<R> Q[H], F[H];                            // Q = (a lo | b lo), F = (a hi | b hi)
+        if (live) {
+            const R* h0 = ring + s0 * HALF + t;
+            const R* h1 = ring + s1 * HALF + t;
+            const R* h2 = ring + s2 * HALF + t;
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                const R m = h1[T * e];
+                Q[e] = {h0[T * e], m};
+                F[e] = {m, h2[T * e]};
+            }
+            if (!haveB) {                            // the odd last frame of the channel: no frame b
+#pragma unroll
+                for (int e = 0; e < H; ++e) {
+                    Q[e].y = (R)0;
+                    F[e].y = (R)0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < H; ++e) Q[e] = F[e] = {(R)0, (R)0};
+        }
+        fft::pass0_windowed<C, PADSHIFT>(Q, F, wp, t, lds);
+        cx<R> v[E];
+        fft::wg_sync<T>();                           // exchange barrier 1: every wave has read its half-frames
+        // refill the two oldest slots with the half-frames of unit u + 2
+        dma_half(2 * u + 5, s0);
+        dma_half(2 * u + 6, s1);
+        fft::pass_reload<C, PADSHIFT, 1, 0>(v, t, lds);
+        fft::wg_sync<T>();
+        fft::pass_compute<C, -1, 1, fft::TW_REG, PADSHIFT, 0>(v, t, tw, table, lds);
+        fft::wg_sync<T>();
+        fft::pass_reload<C, PADSHIFT, 2, 0>(v, t, lds);
+        // all but the batch just issued has landed (this wave's share); behind the barrier the next unit's half-frames are complete
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * GPW) : "memory");
+        fft::wg_sync<T>();
+        fft::pass_compute<C, -1, 2, fft::TW_REG, PADSHIFT, 0>(v, t, tw, table, lds);
+#pragma unroll
+        for (int e = 0; e < E; ++e) accp[e] = fft::lanefma(v[e], v[e], accp[e]);
+        if (++since == FLUSH) flush();
+        s0 = s2;
+    }
+    flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this workgroup may still be writing its LDS when it exits
+}
+
+template <int N, int PADSHIFT> int welch_run_half4(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
+    auto kern = welch_half4_kernel<N, PADSHIFT>;
+    constexpr int threads = N / 16;
+    int grid = 1;
+    MDSP_TRY(grid_for(kern, threads, a.units_per_ch, a.nch, &grid));
+    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)grid * (size_t)a.nch * N));
+    a.out = pl->partial.p;
+    set_schedule(a, a.units_per_ch, (int64_t)grid);
+    if (a.run_len * (int64_t)grid < a.units_per_ch) return -1000;   // several runs per slot (MDSP_RUNS_PER_SLOT): the caller takes welch_half3_kernel
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(threads), 0, st, a);
+    MDSP_LAUNCH_CHECK();
+    *nslices = grid;
+    return MDSP_OK;
 }
 
 template <int N, int PADSHIFT, int NBUF, bool DEEP = false> int welch_run_half3(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
@@ -1207,7 +1387,7 @@ template <int N, int PADSHIFT, int NBUF, bool DEEP = false> int welch_run_half3(
 #ifdef MDSP_WELCH_PROF
     static DevBuf profbuf;
     const size_t nrec = (size_t)grid * (threads / 64);
-    MDSP_TRY(profbuf.reserve(nrec * 12 * 8));
+    MDSP_TRY(profbuf.reserve(nrec * 16 * 8));
     a.rinv = a.nch == 1 ? static_cast<const double*>(profbuf.p) : nullptr;
     hipEvent_t e0, e1;
     MDSP_HIP(hipEventCreate(&e0)); MDSP_HIP(hipEventCreate(&e1));
@@ -1221,20 +1401,21 @@ template <int N, int PADSHIFT, int NBUF, bool DEEP = false> int welch_run_half3(
     float ms = 0;
     MDSP_HIP(hipEventElapsedTime(&ms, e0, e1));
     if (a.rinv) {   // debug build only: one line per launch
-        std::vector<unsigned long long> h(nrec * 12);
-        MDSP_HIP(hipMemcpy(h.data(), profbuf.p, nrec * 12 * 8, hipMemcpyDeviceToHost));
-        double sum[10] = {0}, units = 0, tot = 0, totmax = 0;
+        std::vector<unsigned long long> h(nrec * 16);
+        MDSP_HIP(hipMemcpy(h.data(), profbuf.p, nrec * 16 * 8, hipMemcpyDeviceToHost));
+        double sum[13] = {0}, units = 0, tot = 0, totmax = 0;
         for (size_t r = 0; r < nrec; ++r) {
-            for (int k = 0; k < 10; ++k) sum[k] += (double)h[r * 12 + k];
-            units += (double)h[r * 12 + 10];
-            tot += (double)h[r * 12 + 11];
-            totmax = std::max(totmax, (double)h[r * 12 + 11]);
+            for (int k = 0; k < 13; ++k) sum[k] += (double)h[r * 16 + k];
+            units += (double)h[r * 16 + 13];
+            tot += (double)h[r * 16 + 14];
+            totmax = std::max(totmax, (double)h[r * 16 + 14]);
         }
-        static const char* nm[10] = {"flush+loop", "pass0+ldsW", "barrier1", "reload1", "barrier2", "pass1+ldsW", "barrier3", "reload2", "barrier4", "pass2+acc"};
+        static const char* nm[13] = {"flush+loop", "load-issue", "barrier1", "reload1", "barrier2", "pass1+ldsW", "barrier3", "reload2", "barrier4", "pass2+acc",
+                                     "memwait", "pass0-valu", "pass0-ldsW"};
         fprintf(stderr, "WELCHPROF grid %d x %d waves, %.4f ms, %.0f units/wave, clocks/unit %.0f (max-wave total %.0f clocks -> %.3f GHz):", grid, threads / 64, ms,
                 units / nrec, tot / units, totmax, totmax / (ms * 1e6));
-        for (int k = 1; k <= 9; ++k) fprintf(stderr, " %s %.0f", nm[k], sum[k] / units);
-        fprintf(stderr, " %s %.0f\n", nm[0], sum[0] / units);
+        for (int k : {10, 11, 12, 1, 2, 3, 4, 5, 6, 7, 8, 9, 0}) fprintf(stderr, " %s %.0f", nm[k], sum[k] / units);
+        fprintf(stderr, "\n");
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 #endif
@@ -1313,6 +1494,10 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
                 else if (pl->variant == 33) rc = welch_run_half3<N, 5, 1, true>(pl, a, st, &nslices);   // ... two units in flight (two register sets)
                 else if (pl->variant == 34) rc = welch_run_half3<N, 4, 1, true>(pl, a, st, &nslices);
+                else if (pl->variant == 35 || pl->variant == 36) {   // half-frames staged in LDS by DMA, two units ahead (pad 5 / pad 4)
+                    rc = pl->variant == 35 ? welch_run_half4<N, 5>(pl, a, st, &nslices) : welch_run_half4<N, 4>(pl, a, st, &nslices);
+                    if (rc == -1000) rc = welch_run_half3<N, 5, 1>(pl, a, st, &nslices);
+                }
                 else done = false;
             }
             if (!done) {
