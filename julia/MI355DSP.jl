@@ -822,9 +822,9 @@ function timedelay(f::FIRArbitraryFilter)                                       
     check(ccall((:mdsp_firarb_timedelay, lib), Cint, (Ptr{Cvoid}, Ref{Cdouble}), f.h, τ)); τ[]
 end
 function firinfo(f::FIRArbitraryFilter)
-    tp, hl, od = Ref{Int64}(0), Ref{Int64}(0), Ref{Cint}(0)
-    check(ccall((:mdsp_firarb_info, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Cint}), f.h, tp, hl, od))
-    (tapsPerϕ = Int(tp[]), historyLen = Int(hl[]), outtype = JLTYPE[od[] + 1])
+    nϕ, tp, hl, od, Δ = Ref{Int64}(0), Ref{Int64}(0), Ref{Int64}(0), Ref{Cint}(0), Ref{Cdouble}(0)
+    check(ccall((:mdsp_firarb_info, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Cint}, Ref{Cdouble}), f.h, nϕ, tp, hl, od, Δ))
+    (Nϕ = Int(nϕ[]), tapsPerϕ = Int(tp[]), historyLen = Int(hl[]), outtype = JLTYPE[od[] + 1], Δ = Δ[])
 end
 # the reference's state (stream_filt.jl:96-104): ϕAccumulator, α, ϕIdx, inputDeficit, xIdx, history
 function getstate(f::FIRArbitraryFilter)
@@ -892,6 +892,23 @@ function arb_trajectory(ϕAcc::Real, inputDeficit::Integer, rate::Real, Nϕ::Int
         (Cdouble, Int64, Cdouble, Int64, Int64, Int64, Ptr{Int64}, Ptr{Cdouble}, Int64, Ref{Int64}, Ref{Cdouble}, Ref{Int64}),
         ϕAcc, inputDeficit, rate, Nϕ, xlen, block, pointer(ax), pointer(aa), cap, nout, aend, dend))
     (anchors_x = ax, anchors_acc = aa, nout = Int(nout[]), ϕAcc_end = aend[], deficit_end = Int(dend[]))
+end
+
+# the host emulation of the device's parallel evaluation of the same recurrence (used == false: the scan does not apply to these arguments)
+function arb_trajectory_scan(ϕAcc::Real, inputDeficit::Integer, rate::Real, Nϕ::Integer, xlen::Integer, pilot::Integer, cap::Integer)
+    ax, aa = zeros(Int64, cap), zeros(Float64, cap)
+    nout, dend = Ref{Int64}(0), Ref{Int64}(0)
+    aend = Ref{Cdouble}(0)
+    used, passes = Ref{Cint}(0), Ref{Cint}(0)
+    GC.@preserve ax aa check(ccall((:mdsp_arb_trajectory_scan, lib), Cint,
+        (Cdouble, Int64, Cdouble, Int64, Int64, Int64, Ptr{Int64}, Ptr{Cdouble}, Int64, Ref{Int64}, Ref{Cdouble}, Ref{Int64}, Ref{Cint}, Ref{Cint}),
+        ϕAcc, inputDeficit, rate, Nϕ, xlen, pilot, pointer(ax), pointer(aa), cap, nout, aend, dend, used, passes))
+    (used = used[] != 0, passes = Int(passes[]), anchors_x = ax, anchors_acc = aa, nout = Int(nout[]), ϕAcc_end = aend[], deficit_end = Int(dend[]))
+end
+# updates at which the device replay's branch-free form of update! (stream_filt.jl:567-577) would differ from the reference form: always 0
+function arb_replay_check(ϕAcc::Real, rate::Real, Nϕ::Integer, nsteps::Integer)
+    m = Ref{Int64}(0)
+    check(ccall((:mdsp_arb_replay_check, lib), Cint, (Cdouble, Cdouble, Int64, Int64, Ref{Int64}), ϕAcc, rate, Nϕ, nsteps, m)); Int(m[])
 end
 
 # ---------------------------------------------------------------------------------------------- DF2TFilter (FIR) and filtfilt
