@@ -168,6 +168,239 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
     }
 }
 
+// ---- compile-time schedules for the common nextfastfft sizes (round 3) ------------------------------------------------------------------
+// gen_spectral_kernel above pays for its generality: radices, strides and the butterfly count per pass are run-time values, so every LDS
+// access carries index arithmetic (padding, a multiply-shift division), every butterfly fetches its twiddles from a table, and nothing
+// unrolls -- ~8x the VALU instructions per point of the power-of-two kernels, 0.05 of the HBM roof at nfft = 1000 / 1536 / 3000
+// (profiles/r02g_mixed.json), a 6-7x cliff next to 1024 / 2048 / 4096 for what is the DEFAULT nfft of periodogram / welch_pgram / stft
+// (nfft = nextfastfft(n), periodograms.jl:393, :560, :872).  gen_ct_kernel is the same algorithm with the schedule as template constants:
+//   * passes fully unrolled, M(p) = ceil(N / (R_p T)) butterflies per thread and pass; operand reads are  t*8 + immediate  (one address VGPR),
+//     the scatter index needs one constant division per butterfly;
+//   * a thread runs the SAME butterflies for every frame, so its twiddles are loop invariants: they live in registers for the whole launch
+//     (30-40 complex values), no table reads at all;
+//   * no LDS padding: the FIRST pass has an odd radix (3 or 5), whose scatter stride spreads the 16 lanes of a ds_write_b64 group over all
+//     32 banks by itself, and every read is contiguous by lane.
+template <int N_, int T_, int... RS> struct CtSched {
+    static constexpr int N = N_, T = T_, P = (int)sizeof...(RS);
+    static constexpr int radix(int p) {
+        constexpr int r[] = {RS...};
+        return r[p];
+    }
+    static constexpr int ns(int p) {
+        int v = 1;
+        for (int i = 0; i < p; ++i) v *= radix(i);
+        return v;
+    }
+    static constexpr int nbf(int p) { return N / radix(p); }
+    static constexpr int M(int p) { return (nbf(p) + T - 1) / T; }
+    static constexpr int ntw(int p) { return p == 0 ? 0 : M(p) * (radix(p) - 1); }
+    static constexpr int twoff(int p) {
+        int v = 0;
+        for (int i = 0; i < p; ++i) v += ntw(i);
+        return v;
+    }
+    static constexpr int NTW = twoff(P) > 0 ? twoff(P) : 1;
+    static constexpr int BINS = (N + T - 1) / T;
+    static_assert(ns(P) == N && T % 64 == 0, "the radices multiply to N; whole wavefronts");
+};
+
+template <typename S, int p, typename R> __device__ __forceinline__ void ct_load_twiddles(cx<R> (&tw)[S::NTW], const cx<R>* roots, int t) {
+    if constexpr (p < S::P) {
+        if constexpr (p > 0) {
+            constexpr int Rdx = S::radix(p), Ns = S::ns(p), stride = S::N / (Ns * Rdx);
+#pragma unroll
+            for (int m = 0; m < S::M(p); ++m) {
+                const unsigned j = (unsigned)(t + S::T * m), k = j % (unsigned)Ns;
+#pragma unroll
+                for (int q = 1; q < Rdx; ++q) tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)] = roots[((unsigned)q * k * (unsigned)stride) % (unsigned)S::N];
+            }
+        }
+        ct_load_twiddles<S, p + 1>(tw, roots, t);
+    }
+}
+
+// passes p .. P-1, ping-ponging between the two buffers; returns where the natural-order spectrum ends up
+template <typename S, int p, typename R>
+__device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, const cx<R> (&tw)[S::NTW], int t) {
+    if constexpr (p == S::P) return in;
+    else {
+        constexpr int Rdx = S::radix(p), Ns = S::ns(p), nbf = S::nbf(p), M = S::M(p);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const unsigned j = (unsigned)(t + S::T * m);
+            if ((m + 1) * S::T <= nbf || j < (unsigned)nbf) {   // a compile-time `true` for every trip but a partial last one
+                cx<R> v[Rdx];
+#pragma unroll
+                for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + j + nbf * q);
+                if constexpr (p > 0) {
+#pragma unroll
+                    for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
+                }
+                fft::gen_bfly<Rdx>(v);
+                const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
+                cx<R>* o = out + hi * (unsigned)(Ns * Rdx) + k;
+#pragma unroll
+                for (int q = 0; q < Rdx; ++q) fft::st2(o + Ns * q, v[q]);
+            }
+        }
+        __syncthreads();
+        return ct_passes<S, p + 1>(out, const_cast<cx<R>*>(in), tw, t);
+    }
+}
+
+template <typename R, bool CPLX, int MODE, typename S>   // MODE 0: Welch sums, 1: STFT columns (raw or PSD); one transform per workgroup
+__global__ __launch_bounds__(S::T) void gen_ct_kernel(GenArgs a) {
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    constexpr int N = S::N, T = S::T, BINS = S::BINS;
+    __shared__ __attribute__((aligned(16))) cx<R> buf[2 * N];
+    cx<R>*bufA = buf, *bufB = buf + N;
+    const int t = threadIdx.x;
+    const int64_t ch = blockIdx.y;
+    const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
+    const int64_t gslot = blockIdx.x;
+    const int64_t u0 = gslot * a.per_slot;
+    cx<R> tw[S::NTW];
+    ct_load_twiddles<S, 0>(tw, static_cast<const cx<R>*>(a.roots), t);
+    R w[BINS];   // window of this thread's samples i = t + T u (Float32 signals: rounded to Float32 first, as the other fused kernels do); 0 past n
+#pragma unroll
+    for (int u = 0; u < BINS; ++u) {
+        const int i = t + T * u;
+        w[u] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
+    }
+    double acc[MODE == 0 ? BINS : 1];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < BINS; ++i) acc[i] = 0.0;
+    }
+    for (int64_t it = 0; it < a.per_slot; ++it) {
+        const int64_t u = u0 + it;
+        const bool live = u < a.units_per_ch;
+        const int64_t f0 = CPLX ? u : 2 * u;
+        const bool haveB = !CPLX && live && (f0 + 1) < a.K;
+        const TT* fa = sc + f0 * a.hop;
+        {   // K4 (periodograms.jl:57-69): frame * window, zero tail; all loads of the frame in flight together
+            TT ra[BINS], rb[CPLX ? 1 : BINS];
+#pragma unroll
+            for (int q = 0; q < BINS; ++q) {
+                const int i = t + T * q;
+                const bool on = live && i < a.n;
+                ra[q] = on ? fa[i] : TT{};
+                if constexpr (!CPLX) rb[q] = (on && haveB) ? fa[i + a.hop] : TT{};
+            }
+#pragma unroll
+            for (int q = 0; q < BINS; ++q) {
+                const int i = t + T * q;
+                if (BINS * T == N || i < N) {
+                    cx<R> z;
+                    if constexpr (CPLX) z = {ra[q].x * w[q], ra[q].y * w[q]};
+                    else z = {ra[q] * w[q], rb[q] * w[q]};
+                    fft::st2(bufA + i, z);
+                }
+            }
+        }
+        __syncthreads();
+        const cx<R>* src = ct_passes<S, 0>(bufA, bufB, tw, t);   // ends with a barrier
+        if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
+#pragma unroll
+            for (int i = 0; i < BINS; ++i) {
+                const int k = t + T * i;
+                if ((BINS * T == N || k < N) && live) {
+                    const cx<R> z = fft::ld2(src + k);
+                    acc[i] += (double)(z.x * z.x + z.y * z.y);
+                }
+            }
+        } else if (live) {
+            const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
+            const int64_t o0 = ch * a.chs + f0 * a.ldo;
+            for (int j = t; j < a.nout; j += T) {
+                if constexpr (CPLX) {   // two-sided only (a complex signal has no one-sided form, periodograms.jl:876)
+                    const cx<R> z = fft::ld2(src + j);
+                    if (a.psd) {
+                        R* o = static_cast<R*>(a.out) + o0 + j;
+                        const R pw = z.x * z.x + z.y * z.y;
+                        *o = a.accumulate ? fma(pw, m1, *o) : pw * m1;       // fft2pow!: out = muladd(abs2, m, out)
+                    } else static_cast<cx<R>*>(a.out)[o0 + j] = z;
+                } else {
+                    const bool mirror = j > N / 2;                              // real -> two-sided: X[N-k] = conj(X[k]) (fft2oneortwosided!, :234-244)
+                    const int k = mirror ? N - j : j;
+                    const cx<R> zk = fft::ld2(src + k), zm = fft::ld2(src + (k == 0 ? 0 : N - k));
+                    cx<R> A = {(R)0.5 * (zk.x + zm.x), (R)0.5 * (zk.y - zm.y)};   // (Z[k] + conj Z[N-k]) / 2
+                    cx<R> B = {(R)0.5 * (zk.y + zm.y), (R)0.5 * (zm.x - zk.x)};   // (Z[k] - conj Z[N-k]) / (2i)
+                    if (a.psd) {
+                        R m = m1;
+                        if (a.onesided && !(j == 0 || (j == a.nout - 1 && N % 2 == 0))) m = m2;
+                        R* o = static_cast<R*>(a.out) + o0 + j;
+                        const R pa = A.x * A.x + A.y * A.y;
+                        *o = a.accumulate ? fma(pa, m, *o) : pa * m;
+                        if (haveB) {
+                            const R pb = B.x * B.x + B.y * B.y;
+                            o[a.ldo] = a.accumulate ? fma(pb, m, o[a.ldo]) : pb * m;
+                        }
+                    } else {
+                        if (mirror) {
+                            A.y = -A.y;
+                            B.y = -B.y;
+                        }
+                        cx<R>* o = static_cast<cx<R>*>(a.out) + o0 + j;
+                        *o = A;
+                        if (haveB) o[a.ldo] = B;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the spectrum buffer may be the one the next frame is windowed into
+    }
+    if constexpr (MODE == 0) {
+        double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)N;
+#pragma unroll
+        for (int i = 0; i < BINS; ++i) {
+            const int k = t + T * i;
+            if (BINS * T == N || k < N) part[k] = acc[i];
+        }
+    }
+}
+
+template <typename R, bool CPLX, int MODE, typename S>
+int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial) {
+    auto kern = gen_ct_kernel<R, CPLX, MODE, S>;
+    hipFuncAttributes fa{};
+    MDSP_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
+    const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8), waves = S::T / 64;
+    const size_t lds_bytes = sizeof(cx<R>) * 2 * (size_t)S::N;
+    int per_cu = std::min<int>({32 / waves, (512 / regs) * 4 / waves, (int)((size_t)160 * 1024 / lds_bytes)});
+    if (per_cu < 1) per_cu = 1;
+    if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
+    const int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * per_cu / std::max<int64_t>(1, nch));
+    const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(a.units_per_ch, resident));
+    *nslots = wgs;
+    a.per_slot = cdiv(a.units_per_ch, wgs);
+    if (MODE == 0) {
+        MDSP_TRY(partial->reserve(sizeof(double) * (size_t)wgs * (size_t)nch * (size_t)S::N));
+        a.out = partial->p;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, (unsigned)nch), dim3(S::T), 0, st, a);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+// the sizes with a compile-time schedule (Float32 / ComplexF32): odd radix first, the widest radix last.  -DMDSP_GEN_CT=0 keeps the run-time kernel.
+#ifndef MDSP_GEN_CT
+#define MDSP_GEN_CT 1
+#endif
+template <typename R, bool CPLX, int MODE>
+bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial, int* rc) {
+    if constexpr (sizeof(R) == 4 && MDSP_GEN_CT) {
+        switch (a.N) {
+            case 1000: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<1000, 128, 5, 5, 5, 8>>(a, nch, st, nslots, partial); return true;
+            case 1536: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<1536, 192, 3, 8, 8, 8>>(a, nch, st, nslots, partial); return true;
+            case 2000: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<2000, 256, 5, 5, 5, 16>>(a, nch, st, nslots, partial); return true;
+            case 3000: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<3000, 384, 3, 5, 5, 5, 8>>(a, nch, st, nslots, partial); return true;
+            case 6000: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<6000, 512, 3, 5, 5, 5, 16>>(a, nch, st, nslots, partial); return true;
+            default: break;
+        }
+    }
+    return false;
+}
+
 // geometry + schedule shared by the two launchers; returns the slot count through *nslots
 template <typename R, bool CPLX, int MODE, int EMAX>
 int gen_launch_e(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial) {
@@ -212,6 +445,8 @@ int gen_launch_e(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBu
 }
 template <typename R, bool CPLX, int MODE>
 int gen_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial) {
+    int rc = MDSP_OK;
+    if (gen_ct_dispatch<R, CPLX, MODE>(a, nch, st, nslots, partial, &rc)) return rc;
     if (MODE == 0 && a.N > 4096) return gen_launch_e<R, CPLX, MODE, 32>(a, nch, st, nslots, partial);
     return gen_launch_e<R, CPLX, MODE, 16>(a, nch, st, nslots, partial);
 }

@@ -388,7 +388,7 @@ def test_long_filters_are_reblocked_by_the_fused_engine(d, torch, dt, nb, expect
 
 
 @pytest.mark.parametrize("dt,tol", [(np.float32, TOL32), (np.float64, 1e-12), (np.complex64, TOL32), (np.complex128, 1e-12)])
-@pytest.mark.parametrize("nfft", [1000, 1536, 3000, 625, 120, 2401, 18, 7, 6000])
+@pytest.mark.parametrize("nfft", [1000, 1536, 2000, 3000, 625, 120, 2401, 18, 7, 6000])
 def test_mixed_radix_sizes_run_fused(d, torch, dt, tol, nfft):
     """VERDICT r1 'missing 3': nextfastfft sizes (2^a 3^b 5^c 7^d; util.jl:107-135) are the DEFAULT nfft of periodogram / welch_pgram / stft
     (periodograms.jl:393, :560, :872).  They run on the fused engine (mixed-radix passes through LDS) -- Welch, raw STFT one- and two-sided,
