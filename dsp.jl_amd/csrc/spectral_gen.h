@@ -386,15 +386,29 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
 #ifndef MDSP_GEN_CT
 #define MDSP_GEN_CT 1
 #endif
+// N -> schedule (odd radix first where N has one, the widest radix last; T ~ N / 8 threads so that a thread runs 1-4 butterflies per pass)
+#define MDSP_GEN_CT_SIZES(X)                                                                                              \
+    X(1000, 128, 5, 5, 5, 8) X(1200, 192, 3, 5, 5, 16) X(1500, 192, 3, 5, 5, 5, 4) X(1536, 192, 3, 8, 8, 8)               \
+    X(2000, 256, 5, 5, 5, 16) X(2400, 256, 3, 5, 5, 4, 8) X(2500, 256, 5, 5, 5, 5, 4) X(3000, 384, 3, 5, 5, 5, 8)         \
+    X(4000, 512, 5, 5, 5, 4, 8) X(4800, 512, 3, 5, 5, 8, 8) X(5000, 512, 5, 5, 5, 5, 8) X(6000, 512, 3, 5, 5, 5, 16)      \
+    X(8000, 512, 5, 5, 5, 8, 8)
+inline bool gen_ct_size(int dtype, int64_t nfft) {
+    if (dtype_is_double(dtype) || !MDSP_GEN_CT) return false;
+    switch (nfft) {
+#define MDSP_X(N, ...) case N:
+        MDSP_GEN_CT_SIZES(MDSP_X)
+#undef MDSP_X
+        return true;
+        default: return false;
+    }
+}
 template <typename R, bool CPLX, int MODE>
 bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial, int* rc) {
     if constexpr (sizeof(R) == 4 && MDSP_GEN_CT) {
         switch (a.N) {
-            case 1000: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<1000, 128, 5, 5, 5, 8>>(a, nch, st, nslots, partial); return true;
-            case 1536: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<1536, 192, 3, 8, 8, 8>>(a, nch, st, nslots, partial); return true;
-            case 2000: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<2000, 256, 5, 5, 5, 16>>(a, nch, st, nslots, partial); return true;
-            case 3000: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<3000, 384, 3, 5, 5, 5, 8>>(a, nch, st, nslots, partial); return true;
-            case 6000: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<6000, 512, 3, 5, 5, 5, 16>>(a, nch, st, nslots, partial); return true;
+#define MDSP_X(N, T, ...) case N: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, __VA_ARGS__>>(a, nch, st, nslots, partial); return true;
+            MDSP_GEN_CT_SIZES(MDSP_X)
+#undef MDSP_X
             default: break;
         }
     }

@@ -823,3 +823,32 @@ def test_overlap_save_lds_dma_staging_is_bit_identical(d, torch, variant):
                 assert torch.equal(ys, ref[0, g0 * L:hi])
     finally:
         _lib.set_tunable("MDSP_OLS_VARIANT", None)
+
+
+@pytest.mark.parametrize("nfft", [1000, 1200, 1500, 1536, 2000, 2400, 2500, 3000, 4000, 4800, 5000, 6000, 8000])
+def test_compile_time_mixed_radix_schedules(d, torch, nfft):
+    """Every size with a compile-time schedule (spectral_gen.h MDSP_GEN_CT_SIZES): Welch, raw STFT and spectrogram of Float32 and ComplexF32
+    signals against the Float64 oracle -- full-length and short windows, even and odd frame counts, two channels -- and AUTO takes the fused
+    engine for them (they beat the rocFFT pipeline in every mode, profiles/r03d_mixed_ct.json)."""
+    from oracle import periodograms as opg, windows as ow
+    rng = np.random.default_rng(nfft)
+    for dt in (np.float32, np.complex64):
+        cplx = dt == np.complex64
+        for n in (nfft, nfft - 7):
+            nov = n // 2
+            hop = n - nov
+            L = hop * 20 + n + (hop if n == nfft else 0)                  # 21 / 22 frames
+            x = rng.standard_normal((L, 2)).astype(np.float32)
+            if cplx:
+                x = (x + 1j * rng.standard_normal(x.shape)).astype(dt)
+            xd = torch.from_numpy(x).cuda()
+            cfg = d.WelchConfig(L, dt, n=n, noverlap=nov, nfft=nfft, window=d.hanning)
+            assert cfg.engine == d.ENGINE_FUSED
+            P = d.welch_pgram(xd, cfg).power.cpu().numpy()
+            for c in range(2):
+                assert relerr(P[:, c], opg.welch_pgram(x[:, c], n, nov, nfft=nfft, window=ow.hanning, dtype=np.float64).power) < TOL32, ("welch", dt, n, c)
+            for onesided in ((True, False) if not cplx else (False,)):
+                S = d.stft(xd, n, nov, nfft=nfft, onesided=onesided, window=d.hanning).cpu().numpy()
+                assert relerr(S[:, :, 1], opg.stft(x[:, 1], n, nov, nfft=nfft, onesided=onesided, window=ow.hanning, dtype=np.float64)) < TOL32, ("stft", dt, n, onesided)
+            sp = d.spectrogram(xd[:, 0].contiguous(), n, nov, nfft=nfft, fs=2.0, window=d.hamming).power.cpu().numpy()
+            assert relerr(sp, opg.stft(x[:, 0], n, nov, psdonly=True, nfft=nfft, fs=2.0, window=ow.hamming, dtype=np.float64)) < TOL32, ("spectrogram", dt, n)

@@ -41,7 +41,7 @@ def timeit(fn, reps=5):
 res = {}
 xr = torch.randn(n, generator=g, device="cuda", dtype=torch.float32)
 xc = torch.complex(xr[: n // 2].clone(), torch.randn(n // 2, generator=g, device="cuda", dtype=torch.float32))
-for nfft in (1000, 1024, 1536, 2000, 2048, 3000, 4096, 6000, 8000):
+for nfft in [int(v) for v in os.environ.get("MIXED_SIZES", "1000,1024,1536,2000,2048,3000,4096,6000,8000").split(",")]:
     row = {}
     for eng, ename in ((d.ENGINE_FUSED, "fused"), (d.ENGINE_ROCFFT, "rocfft")):
         # Welch, 50 % overlap, real Float32: 4 B / sample
