@@ -80,12 +80,19 @@ def probe(name, fn):
 
 
 res = {"samples": n, "seconds_per_case": secs, "idle": dict(zip(("power_W", "sclk_MHz", "cap_W"), smi()))}
-for v in wvars:
-    res[f"welch_v{v}_random"] = probe(f"welch v{v} random", lambda v=v: _lib.check(lib.mdsp_welch_exec(cfgs[v]._h, x.data_ptr(), n, 1, n, psd.data_ptr(), 2049, st)))
-res["welch_v0_zeros"] = probe("welch v0 zeros", lambda: _lib.check(lib.mdsp_welch_exec(cfgs[wvars[0]]._h, xz.data_ptr(), n, 1, n, psd.data_ptr(), 2049, st)))
-res["ols_random"] = probe("ols random", lambda: _lib.check(lib.mdsp_ols_exec(plan._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, st)))
-res["ols_zeros"] = probe("ols zeros", lambda: _lib.check(lib.mdsp_ols_exec(plan._h, xz.data_ptr(), n, 1, n, y.data_ptr(), n, n, st)))
-res["copy_float4"] = probe("copy", lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, st)))
-res["copy_nt_4wg"] = probe("copy nt 4wg", lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), n * 4, 2, 4, st)))
+cases = os.environ.get("CASES", "welch,welch_zeros,ols,ols_zeros,copy").split(",")
+if "welch" in cases:
+    for v in wvars:
+        res[f"welch_v{v}_random"] = probe(f"welch v{v} random", lambda v=v: _lib.check(lib.mdsp_welch_exec(cfgs[v]._h, x.data_ptr(), n, 1, n, psd.data_ptr(), 2049, st)))
+if "welch_zeros" in cases:
+    res["welch_v0_zeros"] = probe("welch v0 zeros", lambda: _lib.check(lib.mdsp_welch_exec(cfgs[wvars[0]]._h, xz.data_ptr(), n, 1, n, psd.data_ptr(), 2049, st)))
+if "ols" in cases:
+    res["ols_random"] = probe("ols random", lambda: _lib.check(lib.mdsp_ols_exec(plan._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, st)))
+if "ols_zeros" in cases:
+    res["ols_zeros"] = probe("ols zeros", lambda: _lib.check(lib.mdsp_ols_exec(plan._h, xz.data_ptr(), n, 1, n, y.data_ptr(), n, n, st)))
+if "copy" in cases:
+    res["copy_float4"] = probe("copy", lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), n * 4, st)))
+    res["copy_nt_4wg"] = probe("copy nt 4wg", lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), n * 4, 2, 4, st)))
+res["ablate"] = os.environ.get("MDSP_ABLATE", "")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "power_probe.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "power_probe.json")), "w"), indent=1)
