@@ -1504,8 +1504,13 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else done = false;
             }
             if (!done) {
-                if constexpr (N == 4096 && sizeof(R) == 4)   // identity lanes, pad 5; the conflict-free lane-permuted schedule is variant 20
-                    rc = welch_run_half<R, N, EH, GH, 1, 5, 2, NBH, false>(pl, a, st, &nslices);
+                if constexpr (N == 4096 && sizeof(R) == 4) {
+                    // Round 3 default: welch_half3_kernel (paired samples, branch-free, window in the first stage: 17 % fewer vector instructions).
+                    // The kernel runs AT the 1400 W package power cap (profiles/r03e_power_probe.json), so what the diet buys is energy: 1.4-2.3 %
+                    // less time in sustained runs, nothing measurable in short bursts (profiles/r03a_tune_new.json).  MDSP_WELCH_VARIANT=18 is the
+                    // round-2 kernel (identity lanes, pad 5); several runs per slot (MDSP_RUNS_PER_SLOT) work in both.
+                    rc = welch_run_half3<N, 5, 1>(pl, a, st, &nslices);
+                }
                 else
                     rc = welch_run_half<R, N, EH, GH, Gm::TWREG, pad_default<R>(), 2, NBH>(pl, a, st, &nslices);
             }

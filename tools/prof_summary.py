@@ -80,7 +80,7 @@ def dominant(rowd, pat=""):
     return max(c)[1] if c else None
 
 
-ROW_KERNELS = (("ols_fused", "step", "ols_fused_kernel"), ("welch_fused", "step", "welch_half_kernel"), ("copy", "yardsticks", "mdsp_copy_kernel"),
+ROW_KERNELS = (("ols_fused", "step", "ols_fused_kernel"), ("welch_fused", "step", "welch_half"), ("copy", "yardsticks", "mdsp_copy_kernel"),
                ("stft", "stft", "stft_"), ("spectrogram", "spectrogram", "stft_"), ("resample", "resample", "polyphase_"), ("firarb", "firarb", "arbitrary_fir_kernel"),
                ("resample_f64", "resample_f64", "polyphase_"), ("resample_c32", "resample_c32", "polyphase_"), ("interp2_f32", "interp2_f32", "polyphase_"),
                ("decim2_f32", "decim2_f32", "polyphase_"))
