@@ -392,8 +392,9 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     X(2000, 256, 5, 5, 5, 16) X(2400, 256, 3, 5, 5, 4, 8) X(2500, 256, 5, 5, 5, 5, 4) X(3000, 384, 3, 5, 5, 5, 8)         \
     X(4000, 512, 5, 5, 5, 4, 8) X(4800, 512, 3, 5, 5, 8, 8) X(5000, 512, 5, 5, 5, 5, 8) X(6000, 512, 3, 5, 5, 5, 16)      \
     X(8000, 512, 5, 5, 5, 8, 8)
+constexpr int GEN_CT_F64_MAX = 3000;   // Float64 / ComplexF64: two buffers of N x 16 bytes and twice the registers
 inline bool gen_ct_size(int dtype, int64_t nfft) {
-    if (dtype_is_double(dtype) || !MDSP_GEN_CT) return false;
+    if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > GEN_CT_F64_MAX)) return false;
     switch (nfft) {
 #define MDSP_X(N, ...) case N:
         MDSP_GEN_CT_SIZES(MDSP_X)
@@ -404,9 +405,15 @@ inline bool gen_ct_size(int dtype, int64_t nfft) {
 }
 template <typename R, bool CPLX, int MODE>
 bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial, int* rc) {
-    if constexpr (sizeof(R) == 4 && MDSP_GEN_CT) {
+    if constexpr (MDSP_GEN_CT) {
         switch (a.N) {
-#define MDSP_X(N, T, ...) case N: *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, __VA_ARGS__>>(a, nch, st, nslots, partial); return true;
+#define MDSP_X(N, T, ...)                                                                                          \
+    case N:                                                                                                        \
+        if constexpr (sizeof(R) == 4 || N <= GEN_CT_F64_MAX) {                                                     \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, __VA_ARGS__>>(a, nch, st, nslots, partial);           \
+            return true;                                                                                           \
+        }                                                                                                          \
+        break;
             MDSP_GEN_CT_SIZES(MDSP_X)
 #undef MDSP_X
             default: break;
