@@ -2050,7 +2050,10 @@ int mdsp_stft_exec_host(mdsp_stft_plan plan, const void* s_host, int64_t len, in
     const bool pinned = (flags & MDSP_HOST_PINNED) != 0;
     const size_t esz = dtype_size(plan->dtype);
     const size_t osz = plan->psd_only ? dtype_size(dtype_real_of(plan->dtype)) : dtype_size(dtype_complex_of(plan->dtype));
-    const int64_t fpc = std::max<int64_t>(1, ((int64_t)tunables().host_chunk_mib << 20) / (int64_t)(nout * (int64_t)osz));   // frames per chunk
+    // frames per chunk: EVEN -- real signals ride two consecutive frames (2j, 2j+1) per transform, and a chunk that started at an odd frame would
+    // pair them differently from the device-resident call (same values up to rounding, not bit for bit)
+    int64_t fpc = std::max<int64_t>(2, ((int64_t)tunables().host_chunk_mib << 20) / (int64_t)(nout * (int64_t)osz));
+    fpc &= ~int64_t(1);
     const size_t in_cap = (size_t)((fpc - 1) * hop + n) * esz, out_cap = (size_t)fpc * (size_t)nout * osz;
     hostpipe::Session ss(in_cap, out_cap, pinned);
     int rc = ss.status();
