@@ -86,6 +86,7 @@ const Tunables& tunables() {
     });
     return g_tun;
 }
+// Tuning tools only.  Readers (exec / plan paths) take no lock: a reload must not race with other threads' library calls (mi355dsp.h says so).
 void reload_tunables() {
     (void)tunables();
     std::lock_guard<std::mutex> lk(g_tun_mu);

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
 //      Y[q][j] = sum_k  X[q][k] * H[k][j],    X[q][k] = z[q M + c_{s0} + k],    H[k][j] = pfb[phase_j][k - delta_j]  (0 outside the bank)
 // is a (16 x K)(K x 16) product with K = tp + delta_15 -- what the f32 matrix instruction computes, four k per issue: 1024 multiply-adds
 // per operand read from LDS, at the vector unit's peak FMA rate, and with the VALU left free.  Its arithmetic is bit for bit a k-ordered
-// fmaf chain (one rounding per product, no wider accumulator; /opt/skills/guides/cdna_hip_programming.md section 3), i.e. exactly the oldest-sample-first chain of the
+// fmaf chain (one rounding per product, no wider accumulator: verified bit for bit against the register-tap kernel, tests/test_gpu_boundary.py), i.e. exactly the oldest-sample-first chain of the
 // register-tap kernel: the zero taps add exact zeros and the two kernels agree bit for bit (tests/test_gpu_boundary.py).
 // This is not a GEMM reshaping of the problem: no operand is materialised or reordered in memory, X is the staged signal tile
 // itself (lane l reads z[(q0 + l%16) M + c + 4 t + l/16], one ds_read_b32 per MFMA), H lives in T VGPRs per wave for the whole

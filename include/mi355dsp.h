@@ -62,7 +62,8 @@ int mdsp_init(int device);
 int mdsp_shutdown(void);
 /* Optional tuning variables (MDSP_ENGINE, MDSP_*_VARIANT, MDSP_WG_PER_CU, ... -- DESIGN.md section 5) are read from the environment once,
  * by mdsp_init() or on first use; exec and plan paths never call getenv.  mdsp_reload_tunables() re-reads them (tuning sweeps inside one
- * process).  mdsp_debug_knobs() is 1 only for a library built with -DMDSP_DEBUG_KNOBS, the only builds in which the profiling switches
+ * process) and is NOT thread-safe against concurrent library calls: exec and plan paths read the table without a lock, so call it only while
+ * no other thread is inside the library (tuning tools are single-threaded).  mdsp_debug_knobs() is 1 only for a library built with -DMDSP_DEBUG_KNOBS, the only builds in which the profiling switches
  * (MDSP_ABLATE, MDSP_WELCH_NOHALF, MDSP_STFT_NOSHIFT / _NOPAIR / _NODIRECT, MDSP_FIR_GENERIC, ...) exist at all. */
 int mdsp_reload_tunables(void);
 int mdsp_debug_knobs(void);
