@@ -27,4 +27,7 @@ python tools/prof_summary.py "$(find "$OUT/prof_stats" -name '*.db' | head -1)" 
 python tools/prof_summary.py --pmc "$(find "$OUT/prof_sq" -name '*.db' | head -1)" > "$OUT/pmc_sq.json" 2>/dev/null
 python tools/prof_summary.py --traffic "$(find "$OUT/prof_FETCH_SIZE" -name '*.db' | head -1)" "$(find "$OUT/prof_WRITE_SIZE" -name '*.db' | head -1)" "$OUT/pmc_traffic.json" > /dev/null 2>&1
 python tools/pmc_brief.py "$OUT/pmc_sq.json" > "$OUT/pmc_brief.txt" 2>/dev/null
+python tools/prof_summary.py --rows "$(find "$OUT/prof_sq" -name '*.db' | head -1)" > "$OUT/pmc_sq_rows.json" 2>/dev/null
 head -30 "$OUT/kernel_stats.txt"; cat "$OUT/pmc_brief.txt"
+# the rocpd databases stay on the box (gpurun copies back at most 64 MiB): the summaries above are what profiles/ keeps
+rm -rf "$OUT"/prof_stats "$OUT"/prof_FETCH_SIZE "$OUT"/prof_WRITE_SIZE "$OUT"/prof_sq

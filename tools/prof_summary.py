@@ -92,9 +92,14 @@ def traffic_rows(fetch_db, write_db):
     f, w = rows(fetch_db), rows(write_db)
     out = {}
     for name, row, pat in ROW_KERNELS:
-        fr, wr = f.get(row) or f.get("unmarked") or {}, w.get(row) or w.get("unmarked") or {}
-        k = dominant(fr, pat)
-        if k is None or k not in wr:
+        k = None
+        for cand in (row, "step", "unmarked"):      # --config stft / resample runs carry their kernel in the "step" row; old databases have no markers
+            fr, wr = f.get(cand) or {}, w.get(cand) or {}
+            k = dominant(fr, pat)
+            if k is not None and k in wr:
+                break
+            k = None
+        if k is None:
             continue
         fv, wv = fr[k]["counters"].get("FETCH_SIZE"), wr[k]["counters"].get("WRITE_SIZE")
         if fv is None or wv is None:
