@@ -219,10 +219,10 @@ template <typename S, int p, typename R> __device__ __forceinline__ void ct_load
     }
 }
 
-// passes p .. P-1, ping-ponging between the two buffers; returns where the natural-order spectrum ends up
-template <typename S, int p, typename R>
+// passes p .. END-1, ping-ponging between the two buffers (a barrier behind each); returns the buffer the last of them wrote
+template <typename S, int p, int END = S::P, typename R>
 __device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, const cx<R> (&tw)[S::NTW], int t) {
-    if constexpr (p == S::P) return in;
+    if constexpr (p >= END) return in;
     else {
         constexpr int Rdx = S::radix(p), Ns = S::ns(p), nbf = S::nbf(p), M = S::M(p);
 #pragma unroll
@@ -244,14 +244,76 @@ __device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, c
             }
         }
         __syncthreads();
-        return ct_passes<S, p + 1>(out, const_cast<cx<R>*>(in), tw, t);
+        return ct_passes<S, p + 1, END>(out, const_cast<cx<R>*>(in), tw, t);
+    }
+}
+
+// Pass 0 fed straight from the signal: butterfly j of the first pass reads points j + nbf q, which lanes j = t, t + 1, ... load as contiguous runs --
+// no windowed copy of the frame through LDS.  w0[m R + q] is the window at those points (0 past n: the zero tail), loop-invariant per thread.
+template <typename S, typename R, bool CPLX, typename TT>
+__device__ __forceinline__ void ct_pass0_global(const TT* fa, int64_t hop, bool live, bool haveB, int n, const R (&w0)[S::M(0) * S::radix(0)], cx<R>* out, int t) {
+    constexpr int Rdx = S::radix(0), nbf = S::nbf(0), M = S::M(0);
+    TT ra[M][Rdx], rb[CPLX ? 1 : M][CPLX ? 1 : Rdx];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int j = t + S::T * m;
+#pragma unroll
+        for (int q = 0; q < Rdx; ++q) {
+            const int i = j + nbf * q;
+            const bool on = live && ((m + 1) * S::T <= nbf || j < nbf) && i < n;
+            ra[m][q] = on ? fa[i] : TT{};
+            if constexpr (!CPLX) rb[m][q] = (on && haveB) ? fa[i + hop] : TT{};
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int j = t + S::T * m;
+        if ((m + 1) * S::T <= nbf || j < nbf) {
+            cx<R> v[Rdx];
+#pragma unroll
+            for (int q = 0; q < Rdx; ++q) {
+                const R w = w0[m * Rdx + q];
+                if constexpr (CPLX) v[q] = {ra[m][q].x * w, ra[m][q].y * w};
+                else v[q] = {ra[m][q] * w, rb[m][q] * w};
+            }
+            fft::gen_bfly<Rdx>(v);
+            cx<R>* o = out + (unsigned)j * (unsigned)Rdx;   // Ns = 1: hi = j, k = 0
+#pragma unroll
+            for (int q = 0; q < Rdx; ++q) fft::st2(o + q, v[q]);
+        }
+    }
+}
+
+// The last pass with its results left in registers: butterfly j produces the bins j + (N / R) q in natural order -- lanes j = t, t + 1, ... own
+// contiguous bins, so |Z|^2 sums and complex columns are consumed (and stored, coalesced) without another trip through LDS.
+template <typename S, typename R, typename F>
+__device__ __forceinline__ void ct_last_pass_regs(const cx<R>* in, const cx<R> (&tw)[S::NTW], int t, F&& consume) {
+    constexpr int p = S::P - 1, Rdx = S::radix(p), nbf = S::nbf(p), M = S::M(p);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int j = t + S::T * m;
+        if ((m + 1) * S::T <= nbf || j < nbf) {
+            cx<R> v[Rdx];
+#pragma unroll
+            for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + j + nbf * q);
+#pragma unroll
+            for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
+            fft::gen_bfly<Rdx>(v);
+#pragma unroll
+            for (int q = 0; q < Rdx; ++q) consume(m, q, j + nbf * q, v[q]);
+        }
     }
 }
 
 template <typename R, bool CPLX, int MODE, typename S>   // MODE 0: Welch sums, 1: STFT columns (raw or PSD); one transform per workgroup
 __global__ __launch_bounds__(S::T) void gen_ct_kernel(GenArgs a) {
     using TT = std::conditional_t<CPLX, cx<R>, R>;
-    constexpr int N = S::N, T = S::T, BINS = S::BINS;
+    constexpr int N = S::N, T = S::T;
+    constexpr int PL = S::P - 1, RL = S::radix(PL), ML = S::M(PL), NBL = S::nbf(PL);   // the last pass
+    constexpr int W0 = S::M(0) * S::radix(0);
+    // Welch sums and complex columns take the last pass's results from registers; real-signal columns need the mirror bin N - k of another
+    // thread (A[k] = (Z[k] + conj Z[N-k]) / 2), so their last pass goes through LDS once more
+    constexpr bool DIRECT = MODE == 0 || CPLX;
     __shared__ __attribute__((aligned(16))) cx<R> buf[2 * N];
     cx<R>*bufA = buf, *bufB = buf + N;
     const int t = threadIdx.x;
@@ -261,66 +323,46 @@ __global__ __launch_bounds__(S::T) void gen_ct_kernel(GenArgs a) {
     const int64_t u0 = gslot * a.per_slot;
     cx<R> tw[S::NTW];
     ct_load_twiddles<S, 0>(tw, static_cast<const cx<R>*>(a.roots), t);
-    R w[BINS];   // window of this thread's samples i = t + T u (Float32 signals: rounded to Float32 first, as the other fused kernels do); 0 past n
+    R w0[W0];   // window at the points of this thread's first-pass butterflies (Float32 signals: rounded to Float32 first, as the other fused kernels do)
 #pragma unroll
-    for (int u = 0; u < BINS; ++u) {
-        const int i = t + T * u;
-        w[u] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
-    }
-    double acc[MODE == 0 ? BINS : 1];
+    for (int m = 0; m < S::M(0); ++m)
+#pragma unroll
+        for (int q = 0; q < S::radix(0); ++q) {
+            const int i = t + T * m + S::nbf(0) * q;
+            w0[m * S::radix(0) + q] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
+        }
+    double acc[MODE == 0 ? ML * RL : 1];
     if constexpr (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < BINS; ++i) acc[i] = 0.0;
+        for (int i = 0; i < ML * RL; ++i) acc[i] = 0.0;
     }
+    const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
     for (int64_t it = 0; it < a.per_slot; ++it) {
         const int64_t u = u0 + it;
         const bool live = u < a.units_per_ch;
         const int64_t f0 = CPLX ? u : 2 * u;
         const bool haveB = !CPLX && live && (f0 + 1) < a.K;
-        const TT* fa = sc + f0 * a.hop;
-        {   // K4 (periodograms.jl:57-69): frame * window, zero tail; all loads of the frame in flight together
-            TT ra[BINS], rb[CPLX ? 1 : BINS];
-#pragma unroll
-            for (int q = 0; q < BINS; ++q) {
-                const int i = t + T * q;
-                const bool on = live && i < a.n;
-                ra[q] = on ? fa[i] : TT{};
-                if constexpr (!CPLX) rb[q] = (on && haveB) ? fa[i + a.hop] : TT{};
-            }
-#pragma unroll
-            for (int q = 0; q < BINS; ++q) {
-                const int i = t + T * q;
-                if (BINS * T == N || i < N) {
-                    cx<R> z;
-                    if constexpr (CPLX) z = {ra[q].x * w[q], ra[q].y * w[q]};
-                    else z = {ra[q] * w[q], rb[q] * w[q]};
-                    fft::st2(bufA + i, z);
-                }
-            }
-        }
+        // K4 (periodograms.jl:57-69) fused into the first pass: frame * window, zero tail, straight from the signal
+        ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, t);
         __syncthreads();
-        const cx<R>* src = ct_passes<S, 0>(bufA, bufB, tw, t);   // ends with a barrier
-        if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
-#pragma unroll
-            for (int i = 0; i < BINS; ++i) {
-                const int k = t + T * i;
-                if ((BINS * T == N || k < N) && live) {
-                    const cx<R> z = fft::ld2(src + k);
-                    acc[i] += (double)(z.x * z.x + z.y * z.y);
-                }
-            }
-        } else if (live) {
-            const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
-            const int64_t o0 = ch * a.chs + f0 * a.ldo;
-            for (int j = t; j < a.nout; j += T) {
-                if constexpr (CPLX) {   // two-sided only (a complex signal has no one-sided form, periodograms.jl:876)
-                    const cx<R> z = fft::ld2(src + j);
+        const int64_t o0 = ch * a.chs + f0 * a.ldo;
+        if constexpr (DIRECT) {
+            const cx<R>* src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t);
+            ct_last_pass_regs<S>(src, tw, t, [&](int m, int q, int k, cx<R> z) {
+                if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
+                    if (live) acc[m * RL + q] += (double)(z.x * z.x + z.y * z.y);
+                } else if (live && k < a.nout) {   // complex signal: two-sided columns (periodograms.jl:876)
                     if (a.psd) {
-                        R* o = static_cast<R*>(a.out) + o0 + j;
+                        R* o = static_cast<R*>(a.out) + o0 + k;
                         const R pw = z.x * z.x + z.y * z.y;
                         *o = a.accumulate ? fma(pw, m1, *o) : pw * m1;       // fft2pow!: out = muladd(abs2, m, out)
-                    } else static_cast<cx<R>*>(a.out)[o0 + j] = z;
-                } else {
+                    } else static_cast<cx<R>*>(a.out)[o0 + k] = z;
+                }
+            });
+        } else {
+            const cx<R>* src = ct_passes<S, 1>(bufA, bufB, tw, t);   // ends with a barrier; natural-order spectrum in LDS
+            if (live) {
+                for (int j = t; j < a.nout; j += T) {
                     const bool mirror = j > N / 2;                              // real -> two-sided: X[N-k] = conj(X[k]) (fft2oneortwosided!, :234-244)
                     const int k = mirror ? N - j : j;
                     const cx<R> zk = fft::ld2(src + k), zm = fft::ld2(src + (k == 0 ? 0 : N - k));
@@ -348,14 +390,17 @@ __global__ __launch_bounds__(S::T) void gen_ct_kernel(GenArgs a) {
                 }
             }
         }
-        __syncthreads();   // the spectrum buffer may be the one the next frame is windowed into
+        __syncthreads();   // the buffer the last pass read may be the one the next frame's first pass writes
     }
     if constexpr (MODE == 0) {
         double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)N;
 #pragma unroll
-        for (int i = 0; i < BINS; ++i) {
-            const int k = t + T * i;
-            if (BINS * T == N || k < N) part[k] = acc[i];
+        for (int m = 0; m < ML; ++m) {
+            const int j = t + T * m;
+            if ((m + 1) * T <= NBL || j < NBL) {
+#pragma unroll
+                for (int q = 0; q < RL; ++q) part[j + NBL * q] = acc[m * RL + q];
+            }
         }
     }
 }
