@@ -180,8 +180,11 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
 //     (30-40 complex values), no table reads at all;
 //   * no LDS padding: the FIRST pass has an odd radix (3 or 5), whose scatter stride spreads the 16 lanes of a ds_write_b64 group over all
 //     32 banks by itself, and every read is contiguous by lane.
-template <int N_, int T_, int... RS> struct CtSched {
+template <int N_, int T_, int LDSIN_, int... RS> struct CtSched {
     static constexpr int N = N_, T = T_, P = (int)sizeof...(RS);
+    static constexpr bool LDSIN = LDSIN_ != 0;
+    static constexpr int MINW_REAL = LDSIN_ > 1 ? LDSIN_ : 1;   // waves per SIMD the column (STFT) kernels are compiled for (register cap): a
+                                                                 // workgroup of 6 waves puts two on some SIMDs, and two such workgroups need four there   // real-signal column modes window the frame pair into LDS first (the register-fed first pass costs them a resident workgroup)
     static constexpr int radix(int p) {
         constexpr int r[] = {RS...};
         return r[p];
@@ -306,7 +309,7 @@ __device__ __forceinline__ void ct_last_pass_regs(const cx<R>* in, const cx<R> (
 }
 
 template <typename R, bool CPLX, int MODE, typename S>   // MODE 0: Welch sums, 1: STFT columns (raw or PSD); one transform per workgroup
-__global__ __launch_bounds__(S::T) void gen_ct_kernel(GenArgs a) {
+__global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL : 1) void gen_ct_kernel(GenArgs a) {
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     constexpr int N = S::N, T = S::T;
     constexpr int PL = S::P - 1, RL = S::radix(PL), ML = S::M(PL), NBL = S::nbf(PL);   // the last pass
@@ -331,6 +334,15 @@ __global__ __launch_bounds__(S::T) void gen_ct_kernel(GenArgs a) {
             const int i = t + T * m + S::nbf(0) * q;
             w0[m * S::radix(0) + q] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
         }
+    constexpr bool LDSIN = !DIRECT && S::LDSIN;
+    R wl[LDSIN ? S::BINS : 1];   // LDS-input form: the window at i = t + T q
+    if constexpr (LDSIN) {
+#pragma unroll
+        for (int q = 0; q < S::BINS; ++q) {
+            const int i = t + T * q;
+            wl[q] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
+        }
+    }
     double acc[MODE == 0 ? ML * RL : 1];
     if constexpr (MODE == 0) {
 #pragma unroll
@@ -343,8 +355,32 @@ __global__ __launch_bounds__(S::T) void gen_ct_kernel(GenArgs a) {
         const int64_t f0 = CPLX ? u : 2 * u;
         const bool haveB = !CPLX && live && (f0 + 1) < a.K;
         // K4 (periodograms.jl:57-69) fused into the first pass: frame * window, zero tail, straight from the signal
-        ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, t);
-        __syncthreads();
+        if constexpr (!LDSIN) ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, t);
+        else {   // ... or windowed into LDS first (bufB), the first pass then runs LDS -> LDS like the others
+            constexpr int BINS = S::BINS;
+            const TT* fa = sc + f0 * a.hop;
+            TT ra[BINS], rb[CPLX ? 1 : BINS];
+#pragma unroll
+            for (int q = 0; q < BINS; ++q) {
+                const int i = t + T * q;
+                const bool on = live && i < a.n;
+                ra[q] = on ? fa[i] : TT{};
+                if constexpr (!CPLX) rb[q] = (on && haveB) ? fa[i + a.hop] : TT{};
+            }
+#pragma unroll
+            for (int q = 0; q < BINS; ++q) {
+                const int i = t + T * q;
+                if (BINS * T == N || i < N) {
+                    cx<R> z;
+                    if constexpr (CPLX) z = {ra[q].x * wl[q], ra[q].y * wl[q]};
+                    else z = {ra[q] * wl[q], rb[q] * wl[q]};
+                    fft::st2(bufB + i, z);
+                }
+            }
+            __syncthreads();
+            (void)ct_passes<S, 0, 1>(bufB, bufA, tw, t);   // pass 0: bufB -> bufA (ends with a barrier)
+        }
+        if constexpr (!LDSIN) __syncthreads();
         const int64_t o0 = ch * a.chs + f0 * a.ldo;
         if constexpr (DIRECT) {
             const cx<R>* src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t);
@@ -432,11 +468,11 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
 #define MDSP_GEN_CT 1
 #endif
 // N -> schedule (odd radix first where N has one, the widest radix last; T ~ N / 8 threads so that a thread runs 1-4 butterflies per pass)
-#define MDSP_GEN_CT_SIZES(X)                                                                                              \
-    X(1000, 128, 5, 5, 5, 8) X(1200, 192, 3, 5, 5, 16) X(1500, 192, 3, 5, 5, 5, 4) X(1536, 192, 3, 8, 8, 8)               \
-    X(2000, 256, 5, 5, 5, 16) X(2400, 256, 3, 5, 5, 4, 8) X(2500, 256, 5, 5, 5, 5, 4) X(3000, 384, 3, 5, 5, 5, 8)         \
-    X(4000, 512, 5, 5, 5, 4, 8) X(4800, 512, 3, 5, 5, 8, 8) X(5000, 512, 5, 5, 5, 5, 8) X(6000, 512, 3, 5, 5, 5, 16)      \
-    X(8000, 512, 5, 5, 5, 8, 8)
+#define MDSP_GEN_CT_SIZES(X)                                                                                                                \
+    X(1000, 128, 0, 5, 5, 5, 8) X(1200, 192, 0, 3, 5, 5, 16) X(1500, 192, 0, 3, 5, 5, 5, 4) X(1536, 192, 0, 3, 8, 8, 8)         \
+    X(2000, 256, 0, 5, 5, 5, 16) X(2400, 256, 0, 3, 5, 5, 4, 8) X(2500, 256, 0, 5, 5, 5, 5, 4) X(3000, 384, 4, 3, 5, 5, 5, 8)     \
+    X(4000, 512, 1, 5, 5, 5, 4, 8) X(4800, 512, 0, 3, 5, 5, 8, 8) X(5000, 512, 0, 5, 5, 5, 5, 8) X(6000, 512, 0, 3, 5, 5, 5, 16) \
+    X(8000, 512, 0, 5, 5, 5, 8, 8)
 constexpr int GEN_CT_F64_MAX = 3000;   // Float64 / ComplexF64: two buffers of N x 16 bytes and twice the registers
 inline bool gen_ct_size(int dtype, int64_t nfft) {
     if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > GEN_CT_F64_MAX)) return false;
