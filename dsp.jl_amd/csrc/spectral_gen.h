@@ -468,11 +468,13 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
 #define MDSP_GEN_CT 1
 #endif
 // N -> schedule (odd radix first where N has one, the widest radix last; T ~ N / 8 threads so that a thread runs 1-4 butterflies per pass)
-#define MDSP_GEN_CT_SIZES(X)                                                                                                                \
-    X(1000, 128, 0, 5, 5, 5, 8) X(1200, 192, 0, 3, 5, 5, 16) X(1500, 192, 0, 3, 5, 5, 5, 4) X(1536, 192, 0, 3, 8, 8, 8)         \
-    X(2000, 256, 0, 5, 5, 5, 16) X(2400, 256, 0, 3, 5, 5, 4, 8) X(2500, 256, 0, 5, 5, 5, 5, 4) X(3000, 384, 4, 3, 5, 5, 5, 8)     \
-    X(4000, 512, 1, 5, 5, 5, 4, 8) X(4800, 512, 0, 3, 5, 5, 8, 8) X(5000, 512, 0, 5, 5, 5, 5, 8) X(6000, 512, 0, 3, 5, 5, 5, 16) \
-    X(8000, 512, 0, 5, 5, 5, 8, 8)
+#define MDSP_GEN_CT_SIZES(X)                                                                                                      \
+    X(1000, 128, 0, 5, 5, 5, 8) X(1200, 192, 0, 3, 5, 5, 16) X(1280, 128, 0, 5, 16, 16) X(1500, 192, 0, 3, 5, 5, 5, 4)                \
+    X(1536, 192, 0, 3, 8, 8, 8) X(1600, 128, 0, 5, 5, 8, 8) X(1920, 128, 0, 3, 5, 8, 16) X(2000, 256, 0, 5, 5, 5, 16)                 \
+    X(2400, 256, 0, 3, 5, 5, 4, 8) X(2500, 256, 0, 5, 5, 5, 5, 4) X(2560, 320, 0, 5, 8, 8, 8) X(3000, 384, 4, 3, 5, 5, 5, 8)          \
+    X(3072, 256, 0, 3, 16, 8, 8) X(3200, 256, 0, 5, 5, 8, 16) X(3840, 256, 0, 3, 5, 16, 16) X(4000, 512, 1, 5, 5, 5, 4, 8)            \
+    X(4800, 512, 0, 3, 5, 5, 8, 8) X(5000, 512, 0, 5, 5, 5, 5, 8) X(5120, 320, 0, 5, 16, 8, 8) X(6000, 512, 0, 3, 5, 5, 5, 16)        \
+    X(6144, 512, 0, 3, 16, 16, 8) X(6400, 448, 0, 5, 5, 16, 16) X(8000, 512, 0, 5, 5, 5, 8, 8)
 constexpr int GEN_CT_F64_MAX = 3000;   // Float64 / ComplexF64: two buffers of N x 16 bytes and twice the registers
 inline bool gen_ct_size(int dtype, int64_t nfft) {
     if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > GEN_CT_F64_MAX)) return false;

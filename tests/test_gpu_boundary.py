@@ -825,7 +825,7 @@ def test_overlap_save_lds_dma_staging_is_bit_identical(d, torch, variant):
         _lib.set_tunable("MDSP_OLS_VARIANT", None)
 
 
-@pytest.mark.parametrize("nfft", [1000, 1200, 1500, 1536, 2000, 2400, 2500, 3000, 4000, 4800, 5000, 6000, 8000])
+@pytest.mark.parametrize("nfft", [1000, 1200, 1280, 1500, 1536, 1600, 1920, 2000, 2400, 2500, 2560, 3000, 3072, 3200, 3840, 4000, 4800, 5000, 5120, 6000, 6144, 6400, 8000])
 def test_compile_time_mixed_radix_schedules(d, torch, nfft):
     """Every size with a compile-time schedule (spectral_gen.h MDSP_GEN_CT_SIZES): Welch, raw STFT and spectrogram of Float32 and ComplexF32
     signals against the Float64 oracle -- full-length and short windows, even and odd frame counts, two channels -- and AUTO takes the fused
