@@ -260,11 +260,7 @@ int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64
     // blocks per chunk: ~host_chunk_mib of input, even, at least 2
     int64_t bpc = std::max<int64_t>(2, ((int64_t)tunables().host_chunk_mib << 20) / (int64_t)(L * (int64_t)esz));
     bpc &= ~int64_t(1);
-    // Partitioned plans (long filters) have no block-range entry: a chunk is filtered as a signal of its own that starts nb-1 samples early
-    // (zero initial state), and the nb-1 warm-up outputs are dropped -- equal to the device-resident call up to rounding, not bit for bit.
-    const bool halo = plan->partitions > 1;
-    if (halo) bpc = std::max<int64_t>(bpc, 4 * cdiv(nb, L));   // keep the re-filtered halo below a quarter of a chunk
-    const size_t in_cap = (size_t)(bpc * L + nb - 1) * esz, out_cap = (size_t)(bpc * L + (halo ? nb - 1 : 0)) * esz;
+    const size_t in_cap = (size_t)(bpc * L + nb - 1) * esz, out_cap = (size_t)(bpc * L) * esz;
 
     hostpipe::Session ss(in_cap, out_cap, pinned);
     int rc = ss.status();
@@ -279,10 +275,9 @@ int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64
             const int64_t o0 = g0 * L, o1 = std::min(nout, g1 * L);
             const size_t inb = hi > lo ? (size_t)(hi - lo) * esz : 0, outb = (size_t)(o1 - o0) * esz;
             if ((rc = ss.upload(ln, xc + (size_t)lo * esz, inb, inb, 1)) != MDSP_OK) break;
-            if (halo) rc = mdsp_ols_exec(plan, ln->din.p, hi > lo ? hi - lo : 0, 1, hi > lo ? hi - lo : 0, ln->dout.p, o1 - lo, o1 - lo, ss.kstream());
-            else rc = mdsp_ols_exec_range(plan, ln->din.p, lo, hi > lo ? hi - lo : 0, nx, ln->dout.p, g0, g1 - g0, nout, ss.kstream());
+            rc = mdsp_ols_exec_range(plan, ln->din.p, lo, hi > lo ? hi - lo : 0, nx, ln->dout.p, g0, g1 - g0, nout, ss.kstream());
             if (rc != MDSP_OK) break;
-            rc = ss.download(ln, yc + (size_t)o0 * esz, outb, outb, 1, halo ? (size_t)(o0 - lo) * esz : 0, outb);
+            rc = ss.download(ln, yc + (size_t)o0 * esz, outb, outb, 1, 0, outb);
         }
     }
     return ss.finish(rc);

@@ -385,21 +385,47 @@ struct UpolsArgs {
     const void* table;   // N forward roots
     const void* Hp;      // P spectra of N bins, 1/N folded in
     int64_t nx, nout, ldx, ldy;
-    int64_t nblocks;     // per column: ceil(nout / B)
-    int64_t run_len;     // blocks per run; slot s of S owns blocks [s*R*run_len, (s+1)*R*run_len), R = 2 runs (real) or 1 (complex)
+    int64_t nblocks;     // per column: blocks at / past it do not exist for this launch (ceil(nout / B), or the end of a block range)
+    int64_t g_begin;     // first block of the launch (0, or the start of a block range)
+    int64_t x_lo;        // samples below it are not dereferenced and read as zero (0; block ranges: where the caller's slice starts -- always at
+                         // least P*B - (nb - 1) taps of zeros in front of the samples that matter, see mdsp_ols_exec_range)
+    int64_t run_len;     // blocks per run; slot s of S owns blocks [g_begin + s*R*run_len, g_begin + (s+1)*R*run_len), R = 2 runs (real) or 1 (complex)
+    int ablate;          // MDSP_DEBUG_KNOBS builds: 1 no input, 2 no transforms, 4 no stores, 8 no spectra loads (results are garbage)
 };
 
-template <typename R, int N, int E, int P, int TWMODE, int PADSHIFT, bool CPLX, int MINW>
+// XDMA (Float32 real signals): the half windows live in a two-slot LDS ring per run.  A block's window is [previous half | new half]; the new
+// half of the NEXT block is moved by `buffer_load_dword ... lds` while this block is transformed (no VGPRs, no exposed HBM latency, every
+// sample fetched once instead of twice).  The ring is wave-private: wave w moves exactly the 64-float granules its own lanes read, so the only
+// ordering needed is the wave's own s_waitcnt.
+// NLDS: partitions 1 .. NLDS live in LDS for the whole launch (a workgroup multiplies the SAME bins by the same spectra block after block, but
+// P spectra per thread do not fit in registers next to the delay line): half spectra, B + 1 bins each -- the taps are real, so
+// H_p[N - k] = conj H_p[k] -- read in ascending lane order for the lower bins and descending for the mirrored ones (both conflict-free).  What is
+// left streams from L2: profiles/r03g_longfilt_ablate.json has the L2 traffic of the spectra (24 B per sample at P = 3 against 8 B of signal) as
+// the largest single item of the kernel's memory time.
+template <typename R, int N, int E, int P, int TWMODE, int PADSHIFT, bool CPLX, int MINW, bool XDMA = false, int NLDS = 0>
 __global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
     using C = fft::Cfg<N, E>;
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     constexpr int T = C::T, B = N / 2, H = E / 2;
     constexpr int64_t SZ = (int64_t)sizeof(TT);
     static_assert(T % 64 == 0 && P >= 2 && P <= 4, "geometry");
+    static_assert(!XDMA || (!CPLX && sizeof(R) == 4), "the DMA ring moves Float32 samples");
     constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int RUNS = CPLX ? 1 : 2;
     __shared__ __attribute__((aligned(16))) cx<R> lds[fft::wg_lds_elems<C, PADSHIFT, 1>()];
     __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
+    __shared__ __attribute__((aligned(16))) float ring[XDMA ? RUNS * 2 * B : 1];   // [run][slot][B]
+    static_assert(NLDS >= 0 && NLDS <= P - 1, "partitions 1 .. NLDS");
+    constexpr int HLD = B + 2;                                                       // bins 0 .. B of a half spectrum (+1: 16-byte rows)
+    __shared__ __attribute__((aligned(16))) cx<R> hl[NLDS > 0 ? NLDS * HLD : 1];
     const int t = threadIdx.x;
+    if constexpr (NLDS > 0) {
+        for (int i = t; i < NLDS * (B + 1); i += T) {
+            const int q = i / (B + 1), k = i - q * (B + 1);
+            hl[q * HLD + k] = static_cast<const cx<R>*>(a.Hp)[(int64_t)(q + 1) * N + k];
+        }
+        __syncthreads();
+    }
     const cx<R>* table = static_cast<const cx<R>*>(a.table);
     cx<R> tw[NTWA];
     const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, 0, table);
@@ -407,8 +433,7 @@ __global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
     const int64_t col = blockIdx.y;
     const TT* xc = static_cast<const TT*>(a.x) + col * a.ldx;
     TT* yc = static_cast<TT*>(a.y) + col * a.ldy;
-    constexpr int RUNS = CPLX ? 1 : 2;
-    const int64_t first = (int64_t)blockIdx.x * RUNS * a.run_len;   // run A: [first, first + run_len), run B: the run_len blocks after it
+    const int64_t first = a.g_begin + (int64_t)blockIdx.x * RUNS * a.run_len;   // run A: [first, first + run_len), run B: the run_len blocks after it
 
     cx<R> zp[P - 1][E];   // delay line: zp[q] = spectrum of the block q + 1 steps back
 #pragma unroll
@@ -416,20 +441,75 @@ __global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e) zp[q][e] = {(R)0, (R)0};
 
-    // window of block m of this column: x[(m-1)B .. (m+1)B), zero outside [0, nx)
+    // window of block m of this column: x[(m-1)B .. (m+1)B), zero outside [x_lo, nx)
     auto load_block = [&](TT (&dst)[E], int64_t m, bool on) {
         const int64_t start = (m - 1) * B;
-        const bool live = on && m >= 0 && start < a.nx;
+        const bool live = on && start + N > a.x_lo && start < a.nx;
         const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + start, live ? (a.nx - start) * SZ : 0);
-        const int lead = __builtin_amdgcn_readfirstlane((int)(live && start < 0 ? -start : 0));
+        const int lead = __builtin_amdgcn_readfirstlane((int)(live && start < a.x_lo ? a.x_lo - start : 0));
         io::load_window<TT, E, T>(dst, r, lead, t);
     };
+    // ring: half h = x[h B, (h+1) B) of a run into `slot`; element i of the half belongs to thread i % T (wave-private granules)
+    const unsigned ring_base = io::lds_byte_address(ring);
+    const int wave64 = __builtin_amdgcn_readfirstlane(t & ~63);
+    auto fill_half = [&](int run, int slot, int64_t h, bool on) {
+        if constexpr (XDMA) {
+            const int64_t start = h * B;
+            const bool live = on && start + B > a.x_lo && start < a.nx;
+            const bool interior = live && start >= a.x_lo && start + B <= a.nx;      // wave-uniform
+            float* dst = ring + (run * 2 + slot) * B;
+            if (interior) {
+                const io::dma_i4 r = io::dma_rsrc(xc + start, (long long)B * 4);
+                const unsigned base = ring_base + (unsigned)((run * 2 + slot) * B + wave64) * 4u;
+#pragma unroll
+                for (int e = 0; e < H; ++e) io::dma64(r, base + (unsigned)(T * e) * 4u, (t + T * e) * 4);
+            } else {   // edges and switched-off runs: through registers (zero outside the signal)
+                const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + start, live ? (a.nx - start) * SZ : 0);
+                const int lead = __builtin_amdgcn_readfirstlane((int)(live && start < a.x_lo ? a.x_lo - start : 0));
+                float tmp[H];
+#pragma unroll
+                for (int e = 0; e < H; ++e) tmp[e] = io::Ld<float>::load(r, (t + T * e) < lead ? io::OOB : (t + T * e) * 4);
+#pragma unroll
+                for (int e = 0; e < H; ++e) dst[t + T * e] = tmp[e];
+            }
+        }
+    };
+    if constexpr (XDMA) {   // the first window of each run
+        const int64_t m0 = first - (P - 1);
+        const bool runA = first < a.nblocks, runB = (first + a.run_len) < a.nblocks;
+        fill_half(0, 1, m0 - 1, runA);
+        fill_half(0, 0, m0, runA);
+        fill_half(1, 1, m0 + a.run_len - 1, runB);
+        fill_half(1, 0, m0 + a.run_len, runB);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    int par = 0;   // ring slot of the NEW half of the current block
     for (int64_t k = -(P - 1); k < a.run_len; ++k) {   // same trip count for every workgroup (barriers inside)
         const int64_t mA = first + k, mB = first + a.run_len + k;
         // blocks in front of a run's first block only feed the delay line; blocks at / past nblocks produce nothing (and run B may be empty)
         const bool onA = first < a.nblocks && mA < a.nblocks, onB = !CPLX && (first + a.run_len) < a.nblocks && mB < a.nblocks;
         cx<R> v[E];
-        {
+        if (MDSP_ABLATED(a, 1)) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = {(R)(t + e), (R)(k & 3)};
+        } else if constexpr (XDMA) {
+            const float* lo0 = ring + (0 * 2 + (par ^ 1)) * B;
+            const float* hi0 = ring + (0 * 2 + par) * B;
+            const float* lo1 = ring + (1 * 2 + (par ^ 1)) * B;
+            const float* hi1 = ring + (1 * 2 + par) * B;
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                v[e] = {lo0[t + T * e], lo1[t + T * e]};
+                v[e + H] = {hi0[t + T * e], hi1[t + T * e]};
+            }
+            // the halves just read as "previous" are dead: the next block's new halves land there while this block is transformed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (k + 1 < a.run_len) {
+                fill_half(0, par ^ 1, mA + 1, first < a.nblocks && mA + 1 < a.nblocks);
+                fill_half(1, par ^ 1, mB + 1, (first + a.run_len) < a.nblocks && mB + 1 < a.nblocks);
+            }
+            par ^= 1;
+        } else {
             TT ra[E];
             load_block(ra, mA, onA);
             if constexpr (CPLX) {
@@ -442,11 +522,15 @@ __global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
                 for (int e = 0; e < E; ++e) v[e] = {ra[e], rb[e]};
             }
         }
-        fft::wg_fft<C, -1, TWMODE, PADSHIFT, 1, 0>(v, t, tw, twsrc, lds);
+        if (!MDSP_ABLATED(a, 2)) fft::wg_fft<C, -1, TWMODE, PADSHIFT, 1, 0>(v, t, tw, twsrc, lds);
         if (k >= 0) {   // wave-uniform
             cx<R> y[E];
             {
                 cx<R> hh[E];
+                if (MDSP_ABLATED(a, 8)) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) hh[e] = {(R)0.5, (R)(e + 1)};
+                } else
                 io::load_window<cx<R>, E, T>(hh, hrsrc, 0, t);
 #pragma unroll
                 for (int e = 0; e < E; ++e) y[e] = fft::cmul(v[e], hh[e]);
@@ -455,6 +539,19 @@ __global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
             for (int q = 0; q < P - 1; ++q) {
                 cx<R> hh[E];
                 const __amdgpu_buffer_rsrc_t hq = io::make_rsrc(static_cast<const cx<R>*>(a.Hp) + (int64_t)(q + 1) * N, (int64_t)N * (int64_t)sizeof(cx<R>));
+                if (MDSP_ABLATED(a, 8)) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) hh[e] = {(R)0.25, (R)(e + q)};
+                } else if (q < NLDS) {
+                    const cx<R>* up = hl + q * HLD + t;           // bins t + T e, e < E/2
+                    const cx<R>* dn = hl + q * HLD + (B - t);     // bins N - (t + T e) = B - t - T (e - E/2), e >= E/2
+#pragma unroll
+                    for (int e = 0; e < H; ++e) {
+                        hh[e] = up[T * e];
+                        const cx<R> m = dn[-T * e];
+                        hh[e + H] = {m.x, -m.y};
+                    }
+                } else
                 io::load_window<cx<R>, E, T>(hh, hq, 0, t);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
@@ -462,9 +559,12 @@ __global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
                     y[e] = fft::cadd(y[e], pr);
                 }
             }
-            fft::wg_fft<C, +1, TWMODE, PADSHIFT, 1, 0>(y, t, tw, twsrc, lds);
+            if (!MDSP_ABLATED(a, 2)) fft::wg_fft<C, +1, TWMODE, PADSHIFT, 1, 0>(y, t, tw, twsrc, lds);
+            // the next block's halves have landed (issued two transforms ago); BEFORE this block's stores, which the counter would otherwise
+            // make the next iteration wait for as well
+            if constexpr (XDMA) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             // valid outputs: the upper half of the window, i.e. elements e >= E/2 of every thread (t + T*e >= B)
-            {
+            if (!MDSP_ABLATED(a, 4) || y[0].x == (R)12345.678) {
                 const int64_t o = mA * B;
                 const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + o, (onA && o < a.nout) ? (a.nout - o) * SZ : 0);
                 int off = t * (int)SZ;
@@ -476,14 +576,16 @@ __global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
                 }
             }
             if constexpr (!CPLX) {
-                const int64_t o = mB * B;
-                const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + o, (onB && o < a.nout) ? (a.nout - o) * SZ : 0);
-                int off = t * (int)SZ;
-                asm volatile("" : "+v"(off));
+                if (!MDSP_ABLATED(a, 4) || y[1].y == (R)12345.678) {
+                    const int64_t o = mB * B;
+                    const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + o, (onB && o < a.nout) ? (a.nout - o) * SZ : 0);
+                    int off = t * (int)SZ;
+                    asm volatile("" : "+v"(off));
 #pragma unroll
-                for (int e = 0; e < H; ++e) io::Ld<TT>::store(y[e + H].y, w, off + T * e * (int)SZ);
+                    for (int e = 0; e < H; ++e) io::Ld<TT>::store(y[e + H].y, w, off + T * e * (int)SZ);
+                }
             }
-        }
+        } else if constexpr (XDMA) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         // shift the delay line
 #pragma unroll
         for (int q = P - 2; q > 0; --q)
@@ -491,6 +593,174 @@ __global__ __launch_bounds__(N / E, MINW) void upols_fused_kernel(UpolsArgs a) {
             for (int e = 0; e < E; ++e) zp[q][e] = zp[q - 1][e];
 #pragma unroll
         for (int e = 0; e < E; ++e) zp[0][e] = v[e];
+    }
+}
+
+// ---- round 3 form: every memory latency of a block taken off the transform -> multiply -> transform chain -------------------------------
+// profiles/r03g_longfilt_ablate.json: the transforms alone take 0.72 ms of the round-2 kernel's 1.0 ms (2^28 samples, 5120 taps) and every
+// memory operation ADDS its latency on top (input 0.17, the spectra 0.13, stores 0.08), because with 230 VGPRs only two workgroups share a CU.
+//   * input: a block's window is [previous half | new half]; the previous half is carried in registers and the NEXT block's new half is
+//     loaded one whole iteration ahead (E/2 values per run instead of E, every sample fetched once);
+//   * partitions 1 .. P-1 multiply the DELAY LINE, which is known before the block's own transform: that part of the output spectrum is
+//     accumulated first, from half spectra that live in LDS (NLDS of them; the taps are real, H_p[N-k] = conj H_p[k], so B + 1 bins each,
+//     read in ascending lane order for the lower bins and descending for the mirrored ones) or stream from L2;
+//   * partition 0 multiplies the block's own spectrum: H0REG keeps it in registers for the whole launch, otherwise its loads are issued
+//     BEFORE the forward transform.
+template <typename R, int N, int E, int P, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NLDS, bool H0REG>
+__global__ __launch_bounds__(N / E, MINW) void upols2_fused_kernel(UpolsArgs a) {
+    using C = fft::Cfg<N, E>;
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
+    constexpr int T = C::T, B = N / 2, H = E / 2;
+    constexpr int64_t SZ = (int64_t)sizeof(TT);
+    static_assert(T % 64 == 0 && P >= 2 && P <= 4 && NLDS >= 0 && NLDS <= P - 1, "geometry");
+    constexpr int NTWA = C::NTW > 0 ? C::NTW : 1;
+    constexpr int RUNS = CPLX ? 1 : 2;
+    constexpr int HLD = B + 2;                                                       // bins 0 .. B of a half spectrum (+1: 16-byte rows)
+    __shared__ __attribute__((aligned(16))) cx<R> lds[fft::wg_lds_elems<C, PADSHIFT, 1>()];
+    __shared__ __attribute__((aligned(16))) cx<R> twl[(TWMODE == fft::TW_LDS || TWMODE == fft::TW_HYB) ? fft::tw_lds_entries<C, TWMODE>() : 1];
+    __shared__ __attribute__((aligned(16))) cx<R> hl[NLDS > 0 ? NLDS * HLD : 1];
+    const int t = threadIdx.x;
+    const cx<R>* Hg = static_cast<const cx<R>*>(a.Hp);
+    if constexpr (NLDS > 0) {
+        for (int i = t; i < NLDS * (B + 1); i += T) {
+            const int q = i / (B + 1), k = i - q * (B + 1);
+            hl[q * HLD + k] = Hg[(int64_t)(q + 1) * N + k];
+        }
+    }
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    cx<R> tw[NTWA];
+    const cx<R>* twsrc = fft::wg_twiddle_setup<C, TWMODE>(tw, twl, t, 0, table);
+    __syncthreads();
+    const int64_t col = blockIdx.y;
+    const TT* xc = static_cast<const TT*>(a.x) + col * a.ldx;
+    TT* yc = static_cast<TT*>(a.y) + col * a.ldy;
+    const int64_t first = a.g_begin + (int64_t)blockIdx.x * RUNS * a.run_len;   // run A: [first, first + run_len), run B: the run_len blocks after it
+    const bool runA = first < a.nblocks, runB = !CPLX && (first + a.run_len) < a.nblocks;
+
+    cx<R> h0[H0REG ? E : 1];
+    if constexpr (H0REG) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) h0[e] = Hg[t + T * e];
+    }
+    cx<R> zp[P - 1][E];   // delay line: zp[q] = spectrum of the block q + 1 steps back
+#pragma unroll
+    for (int q = 0; q < P - 1; ++q)
+#pragma unroll
+        for (int e = 0; e < E; ++e) zp[q][e] = {(R)0, (R)0};
+
+    // half h of this column: x[h B, (h+1) B), zero outside [x_lo, nx) and for switched-off runs; thread t takes elements t + T e, e < E/2
+    auto load_half = [&](TT (&dst)[H], int64_t h, bool on) {
+        const int64_t start = h * B;
+        const bool live = on && start + B > a.x_lo && start < a.nx;
+        const __amdgpu_buffer_rsrc_t r = io::make_rsrc(xc + start, live ? (a.nx - start) * SZ : 0);
+        const int lead = __builtin_amdgcn_readfirstlane((int)(live && start < a.x_lo ? a.x_lo - start : 0));
+        io::load_window<TT, H, T>(dst, r, lead, t);
+    };
+    TT carryA[H], carryB[CPLX ? 1 : H], nxtA[H], nxtB[CPLX ? 1 : H];
+    {
+        const int64_t m0 = first - (P - 1);                      // the first (warm-up) block of run A; run B: run_len further on
+        load_half(carryA, m0 - 1, runA && !MDSP_ABLATED(a, 1));
+        load_half(nxtA, m0, runA && !MDSP_ABLATED(a, 1));
+        if constexpr (!CPLX) {
+            load_half(carryB, m0 + a.run_len - 1, runB && !MDSP_ABLATED(a, 1));
+            load_half(nxtB, m0 + a.run_len, runB && !MDSP_ABLATED(a, 1));
+        }
+    }
+    for (int64_t k = -(P - 1); k < a.run_len; ++k) {   // same trip count for every workgroup (barriers inside)
+        const int64_t mA = first + k, mB = first + a.run_len + k;
+        // blocks in front of a run's first block only feed the delay line; blocks at / past nblocks produce nothing (and run B may be empty)
+        const bool onA = runA && mA < a.nblocks, onB = runB && mB < a.nblocks;
+        cx<R> v[E];
+#pragma unroll
+        for (int e = 0; e < H; ++e) {
+            if constexpr (CPLX) {
+                v[e] = carryA[e];
+                v[e + H] = nxtA[e];
+            } else {
+                v[e] = {carryA[e], carryB[e]};
+                v[e + H] = {nxtA[e], nxtB[e]};
+            }
+            carryA[e] = nxtA[e];
+            if constexpr (!CPLX) carryB[e] = nxtB[e];
+        }
+        // partition 0's spectrum first (it returns first: loads retire in order), then the next block's new halves: in flight for a whole block
+        cx<R> hh0[H0REG ? 1 : E];
+        if constexpr (!H0REG) {
+            if (k >= 0 && !MDSP_ABLATED(a, 8)) io::load_window<cx<R>, E, T>(hh0, io::make_rsrc(Hg, (int64_t)N * (int64_t)sizeof(cx<R>)), 0, t);
+        }
+        if (k + 1 < a.run_len && !MDSP_ABLATED(a, 1)) {
+            load_half(nxtA, mA + 1, runA && mA + 1 < a.nblocks);
+            if constexpr (!CPLX) load_half(nxtB, mB + 1, runB && mB + 1 < a.nblocks);
+        }
+        cx<R> y[E];
+        if (k >= 0) {   // wave-uniform: what the delay line contributes
+#pragma unroll
+            for (int q = P - 2; q >= 0; --q) {
+                cx<R> hh[E];
+                if (q < NLDS) {
+                    const cx<R>* up = hl + q * HLD + t;           // bins t + T e, e < E/2
+                    const cx<R>* dn = hl + q * HLD + (B - t);     // bins N - (t + T e) = B - t - T (e - E/2), e >= E/2
+#pragma unroll
+                    for (int e = 0; e < H; ++e) {
+                        hh[e] = up[T * e];
+                        const cx<R> m = dn[-T * e];
+                        hh[e + H] = {m.x, -m.y};
+                    }
+                } else if (MDSP_ABLATED(a, 8)) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) hh[e] = {(R)0.25, (R)(e + q)};
+                } else {
+                    io::load_window<cx<R>, E, T>(hh, io::make_rsrc(Hg + (int64_t)(q + 1) * N, (int64_t)N * (int64_t)sizeof(cx<R>)), 0, t);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const cx<R> pr = fft::cmul(zp[q][e], hh[e]);
+                    y[e] = q == P - 2 ? pr : fft::cadd(y[e], pr);
+                }
+            }
+        }
+        if (!MDSP_ABLATED(a, 2)) fft::wg_fft<C, -1, TWMODE, PADSHIFT, 1, 0>(v, t, tw, twsrc, lds);
+        if (k >= 0) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                cx<R> hv;
+                if constexpr (H0REG) hv = h0[e];
+                else hv = MDSP_ABLATED(a, 8) ? cx<R>{(R)0.5, (R)(e + 1)} : hh0[e];
+                y[e] = fft::cadd(y[e], fft::cmul(v[e], hv));
+            }
+        }
+        // shift the delay line (before the inverse transform: v is dead afterwards)
+#pragma unroll
+        for (int q = P - 2; q > 0; --q)
+#pragma unroll
+            for (int e = 0; e < E; ++e) zp[q][e] = zp[q - 1][e];
+#pragma unroll
+        for (int e = 0; e < E; ++e) zp[0][e] = v[e];
+        if (k >= 0) {
+            if (!MDSP_ABLATED(a, 2)) fft::wg_fft<C, +1, TWMODE, PADSHIFT, 1, 0>(y, t, tw, twsrc, lds);
+            // valid outputs: the upper half of the window, i.e. elements e >= E/2 of every thread (t + T*e >= B)
+            if (!MDSP_ABLATED(a, 4) || y[0].x == (R)12345.678) {
+                const int64_t o = mA * B;
+                const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + o, (onA && o < a.nout) ? (a.nout - o) * SZ : 0);
+                int off = t * (int)SZ;
+                asm volatile("" : "+v"(off));
+#pragma unroll
+                for (int e = 0; e < H; ++e) {
+                    if constexpr (CPLX) io::Ld<TT>::store(y[e + H], w, off + T * e * (int)SZ);
+                    else io::Ld<TT>::store(y[e + H].x, w, off + T * e * (int)SZ);
+                }
+            }
+            if constexpr (!CPLX) {
+                if (!MDSP_ABLATED(a, 4) || y[1].y == (R)12345.678) {
+                    const int64_t o = mB * B;
+                    const __amdgpu_buffer_rsrc_t w = io::make_rsrc(yc + o, (onB && o < a.nout) ? (a.nout - o) * SZ : 0);
+                    int off = t * (int)SZ;
+                    asm volatile("" : "+v"(off));
+#pragma unroll
+                    for (int e = 0; e < H; ++e) io::Ld<TT>::store(y[e + H].y, w, off + T * e * (int)SZ);
+                }
+            }
+        }
     }
 }
 
@@ -671,46 +941,92 @@ template <typename R, bool CPLX> int launch_fused(int64_t nfft, const OlsFusedAr
 }
 
 // ---- partitioned launch ------------------------------------------------------------------------------------
-template <typename R, int N, int E, int P, bool CPLX>
-int launch_upols_np(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, hipStream_t s) {
+// blocks [g0, g1) of every column (whole columns: g0 = 0, g1 = ceil(nout / B)); x_lo: first sample that may be dereferenced
+struct UpolsRange {
+    int64_t g0, g1, x_lo;
+};
+template <typename R, int N, int E, int P, bool CPLX, int MINW, bool XDMA, int NLDS = 0, int FORM = 1, bool H0REG = false>
+int launch_upols_k(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, UpolsRange rg, hipStream_t s) {
     constexpr bool DBL = sizeof(R) == 8;
     constexpr int TW = DBL ? 1 : fft::TW_HYB;       // Float32: pass-1 twiddles from LDS (30 VGPRs less next to the delay line)
-    auto kern = upols_fused_kernel<R, N, E, P, TW, 4, CPLX, 2>;
-    constexpr int threads = N / E, B = N / 2, RUNS = CPLX ? 1 : 2;
+    void (*kern)(UpolsArgs) = nullptr;
+    if constexpr (FORM == 2) kern = upols2_fused_kernel<R, N, E, P, TW, 4, CPLX, MINW, NLDS, H0REG>;
+    else kern = upols_fused_kernel<R, N, E, P, TW, 4, CPLX, MINW, XDMA, NLDS>;
+    constexpr int threads = N / E, RUNS = CPLX ? 1 : 2;
     UpolsArgs a;
     a.x = x; a.y = y; a.table = pl->table.p; a.Hp = pl->H.p;
     a.nx = nx; a.nout = nout; a.ldx = ldx; a.ldy = ldy;
-    a.nblocks = cdiv(nout, (int64_t)B);
-    int per_cu = 0;
-    MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
-    if (per_cu < 1) per_cu = 1;
+    a.nblocks = rg.g1;
+    a.g_begin = rg.g0;
+    a.x_lo = rg.x_lo;
+    a.ablate = MDSP_DBG(ablate);
+    const int64_t nblk = rg.g1 - rg.g0;
+    // resident workgroups per CU from the kernel's own resources (hipOccupancyMaxActiveBlocksPerMultiprocessor has answered half of what the
+    // hardware admits for LDS-heavy kernels)
+    hipFuncAttributes fa;
+    MDSP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
+    const int waves = threads / 64, vg = std::max(1, fa.numRegs);
+    const int by_regs = std::max(1, (512 / ((vg + 7) & ~7)) * 4 / waves);
+    const int by_lds = (int)std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(1, fa.sharedSizeBytes));
+    int per_cu = std::max(1, std::min({by_regs, by_lds, 2048 / threads}));
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
     // persistent grid; runs of at least 16 (P - 1) blocks keep the warm-up blocks of a run below ~6 % of its work
     const int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * per_cu / std::max<int64_t>(1, ncols));
-    const int64_t by_work = std::max<int64_t>(1, a.nblocks / (RUNS * 16 * (P - 1)));
+    const int64_t by_work = std::max<int64_t>(1, nblk / (RUNS * 16 * (P - 1)));
     const int64_t slots = std::min(resident, by_work);
-    a.run_len = cdiv(a.nblocks, slots * RUNS);
-    const int64_t grid = cdiv(a.nblocks, a.run_len * RUNS);
+    a.run_len = cdiv(nblk, slots * RUNS);
+    const int64_t grid = cdiv(nblk, a.run_len * RUNS);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ncols), dim3(threads), 0, s, a);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
+// plan variants (MDSP_OLS_VARIANT when the plan is made; tools/bench_longfilt.py): 0 default; 1 the round-2 form (register loads, every spectrum
+// from L2); 2 / 4 the round-2 form with the LDS ring of half windows; 3 the round-2 form with half spectra in LDS; 5 .. 8 the round-3 form
+// (upols2_fused_kernel): 5 half spectra in LDS + partition 0 prefetched (the default up to three partitions), 6 everything from L2, 7 partition 0
+// in registers and nothing in LDS, 8 half spectra in LDS + partition 0 in registers.  Measured: profiles/r03g_longfilt*.json
+#define UPOLS_ARGS pl, x, nx, ncols, ldx, y, nout, ldy, rg, s
+template <typename R, int N, int E, int P, bool CPLX>
+int launch_upols_np(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, UpolsRange rg, hipStream_t s) {
+    constexpr bool F32 = sizeof(R) == 4;
+    const int v = pl->variant;
+    if constexpr (F32 && N == 4096) {   // 36 KiB of exchange buffer per workgroup, two workgroups per CU: room for two half spectra (2 x 16 KiB) each
+        constexpr int NL = P - 1 < 2 ? P - 1 : 2;
+        if (v == 1) return launch_upols_k<R, N, E, P, CPLX, 2, false>(UPOLS_ARGS);
+        if (v == 3) return launch_upols_k<R, N, E, P, CPLX, 2, false, NL>(UPOLS_ARGS);
+        if (v == 5) return launch_upols_k<R, N, E, P, CPLX, 2, false, NL, 2, false>(UPOLS_ARGS);
+        if (v == 6) return launch_upols_k<R, N, E, P, CPLX, 2, false, 0, 2, false>(UPOLS_ARGS);
+        if (v == 7) return launch_upols_k<R, N, E, P, CPLX, 2, false, 0, 2, true>(UPOLS_ARGS);
+        if (v == 8) return launch_upols_k<R, N, E, P, CPLX, 2, false, NL, 2, true>(UPOLS_ARGS);
+        if constexpr (!CPLX) {
+            if (v == 2 || (v == 0 && P == 4)) return launch_upols_k<R, N, E, P, CPLX, 2, true>(UPOLS_ARGS);   // four partitions: the round-3 form spills
+        } else {
+            if (v == 0 && P == 4) return launch_upols_k<R, N, E, P, CPLX, 2, false, NL>(UPOLS_ARGS);
+        }
+        return launch_upols_k<R, N, E, P, CPLX, 2, false, NL, 2, false>(UPOLS_ARGS);
+    } else {   // 8192 points (one workgroup's exchange buffer is 70 KiB), Float64: the round-3 form spills there and measured slower
+        if constexpr (F32 && !CPLX) {
+            if (v == 4) return launch_upols_k<R, N, E, P, CPLX, 2, true>(UPOLS_ARGS);   // the ring (64 KiB) leaves one workgroup per CU
+        }
+        return launch_upols_k<R, N, E, P, CPLX, 2, false>(UPOLS_ARGS);
+    }
+}
+#undef UPOLS_ARGS
 template <typename R, int N, int E, bool CPLX>
-int launch_upols_n(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, hipStream_t s) {
+int launch_upols_n(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, UpolsRange rg, hipStream_t s) {
     switch (pl->partitions) {
-        case 2: return launch_upols_np<R, N, E, 2, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
-        case 3: return launch_upols_np<R, N, E, 3, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
-        case 4: return launch_upols_np<R, N, E, 4, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
+        case 2: return launch_upols_np<R, N, E, 2, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, rg, s);
+        case 3: return launch_upols_np<R, N, E, 3, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, rg, s);
+        case 4: return launch_upols_np<R, N, E, 4, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, rg, s);
         default: break;
     }
     MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "partitioned overlap-save supports 2..4 partitions, got %d", pl->partitions);
 }
 template <typename R, bool CPLX>
-int launch_upols(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, hipStream_t s) {
+int launch_upols(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, int64_t ldx, void* y, int64_t nout, int64_t ldy, UpolsRange rg, hipStream_t s) {
     constexpr bool DBL = sizeof(R) == 8;
-    if (pl->nfft == 4096) return launch_upols_n<R, 4096, DBL ? 8 : 16, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
+    if (pl->nfft == 4096) return launch_upols_n<R, 4096, DBL ? 8 : 16, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, rg, s);
     if constexpr (!DBL) {
-        if (pl->nfft == 8192) return launch_upols_n<R, 8192, 16, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, s);
+        if (pl->nfft == 8192) return launch_upols_n<R, 8192, 16, CPLX>(pl, x, nx, ncols, ldx, y, nout, ldy, rg, s);
     }
     MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "partitioned overlap-save does not support nfft=%lld", (long long)pl->nfft);
 }
@@ -903,14 +1219,16 @@ int mdsp_ols_plan_geometry(mdsp_ols_plan plan, int64_t* exec_nfft, int64_t* exec
 // blocks [g_begin, g_end) of every column's block grid (g_end < 0: all).  x / y may be "virtual" bases: only the elements those blocks
 // touch are dereferenced (mdsp_ols_exec_range).
 static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev, int64_t nout, int64_t ldy,
-                         int64_t g_begin, int64_t g_end, hipStream_t s) {
+                         int64_t g_begin, int64_t g_end, hipStream_t s, int64_t x_lo = 0) {
     const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
     const int64_t nblocks = cdiv(nout, plan->L);
-    if (plan->partitions > 1) {   // long filters: uniformly partitioned overlap-save (whole columns only)
-        if (g_begin != 0 || (g_end >= 0 && g_end < nblocks)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "block ranges are not available for partitioned plans");
+    if (plan->partitions > 1) {   // long filters: uniformly partitioned overlap-save
         if (ncols > 65535) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "more than 65535 columns per call");
-        if (cplx) return dbl ? launch_upols<double, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s) : launch_upols<float, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s);
-        return dbl ? launch_upols<double, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s) : launch_upols<float, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s);
+        if (g_end < 0 || g_end > nblocks) g_end = nblocks;
+        if (g_begin >= g_end) return MDSP_OK;
+        const UpolsRange rg{g_begin, g_end, x_lo};
+        if (cplx) return dbl ? launch_upols<double, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, rg, s) : launch_upols<float, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, rg, s);
+        return dbl ? launch_upols<double, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, rg, s) : launch_upols<float, false>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, rg, s);
     }
     if (g_end < 0 || g_end > nblocks) g_end = nblocks;
     if (g_begin >= g_end) return MDSP_OK;
@@ -961,11 +1279,10 @@ int mdsp_ols_exec_range(mdsp_ols_plan plan, const void* xs_dev, int64_t xs_first
     if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
     if (nx < 0 || nout < 0 || xs_first < 0 || xs_len < 0 || first_block < 0 || nblocks_range < 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "negative size");
     if (nout > nx + plan->nb - 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nout (%lld) exceeds nx+nb-1", (long long)nout);
-    if (plan->partitions > 1) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "block ranges are not available for partitioned plans (filters longer than half the largest in-LDS transform)");
     const int64_t L = plan->L, nb = plan->nb, nblocks = cdiv(nout, L);
     const int64_t g0 = first_block, g1 = std::min(nblocks, first_block + nblocks_range);
     if (g0 >= g1) return MDSP_OK;
-    if (!dtype_is_complex(plan->dtype) && (g0 & 1)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "first_block must be even (two real blocks share a transform)");
+    if (plan->partitions == 1 && !dtype_is_complex(plan->dtype) && (g0 & 1)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "first_block must be even (two real blocks share a transform)");
     // samples the blocks read: [g0 L - (nb-1), g1 L) clipped to the signal
     const int64_t need_lo = std::max<int64_t>(0, g0 * L - (nb - 1)), need_hi = std::min(nx, g1 * L);
     if (need_hi > need_lo && (xs_first > need_lo || xs_first + xs_len < need_hi))
@@ -979,7 +1296,9 @@ int mdsp_ols_exec_range(mdsp_ols_plan plan, const void* xs_dev, int64_t xs_first
     char* yv = static_cast<char*>(ys_dev) - (ptrdiff_t)(g0 * L) * (ptrdiff_t)esz;
     const int64_t nx_eff = std::min(nx, xs_first + xs_len);      // nothing past the slice is read (hardware zero fill past nx_eff is never reached)
     const int64_t nout_eff = std::min(nout, g1 * L);
-    return ols_exec_core(plan, xv, nx_eff, 1, nx_eff, yv, nout_eff, nout_eff, g0, g1, as_stream(stream));
+    // partitioned plans warm their delay line up with the P blocks in front of g0: what the slice does not hold of them lies more than nb - 1
+    // samples back, under the zero taps of the last partition, and is read as zero (x_lo)
+    return ols_exec_core(plan, xv, nx_eff, 1, nx_eff, yv, nout_eff, nout_eff, g0, g1, as_stream(stream), xs_first);
 }
 
 int mdsp_ols_segment(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t first_block, int64_t nblocks, void* seg_dev, void* stream) {

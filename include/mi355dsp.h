@@ -123,7 +123,9 @@ int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t nco
 /* Blocks [first_block, first_block + nblocks_range) of the SAME block grid mdsp_ols_exec uses for one column of nx samples /
  * nout outputs, from a slice of the signal: xs_dev holds x[xs_first .. xs_first + xs_len) and must cover the samples those blocks
  * read, [first_block L - (nb-1), (first_block + nblocks_range) L) clipped to [0, nx); ys_dev[0..] receives the outputs from
- * first_block L on.  first_block must be even for real dtypes.  Building block of mdsp_ols_exec_host and of a time-axis split
+ * first_block L on (L = exec_block_len of mdsp_ols_plan_geometry).  first_block must be even for real dtypes on single-block plans
+ * (bit-identical to the whole-column call); partitioned plans (long filters) take any first_block and agree with the whole-column call
+ * within rounding.  Building block of mdsp_ols_exec_host and of a time-axis split
  * of one stream over GPUs (no collective: overlap-save blocks are independent, Filters/filt.jl:504-518). */
 int mdsp_ols_exec_range(mdsp_ols_plan plan, const void* xs_dev, int64_t xs_first, int64_t xs_len, int64_t nx, void* ys_dev,
                         int64_t first_block, int64_t nblocks_range, int64_t nout, void* stream);

@@ -372,7 +372,7 @@ def test_long_filters_are_reblocked_by_the_fused_engine(d, torch, dt, nb, expect
         cv = d.conv(xd[:, 1], torch.from_numpy(b).cuda())
         assert cv.shape == (nx + nb - 1,)
         assert relerr(cv.cpu().numpy(), odsp.conv(x[:, 1].astype(np.float64), b.astype(np.float64))) < tol
-        # host-pointer pipeline on a re-blocked plan (halo chunks for the partitioned ones)
+        # host-pointer pipeline on a re-blocked plan (block ranges; partitioned plans warm each chunk's delay line up on its nb - 1 history)
         _lib.set_tunable("MDSP_HOST_CHUNK_MIB", 1)
         try:
             yh = plan.exec_host(np.ascontiguousarray(x.T), nx)
@@ -385,6 +385,65 @@ def test_long_filters_are_reblocked_by_the_fused_engine(d, torch, dt, nb, expect
         got = plan.exec(torch.from_numpy(np.ascontiguousarray(xs)).cuda().view(1, -1), n_small)[0].cpu().numpy()
         ref = odsp.filt_ba(b.astype(np.float64), 1.0, xs.real.astype(np.float64)) + (1j * odsp.filt_ba(b.astype(np.float64), 1.0, xs.imag.astype(np.float64)) if cplx else 0)
         assert relerr(got, ref) < 5 * tol, n_small
+
+
+@pytest.mark.parametrize("dt,nb,variants", [(np.float32, 5120, (0, 1, 2, 3, 6, 7, 8)), (np.float32, 7000, (0, 1, 2, 3, 5, 6, 7, 8)), (np.float32, 12000, (0, 4)),
+                                            (np.float64, 3000, (0,)), (np.float64, 5000, (0,)), (np.complex64, 5000, (0, 1, 3, 6, 7, 8)), (np.complex64, 8000, (0, 5))])
+def test_partitioned_overlap_save_ring_variants_and_block_ranges(d, torch, dt, nb, variants):
+    """Round 3: the partitioned kernel (Float32, 4096 points) carries the previous half window in registers, loads the next block's new half a
+    block ahead, multiplies the delay line by half spectra that live in LDS BEFORE the block's own transform and prefetches partition 0 across
+    it (upols2_fused_kernel; variants 5 .. 8 are its flavours, 1 the round-2 form with every spectrum from L2, 3 that form with LDS spectra,
+    2 / 4 with the half windows in an LDS ring filled by buffer_load ... lds) -- every variant against the Float64 oracle and against each other; and mdsp_ols_exec_range now serves partitioned plans: ranges from slices that hold nothing but
+    the nb - 1 samples of history, any first block, equal to the whole-column call up to rounding (the delay line of a range warms up on
+    zeros where the whole column has samples under the zero taps, so not bit for bit)."""
+    from dsp_jl_amd import _lib, _dev
+    from dsp_jl_amd.dspbase import OlsPlan
+    from oracle import dspbase as odsp
+    rng = np.random.default_rng(nb + 1)
+    cplx = np.dtype(dt).kind == "c"
+    rdt = np.float32 if dt in (np.float32, np.complex64) else np.float64
+    tol = TOL32 if rdt == np.float32 else 1e-12
+    b = (rng.standard_normal(nb) / np.sqrt(nb)).astype(rdt)
+    for nx in (300_007, 2048 * 37, 2048 * 37 + 1, 4500):          # ragged, a whole number of blocks (the last half lands exactly on nx), short
+        x = rng.standard_normal(nx).astype(rdt)
+        if cplx:
+            x = (x + 1j * rng.standard_normal(nx)).astype(dt)
+        xc = x.astype(np.complex128 if cplx else np.float64)
+        ref = odsp.filt_ba(b.astype(np.float64), 1.0, xc) if not cplx else (odsp.filt_ba(b.astype(np.float64), 1.0, xc.real) + 1j * odsp.filt_ba(b.astype(np.float64), 1.0, xc.imag))
+        nfft_ref = d.optimalfftfiltlength(nb, 400_000)
+        xd = torch.from_numpy(x).cuda()
+        outs = {}
+        for v in variants:
+            _lib.set_tunable("MDSP_OLS_VARIANT", v)
+            try:
+                plan = OlsPlan(b.astype(dt), nfft_ref, nx, _lib.OLS_FILT, d.ENGINE_FUSED)
+            finally:
+                _lib.set_tunable("MDSP_OLS_VARIANT", None)
+            en, el, ep = C.c_int64(), C.c_int64(), C.c_int()
+            _lib.check(_lib.lib().mdsp_ols_plan_geometry(plan._h, C.byref(en), C.byref(el), C.byref(ep)))
+            assert ep.value > 1
+            y = plan.exec(xd.view(1, -1), nx)[0]
+            outs[v] = y.cpu().numpy()
+            assert relerr(outs[v], ref) < tol, (nx, v)
+            assert relerr(outs[v][:3000], ref[:3000]) < 5 * tol and relerr(outs[v][-3000:], ref[-3000:]) < 5 * tol, (nx, v)
+            # block ranges (ragged starts, a range that ends inside the grid, one clipped by it)
+            L = el.value
+            nblocks = -(-nx // L)
+            got = torch.full_like(y, float("nan"))
+            for g0, cnt in ((0, 3), (3, 1), (4, 17), (21, nblocks)):
+                g1 = min(nblocks, g0 + cnt)
+                if g0 >= g1:
+                    continue
+                lo, hi = max(0, g0 * L - (nb - 1)), min(nx, g1 * L)
+                o0, o1 = g0 * L, min(nx, g1 * L)
+                xs = xd[lo:hi].clone()
+                ys = torch.empty(o1 - o0, dtype=xd.dtype, device="cuda")
+                _lib.check(_lib.lib().mdsp_ols_exec_range(plan._h, _dev.ptr(xs), lo, hi - lo, nx, _dev.ptr(ys), g0, cnt, nx, _dev.stream_ptr()))
+                got[o0:o1] = ys
+            torch.cuda.synchronize()
+            assert relerr(got.cpu().numpy(), ref) < tol, (nx, v, "ranges")
+        for v in variants[1:]:
+            assert relerr(outs[v], outs[variants[0]]) < tol
 
 
 @pytest.mark.parametrize("dt,tol", [(np.float32, TOL32), (np.float64, 1e-12), (np.complex64, TOL32), (np.complex128, 1e-12)])

@@ -38,27 +38,40 @@ def timeit(fn, reps=5):
     return sorted(ts)[len(ts) // 2]
 
 
+VARIANTS = [int(v) for v in os.environ.get("LONGFILT_VARIANTS", "0").split(",")]      # MDSP_OLS_VARIANT values of the partitioned kernel
+TAPS = [int(v) for v in os.environ.get("LONGFILT_TAPS", "256,1024,1500,2048,3000,5120,8192,12000,16384").split(",")]
+DTYPES = [v for v in os.environ.get("LONGFILT_DTYPES", "float32,float64").split(",")]
 res = {}
 for dt, log2n in ((np.float32, 28), (np.float64, 27)):
+    if np.dtype(dt).name not in DTYPES:
+        continue
     n = 1 << log2n
     x = torch.randn(n, generator=g, device="cuda", dtype=torch.float32 if dt == np.float32 else torch.float64)
     y = torch.empty_like(x)
-    for nb in (256, 1024, 1500, 2048, 3000, 5120, 8192, 12000, 16384):
+    for nb in TAPS:
         taps = (np.random.default_rng(nb).standard_normal(nb) / np.sqrt(nb)).astype(dt)
         nfft = d.optimalfftfiltlength(nb, n)
         row = {"nfft_reference": nfft}
-        for eng, name in ((d.ENGINE_FUSED, "fused"), (d.ENGINE_ROCFFT, "rocfft")):
+        ref = None
+        for eng, name, var in [(d.ENGINE_FUSED, "fused" if v == VARIANTS[0] else f"fused_v{v}", v) for v in VARIANTS] + [(d.ENGINE_ROCFFT, "rocfft", 0)]:
+            if eng == d.ENGINE_ROCFFT and os.environ.get("LONGFILT_NO_ROCFFT"):
+                continue
             try:
+                _lib.set_tunable("MDSP_OLS_VARIANT", str(var))
                 p = OlsPlan(taps, nfft, n, _lib.OLS_FILT, eng)
+                _lib.set_tunable("MDSP_OLS_VARIANT", "0")
             except Exception as e:
                 row[name] = str(e)[:60]
                 continue
             en, el, ep = C.c_int64(), C.c_int64(), C.c_int()
             _lib.check(lib.mdsp_ols_plan_geometry(p._h, C.byref(en), C.byref(el), C.byref(ep)))
             ms = timeit(lambda: _lib.check(lib.mdsp_ols_exec(p._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, stream)))
+            if ref is None:
+                ref = y.clone()
             row[name] = {"ms": round(ms, 4), "Gsamples_per_s": round(n / ms / 1e6, 1), "GBps_algorithmic": round(2 * x.element_size() * n / ms / 1e6, 1),
-                         "exec_nfft": en.value, "exec_block": el.value, "partitions": ep.value}
+                         "exec_nfft": en.value, "exec_block": el.value, "partitions": ep.value, "maxdiff_vs_first": float((y - ref).abs().max())}
             del p
+        del ref
         res[f"{np.dtype(dt).name}_{nb}"] = row
         print(np.dtype(dt).name, nb, row, flush=True)
     del x, y
