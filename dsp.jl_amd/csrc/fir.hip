@@ -538,16 +538,24 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
 #pragma unroll
                             for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[t], acc[p][c]);
                 } else {
-                    for (int t0 = 0; t0 < steps; t0 += 8) {   // steps is a multiple of 8: eight tap fetches in flight
-                        R h[8];
+                    // steps is a multiple of 8: the taps of eight k-steps are fetched while the previous eight are multiplied (a fetch is an L2 round
+                    // trip; a wave that waits for it in front of every group leaves its SIMD's matrix pipe idle half of the time)
+                    R h[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) h[u] = tap(t0 + u);
+                    for (int u = 0; u < 8; ++u) h[u] = tap(u);
+                    for (int t0 = 0; t0 < steps; t0 += 8) {
+                        R hn[8];
+                        const int tn = t0 + 8 < steps ? t0 + 8 : t0;   // (the last group re-reads its own: no branch around the loads)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) hn[u] = tap(tn + u);
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
 #pragma unroll
                             for (int c = 0; c < CH; ++c)
 #pragma unroll
                                 for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) h[u] = hn[u];
                     }
                 }
                 if (16 * wb + lj < a.Lr) {
@@ -1120,7 +1128,8 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     if (f->acc_double != dtype_is_double(f->x_dtype)) return g;
     g.esz = f->acc_double ? 8 : 4;
     g.CS = dtype_is_complex(f->x_dtype) ? 2 : 1;
-    const int chmax = (g.esz == 4 && g.CS == 1) ? 4 : 2;   // 16-row chunks per multiplying wave: fewer when the tile would not fit the LDS
+    int chmax = (g.esz == 4 && g.CS == 1) ? 4 : 2;   // 16-row chunks per multiplying wave: fewer when the tile would not fit the LDS
+    if (tunables().fir_mm_ch > 0) chmax = std::min(chmax, tunables().fir_mm_ch);
     if (f->L > 1024 || f->M > 4096) return g;
     if (f->L < 16) {   // rounds per row: most outputs per LDS cycle of the A-operand reads (16 rows x 2 taps per lane group)
         double best = -1;
@@ -1163,7 +1172,22 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     const double ways_lin = ((g.Mr * dw) & 1) ? 1.0 : ways_of((int64_t)g.Mr * dw), ways_row = ways_of(rpitch);
     // cost per row of outputs ~ max(1, 0.2 ways) [the A-operand reads keep the LDS about 20 % busy when conflict-free] + 32 / rows [one
     // barrier and pipeline turn-around per tile, worth about 32 rows]: the staging mode and tile with the smallest cost
-    double best_score = -1;
+    // Two ways to pick the tile (16 CH rows per multiplying wave, NG groups of NBW waves):
+    //   * ratios above one (and anything with several column blocks per wave): the largest tile that fits, scored by
+    //     max(1, 0.2 ways) + 32 / rows as in round 2 -- with at most FOUR groups when there is one column block (2//1, 3//2, 4//1 ...):
+    //     4 + 2 + 2 waves put one multiplying and one memory wave of a workgroup on every SIMD and three such workgroups share a CU
+    //     (2//1 0.95 -> 0.91 ms, 4//1 2.03 -> 1.82, ComplexF32 2//1 1.84 -> 1.49; 3 and 6 groups leave the SIMDs unevenly loaded and lose
+    //     10 - 20 %).  profiles/r03h_fir_groups.json
+    //   * ratios up to one (decimators, single-rate FIR): one big workgroup per CU, so what a tile costs is the matrix work of its BUSIEST
+    //     SIMD -- waves go round the four SIMDs, ceil(mw / 4) multiplying waves on the fullest -- plus the tap fetches of the long-filter
+    //     mode (every multiplying wave fetches every k-step's taps: ~25 clocks each through the CU's one L1 pipe) plus ~3900 clocks of
+    //     barrier and pipeline turn-around, per row:  cost = (ceil(mw/4) CH steps c_mfma max(1, 0.2 ways) + [T = 0] mw steps 25 + 3900) / rows.
+    //     Fitted on 1//8 (0.98 : 0.87 : 1.22 measured for CH = 4, 2, 1 against 1 : 0.88 : 1.27) and checked on 1//2 ... 1//16, 3//8
+    //     (profiles/r03h_fir_groups.json): 1//3 and 3//8 leave five groups for eight half-size ones (+25 %), 1//8 and 1//16 two / one
+    //     groups of four chunks for twice as many of two (+12 %, +30 %).  Costs within 3 % of each other go to the larger tile.
+    const bool by_model = f->L <= f->M && tunables().fir_mm_ng <= 0 && tunables().fir_mm_ch <= 0;
+    double best_score = -1, best_cost = 0;
+    int best_rows = 0;
     for (int pad = 1; pad >= 0 && !g.ok; --pad) {   // (a last resort: output rows without their 16 bytes of padding -- ComplexF64 at 160//147 then fits exactly)
     if (g.NB > 1) g.Lp = 16 * g.NB * g.CS + (pad ? 16 / g.esz : 0);
     else if (!pad) break;
@@ -1173,13 +1197,24 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
         const double ways = mode ? ways_row : ways_lin;
         for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
             const int rows = 16 * ch;
-            for (int ng = std::min(tunables().fir_mm_ng > 0 ? tunables().fir_mm_ng : 8, 12 / g.NBW); ng >= 1; --ng) {
+            const int ngdef = (g.NBW == 1 && f->L > f->M) ? 4 : 8;
+            for (int ng = std::min(tunables().fir_mm_ng > 0 ? tunables().fir_mm_ng : ngdef, 12 / g.NBW); ng >= 1; --ng) {
                 const int64_t bufsz = mode ? cdiv((int64_t)rows * ng * rpitch, (int64_t)256) * 256 : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
                 const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
-                if (bytes <= 160 * 1024) {
+                if (bytes > 160 * 1024) continue;
+                const auto take = [&] { g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; g.pitch = mode ? rpitch : 0; };
+                if (!by_model) {
                     const double score = 1.0 / (std::max(1.0, 0.2 * ways) + 32.0 / (rows * ng)) + 1e-6 * ch;
-                    if (score > best_score) { best_score = score; g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; g.pitch = mode ? rpitch : 0; }
-                    break;
+                    if (score > best_score) { best_score = score; take(); }
+                    break;   // (only the largest tile of this chunk count)
+                }
+                const int mw = g.NBW * ng, trows = rows * ng;
+                const double c_mfma = (g.esz == 8 ? 64.0 : 32.0) * g.CS;
+                const double cost = (((mw + 3) / 4) * (double)ch * cdiv(g.NB, g.NBW) * g.steps * c_mfma * std::max(1.0, 0.2 * ways) + (g.T == 0 ? mw * g.steps * 25.0 : 0.0) + 3900.0) / trows;
+                if (!g.ok || cost < 0.97 * best_cost || (cost < 1.03 * best_cost && trows > best_rows)) {
+                    best_cost = g.ok ? std::min(best_cost, cost) : cost;
+                    best_rows = trows;
+                    take();
                 }
             }
         }

@@ -56,6 +56,8 @@ def run():
 def select(v):
     _lib.set_tunable("MDSP_FIR_MM", str(v[0])); _lib.set_tunable("MDSP_WG_PER_CU", str(v[1])); _lib.set_tunable("MDSP_FIR_P", str(v[2]))
     _lib.set_tunable("MDSP_FIR_MM_ND", str(v[3]) if len(v) > 3 else "0"); _lib.set_tunable("MDSP_FIR_MM_NS", str(v[4]) if len(v) > 4 else "0")
+    _lib.set_tunable("MDSP_FIR_MM_NG", str(v[5]) if len(v) > 5 else "0")   # cap on the 64-row groups per tile (0: the library's choice)
+    _lib.set_tunable("MDSP_FIR_MM_CH", str(v[6]) if len(v) > 6 else "0")   # cap on the 16-row chunks per multiplying wave
 
 
 def timeit():
@@ -65,19 +67,23 @@ def timeit():
     return ms.value
 
 
+def vkey(v):
+    return "mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "") + (" ng={}".format(v[5]) if len(v) > 5 else "") + (" ch={}".format(v[6]) if len(v) > 6 else "")
+
+
 res = {"dtype": DT, "log2n": log2n, "nch": nch, "ratio": f"{L}//{M}", "taps": len(h), "nout": ol.value, "variants": {}}
 ref = None
 for v in variants:
     select(v); y.zero_(); run(); torch.cuda.synchronize()
     if ref is None:
         ref = y.clone()
-    key = "mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "")
+    key = vkey(v)
     res["variants"][key] = {"maxdiff_vs_first": float((y - ref).abs().max()), "ms": []}
     del_ref = None
 for r in range(rounds):
     for v in variants:
         select(v)
-        res["variants"]["mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "")]["ms"].append(round(timeit(), 4))
+        res["variants"][vkey(v)]["ms"].append(round(timeit(), 4))
 bytes_alg = (esz + esz * L / M) * n * nch
 for k, e in res["variants"].items():
     e["median_ms"] = float(np.median(e["ms"]))
