@@ -1188,7 +1188,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     const bool by_model = f->L <= f->M && tunables().fir_mm_ng <= 0 && tunables().fir_mm_ch <= 0;
     double best_score = -1, best_cost = 0;
     int best_rows = 0;
-    for (int pad = 1; pad >= 0 && !g.ok; --pad) {   // (a last resort: output rows without their 16 bytes of padding -- ComplexF64 at 160//147 then fits exactly)
+    for (int pad = tunables().fir_mm_pad == 0 ? 0 : 1; pad >= 0 && !g.ok; --pad) {   // (a last resort: output rows without their 16 bytes of padding -- ComplexF64 at 160//147 then fits exactly)
     if (g.NB > 1) g.Lp = 16 * g.NB * g.CS + (pad ? 16 / g.esz : 0);
     else if (!pad) break;
     for (int mode = 0; mode < 2; ++mode) {   // 0: one linear run per tile, 1: row by row

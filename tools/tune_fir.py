@@ -58,6 +58,7 @@ def select(v):
     _lib.set_tunable("MDSP_FIR_MM_ND", str(v[3]) if len(v) > 3 else "0"); _lib.set_tunable("MDSP_FIR_MM_NS", str(v[4]) if len(v) > 4 else "0")
     _lib.set_tunable("MDSP_FIR_MM_NG", str(v[5]) if len(v) > 5 else "0")   # cap on the 64-row groups per tile (0: the library's choice)
     _lib.set_tunable("MDSP_FIR_MM_CH", str(v[6]) if len(v) > 6 else "0")   # cap on the 16-row chunks per multiplying wave
+    _lib.set_tunable("MDSP_FIR_MM_PAD", str(v[7]) if len(v) > 7 else "-1")  # 0: unpadded output rows
 
 
 def timeit():
@@ -68,7 +69,7 @@ def timeit():
 
 
 def vkey(v):
-    return "mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "") + (" ng={}".format(v[5]) if len(v) > 5 else "") + (" ch={}".format(v[6]) if len(v) > 6 else "")
+    return "mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "") + (" ng={}".format(v[5]) if len(v) > 5 else "") + (" ch={}".format(v[6]) if len(v) > 6 else "") + (" pad={}".format(v[7]) if len(v) > 7 else "")
 
 
 res = {"dtype": DT, "log2n": log2n, "nch": nch, "ratio": f"{L}//{M}", "taps": len(h), "nout": ol.value, "variants": {}}
