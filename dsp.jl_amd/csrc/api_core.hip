@@ -89,11 +89,14 @@ const Tunables& tunables() {
     return g_tun;
 }
 // Tuning tools only.  Readers (exec / plan paths) take no lock: a reload must not race with other threads' library calls (mi355dsp.h says so).
+static std::atomic<uint64_t> g_tun_gen{1};
 void reload_tunables() {
     (void)tunables();
     std::lock_guard<std::mutex> lk(g_tun_mu);
     read_tunables_locked();
+    g_tun_gen.fetch_add(1, std::memory_order_release);
 }
+uint64_t tunables_generation() { return g_tun_gen.load(std::memory_order_acquire); }
 
 // ---- pure index arithmetic ---------------------------------------------------------------------------
 static int64_t nextprod2357(int64_t n) {

@@ -136,6 +136,7 @@ struct Tunables {
 };
 const Tunables& tunables();
 void reload_tunables();
+uint64_t tunables_generation();   // bumped by every reload: keys host-side memos of values derived from the tunables
 
 // ---------------------------------------------------------------- library-wide LRU of device objects (plancache.hip)
 // key = plan_cache_key(kind, stream) [device, calling thread, stream] + whatever else the object depends on, appended by the caller.

@@ -1122,7 +1122,7 @@ struct FirMGeo {
     size_t lds_bytes = 0;
 };
 int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : steps <= 32 ? 32 : steps <= 48 ? 48 : 64; }
-FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
+FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f) {
     FirMGeo g;
     // element type: signal and compute type must agree (Float32 taps x Float32 samples, or Float64 arithmetic on Float64 samples)
     if (f->acc_double != dtype_is_double(f->x_dtype)) return g;
@@ -1230,6 +1230,23 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     }
     return g;
 }
+// every exec asks twice (use? / dispatch): one memo per calling thread, keyed by what the geometry depends on (the search above is a few
+// hundred iterations -- microseconds, but a sample-at-a-time stream pays them per call)
+FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
+    struct Memo {
+        int64_t L = -1, M = 0, hlen = 0;
+        int td = 0, xd = 0;
+        uint64_t gen = 0;
+        FirMGeo g;
+    };
+    static thread_local Memo m;
+    const uint64_t gen = tunables_generation();
+    if (m.L != f->L || m.M != f->M || m.hlen != f->hlen || m.td != f->taps_dtype || m.xd != f->x_dtype || m.gen != gen) {
+        m.g = fir_mm_geo_compute(f);
+        m.L = f->L; m.M = f->M; m.hlen = f->hlen; m.td = f->taps_dtype; m.xd = f->x_dtype; m.gen = gen;
+    }
+    return m.g;
+}
 bool fir_mm_shape_ok(const mdsp_fir_s* f) { return fir_mm_geo(f).ok; }
 
 template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
@@ -1292,8 +1309,9 @@ int fir_mm_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
     return g.CH == 2 ? fir_mm_dispatch_t<double, 2, 2>(f, a, g, st) : fir_mm_dispatch_t<double, 2, 1>(f, a, g, st);
 }
 
-// where the matrix-core kernel is used: wherever the shape fits -- it is the faster kernel from 2^16 samples (0.019 against 0.042 ms,
-// one channel 2//1) to 2^28 (profiles/r02r_tune_fir); MDSP_FIR_MM=0 turns it off
+// where the matrix-core kernel is used: wherever the shape fits, whatever the chunk length -- one channel of 2^8 ... 2^16 samples takes
+// 17 - 29 us against 32 - 61 us at 2//1, 18 - 23 against 21 - 31 at 160//147, 20 - 26 against 16 - 44 at 1//2 (profiles/r03h_fir_small_chunks.txt:
+// no size gate pays), up to 2^28 (profiles/r02r_tune_fir); MDSP_FIR_MM=0 turns it off
 bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
     (void)a;
     if (tunables().fir_mm == 0) return false;
