@@ -1,4 +1,5 @@
 // Library core: error state, device selection, memory helpers, pure index arithmetic, measurement helpers.
+#include <atomic>
 #include <cmath>
 
 #include "common.h"
