@@ -343,21 +343,10 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
             wl[q] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
         }
     }
-    // Welch power accumulators: Float32 signals run |Z|^2 into Float32 sums (two FMAs per bin and frame pair) that are folded into the Float64
-    // sums every FLUSH frame pairs -- like the power-of-two kernels (the reference accumulates in Float32 over ALL frames, periodograms.jl:757;
-    // runs of <= FLUSH same-sign terms stay far tighter) -- instead of a convert and a Float64 add per bin and frame pair, both half rate.
-    constexpr bool RUNACC = MODE == 0 && sizeof(R) == 4;
-    constexpr int FLUSH = 64;
     double acc[MODE == 0 ? ML * RL : 1];
-    R accf[RUNACC ? ML * RL : 1];
-    int since = 0;
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < ML * RL; ++i) acc[i] = 0.0;
-    }
-    if constexpr (RUNACC) {
-#pragma unroll
-        for (int i = 0; i < ML * RL; ++i) accf[i] = (R)0;
     }
     const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
     for (int64_t it = 0; it < a.per_slot; ++it) {
@@ -396,9 +385,7 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
         if constexpr (DIRECT) {
             const cx<R>* src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t);
             ct_last_pass_regs<S>(src, tw, t, [&](int m, int q, int k, cx<R> z) {
-                if constexpr (RUNACC) {      // K5: |Z|^2 added to the run's Float32 sum (dead units carry zeros: a zero frame adds nothing)
-                    accf[m * RL + q] = fmaf(z.y, z.y, fmaf(z.x, z.x, accf[m * RL + q]));
-                } else if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
+                if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
                     if (live) acc[m * RL + q] += (double)(z.x * z.x + z.y * z.y);
                 } else if (live && k < a.nout) {   // complex signal: two-sided columns (periodograms.jl:876)
                     if (a.psd) {
@@ -439,21 +426,7 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
                 }
             }
         }
-        if constexpr (RUNACC) {
-            if (++since == FLUSH) {
-                since = 0;
-#pragma unroll
-                for (int i = 0; i < ML * RL; ++i) {
-                    acc[i] += (double)accf[i];
-                    accf[i] = (R)0;
-                }
-            }
-        }
         __syncthreads();   // the buffer the last pass read may be the one the next frame's first pass writes
-    }
-    if constexpr (RUNACC) {
-#pragma unroll
-        for (int i = 0; i < ML * RL; ++i) acc[i] += (double)accf[i];
     }
     if constexpr (MODE == 0) {
         double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)N;
