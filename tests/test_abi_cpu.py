@@ -505,6 +505,39 @@ def test_julia_twin_binds_exported_symbols_with_matching_argument_types():
         assert fn in src, fn
 
 
+def test_matrix_core_tile_choice_round3():
+    # Round 3: decimating shapes whose windows leave room for a small tile only no longer take the largest tile whatever its wave
+    # count (two or one multiplying waves per CU at 1//8, 1//16; five at 1//3, 3//8: idle or doubly loaded SIMDs) but the cheapest by the cost
+    # line of fir_mm_geo; interpolators with one column block take four row groups (three workgroups per CU).  MDSP_FIR_MM_NG=8 is round 2's rule.
+    import ctypes as C
+    from dsp_jl_amd import _lib
+    lib = _lib.lib()
+    out = (C.c_int64 * 12)()
+
+    def geo(L, M, hlen, tdt=_lib.F32, xdt=_lib.F32):
+        _lib.check(lib.mdsp_fir_mm_geometry(L, M, hlen, tdt, xdt, out))
+        ok, RB, Lr, Mr, NB, NG, T, CH, CS, nd, ns, lds = list(out)
+        return dict(ok=ok, NB=NB, NG=NG, CH=CH, nd=nd, ns=ns, lds=lds, rows=16 * CH * NG)
+
+    try:
+        for L, M, hlen in ((1, 8, 293), (1, 16, 583), (1, 3, 111), (3, 8, 295), (1, 4, 147)):
+            _lib.set_tunable("MDSP_FIR_MM_NG", 8)
+            old = geo(L, M, hlen)
+            _lib.set_tunable("MDSP_FIR_MM_NG", None)
+            new = geo(L, M, hlen)
+            assert new["ok"] and new["lds"] <= 160 * 1024
+            assert new["NG"] % 4 == 0 or new["NG"] > old["NG"], (L, M, old, new)      # every SIMD gets a multiplying wave (or at least more of them do)
+            assert new["rows"] * 2 >= old["rows"], (L, M, old, new)                   # ... without giving up more than half of the tile
+        assert geo(1, 8, 293) == dict(ok=1, NB=1, NG=4, CH=2, nd=2, ns=4, lds=144384, rows=128)
+        assert geo(1, 2, 75)["NG"] == 6 and geo(1, 2, 75)["CH"] == 4                # measured: the large tile wins here (0.45 against 0.53 ms)
+        for L, M, hlen in ((2, 1, 75), (3, 2, 111), (4, 1, 149), (5, 3, 185)):
+            g = geo(L, M, hlen)
+            assert g["NG"] == 4 and g["nd"] == 2 and g["ns"] == 2 and 3 * g["lds"] <= 160 * 1024, (L, M, g)   # 4 + 2 + 2 waves, three workgroups per CU
+        assert geo(160, 147, 5120)["NG"] == 1 and geo(160, 147, 5120)["CH"] == 4    # ten column blocks: unchanged
+    finally:
+        _lib.set_tunable("MDSP_FIR_MM_NG", None)
+
+
 def test_matrix_core_polyphase_geometry_is_consistent():
     # mdsp_fir_mm_geometry is the host arithmetic that sizes the matrix-core polyphase kernel (rows of RB rounds, blocks of 16 outputs,
     # k-steps, LDS buffers, wave roles): pure integer code, checked here without a device over random ratios and tap counts.
