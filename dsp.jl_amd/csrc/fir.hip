@@ -313,6 +313,7 @@ struct FirMArgs {
     int bufsz;                   // dwords per LDS sample buffer (two of them, then two output buffers)
     int steps;                   // k-steps of four taps when they do not fit registers (template T = 0): the taps are then fetched per tile
     int pitch;                   // 0: the samples of a tile are staged as one run (row r starts at r Mr); else every row is staged on its own, pitch dwords apart
+    int vstore;                  // 1: output rows that are not whole vectors leave as gathered wide stores (0: element by element, round 2)
     int nd, ns;                  // waves that issue the LDS-DMA / that store, after the multiplying waves
     unsigned lmagic, rmagic;     // ceil(2^32 / L), ceil(2^32 / (Lr CS)): quotients of small numbers by multiply-high
     int phi0m1;                  // phi0 - 1: output j of a row has phase (phi0-1 + j M) mod L and window start (phi0-1 + j M) div L
@@ -474,6 +475,30 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
             }
             for (int idx = nv * VW + st0; idx < total; idx += stn) {
                 const int row = flat ? 0 : (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * lrc;
+                yo[idx] = zo[row * a.Lp + col];
+            }
+        } else if (a.vstore) {
+            // rows of Lr elements that are not whole vectors (147//160: ten column blocks, 147 outputs per row): a vector's elements are
+            // gathered one by one -- they may straddle a row end -- and leave as ONE wide store; the run of outputs itself is contiguous
+            const int nv = total / VW;
+            for (int iv = st0; iv < nv; iv += 2 * stn) {
+                vec_t v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int idx = VW * std::min(iv + u * stn, nv - 1);
+                    int row = (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * lrc;
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) {
+                        v[u][j] = zo[row * a.Lp + col];
+                        if (++col == lrc) { col = 0; ++row; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (iv + u * stn < nv) __builtin_memcpy(yo + VW * (iv + u * stn), &v[u], sizeof(vec_t));
+            }
+            for (int idx = nv * VW + st0; idx < total; idx += stn) {
+                const int row = (int)__umulhi((unsigned)idx, a.rmagic), col = idx - row * lrc;
                 yo[idx] = zo[row * a.Lp + col];
             }
         } else {
@@ -1266,6 +1291,7 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
     b.bufsz = (int)g.bufsz;
     b.pitch = g.pitch;
     b.steps = g.steps;
+    b.vstore = tunables().fir_mm_vstore;
     const int nw = g.NBW * g.NG + g.nd + g.ns;
     auto kern = polyphase_mfma_kernel<R, CS, CH, T>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB
