@@ -313,7 +313,11 @@ struct FirMArgs {
     int bufsz;                   // dwords per LDS sample buffer (two of them, then two output buffers)
     int steps;                   // k-steps of four taps when they do not fit registers (template T = 0): the taps are then fetched per tile
     int pitch;                   // 0: the samples of a tile are staged as one run (row r starts at r Mr); else every row is staged on its own, pitch dwords apart
+    int rowpad;                  // > 0 (with pitch == 0): one run per tile, staged in the same 256-dword DMA granules as the plain run, with rowpad dwords of
+                                 // padding behind every granule (dword d of the tile sits at d + (d / 256) rowpad): rows whose stride is bank-hostile spread
+                                 // over the banks without the duplicated window tails of the row-staged form
     int vstore;                  // 1: output rows that are not whole vectors leave as gathered wide stores (0: element by element, round 2)
+    int ablate;                  // MDSP_DEBUG_KNOBS builds (MDSP_ABLATE): 1 no tile DMA after the first, 2 no matrix products, 4 no output stores
     int nd, ns;                  // waves that issue the LDS-DMA / that store, after the multiplying waves
     unsigned lmagic, rmagic;     // ceil(2^32 / L), ceil(2^32 / (Lr CS)): quotients of small numbers by multiply-high
     int phi0m1;                  // phi0 - 1: output j of a row has phase (phi0-1 + j M) mod L and window start (phi0-1 + j M) div L
@@ -417,9 +421,11 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     const auto dma_ok = [&](int64_t tile) { return tile < ntiles && tile * Q * a.Mr + cbase >= a.hl; };
     // Row-staged tiles (pitch != 0): when the sample stride of a row, Mr, is a multiple of 8 the 16 rows of an A operand would sit on
     // 2 - 8 banks of a linear tile (147//160: all on one); every row is then DMA-ed on its own -- its Mr samples and the window tail
-    // again -- to rows pitch = 256 g + 4 dwords apart (two-way conflicts at worst); the duplicates come from L2.
+    // again -- to rows pitch = 256 g + 4 dwords apart (two-way conflicts at worst); the duplicates come from L2.  (Round 3: where a window is
+    // shorter than a granule the padded run -- rowpad, below -- replaces this form.)
     const int rgran = a.pitch ? (a.pitch - 4) / 256 : 0;                    // 256-dword granules per row
-    const int zpitch = a.pitch ? a.pitch / (int)(sizeof(R) / 4) : a.Mr * CS;   // R elements between rows
+    const int padE = a.rowpad / (int)(sizeof(R) / 4);                          // R elements of padding behind a granule (padded runs)
+    const int zpitch = a.pitch ? a.pitch / (int)(sizeof(R) / 4) : a.Mr * CS;   // R elements between rows (padded runs: + padE from segment to segment)
     const auto dma = [&](int64_t tile, int buf) {
         if (!is_dma || !dma_ok(tile)) return;
         const int64_t q0 = tile * Q, z0 = q0 * a.Mr + cbase;
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
         if (a.pitch == 0) {
             const int nzd = (nq * a.Mr + a.Mr + wtail) * DW;   // dwords of the tile
             for (int i = wave - ncomp; 256 * i < nzd; i += a.nd) {   // granules of 256 dwords, round-robin over the DMA waves
-                const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + 256 * i) * 4u;
+                const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + (256 + a.rowpad) * i) * 4u;   // (padded runs: rowpad dwords between granules)
                 if (256 * (int64_t)(i + 1) <= exist) mm_dma256(rs, dst, (256 * i + 4 * lane) * 4);
                 else {
 #pragma unroll
@@ -537,14 +543,14 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                 R v = (R)0;
                 if (zi < a.hl) v = hc[zi * CS + part];
                 else if (zi - a.hl < a.xlen) v = xc[(zi - a.hl) * CS + part];
-                zw[row * zpitch + e] = v;
+                zw[row * zpitch + e + (a.rowpad > 0 ? ((e * (int)(sizeof(R) / 4)) >> 8) * padE : 0)] = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);
         }
         __syncthreads();   // tile t is in; the outputs of t-1 are complete; the other sample buffer and the other output buffer are free
-        dma(tile + gridDim.x, cur ^ 1);
-        if (prev_tile >= 0) copy_out(prev_tile, zout + (cur ^ 1) * osz);
-        if (is_comp) {
+        if (!MDSP_ABLATED(a, 1)) dma(tile + gridDim.x, cur ^ 1);
+        if (prev_tile >= 0 && !MDSP_ABLATED(a, 4)) copy_out(prev_tile, zout + (cur ^ 1) * osz);
+        if (is_comp && !MDSP_ABLATED(a, 2)) {
             for (int b = wb0; b < a.NB; b += a.NBW) {   // (one block per wave unless T = 0)
                 if (T == 0 && a.NBW < a.NB) block_setup(b);
                 acc_t acc[CS][CH];
@@ -554,8 +560,28 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                     for (int c = 0; c < CH; ++c) acc[p][c] = acc_t{(R)0, (R)0, (R)0, (R)0};
                 const R* ap[CH];   // A operand: row = lane % 16, k = lane / 16
 #pragma unroll
-                for (int c = 0; c < CH; ++c) ap[c] = zt + (ra * lj + rbase(c)) * zpitch + (c0 + lk) * CS;
-                if constexpr (T != 0) {
+                for (int c = 0; c < CH; ++c) {
+                    const int row = ra * lj + rbase(c);
+                    ap[c] = zt + row * zpitch + (a.rowpad > 0 ? (((row * a.Mr + c0 + lk) * DW) >> 8) * padE : 0) + (c0 + lk) * CS;
+                }
+                // padded runs (T != 0, a window shorter than a granule: it meets ONE pad at most): the positions behind the granule boundary sit
+                // padE elements further on -- a per-lane choice between two base pointers, so that every read keeps its immediate offset (computed
+                // addresses cost the read-ahead of the A operands: measured 1.08 against 0.78 ms at 147//160)
+                if (T != 0 && a.rowpad > 0) {
+                    // dwords from this lane's first window position to the next granule boundary (16 rows are a whole number of granules,
+                    // so the distance is the same for every chunk)
+                    const int th = 256 - (((ra * lj) * a.Mr + c0 + lk) * DW & 255);
+#pragma unroll
+                    for (int t = 0; t < TR; ++t) {
+                        const bool hi = 4 * t * DW >= th;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            const R* pp = hi ? ap[c] + padE : ap[c];
+#pragma unroll
+                            for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(pp[4 * t * CS + p], hreg[t], acc[p][c]);
+                        }
+                    }
+                } else if constexpr (T != 0) {
 #pragma unroll
                     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -1144,6 +1170,7 @@ struct FirMGeo {
     int RB = 1, Lr = 0, Mr = 0, NB = 0, NBW = 0, NG = 1, T = 0, steps = 0, Lp = 0, nd = 1, ns = 1;   // T = 0: `steps` k-steps with the taps fetched per tile
     int64_t bufsz = 0;             // dwords per sample buffer
     int pitch = 0;                 // dwords between separately staged rows (0: one linear run per tile)
+    int rowpad = 0;                // dwords of padding behind every 256-dword granule of a linear run (0: none)
     size_t lds_bytes = 0;
 };
 int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : steps <= 32 ? 32 : steps <= 48 ? 48 : 64; }
@@ -1216,18 +1243,41 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f) {
     for (int pad = tunables().fir_mm_pad == 0 ? 0 : 1; pad >= 0 && !g.ok; --pad) {   // (a last resort: output rows without their 16 bytes of padding -- ComplexF64 at 160//147 then fits exactly)
     if (g.NB > 1) g.Lp = 16 * g.NB * g.CS + (pad ? 16 / g.esz : 0);
     else if (!pad) break;
-    for (int mode = 0; mode < 2; ++mode) {   // 0: one linear run per tile, 1: row by row
-        if (mode == 1 && (tunables().fir_mm_rows == 0 || (tunables().fir_mm_rows < 0 && ways_lin < 4))) continue;
-        if (mode == 0 && tunables().fir_mm_rows == 1) continue;
-        const double ways = mode ? ways_row : ways_lin;
+    // round 3: a third staging form for the bank-hostile strides -- ONE run per tile, moved by the same full 256-dword DMA granules as mode 0,
+    // with 4 dwords of padding behind every GRANULE (dword d of the tile at d + 4 (d / 256)).  Rows then spread over the banks (counted below),
+    // no window tail is fetched twice (row-staged 147//160: 228 samples per 160 new ones in 256-dword granules, 1.6x the L2 -> LDS traffic; its
+    // DMA alone took 0.53 of the kernel's 0.78 ms) and the tile is not shrunk by the duplicates.  A window shorter than a granule meets one pad
+    // at most, at a lane-dependent step: the A-operand reads choose between two base pointers per lane and keep their immediate offsets.
+    // What did NOT work on the way (profiles/r03k_fir_padded_runs.json): padding behind every row or every two rows -- the segments then are
+    // 640 or 1280 bytes, i.e. 16-byte DMA with lanes switched off, or a 16-byte plus a 4-byte instruction: 0.87 - 1.0 ms of DMA alone against 0.36
+    // for whole granules -- and computed (instead of immediate) read offsets.  147//160 0.76 -> 0.60 ms, Float64 1.41 -> 1.08, 49//48 1.64 -> 0.73.
+    const int RPAD = tunables().fir_mm_rpad > 0 ? tunables().fir_mm_rpad : 4;
+    double ways_pad = 1;
+    {   // conflict ways of the 16 rows of an A operand, counted on the layout itself
+        int cnt[64] = {0};
+        for (int i = 0; i < 16; ++i) {
+            const int64_t d = (int64_t)i * g.Mr * dw, ad = d + (d >> 8) * RPAD;
+            ways_pad = std::max<double>(ways_pad, ++cnt[(int)((g.esz == 8 ? ad / 2 : ad) % 32)]);
+        }
+    }
+    const int fm = tunables().fir_mm_rows;
+    for (int mode = 0; mode < 3; ++mode) {   // 0: one linear run per tile, 1: row by row, 2: one run with padded rows
+        if (mode >= 1 && ways_lin < 4 && fm < 0) continue;
+        if (fm >= 0 && mode != fm) continue;
+        const bool pad_ok = !((g.Mr * dw) & 15) && g.T != 0 && g.T * dw <= 64;   // 16 rows are whole granules; taps in registers; a window (4 T dw dwords) meets one pad at most
+        if (mode == 2 && !pad_ok) continue;
+        if (mode == 1 && fm < 0 && pad_ok) continue;   // the padded run replaces the row-staged form wherever it applies
+        const double ways = mode == 1 ? ways_row : mode == 2 ? ways_pad : ways_lin;
         for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
             const int rows = 16 * ch;
             const int ngdef = (g.NBW == 1 && f->L > f->M) ? 4 : 8;
             for (int ng = std::min(tunables().fir_mm_ng > 0 ? tunables().fir_mm_ng : ngdef, 12 / g.NBW); ng >= 1; --ng) {
-                const int64_t bufsz = mode ? cdiv((int64_t)rows * ng * rpitch, (int64_t)256) * 256 : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
+                const int64_t bufsz = mode == 1 ? cdiv((int64_t)rows * ng * rpitch, (int64_t)256) * 256
+                                    : mode == 2 ? cdiv((cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) + 1) * (256 + RPAD), (int64_t)256) * 256
+                                                : cdiv(((int64_t)rows * ng * g.Mr + g.Mr + wtail) * dw, (int64_t)256) * 256;
                 const size_t bytes = (size_t)(2 * bufsz) * 4 + (size_t)(2 * rows * ng * g.Lp) * (size_t)g.esz;
                 if (bytes > 160 * 1024) continue;
-                const auto take = [&] { g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; g.pitch = mode ? rpitch : 0; };
+                const auto take = [&] { g.CH = ch; g.NG = ng; g.bufsz = bufsz; g.lds_bytes = bytes; g.ok = true; g.pitch = mode == 1 ? rpitch : 0; g.rowpad = mode == 2 ? RPAD : 0; };
                 if (!by_model) {
                     const double score = 1.0 / (std::max(1.0, 0.2 * ways) + 32.0 / (rows * ng)) + 1e-6 * ch;
                     if (score > best_score) { best_score = score; take(); }
@@ -1290,8 +1340,10 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
     b.phi0m1 = (int)a.phi0m1;
     b.bufsz = (int)g.bufsz;
     b.pitch = g.pitch;
+    b.rowpad = g.rowpad;
     b.steps = g.steps;
     b.vstore = tunables().fir_mm_vstore;
+    b.ablate = MDSP_DBG(ablate);
     const int nw = g.NBW * g.NG + g.nd + g.ns;
     auto kern = polyphase_mfma_kernel<R, CS, CH, T>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB

@@ -560,7 +560,7 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     assert geo(160, 147, 5120, _lib.F64, _lib.F32)[0] == 0                                                  # Float64 taps on a Float32 signal
     assert geo(160, 147, 5120, _lib.F64, _lib.C64)[-1] == 160 * 1024                                        # ComplexF64: 16 rows per wave, unpadded output rows: exactly the LDS
     assert geo(147, 160, 5881, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
-    assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:7] == [1, 1, 147, 160, 10, 1, 16]                       # 48 kHz -> 44.1 kHz (rows staged one by one: M = 160 is a multiple of 32)
+    assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:7] == [1, 1, 147, 160, 10, 1, 16]                       # 48 kHz -> 44.1 kHz (padded rows: M = 160 is a multiple of 32)
     assert geo(160, 441, 16001, _lib.F32, _lib.F32)[7] == 2                                                 # 44.1 kHz -> 16 kHz
     assert geo(1, 2, 48 * 4 + 1, _lib.F32, _lib.F32)[6] == 56                                               # more than 192 window positions: taps fetched per tile
     assert geo(1, 2, 5000, _lib.F32, _lib.F32)[0] == 0                                                      # more than 4096 window positions
@@ -590,9 +590,11 @@ def test_matrix_core_polyphase_geometry_is_consistent():
         dw = (esz // 4) * CS
         pitch = -(-((Mr + 4 * T + 4) * dw) // 256) * 256 + 4               # rows staged one by one (sample strides that are multiples of 8) ...
         lin = -(-((rows * Mr + Mr + 4 * T + 4) * dw) // 256) * 256           # ... or the tile as one run
+        def prun(S):   # ... or one run with 4 dwords of padding behind every 256-dword granule (round 3)
+            return -(-((-(-((rows * Mr + Mr + 4 * T + 4) * dw) // 256) + 1) * 260) // 256) * 256
         def total(padded, rowwise):
-            ibuf = -(-(rows * pitch) // 256) * 256 if rowwise else lin
+            ibuf = -(-(rows * pitch) // 256) * 256 if rowwise == 1 else prun(rowwise // 2) if rowwise >= 2 else lin
             return 2 * 4 * ibuf + 2 * rows * (Lr * CS if NB == 1 else 16 * NB * CS + (16 // esz if padded else 0)) * esz
-        need = next((v for v in (total(True, False), total(True, True), total(False, False), total(False, True)) if v == lds), None)
+        need = next((v for v in [total(pd, rw) for pd in (True, False) for rw in (0, 1, 2, 4, 8)] if v == lds), None)
         assert need is not None and lds <= 160 * 1024
     assert fits > 300
