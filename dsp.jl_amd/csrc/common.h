@@ -123,6 +123,8 @@ struct Tunables {
     int fir_mm = -1;                    // MDSP_FIR_MM=0            : matrix-core polyphase kernel off (default: wherever the shape fits)
     int fir_mm_rows = -1;               // MDSP_FIR_MM_ROWS=0|1|2   : its tiles staged as one run / row by row / one run with padded rows (default: by cost; padded rows
                                         //                            where the rows' sample stride is bank-hostile)
+    int fir_mm_prio = -1;               // MDSP_FIR_MM_PRIO=0|1     : DMA and store waves of the matrix-core kernel at normal / raised priority (default: raised where a
+                                        //                            multiplying wave owns one column block)
     int fir_mm_rpad = 0;                // MDSP_FIR_MM_RPAD         : dwords of padding behind a granule of a padded run (0 = 4)
     int fir_mm_vstore = 1;              // MDSP_FIR_MM_VSTORE       : 0 = the matrix-core kernel stores output rows that are not whole vectors element by element (round 2)
     int fir_mm_pad = -1;                // MDSP_FIR_MM_PAD          : 0 = output rows of the matrix-core kernel's LDS tile without their 16 bytes of padding

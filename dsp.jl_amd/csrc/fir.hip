@@ -316,6 +316,7 @@ struct FirMArgs {
     int rowpad;                  // > 0 (with pitch == 0): one run per tile, staged in the same 256-dword DMA granules as the plain run, with rowpad dwords of
                                  // padding behind every granule (dword d of the tile sits at d + (d / 256) rowpad): rows whose stride is bank-hostile spread
                                  // over the banks without the duplicated window tails of the row-staged form
+    int memprio;                 // 1: the DMA and store waves run at raised priority (s_setprio)
     int vstore;                  // 1: output rows that are not whole vectors leave as gathered wide stores (0: element by element, round 2)
     int ablate;                  // MDSP_DEBUG_KNOBS builds (MDSP_ABLATE): 1 no tile DMA after the first, 2 no matrix products, 4 no output stores
     int nd, ns;                  // waves that issue the LDS-DMA / that store, after the multiplying waves
@@ -361,7 +362,8 @@ template <> struct Mm<double> {
 
 // R: Float32 / Float64 arithmetic (signal and taps of that type); CS: 1 real signal, 2 complex signal (interleaved pairs: the two parts
 // are two products against the same taps); CH: 16-row chunks per multiplying wave (independent accumulators); T: k-steps of four taps
-template <typename R, int CS, int CH, int T>
+// RP: padded runs (a separate instantiation: the two forms of the product loop in one function cost the plain form 20 - 70 VGPRs)
+template <typename R, int CS, int CH, int T, bool RP = false>
 __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     typedef typename Mm<R>::acc_t acc_t;
     constexpr int DW = (int)(sizeof(R) / 4) * CS;   // dwords per sample
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     const int ncomp = a.NBW * a.NG;
     const bool is_comp = wave < ncomp, is_dma = wave >= ncomp && wave < ncomp + a.nd, is_store = wave >= ncomp + a.nd;
     const int wb0 = wave % a.NBW, wg = wave / a.NBW;
+    if (!is_comp && a.memprio) __builtin_amdgcn_s_setprio(3);   // the memory waves' few instructions go first: a late DMA or store holds the whole tile up
     // H: this wave's taps, in registers for the whole kernel (T k-steps) -- or, for filters too long for that (T = 0), fetched from the
     // bank in L2 for every tile (a dword per lane and k-step, beside the four to eight MFMAs it feeds)
     constexpr int TR = T ? T : 1;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     // again -- to rows pitch = 256 g + 4 dwords apart (two-way conflicts at worst); the duplicates come from L2.  (Round 3: where a window is
     // shorter than a granule the padded run -- rowpad, below -- replaces this form.)
     const int rgran = a.pitch ? (a.pitch - 4) / 256 : 0;                    // 256-dword granules per row
-    const int padE = a.rowpad / (int)(sizeof(R) / 4);                          // R elements of padding behind a granule (padded runs)
+    const int padE = RP ? a.rowpad / (int)(sizeof(R) / 4) : 0;                 // R elements of padding behind a granule (padded runs)
     const int zpitch = a.pitch ? a.pitch / (int)(sizeof(R) / 4) : a.Mr * CS;   // R elements between rows (padded runs: + padE from segment to segment)
     const auto dma = [&](int64_t tile, int buf) {
         if (!is_dma || !dma_ok(tile)) return;
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
         if (a.pitch == 0) {
             const int nzd = (nq * a.Mr + a.Mr + wtail) * DW;   // dwords of the tile
             for (int i = wave - ncomp; 256 * i < nzd; i += a.nd) {   // granules of 256 dwords, round-robin over the DMA waves
-                const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + (256 + a.rowpad) * i) * 4u;   // (padded runs: rowpad dwords between granules)
+                const unsigned dst = lds0 + (unsigned)(buf * a.bufsz + (256 + (RP ? a.rowpad : 0)) * i) * 4u;   // (padded runs: rowpad dwords between granules)
                 if (256 * (int64_t)(i + 1) <= exist) mm_dma256(rs, dst, (256 * i + 4 * lane) * 4);
                 else {
 #pragma unroll
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                 R v = (R)0;
                 if (zi < a.hl) v = hc[zi * CS + part];
                 else if (zi - a.hl < a.xlen) v = xc[(zi - a.hl) * CS + part];
-                zw[row * zpitch + e + (a.rowpad > 0 ? ((e * (int)(sizeof(R) / 4)) >> 8) * padE : 0)] = v;
+                zw[row * zpitch + e + (RP ? ((e * (int)(sizeof(R) / 4)) >> 8) * padE : 0)] = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);
         }
@@ -562,12 +565,12 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     const int row = ra * lj + rbase(c);
-                    ap[c] = zt + row * zpitch + (a.rowpad > 0 ? (((row * a.Mr + c0 + lk) * DW) >> 8) * padE : 0) + (c0 + lk) * CS;
+                    ap[c] = zt + row * zpitch + (RP ? (((row * a.Mr + c0 + lk) * DW) >> 8) * padE : 0) + (c0 + lk) * CS;
                 }
                 // padded runs (T != 0, a window shorter than a granule: it meets ONE pad at most): the positions behind the granule boundary sit
                 // padE elements further on -- a per-lane choice between two base pointers, so that every read keeps its immediate offset (computed
                 // addresses cost the read-ahead of the A operands: measured 1.08 against 0.78 ms at 147//160)
-                if (T != 0 && a.rowpad > 0) {
+                if constexpr (T != 0 && RP) {
                     // dwords from this lane's first window position to the next granule boundary (16 rows are a whole number of granules,
                     // so the distance is the same for every chunk)
                     const int th = 256 - (((ra * lj) * a.Mr + c0 + lk) * DW & 255);
@@ -1264,7 +1267,7 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f) {
     for (int mode = 0; mode < 3; ++mode) {   // 0: one linear run per tile, 1: row by row, 2: one run with padded rows
         if (mode >= 1 && ways_lin < 4 && fm < 0) continue;
         if (fm >= 0 && mode != fm) continue;
-        const bool pad_ok = !((g.Mr * dw) & 15) && g.T != 0 && g.T * dw <= 64;   // 16 rows are whole granules; taps in registers; a window (4 T dw dwords) meets one pad at most
+        const bool pad_ok = !((g.Mr * dw) & 15) && g.T != 0 && g.T <= 32 && g.T * dw <= 64;   // 16 rows are whole granules; taps in registers; a window (4 T dw dwords) meets one pad at most
         if (mode == 2 && !pad_ok) continue;
         if (mode == 1 && fm < 0 && pad_ok) continue;   // the padded run replaces the row-staged form wherever it applies
         const double ways = mode == 1 ? ways_row : mode == 2 ? ways_pad : ways_lin;
@@ -1324,7 +1327,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
 }
 bool fir_mm_shape_ok(const mdsp_fir_s* f) { return fir_mm_geo(f).ok; }
 
-template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
+template <typename R, int CS, int CH, int T, bool RP = false> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
     FirMArgs b{};
     b.x = a.x;
     b.hist = a.hist;
@@ -1343,9 +1346,12 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
     b.rowpad = g.rowpad;
     b.steps = g.steps;
     b.vstore = tunables().fir_mm_vstore;
+    // measured on 19 ratio x type combinations (profiles/r03l_fir_memprio.json): +2 ... +16 % (config 5 1.86 -> 1.76 ms) wherever a wave owns one column
+    // block; -4 % where it walks several (441//160), which keep the default priority
+    b.memprio = tunables().fir_mm_prio >= 0 ? tunables().fir_mm_prio : (g.NBW == g.NB ? 1 : 0);
     b.ablate = MDSP_DBG(ablate);
     const int nw = g.NBW * g.NG + g.nd + g.ns;
-    auto kern = polyphase_mfma_kernel<R, CS, CH, T>;
+    auto kern = polyphase_mfma_kernel<R, CS, CH, T, RP>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB
     int dev = 0;
     MDSP_HIP(hipGetDevice(&dev));
@@ -1367,13 +1373,13 @@ template <typename R, int CS, int CH, int T> int fir_mm_launch(mdsp_fir_s* f, co
 template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
     switch (g.T) {
         case 0: return fir_mm_launch<R, CS, CH, 0>(f, a, g, st);
-        case 4: return fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
-        case 8: return fir_mm_launch<R, CS, CH, 8>(f, a, g, st);
-        case 12: return fir_mm_launch<R, CS, CH, 12>(f, a, g, st);
-        case 16: return fir_mm_launch<R, CS, CH, 16>(f, a, g, st);
-        case 20: return fir_mm_launch<R, CS, CH, 20>(f, a, g, st);
-        case 24: return fir_mm_launch<R, CS, CH, 24>(f, a, g, st);
-        case 32: return fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
+        case 4: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 4, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
+        case 8: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 8, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 8>(f, a, g, st);
+        case 12: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 12, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 12>(f, a, g, st);
+        case 16: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 16, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 16>(f, a, g, st);
+        case 20: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 20, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 20>(f, a, g, st);
+        case 24: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 24, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 24>(f, a, g, st);
+        case 32: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 32, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
         default:
             if constexpr (sizeof(R) == 4) return g.T == 48 ? fir_mm_launch<R, CS, CH, 48>(f, a, g, st) : fir_mm_launch<R, CS, CH, 64>(f, a, g, st);
             else return fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
