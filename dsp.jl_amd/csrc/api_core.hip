@@ -51,6 +51,8 @@ static void read_tunables_locked() {
     t.wg_per_cu = std::max(0, geti("MDSP_WG_PER_CU", 0));
     t.runs_per_slot = std::max(1, geti("MDSP_RUNS_PER_SLOT", 1));
     t.ols_variant = geti("MDSP_OLS_VARIANT", 0);
+    t.ols_prio = geti("MDSP_OLS_PRIO", 1);
+    t.spec_prio = geti("MDSP_SPEC_PRIO", 1);
     t.welch_variant = geti("MDSP_WELCH_VARIANT", 0);
     t.stft_variant = geti("MDSP_STFT_VARIANT", 1);
     t.rocfft_chunk_mib = std::max(1, geti("MDSP_ROCFFT_CHUNK_MIB", 192));

@@ -112,6 +112,10 @@ struct Tunables {
     int engine = MDSP_ENGINE_AUTO;      // MDSP_ENGINE=fused|rocfft : engine of plans created with MDSP_ENGINE_AUTO
     int wg_per_cu = 0;                  // MDSP_WG_PER_CU           : persistent-grid workgroups per CU (0 = occupancy query / kernel default)
     int runs_per_slot = 1;              // MDSP_RUNS_PER_SLOT       : contiguous runs per transform slot
+    int spec_prio = 1;                  // MDSP_SPEC_PRIO           : Welch / STFT kernels: bit 0 a unit's loads, bit 1 the STFT column stores issued at raised wave
+                                        //                            priority (default 1: Welch 1.374 -> 1.356 ms; STFT loads no effect, stores +5 % time)
+    int ols_prio = 1;                   // MDSP_OLS_PRIO            : overlap-save kernel: bit 0 loads, bit 1 stores issued at raised wave priority (default 1:
+                                        //                            1.799 -> 1.774 ms per 2^30 samples, profiles/r03l_tune_prio.json)
     int ols_variant = 0, welch_variant = 0, stft_variant = 1;   // MDSP_{OLS,WELCH,STFT}_VARIANT : alternative kernel instantiations
     int rocfft_chunk_mib = 192;         // MDSP_ROCFFT_CHUNK_MIB    : intermediates per rocFFT-engine chunk
     int fir_lds_kib = 20;               // MDSP_FIR_LDS_KIB         : staging tile of the fast polyphase kernel

@@ -102,6 +102,7 @@ struct OlsFusedArgs {
     int64_t run_len;        // a slot takes runs of run_len consecutive units ...
     int64_t niter;          // ... runs_per_slot * run_len iterations in total (same for every slot)
     int ablate;             // profiling aid, -DMDSP_DEBUG_KNOBS builds only (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip stores
+    int memprio;            // MDSP_OLS_PRIO: 1 loads, 2 stores, 3 both issued at raised wave priority (s_setprio)
 };
 
 // Raw samples of one unit as they come from HBM: two real blocks (a, b) or one complex block.
@@ -314,7 +315,13 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
                     raw.b[e] = stage[L + ti + T * e];
                 }
             } else if (!MDSP_ABLATED(a, 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti);
-        } else if constexpr (!PREFETCH) { if (!MDSP_ABLATED(a, 1)) ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti); }
+        } else if constexpr (!PREFETCH) {
+            if (!MDSP_ABLATED(a, 1)) {
+                if (a.memprio & 1) __builtin_amdgcn_s_setprio(3);
+                ols_issue_loads<R, E, T, CPLX>(raw, a, cur, ti);
+                if (a.memprio & 1) __builtin_amdgcn_s_setprio(0);
+            }
+        }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -361,7 +368,11 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
                 const bool whole = cur.live && (2 * cur.p + 1) < a.nblocks && (2 * cur.p + 2) * a.L <= a.nout;
                 if (whole) ols_store_staged<R, E, T, N>(v, a, cur, ti, reinterpret_cast<float*>(lds));
                 else ols_store<R, E, T, CPLX>(v, a, cur, ti);
-            } else ols_store<R, E, T, CPLX>(v, a, cur, ti);
+            } else {
+                if (a.memprio & 2) __builtin_amdgcn_s_setprio(3);
+                ols_store<R, E, T, CPLX>(v, a, cur, ti);
+                if (a.memprio & 2) __builtin_amdgcn_s_setprio(0);
+            }
         }
         cur = nxt;
     }
@@ -1257,6 +1268,7 @@ static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int6
     a.run_len = 1;
     a.niter = 0;
     a.ablate = MDSP_DBG(ablate);
+    a.memprio = tunables().ols_prio;
     if (cplx) return dbl ? launch_fused<double, true>(plan->nfft, a, plan->variant, s) : launch_fused<float, true>(plan->nfft, a, plan->variant, s);
     return dbl ? launch_fused<double, false>(plan->nfft, a, plan->variant, s) : launch_fused<float, false>(plan->nfft, a, plan->variant, s);
 }

@@ -197,6 +197,7 @@ struct SpecArgs {
     int n, nout, onesided;
     int64_t run_len, niter;  // unit schedule: runs of run_len consecutive units per slot, niter iterations per slot
     int ablate;              // profiling aid (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip accumulate/stores
+    int memprio;             // MDSP_SPEC_PRIO: 1 = a unit's loads (Welch) / loads and stores (STFT) are issued at raised wave priority
     int accumulate;          // STFT PSD mode: add to the output column instead of overwriting it (multitaper)
     int ntapers;             // > 0: multitaper PSD in one launch (stft_pair_kernel<MT>): win holds ntapers windows of n doubles, rinv their 1/r
     const double* rinv;
@@ -397,7 +398,11 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
         const int64_t f = fcur;
         walk();
         fcur = unit_cur(it + 1 < niter);
-        if constexpr (!PREFETCH) issue(f);
+        if constexpr (!PREFETCH) {
+            if (a.memprio & 1) __builtin_amdgcn_s_setprio(3);
+            issue(f);
+            if (a.memprio & 1) __builtin_amdgcn_s_setprio(0);
+        }
         cx<R> v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -409,6 +414,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
         if constexpr (C::P > 1 && NBUF > 1 && ((C::P - 1) % NBUF) != 0) fft::wg_sync<T>();  // NBUF == 1: wg_fft already ends every exchange with a barrier
         // column store: bins k = t + T*e < nout, contiguous across lanes
         const bool live = f < a.K;
+        if (a.memprio & 2) __builtin_amdgcn_s_setprio(3);
         if constexpr (PSD) {
             R* col = static_cast<R*>(a.out) + ch * a.chs + f * a.ldo;
             const __amdgpu_buffer_rsrc_t wr = io::make_rsrc(col, live ? (int64_t)a.nout * (int64_t)sizeof(R) : 0);
@@ -428,6 +434,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_fused_kernel(SpecArgs 
             const __amdgpu_buffer_rsrc_t wr = io::make_rsrc(col, live ? (int64_t)a.nout * (int64_t)sizeof(cx<R>) : 0);
             io::store_window<cx<R>, E, T>([&](int e) { return v[e]; }, wr, 0, t);
         }
+        if (a.memprio & 2) __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -690,6 +697,7 @@ template <typename R, int N> struct Geo {
 // runs of consecutive units per slot (default: one run = fully contiguous), identical trip count for every slot
 void set_schedule(SpecArgs& a, int64_t nunits, int64_t nslots) {
     a.ablate = MDSP_DBG(ablate);
+    a.memprio = tunables().spec_prio;
     const int64_t runs = tunables().runs_per_slot;
     a.run_len = std::max<int64_t>(1, cdiv(nunits, nslots * runs));
     a.niter = cdiv(cdiv(nunits, a.run_len), nslots) * a.run_len;
@@ -1092,10 +1100,12 @@ __global__ __launch_bounds__(N / 16, 2) void welch_half3_kernel(SpecArgs a) {
     // all four half-frame streams of unit u: Q = (a lo | b lo), F = (a hi | b hi); `carry`: a lo is already in Q (handed over by the predecessor)
     auto load_unit = [&](cx<R> (&Q)[H], cx<R> (&F)[H], bool xa, int64_t u, bool carry) {
         const bool live = u < a.units_per_ch, haveB = live && (2 * u + 1) < a.K;
+        if (a.memprio) __builtin_amdgcn_s_setprio(3);
         if (!carry) ld8(Q, xa, half_rsrc(u, 0, live));
         ld8(Q, !xa, half_rsrc(u, 1, haveB));
         ld8(F, xa, half_rsrc(u, 1, live));
         ld8(F, !xa, half_rsrc(u, 2, haveB));
+        if (a.memprio) __builtin_amdgcn_s_setprio(0);
     };
     cx<R> P1[H], P2[H];
     int64_t u = unit_cur(a.niter > 0);
