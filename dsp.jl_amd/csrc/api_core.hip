@@ -58,6 +58,7 @@ static void read_tunables_locked() {
     t.rocfft_chunk_mib = std::max(1, geti("MDSP_ROCFFT_CHUNK_MIB", 192));
     t.fir_lds_kib = std::max(4, geti("MDSP_FIR_LDS_KIB", 20));
     t.arb_nch = geti("MDSP_ARB_NCH", 4);
+    t.arb_prio = geti("MDSP_ARB_PRIO", 0);
     t.arb_tile = std::max(0, geti("MDSP_ARB_TILE", 0));
     t.arb_scan = geti("MDSP_ARB_SCAN", 1);
     if (const char* e = getenv("MDSP_ARB_SCAN_MIN")) t.arb_scan_min = atoll(e);

@@ -119,6 +119,7 @@ struct Tunables {
     int ols_variant = 0, welch_variant = 0, stft_variant = 1;   // MDSP_{OLS,WELCH,STFT}_VARIANT : alternative kernel instantiations
     int rocfft_chunk_mib = 192;         // MDSP_ROCFFT_CHUNK_MIB    : intermediates per rocFFT-engine chunk
     int fir_lds_kib = 20;               // MDSP_FIR_LDS_KIB         : staging tile of the fast polyphase kernel
+    int arb_prio = 0;                   // MDSP_ARB_PRIO            : FIRArbitrary: the prologue of a workgroup at raised wave priority
     int arb_nch = 4, arb_tile = 0;      // MDSP_ARB_NCH / _TILE     : FIRArbitrary channels per group / outputs per workgroup (0 = default)
     int arb_scan = 1;                   // MDSP_ARB_SCAN=0          : serial host recurrence only
     int64_t arb_scan_min = (int64_t)1 << 19;   // MDSP_ARB_SCAN_MIN : outputs from which the device scan is used

@@ -713,6 +713,7 @@ struct ArbArgs {
     int taps_in_lds;
     long long* prof;      // profiling only (MDSP_ARB_PROF): 8 clock64() stamps per workgroup
     int ablate;           // profiling only (MDSP_ABLATE): 1 no phase-A replay, 2 one tap instead of tp, 4 no staging loads, 8 no tap copy
+    int prio;             // MDSP_ARB_PRIO: 1 = the prologue (replay, tap copy, staging) runs at raised wave priority
 };
 
 struct ArbRec {
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
     auto stamp = [&](int k) {
         if (a.prof && tid == 0) a.prof[(int64_t)blockIdx.x * 8 + k] = clock64();
     };
+    if (a.prio) __builtin_amdgcn_s_setprio(3);   // a workgroup in its latency-bound prologue goes first among the co-resident ones
     stamp(0);
     const int64_t x_first = a.tab_x[b0];
     const int64_t z_first = x_first - 1;                                    // z = [history ; x], output n reads z[n-1 .. n-1+tp)
@@ -872,6 +874,7 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
         if (a.span > 0 && c_first < a.nch && !MDSP_ABLATED(a, 4)) stage(c_first, (int)std::min<int64_t>(NCH, a.nch - c_first), u, lanes, a.span);
     }
     __syncthreads();
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
     stamp(3);
     const int64_t nz = (int64_t)rec[arb_rec_slot(cnt - 1)].xrel + a.tp;
     const bool staged = nz <= a.span;                                       // workgroup-uniform
@@ -2038,6 +2041,7 @@ template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, 
     const int64_t taps_bytes = 2 * (int64_t)f->base.tp * f->nphi * (int64_t)sizeof(R);
     a.taps_in_lds = taps_bytes <= 32 * 1024;
     a.ablate = MDSP_DBG(ablate);
+    a.prio = tunables().arb_prio;
     const int nch_max = tunables().arb_nch;   // tuning knob
     // channels per group: the most whose workgroup (trajectory records + interleaved input span of tile * Delta / Nphi + tp
     // samples per channel + tap pairs) stays within 44 KiB of LDS, i.e. leaves >= 3 workgroups per CU; measured on MI355X,
