@@ -402,6 +402,7 @@ struct UpolsArgs {
                          // least P*B - (nb - 1) taps of zeros in front of the samples that matter, see mdsp_ols_exec_range)
     int64_t run_len;     // blocks per run; slot s of S owns blocks [g_begin + s*R*run_len, g_begin + (s+1)*R*run_len), R = 2 runs (real) or 1 (complex)
     int ablate;          // MDSP_DEBUG_KNOBS builds: 1 no input, 2 no transforms, 4 no stores, 8 no spectra loads (results are garbage)
+    int memprio;         // MDSP_OLS_PRIO bit 0: a block's loads (next half window, partition 0's spectrum) issued at raised wave priority
 };
 
 // XDMA (Float32 real signals): the half windows live in a two-slot LDS ring per run.  A block's window is [previous half | new half]; the new
@@ -695,6 +696,7 @@ __global__ __launch_bounds__(N / E, MINW) void upols2_fused_kernel(UpolsArgs a) 
             if constexpr (!CPLX) carryB[e] = nxtB[e];
         }
         // partition 0's spectrum first (it returns first: loads retire in order), then the next block's new halves: in flight for a whole block
+        if (a.memprio & 1) __builtin_amdgcn_s_setprio(3);
         cx<R> hh0[H0REG ? 1 : E];
         if constexpr (!H0REG) {
             if (k >= 0 && !MDSP_ABLATED(a, 8)) io::load_window<cx<R>, E, T>(hh0, io::make_rsrc(Hg, (int64_t)N * (int64_t)sizeof(cx<R>)), 0, t);
@@ -703,6 +705,7 @@ __global__ __launch_bounds__(N / E, MINW) void upols2_fused_kernel(UpolsArgs a) 
             load_half(nxtA, mA + 1, runA && mA + 1 < a.nblocks);
             if constexpr (!CPLX) load_half(nxtB, mB + 1, runB && mB + 1 < a.nblocks);
         }
+        if (a.memprio & 1) __builtin_amdgcn_s_setprio(0);
         cx<R> y[E];
         if (k >= 0) {   // wave-uniform: what the delay line contributes
 #pragma unroll
@@ -971,6 +974,7 @@ int launch_upols_k(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t
     a.g_begin = rg.g0;
     a.x_lo = rg.x_lo;
     a.ablate = MDSP_DBG(ablate);
+    a.memprio = tunables().ols_prio;
     const int64_t nblk = rg.g1 - rg.g0;
     // resident workgroups per CU from the kernel's own resources (hipOccupancyMaxActiveBlocksPerMultiprocessor has answered half of what the
     // hardware admits for LDS-heavy kernels)
