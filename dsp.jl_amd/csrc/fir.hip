@@ -406,7 +406,11 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     if (is_comp) block_setup(wb0);
     const auto tap = [&](int t) -> R {   // H[k = 4 t + lane / 16][j = lane % 16]
         const int i = 4 * t + lk - tap_delta;
-        return (tap_valid && i >= 0 && i < a.tp) ? pf[(int64_t)i * a.L + tap_phase] : (R)0;
+        const bool ok = tap_valid && i >= 0 && i < a.tp;
+        // branch-free: lanes without a tap read the bank's first entry and discard it -- a skipped load is an exec-masked branch per fetch,
+        // and the long-filter mode's eight fetches in flight then come out one by one with a wait between them
+        const R v = pf[ok ? (int64_t)i * a.L + tap_phase : (int64_t)0];
+        return ok ? v : (R)0;
     };
 #pragma unroll
     for (int t = 0; t < TR; ++t) hreg[t] = (T && is_comp) ? tap(t) : (R)0;

@@ -3,8 +3,8 @@
 #   fields: mm,wg,p,nd,ns,ng,ch,pad,rows,vstore,rpad,prio
 mkdir -p gpurun_out/prio
 echo "== tests"
-timeout 900 python -m pytest tests/test_gpu_boundary.py tests/test_gpu_fullsize.py -x -q -m gpu -k "polyphase or matrix_core or resample or fir or config5" 2>&1 | tail -3
-V="1,0,0;1,0,0,0,0,0,0,-1,-1,1,0,1"
+[ -n "$PRIO_SKIP_TESTS" ] || timeout 900 python -m pytest tests/test_gpu_boundary.py tests/test_gpu_fullsize.py -x -q -m gpu -k "polyphase or matrix_core or resample or fir or config5" 2>&1 | tail -3
+V="${PRIO_V:-1,0,0,0,0,0,0,-1,-1,1,0,0;1,0,0,0,0,0,0,-1,-1,1,0,1}"
 for c in ${PRIO_CASES:-f32:160/147:28 f32:147/160:26 f32:2/1:26 f32:1/2:26 f32:3/2:26 f32:2/3:26 f32:4/1:26 f32:1/4:26 f32:1/8:26 f32:441/160:26 f64:160/147:26 f64:2/1:26 f64:1/2:26 c32:160/147:26 c32:2/1:26 c32:1/2:26 c32:147/160:26 c64:160/147:26 c64:2/1:26}; do
   IFS=: read dt r lg <<< "$c"
   echo "== $dt $r 2^$lg"
