@@ -324,6 +324,9 @@ struct FirMArgs {
     int phi0m1;                  // phi0 - 1: output j of a row has phase (phi0-1 + j M) mod L and window start (phi0-1 + j M) div L
 };
 
+#ifndef MDSP_FIR_TAP_CARRY
+#define MDSP_FIR_TAP_CARRY 1   // long-filter mode, ComplexF64: fetched taps carried raw into the next group of k-steps (0: masked next to the fetch)
+#endif
 typedef int mm_i4 __attribute__((ext_vector_type(4)));
 // 64 consecutive dwords of a raw buffer straight into LDS (no VGPRs, no ds_write pass): lane l moves the dword at byte offset voff
 // to lds_byte + 4 l.  Issued by hand: the compiler's wait-count bookkeeping makes every later ds_read wait for a DMA it knows of
@@ -597,13 +600,43 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                             for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[t], acc[p][c]);
                 } else {
                     // steps is a multiple of 8: the taps of eight k-steps are fetched while the previous eight are multiplied (a fetch is an L2 round
-                    // trip; a wave that waits for it in front of every group leaves its SIMD's matrix pipe idle half of the time)
+                    // trip; a wave that waits for it in front of every group leaves its SIMD's matrix pipe idle half of the time).  The fetched
+                    // words are carried RAW into the next group and only then masked: a select next to the fetch would wait for it on the spot.
+                    // Measured against masking next to the fetch, alternating processes on one box (tools/r03_session35.sh): ComplexF64 3//8 4.94 -> 4.37 ms,
+                    // 1//4 2.99 -> 2.76, 1//8 5.16 -> 5.04; Float32 1//8 +3 %, but 1//16 -7 %, Float64 1//16 -4 %: the carried form for ComplexF64 only.
+                    if constexpr (MDSP_FIR_TAP_CARRY && CS == 2 && sizeof(R) == 8) {
+                    R hraw[8];
+                    unsigned okm = 0;
+                    const auto fetch = [&](int tb) {
+                        okm = 0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = 4 * (tb + u) + lk - tap_delta;
+                            const bool ok = tap_valid && i >= 0 && i < a.tp;
+                            hraw[u] = pf[ok ? (int64_t)i * a.L + tap_phase : (int64_t)0];
+                            okm |= ok ? 1u << u : 0u;
+                        }
+                    };
+                    fetch(0);
+                    for (int t0 = 0; t0 < steps; t0 += 8) {
+                        R h[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) h[u] = (okm >> u & 1u) ? hraw[u] : (R)0;
+                        fetch(t0 + 8 < steps ? t0 + 8 : t0);   // (the last group re-reads its own: no branch around the loads)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+#pragma unroll
+                            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+                    }
+                    } else {
                     R h[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) h[u] = tap(u);
                     for (int t0 = 0; t0 < steps; t0 += 8) {
                         R hn[8];
-                        const int tn = t0 + 8 < steps ? t0 + 8 : t0;   // (the last group re-reads its own: no branch around the loads)
+                        const int tn = t0 + 8 < steps ? t0 + 8 : t0;
 #pragma unroll
                         for (int u = 0; u < 8; ++u) hn[u] = tap(tn + u);
 #pragma unroll
@@ -614,6 +647,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                                 for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
 #pragma unroll
                         for (int u = 0; u < 8; ++u) h[u] = hn[u];
+                    }
                     }
                 }
                 if (16 * wb + lj < a.Lr) {
