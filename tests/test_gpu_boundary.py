@@ -582,6 +582,67 @@ def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "f64", "c32", "c64"])
+@pytest.mark.parametrize("L,M,ntaps", [(147, 160, 5881), (49, 48, 1813), (147, 80, 5439), (147, 320, 5000), (21, 16, 640), (160, 147, 5120), (1, 8, 293), (2, 1, 75)])
+def test_polyphase_matrix_core_round3_forms_are_bit_identical(d, torch, L, M, ntaps, dt):
+    """Round 3's forms of the matrix-core kernel change where samples sit in LDS and when instructions issue, never the arithmetic: padded runs
+    (MDSP_FIR_MM_ROWS=2, the default where the row stride is bank-hostile) against the row-staged form (=1) and the plain run (=0); the tile
+    choice by cost against round 2's rule (MDSP_FIR_MM_NG=8); memory waves at raised / normal priority; gathered wide stores / element stores --
+    bit for bit, with a stream cut at odd places (history tiles, ragged last tile), and against the Float64 oracle."""
+    from fractions import Fraction
+    from dsp_jl_amd import _lib
+    from oracle import stream_filt as osf
+    lib = _lib.lib()
+    tdt, hdt, ldt_h, ldt_x, tol = {"f32": (torch.float32, np.float32, _lib.F32, _lib.F32, 2e-6), "c32": (torch.complex64, np.float32, _lib.F32, _lib.C32, 2e-6),
+                                   "f64": (torch.float64, np.float64, _lib.F64, _lib.F64, 1e-13), "c64": (torch.complex128, np.float64, _lib.F64, _lib.C64, 1e-13)}[dt]
+    out12 = (C.c_int64 * 12)()
+    _lib.check(lib.mdsp_fir_mm_geometry(L, M, ntaps, ldt_h, ldt_x, out12))
+    if not out12[0]:
+        pytest.skip("the shape does not fit the matrix-core kernel in this signal type")
+    rng = np.random.default_rng(L * 977 + M)
+    h = (rng.standard_normal(ntaps) / np.sqrt(ntaps / L)).astype(hdt)
+    nch, n = 2, 150_001
+    g = torch.Generator(device="cuda"); g.manual_seed(L * 3 + M)
+    x = torch.randn((nch, n), generator=g, device="cuda", dtype=tdt)
+    stream = torch.cuda.current_stream().cuda_stream
+    cuts = (0, 3, 40_000, n)
+    knobs = [{}, {"MDSP_FIR_MM_ROWS": 1}, {"MDSP_FIR_MM_ROWS": 0}, {"MDSP_FIR_MM_ROWS": 2}, {"MDSP_FIR_MM_NG": 8}, {"MDSP_FIR_MM_PRIO": 0}, {"MDSP_FIR_MM_PRIO": 1},
+             {"MDSP_FIR_MM_VSTORE": 0}, {"MDSP_FIR_MM_CH": 1}]
+    outs = []
+    try:
+        for kn in knobs:
+            for k, v in kn.items():
+                _lib.set_tunable(k, v)
+            _lib.check(lib.mdsp_fir_mm_geometry(L, M, ntaps, ldt_h, ldt_x, out12))
+            fits = bool(out12[0])
+            if fits:
+                fh = C.c_void_p()
+                _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, ldt_h, ldt_x, nch))
+                pieces = []
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, b - a, C.byref(ol)))
+                    y = torch.empty((nch, ol.value), dtype=tdt, device="cuda")
+                    nw = C.c_int64()
+                    _lib.check(lib.mdsp_fir_exec(fh, x[:, a:].data_ptr(), b - a, n, y.data_ptr(), ol.value, ol.value, C.byref(nw), stream))
+                    torch.cuda.synchronize()
+                    pieces.append(y)
+                outs.append((kn, torch.cat(pieces, dim=1)))
+                _lib.check(lib.mdsp_fir_destroy(fh))
+            for k in kn:
+                _lib.set_tunable(k, None)
+    finally:
+        for k in ("MDSP_FIR_MM_ROWS", "MDSP_FIR_MM_NG", "MDSP_FIR_MM_PRIO", "MDSP_FIR_MM_VSTORE", "MDSP_FIR_MM_CH"):
+            _lib.set_tunable(k, None)
+    assert len(outs) >= 5
+    for kn, y in outs[1:]:
+        assert torch.equal(y, outs[0][1]), kn
+    m = 15_000
+    xr = x[1, :m].cpu().numpy()
+    ref = osf.FIRFilter(h.astype(np.float64), Fraction(L, M)).filt(xr.astype(np.complex128 if np.iscomplexobj(xr) else np.float64))
+    assert relerr(outs[0][1][1, :len(ref)].cpu().numpy(), ref) < tol
+
+
+@pytest.mark.gpu
 def test_polyphase_kernel_choice(d, torch):
     # BASELINE config 5's shape runs on the matrix-core kernel, Float64 on
     # the matrix-core kernel in Float64, mixed precisions on the generic one -- a silent fallback would show up here, not as a slow benchmark.
