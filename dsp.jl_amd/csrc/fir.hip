@@ -1237,7 +1237,14 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f) {
                 for (int i = 0; i < 16; ++i)
                     for (int k = 0; k < 2; ++k) worst = std::max(worst, ++cnt[(int)((i * mr + k) & 31)]);
             }
-            const double score = (double)(rb * f->L) / worst + 1e-3 * rb;
+            double score = (double)(rb * f->L) / worst + 1e-3 * rb;
+            // rows short enough for the taps to stay in registers (single-chunk waves) run up to twice as fast per k-step as rows whose taps are
+            // fetched per tile (profiles/r03o_fir_register_taps.json): 1//8 with 293 taps takes 11 outputs per row (94 k-steps) instead of 15 (104)
+            if (tunables().fir_mm_t64 != 0) {
+                const int64_t st = cdiv(f->tp + ((f->L - 1) + (int64_t)(std::min<int64_t>(rb * f->L, 16) - 1) * f->M) / f->L, (int64_t)4);
+                const int64_t treg = g.esz == 4 ? 96 : (g.CS == 1 ? 48 : 32);
+                if (st <= treg) score *= 1.6;   // (2.0 takes 9 of 16 columns for ComplexF64 3//8: measured 14 % slower than fetching with 15)
+            }
             if (score > best) { best = score; g.RB = rb; }
         }
     }
@@ -1248,6 +1255,26 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f) {
     if (steps > 1024 || (int64_t)(f->L + (int64_t)(g.Lr + 16) * f->M) * f->L >= ((int64_t)1 << 32)) return g;   // (the multiply-high quotients stay exact)
     g.NBW = std::min(g.NB, 12);   // more than 12 column blocks (L > 192): a wave takes several, with their taps fetched per tile
     if (g.NBW < g.NB) g.NBW = (int)cdiv((int64_t)g.NB, cdiv((int64_t)g.NB, (int64_t)12));   // as even as it gets
+    // Taps in registers whenever SOME chunk count admits it (round 3): a wave that carries fewer chunks of 16 rows has fewer accumulators and
+    // room for more taps -- Float32: 48 k-steps with four chunks, 64 with two, 96 with one (ComplexF32 64 / 96); Float64 32 / 48 (ComplexF64
+    // 24 / 32).  Fetching the taps per tile instead (T = 0) costs far more than the smaller tile: 1//4 (56 steps) 0.67 -> 0.46 ms with two
+    // chunks, profiles/r03o_fir_register_taps.json.  MDSP_FIR_MM_T64=0: round 2's limits.
+    const auto tmax_of = [&](int ch) {
+        if (g.esz == 4) return g.CS == 1 ? (ch >= 4 ? 48 : ch == 2 ? 64 : 96) : (ch >= 2 ? 64 : 96);   // (112 steps spill 43 registers: slower than fetching)
+        return g.CS == 1 ? (ch >= 2 ? 32 : 48) : (ch >= 2 ? 24 : 32);
+    };
+    bool regs = false;
+    if (g.NBW == g.NB && tunables().fir_mm_t64 != 0 && steps > tmax_of(chmax)) {
+        for (int ch = chmax / 2; ch >= 1 && !regs; ch /= 2)
+            if (steps <= tmax_of(ch)) {
+                chmax = ch;
+                regs = true;
+            }
+    }
+    if (regs) {
+        g.T = steps <= 64 ? fir_mm_tsel(steps) : steps <= 80 ? 80 : 96;
+        g.steps = g.T;
+    } else
     if (steps > (g.esz == 8 ? (g.CS == 2 ? 24 : 32) : (g.CS == 2 ? 64 : 48)) || g.NBW < g.NB) {   // (beyond: too many registers -- measured: ComplexF64 at T = 32 and Float32 at T = 64 spill and lose 40 - 50 %)   // the taps do not fit registers (T, Float64 2 T, VGPRs): fetched per tile
         g.T = 0;
         g.steps = (int)cdiv(steps, (int64_t)8) * 8;
@@ -1422,6 +1449,15 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
         case 24: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 24, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 24>(f, a, g, st);
         case 32: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 32, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
         default:
+            if constexpr (CH == 1) {   // the long register forms exist for single-chunk waves only
+                if constexpr (sizeof(R) == 4) {
+                    if (g.T == 80) return fir_mm_launch<R, CS, CH, 80>(f, a, g, st);
+                    if (g.T == 96) return fir_mm_launch<R, CS, CH, 96>(f, a, g, st);
+                } else if constexpr (CS == 1) {
+                    if (g.T == 48) return fir_mm_launch<R, CS, CH, 48>(f, a, g, st);
+                }
+            }
+            if (g.T > 64 || (sizeof(R) == 8 && g.T > 32)) MDSP_FAIL(MDSP_ERR_ASSERTION, "no matrix-core instantiation for %d k-steps", g.T);
             if constexpr (sizeof(R) == 4) return g.T == 48 ? fir_mm_launch<R, CS, CH, 48>(f, a, g, st) : fir_mm_launch<R, CS, CH, 64>(f, a, g, st);
             else return fir_mm_launch<R, CS, CH, 32>(f, a, g, st);
     }

@@ -528,7 +528,7 @@ def test_matrix_core_tile_choice_round3():
             assert new["ok"] and new["lds"] <= 160 * 1024
             assert new["NG"] % 4 == 0 or new["NG"] > old["NG"], (L, M, old, new)      # every SIMD gets a multiplying wave (or at least more of them do)
             assert new["rows"] * 2 >= old["rows"], (L, M, old, new)                   # ... without giving up more than half of the tile
-        assert geo(1, 8, 293) == dict(ok=1, NB=1, NG=4, CH=2, nd=2, ns=4, lds=144384, rows=128)
+        assert geo(1, 8, 293) == dict(ok=1, NB=1, NG=8, CH=1, nd=2, ns=4, lds=105472, rows=128)   # 11 outputs per row: 94 k-steps, taps in registers
         assert geo(1, 2, 75)["NG"] == 6 and geo(1, 2, 75)["CH"] == 4                # measured: the large tile wins here (0.45 against 0.53 ms)
         for L, M, hlen in ((2, 1, 75), (3, 2, 111), (4, 1, 149), (5, 3, 185)):
             g = geo(L, M, hlen)
@@ -562,7 +562,8 @@ def test_matrix_core_polyphase_geometry_is_consistent():
     assert geo(147, 160, 5881, _lib.F64, _lib.C64)[0] == 0                                                  # tile does not fit the LDS
     assert geo(147, 160, 5881, _lib.F32, _lib.F32)[:7] == [1, 1, 147, 160, 10, 1, 16]                       # 48 kHz -> 44.1 kHz (padded rows: M = 160 is a multiple of 32)
     assert geo(160, 441, 16001, _lib.F32, _lib.F32)[7] == 2                                                 # 44.1 kHz -> 16 kHz
-    assert geo(1, 2, 48 * 4 + 1, _lib.F32, _lib.F32)[6] == 56                                               # more than 192 window positions: taps fetched per tile
+    assert geo(1, 2, 48 * 4 + 1, _lib.F32, _lib.F32)[6:8] == [64, 2]                                        # more than 192 window positions: two chunks per wave, 64 k-steps of taps in registers (round 3)
+    assert geo(1, 2, 100 * 4 + 1, _lib.F32, _lib.F32)[6] == 112                                             # more than 384: taps fetched per tile
     assert geo(1, 2, 5000, _lib.F32, _lib.F32)[0] == 0                                                      # more than 4096 window positions
     rng = np.random.default_rng(42)
     fits = 0
@@ -584,7 +585,7 @@ def test_matrix_core_polyphase_geometry_is_consistent():
         assert NB == -(-Lr // 16) and 1 <= NG <= 8 and NBW * NG + nd + ns <= 16 and nd >= 1 and ns >= 1
         assert CS == (2 if xdt in (_lib.C32, _lib.C64) else 1) and CH in ((4, 2, 1) if (not dbl and CS == 1) else (2, 1))
         dmax = ((Lq - 1) + (min(Lr, 16) - 1) * Mq) // Lq
-        assert 4 * T >= tp + dmax and T <= 1024 and (T <= (32 if dbl else 64) or T % 8 == 0)   # every tap of every column of a block has a k-step
+        assert 4 * T >= tp + dmax and T <= 1024 and (T <= (48 if dbl else 96) or T % 8 == 0)   # every tap of every column of a block has a k-step
         esz = 8 if dbl else 4
         rows = 16 * CH * NG
         dw = (esz // 4) * CS
