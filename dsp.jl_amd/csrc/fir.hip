@@ -1218,8 +1218,9 @@ struct FirMGeo {
     size_t lds_bytes = 0;
 };
 int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : steps <= 32 ? 32 : steps <= 48 ? 48 : 64; }
-FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f) {
+FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_regs: round 3's register-tap rules (fewer chunks / shorter rows)
     FirMGeo g;
+    const bool t64 = allow_regs && tunables().fir_mm_t64 != 0;
     // element type: signal and compute type must agree (Float32 taps x Float32 samples, or Float64 arithmetic on Float64 samples)
     if (f->acc_double != dtype_is_double(f->x_dtype)) return g;
     g.esz = f->acc_double ? 8 : 4;
@@ -1240,7 +1241,7 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f) {
             double score = (double)(rb * f->L) / worst + 1e-3 * rb;
             // rows short enough for the taps to stay in registers (single-chunk waves) run up to twice as fast per k-step as rows whose taps are
             // fetched per tile (profiles/r03o_fir_register_taps.json): 1//8 with 293 taps takes 11 outputs per row (94 k-steps) instead of 15 (104)
-            if (tunables().fir_mm_t64 != 0) {
+            if (t64) {
                 const int64_t st = cdiv(f->tp + ((f->L - 1) + (int64_t)(std::min<int64_t>(rb * f->L, 16) - 1) * f->M) / f->L, (int64_t)4);
                 const int64_t treg = g.esz == 4 ? 96 : (g.CS == 1 ? 48 : 32);
                 if (st <= treg) score *= 1.6;   // (2.0 takes 9 of 16 columns for ComplexF64 3//8: measured 14 % slower than fetching with 15)
@@ -1264,7 +1265,7 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f) {
         return g.CS == 1 ? (ch >= 2 ? 32 : 48) : (ch >= 2 ? 24 : 32);
     };
     bool regs = false;
-    if (g.NBW == g.NB && tunables().fir_mm_t64 != 0 && steps > tmax_of(chmax)) {
+    if (g.NBW == g.NB && t64 && steps > tmax_of(chmax)) {
         for (int ch = chmax / 2; ch >= 1 && !regs; ch /= 2)
             if (steps <= tmax_of(ch)) {
                 chmax = ch;
@@ -1388,7 +1389,8 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     static thread_local Memo m;
     const uint64_t gen = tunables_generation();
     if (m.L != f->L || m.M != f->M || m.hlen != f->hlen || m.td != f->taps_dtype || m.xd != f->x_dtype || m.gen != gen) {
-        m.g = fir_mm_geo_compute(f);
+        m.g = fir_mm_geo_compute(f, true);
+        if (!m.g.ok) m.g = fir_mm_geo_compute(f, false);   // (longer register forms read a longer window tail: where that no longer fits the LDS, fetch the taps)
         m.L = f->L; m.M = f->M; m.hlen = f->hlen; m.td = f->taps_dtype; m.xd = f->x_dtype; m.gen = gen;
     }
     return m.g;
