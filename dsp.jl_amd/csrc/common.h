@@ -128,6 +128,7 @@ struct Tunables {
     int fir_mm = -1;                    // MDSP_FIR_MM=0            : matrix-core polyphase kernel off (default: wherever the shape fits)
     int fir_mm_rows = -1;               // MDSP_FIR_MM_ROWS=0|1|2   : its tiles staged as one run / row by row / one run with padded rows (default: by cost; padded rows
                                         //                            where the rows' sample stride is bank-hostile)
+    int fir_mm_nblk = 1;                // MDSP_FIR_MM_NBLK=0       : L > 192: the taps of a wave's column blocks fetched per tile (round 2) instead of all in registers
     int fir_mm_t64 = 1;                 // MDSP_FIR_MM_T64=0        : round 2's register limits of the matrix-core polyphase kernel (taps fetched per tile beyond 48 / 64 / 32 / 24
                                         //                            k-steps whatever the chunk count; default: fewer chunks per wave, taps in registers)
     int fir_mm_prio = -1;               // MDSP_FIR_MM_PRIO=0|1     : DMA and store waves of the matrix-core kernel at normal / raised priority (default: raised where a

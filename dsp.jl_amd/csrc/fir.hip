@@ -366,7 +366,8 @@ template <> struct Mm<double> {
 // R: Float32 / Float64 arithmetic (signal and taps of that type); CS: 1 real signal, 2 complex signal (interleaved pairs: the two parts
 // are two products against the same taps); CH: 16-row chunks per multiplying wave (independent accumulators); T: k-steps of four taps
 // RP: padded runs (a separate instantiation: the two forms of the product loop in one function cost the plain form 20 - 70 VGPRs)
-template <typename R, int CS, int CH, int T, bool RP = false>
+// NBLK > 1: a multiplying wave owns NBLK column blocks (L > 192) with the taps of ALL of them in registers (T k-steps each)
+template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1>
 __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     typedef typename Mm<R>::acc_t acc_t;
     constexpr int DW = (int)(sizeof(R) / 4) * CS;   // dwords per sample
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     // bank in L2 for every tile (a dword per lane and k-step, beside the four to eight MFMAs it feeds)
     constexpr int TR = T ? T : 1;
     const int steps = T ? T : a.steps;
-    R hreg[TR];
+    R hreg[NBLK][TR];
     int wb = wb0, c0 = 0, tap_phase = 0, tap_delta = 0;
     bool tap_valid = false;
     const R* pf = static_cast<const R*>(a.pfbT);
@@ -416,7 +417,11 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
         return ok ? v : (R)0;
     };
 #pragma unroll
-    for (int t = 0; t < TR; ++t) hreg[t] = (T && is_comp) ? tap(t) : (R)0;
+    for (int kb = 0; kb < NBLK; ++kb) {
+        if (NBLK > 1 && is_comp && wb0 + kb * a.NBW < a.NB) block_setup(wb0 + kb * a.NBW);
+#pragma unroll
+        for (int t = 0; t < TR; ++t) hreg[kb][t] = (T && is_comp && wb0 + kb * a.NBW < a.NB) ? tap(t) : (R)0;
+    }
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the taps are in (their first use must not look like a pending load inside the tile loop)
     const int64_t cbase = a.d0 - 1;
     const int wtail = 4 * steps + 4;   // samples read past a window start
@@ -561,8 +566,13 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
         if (!MDSP_ABLATED(a, 1)) dma(tile + gridDim.x, cur ^ 1);
         if (prev_tile >= 0 && !MDSP_ABLATED(a, 4)) copy_out(prev_tile, zout + (cur ^ 1) * osz);
         if (is_comp && !MDSP_ABLATED(a, 2)) {
-            for (int b = wb0; b < a.NB; b += a.NBW) {   // (one block per wave unless T = 0)
-                if (T == 0 && a.NBW < a.NB) block_setup(b);
+            constexpr int KBU = T == 0 ? 1 : NBLK;   // blocks of the unrolled inner loop (their taps are registers hreg[kb])
+            for (int b0 = wb0; b0 < a.NB; b0 += KBU * a.NBW)   // (T = 0: the run-time walk over a wave's blocks; else one trip)
+#pragma unroll
+            for (int kb = 0; kb < KBU; ++kb) {   // (one block per wave unless the taps are fetched, T = 0, or NBLK > 1)
+                const int b = b0 + kb * a.NBW;
+                if (b >= a.NB) break;
+                if (a.NBW < a.NB) block_setup(b);
                 acc_t acc[CS][CH];
 #pragma unroll
                 for (int p = 0; p < CS; ++p)
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                         for (int c = 0; c < CH; ++c) {
                             const R* pp = hi ? ap[c] + padE : ap[c];
 #pragma unroll
-                            for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(pp[4 * t * CS + p], hreg[t], acc[p][c]);
+                            for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(pp[4 * t * CS + p], hreg[T == 0 ? 0 : kb][t], acc[p][c]);
                         }
                     }
                 } else if constexpr (T != 0) {
@@ -597,7 +607,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
 #pragma unroll
                         for (int c = 0; c < CH; ++c)
 #pragma unroll
-                            for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[t], acc[p][c]);
+                            for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * t * CS + p], hreg[T == 0 ? 0 : kb][t], acc[p][c]);
                 } else {
                     // steps is a multiple of 8: the taps of eight k-steps are fetched while the previous eight are multiplied (a fetch is an L2 round
                     // trip; a wave that waits for it in front of every group leaves its SIMD's matrix pipe idle half of the time).  The fetched
@@ -1212,6 +1222,7 @@ struct FirMGeo {
     bool ok = false;
     int esz = 4, CS = 1, CH = 4;   // bytes of R; parts per sample; 16-row chunks per multiplying wave
     int RB = 1, Lr = 0, Mr = 0, NB = 0, NBW = 0, NG = 1, T = 0, steps = 0, Lp = 0, nd = 1, ns = 1;   // T = 0: `steps` k-steps with the taps fetched per tile
+    int NBLK = 1;                  // column blocks per multiplying wave whose taps ALL live in registers (L > 192 with T = 12 / 16; else 1)
     int64_t bufsz = 0;             // dwords per sample buffer
     int pitch = 0;                 // dwords between separately staged rows (0: one linear run per tile)
     int rowpad = 0;                // dwords of padding behind every 256-dword granule of a linear run (0: none)
@@ -1272,8 +1283,17 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_re
                 regs = true;
             }
     }
+    // L > 192 (more than 12 column blocks): a wave walks two or three blocks.  With short windows (12 / 16 k-steps: the 32 taps per phase of the
+    // default resampling filters) the taps of ALL its blocks fit registers -- single-chunk waves -- instead of being fetched per tile.
+    const int nblk = (int)cdiv((int64_t)g.NB, (int64_t)g.NBW);
+    if (g.NBW < g.NB && t64 && nblk <= 3 && steps <= 16 && tunables().fir_mm_nblk != 0) {
+        chmax = 1;
+        g.NBLK = nblk;
+        g.T = steps <= 12 ? 12 : 16;
+        g.steps = g.T;
+    } else
     if (regs) {
-        g.T = steps <= 64 ? fir_mm_tsel(steps) : steps <= 80 ? 80 : 96;
+        g.T = (g.esz == 8 && steps > 32 && steps <= 40) ? 40 : steps <= 64 ? fir_mm_tsel(steps) : steps <= 80 ? 80 : 96;   // (Float64: 40 between 32 and 48 -- a shorter window tail)
         g.steps = g.T;
     } else
     if (steps > (g.esz == 8 ? (g.CS == 2 ? 24 : 32) : (g.CS == 2 ? 64 : 48)) || g.NBW < g.NB) {   // (beyond: too many registers -- measured: ComplexF64 at T = 32 and Float32 at T = 64 spill and lose 40 - 50 %)   // the taps do not fit registers (T, Float64 2 T, VGPRs): fetched per tile
@@ -1397,7 +1417,7 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
 }
 bool fir_mm_shape_ok(const mdsp_fir_s* f) { return fir_mm_geo(f).ok; }
 
-template <typename R, int CS, int CH, int T, bool RP = false> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
+template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1> int fir_mm_launch(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
     FirMArgs b{};
     b.x = a.x;
     b.hist = a.hist;
@@ -1421,7 +1441,7 @@ template <typename R, int CS, int CH, int T, bool RP = false> int fir_mm_launch(
     b.memprio = tunables().fir_mm_prio >= 0 ? tunables().fir_mm_prio : (g.NBW == g.NB ? 1 : 0);
     b.ablate = MDSP_DBG(ablate);
     const int nw = g.NBW * g.NG + g.nd + g.ns;
-    auto kern = polyphase_mfma_kernel<R, CS, CH, T, RP>;
+    auto kern = polyphase_mfma_kernel<R, CS, CH, T, RP, NBLK>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB
     int dev = 0;
     MDSP_HIP(hipGetDevice(&dev));
@@ -1441,6 +1461,10 @@ template <typename R, int CS, int CH, int T, bool RP = false> int fir_mm_launch(
 }
 
 template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
+    if constexpr (CH == 1) {
+        if (g.NBLK == 2) return g.T == 12 ? fir_mm_launch<R, CS, CH, 12, false, 2>(f, a, g, st) : fir_mm_launch<R, CS, CH, 16, false, 2>(f, a, g, st);
+        if (g.NBLK == 3) return g.T == 12 ? fir_mm_launch<R, CS, CH, 12, false, 3>(f, a, g, st) : fir_mm_launch<R, CS, CH, 16, false, 3>(f, a, g, st);
+    }
     switch (g.T) {
         case 0: return fir_mm_launch<R, CS, CH, 0>(f, a, g, st);
         case 4: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 4, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
@@ -1456,6 +1480,7 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
                     if (g.T == 80) return fir_mm_launch<R, CS, CH, 80>(f, a, g, st);
                     if (g.T == 96) return fir_mm_launch<R, CS, CH, 96>(f, a, g, st);
                 } else if constexpr (CS == 1) {
+                    if (g.T == 40) return fir_mm_launch<R, CS, CH, 40>(f, a, g, st);
                     if (g.T == 48) return fir_mm_launch<R, CS, CH, 48>(f, a, g, st);
                 }
             }
@@ -1482,7 +1507,9 @@ bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
     if (!g.ok) return false;
     // L > 192 (several column blocks per wave, small tiles): measured slower than the register-tap kernel where that one applies
     // (Float32, 441//160: 1.1 against 2.3 TB/s) and 4 - 5x faster than the generic kernel everything else would take (Float64: 0.26 -> 1.2)
-    if (g.NBW < g.NB && tunables().fir_mm != 1 && fir_fast_ok(f, 2)) return false;
+    // (round 3: with the taps of TWO blocks per wave in registers the matrix cores win -- 320//147 1.11 against 1.32 ms, 250//249 0.70 against 0.92;
+    // with three the register-tap kernel still does: 441//160 1.67 against 2.39)
+    if (g.NBW < g.NB && g.NBLK != 2 && tunables().fir_mm != 1 && fir_fast_ok(f, 2)) return false;
     return true;
 }
 

@@ -667,7 +667,8 @@ def test_polyphase_kernel_choice(d, torch):
     assert path(h.astype(np.float64), 160, 147, _lib.F32, 4, 2 ** 28) == 0      # Float64 taps on a Float32 signal: generic kernel
     assert path(rng.standard_normal(48).astype(np.float32), 2, 1, _lib.F32, 1, 2 ** 26) == 2      # interpolation by 2: a row is 7 rounds
     assert path(rng.standard_normal(64).astype(np.float32), 1, 2, _lib.F32, 1, 2 ** 26) == 2      # decimation by 2
-    assert path(rng.standard_normal(4000).astype(np.float32), 250, 249, _lib.F32, 1, 2 ** 26) == 1  # L > 192 in Float32: the register-tap kernel is the faster one
+    assert path(rng.standard_normal(4000).astype(np.float32), 250, 249, _lib.F32, 1, 2 ** 26) == 2  # L > 192 in Float32, two column blocks per wave: their taps live in registers (round 3: 0.70 against 0.92 ms)
+    assert path(rng.standard_normal(16317).astype(np.float32), 441, 160, _lib.F32, 1, 2 ** 26) == 1  # three blocks per wave: the register-tap kernel is still the faster one (1.67 against 2.39 ms)
     assert path(rng.standard_normal(4000), 250, 249, _lib.F64, 1, 2 ** 26) == 2                     # ... in Float64 the matrix cores (several column blocks per wave)
     assert path(rng.standard_normal(40000).astype(np.float32), 2000, 1999, _lib.F32, 1, 2 ** 26) == 0  # L > 1024
 

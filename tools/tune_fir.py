@@ -60,6 +60,7 @@ def select(v):
     _lib.set_tunable("MDSP_FIR_MM_CH", str(v[6]) if len(v) > 6 else "0")   # cap on the 16-row chunks per multiplying wave
     _lib.set_tunable("MDSP_FIR_MM_PAD", str(v[7]) if len(v) > 7 else "-1")  # 0: unpadded output rows
     _lib.set_tunable("MDSP_FIR_MM_ROWS", str(v[8]) if len(v) > 8 else "-1")  # 0 / 1: tile staged as one run / row by row
+    _lib.set_tunable("MDSP_FIR_MM_NBLK", str(v[13]) if len(v) > 13 else "1")  # 0: L > 192 fetches its taps per tile
     _lib.set_tunable("MDSP_FIR_MM_T64", str(v[12]) if len(v) > 12 else "1")   # 0: 49 .. 64 k-steps fetched per tile
     _lib.set_tunable("MDSP_FIR_MM_PRIO", str(v[11]) if len(v) > 11 else "-1")   # 0 / 1: memory waves at normal / raised priority (-1: the library's choice)
     _lib.set_tunable("MDSP_FIR_MM_RPAD", str(v[10]) if len(v) > 10 else "0")   # dwords of padding behind a granule of a padded run
@@ -74,7 +75,7 @@ def timeit():
 
 
 def vkey(v):
-    return "mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "") + (" ng={}".format(v[5]) if len(v) > 5 else "") + (" ch={}".format(v[6]) if len(v) > 6 else "") + (" pad={}".format(v[7]) if len(v) > 7 else "") + (" rows={}".format(v[8]) if len(v) > 8 else "") + (" vstore={}".format(v[9]) if len(v) > 9 else "") + (" rpad={}".format(v[10]) if len(v) > 10 else "") + (" prio={}".format(v[11]) if len(v) > 11 else "") + (" t64={}".format(v[12]) if len(v) > 12 else "")
+    return "mm={} wg_per_cu={} p={}".format(*v[:3]) + (" nd={} ns={}".format(*v[3:5]) if len(v) > 4 else "") + (" ng={}".format(v[5]) if len(v) > 5 else "") + (" ch={}".format(v[6]) if len(v) > 6 else "") + (" pad={}".format(v[7]) if len(v) > 7 else "") + (" rows={}".format(v[8]) if len(v) > 8 else "") + (" vstore={}".format(v[9]) if len(v) > 9 else "") + (" rpad={}".format(v[10]) if len(v) > 10 else "") + (" prio={}".format(v[11]) if len(v) > 11 else "") + (" t64={}".format(v[12]) if len(v) > 12 else "") + (" nblk={}".format(v[13]) if len(v) > 13 else "")
 
 
 res = {"dtype": DT, "log2n": log2n, "nch": nch, "ratio": f"{L}//{M}", "taps": len(h), "nout": ol.value, "variants": {}}
