@@ -583,11 +583,13 @@ def test_polyphase_matrix_core_kernel_equals_register_tap_kernel(d, torch, L, M,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["f32", "f64", "c32", "c64"])
-@pytest.mark.parametrize("L,M,ntaps", [(147, 160, 5881), (49, 48, 1813), (147, 80, 5439), (147, 320, 5000), (21, 16, 640), (160, 147, 5120), (1, 8, 293), (2, 1, 75)])
+@pytest.mark.parametrize("L,M,ntaps", [(147, 160, 5881), (49, 48, 1813), (147, 80, 5439), (147, 320, 5000), (21, 16, 640), (160, 147, 5120), (1, 8, 293), (2, 1, 75),
+                                       (1, 4, 147), (1, 6, 219), (160, 441, 16001), (320, 147, 10240), (441, 160, 16317), (1, 3, 111), (1, 2, 75)])
 def test_polyphase_matrix_core_round3_forms_are_bit_identical(d, torch, L, M, ntaps, dt):
     """Round 3's forms of the matrix-core kernel change where samples sit in LDS and when instructions issue, never the arithmetic: padded runs
     (MDSP_FIR_MM_ROWS=2, the default where the row stride is bank-hostile) against the row-staged form (=1) and the plain run (=0); the tile
-    choice by cost against round 2's rule (MDSP_FIR_MM_NG=8); memory waves at raised / normal priority; gathered wide stores / element stores --
+    choice by cost against round 2's rule (MDSP_FIR_MM_NG=8); memory waves at raised / normal priority; gathered wide stores / element stores; taps
+    in registers (fewer chunks per wave, shorter rows, several column blocks per wave) against fetched per tile (MDSP_FIR_MM_T64 / _NBLK = 0) --
     bit for bit, with a stream cut at odd places (history tiles, ragged last tile), and against the Float64 oracle."""
     from fractions import Fraction
     from dsp_jl_amd import _lib
@@ -606,8 +608,10 @@ def test_polyphase_matrix_core_round3_forms_are_bit_identical(d, torch, L, M, nt
     x = torch.randn((nch, n), generator=g, device="cuda", dtype=tdt)
     stream = torch.cuda.current_stream().cuda_stream
     cuts = (0, 3, 40_000, n)
-    knobs = [{}, {"MDSP_FIR_MM_ROWS": 1}, {"MDSP_FIR_MM_ROWS": 0}, {"MDSP_FIR_MM_ROWS": 2}, {"MDSP_FIR_MM_NG": 8}, {"MDSP_FIR_MM_PRIO": 0}, {"MDSP_FIR_MM_PRIO": 1},
-             {"MDSP_FIR_MM_VSTORE": 0}, {"MDSP_FIR_MM_CH": 1}]
+    knobs = [{"MDSP_FIR_MM": 1}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_ROWS": 1}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_ROWS": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_ROWS": 2},
+             {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_NG": 8}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_PRIO": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_PRIO": 1},
+             {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_VSTORE": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_CH": 1},
+             {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_T64": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_NBLK": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_T64": 0, "MDSP_FIR_MM_NBLK": 0}]   # (the last three: round 2's register limits / fetched taps)
     outs = []
     try:
         for kn in knobs:
@@ -631,7 +635,7 @@ def test_polyphase_matrix_core_round3_forms_are_bit_identical(d, torch, L, M, nt
             for k in kn:
                 _lib.set_tunable(k, None)
     finally:
-        for k in ("MDSP_FIR_MM_ROWS", "MDSP_FIR_MM_NG", "MDSP_FIR_MM_PRIO", "MDSP_FIR_MM_VSTORE", "MDSP_FIR_MM_CH"):
+        for k in ("MDSP_FIR_MM", "MDSP_FIR_MM_ROWS", "MDSP_FIR_MM_NG", "MDSP_FIR_MM_PRIO", "MDSP_FIR_MM_VSTORE", "MDSP_FIR_MM_CH", "MDSP_FIR_MM_T64", "MDSP_FIR_MM_NBLK"):
             _lib.set_tunable(k, None)
     assert len(outs) >= 5
     for kn, y in outs[1:]:
