@@ -1254,7 +1254,7 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_re
             // fetched per tile (profiles/r03o_fir_register_taps.json): 1//8 with 293 taps takes 11 outputs per row (94 k-steps) instead of 15 (104)
             if (t64) {
                 const int64_t st = cdiv(f->tp + ((f->L - 1) + (int64_t)(std::min<int64_t>(rb * f->L, 16) - 1) * f->M) / f->L, (int64_t)4);
-                const int64_t treg = g.esz == 4 ? 96 : (g.CS == 1 ? 48 : 32);
+                const int64_t treg = g.esz == 4 ? 96 : (g.CS == 1 ? 48 : 40);
                 if (st <= treg) score *= 1.6;   // (2.0 takes 9 of 16 columns for ComplexF64 3//8: measured 14 % slower than fetching with 15)
             }
             if (score > best) { best = score; g.RB = rb; }
@@ -1269,11 +1269,11 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_re
     if (g.NBW < g.NB) g.NBW = (int)cdiv((int64_t)g.NB, cdiv((int64_t)g.NB, (int64_t)12));   // as even as it gets
     // Taps in registers whenever SOME chunk count admits it (round 3): a wave that carries fewer chunks of 16 rows has fewer accumulators and
     // room for more taps -- Float32: 48 k-steps with four chunks, 64 with two, 96 with one (ComplexF32 64 / 96); Float64 32 / 48 (ComplexF64
-    // 24 / 32).  Fetching the taps per tile instead (T = 0) costs far more than the smaller tile: 1//4 (56 steps) 0.67 -> 0.46 ms with two
+    // 24 / 40).  Fetching the taps per tile instead (T = 0) costs far more than the smaller tile: 1//4 (56 steps) 0.67 -> 0.46 ms with two
     // chunks, profiles/r03o_fir_register_taps.json.  MDSP_FIR_MM_T64=0: round 2's limits.
     const auto tmax_of = [&](int ch) {
         if (g.esz == 4) return g.CS == 1 ? (ch >= 4 ? 48 : ch == 2 ? 64 : 96) : (ch >= 2 ? 64 : 96);   // (112 steps spill 43 registers: slower than fetching)
-        return g.CS == 1 ? (ch >= 2 ? 32 : 48) : (ch >= 2 ? 24 : 32);
+        return g.CS == 1 ? (ch >= 2 ? 32 : 48) : (ch >= 2 ? 24 : 40);
     };
     bool regs = false;
     if (g.NBW == g.NB && t64 && steps > tmax_of(chmax)) {
@@ -1479,9 +1479,9 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
                 if constexpr (sizeof(R) == 4) {
                     if (g.T == 80) return fir_mm_launch<R, CS, CH, 80>(f, a, g, st);
                     if (g.T == 96) return fir_mm_launch<R, CS, CH, 96>(f, a, g, st);
-                } else if constexpr (CS == 1) {
+                } else {
                     if (g.T == 40) return fir_mm_launch<R, CS, CH, 40>(f, a, g, st);
-                    if (g.T == 48) return fir_mm_launch<R, CS, CH, 48>(f, a, g, st);
+                    if constexpr (CS == 1) { if (g.T == 48) return fir_mm_launch<R, CS, CH, 48>(f, a, g, st); }
                 }
             }
             if (g.T > 64 || (sizeof(R) == 8 && g.T > 32)) MDSP_FAIL(MDSP_ERR_ASSERTION, "no matrix-core instantiation for %d k-steps", g.T);
