@@ -1287,7 +1287,7 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_re
     // default resampling filters) the taps of ALL its blocks fit registers -- single-chunk waves -- instead of being fetched per tile.
     const int nblk = (int)cdiv((int64_t)g.NB, (int64_t)g.NBW);
     if (g.NBW < g.NB && t64 && nblk <= 3 && steps <= 16 && tunables().fir_mm_nblk != 0) {
-        chmax = 1;
+        chmax = g.esz == 4 ? std::min(chmax, 2) : 1;   // (Float32: two chunks of 16 rows per wave still leave room for three blocks' taps)
         g.NBLK = nblk;
         g.T = steps <= 12 ? 12 : 16;
         g.steps = g.T;
@@ -1461,10 +1461,11 @@ template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1> int 
 }
 
 template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const FirArgs& a, const FirMGeo& g, hipStream_t st) {
-    if constexpr (CH == 1) {
+    if constexpr (CH == 1 || (CH == 2 && sizeof(R) == 4)) {
         if (g.NBLK == 2) return g.T == 12 ? fir_mm_launch<R, CS, CH, 12, false, 2>(f, a, g, st) : fir_mm_launch<R, CS, CH, 16, false, 2>(f, a, g, st);
         if (g.NBLK == 3) return g.T == 12 ? fir_mm_launch<R, CS, CH, 12, false, 3>(f, a, g, st) : fir_mm_launch<R, CS, CH, 16, false, 3>(f, a, g, st);
     }
+    if (g.NBLK > 1) MDSP_FAIL(MDSP_ERR_ASSERTION, "no matrix-core instantiation for %d blocks per wave with %d chunks", g.NBLK, CH);
     switch (g.T) {
         case 0: return fir_mm_launch<R, CS, CH, 0>(f, a, g, st);
         case 4: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 4, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
