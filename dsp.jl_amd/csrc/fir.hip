@@ -1358,7 +1358,8 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_re
         if (fm >= 0 && mode != fm) continue;
         const bool pad_ok = !((g.Mr * dw) & 15) && g.T != 0 && g.T <= 32 && g.T * dw <= 64;   // 16 rows are whole granules; taps in registers; a window (4 T dw dwords) meets one pad at most
         if (mode == 2 && !pad_ok) continue;
-        if (mode == 1 && fm < 0 && pad_ok) continue;   // the padded run replaces the row-staged form wherever it applies
+        if (mode == 1 && fm < 0 && pad_ok && ways_pad <= 2 * ways_row) continue;   // the padded run replaces the row-staged form wherever it applies and spreads the
+                                                                                     // rows comparably (rows shorter than a granule share its pad: Mr dw = 16 stays 15-way)
         const double ways = mode == 1 ? ways_row : mode == 2 ? ways_pad : ways_lin;
         for (int ch = chmax; ch >= 1; ch /= 2) {   // the largest tile (16 CH NG rows) that leaves four memory waves and fits the LDS
             const int rows = 16 * ch;

@@ -97,3 +97,52 @@ def test_matrix_form_random_shapes():
         if len(ref):
             assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), (L, M, ntaps, len(x))
         done += 1
+
+
+def test_padded_run_addressing_model():
+    """Round 3, padded runs (fir.hip, polyphase_mfma_kernel<..., RP = true>): a tile is staged as one run of 256-dword DMA granules with PAD dwords
+    behind every granule (dword d of the tile at d + PAD (d >> 8)); a lane reads its window positions through ONE of two base pointers -- the
+    window's start, or PAD further on from the step at which the window crosses a granule boundary -- with immediate offsets 4 t DW.  Replayed
+    here for random geometries: every read lands on the sample the plain run would have read, no read lands on a pad, the crossing step is the
+    same for every 16-row chunk of a wave (16 rows are a whole number of granules), and the 16 rows of an A operand spread over the banks."""
+    rng = np.random.default_rng(20260926)
+    PAD = 4
+    for _ in range(400):
+        DW = int(rng.choice([1, 2, 4]))                       # dwords per sample: Float32, Float64 / ComplexF32, ComplexF64
+        Mr = int(rng.integers(1, 64)) * (16 // DW if DW < 16 else 1)
+        if (Mr * DW) % 16:
+            continue                                          # the form applies where 16 rows are a whole number of granules
+        T = int(rng.choice([4, 8, 12, 16, 20, 24, 32]))
+        if T * DW > 64:
+            continue                                          # ... and a window (4 T DW dwords) is at most one granule long
+        rows = 64
+        ndw = (rows * Mr + Mr + 4 * T + 4) * DW
+        lds = np.full(ndw + PAD * (ndw // 256 + 2), -1, dtype=np.int64)
+        for d in range(ndw):                                  # DMA: granule i of the source lands at (256 + PAD) i
+            lds[d + PAD * (d >> 8)] = d
+        c0 = int(rng.integers(0, Mr))
+        crossing = {}
+        for row in range(rows):
+            for lk in range(4):
+                d0 = (row * Mr + c0 + lk) * DW                 # first window position of this lane, dwords from the tile start
+                base = d0 + PAD * (d0 >> 8)
+                th = 256 - (d0 & 255)
+                for t in range(T):
+                    hi = 4 * t * DW >= th
+                    for part in range(DW):
+                        got = lds[base + (PAD if hi else 0) + 4 * t * DW + part]
+                        assert got == d0 + 4 * t * DW + part, (DW, Mr, T, row, lk, t)
+                crossing.setdefault((row % 16, lk), set()).add(th)
+        assert all(len(v) == 1 for v in crossing.values())    # one threshold per lane, whatever the chunk
+        # bank spread of the 16 rows of an A operand (4-byte banks; k = 0 lanes): never worse than the plain run, and usable where that one is hostile
+        def ways(pad):
+            cnt = {}
+            for i in range(16):
+                d = i * Mr * DW
+                cnt[(d + pad * (d >> 8)) % 32] = cnt.get((d + pad * (d >> 8)) % 32, 0) + 1
+            return max(cnt.values())
+        if 48 <= Mr * DW < 1008:
+            assert ways(PAD) <= 5                   # (strides 16, 32, 1008, 1024 stay 8- / 15-way: the library keeps the row-staged form where the
+                                                    #  padded run spreads the rows more than twice as badly, fir_mm_geo)
+        if Mr * DW == 160:
+            assert ways(PAD) == 4 and ways(0) == 16
