@@ -82,10 +82,35 @@ typedef float f2v __attribute__((ext_vector_type(2)));
         asm(INSN " %0, %1, %2, %3 " MODS : "=v"(d) : "v"(f2v{a.x, a.y}), "v"(f2v{b.x, b.y}), "v"(f2v{c.x, c.y})); \
         return {d.x, d.y};                                                                          \
     }
+// MDSP_PK_NATIVE: the forms the compiler can express itself (plain add / subtract / multiply / FMA, broadcasts and swaps of a multiplicand --
+// it folds those into op_sel, and a whole-operand negation into neg_lo + neg_hi) are written on float2 vectors instead of asm.  What that buys:
+// hipcc pads every asm statement whose result the NEXT instruction reads with an `s_nop 0` (the gfx940+ dst_sel-forwarding hazard: the asm
+// might have written half a register), 240 of the 1994 instructions of welch_w64_kernel's unit loop; its own v_pk_* need no pad, and it knows
+// their latency when it schedules.  The forms with a per-half negation (a +- i b, the second step of a complex product) stay asm: the
+// compiler spends a v_xor + v_mov on those.
+#ifndef MDSP_PK_NATIVE
+#define MDSP_PK_NATIVE 0
+#endif
+#if MDSP_PK_NATIVE
+#define MDSP_V(a) (f2v{(a).x, (a).y})
+__device__ __forceinline__ cx<float> mdsp_c(f2v d) { return {d.x, d.y}; }
+__device__ __forceinline__ cx<float> cadd(cx<float> a, cx<float> b) { return mdsp_c(MDSP_V(a) + MDSP_V(b)); }
+__device__ __forceinline__ cx<float> csub(cx<float> a, cx<float> b) { return mdsp_c(MDSP_V(a) - MDSP_V(b)); }
+#else
 MDSP_PK2(cadd, "v_pk_add_f32", "")
 MDSP_PK2(csub, "v_pk_add_f32", "neg_lo:[0,1] neg_hi:[0,1]")
+#endif
 MDSP_PK2(pk_add_ib, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")   // a + i b = (ax - by, ay + bx)
 MDSP_PK2(pk_sub_ib, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")   // a - i b = (ax + by, ay - bx)
+#if MDSP_PK_NATIVE
+__device__ __forceinline__ cx<float> pk_mul(cx<float> a, cx<float> b) { return mdsp_c(MDSP_V(a) * MDSP_V(b)); }
+__device__ __forceinline__ cx<float> pk_mul_swap(cx<float> a, cx<float> b) { return mdsp_c(f2v{a.y, a.x} * MDSP_V(b)); }
+__device__ __forceinline__ cx<float> pk_mul_blo(cx<float> a, cx<float> b) { return mdsp_c(MDSP_V(a) * f2v{b.x, b.x}); }
+__device__ __forceinline__ cx<float> pk_mul_bhi(cx<float> a, cx<float> b) { return mdsp_c(MDSP_V(a) * f2v{b.y, b.y}); }
+__device__ __forceinline__ cx<float> pk_mul_yy(cx<float> a, cx<float> b) { return mdsp_c(f2v{a.y, a.y} * f2v{b.y, b.x}); }
+__device__ __forceinline__ cx<float> pk_fma(cx<float> a, cx<float> b, cx<float> c) { return mdsp_c(__builtin_elementwise_fma(MDSP_V(a), MDSP_V(b), MDSP_V(c))); }
+__device__ __forceinline__ cx<float> pk_fnma(cx<float> a, cx<float> b, cx<float> c) { return mdsp_c(__builtin_elementwise_fma(-MDSP_V(a), MDSP_V(b), MDSP_V(c))); }
+#else
 MDSP_PK2(pk_mul, "v_pk_mul_f32", "")
 MDSP_PK2(pk_mul_swap, "v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,1]")              // (a.y b.x, a.x b.y)
 MDSP_PK2(pk_mul_blo, "v_pk_mul_f32", "op_sel_hi:[1,0]")                          // (a.x b.x, a.y b.x): both lanes times b's low half
@@ -93,6 +118,7 @@ MDSP_PK2(pk_mul_bhi, "v_pk_mul_f32", "op_sel:[0,1] op_sel_hi:[1,1]")            
 MDSP_PK2(pk_mul_yy, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0]")                // (a.y b.y, a.y b.x)
 MDSP_PK3(pk_fma, "v_pk_fma_f32", "")                                               // a b + c, lane-wise
 MDSP_PK3(pk_fnma, "v_pk_fma_f32", "neg_lo:[1,0,0] neg_hi:[1,0,0]")                 // c - a b
+#endif
 MDSP_PK3(pk_cmul_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_lo:[0,0,1]")          // (ax bx - c.x, ax by + c.y)
 MDSP_PK3(pk_cmulc_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_hi:[1,0,0]")         // (ax bx + c.x, -ax by + c.y)
 #undef MDSP_PK2
@@ -137,10 +163,17 @@ __device__ __forceinline__ cx<float> wfms_lo(cx<float> a, cx<float> w, cx<float>
         asm(INSN " %0, %1, %2, %3 " MODS : "=v"(d) : "v"(f2v{a.x, a.y}), "s"(f2v{k.x, k.y}), "v"(f2v{c.x, c.y})); \
         return {d.x, d.y};                                                                          \
     }
+#if MDSP_PK_NATIVE >= 2   // compile-time constants: the compiler chooses an SGPR pair (or an inline constant) itself
+__device__ __forceinline__ cx<float> pks_mul(cx<float> a, cx<float> k) { return pk_mul(a, k); }
+__device__ __forceinline__ cx<float> pks_mul_yy(cx<float> a, cx<float> k) { return pk_mul_yy(a, k); }
+__device__ __forceinline__ cx<float> pks_fma(cx<float> a, cx<float> k, cx<float> c) { return pk_fma(a, k, c); }
+__device__ __forceinline__ cx<float> pks_fnma(cx<float> a, cx<float> k, cx<float> c) { return pk_fnma(a, k, c); }
+#else
 MDSP_PK2S(pks_mul, "v_pk_mul_f32", "")
 MDSP_PK2S(pks_mul_yy, "v_pk_mul_f32", "op_sel:[1,1] op_sel_hi:[1,0]")
 MDSP_PK3S(pks_fma, "v_pk_fma_f32", "")
 MDSP_PK3S(pks_fnma, "v_pk_fma_f32", "neg_lo:[1,0,0] neg_hi:[1,0,0]")
+#endif
 MDSP_PK3S(pks_cmul_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_lo:[0,0,1]")
 MDSP_PK3S(pks_cmulc_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_hi:[1,0,0]")
 #undef MDSP_PK2S

@@ -19,6 +19,7 @@
 //     STFT  : window -> FFT -> (|X|^2 * m | X) -> coalesced column store, one kernel.
 //   ROCFFT : K4 kernel -> batched rocFFT -> K5/K6 kernel over cache-sized chunks; any nfft.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include <memory>
@@ -29,6 +30,7 @@
 #include "devio.h"
 #include "fft_lds.h"
 #include "fft_wg.h"
+#include "fft_w64.h"
 #include "hostfft.h"
 #include "rocfft_wrap.h"
 #include "welch_plan.h"
@@ -1436,6 +1438,8 @@ template <int N, int PADSHIFT, int NBUF, bool DEEP = false> int welch_run_half3(
     return MDSP_OK;
 }
 
+#include "welch_w64.h"   // one wavefront per transform (round 4): welch_w64_kernel, welch_run_w64
+
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, int MINW, int NBUF, int PERM = false, bool PREF = true>
 int welch_run_half(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
     auto kern = welch_half_kernel<R, N, E, G, TWMODE, PADSHIFT, MINW, NBUF, PERM, PREF>;
@@ -1507,6 +1511,7 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
                 else if (pl->variant == 33) rc = welch_run_half3<N, 5, 1, true>(pl, a, st, &nslices);   // ... two units in flight (two register sets)
                 else if (pl->variant == 34) rc = welch_run_half3<N, 4, 1, true>(pl, a, st, &nslices);
+                else if (pl->variant == 40) rc = w64::welch_run_w64(pl, a, st, &nslices);   // round 4: one wavefront per transform, 64 x 64, one exchange
                 else if (pl->variant == 35 || pl->variant == 36) {   // half-frames staged in LDS by DMA, two units ahead (pad 5 / pad 4)
                     rc = pl->variant == 35 ? welch_run_half4<N, 5>(pl, a, st, &nslices) : welch_run_half4<N, 4>(pl, a, st, &nslices);
                     if (rc == -1000) rc = welch_run_half3<N, 5, 1>(pl, a, st, &nslices);

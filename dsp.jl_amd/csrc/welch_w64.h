@@ -1,0 +1,229 @@
+// Welch, nfft = n = 4096, hop = n/2, real Float32 signals: ONE wavefront per transform, one exchange (round 4; fft_w64.h has the algebra).
+// Included by spectral.hip (SpecArgs, set_schedule and the partial-sum protocol live there).
+//
+// Why: welch_half3_kernel shares a transform between four waves -- three radix-16 passes, two exchanges, four workgroup barriers per unit -- and its
+// phase profile (profiles/r03c_welch_phases.txt) shows a wave issuing ~1650 clocks of vector work in a 4700-5300 clock unit: the rest is waiting
+// (barriers, LDS round trips, the load burst).  A 64 x 64 factorisation needs one exchange and, with the whole transform inside one wave, no
+// barrier at all; what it costs is registers: 64 points + 64 power accumulators per lane fill the 256 architectural VGPRs, so one wave per
+// SIMD, and everything that is only READ once per unit lives in the accumulation registers (AGPRs: 512-entry unified file, the other half is
+// free when a SIMD holds one wave) behind explicit v_accvgpr_read/write:
+//   * the 63 per-lane twiddles W4096^{lane T} (126 AGPRs), * the half-frame a unit hands to its successor (32 AGPRs).
+// A single wave per SIMD issues one instruction every ~4 clocks whatever its type, so the budget is counted in instructions per unit:
+//   ~1190 packed arithmetic + 128 |Z|^2 FMAs + 64 sample reads + 32 window reads + 64 (carry) + 126 (twiddles) AGPR moves + 64 lane swaps +
+//   128 exchange DS operations + 16 DMA  ~= 1850 -> ~7400 clocks per TRANSFORM and SIMD, against ~10600 for welch_half3_kernel (2 x 5300 for
+//   half a transform per SIMD).
+// Samples: the two new half-frames of a unit arrive in LDS by DMA (buffer_load_dwordx4 ... lds, 16 instructions per unit, no VGPRs), issued as soon
+// as the previous unit's samples have been consumed -- a whole unit of cover; the wave waits with s_waitcnt vmcnt(0) at the top of a unit.
+// LDS per workgroup of four independent waves: window pairs 16 KiB (shared) + 4 x (16 KiB staging + 16.5 KiB exchange) = 146 KiB: one workgroup per CU.
+#pragma once
+// (spectral.hip includes fft_w64.h at file scope)
+
+namespace w64 {
+
+__device__ __forceinline__ float agpr_read(float a, int token) {   // `token` changes per unit: the read cannot be hoisted out of the unit loop
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a), "s"(token));
+    return v;
+}
+__device__ __forceinline__ float agpr_write(float v) {
+    float a;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+    return a;
+}
+
+__device__ __forceinline__ float fma_sq(float x, float c) {   // x x + c
+    float d;
+    asm("v_fma_f32 %0, %1, %1, %2" : "=v"(d) : "v"(x), "v"(c));
+    return d;
+}
+
+typedef __attribute__((address_space(3))) float lds_cf;
+typedef volatile __attribute__((address_space(3))) float lds_cvf;
+constexpr int N = 4096, HALF = N / 2;
+constexpr int STAGE_BYTES = 2 * HALF * 4;                         // H1 | H2
+constexpr int XBUF_BYTES = fft::XP64_ELEMS * 8;
+constexpr int WAVE_BYTES = STAGE_BYTES + XBUF_BYTES;
+constexpr int WIN_BYTES = HALF * 8;                               // (w[p], w[p + N/2]) pairs
+constexpr int LDS_BYTES = WIN_BYTES + 4 * WAVE_BYTES;
+static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+
+// the 64 x 64 transposition of fft_w64.h on the wave's registers: v[slot64(ke)] = M[lane][ke] in, v[T] = M[T][lane] out
+__device__ __forceinline__ void transpose64(cx<float> (&v)[64], cx<float>* xb, int lane) {
+    cx<float> m[64];   // logical registers
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const cx<float> lo = v[fft::slot64(r)], hi = v[fft::slot64(r + 32)];
+        const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
+        m[r] = {__uint_as_float(sx[0]), __uint_as_float(sy[0])};
+        m[r + 32] = {__uint_as_float(sx[1]), __uint_as_float(sy[1])};
+    }
+    cx<float>* wr = xb + fft::xp64_write_index(lane, 0);
+    const cx<float>* rd = xb + fft::xp64_read_index(lane, 0);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) fft::st2(wr + r, m[32 * round + r]);
+#pragma unroll
+        for (int T = 0; T < 32; ++T) v[32 * round + T] = fft::ld2(rd + T * fft::XP64_ROW);
+    }
+}
+
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256, 1) void welch_w64_kernel(SpecArgs a) {
+    using R = float;
+    extern __shared__ __attribute__((aligned(16))) unsigned char w64_smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    cx<R>* winl = reinterpret_cast<cx<R>*>(w64_smem);
+    unsigned char* mine = w64_smem + WIN_BYTES + wave * WAVE_BYTES;
+    R* stage = reinterpret_cast<R*>(mine);
+    cx<R>* xb = reinterpret_cast<cx<R>*>(mine + STAGE_BYTES);
+    const unsigned stage_lds = io::lds_byte_address(w64_smem) + (unsigned)(WIN_BYTES + wave * WAVE_BYTES);
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    const int64_t ch = blockIdx.y;
+
+    // window pairs, shared by the four waves (the only barrier of the kernel)
+    for (int p = tid; p < HALF; p += 256) {
+        const double lo = p < a.n ? (a.win ? a.win[p] : 1.0) : 0.0, hi = (p + HALF) < a.n ? (a.win ? a.win[p + HALF] : 1.0) : 0.0;
+        winl[p] = {(R)lo, (R)hi};
+    }
+    __syncthreads();
+
+    // per-lane twiddles W^{lane T}, T = 1..63, in AGPRs
+    float twx[64], twy[64];
+#pragma unroll
+    for (int T = 1; T < 64; ++T) {
+        const cx<R> w = table[(lane * T) & (N - 1)];
+        twx[T] = agpr_write(w.x);
+        twy[T] = agpr_write(w.y);
+    }
+
+    float acc[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) acc[s] = 0.f;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
+    double* part = static_cast<double*>(a.out) + (slot * a.nch + ch) * N;
+    const __amdgpu_buffer_rsrc_t prs = io::make_rsrc(part, (int64_t)N * 8);
+    bool first = true;
+    auto flush = [&]() __attribute__((always_inline)) {
+        int off = lane * 8;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int kt = 0; kt < 64; ++kt) {   // bin lane + 64 kt sits in slot64(kt)
+            double s = (double)acc[fft::slot64(kt)];
+            if (!first) s += io::Ld<double>::load(prs, off + 64 * kt * 8);
+            io::Ld<double>::store(s, prs, off + 64 * kt * 8);
+            acc[fft::slot64(kt)] = 0.f;
+        }
+        first = false;
+    };
+
+    const R* sc = static_cast<const R*>(a.s) + ch * a.lds_;
+    const int64_t u0 = slot * a.run_len;
+    const int64_t uend = std::min<int64_t>(u0 + a.run_len, a.units_per_ch);   // one past this wave's last unit
+    const int64_t klast = uend > u0 ? 2 * (uend - 1) + (((2 * (uend - 1) + 1) < a.K) ? 2 : 1) : -1;   // last half-frame any of its frames touches
+    // half-frame k of the channel -> staging region `reg` (0: H1, 1: H2); always eight instructions (an unwanted half-frame moves nothing)
+    auto dma_half = [&](int64_t k, int reg) __attribute__((always_inline)) {
+        const bool want = k >= 2 * u0 && k <= klast;
+        const io::dma_i4 r = io::dma_rsrc(sc + k * HALF, want ? (long long)HALF * 4 : 0);
+#pragma unroll
+        for (int g = 0; g < HALF / 256; ++g) io::dma256(r, stage_lds + (unsigned)reg * (unsigned)(HALF * 4) + (unsigned)g * 1024u, g * 1024 + lane * 16);
+    };
+
+    if (uend > u0) {
+        // the first unit's H0 passes through the H2 region into the carry registers
+        float carry[32];
+        dma_half(2 * u0, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 32; ++e) carry[e] = agpr_write(stage[HALF + lane + 64 * e]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_half(2 * u0 + 1, 0);
+        dma_half(2 * u0 + 2, 1);
+        int since = 0;
+        auto unit = [&](auto frame_b, int64_t u, int token) __attribute__((always_inline)) {
+            constexpr bool FRAME_B = decltype(frame_b)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this unit's half-frames have landed
+            cx<R> v[64];
+            // first layer + first radix-8 layer, one group of four sample pairs at a time; group n1 + 1 is fetched from LDS while group n1 is evaluated
+            // (all 32 groups' operands at once would need 160 registers next to the 64 accumulators and the growing result)
+            struct Grp { cx<R> xp[4], hh[2], wp[4]; };
+            auto fetch = [&](Grp& g, int n1) __attribute__((always_inline)) {
+                const lds_cf* st = (const lds_cf*)stage_lds + lane;
+                const lds_cvf* sv = (const lds_cvf*)stage_lds + HALF + lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = n1 + 8 * j;
+                    const R h2 = sv[64 * e];                                   // volatile: never merged into a two-address read -- it lands in the pair's upper half
+                    g.xp[j] = {agpr_read(carry[e], token), h2};
+                    carry[e] = agpr_write(h2);
+                    g.wp[j] = fft::ld2(winl + lane + 64 * e);
+                }
+                g.hh[0] = {st[64 * n1], st[64 * (n1 + 8)]};
+                g.hh[1] = {st[64 * (n1 + 16)], st[64 * (n1 + 24)]};
+            };
+            Grp ga, gb;
+            fetch(ga, 0);
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1 += 2) {
+                fetch(gb, n1 + 1);
+                fft::passA_welch_group<FRAME_B>(n1, ga.xp, ga.hh, ga.wp, v);
+                __builtin_amdgcn_sched_barrier(0);
+                if (n1 + 2 < 8) fetch(ga, n1 + 2);
+                fft::passA_welch_group<FRAME_B>(n1 + 1, gb.xp, gb.hh, gb.wp, v);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fft::bfly64_tail<-1>(v);
+            // the staging buffer is free: the next unit's half-frames (a whole unit of cover)
+            dma_half(2 * u + 3, 0);
+            dma_half(2 * u + 4, 1);
+            transpose64(v, xb, lane);
+#pragma unroll
+            for (int T = 1; T < 64; ++T) v[T] = fft::cmul(v[T], cx<R>{agpr_read(twx[T], token), agpr_read(twy[T], token)});
+            fft::bfly64<-1>(v);
+#pragma unroll
+            for (int s = 0; s < 64; ++s) {   // asm: hipcc's SLP pass would pair bins into v_pk_fma and pay three v_mov per pair to build the operands
+                acc[s] = fma_sq(v[s].y, fma_sq(v[s].x, acc[s]));
+            }
+        };
+        for (int64_t u = u0; u < uend; ++u) {
+            const int token = (int)(u - u0);
+            if ((2 * u + 1) < a.K) unit(std::true_type{}, u, token);
+            else unit(std::false_type{}, u, token);
+            if (++since == 128 || u + 1 == uend) {   // Float32 sums of at most 128 units, folded into the Float64 partial row (as welch_half3_kernel)
+                flush();
+                since = 0;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave may still be writing LDS when the workgroup exits
+    } else {   // a slot without units still owns a partial row: zeros
+#pragma unroll 1
+        for (int kt = 0; kt < 64; ++kt) io::Ld<double>::store(0.0, prs, lane * 8 + 64 * kt * 8);
+    }
+}
+
+inline int welch_run_w64(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
+    auto kern = welch_w64_kernel<0>;
+    static std::atomic<unsigned long long> lds_opt_in{0};
+    int dev = 0;
+    MDSP_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(lds_opt_in.load(std::memory_order_acquire) & bit)) {
+        MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_opt_in.fetch_or(bit, std::memory_order_release);
+    }
+    const int64_t per_ch = std::max<int64_t>(1, (int64_t)device_cu_count() / std::max<int64_t>(1, a.nch));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(a.units_per_ch, 4), per_ch));
+    const int64_t nslots = (int64_t)grid * 4;
+    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)nslots * (size_t)a.nch * N));
+    a.out = pl->partial.p;
+    set_schedule(a, a.units_per_ch, nslots);
+    a.run_len = cdiv(a.units_per_ch, nslots);   // one contiguous run per wave
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(256), LDS_BYTES, st, a);
+    MDSP_LAUNCH_CHECK();
+    *nslices = (int)nslots;
+    return MDSP_OK;
+}
+
+}  // namespace w64

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../dsp.jl_amd/csrc/fft_lds.h"
+#include "../../dsp.jl_amd/csrc/fft_w64.h"
 
 using namespace mdsp::fft;
 
@@ -193,8 +194,96 @@ template <int N, typename R, int PADSHIFT> static double check_windowed(bool swa
     return (double)sqrtl(err2 / norm);
 }
 
+// One wavefront per 4096-point transform (fft_w64.h): bfly64 alone against the 64-point DFT, then a whole Welch unit -- passA_welch lane by lane,
+// the 64 x 64 transposition (the half exchange v_permlane32_swap performs + two rounds through the padded buffer, with the kernel's index
+// functions), the W4096^{lane * register} twiddles on the reader side and bfly64 -- against the long-double DFT of w (a + i b).
+template <typename R> static double check_bfly64() {
+    cx<R> v[64];
+    std::complex<long double> in[64];
+    srand(640);
+    for (int i = 0; i < 64; ++i) {
+        v[i] = {(R)((double)rand() / RAND_MAX - 0.5), (R)((double)rand() / RAND_MAX - 0.5)};
+        in[i] = {v[i].x, v[i].y};
+    }
+    bfly64<-1>(v);
+    long double err2 = 0, norm = 0;
+    for (int k = 0; k < 64; ++k) {
+        std::complex<long double> acc = 0;
+        for (int n = 0; n < 64; ++n) {
+            const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)((n * k) % 64) / 64;
+            acc += in[n] * std::complex<long double>(cosl(ang), sinl(ang));
+        }
+        err2 += std::norm(std::complex<long double>(v[slot64(k)].x, v[slot64(k)].y) - acc);
+        norm += std::norm(acc);
+    }
+    return (double)sqrtl(err2 / norm);
+}
+template <typename R> static double check_wave64(bool frame_b) {
+    constexpr int N = 4096, HALF = N / 2;
+    std::vector<cx<R>> table(N);
+    for (int k = 0; k < N; ++k) {
+        const long double a = -2.0L * 3.141592653589793238462643383279502884L * k / N;
+        table[k] = {(R)cosl(a), (R)sinl(a)};
+    }
+    std::vector<R> h0(HALF), h1(HALF), h2(HALF), w(N);
+    srand(6464);
+    for (int i = 0; i < HALF; ++i) {
+        h0[i] = (R)((double)rand() / RAND_MAX - 0.5);
+        h1[i] = (R)((double)rand() / RAND_MAX - 0.5);
+        h2[i] = (R)((double)rand() / RAND_MAX - 0.5);
+    }
+    for (int i = 0; i < N; ++i) w[i] = (R)(0.5 - 0.5 * cos(2.0 * 3.14159265358979323846 * i / (N - 1)));
+    std::vector<cx<R>> reg((size_t)64 * 64), lds(XP64_ELEMS);   // reg[lane * 64 + logical register]
+    for (int t = 0; t < 64; ++t) {                             // pass A
+        cx<R> xp[32], wp[32], v[64];
+        R hh[32];
+        for (int e = 0; e < 32; ++e) {
+            const int p = t + 64 * e;
+            xp[e] = {h0[p], h2[p]};
+            hh[e] = h1[p];
+            wp[e] = {w[p], w[p + HALF]};
+        }
+        if (frame_b) passA_welch<true>(xp, hh, wp, v);
+        else passA_welch<false>(xp, hh, wp, v);
+        for (int ke = 0; ke < 64; ++ke) reg[(size_t)t * 64 + ke] = v[slot64(ke)];
+    }
+    for (int r = 0; r < 32; ++r)                               // step 1: lanes 32..63 of register r <-> lanes 0..31 of register r + 32
+        for (int l = 0; l < 32; ++l) std::swap(reg[(size_t)(l + 32) * 64 + r], reg[(size_t)l * 64 + r + 32]);
+    for (int round = 0; round < 2; ++round) {                  // step 2: two rounds of 32 registers through the padded buffer
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 32; ++r) lds[xp64_write_index(l, r)] = reg[(size_t)l * 64 + 32 * round + r];
+        for (int l = 0; l < 64; ++l)
+            for (int T = 0; T < 32; ++T) reg[(size_t)l * 64 + 32 * round + T] = lds[xp64_read_index(l, T)];
+    }
+    long double err2 = 0, norm = 0;
+    std::vector<std::complex<long double>> got(N);
+    for (int ke = 0; ke < 64; ++ke) {                          // reader side: twiddle W^{lane * register}, pass B
+        cx<R> v[64];
+        for (int t = 0; t < 64; ++t) v[t] = t == 0 ? reg[(size_t)ke * 64] : twmul<-1>(reg[(size_t)ke * 64 + t], table[(ke * t) & (N - 1)]);
+        bfly64<-1>(v);
+        for (int kt = 0; kt < 64; ++kt) got[ke + 64 * kt] = {v[slot64(kt)].x, v[slot64(kt)].y};
+    }
+    for (int k = 0; k < N; ++k) {
+        std::complex<long double> acc = 0;
+        for (int n = 0; n < N; ++n) {
+            const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)(((long long)n * k) % N) / N;
+            const long double a = n < HALF ? h0[n] : h1[n - HALF], b = frame_b ? (n < HALF ? h1[n] : h2[n - HALF]) : 0.0L;
+            acc += (long double)w[n] * std::complex<long double>(a, b) * std::complex<long double>(cosl(ang), sinl(ang));
+        }
+        err2 += std::norm(got[k] - acc);
+        norm += std::norm(acc);
+    }
+    return (double)sqrtl(err2 / norm);
+}
+
 int main() {
     int bad = 0;
+    {
+        const double b32 = check_bfly64<float>(), b64 = check_bfly64<double>();
+        const double e32 = std::max(check_wave64<float>(true), check_wave64<float>(false)), e64 = std::max(check_wave64<double>(true), check_wave64<double>(false));
+        printf("one wavefront per transform (64 x 64): bfly64 f32 %.2e f64 %.2e, Welch unit f32 %.2e f64 %.2e\n", b32, b64, e32, e64);
+        if (!(b32 < 1e-6) || !(b64 < 1e-15) || !(e32 < 2e-6) || !(e64 < 1e-14)) bad = 1;
+    }
     {
         const double e1 = std::max(check_windowed<4096, float, 5>(false), check_windowed<4096, float, 5>(true));
         const double e2 = std::max(check_windowed<2048, float, 5>(false), check_windowed<1024, float, 4>(true));

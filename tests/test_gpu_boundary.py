@@ -733,7 +733,7 @@ def test_polyphase_matrix_core_kernel_fuzz(d, torch):
     assert used >= tried // 2          # most random shapes fit the matrix-core kernel
 
 
-@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36])
+@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36, 40])
 def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
     """welch_half3_kernel (paired samples, role-swapping units, window folded into the first butterfly stage, frame b's first half loaded a
     second time under the unit's have-frame-b predicate): every frame count parity, the odd last frame, one to three frames, several
