@@ -219,7 +219,8 @@ class Timer:
         self._lib.check(self.lib.mdsp_event_elapsed_ms(a, b, C.byref(v)))
         return v.value
 
-    def time(self, fn, reps=5):
+    def time(self, fn, reps=9):
+        """Median and best of `reps` timed launches (one untimed first); `self.last` keeps min / max / reps of the same sample for the row."""
         import torch
         fn()
         torch.cuda.synchronize()
@@ -230,13 +231,15 @@ class Timer:
             torch.cuda.synchronize()
             ts.append(self.ms(a, b))
         ts.sort()
+        self.last = {"min_ms": round(ts[0], 4), "max_ms": round(ts[-1], 4), "reps": reps}
         return ts[len(ts) // 2], ts[0]
 
 
 class Marks:
     """Row markers for the profiler: before each measured row, one mdsp_fill_kernel launch with (100 + row index) workgroups on the launch stream
     (tools/prof_summary.py rows() cuts the dispatch list at them).  ~2 us each, always outside the timed regions."""
-    ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32")
+    ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32",
+            "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64")
 
     def __init__(self, lib, _lib, stream):
         import torch
@@ -255,6 +258,11 @@ def roof(kernel, ms, alg_bytes, traffic=None, extra=None):
     if extra:
         r.update(extra)
     return r
+
+
+def spread(tm):
+    """min / max / reps of the timer's last sample (the row's median is ms_per_launch)."""
+    return dict(getattr(tm, "last", {}))
 
 
 def git_head():
@@ -329,7 +337,7 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
         mark(name)
         med, best = tm.time(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, s.data_ptr(), n, nch, n, out.data_ptr(), 1024, K * 1024, stream)))
         rows[name] = roof(f"stft_fused_kernel ({name}, config 4 share: 8 ch x 2^26 ComplexF32, {bps:.0f} B/sample)", med, bps * n * nch,
-                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
+                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
         del out, plan
     del s
     torch.cuda.empty_cache()
@@ -349,7 +357,7 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
     mark("resample")
     med, best = tm.time(fir)
     rows["resample"] = roof("polyphase_mfma_kernel (config 5 share: 4 ch x 2^28 Float32, 160//147, 8.354 B/sample)", med, (4 + 4 * 160 / 147) * n * nch,
-                            extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4)})
+                            extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
     _lib.check(lib.mdsp_fir_destroy(fh))
     rate = 160 / 147
     ha = d.resample_filter(rate, 32).astype(np.float32)
@@ -373,7 +381,7 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
     tfl = 2.0 * fma / (med * 1e-3) / 1e12
     peak = 2.0 * 29.1 * 1024 * 2.4e9 / 1e12
     rows["firarb"] = roof("arbitrary_fir_kernel (row f1: 4 ch x 2^28 Float32, rate 160/147 as Float64, warm trajectory)", med, (4 + 4 * rate) * n * nch,
-                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4),
+                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm),
                                  "valu": {"achieved": round(tfl, 1), "peak": round(peak, 1), "unit": "TFLOP/s (v_pk_fma_f32 issue rate, measured)", "frac": round(tfl / peak, 4),
                                           "fma_per_output": 2 * tpp,
                                           "note": "FMA issue alone is not the bound either: the SQ counters show the vector unit 70 % busy, most of it LDS-operand "
@@ -383,10 +391,15 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
     torch.cuda.empty_cache()
     # the same resampler on the other signal types (DSP.jl's default is Float64), and two small ratios: 4 channels x 2^26 samples
     n2 = 1 << 26
+    # ... and (round 4) the shapes whose gains had only been measured by builder-run tools: a decimator by eight, the downsampling twin of
+    # config 5 (147//160) and the Float64 160//441 resampler, each with DSP.jl's own resample_filter design for its ratio
     for name, tdt, hdt, lt, lx, esz, (L, M) in (("resample_f64", torch.float64, np.float64, _lib.F64, _lib.F64, 8, (160, 147)),
                                                 ("resample_c32", torch.complex64, np.float32, _lib.F32, _lib.C32, 8, (160, 147)),
                                                 ("interp2_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (2, 1)),
-                                                ("decim2_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (1, 2))):
+                                                ("decim2_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (1, 2)),
+                                                ("decim8_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (1, 8)),
+                                                ("resample_147_160_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (147, 160)),
+                                                ("resample_160_441_f64", torch.float64, np.float64, _lib.F64, _lib.F64, 8, (160, 441))):
         from fractions import Fraction
         hh = resample_taps().astype(hdt) if (L, M) == (160, 147) else np.asarray(d.resample_filter(Fraction(L, M)), dtype=hdt)
         xx = torch.randn((nch, n2), generator=g, device="cuda", dtype=tdt)
@@ -403,11 +416,41 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
         mark(name)
         med, best = tm.time(fir2)
         rows[name] = roof(f"{('generic', 'register-tap', 'matrix-core')[pth.value]} polyphase kernel ({L}//{M}, {len(hh)} taps, 4 ch x 2^26 {str(tdt).split('.')[-1]}, {esz * (1 + L / M):.2f} B/sample)",
-                          med, esz * (1 + L / M) * n2 * nch, extra={"Gsamples_per_s": round(n2 * nch / med / 1e6, 2), "best_ms": round(best, 4)})
+                          med, esz * (1 + L / M) * n2 * nch, extra={"Gsamples_per_s": round(n2 * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
         _lib.check(lib.mdsp_fir_destroy(f2))
         del xx, yy
     torch.cuda.empty_cache()
+    # Welch at the reference's DEFAULT transform sizes (nfft = nextfastfft(n), util.jl:134, periodograms.jl:560): 7-smooth, not powers of two --
+    # the compile-time mixed-radix schedules of csrc/spectral_gen.h.  2^27 Float32 samples, 50 % overlap, 4 B/sample.
+    n3 = 1 << 27
+    xr = torch.randn(n3, generator=g, device="cuda", dtype=torch.float32)
+    for nfft in (3000, 1536):
+        cfg = d.WelchConfig(n3, np.float32, n=nfft, noverlap=nfft // 2, nfft=nfft, window=d.hanning, engine=d.ENGINE_FUSED)
+        psd = torch.empty(cfg.nout, dtype=torch.float32, device="cuda")
+        mark(f"welch_{nfft}")
+        med, best = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xr.data_ptr(), n3, 1, n3, psd.data_ptr(), cfg.nout, stream)))
+        rows[f"welch_{nfft}"] = roof(f"mixed-radix fused Welch kernel (nfft = n = {nfft} = nextfastfft size, hanning, 50 % overlap, 2^27 Float32, 4 B/sample)", med, 4.0 * n3,
+                                     extra={"Gsamples_per_s": round(n3 / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
+        del cfg, psd
+    del xr
+    # filt with a LONG filter: 5120 taps (config 5's prototype length), where optimalfftfiltlength asks for nfft 65536 (dspbase.jl:268-291); the fused
+    # engine runs it as a partitioned overlap-save.  2^28 Float32 samples, 8 B/sample.
+    from dsp_jl_amd.dspbase import OlsPlan
+    n4 = 1 << 28
+    xl = torch.randn(n4, generator=g, device="cuda", dtype=torch.float32)
+    yl = torch.empty_like(xl)
+    tl = (np.random.default_rng(5120).standard_normal(5120) / math.sqrt(5120)).astype(np.float32)
+    pl = OlsPlan(tl, d.optimalfftfiltlength(5120, n4), n4, 0, d.ENGINE_FUSED)
+    mark("filt_5120")
+    med, best = tm.time(lambda: _lib.check(lib.mdsp_ols_exec(pl._h, xl.data_ptr(), n4, 1, n4, yl.data_ptr(), n4, n4, stream)))
+    rows["filt_5120"] = roof("partitioned overlap-save kernel (filt, 5120 taps, 2^28 Float32, 8 B/sample)", med, 8.0 * n4,
+                             extra={"Gsamples_per_s": round(n4 / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
+    del pl, xl, yl
+    torch.cuda.empty_cache()
     return rows
+
+
+NEW_ROWS_R4 = ("welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64")
 
 
 def measure_host_path(lib, _lib, d, log2n):
@@ -780,7 +823,7 @@ def main():
             torch.cuda.empty_cache()
             try:
                 kernels.update(measure_rows(tm, lib, _lib, d, stream, mark))
-                for key in ("stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32"):
+                for key in ("stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32") + NEW_ROWS_R4:
                     if key in kernels and traffic:
                         kernels[key]["traffic"] = traffic.get(f"{key}_bytes_per_launch")
                         kernels[key]["traffic_source"] = traffic_source

@@ -50,6 +50,8 @@ static void read_tunables_locked() {
     }
     t.wg_per_cu = std::max(0, geti("MDSP_WG_PER_CU", 0));
     t.runs_per_slot = std::max(1, geti("MDSP_RUNS_PER_SLOT", 1));
+    t.plan_cache_total = std::max(1, geti("MDSP_PLAN_CACHE_TOTAL", 8 * MDSP_PLAN_CACHE_SIZE));
+    t.plan_cache_idle = std::max(1, geti("MDSP_PLAN_CACHE_IDLE", 64));
     t.ols_variant = geti("MDSP_OLS_VARIANT", 0);
     t.ols_prio = geti("MDSP_OLS_PRIO", 1);
     t.spec_prio = geti("MDSP_SPEC_PRIO", 1);

@@ -25,6 +25,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -52,6 +54,8 @@ Rccl& rccl() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     });
     return r;
 }
@@ -68,6 +72,8 @@ int need_rccl() {
         if (mdsp_r_ != ncclSuccess)                                                                                     \
             return ::mdsp::set_error(MDSP_ERR_DEVICE, "%s failed: %s", #expr, rccl().GetErrorString(mdsp_r_));          \
     } while (0)
+
+__global__ void set_scalar_kernel(double* __restrict__ p, double v) { *p = v; }
 
 template <typename R> __global__ __launch_bounds__(256) void scale_kernel(R* __restrict__ v, int64_t n, double f) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,24 +171,28 @@ int mdsp_welch_mean_allreduce(mdsp_welch_plan plan, const void* psd_dev, int64_t
     return MDSP_OK;
 }
 
-// One stream split along TIME over ranks: every rank accumulated the frames of its slice (mdsp_welch_accumulate); the
-// Float64 |X|^2 sums are added over ranks in place and the frame counts with them, so that mdsp_welch_finalize(plan, 0, ...)
-// on every rank yields the PSD of the whole stream (periodograms.jl:746-759: sum over ALL frames / (K fs sum w^2)).
+// One stream split along TIME over ranks: every rank accumulated the frames of its slice (mdsp_welch_accumulate); the Float64 |X|^2 sums are
+// added over ranks in place and the frame counts with them -- ONE RCCL group (the sums and one more double), the local count written by a
+// kernel on the same stream, the total left on the device -- so that mdsp_welch_finalize(plan, 0, ...) on every rank yields the PSD of the whole
+// stream (periodograms.jl:746-759: sum over ALL frames / (K fs sum w^2)).  Stream-ordered: nothing is copied from the host stack, nothing
+// synchronises (round 3 did both).
 int mdsp_welch_allreduce(mdsp_welch_plan plan, mdsp_comm comm, void* stream) {
     if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
     if (!comm || comm->nranks <= 1) return MDSP_OK;
     void* acc = nullptr;
     int64_t count = 0;
     MDSP_TRY(mdsp_welch_accumulator(plan, &acc, &count));
-    MDSP_TRY(mdsp_allreduce_sum(comm, acc, count, MDSP_F64, stream));
-    MDSP_TRY(comm->scratch.reserve(sizeof(double)));
-    const double k = (double)plan->acc_frames;     // exact below 2^53 frames
-    MDSP_HIP(hipMemcpyAsync(comm->scratch.p, &k, sizeof(double), hipMemcpyHostToDevice, as_stream(stream)));
-    MDSP_TRY(mdsp_allreduce_sum(comm, comm->scratch.p, 1, MDSP_F64, stream));
-    double ktot = 0;
-    MDSP_HIP(hipMemcpyAsync(&ktot, comm->scratch.p, sizeof(double), hipMemcpyDeviceToHost, as_stream(stream)));
-    MDSP_HIP(hipStreamSynchronize(as_stream(stream)));
-    plan->acc_frames = (int64_t)ktot;
+    MDSP_TRY(plan->kdev.reserve(sizeof(double)));
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, plan->kdev.as<double>(), (double)plan->acc_frames);   // exact below 2^53 frames
+    MDSP_LAUNCH_CHECK();
+    MDSP_NCCL(rccl().GroupStart());
+    ncclResult_t r1 = rccl().AllReduce(acc, acc, (size_t)count, ncclFloat64, ncclSum, comm->comm, st);
+    ncclResult_t r2 = rccl().AllReduce(plan->kdev.p, plan->kdev.p, 1, ncclFloat64, ncclSum, comm->comm, st);
+    ncclResult_t r3 = rccl().GroupEnd();
+    for (ncclResult_t r : {r1, r2, r3})
+        if (r != ncclSuccess) MDSP_FAIL(MDSP_ERR_DEVICE, "ncclAllReduce (Welch sums + frame count) failed: %s", rccl().GetErrorString(r));
+    plan->frames_on_device = true;
     return MDSP_OK;
 }
 

@@ -123,8 +123,45 @@ MDSP_PK3(pk_cmul_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_lo:[0,0,1]")       
 MDSP_PK3(pk_cmulc_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_hi:[1,0,0]")         // (ax bx + c.x, -ax by + c.y)
 #undef MDSP_PK2
 #undef MDSP_PK3
+// MDSP_PK_FUSED: dependent packed instructions in ONE asm statement.  hipcc pads every (producer, consumer) pair of which at least one is an
+// asm statement with an `s_nop 0` unless another non-asm instruction sits between them (the gfx940+ dst_sel-forwarding hazard rule cannot see
+// inside an asm, and asm statements count as zero wait states): with one instruction per statement that was 171 s_nop in the 2333
+// instructions of welch_half3_kernel, 11 % of overlap-save's unit loop.  The two halves of a complex product and the eight instructions of a
+// radix-4 butterfly as single statements leave at most one pad per statement; the arithmetic (operations, operands, rounding) is unchanged.
+#ifndef MDSP_PK_FUSED
+#define MDSP_PK_FUSED 1
+#endif
+#if MDSP_PK_FUSED
+__device__ __forceinline__ cx<float> cmul(cx<float> a, cx<float> w) {
+    f2v d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : "=&v"(d) : "v"(f2v{a.x, a.y}), "v"(f2v{w.x, w.y}));
+    return {d.x, d.y};
+}
+__device__ __forceinline__ cx<float> cmulc(cx<float> a, cx<float> w) {
+    f2v d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(d) : "v"(f2v{a.x, a.y}), "v"(f2v{w.x, w.y}));
+    return {d.x, d.y};
+}
+// two products at once, interleaved (the twiddle loops of the passes): no dependent pair is adjacent
+__device__ __forceinline__ void cmul2(cx<float>& a0, cx<float> w0, cx<float>& a1, cx<float> w1, bool conj) {
+    f2v d0, d1;
+    if (!conj)
+        asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %4, %5 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\tv_pk_fma_f32 %1, %4, %5, %1 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+            : "=&v"(d0), "=&v"(d1) : "v"(f2v{a0.x, a0.y}), "v"(f2v{w0.x, w0.y}), "v"(f2v{a1.x, a1.y}), "v"(f2v{w1.x, w1.y}));
+    else
+        asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %1, %4, %5 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\tv_pk_fma_f32 %1, %4, %5, %1 op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+            : "=&v"(d0), "=&v"(d1) : "v"(f2v{a0.x, a0.y}), "v"(f2v{w0.x, w0.y}), "v"(f2v{a1.x, a1.y}), "v"(f2v{w1.x, w1.y}));
+    a0 = {d0.x, d0.y};
+    a1 = {d1.x, d1.y};
+}
+#else
 __device__ __forceinline__ cx<float> cmul(cx<float> a, cx<float> w) { return pk_cmul_fin(a, w, pk_mul_yy(a, w)); }
 __device__ __forceinline__ cx<float> cmulc(cx<float> a, cx<float> w) { return pk_cmulc_fin(a, w, pk_mul_yy(a, w)); }
+#endif
 template <int DIR> __device__ __forceinline__ cx<float> add_mi(cx<float> a, cx<float> b) { return DIR < 0 ? pk_sub_ib(a, b) : pk_add_ib(a, b); }
 template <int DIR> __device__ __forceinline__ cx<float> sub_mi(cx<float> a, cx<float> b) { return DIR < 0 ? pk_add_ib(a, b) : pk_sub_ib(a, b); }
 template <int DIR> __device__ __forceinline__ cx<float> mul_mi(cx<float> a) {
@@ -178,9 +215,22 @@ MDSP_PK3S(pks_cmul_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_lo:[0,0,1]")
 MDSP_PK3S(pks_cmulc_fin, "v_pk_fma_f32", "op_sel_hi:[0,1,1] neg_hi:[1,0,0]")
 #undef MDSP_PK2S
 #undef MDSP_PK3S
+#if MDSP_PK_FUSED
+template <int DIR> __device__ __forceinline__ cx<float> twmul_k(cx<float> a, cx<float> w) {
+    f2v d;
+    if constexpr (DIR < 0)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+            : "=&v"(d) : "v"(f2v{a.x, a.y}), "s"(f2v{w.x, w.y}));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+            : "=&v"(d) : "v"(f2v{a.x, a.y}), "s"(f2v{w.x, w.y}));
+    return {d.x, d.y};
+}
+#else
 template <int DIR> __device__ __forceinline__ cx<float> twmul_k(cx<float> a, cx<float> w) {
     return DIR < 0 ? pks_cmul_fin(a, w, pks_mul_yy(a, w)) : pks_cmulc_fin(a, w, pks_mul_yy(a, w));
 }
+#endif
 __device__ __forceinline__ cx<float> cscale_k(float h, cx<float> u) { return pks_mul(u, cx<float>{h, h}); }
 __device__ __forceinline__ cx<float> caxpy_k(float h, cx<float> u, cx<float> e) { return pks_fma(u, cx<float>{h, h}, e); }
 __device__ __forceinline__ cx<float> caxmy_k(float h, cx<float> u, cx<float> e) { return pks_fnma(u, cx<float>{h, h}, e); }
@@ -195,6 +245,40 @@ template <int DIR, typename R> MDSP_HD void bfly2(cx<R>& a, cx<R>& b) {
     a = cadd(a, b);
     b = t;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDSP_NO_PACKED_F32) && MDSP_PK_FUSED
+// the radix-4 butterfly as ONE statement of eight packed instructions, in place with one temporary (see MDSP_PK_FUSED above):
+//   T0 = a0 + a2, T1 = a0 - a2, T2 = a1 + a3, D = a1 - a3;  X0 = T0 + T2, X2 = T0 - T2, X1 = T1 -+ i D, X3 = T1 +- i D  (forward: X1 = T1 - i D)
+// no instruction reads the result of its predecessor.  X0 lands in a0's registers, X2 in a1's, X1 in the temporary, X3 in a3's: the renaming
+// behind the statement is free.
+template <int DIR> __device__ __forceinline__ void bfly4(cx<float>& a0, cx<float>& a1, cx<float>& a2, cx<float>& a3) {
+    f2v r0 = {a0.x, a0.y}, r1 = {a1.x, a1.y}, r2 = {a2.x, a2.y}, r3 = {a3.x, a3.y}, t;
+    if constexpr (DIR < 0)
+        asm("v_pk_add_f32 %4, %0, %2\n\t"                                               // t  = T0
+            "v_pk_add_f32 %2, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"                     // r2 = T1
+            "v_pk_add_f32 %0, %1, %3\n\t"                                               // r0 = T2
+            "v_pk_add_f32 %3, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"                     // r3 = D
+            "v_pk_add_f32 %1, %4, %0 neg_lo:[0,1] neg_hi:[0,1]\n\t"                     // r1 = X2 = T0 - T2
+            "v_pk_add_f32 %0, %4, %0\n\t"                                               // r0 = X0 = T0 + T2
+            "v_pk_add_f32 %4, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"     // t  = X1 = T1 - i D
+            "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"           // r3 = X3 = T1 + i D
+            : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=&v"(t));
+    else
+        asm("v_pk_add_f32 %4, %0, %2\n\t"
+            "v_pk_add_f32 %2, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %0, %1, %3\n\t"
+            "v_pk_add_f32 %3, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %1, %4, %0 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %0, %4, %0\n\t"
+            "v_pk_add_f32 %4, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"     // t  = X1 = T1 + i D
+            "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"           // r3 = X3 = T1 - i D
+            : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=&v"(t));
+    a0 = {r0.x, r0.y};
+    a1 = {t.x, t.y};
+    a2 = {r1.x, r1.y};
+    a3 = {r3.x, r3.y};
+}
+#endif
 
 // natural-order in, natural-order out
 template <int DIR, typename R> MDSP_HD void bfly4(cx<R>& a0, cx<R>& a1, cx<R>& a2, cx<R>& a3) {
@@ -287,6 +371,21 @@ template <int RDX, int DIR, typename R> MDSP_HD void bfly(cx<R> (&v)[RDX]) {
     else if constexpr (RDX == 4) bfly4<DIR>(v[0], v[1], v[2], v[3]);
     else if constexpr (RDX == 8) bfly8<DIR>(v);
     else bfly16<DIR>(v);
+}
+
+// v[r] *= w[r] (conjugated for the inverse), r = 1..RDX-1: the twiddle products in front of a butterfly (pairs of products per statement in the
+// fused packed form)
+template <int DIR, int RDX, typename R> MDSP_HD void twmul_all(cx<R> (&v)[RDX], const cx<R> (&w)[RDX]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDSP_NO_PACKED_F32) && MDSP_PK_FUSED
+    if constexpr (sizeof(R) == 4) {
+#pragma unroll
+        for (int r = 1; r + 1 < RDX; r += 2) cmul2(v[r], w[r], v[r + 1], w[r + 1], DIR > 0);
+        if constexpr (((RDX - 1) & 1) != 0) v[RDX - 1] = twmul<DIR>(v[RDX - 1], w[RDX - 1]);
+        return;
+    }
+#endif
+#pragma unroll
+    for (int r = 1; r < RDX; ++r) v[r] = twmul<DIR>(v[r], w[r]);
 }
 
 // ------------------------------------------------------------------------------------------------ configuration
@@ -469,18 +568,18 @@ MDSP_HD void pass_compute(cx<R> (&x)[C::E], int t_raw, const cx<R> (&tw)[C::NTW 
             [[maybe_unused]] int kt = (Ns > C::T) ? t : (t & (Ns - 1));   // TW_LDS: k = kt + (T*b mod Ns), see below
             constexpr bool IN_LDS = tw_pass_in_lds<C, TWMODE, PASS>(), IN_REGS = tw_pass_in_regs<C, TWMODE, PASS>();
             if constexpr (IN_LDS) MDSP_OPAQUE_INT(kt);
+            cx<R> wv[Rdx];
 #pragma unroll
             for (int r = 1; r < Rdx; ++r) {
-                cx<R> w;
-                if constexpr (IN_REGS) w = tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)];
+                if constexpr (IN_REGS) wv[r] = tw[C::twoff(PASS) + b * (Rdx - 1) + (r - 1)];
                 else if constexpr (IN_LDS) {
                     // `table` points at the LDS twiddle table.  k = (t + T*b) mod Ns = kt + KB with kt = t mod Ns (or t when
                     // Ns > T) and KB = (T*b) mod Ns a compile-time constant (no carry: KB is a multiple of T, kt < T).
                     const int KB = (C::T * b) & (Ns - 1);   // constant after unrolling
-                    w = table[kt + (C::ldsoff(PASS) + (r - 1) * Ns + KB)];
-                } else w = table[tw_index<C, PASS>(t, b, r)];
-                v[r] = twmul<DIR>(v[r], w);
+                    wv[r] = table[kt + (C::ldsoff(PASS) + (r - 1) * Ns + KB)];
+                } else wv[r] = table[tw_index<C, PASS>(t, b, r)];
             }
+            twmul_all<DIR, Rdx>(v, wv);
         }
         bfly<Rdx, DIR>(v);
         if constexpr (LAST) {

@@ -7,14 +7,23 @@
 // the key is everything the plan depends on -- device, calling thread, stream, sizes, dtype, engine, mode and the CONTENTS of the taps /
 // window -- so a hit is exactly the plan a fresh create would have produced.
 //
-// Ownership: a cached handle is BORROWED.  It must not be passed to mdsp_*_plan_destroy.  The cache is partitioned BY CALLING THREAD: every
-// thread has its own two LRU lists -- one of MDSP_PLAN_CACHE_SIZE user-visible plans ('o' overlap-save, 'w' Welch, 's' STFT), one of the same
-// size for the objects the library caches for itself ('f' per-call FIR filters, 't' tap uploads of the stateful FIR entry points) -- and only
-// that thread's own requests of the same class ever evict from them.  So a borrowed handle stays valid until the thread that borrowed it has
-// made MDSP_PLAN_CACHE_SIZE further DISTINCT cached-plan requests, whatever other threads do, and the library's internal objects can never
-// push a user's plan out.  (Round 2 kept one global list: misses of other threads, or this thread's own internal entries, could destroy a plan
-// between its lookup and its use.)  mdsp_plan_cache_clear() destroys every thread's entries: call it only while no other thread is inside the
-// library.  The lists of threads that have exited stay until then (at most 2 x MDSP_PLAN_CACHE_SIZE small objects per thread).
+// Ownership: a cached handle is BORROWED.  It must not be passed to mdsp_*_plan_destroy.  The cache is PARTITIONED: every partition has its own
+// two LRU lists -- one of MDSP_PLAN_CACHE_SIZE user-visible plans ('o' overlap-save, 'w' Welch, 's' STFT), one of the same size for the objects
+// the library caches for itself ('f' per-call FIR filters, 't' tap uploads of the stateful FIR entry points) -- and only requests of the same
+// partition and class evict from them.  The partition of a request is the calling OS thread, unless the caller has bound an explicit context
+// (mdsp_plan_cache_set_context(id != 0), thread-local): hosts whose logical tasks migrate between OS threads -- Julia tasks -- bind their own
+// id before their calls and keep one partition wherever they run; mdsp_plan_cache_release_context(id) frees it.
+//   * A borrowed handle stays valid until its partition has made MDSP_PLAN_CACHE_SIZE further DISTINCT cached-plan requests (and the library's
+//     internal objects can never push a user's plan out), with ONE exception that bounds the device memory of a churning host: when the whole
+//     cache holds more than MDSP_PLAN_CACHE_TOTAL entries (default 8 x MDSP_PLAN_CACHE_SIZE), entries of OTHER partitions that have not
+//     made a request for MDSP_PLAN_CACHE_IDLE (default 64) cache requests are evicted, most idle partition first.  Partitions that are in
+//     use are never touched by other partitions' requests; if none is idle the cap is not enforced.
+//   * The lists of an OS thread that EXITS are reaped: a thread-local sentinel moves them to a graveyard at thread exit and the next cache
+//     request (of any thread) or mdsp_plan_cache_clear() destroys them.  (Round 3 kept them until mdsp_plan_cache_clear(): every Welch / STFT
+//     plan owns device buffers -- partial sums of nslots x nch x nfft doubles, rocFFT intermediates of up to MDSP_ROCFFT_CHUNK_MIB -- so a
+//     thread pool leaked device memory: ADVICE r3.)
+// mdsp_plan_cache_clear() destroys every partition's entries: call it only while no other thread is inside the library.
+#include <cstdlib>
 #include <functional>
 #include <list>
 #include <thread>
@@ -28,26 +37,65 @@ namespace {
 
 constexpr size_t kCapacity = MDSP_PLAN_CACHE_SIZE;
 
+size_t total_cap() { return (size_t)tunables().plan_cache_total; }     // MDSP_PLAN_CACHE_TOTAL (read with the other tunables, api_core.hip)
+uint64_t idle_ticks() { return (uint64_t)tunables().plan_cache_idle; } // MDSP_PLAN_CACHE_IDLE
+
 struct Entry {
     std::string key;
     void* handle;
     std::function<void(void*)> destroy;
 };
 
-struct PerThread {
+struct Partition {
     std::list<Entry> user, internal;   // front = most recently used
+    uint64_t last_use = 0;             // tick of this partition's latest request
+    size_t size() const { return user.size() + internal.size(); }
 };
 
+// partition id: bit 63 set = an explicit context (mdsp_plan_cache_set_context), clear = hash of the OS thread id
+using Pid = uint64_t;
+constexpr Pid kCtxBit = 1ull << 63;
+
 struct Cache {
-    std::mutex mu;                                         // guards the map and the lists (held for list surgery only, never across device work)
-    std::unordered_map<std::thread::id, PerThread> by_thread;
-    int64_t hits = 0, misses = 0;
+    std::mutex mu;                                         // guards everything below (held for list surgery only, never across device work)
+    std::unordered_map<Pid, Partition> parts;
+    std::list<Entry> graveyard;                            // entries of exited threads / released contexts / cap evictions, awaiting destruction
+    uint64_t tick = 0;
+    int64_t hits = 0, misses = 0, reaped = 0;
 };
 
 Cache& cache() {
     static Cache* c = new Cache();   // never destroyed: no device calls from static destructors at process exit
     return *c;
 }
+
+thread_local Pid tl_context = 0;     // 0: the OS thread is the partition
+
+Pid thread_pid() { return (Pid)std::hash<std::thread::id>()(std::this_thread::get_id()) & ~kCtxBit; }
+Pid current_pid() { return tl_context ? (tl_context | kCtxBit) : thread_pid(); }
+
+// moves the partition's entries to the graveyard (caller holds the mutex)
+void bury(Cache& c, Pid pid) {
+    auto it = c.parts.find(pid);
+    if (it == c.parts.end()) return;
+    c.reaped += (int64_t)it->second.size();
+    c.graveyard.splice(c.graveyard.end(), it->second.user);
+    c.graveyard.splice(c.graveyard.end(), it->second.internal);
+    c.parts.erase(it);
+}
+
+// One per OS thread that ever used the cache: at thread exit its partition goes to the graveyard (no device call here: the next request drains it).
+struct ThreadSentinel {
+    Pid pid;
+    bool armed = false;
+    ~ThreadSentinel() {
+        if (!armed) return;
+        Cache& c = cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        bury(c, pid);
+    }
+};
+thread_local ThreadSentinel tl_sentinel;
 
 bool is_internal(const std::string& key) { return !key.empty() && (key[0] == 'f' || key[0] == 't'); }
 
@@ -62,7 +110,7 @@ std::string plan_cache_key(char kind, void* stream) {
     int dev = -1;
     (void)hipGetDevice(&dev);
     put(k, dev);
-    put(k, std::hash<std::thread::id>()(std::this_thread::get_id()));
+    put(k, current_pid());
     put(k, stream);
     return k;
 }
@@ -74,38 +122,65 @@ std::string base_key(char kind, void* stream) { return plan_cache_key(kind, stre
 }  // namespace
 
 namespace mdsp {
-// find or create; `make` builds a new object into *out.  Only the calling thread's list of the key's class is searched and evicted from.
+// find or create; `make` builds a new object into *out.  Only the caller's partition's list of the key's class is searched and evicted from
+// (plus, above the global cap, the tails of partitions that have been idle for a long time: see the header).
 int plan_cache_get(const std::string& key, void** out, const std::function<int(void**)>& make, std::function<void(void*)> destroy) {
     Cache& c = cache();
-    const std::thread::id me = std::this_thread::get_id();
+    const Pid me = current_pid();
     const bool internal = is_internal(key);
+    std::list<Entry> dead;
+    bool hit = false;
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        PerThread& pt = c.by_thread[me];
+        if (!tl_context && !tl_sentinel.armed) {
+            tl_sentinel.pid = me;
+            tl_sentinel.armed = true;
+        }
+        dead.splice(dead.end(), c.graveyard);
+        Partition& pt = c.parts[me];
+        pt.last_use = ++c.tick;
         std::list<Entry>& lru = internal ? pt.internal : pt.user;
         for (auto it = lru.begin(); it != lru.end(); ++it)
             if (it->key == key) {
                 lru.splice(lru.begin(), lru, it);
                 ++c.hits;
                 *out = it->handle;
-                return MDSP_OK;
+                hit = true;
+                break;
             }
     }
+    for (auto& e : dead) e.destroy(e.handle);   // outside the lock: hipFree synchronises
+    dead.clear();
+    if (hit) return MDSP_OK;
     void* h = nullptr;
     MDSP_TRY(make(&h));            // outside the lock: plan creation touches the device
-    std::vector<Entry> evicted;
     {
         std::lock_guard<std::mutex> lk(c.mu);
         ++c.misses;
-        PerThread& pt = c.by_thread[me];
+        Partition& pt = c.parts[me];
         std::list<Entry>& lru = internal ? pt.internal : pt.user;
         lru.push_front(Entry{key, h, std::move(destroy)});
-        while (lru.size() > kCapacity) {   // this thread's least recently used entries of this class
-            evicted.push_back(std::move(lru.back()));
+        while (lru.size() > kCapacity) {   // this partition's least recently used entries of this class
+            dead.push_back(std::move(lru.back()));
             lru.pop_back();
         }
+        // the global cap: tails of the most idle OTHER partitions
+        size_t total = 0;
+        for (auto& kv : c.parts) total += kv.second.size();
+        while (total > total_cap()) {
+            Partition* victim = nullptr;
+            for (auto& kv : c.parts)
+                if (kv.first != me && kv.second.size() > 0 && c.tick - kv.second.last_use >= idle_ticks() && (!victim || kv.second.last_use < victim->last_use))
+                    victim = &kv.second;
+            if (!victim) break;            // nobody is idle: the cap is soft
+            std::list<Entry>& from = victim->internal.size() > victim->user.size() ? victim->internal : victim->user;
+            dead.push_back(std::move(from.back()));
+            from.pop_back();
+            ++c.reaped;
+            --total;
+        }
     }
-    for (auto& e : evicted) e.destroy(e.handle);   // hipFree inside synchronises with any launch still using the buffers
+    for (auto& e : dead) e.destroy(e.handle);   // hipFree inside synchronises with any launch still using the buffers
     *out = h;
     return MDSP_OK;
 }
@@ -176,11 +251,37 @@ int mdsp_plan_cache_stats(int64_t* entries, int64_t* hits, int64_t* misses) {
     Cache& c = cache();
     std::lock_guard<std::mutex> lk(c.mu);
     if (entries) {
-        *entries = 0;
-        for (auto& kv : c.by_thread) *entries += (int64_t)(kv.second.user.size() + kv.second.internal.size());
+        *entries = (int64_t)c.graveyard.size();
+        for (auto& kv : c.parts) *entries += (int64_t)kv.second.size();
     }
     if (hits) *hits = c.hits;
     if (misses) *misses = c.misses;
+    return MDSP_OK;
+}
+
+int mdsp_plan_cache_partitions(int64_t* partitions, int64_t* reaped) {
+    Cache& c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (partitions) *partitions = (int64_t)c.parts.size();
+    if (reaped) *reaped = c.reaped;
+    return MDSP_OK;
+}
+
+int mdsp_plan_cache_set_context(uint64_t id) {
+    tl_context = id & ~kCtxBit;
+    return MDSP_OK;
+}
+
+int mdsp_plan_cache_release_context(uint64_t id) {
+    if (id == 0) MDSP_FAIL(MDSP_ERR_ARGUMENT, "context 0 is the calling thread's own partition");
+    Cache& c = cache();
+    std::list<Entry> dead;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        bury(c, (id & ~kCtxBit) | kCtxBit);
+        dead.splice(dead.end(), c.graveyard);
+    }
+    for (auto& e : dead) e.destroy(e.handle);
     return MDSP_OK;
 }
 
@@ -189,11 +290,12 @@ int mdsp_plan_cache_clear(void) {
     std::list<Entry> all;
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        for (auto& kv : c.by_thread) {
+        for (auto& kv : c.parts) {
             all.splice(all.end(), kv.second.user);
             all.splice(all.end(), kv.second.internal);
         }
-        c.by_thread.clear();
+        c.parts.clear();
+        all.splice(all.end(), c.graveyard);
     }
     for (auto& e : all) e.destroy(e.handle);
     return MDSP_OK;

@@ -122,10 +122,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
 //   MODE 4: two-sided from PAIR-PACKED full spectrum
 template <typename R, int MODE>
 __global__ __launch_bounds__(256) void welch_finalize_kernel(const double* __restrict__ partial, R* __restrict__ psd, int64_t ldp, int nslices,
-                                                             int64_t nch, int nacc, int nfft, int nout, double r_total) {
+                                                             int64_t nch, int nacc, int nfft, int nout, double r_total, const double* __restrict__ kdev,
+                                                             double r_unit) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ch = blockIdx.y;
     if (j >= nout) return;
+    if (kdev) {   // frame count summed over ranks on the device (mdsp_welch_allreduce): r = K fs sum(w^2) is formed here
+        const double k = *kdev;
+        if (!(k > 0)) {   // no frames anywhere: fill!(out, 0)
+            psd[ch * ldp + j] = (R)0;
+            return;
+        }
+        r_total = k * r_unit;
+    }
     auto sum_bin = [&](int k) {
         double a = 0;
         for (int s = 0; s < nslices; ++s) a += partial[((int64_t)s * nch + ch) * nacc + k];
@@ -804,7 +813,8 @@ int welch_accumulate_rocfft(mdsp_welch_plan_s* pl, const void* s, int64_t len, i
 // psd[ch][j] = T( m_j * fold(accumulated |X|^2 sums) ), m from r_total = K_total * fs * sum(w^2)  (periodograms.jl:751, :142-172)
 template <typename R> int welch_finalize(mdsp_welch_plan_s* pl, int64_t K_total, int64_t nch, void* psd, int64_t ldp, hipStream_t st) {
     const int nout = (int)pl->nout;
-    if (K_total <= 0) {  // fill!(out, 0); no frames (0 * r would be a division by zero in m)
+    const double* kdev = (K_total == 0 && pl->frames_on_device) ? pl->kdev.as<double>() : nullptr;
+    if (K_total <= 0 && !kdev) {  // fill!(out, 0); no frames (0 * r would be a division by zero in m)
         for (int64_t c = 0; c < nch; ++c) MDSP_HIP(hipMemsetAsync((R*)psd + c * ldp, 0, sizeof(R) * (size_t)nout, st));
         return MDSP_OK;
     }
@@ -812,7 +822,7 @@ template <typename R> int welch_finalize(mdsp_welch_plan_s* pl, int64_t K_total,
     const dim3 grid((unsigned)cdiv(nout, 256), (unsigned)nch);
     const double* acc = pl->acc_ptr();
     const int ns = pl->acc_nslices, na = pl->acc_nacc, nfft = (int)pl->nfft;
-#define MDSP_FIN(MODE) hipLaunchKernelGGL((welch_finalize_kernel<R, MODE>), grid, dim3(256), 0, st, acc, (R*)psd, ldp, ns, nch, na, nfft, nout, r_total)
+#define MDSP_FIN(MODE) hipLaunchKernelGGL((welch_finalize_kernel<R, MODE>), grid, dim3(256), 0, st, acc, (R*)psd, ldp, ns, nch, na, nfft, nout, r_total, kdev, pl->r)
     switch (pl->acc_mode) {
         case 0: MDSP_FIN(0); break;
         case 1: MDSP_FIN(1); break;
@@ -1511,6 +1521,7 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
                 else if (pl->variant == 33) rc = welch_run_half3<N, 5, 1, true>(pl, a, st, &nslices);   // ... two units in flight (two register sets)
                 else if (pl->variant == 34) rc = welch_run_half3<N, 4, 1, true>(pl, a, st, &nslices);
+                else if (pl->variant == 41) rc = w64::welch_run_w64b(pl, a, st, &nslices);  // ... two waves per SIMD: two-level twiddles, direct loads
                 else if (pl->variant == 40) rc = w64::welch_run_w64(pl, a, st, &nslices);   // round 4: one wavefront per transform, 64 x 64, one exchange
                 else if (pl->variant == 35 || pl->variant == 36) {   // half-frames staged in LDS by DMA, two units ahead (pad 5 / pad 4)
                     rc = pl->variant == 35 ? welch_run_half4<N, 5>(pl, a, st, &nslices) : welch_run_half4<N, 4>(pl, a, st, &nslices);
@@ -1699,6 +1710,7 @@ int mdsp_welch_reset(mdsp_welch_plan plan) {
     plan->acc_fresh = true;
     plan->acc_frames = 0;
     plan->acc_nch = 0;
+    plan->frames_on_device = false;
     return MDSP_OK;
 }
 
@@ -1720,12 +1732,18 @@ int mdsp_welch_accumulate(mdsp_welch_plan plan, const void* s_dev, int64_t len, 
     if (rc != MDSP_OK) return rc;
     plan->acc_nch = nch;
     plan->acc_frames += mdsp_frame_count(len, plan->n, plan->noverlap);
+    plan->frames_on_device = false;   // an all-reduced count (mdsp_welch_allreduce) does not know about these frames: finalize takes frames_total from its caller then
     return MDSP_OK;
 }
 
 int mdsp_welch_frames_accumulated(mdsp_welch_plan plan, int64_t* frames_per_channel) {
     if (!plan || !frames_per_channel) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL argument");
     *frames_per_channel = plan->acc_frames;
+    if (plan->frames_on_device) {   // after mdsp_welch_allreduce: the total over ranks, read back (this query, unlike the collective, synchronises)
+        double k = 0;
+        MDSP_HIP(hipMemcpy(&k, plan->kdev.p, sizeof(double), hipMemcpyDeviceToHost));
+        *frames_per_channel = (int64_t)k;
+    }
     return MDSP_OK;
 }
 
@@ -1742,7 +1760,7 @@ int mdsp_welch_finalize(mdsp_welch_plan plan, int64_t frames_total, void* psd_de
     if (!psd_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "out is NULL");
     if (plan->acc_fresh) MDSP_FAIL(MDSP_ERR_ARGUMENT, "nothing accumulated since the last mdsp_welch_reset");
     if (plan->acc_nch > 1 && ldp < plan->nout) MDSP_FAIL(MDSP_ERR_DIMENSION, "leading dimension smaller than the column length");
-    const int64_t K = frames_total > 0 ? frames_total : plan->acc_frames;
+    const int64_t K = frames_total > 0 ? frames_total : (plan->frames_on_device ? 0 : plan->acc_frames);   // 0 with frames_on_device: the kernel reads the all-reduced count
     return dtype_is_double(plan->dtype) ? welch_finalize<double>(plan, K, plan->acc_nch, psd_dev, ldp, as_stream(stream))
                                         : welch_finalize<float>(plan, K, plan->acc_nch, psd_dev, ldp, as_stream(stream));
 }

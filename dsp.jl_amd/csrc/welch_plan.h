@@ -20,6 +20,10 @@ struct mdsp_welch_plan_s {
     //   rocFFT engine: `partial`, acc_nslices = 32 deterministic slices, acc_nacc = nspec bins per channel
     bool acc_fresh = true;       // nothing accumulated yet: the next accumulate overwrites instead of adding
     int64_t acc_nch = 0, acc_frames = 0;
+    // after mdsp_welch_allreduce the frame count summed over ranks lives on the DEVICE (kdev, one double, reduced together with the sums: no host
+    // round trip, no stream synchronisation); mdsp_welch_finalize(plan, 0, ...) reads it there.  acc_frames stays this rank's own count.
+    mdsp::DevBuf kdev;
+    bool frames_on_device = false;
     int acc_nslices = 1, acc_nacc = 0, acc_mode = 0;   // welch_finalize_kernel MODE
     double* acc_ptr() const { return engine == MDSP_ENGINE_ROCFFT ? partial.as<double>() : reduced.as<double>(); }
 };

@@ -203,6 +203,153 @@ __global__ __launch_bounds__(256, 1) void welch_w64_kernel(SpecArgs a) {
     }
 }
 
+// ---- the same transform with TWO waves per SIMD (variant 41) -----------------------------------------------------------------------------
+// What the first GPU session said about welch_w64_kernel (gpurun_out/s1, 2^30 samples): parity green at the first attempt, 1.65 ms against
+// 1.36 ms for welch_half3_kernel.  Its unit loop is 2177 instructions and a unit takes ~14 200 clocks: ~6.5 clocks per instruction, which is what
+// ONE wave per SIMD issues (tools/ubench/valu_rate.hip, profiles/r02t_valu_rate.txt: v_pk_* at 5.69 clocks per instruction with one wave per SIMD,
+// 4.75 with two, 4.40 with four).  The registers that forced one wave per SIMD were the AGPR-resident twiddles, carry and the DMA staging; here:
+//   * twiddles W^{lane T}, T = t1 + 8 t2, as a product of two per-lane tables of seven roots each (28 VGPRs): W^{8 lane t2} on the operands of
+//     pass B's first radix-8 layer, W^{lane t1} on its results (112 complex products instead of 63: +98 packed instructions per unit),
+//   * no staging and no carry: a unit's three half-frames are loaded straight into the operand registers of the first layer (96 loads of 256
+//     bytes per wave; the middle half-frame comes from L2 the second time) once the previous unit's spectrum has been accumulated -- the partner
+//     wave of the SIMD computes while they are in flight,
+// so a wave needs <= 256 registers, eight waves (one 512-thread workgroup, no barriers after the window table) share a CU, and LDS holds the
+// window pairs + 8 x 16.5 KiB of exchange buffers = 148 KiB.
+constexpr int LDS_BYTES_B = WIN_BYTES + 8 * XBUF_BYTES;
+static_assert(LDS_BYTES_B <= 160 * 1024, "one workgroup per CU");
+
+template <int DUMMY = 0>
+__global__ __launch_bounds__(512, 2) void welch_w64b_kernel(SpecArgs a) {
+    using R = float;
+    extern __shared__ __attribute__((aligned(16))) unsigned char w64_smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    cx<R>* winl = reinterpret_cast<cx<R>*>(w64_smem);
+    cx<R>* xb = reinterpret_cast<cx<R>*>(w64_smem + WIN_BYTES + wave * XBUF_BYTES);
+    const cx<R>* table = static_cast<const cx<R>*>(a.table);
+    const int64_t ch = blockIdx.y;
+    for (int p = tid; p < HALF; p += 512) {
+        const double lo = p < a.n ? (a.win ? a.win[p] : 1.0) : 0.0, hi = (p + HALF) < a.n ? (a.win ? a.win[p + HALF] : 1.0) : 0.0;
+        winl[p] = {(R)lo, (R)hi};
+    }
+    __syncthreads();
+    cx<R> twa[8], twb[8];   // [0] unused
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        twa[j] = table[(8 * lane * j) & (N - 1)];
+        twb[j] = table[(lane * j) & (N - 1)];
+    }
+    float acc[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) acc[s] = 0.f;
+    const int64_t slot = (int64_t)blockIdx.x * 8 + wave;
+    double* part = static_cast<double*>(a.out) + (slot * a.nch + ch) * N;
+    const __amdgpu_buffer_rsrc_t prs = io::make_rsrc(part, (int64_t)N * 8);
+    bool first = true;
+    auto flush = [&]() __attribute__((always_inline)) {
+        int off = lane * 8;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int kt = 0; kt < 64; ++kt) {
+            double s = (double)acc[fft::slot64(kt)];
+            if (!first) s += io::Ld<double>::load(prs, off + 64 * kt * 8);
+            io::Ld<double>::store(s, prs, off + 64 * kt * 8);
+            acc[fft::slot64(kt)] = 0.f;
+        }
+        first = false;
+    };
+    const R* sc = static_cast<const R*>(a.s) + ch * a.lds_;
+    const int64_t u0 = slot * a.run_len;
+    const int64_t uend = std::min<int64_t>(u0 + a.run_len, a.units_per_ch);
+    if (uend > u0) {
+        struct Grp { cx<R> xp[4], hh[2]; };
+        Grp g[8];   // the operands of the first layer: g[n1].xp[j] = (H0, H2)[lane + 64 (n1 + 8 j)], g[n1].hh = H1 at j = (0, 1), (2, 3)
+        auto load_unit = [&](int64_t u) __attribute__((always_inline)) {
+            const bool live = u < uend, haveB = live && (2 * u + 1) < a.K;
+            const int64_t pos = u * N;
+            const __amdgpu_buffer_rsrc_t r0 = io::make_rsrc(sc + pos, live ? (int64_t)HALF * 4 : 0);
+            const __amdgpu_buffer_rsrc_t r1 = io::make_rsrc(sc + pos + HALF, live ? (int64_t)HALF * 4 : 0);
+            const __amdgpu_buffer_rsrc_t r2 = io::make_rsrc(sc + pos + 2 * HALF, haveB ? (int64_t)HALF * 4 : 0);
+            int off = lane * 4;
+            asm volatile("" : "+v"(off));
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = n1 + 8 * j;
+                    g[n1].xp[j] = {io::Ld<R>::load(r0, off + 256 * e), io::Ld<R>::load(r2, off + 256 * e)};
+                }
+                g[n1].hh[0] = {io::Ld<R>::load(r1, off + 256 * n1), io::Ld<R>::load(r1, off + 256 * (n1 + 8))};
+                g[n1].hh[1] = {io::Ld<R>::load(r1, off + 256 * (n1 + 16)), io::Ld<R>::load(r1, off + 256 * (n1 + 24))};
+            }
+        };
+        load_unit(u0);
+        int since = 0;
+        auto unit = [&](auto frame_b, int64_t u) __attribute__((always_inline)) {
+            constexpr bool FRAME_B = decltype(frame_b)::value;
+            cx<R> v[64];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                cx<R> wp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wp[j] = fft::ld2(winl + lane + 64 * (n1 + 8 * j));
+                fft::passA_welch_group<FRAME_B>(n1, g[n1].xp, g[n1].hh, wp, v);
+            }
+            fft::bfly64_tail<-1>(v);
+            transpose64(v, xb, lane);
+            // pass B with the two-level twiddles: W^{8 lane t2} before the first radix-8 layer, W^{lane t1} behind it
+#pragma unroll
+            for (int t1 = 0; t1 < 8; ++t1) {
+                cx<R> q[8];
+                q[0] = v[t1];
+#pragma unroll
+                for (int t2 = 1; t2 < 8; ++t2) q[t2] = fft::cmul(v[t1 + 8 * t2], twa[t2]);
+                fft::bfly8<-1>(q);
+#pragma unroll
+                for (int k1 = 0; k1 < 8; ++k1) v[t1 + 8 * k1] = t1 == 0 ? q[k1] : fft::cmul(q[k1], twb[t1]);
+            }
+            fft::bfly64_tail<-1>(v);
+#pragma unroll
+            for (int s = 0; s < 64; ++s) acc[s] = fma_sq(v[s].y, fma_sq(v[s].x, acc[s]));
+            load_unit(u + 1);   // into the registers the spectrum has just left
+        };
+        for (int64_t u = u0; u < uend; ++u) {
+            if ((2 * u + 1) < a.K) unit(std::true_type{}, u);
+            else unit(std::false_type{}, u);
+            if (++since == 128 || u + 1 == uend) {
+                flush();
+                since = 0;
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int kt = 0; kt < 64; ++kt) io::Ld<double>::store(0.0, prs, lane * 8 + 64 * kt * 8);
+    }
+}
+
+inline int welch_run_w64b(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
+    auto kern = welch_w64b_kernel<0>;
+    static std::atomic<unsigned long long> lds_opt_in{0};
+    int dev = 0;
+    MDSP_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(lds_opt_in.load(std::memory_order_acquire) & bit)) {
+        MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_opt_in.fetch_or(bit, std::memory_order_release);
+    }
+    const int64_t per_ch = std::max<int64_t>(1, (int64_t)device_cu_count() / std::max<int64_t>(1, a.nch));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(a.units_per_ch, 8), per_ch));
+    const int64_t nslots = (int64_t)grid * 8;
+    MDSP_TRY(pl->partial.reserve(sizeof(double) * (size_t)nslots * (size_t)a.nch * N));
+    a.out = pl->partial.p;
+    set_schedule(a, a.units_per_ch, nslots);
+    a.run_len = cdiv(a.units_per_ch, nslots);
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)a.nch), dim3(512), LDS_BYTES_B, st, a);
+    MDSP_LAUNCH_CHECK();
+    *nslices = (int)nslots;
+    return MDSP_OK;
+}
+
 inline int welch_run_w64(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int* nslices) {
     auto kern = welch_w64_kernel<0>;
     static std::atomic<unsigned long long> lds_opt_in{0};

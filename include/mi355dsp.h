@@ -194,7 +194,8 @@ int mdsp_allreduce_sum(mdsp_comm comm, void* buf_dev, int64_t count, int real_dt
 int mdsp_welch_mean_allreduce(mdsp_welch_plan plan, const void* psd_dev, int64_t nch_local, int64_t ldp, int64_t nch_total,
                               void* mean_dev, mdsp_comm comm, void* stream);
 /* ONE stream split along time over ranks: sums the plans' Float64 accumulators and frame counts over ranks in place; a following
- * mdsp_welch_finalize(plan, 0, ...) gives every rank the PSD of the whole stream.  Synchronises `stream`. */
+ * mdsp_welch_finalize(plan, 0, ...) gives every rank the PSD of the whole stream.  Stream-ordered (one RCCL group of the sums and the
+ * frame count; the total count stays on the device and finalize reads it there); mdsp_welch_frames_accumulated afterwards reads it back. */
 int mdsp_welch_allreduce(mdsp_welch_plan plan, mdsp_comm comm, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -386,10 +387,16 @@ int mdsp_hilbert(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int r
  * Plan cache inside the library: the per-call fast path for hosts that mirror DSP.jl's function-style entry points one-to-one
  * (filt(b, x), conv(u, v), welch_pgram(s, n, noverlap), stft / spectrogram / periodogram build their FFTW plans on every call;
  * a device plan costs ~1 ms, the call ~45 us).  Same arguments as the matching *_plan_create plus the stream the plan will run on;
- * the key is (device, calling thread, stream, every argument, CONTENTS of taps / window).  The returned handle is BORROWED: never
- * destroy it.  The cache is partitioned by calling thread (and the library's own cached objects live in separate lists), so the handle
- * stays valid until THE SAME THREAD has made MDSP_PLAN_CACHE_SIZE further distinct cached requests, whatever other threads do, or until
- * mdsp_plan_cache_clear() -- which destroys every thread's entries and must not race with other threads' library calls.
+ * the key is (device, partition, stream, every argument, CONTENTS of taps / window).  The returned handle is BORROWED: never destroy it.
+ * Partitions: the calling OS thread by default; a host whose logical tasks migrate between OS threads (Julia tasks) binds its own id with
+ * mdsp_plan_cache_set_context(id != 0) -- thread-local, 0 restores the per-thread default -- and frees that partition with
+ * mdsp_plan_cache_release_context(id).  Only requests of the same partition evict from its two lists (user plans / the library's own cached
+ * objects, MDSP_PLAN_CACHE_SIZE each), so a handle stays valid until ITS PARTITION has made MDSP_PLAN_CACHE_SIZE further distinct cached requests,
+ * with one exception that bounds device memory: above MDSP_PLAN_CACHE_TOTAL entries in the whole cache (environment, default 8 x
+ * MDSP_PLAN_CACHE_SIZE) entries of partitions that have made no request for MDSP_PLAN_CACHE_IDLE (default 64) cache requests are evicted.
+ * The entries of an OS thread that exits are reaped automatically (destroyed at the next cache request of any thread).
+ * mdsp_plan_cache_clear() destroys every partition's entries and must not race with other threads' library calls.
+ * mdsp_plan_cache_partitions: live partitions and the number of entries reaped so far (exited threads, released contexts, cap evictions).
  * ---------------------------------------------------------------------------------------------------- */
 #define MDSP_PLAN_CACHE_SIZE 16
 int mdsp_ols_plan_cached(mdsp_ols_plan* plan, const void* taps_host, int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode,
@@ -399,6 +406,9 @@ int mdsp_welch_plan_cached(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, i
 int mdsp_stft_plan_cached(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int64_t nfft, const double* window_host, double r,
                           int onesided, int psd_only, int dtype, int engine, void* stream);
 int mdsp_plan_cache_stats(int64_t* entries, int64_t* hits, int64_t* misses);
+int mdsp_plan_cache_partitions(int64_t* partitions, int64_t* reaped);
+int mdsp_plan_cache_set_context(uint64_t id);
+int mdsp_plan_cache_release_context(uint64_t id);
 int mdsp_plan_cache_clear(void);
 
 /* ------------------------------------------------------------------------------------------------------

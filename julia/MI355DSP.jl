@@ -89,6 +89,23 @@ function plan_cache_stats()
     (entries = Int(e[]), hits = Int(h[]), misses = Int(m[]))
 end
 plan_cache_clear() = check(ccall((:mdsp_plan_cache_clear, lib), Cint, ()))
+function plan_cache_partitions()
+    p, r = Ref{Int64}(0), Ref{Int64}(0)
+    check(ccall((:mdsp_plan_cache_partitions, lib), Cint, (Ref{Int64}, Ref{Int64}), p, r))
+    (partitions = Int(p[]), reaped = Int(r[]))
+end
+# Julia tasks migrate between OS threads: a task that borrows cached plans binds its own partition (thread-local in the library, so it is bound
+# again after every yield point that may migrate the task -- `with_plan_context` does that around one call).
+plan_cache_set_context(id::Integer) = check(ccall((:mdsp_plan_cache_set_context, lib), Cint, (UInt64,), UInt64(id)))
+plan_cache_release_context(id::Integer) = check(ccall((:mdsp_plan_cache_release_context, lib), Cint, (UInt64,), UInt64(id)))
+function with_plan_context(f, id::Integer=objectid(current_task()) % UInt64)
+    plan_cache_set_context(id)
+    try
+        return f()
+    finally
+        plan_cache_set_context(0)
+    end
+end
 
 # HIP events on the library's launch stream (what bench.py times with)
 mutable struct Event

@@ -45,3 +45,18 @@ def relerr(a, ref):
 @pytest.fixture(scope="session")
 def approx():
     return isapprox
+
+
+EPS32 = 2.0 ** -24          # unit roundoff of Float32
+
+
+def ulps_of_max(a, ref, axis=None):
+    """Element-wise error in units of (Float32 unit roundoff x the largest reference magnitude along `axis`): max |a - ref| / (2^-24 max|ref|).
+    north_star asks for a STATED ulp tolerance; the parity tests assert this figure against c * log2(nfft) (FFT paths) or c * taps (dot products)
+    next to the norm-wise bound -- a handful of badly wrong small bins cannot hide in a norm."""
+    a = np.asarray(a)
+    ref = np.asarray(ref)
+    ct = np.complex128 if (a.dtype.kind == "c" or ref.dtype.kind == "c") else np.float64
+    err = np.abs(a.astype(ct) - ref.astype(ct))
+    scale = np.max(np.abs(ref.astype(ct)), axis=axis, keepdims=axis is not None)
+    return float(np.max(err / (EPS32 * scale)))

@@ -456,7 +456,7 @@ def _julia_ccalls(src):
 
 def _jl_kind(t):
     """Julia ccall type -> ABI class."""
-    scal = {"Cint": "i32", "Int64": "i64", "Cdouble": "f64", "Float64": "f64", "Cfloat": "f32", "Csize_t": "usize", "Cstring": "cstr"}
+    scal = {"Cint": "i32", "Int64": "i64", "UInt64": "u64", "Cdouble": "f64", "Float64": "f64", "Cfloat": "f32", "Csize_t": "u64", "Cstring": "cstr"}
     if t in scal:
         return scal[t]
     m = re.fullmatch(r"(?:Ptr|Ref)\{(.*)\}", t)
@@ -472,7 +472,7 @@ def _jl_kind(t):
 def _ct_kind(t):
     """ctypes prototype entry -> ABI class."""
     import ctypes as C
-    table = {C.c_int: "i32", C.c_int64: "i64", C.c_double: "f64", C.c_float: "f32", C.c_size_t: "usize", C.c_void_p: "ptr:void", C.c_char_p: "cstr",
+    table = {C.c_int: "i32", C.c_int64: "i64", C.c_uint64: "u64", C.c_double: "f64", C.c_float: "f32", C.c_size_t: "u64", C.c_void_p: "ptr:void", C.c_char_p: "cstr",
              C.POINTER(C.c_void_p): "ptr:pvoid", C.POINTER(C.c_int64): "ptr:i64", C.POINTER(C.c_int): "ptr:i32", C.POINTER(C.c_double): "ptr:f64",
              C.POINTER(C.c_float): "ptr:f32"}
     return table[t]

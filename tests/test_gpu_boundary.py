@@ -733,7 +733,142 @@ def test_polyphase_matrix_core_kernel_fuzz(d, torch):
     assert used >= tried // 2          # most random shapes fit the matrix-core kernel
 
 
-@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36, 40])
+def test_plan_cache_reaps_exited_threads_and_honours_contexts(d, torch):
+    """csrc/plancache.hip: the plan cache is partitioned by calling thread, and every Welch plan owns device
+    buffers -- so the lists of exited threads must not stay.  A churned pool of short-lived OS threads borrows cached plans (and runs them, so
+    that they own their partial sums); afterwards one request from this thread drains the graveyard: the entry count is back to this thread's
+    own, free device memory is back where it was.  Explicit contexts: two threads that bind the same context id share one partition (a hit, the
+    same handle), and releasing the context frees it."""
+    import ctypes as C
+    import threading
+    from dsp_jl_amd import _lib
+    lib = _lib.lib()
+    _lib.check(lib.mdsp_plan_cache_clear())
+    torch.cuda.synchronize()
+    x = torch.randn(1 << 20, device="cuda", dtype=torch.float32)
+    psd = torch.empty(4097, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    errs = []
+
+    def borrow(n, run=True):
+        h = C.c_void_p()
+        _lib.check(lib.mdsp_welch_plan_cached(C.byref(h), n, n // 2, n, None, float(n), 1, _lib.F32, d.ENGINE_FUSED, None))
+        if run:
+            _lib.check(lib.mdsp_welch_exec(h, x.data_ptr(), x.numel(), 1, x.numel(), psd.data_ptr(), n // 2 + 1, None))
+            _lib.check(lib.mdsp_stream_synchronize(None))
+        return h.value
+
+    def worker(k):
+        try:
+            _lib.check(lib.mdsp_init(0))
+            for n in (256, 512, 1024, 2048, 4096, 8192):
+                borrow(n)
+        except Exception as e:   # pragma: no cover
+            errs.append(repr(e))
+
+    borrow(4096)                                              # this thread's own entry
+    free0 = torch.cuda.mem_get_info()[0]
+    for rnd in range(6):                                      # 24 threads, four at a time, all gone afterwards
+        ts = [threading.Thread(target=worker, args=(4 * rnd + k,)) for k in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not errs, errs
+    borrow(4096)                                              # any request drains the graveyard
+    e, hh, m = C.c_int64(), C.c_int64(), C.c_int64()
+    parts, reaped = C.c_int64(), C.c_int64()
+    _lib.check(lib.mdsp_plan_cache_stats(C.byref(e), C.byref(hh), C.byref(m)))
+    _lib.check(lib.mdsp_plan_cache_partitions(C.byref(parts), C.byref(reaped)))
+    assert e.value == 1 and parts.value == 1, (e.value, parts.value)
+    assert reaped.value >= 24 * 6 - 16, reaped.value          # (a few may have gone through the global cap instead: also counted)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)           # 144 plans with their partial sums would be gigabytes
+    # explicit contexts: the partition follows the id, not the OS thread
+    got = {}
+
+    def in_ctx(name):
+        _lib.check(lib.mdsp_init(0))
+        _lib.check(lib.mdsp_plan_cache_set_context(7))
+        got[name] = borrow(1024, run=False)
+        _lib.check(lib.mdsp_plan_cache_set_context(0))
+
+    for name in ("a", "b"):
+        t = threading.Thread(target=in_ctx, args=(name,))
+        t.start(); t.join()
+    assert got["a"] == got["b"]                               # second thread: a hit in the shared partition
+    _lib.check(lib.mdsp_plan_cache_stats(C.byref(e), None, None))
+    assert e.value == 2                                       # context entries survive their threads' exit
+    _lib.check(lib.mdsp_plan_cache_release_context(7))
+    _lib.check(lib.mdsp_plan_cache_stats(C.byref(e), None, None))
+    assert e.value == 1
+    _lib.check(lib.mdsp_plan_cache_clear())
+
+
+@pytest.mark.parametrize("L,M,ntaps", [(160, 147, 5120), (3, 2, 96), (1, 2, 48), (2, 1, 64)])
+def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, ntaps):
+    """stream_filt.jl:496-509: an output is the dot product of ONE column of the polyphase bank with ITS window of tapsPerPhi samples, so a NaN / Inf
+    sample makes exactly the outputs whose own window holds it non-finite.  With MDSP_FIR_MM=0 (register-tap / generic kernels: the reference's
+    windows and nothing else) the non-finite outputs are EXACTLY the oracle's.  The default matrix-core kernel multiplies a block's common window
+    by explicit zero taps, so its hole may be wider -- by at most 15 outputs plus the outputs of 64 more input positions on either side (DESIGN.md
+    section 4.6) -- and outside that widened hole its outputs are bit-identical to the MDSP_FIR_MM=0 run."""
+    import ctypes as C
+    from fractions import Fraction
+    from dsp_jl_amd import _lib
+    from oracle import stream_filt as osf
+    lib = _lib.lib()
+    rng = np.random.default_rng(77 + L + M)
+    h = (rng.standard_normal(ntaps) / np.sqrt(ntaps / L)).astype(np.float32)
+    h[np.abs(h) < 1e-3] = 1e-3                                   # no tap is zero: Inf * tap stays Inf, never NaN-by-0
+    n = 120_001
+    x = rng.standard_normal(n).astype(np.float32)
+    planted = {5: np.nan, 40_000: np.inf, 40_003: -np.inf, 77_777: np.nan, n - 2: np.inf}
+    for pos, v in planted.items():
+        x[pos] = v
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref = osf.filt_stateless(h.astype(np.float64), x.astype(np.float64), Fraction(L, M))
+    bad_ref = ~np.isfinite(ref)
+    assert 0 < bad_ref.sum() < len(ref) // 10
+    xd = torch.from_numpy(x).cuda()[None, :].contiguous()
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    try:
+        for mm in (0, 1):
+            _lib.set_tunable("MDSP_FIR_MM", mm)
+            fh = C.c_void_p()
+            _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, _lib.F32, _lib.F32, 1))
+            ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, n, C.byref(ol)))
+            assert ol.value == len(ref)
+            y = torch.zeros((1, ol.value + 1), dtype=torch.float32, device="cuda")
+            nw = C.c_int64()
+            _lib.check(lib.mdsp_fir_exec(fh, xd.data_ptr(), n, n, y.data_ptr(), ol.value, ol.value + 1, C.byref(nw), stream))
+            torch.cuda.synchronize()
+            pth = C.c_int(-1); _lib.check(lib.mdsp_fir_kernel_path(fh, n, C.byref(pth)))
+            outs[mm] = (y[0, :ol.value].cpu().numpy(), pth.value)
+            _lib.check(lib.mdsp_fir_destroy(fh))
+    finally:
+        _lib.set_tunable("MDSP_FIR_MM", None)
+    y0, path0 = outs[0]
+    y1, path1 = outs[1]
+    assert path0 != 2                                              # MDSP_FIR_MM=0 never takes the matrix-core kernel
+    bad0, bad1 = ~np.isfinite(y0), ~np.isfinite(y1)
+    assert np.array_equal(bad0, bad_ref)                           # the reference's hole, exactly
+    assert relerr(y0[~bad_ref], ref[~bad_ref]) < 2e-6
+    assert np.all(bad1[bad_ref])                                   # the default kernel's hole covers the reference's ...
+    W = 15 + int(np.ceil(64 * L / M))                              # ... and exceeds it by at most this many outputs on either side
+    idx = np.flatnonzero(bad_ref)
+    near = np.zeros(len(ref), dtype=bool)
+    for i in idx:
+        near[max(0, i - W):i + W + 1] = True
+    assert not np.any(bad1 & ~near), (int(np.sum(bad1 & ~near)), W)
+    assert np.array_equal(y1[~near], y0[~near])                    # untouched outputs: the same bits as the reference-window kernels
+    if path1 != 2:
+        assert np.array_equal(bad1, bad_ref)
+
+
+@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36, 40, 41])
 def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
     """welch_half3_kernel (paired samples, role-swapping units, window folded into the first butterfly stage, frame b's first half loaded a
     second time under the unit's have-frame-b predicate): every frame count parity, the odd last frame, one to three frames, several

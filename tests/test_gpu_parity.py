@@ -15,7 +15,7 @@ from fractions import Fraction
 import numpy as np
 import pytest
 
-from conftest import isapprox, relerr
+from conftest import isapprox, relerr, ulps_of_max
 
 pytestmark = pytest.mark.gpu
 
@@ -217,6 +217,7 @@ def test_config2_full_size_properties(d, torch):
     nblk = -(-n // L)
     spots = [0, 1, L - 3, L, 2 * L - 1, (nblk // 2) * L - 5, (nblk // 2 + 1) * L, n - 4000, n - L - 7]
     results = {}
+    worst_u = 0.0
     for engine in ENGINES:
         y = d.fftfilt(b, x, 2048, engine=engine)
         assert y.shape == (n,) and y.dtype == torch.float32
@@ -226,7 +227,12 @@ def test_config2_full_size_properties(d, torch):
             xs = x[lo:s + 600].cpu().numpy().astype(np.float64)
             ref = odsp.filt_ba(b.astype(np.float64), 1.0, xs)[s - lo:]
             assert relerr(y[s:s + 600].cpu().numpy(), ref) < TOL32, (engine, s)
+            # element-wise, in Float32 unit roundoffs of the window's largest output: two 2048-point transforms and a spectrum product per output
+            u = ulps_of_max(y[s:s + 600].cpu().numpy(), ref)
+            worst_u = max(worst_u, u)
+            assert u < 2 * 3.0 * 11, (engine, s, u)
         results[engine] = y
+    print("config 2 element-wise error, Float32 unit roundoffs of the window maximum:", worst_u)
     assert relerr(results[1][:10 ** 7].cpu().numpy(), results[2][:10 ** 7].cpu().numpy()) < TOL32
     assert float((results[1] - results[2]).abs().max()) < 1e-4
     del results

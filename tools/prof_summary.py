@@ -44,7 +44,8 @@ def pmc(path):
 # bench.py launches a marker before every measured row: mdsp_fill_kernel with (MARK_BASE + row index) workgroups.  Dispatches between two markers
 # belong to the row of the first, so a row's counters never mix with another row's dispatches of the same template instantiation.
 MARK_KERNEL, MARK_BASE = "mdsp_fill_kernel", 100
-ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32")
+ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32",
+        "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64")   # == bench.py Marks.ROWS
 
 
 def rows(path, min_ns=20000):
@@ -80,10 +81,12 @@ def dominant(rowd, pat=""):
     return max(c)[1] if c else None
 
 
-ROW_KERNELS = (("ols_fused", "step", "ols_fused_kernel"), ("welch_fused", "step", "welch_half"), ("copy", "yardsticks", "mdsp_copy_kernel"),
+ROW_KERNELS = (("ols_fused", "step", "ols_fused_kernel"), ("welch_fused", "step", "welch_"), ("copy", "yardsticks", "mdsp_copy_kernel"),
                ("stft", "stft", "stft_"), ("spectrogram", "spectrogram", "stft_"), ("resample", "resample", "polyphase_"), ("firarb", "firarb", "arbitrary_fir_kernel"),
                ("resample_f64", "resample_f64", "polyphase_"), ("resample_c32", "resample_c32", "polyphase_"), ("interp2_f32", "interp2_f32", "polyphase_"),
-               ("decim2_f32", "decim2_f32", "polyphase_"))
+               ("decim2_f32", "decim2_f32", "polyphase_"), ("welch_3000", "welch_3000", "gen_"), ("welch_1536", "welch_1536", "gen_"),
+               ("filt_5120", "filt_5120", "upols"), ("decim8_f32", "decim8_f32", "polyphase_"), ("resample_147_160_f32", "resample_147_160_f32", "polyphase_"),
+               ("resample_160_441_f64", "resample_160_441_f64", "polyphase_"))
 
 
 def traffic_rows(fetch_db, write_db):
