@@ -152,6 +152,7 @@ PROTOTYPES = {
     "mdsp_stft_plan_cached": (ci, [pvp, i64, i64, i64, pdbl, cd, ci, ci, ci, ci, vp]),
     "mdsp_plan_cache_stats": (ci, [pi64, pi64, pi64]),
     "mdsp_plan_cache_clear": (ci, []),
+    "mdsp_host_pipeline_trim": (ci, []),
     "mdsp_plan_cache_partitions": (ci, [pi64, pi64]),
     "mdsp_plan_cache_set_context": (ci, [C.c_uint64]),
     "mdsp_plan_cache_release_context": (ci, [C.c_uint64]),

@@ -68,6 +68,7 @@ static void read_tunables_locked() {
     t.ols_prefetch = geti("MDSP_OLS_PREFETCH", 0);
     t.fir_p = geti("MDSP_FIR_P", 0);
     t.fir_mm = geti("MDSP_FIR_MM", -1);
+    t.fir_exact = geti("MDSP_FIR_EXACT", 0);
     t.fir_mm_rows = geti("MDSP_FIR_MM_ROWS", -1);
     t.fir_mm_ng = geti("MDSP_FIR_MM_NG", 0);
     t.fir_mm_ch = geti("MDSP_FIR_MM_CH", 0);

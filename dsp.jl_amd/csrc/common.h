@@ -126,6 +126,8 @@ struct Tunables {
     int host_chunk_mib = 64;            // MDSP_HOST_CHUNK_MIB      : pinned staging chunk of the host-pointer entry points
     int fir_p = 0;                      // MDSP_FIR_P=4             : four output residues per thread in the fast polyphase kernel (default 2)
     int fir_mm = -1;                    // MDSP_FIR_MM=0            : matrix-core polyphase kernel off (default: wherever the shape fits)
+    int fir_exact = 0;                  // MDSP_FIR_EXACT=1         : polyphase filters run the generic kernel only -- every output reads exactly its own tapsPerPhi-sample
+                                        //                            window (stream_filt.jl:496-509), so a NaN / Inf sample leaves exactly the reference's hole
     int fir_mm_rows = -1;               // MDSP_FIR_MM_ROWS=0|1|2   : its tiles staged as one run / row by row / one run with padded rows (default: by cost; padded rows
                                         //                            where the rows' sample stride is bank-hostile)
     int fir_mm_nblk = 1;                // MDSP_FIR_MM_NBLK=0       : L > 192: the taps of a wave's column blocks fetched per tile (round 2) instead of all in registers

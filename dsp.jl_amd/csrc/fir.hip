@@ -1192,7 +1192,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
 // Fast path applies to Float32 taps x real Float32 signal with <= 64 taps per phase and <= 1024 phase groups.
 bool fir_fast_ok(const mdsp_fir_s* f, int P) {
     if (f->acc_double || f->x_dtype != MDSP_F32 || f->tp > 64) return false;
-    if (MDSP_DBG(fir_generic)) return false;
+    if (MDSP_DBG(fir_generic) || tunables().fir_exact) return false;
     if (P >= 2 && (f->M > f->L || f->L < P)) return false;
     return cdiv(f->L, P) <= 256;
 }
@@ -1504,7 +1504,7 @@ int fir_mm_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
 // no size gate pays), up to 2^28 (profiles/r02r_tune_fir); MDSP_FIR_MM=0 turns it off
 bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
     (void)a;
-    if (tunables().fir_mm == 0) return false;
+    if (tunables().fir_mm == 0 || tunables().fir_exact) return false;
     const FirMGeo g = fir_mm_geo(f);
     if (!g.ok) return false;
     // L > 192 (several column blocks per wave, small tiles): measured slower than the register-tap kernel where that one applies

@@ -129,6 +129,11 @@ void release_all() {
 Session::Session(size_t in_cap, size_t out_cap, bool pinned) : p_(pipe_for_device()), pinned_(pinned) {
     p_->mu.lock();
     rc_ = p_->init();
+    // The pipeline's streams are non-blocking: nothing orders them behind work the SAME plan / filter handle has queued on the caller's (or
+    // torch's) stream -- a device-resident mdsp_fir_exec chunk whose shift-in kernel still runs while this call rewrites the history.
+    // The host-array entries are synchronous calls that move tens of megabytes over PCIe: one device-wide synchronisation up front costs nothing
+    // measurable and closes that window whatever stream the earlier work was queued on.
+    if (rc_ == MDSP_OK && hipDeviceSynchronize() != hipSuccess) rc_ = set_error(MDSP_ERR_DEVICE, "hipDeviceSynchronize failed in front of a host-array call");
     for (Lane& ln : p_->lane) {
         ln.busy = ln.has_out = false;
         if (rc_ == MDSP_OK) rc_ = ln.din.reserve(in_cap);
@@ -218,6 +223,11 @@ int Session::finish(int rc) {
 }  // namespace mdsp
 
 extern "C" {
+
+int mdsp_host_pipeline_trim(void) {
+    hostpipe::release_all();
+    return MDSP_OK;
+}
 
 int mdsp_host_alloc(void** host_ptr, size_t bytes) {
     if (!host_ptr) MDSP_FAIL(MDSP_ERR_ARGUMENT, "host_ptr is NULL");

@@ -19,6 +19,7 @@
 //            write y once.
 //   ROCFFT : K1 -> rocFFT R2C -> K2 -> rocFFT C2R -> K3 over chunks sized to stay in the 256 MiB Infinity Cache.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 // The butterflies' constant roots stay in VGPRs here: these kernels run both transform directions next to the filter spectrum and already
@@ -978,12 +979,25 @@ int launch_upols_k(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t
     const int64_t nblk = rg.g1 - rg.g0;
     // resident workgroups per CU from the kernel's own resources (hipOccupancyMaxActiveBlocksPerMultiprocessor has answered half of what the
     // hardware admits for LDS-heavy kernels)
-    hipFuncAttributes fa;
-    MDSP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
-    const int waves = threads / 64, vg = std::max(1, fa.numRegs);
-    const int by_regs = std::max(1, (512 / ((vg + 7) & ~7)) * 4 / waves);
-    const int by_lds = (int)std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(1, fa.sharedSizeBytes));
-    int per_cu = std::max(1, std::min({by_regs, by_lds, 2048 / threads}));
+    // Queried once per instantiation and device (hipFuncGetAttributes on every launch was host latency on every chunk of the host
+    // pipeline); the register file and LDS sizes come from the device properties, the 8-register allocation granule is gfx950's.
+    static std::atomic<int> per_cu_cache[64];
+    int dev = 0;
+    MDSP_HIP(hipGetDevice(&dev));
+    int per_cu = per_cu_cache[dev & 63].load(std::memory_order_acquire);
+    if (per_cu == 0) {
+        hipFuncAttributes fa;
+        MDSP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
+        hipDeviceProp_t prop;
+        MDSP_HIP(hipGetDeviceProperties(&prop, dev));
+        const int regs_per_simd_lane = std::max(64, prop.regsPerBlock / 256);                     // 131072 / 256 = 512 on MI355X
+        const size_t lds_per_cu = std::max<size_t>(64 * 1024, prop.maxSharedMemoryPerMultiProcessor);   // 160 KiB
+        const int waves = threads / 64, vg = std::max(1, fa.numRegs);
+        const int by_regs = std::max(1, (regs_per_simd_lane / ((vg + 7) & ~7)) * 4 / waves);
+        const int by_lds = (int)std::max<size_t>(1, lds_per_cu / std::max<size_t>(1, fa.sharedSizeBytes));
+        per_cu = std::max(1, std::min({by_regs, by_lds, prop.maxThreadsPerMultiProcessor / threads}));
+        per_cu_cache[dev & 63].store(per_cu, std::memory_order_release);
+    }
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
     // persistent grid; runs of at least 16 (P - 1) blocks keep the warm-up blocks of a run below ~6 % of its work
     const int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * per_cu / std::max<int64_t>(1, ncols));

@@ -205,10 +205,20 @@ int mdsp_welch_allreduce(mdsp_welch_plan plan, mdsp_comm comm, void* stream);
  * download, chunk k+1's kernels and chunk k+2's upload are in flight together (full duplex).
  * Synchronous (results are in the host arrays on return); PCIe-bound -- see DESIGN.md section 5 for the measured rates.
  *   flags: MDSP_HOST_PINNED = the caller's arrays are already page-locked (mdsp_host_alloc / mdsp_host_register): no staging copies.
- *   Chunk size: MDSP_HOST_CHUNK_MIB (default 64).  Results are bit-identical to the device-resident calls for overlap-save
- *   (same block grid) and equal up to Float64 summation order for Welch.
+ *   Chunk size: MDSP_HOST_CHUNK_MIB (default 64).  Overlap-save results are bit-identical to the device-resident calls for single-block
+ *   plans (same block grid); PARTITIONED (long-filter) plans run block ranges from slices of the signal (mdsp_ols_exec_range: samples under
+ *   the zero taps in front of a slice read as zero), so they equal the whole-column call within rounding, and a NaN / Inf earlier in the
+ *   stream does not propagate into later slices the way it does through the device-resident delay line.  Welch: equal up to Float64
+ *   summation order.
+ *   Ordering and resources: every host-array call starts with a device-wide synchronisation (the pipeline's streams are non-blocking; this
+ *   orders them behind whatever the same handle has queued on other streams); one pipeline per device, guarded by a mutex for the whole
+ *   call -- host-array calls of several threads on one device run one after the other; its three lanes of device (and page-locked staging)
+ *   buffers only grow and stay until mdsp_host_pipeline_trim() or mdsp_shutdown().  mdsp_fir_exec_host advances the filter state chunk by
+ *   chunk: after an error return the filter's state is unspecified -- mdsp_fir_reset (or set_state) before using it again.
  * ---------------------------------------------------------------------------------------------------- */
 #define MDSP_HOST_PINNED 1
+/* frees the host pipelines' device and page-locked buffers of every device (they are re-grown on the next host-array call) */
+int mdsp_host_pipeline_trim(void);
 int mdsp_host_alloc(void** host_ptr, size_t bytes);      /* hipHostMalloc */
 int mdsp_host_free(void* host_ptr);
 int mdsp_host_register(void* host_ptr, size_t bytes);    /* hipHostRegister: page-lock an existing allocation (e.g. a Julia Array) */

@@ -89,6 +89,7 @@ function plan_cache_stats()
     (entries = Int(e[]), hits = Int(h[]), misses = Int(m[]))
 end
 plan_cache_clear() = check(ccall((:mdsp_plan_cache_clear, lib), Cint, ()))
+host_pipeline_trim() = check(ccall((:mdsp_host_pipeline_trim, lib), Cint, ()))   # frees the host-array pipelines' device / pinned buffers
 function plan_cache_partitions()
     p, r = Ref{Int64}(0), Ref{Int64}(0)
     check(ccall((:mdsp_plan_cache_partitions, lib), Cint, (Ref{Int64}, Ref{Int64}), p, r))

@@ -810,10 +810,11 @@ def test_plan_cache_reaps_exited_threads_and_honours_contexts(d, torch):
 @pytest.mark.parametrize("L,M,ntaps", [(160, 147, 5120), (3, 2, 96), (1, 2, 48), (2, 1, 64)])
 def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, ntaps):
     """stream_filt.jl:496-509: an output is the dot product of ONE column of the polyphase bank with ITS window of tapsPerPhi samples, so a NaN / Inf
-    sample makes exactly the outputs whose own window holds it non-finite.  With MDSP_FIR_MM=0 (register-tap / generic kernels: the reference's
-    windows and nothing else) the non-finite outputs are EXACTLY the oracle's.  The default matrix-core kernel multiplies a block's common window
-    by explicit zero taps, so its hole may be wider -- by at most 15 outputs plus the outputs of 64 more input positions on either side (DESIGN.md
-    section 4.6) -- and outside that widened hole its outputs are bit-identical to the MDSP_FIR_MM=0 run."""
+    sample makes exactly the outputs whose own window holds it non-finite.  With MDSP_FIR_EXACT=1 (the generic kernel: the reference's windows
+    and nothing else) the non-finite outputs are EXACTLY the oracle's.  The fast kernels multiply a block's (matrix-core) or a residue pair's
+    (register-tap, MDSP_FIR_MM=0) common window by explicit zero taps, so their hole may be wider -- by at most 15 outputs plus the outputs of 64
+    more input positions on either side -- and outside that widened hole their outputs are finite and equal the exact run's
+    to rounding."""
     import ctypes as C
     from fractions import Fraction
     from dsp_jl_amd import _lib
@@ -835,8 +836,9 @@ def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, nt
     stream = torch.cuda.current_stream().cuda_stream
     outs = {}
     try:
-        for mm in (0, 1):
-            _lib.set_tunable("MDSP_FIR_MM", mm)
+        for mode, knobs in (("exact", {"MDSP_FIR_EXACT": 1}), ("regtap", {"MDSP_FIR_MM": 0}), ("default", {})):
+            for k, v in knobs.items():
+                _lib.set_tunable(k, v)
             fh = C.c_void_p()
             _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, _lib.F32, _lib.F32, 1))
             ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, n, C.byref(ol)))
@@ -846,26 +848,32 @@ def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, nt
             _lib.check(lib.mdsp_fir_exec(fh, xd.data_ptr(), n, n, y.data_ptr(), ol.value, ol.value + 1, C.byref(nw), stream))
             torch.cuda.synchronize()
             pth = C.c_int(-1); _lib.check(lib.mdsp_fir_kernel_path(fh, n, C.byref(pth)))
-            outs[mm] = (y[0, :ol.value].cpu().numpy(), pth.value)
+            outs[mode] = (y[0, :ol.value].cpu().numpy(), pth.value)
             _lib.check(lib.mdsp_fir_destroy(fh))
+            for k in knobs:
+                _lib.set_tunable(k, None)
     finally:
         _lib.set_tunable("MDSP_FIR_MM", None)
-    y0, path0 = outs[0]
-    y1, path1 = outs[1]
-    assert path0 != 2                                              # MDSP_FIR_MM=0 never takes the matrix-core kernel
-    bad0, bad1 = ~np.isfinite(y0), ~np.isfinite(y1)
-    assert np.array_equal(bad0, bad_ref)                           # the reference's hole, exactly
+        _lib.set_tunable("MDSP_FIR_EXACT", None)
+    y0, path0 = outs["exact"]
+    assert path0 == 0                                              # the generic kernel
+    bad0 = ~np.isfinite(y0)
+    assert np.array_equal(bad0, bad_ref), (int(bad0.sum()), int(bad_ref.sum()), np.flatnonzero(bad0 != bad_ref)[:10])   # the reference's hole, exactly
     assert relerr(y0[~bad_ref], ref[~bad_ref]) < 2e-6
-    assert np.all(bad1[bad_ref])                                   # the default kernel's hole covers the reference's ...
-    W = 15 + int(np.ceil(64 * L / M))                              # ... and exceeds it by at most this many outputs on either side
+    W = 15 + int(np.ceil(64 * L / M))                              # the fast kernels exceed it by at most this many outputs on either side
     idx = np.flatnonzero(bad_ref)
     near = np.zeros(len(ref), dtype=bool)
     for i in idx:
         near[max(0, i - W):i + W + 1] = True
-    assert not np.any(bad1 & ~near), (int(np.sum(bad1 & ~near)), W)
-    assert np.array_equal(y1[~near], y0[~near])                    # untouched outputs: the same bits as the reference-window kernels
-    if path1 != 2:
-        assert np.array_equal(bad1, bad_ref)
+    for mode in ("regtap", "default"):
+        y1, path1 = outs[mode]
+        bad1 = ~np.isfinite(y1)
+        assert np.all(bad1[bad_ref]), mode                         # the hole covers the reference's ...
+        assert not np.any(bad1 & ~near), (mode, int(np.sum(bad1 & ~near)), W)
+        assert np.all(np.isfinite(y1[~near])) and relerr(y1[~near], y0[~near]) < 2e-6, mode   # untouched outputs: finite, the reference-window kernel's values
+        if path1 == 0:
+            assert np.array_equal(bad1, bad_ref)
+    assert outs["regtap"][1] != 2                                  # MDSP_FIR_MM=0 never takes the matrix-core kernel
 
 
 @pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36, 40, 41])
