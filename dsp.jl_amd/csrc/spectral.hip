@@ -1521,6 +1521,11 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
                 else if (pl->variant == 33) rc = welch_run_half3<N, 5, 1, true>(pl, a, st, &nslices);   // ... two units in flight (two register sets)
                 else if (pl->variant == 34) rc = welch_run_half3<N, 4, 1, true>(pl, a, st, &nslices);
+                else if (pl->variant == 42) {   // ... the same, hand-allocated (csrc/welch_w64_asm.s): reduces into pl->reduced itself
+                    bool handled = false;
+                    rc = w64::welch_run_w64asm(pl, a, st, &handled);
+                    if (rc == MDSP_OK && handled) goto reduced_done;
+                }
                 else if (pl->variant == 41) rc = w64::welch_run_w64b(pl, a, st, &nslices);  // ... two waves per SIMD: two-level twiddles, direct loads
                 else if (pl->variant == 40) rc = w64::welch_run_w64(pl, a, st, &nslices);   // round 4: one wavefront per transform, 64 x 64, one exchange
                 else if (pl->variant == 35 || pl->variant == 36) {   // half-frames staged in LDS by DMA, two units ahead (pad 5 / pad 4)
@@ -1577,6 +1582,8 @@ finalize:
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<double>(),
                        pl->reduced.as<double>(), nslices, a.nch, N, pl->acc_fresh ? 0 : 1);
     MDSP_LAUNCH_CHECK();
+reduced_done:
+    if (rc != MDSP_OK) return rc;
     pl->acc_fresh = false;
     pl->acc_nslices = 1;
     pl->acc_nacc = N;

@@ -373,4 +373,145 @@ inline int welch_run_w64(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int
     return MDSP_OK;
 }
 
+// ---- the hand-allocated form (variant 42): csrc/welch_w64_asm.s, generated by tools/gen_welch_asm.py ------------------------------------------------
+// Same transform as welch_w64b_kernel (two waves per SIMD, two-level twiddles, direct loads) with every register assigned by the generator: 244
+// VGPRs, no spill, 1682 instructions per unit.  The code object is assembled by build.py and embedded as a byte array (welch_w64_asm_co.h in the
+// object directory); it is loaded once per device with hipModuleLoadData.  Host side of its contract:
+//   * a prepared per-plan block: window pairs (w[p], w[p + N/2]) as Float32 (16 KiB) + the per-lane twiddles W^{8 lane j}, W^{lane j}, j = 1..7;
+//   * Float32 partial rows part[((slot nch + ch) nflush + f) N + bin], zeroed here (a slot without units, or with fewer flushes, leaves zeros);
+//   * the units it runs all have both frames; the odd last frame of a channel goes through welch_half3_kernel and is added to the same sums.
+#include "welch_w64_asm_co.h"   // static const unsigned char welch_w64_asm_co[]; generated by build.py from welch_w64_asm.s
+
+struct W64AsmArgs {
+    const float* s;
+    float* part;
+    const float* winpairs;
+    const float* tw;
+    int64_t lds_, units, run_len, nch;
+    int nflush, pad;
+};
+static_assert(sizeof(W64AsmArgs) == 72, "kernarg layout of mdsp_welch_w64_asm");
+
+__global__ __launch_bounds__(256) void w64asm_prepare_kernel(const double* __restrict__ win, int n, const cx<float>* __restrict__ table, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < HALF) {
+        out[2 * i] = (float)(i < n ? (win ? win[i] : 1.0) : 0.0);
+        out[2 * i + 1] = (float)((i + HALF) < n ? (win ? win[i + HALF] : 1.0) : 0.0);
+    }
+    if (i < 64) {   // lane i: 28 floats behind the window pairs
+        float* tw = out + 2 * HALF + 28 * i;
+        for (int j = 1; j < 8; ++j) {
+            const cx<float> a = table[(8 * i * j) & (N - 1)], b = table[(i * j) & (N - 1)];
+            tw[2 * (j - 1)] = a.x;
+            tw[2 * (j - 1) + 1] = a.y;
+            tw[14 + 2 * (j - 1)] = b.x;
+            tw[14 + 2 * (j - 1) + 1] = b.y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void w64asm_zero_kernel(float4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = float4{0.f, 0.f, 0.f, 0.f};
+}
+
+// reduced[ch][k] (+)= sum over this channel's rows of part (Float32 rows, Float64 sum, fixed order)
+__global__ __launch_bounds__(256) void w64asm_reduce_kernel(const float* __restrict__ part, double* __restrict__ reduced, int nslots, int nflush, int64_t nch, int accumulate) {
+    __shared__ double sm[8][33];
+    const int bx = threadIdx.x & 31, sy = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + bx;
+    const int64_t ch = blockIdx.y;
+    double a = 0;
+    for (int s = sy; s < nslots; s += 8)
+        for (int f = 0; f < nflush; ++f) a += (double)part[(((int64_t)s * nch + ch) * nflush + f) * N + k];
+    sm[sy][bx] = a;
+    __syncthreads();
+    if (sy == 0) {
+        double t = sm[0][bx];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += sm[i][bx];
+        reduced[ch * N + k] = accumulate ? reduced[ch * N + k] + t : t;
+    }
+}
+
+struct W64AsmModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+};
+inline int w64asm_function(hipFunction_t* fn) {
+    static std::mutex mu;
+    static W64AsmModule mods[64];
+    int dev = 0;
+    MDSP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    W64AsmModule& m = mods[dev & 63];
+    if (!m.fn) {
+        MDSP_HIP(hipModuleLoadData(&m.mod, welch_w64_asm_co));
+        MDSP_HIP(hipModuleGetFunction(&m.fn, m.mod, "mdsp_welch_w64_asm"));
+    }
+    *fn = m.fn;
+    return MDSP_OK;
+}
+
+// returns MDSP_OK with *handled = true when the sums have been added to pl->reduced (the caller skips its own slice reduction)
+template <int DUMMY = 0> int welch_run_w64asm(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, bool* handled) {
+    *handled = false;
+    hipFunction_t fn = nullptr;
+    MDSP_TRY(w64asm_function(&fn));
+    // the prepared block (per plan: the window and the root table never change)
+    constexpr size_t PREP_FLOATS = 2 * HALF + 28 * 64;
+    if (pl->w64prep.bytes == 0) {
+        MDSP_TRY(pl->w64prep.reserve(PREP_FLOATS * sizeof(float)));
+        hipLaunchKernelGGL(w64asm_prepare_kernel, dim3(HALF / 256), dim3(256), 0, st, a.win, a.n, static_cast<const cx<float>*>(a.table), pl->w64prep.as<float>());
+        MDSP_LAUNCH_CHECK();
+    }
+    const int64_t units = a.K / 2;                                  // units with both frames
+    MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)a.nch * N));
+    bool fresh = pl->acc_fresh;
+    if (units > 0) {
+        const int64_t per_ch = std::max<int64_t>(1, (int64_t)device_cu_count() / std::max<int64_t>(1, a.nch));
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(units, 8), per_ch));
+        const int64_t nslots = (int64_t)grid * 8;
+        const int64_t run_len = cdiv(units, nslots);
+        const int nflush = (int)cdiv(run_len, 128);
+        const size_t part_bytes = sizeof(float) * (size_t)nslots * (size_t)a.nch * (size_t)nflush * N;
+        MDSP_TRY(pl->partial.reserve(part_bytes));
+        hipLaunchKernelGGL(w64asm_zero_kernel, dim3((unsigned)std::min<size_t>(4096, cdiv((int64_t)(part_bytes / 16), 256))), dim3(256), 0, st,
+                           reinterpret_cast<float4*>(pl->partial.p), part_bytes / 16);
+        MDSP_LAUNCH_CHECK();
+        W64AsmArgs ka;
+        ka.s = static_cast<const float*>(a.s);
+        ka.part = pl->partial.as<float>();
+        ka.winpairs = pl->w64prep.as<float>();
+        ka.tw = pl->w64prep.as<float>() + 2 * HALF;
+        ka.lds_ = a.lds_;
+        ka.units = units;
+        ka.run_len = run_len;
+        ka.nch = a.nch;
+        ka.nflush = nflush;
+        ka.pad = 0;
+        size_t ksz = sizeof(ka);
+        void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
+        MDSP_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, (unsigned)a.nch, 1, 512, 1, 1, 0, st, nullptr, cfg));
+        hipLaunchKernelGGL(w64asm_reduce_kernel, dim3(N / 32, (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<float>(), pl->reduced.as<double>(), (int)nslots,
+                           nflush, a.nch, fresh ? 0 : 1);
+        MDSP_LAUNCH_CHECK();
+        fresh = false;
+    }
+    if (a.K & 1) {   // the channel's odd last frame: one unit of welch_half3_kernel on the last n samples, added to the same sums
+        SpecArgs t = a;
+        t.s = static_cast<const float*>(a.s) + (a.K - 1) * a.hop;
+        t.len = a.n;
+        t.K = 1;
+        t.units_per_ch = 1;
+        int ns2 = 0;
+        MDSP_TRY((welch_run_half3<N, 5, 1>(pl, t, st, &ns2)));
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<double>(), pl->reduced.as<double>(), ns2,
+                           a.nch, N, fresh ? 0 : 1);
+        MDSP_LAUNCH_CHECK();
+        fresh = false;
+    }
+    *handled = true;
+    return MDSP_OK;
+}
+
 }  // namespace w64
