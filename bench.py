@@ -663,7 +663,7 @@ def main():
         coll = lambda: (psd.sum(0, dtype=torch.float64), mean, float(world))     # (this rank's contribution, the collective's result, divisor)
         names = ("filt", "welch")
         alg = (8.0 * n, 4.0 * n)
-        kern = ("ols_fused_kernel (overlap-save filt, 8 B/sample)", "welch_half3_kernel (+reduce+finalize; 4 B/sample)")
+        kern = ("ols_fused_kernel (overlap-save filt, 8 B/sample)", "mdsp_welch_w64_asm (one wavefront per transform, hand-allocated; + zero / reduce / finalize; 4 B/sample)")
         workload = (f"filt(256-tap overlap-save, nfft=2048) + welch_pgram(nfft=4096, hanning, 50% overlap) per 2^{log2n}-sample Float32 stream; "
                     "one stream (channel) per GPU; RCCL all-reduce of the 2049-bin PSD for N>1")
         metric, dtype, engine_used = METRIC, "f32", {1: "fused", 2: "rocfft"}[plan.engine]

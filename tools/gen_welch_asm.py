@@ -40,19 +40,32 @@ def slot64(k):
 
 
 # ------------------------------------------------------------------------------------------------------------------ instruction records
+# Operands:  ('v', p)      a 64-bit VGPR pair; p < 256 physical, p >= VBASE virtual (mapped by the allocator after scheduling)
+#            ('h', p, k)   half k (0 lo, 1 hi) of pair p as a 32-bit register
+#            ('r', n)      a physical 32-bit VGPR (accumulators, addresses)
+#            ('s', p)      an SGPR pair (constants)
+VBASE = 1000
+
+
 class Ins:
-    __slots__ = ("op", "d", "s", "mods", "text", "imm", "extra")
+    __slots__ = ("op", "d", "s", "mods", "imm", "text", "idx")
 
-    def __init__(self, op, d=None, s=(), mods=None, text="", imm=0, extra=None):
-        self.op, self.d, self.s, self.mods, self.text, self.imm, self.extra = op, d, tuple(s), mods or {}, text, imm, extra
+    def __init__(self, op, d=None, s=(), mods=None, imm=0, text=""):
+        self.op, self.d, self.s, self.mods, self.imm, self.text, self.idx = op, d, tuple(s), mods or {}, imm, text, -1
+
+    def operands(self):
+        return ([self.d] if self.d is not None else []) + list(self.s)
 
 
-def vp(p):           # a 64-bit VGPR pair operand
-    return f"v[{p}:{p + 1}]"
-
-
-def sp(p):
-    return f"s[{p}:{p + 1}]"
+def keys_of(o):
+    """32-bit register units an operand covers (scheduling / liveness granularity)."""
+    if o[0] == "v":
+        return [("p", o[1], 0), ("p", o[1], 1)]
+    if o[0] == "h":
+        return [("p", o[1], o[2])]
+    if o[0] == "r":
+        return [("r", o[1])]
+    return []
 
 
 def modtext(mods, nsrc):
@@ -66,21 +79,60 @@ def modtext(mods, nsrc):
     return (" " + " ".join(out)) if out else ""
 
 
+def render(ins, pmap):
+    """Assembly text of an instruction once its virtual pairs are mapped (pmap: virtual pair -> physical pair)."""
+    def P(p):
+        return pmap[p] if p >= VBASE else p
+
+    def R(o):
+        if o[0] == "v":
+            return f"v[{P(o[1])}:{P(o[1]) + 1}]"
+        if o[0] == "h":
+            return f"v{P(o[1]) + o[2]}"
+        if o[0] == "r":
+            return f"v{o[1]}"
+        return f"s[{o[1]}:{o[1] + 1}]"
+
+    op = ins.op
+    if op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"):
+        return f"{op} {R(ins.d)}, " + ", ".join(R(x) for x in ins.s) + modtext(ins.mods, len(ins.s))
+    if op == "v_fma_f32":
+        return f"v_fma_f32 {R(ins.d)}, {R(ins.s[0])}, {R(ins.s[1])}, {R(ins.s[2])}"
+    if op == "ds_read_b64":
+        return f"ds_read_b64 {R(ins.d)}, {R(ins.s[0])} offset:{ins.imm}"
+    if op == "ds_write_b64":
+        return f"ds_write_b64 {R(ins.s[0])}, {R(ins.s[1])} offset:{ins.imm}"
+    if op == "buffer_load_dword":
+        k, imm = divmod(ins.imm, 4096)
+        so = "0" if k == 0 else f"s{Gen.S_K4 + k - 1}"
+        return f"buffer_load_dword {R(ins.d)}, {R(ins.s[0])}, s[{Gen.S_RS}:{Gen.S_RS + 3}], {so} offen offset:{imm}"
+    if op == "v_permlane32_swap":
+        return f"v_permlane32_swap_b32_e32 {R(ins.s[0])}, {R(ins.s[1])}"
+    if op == "s_waitcnt_lgkm":
+        return f"s_waitcnt lgkmcnt({ins.imm})"
+    if op == "s_waitcnt_vm":
+        return f"s_waitcnt vmcnt({ins.imm})"
+    if op == "s_nop":
+        return f"s_nop {ins.imm}"
+    if op == "comment":
+        return ins.text
+    raise RuntimeError(op)
+
+
 class Val:
-    """A complex (pair) value living in VGPR pair `p`; `.lo` / `.hi` are its 32-bit registers."""
-    __slots__ = ("p", "pend")
+    """A complex value in VGPR pair `p` (virtual until allocation); `.lo` / `.hi` are its 32-bit halves as operands."""
+    __slots__ = ("p",)
 
     def __init__(self, p):
         self.p = p
-        self.pend = None       # sequence number of the LDS read that fills it (None once waited for)
 
     @property
     def lo(self):
-        return self.p
+        return ("h", self.p, 0)
 
     @property
     def hi(self):
-        return self.p + 1
+        return ("h", self.p, 1)
 
 
 class Gen:
@@ -101,63 +153,29 @@ class Gen:
 
     def __init__(self):
         self.ins = []
-        self.free = deque(range(self.POOL0, self.POOL0 + 2 * self.NPOOL, 2))
-        self.quar = deque()            # (release_at_instruction_index, pair)
-        self.lds_seq = 0               # LDS operations issued so far
-        self.pending = {}              # pair -> lds sequence number of the read that fills it
-        self.maxlive = 0
+        self.nvirt = 0
         self.wexp = {m: self.S_W + 2 * i for i, m in enumerate(self.W_EXPS)}
+        self.maxlive = 0
+        self.stalls = 0
 
-    # ---- emission
-    def emit(self, op, d=None, s=(), mods=None, text="", imm=0, extra=None):
-        self.ins.append(Ins(op, d, s, mods, text, imm, extra))
-        while self.quar and self.quar[0][0] <= len(self.ins):
-            self.free.append(self.quar.popleft()[1])
+    # ---- emission (virtual registers; kill() is a no-op: liveness is computed after scheduling)
+    def emit(self, op, d=None, s=(), mods=None, imm=0, text=""):
+        self.ins.append(Ins(op, d, s, mods, imm, text))
 
     def comment(self, t):
         self.ins.append(Ins("comment", text="; " + t))
 
     def alloc(self):
-        if not self.free:
-            # let quarantined registers out early if the pool ran dry (they are at least one instruction old)
-            if self.quar:
-                self.free.append(self.quar.popleft()[1])
-            else:
-                raise RuntimeError("register pool exhausted")
-        p = min(self.free)
-        self.free.remove(p)
-        live = self.NPOOL - len(self.free) - len(self.quar)
-        self.maxlive = max(self.maxlive, live)
-        return Val(p)
+        self.nvirt += 1
+        return Val(VBASE + 2 * self.nvirt)
 
     def kill(self, *vals):
-        for v in vals:
-            assert v.p not in self.pending, "freeing a value whose load was never waited for"
-            self.quar.append((len(self.ins) + 4, v.p))
+        pass
 
-    def use(self, *vals):
-        """Wait for the LDS reads that fill these values (in-order return: lgkmcnt = operations issued after the youngest one needed)."""
-        need = [self.pending[v.p] for v in vals if isinstance(v, Val) and v.p in self.pending]
-        if not need:
-            return
-        youngest = max(need)
-        cnt = min(self.lds_seq - youngest, 14)   # four bits, and 15 means "do not wait": 14 is the largest wait the encoding can express (conservative beyond)
-        self.emit("s_waitcnt_lgkm", imm=cnt, text=f"s_waitcnt lgkmcnt({cnt})")
-        for p, q in list(self.pending.items()):
-            if q <= youngest:
-                del self.pending[p]
-
-    # ---- packed arithmetic: every source is ('v', pair) | ('s', pair)
     def _src(self, x):
-        if isinstance(x, Val):
-            return ("v", x.p)
-        return x
-
-    def _srctext(self, s):
-        return vp(s[1]) if s[0] == "v" else sp(s[1])
+        return ("v", x.p) if isinstance(x, Val) else x
 
     def pk(self, op, srcs, mods=None, dst=None):
-        self.use(*[x for x in srcs if isinstance(x, Val)])
         d = dst or self.alloc()
         ss = [self._src(x) for x in srcs]
         n = len(ss)
@@ -166,8 +184,7 @@ class Gen:
             v = list(mods.get(key, [dflt] * n))
             v += [dflt] * (n - len(v))
             mods[key] = v
-        text = f"{op} {vp(d.p)}, " + ", ".join(self._srctext(s) for s in ss) + modtext(mods, n)
-        self.emit(op, ("v", d.p), ss, mods, text)
+        self.emit(op, ("v", d.p), ss, mods)
         return d
 
     def add(self, a, b):
@@ -193,34 +210,29 @@ class Gen:
         return self.pk("v_pk_fma_f32", [a, w, t], {"op_sel_hi": [0, 1, 1], "neg_lo": [0, 0, 1]}, dst=t)      # (a.x w.x - t.x, a.x w.y + t.y)
 
     def mul_w64(self, a, m):
-        """a W64^m (forward root), m = n1 k1 < 64.  Consumes `a` (frees it) unless m == 0."""
+        """a W64^m (forward root), m = n1 k1 < 64."""
         if m == 0:
             return a
         if m == 16:              # -i a = (a.y, -a.x)
-            d = self.pk("v_pk_mul_f32", [a, ("s", self.S_PM)], {"op_sel": [1, 0], "op_sel_hi": [0, 1]})
-        elif m == 8:             # h (a - i a)
+            return self.pk("v_pk_mul_f32", [a, ("s", self.S_PM)], {"op_sel": [1, 0], "op_sel_hi": [0, 1]})
+        if m == 8:               # h (a - i a)
             t = self.sub_ib(a, a)
-            d = self.pk("v_pk_mul_f32", [t, ("s", self.S_HH)], dst=t)
-        elif m == 24:            # -h (a + i a)
+            return self.pk("v_pk_mul_f32", [t, ("s", self.S_HH)], dst=t)
+        if m == 24:              # -h (a + i a)
             t = self.add_ib(a, a)
-            d = self.pk("v_pk_mul_f32", [t, ("s", self.S_HH)], {"neg_lo": [1, 0], "neg_hi": [1, 0]}, dst=t)
-        else:
-            d = self.cmul(a, ("s", self.wexp[m]))
-        self.kill(a)
-        return d
+            return self.pk("v_pk_mul_f32", [t, ("s", self.S_HH)], {"neg_lo": [1, 0], "neg_hi": [1, 0]}, dst=t)
+        return self.cmul(a, ("s", self.wexp[m]))
 
-    # ---- butterflies (forward), consuming their inputs
+    # ---- butterflies (forward)
     def bfly4(self, a0, a1, a2, a3):
         t0 = self.add(a0, a2)
         t2 = self.add(a1, a3)
         t1 = self.sub(a0, a2)
         d = self.sub(a1, a3)
-        self.kill(a0, a1, a2, a3)
         x0 = self.add(t0, t2)
         x2 = self.sub(t0, t2)
         x1 = self.sub_ib(t1, d)
         x3 = self.add_ib(t1, d)
-        self.kill(t0, t2, t1, d)
         return x0, x1, x2, x3
 
     def bfly8_tail(self, e, o):
@@ -232,12 +244,10 @@ class Gen:
         u3 = self.add_ib(o[3], o[3])
         out[2] = self.sub_ib(e[2], o[2])
         out[6] = self.add_ib(e[2], o[2])
-        self.kill(e[0], o[0], o[1], o[3], e[2], o[2])
         out[1] = self.axpy(u1, e[1])
         out[5] = self.axmy(u1, e[1])
         out[3] = self.axmy(u3, e[3])
         out[7] = self.axpy(u3, e[3])
-        self.kill(u1, u3, e[1], e[3])
         return out
 
     def bfly8(self, v):
@@ -250,12 +260,10 @@ class Gen:
         e2 = self.sub(S[0], S[2])
         o0 = self.add(S[1], S[3])
         o2 = self.sub(S[1], S[3])
-        self.kill(*S)
         e1 = self.sub_ib(D[0], D[2])
         e3 = self.add_ib(D[0], D[2])
         o1 = self.sub_ib(D[1], D[3])
         o3 = self.add_ib(D[1], D[3])
-        self.kill(*D)
         return self.bfly8_tail([e0, e1, e2, e3], [o0, o1, o2, o3])
 
     def bfly64_tail(self, v):
@@ -267,23 +275,16 @@ class Gen:
                 v[k2 + 8 * k1] = out[k2]
 
     # ---- memory
-    def ds_read(self, addr_vgpr, offset, dst=None):
-        d = dst or self.alloc()
-        self.emit("ds_read_b64", ("v", d.p), [("v32", addr_vgpr)], imm=offset, text=f"ds_read_b64 {vp(d.p)}, v{addr_vgpr} offset:{offset}")
-        self.lds_seq += 1
-        self.pending[d.p] = self.lds_seq
+    def ds_read(self, addr_vgpr, offset):
+        d = self.alloc()
+        self.emit("ds_read_b64", ("v", d.p), [("r", addr_vgpr)], imm=offset)
         return d
 
     def ds_write(self, addr_vgpr, offset, src):
-        self.use(src)
-        self.emit("ds_write_b64", None, [("v32", addr_vgpr), ("v", src.p)], imm=offset, text=f"ds_write_b64 v{addr_vgpr}, {vp(src.p)} offset:{offset}")
-        self.lds_seq += 1
+        self.emit("ds_write_b64", None, [("r", addr_vgpr), ("v", src.p)], imm=offset)
 
-    def buffer_load(self, dst32, off_bytes):
-        k, imm = divmod(off_bytes, 4096)
-        so = "0" if k == 0 else f"s{self.S_K4 + k - 1}"
-        self.emit("buffer_load_dword", ("v32", dst32), [("v32", self.V_OFF)], imm=off_bytes,
-                  text=f"buffer_load_dword v{dst32}, v{self.V_OFF}, s[{self.S_RS}:{self.S_RS + 3}], {so} offen offset:{imm}")
+    def buffer_load(self, dst, off_bytes):
+        self.emit("buffer_load_dword", dst, [("r", self.V_OFF)], imm=off_bytes)
 
     # ---- one unit -------------------------------------------------------------------------------------------------
     def in_layout(self):
@@ -306,19 +307,10 @@ class Gen:
 
     def emit_unit(self):
         xp, hh = self.in_layout()
-        inpairs = {v.p for v in xp} | {v.p for g in hh for v in g}
-        self.free = deque(p for p in range(self.POOL0, self.POOL0 + 2 * self.NPOOL, 2) if p not in inpairs)
-        self.quar.clear()
-        self.emit("s_waitcnt_vm", imm=0, text="s_waitcnt vmcnt(0)")
         v = [None] * 64
         self.comment("pass A, first layer (window folded in) + first radix-8 layer")
-
-        def fetch_win(n1):
-            return [self.ds_read(self.V_WIN, 512 * (n1 + 8 * j)) for j in range(4)]
-
-        wp = fetch_win(0)
         for n1 in range(8):
-            wnext = fetch_win(n1 + 1) if n1 < 7 else None
+            wp = [self.ds_read(self.V_WIN, 512 * (n1 + 8 * j)) for j in range(4)]
             S, D = [], []
             for j in range(4):
                 e = n1 + 8 * j
@@ -329,79 +321,273 @@ class Gen:
                              {"op_sel": [h, 1, 0], "op_sel_hi": [h, 0, 1], "neg_lo": [1, 0, 0], "neg_hi": [0, 0, 1]}, dst=T)
                 S.append(s_)
                 D.append(d_)
-                self.kill(xp[e], wp[j])
-                if h:
-                    self.kill(hh[n1][j >> 1])
             o = self.bfly8_sd(S, D)
             for k1 in range(8):
                 v[n1 + 8 * k1] = o[k1]
-            wp = wnext
-        self.comment("pass A, second radix-8 layer (W64 roots from SGPR pairs)")
-        self.bfly64_tail(v)           # v[slot64(ke)] = Y_t[ke]
-        self.comment("64 x 64 transposition: half exchange in registers, then two rounds of 32 x 32 through LDS")
-        m = [v[slot64(r)] for r in range(64)]
-        for r in range(32):
-            for half in ("lo", "hi"):
-                a, b = getattr(m[r], half), getattr(m[r + 32], half)
-                self.emit("v_permlane32_swap", None, [("v32", a), ("v32", b)], text=f"v_permlane32_swap_b32_e32 v{a}, v{b}")
+        self.comment("pass A, second radix-8 layer (W64 roots from SGPR pairs); each butterfly's eight results are four pairs (ke, ke + 32) of the half")
+        self.comment("exchange: swapped at once, and the lower halves' rows go to LDS at once (round 0 of the 64 x 64 transposition)")
+        m = [None] * 64
+        for k1 in range(8):
+            u = [v[j + 8 * k1] for j in range(8)]
+            u = [u[0]] + [self.mul_w64(u[j], (j * k1) & 63) for j in range(1, 8)]
+            out = self.bfly8(u)               # out[k2] = Y_t[k1 + 8 k2]
+            for k2 in range(4):
+                lo_, hi_ = out[k2], out[k2 + 4]
+                for half in ("lo", "hi"):
+                    self.emit("v_permlane32_swap", None, [getattr(lo_, half), getattr(hi_, half)])
+                m[k1 + 8 * k2] = lo_
+                m[k1 + 8 * (k2 + 4)] = hi_
+            for k2 in range(4):
+                self.ds_write(self.V_XW, 8 * (k1 + 8 * k2), m[k1 + 8 * k2])
         nv = [None] * 64
-        for rnd in range(2):
-            for r in range(32):
-                self.ds_write(self.V_XW, 8 * r, m[32 * rnd + r])
-                self.kill(m[32 * rnd + r])
-            # read order: the operands of pass B's first groups first
-            for T in sorted(range(32), key=lambda T: (T & 7, T >> 3)):
-                nv[32 * rnd + T] = self.ds_read(self.V_XR, 8 * XROW * T)
+        order = sorted(range(32), key=lambda T: (T & 7, T >> 3))     # the operands of pass B's first groups first
+        for T in order:
+            nv[T] = self.ds_read(self.V_XR, 8 * XROW * T)
+        for r in range(32):
+            self.ds_write(self.V_XW, 8 * r, m[32 + r])
+        for T in order:
+            nv[32 + T] = self.ds_read(self.V_XR, 8 * XROW * T)
         v = nv
-        self.comment("pass B: two-level twiddles W^{8 lane t2} in front of, W^{lane t1} behind the first radix-8 layer")
+        self.comment("pass B: two-level twiddles W^{8 lane t2} in front of, W^{lane t1} behind the first radix-8 layer; the products on round 0's")
+        self.comment("operands (t2 < 4) come first: they cover round 1's trip through LDS")
+        tw = {}
+        for t2 in (1, 2, 3, 4, 5, 6, 7):
+            for t1 in range(8):
+                tw[(t1, t2)] = self.cmul(v[t1 + 8 * t2], Val(self.TW0 + 2 * (t2 - 1)))
         for t1 in range(8):
-            q = [v[t1]] + [None] * 7
-            for t2 in range(1, 8):
-                q[t2] = self.cmul(v[t1 + 8 * t2], Val(self.TW0 + 2 * (t2 - 1)))
-                self.kill(v[t1 + 8 * t2])
+            q = [v[t1]] + [tw[(t1, t2)] for t2 in range(1, 8)]
             out = self.bfly8(q)
             for k1 in range(8):
-                if t1 == 0:
-                    v[t1 + 8 * k1] = out[k1]
-                else:
-                    v[t1 + 8 * k1] = self.cmul(out[k1], Val(self.TW0 + 14 + 2 * (t1 - 1)))
-                    self.kill(out[k1])
+                v[t1 + 8 * k1] = out[k1] if t1 == 0 else self.cmul(out[k1], Val(self.TW0 + 14 + 2 * (t1 - 1)))
         self.bfly64_tail(v)           # v[slot64(kt)] = X[lane + 64 kt]
         self.comment("power: acc[s] += re^2 + im^2")
         for s in range(64):
-            a = self.ACC0 + s
-            self.use(v[s])
-            self.emit("v_fma_f32", ("v32", a), [("v32", v[s].lo), ("v32", v[s].lo), ("v32", a)], text=f"v_fma_f32 v{a}, v{v[s].lo}, v{v[s].lo}, v{a}")
-            self.emit("v_fma_f32", ("v32", a), [("v32", v[s].hi), ("v32", v[s].hi), ("v32", a)], text=f"v_fma_f32 v{a}, v{v[s].hi}, v{v[s].hi}, v{a}")
-        for s in range(64):
-            self.kill(v[s])
-        assert not self.pending
+            a = ("r", self.ACC0 + s)
+            self.emit("v_fma_f32", a, [v[s].lo, v[s].lo, a])
+            self.emit("v_fma_f32", a, [v[s].hi, v[s].hi, a])
+
+    # ---- scheduling ---------------------------------------------------------------------------------------------------
+    # A wave's packed result is usable ~16 clocks after issue and, with two waves per SIMD taking turns, the wave issues every ~9.5 clocks: an
+    # instruction should not sit closer than LAT issue slots behind the producers of its operands (measured: the same instructions in emission
+    # order -- 200 back-to-back dependent pairs per unit -- ran at 7.1 clocks per instruction and SIMD instead of 4.75).
+    LAT_VALU = 4
+    LAT_LDS = 14
+
+    def schedule(self, window=28):
+        ins = [i for i in self.ins if i.op != "comment"]
+        n = len(ins)
+        for k, i in enumerate(ins):
+            i.idx = k
+        preds = [set() for _ in range(n)]
+        chain = [None] * n
+        last_w, readers, last_mem = {}, {}, None
+        for k, i in enumerate(ins):
+            rd = [key for o in i.s for key in keys_of(o)]
+            wr = [key for key in keys_of(i.d)] if i.d is not None else []
+            if i.op == "v_permlane32_swap":
+                wr = rd
+            for key in rd:
+                if key in last_w:
+                    preds[k].add(last_w[key])
+            for key in wr:
+                if key in last_w:
+                    preds[k].add(last_w[key])
+                for r in readers.get(key, ()):
+                    if r != k:
+                        preds[k].add(r)
+            for key in rd:
+                readers.setdefault(key, []).append(k)
+            for key in wr:
+                last_w[key] = k
+                readers[key] = []
+            if i.op.startswith("ds_"):
+                if last_mem is not None and last_mem not in preds[k]:
+                    chain[k] = last_mem          # issue order only (one slot), not a data dependence
+                last_mem = k
+        succs = [[] for _ in range(n)]
+        for k in range(n):
+            for p_ in preds[k]:
+                succs[p_].append(k)
+        npred = [len(p_) + (1 if chain[k] is not None else 0) for k, p_ in enumerate(preds)]
+        chain_succ = [None] * n
+        for k in range(n):
+            if chain[k] is not None:
+                chain_succ[chain[k]] = k
+        ready_at = [0] * n            # earliest slot at which all operands are available
+        done = [False] * n
+        order = []
+        lo = 0                         # lowest unscheduled original index
+        slot = 0
+        stalls = 0
+        while len(order) < n:
+            while lo < n and done[lo]:
+                lo += 1
+            cand = [k for k in range(lo, min(n, lo + window)) if not done[k] and npred[k] == 0]
+            good = [k for k in cand if ready_at[k] <= slot]
+            if good:
+                k = good[0]
+            else:
+                k = min(cand, key=lambda c: (ready_at[c], c))
+                stalls += ready_at[k] - slot
+                slot = ready_at[k]
+            done[k] = True
+            order.append(ins[k])
+            lat = self.LAT_LDS if ins[k].op == "ds_read_b64" else (self.LAT_VALU if ins[k].op.startswith("v_") else 1)
+            for s_ in succs[k]:
+                npred[s_] -= 1
+                ready_at[s_] = max(ready_at[s_], slot + lat)
+            if chain_succ[k] is not None:
+                npred[chain_succ[k]] -= 1
+                ready_at[chain_succ[k]] = max(ready_at[chain_succ[k]], slot + 1)
+            slot += 1
+        self.stalls = stalls
+        self.ins = order
+
+    # ---- register allocation over the scheduled order
+    def allocate(self):
+        xp, hh = self.in_layout()
+        last = {}
+        for k, i in enumerate(self.ins):
+            for o in i.operands():
+                if o[0] in ("v", "h"):
+                    last[o[1]] = k
+        free = sorted(p for p in range(self.POOL0, self.POOL0 + 2 * self.NPOOL, 2))
+        inputs = {v.p for v in xp} | {v.p for g in hh for v in g}
+        free = [p for p in free if p not in inputs]
+        pmap = {}
+        quar = deque()
+        live = len(inputs)
+        for k, i in enumerate(self.ins):
+            while quar and quar[0][0] <= k:
+                free.append(quar.popleft()[1])
+            for o in i.operands():
+                if o[0] in ("v", "h") and o[1] >= VBASE and o[1] not in pmap:
+                    if not free:
+                        if quar:
+                            free.append(quar.popleft()[1])
+                        else:
+                            raise RuntimeError(f"register pool exhausted at instruction {k}")
+                    late = [q_ for q_ in free if q_ not in inputs]          # pairs that are not a unit's operand registers first: those
+                    p = min(late) if late else min(free)                    # stay free from their last use on, and the next unit's loads move in early
+                    free.remove(p)
+                    pmap[o[1]] = p
+                    live += 1
+                    self.maxlive = max(self.maxlive, live)
+            for o in i.operands():
+                if o[0] in ("v", "h") and last.get(o[1]) == k:
+                    phys = pmap[o[1]] if o[1] >= VBASE else o[1]
+                    if self.POOL0 <= phys < self.POOL0 + 2 * self.NPOOL and (phys, k) not in [(q[1], k) for q in quar]:
+                        quar.append((k + 3, phys))
+                        last[o[1]] = -1
+                        live -= 1
+        # rewrite to physical operands
+        def ph(o):
+            if o is None:
+                return None
+            if o[0] == "v" and o[1] >= VBASE:
+                return ("v", pmap[o[1]])
+            if o[0] == "h" and o[1] >= VBASE:
+                return ("h", pmap[o[1]], o[2])
+            return o
+        for i in self.ins:
+            i.d = ph(i.d)
+            i.s = tuple(ph(o) for o in i.s)
+
+    # ---- wait counts: before the first instruction that touches the destination of an outstanding LDS read
+    def insert_waits(self):
+        out = []
+        q = []          # outstanding LDS operations, oldest first: set of register units or None (stores)
+        for i in self.ins:
+            regs = {key for o in i.operands() for key in keys_of(o)}
+            need = -1
+            for pos, dst in enumerate(q):
+                if dst and dst & regs:
+                    need = pos
+            if need >= 0:
+                cnt = min(len(q) - 1 - need, 14)      # four bits, and 15 means "do not wait"
+                out.append(Ins("s_waitcnt_lgkm", imm=cnt))
+                del q[: len(q) - cnt]
+            out.append(i)
+            if i.op == "ds_read_b64":
+                q.append(set(keys_of(i.d)))
+            elif i.op == "ds_write_b64":
+                q.append(None)
+        self.ins = out
 
     # ---- permlane hazard: a VALU write of a swap operand needs two wait states before the swap reads it
     def fix_permlane_hazards(self):
         out = []
-        for i, ins in enumerate(self.ins):
+        for ins in self.ins:
             if ins.op == "v_permlane32_swap":
-                regs = {s[1] for s in ins.s}
-                need = 0
-                dist = 0
+                regs = {key for o in ins.s for key in keys_of(o)}
+                need, dist = 0, 0
                 for prev in reversed(out):
-                    if prev.op == "comment":
-                        continue
                     if dist >= 2:
                         break
                     wr = set()
-                    if prev.d is not None:
-                        wr = {prev.d[1], prev.d[1] + 1} if prev.d[0] == "v" else {prev.d[1]}
                     if prev.op == "v_permlane32_swap":
-                        wr = {s[1] for s in prev.s}
+                        wr = {key for o in prev.s for key in keys_of(o)}
+                    elif prev.d is not None and prev.op.startswith("v_"):
+                        wr = set(keys_of(prev.d))
                     if wr & regs:
                         need = max(need, 2 - dist)
                     dist += prev.imm + 1 if prev.op == "s_nop" else 1
                 if need:
-                    out.append(Ins("s_nop", imm=need - 1, text=f"s_nop {need - 1}"))
+                    out.append(Ins("s_nop", imm=need - 1))
             out.append(ins)
         self.ins = out
+
+    def merge_loads(self, body, loads, gap=4):
+        """Spread the NEXT unit's loads through the tail of this unit's body: a load may be issued once its destination pair has been touched for the
+        last time.  A burst of 96 VMEM instructions at the end of the unit kept the wave ~2000 clocks in the issue queue of the memory pipeline
+        (ablation: 0.18 of 1.13 ms); between arithmetic instructions each load finds the queue empty."""
+        last = {}
+        for k, i in enumerate(body):
+            for o in i.operands():
+                if o[0] in ("v", "h"):
+                    last[o[1]] = k
+        pend = []
+        for ld in loads:
+            if ld.op != "buffer_load_dword":
+                continue
+            pend.append((last.get(ld.d[1], -1) + gap, ld))
+        pend.sort(key=lambda t: t[0])
+        out = []
+        qi = 0
+        since = 0
+        n = len(body)
+        for k, i in enumerate(body):
+            out.append(i)
+            since += 1
+            remaining_loads = len(pend) - qi
+            if remaining_loads == 0:
+                continue
+            stride = max(1, (n - k) // (remaining_loads + 1))
+            if pend[qi][0] <= k and since >= min(stride, 6):
+                out.append(pend[qi][1])
+                qi += 1
+                since = 0
+        out.extend(ld for _, ld in pend[qi:])
+        self.loads_in_body = qi
+        return out
+
+    def build_unit(self, window=64):
+        """Emission -> schedule -> allocate -> waits -> hazards; returns the unit body (after the vmcnt(0) at its top)."""
+        self.ins = []
+        self.emit_unit()
+        self.schedule(window)
+        self.allocate()
+        self.insert_waits()
+        self.fix_permlane_hazards()
+        body = self.ins
+        loads = self.build_loads()
+        body = self.merge_loads(body, loads)
+        return [Ins("s_waitcnt_vm", imm=0)] + body
+
+    def build_loads(self):
+        self.ins = []
+        self.emit_loads()
+        return [i for i in self.ins]
 
 
 # ------------------------------------------------------------------------------------------------------------------ emulator
@@ -414,7 +600,11 @@ class Emu:
         self.glob = None
         self.gbase = 0
 
-    def src(self, s, half, mods, i, which):
+    def reg(self, o):
+        """index of the 32-bit register an ('h', p, k) / ('r', n) operand names"""
+        return o[1] + o[2] if o[0] == "h" else o[1]
+
+    def src(self, s, mods, i, which):
         sel = mods["op_sel"][i] if which == "lo" else mods["op_sel_hi"][i]
         neg = mods["neg_lo"][i] if which == "lo" else mods["neg_hi"][i]
         if s[0] == "v":
@@ -424,7 +614,6 @@ class Emu:
         return -x if neg else x
 
     def run(self, ins_list):
-        lane = np.arange(64)
         for ins in ins_list:
             op = ins.op
             if op in ("comment", "s_waitcnt_lgkm", "s_waitcnt_vm", "s_nop"):
@@ -432,7 +621,7 @@ class Emu:
             if op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"):
                 res = []
                 for which in ("lo", "hi"):
-                    xs = [self.src(s, None, ins.mods, i, which) for i, s in enumerate(ins.s)]
+                    xs = [self.src(s, ins.mods, i, which) for i, s in enumerate(ins.s)]
                     if op == "v_pk_add_f32":
                         r = xs[0] + xs[1]
                     elif op == "v_pk_mul_f32":
@@ -443,23 +632,23 @@ class Emu:
                 self.v[ins.d[1]] = res[0]
                 self.v[ins.d[1] + 1] = res[1]
             elif op == "v_fma_f32":
-                a, b, c = (self.v[s[1]] for s in ins.s)
-                self.v[ins.d[1]] = (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+                a, b, c = (self.v[self.reg(s)] for s in ins.s)
+                self.v[self.reg(ins.d)] = (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
             elif op == "ds_read_b64":
-                addr = self.vi[ins.s[0][1]] + ins.imm
+                addr = self.vi[self.reg(ins.s[0])] + ins.imm
                 assert np.all(addr % 8 == 0)
                 self.v[ins.d[1]] = self.lds[addr // 4]
                 self.v[ins.d[1] + 1] = self.lds[addr // 4 + 1]
             elif op == "ds_write_b64":
-                addr = self.vi[ins.s[0][1]] + ins.imm
+                addr = self.vi[self.reg(ins.s[0])] + ins.imm
                 assert np.all(addr % 8 == 0) and len(set(addr.tolist())) == 64
                 self.lds[addr // 4] = self.v[ins.s[1][1]]
                 self.lds[addr // 4 + 1] = self.v[ins.s[1][1] + 1]
             elif op == "buffer_load_dword":
-                addr = self.gbase + ins.imm + self.vi[ins.s[0][1]]
-                self.v[ins.d[1]] = self.glob[addr // 4]
+                addr = self.gbase + ins.imm + self.vi[self.reg(ins.s[0])]
+                self.v[self.reg(ins.d)] = self.glob[addr // 4]
             elif op == "v_permlane32_swap":
-                a, b = ins.s[0][1], ins.s[1][1]
+                a, b = self.reg(ins.s[0]), self.reg(ins.s[1])
                 ta = self.v[a].copy()
                 self.v[a, 32:] = self.v[b, :32]
                 self.v[b, :32] = ta[32:]
@@ -480,15 +669,14 @@ def sconsts(g):
     return sc
 
 
-def check():
+def check(window=64):
     rng = np.random.default_rng(1776)
     g = Gen()
-    g.emit_loads()
-    g.emit_unit()
-    g.fix_permlane_hazards()
-    body = list(g.ins)
+    unit = g.build_unit(window)
+    loads = g.build_loads()
+    body = unit
     nunits = 3
-    sig = rng.standard_normal((nunits + 1) * N).astype(np.float32)
+    sig = rng.standard_normal((nunits + 3) * N).astype(np.float32)
     win = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / (N - 1))).astype(np.float32)
     em = Emu(g, sconsts(g))
     lane = np.arange(64)
@@ -511,9 +699,12 @@ def check():
         em.v[g.TW0 + 14 + 2 * (j - 1) + 1] = wb.imag.astype(np.float32)
     em.glob = sig
     ref = np.zeros(N)
+    em.v[g.POOL0:] = np.float32(np.nan)      # nothing may depend on what the pool held before
+    em.gbase = 0
+    em.run(loads)                            # the prologue's loads of the first unit
     for u in range(nunits):
-        em.gbase = u * N * 4
-        em.run(body)          # loads of unit u (the kernel issues them at the end of the previous unit), then the unit
+        em.gbase = (u + 1) * N * 4           # the body carries the NEXT unit's loads
+        em.run(body)
         a = sig[u * N: u * N + N].astype(np.float64)
         b = sig[u * N + HALF: u * N + HALF + N].astype(np.float64)
         Z = np.fft.fft(win.astype(np.float64) * (a + 1j * b))
@@ -523,16 +714,33 @@ def check():
         got[lane + 64 * kt] = em.v[g.ACC0 + slot64(kt)]
     err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     worst = np.max(np.abs(got - ref) / ref.max())
-    nins = sum(1 for i in body if i.op != "comment")
     kinds = {}
     for i in body:
         kinds[i.op] = kinds.get(i.op, 0) + 1
-    print(f"emulated {nunits} units: relerr {err:.3e}, worst bin / max {worst:.3e}; {nins} instructions per unit, peak live pairs {g.maxlive} of {g.NPOOL}")
+    nins = sum(v for k, v in kinds.items() if k != "comment")
+    nbad = verify_waits(loads + body + body)
+    print(f"emulated {nunits} units: relerr {err:.3e}, worst bin / max {worst:.3e}; {nins} instructions per unit, peak live pairs {g.maxlive} of {g.NPOOL}, "
+          f"scheduler stall slots {g.stalls}, {g.loads_in_body} of 96 loads inside the body, wait check: {nbad} problems")
     print("  ", {k: v for k, v in sorted(kinds.items()) if k != "comment"})
-    return err < 2e-6
+    return err < 2e-6 and nbad == 0
 
 
 # ------------------------------------------------------------------------------------------------------------------ the kernel text
+ABLATE = set()      # --ablate loads,lds,perm,acc : leave those instruction classes out of the emitted kernel (timing experiments; results are garbage)
+
+
+def keep(ins):
+    if "loads" in ABLATE and ins.op == "buffer_load_dword":
+        return False
+    if "lds" in ABLATE and ins.op in ("ds_read_b64", "ds_write_b64", "s_waitcnt_lgkm"):
+        return False
+    if "perm" in ABLATE and ins.op == "v_permlane32_swap":
+        return False
+    if "acc" in ABLATE and ins.op == "v_fma_f32":
+        return False
+    return True
+
+
 def kernel_text():
     g = Gen()
     L = []
@@ -638,27 +846,24 @@ def kernel_text():
     A("\ts_mov_b32 s31, 0x00020000")
     A(f"\ts_mov_b32 s91, {FLUSH}                        ; units until the next flush")
     # first unit's loads
-    g.emit_loads()
-    for ins in g.ins:
-        A("\t" + ins.text)
-    g.ins = []
+    unit = g.build_unit()
+    loads = g.build_loads()
+    for ins in loads:
+        if keep(ins):
+            A("\t" + render(ins, {}))
     A(".Lunit:")
-    g.emit_unit()
-    g.fix_permlane_hazards()
-    for ins in g.ins:
-        A("\t" + ins.text)
-    nbody = sum(1 for i in g.ins if i.op != "comment")
-    g.ins = []
-    # advance to the next unit; its loads go into the registers the spectrum has just left
-    A("\ts_add_u32 s24, s24, 0x4000")
+    A("\ts_waitcnt vmcnt(0)")
+    A("\ts_add_u32 s24, s24, 0x4000                    ; the loads inside the body fetch the NEXT unit ...")
     A("\ts_addc_u32 s25, s25, 0")
+    A("\ts_cmp_eq_u32 s87, 1")
+    A("\ts_cselect_b32 s26, 0, 0x6000                  ; ... which does not exist behind this wave's last one: an empty descriptor returns zeros")
+    for ins in unit[1:]:
+        if keep(ins):
+            A("\t" + render(ins, {}))
+    nbody = sum(1 for i in unit if i.op != "comment")
     A("\ts_sub_u32 s87, s87, 1")
     A("\ts_cmp_eq_u32 s87, 0")
     A("\ts_cbranch_scc1 .Lflush")
-    g.emit_loads()
-    for ins in g.ins:
-        A("\t" + ins.text)
-    g.ins = []
     A("\ts_sub_u32 s91, s91, 1")
     A("\ts_cmp_lg_u32 s91, 0")
     A("\ts_cbranch_scc1 .Lunit")
@@ -752,22 +957,10 @@ def kernel_text():
     return "\n".join(L) + "\n", nbody
 
 
-if __name__ == "__main__":
-    import os
-    if "--check" in sys.argv:
-        sys.exit(0 if check() else 1)
-    if "--verify" in sys.argv:
-        sys.exit(0)
-    text, nbody = kernel_text()
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dsp.jl_amd", "csrc", "welch_w64_asm.s")
-    open(out, "w").write(text)
-    print(f"wrote {out}: {text.count(chr(10))} lines, {nbody} instructions per unit")
-
-
 def verify_waits(ins_list):
     """Independent check of the wait counts: replay the instruction list keeping the in-order queues of outstanding LDS and VMEM operations; every
     register an instruction reads (or overwrites) must not be the destination of an operation still in its queue."""
-    lds, vm = [], []          # destination register sets of outstanding operations, oldest first (None for stores)
+    lds, vm = [], []          # destination register units of outstanding operations, oldest first (None for stores)
     bad = 0
     for n, ins in enumerate(ins_list):
         if ins.op == "comment":
@@ -782,32 +975,34 @@ def verify_waits(ins_list):
             continue
         if ins.op == "s_nop":
             continue
-        regs = set()
-        for s in ins.s:
-            if s[0] == "v":
-                regs |= {s[1], s[1] + 1}
-            elif s[0] == "v32":
-                regs.add(s[1])
-        if ins.d is not None:
-            regs |= {ins.d[1], ins.d[1] + 1} if ins.d[0] == "v" else {ins.d[1]}
+        regs = {key for o in ins.operands() for key in keys_of(o)}
         for q, name in ((lds, "LDS"), (vm, "VMEM")):
             for dst in q:
                 if dst and dst & regs:
-                    print(f"  wait missing: instruction {n} ({ins.text}) touches {sorted(dst & regs)} of an outstanding {name} operation")
+                    print(f"  wait missing: instruction {n} ({render(ins, {})}) touches the destination of an outstanding {name} operation")
                     bad += 1
         if ins.op == "ds_read_b64":
-            lds.append({ins.d[1], ins.d[1] + 1})
+            lds.append(set(keys_of(ins.d)))
         elif ins.op == "ds_write_b64":
             lds.append(None)
         elif ins.op == "buffer_load_dword":
-            vm.append({ins.d[1]})
+            vm.append(set(keys_of(ins.d)))
     return bad
 
 
-if __name__ == "__main__" and "--verify" in sys.argv:
-    g = Gen()
-    g.emit_loads()
-    g.emit_unit()
-    g.fix_permlane_hazards()
-    one = list(g.ins)
-    print("wait check over two consecutive units:", verify_waits(one + one), "problems")
+
+if __name__ == "__main__":
+    import os
+    if "--check" in sys.argv:
+        sys.exit(0 if check() else 1)
+    if "--window" in sys.argv:
+        w = int(sys.argv[sys.argv.index("--window") + 1])
+        sys.exit(0 if check(w) else 1)
+    if "--ablate" in sys.argv:
+        ABLATE.update(sys.argv[sys.argv.index("--ablate") + 1].split(","))
+    text, nbody = kernel_text()
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dsp.jl_amd", "csrc", "welch_w64_asm.s")
+    open(out, "w").write(text)
+    print(f"wrote {out}: {text.count(chr(10))} lines, {nbody} instructions per unit")
+
+

@@ -85,7 +85,8 @@ if "welch" in cases:
     for v in wvars:
         res[f"welch_v{v}_random"] = probe(f"welch v{v} random", lambda v=v: _lib.check(lib.mdsp_welch_exec(cfgs[v]._h, x.data_ptr(), n, 1, n, psd.data_ptr(), 2049, st)))
 if "welch_zeros" in cases:
-    res["welch_v0_zeros"] = probe("welch v0 zeros", lambda: _lib.check(lib.mdsp_welch_exec(cfgs[wvars[0]]._h, xz.data_ptr(), n, 1, n, psd.data_ptr(), 2049, st)))
+    for v in wvars:     # (round 4: every variant on the all-zero stream, not only the first)
+        res[f"welch_v{v}_zeros"] = probe(f"welch v{v} zeros", lambda v=v: _lib.check(lib.mdsp_welch_exec(cfgs[v]._h, xz.data_ptr(), n, 1, n, psd.data_ptr(), 2049, st)))
 if "ols" in cases:
     res["ols_random"] = probe("ols random", lambda: _lib.check(lib.mdsp_ols_exec(plan._h, x.data_ptr(), n, 1, n, y.data_ptr(), n, n, st)))
 if "ols_zeros" in cases:
