@@ -268,8 +268,9 @@ int mdsp_ols_exec_host(mdsp_ols_plan plan, const void* x_host, int64_t nx, int64
     const size_t esz = dtype_size(dtype);
     const int64_t nblocks = cdiv(nout, L);
     // blocks per chunk: ~host_chunk_mib of input, even, at least 2
-    int64_t bpc = std::max<int64_t>(2, ((int64_t)tunables().host_chunk_mib << 20) / (int64_t)(L * (int64_t)esz));
-    bpc &= ~int64_t(1);
+    int64_t bpc = std::max<int64_t>(4, ((int64_t)tunables().host_chunk_mib << 20) / (int64_t)(L * (int64_t)esz));
+    bpc &= ~int64_t(3);   // a multiple of four blocks: the hand-allocated kernel's units (mdsp_ols_w64_asm) start at multiples of four, so a chunk and the
+                          // whole column run every block through the same kernel and the results stay bit-identical
     const size_t in_cap = (size_t)(bpc * L + nb - 1) * esz, out_cap = (size_t)(bpc * L) * esz;
 
     hostpipe::Session ss(in_cap, out_cap, pinned);

@@ -1093,6 +1093,52 @@ def test_overlap_save_lds_dma_staging_is_bit_identical(d, torch, variant):
         _lib.set_tunable("MDSP_OLS_VARIANT", None)
 
 
+def test_overlap_save_hand_allocated_kernel_vs_oracle(d, torch):
+    """mdsp_ols_w64_asm (MDSP_OLS_VARIANT=40; csrc/ols_w64_asm.s, generated by tools/gen_ols_asm.py): one wavefront per four blocks, 2048 = 32 x 64 with one
+    exchange each way, the inverse transform run as a forward transform of the swapped product.  It takes the interior units of a column (multiples of
+    four blocks, runs of at least 64 units) and leaves the edges to ols_fused_kernel -- so: columns that are all edge (too short), columns with both,
+    several columns with a leading dimension, conv mode, a block range from a slice, all against the default kernel (different factorisation: equal to
+    rounding) and against the Float64 oracle, norm-wise and element-wise."""
+    from conftest import ulps_of_max
+    from dsp_jl_amd import _lib
+    from dsp_jl_amd.dspbase import OlsPlan
+    from oracle import dspbase as odsp
+    rng = np.random.default_rng(4040)
+    lib = _lib.lib()
+    b = _taps(256, np.float32)
+    try:
+        for nx, ncols, mode in ((100_000, 1, _lib.OLS_FILT), (1793 * 4 * 64 + 1793 * 4, 1, _lib.OLS_FILT), (1_000_003, 1, _lib.OLS_FILT), (2_000_001, 3, _lib.OLS_FILT),
+                                (700_001, 2, _lib.OLS_CONV), ((1 << 24) + 12345, 1, _lib.OLS_FILT)):
+            x = torch.from_numpy(rng.standard_normal((ncols, nx)).astype(np.float32)).cuda()
+            nout = nx if mode == _lib.OLS_FILT else nx + 255
+            _lib.set_tunable("MDSP_OLS_VARIANT", "0")
+            ref = OlsPlan(b, 2048, nx, mode, d.ENGINE_FUSED).exec(x, nout)
+            _lib.set_tunable("MDSP_OLS_VARIANT", "40")
+            plan = OlsPlan(b, 2048, nx, mode, d.ENGINE_FUSED)
+            got = plan.exec(x, nout)
+            torch.cuda.synchronize()
+            assert torch.equal(plan.exec(x, nout), got)                       # deterministic
+            for c in range(ncols):
+                assert relerr(got[c].cpu().numpy(), ref[c].double().cpu().numpy()) < 1e-6, (nx, c)
+            if nx <= 1_000_003:
+                want = odsp.filt_ba(b.astype(np.float64), 1.0, x[0].cpu().numpy().astype(np.float64)) if mode == _lib.OLS_FILT else None
+                if want is not None:
+                    assert relerr(got[0].cpu().numpy(), want) < TOL32
+                    u = max(ulps_of_max(got[0, k:k + 600].cpu().numpy(), want[k:k + 600]) for k in range(0, nx - 600, 50_000))
+                    assert u < 2 * 1.0 * 11, u
+            if nx == 1_000_003:
+                # a block range from a slice: blocks [100, 500) hold 100 aligned units -> the same kernels take the same blocks as in the whole column
+                L, g0, g1 = 1793, 100, 500
+                lo, hi = g0 * L - 255, g1 * L
+                xs = x[0, lo:hi].contiguous()
+                ys = torch.empty(hi - g0 * L, dtype=torch.float32, device="cuda")
+                _lib.check(lib.mdsp_ols_exec_range(plan._h, xs.data_ptr(), lo, hi - lo, nx, ys.data_ptr(), g0, g1 - g0, nx, None))
+                torch.cuda.synchronize()
+                assert torch.equal(ys, got[0, g0 * L:hi])
+    finally:
+        _lib.set_tunable("MDSP_OLS_VARIANT", None)
+
+
 @pytest.mark.parametrize("nfft", [1000, 1200, 1280, 1500, 1536, 1600, 1920, 2000, 2400, 2500, 2560, 3000, 3072, 3200, 3840, 4000, 4800, 5000, 5120, 6000, 6144, 6400, 8000])
 def test_compile_time_mixed_radix_schedules(d, torch, nfft):
     """Every size with a compile-time schedule (spectral_gen.h MDSP_GEN_CT_SIZES): Welch, raw STFT and spectrogram of Float32 and ComplexF32

@@ -228,9 +228,10 @@ def test_config2_full_size_properties(d, torch):
             ref = odsp.filt_ba(b.astype(np.float64), 1.0, xs)[s - lo:]
             assert relerr(y[s:s + 600].cpu().numpy(), ref) < TOL32, (engine, s)
             # element-wise, in Float32 unit roundoffs of the window's largest output: two 2048-point transforms and a spectrum product per output
+            # (bound 2 log2(nfft) = 22; measured 4.3 on MI355X, gpurun_out/s4)
             u = ulps_of_max(y[s:s + 600].cpu().numpy(), ref)
             worst_u = max(worst_u, u)
-            assert u < 2 * 3.0 * 11, (engine, s, u)
+            assert u < 2 * 1.0 * 11, (engine, s, u)
         results[engine] = y
     print("config 2 element-wise error, Float32 unit roundoffs of the window maximum:", worst_u)
     assert relerr(results[1][:10 ** 7].cpu().numpy(), results[2][:10 ** 7].cpu().numpy()) < TOL32

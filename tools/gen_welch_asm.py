@@ -987,6 +987,8 @@ def verify_waits(ins_list):
             lds.append(None)
         elif ins.op == "buffer_load_dword":
             vm.append(set(keys_of(ins.d)))
+        elif ins.op == "buffer_store_dword":
+            vm.append(None)
     return bad
 
 
