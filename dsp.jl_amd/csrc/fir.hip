@@ -740,8 +740,9 @@ struct ArbStep {              // one update! (stream_filt.jl:567-577), shared by
     // makes s - q nphi exact (Sterbenz) -- the exact remainder divrem returns.  Valid while qd nphi < 2^53.
     __host__ __device__ inline void fast(double& acc, int64_t& xidx) const {
         const double s = acc + delta;
+        const double r1 = s - c1, r2 = s - c2;   // both candidates next to the compare: three dependent operations per update instead of four
         const bool big = s >= c2;
-        acc = s - (big ? c2 : c1);
+        acc = big ? r2 : r1;
         xidx += qd + (big ? 1 : 0);
     }
 };
@@ -764,15 +765,19 @@ struct ArbArgs {
     int prio;             // MDSP_ARB_PRIO: 1 = the prologue (replay, tap copy, staging) runs at raised wave priority
 };
 
-struct ArbRec {
-    int xrel;             // xIdx - xIdx(first output of the tile)
-    int phi;              // 0-based phase
-    double alpha;
+// Per-output trajectory records of a tile, written by phase A: the phase accumulator (phi = floor(acc), alpha = acc - phi: both exact, taken
+// at the point of use) and xIdx relative to the tile's first output.  Two arrays (8 + 4 bytes per output instead of one 16-byte record):
+// with 1185 taps x 32 phases and four interleaved channels the workgroup needs 38 KiB of LDS instead of 43 -- FOUR workgroups per CU instead
+// of three, which is what this kernel's prologue / compute overlap lives on.
+struct ArbRecs {
+    double* acc;
+    int* xrel;
 };
 
-// rec[] is written by phase A with a lane stride of ARB_BLK records: one pad record per ARB_BLK keeps those 16-byte stores
-// off a single bank group
+// both arrays are written by phase A with a lane stride of ARB_BLK records: one pad record per ARB_BLK keeps those stores off a single
+// bank group
 __host__ __device__ constexpr int arb_rec_slot(int j) { return j + j / ARB_BLK; }
+__host__ __device__ constexpr size_t arb_rec_bytes(int tile) { return ((size_t)arb_rec_slot(tile) * 12 + 15) & ~size_t(15); }
 
 template <typename R> struct alignas(2 * sizeof(R)) Tap2 {   // (pfb, dpfb) of one (tap, phase): one 8 / 16-byte LDS read feeds both chains
     R p, d;
@@ -792,7 +797,7 @@ __device__ const unsigned char ARB_B128_ORDER[32] = {0,  1,  2,  3,  16, 17, 18,
 // NPHI: the number of phases when it is known at compile time (32, the reference's default: the tap reads of an unrolled batch
 // then differ by immediate offsets from one address register instead of one register and one v_add each), 0: run-time nphi
 template <typename A, typename R, int NCH, int NPHI>
-__device__ __forceinline__ void arb_tile_staged_n(const ArbRec* rec, const Tap2<R>* __restrict__ pf, const A* zs, A* const (&yc)[NCH], int nc, int cnt,
+__device__ __forceinline__ void arb_tile_staged_n(const ArbRecs rec, const Tap2<R>* __restrict__ pf, const A* zs, A* const (&yc)[NCH], int nc, int cnt,
                                                   int tp, int nphi_rt) {
     const int nphi = NPHI ? NPHI : nphi_rt;
     struct alignas(sizeof(A) * NCH <= 16 ? sizeof(A) * NCH : 16) ZV {
@@ -802,9 +807,11 @@ __device__ __forceinline__ void arb_tile_staged_n(const ArbRec* rec, const Tap2<
     int j0 = threadIdx.x;
     if constexpr (sizeof(ZV) == 16) j0 = (j0 & ~31) + ARB_B128_ORDER[j0 & 31];
     for (int j = j0; j < cnt; j += blockDim.x) {
-        const ArbRec rc = rec[arb_rec_slot(j)];
-        const Tap2<R>* hq = pf + rc.phi;
-        const ZV* zp = zv + rc.xrel;
+        const double racc = rec.acc[arb_rec_slot(j)];
+        const double rfl = floor(racc);
+        const double ralpha = racc - rfl;
+        const Tap2<R>* hq = pf + (int)rfl;
+        const ZV* zp = zv + rec.xrel[arb_rec_slot(j)];
         A lo[NCH], up[NCH];
         {
             const Tap2<R> t = *hq;
@@ -815,34 +822,56 @@ __device__ __forceinline__ void arb_tile_staged_n(const ArbRec* rec, const Tap2<
                 up[c] = mul_first(t.d, z.v[c]);
             }
         }
-#pragma unroll 8
-        for (int i = 1; i < tp; ++i) {
-            const Tap2<R> t = hq[i * nphi];
-            const ZV z = zp[i];
+        // taps 1 .. tp-1 in batches of 8 (sixteen LDS reads in flight, then their FMAs in tap order), the remainder as one batch of 4, 2 and 1
+        // (wave-uniform branches) instead of single taps that each wait for their own two reads
+        auto batch = [&](auto n, int i0) __attribute__((always_inline)) {
+            constexpr int N = decltype(n)::value;
+            Tap2<R> t[N];
+            ZV z[N];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                fma_acc(lo[c], t.p, z.v[c]);
-                fma_acc(up[c], t.d, z.v[c]);
+            for (int r = 0; r < N; ++r) {
+                t[r] = hq[(i0 + r) * nphi];
+                z[r] = zp[i0 + r];
             }
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    fma_acc(lo[c], t[r].p, z[r].v[c]);
+                    fma_acc(up[c], t[r].d, z[r].v[c]);
+                }
+            }
+        };
+        int i = 1;
+        for (; i + 8 <= tp; i += 8) batch(std::integral_constant<int, 8>{}, i);
+        if ((tp - i) & 4) {
+            batch(std::integral_constant<int, 4>{}, i);
+            i += 4;
         }
+        if ((tp - i) & 2) {
+            batch(std::integral_constant<int, 2>{}, i);
+            i += 2;
+        }
+        if ((tp - i) & 1) batch(std::integral_constant<int, 1>{}, i);
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
-            if (c < nc) yc[c][j] = arb_combine(up[c], rc.alpha, lo[c]);
+            if (c < nc) yc[c][j] = arb_combine(up[c], ralpha, lo[c]);
     }
 }
 template <typename A, typename R, int NCH>
-__device__ __forceinline__ void arb_tile_staged(const ArbRec* rec, const Tap2<R>* __restrict__ pf, const A* zs, A* const (&yc)[NCH], int nc, int cnt,
+__device__ __forceinline__ void arb_tile_staged(const ArbRecs rec, const Tap2<R>* __restrict__ pf, const A* zs, A* const (&yc)[NCH], int nc, int cnt,
                                                 int tp, int nphi) {
     if (nphi == 32) arb_tile_staged_n<A, R, NCH, 32>(rec, pf, zs, yc, nc, cnt, tp, nphi);
     else arb_tile_staged_n<A, R, NCH, 0>(rec, pf, zs, yc, nc, cnt, tp, nphi);
 }
 
+// (the second launch bound: four workgroups per CU -- what the 38 KiB of LDS of the Float32 four-channel form admit -- need <= 128 VGPRs)
 template <typename XS, typename A, typename R, int NCH>
-__global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
+__global__ __launch_bounds__(256, (sizeof(A) * NCH <= 16 ? 4 : 1)) void arbitrary_fir_kernel(ArbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ArbRec* rec = reinterpret_cast<ArbRec*>(smem);
-    A* zs = reinterpret_cast<A*>(smem + (size_t)arb_rec_slot(a.tile) * sizeof(ArbRec));
-    Tap2<R>* ps = reinterpret_cast<Tap2<R>*>(smem + (size_t)arb_rec_slot(a.tile) * sizeof(ArbRec) + (size_t)a.span * NCH * sizeof(A));
+    const ArbRecs rec{reinterpret_cast<double*>(smem), reinterpret_cast<int*>(smem + (size_t)arb_rec_slot(a.tile) * sizeof(double))};
+    A* zs = reinterpret_cast<A*>(smem + arb_rec_bytes(a.tile));
+    Tap2<R>* ps = reinterpret_cast<Tap2<R>*>(smem + arb_rec_bytes(a.tile) + (size_t)a.span * NCH * sizeof(A));
     const int64_t m0 = (int64_t)blockIdx.x * a.tile;
     if (m0 >= a.nout) return;
     const int cnt = (int)std::min<int64_t>(a.tile, a.nout - m0);
@@ -851,7 +880,7 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
     auto stamp = [&](int k) {
         if (a.prof && tid == 0) a.prof[(int64_t)blockIdx.x * 8 + k] = clock64();
     };
-    if (a.prio) __builtin_amdgcn_s_setprio(3);   // a workgroup in its latency-bound prologue goes first among the co-resident ones
+    if ((a.prio & 1) || ((a.prio & 2) && tid < 64)) __builtin_amdgcn_s_setprio(3);   // a workgroup in its latency-bound prologue (1), or only its replaying wave (2), goes first among the co-resident ones
     stamp(0);
     const int64_t x_first = a.tab_x[b0];
     const int64_t z_first = x_first - 1;                                    // z = [history ; x], output n reads z[n-1 .. n-1+tp)
@@ -865,11 +894,25 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
         const A v = to_acc(*p, (A*)nullptr);
         return ok ? v : A{};
     };
-    // stage z[z_first .. z_first + count) of the channel group at c0 into zs, interleaved; `lanes` threads starting at `first`
-    auto stage = [&](int64_t c0, int nc, int first, int lanes, int count) {
-        constexpr int RB = 4;   // RB * NCH independent loads in flight per thread
-        for (int k0 = first; k0 < count; k0 += RB * lanes) {
-            A v[RB][NCH];
+    // stage z[z_first .. z_first + count) of the channel group at c0 into zs, interleaved; `lanes` threads starting at `first`.  Loads and
+    // stores of a round are separate steps so that the prologue can put the tap copy's loads in front of the same wait.
+    constexpr int RB = sizeof(A) * NCH <= 16 ? 6 : 4;   // RB * NCH independent loads in flight per thread (six rounds of 192 threads cover a 1024-output tile's span at rates >= 1)
+    // a tile whose whole span lies inside x (every tile but the first and the last few of a call) loads through one uniform base pointer per
+    // channel: the history / end-of-input selects of zload cost a dozen vector instructions per load, which is most of what the staging
+    // waves issue -- and they issue in competition with three computing workgroups
+    const bool interior = z_first >= a.hl && z_first + a.span <= (int64_t)a.hl + a.xlen;
+    auto stage_loads = [&](A(&v)[RB][NCH], int64_t c0, int nc, int k0, int lanes, int count) __attribute__((always_inline)) {
+        if (interior) {
+            const XS* xb[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) xb[c] = static_cast<const XS*>(a.x) + (c0 + (c < nc ? c : 0)) * a.ldx + (z_first - a.hl);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int k = min(k0 + r * lanes, count - 1);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) v[r][c] = to_acc(xb[c][k], (A*)nullptr);
+            }
+        } else {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int k = k0 + r * lanes;
@@ -877,14 +920,23 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) v[r][c] = zload(c0 + (c < nc ? c : 0), zi);
             }
+        }
+    };
+    auto stage_stores = [&](const A(&v)[RB][NCH], int nc, int k0, int lanes, int count) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int k = k0 + r * lanes;
-                if (k < count) {
+        for (int r = 0; r < RB; ++r) {
+            const int k = k0 + r * lanes;
+            if (k < count) {
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) zs[k * NCH + c] = c < nc ? v[r][c] : A{};
-                }
+                for (int c = 0; c < NCH; ++c) zs[k * NCH + c] = c < nc ? v[r][c] : A{};
             }
+        }
+    };
+    auto stage = [&](int64_t c0, int nc, int first, int lanes, int count) __attribute__((always_inline)) {
+        for (int k0 = first; k0 < count; k0 += RB * lanes) {
+            A v[RB][NCH];
+            stage_loads(v, c0, nc, k0, lanes, count);
+            stage_stores(v, nc, k0, lanes, count);
         }
     };
     const Tap2<R>* pg = static_cast<const Tap2<R>*>(a.taps2);
@@ -899,32 +951,53 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
             const int base = tid * ARB_BLK;
             const int n = min(ARB_BLK, cnt - base);
             for (int k = 0; k < n; ++k) {
-                const double fl = floor(acc);
-                rec[arb_rec_slot(base + k)] = {(int)(xi - x_first), (int)fl, acc - fl};   // alpha = modf(acc)[1] is exact
+                rec.acc[arb_rec_slot(base + k)] = acc;
+                rec.xrel[arb_rec_slot(base + k)] = (int)(xi - x_first);
                 if (!MDSP_ABLATED(a, 1)) a.step.fast(acc, xi);
             }
         }
         stamp(2);
     } else {
         const int lanes = (int)blockDim.x - 64, u = tid - 64;
-        if (a.taps_in_lds && !MDSP_ABLATED(a, 8)) {
-            const int np = a.tp * a.nphi;
-            constexpr int RB = 4;
-            for (int k0 = u; k0 < np; k0 += RB * lanes) {
-                Tap2<R> v[RB];
+        // the tap pairs travel as 16-byte units (two Float32 pairs, one Float64 pair); round 0 of the tap copy and round 0 of the staging
+        // issue ALL their loads before the first wait -- one memory latency for the tap table and the whole span of a 1024-output tile
+        constexpr int RT = 4;
+        const bool do_taps = a.taps_in_lds && !MDSP_ABLATED(a, 8);
+        const bool do_stage = a.span > 0 && c_first < a.nch && !MDSP_ABLATED(a, 4);
+        const int np = a.tp * a.nphi;
+        const int nu = do_taps ? (int)((size_t)np * sizeof(Tap2<R>) / 16) : 0;
+        const int nc0 = (int)std::min<int64_t>(NCH, a.nch - c_first);
+        const uint4* pg16 = reinterpret_cast<const uint4*>(pg);
+        uint4* ps16 = reinterpret_cast<uint4*>(ps);
+        uint4 tv[RT];
+        A sv[RB][NCH];
 #pragma unroll
-                for (int r = 0; r < RB; ++r) v[r] = pg[min(k0 + r * lanes, np - 1)];
+        for (int r = 0; r < RT; ++r) tv[r] = pg16[min(u + r * lanes, max(nu, 1) - 1)];   // unconditional (the table always exists): no private copy of tv
+        stage_loads(sv, do_stage ? c_first : 0, do_stage ? nc0 : 1, u, lanes, max(a.span, 1));
+        if (do_taps) {
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
-                    if (k0 + r * lanes < np) ps[k0 + r * lanes] = v[r];
+            for (int r = 0; r < RT; ++r)
+                if (u + r * lanes < nu) ps16[u + r * lanes] = tv[r];
+        }
+        if (do_stage) stage_stores(sv, nc0, u, lanes, a.span);
+        if (do_taps) {
+            for (int k0 = u + RT * lanes; k0 < nu; k0 += RT * lanes) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) tv[r] = pg16[min(k0 + r * lanes, nu - 1)];
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    if (k0 + r * lanes < nu) ps16[k0 + r * lanes] = tv[r];
+            }
+            if constexpr (sizeof(Tap2<R>) == 8) {
+                if ((np & 1) && u == 0) ps[np - 1] = pg[np - 1];   // an odd number of 8-byte pairs: the last one is not part of a 16-byte unit
             }
         }
-        if (a.span > 0 && c_first < a.nch && !MDSP_ABLATED(a, 4)) stage(c_first, (int)std::min<int64_t>(NCH, a.nch - c_first), u, lanes, a.span);
+        if (do_stage) stage(c_first, nc0, u + RB * lanes, lanes, a.span);
     }
     __syncthreads();
     if (a.prio) __builtin_amdgcn_s_setprio(0);
     stamp(3);
-    const int64_t nz = (int64_t)rec[arb_rec_slot(cnt - 1)].xrel + a.tp;
+    const int64_t nz = (int64_t)rec.xrel[arb_rec_slot(cnt - 1)] + a.tp;
     const bool staged = nz <= a.span;                                       // workgroup-uniform
     for (int64_t c0 = c_first; c0 < a.nch; c0 += (int64_t)gridDim.y * NCH) {
         const int nc = (int)std::min<int64_t>(NCH, a.nch - c0);
@@ -946,9 +1019,10 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
             for (int c = 0; c < nc; ++c) {
                 A* yc = static_cast<A*>(a.y) + (c0 + c) * a.ldy;
                 for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
-                    const ArbRec rc = rec[arb_rec_slot(j)];
-                    const Tap2<R>* hp = pf + rc.phi;
-                    const int64_t z0 = z_first + rc.xrel;
+                    const double racc = rec.acc[arb_rec_slot(j)];
+                    const double rfl = floor(racc);                                 // alpha = modf(acc)[1] is exact
+                    const Tap2<R>* hp = pf + (int)rfl;
+                    const int64_t z0 = z_first + rec.xrel[arb_rec_slot(j)];
                     A z = zload(c0 + c, z0);
                     Tap2<R> t = hp[0];
                     A lo = mul_first(t.p, z);
@@ -959,7 +1033,7 @@ __global__ __launch_bounds__(256) void arbitrary_fir_kernel(ArbArgs a) {
                         fma_acc(lo, t.p, z);
                         fma_acc(up, t.d, z);
                     }
-                    yc[m0 + j] = arb_combine(up, rc.alpha, lo);
+                    yc[m0 + j] = arb_combine(up, racc - rfl, lo);
                 }
             }
         }
@@ -2106,7 +2180,7 @@ template <typename XS, typename A, typename R, int NCH> int arb_launch_n(mdsp_fi
     const int64_t taps_bytes = 2 * (int64_t)f->base.tp * f->nphi * (int64_t)sizeof(R);
     a.tile = tile;
     a.span = (int)span;
-    const size_t lds_bytes = (size_t)arb_rec_slot(tile) * sizeof(ArbRec) + (size_t)span * NCH * sizeof(A) + (a.taps_in_lds ? (size_t)taps_bytes : 0);
+    const size_t lds_bytes = arb_rec_bytes(tile) + (size_t)span * NCH * sizeof(A) + (a.taps_in_lds ? (size_t)taps_bytes : 0);
     auto kern = arbitrary_fir_kernel<XS, A, R, NCH>;
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // channels share a tile's replayed trajectory (and, NCH at a time, its tap reads): loop over the channel groups inside the
@@ -2158,7 +2232,7 @@ template <typename XS, typename A, typename R> int arb_launch(mdsp_firarb_s* f, 
     const int tile0 = tile;
     int64_t span = 0;
     const auto span_of = [&](int t) { return ((int64_t)std::ceil((double)t * f->delta / (double)f->nphi) + f->base.tp + 4 + 3) & ~int64_t(3); };   // multiple of 4: the tap pairs that follow stay 16-byte aligned
-    const int64_t fixed = (int64_t)arb_rec_slot(tile0) * (int64_t)sizeof(ArbRec) + (a.taps_in_lds ? taps_bytes : 0);
+    const int64_t fixed = (int64_t)arb_rec_bytes(tile0) + (a.taps_in_lds ? taps_bytes : 0);
     span = span_of(tile);
     while (nchg > 1 && fixed + span * nchg * (int64_t)sizeof(A) > 44 * 1024) nchg /= 2;
     if (nchg == 1) {   // one channel at a time: shrink the tile until its span fits 48 KiB
