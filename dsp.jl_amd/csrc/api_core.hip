@@ -66,6 +66,7 @@ static void read_tunables_locked() {
     if (const char* e = getenv("MDSP_ARB_SCAN_MIN")) t.arb_scan_min = atoll(e);
     t.host_chunk_mib = std::max(1, geti("MDSP_HOST_CHUNK_MIB", 64));
     t.ols_prefetch = geti("MDSP_OLS_PREFETCH", 0);
+    t.gen_wide = geti("MDSP_GEN_WIDE", 1);
     t.fir_p = geti("MDSP_FIR_P", 0);
     t.fir_mm = geti("MDSP_FIR_MM", -1);
     t.fir_exact = geti("MDSP_FIR_EXACT", 0);

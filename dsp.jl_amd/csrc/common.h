@@ -141,6 +141,7 @@ struct Tunables {
     int fir_mm_ch = 0;                  // MDSP_FIR_MM_CH           : at most this many 16-row chunks per multiplying wave (0 = 4 Float32, 2 otherwise)
     int fir_mm_ng = 0;                  // MDSP_FIR_MM_NG           : at most this many 16 CH-row groups per tile (0 = default 8)
     int fir_mm_nd = 0, fir_mm_ns = 0;   // MDSP_FIR_MM_ND / _NS     : its DMA / store waves (0 = default: 2 DMA waves, 2 store waves for ratios >= 1, else 4)
+    int gen_wide = 1;                   // MDSP_GEN_WIDE=0          : nextfastfft sizes: round 3's schedules of small radices instead of the three-pass composite-radix ones
     int ols_prefetch = 0;               // MDSP_OLS_PREFETCH=1      : overlap-save kernel with software prefetch of the next unit (default: off)
     int plan_cache_total = 8 * MDSP_PLAN_CACHE_SIZE;   // MDSP_PLAN_CACHE_TOTAL : entries in the whole plan cache above which idle partitions are trimmed
     int plan_cache_idle = 64;           // MDSP_PLAN_CACHE_IDLE     : cache requests without one of its own after which a partition counts as idle

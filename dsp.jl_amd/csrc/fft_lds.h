@@ -14,6 +14,8 @@
 // exact same code thread-by-thread on the host against numpy.
 #pragma once
 
+#include <utility>
+
 #ifdef __HIPCC__
 #define MDSP_HD __host__ __device__ __forceinline__
 #else
@@ -680,10 +682,81 @@ template <typename R> MDSP_HD void bfly7f(cx<R> (&v)[7]) {
     v[3] = cadd(m3, n3);
     v[4] = csub(m3, n3);
 }
+// ---- composite radices (round 4): 6, 10, 12, 15, 20, 24, 25 as two levels of the small butterflies INSIDE the registers of one thread -------------
+// A pass of radix R1 R2 replaces two passes (one LDS round trip and one barrier less): 3000 = 5 x 24 x 25 runs three passes instead of the five
+// of 3 x 5 x 5 x 5 x 8.  Cooley-Tukey inside the butterfly: R1 transforms of length R2 over the points n1 + R1 n2, the constant twiddles
+// exp(-2 pi i n1 k2 / (R1 R2)), R2 transforms of length R1; result k2 + R2 k1, natural order.  cos / sin (2 pi m / N) to 21 digits (mpmath);
+// multiples of a quarter turn are exact and cost a swap, not a product.
+template <int N> struct CompRoots;
+template <> struct CompRoots<6> {
+    static constexpr double c[6] = {1.0, 0.5, -0.5, -1.0, -0.5, 0.5};
+    static constexpr double s[6] = {0.0, 0.866025403784438646764, 0.866025403784438646764, 0.0, -0.866025403784438646764, -0.866025403784438646764};
+};
+template <> struct CompRoots<10> {
+    static constexpr double c[10] = {1.0, 0.809016994374947424102, 0.309016994374947424102, -0.309016994374947424102, -0.809016994374947424102, -1.0, -0.809016994374947424102, -0.309016994374947424102, 0.309016994374947424102, 0.809016994374947424102};
+    static constexpr double s[10] = {0.0, 0.587785252292473129169, 0.951056516295153572116, 0.951056516295153572116, 0.587785252292473129169, 0.0, -0.587785252292473129169, -0.951056516295153572116, -0.951056516295153572116, -0.587785252292473129169};
+};
+template <> struct CompRoots<12> {
+    static constexpr double c[12] = {1.0, 0.866025403784438646764, 0.5, 0.0, -0.5, -0.866025403784438646764, -1.0, -0.866025403784438646764, -0.5, 0.0, 0.5, 0.866025403784438646764};
+    static constexpr double s[12] = {0.0, 0.5, 0.866025403784438646764, 1.0, 0.866025403784438646764, 0.5, 0.0, -0.5, -0.866025403784438646764, -1.0, -0.866025403784438646764, -0.5};
+};
+template <> struct CompRoots<15> {
+    static constexpr double c[15] = {1.0, 0.913545457642600895502, 0.669130606358858213826, 0.309016994374947424102, -0.1045284632676534714, -0.5, -0.809016994374947424102, -0.978147600733805637929, -0.978147600733805637929, -0.809016994374947424102, -0.5, -0.1045284632676534714, 0.309016994374947424102, 0.669130606358858213826, 0.913545457642600895502};
+    static constexpr double s[15] = {0.0, 0.406736643075800207754, 0.743144825477394235015, 0.951056516295153572116, 0.994521895368273336923, 0.866025403784438646764, 0.587785252292473129169, 0.207911690817759337102, -0.207911690817759337102, -0.587785252292473129169, -0.866025403784438646764, -0.994521895368273336923, -0.951056516295153572116, -0.743144825477394235015, -0.406736643075800207754};
+};
+template <> struct CompRoots<20> {
+    static constexpr double c[20] = {1.0, 0.951056516295153572116, 0.809016994374947424102, 0.587785252292473129169, 0.309016994374947424102, 0.0, -0.309016994374947424102, -0.587785252292473129169, -0.809016994374947424102, -0.951056516295153572116, -1.0, -0.951056516295153572116, -0.809016994374947424102, -0.587785252292473129169, -0.309016994374947424102, 0.0, 0.309016994374947424102, 0.587785252292473129169, 0.809016994374947424102, 0.951056516295153572116};
+    static constexpr double s[20] = {0.0, 0.309016994374947424102, 0.587785252292473129169, 0.809016994374947424102, 0.951056516295153572116, 1.0, 0.951056516295153572116, 0.809016994374947424102, 0.587785252292473129169, 0.309016994374947424102, 0.0, -0.309016994374947424102, -0.587785252292473129169, -0.809016994374947424102, -0.951056516295153572116, -1.0, -0.951056516295153572116, -0.809016994374947424102, -0.587785252292473129169, -0.309016994374947424102};
+};
+template <> struct CompRoots<24> {
+    static constexpr double c[24] = {1.0, 0.96592582628906828675, 0.866025403784438646764, 0.707106781186547524401, 0.5, 0.258819045102520762349, 0.0, -0.258819045102520762349, -0.5, -0.707106781186547524401, -0.866025403784438646764, -0.96592582628906828675, -1.0, -0.96592582628906828675, -0.866025403784438646764, -0.707106781186547524401, -0.5, -0.258819045102520762349, 0.0, 0.258819045102520762349, 0.5, 0.707106781186547524401, 0.866025403784438646764, 0.96592582628906828675};
+    static constexpr double s[24] = {0.0, 0.258819045102520762349, 0.5, 0.707106781186547524401, 0.866025403784438646764, 0.96592582628906828675, 1.0, 0.96592582628906828675, 0.866025403784438646764, 0.707106781186547524401, 0.5, 0.258819045102520762349, 0.0, -0.258819045102520762349, -0.5, -0.707106781186547524401, -0.866025403784438646764, -0.96592582628906828675, -1.0, -0.96592582628906828675, -0.866025403784438646764, -0.707106781186547524401, -0.5, -0.258819045102520762349};
+};
+template <> struct CompRoots<25> {
+    static constexpr double c[25] = {1.0, 0.96858316112863111949, 0.876306680043863587308, 0.728968627421411523147, 0.535826794978996618271, 0.309016994374947424102, 0.0627905195293133760762, -0.187381314585724630543, -0.425779291565072648863, -0.637423989748689710177, -0.809016994374947424102, -0.929776485888251403661, -0.99211470131447783105, -0.99211470131447783105, -0.929776485888251403661, -0.809016994374947424102, -0.637423989748689710177, -0.425779291565072648863, -0.187381314585724630543, 0.0627905195293133760762, 0.309016994374947424102, 0.535826794978996618271, 0.728968627421411523147, 0.876306680043863587308, 0.96858316112863111949};
+    static constexpr double s[25] = {0.0, 0.248689887164854788242, 0.481753674101715274987, 0.684547105928688673732, 0.844327925502015078549, 0.951056516295153572116, 0.998026728428271561952, 0.982287250728688681086, 0.904827052466019527714, 0.770513242775789230803, 0.587785252292473129169, 0.368124552684677959157, 0.125333233564304245373, -0.125333233564304245373, -0.368124552684677959157, -0.587785252292473129169, -0.770513242775789230803, -0.904827052466019527714, -0.982287250728688681086, -0.998026728428271561952, -0.951056516295153572116, -0.844327925502015078549, -0.684547105928688673732, -0.481753674101715274987, -0.248689887164854788242};
+};
+template <int RDX, typename R> MDSP_HD void gen_bfly(cx<R> (&v)[RDX]);
+template <int N, int M, typename R> MDSP_HD cx<R> comp_twiddle(cx<R> a) {   // a exp(-2 pi i M / N), 0 <= M < N
+    if constexpr (M == 0) return a;
+    else if constexpr (4 * M == N) return mul_mi<-1>(a);      // -i a
+    else if constexpr (2 * M == N) return cx<R>{-a.x, -a.y};
+    else if constexpr (4 * M == 3 * N) return mul_mi<1>(a);   // +i a
+    else return twmul_k<-1>(a, cx<R>{(R)CompRoots<N>::c[M], (R)-CompRoots<N>::s[M]});
+}
+template <int R1, int R2, int K2, typename R, int... N1>
+MDSP_HD void comp_column(const cx<R> (&y)[R1][R2], cx<R> (&v)[R1 * R2], std::integer_sequence<int, N1...>) {
+    cx<R> u[R1] = {comp_twiddle<R1 * R2, N1 * K2>(y[N1][K2])...};
+    gen_bfly<R1>(u);
+    ((v[K2 + R2 * N1] = u[N1]), ...);
+}
+template <int R1, int R2, typename R, int... K2> MDSP_HD void comp_columns(const cx<R> (&y)[R1][R2], cx<R> (&v)[R1 * R2], std::integer_sequence<int, K2...>) {
+    (comp_column<R1, R2, K2>(y, v, std::make_integer_sequence<int, R1>{}), ...);
+}
+template <int R1, int R2, typename R> MDSP_HD void bfly_comp(cx<R> (&v)[R1 * R2]) {
+    cx<R> y[R1][R2];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) {
+        cx<R> u[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) u[n2] = v[n1 + R1 * n2];
+        gen_bfly<R2>(u);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) y[n1][k2] = u[k2];
+    }
+    comp_columns<R1, R2>(y, v, std::make_integer_sequence<int, R2>{});
+}
 template <int RDX, typename R> MDSP_HD void gen_bfly(cx<R> (&v)[RDX]) {
     if constexpr (RDX == 3) bfly3f(v[0], v[1], v[2]);
     else if constexpr (RDX == 5) bfly5f(v);
     else if constexpr (RDX == 7) bfly7f(v);
+    else if constexpr (RDX == 6) bfly_comp<3, 2>(v);
+    else if constexpr (RDX == 10) bfly_comp<5, 2>(v);
+    else if constexpr (RDX == 12) bfly_comp<3, 4>(v);
+    else if constexpr (RDX == 15) bfly_comp<3, 5>(v);
+    else if constexpr (RDX == 20) bfly_comp<5, 4>(v);
+    else if constexpr (RDX == 24) bfly_comp<3, 8>(v);
+    else if constexpr (RDX == 25) bfly_comp<5, 5>(v);
     else bfly<RDX, -1>(v);
 }
 

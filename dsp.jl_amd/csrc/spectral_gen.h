@@ -182,8 +182,12 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
 //     32 banks by itself, and every read is contiguous by lane.
 template <int N_, int T_, int LDSIN_, int... RS> struct CtSched {
     static constexpr int N = N_, T = T_, P = (int)sizeof...(RS);
-    static constexpr bool LDSIN = LDSIN_ != 0;
-    static constexpr int MINW_REAL = LDSIN_ > 1 ? LDSIN_ : 1;   // waves per SIMD the column (STFT) kernels are compiled for (register cap): a
+    static constexpr bool LDSIN = (LDSIN_ & 7) != 0;
+    static constexpr bool PREFETCH = (LDSIN_ & 8) != 0;      // the next unit's samples are loaded behind the first pass and ride through the other passes in registers
+    static constexpr bool INPLACE = (LDSIN_ & 16) != 0;      // ONE LDS buffer: a pass reads its operands, waits for every thread's reads, writes its results in place
+                                                             // (a barrier more per pass, half the LDS: twice the workgroups per CU) -- register-consumed modes only
+    static constexpr int MINW_WELCH = (LDSIN_ & 32) ? 2 : 1; // waves per SIMD the Welch kernel is compiled for (register cap 256)
+    static constexpr int MINW_REAL = (LDSIN_ & 7) > 1 ? (LDSIN_ & 7) : 1;   // waves per SIMD the column (STFT) kernels are compiled for (register cap): a
                                                                  // workgroup of 6 waves puts two on some SIMDs, and two such workgroups need four there   // real-signal column modes window the frame pair into LDS first (the register-fed first pass costs them a resident workgroup)
     static constexpr int radix(int p) {
         constexpr int r[] = {RS...};
@@ -251,23 +255,67 @@ __device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, c
     }
 }
 
+// the middle passes on ONE buffer (CtSched::INPLACE): every butterfly of the pass is read into registers, a barrier, then twiddles, butterflies and
+// the scatter, a barrier
+template <typename S, int p, int END, typename R> __device__ __forceinline__ void ct_passes_inplace(cx<R>* buf, const cx<R> (&tw)[S::NTW], int t) {
+    if constexpr (p < END) {
+        constexpr int Rdx = S::radix(p), Ns = S::ns(p), nbf = S::nbf(p), M = S::M(p);
+        cx<R> v[M][Rdx];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const unsigned j = (unsigned)(t + S::T * m);
+            if ((m + 1) * S::T <= nbf || j < (unsigned)nbf) {
+#pragma unroll
+                for (int q = 0; q < Rdx; ++q) v[m][q] = fft::ld2(buf + j + nbf * q);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const unsigned j = (unsigned)(t + S::T * m);
+            if ((m + 1) * S::T <= nbf || j < (unsigned)nbf) {
+#pragma unroll
+                for (int q = 1; q < Rdx; ++q) v[m][q] = fft::cmul(v[m][q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
+                fft::gen_bfly<Rdx>(v[m]);
+                const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
+                cx<R>* o = buf + hi * (unsigned)(Ns * Rdx) + k;
+#pragma unroll
+                for (int q = 0; q < Rdx; ++q) fft::st2(o + Ns * q, v[m][q]);
+            }
+        }
+        __syncthreads();
+        ct_passes_inplace<S, p + 1, END>(buf, tw, t);
+    }
+}
+
 // Pass 0 fed straight from the signal: butterfly j of the first pass reads points j + nbf q, which lanes j = t, t + 1, ... load as contiguous runs --
 // no windowed copy of the frame through LDS.  w0[m R + q] is the window at those points (0 past n: the zero tail), loop-invariant per thread.
-template <typename S, typename R, bool CPLX, typename TT>
-__device__ __forceinline__ void ct_pass0_global(const TT* fa, int64_t hop, bool live, bool haveB, int n, const R (&w0)[S::M(0) * S::radix(0)], cx<R>* out, int t) {
-    constexpr int Rdx = S::radix(0), nbf = S::nbf(0), M = S::M(0);
-    TT ra[M][Rdx], rb[CPLX ? 1 : M][CPLX ? 1 : Rdx];
+// (round 4: through buffer descriptors -- one per frame, `n` elements long, empty for a frame that does not exist -- so a load is one VGPR offset
+// plus a constant and the zero tail / missing frames come from the bounds check: the 64-bit address arithmetic, compares and selects of the
+// pointer form were a fifth of the kernel's vector instructions)
+template <typename S, bool CPLX, typename TT>
+__device__ __forceinline__ void ct_pass0_loads(const TT* fa, int64_t hop, bool live, bool haveB, int n, TT (&ra)[S::M(0)][S::radix(0)],
+                                               TT (&rb)[CPLX ? 1 : S::M(0)][CPLX ? 1 : S::radix(0)], int t) {
+    constexpr int Rdx = S::radix(0), nbf = S::nbf(0), M = S::M(0), SZ = (int)sizeof(TT);
+    const __amdgpu_buffer_rsrc_t da = io::make_rsrc(fa, live ? (long long)n * SZ : 0);
+    int off = t * SZ;
+    asm volatile("" : "+v"(off));   // one offset VGPR; the rest of every address is a constant
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const int j = t + S::T * m;
+    for (int m = 0; m < M; ++m)
 #pragma unroll
-        for (int q = 0; q < Rdx; ++q) {
-            const int i = j + nbf * q;
-            const bool on = live && ((m + 1) * S::T <= nbf || j < nbf) && i < n;
-            ra[m][q] = on ? fa[i] : TT{};
-            if constexpr (!CPLX) rb[m][q] = (on && haveB) ? fa[i + hop] : TT{};
-        }
+        for (int q = 0; q < Rdx; ++q) ra[m][q] = io::Ld<TT>::load(da, off + (S::T * m + nbf * q) * SZ);   // lanes past the last butterfly read points nobody uses
+    if constexpr (!CPLX) {
+        const __amdgpu_buffer_rsrc_t db = io::make_rsrc(fa + hop, haveB ? (long long)n * SZ : 0);
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int q = 0; q < Rdx; ++q) rb[m][q] = io::Ld<TT>::load(db, off + (S::T * m + nbf * q) * SZ);
     }
+}
+template <typename S, typename R, bool CPLX, typename TT>
+__device__ __forceinline__ void ct_pass0_compute(const TT (&ra)[S::M(0)][S::radix(0)], const TT (&rb)[CPLX ? 1 : S::M(0)][CPLX ? 1 : S::radix(0)],
+                                                 const R (&w0)[S::M(0) * S::radix(0)], cx<R>* out, int t) {
+    constexpr int Rdx = S::radix(0), nbf = S::nbf(0), M = S::M(0);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const int j = t + S::T * m;
@@ -285,6 +333,12 @@ __device__ __forceinline__ void ct_pass0_global(const TT* fa, int64_t hop, bool 
             for (int q = 0; q < Rdx; ++q) fft::st2(o + q, v[q]);
         }
     }
+}
+template <typename S, typename R, bool CPLX, typename TT>
+__device__ __forceinline__ void ct_pass0_global(const TT* fa, int64_t hop, bool live, bool haveB, int n, const R (&w0)[S::M(0) * S::radix(0)], cx<R>* out, int t) {
+    TT ra[S::M(0)][S::radix(0)], rb[CPLX ? 1 : S::M(0)][CPLX ? 1 : S::radix(0)];
+    ct_pass0_loads<S, CPLX>(fa, hop, live, haveB, n, ra, rb, t);
+    ct_pass0_compute<S, R, CPLX>(ra, rb, w0, out, t);
 }
 
 // The last pass with its results left in registers: butterfly j produces the bins j + (N / R) q in natural order -- lanes j = t, t + 1, ... own
@@ -309,7 +363,7 @@ __device__ __forceinline__ void ct_last_pass_regs(const cx<R>* in, const cx<R> (
 }
 
 template <typename R, bool CPLX, int MODE, typename S>   // MODE 0: Welch sums, 1: STFT columns (raw or PSD); one transform per workgroup
-__global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL : 1) void gen_ct_kernel(GenArgs a) {
+__global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL : (MODE == 0 && sizeof(R) == 4) ? S::MINW_WELCH : 1) void gen_ct_kernel(GenArgs a) {
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     constexpr int N = S::N, T = S::T;
     constexpr int PL = S::P - 1, RL = S::radix(PL), ML = S::M(PL), NBL = S::nbf(PL);   // the last pass
@@ -317,8 +371,9 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
     // Welch sums and complex columns take the last pass's results from registers; real-signal columns need the mirror bin N - k of another
     // thread (A[k] = (Z[k] + conj Z[N-k]) / 2), so their last pass goes through LDS once more
     constexpr bool DIRECT = MODE == 0 || CPLX;
-    __shared__ __attribute__((aligned(16))) cx<R> buf[2 * N];
-    cx<R>*bufA = buf, *bufB = buf + N;
+    constexpr bool INPL = S::INPLACE && DIRECT;
+    __shared__ __attribute__((aligned(16))) cx<R> buf[INPL ? N : 2 * N];
+    cx<R>*bufA = buf, *bufB = INPL ? buf : buf + N;
     const int t = threadIdx.x;
     const int64_t ch = blockIdx.y;
     const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
@@ -349,13 +404,29 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
         for (int i = 0; i < ML * RL; ++i) acc[i] = 0.0;
     }
     const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
+    constexpr bool PREF = S::PREFETCH && !LDSIN;
+    TT pra[PREF ? S::M(0) : 1][PREF ? S::radix(0) : 1], prb[(PREF && !CPLX) ? S::M(0) : 1][(PREF && !CPLX) ? S::radix(0) : 1];
+    auto unit_loads = [&](int64_t it) __attribute__((always_inline)) {
+        if constexpr (PREF) {
+            const int64_t u = u0 + it;
+            const bool live = it < a.per_slot && u < a.units_per_ch;
+            const int64_t f0 = live ? (CPLX ? u : 2 * u) : 0;
+            const bool haveB = !CPLX && live && (f0 + 1) < a.K;
+            ct_pass0_loads<S, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, pra, prb, t);
+            asm volatile("" ::: "memory");   // the loads are issued HERE, in front of the passes that follow
+        }
+    };
+    unit_loads(0);
     for (int64_t it = 0; it < a.per_slot; ++it) {
         const int64_t u = u0 + it;
         const bool live = u < a.units_per_ch;
         const int64_t f0 = CPLX ? u : 2 * u;
         const bool haveB = !CPLX && live && (f0 + 1) < a.K;
         // K4 (periodograms.jl:57-69) fused into the first pass: frame * window, zero tail, straight from the signal
-        if constexpr (!LDSIN) ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, t);
+        if constexpr (PREF) {
+            ct_pass0_compute<S, R, CPLX>(pra, prb, w0, bufA, t);
+            unit_loads(it + 1);
+        } else if constexpr (!LDSIN) ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, t);
         else {   // ... or windowed into LDS first (bufB), the first pass then runs LDS -> LDS like the others
             constexpr int BINS = S::BINS;
             const TT* fa = sc + f0 * a.hop;
@@ -383,7 +454,9 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
         if constexpr (!LDSIN) __syncthreads();
         const int64_t o0 = ch * a.chs + f0 * a.ldo;
         if constexpr (DIRECT) {
-            const cx<R>* src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t);
+            const cx<R>* src = bufA;
+            if constexpr (INPL) ct_passes_inplace<S, 1, S::P - 1>(bufA, tw, t);
+            else src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t);
             ct_last_pass_regs<S>(src, tw, t, [&](int m, int q, int k, cx<R> z) {
                 if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
                     if (live) acc[m * RL + q] += (double)(z.x * z.x + z.y * z.y);
@@ -447,7 +520,7 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     hipFuncAttributes fa{};
     MDSP_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
     const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8), waves = S::T / 64;
-    const size_t lds_bytes = sizeof(cx<R>) * 2 * (size_t)S::N;
+    const size_t lds_bytes = sizeof(cx<R>) * ((S::INPLACE && (MODE == 0 || CPLX)) ? 1 : 2) * (size_t)S::N;
     int per_cu = std::min<int>({32 / waves, (512 / regs) * 4 / waves, (int)((size_t)160 * 1024 / lds_bytes)});
     if (per_cu < 1) per_cu = 1;
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
@@ -475,6 +548,17 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     X(3072, 256, 0, 3, 16, 8, 8) X(3200, 256, 0, 5, 5, 8, 16) X(3840, 256, 0, 3, 5, 16, 16) X(4000, 512, 1, 5, 5, 5, 4, 8)            \
     X(4800, 512, 0, 3, 5, 5, 8, 8) X(5000, 512, 0, 5, 5, 5, 5, 8) X(5120, 320, 0, 5, 16, 8, 8) X(6000, 512, 0, 3, 5, 5, 5, 16)        \
     X(6144, 512, 0, 3, 16, 16, 8) X(6400, 448, 0, 5, 5, 16, 16) X(8000, 512, 0, 5, 5, 5, 8, 8)
+// Round 4: Float32 schedules with composite radices (fft_lds.h bfly_comp: 6 ... 25 inside one thread's registers) -- THREE passes where the list
+// above runs four or five, one or two LDS round trips and barriers less per transform; fewer, fatter threads (T ~ N / 24).  Taken where the
+// butterfly counts N / R fill the lanes of T threads (>= 78 % in every pass); MDSP_GEN_WIDE=0 keeps the list above.
+// Flags: 16 one LDS buffer, 32 Welch kernel compiled for two waves per SIMD, 64 / 128 / 256 NOT taken for Welch / complex columns / real columns
+// (measured per mode, tools/bench_wide.py, profiles/r04_wide_schedules.json; 1000, 1600 and 8000 were tried and lost in every mode).
+#define MDSP_GEN_CT_WIDE_SIZES(X)                                                                                               \
+    X(1200, 64, 48, 5, 12, 20) X(1500, 64, 304, 5, 12, 25) X(1920, 128, 48, 15, 8, 16) X(2000, 128, 304, 5, 16, 25)                 \
+    X(2400, 128, 48, 5, 20, 24) X(2500, 128, 48, 25, 10, 10) X(3000, 128, 48, 5, 24, 25) X(3200, 128, 112, 25, 8, 16)               \
+    X(3840, 256, 48, 15, 16, 16) X(4800, 320, 48, 15, 16, 20) X(5000, 256, 48, 25, 10, 20) X(6000, 256, 304, 25, 24, 10)            \
+    X(6400, 256, 368, 25, 16, 16)
+constexpr bool gen_ct_wide_mode(int flags, int mode, bool cplx) { return !(flags & (mode == 0 ? 64 : cplx ? 128 : 256)); }
 constexpr int GEN_CT_F64_MAX = 3000;   // Float64 / ComplexF64: two buffers of N x 16 bytes and twice the registers
 inline bool gen_ct_size(int dtype, int64_t nfft) {
     if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > GEN_CT_F64_MAX)) return false;
@@ -488,6 +572,22 @@ inline bool gen_ct_size(int dtype, int64_t nfft) {
 }
 template <typename R, bool CPLX, int MODE>
 bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial, int* rc) {
+    if constexpr (MDSP_GEN_CT && sizeof(R) == 4) {
+        if (tunables().gen_wide) {
+            switch (a.N) {
+#define MDSP_X(N, T, F, ...)                                                                               \
+    case N:                                                                                                \
+        if constexpr (gen_ct_wide_mode(F, MODE, CPLX)) {                                                   \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, F, __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            return true;                                                                                   \
+        }                                                                                                  \
+        break;
+                MDSP_GEN_CT_WIDE_SIZES(MDSP_X)
+#undef MDSP_X
+                default: break;
+            }
+        }
+    }
     if constexpr (MDSP_GEN_CT) {
         switch (a.N) {
 #define MDSP_X(N, T, ...)                                                                                          \

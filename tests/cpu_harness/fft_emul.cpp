@@ -276,8 +276,45 @@ template <typename R> static double check_wave64(bool frame_b) {
     return (double)sqrtl(err2 / norm);
 }
 
+// composite butterflies (radix 6 ... 25 inside one thread's registers, fft_lds.h bfly_comp) against the long-double DFT
+template <int RDX, typename R> double check_comp() {
+    cx<R> v[RDX];
+    std::complex<long double> x[RDX];
+    srand(17 + RDX);
+    for (int i = 0; i < RDX; ++i) {
+        const R a = (R)(rand() / (double)RAND_MAX - 0.5), b = (R)(rand() / (double)RAND_MAX - 0.5);
+        v[i] = {a, b};
+        x[i] = {(long double)a, (long double)b};
+    }
+    gen_bfly<RDX>(v);
+    long double err2 = 0, norm = 0;
+    for (int k = 0; k < RDX; ++k) {
+        std::complex<long double> acc = 0;
+        for (int n = 0; n < RDX; ++n) {
+            const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)((n * k) % RDX) / RDX;
+            acc += x[n] * std::complex<long double>(cosl(ang), sinl(ang));
+        }
+        err2 += std::norm(std::complex<long double>(v[k].x, v[k].y) - acc);
+        norm += std::norm(acc);
+    }
+    return (double)sqrtl(err2 / norm);
+}
+template <int... RS> int check_comps() {
+    int bad = 0;
+    const double e32[] = {check_comp<RS, float>()...}, e64[] = {check_comp<RS, double>()...};
+    const int rs[] = {RS...};
+    printf("composite butterflies:");
+    for (size_t i = 0; i < sizeof...(RS); ++i) {
+        printf(" %d: %.1e / %.1e", rs[i], e32[i], e64[i]);
+        if (!(e32[i] < 4e-7) || !(e64[i] < 1e-15)) bad = 1;
+    }
+    printf("\n");
+    return bad;
+}
+
 int main() {
     int bad = 0;
+    bad |= check_comps<6, 10, 12, 15, 20, 24, 25>();
     {
         const double b32 = check_bfly64<float>(), b64 = check_bfly64<double>();
         const double e32 = std::max(check_wave64<float>(true), check_wave64<float>(false)), e64 = std::max(check_wave64<double>(true), check_wave64<double>(false));
