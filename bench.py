@@ -373,19 +373,29 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
 
     mark("firarb")
     med, best = tm.time(arb)
-    # the kernel's other roof: two dot products of tapsPerPhi terms per output (pfb and its derivative bank, stream_filt.jl:596-616) against the
-    # measured packed-FMA issue rate (profiles/r02t_valu_rate.txt: v_pk_fma_f32 at 4.40 clocks per wave instruction = 29.1 FMA lanes per clock and
-    # SIMD with four waves per SIMD; 1024 SIMDs, 2.4 GHz)
+    # the kernel's own roofs (it is nowhere near HBM's): per output and tap ONE 8-byte tap-pair read (pfb and its derivative bank, stream_filt.jl:596-616)
+    # and one 16-byte read of the four interleaved channels feed eight FMAs -- 24 bytes of LDS traffic per (output, tap) against the LDS array's
+    # 256 B / clock / CU (MI355X_MICROARCH.md, LDS), and four v_pk_fma_f32 against the measured packed-FMA issue rate (profiles/r02t_valu_rate.txt:
+    # 4.40 clocks per wave instruction with four waves per SIMD = 29.1 FMA lanes per clock and SIMD); both at the 2.4 GHz the part reaches on light
+    # kernels.  SQ counters of the round-4 kernel (tools/sessions/r04_s15.sh): LDS array 65 % busy (1.6 % of it bank conflicts), vector unit 76 % busy,
+    # 1.71 GHz -- the kernel runs at both of its on-chip roofs at the clock the package power allows.
     tpp = -(-len(ha) // 32)
     fma = 2.0 * tpp * ola.value * nch
     tfl = 2.0 * fma / (med * 1e-3) / 1e12
     peak = 2.0 * 29.1 * 1024 * 2.4e9 / 1e12
+    lds_bytes = float(tpp) * ola.value * -(-nch // 4) * (8 + 4 * min(nch, 4))   # channel groups of four share one tap-pair read
+    lds_tbs = lds_bytes / (med * 1e-3) / 1e12
+    lds_peak = 256.0 * 256 * 2.4e9 / 1e12
     rows["firarb"] = roof("arbitrary_fir_kernel (row f1: 4 ch x 2^28 Float32, rate 160/147 as Float64, warm trajectory)", med, (4 + 4 * rate) * n * nch,
                           extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm),
+                                 "lds": {"achieved": round(lds_tbs, 1), "peak": round(lds_peak, 1), "unit": "TB/s of LDS reads (256 B/clk/CU x 256 CUs x 2.4 GHz)",
+                                         "frac": round(lds_tbs / lds_peak, 4), "bytes_per_output_and_tap": 8 + 4 * min(nch, 4),
+                                         "note": "the sub-roof that binds: SQ_LDS_IDX_ACTIVE says 65 % of the LDS-array cycles at the kernel's own 1.71 GHz "
+                                                 "(power-limited clock); conflicts 1.6 %"},
                                  "valu": {"achieved": round(tfl, 1), "peak": round(peak, 1), "unit": "TFLOP/s (v_pk_fma_f32 issue rate, measured)", "frac": round(tfl / peak, 4),
                                           "fma_per_output": 2 * tpp,
-                                          "note": "FMA issue alone is not the bound either: the SQ counters show the vector unit 70 % busy, most of it LDS-operand "
-                                                  "fetch and address arithmetic around each FMA (DESIGN.md section 4.7)"}})
+                                          "note": "vector unit 76 % busy at 1.71 GHz: half of its instructions are the FMAs, the rest the trajectory replay, staging "
+                                                  "and the Float64 combine of each output"}})
     _lib.check(lib.mdsp_firarb_destroy(fa))
     del x, y, ya
     torch.cuda.empty_cache()

@@ -9,10 +9,10 @@ wave for 64 complex points (128) + 64 power accumulators + 28 twiddle values + t
 their last use, which the script knows because it emits the dataflow itself.
 
 What it writes:  dsp.jl_amd/csrc/welch_w64_asm.s  (assembled by build.py with clang -x assembler, linked by ld.lld, loaded with
-hipModuleLoadData by csrc/asmkernels.hip).  `--check` runs the emitted instruction list through a lane-level emulator of the ~15 opcodes it
+hipModuleLoadData by csrc/welch_w64.h (included by spectral.hip)).  `--check` runs the emitted instruction list through a lane-level emulator of the ~15 opcodes it
 uses (numpy, one wavefront) for two consecutive units and compares the accumulators with numpy's FFT of the windowed frame pairs.
 
-Kernel contract (csrc/asmkernels.hip fills the arguments):
+Kernel contract (welch_run_w64asm in csrc/welch_w64.h fills the arguments):
     struct W64AsmArgs { const float* s; float* part; const float* winpairs; const float* tw; int64 lds_, units, run_len, nch; int nflush, pad; }
     grid (G, nch), 512 threads = 8 independent waves; wave w of workgroup b is slot 8 b + w and owns units [slot run_len, (slot+1) run_len) of
     its channel (a unit = two frames = 4096 new samples; every unit handed to this kernel has BOTH frames -- the odd last frame of a channel
