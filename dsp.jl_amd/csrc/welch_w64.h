@@ -410,25 +410,47 @@ __global__ __launch_bounds__(256) void w64asm_prepare_kernel(const double* __res
     }
 }
 
-__global__ __launch_bounds__(256) void w64asm_zero_kernel(float4* __restrict__ p, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = float4{0.f, 0.f, 0.f, 0.f};
+// reduced[ch][k] (+)= sum over this channel's rows of part (Float32 rows, Float64 sum, fixed order), in two steps: 2048 slots x 16 KiB of rows
+// are 32 MiB per launch, and one thread per bin walking all of them (the first form: 128 workgroups, 128-byte reads) took 116 us of a 1.37 ms stage.
+// Step 1: a workgroup owns 1024 bins x one group of rows (16-byte reads, 4 KiB per wave and row), tmp[ch][g][k]; step 2 adds the groups in order.
+constexpr int W64_RED_GROUPS = 64;
+// (rows a wave never wrote -- it flushes ceil(units / 128) rows, mdsp_welch_w64_asm .Lflush -- are skipped: the row buffer needs no zeroing)
+__global__ __launch_bounds__(256) void w64asm_reduce1_kernel(const float* __restrict__ part, double* __restrict__ tmp, int nslots, int nflush, int64_t nch, int rows_per_group,
+                                                             int64_t units, int64_t run_len) {
+    const int k4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int g = blockIdx.y;
+    const int64_t ch = blockIdx.z;
+    const int rows = nslots * nflush;
+    const int r0 = g * rows_per_group, r1 = min(rows, r0 + rows_per_group);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+        const int sl = r / nflush, f = r - sl * nflush;
+        const int64_t mine = min(run_len, units - (int64_t)sl * run_len);   // units of slot sl (<= 0: none)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int64_t)f * 128 < mine) v = *reinterpret_cast<const float4*>(part + (((int64_t)sl * nch + ch) * nflush + f) * N + k4);
+        a0 += (double)v.x;
+        a1 += (double)v.y;
+        a2 += (double)v.z;
+        a3 += (double)v.w;
+    }
+    double* o = tmp + ((int64_t)ch * W64_RED_GROUPS + g) * N + k4;
+    o[0] = a0;
+    o[1] = a1;
+    o[2] = a2;
+    o[3] = a3;
 }
-
-// reduced[ch][k] (+)= sum over this channel's rows of part (Float32 rows, Float64 sum, fixed order)
-__global__ __launch_bounds__(256) void w64asm_reduce_kernel(const float* __restrict__ part, double* __restrict__ reduced, int nslots, int nflush, int64_t nch, int accumulate) {
-    __shared__ double sm[8][33];
-    const int bx = threadIdx.x & 31, sy = threadIdx.x >> 5;
-    const int k = blockIdx.x * 32 + bx;
+__global__ __launch_bounds__(256) void w64asm_reduce2_kernel(const double* __restrict__ tmp, double* __restrict__ reduced, int ngroups, int accumulate) {
+    __shared__ double sm[4][64];
+    const int b = threadIdx.x & 63, gl = threadIdx.x >> 6;   // 64 bins x 4 lanes of groups per workgroup; the four lanes are added in order
+    const int k = blockIdx.x * 64 + b;
     const int64_t ch = blockIdx.y;
-    double a = 0;
-    for (int s = sy; s < nslots; s += 8)
-        for (int f = 0; f < nflush; ++f) a += (double)part[(((int64_t)s * nch + ch) * nflush + f) * N + k];
-    sm[sy][bx] = a;
+    double t = 0;
+    for (int g = gl; g < ngroups; g += 4) t += tmp[((int64_t)ch * W64_RED_GROUPS + g) * N + k];
+    sm[gl][b] = t;
     __syncthreads();
-    if (sy == 0) {
-        double t = sm[0][bx];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) t += sm[i][bx];
+    if (gl == 0) {
+        t = ((sm[0][b] + sm[1][b]) + sm[2][b]) + sm[3][b];
         reduced[ch * N + k] = accumulate ? reduced[ch * N + k] + t : t;
     }
 }
@@ -474,10 +496,8 @@ template <int DUMMY = 0> int welch_run_w64asm(mdsp_welch_plan_s* pl, SpecArgs& a
         const int64_t run_len = cdiv(units, nslots);
         const int nflush = (int)cdiv(run_len, 128);
         const size_t part_bytes = sizeof(float) * (size_t)nslots * (size_t)a.nch * (size_t)nflush * N;
-        MDSP_TRY(pl->partial.reserve(part_bytes));
-        hipLaunchKernelGGL(w64asm_zero_kernel, dim3((unsigned)std::min<size_t>(4096, cdiv((int64_t)(part_bytes / 16), 256))), dim3(256), 0, st,
-                           reinterpret_cast<float4*>(pl->partial.p), part_bytes / 16);
-        MDSP_LAUNCH_CHECK();
+        const size_t tmp_bytes = sizeof(double) * (size_t)a.nch * W64_RED_GROUPS * N;   // the reduction's intermediate sums, behind the rows
+        MDSP_TRY(pl->partial.reserve(part_bytes + tmp_bytes));
         W64AsmArgs ka;
         ka.s = static_cast<const float*>(a.s);
         ka.part = pl->partial.as<float>();
@@ -492,9 +512,16 @@ template <int DUMMY = 0> int welch_run_w64asm(mdsp_welch_plan_s* pl, SpecArgs& a
         size_t ksz = sizeof(ka);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
         MDSP_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, (unsigned)a.nch, 1, 512, 1, 1, 0, st, nullptr, cfg));
-        hipLaunchKernelGGL(w64asm_reduce_kernel, dim3(N / 32, (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<float>(), pl->reduced.as<double>(), (int)nslots,
-                           nflush, a.nch, fresh ? 0 : 1);
-        MDSP_LAUNCH_CHECK();
+        {
+            const int rows = (int)nslots * nflush;
+            const int rpg = (int)cdiv(rows, W64_RED_GROUPS), ngroups = (int)cdiv(rows, rpg);
+            double* tmp = reinterpret_cast<double*>(static_cast<char*>(pl->partial.p) + part_bytes);
+            hipLaunchKernelGGL(w64asm_reduce1_kernel, dim3(N / 1024, (unsigned)ngroups, (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<float>(), tmp, (int)nslots, nflush,
+                               a.nch, rpg, units, run_len);
+            MDSP_LAUNCH_CHECK();
+            hipLaunchKernelGGL(w64asm_reduce2_kernel, dim3(N / 64, (unsigned)a.nch), dim3(256), 0, st, tmp, pl->reduced.as<double>(), ngroups, fresh ? 0 : 1);
+            MDSP_LAUNCH_CHECK();
+        }
         fresh = false;
     }
     if (a.K & 1) {   // the channel's odd last frame: one unit of welch_half3_kernel on the last n samples, added to the same sums

@@ -17,7 +17,7 @@ Kernel contract (welch_run_w64asm in csrc/welch_w64.h fills the arguments):
     grid (G, nch), 512 threads = 8 independent waves; wave w of workgroup b is slot 8 b + w and owns units [slot run_len, (slot+1) run_len) of
     its channel (a unit = two frames = 4096 new samples; every unit handed to this kernel has BOTH frames -- the odd last frame of a channel
     goes through welch_half3_kernel); every 128 units (and at the end) the 64 Float32 sums per lane are stored as one row of
-    part[((slot nch + ch) nflush + f) 4096 + bin] -- rows that are never written stay at the zeros the launcher put there.
+    part[((slot nch + ch) nflush + f) 4096 + bin] -- a wave with U units writes exactly ceil(U / 128) rows; the reduction skips the others.
     LDS: window pairs (w[p], w[p + 2048]) 16 KiB + 8 x 16.5 KiB exchange buffers.
 """
 import math
