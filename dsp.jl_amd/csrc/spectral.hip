@@ -114,6 +114,37 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
     }
 }
 
+// With hundreds of slices (a persistent grid writes one row per workgroup: 1024 rows of nfft doubles are 24-32 MiB) the single kernel above is
+// ~100 workgroups walking 128 rows each with 256-byte reads -- 60-120 us behind a 0.3-1.4 ms kernel.  Two steps instead: groups of rows summed by
+// (bins / 256) x groups workgroups with 2 KiB reads per wave, then the kernel above over the groups.  Fixed order either way.
+constexpr int REDUCE_GROUPS = 64;
+__global__ __launch_bounds__(256) void reduce_partials_groups_kernel(const double* __restrict__ partial, double* __restrict__ tmp, int nslices, int64_t nch, int nacc,
+                                                                     int per_group) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    const int64_t ch = blockIdx.z;
+    if (k >= nacc) return;
+    const int s0 = g * per_group, s1 = min(nslices, s0 + per_group);
+    double a = 0;
+#pragma unroll 4
+    for (int s = s0; s < s1; ++s) a += partial[((int64_t)s * nch + ch) * nacc + k];
+    tmp[((int64_t)g * nch + ch) * nacc + k] = a;
+}
+inline int reduce_partials(mdsp_welch_plan_s* pl, const double* partial, double* reduced, int nslices, int64_t nch, int nacc, int accumulate, hipStream_t st) {
+    if (nslices > 2 * REDUCE_GROUPS) {
+        const int per_group = (int)cdiv(nslices, REDUCE_GROUPS), ng = (int)cdiv(nslices, per_group);
+        MDSP_TRY(pl->redtmp.reserve(sizeof(double) * (size_t)ng * (size_t)nch * (size_t)nacc));
+        hipLaunchKernelGGL(reduce_partials_groups_kernel, dim3((unsigned)cdiv(nacc, 256), (unsigned)ng, (unsigned)nch), dim3(256), 0, st, partial, pl->redtmp.as<double>(),
+                           nslices, nch, nacc, per_group);
+        MDSP_LAUNCH_CHECK();
+        partial = pl->redtmp.as<double>();
+        nslices = ng;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(nacc, 32), (unsigned)nch), dim3(256), 0, st, partial, reduced, nslices, nch, nacc, accumulate);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
 // Welch finalize: psd[ch][j] = T( m_j * fold(sum over slices) )
 //   MODE 0: one-sided from half spectrum  (acc has nspec = nfft/2+1 bins)       m = 1/r (DC, Nyquist if even) else 2/r
 //   MODE 1: two-sided from full spectrum  (acc has nfft bins)                   m = 1/r
@@ -1588,9 +1619,7 @@ finalize:
     if (rc != MDSP_OK) return rc;
     // fold the slots' partial rows into the plan's Float64 accumulator (added to what earlier slices of the stream left there)
     MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)a.nch * N));
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<double>(),
-                       pl->reduced.as<double>(), nslices, a.nch, N, pl->acc_fresh ? 0 : 1);
-    MDSP_LAUNCH_CHECK();
+    MDSP_TRY(reduce_partials(pl, pl->partial.as<double>(), pl->reduced.as<double>(), nslices, a.nch, N, pl->acc_fresh ? 0 : 1, st));
 reduced_done:
     if (rc != MDSP_OK) return rc;
     pl->acc_fresh = false;
@@ -1637,9 +1666,7 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
         MDSP_TRY((gen_launch<R, CPLX, 0>(g, nch, st, &nslots, &pl->partial)));
         const int N = (int)pl->nfft;
         MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)nch * (size_t)N));
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(N, 32), (unsigned)nch), dim3(256), 0, st, pl->partial.as<double>(),
-                           pl->reduced.as<double>(), (int)nslots, nch, N, pl->acc_fresh ? 0 : 1);
-        MDSP_LAUNCH_CHECK();
+        MDSP_TRY(reduce_partials(pl, pl->partial.as<double>(), pl->reduced.as<double>(), (int)nslots, nch, N, pl->acc_fresh ? 0 : 1, st));
         pl->acc_fresh = false;
         pl->acc_nslices = 1;
         pl->acc_nacc = N;

@@ -23,6 +23,7 @@ struct mdsp_welch_plan_s {
     // after mdsp_welch_allreduce the frame count summed over ranks lives on the DEVICE (kdev, one double, reduced together with the sums: no host
     // round trip, no stream synchronisation); mdsp_welch_finalize(plan, 0, ...) reads it there.  acc_frames stays this rank's own count.
     mdsp::DevBuf kdev;
+    mdsp::DevBuf redtmp;         // group sums of the two-step slice reduction (reduce_partials, spectral.hip)
     mdsp::DevBuf w64prep;        // mdsp_welch_w64_asm: Float32 window pairs + per-lane twiddles (built at the plan's first launch of that kernel)
     bool frames_on_device = false;
     int acc_nslices = 1, acc_nacc = 0, acc_mode = 0;   // welch_finalize_kernel MODE

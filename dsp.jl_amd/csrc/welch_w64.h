@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void w64asm_prepare_kernel(const double* __res
 // reduced[ch][k] (+)= sum over this channel's rows of part (Float32 rows, Float64 sum, fixed order), in two steps: 2048 slots x 16 KiB of rows
 // are 32 MiB per launch, and one thread per bin walking all of them (the first form: 128 workgroups, 128-byte reads) took 116 us of a 1.37 ms stage.
 // Step 1: a workgroup owns 1024 bins x one group of rows (16-byte reads, 4 KiB per wave and row), tmp[ch][g][k]; step 2 adds the groups in order.
-constexpr int W64_RED_GROUPS = 64;
+constexpr int W64_RED_GROUPS = 128;
 // (rows a wave never wrote -- it flushes ceil(units / 128) rows, mdsp_welch_w64_asm .Lflush -- are skipped: the row buffer needs no zeroing)
 __global__ __launch_bounds__(256) void w64asm_reduce1_kernel(const float* __restrict__ part, double* __restrict__ tmp, int nslots, int nflush, int64_t nch, int rows_per_group,
                                                              int64_t units, int64_t run_len) {
@@ -441,16 +441,18 @@ __global__ __launch_bounds__(256) void w64asm_reduce1_kernel(const float* __rest
     o[3] = a3;
 }
 __global__ __launch_bounds__(256) void w64asm_reduce2_kernel(const double* __restrict__ tmp, double* __restrict__ reduced, int ngroups, int accumulate) {
-    __shared__ double sm[4][64];
-    const int b = threadIdx.x & 63, gl = threadIdx.x >> 6;   // 64 bins x 4 lanes of groups per workgroup; the four lanes are added in order
-    const int k = blockIdx.x * 64 + b;
+    __shared__ double sm[8][32];
+    const int b = threadIdx.x & 31, gl = threadIdx.x >> 5;   // 32 bins x 8 lanes of groups per workgroup; the eight lanes are added in order
+    const int k = blockIdx.x * 32 + b;
     const int64_t ch = blockIdx.y;
     double t = 0;
-    for (int g = gl; g < ngroups; g += 4) t += tmp[((int64_t)ch * W64_RED_GROUPS + g) * N + k];
+    for (int g = gl; g < ngroups; g += 8) t += tmp[((int64_t)ch * W64_RED_GROUPS + g) * N + k];
     sm[gl][b] = t;
     __syncthreads();
     if (gl == 0) {
-        t = ((sm[0][b] + sm[1][b]) + sm[2][b]) + sm[3][b];
+        t = sm[0][b];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += sm[i][b];
         reduced[ch * N + k] = accumulate ? reduced[ch * N + k] + t : t;
     }
 }
@@ -519,7 +521,7 @@ template <int DUMMY = 0> int welch_run_w64asm(mdsp_welch_plan_s* pl, SpecArgs& a
             hipLaunchKernelGGL(w64asm_reduce1_kernel, dim3(N / 1024, (unsigned)ngroups, (unsigned)a.nch), dim3(256), 0, st, pl->partial.as<float>(), tmp, (int)nslots, nflush,
                                a.nch, rpg, units, run_len);
             MDSP_LAUNCH_CHECK();
-            hipLaunchKernelGGL(w64asm_reduce2_kernel, dim3(N / 64, (unsigned)a.nch), dim3(256), 0, st, tmp, pl->reduced.as<double>(), ngroups, fresh ? 0 : 1);
+            hipLaunchKernelGGL(w64asm_reduce2_kernel, dim3(N / 32, (unsigned)a.nch), dim3(256), 0, st, tmp, pl->reduced.as<double>(), ngroups, fresh ? 0 : 1);
             MDSP_LAUNCH_CHECK();
         }
         fresh = false;
