@@ -640,28 +640,30 @@ template <typename C, int PADSHIFT, int NEXT = 1, int PERMUTE = false, typename 
 // results into the other (Stockham autosort, natural order in, natural order out), radices 16 / 8 / 4 / 2 / 3 / 5 / 7 chosen per pass at run
 // time, any thread count.  Slower per point than the register form, but fused all the same: the frame is windowed into LDS straight
 // from the signal and the spectrum is consumed from LDS, so HBM sees the signal once and the output once.
+// (round 4: the constants ride as SGPR-pair operands of the packed instructions -- cscale_k / caxpy_k / caxmy_k -- instead of VGPR pairs that hipcc
+// re-materialised with a v_mov_b64 in front of every butterfly once the kernel was near its register cap; the -i products are folded into the last add / subtract)
 template <typename R> MDSP_HD void bfly3f(cx<R>& a0, cx<R>& a1, cx<R>& a2) {   // forward: w = exp(-2 pi i / 3)
     constexpr R s = (R)0.86602540378443864676372317075294L;
     const cx<R> t1 = cadd(a1, a2), d = csub(a1, a2);
-    const cx<R> t2 = {a0.x - (R)0.5 * t1.x, a0.y - (R)0.5 * t1.y};
-    const cx<R> t3 = mul_mi<-1>(cscale(s, d));   // -i (sqrt(3)/2) (a1 - a2)
+    const cx<R> t2 = caxmy_k((R)0.5, t1, a0);   // a0 - t1 / 2
+    const cx<R> t3 = cscale_k(s, d);            // (sqrt(3)/2) (a1 - a2), times -i below
     a0 = cadd(a0, t1);
-    a1 = cadd(t2, t3);
-    a2 = csub(t2, t3);
+    a1 = add_mi<-1>(t2, t3);
+    a2 = sub_mi<-1>(t2, t3);
 }
 template <typename R> MDSP_HD void bfly5f(cx<R> (&v)[5]) {
     constexpr R c1 = (R)0.30901699437494742410229341718282L, c2 = (R)-0.80901699437494742410229341718282L;
     constexpr R s1 = (R)0.95105651629515357211643933337938L, s2 = (R)0.58778525229247312916870595463907L;
     const cx<R> t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-    const cx<R> m1 = {v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y};
-    const cx<R> m2 = {v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y};
-    const cx<R> n1 = mul_mi<-1>(cx<R>{s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y});   // -i n1
-    const cx<R> n2 = mul_mi<-1>(cx<R>{s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y});
+    const cx<R> m1 = caxpy_k(c2, t2, caxpy_k(c1, t1, v[0]));
+    const cx<R> m2 = caxpy_k(c1, t2, caxpy_k(c2, t1, v[0]));
+    const cx<R> n1 = caxpy_k(s2, t4, cscale_k(s1, t3));   // times -i below
+    const cx<R> n2 = caxmy_k(s1, t4, cscale_k(s2, t3));
     v[0] = cadd(v[0], cadd(t1, t2));
-    v[1] = cadd(m1, n1);
-    v[4] = csub(m1, n1);
-    v[2] = cadd(m2, n2);
-    v[3] = csub(m2, n2);
+    v[1] = add_mi<-1>(m1, n1);
+    v[4] = sub_mi<-1>(m1, n1);
+    v[2] = add_mi<-1>(m2, n2);
+    v[3] = sub_mi<-1>(m2, n2);
 }
 template <typename R> MDSP_HD void bfly7f(cx<R> (&v)[7]) {
     constexpr R c1 = (R)0.62348980185873353052500488400424L, c2 = (R)-0.22252093395631440428890256449679L, c3 = (R)-0.90096886790241912623610231950745L;

@@ -555,7 +555,7 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
 // (measured per mode, tools/bench_wide.py, profiles/r04_wide_schedules.json; 1000, 1600 and 8000 were tried and lost in every mode).
 #define MDSP_GEN_CT_WIDE_SIZES(X)                                                                                               \
     X(1200, 64, 48, 5, 12, 20) X(1500, 64, 304, 5, 12, 25) X(1920, 128, 48, 15, 8, 16) X(2000, 128, 304, 5, 16, 25)                 \
-    X(2400, 128, 48, 5, 20, 24) X(2500, 128, 48, 25, 10, 10) X(3000, 128, 48, 5, 24, 25) X(3200, 128, 112, 25, 8, 16)               \
+    X(2400, 128, 48, 5, 20, 24) X(2500, 128, 304, 25, 10, 10) X(3000, 128, 48, 5, 24, 25) X(3200, 128, 368, 25, 8, 16)               \
     X(3840, 256, 48, 15, 16, 16) X(4800, 320, 48, 15, 16, 20) X(5000, 256, 48, 25, 10, 20) X(6000, 256, 304, 25, 24, 10)            \
     X(6400, 256, 368, 25, 16, 16)
 constexpr bool gen_ct_wide_mode(int flags, int mode, bool cplx) { return !(flags & (mode == 0 ? 64 : cplx ? 128 : 256)); }

@@ -74,4 +74,6 @@ for nfft in [int(v) for v in os.environ.get("WIDE_SIZES", "3000").split(",")]:
     del cfg, pc, pr, oc, orr
 _lib.set_tunable("MDSP_GEN_WIDE", None)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "wide.json")), "w"), indent=1)
+outp = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "wide.json"))
+os.makedirs(os.path.dirname(outp), exist_ok=True)
+json.dump(res, open(outp, "w"), indent=1)
