@@ -161,9 +161,12 @@ int mdsp_welch_mean_allreduce(mdsp_welch_plan plan, const void* psd_dev, int64_t
     const int T = dtype_real_of(plan->dtype);
     const int64_t nout = plan->nout;
     hipStream_t st = as_stream(stream);
+    const bool collective = comm && comm->nranks > 1;
+    if (!collective && nch_local > 0)   // one rank: sum and 1 / nch in ONE launch (the same roundings as sum-then-scale)
+        return channel_sum_scaled(psd_dev, nout, nch_local, ldp, T, mean_dev, 1.0 / (double)nch_total, stream);
     if (nch_local == 0) MDSP_HIP(hipMemsetAsync(mean_dev, 0, dtype_size(T) * (size_t)nout, st));   // a rank without channels contributes zeros
     else MDSP_TRY(mdsp_channel_sum(psd_dev, nout, nch_local, ldp, T, mean_dev, stream));
-    if (comm && comm->nranks > 1) MDSP_TRY(mdsp_allreduce_sum(comm, mean_dev, nout, T, stream));
+    if (collective) MDSP_TRY(mdsp_allreduce_sum(comm, mean_dev, nout, T, stream));
     const dim3 g((unsigned)cdiv(nout, 256));
     if (T == MDSP_F32) hipLaunchKernelGGL(scale_kernel<float>, g, dim3(256), 0, st, (float*)mean_dev, nout, 1.0 / (double)nch_total);
     else hipLaunchKernelGGL(scale_kernel<double>, g, dim3(256), 0, st, (double*)mean_dev, nout, 1.0 / (double)nch_total);

@@ -169,4 +169,6 @@ int plan_cache_get(const std::string& key, void** out, const std::function<int(v
 #define MDSP_ABLATED(a, bit) false
 #endif
 
+// spectral.hip: out[j] = (R)(sum over channels of psd[c][j]) (* scale, rounded once more) -- the local part of the cross-channel Welch mean (comm.hip)
+int channel_sum_scaled(const void* psd_dev, int64_t nout, int64_t nch, int64_t ldp, int real_dtype, void* sum_dev, double scale, void* stream);
 }  // namespace mdsp

@@ -1820,25 +1820,33 @@ int mdsp_welch_exec(mdsp_welch_plan plan, const void* s_dev, int64_t len, int64_
 
 }  // extern "C"
 
-// channel sum (local part of the cross-channel Welch mean)
-template <typename R> __global__ __launch_bounds__(256) void channel_sum_kernel(const R* __restrict__ psd, R* __restrict__ out, int64_t nout, int64_t nch, int64_t ldp) {
+// channel sum (local part of the cross-channel Welch mean); `scale` != 1: the mean in the same launch, rounded exactly as sum-then-scale would be
+template <typename R>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const R* __restrict__ psd, R* __restrict__ out, int64_t nout, int64_t nch, int64_t ldp, double scale) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nout) return;
     double a = 0;
     for (int64_t c = 0; c < nch; ++c) a += (double)psd[c * ldp + j];
-    out[j] = (R)a;
+    const R sum = (R)a;
+    out[j] = scale == 1.0 ? sum : (R)((double)sum * scale);
 }
 
-extern "C" int mdsp_channel_sum(const void* psd_dev, int64_t nout, int64_t nch, int64_t ldp, int real_dtype, void* sum_dev, void* stream) {
+namespace mdsp {
+int channel_sum_scaled(const void* psd_dev, int64_t nout, int64_t nch, int64_t ldp, int real_dtype, void* sum_dev, double scale, void* stream) {
     if (real_dtype != MDSP_F32 && real_dtype != MDSP_F64) MDSP_FAIL(MDSP_ERR_ARGUMENT, "real dtype expected");
     if (nout <= 0) return MDSP_OK;
     const dim3 g((unsigned)cdiv(nout, 256));
     if (real_dtype == MDSP_F32)
-        hipLaunchKernelGGL(channel_sum_kernel<float>, g, dim3(256), 0, as_stream(stream), (const float*)psd_dev, (float*)sum_dev, nout, nch, ldp);
+        hipLaunchKernelGGL(channel_sum_kernel<float>, g, dim3(256), 0, as_stream(stream), (const float*)psd_dev, (float*)sum_dev, nout, nch, ldp, scale);
     else
-        hipLaunchKernelGGL(channel_sum_kernel<double>, g, dim3(256), 0, as_stream(stream), (const double*)psd_dev, (double*)sum_dev, nout, nch, ldp);
+        hipLaunchKernelGGL(channel_sum_kernel<double>, g, dim3(256), 0, as_stream(stream), (const double*)psd_dev, (double*)sum_dev, nout, nch, ldp, scale);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
+}
+}  // namespace mdsp
+
+extern "C" int mdsp_channel_sum(const void* psd_dev, int64_t nout, int64_t nch, int64_t ldp, int real_dtype, void* sum_dev, void* stream) {
+    return mdsp::channel_sum_scaled(psd_dev, nout, nch, ldp, real_dtype, sum_dev, 1.0, stream);
 }
 
 // ======================================================================================================
