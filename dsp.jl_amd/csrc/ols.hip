@@ -980,7 +980,9 @@ int launch_upols_k(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t
     // resident workgroups per CU from the kernel's own resources (hipOccupancyMaxActiveBlocksPerMultiprocessor has answered half of what the
     // hardware admits for LDS-heavy kernels)
     // Queried once per instantiation and device (hipFuncGetAttributes on every launch was host latency on every chunk of the host
-    // pipeline); the register file and LDS sizes come from the device properties, the 8-register allocation granule is gfx950's.
+    // pipeline).  The register file (512 per SIMD lane, 8-register granule) and the LDS (160 KiB per CU) are gfx950's, as constants: the runtime's
+    // device properties describe a workgroup's limits (65536 registers, 64 KiB), not the CU, and sizing the grid from them halved the occupancy of
+    // the 256-VGPR partitioned kernels (5120 taps 1.06 -> 1.32 ms until found, round 4).
     static std::atomic<int> per_cu_cache[64];
     int dev = 0;
     MDSP_HIP(hipGetDevice(&dev));
@@ -988,14 +990,10 @@ int launch_upols_k(const mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t
     if (per_cu == 0) {
         hipFuncAttributes fa;
         MDSP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
-        hipDeviceProp_t prop;
-        MDSP_HIP(hipGetDeviceProperties(&prop, dev));
-        const int regs_per_simd_lane = std::max(64, prop.regsPerBlock / 256);                     // 131072 / 256 = 512 on MI355X
-        const size_t lds_per_cu = std::max<size_t>(64 * 1024, prop.maxSharedMemoryPerMultiProcessor);   // 160 KiB
         const int waves = threads / 64, vg = std::max(1, fa.numRegs);
-        const int by_regs = std::max(1, (regs_per_simd_lane / ((vg + 7) & ~7)) * 4 / waves);
-        const int by_lds = (int)std::max<size_t>(1, lds_per_cu / std::max<size_t>(1, fa.sharedSizeBytes));
-        per_cu = std::max(1, std::min({by_regs, by_lds, prop.maxThreadsPerMultiProcessor / threads}));
+        const int by_regs = std::max(1, (512 / ((vg + 7) & ~7)) * 4 / waves);
+        const int by_lds = (int)std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(1, fa.sharedSizeBytes));
+        per_cu = std::max(1, std::min({by_regs, by_lds, 2048 / threads}));
         per_cu_cache[dev & 63].store(per_cu, std::memory_order_release);
     }
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
