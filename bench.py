@@ -266,8 +266,15 @@ def spread(tm):
 
 
 def git_head():
+    """HEAD of the checkout; on the GPU box (a snapshot without .git) the hash the builder wrote into .build_commit before sending it."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        if h:
+            return h
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, ".build_commit")).read().strip()[:12] or None
     except Exception:
         return None
 

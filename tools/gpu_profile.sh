@@ -31,3 +31,39 @@ python tools/prof_summary.py --rows "$(find "$OUT/prof_sq" -name '*.db' | head -
 head -30 "$OUT/kernel_stats.txt"; cat "$OUT/pmc_brief.txt"
 # the rocpd databases stay on the box (gpurun copies back at most 64 MiB): the summaries above are what profiles/ keeps
 rm -rf "$OUT"/prof_stats "$OUT"/prof_FETCH_SIZE "$OUT"/prof_WRITE_SIZE "$OUT"/prof_sq
+# the un-profiled lines of the same snapshot: the driver's command, and the two 8-GPU configs at their single-GPU shares
+python bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
+python bench.py --config stft > "$OUT/bench_config4.json" 2> /dev/null
+python bench.py --config resample > "$OUT/bench_config5.json" 2> /dev/null
+# RULE: this script is the LAST GPU session of a round -- `git rev-parse HEAD > .build_commit` before sending the snapshot, no kernel
+# commit after it.  Every summary carries that hash.
+python - <<'PY'
+import json, os
+out = os.path.join(os.getcwd(), "gpurun_out")
+try:
+    commit = open(".build_commit").read().strip()
+except Exception:
+    commit = "unknown (no .build_commit in the snapshot)"
+for f in ("pmc_sq.json", "pmc_traffic.json", "pmc_sq_rows.json"):
+    p = os.path.join(out, f)
+    try:
+        d = json.load(open(p))
+        if isinstance(d, dict):
+            d["commit"] = commit
+            json.dump(d, open(p, "w"), indent=1)
+    except Exception as e:
+        print("no", f, e)
+for f in ("kernel_stats.txt", "pmc_brief.txt"):
+    p = os.path.join(out, f)
+    try:
+        t = open(p).read()
+        open(p, "w").write(f"# commit {commit}; tools/gpu_profile.sh\n" + t)
+    except Exception as e:
+        print("no", f, e)
+for f in ("bench_line.json", "bench_config4.json", "bench_config5.json"):
+    try:
+        d = json.loads(open(os.path.join(out, f)).read().strip().splitlines()[-1])
+        print(f, d["value"], d["unit"], d.get("ms_per_step"), d.get("commit"))
+    except Exception as e:
+        print("no", f, e)
+PY

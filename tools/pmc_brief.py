@@ -7,6 +7,8 @@ import sys
 d = json.load(open(sys.argv[1]))
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 for k, v in d.items():
+    if not isinstance(v, dict) or "counters" not in v:   # e.g. the "commit" entry tools/gpu_profile.sh adds
+        continue
     c = v["counters"]
     if flt not in k or "SQ_BUSY_CYCLES" not in c or v["avg_ns"] < 20000:
         continue
