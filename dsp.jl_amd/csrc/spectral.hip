@@ -1552,9 +1552,9 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
                 else if (pl->variant == 33) rc = welch_run_half3<N, 5, 1, true>(pl, a, st, &nslices);   // ... two units in flight (two register sets)
                 else if (pl->variant == 34) rc = welch_run_half3<N, 4, 1, true>(pl, a, st, &nslices);
-                else if (pl->variant == 42) {   // ... the same, hand-allocated (csrc/welch_w64_asm.s): reduces into pl->reduced itself
+                else if (pl->variant == 42 || pl->variant == 43) {   // ... the same, hand-allocated (csrc/welch_w64_asm.s; 43: welch_w64c_asm.s, shared half-frame carried): reduces into pl->reduced itself
                     bool handled = false;
-                    rc = w64::welch_run_w64asm(pl, a, st, &handled);
+                    rc = w64::welch_run_w64asm(pl, a, st, &handled, pl->variant == 43);
                     if (rc == MDSP_OK && handled) goto reduced_done;
                 }
                 else if (pl->variant == 41) rc = w64::welch_run_w64b(pl, a, st, &nslices);  // ... two waves per SIMD: two-level twiddles, direct loads

@@ -380,7 +380,8 @@ inline int welch_run_w64(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int
 //   * a prepared per-plan block: window pairs (w[p], w[p + N/2]) as Float32 (16 KiB) + the per-lane twiddles W^{8 lane j}, W^{lane j}, j = 1..7;
 //   * Float32 partial rows part[((slot nch + ch) nflush + f) N + bin], zeroed here (a slot without units, or with fewer flushes, leaves zeros);
 //   * the units it runs all have both frames; the odd last frame of a channel goes through welch_half3_kernel and is added to the same sums.
-#include "welch_w64_asm_co.h"   // static const unsigned char welch_w64_asm_co[]; generated by build.py from welch_w64_asm.s
+#include "welch_w64_asm_co.h"    // static const unsigned char welch_w64_asm_co[]; generated by build.py from welch_w64_asm.s
+#include "welch_w64c_asm_co.h"   // ... welch_w64c_asm_co[]: the same kernel with the shared half-frame carried (tools/gen_welch_asm_c.py)
 
 struct W64AsmArgs {
     const float* s;
@@ -461,26 +462,28 @@ struct W64AsmModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
 };
-inline int w64asm_function(hipFunction_t* fn) {
+// carry: mdsp_welch_w64c_asm (the shared half-frame of consecutive units stays in registers: 64 loads per unit, 1.0 x the algorithmic bytes) instead
+// of mdsp_welch_w64_asm (96 loads, 1.32 x)
+inline int w64asm_function(hipFunction_t* fn, bool carry) {
     static std::mutex mu;
-    static W64AsmModule mods[64];
+    static W64AsmModule mods[2][64];
     int dev = 0;
     MDSP_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    W64AsmModule& m = mods[dev & 63];
+    W64AsmModule& m = mods[carry ? 1 : 0][dev & 63];
     if (!m.fn) {
-        MDSP_HIP(hipModuleLoadData(&m.mod, welch_w64_asm_co));
-        MDSP_HIP(hipModuleGetFunction(&m.fn, m.mod, "mdsp_welch_w64_asm"));
+        MDSP_HIP(hipModuleLoadData(&m.mod, carry ? welch_w64c_asm_co : welch_w64_asm_co));
+        MDSP_HIP(hipModuleGetFunction(&m.fn, m.mod, carry ? "mdsp_welch_w64c_asm" : "mdsp_welch_w64_asm"));
     }
     *fn = m.fn;
     return MDSP_OK;
 }
 
 // returns MDSP_OK with *handled = true when the sums have been added to pl->reduced (the caller skips its own slice reduction)
-template <int DUMMY = 0> int welch_run_w64asm(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, bool* handled) {
+template <int DUMMY = 0> int welch_run_w64asm(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, bool* handled, bool carry = true) {
     *handled = false;
     hipFunction_t fn = nullptr;
-    MDSP_TRY(w64asm_function(&fn));
+    MDSP_TRY(w64asm_function(&fn, carry));
     // the prepared block (per plan: the window and the root table never change)
     constexpr size_t PREP_FLOATS = 2 * HALF + 28 * 64;
     if (pl->w64prep.bytes == 0) {

@@ -876,7 +876,7 @@ def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, nt
     assert outs["regtap"][1] != 2                                  # MDSP_FIR_MM=0 never takes the matrix-core kernel
 
 
-@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36, 40, 41, 42])
+@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36, 40, 41, 42, 43])
 def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
     """welch_half3_kernel (paired samples, role-swapping units, window folded into the first butterfly stage, frame b's first half loaded a
     second time under the unit's have-frame-b predicate): every frame count parity, the odd last frame, one to three frames, several
