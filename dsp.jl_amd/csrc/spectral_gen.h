@@ -559,6 +559,8 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     X(3840, 256, 48, 15, 16, 16) X(4800, 320, 48, 15, 16, 20) X(5000, 256, 48, 25, 10, 20) X(6000, 256, 304, 25, 24, 10)            \
     X(6400, 256, 368, 25, 16, 16)
 constexpr bool gen_ct_wide_mode(int flags, int mode, bool cplx) { return !(flags & (mode == 0 ? 64 : cplx ? 128 : 256)); }
+// (The single LDS buffer was also tried on the small-radix list above -- flag 16 on all of it, tools/sessions/r04_s28: Welch -1 ... -5 %, ComplexF32 STFT
+// -1 ... -4 %: those kernels are register-, not LDS-limited in residency, and the extra barrier per pass costs.)
 constexpr int GEN_CT_F64_MAX = 3000;   // Float64 / ComplexF64: two buffers of N x 16 bytes and twice the registers
 inline bool gen_ct_size(int dtype, int64_t nfft) {
     if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > GEN_CT_F64_MAX)) return false;
@@ -590,10 +592,10 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
     }
     if constexpr (MDSP_GEN_CT) {
         switch (a.N) {
-#define MDSP_X(N, T, ...)                                                                                          \
+#define MDSP_X(N, T, F, ...)                                                                                       \
     case N:                                                                                                        \
         if constexpr (sizeof(R) == 4 || N <= GEN_CT_F64_MAX) {                                                     \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, __VA_ARGS__>>(a, nch, st, nslots, partial);           \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, F, __VA_ARGS__>>(a, nch, st, nslots, partial);               \
             return true;                                                                                           \
         }                                                                                                          \
         break;
