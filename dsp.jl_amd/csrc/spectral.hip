@@ -684,12 +684,13 @@ int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) 
     int eng = engine;
     if (eng == MDSP_ENGINE_AUTO) eng = tunables().engine;
     // fused: the register-resident power-of-two sizes, and the mixed-radix LDS kernel for the other 7-smooth sizes nextfastfft returns
-    const bool fused_ok = fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft);
+    const bool direct = kind == 0 || dtype_is_complex(dtype);   // the last pass is consumed from registers (spectral_gen.h)
+    const bool fused_ok = fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct);
     // AUTO takes the mixed-radix kernel where it measured faster than the rocFFT pipeline (profiles/r02g_mixed.json, 2^27 samples): Welch and
     // real-signal columns up to 4096 points (1.4-3x), complex columns above (1.6x); elsewhere the two are within 20 % and rocFFT is kept.
     // Round 3: the sizes with a compile-time schedule (spectral_gen.h, Float32 / ComplexF32) beat the rocFFT pipeline 2-9x in every mode
     // (profiles/r03d_mixed_ct.json) and are always taken.
-    const bool gen_wins = fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft) ||
+    const bool gen_wins = fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
                           (gen_size_ok(dtype, nfft) && ((nfft <= 4096) == (kind == 0 || !dtype_is_complex(dtype))));
     if (eng == MDSP_ENGINE_AUTO) eng = gen_wins ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
     if (eng == MDSP_ENGINE_FUSED && !fused_ok)

@@ -561,9 +561,13 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
 constexpr bool gen_ct_wide_mode(int flags, int mode, bool cplx) { return !(flags & (mode == 0 ? 64 : cplx ? 128 : 256)); }
 // (The single LDS buffer was also tried on the small-radix list above -- flag 16 on all of it, tools/sessions/r04_s28: Welch -1 ... -5 %, ComplexF32 STFT
 // -1 ... -4 %: those kernels are register-, not LDS-limited in residency, and the extra barrier per pass costs.)
-constexpr int GEN_CT_F64_MAX = 3000;   // Float64 / ComplexF64: two buffers of N x 16 bytes and twice the registers
-inline bool gen_ct_size(int dtype, int64_t nfft) {
-    if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > GEN_CT_F64_MAX)) return false;
+// Float64 / ComplexF64 (DSP.jl's default element type): up to 3000 points two buffers of N x 16 bytes as in Float32; beyond (round 4), the
+// register-consumed modes (Welch sums, complex columns) run on ONE buffer (CtSched flag 16, ct_passes_inplace): 8000 x 16 bytes = 125 KiB; real-signal
+// columns need the natural-order spectrum in LDS next to the pass's input, i.e. two buffers, which fit up to 5000 points.
+constexpr int GEN_CT_F64_TWO_BUF = 3000, GEN_CT_F64_MAX = 8000, GEN_CT_F64_REAL_COLUMNS_MAX = 5000;
+// direct: Welch sums or complex columns (the last pass is consumed from registers)
+inline bool gen_ct_size(int dtype, int64_t nfft, bool direct) {
+    if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > (direct ? GEN_CT_F64_MAX : GEN_CT_F64_REAL_COLUMNS_MAX))) return false;
     switch (nfft) {
 #define MDSP_X(N, ...) case N:
         MDSP_GEN_CT_SIZES(MDSP_X)
@@ -594,8 +598,14 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
         switch (a.N) {
 #define MDSP_X(N, T, F, ...)                                                                                       \
     case N:                                                                                                        \
-        if constexpr (sizeof(R) == 4 || N <= GEN_CT_F64_MAX) {                                                     \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, F, __VA_ARGS__>>(a, nch, st, nslots, partial);               \
+        if constexpr (sizeof(R) == 4 || N <= GEN_CT_F64_TWO_BUF) {                                                 \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, F, __VA_ARGS__>>(a, nch, st, nslots, partial);        \
+            return true;                                                                                           \
+        } else if constexpr (MODE == 0 || CPLX) {                                                                  \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) | 16, __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            return true;                                                                                           \
+        } else if constexpr (N <= GEN_CT_F64_REAL_COLUMNS_MAX) {                                                   \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, F, __VA_ARGS__>>(a, nch, st, nslots, partial);        \
             return true;                                                                                           \
         }                                                                                                          \
         break;

@@ -1146,7 +1146,7 @@ def test_compile_time_mixed_radix_schedules(d, torch, nfft):
     engine for them (they beat the rocFFT pipeline in every mode, profiles/r03d_mixed_ct.json)."""
     from oracle import periodograms as opg, windows as ow
     rng = np.random.default_rng(nfft)
-    for dt in (np.float32, np.complex64) + ((np.float64, np.complex128) if nfft <= 3000 else ()):      # Float64 schedules stop at 3000 points (LDS)
+    for dt in (np.float32, np.complex64, np.float64, np.complex128):      # Float64 beyond 3000 points: one LDS buffer for Welch / complex columns (round 4); real columns up to 5000, else rocFFT
         cplx = np.dtype(dt).kind == "c"
         TOL = TOL32 if dt in (np.float32, np.complex64) else 1e-12
         for n in (nfft, nfft - 7):
