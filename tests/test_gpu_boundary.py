@@ -911,6 +911,23 @@ def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
         _lib.set_tunable("MDSP_WELCH_VARIANT", None)
 
 
+def test_welch_hand_allocated_kernel_several_channels(d, torch):
+    """mdsp_welch_w64c_asm with more than one channel per launch (grid (G, nch), rows part[((slot nch + ch) nflush + f)], the two-step row reduction
+    per channel): three channels of 2^23 + 4096 + 2048 k samples (even and odd frame counts reach the kernel: it takes over from eight units per CU) --
+    equal to the channels taken one by one (to rounding: the units are partitioned over the waves differently) and to the Float64 oracle."""
+    from oracle import periodograms as opg, windows as ow
+    rng = np.random.default_rng(77)
+    for extra in (0, 2048):
+        L = (1 << 23) + 4096 + extra
+        S = (rng.standard_normal((L, 3)) + 0.25 * np.sin(2 * np.pi * 0.05 * np.arange(L))[:, None]).astype(np.float32)
+        cfg = d.WelchConfig(L, np.float32, n=4096, noverlap=2048, window=d.hanning, engine=d.ENGINE_FUSED)
+        P = d.welch_pgram(S, cfg).power
+        for c in range(3):
+            one = d.welch_pgram(S[:, c].copy(), cfg).power
+            assert relerr(P[:, c], one.astype(np.float64)) < 1e-6, (extra, c)      # another partition of the units over waves: other Float32 run sums
+        assert relerr(P[:, 1], opg.welch_pgram(S[:, 1], 4096, 2048, window=ow.hanning, dtype=np.float64).power) < TOL32
+
+
 @pytest.mark.parametrize("engine", [1, 2], ids=["fused", "rocfft"])
 def test_host_pipeline_stft(d, torch, engine):
     """mdsp_stft_exec_host: stft / spectrogram of host arrays in runs of whole frames on the three-stage pipeline -- the same frames the

@@ -22,6 +22,12 @@ rounds = int(os.environ.get("TUNE_ROUNDS", "5"))
 nch, n = int(os.environ.get("TUNE_NCH", "4")), 1 << log2n
 L, M = (int(v) for v in os.environ.get("TUNE_RATIO", "160/147").split("/"))
 variants = [tuple(int(t) for t in v.split(",")) for v in os.environ.get("TUNE_FIR", "0,0,0;1,0,0;1,2,0;1,1,0").split(";")]
+# MDSP_FIR_MM_VERIFY_CHOICE=1: the library's own choice of form (tile by cost, padded runs, register taps, memory-wave priority) against
+# round 2's rule (largest tile, rows staged one by one, taps fetched per tile beyond the round-2 limits, memory waves at normal priority) on THIS box, for
+# the ratio / type given by TUNE_RATIO / TUNE_DTYPE; exit status 3 and a REGRESSION line if the choice is more than 2 % slower than the rule it replaced.
+VERIFY = os.environ.get("MDSP_FIR_MM_VERIFY_CHOICE", "0") == "1"
+if VERIFY:
+    variants = [(-1, 0, 0), (1, 0, 0, 0, 0, 8, 0, -1, 1, 1, 0, 0, 0, 0)]
 g = torch.Generator(device="cuda"); g.manual_seed(1776)
 DT = os.environ.get("TUNE_DTYPE", "f32")   # f32 | f64 | c32 | c64 (complex signal, real taps)
 tdt, xdt, ydt, esz, lt, lx = {"f32": (torch.float32, np.float32, torch.float32, 4, _lib.F32, _lib.F32), "f64": (torch.float64, np.float64, torch.float64, 8, _lib.F64, _lib.F64),
@@ -96,6 +102,13 @@ for k, e in res["variants"].items():
     e["median_ms"] = float(np.median(e["ms"]))
     e["GBps"] = round(bytes_alg / e["median_ms"] / 1e6, 1)
     print(k, e["median_ms"], "ms", e["GBps"], "GB/s  maxdiff", e["maxdiff_vs_first"], flush=True)
+if VERIFY:
+    (kc, ec), (kr, er) = list(res["variants"].items())
+    ratio = ec["median_ms"] / er["median_ms"]
+    res["verify_choice"] = {"choice_ms": ec["median_ms"], "round2_rule_ms": er["median_ms"], "choice_over_rule": round(ratio, 4), "regression": bool(ratio > 1.02)}
+    print(("REGRESSION" if ratio > 1.02 else "ok") + f": {L}//{M} {DT}: library's choice {ec['median_ms']:.4f} ms, round-2 rule {er['median_ms']:.4f} ms ({ratio:.3f})", flush=True)
 select((-1, 0, 0)); _lib.set_tunable("MDSP_FIR_MM", None); _lib.set_tunable("MDSP_WG_PER_CU", None); _lib.set_tunable("MDSP_FIR_P", None)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "tune_fir.json"), "w"), indent=1)
+if VERIFY and res["verify_choice"]["regression"]:
+    sys.exit(3)
