@@ -23,11 +23,11 @@ nch, n = int(os.environ.get("TUNE_NCH", "4")), 1 << log2n
 L, M = (int(v) for v in os.environ.get("TUNE_RATIO", "160/147").split("/"))
 variants = [tuple(int(t) for t in v.split(",")) for v in os.environ.get("TUNE_FIR", "0,0,0;1,0,0;1,2,0;1,1,0").split(";")]
 # MDSP_FIR_MM_VERIFY_CHOICE=1: the library's own choice of form (tile by cost, padded runs, register taps, memory-wave priority) against
-# round 2's rule (largest tile, rows staged one by one, taps fetched per tile beyond the round-2 limits, memory waves at normal priority) on THIS box, for
+# round 2's rule (largest tile, taps fetched per tile beyond the round-2 register limits, memory waves at normal priority) on THIS box, for
 # the ratio / type given by TUNE_RATIO / TUNE_DTYPE; exit status 3 and a REGRESSION line if the choice is more than 2 % slower than the rule it replaced.
 VERIFY = os.environ.get("MDSP_FIR_MM_VERIFY_CHOICE", "0") == "1"
 if VERIFY:
-    variants = [(-1, 0, 0), (1, 0, 0, 0, 0, 8, 0, -1, 1, 1, 0, 0, 0, 0)]
+    variants = [(-1, 0, 0), (1, 0, 0, 0, 0, 8, 0, -1, -1, 1, 0, 0, 0, 0)]   # round 2: NG = 8 (largest tile), PRIO 0, T64 0, NBLK 0; row staging left to the library
 g = torch.Generator(device="cuda"); g.manual_seed(1776)
 DT = os.environ.get("TUNE_DTYPE", "f32")   # f32 | f64 | c32 | c64 (complex signal, real taps)
 tdt, xdt, ydt, esz, lt, lx = {"f32": (torch.float32, np.float32, torch.float32, 4, _lib.F32, _lib.F32), "f64": (torch.float64, np.float64, torch.float64, 8, _lib.F64, _lib.F64),
