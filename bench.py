@@ -220,14 +220,16 @@ class Timer:
         return v.value
 
     def time(self, fn, reps=9):
-        """Median and best of `reps` timed launches (one untimed first); `self.last` keeps min / max / reps of the same sample for the row."""
+        """Median and best of `reps` timed launches; `self.last` keeps min / max / reps of the same sample for the row.  Every timed launch directly
+        follows an untimed one on the same stream -- steady state, as in the headline's K back-to-back steps: a launch behind an idle gap (the
+        synchronisation between repetitions) pays the clock ramp of the idle part, 5-10 % of a 2 ms kernel."""
         import torch
         fn()
         torch.cuda.synchronize()
         a, b = self.ev(), self.ev()
         ts = []
         for _ in range(reps):
-            self.rec(a); fn(); self.rec(b)
+            fn(); self.rec(a); fn(); self.rec(b)
             torch.cuda.synchronize()
             ts.append(self.ms(a, b))
         ts.sort()
