@@ -1573,8 +1573,9 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                     // less time in sustained runs, nothing measurable in short bursts (profiles/r03a_tune_new.json).  MDSP_WELCH_VARIANT=18 is the
                     // round-2 kernel (identity lanes, pad 5); several runs per slot (MDSP_RUNS_PER_SLOT) work in both.
                     // Round 4: streams long enough to give every wave of the chip a unit take the hand-allocated one-wavefront-per-transform kernel
-                    // (csrc/welch_w64_asm.s, variant 42: 1.13 against 1.18 ms on an all-zero stream, 1.34 against 1.35-1.41 under the power cap;
-                    // profiles/r04_welch_power.json); MDSP_WELCH_VARIANT=30 keeps welch_half3_kernel.
+                    // (csrc/welch_w64c_asm.s = variant 43, the form that carries the shared half-frame: 1.00 against 1.17 ms on an all-zero stream,
+                    // 1.22 against 1.34 under the power cap, HBM traffic 1.01 x algorithmic; profiles/r04_welch_carry_power.json; variant 42 is the
+                    // first form, which re-reads that half-frame); MDSP_WELCH_VARIANT=30 keeps welch_half3_kernel.
                     if (a.K / 2 >= (int64_t)device_cu_count() * 8 && tunables().runs_per_slot == 1) {
                         bool handled = false;
                         rc = w64::welch_run_w64asm(pl, a, st, &handled);

@@ -373,13 +373,17 @@ inline int welch_run_w64(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int
     return MDSP_OK;
 }
 
-// ---- the hand-allocated form (variant 42): csrc/welch_w64_asm.s, generated by tools/gen_welch_asm.py ------------------------------------------------
-// Same transform as welch_w64b_kernel (two waves per SIMD, two-level twiddles, direct loads) with every register assigned by the generator: 244
-// VGPRs, no spill, 1682 instructions per unit.  The code object is assembled by build.py and embedded as a byte array (welch_w64_asm_co.h in the
-// object directory); it is loaded once per device with hipModuleLoadData.  Host side of its contract:
+// ---- the hand-allocated forms: csrc/welch_w64c_asm.s (variant 43, the default: tools/gen_welch_asm_c.py) and csrc/welch_w64_asm.s (variant 42:
+// tools/gen_welch_asm.py) -----------------------------------------------------------------------------------------------------------------------------
+// Same transform as welch_w64b_kernel (two waves per SIMD, two-level twiddles, direct loads) with every register assigned by the generator: all 256
+// VGPRs, no spill, 1770-1790 instructions per unit.  Variant 43 keeps the half-frame two consecutive units share in registers (twiddles in LDS, compact
+// operand banks, a two-unit loop body: 64 loads per unit, HBM traffic 1.01 x algorithmic); variant 42 loads it again (96 loads, 1.32 x).  The code
+// objects are assembled by build.py and embedded as byte arrays (*_co.h in the object directory), loaded once per device with hipModuleLoadData.
+// Host side of their contract:
 //   * a prepared per-plan block: window pairs (w[p], w[p + N/2]) as Float32 (16 KiB) + the per-lane twiddles W^{8 lane j}, W^{lane j}, j = 1..7;
-//   * Float32 partial rows part[((slot nch + ch) nflush + f) N + bin], zeroed here (a slot without units, or with fewer flushes, leaves zeros);
-//   * the units it runs all have both frames; the odd last frame of a channel goes through welch_half3_kernel and is added to the same sums.
+//   * Float32 partial rows part[((slot nch + ch) nflush + f) N + bin]: a wave with U units writes exactly ceil(U / 128) of its nflush rows, the row
+//     reduction skips the others (no zeroing);
+//   * the units they run all have both frames; the odd last frame of a channel goes through welch_half3_kernel and is added to the same sums.
 #include "welch_w64_asm_co.h"    // static const unsigned char welch_w64_asm_co[]; generated by build.py from welch_w64_asm.s
 #include "welch_w64c_asm_co.h"   // ... welch_w64c_asm_co[]: the same kernel with the shared half-frame carried (tools/gen_welch_asm_c.py)
 
