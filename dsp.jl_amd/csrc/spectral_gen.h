@@ -208,6 +208,28 @@ template <int N_, int T_, int LDSIN_, int... RS> struct CtSched {
     }
     static constexpr int NTW = twoff(P) > 0 ? twoff(P) : 1;
     static constexpr int BINS = (N + T - 1) / T;
+    // Round 4: one element of padding behind every output GROUP of a pass (group = Ns R consecutive elements = the next pass's Ns) wherever the group's
+    // byte stride aliases the LDS banks (G % 4 == 0: 16-lane groups of a ds_write_b64 that straddle two groups hit the same banks -- 28 % of the LDS
+    // cycles of 3 x 8 x 8 x 8, 20 % of 5 x 24 x 25).  It costs nothing at either end: the scatter is  hi (G + 1) + k + Ns q,  and the next pass reads
+    // j + nbf q with nbf a multiple of G, i.e.  (j + j / G) + (nbf + nbf / G) q  -- one per-thread constant and compile-time strides.  The last
+    // pass's output (registers, or the natural-order spectrum the real-column modes read back) is never padded.  Flag 512 turns it on for a schedule
+    // (1024: only in the register-consumed modes): measured on all 23 sizes it is worth +12 % / +5-9 % at 3072 and 6144 (Welch / columns), within
+    // +-2 % elsewhere, and costs the real-column modes 8-20 % at 1536 / 2560 / 3072 (a resident workgroup, where the larger buffer crosses an LDS step).
+#ifndef MDSP_GEN_CT_PAD
+#define MDSP_GEN_CT_PAD 1
+#endif
+    static constexpr int G(int p) { return ns(p) * radix(p); }
+    static constexpr bool PAD = (LDSIN_ & 512) != 0;         // per schedule: measured per size and mode (tools/sessions/r04_s30.sh)
+    static constexpr bool padded(int p) { return MDSP_GEN_CT_PAD && PAD && p >= 0 && p < P - 1 && G(p) % 4 == 0; }
+    static constexpr int gin(int p) { return p > 0 && padded(p - 1) ? G(p - 1) : 0; }               // padding group of the layout pass p READS (0: none)
+    static constexpr int rstride(int p) { return gin(p) ? nbf(p) + nbf(p) / gin(p) : nbf(p); }      // distance of a butterfly's operands in that layout
+    static constexpr int extra() {
+        int e = 0;
+        for (int p = 0; p < P; ++p)
+            if (padded(p) && N / G(p) > e) e = N / G(p);
+        return e;
+    }
+    static constexpr int NP = N + extra();   // elements per LDS buffer
     static_assert(ns(P) == N && T % 64 == 0, "the radices multiply to N; whole wavefronts");
 };
 
@@ -237,15 +259,16 @@ __device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, c
             const unsigned j = (unsigned)(t + S::T * m);
             if ((m + 1) * S::T <= nbf || j < (unsigned)nbf) {   // a compile-time `true` for every trip but a partial last one
                 cx<R> v[Rdx];
+                const unsigned jb = S::gin(p) ? j + j / (unsigned)(S::gin(p) ? S::gin(p) : 1) : j;
 #pragma unroll
-                for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + j + nbf * q);
+                for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + jb + S::rstride(p) * q);
                 if constexpr (p > 0) {
 #pragma unroll
                     for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
                 }
                 fft::gen_bfly<Rdx>(v);
                 const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
-                cx<R>* o = out + hi * (unsigned)(Ns * Rdx) + k;
+                cx<R>* o = out + hi * (unsigned)(Ns * Rdx + (S::padded(p) ? 1 : 0)) + k;
 #pragma unroll
                 for (int q = 0; q < Rdx; ++q) fft::st2(o + Ns * q, v[q]);
             }
@@ -265,8 +288,9 @@ template <typename S, int p, int END, typename R> __device__ __forceinline__ voi
         for (int m = 0; m < M; ++m) {
             const unsigned j = (unsigned)(t + S::T * m);
             if ((m + 1) * S::T <= nbf || j < (unsigned)nbf) {
+                const unsigned jb = S::gin(p) ? j + j / (unsigned)(S::gin(p) ? S::gin(p) : 1) : j;
 #pragma unroll
-                for (int q = 0; q < Rdx; ++q) v[m][q] = fft::ld2(buf + j + nbf * q);
+                for (int q = 0; q < Rdx; ++q) v[m][q] = fft::ld2(buf + jb + S::rstride(p) * q);
             }
         }
         __syncthreads();
@@ -278,7 +302,7 @@ template <typename S, int p, int END, typename R> __device__ __forceinline__ voi
                 for (int q = 1; q < Rdx; ++q) v[m][q] = fft::cmul(v[m][q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
                 fft::gen_bfly<Rdx>(v[m]);
                 const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
-                cx<R>* o = buf + hi * (unsigned)(Ns * Rdx) + k;
+                cx<R>* o = buf + hi * (unsigned)(Ns * Rdx + (S::padded(p) ? 1 : 0)) + k;
 #pragma unroll
                 for (int q = 0; q < Rdx; ++q) fft::st2(o + Ns * q, v[m][q]);
             }
@@ -328,7 +352,7 @@ __device__ __forceinline__ void ct_pass0_compute(const TT (&ra)[S::M(0)][S::radi
                 else v[q] = {ra[m][q] * w, rb[m][q] * w};
             }
             fft::gen_bfly<Rdx>(v);
-            cx<R>* o = out + (unsigned)j * (unsigned)Rdx;   // Ns = 1: hi = j, k = 0
+            cx<R>* o = out + (unsigned)j * (unsigned)(Rdx + (S::padded(0) ? 1 : 0));   // Ns = 1: hi = j, k = 0
 #pragma unroll
             for (int q = 0; q < Rdx; ++q) fft::st2(o + q, v[q]);
         }
@@ -351,8 +375,9 @@ __device__ __forceinline__ void ct_last_pass_regs(const cx<R>* in, const cx<R> (
         const int j = t + S::T * m;
         if ((m + 1) * S::T <= nbf || j < nbf) {
             cx<R> v[Rdx];
+            const unsigned jb = S::gin(p) ? (unsigned)j + (unsigned)j / (unsigned)(S::gin(p) ? S::gin(p) : 1) : (unsigned)j;
 #pragma unroll
-            for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + j + nbf * q);
+            for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + jb + S::rstride(p) * q);
 #pragma unroll
             for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
             fft::gen_bfly<Rdx>(v);
@@ -372,8 +397,8 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
     // thread (A[k] = (Z[k] + conj Z[N-k]) / 2), so their last pass goes through LDS once more
     constexpr bool DIRECT = MODE == 0 || CPLX;
     constexpr bool INPL = S::INPLACE && DIRECT;
-    __shared__ __attribute__((aligned(16))) cx<R> buf[INPL ? N : 2 * N];
-    cx<R>*bufA = buf, *bufB = INPL ? buf : buf + N;
+    __shared__ __attribute__((aligned(16))) cx<R> buf[INPL ? S::NP : 2 * S::NP];
+    cx<R>*bufA = buf, *bufB = INPL ? buf : buf + S::NP;
     const int t = threadIdx.x;
     const int64_t ch = blockIdx.y;
     const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
@@ -520,7 +545,7 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     hipFuncAttributes fa{};
     MDSP_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
     const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8), waves = S::T / 64;
-    const size_t lds_bytes = sizeof(cx<R>) * ((S::INPLACE && (MODE == 0 || CPLX)) ? 1 : 2) * (size_t)S::N;
+    const size_t lds_bytes = sizeof(cx<R>) * ((S::INPLACE && (MODE == 0 || CPLX)) ? 1 : 2) * (size_t)S::NP;
     int per_cu = std::min<int>({32 / waves, (512 / regs) * 4 / waves, (int)((size_t)160 * 1024 / lds_bytes)});
     if (per_cu < 1) per_cu = 1;
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
@@ -545,9 +570,9 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     X(1000, 128, 0, 5, 5, 5, 8) X(1200, 192, 0, 3, 5, 5, 16) X(1280, 128, 0, 5, 16, 16) X(1500, 192, 0, 3, 5, 5, 5, 4)                \
     X(1536, 192, 0, 3, 8, 8, 8) X(1600, 128, 0, 5, 5, 8, 8) X(1920, 128, 0, 3, 5, 8, 16) X(2000, 256, 0, 5, 5, 5, 16)                 \
     X(2400, 256, 0, 3, 5, 5, 4, 8) X(2500, 256, 0, 5, 5, 5, 5, 4) X(2560, 320, 0, 5, 8, 8, 8) X(3000, 384, 4, 3, 5, 5, 5, 8)          \
-    X(3072, 256, 0, 3, 16, 8, 8) X(3200, 256, 0, 5, 5, 8, 16) X(3840, 256, 0, 3, 5, 16, 16) X(4000, 512, 1, 5, 5, 5, 4, 8)            \
+    X(3072, 256, 1536, 3, 16, 8, 8) X(3200, 256, 0, 5, 5, 8, 16) X(3840, 256, 0, 3, 5, 16, 16) X(4000, 512, 1, 5, 5, 5, 4, 8)            \
     X(4800, 512, 0, 3, 5, 5, 8, 8) X(5000, 512, 0, 5, 5, 5, 5, 8) X(5120, 320, 0, 5, 16, 8, 8) X(6000, 512, 0, 3, 5, 5, 5, 16)        \
-    X(6144, 512, 0, 3, 16, 16, 8) X(6400, 448, 0, 5, 5, 16, 16) X(8000, 512, 0, 5, 5, 5, 8, 8)
+    X(6144, 512, 512, 3, 16, 16, 8) X(6400, 448, 0, 5, 5, 16, 16) X(8000, 512, 0, 5, 5, 5, 8, 8)
 // Round 4: Float32 schedules with composite radices (fft_lds.h bfly_comp: 6 ... 25 inside one thread's registers) -- THREE passes where the list
 // above runs four or five, one or two LDS round trips and barriers less per transform; fewer, fatter threads (T ~ N / 24).  Taken where the
 // butterfly counts N / R fill the lanes of T threads (>= 78 % in every pass); MDSP_GEN_WIDE=0 keeps the list above.
@@ -558,6 +583,7 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     X(2400, 128, 48, 5, 20, 24) X(2500, 128, 304, 25, 10, 10) X(3000, 128, 48, 5, 24, 25) X(3200, 128, 368, 25, 8, 16)               \
     X(3840, 256, 48, 15, 16, 16) X(4800, 320, 48, 15, 16, 20) X(5000, 256, 48, 25, 10, 20) X(6000, 256, 304, 25, 24, 10)            \
     X(6400, 256, 368, 25, 16, 16)
+constexpr int gen_ct_flags(int flags, int mode, bool cplx) { return ((flags & 1024) && !(mode == 0 || cplx)) ? (flags & ~512) : flags; }   // 1024: padding only where the last pass is consumed from registers
 constexpr bool gen_ct_wide_mode(int flags, int mode, bool cplx) { return !(flags & (mode == 0 ? 64 : cplx ? 128 : 256)); }
 // (The single LDS buffer was also tried on the small-radix list above -- flag 16 on all of it, tools/sessions/r04_s28: Welch -1 ... -5 %, ComplexF32 STFT
 // -1 ... -4 %: those kernels are register-, not LDS-limited in residency, and the extra barrier per pass costs.)
@@ -598,14 +624,17 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
         switch (a.N) {
 #define MDSP_X(N, T, F, ...)                                                                                       \
     case N:                                                                                                        \
-        if constexpr (sizeof(R) == 4 || N <= GEN_CT_F64_TWO_BUF) {                                                 \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, F, __VA_ARGS__>>(a, nch, st, nslots, partial);        \
+        if constexpr (sizeof(R) == 4) {                                                                            \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, gen_ct_flags(F, MODE, CPLX), __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            return true;                                                                                           \
+        } else if constexpr (N <= GEN_CT_F64_TWO_BUF) {                                                            \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) & ~1536, __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (MODE == 0 || CPLX) {                                                                  \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) | 16, __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | 16, __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (N <= GEN_CT_F64_REAL_COLUMNS_MAX) {                                                   \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, F, __VA_ARGS__>>(a, nch, st, nslots, partial);        \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) & ~1536, __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         }                                                                                                          \
         break;
