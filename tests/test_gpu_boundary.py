@@ -911,6 +911,25 @@ def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
         _lib.set_tunable("MDSP_WELCH_VARIANT", None)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_filters_beyond_the_partitioned_range_stay_correct(d, torch, dt):
+    """32768 taps: beyond the four 4096-tap partitions of the fused engine (16384 Float32 / 8192 Float64 taps), so `filt(b, x)` runs the rocFFT
+    engine at the reference's own block length (optimalfftfiltlength, dspbase.jl:268-291) -- slower but the same convolution: against the
+    oracle, and the fused engine declines the plan with the reference-side error class instead of computing something else."""
+    from dsp_jl_amd import _lib
+    from dsp_jl_amd.dspbase import OlsPlan
+    from oracle import filt as ofilt
+    rng = np.random.default_rng(32768)
+    nb, nx = 32768, 700_000 + 11
+    b = (rng.standard_normal(nb) / np.sqrt(nb)).astype(dt)
+    x = rng.standard_normal(nx).astype(dt)
+    got = d.filt(b, torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = ofilt.fftfilt(b.astype(np.float64), x.astype(np.float64))
+    assert relerr(got, ref) < (TOL32 if dt == np.float32 else 1e-12)
+    with pytest.raises(d.UnsupportedError):
+        OlsPlan(b, d.optimalfftfiltlength(nb, nx), nx, _lib.OLS_FILT, d.ENGINE_FUSED)
+
+
 def test_welch_hand_allocated_kernel_several_channels(d, torch):
     """mdsp_welch_w64c_asm with more than one channel per launch (grid (G, nch), rows part[((slot nch + ch) nflush + f)], the two-step row reduction
     per channel): three channels of 2^23 + 4096 + 2048 k samples (even and odd frame counts reach the kernel: it takes over from eight units per CU) --
