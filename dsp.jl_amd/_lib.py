@@ -74,6 +74,7 @@ PROTOTYPES = {
     "mdsp_ols_plan_info": (ci, [vp, pi64, pi64, pint]),
     "mdsp_ols_plan_geometry": (ci, [vp, pi64, pi64, pint]),
     "mdsp_ols_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, vp]),
+    "mdsp_shift_add": (ci, [vp, vp, i64, i64, i64, i64, i64, ci, vp]),
     "mdsp_ols_exec_range": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, i64, vp]),
     "mdsp_ols_exec_host": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, ci]),
     "mdsp_ols_segment": (ci, [vp, vp, i64, i64, i64, vp, vp]),

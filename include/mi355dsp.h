@@ -120,6 +120,11 @@ int mdsp_ols_plan_geometry(mdsp_ols_plan plan, int64_t* exec_nfft, int64_t* exec
  * 0 <= nout <= nx+nb-1.  x and y must not alias (Filters/filt.jl:438-439). */
 int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,
                   int64_t nout, int64_t ldy, void* stream);
+/* y[shift + i, c] += t[i, c] for 0 <= i < n - shift, every column (real Float32 / Float64).  The one piece of arithmetic a host needs to run filters
+ * LONGER than the fused engine's partitioned range (16384 Float32 / 8192 Float64 taps) on it instead of the rocFFT engine: split the taps into segments
+ * of that length, filter with each (filt: causal, same length as x), and add segment k's output delayed by k * segment_length -- the reference's own
+ * result, fftfilt being linear in b (Filters/filt.jl:479-521).  dsp.jl_amd/filters.py and julia/MI355DSP.jl do exactly that for `filt` / `fftfilt`. */
+int mdsp_shift_add(void* y_dev, const void* t_dev, int64_t n, int64_t shift, int64_t ncols, int64_t ldy, int64_t ldt, int real_dtype, void* stream);
 /* Blocks [first_block, first_block + nblocks_range) of the SAME block grid mdsp_ols_exec uses for one column of nx samples /
  * nout outputs, from a slice of the signal: xs_dev holds x[xs_first .. xs_first + xs_len) and must cover the samples those blocks
  * read, [first_block L - (nb-1), (first_block + nblocks_range) L) clipped to [0, nx); ys_dev[0..] receives the outputs from

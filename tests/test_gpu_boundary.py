@@ -913,9 +913,10 @@ def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_filters_beyond_the_partitioned_range_stay_correct(d, torch, dt):
-    """32768 taps: beyond the four 4096-tap partitions of the fused engine (16384 Float32 / 8192 Float64 taps), so `filt(b, x)` runs the rocFFT
-    engine at the reference's own block length (optimalfftfiltlength, dspbase.jl:268-291) -- slower but the same convolution: against the
-    oracle, and the fused engine declines the plan with the reference-side error class instead of computing something else."""
+    """32768 taps: beyond the four 4096-tap partitions of the fused engine (16384 Float32 / 8192 Float64 taps).  `filt(b, x)` runs them as a delayed sum
+    of segments on the fused engine (mdsp_shift_add; filters.py _fftfilt_segments), an explicit rocFFT-engine plan at the reference's own block length
+    (optimalfftfiltlength, dspbase.jl:268-291) gives the same convolution, both against the oracle; a single FUSED plan of that length is declined with
+    the reference-side error class instead of computing something else."""
     from dsp_jl_amd import _lib
     from dsp_jl_amd.dspbase import OlsPlan
     from oracle import filt as ofilt
@@ -925,7 +926,15 @@ def test_filters_beyond_the_partitioned_range_stay_correct(d, torch, dt):
     x = rng.standard_normal(nx).astype(dt)
     got = d.filt(b, torch.from_numpy(x).cuda()).cpu().numpy()
     ref = ofilt.fftfilt(b.astype(np.float64), x.astype(np.float64))
-    assert relerr(got, ref) < (TOL32 if dt == np.float32 else 1e-12)
+    tol = TOL32 if dt == np.float32 else 1e-12
+    assert relerr(got, ref) < tol
+    roc = d.fftfilt(b, torch.from_numpy(x).cuda(), d.optimalfftfiltlength(nb, nx), engine=d.ENGINE_ROCFFT).cpu().numpy()
+    assert relerr(roc, ref) < tol and relerr(got, roc.astype(np.float64)) < 2 * tol
+    # two columns, and a signal shorter than the filter's second segment reaches
+    X = rng.standard_normal((40_000, 2)).astype(dt)
+    Y = d.filt(b, torch.from_numpy(X).cuda()).cpu().numpy()
+    for c in range(2):
+        assert relerr(Y[:, c], ofilt.fftfilt(b.astype(np.float64), X[:, c].astype(np.float64))) < tol, c
     with pytest.raises(d.UnsupportedError):
         OlsPlan(b, d.optimalfftfiltlength(nb, nx), nx, _lib.OLS_FILT, d.ENGINE_FUSED)
 
