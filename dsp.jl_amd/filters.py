@@ -67,6 +67,12 @@ def _fftfilt(b: np.ndarray, x, nfft: int, engine: int = _lib.ENGINE_AUTO):
 FUSED_MAX_TAPS = {4: 16384, 8: 8192}
 
 
+def _fused_nfft(nb: int) -> int:
+    """A transform length the fused engine accepts for nb taps whatever the signal length (a power of two >= 2 nb; it re-blocks long filters by
+    itself, and optimalfftfiltlength may return a 7-smooth length for signals not much longer than the filter)."""
+    return max(256, 1 << (2 * nb - 1).bit_length())
+
+
 def _fftfilt_segments(taps: np.ndarray, cols, nx: int, seg: int):
     """Filters beyond the partitioned range of the fused engine: fftfilt is linear in b, so  filt(b, x) = sum_k delay(filt(b[k seg : (k + 1) seg], x), k seg);
     every segment runs the partitioned fused kernel (1.3 TB/s at 16384 Float32 taps) instead of the rocFFT engine at the reference's block length
@@ -77,7 +83,7 @@ def _fftfilt_segments(taps: np.ndarray, cols, nx: int, seg: int):
         hk = np.ascontiguousarray(taps[k * seg:(k + 1) * seg])
         if k * seg >= nx:
             break                                   # this segment only reaches outputs beyond the signal
-        plan = OlsPlan(hk, optimalfftfiltlength(len(hk), nx), nx, _lib.OLS_FILT, _lib.ENGINE_FUSED, cached=True)
+        plan = OlsPlan(hk, _fused_nfft(len(hk)), nx, _lib.OLS_FILT, _lib.ENGINE_FUSED, cached=True)
         t = plan.exec(cols, nx)
         if out is None:
             out = t

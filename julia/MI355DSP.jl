@@ -274,7 +274,7 @@ function fftfilt(b::AbstractVector{H}, x::DeviceArray{T}, nfft::Integer=optimalf
         for k in 0:cld(length(taps), seg)-1
             k * seg >= nx && break
             hk = taps[k*seg+1:min(end, (k + 1) * seg)]
-            plan = cached_ols_plan(hk, optimalfftfiltlength(length(hk), nx), nx, OLS_FILT, ENGINE_FUSED)
+            plan = cached_ols_plan(hk, max(256, nextpow(2, 2 * length(hk))), nx, OLS_FILT, ENGINE_FUSED)   # a power of two >= 2 nb: the fused engine re-blocks by itself
             t = ols_exec!(DeviceArray{W}(size(xd)), plan, xd, nx)
             y = y === nothing ? t : shift_add!(y, t, k * seg)
         end

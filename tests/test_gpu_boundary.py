@@ -935,6 +935,11 @@ def test_filters_beyond_the_partitioned_range_stay_correct(d, torch, dt):
     Y = d.filt(b, torch.from_numpy(X).cuda()).cpu().numpy()
     for c in range(2):
         assert relerr(Y[:, c], ofilt.fftfilt(b.astype(np.float64), X[:, c].astype(np.float64))) < tol, c
+    # conv is linear in the kernel too: the full convolution (nx + nb - 1 samples) as the sum of the segments' convolutions
+    from oracle import dspbase as odsp
+    cv = d.conv(torch.from_numpy(x).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    assert cv.shape == (nx + nb - 1,)
+    assert relerr(cv, odsp.conv(x.astype(np.float64), b.astype(np.float64))) < tol
     with pytest.raises(d.UnsupportedError):
         OlsPlan(b, d.optimalfftfiltlength(nb, nx), nx, _lib.OLS_FILT, d.ENGINE_FUSED)
 
