@@ -14,3 +14,15 @@ def test_fft_passes_on_the_host(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:]
     assert "wave-private last exchange" in r.stdout and "gen N= 3000" in r.stdout and "windowed first pass" in r.stdout
+
+
+def test_compile_time_schedules_on_the_host(tmp_path):
+    """tests/cpu_harness/ct_layout.cpp: every entry of the two schedule tables (csrc/ct_sched.h: 23 small-radix + 13 composite-radix schedules) run on the
+    host with the schedule type's own index arithmetic -- butterflies per pass, twiddle indices, group padding, buffer size, two buffers and one -- and
+    the butterflies of fft_lds.h, against a Float64 DFT."""
+    exe = str(tmp_path / "ct_layout")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpu_harness", "ct_layout.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:]
+    assert "36 schedules" in r.stdout and "N  3072 T 256 flags 1536 passes 4 NP  3136" in r.stdout and "FAIL" not in r.stdout
