@@ -78,6 +78,7 @@ static void read_tunables_locked() {
     t.fir_mm_rpad = geti("MDSP_FIR_MM_RPAD", 0);
     t.fir_mm_prio = geti("MDSP_FIR_MM_PRIO", -1);
     t.fir_mm_t64 = geti("MDSP_FIR_MM_T64", 1);
+    t.fir_mm_tight = geti("MDSP_FIR_MM_TIGHT", 1);
     t.fir_mm_nblk = geti("MDSP_FIR_MM_NBLK", 1);
     t.fir_mm_nd = geti("MDSP_FIR_MM_ND", 0);
     t.fir_mm_ns = geti("MDSP_FIR_MM_NS", 0);

@@ -133,6 +133,8 @@ struct Tunables {
     int fir_mm_nblk = 1;                // MDSP_FIR_MM_NBLK=0       : L > 192: the taps of a wave's column blocks fetched per tile (round 2) instead of all in registers
     int fir_mm_t64 = 1;                 // MDSP_FIR_MM_T64=0        : round 2's register limits of the matrix-core polyphase kernel (taps fetched per tile beyond 48 / 64 / 32 / 24
                                         //                            k-steps whatever the chunk count; default: fewer chunks per wave, taps in registers)
+    int fir_mm_tight = 1;               // MDSP_FIR_MM_TIGHT=0      : no last-resort tile forms (shorter rows for L < 16, the 40-step Float32 register form): shapes that do not
+                                        //                            fit the LDS otherwise go to the generic kernel, as up to round 3
     int fir_mm_prio = -1;               // MDSP_FIR_MM_PRIO=0|1     : DMA and store waves of the matrix-core kernel at normal / raised priority (default: raised where a
                                         //                            multiplying wave owns one column block)
     int fir_mm_rpad = 0;                // MDSP_FIR_MM_RPAD         : dwords of padding behind a granule of a padded run (0 = 4)

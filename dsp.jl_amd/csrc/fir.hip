@@ -1303,7 +1303,11 @@ struct FirMGeo {
     size_t lds_bytes = 0;
 };
 int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps <= 12 ? 12 : steps <= 16 ? 16 : steps <= 20 ? 20 : steps <= 24 ? 24 : steps <= 32 ? 32 : steps <= 48 ? 48 : 64; }
-FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_regs: round 3's register-tap rules (fewer chunks / shorter rows)
+// tight (round 4, only tried where nothing else fits the LDS -- shapes that would otherwise fall to the generic kernel at 0.03 - 0.07 of the roofline):
+//   rb_cap > 0: rows of at most rb_cap rounds for L < 16 (ComplexF64 1//16: 14 rounds of 16 samples fit where the conflict-best 15 miss by 1 KiB);
+//   Float32 windows of 33 - 40 k-steps take the 40-step register form with single-chunk waves instead of 48 (ComplexF32 160//441: the 32 samples
+//   less of window tail per buffer are what the tile misses).
+FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0) {   // allow_regs: round 3's register-tap rules (fewer chunks / shorter rows)
     FirMGeo g;
     const bool t64 = allow_regs && tunables().fir_mm_t64 != 0;
     // element type: signal and compute type must agree (Float32 taps x Float32 samples, or Float64 arithmetic on Float64 samples)
@@ -1315,7 +1319,7 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_re
     if (f->L > 1024 || f->M > 4096) return g;
     if (f->L < 16) {   // rounds per row: most outputs per LDS cycle of the A-operand reads (16 rows x 2 taps per lane group)
         double best = -1;
-        for (int rb = 1; rb * f->L <= 16; ++rb) {
+        for (int rb = 1; rb * f->L <= 16 && (rb_cap <= 0 || rb <= rb_cap); ++rb) {
             const int64_t mr = rb * f->M;
             int worst = 1;
             if (!(mr & 1)) {   // odd strides are conflict-free with the even / odd row order of the kernel
@@ -1373,6 +1377,11 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs) {   // allow_re
     if (steps > (g.esz == 8 ? (g.CS == 2 ? 24 : 32) : (g.CS == 2 ? 64 : 48)) || g.NBW < g.NB) {   // (beyond: too many registers -- measured: ComplexF64 at T = 32 and Float32 at T = 64 spill and lose 40 - 50 %)   // the taps do not fit registers (T, Float64 2 T, VGPRs): fetched per tile
         g.T = 0;
         g.steps = (int)cdiv(steps, (int64_t)8) * 8;
+    } else
+    if (rb_cap < 0 && g.esz == 4 && steps > 32 && steps <= 40) {
+        g.T = 40;
+        g.steps = 40;
+        chmax = 1;
     } else {
         g.T = fir_mm_tsel(steps);
         g.steps = g.T;
@@ -1486,6 +1495,11 @@ FirMGeo fir_mm_geo(const mdsp_fir_s* f) {
     if (m.L != f->L || m.M != f->M || m.hlen != f->hlen || m.td != f->taps_dtype || m.xd != f->x_dtype || m.gen != gen) {
         m.g = fir_mm_geo_compute(f, true);
         if (!m.g.ok) m.g = fir_mm_geo_compute(f, false);   // (longer register forms read a longer window tail: where that no longer fits the LDS, fetch the taps)
+        if (!m.g.ok && tunables().fir_mm_tight != 0) {     // the tight forms: see fir_mm_geo_compute
+            if (f->L < 16)
+                for (int cap = (int)(16 / f->L) - 1; cap >= 1 && !m.g.ok; --cap) m.g = fir_mm_geo_compute(f, true, cap);
+            else m.g = fir_mm_geo_compute(f, true, -1);
+        }
         m.L = f->L; m.M = f->M; m.hlen = f->hlen; m.td = f->taps_dtype; m.xd = f->x_dtype; m.gen = gen;
     }
     return m.g;
@@ -1553,6 +1567,7 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
         default:
             if constexpr (CH == 1) {   // the long register forms exist for single-chunk waves only
                 if constexpr (sizeof(R) == 4) {
+                    if (g.T == 40) return fir_mm_launch<R, CS, CH, 40>(f, a, g, st);
                     if (g.T == 80) return fir_mm_launch<R, CS, CH, 80>(f, a, g, st);
                     if (g.T == 96) return fir_mm_launch<R, CS, CH, 96>(f, a, g, st);
                 } else {

@@ -538,6 +538,39 @@ def test_matrix_core_tile_choice_round3():
         _lib.set_tunable("MDSP_FIR_MM_NG", None)
 
 
+def test_matrix_core_last_resort_tiles():
+    # Round 4: shapes whose tile misses the LDS by a kilobyte or two no longer fall to the generic kernel (0.03 - 0.07 of the roofline there):
+    # decimators take rows of fewer rounds, Float32 windows of 33 - 40 k-steps the 40-step register form with single-chunk waves.  Shapes that
+    # fitted before keep their geometry (the forms are tried only after everything else failed); MDSP_FIR_MM_TIGHT=0 is the old behaviour.
+    import ctypes as C
+    from dsp_jl_amd import _lib
+    lib = _lib.lib()
+    out = (C.c_int64 * 12)()
+
+    def geo(L, M, hlen, tdt, xdt):
+        _lib.check(lib.mdsp_fir_mm_geometry(L, M, hlen, tdt, xdt, out))
+        return list(out)
+
+    shapes = [(1, 16, 583, _lib.F64, _lib.C64), (160, 441, 16001, _lib.F32, _lib.C32), (1, 32, 1100, _lib.F64, _lib.F64), (1, 32, 1100, _lib.F32, _lib.C32)]
+    keep = [(160, 147, 5120, _lib.F32, _lib.F32), (1, 16, 583, _lib.F32, _lib.F32), (160, 441, 16001, _lib.F64, _lib.F64), (1, 8, 293, _lib.F64, _lib.C64), (147, 160, 5881, _lib.F32, _lib.C32)]
+    try:
+        _lib.set_tunable("MDSP_FIR_MM_TIGHT", 0)
+        assert all(geo(*sh)[0] == 0 for sh in shapes)
+        before = [geo(*sh) for sh in keep]
+        _lib.set_tunable("MDSP_FIR_MM_TIGHT", None)
+        assert [geo(*sh) for sh in keep] == before
+        g = geo(1, 16, 583, _lib.F64, _lib.C64)
+        assert g[:5] == [1, 13, 13, 208, 1] and g[7] == 1 and g[-1] <= 160 * 1024          # 13 rounds per row instead of 15
+        g = geo(160, 441, 16001, _lib.F32, _lib.C32)
+        assert g[:5] == [1, 1, 160, 441, 10] and g[6] == 40 and g[7] == 1 and g[-1] == 160 * 1024   # 40 k-steps of taps in registers, 16 rows per tile: exactly the LDS
+        for sh in shapes:
+            g = geo(*sh)
+            assert g[0] == 1 and g[-1] <= 160 * 1024 and (sh[0] >= 16 or 1 <= g[1] * sh[0] <= 16), (sh, g)
+        assert geo(147, 160, 5881, _lib.F64, _lib.C64)[0] == 0                               # two output buffers of 41 KiB beside 2 x 45 KiB of samples: still the generic kernel
+    finally:
+        _lib.set_tunable("MDSP_FIR_MM_TIGHT", None)
+
+
 def test_matrix_core_polyphase_geometry_is_consistent():
     # mdsp_fir_mm_geometry is the host arithmetic that sizes the matrix-core polyphase kernel (rows of RB rounds, blocks of 16 outputs,
     # k-steps, LDS buffers, wave roles): pure integer code, checked here without a device over random ratios and tap counts.

@@ -13,11 +13,11 @@ from dsp_jl_amd import _lib
 from oracle import stream_filt as osf
 
 
-def matrix_form(h, L, M, x, phi_idx=1, deficit=1):
+def matrix_form(h, L, M, x, phi_idx=1, deficit=1, tdt=None, xdt=None):
     """Outputs of FIRFilter(h, L//M) on x (zero history, state (phi_idx, deficit)) computed the way the kernel does."""
     g0 = gcd(L, M); L //= g0; M //= g0
     out = (C.c_int64 * 12)()
-    _lib.check(_lib.lib().mdsp_fir_mm_geometry(L, M, len(h), _lib.F64, _lib.F64, out))
+    _lib.check(_lib.lib().mdsp_fir_mm_geometry(L, M, len(h), _lib.F64 if tdt is None else tdt, _lib.F64 if xdt is None else xdt, out))
     ok, RB, Lr, Mr, NB, NG, steps = list(out)[:7]
     assert ok
     tp = -(-len(h) // L)
@@ -59,6 +59,19 @@ def test_matrix_form_equals_the_oracle(L, M, ntaps):
     x = rng.standard_normal(3000)
     ref = osf.FIRFilter(h, Fraction(L, M)).filt(x)
     got = matrix_form(h, L, M, x)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("L,M,ntaps,types", [(1, 16, 583, "c64"), (160, 441, 16001, "c32"), (1, 32, 1100, "f64"), (1, 32, 1100, "c64")])
+def test_matrix_form_of_the_last_resort_tiles(L, M, ntaps, types):
+    # round 4: the geometries tried when nothing else fits the LDS (rows of fewer rounds; 40 k-steps in Float32) obey the same algebra
+    tdt, xdt = {"c64": (_lib.F64, _lib.C64), "c32": (_lib.F32, _lib.C32), "f64": (_lib.F64, _lib.F64)}[types]
+    rng = np.random.default_rng(L * 1000 + M)
+    h = rng.standard_normal(ntaps)
+    x = rng.standard_normal(20000)
+    ref = osf.FIRFilter(h, Fraction(L, M)).filt(x)
+    got = matrix_form(h, L, M, x, tdt=tdt, xdt=xdt)
     assert got.shape == ref.shape
     assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
 
