@@ -67,6 +67,9 @@ static void read_tunables_locked() {
     t.host_chunk_mib = std::max(1, geti("MDSP_HOST_CHUNK_MIB", 64));
     t.ols_prefetch = geti("MDSP_OLS_PREFETCH", 0);
     t.gen_wide = geti("MDSP_GEN_WIDE", 1);
+    t.bigfft = geti("MDSP_BIGFFT", 1);
+    t.big_chunk_mib = std::max(1, geti("MDSP_BIG_CHUNK_MIB", 64));
+    t.big_groups = std::max(0, geti("MDSP_BIG_GROUPS", 0));
     t.fir_p = geti("MDSP_FIR_P", 0);
     t.fir_mm = geti("MDSP_FIR_MM", -1);
     t.fir_exact = geti("MDSP_FIR_EXACT", 0);

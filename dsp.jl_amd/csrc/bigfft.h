@@ -1,0 +1,35 @@
+// Multi-pass fused spectral engine for transforms no single workgroup holds (bigfft.hip; the passes are bigfft_pass.h).  Internal to the
+// library: spectral.hip routes Welch / STFT / spectrogram / periodogram plans with a large nfft here.
+#pragma once
+
+#include "common.h"
+
+namespace mdsp {
+namespace big {
+
+// nfft the engine plans: 7-smooth, above the single-workgroup kernels of spectral.hip, splitting into 2..4 factors of at most 512
+bool size_ok(int dtype, int64_t nfft);
+
+struct Engine;
+struct EngineHolder {   // a plan's engine (created on first use; one per plan, so one owner and one stream at a time like the plan itself)
+    Engine* p = nullptr;
+    EngineHolder() = default;
+    EngineHolder(const EngineHolder&) = delete;
+    EngineHolder& operator=(const EngineHolder&) = delete;
+    ~EngineHolder();
+};
+
+// Every entry: one channel.  `s` is the channel's first sample (dtype of the plan), K frames of n samples, `hop` apart, zero-padded to nfft;
+// win_dev: n doubles on the device or nullptr.
+//
+// Welch: acc[k] (+)= sum over the frames of |Z[k]|^2, k < nfft, Float64 -- the pair-packed full spectrum for real signals (two frames per
+// transform, folded by welch_finalize_kernel modes 3 / 4), the plain one for complex signals.  fresh: overwrite acc instead of adding.
+int welch(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, int64_t K, int64_t hop, const double* win_dev, double* acc, bool fresh,
+          hipStream_t st);
+// STFT / spectrogram / periodogram columns: out[f * ldo + j], j < nout -- raw spectra (complex) or |X|^2 m (real; accumulate: added to what is
+// there), one- or two-sided exactly as the single-workgroup kernels produce them.
+int stft(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, int64_t K, int64_t hop, const double* win_dev, void* out, int64_t ldo,
+         int64_t nout, int onesided, int psd, int accumulate, double r, hipStream_t st);
+
+}  // namespace big
+}  // namespace mdsp

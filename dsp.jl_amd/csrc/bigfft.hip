@@ -1,0 +1,366 @@
+// Multi-pass fused spectral engine: Welch sums, STFT / spectrogram / periodogram columns for transforms of 2^13 .. 2^30 points (bigfft.h).
+//
+// Reference loops being replaced (src/periodograms.jl) -- the same four as spectral.hip, at the sizes the reference's DEFAULT arguments ask for
+// (n = length(s) >> 3, nfft = nextfastfft(n): :560, :647, :828, :872):
+//   K4  ArraySplit getindex :57-69     buf[i] = s[offset+i] * window[i], zero tail up to nfft   -> the loads of pass 0
+//   F3  mul!(outbuf, plan, sig) :754, :888                                                       -> P passes of bigfft_pass.h, one launch each
+//   K5  fft2pow! :142-172              out[i] = muladd(abs2(X[i]), m, out[i])                    -> the stores of the last pass
+//   K6  fft2oneortwosided! :234-244    raw column, conjugate mirror for real -> two-sided       -> the stores of the last pass / big_untangle_kernel
+//
+// HBM traffic per transform of N complex points (Float32: 8 N bytes): pass 0 reads the frames (and the window) and writes 8 N, every middle
+// pass reads and writes 8 N in place, the last pass reads 8 N -- against window + three rocFFT kernels + abs2 over separate buffers before.
+// Transforms are processed in groups small enough (MDSP_BIG_CHUNK_MIB) that a group's work buffer can stay in the 256 MiB Infinity Cache from
+// one pass to the next.
+//
+// Real signals ride two frames per transform (z = w (a + i b), as in the single-workgroup kernels): Welch needs no untangling, columns are
+// untangled by big_untangle_kernel from the natural-order spectrum the last pass leaves.
+#include <algorithm>
+#include <memory>
+#include <vector>
+
+#include "bigfft.h"
+#include "bigfft_plan.h"
+
+using namespace mdsp;
+using mdsp::fft::cx;
+
+namespace mdsp {
+namespace big {
+
+struct Engine {
+    int dtype = MDSP_F32;
+    int64_t n = 0, nfft = 0;
+    int P = 0;
+    Pass pass[MAXP];
+    DevBuf tables, work, nat, partial, winR;
+};
+EngineHolder::~EngineHolder() { delete p; }
+
+namespace {
+
+template <typename R> struct BigArgs {
+    Pass p;
+    int in_mode;        // 0: the work buffer; 1: two real frames per transform, windowed; 2: one complex frame, windowed
+    const void* s;      // the channel's first sample
+    const R* win;       // n window values or nullptr
+    cx<R>* buf;         // work buffer [ntrans][N]
+    void* out;          // OUT 1: Float64 rows [groups][N];  OUT 2: the channel's output matrix;  OUT 3: natural-order spectra [ntrans][N]
+    int64_t t0, ntrans; // first transform of this launch (unit index inside the channel), transforms in this launch
+    int64_t K, hop, ldo;
+    int n, psd, accumulate, acc_add;
+    int64_t nout;
+    R m1;
+};
+
+// OUT 0: twiddled results back into the work buffer (every pass but the last)
+// OUT 1: Welch -- |Z|^2 summed over the launch's transforms of this group in registers (Float64), one row of N per group
+// OUT 2: complex signal -- the frame's column: raw spectrum or |Z|^2 / r
+// OUT 3: natural-order spectrum into `out` (real signals' columns: untangled by big_untangle_kernel)
+template <typename R, int OUT> __global__ __launch_bounds__(TPB, 2) void big_pass_kernel(const BigArgs<R> a) {
+    constexpr int B = cols<R>(), Bp = B + 1, E = elems<R>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    const Pass& p = a.p;
+    cx<R>* bufA = reinterpret_cast<cx<R>*>(big_smem);
+    cx<R>* bufB = bufA + p.Rp * Bp;
+    cx<R>* rootsL = bufB + p.Rp * Bp;
+    const int tid = threadIdx.x;
+    {   // the sub-transform's roots: R_p entries, read by every butterfly of every sub-pass
+        const cx<R>* g = static_cast<const cx<R>*>(p.roots);
+        for (int i = tid; i < p.Rp; i += TPB) fft::st2(rootsL + i, g[i]);
+    }
+    const Tile tc = tile_of<R>(p, (int64_t)blockIdx.x);
+    const int64_t N = p.N;
+    [[maybe_unused]] double acc[OUT == 1 ? E : 1];
+    if constexpr (OUT == 1) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.0;
+    }
+    __syncthreads();
+    for (int64_t t = blockIdx.y; t < a.ntrans; t += gridDim.y) {
+        const int64_t u = a.t0 + t;
+        if (a.in_mode == 0) {
+            const cx<R>* src = a.buf + t * N;
+            phase_load<R>(p, tc, tid, bufA, [&](int64_t pos) { return src[pos]; });
+        } else if (a.in_mode == 1) {   // K4, two frames: z = w (a + i b); frame b may not exist (odd K), the tail past n is zero
+            const R* fa = static_cast<const R*>(a.s) + 2 * u * a.hop;
+            const bool haveB = 2 * u + 1 < a.K;
+            phase_load<R>(p, tc, tid, bufA, [&](int64_t pos) {
+                cx<R> z = {(R)0, (R)0};
+                if (pos < a.n) {
+                    const R w = a.win ? a.win[pos] : (R)1;
+                    z.x = fa[pos] * w;
+                    if (haveB) z.y = fa[pos + a.hop] * w;
+                }
+                return z;
+            });
+        } else {
+            const cx<R>* fa = static_cast<const cx<R>*>(a.s) + u * a.hop;
+            phase_load<R>(p, tc, tid, bufA, [&](int64_t pos) {
+                cx<R> z = {(R)0, (R)0};
+                if (pos < a.n) {
+                    const R w = a.win ? a.win[pos] : (R)1;
+                    const cx<R> v = fa[pos];
+                    z = {v.x * w, v.y * w};
+                }
+                return z;
+            });
+        }
+        __syncthreads();
+        cx<R>*src = bufA, *dst = bufB;
+        for (int sp = 0; sp < p.nsub; ++sp) {
+            phase_sub<R>(p, sp, tid, src, dst, rootsL);
+            __syncthreads();
+            cx<R>* tmp = src;
+            src = dst;
+            dst = tmp;
+        }
+        if constexpr (OUT == 0) {
+            cx<R>* o = a.buf + t * N;
+            phase_store<R, false>(p, tc, tid, src, [&](int, int64_t pos, cx<R> z) { o[pos] = z; });
+        } else if constexpr (OUT == 1) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
+            phase_store<R, true>(p, tc, tid, src, [&](int e, int64_t, cx<R> z) { acc[e] += (double)(z.x * z.x + z.y * z.y); });
+        } else if constexpr (OUT == 2) {
+            const int64_t o0 = u * a.ldo;
+            phase_store<R, false>(p, tc, tid, src, [&](int, int64_t k, cx<R> z) {
+                if (k < a.nout) {
+                    if (a.psd) {
+                        R* o = static_cast<R*>(a.out) + o0 + k;
+                        const R pw = z.x * z.x + z.y * z.y;
+                        *o = a.accumulate ? fma(pw, a.m1, *o) : pw * a.m1;   // fft2pow!: out = muladd(abs2, m, out)
+                    } else static_cast<cx<R>*>(a.out)[o0 + k] = z;
+                }
+            });
+        } else {
+            cx<R>* o = static_cast<cx<R>*>(a.out) + t * N;
+            phase_store<R, false>(p, tc, tid, src, [&](int, int64_t k, cx<R> z) { o[k] = z; });
+        }
+        __syncthreads();   // the buffer the stores read is the one the next transform's loads or first sub-pass write
+    }
+    if constexpr (OUT == 1) {
+        double* row = static_cast<double*>(a.out) + (int64_t)blockIdx.y * N;
+        phase_store<R, true>(p, tc, tid, bufA, [&](int e, int64_t k, cx<R>) { row[k] = a.acc_add ? row[k] + acc[e] : acc[e]; });
+    }
+}
+
+// acc[k] = (add ? acc[k] : 0) + sum_g rows[g][k], fixed order
+__global__ __launch_bounds__(256) void big_reduce_kernel(const double* __restrict__ rows, double* __restrict__ acc, int64_t N, int groups, int add) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    double v = add ? acc[k] : 0.0;
+    for (int g = 0; g < groups; ++g) v += rows[(int64_t)g * N + k];
+    acc[k] = v;
+}
+
+template <typename R> __global__ __launch_bounds__(256) void big_window_kernel(const double* __restrict__ win, R* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (R)win[i];
+}
+
+// Columns of the two real frames of a transform from its natural-order spectrum: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / (2i)
+// (the same arithmetic as the single-workgroup kernels, spectral_gen.h); grid (bins / 256, transforms)
+template <typename R>
+__global__ __launch_bounds__(256) void big_untangle_kernel(const cx<R>* __restrict__ nat, void* __restrict__ out, int64_t N, int64_t t0, int64_t K, int64_t ldo,
+                                                            int64_t nout, int psd, int accumulate, int onesided, R m1, R m2) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nout) return;
+    const int64_t t = blockIdx.y, f0 = 2 * (t0 + t);
+    const bool haveB = f0 + 1 < K;
+    const cx<R>* z = nat + t * N;
+    const bool mirror = j > N / 2;                     // real -> two-sided: X[N-k] = conj(X[k]) (fft2oneortwosided!, :234-244)
+    const int64_t k = mirror ? N - j : j;
+    const cx<R> zk = z[k], zm = z[k == 0 ? 0 : N - k];
+    cx<R> A = {(R)0.5 * (zk.x + zm.x), (R)0.5 * (zk.y - zm.y)};
+    cx<R> Bv = {(R)0.5 * (zk.y + zm.y), (R)0.5 * (zm.x - zk.x)};
+    const int64_t o0 = f0 * ldo + j;
+    if (psd) {
+        R m = m1;
+        if (onesided && !(j == 0 || (j == nout - 1 && N % 2 == 0))) m = m2;
+        R* o = static_cast<R*>(out) + o0;
+        const R pa = A.x * A.x + A.y * A.y;
+        *o = accumulate ? fma(pa, m, *o) : pa * m;
+        if (haveB) {
+            const R pb = Bv.x * Bv.x + Bv.y * Bv.y;
+            o[ldo] = accumulate ? fma(pb, m, o[ldo]) : pb * m;
+        }
+    } else {
+        if (mirror) {
+            A.y = -A.y;
+            Bv.y = -Bv.y;
+        }
+        cx<R>* o = static_cast<cx<R>*>(out) + o0;
+        *o = A;
+        if (haveB) o[ldo] = Bv;
+    }
+}
+
+template <typename R> int build(Engine* e) {
+    HostPlan<R> hp;
+    if (!make_plan<R>(e->nfft, hp)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%lld does not split into 2..4 factors of at most %d", (long long)e->nfft, RMAX);
+    size_t total = 0;
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    for (int p = 0; p < hp.P; ++p) total += al(hp.roots[p].size()) + al(hp.T0[p].size()) + al(hp.T1[p].size());
+    std::vector<cx<R>> all(total);
+    MDSP_TRY(e->tables.reserve(sizeof(cx<R>) * total));
+    size_t off = 0;
+    auto put = [&](const std::vector<cx<R>>& v) -> const void* {
+        const void* dev = e->tables.as<cx<R>>() + off;
+        std::copy(v.begin(), v.end(), all.begin() + (long)off);
+        off += al(v.size());
+        return dev;
+    };
+    e->P = hp.P;
+    for (int p = 0; p < hp.P; ++p) {
+        e->pass[p] = hp.pass[p];
+        e->pass[p].roots = put(hp.roots[p]);
+        e->pass[p].T0 = put(hp.T0[p]);
+        e->pass[p].T1 = put(hp.T1[p]);
+    }
+    MDSP_HIP(hipMemcpy(e->tables.p, all.data(), sizeof(cx<R>) * total, hipMemcpyHostToDevice));
+    return MDSP_OK;
+}
+
+int get_engine(EngineHolder& h, int dtype, int64_t n, int64_t nfft, Engine** out) {
+    if (h.p && (h.p->dtype != dtype || h.p->n != n || h.p->nfft != nfft)) {
+        delete h.p;
+        h.p = nullptr;
+    }
+    if (!h.p) {
+        std::unique_ptr<Engine> e(new Engine());
+        e->dtype = dtype;
+        e->n = n;
+        e->nfft = nfft;
+        MDSP_TRY(dtype_is_double(dtype) ? build<double>(e.get()) : build<float>(e.get()));
+        h.p = e.release();
+    }
+    *out = h.p;
+    return MDSP_OK;
+}
+
+template <typename R, int OUT> int launch_pass(const BigArgs<R>& a, int groups, hipStream_t st) {
+    constexpr int Bp = cols<R>() + 1;
+    auto kern = big_pass_kernel<R, OUT>;
+    const size_t lds_bytes = sizeof(cx<R>) * ((size_t)2 * a.p.Rp * Bp + (size_t)a.p.Rp);
+    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.p.ntiles, (unsigned)groups), dim3(TPB), lds_bytes, st, a);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
+// mode 0: Welch sums into acc; 1: columns
+template <typename R, bool CPLX>
+int run(Engine* e, int mode, const void* s, int64_t K, int64_t hop, const double* win_dev, double* acc, bool fresh, void* out, int64_t ldo, int64_t nout,
+        int onesided, int psd, int accumulate, double r, hipStream_t st) {
+    const int64_t N = e->nfft;
+    const int64_t units = CPLX ? K : cdiv(K, 2);
+    if (units == 0) return MDSP_OK;
+    const R* win = nullptr;
+    if (win_dev) {
+        if constexpr (sizeof(R) == 8) win = reinterpret_cast<const R*>(win_dev);
+        else {   // Float32 signals: the window rounded to Float32 first, as the single-workgroup kernels do -- and half the bytes per frame
+            MDSP_TRY(e->winR.reserve(sizeof(R) * (size_t)e->n));
+            hipLaunchKernelGGL(big_window_kernel<R>, dim3((unsigned)cdiv(e->n, 256)), dim3(256), 0, st, win_dev, e->winR.as<R>(), e->n);
+            MDSP_LAUNCH_CHECK();
+            win = e->winR.as<R>();
+        }
+    }
+    const int64_t per = (int64_t)sizeof(cx<R>) * N;
+    const int64_t C = std::max<int64_t>(1, std::min<int64_t>(units, ((int64_t)tunables().big_chunk_mib << 20) / per));
+    MDSP_TRY(e->work.reserve((size_t)(per * C)));
+    const bool untangle = mode == 1 && !CPLX;
+    if (untangle) MDSP_TRY(e->nat.reserve((size_t)(per * C)));
+    const int cus = device_cu_count();
+    bool add = !fresh;
+    for (int64_t c0 = 0; c0 < units; c0 += C) {
+        const int64_t cnt = std::min<int64_t>(C, units - c0);
+        for (int p = 0; p < e->P; ++p) {
+            BigArgs<R> a{};
+            a.p = e->pass[p];
+            a.in_mode = p == 0 ? (CPLX ? 2 : 1) : 0;
+            a.s = s;
+            a.win = win;
+            a.buf = e->work.as<cx<R>>();
+            a.t0 = c0;
+            a.ntrans = cnt;
+            a.K = K;
+            a.hop = hop;
+            a.ldo = ldo;
+            a.n = (int)e->n;
+            a.nout = nout;
+            a.psd = psd;
+            a.accumulate = accumulate;
+            a.m1 = (R)(1.0 / r);
+            int groups = tunables().big_groups > 0 ? tunables().big_groups : (int)cdiv((int64_t)4 * cus, a.p.ntiles);
+            groups = (int)std::max<int64_t>(1, std::min<int64_t>(groups, cnt));
+            if (p < e->P - 1) {
+                MDSP_TRY((launch_pass<R, 0>(a, groups, st)));
+            } else if (mode == 0) {
+                groups = std::min(groups, 32);
+                if (groups == 1) {
+                    a.out = acc;
+                    a.acc_add = add ? 1 : 0;
+                    MDSP_TRY((launch_pass<R, 1>(a, 1, st)));
+                } else {
+                    MDSP_TRY(e->partial.reserve(sizeof(double) * (size_t)groups * (size_t)N));
+                    a.out = e->partial.p;
+                    a.acc_add = 0;
+                    MDSP_TRY((launch_pass<R, 1>(a, groups, st)));
+                    hipLaunchKernelGGL(big_reduce_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, e->partial.as<double>(), acc, N, groups, add ? 1 : 0);
+                    MDSP_LAUNCH_CHECK();
+                }
+                add = true;
+            } else if (!untangle) {
+                a.out = out;
+                MDSP_TRY((launch_pass<R, 2>(a, groups, st)));
+            } else {
+                a.out = e->nat.p;
+                MDSP_TRY((launch_pass<R, 3>(a, groups, st)));
+                hipLaunchKernelGGL(big_untangle_kernel<R>, dim3((unsigned)cdiv(nout, 256), (unsigned)cnt), dim3(256), 0, st, e->nat.as<cx<R>>(), out, N, c0, K, ldo,
+                                   nout, psd, accumulate, onesided, (R)(1.0 / r), (R)(2.0 / r));
+                MDSP_LAUNCH_CHECK();
+            }
+        }
+    }
+    return MDSP_OK;
+}
+
+}  // namespace
+
+bool size_ok(int dtype, int64_t nfft) {
+    if (!tunables().bigfft) return false;
+    // above the single-workgroup kernels of spectral.hip (which keep precedence where they exist: power-of-two register forms to 8192 / 4096,
+    // mixed-radix LDS forms to 8192 / 8000 -- spectral.hip use_big)
+    (void)dtype;
+    if (nfft <= 4096 || nfft >= ((int64_t)1 << 31) || !seven_smooth(nfft)) return false;
+    int R[MAXP];
+    return factorise(nfft, R) >= 2;
+}
+
+int welch(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, int64_t K, int64_t hop, const double* win_dev, double* acc, bool fresh,
+          hipStream_t st) {
+    Engine* e = nullptr;
+    MDSP_TRY(get_engine(h, dtype, n, nfft, &e));
+    const bool cplx = dtype_is_complex(dtype), dbl = dtype_is_double(dtype);
+    if (K == 0) {
+        if (fresh) MDSP_HIP(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nfft, st));
+        return MDSP_OK;
+    }
+    if (cplx) return dbl ? run<double, true>(e, 0, s, K, hop, win_dev, acc, fresh, nullptr, 0, 0, 0, 0, 0, 1.0, st)
+                         : run<float, true>(e, 0, s, K, hop, win_dev, acc, fresh, nullptr, 0, 0, 0, 0, 0, 1.0, st);
+    return dbl ? run<double, false>(e, 0, s, K, hop, win_dev, acc, fresh, nullptr, 0, 0, 0, 0, 0, 1.0, st)
+               : run<float, false>(e, 0, s, K, hop, win_dev, acc, fresh, nullptr, 0, 0, 0, 0, 0, 1.0, st);
+}
+
+int stft(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, int64_t K, int64_t hop, const double* win_dev, void* out, int64_t ldo,
+         int64_t nout, int onesided, int psd, int accumulate, double r, hipStream_t st) {
+    Engine* e = nullptr;
+    MDSP_TRY(get_engine(h, dtype, n, nfft, &e));
+    const bool cplx = dtype_is_complex(dtype), dbl = dtype_is_double(dtype);
+    if (K == 0) return MDSP_OK;
+    if (cplx) return dbl ? run<double, true>(e, 1, s, K, hop, win_dev, nullptr, false, out, ldo, nout, onesided, psd, accumulate, r, st)
+                         : run<float, true>(e, 1, s, K, hop, win_dev, nullptr, false, out, ldo, nout, onesided, psd, accumulate, r, st);
+    return dbl ? run<double, false>(e, 1, s, K, hop, win_dev, nullptr, false, out, ldo, nout, onesided, psd, accumulate, r, st)
+               : run<float, false>(e, 1, s, K, hop, win_dev, nullptr, false, out, ldo, nout, onesided, psd, accumulate, r, st);
+}
+
+}  // namespace big
+}  // namespace mdsp

@@ -145,6 +145,9 @@ struct Tunables {
     int fir_mm_nd = 0, fir_mm_ns = 0;   // MDSP_FIR_MM_ND / _NS     : its DMA / store waves (0 = default: 2 DMA waves, 2 store waves for ratios >= 1, else 4)
     int gen_wide = 1;                   // MDSP_GEN_WIDE=0          : nextfastfft sizes: round 3's schedules of small radices instead of the three-pass composite-radix ones
     int ols_prefetch = 0;               // MDSP_OLS_PREFETCH=1      : overlap-save kernel with software prefetch of the next unit (default: off)
+    int bigfft = 1;                     // MDSP_BIGFFT=0            : transforms above the one-workgroup sizes go to the rocFFT pipeline instead of the multi-pass fused engine (bigfft.hip)
+    int big_chunk_mib = 64;             // MDSP_BIG_CHUNK_MIB       : work buffer of the multi-pass engine per launch group (small enough to stay in the Infinity Cache between passes)
+    int big_groups = 0;                 // MDSP_BIG_GROUPS          : transform groups per launch of its passes (0 = enough workgroups for four per CU)
     int plan_cache_total = 8 * MDSP_PLAN_CACHE_SIZE;   // MDSP_PLAN_CACHE_TOTAL : entries in the whole plan cache above which idle partitions are trimmed
     int plan_cache_idle = 64;           // MDSP_PLAN_CACHE_IDLE     : cache requests without one of its own after which a partition counts as idle
 #ifdef MDSP_DEBUG_KNOBS

@@ -679,22 +679,29 @@ bool fused_size_ok(int dtype, int64_t nfft) {
     }
 }
 
+// the multi-pass engine takes what no single-workgroup kernel does
+bool use_big(int dtype, int64_t nfft, bool direct) {
+    return !fused_size_ok(dtype, nfft) && !gen_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && big::size_ok(dtype, nfft);
+}
+
 // kind: 0 = Welch (sums of |X|^2), 1 = STFT / spectrogram / periodogram columns
 int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) {
     int eng = engine;
     if (eng == MDSP_ENGINE_AUTO) eng = tunables().engine;
     // fused: the register-resident power-of-two sizes, and the mixed-radix LDS kernel for the other 7-smooth sizes nextfastfft returns
     const bool direct = kind == 0 || dtype_is_complex(dtype);   // the last pass is consumed from registers (spectral_gen.h)
-    const bool fused_ok = fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct);
+    const bool big_ok = use_big(dtype, nfft, direct);   // round 5: the multi-pass engine (bigfft.hip) for everything above the one-workgroup sizes
+    const bool fused_ok = fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) || big_ok;
     // AUTO takes the mixed-radix kernel where it measured faster than the rocFFT pipeline (profiles/r02g_mixed.json, 2^27 samples): Welch and
     // real-signal columns up to 4096 points (1.4-3x), complex columns above (1.6x); elsewhere the two are within 20 % and rocFFT is kept.
     // Round 3: the sizes with a compile-time schedule (spectral_gen.h, Float32 / ComplexF32) beat the rocFFT pipeline 2-9x in every mode
     // (profiles/r03d_mixed_ct.json) and are always taken.
-    const bool gen_wins = fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
+    const bool gen_wins = big_ok || fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
                           (gen_size_ok(dtype, nfft) && ((nfft <= 4096) == (kind == 0 || !dtype_is_complex(dtype))));
     if (eng == MDSP_ENGINE_AUTO) eng = gen_wins ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
     if (eng == MDSP_ENGINE_FUSED && !fused_ok)
-        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports nfft = 2^a 3^b 5^c 7^d up to %d; got %lld", dtype_is_double(dtype) ? 4096 : 8192, (long long)nfft);
+        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports nfft = 2^a 3^b 5^c 7^d (up to %d, or splitting into 2..4 factors of at most 512); got %lld",
+                  dtype_is_double(dtype) ? 4096 : 8192, (long long)nfft);
     if (eng != MDSP_ENGINE_FUSED && eng != MDSP_ENGINE_ROCFFT) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid engine %d", engine);
     *out = eng;
     return MDSP_OK;
@@ -1645,6 +1652,19 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
         }
         return MDSP_OK;
     }
+    if (use_big(pl->dtype, pl->nfft, true)) {   // nfft above the one-workgroup sizes: channel by channel through the multi-pass engine, same accumulator protocol
+        using TT = std::conditional_t<CPLX, cx<R>, R>;
+        const int64_t N = pl->nfft;
+        MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)nch * (size_t)N));
+        for (int64_t c = 0; c < nch; ++c)
+            MDSP_TRY(big::welch(pl->big, pl->dtype, pl->n, N, static_cast<const TT*>(s) + c * lds_, K, pl->n - pl->noverlap,
+                                pl->have_win ? pl->win.as<double>() : nullptr, pl->reduced.as<double>() + c * N, pl->acc_fresh, st));
+        pl->acc_fresh = false;
+        pl->acc_nslices = 1;
+        pl->acc_nacc = (int)N;
+        pl->acc_mode = CPLX ? 1 : (pl->onesided ? 3 : 4);
+        return MDSP_OK;
+    }
     SpecArgs a{};
     a.s = s;
     a.table = pl->table.p;
@@ -1720,7 +1740,8 @@ int mdsp_welch_plan_create(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, i
         if (st == MDSP_OK && hipMemcpy(pl->win.p, window_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
             st = set_error(MDSP_ERR_DEVICE, "window upload failed");
     }
-    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED) st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, true))   // (the multi-pass engine builds its own, much shorter, tables)
+        st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
     if (st != MDSP_OK) {
         delete pl;
         return st;
@@ -1867,6 +1888,7 @@ struct mdsp_stft_plan_s {
     RocPlan fwd;
     DevBuf fr, spec;
     int64_t batch = 0;
+    big::EngineHolder big;             // nfft above the single-workgroup kernels: the multi-pass engine (bigfft.hip)
 };
 
 namespace {
@@ -1999,6 +2021,14 @@ template <typename R, bool CPLX>
 int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* out, int64_t ldo, int64_t chs, hipStream_t st) {
     const int64_t K = mdsp_frame_count(len, pl->n, pl->noverlap);
     if (K == 0) return MDSP_OK;
+    if (use_big(pl->dtype, pl->nfft, CPLX)) {   // nfft above the one-workgroup sizes (bigfft.hip); multitaper plans come here once per taper (accumulate)
+        using TT = std::conditional_t<CPLX, cx<R>, R>;
+        const size_t osz = pl->psd_only ? sizeof(R) : sizeof(cx<R>);
+        for (int64_t c = 0; c < nch; ++c)
+            MDSP_TRY(big::stft(pl->big, pl->dtype, pl->n, pl->nfft, static_cast<const TT*>(s) + c * lds_, K, pl->n - pl->noverlap, pl->have_win ? pl->win_ptr : nullptr,
+                               static_cast<char*>(out) + (size_t)(c * chs) * osz, ldo, pl->nout, pl->onesided, pl->psd_only, pl->accumulate, pl->r, st));
+        return MDSP_OK;
+    }
     SpecArgs a{};
     a.s = s;
     a.out = out;
@@ -2073,7 +2103,8 @@ int mdsp_stft_plan_create(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int
             st = set_error(MDSP_ERR_DEVICE, "window upload failed");
         pl->win_ptr = pl->win.as<double>();
     }
-    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED) st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, dtype_is_complex(dtype)))
+        st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
     if (st != MDSP_OK) {
         delete pl;
         return st;

@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include "rocfft_wrap.h"
+#include "bigfft.h"
 
 struct mdsp_welch_plan_s {
     int dtype = MDSP_F32, engine = MDSP_ENGINE_ROCFFT, onesided = 1;
@@ -24,6 +25,7 @@ struct mdsp_welch_plan_s {
     // round trip, no stream synchronisation); mdsp_welch_finalize(plan, 0, ...) reads it there.  acc_frames stays this rank's own count.
     mdsp::DevBuf kdev;
     mdsp::DevBuf redtmp;         // group sums of the two-step slice reduction (reduce_partials, spectral.hip)
+    mdsp::big::EngineHolder big;   // nfft above the single-workgroup kernels: the multi-pass engine (bigfft.hip), built at the first accumulate
     mdsp::DevBuf w64prep;        // mdsp_welch_w64_asm: Float32 window pairs + per-lane twiddles (built at the plan's first launch of that kernel)
     bool frames_on_device = false;
     int acc_nslices = 1, acc_nacc = 0, acc_mode = 0;   // welch_finalize_kernel MODE

@@ -26,3 +26,15 @@ def test_compile_time_schedules_on_the_host(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:]
     assert "36 schedules" in r.stdout and "N  3072 T 256 flags 1536 passes 4 NP  3136" in r.stdout and "FAIL" not in r.stdout
+
+
+def test_multipass_transform_on_the_host(tmp_path):
+    """tests/cpu_harness/bigfft_emul.cpp: the tile / sub-pass / store phases of the multi-pass engine (csrc/bigfft_pass.h) and its planner
+    (csrc/bigfft_plan.h: factorisation, radix schedules, two-level twiddle tables) run thread by thread on the host against a Float64 DFT --
+    two, three and four passes, powers of two, the 2^a 5^b sizes of the default arguments, odd sizes with partial tiles, both precisions."""
+    exe = str(tmp_path / "bigfft_emul")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpu_harness", "bigfft_emul.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:]
+    assert "N=   125000 f32 P=2" in r.stdout and "P=4" in r.stdout and "FAIL" not in r.stdout
