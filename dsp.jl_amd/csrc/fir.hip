@@ -590,13 +590,15 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                 if constexpr (T != 0 && RP) {
                     // dwords from this lane's first window position to the next granule boundary (16 rows are a whole number of granules,
                     // so the distance is the same for every chunk)
-                    const int th = 256 - (((ra * lj) * a.Mr + c0 + lk) * DW & 255);
+                    const int th = 256 - (((ra * lj + rbase(0)) * a.Mr + c0 + lk) * DW & 255);   // (rbase(0): single-chunk waves need not start on a granule, round 5 prep)
 #pragma unroll
                     for (int t = 0; t < TR; ++t) {
                         const bool hi = 4 * t * DW >= th;
+                        // (round 5 prep) windows longer than a granule -- 4 T DW dwords up to 512 -- meet a second pad: a third base pointer
+                        const bool hi2 = 4 * (T - 1) * DW + DW > 256 && 4 * t * DW >= th + 256;
 #pragma unroll
                         for (int c = 0; c < CH; ++c) {
-                            const R* pp = hi ? ap[c] + padE : ap[c];
+                            const R* pp = hi2 ? ap[c] + 2 * padE : hi ? ap[c] + padE : ap[c];
 #pragma unroll
                             for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(pp[4 * t * CS + p], hreg[T == 0 ? 0 : kb][t], acc[p][c]);
                         }
@@ -614,6 +616,10 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                     // words are carried RAW into the next group and only then masked: a select next to the fetch would wait for it on the spot.
                     // Measured against masking next to the fetch, alternating processes on one box (tools/r03_session35.sh): ComplexF64 3//8 4.94 -> 4.37 ms,
                     // 1//4 2.99 -> 2.76, 1//8 5.16 -> 5.04; Float32 1//8 +3 %, but 1//16 -7 %, Float64 1//16 -4 %: the carried form for ComplexF64 only.
+                    // (round 5 prep) padded runs with fetched taps: the window spans any number of granules, so the pads in front of a position are
+                    // computed per k-step (one shift and one multiply-add beside a tap fetch and CH matrix instructions; the vector unit idles here)
+                    const int off0 = RP ? (((ra * lj + rbase(0)) * a.Mr + c0 + lk) * DW & 255) : 0;
+                    const auto padx = [&](int t) { return RP ? ((off0 + 4 * t * DW) >> 8) * padE : 0; };
                     if constexpr (MDSP_FIR_TAP_CARRY && CS == 2 && sizeof(R) == 8) {
                     R hraw[8];
                     unsigned okm = 0;
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
 #pragma unroll
                             for (int c = 0; c < CH; ++c)
 #pragma unroll
-                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p + padx(t0 + u)], h[u], acc[p][c]);
                     }
                     } else {
                     R h[8];
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
 #pragma unroll
                             for (int c = 0; c < CH; ++c)
 #pragma unroll
-                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p + padx(t0 + u)], h[u], acc[p][c]);
 #pragma unroll
                         for (int u = 0; u < 8; ++u) h[u] = hn[u];
                     }
@@ -1414,7 +1420,7 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0)
     //     groups of four chunks for twice as many of two (+12 %, +30 %).  Costs within 3 % of each other go to the larger tile.
     const bool by_model = f->L <= f->M && tunables().fir_mm_ng <= 0 && tunables().fir_mm_ch <= 0;
     double best_score = -1, best_cost = 0;
-    int best_rows = 0;
+    int best_rows = 0, best_mw = 0;
     for (int pad = tunables().fir_mm_pad == 0 ? 0 : 1; pad >= 0 && !g.ok; --pad) {   // (a last resort: output rows without their 16 bytes of padding -- ComplexF64 at 160//147 then fits exactly)
     if (g.NB > 1) g.Lp = 16 * g.NB * g.CS + (pad ? 16 / g.esz : 0);
     else if (!pad) break;
@@ -1439,7 +1445,12 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0)
     for (int mode = 0; mode < 3; ++mode) {   // 0: one linear run per tile, 1: row by row, 2: one run with padded rows
         if (mode >= 1 && ways_lin < 4 && fm < 0) continue;
         if (fm >= 0 && mode != fm) continue;
-        const bool pad_ok = !((g.Mr * dw) & 15) && g.T != 0 && g.T <= 32 && g.T * dw <= 64;   // 16 rows are whole granules; taps in registers; a window (4 T dw dwords) meets one pad at most
+        // 16 rows are whole granules; taps in registers; a window (4 T dw dwords) meets one pad at most.  (round 5 prep, MDSP_FIR_MM_RPX=1: fetched taps
+        // with computed pads, and register forms of single-chunk waves whose window meets two pads at most -- 4 T dw <= 512)
+        const bool rpx = tunables().fir_mm_rpx != 0;
+        const bool gran16 = !((g.Mr * dw) & 15);   // 16 rows are whole granules: every chunk of a wave crosses at the same step (single-chunk waves do not need it)
+        const bool pad_ok = (gran16 && g.T != 0 && g.T <= 32 && g.T * dw <= 64) || (rpx && g.T == 0 && (gran16 || chmax == 1)) ||
+                            (rpx && g.T != 0 && g.NBLK == 1 && g.T * dw <= 128 && chmax == 1);
         if (mode == 2 && !pad_ok) continue;
         if (mode == 1 && fm < 0 && pad_ok && ways_pad <= 2 * ways_row) continue;   // the padded run replaces the row-staged form wherever it applies and spreads the
                                                                                      // rows comparably (rows shorter than a granule share its pad: Mr dw = 16 stays 15-way)
@@ -1462,9 +1473,14 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0)
                 const int mw = g.NBW * ng, trows = rows * ng;
                 const double c_mfma = (g.esz == 8 ? 64.0 : 32.0) * g.CS;
                 const double cost = (((mw + 3) / 4) * (double)ch * cdiv(g.NB, g.NBW) * g.steps * c_mfma * std::max(1.0, 0.2 * ways) + (g.T == 0 ? mw * g.steps * 25.0 : 0.0) + 3900.0) / trows;
-                if (!g.ok || cost < 0.97 * best_cost || (cost < 1.03 * best_cost && trows > best_rows)) {
+                // (round 5 prep, MDSP_FIR_MM_TIEWAVES=1, unmeasured as a rule) equal tiles at equal cost: the one with more multiplying waves -- the k-steps of
+                // a wave are a latency chain (profiles/r04_fir_decim16_pmc.json), and profiles/r04_fir_ch1_ab.json has both tie cases faster that way
+                // (1//16 Float32 1.74 -> 1.46 ms, ComplexF32 1//4 1.01 -> 0.83)
+                const bool tie_waves = tunables().fir_mm_tiewaves != 0 && g.ok && cost < 1.03 * best_cost && trows == best_rows && mw > best_mw;
+                if (!g.ok || cost < 0.97 * best_cost || (cost < 1.03 * best_cost && trows > best_rows) || tie_waves) {
                     best_cost = g.ok ? std::min(best_cost, cost) : cost;
                     best_rows = trows;
+                    best_mw = mw;
                     take();
                 }
             }
@@ -1556,7 +1572,7 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
     }
     if (g.NBLK > 1) MDSP_FAIL(MDSP_ERR_ASSERTION, "no matrix-core instantiation for %d blocks per wave with %d chunks", g.NBLK, CH);
     switch (g.T) {
-        case 0: return fir_mm_launch<R, CS, CH, 0>(f, a, g, st);
+        case 0: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 0, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 0>(f, a, g, st);
         case 4: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 4, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
         case 8: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 8, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 8>(f, a, g, st);
         case 12: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 12, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 12>(f, a, g, st);
@@ -1567,10 +1583,27 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
         default:
             if constexpr (CH == 1) {   // the long register forms exist for single-chunk waves only
                 if constexpr (sizeof(R) == 4) {
+                    if (g.rowpad > 0) {   // (round 5 prep) padded runs with two pads per window: Float32 up to 96 k-steps (ComplexF32: 64)
+                        if (g.T == 40) return fir_mm_launch<R, CS, CH, 40, true>(f, a, g, st);
+                        if (g.T == 48) return fir_mm_launch<R, CS, CH, 48, true>(f, a, g, st);
+                        if (g.T == 64) return fir_mm_launch<R, CS, CH, 64, true>(f, a, g, st);
+                        if constexpr (CS == 1) {
+                            if (g.T == 80) return fir_mm_launch<R, CS, CH, 80, true>(f, a, g, st);
+                            if (g.T == 96) return fir_mm_launch<R, CS, CH, 96, true>(f, a, g, st);
+                        }
+                        MDSP_FAIL(MDSP_ERR_ASSERTION, "no padded-run instantiation for %d k-steps", g.T);
+                    }
                     if (g.T == 40) return fir_mm_launch<R, CS, CH, 40>(f, a, g, st);
                     if (g.T == 80) return fir_mm_launch<R, CS, CH, 80>(f, a, g, st);
                     if (g.T == 96) return fir_mm_launch<R, CS, CH, 96>(f, a, g, st);
                 } else {
+                    if (g.rowpad > 0) {   // Float64 up to 48 k-steps (ComplexF64: 32 -- one pad, above)
+                        if constexpr (CS == 1) {
+                            if (g.T == 40) return fir_mm_launch<R, CS, CH, 40, true>(f, a, g, st);
+                            if (g.T == 48) return fir_mm_launch<R, CS, CH, 48, true>(f, a, g, st);
+                        }
+                        MDSP_FAIL(MDSP_ERR_ASSERTION, "no padded-run instantiation for %d k-steps", g.T);
+                    }
                     if (g.T == 40) return fir_mm_launch<R, CS, CH, 40>(f, a, g, st);
                     if constexpr (CS == 1) { if (g.T == 48) return fir_mm_launch<R, CS, CH, 48>(f, a, g, st); }
                 }
