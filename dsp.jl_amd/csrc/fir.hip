@@ -35,6 +35,10 @@
 using namespace mdsp;
 using mdsp::fft::cx;
 
+// The SI load / store optimizer per KERNEL (round 5 prep; round 4 switched it off for this whole file): merged ds_read2_b64 run at half rate and cost
+// FIRArbitrary 8 %, 160//441 Float32 7 %, but the matrix-core kernel's fetched-tap and padded-run forms LOSE 6 - 13 % without the pass
+// (profiles/r04_fir_lso_ab.json).  A function attribute decides it, and a body inlined into a kernel takes the kernel's setting.
+#define MDSP_NO_LSO __attribute__((target("no-load-store-opt")))
 namespace {
 
 template <typename R> __device__ __forceinline__ R to_acc(float v, R*) { return (R)v; }
@@ -76,7 +80,7 @@ struct FirArgs {
 
 // XS: storage type of x (float, double, cx<float>, cx<double>);  A: accumulate/output type (R or cx<R>)
 template <typename XS, typename A, typename R>
-__global__ __launch_bounds__(256) void polyphase_fir_kernel(FirArgs a) {
+MDSP_NO_LSO __global__ __launch_bounds__(256) void polyphase_fir_kernel(FirArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     A* zs = reinterpret_cast<A*>(smem);                                  // staged input span (converted to A)
     R* ps = reinterpret_cast<R*>(smem + (size_t)a.span * sizeof(A));      // pfbT (optional)
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void polyphase_fir_kernel(FirArgs a) {
 
 // history update (shiftin!, util.jl:299-314): new = last hl samples of [old ; x]
 template <typename XS>
-__global__ __launch_bounds__(256) void shiftin_kernel(const XS* __restrict__ x, const XS* __restrict__ old, XS* __restrict__ neu, int64_t xlen,
+MDSP_NO_LSO __global__ __launch_bounds__(256) void shiftin_kernel(const XS* __restrict__ x, const XS* __restrict__ old, XS* __restrict__ neu, int64_t xlen,
                                                       int64_t ldx, int hl) {
     const int64_t ch = blockIdx.y;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < hl; k += gridDim.x * blockDim.x) {
@@ -157,7 +161,7 @@ struct FirFastArgs {
 };
 
 template <int TPC, int P>
-__global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
+MDSP_NO_LSO __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
     constexpr int W = TPC + P - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* zs = reinterpret_cast<float*>(smem);
@@ -368,7 +372,7 @@ template <> struct Mm<double> {
 // RP: padded runs (a separate instantiation: the two forms of the product loop in one function cost the plain form 20 - 70 VGPRs)
 // NBLK > 1: a multiplying wave owns NBLK column blocks (L > 192) with the taps of ALL of them in registers (T k-steps each)
 template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1>
-__global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
+__device__ __forceinline__ void polyphase_mfma_body(const FirMArgs& a) {
     typedef typename Mm<R>::acc_t acc_t;
     constexpr int DW = (int)(sizeof(R) / 4) * CS;   // dwords per sample
     constexpr int VW = 16 / (int)sizeof(R);         // R elements per 16-byte store
@@ -681,6 +685,11 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     __syncthreads();
     if (prev_tile >= 0) copy_out(prev_tile, zout + (cur ^ 1) * osz);
 }
+// the two kernels around the body: taps in registers on a plain run -> no merged LDS reads; fetched taps (T = 0) and padded runs -> the pass stays on
+template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1>
+MDSP_NO_LSO __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) { polyphase_mfma_body<R, CS, CH, T, RP, NBLK>(a); }
+template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1>
+__global__ __launch_bounds__(1024) void polyphase_mfma_kernel_lso(FirMArgs a) { polyphase_mfma_body<R, CS, CH, T, RP, NBLK>(a); }
 
 int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 
@@ -873,7 +882,7 @@ __device__ __forceinline__ void arb_tile_staged(const ArbRecs rec, const Tap2<R>
 
 // (the second launch bound: four workgroups per CU -- what the 38 KiB of LDS of the Float32 four-channel form admit -- need <= 128 VGPRs)
 template <typename XS, typename A, typename R, int NCH>
-__global__ __launch_bounds__(256, (sizeof(A) * NCH <= 16 ? 4 : 1)) void arbitrary_fir_kernel(ArbArgs a) {
+MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(A) * NCH <= 16 ? 4 : 1)) void arbitrary_fir_kernel(ArbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ArbRecs rec{reinterpret_cast<double*>(smem), reinterpret_cast<int*>(smem + (size_t)arb_rec_slot(a.tile) * sizeof(double))};
     A* zs = reinterpret_cast<A*>(smem + arb_rec_bytes(a.tile));
@@ -1059,7 +1068,7 @@ __global__ __launch_bounds__(256, (sizeof(A) * NCH <= 16 ? 4 : 1)) void arbitrar
 // the reference to the last fused-multiply-add.
 // ------------------------------------------------------------------------------------------------------------
 template <typename A, typename R>
-__global__ __launch_bounds__(256) void tdfir_state_out_kernel(const A* __restrict__ x, const A* __restrict__ si0, A* __restrict__ y, const R* __restrict__ b,
+MDSP_NO_LSO __global__ __launch_bounds__(256) void tdfir_state_out_kernel(const A* __restrict__ x, const A* __restrict__ si0, A* __restrict__ y, const R* __restrict__ b,
                                                               int64_t nx, int64_t ldx, int64_t ldy, int nb) {
     const int64_t col = blockIdx.y;
     const A* xc = x + col * ldx;
@@ -1081,7 +1090,7 @@ __global__ __launch_bounds__(256) void tdfir_state_out_kernel(const A* __restric
 
 // one workgroup per column; every thread first computes its new registers (reading the OLD state), then all write
 template <typename A, typename R>
-__global__ __launch_bounds__(256) void tdfir_state_next_kernel(const A* __restrict__ x, A* __restrict__ si, const R* __restrict__ b, int64_t N, int64_t ldx,
+MDSP_NO_LSO __global__ __launch_bounds__(256) void tdfir_state_next_kernel(const A* __restrict__ x, A* __restrict__ si, const R* __restrict__ b, int64_t N, int64_t ldx,
                                                                int nb) {
     constexpr int MAXPER = 16;   // nb - 1 <= 256 * MAXPER
     const int64_t col = blockIdx.x;
@@ -1116,7 +1125,7 @@ __global__ __launch_bounds__(256) void tdfir_state_next_kernel(const A* __restri
 
 // extrapolate_signal! (Filters/filt.jl:243-257): out = [2 x[1] .- x[pad+1:-1:2]; x; 2 x[end] .- x[end-1:-1:end-pad]]
 template <typename A>
-__global__ __launch_bounds__(256) void extrapolate_kernel(const A* __restrict__ x, A* __restrict__ out, int64_t n, int64_t ldx, int64_t ldo, int64_t pad) {
+MDSP_NO_LSO __global__ __launch_bounds__(256) void extrapolate_kernel(const A* __restrict__ x, A* __restrict__ out, int64_t n, int64_t ldx, int64_t ldo, int64_t pad) {
     const int64_t col = blockIdx.y;
     const A* xc = x + col * ldx;
     A* oc = out + col * ldo;
@@ -1546,7 +1555,9 @@ template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1> int 
     b.memprio = tunables().fir_mm_prio >= 0 ? tunables().fir_mm_prio : (g.NBW == g.NB ? 1 : 0);
     b.ablate = MDSP_DBG(ablate);
     const int nw = g.NBW * g.NG + g.nd + g.ns;
-    auto kern = polyphase_mfma_kernel<R, CS, CH, T, RP, NBLK>;
+    void (*kern)(FirMArgs);
+    if constexpr (T == 0 || RP) kern = polyphase_mfma_kernel_lso<R, CS, CH, T, RP, NBLK>;
+    else kern = polyphase_mfma_kernel<R, CS, CH, T, RP, NBLK>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB
     int dev = 0;
     MDSP_HIP(hipGetDevice(&dev));
