@@ -82,6 +82,8 @@ static void read_tunables_locked() {
     t.fir_mm_prio = geti("MDSP_FIR_MM_PRIO", -1);
     t.fir_mm_t64 = geti("MDSP_FIR_MM_T64", 1);
     t.fir_mm_tight = geti("MDSP_FIR_MM_TIGHT", 1);
+    t.fir_mm_rpx = geti("MDSP_FIR_MM_RPX", 0);
+    t.fir_mm_tiewaves = geti("MDSP_FIR_MM_TIEWAVES", 0);
     t.fir_mm_nblk = geti("MDSP_FIR_MM_NBLK", 1);
     t.fir_mm_nd = geti("MDSP_FIR_MM_ND", 0);
     t.fir_mm_ns = geti("MDSP_FIR_MM_NS", 0);

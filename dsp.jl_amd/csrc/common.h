@@ -135,6 +135,8 @@ struct Tunables {
                                         //                            k-steps whatever the chunk count; default: fewer chunks per wave, taps in registers)
     int fir_mm_tight = 1;               // MDSP_FIR_MM_TIGHT=0      : no last-resort tile forms (shorter rows for L < 16, the 40-step Float32 register form): shapes that do not
                                         //                            fit the LDS otherwise go to the generic kernel, as up to round 3
+    int fir_mm_rpx = 0;                 // MDSP_FIR_MM_RPX=1        : (round 5 prep, unmeasured) padded runs also for fetched taps and for register forms whose window meets two pads
+    int fir_mm_tiewaves = 0;            // MDSP_FIR_MM_TIEWAVES=1   : (round 5 prep) equal tiles at equal cost: the one with more multiplying waves
     int fir_mm_prio = -1;               // MDSP_FIR_MM_PRIO=0|1     : DMA and store waves of the matrix-core kernel at normal / raised priority (default: raised where a
                                         //                            multiplying wave owns one column block)
     int fir_mm_rpad = 0;                // MDSP_FIR_MM_RPAD         : dwords of padding behind a granule of a padded run (0 = 4)

@@ -35,6 +35,10 @@
 using namespace mdsp;
 using mdsp::fft::cx;
 
+// The SI load / store optimizer per KERNEL (round 5 prep; round 4 switched it off for this whole file): merged ds_read2_b64 run at half rate and cost
+// FIRArbitrary 8 %, 160//441 Float32 7 %, but the matrix-core kernel's fetched-tap and padded-run forms LOSE 6 - 13 % without the pass
+// (profiles/r04_fir_lso_ab.json).  A function attribute decides it, and a body inlined into a kernel takes the kernel's setting.
+#define MDSP_NO_LSO __attribute__((target("no-load-store-opt")))
 namespace {
 
 template <typename R> __device__ __forceinline__ R to_acc(float v, R*) { return (R)v; }
@@ -76,7 +80,7 @@ struct FirArgs {
 
 // XS: storage type of x (float, double, cx<float>, cx<double>);  A: accumulate/output type (R or cx<R>)
 template <typename XS, typename A, typename R>
-__global__ __launch_bounds__(256) void polyphase_fir_kernel(FirArgs a) {
+MDSP_NO_LSO __global__ __launch_bounds__(256) void polyphase_fir_kernel(FirArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     A* zs = reinterpret_cast<A*>(smem);                                  // staged input span (converted to A)
     R* ps = reinterpret_cast<R*>(smem + (size_t)a.span * sizeof(A));      // pfbT (optional)
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void polyphase_fir_kernel(FirArgs a) {
 
 // history update (shiftin!, util.jl:299-314): new = last hl samples of [old ; x]
 template <typename XS>
-__global__ __launch_bounds__(256) void shiftin_kernel(const XS* __restrict__ x, const XS* __restrict__ old, XS* __restrict__ neu, int64_t xlen,
+MDSP_NO_LSO __global__ __launch_bounds__(256) void shiftin_kernel(const XS* __restrict__ x, const XS* __restrict__ old, XS* __restrict__ neu, int64_t xlen,
                                                       int64_t ldx, int hl) {
     const int64_t ch = blockIdx.y;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < hl; k += gridDim.x * blockDim.x) {
@@ -157,7 +161,7 @@ struct FirFastArgs {
 };
 
 template <int TPC, int P>
-__global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
+MDSP_NO_LSO __global__ __launch_bounds__(256) void polyphase_fast_kernel(FirFastArgs a) {
     constexpr int W = TPC + P - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* zs = reinterpret_cast<float*>(smem);
@@ -368,7 +372,7 @@ template <> struct Mm<double> {
 // RP: padded runs (a separate instantiation: the two forms of the product loop in one function cost the plain form 20 - 70 VGPRs)
 // NBLK > 1: a multiplying wave owns NBLK column blocks (L > 192) with the taps of ALL of them in registers (T k-steps each)
 template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1>
-__global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
+__device__ __forceinline__ void polyphase_mfma_body(const FirMArgs& a) {
     typedef typename Mm<R>::acc_t acc_t;
     constexpr int DW = (int)(sizeof(R) / 4) * CS;   // dwords per sample
     constexpr int VW = 16 / (int)sizeof(R);         // R elements per 16-byte store
@@ -590,13 +594,15 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                 if constexpr (T != 0 && RP) {
                     // dwords from this lane's first window position to the next granule boundary (16 rows are a whole number of granules,
                     // so the distance is the same for every chunk)
-                    const int th = 256 - (((ra * lj) * a.Mr + c0 + lk) * DW & 255);
+                    const int th = 256 - (((ra * lj + rbase(0)) * a.Mr + c0 + lk) * DW & 255);   // (rbase(0): single-chunk waves need not start on a granule, round 5 prep)
 #pragma unroll
                     for (int t = 0; t < TR; ++t) {
                         const bool hi = 4 * t * DW >= th;
+                        // (round 5 prep) windows longer than a granule -- 4 T DW dwords up to 512 -- meet a second pad: a third base pointer
+                        const bool hi2 = 4 * (T - 1) * DW + DW > 256 && 4 * t * DW >= th + 256;
 #pragma unroll
                         for (int c = 0; c < CH; ++c) {
-                            const R* pp = hi ? ap[c] + padE : ap[c];
+                            const R* pp = hi2 ? ap[c] + 2 * padE : hi ? ap[c] + padE : ap[c];
 #pragma unroll
                             for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(pp[4 * t * CS + p], hreg[T == 0 ? 0 : kb][t], acc[p][c]);
                         }
@@ -614,6 +620,10 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
                     // words are carried RAW into the next group and only then masked: a select next to the fetch would wait for it on the spot.
                     // Measured against masking next to the fetch, alternating processes on one box (tools/r03_session35.sh): ComplexF64 3//8 4.94 -> 4.37 ms,
                     // 1//4 2.99 -> 2.76, 1//8 5.16 -> 5.04; Float32 1//8 +3 %, but 1//16 -7 %, Float64 1//16 -4 %: the carried form for ComplexF64 only.
+                    // (round 5 prep) padded runs with fetched taps: the window spans any number of granules, so the pads in front of a position are
+                    // computed per k-step (one shift and one multiply-add beside a tap fetch and CH matrix instructions; the vector unit idles here)
+                    const int off0 = RP ? (((ra * lj + rbase(0)) * a.Mr + c0 + lk) * DW & 255) : 0;
+                    const auto padx = [&](int t) { return RP ? ((off0 + 4 * t * DW) >> 8) * padE : 0; };
                     if constexpr (MDSP_FIR_TAP_CARRY && CS == 2 && sizeof(R) == 8) {
                     R hraw[8];
                     unsigned okm = 0;
@@ -638,7 +648,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
 #pragma unroll
                             for (int c = 0; c < CH; ++c)
 #pragma unroll
-                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p + padx(t0 + u)], h[u], acc[p][c]);
                     }
                     } else {
                     R h[8];
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
 #pragma unroll
                             for (int c = 0; c < CH; ++c)
 #pragma unroll
-                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p], h[u], acc[p][c]);
+                                for (int p = 0; p < CS; ++p) acc[p][c] = Mm<R>::mfma(ap[c][4 * (t0 + u) * CS + p + padx(t0 + u)], h[u], acc[p][c]);
 #pragma unroll
                         for (int u = 0; u < 8; ++u) h[u] = hn[u];
                     }
@@ -675,6 +685,11 @@ __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) {
     __syncthreads();
     if (prev_tile >= 0) copy_out(prev_tile, zout + (cur ^ 1) * osz);
 }
+// the two kernels around the body: taps in registers on a plain run -> no merged LDS reads; fetched taps (T = 0) and padded runs -> the pass stays on
+template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1>
+MDSP_NO_LSO __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMArgs a) { polyphase_mfma_body<R, CS, CH, T, RP, NBLK>(a); }
+template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1>
+__global__ __launch_bounds__(1024) void polyphase_mfma_kernel_lso(FirMArgs a) { polyphase_mfma_body<R, CS, CH, T, RP, NBLK>(a); }
 
 int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 
@@ -867,7 +882,7 @@ __device__ __forceinline__ void arb_tile_staged(const ArbRecs rec, const Tap2<R>
 
 // (the second launch bound: four workgroups per CU -- what the 38 KiB of LDS of the Float32 four-channel form admit -- need <= 128 VGPRs)
 template <typename XS, typename A, typename R, int NCH>
-__global__ __launch_bounds__(256, (sizeof(A) * NCH <= 16 ? 4 : 1)) void arbitrary_fir_kernel(ArbArgs a) {
+MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(A) * NCH <= 16 ? 4 : 1)) void arbitrary_fir_kernel(ArbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ArbRecs rec{reinterpret_cast<double*>(smem), reinterpret_cast<int*>(smem + (size_t)arb_rec_slot(a.tile) * sizeof(double))};
     A* zs = reinterpret_cast<A*>(smem + arb_rec_bytes(a.tile));
@@ -1053,7 +1068,7 @@ __global__ __launch_bounds__(256, (sizeof(A) * NCH <= 16 ? 4 : 1)) void arbitrar
 // the reference to the last fused-multiply-add.
 // ------------------------------------------------------------------------------------------------------------
 template <typename A, typename R>
-__global__ __launch_bounds__(256) void tdfir_state_out_kernel(const A* __restrict__ x, const A* __restrict__ si0, A* __restrict__ y, const R* __restrict__ b,
+MDSP_NO_LSO __global__ __launch_bounds__(256) void tdfir_state_out_kernel(const A* __restrict__ x, const A* __restrict__ si0, A* __restrict__ y, const R* __restrict__ b,
                                                               int64_t nx, int64_t ldx, int64_t ldy, int nb) {
     const int64_t col = blockIdx.y;
     const A* xc = x + col * ldx;
@@ -1075,7 +1090,7 @@ __global__ __launch_bounds__(256) void tdfir_state_out_kernel(const A* __restric
 
 // one workgroup per column; every thread first computes its new registers (reading the OLD state), then all write
 template <typename A, typename R>
-__global__ __launch_bounds__(256) void tdfir_state_next_kernel(const A* __restrict__ x, A* __restrict__ si, const R* __restrict__ b, int64_t N, int64_t ldx,
+MDSP_NO_LSO __global__ __launch_bounds__(256) void tdfir_state_next_kernel(const A* __restrict__ x, A* __restrict__ si, const R* __restrict__ b, int64_t N, int64_t ldx,
                                                                int nb) {
     constexpr int MAXPER = 16;   // nb - 1 <= 256 * MAXPER
     const int64_t col = blockIdx.x;
@@ -1110,7 +1125,7 @@ __global__ __launch_bounds__(256) void tdfir_state_next_kernel(const A* __restri
 
 // extrapolate_signal! (Filters/filt.jl:243-257): out = [2 x[1] .- x[pad+1:-1:2]; x; 2 x[end] .- x[end-1:-1:end-pad]]
 template <typename A>
-__global__ __launch_bounds__(256) void extrapolate_kernel(const A* __restrict__ x, A* __restrict__ out, int64_t n, int64_t ldx, int64_t ldo, int64_t pad) {
+MDSP_NO_LSO __global__ __launch_bounds__(256) void extrapolate_kernel(const A* __restrict__ x, A* __restrict__ out, int64_t n, int64_t ldx, int64_t ldo, int64_t pad) {
     const int64_t col = blockIdx.y;
     const A* xc = x + col * ldx;
     A* oc = out + col * ldo;
@@ -1414,7 +1429,7 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0)
     //     groups of four chunks for twice as many of two (+12 %, +30 %).  Costs within 3 % of each other go to the larger tile.
     const bool by_model = f->L <= f->M && tunables().fir_mm_ng <= 0 && tunables().fir_mm_ch <= 0;
     double best_score = -1, best_cost = 0;
-    int best_rows = 0;
+    int best_rows = 0, best_mw = 0;
     for (int pad = tunables().fir_mm_pad == 0 ? 0 : 1; pad >= 0 && !g.ok; --pad) {   // (a last resort: output rows without their 16 bytes of padding -- ComplexF64 at 160//147 then fits exactly)
     if (g.NB > 1) g.Lp = 16 * g.NB * g.CS + (pad ? 16 / g.esz : 0);
     else if (!pad) break;
@@ -1439,7 +1454,12 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0)
     for (int mode = 0; mode < 3; ++mode) {   // 0: one linear run per tile, 1: row by row, 2: one run with padded rows
         if (mode >= 1 && ways_lin < 4 && fm < 0) continue;
         if (fm >= 0 && mode != fm) continue;
-        const bool pad_ok = !((g.Mr * dw) & 15) && g.T != 0 && g.T <= 32 && g.T * dw <= 64;   // 16 rows are whole granules; taps in registers; a window (4 T dw dwords) meets one pad at most
+        // 16 rows are whole granules; taps in registers; a window (4 T dw dwords) meets one pad at most.  (round 5 prep, MDSP_FIR_MM_RPX=1: fetched taps
+        // with computed pads, and register forms of single-chunk waves whose window meets two pads at most -- 4 T dw <= 512)
+        const bool rpx = tunables().fir_mm_rpx != 0;
+        const bool gran16 = !((g.Mr * dw) & 15);   // 16 rows are whole granules: every chunk of a wave crosses at the same step (single-chunk waves do not need it)
+        const bool pad_ok = (gran16 && g.T != 0 && g.T <= 32 && g.T * dw <= 64) || (rpx && g.T == 0 && (gran16 || chmax == 1)) ||
+                            (rpx && g.T != 0 && g.NBLK == 1 && g.T * dw <= 128 && chmax == 1);
         if (mode == 2 && !pad_ok) continue;
         if (mode == 1 && fm < 0 && pad_ok && ways_pad <= 2 * ways_row) continue;   // the padded run replaces the row-staged form wherever it applies and spreads the
                                                                                      // rows comparably (rows shorter than a granule share its pad: Mr dw = 16 stays 15-way)
@@ -1462,9 +1482,14 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0)
                 const int mw = g.NBW * ng, trows = rows * ng;
                 const double c_mfma = (g.esz == 8 ? 64.0 : 32.0) * g.CS;
                 const double cost = (((mw + 3) / 4) * (double)ch * cdiv(g.NB, g.NBW) * g.steps * c_mfma * std::max(1.0, 0.2 * ways) + (g.T == 0 ? mw * g.steps * 25.0 : 0.0) + 3900.0) / trows;
-                if (!g.ok || cost < 0.97 * best_cost || (cost < 1.03 * best_cost && trows > best_rows)) {
+                // (round 5 prep, MDSP_FIR_MM_TIEWAVES=1, unmeasured as a rule) equal tiles at equal cost: the one with more multiplying waves -- the k-steps of
+                // a wave are a latency chain (profiles/r04_fir_decim16_pmc.json), and profiles/r04_fir_ch1_ab.json has both tie cases faster that way
+                // (1//16 Float32 1.74 -> 1.46 ms, ComplexF32 1//4 1.01 -> 0.83)
+                const bool tie_waves = tunables().fir_mm_tiewaves != 0 && g.ok && cost < 1.03 * best_cost && trows == best_rows && mw > best_mw;
+                if (!g.ok || cost < 0.97 * best_cost || (cost < 1.03 * best_cost && trows > best_rows) || tie_waves) {
                     best_cost = g.ok ? std::min(best_cost, cost) : cost;
                     best_rows = trows;
+                    best_mw = mw;
                     take();
                 }
             }
@@ -1530,7 +1555,9 @@ template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1> int 
     b.memprio = tunables().fir_mm_prio >= 0 ? tunables().fir_mm_prio : (g.NBW == g.NB ? 1 : 0);
     b.ablate = MDSP_DBG(ablate);
     const int nw = g.NBW * g.NG + g.nd + g.ns;
-    auto kern = polyphase_mfma_kernel<R, CS, CH, T, RP, NBLK>;
+    void (*kern)(FirMArgs);
+    if constexpr (T == 0 || RP) kern = polyphase_mfma_kernel_lso<R, CS, CH, T, RP, NBLK>;
+    else kern = polyphase_mfma_kernel<R, CS, CH, T, RP, NBLK>;
     static std::atomic<unsigned long long> lds_opt_in{0};   // once per instantiation and device (later calls may sit inside a stream capture): the whole 160 KiB
     int dev = 0;
     MDSP_HIP(hipGetDevice(&dev));
@@ -1556,7 +1583,7 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
     }
     if (g.NBLK > 1) MDSP_FAIL(MDSP_ERR_ASSERTION, "no matrix-core instantiation for %d blocks per wave with %d chunks", g.NBLK, CH);
     switch (g.T) {
-        case 0: return fir_mm_launch<R, CS, CH, 0>(f, a, g, st);
+        case 0: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 0, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 0>(f, a, g, st);
         case 4: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 4, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
         case 8: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 8, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 8>(f, a, g, st);
         case 12: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 12, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 12>(f, a, g, st);
@@ -1567,10 +1594,27 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
         default:
             if constexpr (CH == 1) {   // the long register forms exist for single-chunk waves only
                 if constexpr (sizeof(R) == 4) {
+                    if (g.rowpad > 0) {   // (round 5 prep) padded runs with two pads per window: Float32 up to 96 k-steps (ComplexF32: 64)
+                        if (g.T == 40) return fir_mm_launch<R, CS, CH, 40, true>(f, a, g, st);
+                        if (g.T == 48) return fir_mm_launch<R, CS, CH, 48, true>(f, a, g, st);
+                        if (g.T == 64) return fir_mm_launch<R, CS, CH, 64, true>(f, a, g, st);
+                        if constexpr (CS == 1) {
+                            if (g.T == 80) return fir_mm_launch<R, CS, CH, 80, true>(f, a, g, st);
+                            if (g.T == 96) return fir_mm_launch<R, CS, CH, 96, true>(f, a, g, st);
+                        }
+                        MDSP_FAIL(MDSP_ERR_ASSERTION, "no padded-run instantiation for %d k-steps", g.T);
+                    }
                     if (g.T == 40) return fir_mm_launch<R, CS, CH, 40>(f, a, g, st);
                     if (g.T == 80) return fir_mm_launch<R, CS, CH, 80>(f, a, g, st);
                     if (g.T == 96) return fir_mm_launch<R, CS, CH, 96>(f, a, g, st);
                 } else {
+                    if (g.rowpad > 0) {   // Float64 up to 48 k-steps (ComplexF64: 32 -- one pad, above)
+                        if constexpr (CS == 1) {
+                            if (g.T == 40) return fir_mm_launch<R, CS, CH, 40, true>(f, a, g, st);
+                            if (g.T == 48) return fir_mm_launch<R, CS, CH, 48, true>(f, a, g, st);
+                        }
+                        MDSP_FAIL(MDSP_ERR_ASSERTION, "no padded-run instantiation for %d k-steps", g.T);
+                    }
                     if (g.T == 40) return fir_mm_launch<R, CS, CH, 40>(f, a, g, st);
                     if constexpr (CS == 1) { if (g.T == 48) return fir_mm_launch<R, CS, CH, 48>(f, a, g, st); }
                 }

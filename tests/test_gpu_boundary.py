@@ -611,7 +611,8 @@ def test_polyphase_matrix_core_round3_forms_are_bit_identical(d, torch, L, M, nt
     knobs = [{"MDSP_FIR_MM": 1}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_ROWS": 1}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_ROWS": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_ROWS": 2},
              {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_NG": 8}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_PRIO": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_PRIO": 1},
              {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_VSTORE": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_CH": 1},
-             {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_T64": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_NBLK": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_T64": 0, "MDSP_FIR_MM_NBLK": 0}]   # (the last three: round 2's register limits / fetched taps)
+             {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_T64": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_NBLK": 0}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_T64": 0, "MDSP_FIR_MM_NBLK": 0},   # (these three: round 2's register limits / fetched taps)
+             {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_RPX": 1}, {"MDSP_FIR_MM": 1, "MDSP_FIR_MM_RPX": 1, "MDSP_FIR_MM_ROWS": 2}]   # (round 5 prep: padded runs for windows longer than a granule / fetched taps)
     outs = []
     try:
         for kn in knobs:
@@ -635,7 +636,7 @@ def test_polyphase_matrix_core_round3_forms_are_bit_identical(d, torch, L, M, nt
             for k in kn:
                 _lib.set_tunable(k, None)
     finally:
-        for k in ("MDSP_FIR_MM", "MDSP_FIR_MM_ROWS", "MDSP_FIR_MM_NG", "MDSP_FIR_MM_PRIO", "MDSP_FIR_MM_VSTORE", "MDSP_FIR_MM_CH", "MDSP_FIR_MM_T64", "MDSP_FIR_MM_NBLK"):
+        for k in ("MDSP_FIR_MM", "MDSP_FIR_MM_ROWS", "MDSP_FIR_MM_NG", "MDSP_FIR_MM_PRIO", "MDSP_FIR_MM_VSTORE", "MDSP_FIR_MM_CH", "MDSP_FIR_MM_T64", "MDSP_FIR_MM_NBLK", "MDSP_FIR_MM_RPX"):
             _lib.set_tunable(k, None)
     assert len(outs) >= 5
     for kn, y in outs[1:]:

@@ -159,3 +159,55 @@ def test_padded_run_addressing_model():
                                                     #  padded run spreads the rows more than twice as badly, fir_mm_geo)
         if Mr * DW == 160:
             assert ways(PAD) == 4 and ways(0) == 16
+
+
+def test_padded_run_addressing_model_long_windows():
+    """Round 5 prep (MDSP_FIR_MM_RPX=1, unmeasured): the padded run for windows longer than a granule.  Register forms of up to 4 T DW = 512 dwords
+    choose among THREE base pointers (the window start, one pad on from the step that crosses the first granule boundary, two pads on from 256 dwords
+    later), still with immediate offsets; the fetched-tap form (T = 0, windows of any length) computes the pads in front of a position per k-step:
+    ((d0 & 255) + 4 t DW) >> 8.  Every read lands on the sample the plain run would have read."""
+    rng = np.random.default_rng(20260927)
+    PAD = 4
+    cases = 0
+    for _ in range(600):
+        DW = int(rng.choice([1, 2, 4]))
+        Mr = int(rng.integers(1, 64)) * (16 // DW if DW < 16 else 1)
+        if (Mr * DW) % 16:
+            continue
+        fetched = bool(rng.integers(0, 2))
+        T = int(rng.choice([104, 208, 392])) if fetched else int(rng.choice([20, 24, 32, 40, 48, 64, 80, 96]))
+        if not fetched and 4 * T * DW > 512:
+            continue
+        rows = 32
+        ndw = (rows * Mr + Mr + 4 * T + 4) * DW
+        lds = np.full(ndw + PAD * (ndw // 256 + 2), -1, dtype=np.int64)
+        d = np.arange(ndw)
+        lds[d + PAD * (d >> 8)] = d
+        c0 = int(rng.integers(0, Mr))
+        for row in range(rows):
+            for lk in range(4):
+                d0 = (row * Mr + c0 + lk) * DW
+                base = d0 + PAD * (d0 >> 8)
+                th = 256 - (d0 & 255)
+                off0 = d0 & 255
+                for t in range(T):
+                    if fetched:
+                        pads = (off0 + 4 * t * DW) >> 8
+                    else:
+                        pads = 2 if 4 * t * DW >= th + 256 else 1 if 4 * t * DW >= th else 0
+                    for part in range(DW):
+                        assert lds[base + PAD * pads + 4 * t * DW + part] == d0 + 4 * t * DW + part, (DW, Mr, T, fetched, row, lk, t)
+        cases += 1
+    assert cases > 100
+    # what it buys where the round-4 counters put the conflicts: 1//16 Float32 (rows 240 dwords apart) eight-way -> three-way, 1//8 (88) four-way -> two-way
+    def ways(stride, pad):
+        cnt = {}
+        for i in range(16):
+            dd = i * stride
+            for k in range(4):
+                b = (dd + pad * (dd >> 8) + k) % 32
+                cnt[b] = cnt.get(b, 0) + 1
+        return max(cnt.values())
+    assert ways(240, 0) == 8 and ways(240, PAD) == 3
+    assert ways(88, 0) == 4 and ways(88, PAD) <= 3
+
