@@ -68,8 +68,12 @@ static void read_tunables_locked() {
     t.ols_prefetch = geti("MDSP_OLS_PREFETCH", 0);
     t.gen_wide = geti("MDSP_GEN_WIDE", 1);
     t.bigfft = geti("MDSP_BIGFFT", 1);
-    t.big_chunk_mib = std::max(1, geti("MDSP_BIG_CHUNK_MIB", 64));
+    t.big_chunk_mib = std::max(1, geti("MDSP_BIG_CHUNK_MIB", 1024));
     t.big_groups = std::max(0, geti("MDSP_BIG_GROUPS", 0));
+    t.big_wgs = std::max(0, geti("MDSP_BIG_WGS", 0));
+    t.big_ablate = geti("MDSP_BIG_ABLATE", 0);
+    t.big_rmax = std::min(512, std::max(16, geti("MDSP_BIG_RMAX", 512)));
+    t.big_fast = geti("MDSP_BIG_FAST", 1);
     t.fir_p = geti("MDSP_FIR_P", 0);
     t.fir_mm = geti("MDSP_FIR_MM", -1);
     t.fir_exact = geti("MDSP_FIR_EXACT", 0);

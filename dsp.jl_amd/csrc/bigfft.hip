@@ -9,8 +9,10 @@
 //
 // HBM traffic per transform of N complex points (Float32: 8 N bytes): pass 0 reads the frames (and the window) and writes 8 N, every middle
 // pass reads and writes 8 N in place, the last pass reads 8 N -- against window + three rocFFT kernels + abs2 over separate buffers before.
-// Transforms are processed in groups small enough (MDSP_BIG_CHUNK_MIB) that a group's work buffer can stay in the 256 MiB Infinity Cache from
-// one pass to the next.
+// Transforms are processed in groups of MDSP_BIG_CHUNK_MIB of work buffer (default 1 GiB: the default call's 8 transforms of 2^24 points in one
+// group).  Measured on the default Welch call at 2^27 samples (profiles/r05_bigfft_sessions.json): 1.77 ms with everything in one group against
+// 2.7 ms with a 128 MiB group -- fewer launches and one accumulator update instead of eight; no Infinity Cache effect was visible at any size.
+// The same profile has the bound of the three-pass form: loads 1.0 ms + stores 0.5 ms + butterflies 0.5 ms when each runs alone, 1.8 ms together.
 //
 // Real signals ride two frames per transform (z = w (a + i b), as in the single-workgroup kernels): Welch needs no untangling, columns are
 // untangled by big_untangle_kernel from the natural-order spectrum the last pass leaves.
@@ -33,6 +35,7 @@ struct Engine {
     int P = 0;
     Pass pass[MAXP];
     DevBuf tables, work, nat, partial, winR;
+    const double* win_src = nullptr;   // the Float64 window winR was converted from
 };
 EngineHolder::~EngineHolder() { delete p; }
 
@@ -50,41 +53,51 @@ template <typename R> struct BigArgs {
     int n, psd, accumulate, acc_add;
     int64_t nout;
     R m1;
+    int out_mode;       // the two-stage kernel: OUT of big_pass_kernel as a run-time value (0, 2, 3)
+    int ablate;         // MDSP_BIG_ABLATE (profiling; results are garbage): 1 no sub-transforms, 2 no stores, 4 no loads after the first item, 8 no tile twiddles
 };
 
 // OUT 0: twiddled results back into the work buffer (every pass but the last)
 // OUT 1: Welch -- |Z|^2 summed over the launch's transforms of this group in registers (Float64), one row of N per group
 // OUT 2: complex signal -- the frame's column: raw spectrum or |Z|^2 / r
 // OUT 3: natural-order spectrum into `out` (real signals' columns: untangled by big_untangle_kernel)
-template <typename R, int OUT> __global__ __launch_bounds__(TPB, 2) void big_pass_kernel(const BigArgs<R> a) {
-    constexpr int B = cols<R>(), Bp = B + 1, E = elems<R>();
+// E: elements per thread (R_p B <= E TPB).  grid = (tile lanes, transform groups): a workgroup walks tiles blockIdx.x, + gridDim.x, ... and for each
+// the transforms blockIdx.y, + gridDim.y, ... of the launch; OUT 1 is launched with one tile per workgroup (its sums belong to the tile).
+// The NEXT item's elements are loaded into registers before this item's sub-transform starts: first measured without that (and with two table
+// reads per element for the twiddles), a workgroup spent 21 us per tile, two thirds of it waiting (profiles/r05_bigfft_first.txt).
+// (sub-transforms above 256 points fill the LDS with ONE workgroup per CU: that form may use the whole register file)
+template <typename R, int OUT, int E> __global__ __launch_bounds__(TPB, (E < elems<R>() ? 2 : 1)) void big_pass_kernel(const BigArgs<R> a) {
+    constexpr int B = cols<R>(), Bp = B + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
     const Pass& p = a.p;
     cx<R>* bufA = reinterpret_cast<cx<R>*>(big_smem);
     cx<R>* bufB = bufA + p.Rp * Bp;
     cx<R>* rootsL = bufB + p.Rp * Bp;
+    cx<R>* twc = rootsL + p.Rp;
     const int tid = threadIdx.x;
     {   // the sub-transform's roots: R_p entries, read by every butterfly of every sub-pass
         const cx<R>* g = static_cast<const cx<R>*>(p.roots);
         for (int i = tid; i < p.Rp; i += TPB) fft::st2(rootsL + i, g[i]);
     }
-    const Tile tc = tile_of<R>(p, (int64_t)blockIdx.x);
     const int64_t N = p.N;
+    cx<R> twb[E];
+    if (!p.last) load_twb<R, E>(p, tid, twb);
     [[maybe_unused]] double acc[OUT == 1 ? E : 1];
     if constexpr (OUT == 1) {
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = 0.0;
     }
-    __syncthreads();
-    for (int64_t t = blockIdx.y; t < a.ntrans; t += gridDim.y) {
+    cx<R> pre[E];
+    auto fetch = [&](int64_t tile, int64_t t) __attribute__((always_inline)) {
+        const Tile tc = tile_of<R>(p, tile);
         const int64_t u = a.t0 + t;
         if (a.in_mode == 0) {
             const cx<R>* src = a.buf + t * N;
-            phase_load<R>(p, tc, tid, bufA, [&](int64_t pos) { return src[pos]; });
+            load_regs<R, E>(p, tc, tid, pre, [&](int64_t pos) { return src[pos]; });
         } else if (a.in_mode == 1) {   // K4, two frames: z = w (a + i b); frame b may not exist (odd K), the tail past n is zero
             const R* fa = static_cast<const R*>(a.s) + 2 * u * a.hop;
             const bool haveB = 2 * u + 1 < a.K;
-            phase_load<R>(p, tc, tid, bufA, [&](int64_t pos) {
+            load_regs<R, E>(p, tc, tid, pre, [&](int64_t pos) {
                 cx<R> z = {(R)0, (R)0};
                 if (pos < a.n) {
                     const R w = a.win ? a.win[pos] : (R)1;
@@ -95,7 +108,7 @@ template <typename R, int OUT> __global__ __launch_bounds__(TPB, 2) void big_pas
             });
         } else {
             const cx<R>* fa = static_cast<const cx<R>*>(a.s) + u * a.hop;
-            phase_load<R>(p, tc, tid, bufA, [&](int64_t pos) {
+            load_regs<R, E>(p, tc, tid, pre, [&](int64_t pos) {
                 cx<R> z = {(R)0, (R)0};
                 if (pos < a.n) {
                     const R w = a.win ? a.win[pos] : (R)1;
@@ -105,23 +118,45 @@ template <typename R, int OUT> __global__ __launch_bounds__(TPB, 2) void big_pas
                 return z;
             });
         }
+    };
+    int64_t tile = blockIdx.x, t = blockIdx.y;
+    bool have = tile < p.ntiles && t < a.ntrans;
+    if (have) fetch(tile, t);
+    int64_t twc_tile = -1;
+    __syncthreads();
+    while (have) {
+        const Tile tc = tile_of<R>(p, tile);
+        const int64_t u = a.t0 + t;
+        regs_to_lds<R, E>(p, tid, pre, bufA);
+        if (!p.last && tile != twc_tile && !(a.ablate & 8)) {   // (rewritten only behind the barrier that ends the previous item's stores)
+            fill_twc<R>(p, tc, tid, twc);
+            twc_tile = tile;
+        }
+        int64_t nt = t + gridDim.y, ntile = tile;
+        if (nt >= a.ntrans) {
+            nt = blockIdx.y;
+            ntile = tile + gridDim.x;
+        }
+        const bool nhave = ntile < p.ntiles;
+        if (nhave && !(a.ablate & 4)) fetch(ntile, nt);   // in flight while this item is transformed
         __syncthreads();
         cx<R>*src = bufA, *dst = bufB;
-        for (int sp = 0; sp < p.nsub; ++sp) {
+        for (int sp = 0; sp < ((a.ablate & 1) ? 0 : p.nsub); ++sp) {
             phase_sub<R>(p, sp, tid, src, dst, rootsL);
             __syncthreads();
             cx<R>* tmp = src;
             src = dst;
             dst = tmp;
         }
-        if constexpr (OUT == 0) {
+        if (a.ablate & 2) {
+        } else if constexpr (OUT == 0) {
             cx<R>* o = a.buf + t * N;
-            phase_store<R, false>(p, tc, tid, src, [&](int, int64_t pos, cx<R> z) { o[pos] = z; });
+            phase_store<R, E>(p, tc, tid, src, twc, twb, [&](int, int64_t pos, cx<R> z) { o[pos] = z; });
         } else if constexpr (OUT == 1) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
-            phase_store<R, true>(p, tc, tid, src, [&](int e, int64_t, cx<R> z) { acc[e] += (double)(z.x * z.x + z.y * z.y); });
+            phase_store<R, E>(p, tc, tid, src, twc, twb, [&](int e, int64_t, cx<R> z) { acc[e] += (double)(z.x * z.x + z.y * z.y); });
         } else if constexpr (OUT == 2) {
             const int64_t o0 = u * a.ldo;
-            phase_store<R, false>(p, tc, tid, src, [&](int, int64_t k, cx<R> z) {
+            phase_store<R, E>(p, tc, tid, src, twc, twb, [&](int, int64_t k, cx<R> z) {
                 if (k < a.nout) {
                     if (a.psd) {
                         R* o = static_cast<R*>(a.out) + o0 + k;
@@ -132,13 +167,145 @@ template <typename R, int OUT> __global__ __launch_bounds__(TPB, 2) void big_pas
             });
         } else {
             cx<R>* o = static_cast<cx<R>*>(a.out) + t * N;
-            phase_store<R, false>(p, tc, tid, src, [&](int, int64_t k, cx<R> z) { o[k] = z; });
+            phase_store<R, E>(p, tc, tid, src, twc, twb, [&](int, int64_t k, cx<R> z) { o[k] = z; });
         }
-        __syncthreads();   // the buffer the stores read is the one the next transform's loads or first sub-pass write
+        __syncthreads();   // the buffer the stores read is the one the next item's samples or first sub-pass write
+        tile = ntile;
+        t = nt;
+        have = nhave;
     }
-    if constexpr (OUT == 1) {
-        double* row = static_cast<double*>(a.out) + (int64_t)blockIdx.y * N;
-        phase_store<R, true>(p, tc, tid, bufA, [&](int e, int64_t k, cx<R>) { row[k] = a.acc_add ? row[k] + acc[e] : acc[e]; });
+    if constexpr (OUT == 1) {   // one tile per workgroup (gridDim.x == ntiles)
+        if (blockIdx.x < p.ntiles) {
+            const Tile tc = tile_of<R>(p, (int64_t)blockIdx.x);
+            double* row = static_cast<double*>(a.out) + (int64_t)blockIdx.y * N;
+            phase_store<R, E>(p, tc, tid, bufA, twc, twb, [&](int e, int64_t k, cx<R>) { row[k] = a.acc_add ? row[k] + acc[e] : acc[e]; });
+        }
+    }
+}
+
+// The same pass with the sub-transform as two register stages around ONE LDS exchange (bigfft_pass.h "two-stage sub-transforms"): R_p = RA x TJ,
+// tiles of 256 / TJ columns.  Two exchange buffers alternate from item to item, so an item costs one barrier (the last pass: two -- its elements
+// reach the owners of their rows through LDS first).  out_mode: 0 / 2 / 3 as OUT of big_pass_kernel; WELCH is its OUT 1.
+template <typename R, bool WELCH, int RA, int TJ>
+__global__ __launch_bounds__(TPB, (sizeof(R) == 4 ? 2 : 1)) void big_fast_kernel(const BigArgs<R> a) {
+    using G = FastGeo<RA, TJ>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+    const Pass& p = a.p;
+    cx<R>* buf0 = reinterpret_cast<cx<R>*>(big_smem);
+    cx<R>* buf1 = buf0 + G::Rp * G::Bp;
+    cx<R>* twc0 = buf1 + G::Rp * G::Bp;
+    cx<R>* twc1 = twc0 + G::Rp;
+    const int tid = threadIdx.x;
+    const int64_t N = p.N;
+    cx<R> rt[TJ], twb[TJ];
+    fast_roots<R, RA, TJ>(p, tid, rt);
+    if (!p.last) fast_twb<R, RA, TJ>(p, tid, twb);
+    [[maybe_unused]] double acc[WELCH ? TJ : 1];
+    if constexpr (WELCH) {
+#pragma unroll
+        for (int e = 0; e < TJ; ++e) acc[e] = 0.0;
+    }
+    cx<R> pre[RA];
+    // MDSP_BIG_ABLATE (profiling; garbage results): 1 no butterflies, 2 no stores, 4 no loads after the first item, 8 no tile twiddles,
+    // 16 every tile a contiguous block of the buffer (the same bytes without the strided access pattern; passes other than the last)
+    auto tile_at = [&](int64_t tile) __attribute__((always_inline)) {
+        Tile tc = tile_of_b<R>(p, tile, G::B);
+        if ((a.ablate & 16) && !p.last) {
+            tc.base = tile * (G::Rp * G::B);
+            tc.row_stride = G::B;
+        }
+        return tc;
+    };
+    auto fetch = [&](int64_t tile, int64_t t) __attribute__((always_inline)) {
+        const Tile tc = tile_at(tile);
+        const int64_t u = a.t0 + t;
+        if (a.in_mode == 0) {
+            const cx<R>* src = a.buf + t * N;
+            fast_load<R, RA, TJ>(p, tc, tid, pre, [&](int64_t pos) { return src[pos]; });
+        } else if (a.in_mode == 1) {   // K4, two frames: z = w (a + i b); frame b may not exist (odd K), the tail past n is zero
+            const R* fa = static_cast<const R*>(a.s) + 2 * u * a.hop;
+            const bool haveB = 2 * u + 1 < a.K;
+            fast_load<R, RA, TJ>(p, tc, tid, pre, [&](int64_t pos) {
+                cx<R> z = {(R)0, (R)0};
+                if (pos < a.n) {
+                    const R w = a.win ? a.win[pos] : (R)1;
+                    z.x = fa[pos] * w;
+                    if (haveB) z.y = fa[pos + a.hop] * w;
+                }
+                return z;
+            });
+        } else {
+            const cx<R>* fa = static_cast<const cx<R>*>(a.s) + u * a.hop;
+            fast_load<R, RA, TJ>(p, tc, tid, pre, [&](int64_t pos) {
+                cx<R> z = {(R)0, (R)0};
+                if (pos < a.n) {
+                    const R w = a.win ? a.win[pos] : (R)1;
+                    const cx<R> v = fa[pos];
+                    z = {v.x * w, v.y * w};
+                }
+                return z;
+            });
+        }
+    };
+    int64_t tile = blockIdx.x, t = blockIdx.y;
+    bool have = tile < p.ntiles && t < a.ntrans;
+    if (have) fetch(tile, t);
+    for (int it = 0; have; ++it) {
+        const Tile tc = tile_at(tile);
+        const int64_t u = a.t0 + t;
+        cx<R>* X = p.last ? buf1 : ((it & 1) ? buf1 : buf0);
+        cx<R>* twc = (it & 1) ? twc1 : twc0;
+        if (!p.last && !(a.ablate & 8)) fill_twc<R>(p, tc, tid, twc);
+        int64_t nt = t + gridDim.y, ntile = tile;
+        if (nt >= a.ntrans) {
+            nt = blockIdx.y;
+            ntile = tile + gridDim.x;
+        }
+        const bool nhave = ntile < p.ntiles;
+        if (p.last) {
+            fast_stage_put<R, RA, TJ>(tid, pre, buf0);
+            __syncthreads();
+            fast_stage_get<R, RA, TJ>(tid, pre, buf0);
+        }
+        fast_stage1<R, RA, TJ>(tid, pre, X);
+        if (nhave && !(a.ablate & 4)) fetch(ntile, nt);   // the next item's samples take over the registers stage 1 has just emptied: in flight through the barrier, stage 2 and the stores
+        __syncthreads();
+        cx<R> y[TJ];
+        fast_stage2<R, RA, TJ>(tid, X, rt, y);
+        if (a.ablate & 2) {
+        } else if constexpr (WELCH) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
+            fast_store<R, RA, TJ>(p, tc, tid, y, twc, twb, [&](int e, int64_t, cx<R> z) { acc[e] += (double)(z.x * z.x + z.y * z.y); });
+        } else if (a.out_mode == 0) {
+            cx<R>* o = a.buf + t * N;
+            fast_store<R, RA, TJ>(p, tc, tid, y, twc, twb, [&](int, int64_t pos, cx<R> z) { o[pos] = z; });
+        } else if (a.out_mode == 2) {
+            const int64_t o0 = u * a.ldo;
+            fast_store<R, RA, TJ>(p, tc, tid, y, twc, twb, [&](int, int64_t k, cx<R> z) {
+                if (k < a.nout) {
+                    if (a.psd) {
+                        R* o = static_cast<R*>(a.out) + o0 + k;
+                        const R pw = z.x * z.x + z.y * z.y;
+                        *o = a.accumulate ? fma(pw, a.m1, *o) : pw * a.m1;   // fft2pow!: out = muladd(abs2, m, out)
+                    } else static_cast<cx<R>*>(a.out)[o0 + k] = z;
+                }
+            });
+        } else {
+            cx<R>* o = static_cast<cx<R>*>(a.out) + t * N;
+            fast_store<R, RA, TJ>(p, tc, tid, y, twc, twb, [&](int, int64_t k, cx<R> z) { o[k] = z; });
+        }
+        tile = ntile;
+        t = nt;
+        have = nhave;
+    }
+    if constexpr (WELCH) {   // one tile per workgroup (gridDim.x == ntiles)
+        if (blockIdx.x < p.ntiles) {
+            const Tile tc = tile_of_b<R>(p, (int64_t)blockIdx.x, G::B);
+            double* row = static_cast<double*>(a.out) + (int64_t)blockIdx.y * N;
+            cx<R> y[TJ];
+#pragma unroll
+            for (int e = 0; e < TJ; ++e) y[e] = {(R)0, (R)0};
+            fast_store<R, RA, TJ>(p, tc, tid, y, twc0, twb, [&](int e, int64_t k, cx<R>) { row[k] = a.acc_add ? row[k] + acc[e] : acc[e]; });
+        }
     }
 }
 
@@ -195,7 +362,7 @@ __global__ __launch_bounds__(256) void big_untangle_kernel(const cx<R>* __restri
 
 template <typename R> int build(Engine* e) {
     HostPlan<R> hp;
-    if (!make_plan<R>(e->nfft, hp)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%lld does not split into 2..4 factors of at most %d", (long long)e->nfft, RMAX);
+    if (!make_plan<R>(e->nfft, hp, tunables().big_rmax, tunables().big_fast != 0)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%lld does not split into 2..4 factors of at most %d", (long long)e->nfft, RMAX);
     size_t total = 0;
     auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
     for (int p = 0; p < hp.P; ++p) total += al(hp.roots[p].size()) + al(hp.T0[p].size()) + al(hp.T1[p].size());
@@ -236,14 +403,40 @@ int get_engine(EngineHolder& h, int dtype, int64_t n, int64_t nfft, Engine** out
     return MDSP_OK;
 }
 
-template <typename R, int OUT> int launch_pass(const BigArgs<R>& a, int groups, hipStream_t st) {
+template <typename R, int OUT, int E> int launch_pass_e(const BigArgs<R>& a, int lanes, int groups, hipStream_t st) {
     constexpr int Bp = cols<R>() + 1;
-    auto kern = big_pass_kernel<R, OUT>;
-    const size_t lds_bytes = sizeof(cx<R>) * ((size_t)2 * a.p.Rp * Bp + (size_t)a.p.Rp);
+    auto kern = big_pass_kernel<R, OUT, E>;
+    const size_t lds_bytes = sizeof(cx<R>) * ((size_t)2 * a.p.Rp * Bp + (size_t)2 * a.p.Rp);
     if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.p.ntiles, (unsigned)groups), dim3(TPB), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)lanes, (unsigned)groups), dim3(TPB), lds_bytes, st, a);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
+}
+template <typename R, bool WELCH, int RA, int TJ> int launch_fast(const BigArgs<R>& a, int lanes, int groups, hipStream_t st) {
+    using G = FastGeo<RA, TJ>;
+    auto kern = big_fast_kernel<R, WELCH, RA, TJ>;
+    const size_t lds_bytes = sizeof(cx<R>) * ((size_t)2 * G::Rp * G::Bp + (size_t)2 * G::Rp);
+    if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)lanes, (unsigned)groups), dim3(TPB), lds_bytes, st, a);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+// lanes: workgroups along the tiles (each walks tiles lane, lane + lanes, ...); OUT 1 takes one tile per workgroup
+template <typename R, int OUT> int launch_pass(const BigArgs<R>& a0, int lanes, int groups, hipStream_t st) {
+    constexpr int EH = elems<R>() / 2;   // sub-transforms up to 256 points: half the elements per thread (and half the registers of samples in flight)
+    if (OUT == 1) lanes = (int)a0.p.ntiles;
+    if (a0.p.fTJ) {   // the two-stage register form
+        BigArgs<R> a = a0;
+        a.out_mode = OUT;
+        constexpr bool W = OUT == 1;
+        if (a.p.fRA == 16) return launch_fast<R, W, 16, 16>(a, lanes, groups, st);
+        if (a.p.fRA == 8 && a.p.fTJ == 16) return launch_fast<R, W, 8, 16>(a, lanes, groups, st);
+        if (a.p.fRA == 8) return launch_fast<R, W, 8, 8>(a, lanes, groups, st);
+        return launch_fast<R, W, 4, 8>(a, lanes, groups, st);
+    }
+    const BigArgs<R>& a = a0;
+    if (a.p.Rp * cols<R>() <= EH * TPB) return launch_pass_e<R, OUT, EH>(a, lanes, groups, st);
+    return launch_pass_e<R, OUT, elems<R>()>(a, lanes, groups, st);
 }
 
 // mode 0: Welch sums into acc; 1: columns
@@ -256,10 +449,14 @@ int run(Engine* e, int mode, const void* s, int64_t K, int64_t hop, const double
     const R* win = nullptr;
     if (win_dev) {
         if constexpr (sizeof(R) == 8) win = reinterpret_cast<const R*>(win_dev);
-        else {   // Float32 signals: the window rounded to Float32 first, as the single-workgroup kernels do -- and half the bytes per frame
-            MDSP_TRY(e->winR.reserve(sizeof(R) * (size_t)e->n));
-            hipLaunchKernelGGL(big_window_kernel<R>, dim3((unsigned)cdiv(e->n, 256)), dim3(256), 0, st, win_dev, e->winR.as<R>(), e->n);
-            MDSP_LAUNCH_CHECK();
+        else {   // Float32 signals: the window rounded to Float32 first, as the single-workgroup kernels do -- and half the bytes per frame.
+                 // Converted once per window (a plan's window never changes; a multitaper plan walks its tapers, one pointer each).
+            if (e->win_src != win_dev) {
+                MDSP_TRY(e->winR.reserve(sizeof(R) * (size_t)e->n));
+                hipLaunchKernelGGL(big_window_kernel<R>, dim3((unsigned)cdiv(e->n, 256)), dim3(256), 0, st, win_dev, e->winR.as<R>(), e->n);
+                MDSP_LAUNCH_CHECK();
+                e->win_src = win_dev;
+            }
             win = e->winR.as<R>();
         }
     }
@@ -289,31 +486,35 @@ int run(Engine* e, int mode, const void* s, int64_t K, int64_t hop, const double
             a.psd = psd;
             a.accumulate = accumulate;
             a.m1 = (R)(1.0 / r);
-            int groups = tunables().big_groups > 0 ? tunables().big_groups : (int)cdiv((int64_t)4 * cus, a.p.ntiles);
+            a.ablate = tunables().big_ablate;
+            // workgroups: `wgs` per CU resident (two fit: LDS), each walking several (tile, transform) items with the next one's samples in flight
+            const int64_t wgs = (int64_t)cus * (tunables().big_wgs > 0 ? tunables().big_wgs : ((a.p.Rp > RMAX / 2 || (a.p.fTJ && sizeof(R) == 8)) ? 1 : (a.p.fTJ && a.p.Rp <= 64 ? 4 : 2)));
+            int groups = tunables().big_groups > 0 ? tunables().big_groups : (int)cdiv(wgs, a.p.ntiles);
             groups = (int)std::max<int64_t>(1, std::min<int64_t>(groups, cnt));
+            const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(a.p.ntiles, wgs / groups));
             if (p < e->P - 1) {
-                MDSP_TRY((launch_pass<R, 0>(a, groups, st)));
+                MDSP_TRY((launch_pass<R, 0>(a, lanes, groups, st)));
             } else if (mode == 0) {
                 groups = std::min(groups, 32);
                 if (groups == 1) {
                     a.out = acc;
                     a.acc_add = add ? 1 : 0;
-                    MDSP_TRY((launch_pass<R, 1>(a, 1, st)));
+                    MDSP_TRY((launch_pass<R, 1>(a, lanes, 1, st)));
                 } else {
                     MDSP_TRY(e->partial.reserve(sizeof(double) * (size_t)groups * (size_t)N));
                     a.out = e->partial.p;
                     a.acc_add = 0;
-                    MDSP_TRY((launch_pass<R, 1>(a, groups, st)));
+                    MDSP_TRY((launch_pass<R, 1>(a, lanes, groups, st)));
                     hipLaunchKernelGGL(big_reduce_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, e->partial.as<double>(), acc, N, groups, add ? 1 : 0);
                     MDSP_LAUNCH_CHECK();
                 }
                 add = true;
             } else if (!untangle) {
                 a.out = out;
-                MDSP_TRY((launch_pass<R, 2>(a, groups, st)));
+                MDSP_TRY((launch_pass<R, 2>(a, lanes, groups, st)));
             } else {
                 a.out = e->nat.p;
-                MDSP_TRY((launch_pass<R, 3>(a, groups, st)));
+                MDSP_TRY((launch_pass<R, 3>(a, lanes, groups, st)));
                 hipLaunchKernelGGL(big_untangle_kernel<R>, dim3((unsigned)cdiv(nout, 256), (unsigned)cnt), dim3(256), 0, st, e->nat.as<cx<R>>(), out, N, c0, K, ldo,
                                    nout, psd, accumulate, onesided, (R)(1.0 / r), (R)(2.0 / r));
                 MDSP_LAUNCH_CHECK();
@@ -332,7 +533,7 @@ bool size_ok(int dtype, int64_t nfft) {
     (void)dtype;
     if (nfft <= 4096 || nfft >= ((int64_t)1 << 31) || !seven_smooth(nfft)) return false;
     int R[MAXP];
-    return factorise(nfft, R) >= 2;
+    return factorise(nfft, R, tunables().big_rmax) >= 2;
 }
 
 int welch(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, int64_t K, int64_t hop, const double* win_dev, double* acc, bool fresh,

@@ -36,7 +36,7 @@ constexpr int MAXP = 4;        // passes of the large transform
 constexpr int MAXSUB = 8;      // passes of a sub-transform
 constexpr int RMAX = 512;      // longest sub-transform
 template <typename R> constexpr int cols() { return sizeof(R) == 4 ? 16 : 8; }             // B: columns per tile (128-byte rows either way)
-template <typename R> constexpr int elems() { return RMAX * cols<R>() / TPB; }             // elements per thread at most (32 / 16)
+template <typename R> constexpr int elems() { return RMAX * cols<R>() / TPB; }             // elements per thread at most (32 / 16); sub-transforms up to 256 points need half
 
 struct Pass {
     int64_t N;            // transform length
@@ -44,6 +44,8 @@ struct Pass {
     int64_t tpp, ntiles;  // tiles per prefix block (last pass: per value of `rest`), tiles per transform
     int64_t Q;            // last pass: runs per k_0 = N / (R_0 R_p)
     int Rp, R0, last;
+    int B;                // columns per tile: cols<R>() for the generic phases, 256 / TJ for the two-stage form
+    int fRA, fTJ;         // two-stage form: R_p = fRA x fTJ (0: generic phases)
     unsigned divR;        // ceil(2^24 / Rp): idx div Rp == (idx * divR) >> 24 for idx < 8192
     int nd;               // last pass: digits of `rest` (k_{P-2} fastest .. k_1), their radices and natural weights M_q
     int dR[MAXP];
@@ -88,34 +90,62 @@ template <typename R> MDSP_HD Tile tile_of(const Pass& p, int64_t tile) {
     return t;
 }
 
-// ---- phase 1: the tile into LDS as [row][B + 1] ----------------------------------------------------------------------------------------
-// get(pos) -> cx<R>: element `pos` of the transform's input (the work buffer, or the windowed frames)
-template <typename R, typename F> MDSP_HD void phase_load(const Pass& p, const Tile& t, int tid, cx<R>* lds, F&& get) {
-    constexpr int B = cols<R>(), Bp = B + 1, U = 8;   // U loads in flight per thread and trip (the loop is NOT unrolled further: 32 x (value + 64-bit address) would not fit)
-    const int total = p.Rp * B;
-#pragma unroll 1
-    for (int e0 = tid; e0 < total; e0 += U * TPB) {
-        cx<R> v[U];
-        int at[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = e0 + TPB * u;
-            int r, b;
-            if (!p.last) {   // lanes along the columns: rows of B consecutive elements
-                b = idx & (B - 1);
-                r = idx / B;
-            } else {         // lanes along a run
-                b = (int)(((unsigned long long)(unsigned)idx * p.divR) >> 24);
-                r = idx - b * p.Rp;
-            }
-            at[u] = idx < total ? r * Bp + b : -1;
-            v[u] = {(R)0, (R)0};
-            if (idx < total && b < t.ncols) v[u] = get(t.base + (int64_t)r * t.row_stride + (int64_t)b * t.col_stride);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (at[u] >= 0) fft::st2(lds + at[u], v[u]);
+// ---- phase 1: the tile into registers, then into LDS as [row][B + 1] ---------------------------------------------------------------------
+// A thread's element e (E of them, E * TPB >= R_p * B):  not the last pass: column b = tid mod B, row r = tid div B + (TPB / B) e -- lanes along
+// the columns, rows of B consecutive elements;  the last pass: idx = tid + TPB e, b = idx div R_p, r = idx mod R_p -- lanes along a run.
+// The two halves are separate so that a kernel can have the NEXT tile's loads in flight while it transforms this one.
+template <typename R> MDSP_HD bool elem_of(const Pass& p, int tid, int e, int& r, int& b) {
+    constexpr int B = cols<R>();
+    if (!p.last) {
+        b = tid & (B - 1);
+        r = tid / B + (TPB / B) * e;
+        return r < p.Rp;
     }
+    const int idx = tid + TPB * e;
+    b = (int)(((unsigned long long)(unsigned)idx * p.divR) >> 24);
+    r = idx - b * p.Rp;
+    return idx < p.Rp * B;
+}
+// get(pos) -> cx<R>: element `pos` of the transform's input (the work buffer, or the windowed frames)
+template <typename R, int E, typename F> MDSP_HD void load_regs(const Pass& p, const Tile& t, int tid, cx<R> (&v)[E], F&& get) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int r, b;
+        const bool in = elem_of<R>(p, tid, e, r, b);
+        v[e] = {(R)0, (R)0};
+        if (in && b < t.ncols) v[e] = get(t.base + (int64_t)r * t.row_stride + (int64_t)b * t.col_stride);
+    }
+}
+template <typename R, int E> MDSP_HD void regs_to_lds(const Pass& p, int tid, const cx<R> (&v)[E], cx<R>* lds) {
+    constexpr int Bp = cols<R>() + 1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int r, b;
+        if (elem_of<R>(p, tid, e, r, b)) fft::st2(lds + r * Bp + b, v[e]);
+    }
+}
+
+// ---- twiddles behind a pass: W_{N_p}^{(c0 + b) r} = W^{c0 r} W^{b r} ------------------------------------------------------------------------
+// W^{b r} belongs to the thread (its b and rows never change): E registers, filled once per kernel.  W^{c0 r} belongs to the tile: R_p values,
+// one table walk per THREAD and tile, shared through LDS -- instead of two scattered table reads per ELEMENT (which kept the L1 busier than the
+// data did: profiles/r05_bigfft_first.txt).
+template <typename R> MDSP_HD cx<R> big_root(const Pass& p, unsigned m) {   // W_{N_p}^m, m < N_p
+    const cx<R>*T0 = static_cast<const cx<R>*>(p.T0), *T1 = static_cast<const cx<R>*>(p.T1);
+    cx<R> w = T0[m & ((1u << p.logS) - 1u)];
+    if (p.nT1 > 1) w = fft::cmul(w, T1[m >> p.logS]);
+    return w;
+}
+template <typename R, int E> MDSP_HD void load_twb(const Pass& p, int tid, cx<R> (&twb)[E]) {
+    constexpr int B = cols<R>();
+    const unsigned b = (unsigned)(tid & (B - 1));
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned r = (unsigned)(tid / B + (TPB / B) * e);
+        twb[e] = big_root<R>(p, r < (unsigned)p.Rp ? b * r : 0u);
+    }
+}
+template <typename R> MDSP_HD void fill_twc(const Pass& p, const Tile& t, int tid, cx<R>* twc) {
+    for (int r = tid; r < p.Rp; r += TPB) fft::st2(twc + r, big_root<R>(p, (unsigned)t.c0 * (unsigned)r));   // c0 r < S_p R_p = N_p < 2^31
 }
 
 // ---- phase 2: one pass of the B sub-transforms, LDS -> LDS -----------------------------------------------------------------------------
@@ -161,38 +191,155 @@ template <typename R> MDSP_HD void phase_sub(const Pass& p, int sp, int tid, con
 }
 
 // ---- phase 3: results out of LDS, lanes along the columns ------------------------------------------------------------------------------
-// not the last pass:  put(e, pos, z)  with the twiddle W_{N_p}^{(c0 + b) r} applied, pos = the element's own place in the work buffer
+// not the last pass:  put(e, pos, z)  with the twiddle W_{N_p}^{(c0 + b) r} = twc[r] twb[e] applied, pos = the element's own place in the work buffer
 // the last pass:      put(e, k, z)    with k the natural index of the bin
-// ALL: the loop over a thread's elements fully unrolled, so that `e` is a constant for the caller (register accumulators of the Welch form)
-template <typename R, bool ALL, typename F> MDSP_HD void phase_store(const Pass& p, const Tile& t, int tid, const cx<R>* lds, F&& put) {
-    constexpr int B = cols<R>(), Bp = B + 1, E = elems<R>(), TJ = TPB / B, U = ALL ? E : 4;
+// (`e` is a compile-time constant for the caller: the register accumulators of the Welch form)
+template <typename R, int E, typename F>
+MDSP_HD void phase_store(const Pass& p, const Tile& t, int tid, const cx<R>* lds, const cx<R>* twc, const cx<R> (&twb)[E], F&& put) {
+    constexpr int B = cols<R>(), Bp = B + 1, TJ = TPB / B;
     const int b = tid & (B - 1), tj = tid / B;
     if (b >= t.ncols) return;
-    const cx<R>*T0 = static_cast<const cx<R>*>(p.T0), *T1 = static_cast<const cx<R>*>(p.T1);
-    const unsigned mask = (1u << p.logS) - 1u;
     const int64_t rs = p.last ? p.N / p.Rp : t.row_stride;
     const int64_t o0 = p.last ? t.c0 + b + t.nat : t.base + b;
-#pragma unroll 1
-    for (int e0 = 0; e0 < E && tj + TJ * e0 < p.Rp; e0 += U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u, r = tj + TJ * e;
-            if (r < p.Rp) {
-                cx<R> z = fft::ld2(lds + r * Bp + b);
-                if (!p.last) {
-                    const unsigned m = (unsigned)(t.c0 + b) * (unsigned)r;   // < N_p < 2^31
-                    if (m != 0u) {
-                        cx<R> w = T0[m & mask];
-                        if (p.nT1 > 1) w = fft::cmul(w, T1[m >> p.logS]);
-                        z = fft::cmul(z, w);
-                    }
-                }
-                put(ALL ? u : e, o0 + (int64_t)r * rs, z);
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-            if (ALL && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four LDS reads in flight, not all 32 (their registers come on top of the accumulators)
-#endif
+    for (int e = 0; e < E; ++e) {
+        const int r = tj + TJ * e;
+        if (r < p.Rp) {
+            cx<R> z = fft::ld2(lds + r * Bp + b);
+            if (!p.last) z = fft::cmul(z, fft::cmul(fft::ld2(twc + r), twb[e]));
+            put(e, o0 + (int64_t)r * rs, z);
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four elements in flight at a time (their registers come on top of accumulators and prefetched samples)
+#endif
+    }
+}
+
+// ================================================================================================ two-stage sub-transforms in registers
+// The generic phases above move every element through LDS four times (tile in, two or three sub-passes, tile out) with a barrier behind each
+// step, and a workgroup spent two thirds of its time waiting (profiles/r05_bigfft_first.txt).  For R_p = RA x TJ -- 256 = 16 x 16, 128 = 8 x 16,
+// 64 = 8 x 8, 32 = 4 x 8 -- the Stockham pair needs ONE exchange, as in the single-workgroup kernels (fft_lds.h):
+//   * a column's TJ threads (B = 256 / TJ columns per tile) each hold rows tj + TJ q, q < RA, straight from their coalesced loads: those are the
+//     operands of butterfly tj of the first stage (radix RA) -- no staging;
+//   * its results go to LDS rows tj RA + q; after the one barrier, thread tj < RA reads rows tj + RA q, q < TJ, multiplies by W_{R_p}^{q tj}
+//     (loop-invariant per thread) and runs butterfly tj of the second stage (radix TJ): it now holds rows tj + RA q' in natural order, which
+//     leave for memory from registers with the inter-pass twiddle applied.
+// The last pass reads its runs coalesced along the run, so its elements take one extra trip through LDS to reach the owner of their row.
+template <int RA, int TJ> struct FastGeo {
+    static constexpr int Rp = RA * TJ, B = TPB / TJ, Bp = B + 1;
+    static_assert(TPB % TJ == 0 && RA <= TJ, "stage 2 runs on the first RA threads of a column");
+};
+
+template <typename R> MDSP_HD Tile tile_of_b(const Pass& p, int64_t tile, int B) {
+    Tile t;
+    if (!p.last) {
+        const int64_t prefix = tile / p.tpp, c0 = (tile - prefix * p.tpp) * B;
+        t.base = prefix * p.Np + c0;
+        t.row_stride = p.Sp;
+        t.col_stride = 1;
+        t.c0 = c0;
+        t.nat = 0;
+        t.ncols = (int)((p.Sp - c0) < B ? (p.Sp - c0) : B);
+    } else {
+        const int64_t rest = tile / p.tpp, k00 = (tile - rest * p.tpp) * B;
+        t.base = (k00 * p.Q + rest) * p.Rp;
+        t.row_stride = 1;
+        t.col_stride = p.Q * p.Rp;
+        t.c0 = k00;
+        int64_t rem = rest, nat = 0;
+        for (int d = 0; d < p.nd; ++d) {
+            const int64_t dig = rem % p.dR[d];
+            rem /= p.dR[d];
+            nat += dig * p.dM[d];
+        }
+        t.nat = nat;
+        t.ncols = (int)((p.R0 - k00) < B ? (p.R0 - k00) : B);
+    }
+    return t;
+}
+
+// a thread's RA input elements.  Not the last pass: (row tj + TJ q, column b);  the last pass: element idx = tid + TPB q of the tile counted
+// along the runs (column idx div R_p, row idx mod R_p)
+template <typename R, int RA, int TJ, typename F> MDSP_HD void fast_load(const Pass& p, const Tile& t, int tid, cx<R> (&v)[RA], F&& get) {
+    using G = FastGeo<RA, TJ>;
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+        int r, b;
+        if (!p.last) {
+            b = tid % G::B;
+            r = tid / G::B + TJ * q;
+        } else {
+            const int idx = tid + TPB * q;
+            b = idx / G::Rp;
+            r = idx % G::Rp;
+        }
+        v[q] = {(R)0, (R)0};
+        if (b < t.ncols) v[q] = get(t.base + (int64_t)r * t.row_stride + (int64_t)b * t.col_stride);
+    }
+}
+// the last pass only: elements to the owners of their rows through `stage` (a barrier between the two halves)
+template <typename R, int RA, int TJ> MDSP_HD void fast_stage_put(int tid, const cx<R> (&v)[RA], cx<R>* stage) {
+    using G = FastGeo<RA, TJ>;
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+        const int idx = tid + TPB * q;
+        fft::st2(stage + (idx % G::Rp) * G::Bp + idx / G::Rp, v[q]);
+    }
+}
+template <typename R, int RA, int TJ> MDSP_HD void fast_stage_get(int tid, cx<R> (&v)[RA], const cx<R>* stage) {
+    using G = FastGeo<RA, TJ>;
+    const int b = tid % G::B, tj = tid / G::B;
+#pragma unroll
+    for (int q = 0; q < RA; ++q) v[q] = fft::ld2(stage + (tj + TJ * q) * G::Bp + b);
+}
+// stage 1: butterfly tj (radix RA) on the thread's own rows; results to LDS rows tj RA + q
+template <typename R, int RA, int TJ> MDSP_HD void fast_stage1(int tid, cx<R> (&v)[RA], cx<R>* lds) {
+    using G = FastGeo<RA, TJ>;
+    const int b = tid % G::B, tj = tid / G::B;
+    fft::gen_bfly<RA>(v);
+#pragma unroll
+    for (int q = 0; q < RA; ++q) fft::st2(lds + (tj * RA + q) * G::Bp + b, v[q]);
+}
+// the thread's loop-invariant second-stage twiddles W_{R_p}^{q tj}, q = 1 .. TJ - 1 (rt[0] unused)
+template <typename R, int RA, int TJ> MDSP_HD void fast_roots(const Pass& p, int tid, cx<R> (&rt)[TJ]) {
+    using G = FastGeo<RA, TJ>;
+    const int tj = tid / G::B;
+    const cx<R>* roots = static_cast<const cx<R>*>(p.roots);
+#pragma unroll
+    for (int q = 0; q < TJ; ++q) rt[q] = roots[tj < RA ? (q * tj) % G::Rp : 0];
+}
+// stage 2 (threads tj < RA): rows tj + RA q from LDS, twiddles, butterfly tj (radix TJ): y[q'] = row tj + RA q' of the sub-transform
+template <typename R, int RA, int TJ> MDSP_HD void fast_stage2(int tid, const cx<R>* lds, const cx<R> (&rt)[TJ], cx<R> (&y)[TJ]) {
+    using G = FastGeo<RA, TJ>;
+    const int b = tid % G::B, tj = tid / G::B;
+    if (tj >= RA) return;
+#pragma unroll
+    for (int q = 0; q < TJ; ++q) y[q] = fft::ld2(lds + (tj + RA * q) * G::Bp + b);
+#pragma unroll
+    for (int q = 1; q < TJ; ++q) y[q] = fft::cmul(y[q], rt[q]);
+    fft::gen_bfly<TJ>(y);
+}
+// W_{N_p}^{b r} for the thread's output rows r = tj + RA e
+template <typename R, int RA, int TJ> MDSP_HD void fast_twb(const Pass& p, int tid, cx<R> (&twb)[TJ]) {
+    using G = FastGeo<RA, TJ>;
+    const unsigned b = (unsigned)(tid % G::B), tj = (unsigned)(tid / G::B);
+#pragma unroll
+    for (int e = 0; e < TJ; ++e) twb[e] = big_root<R>(p, tj < (unsigned)RA ? b * (tj + RA * e) : 0u);
+}
+// results out of registers: put(e, pos or k, z) as phase_store
+template <typename R, int RA, int TJ, typename F>
+MDSP_HD void fast_store(const Pass& p, const Tile& t, int tid, const cx<R> (&y)[TJ], const cx<R>* twc, const cx<R> (&twb)[TJ], F&& put) {
+    using G = FastGeo<RA, TJ>;
+    const int b = tid % G::B, tj = tid / G::B;
+    if (tj >= RA || b >= t.ncols) return;
+    const int64_t rs = p.last ? p.N / p.Rp : t.row_stride;
+    const int64_t o0 = p.last ? t.c0 + b + t.nat : t.base + b;
+#pragma unroll
+    for (int e = 0; e < TJ; ++e) {
+        const int r = tj + RA * e;
+        cx<R> z = y[e];
+        if (!p.last) z = fft::cmul(z, fft::cmul(fft::ld2(twc + r), twb[e]));
+        put(e, o0 + (int64_t)r * rs, z);
     }
 }
 

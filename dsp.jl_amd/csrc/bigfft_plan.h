@@ -67,6 +67,35 @@ inline int sub_schedule(int R, bool dbl, int* radix, int* ns, unsigned* divm) {
 // N = R_0 ... R_{P-1}: fewest passes (2..MAXP), every factor in [2, RMAX]; among those the split whose smallest factor is largest, then the one
 // whose largest factor is smallest; factors in non-decreasing order (the widest sub-transform runs over contiguous memory in the last pass).
 inline int factorise(int64_t N, int* R, int rmax = RMAX) {
+    if ((N & (N - 1)) == 0 && rmax >= 64) {   // powers of two: factors the two-stage form takes (256 and 64 are its square geometries; 128 and 32 idle half of
+                                              // a column's threads in the second stage; 512 runs the generic phases) -- fewest passes, then fewest non-square factors
+        int k = 0;
+        while (((int64_t)1 << k) < N) ++k;
+        // (512 is never taken for a power of two: 2^17 as 32 x 64 x 64, three two-stage passes, measured 0.098 TB/s against 0.080 for 256 x 512 with the
+        // generic phases in the second pass -- profiles/r05_bigfft_sessions.json)
+        const int lgmax = rmax >= 256 ? 8 : rmax >= 128 ? 7 : 6;
+        int bestP = 0, bestOdd = 0, bestE[MAXP] = {0, 0, 0, 0}, e[MAXP];
+        for (int P = 2; P <= MAXP && !bestP; ++P) {
+            // non-decreasing exponents e[0] <= ... <= e[P-1] in [5, lgmax] summing to k
+            for (e[0] = 5; e[0] <= lgmax; ++e[0])
+                for (e[1] = e[0]; e[1] <= lgmax; ++e[1])
+                    for (e[2] = P > 2 ? e[1] : 0; e[2] <= (P > 2 ? lgmax : 0); ++e[2])
+                        for (e[3] = P > 3 ? e[2] : 0; e[3] <= (P > 3 ? lgmax : 0); ++e[3]) {
+                            int sum = 0, odd = 0;
+                            for (int i = 0; i < P; ++i) sum += e[i], odd += (e[i] != 8 && e[i] != 6) ? (e[i] == 9 ? 2 : 1) : 0;
+                            if (sum != k) continue;
+                            if (!bestP || odd < bestOdd) {
+                                bestP = P;
+                                bestOdd = odd;
+                                for (int i = 0; i < P; ++i) bestE[i] = e[i];
+                            }
+                        }
+        }
+        if (bestP) {
+            for (int i = 0; i < bestP; ++i) R[i] = 1 << bestE[i];
+            return bestP;
+        }
+    }
     std::vector<int> best, cur;
     struct Rec {
         std::vector<int>&best, &cur;
@@ -110,8 +139,7 @@ template <typename R> struct HostPlan {
 };
 
 // false: N cannot be planned (a prime factor above 7, or a factor that no schedule covers)
-template <typename R> bool make_plan(int64_t N, HostPlan<R>& hp, int rmax = RMAX) {
-    constexpr int B = cols<R>();
+template <typename R> bool make_plan(int64_t N, HostPlan<R>& hp, int rmax = RMAX, bool fast = true) {
     constexpr bool dbl = sizeof(R) == 8;
     if (N < 4 || N >= ((int64_t)1 << 31) || !seven_smooth(N)) return false;
     int Rf[MAXP];
@@ -137,6 +165,16 @@ template <typename R> bool make_plan(int64_t N, HostPlan<R>& hp, int rmax = RMAX
         for (int k = p + 1; k < P; ++k) S *= Rf[k];
         q.Sp = S;
         q.Np = S * q.Rp;
+        // the two-stage register form (bigfft_pass.h) where the sub-transform is 256 / 128 / 64 / 32 points; its tiles have 256 / TJ columns
+        q.fRA = q.fTJ = 0;
+        if (fast) {
+            if (q.Rp == 256) q.fRA = 16, q.fTJ = 16;
+            else if (q.Rp == 128) q.fRA = 8, q.fTJ = 16;
+            else if (q.Rp == 64) q.fRA = 8, q.fTJ = 8;
+            else if (q.Rp == 32) q.fRA = 4, q.fTJ = 8;
+        }
+        const int B = q.fTJ ? TPB / q.fTJ : cols<R>();
+        q.B = B;
         if (!q.last) {
             q.tpp = (S + B - 1) / B;
             q.ntiles = (N / q.Np) * q.tpp;

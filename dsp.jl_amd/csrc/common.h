@@ -148,7 +148,12 @@ struct Tunables {
     int gen_wide = 1;                   // MDSP_GEN_WIDE=0          : nextfastfft sizes: round 3's schedules of small radices instead of the three-pass composite-radix ones
     int ols_prefetch = 0;               // MDSP_OLS_PREFETCH=1      : overlap-save kernel with software prefetch of the next unit (default: off)
     int bigfft = 1;                     // MDSP_BIGFFT=0            : transforms above the one-workgroup sizes go to the rocFFT pipeline instead of the multi-pass fused engine (bigfft.hip)
-    int big_chunk_mib = 64;             // MDSP_BIG_CHUNK_MIB       : work buffer of the multi-pass engine per launch group (small enough to stay in the Infinity Cache between passes)
+    int big_chunk_mib = 1024;           // MDSP_BIG_CHUNK_MIB       : work buffer of the multi-pass engine per launch group.  Measured 16 .. 2048 MiB (profiles/r05_bigfft_sessions.json):
+                                        //                            larger is faster up to all transforms in one group (fewer launches, one accumulator update); no Infinity Cache effect seen
+    int big_wgs = 0;                    // MDSP_BIG_WGS             : workgroups per CU of its pass kernels (0 = 2, what the LDS admits)
+    int big_rmax = 512;                 // MDSP_BIG_RMAX            : longest sub-transform of its passes (512; 256 / 128 / 64 force more, shorter passes)
+    int big_fast = 1;                   // MDSP_BIG_FAST=0          : generic LDS phases also where the two-stage register form applies (sub-transforms of 32 .. 256 points)
+    int big_ablate = 0;                 // MDSP_BIG_ABLATE          : profiling only (results are garbage): phases of its pass kernels switched off, see bigfft.hip
     int big_groups = 0;                 // MDSP_BIG_GROUPS          : transform groups per launch of its passes (0 = enough workgroups for four per CU)
     int plan_cache_total = 8 * MDSP_PLAN_CACHE_SIZE;   // MDSP_PLAN_CACHE_TOTAL : entries in the whole plan cache above which idle partitions are trimmed
     int plan_cache_idle = 64;           // MDSP_PLAN_CACHE_IDLE     : cache requests without one of its own after which a partition counts as idle

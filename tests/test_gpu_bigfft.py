@@ -126,7 +126,7 @@ def test_default_arguments_take_the_multipass_engine(d, torch):
         n = length >> 3
         nfft = outil.nextfastfft(n)
         K = opg.frame_count(length, n, n >> 1)
-        assert K == 15
+        assert K == (15 if n % 2 == 0 else 14)     # hop = n - (n >> 1): an odd n loses the fifteenth frame
         cfg = d.WelchConfig(length, np.float32, window=None)
         assert (cfg.nsamples, cfg.noverlap, cfg.nfft, cfg.engine) == (n, n >> 1, nfft, d.ENGINE_FUSED)
         got = d.welch_pgram(s, window=None)
@@ -135,7 +135,7 @@ def test_default_arguments_take_the_multipass_engine(d, torch):
         assert relerr(got.power, ref.power) < TOL32 and ulps_of_max(got.power, ref.power) < _ulp_bound(nfft)
         sp = d.spectrogram(s)
         rs = opg.spectrogram(s, n, n >> 1, dtype=np.float64)
-        assert sp.power.shape == rs.power.shape == (nfft // 2 + 1, 15) and relerr(sp.power, rs.power) < TOL32
+        assert sp.power.shape == rs.power.shape == (nfft // 2 + 1, K) and relerr(sp.power, rs.power) < TOL32
         assert np.array_equal(sp.time, rs.time)
         st = d.stft(s)
         rt = opg.stft(s, n, n >> 1, dtype=np.float64)

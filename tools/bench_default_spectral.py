@@ -57,7 +57,7 @@ for length in lengths:
     nfft = util.nextfastfft(n)
     K = d.frame_count(length, n, nov)
     r = {"n": n, "nfft": nfft, "frames": K}
-    for eng, ename in ((d.ENGINE_AUTO, "auto"), (d.ENGINE_ROCFFT, "rocfft")):
+    for eng, ename in [e for e in ((d.ENGINE_AUTO, "auto"), (d.ENGINE_ROCFFT, "rocfft")) if e[1] in os.environ.get("DEFSPEC_ENGINES", "auto,rocfft").split(",")]:
         cfg = d.WelchConfig(length, npdt, n=n, noverlap=nov, nfft=nfft, window=d.hanning, engine=eng)
         psd = torch.empty(cfg.nout, dtype=tdt, device="cuda")
         ms = timeit(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, x.data_ptr(), length, 1, length, psd.data_ptr(), cfg.nout, stream)))
@@ -72,6 +72,8 @@ for length in lengths:
                 del os.environ["MDSP_BIG_CHUNK_MIB"]
                 _lib.check(lib.mdsp_reload_tunables())
         del cfg, psd
+        if os.environ.get("DEFSPEC_WELCH_ONLY"):
+            continue
         win, norm2 = compute_window(d.hanning, n)
         for psd_only, name, osz in ((1, "spectrogram", esz), (0, "stft", 2 * esz)):
             plan = _StftPlan(n, nov, nfft, win, norm2, True, psd_only, npdt, eng)
