@@ -128,6 +128,9 @@ struct Tunables {
     int fir_mm = -1;                    // MDSP_FIR_MM=0            : matrix-core polyphase kernel off (default: wherever the shape fits)
     int fir_exact = 0;                  // MDSP_FIR_EXACT=1         : polyphase filters run the generic kernel only -- every output reads exactly its own tapsPerPhi-sample
                                         //                            window (stream_filt.jl:496-509), so a NaN / Inf sample leaves exactly the reference's hole
+    int fir_dec = 1;                    // MDSP_FIR_DEC=0|2|3       : 0 = decimators (L = 1) on the matrix-core / register-tap kernels as up to round 4; default: the phase-per-lane
+                                        //                            decimator kernel where it measured faster; 2 = its run-time M form for every M; 3 = the kernel for every M <= 64
+    int fir_dec_ablate = 0;             // MDSP_FIR_DEC_ABLATE      : profiling only: phases of the decimator kernel switched off (fir.hip)
     int fir_mm_rows = -1;               // MDSP_FIR_MM_ROWS=0|1|2   : its tiles staged as one run / row by row / one run with padded rows (default: by cost; padded rows
                                         //                            where the rows' sample stride is bank-hostile)
     int fir_mm_nblk = 1;                // MDSP_FIR_MM_NBLK=0       : L > 192: the taps of a wave's column blocks fetched per tile (round 2) instead of all in registers

@@ -691,6 +691,181 @@ MDSP_NO_LSO __global__ __launch_bounds__(1024) void polyphase_mfma_kernel(FirMAr
 template <typename R, int CS, int CH, int T, bool RP = false, int NBLK = 1>
 __global__ __launch_bounds__(1024) void polyphase_mfma_kernel_lso(FirMArgs a) { polyphase_mfma_body<R, CS, CH, T, RP, NBLK>(a); }
 
+// ------------------------------------------------------------------------------------------------------------
+// Decimator kernel (round 5): L = 1, any M <= 64, any filter length.  FIRDecimator (stream_filt.jl:43-56, :522-558) is the commonest multirate
+// call and was the matrix-core kernel's worst shape: its product has 15 M structural-zero rows, the taps do not fit registers and the row stride M
+// is bank-hostile (1//16 Float32 at 0.08 of the HBM roof, 87 % of the LDS cycles bank conflicts: profiles/r04_fir_decim16_pmc.json).
+//
+//     y[m] = sum_i h'[i] z[c + m M + i]     (h' = pfbT, the taps oldest sample first; z = [history ; x]; c = d0 - 1 + phi0 - 1)
+//          = sum_{r < M}  sum_q h'[M q + r] z[c + M (m + q) + r]
+//
+// A lane owns ONE PHASE r of the M-decimated input: its inner sum is a short correlation (ceil(tp / M) taps) over every M-th sample, and the M
+// lanes of a group read M CONSECUTIVE samples per step -- conflict-free whatever M is.  Per block of P = 16 outputs and chunk of QC = 8 taps a
+// lane reads P + QC - 1 samples and QC taps from LDS for P QC multiply-adds; the M partial sums of an output meet through LDS (one write per
+// lane and output, M reads by the lane that stores it).  Multiply-adds are packed pairs: a complex sample is one (real taps), and a real signal
+// pairs the two halves of its tile (the staging loop writes sample k of the first half next to sample k of the second).
+// Every output reads exactly its own tp-sample window, as the reference does: the zero taps that pad the last chunk are masked, not multiplied.
+// The summation order differs from the reference's oldest-first chain (phases first, then across phases): results agree to rounding, state
+// (history, phase, deficit) stays bit-exact -- it never was arithmetic.
+// ------------------------------------------------------------------------------------------------------------
+template <typename R> struct DecV { R x, y; };
+__device__ __forceinline__ DecV<float> dec_fma(DecV<float> w, float g, DecV<float> a) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v d = __builtin_elementwise_fma(f2v{w.x, w.y}, f2v{g, g}, f2v{a.x, a.y});
+    return {d.x, d.y};
+}
+__device__ __forceinline__ DecV<double> dec_fma(DecV<double> w, double g, DecV<double> a) { return {fma(w.x, g, a.x), fma(w.y, g, a.y)}; }
+
+struct DecArgs {
+    const void* x;
+    const void* hist;
+    void* y;
+    const void* pfbT;      // tp taps, oldest sample first
+    int64_t xlen, ldx, ldy, nout, zb;   // zb: index into [history ; x] of the first sample of output 0's window
+    int M, Mp, logMp, tp, hl;
+    int nq;                // ceil(tp / M) tap steps; the LDS tap table is padded to a multiple of QC steps
+    int nbh;               // blocks of P outputs per half tile (real signals: a tile is two halves) / per tile (complex)
+    int nz;                // staged samples per (half) tile
+    unsigned blkmagic;     // ceil(2^32 / (P M)): k div (P M) == umulhi(k, blkmagic) for the staged indices
+    int ablate;            // MDSP_FIR_DEC_ABLATE (profiling; garbage results): 1 no multiply-adds, 2 no staging, 4 no reduction / stores
+};
+
+// LDS position of staged sample k of a tile: M elements of padding behind every block of P M samples, so that the groups of a wavefront -- whose
+// blocks start P M samples apart, a multiple of the 256-byte bank row for every power-of-two M -- read bank rows that interleave instead of coincide
+// (first run without it: 2-way conflicts on every read at M = 16, 16-way at M = 2; profiles/r05_fir_dec_ab.json "first").
+__device__ __forceinline__ int dec_pos(int k, int M, unsigned blkmagic) { return k + (int)__umulhi((unsigned)k, blkmagic) * M; }
+
+// MC: M as a compile-time constant (0: run-time M) -- the window reads are then one address register plus immediates
+template <typename R, bool CPLX, int P, int MC>
+MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void decimator_kernel(DecArgs a) {
+    using V = DecV<R>;
+    using XS = std::conditional_t<CPLX, cx<R>, R>;
+    constexpr int QC = 8, PH = 4;   // taps per chunk; outputs per reduction round
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = MC ? MC : a.M, Mp = a.Mp;
+    const int nqp = (a.nq + QC - 1) / QC * QC;
+    const int nzp = dec_pos(a.nz - 1, M, a.blkmagic) + 1;
+    V* zs = reinterpret_cast<V*>(smem);
+    R* tl = reinterpret_cast<R*>(zs + nzp);
+    V* red = reinterpret_cast<V*>(tl + (((size_t)nqp * M + 3) & ~(size_t)3));
+    const int64_t ch = blockIdx.y;
+    const int TO = (CPLX ? 1 : 2) * a.nbh * P;                  // outputs per tile
+    const int64_t m0 = (int64_t)blockIdx.x * TO;
+    if (m0 >= a.nout) return;
+    const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
+    const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
+    const int64_t zf = a.zb + m0 * M;                           // first staged sample
+    const int H = a.nbh * P * M;                                // samples between the two halves of a real tile
+    if (a.ablate & 2) {
+    } else if (zf >= a.hl) {
+        // steady state: the tile lies inside x.  A descriptor based at the tile's first sample (reads past the end of the signal return 0), eight
+        // independent loads (pairs of them for a real signal's two halves) in flight per thread before the LDS writes
+        const XS* src = xc + (zf - a.hl);
+        const __amdgpu_buffer_rsrc_t rs = io::make_rsrc(src, (a.xlen - (zf - a.hl)) * (long long)sizeof(XS));
+        constexpr int U = 8, SZ = (int)sizeof(XS);
+        for (int k0 = threadIdx.x; k0 < a.nz; k0 += U * 256) {
+            XS v0[U], v1[CPLX ? 1 : U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * 256;
+                v0[u] = io::Ld<XS>::load(rs, k < a.nz ? k * SZ : io::OOB);
+                if constexpr (!CPLX) v1[u] = io::Ld<XS>::load(rs, k < a.nz ? (k + H) * SZ : io::OOB);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * 256;
+                if (k < a.nz) {
+                    if constexpr (CPLX) zs[dec_pos(k, M, a.blkmagic)] = {v0[u].x, v0[u].y};
+                    else zs[dec_pos(k, M, a.blkmagic)] = {v0[u], v1[u]};
+                }
+            }
+        }
+    } else {   // the first tile(s) straddle the history
+        auto sample = [&](int64_t zi) -> XS {
+            if (zi < a.hl) return hc[zi];
+            if (zi - a.hl < a.xlen) return xc[zi - a.hl];
+            return XS{};
+        };
+        for (int k = threadIdx.x; k < a.nz; k += 256) {
+            if constexpr (CPLX) {
+                const XS v = sample(zf + k);
+                zs[dec_pos(k, M, a.blkmagic)] = {v.x, v.y};
+            } else zs[dec_pos(k, M, a.blkmagic)] = {sample(zf + k), sample(zf + k + H)};
+        }
+    }
+    {
+        const R* pf = static_cast<const R*>(a.pfbT);
+        for (int k = threadIdx.x; k < nqp * M; k += 256) tl[k] = k < a.tp ? pf[k] : (R)0;
+    }
+    __syncthreads();
+    const int r = threadIdx.x & (Mp - 1), gq = threadIdx.x >> a.logMp, ng = 256 >> a.logMp;
+    const bool lane_on = r < M;
+    const int rr = lane_on ? r : 0;
+    V* myred = red + (size_t)gq * PH * (Mp + 1);
+    using Y = std::conditional_t<CPLX, cx<R>, R>;
+    Y* yc = static_cast<Y*>(a.y) + ch * a.ldy;
+    for (int bl = gq; bl < a.nbh; bl += ng) {
+        V acc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p] = {(R)0, (R)0};
+        // sample (bl P + t) M + r of the tile sits at  bl (P + 1) M + (t + t div P) M + r : t = q0 + j walks the window
+        const V* zb = zs + (size_t)bl * (P + 1) * M + rr;
+        for (int q0 = 0; q0 < ((a.ablate & 1) ? 0 : a.nq); q0 += QC) {
+            R g[QC];
+            V w[P + QC - 1];
+#pragma unroll
+            for (int u = 0; u < QC; ++u) g[u] = tl[(q0 + u) * M + rr];
+#pragma unroll
+            for (int j = 0; j < P + QC - 1; ++j) {
+                const int t = q0 + j;
+                w[j] = zb[(t + t / P) * M];
+            }
+            if ((q0 + QC) * M <= a.tp) {   // every tap of the chunk exists (uniform)
+#pragma unroll
+                for (int u = 0; u < QC; ++u)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = dec_fma(w[p + u], g[u], acc[p]);
+            } else {                       // the last chunk: positions past the filter's end are not read (a NaN there must not reach the output).  A lane
+                                           // whose tap does not exist sits the step out under the execution mask (first form: a select per multiply-add --
+                                           // 256 v_cndmask next to 128 packed FMAs, the chunk cost as much as three others: profiles/r05_fir_dec_ab.json)
+#pragma unroll
+                for (int u = 0; u < QC; ++u) {
+                    if ((q0 + u) * M + rr < a.tp) {
+#pragma unroll
+                        for (int p = 0; p < P; ++p) acc[p] = dec_fma(w[p + u], g[u], acc[p]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keeps the eight guarded groups apart (if-conversion would bring the selects back)
+                }
+            }
+        }
+        // the M partial sums of every output meet in LDS (the lanes of a group sit in one wavefront: its DS operations execute in order)
+#pragma unroll
+        for (int p0 = 0; p0 < ((a.ablate & 4) ? 0 : P); p0 += PH) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane_on) {
+#pragma unroll
+                for (int p = 0; p < PH; ++p) myred[p * (Mp + 1) + r] = acc[p0 + p];
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int pp = r; pp < PH; pp += Mp) {
+                V s = myred[pp * (Mp + 1)];
+                for (int k = 1; k < M; ++k) {
+                    const V t = myred[pp * (Mp + 1) + k];
+                    s.x += t.x;
+                    s.y += t.y;
+                }
+                const int64_t m = m0 + (int64_t)bl * P + p0 + pp;
+                if constexpr (CPLX) {
+                    if (m < a.nout) yc[m] = Y{s.x, s.y};
+                } else {
+                    if (m < a.nout) yc[m] = s.x;
+                    if (m + (int64_t)a.nbh * P < a.nout) yc[m + (int64_t)a.nbh * P] = s.y;
+                }
+            }
+        }
+    }
+}
+
 int64_t gcd64(int64_t a, int64_t b) { return std::gcd(a, b); }
 
 
@@ -1648,7 +1823,91 @@ bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
     return true;
 }
 
+// ---- decimator kernel: geometry and launch ---------------------------------------------------------------------------------------------------
+struct DecGeo {
+    bool ok = false;
+    int Mp = 0, logMp = 0, nq = 0, nbh = 0, nz = 0, P = 0;
+    size_t lds = 0;
+};
+DecGeo fir_dec_geo(const mdsp_fir_s* f) {
+    DecGeo g;
+    if (f->L != 1 || f->M < 2 || f->M > 64 || tunables().fir_dec == 0 || tunables().fir_exact || MDSP_DBG(fir_generic)) return g;
+    if (f->acc_double != dtype_is_double(f->x_dtype)) return g;   // Float32 samples under Float64 taps: the generic kernel converts as it stages
+    // Where it wins (profiles/r05_fir_dec_ab.json, 4 channels x 2^26 samples, resample_filter taps): Float64 / ComplexF64 from M = 4 on (1.03 - 4.4x),
+    // Float32 / ComplexF32 at M = 4 (1.03 - 1.06x) and from M = 8 on (1.0 - 3.7x); at M = 2, 3 and the Float32 M = 5, 6 the matrix-core kernel's
+    // short products stay ahead (0.37 - 0.53 of the roof against 0.23 - 0.42).  MDSP_FIR_DEC=3 takes it for every M <= 64 (tests).
+    if (tunables().fir_dec == 1 && !(f->acc_double ? f->M >= 4 : (f->M == 4 || f->M >= 8))) return g;
+    const bool dbl = f->acc_double, cplx = dtype_is_complex(f->x_dtype);
+    const int M = (int)f->M;
+    g.P = dbl ? 8 : 16;
+    g.Mp = 2;
+    g.logMp = 1;
+    while (g.Mp < M) g.Mp *= 2, ++g.logMp;
+    if (f->tp > (int64_t)1 << 20) return g;
+    g.nq = (int)cdiv(f->tp, M);
+    const int nqp = (g.nq + 7) / 8 * 8, ng = 256 / g.Mp;
+    const size_t vsz = dbl ? 16 : 8, rsz = dbl ? 8 : 4;
+    // blocks per (half) tile: a multiple of the groups of a workgroup (every group the same number of blocks), as many as ~40 KiB of samples hold
+    int kb = 1;
+    while (((size_t)ng * (kb + 1) * g.P * M + (size_t)nqp * M) * vsz <= 40 * 1024) ++kb;
+    g.nbh = ng * kb;
+    g.nz = g.nbh * g.P * M + nqp * M;
+    const size_t nzp = (size_t)g.nz + (size_t)((g.nz - 1) / (g.P * M)) * M;   // with M elements of padding behind every block (dec_pos)
+    g.lds = nzp * vsz + (((size_t)nqp * M + 3) & ~(size_t)3) * rsz + (size_t)ng * 4 * (g.Mp + 1) * vsz;
+    (void)cplx;
+    g.ok = g.lds <= 150 * 1024;
+    return g;
+}
+template <typename R, bool CPLX, int P> int fir_dec_launch(mdsp_fir_s* f, const FirArgs& a, const DecGeo& g, hipStream_t st) {
+    DecArgs d{};
+    d.x = a.x;
+    d.hist = a.hist;
+    d.y = a.y;
+    d.pfbT = a.pfbT;
+    d.xlen = a.xlen;
+    d.ldx = a.ldx;
+    d.ldy = a.ldy;
+    d.nout = a.nout;
+    d.zb = a.d0 - 1 + a.phi0m1;
+    d.M = a.M;
+    d.Mp = g.Mp;
+    d.logMp = g.logMp;
+    d.tp = a.tp;
+    d.hl = a.hl;
+    d.nq = g.nq;
+    d.nbh = g.nbh;
+    d.nz = g.nz;
+    d.ablate = tunables().fir_dec_ablate;
+    d.blkmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)(P * a.M) - 1) / (uint64_t)(P * a.M));
+    void (*kern)(DecArgs) = decimator_kernel<R, CPLX, P, 0>;
+    switch (a.M) {
+        case 2: kern = decimator_kernel<R, CPLX, P, 2>; break;
+        case 4: kern = decimator_kernel<R, CPLX, P, 4>; break;
+        case 8: kern = decimator_kernel<R, CPLX, P, 8>; break;
+        case 16: kern = decimator_kernel<R, CPLX, P, 16>; break;
+        default: break;
+    }
+    if (tunables().fir_dec == 2) kern = decimator_kernel<R, CPLX, P, 0>;   // MDSP_FIR_DEC=2: the run-time M form for every M
+    if (g.lds > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+    const int64_t TO = (int64_t)(CPLX ? 1 : 2) * g.nbh * P;
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(a.nout, TO), (unsigned)f->nch), dim3(256), g.lds, st, d);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+int fir_dec_dispatch(mdsp_fir_s* f, const FirArgs& a, const DecGeo& g, hipStream_t st) {
+    switch (f->x_dtype) {
+        case MDSP_F32: return fir_dec_launch<float, false, 16>(f, a, g, st);
+        case MDSP_F64: return fir_dec_launch<double, false, 8>(f, a, g, st);
+        case MDSP_C32: return fir_dec_launch<float, true, 16>(f, a, g, st);
+        default: return fir_dec_launch<double, true, 8>(f, a, g, st);
+    }
+}
+
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
+    {
+        const DecGeo dg = fir_dec_geo(f);
+        if (dg.ok) return fir_dec_dispatch(f, a, dg, st);
+    }
     if (fir_mm_use(f, a)) return fir_mm_dispatch(f, a, st);
     if (tunables().fir_p == 4 && f->tp <= 32 && fir_fast_ok(f, 4)) return fir_fast_dispatch<4>(f, a, st);   // tuning: four residues per thread
     if (tunables().fir_p == 3 && f->tp <= 32 && fir_fast_ok(f, 3)) return fir_fast_dispatch<3>(f, a, st);   // tuning: three residues per thread
@@ -1838,7 +2097,7 @@ int mdsp_fir_kernel_path(mdsp_fir f, int64_t xlen, int* path) {
     a.nout = f->kind == 0 ? xlen : (xlen < d0 ? 0 : mdsp_outputlength(xlen - d0 + 1, f->L, f->M, phi0));
     a.L = (int)f->L;
     a.M = (int)f->M;
-    *path = fir_mm_use(f, a) ? 2 : (fir_fast_ok(f, 2) || fir_fast_ok(f, 1)) ? 1 : 0;
+    *path = fir_dec_geo(f).ok ? 3 : fir_mm_use(f, a) ? 2 : (fir_fast_ok(f, 2) || fir_fast_ok(f, 1)) ? 1 : 0;   // 3: decimator kernel, 2: matrix cores, 1: register taps, 0: generic
     return MDSP_OK;
 }
 

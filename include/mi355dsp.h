@@ -296,7 +296,8 @@ int mdsp_fir_info(mdsp_fir f, int* kind /*0 std,1 interp,2 decim,3 rational*/, i
                   int64_t* taps_per_phase, int64_t* history_len, int* out_dtype);
 /* Which kernel mdsp_fir_exec would run for a chunk of `xlen` samples in the filter's current state: 0 generic polyphase kernel
  * (any dtype), 1 register-tap kernel (Float32, <= 64 taps per phase), 2 matrix-core kernel (rows of 16 outputs on
- * v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64; Float32 results bit-identical to 0 / 1).  Diagnostics / tests: the choice never changes results beyond the sign of a zero. */
+ * v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64; Float32 results bit-identical to 0 / 1), 3 decimator kernel (L = 1, M <= 64, any length: a lane
+ * per input phase; sums phases first, so it agrees with 0 to rounding, and reads exactly the reference's windows).  Diagnostics / tests. */
 int mdsp_fir_kernel_path(mdsp_fir f, int64_t xlen, int* path);
 /* Geometry the matrix-core kernel would use for a filter of hlen taps at ratio L // M (pure host arithmetic, no device):
  * out12 = {fits, rounds per row RB, outputs per row Lr = RB L, samples per row Mr = RB M, column blocks NB, row groups NG, k-steps of four taps (in registers up to 64, Float64 32; beyond that fetched per tile),

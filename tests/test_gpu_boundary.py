@@ -671,7 +671,12 @@ def test_polyphase_kernel_choice(d, torch):
     assert path(h, 160, 147, _lib.C32, 4, 2 ** 28) == 2                         # complex signal: two products against the same taps
     assert path(h.astype(np.float64), 160, 147, _lib.F32, 4, 2 ** 28) == 0      # Float64 taps on a Float32 signal: generic kernel
     assert path(rng.standard_normal(48).astype(np.float32), 2, 1, _lib.F32, 1, 2 ** 26) == 2      # interpolation by 2: a row is 7 rounds
-    assert path(rng.standard_normal(64).astype(np.float32), 1, 2, _lib.F32, 1, 2 ** 26) == 2      # decimation by 2
+    assert path(rng.standard_normal(64).astype(np.float32), 1, 2, _lib.F32, 1, 2 ** 26) == 2      # decimation by 2: still the matrix cores
+    assert path(rng.standard_normal(581).astype(np.float32), 1, 16, _lib.F32, 2, 2 ** 26) == 3      # from M = 8 on (Float64: 4): the decimator kernel (round 5)
+    assert path(rng.standard_normal(581), 1, 16, _lib.C64, 2, 2 ** 26) == 3                         # ... in every signal type
+    assert path(rng.standard_normal(150), 1, 4, _lib.F64, 2, 2 ** 26) == 3
+    assert path(rng.standard_normal(581), 1, 16, _lib.F32, 2, 2 ** 26) == 0                         # (Float64 taps on Float32 samples: generic)
+    assert path(rng.standard_normal(900).astype(np.float32), 1, 100, _lib.F32, 1, 2 ** 26) != 3     # M > 64: the older kernels
     assert path(rng.standard_normal(4000).astype(np.float32), 250, 249, _lib.F32, 1, 2 ** 26) == 2  # L > 192 in Float32, two column blocks per wave: their taps live in registers (round 3: 0.70 against 0.92 ms)
     assert path(rng.standard_normal(16317).astype(np.float32), 441, 160, _lib.F32, 1, 2 ** 26) == 1  # three blocks per wave: the register-tap kernel is still the faster one (1.67 against 2.39 ms)
     assert path(rng.standard_normal(4000), 250, 249, _lib.F64, 1, 2 ** 26) == 2                     # ... in Float64 the matrix cores (several column blocks per wave)
@@ -1218,3 +1223,93 @@ def test_compile_time_mixed_radix_schedules(d, torch, nfft):
                 assert relerr(S[:, :, 1], opg.stft(x[:, 1], n, nov, nfft=nfft, onesided=onesided, window=ow.hanning, dtype=np.float64)) < TOL, ("stft", dt, n, onesided)
             sp = d.spectrogram(xd[:, 0].contiguous(), n, nov, nfft=nfft, fs=2.0, window=d.hamming).power.cpu().numpy()
             assert relerr(sp, opg.stft(x[:, 0], n, nov, psdonly=True, nfft=nfft, fs=2.0, window=ow.hamming, dtype=np.float64)) < TOL, ("spectrogram", dt, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Tx", [np.float32, np.float64, np.complex64, np.complex128])
+def test_decimator_kernel_vs_oracle_streaming_and_nonfinite(d, torch, Tx):
+    """FIRDecimator (stream_filt.jl:43-56, :522-558) on the phase-per-lane decimator kernel: every M up to 64 (powers of two and not), filters shorter
+    than M, lengths that are not multiples of M, several channels, tiles with a ragged end; against the Float64 oracle (<= 2e-6 Float32, 1e-12
+    Float64 -- the kernel sums phases first, the reference oldest sample first); chunked == one-shot BIT FOR BIT (an output's arithmetic does not
+    depend on where its tile starts) with the reference's state after every chunk; NaN / Inf samples leave EXACTLY the reference's hole."""
+    import ctypes as C
+    from fractions import Fraction
+    from dsp_jl_amd import _lib
+    from oracle import stream_filt as osf
+    lib = _lib.lib()
+    rng = np.random.default_rng(2026)
+    cplx = np.dtype(Tx).kind == "c"
+    dbl = np.dtype(Tx) in (np.dtype(np.float64), np.dtype(np.complex128))
+    Th = np.float64 if dbl else np.float32
+    tol = 1e-12 if dbl else 2e-6
+    lx = {np.float32: _lib.F32, np.float64: _lib.F64, np.complex64: _lib.C32, np.complex128: _lib.C64}[Tx]
+    lt = _lib.F64 if dbl else _lib.F32
+    tdt = {np.float32: torch.float32, np.float64: torch.float64, np.complex64: torch.complex64, np.complex128: torch.complex128}[Tx]
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.set_tunable("MDSP_FIR_DEC", 3)     # the decimator kernel for every M <= 64 (by default only where it measured faster than the matrix-core kernel)
+    try:
+        _decimator_cases(d, torch, Tx, lib, rng, cplx, dbl, Th, tol, lx, lt, tdt, stream)
+    finally:
+        _lib.set_tunable("MDSP_FIR_DEC", None)
+
+
+def _decimator_cases(d, torch, Tx, lib, rng, cplx, dbl, Th, tol, lx, lt, tdt, stream):
+    import ctypes as C
+    from fractions import Fraction
+    from dsp_jl_amd import _lib
+    from oracle import stream_filt as osf
+    for (M, ntaps, n, nch) in ((2, 48, 100_003, 1), (3, 7, 50_000, 2), (4, 147, 70_001, 1), (5, 3, 20_000, 1), (8, 291, 300_000, 3), (16, 581, 400_017, 2),
+                               (17, 600, 123_457, 1), (33, 1000, 200_000, 1), (64, 2309, 500_000, 1), (16, 5000, 150_000, 1), (7, 1, 30_000, 1)):
+        h = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(Th)
+        x = rng.standard_normal((nch, n))
+        x = (x + 1j * rng.standard_normal((nch, n))).astype(Tx) if cplx else x.astype(Tx)
+        xd = torch.from_numpy(x).cuda()
+        fh = C.c_void_p()
+        _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), 1, M, lt, lx, nch))
+        pth = C.c_int(-1); _lib.check(lib.mdsp_fir_kernel_path(fh, n, C.byref(pth)))
+        assert pth.value == 3 or (ntaps == 5000 and dbl), (M, ntaps)   # (5000 Float64 taps at M = 16 do not fit the LDS next to a tile: the older kernels take it)
+        ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, n, C.byref(ol)))
+        y = torch.zeros((nch, ol.value + 2), dtype=tdt, device="cuda")
+        nw = C.c_int64()
+        _lib.check(lib.mdsp_fir_exec(fh, xd.data_ptr(), n, n, y.data_ptr(), ol.value, ol.value + 2, C.byref(nw), stream))
+        torch.cuda.synchronize()
+        assert nw.value == ol.value and not y[:, ol.value:].abs().any()
+        one = y[:, :ol.value].cpu().numpy()
+        for c in range(nch):
+            ref = osf.FIRFilter(h.astype(np.float64), Fraction(1, M)).filt(x[c].astype(np.complex128 if cplx else np.float64))
+            assert ref.shape == one[c].shape and relerr(one[c], ref) < tol, (M, ntaps, c, relerr(one[c], ref))
+        # streaming: three ragged chunks, the oracle's state after each, outputs bit-identical to the one-shot run
+        _lib.check(lib.mdsp_fir_reset(fh))
+        o = osf.FIRFilter(h, Fraction(1, M))
+        cuts = [0, n // 3 + 1, n // 3 + 2, n]
+        pieces = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            olc = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, b - a, C.byref(olc)))
+            yc = torch.zeros((nch, max(1, olc.value)), dtype=tdt, device="cuda")
+            _lib.check(lib.mdsp_fir_exec(fh, xd[:, a:].data_ptr(), b - a, n, yc.data_ptr(), olc.value, max(1, olc.value), C.byref(nw), stream))
+            torch.cuda.synchronize()
+            pieces.append(yc[:, :nw.value].cpu().numpy())
+            o.filt(x[0, a:b])
+            p_, d_ = C.c_int64(), C.c_int64()
+            hist = np.zeros((nch, max(1, ntaps - 1)), dtype=Tx)
+            _lib.check(lib.mdsp_fir_get_state(fh, C.byref(p_), C.byref(d_), hist.ctypes.data_as(C.c_void_p)))
+            assert (p_.value, d_.value) == (o.phi_idx, o.input_deficit)
+            if ntaps > 1:
+                assert np.array_equal(hist[0, :ntaps - 1], o.history.astype(Tx))
+        assert np.array_equal(np.concatenate(pieces, axis=1), one), (M, ntaps)
+        _lib.check(lib.mdsp_fir_destroy(fh))
+    # non-finite samples: exactly the reference's hole on the DEFAULT path
+    for (M, ntaps) in ((2, 48), (16, 581), (5, 33)):
+        n = 60_001
+        h = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(Th)
+        h[np.abs(h) < 1e-3] = 1e-3
+        xr = rng.standard_normal(n)
+        for pos, v in {5: np.nan, 20_000: np.inf, 20_003: -np.inf, 41_111: np.nan, n - 2: np.inf}.items():
+            xr[pos] = v
+        x = xr.astype(Tx)
+        with np.errstate(invalid="ignore", over="ignore"):
+            ref = osf.filt_stateless(h.astype(np.float64), x.astype(np.complex128 if cplx else np.float64), Fraction(1, M))
+        got = np.asarray(d.filt(h, x, Fraction(1, M)))
+        bad = ~np.isfinite(ref)
+        assert 0 < bad.sum() < len(ref) // 5 and np.array_equal(~np.isfinite(got), bad), (M, ntaps)
+        assert relerr(got[~bad], ref[~bad]) < tol
