@@ -118,6 +118,7 @@ PROTOTYPES = {
     "mdsp_coherence_from_cs": (ci, [vp, i64, i64, ci, vp, vp]),
     "mdsp_fir_create": (ci, [pvp, vp, i64, i64, i64, ci, ci, i64]),
     "mdsp_fir_destroy": (ci, [vp]),
+    "mdsp_fir_set_exact": (ci, [vp, ci]),
     "mdsp_fir_reset": (ci, [vp]),
     "mdsp_fir_setphase": (ci, [vp, cd]),
     "mdsp_fir_timedelay": (ci, [vp, pdbl]),

@@ -1325,6 +1325,7 @@ struct mdsp_fir_s {
     DevBuf pfbT;
     DevBuf hist[2];
     int cur = 0;
+    bool exact = false;   // mdsp_fir_set_exact: the generic kernel only -- every output reads exactly its own tapsPerPhi-sample window (stream_filt.jl:496-509)
 };
 
 
@@ -1456,7 +1457,7 @@ template <int TPC, int P> int fir_fast_launch(mdsp_fir_s* f, const FirArgs& a, h
 // Fast path applies to Float32 taps x real Float32 signal with <= 64 taps per phase and <= 1024 phase groups.
 bool fir_fast_ok(const mdsp_fir_s* f, int P) {
     if (f->acc_double || f->x_dtype != MDSP_F32 || f->tp > 64) return false;
-    if (MDSP_DBG(fir_generic) || tunables().fir_exact) return false;
+    if (MDSP_DBG(fir_generic) || tunables().fir_exact || f->exact) return false;
     if (P >= 2 && (f->M > f->L || f->L < P)) return false;
     return cdiv(f->L, P) <= 256;
 }
@@ -1812,7 +1813,7 @@ int fir_mm_dispatch(mdsp_fir_s* f, const FirArgs& a, hipStream_t st) {
 // no size gate pays), up to 2^28 (profiles/r02r_tune_fir); MDSP_FIR_MM=0 turns it off
 bool fir_mm_use(const mdsp_fir_s* f, const FirArgs& a) {
     (void)a;
-    if (tunables().fir_mm == 0 || tunables().fir_exact) return false;
+    if (tunables().fir_mm == 0 || tunables().fir_exact || f->exact) return false;
     const FirMGeo g = fir_mm_geo(f);
     if (!g.ok) return false;
     // L > 192 (several column blocks per wave, small tiles): measured slower than the register-tap kernel where that one applies
@@ -1831,7 +1832,7 @@ struct DecGeo {
 };
 DecGeo fir_dec_geo(const mdsp_fir_s* f) {
     DecGeo g;
-    if (f->L != 1 || f->M < 2 || f->M > 64 || tunables().fir_dec == 0 || tunables().fir_exact || MDSP_DBG(fir_generic)) return g;
+    if (f->L != 1 || f->M < 2 || f->M > 64 || tunables().fir_dec == 0 || tunables().fir_exact || f->exact || MDSP_DBG(fir_generic)) return g;
     if (f->acc_double != dtype_is_double(f->x_dtype)) return g;   // Float32 samples under Float64 taps: the generic kernel converts as it stages
     // Where it wins (profiles/r05_fir_dec_ab.json, 4 channels x 2^26 samples, resample_filter taps): Float64 / ComplexF64 from M = 4 on (1.03 - 4.4x),
     // Float32 / ComplexF32 at M = 4 (1.03 - 1.06x) and from M = 8 on (1.0 - 3.7x); at M = 2, 3 and the Float32 M = 5, 6 the matrix-core kernel's
@@ -2008,6 +2009,12 @@ int mdsp_fir_create(mdsp_fir* fo, const void* taps_host, int64_t hlen, int64_t L
 
 int mdsp_fir_destroy(mdsp_fir f) {
     delete f;
+    return MDSP_OK;
+}
+
+int mdsp_fir_set_exact(mdsp_fir f, int exact) {
+    if (!f) MDSP_FAIL(MDSP_ERR_ARGUMENT, "handle is NULL");
+    f->exact = exact != 0;
     return MDSP_OK;
 }
 

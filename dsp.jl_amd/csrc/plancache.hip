@@ -16,8 +16,11 @@
 //   * A borrowed handle stays valid until its partition has made MDSP_PLAN_CACHE_SIZE further DISTINCT cached-plan requests (and the library's
 //     internal objects can never push a user's plan out), with ONE exception that bounds the device memory of a churning host: when the whole
 //     cache holds more than MDSP_PLAN_CACHE_TOTAL entries (default 8 x MDSP_PLAN_CACHE_SIZE), entries of OTHER partitions that have not
-//     made a request for MDSP_PLAN_CACHE_IDLE (default 64) cache requests are evicted, most idle partition first.  Partitions that are in
-//     use are never touched by other partitions' requests; if none is idle the cap is not enforced.
+//     made a request for MDSP_PLAN_CACHE_IDLE (default 64) cache requests are evicted, most idle partition first -- and only partitions that
+//     CANNOT be in use: explicit contexts that no thread has bound at the moment (a host binds its context around the calls that use its borrowed
+//     handles: with_plan_context in julia/MI355DSP.jl).  The partition of a live OS thread is never touched by another partition's request --
+//     that thread may be inside a long call on a borrowed handle without having asked the cache for anything (round 4 judged idleness by request
+//     ticks alone and could free such a plan's buffers mid-call: ADVICE r4) -- so if nothing is evictable the cap is not enforced.
 //   * The lists of an OS thread that EXITS are reaped: a thread-local sentinel moves them to a graveyard at thread exit and the next cache
 //     request (of any thread) or mdsp_plan_cache_clear() destroys them.  (Round 3 kept them until mdsp_plan_cache_clear(): every Welch / STFT
 //     plan owns device buffers -- partial sums of nslots x nch x nfft doubles, rocFFT intermediates of up to MDSP_ROCFFT_CHUNK_MIB -- so a
@@ -49,6 +52,7 @@ struct Entry {
 struct Partition {
     std::list<Entry> user, internal;   // front = most recently used
     uint64_t last_use = 0;             // tick of this partition's latest request
+    int bound = 0;                     // explicit contexts: threads that have this context bound right now (mdsp_plan_cache_set_context)
     size_t size() const { return user.size() + internal.size(); }
 };
 
@@ -81,7 +85,14 @@ void bury(Cache& c, Pid pid) {
     c.reaped += (int64_t)it->second.size();
     c.graveyard.splice(c.graveyard.end(), it->second.user);
     c.graveyard.splice(c.graveyard.end(), it->second.internal);
-    c.parts.erase(it);
+    if (it->second.bound == 0) c.parts.erase(it);   // (a context some thread still has bound keeps its -- now empty -- partition and its count)
+}
+
+// the calling thread stops using its bound context (caller holds the mutex)
+void unbind(Cache& c, Pid ctx) {
+    if (!ctx) return;
+    auto it = c.parts.find(ctx | kCtxBit);
+    if (it != c.parts.end() && it->second.bound > 0) --it->second.bound;
 }
 
 // One per OS thread that ever used the cache: at thread exit its partition goes to the graveyard (no device call here: the next request drains it).
@@ -89,10 +100,11 @@ struct ThreadSentinel {
     Pid pid;
     bool armed = false;
     ~ThreadSentinel() {
-        if (!armed) return;
+        if (!armed && !tl_context) return;
         Cache& c = cache();
         std::lock_guard<std::mutex> lk(c.mu);
-        bury(c, pid);
+        unbind(c, tl_context);   // a thread that exits with a context bound no longer holds it
+        if (armed) bury(c, pid);
     }
 };
 thread_local ThreadSentinel tl_sentinel;
@@ -170,7 +182,8 @@ int plan_cache_get(const std::string& key, void** out, const std::function<int(v
         while (total > total_cap()) {
             Partition* victim = nullptr;
             for (auto& kv : c.parts)
-                if (kv.first != me && kv.second.size() > 0 && c.tick - kv.second.last_use >= idle_ticks() && (!victim || kv.second.last_use < victim->last_use))
+                if (kv.first != me && (kv.first & kCtxBit) && kv.second.bound == 0 && kv.second.size() > 0 && c.tick - kv.second.last_use >= idle_ticks() &&
+                    (!victim || kv.second.last_use < victim->last_use))
                     victim = &kv.second;
             if (!victim) break;            // nobody is idle: the cap is soft
             std::list<Entry>& from = victim->internal.size() > victim->user.size() ? victim->internal : victim->user;
@@ -268,7 +281,14 @@ int mdsp_plan_cache_partitions(int64_t* partitions, int64_t* reaped) {
 }
 
 int mdsp_plan_cache_set_context(uint64_t id) {
+    Cache& c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    unbind(c, tl_context);
     tl_context = id & ~kCtxBit;
+    if (tl_context) {
+        ++c.parts[tl_context | kCtxBit].bound;
+        (void)tl_sentinel.armed;   // instantiate the thread's sentinel: its destructor unbinds the context if the thread exits with it bound
+    }
     return MDSP_OK;
 }
 

@@ -1807,6 +1807,7 @@ int mdsp_welch_frames_accumulated(mdsp_welch_plan plan, int64_t* frames_per_chan
     *frames_per_channel = plan->acc_frames;
     if (plan->frames_on_device) {   // after mdsp_welch_allreduce: the total over ranks, read back (this query, unlike the collective, synchronises)
         double k = 0;
+        MDSP_HIP(hipStreamSynchronize(plan->count_stream));   // the set / all-reduce of the count were queued there (possibly a non-blocking stream)
         MDSP_HIP(hipMemcpy(&k, plan->kdev.p, sizeof(double), hipMemcpyDeviceToHost));
         *frames_per_channel = (int64_t)k;
     }

@@ -28,6 +28,7 @@ struct mdsp_welch_plan_s {
     mdsp::big::EngineHolder big;   // nfft above the single-workgroup kernels: the multi-pass engine (bigfft.hip), built at the first accumulate
     mdsp::DevBuf w64prep;        // mdsp_welch_w64_asm: Float32 window pairs + per-lane twiddles (built at the plan's first launch of that kernel)
     bool frames_on_device = false;
+    hipStream_t count_stream = nullptr;   // the stream mdsp_welch_allreduce queued the count's reduction on
     int acc_nslices = 1, acc_nacc = 0, acc_mode = 0;   // welch_finalize_kernel MODE
     double* acc_ptr() const { return engine == MDSP_ENGINE_ROCFFT ? partial.as<double>() : reduced.as<double>(); }
 };

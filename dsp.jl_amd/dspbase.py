@@ -326,12 +326,20 @@ def xcorr(u, v=None, padmode: str = "none", scaling: str = "none"):
         raise _lib.DimensionMismatch("scaling only valid for vectors of same length")
     if padmode not in ("none", "longest"):
         raise ArgumentError("padmode keyword argument must be either :none or :longest")
-    uh, vh = (a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a) for a in (u, v))
-    if padmode == "longest":
-        n = max(su, sv)
-        uh = np.concatenate([uh, np.zeros(n - su, dtype=uh.dtype)])
-        vh = np.concatenate([vh, np.zeros(n - sv, dtype=vh.dtype)])
-    res = conv(uh, np.conj(vh)[::-1].copy())
+    # device in -> device out, like every other entry (round 4 pulled both operands to the host): padding, conjugation and reversal happen where the
+    # operand lives; conv() keeps the longer operand where it is and takes the shorter one as the filter
+    tt = _dev.torch
+
+    def prep(a, n, rev):
+        if _dev.is_device_array(a):
+            a = tt.cat([a, tt.zeros(n - int(a.shape[0]), dtype=a.dtype, device=a.device)]) if n > int(a.shape[0]) else a
+            return tt.conj(a).flip(0).resolve_conj().contiguous() if rev else a
+        a = np.asarray(a)
+        a = np.concatenate([a, np.zeros(n - len(a), dtype=a.dtype)]) if n > len(a) else a
+        return np.conj(a)[::-1].copy() if rev else a
+
+    n_u, n_v = (max(su, sv),) * 2 if padmode == "longest" else (su, sv)
+    res = conv(prep(u, n_u, False), prep(v, n_v, True))
     return res / su if scaling == "biased" else res
 
 

@@ -162,7 +162,8 @@ class FIRFilter:
 
     KINDS = ("FIRStandard", "FIRInterpolator", "FIRDecimator", "FIRRational", "FIRArbitrary")
 
-    def __init__(self, h, ratio=1, Nphi: int = 32):
+    def __init__(self, h, ratio=1, Nphi: int = 32, *, exact: bool = False):
+        self.exact = bool(exact)     # exact=True: the generic kernel only -- every output reads exactly its own window (mdsp_fir_set_exact)
         self.h = _host_vec(h)
         if self.h.dtype.kind == "c":
             raise UnsupportedError("complex FIR taps are not accelerated")
@@ -313,6 +314,8 @@ class FIRFilter:
                 _lib.check(_lib.lib().mdsp_fir_create(C.byref(h), taps.ctypes.data_as(C.c_void_p), len(taps), self.ratio.numerator,
                                                       self.ratio.denominator, _dev.md_dtype(taps.dtype), _dev.md_dtype(xdtype), nch))
                 _lib.check(_lib.lib().mdsp_fir_info(h, None, None, None, None, None, C.byref(od)))
+                if self.exact:
+                    _lib.check(_lib.lib().mdsp_fir_set_exact(h, 1))
             self._handle, self._xdtype, self._nch = h, np.dtype(xdtype), nch
             self._outdtype = {_lib.F32: np.float32, _lib.F64: np.float64, _lib.C32: np.complex64, _lib.C64: np.complex128}[od.value]
             if self._history_host is not None and self.historyLen > 0:

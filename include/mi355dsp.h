@@ -287,6 +287,11 @@ typedef struct mdsp_fir_s* mdsp_fir;
 int mdsp_fir_create(mdsp_fir* f, const void* taps_host, int64_t hlen, int64_t L, int64_t M, int taps_dtype,
                     int x_dtype, int64_t nch);
 int mdsp_fir_destroy(mdsp_fir f);
+/* exact != 0: this filter runs the generic kernel only, in which every output reads exactly its own tapsPerPhi-sample window
+ * (stream_filt.jl:496-509) -- a NaN / Inf sample then leaves exactly the reference's hole.  The default kernels multiply a tile's common window
+ * by explicit zero taps, so their hole can be wider by up to 15 outputs plus the outputs of 64 more input positions (the decimator kernel, L = 1,
+ * is exact either way).  Same results otherwise, to rounding.  (Round 4 had this as the process-wide environment variable MDSP_FIR_EXACT only.) */
+int mdsp_fir_set_exact(mdsp_fir f, int exact);
 int mdsp_fir_reset(mdsp_fir f);                       /* reset!     stream_filt.jl:247-276 */
 int mdsp_fir_setphase(mdsp_fir f, double phi);        /* setphase!  :216-229 */
 int mdsp_fir_timedelay(mdsp_fir f, double* tau);      /* timedelay  :400-403 */
@@ -409,7 +414,9 @@ int mdsp_hilbert(const void* x_dev, int64_t n, int64_t ncols, int64_t ldx, int r
  * mdsp_plan_cache_release_context(id).  Only requests of the same partition evict from its two lists (user plans / the library's own cached
  * objects, MDSP_PLAN_CACHE_SIZE each), so a handle stays valid until ITS PARTITION has made MDSP_PLAN_CACHE_SIZE further distinct cached requests,
  * with one exception that bounds device memory: above MDSP_PLAN_CACHE_TOTAL entries in the whole cache (environment, default 8 x
- * MDSP_PLAN_CACHE_SIZE) entries of partitions that have made no request for MDSP_PLAN_CACHE_IDLE (default 64) cache requests are evicted.
+ * MDSP_PLAN_CACHE_SIZE) entries of explicit contexts that NO thread has bound at the moment and that have made no request for MDSP_PLAN_CACHE_IDLE
+ * (default 64) cache requests are evicted -- a host therefore keeps its context bound for as long as it uses handles borrowed under it; the
+ * partition of a live OS thread is never evicted by others (it may be inside a long call on a borrowed handle).
  * The entries of an OS thread that exits are reaped automatically (destroyed at the next cache request of any thread).
  * mdsp_plan_cache_clear() destroys every partition's entries and must not race with other threads' library calls.
  * mdsp_plan_cache_partitions: live partitions and the number of entries reaped so far (exited threads, released contexts, cap evictions).

@@ -729,11 +729,13 @@ mutable struct FIRFilter                                                        
     xtype::DataType
     nch::Int
 end
-function FIRFilter(taps::Vector{Th}, ratio::Union{Integer,Rational}=1; xtype::DataType=Th, nch::Integer=1) where {Th<:Union{Float32,Float64}}
+# exact=true: the generic kernel only -- every output reads exactly its own tapsPerϕ-sample window, so NaN / Inf samples leave exactly DSP.jl's hole
+function FIRFilter(taps::Vector{Th}, ratio::Union{Integer,Rational}=1; xtype::DataType=Th, nch::Integer=1, exact::Bool=false) where {Th<:Union{Float32,Float64}}
     p = Ref{Ptr{Cvoid}}(C_NULL)
     r = convert(Rational{Int}, ratio)
     GC.@preserve taps check(ccall((:mdsp_fir_create, lib), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Cint, Int64),
                                   p, pointer(taps), length(taps), numerator(r), denominator(r), mdtype(Th), mdtype(xtype), nch))
+    exact && check(ccall((:mdsp_fir_set_exact, lib), Cint, (Ptr{Cvoid}, Cint), p[], 1))
     f = FIRFilter(p[], taps, r, xtype, nch)
     finalizer(x -> ccall((:mdsp_fir_destroy, lib), Cint, (Ptr{Cvoid},), x.h), f)
     f

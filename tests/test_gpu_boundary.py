@@ -816,7 +816,7 @@ def test_plan_cache_reaps_exited_threads_and_honours_contexts(d, torch):
 @pytest.mark.parametrize("L,M,ntaps", [(160, 147, 5120), (3, 2, 96), (1, 2, 48), (2, 1, 64)])
 def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, ntaps):
     """stream_filt.jl:496-509: an output is the dot product of ONE column of the polyphase bank with ITS window of tapsPerPhi samples, so a NaN / Inf
-    sample makes exactly the outputs whose own window holds it non-finite.  With MDSP_FIR_EXACT=1 (the generic kernel: the reference's windows
+    sample makes exactly the outputs whose own window holds it non-finite.  With mdsp_fir_set_exact(f, 1) -- FIRFilter(...; exact=true) -- (the generic kernel: the reference's windows
     and nothing else) the non-finite outputs are EXACTLY the oracle's.  The fast kernels multiply a block's (matrix-core) or a residue pair's
     (register-tap, MDSP_FIR_MM=0) common window by explicit zero taps, so their hole may be wider -- by at most 15 outputs plus the outputs of 64
     more input positions on either side -- and outside that widened hole their outputs are finite and equal the exact run's
@@ -842,11 +842,13 @@ def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, nt
     stream = torch.cuda.current_stream().cuda_stream
     outs = {}
     try:
-        for mode, knobs in (("exact", {"MDSP_FIR_EXACT": 1}), ("regtap", {"MDSP_FIR_MM": 0}), ("default", {})):
+        for mode, knobs in (("exact", {}), ("exact_env", {"MDSP_FIR_EXACT": 1}), ("regtap", {"MDSP_FIR_MM": 0}), ("default", {})):
             for k, v in knobs.items():
                 _lib.set_tunable(k, v)
             fh = C.c_void_p()
             _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), L, M, _lib.F32, _lib.F32, 1))
+            if mode == "exact":     # the flag of the FILTER (round 5; the environment variable of round 4 still works: "exact_env")
+                _lib.check(lib.mdsp_fir_set_exact(fh, 1))
             ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, n, C.byref(ol)))
             assert ol.value == len(ref)
             y = torch.zeros((1, ol.value + 1), dtype=torch.float32, device="cuda")
@@ -863,6 +865,9 @@ def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, nt
         _lib.set_tunable("MDSP_FIR_EXACT", None)
     y0, path0 = outs["exact"]
     assert path0 == 0                                              # the generic kernel
+    assert outs["exact_env"][1] == 0 and np.array_equal(outs["exact_env"][0], y0, equal_nan=True)
+    yp = np.asarray(d.FIRFilter(h, Fraction(L, M), exact=True).filt(x))   # ... and through the host mirror: FIRFilter(h, ratio; exact=true)
+    assert np.array_equal(yp, y0, equal_nan=True)
     bad0 = ~np.isfinite(y0)
     assert np.array_equal(bad0, bad_ref), (int(bad0.sum()), int(bad_ref.sum()), np.flatnonzero(bad0 != bad_ref)[:10])   # the reference's hole, exactly
     assert relerr(y0[~bad_ref], ref[~bad_ref]) < 2e-6

@@ -1162,6 +1162,10 @@ def test_xcorr(d, torch):
             got = d.xcorr(u, v, **kw)
             assert got.dtype == T and got.shape == ref.shape and relerr(got, ref) < tol, (T, kw, relerr(got, ref))
         assert relerr(d.xcorr(u), odsp.xcorr(u.astype(wide))) < tol                                  # autocorrelation
+        ud, vd = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()                              # device in -> device out, the same numbers
+        for kw in ({}, {"padmode": "longest"}):
+            gd = d.xcorr(ud, vd, **kw)
+            assert isinstance(gd, torch.Tensor) and gd.is_cuda and np.array_equal(gd.cpu().numpy(), d.xcorr(u, v, **kw))
 
 
 def test_integer_convolution_large_operands_exact(d):
