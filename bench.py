@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
     ap.add_argument("--host-log2n", type=int, default=28)
     ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run under rocprofv3 for roofline.traffic")
+    ap.add_argument("--describe-rows", action="store_true", help="print what every row of `kernels` runs (ROW_INFO) and exit")
     ap.add_argument("--dry", action="store_true", help="CPU dry mode (tests): gloo, no device work; exercises sharding, the collective and the JSON schema")
     return ap.parse_args()
 
@@ -144,13 +145,10 @@ def cpu_baseline(log2n: int):
     if ctl is not None and hasattr(ctl, "restore_original_limits"):
         ctl.restore_original_limits()
     return {"value": round(n / (tf1 + tw1) / 1e9, 5), "unit": "Gsamples/s", "cores": 1, "kind": "port",
-            "sample": f"2^{log2n} Float32 samples in 2^24-sample segments: overlap-save filt {tf1:.2f}s + welch {tw1:.2f}s, numpy/scipy(pocketfft) "
-                      f"restatement of DSP.jl (not DSP.jl/FFTW; the filt leg is the block loop vectorised over 2048 blocks per call), host has {ncores} cores",
-            "multi": {"value": round(n / (tfm + twm) / 1e9, 5), "cores": ncores,
-                      "sample": f"same sample, scipy.fft.set_workers({ncores}): filt {tfm:.2f}s + welch {twm:.2f}s"},
+            "sample": f"2^{log2n} Float32 samples: filt {tf1:.2f}s + welch {tw1:.2f}s; numpy/scipy(pocketfft) restatement of DSP.jl, not DSP.jl/FFTW; host has {ncores} cores",
+            "multi": {"value": round(n / (tfm + twm) / 1e9, 5), "cores": ncores, "sample": f"same, scipy.fft workers={ncores}: {tfm:.2f}s + {twm:.2f}s"},
             "faithful": {"value": round(nf / (t_faith_filt + t_faith_welch) / 1e9, 5), "cores": 1,
-                         "sample": f"2^{min(log2n, 24)} samples through the line-faithful oracle (one Python iteration per block / frame, frame-by-frame "
-                                   f"Float32 accumulation): filt {t_faith_filt:.2f}s + welch {t_faith_welch:.2f}s"}}
+                         "sample": f"2^{min(log2n, 24)} samples, line-faithful block / frame loops: {t_faith_filt:.2f}s + {t_faith_welch:.2f}s"}}
 
 
 def cpu_baseline_config(config: str, log2n: int):
@@ -241,7 +239,10 @@ class Marks:
     """Row markers for the profiler: before each measured row, one mdsp_fill_kernel launch with (100 + row index) workgroups on the launch stream
     (tools/prof_summary.py rows() cuts the dispatch list at them).  ~2 us each, always outside the timed regions."""
     ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32",
-            "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64")
+            "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64",
+            # round 5
+            "decim16_f32", "resample_441_160_c64", "welch_default", "welch_default_2p24", "spectrogram_default", "filt_32768", "filt_f64", "welch_f64",
+            "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt")
 
     def __init__(self, lib, _lib, stream):
         import torch
@@ -260,6 +261,47 @@ def roof(kernel, ms, alg_bytes, traffic=None, extra=None):
     if extra:
         r.update(extra)
     return r
+
+
+def crow(tm, med, alg_bytes, **extra):
+    """One compact row of `kernels`: median ms of the timer's last sample, algorithmic bytes / time as a fraction of the 8 TB/s HBM peak, the sample's fastest ms.
+    (What each row runs is in ROW_INFO below and in DESIGN.md section 5: the line stays small enough for the driver's record to hold every row.)"""
+    gbs = alg_bytes / (med * 1e-3) / 1e9
+    last = getattr(tm, "last", {})
+    return {"ms": round(med, 4), "frac": round(gbs / HBM_PEAK_GBS, 4), "min": last.get("min_ms"), **extra}   # GB/s = frac x 8000; min: the fastest of the sample
+
+
+# row -> (what runs, shape, algorithmic bytes per input sample); printed by `python bench.py --describe-rows`, not in the JSON line
+ROW_INFO = {
+    "stft": ("stft_fused_kernel", "config 4 share: 8 ch x 2^26 ComplexF32, nfft 1024, hop 256", "40"),
+    "spectrogram": ("stft_fused_kernel (PSD form)", "same signal", "24"),
+    "resample": ("polyphase_mfma_kernel", "config 5 share: 4 ch x 2^28 Float32, 160//147, 5120 taps", "8.354"),
+    "firarb": ("arbitrary_fir_kernel", "row f1: 4 ch x 2^28 Float32, rate 160/147 as Float64, warm trajectory", "8.354"),
+    "resample_f64": ("polyphase kernel", "4 ch x 2^26 Float64, 160//147, 5120 taps", "16.7"),
+    "resample_c32": ("polyphase kernel", "4 ch x 2^26 ComplexF32, 160//147, 5120 taps", "16.7"),
+    "interp2_f32": ("polyphase kernel", "4 ch x 2^26 Float32, 2//1, resample_filter taps", "12"),
+    "decim2_f32": ("polyphase kernel", "4 ch x 2^26 Float32, 1//2", "6"),
+    "decim8_f32": ("decimator kernel (round 5) / matrix cores before", "4 ch x 2^26 Float32, 1//8", "4.5"),
+    "decim16_f32": ("decimator kernel (round 5)", "4 ch x 2^26 Float32, 1//16", "4.25"),
+    "resample_147_160_f32": ("polyphase kernel", "4 ch x 2^26 Float32, 147//160", "7.675"),
+    "resample_160_441_f64": ("polyphase kernel", "4 ch x 2^26 Float64, 160//441", "10.9"),
+    "resample_441_160_c64": ("polyphase kernel", "4 ch x 2^26 ComplexF64, 441//160", "60.1"),
+    "welch_3000": ("gen_ct_kernel<3000>", "2^27 Float32, n = nfft = 3000, 50 % overlap", "4"),
+    "welch_1536": ("gen_ct_kernel<1536>", "2^27 Float32, n = nfft = 1536", "4"),
+    "welch_default": ("multi-pass engine (bigfft.hip)", "welch_pgram(s) with DEFAULT arguments, 2^27 Float32: n = nfft = 2^24, 15 frames", "4"),
+    "welch_default_2p24": ("multi-pass engine", "welch_pgram(s), 2^24 Float32: n = nfft = 2^21", "4"),
+    "spectrogram_default": ("multi-pass engine + untangle", "spectrogram(s) with DEFAULT arguments, 2^27 Float32 -> (2^23 + 1) x 15 Float32", "4 in + 4 per bin out"),
+    "filt_5120": ("upols2_fused_kernel", "filt, 5120 taps, 2^28 Float32", "8"),
+    "filt_32768": ("d.filt(b, x) through the host mirror: segments of 16384 taps on the fused engine + mdsp_shift_add", "32768 taps, 2^27 Float32", "8"),
+    "filt_f64": ("ols_fused_kernel<double>", "the headline filt in Float64: 256 taps, nfft 2048, 2^29 samples", "16"),
+    "welch_f64": ("welch_half_kernel<double>", "the headline welch_pgram in Float64: nfft 4096, 2^29 samples", "8"),
+    "welch_f64_5000": ("gen_ct_kernel<double, 5000>", "2^27 Float64, n = nfft = 5000", "8"),
+    "welch_f64_8000": ("gen_ct_kernel<double, 8000>", "2^27 Float64, n = nfft = 8000", "8"),
+    "mt_pgram": ("d.mt_pgram(x; nw = 4, ntapers = 7) through the host mirror (one multi-pass transform per taper)", "2^22 Float32 (the DPSS tapers are a host eigenproblem: 2^26 would take minutes to set up)", "4"),
+    "hilbert": ("mdsp_hilbert (rocFFT forward, spectrum kernel, rocFFT inverse, scale)", "2^27 Float32 -> ComplexF32", "12"),
+    "conv2d": ("d.conv(A, B): mdsp_convnd_fft", "4096 x 4096 Float32 with a 33 x 33 kernel", "4 in + 4 out"),
+    "filtfilt": ("d.filtfilt(b, x) through the host mirror", "256 taps, 2^26 Float32", "8"),
+}
 
 
 def spread(tm):
@@ -324,18 +366,31 @@ def live_traffic(args):
     except Exception as e:
         return None, f"cannot read the PMC databases: {e}"
     shutil.rmtree(tmp, ignore_errors=True)
-    return res, "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes of this command, 2 steps); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH correction); each row's dispatches are separated by marker launches, so a row reports its OWN launch shape"
+    # bytes = 2 FETCH_SIZE 1024 + WRITE_SIZE 1024 (gfx950 FETCH correction, MI355X_MICROARCH.md); each row's dispatches sit between marker launches
+    return res, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (2 steps), bytes = 2*FETCH*1024 + WRITE*1024"
 
 
 # ------------------------------------------------------------------------------------------------------------------ rows / host path
 def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
-    """The remaining SURVEY section-8 rows at their single-GPU shares (device-resident, HIP events): config 4 stft / spectrogram
-    (8 ch x 2^26 ComplexF32, nfft 1024, hop 256), config 5 resample 160//147 (4 ch x 2^28 Float32), (f)1 FIRArbitrary at the same shape."""
+    """The remaining SURVEY section-8 rows (device-resident, HIP events on the launch stream, median of 9 back-to-back pairs): what each row runs
+    is in ROW_INFO; every row comes back as crow()'s compact dict."""
     import numpy as np
     import torch
+    from fractions import Fraction
     from dsp_jl_amd.periodograms import _StftPlan, compute_window
+    from dsp_jl_amd.dspbase import OlsPlan
     rows = {}
     g = torch.Generator(device="cuda"); g.manual_seed(1776)
+
+    def guarded(name, fn):
+        """a row that fails must not take the others with it"""
+        try:
+            fn()
+        except Exception as e:  # pragma: no cover
+            rows[name] = {"error": str(e)[:120]}
+        torch.cuda.empty_cache()
+
+    # ---- config 4 share: stft / spectrogram
     nch, n = 8, 1 << 26
     s = torch.view_as_complex(torch.randn((nch, n, 2), generator=g, device="cuda", dtype=torch.float32) * math.sqrt(0.5))
     win, norm2 = compute_window(d.hanning, 1024)
@@ -344,12 +399,12 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
         plan = _StftPlan(1024, 768, 1024, win, 1.0 * norm2, False, psd, np.complex64, d.ENGINE_FUSED)
         out = torch.empty((nch, K, 1024), dtype=outdt, device="cuda")
         mark(name)
-        med, best = tm.time(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, s.data_ptr(), n, nch, n, out.data_ptr(), 1024, K * 1024, stream)))
-        rows[name] = roof(f"stft_fused_kernel ({name}, config 4 share: 8 ch x 2^26 ComplexF32, {bps:.0f} B/sample)", med, bps * n * nch,
-                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, s.data_ptr(), n, nch, n, out.data_ptr(), 1024, K * 1024, stream)))
+        rows[name] = crow(tm, med, bps * n * nch)
         del out, plan
     del s
     torch.cuda.empty_cache()
+    # ---- config 5 share: resample 160//147, and FIRArbitrary at the same shape
     nch, n = 4, 1 << 28
     h = resample_taps()
     x = torch.randn((nch, n), generator=g, device="cuda", dtype=torch.float32)
@@ -364,9 +419,8 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
         _lib.check(lib.mdsp_fir_exec(fh, x.data_ptr(), n, n, y.data_ptr(), ol.value, ol.value + 1, C.byref(nw), stream))
 
     mark("resample")
-    med, best = tm.time(fir)
-    rows["resample"] = roof("polyphase_mfma_kernel (config 5 share: 4 ch x 2^28 Float32, 160//147, 8.354 B/sample)", med, (4 + 4 * 160 / 147) * n * nch,
-                            extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
+    med, _ = tm.time(fir)
+    rows["resample"] = crow(tm, med, (4 + 4 * 160 / 147) * n * nch)
     _lib.check(lib.mdsp_fir_destroy(fh))
     rate = 160 / 147
     ha = d.resample_filter(rate, 32).astype(np.float32)
@@ -381,95 +435,166 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
         _lib.check(lib.mdsp_firarb_exec(fa, x.data_ptr(), n, n, ya.data_ptr(), ola.value + 1, ld, C.byref(nw), stream))
 
     mark("firarb")
-    med, best = tm.time(arb)
-    # the kernel's own roofs (it is nowhere near HBM's): per output and tap ONE 8-byte tap-pair read (pfb and its derivative bank, stream_filt.jl:596-616)
-    # and one 16-byte read of the four interleaved channels feed eight FMAs -- 24 bytes of LDS traffic per (output, tap) against the LDS array's
-    # 256 B / clock / CU (MI355X_MICROARCH.md, LDS), and four v_pk_fma_f32 against the measured packed-FMA issue rate (profiles/r02t_valu_rate.txt:
-    # 4.40 clocks per wave instruction with four waves per SIMD = 29.1 FMA lanes per clock and SIMD); both at the 2.4 GHz the part reaches on light
-    # kernels.  SQ counters of the round-4 kernel (tools/sessions/r04_s15.sh): LDS array 65 % busy (1.6 % of it bank conflicts), vector unit 76 % busy,
-    # 1.71 GHz -- the kernel runs at both of its on-chip roofs at the clock the package power allows.
+    med, _ = tm.time(arb)
+    # the kernel's own roofs (it is nowhere near HBM's): 24 bytes of LDS reads per (output, tap) against 256 B / clock / CU, and four v_pk_fma_f32 against the
+    # measured packed-FMA issue rate (profiles/r02t_valu_rate.txt), both at 2.4 GHz -- DESIGN.md section 4.7
     tpp = -(-len(ha) // 32)
-    fma = 2.0 * tpp * ola.value * nch
-    tfl = 2.0 * fma / (med * 1e-3) / 1e12
-    peak = 2.0 * 29.1 * 1024 * 2.4e9 / 1e12
-    lds_bytes = float(tpp) * ola.value * -(-nch // 4) * (8 + 4 * min(nch, 4))   # channel groups of four share one tap-pair read
-    lds_tbs = lds_bytes / (med * 1e-3) / 1e12
-    lds_peak = 256.0 * 256 * 2.4e9 / 1e12
-    rows["firarb"] = roof("arbitrary_fir_kernel (row f1: 4 ch x 2^28 Float32, rate 160/147 as Float64, warm trajectory)", med, (4 + 4 * rate) * n * nch,
-                          extra={"Gsamples_per_s": round(n * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm),
-                                 "lds": {"achieved": round(lds_tbs, 1), "peak": round(lds_peak, 1), "unit": "TB/s of LDS reads (256 B/clk/CU x 256 CUs x 2.4 GHz)",
-                                         "frac": round(lds_tbs / lds_peak, 4), "bytes_per_output_and_tap": 8 + 4 * min(nch, 4),
-                                         "note": "the sub-roof that binds: SQ_LDS_IDX_ACTIVE says 65 % of the LDS-array cycles at the kernel's own 1.71 GHz "
-                                                 "(power-limited clock); conflicts 1.6 %"},
-                                 "valu": {"achieved": round(tfl, 1), "peak": round(peak, 1), "unit": "TFLOP/s (v_pk_fma_f32 issue rate, measured)", "frac": round(tfl / peak, 4),
-                                          "fma_per_output": 2 * tpp,
-                                          "note": "vector unit 76 % busy at 1.71 GHz: half of its instructions are the FMAs, the rest the trajectory replay, staging "
-                                                  "and the Float64 combine of each output"}})
+    tfl = 2.0 * 2.0 * tpp * ola.value * nch / (med * 1e-3) / 1e12
+    lds_tbs = float(tpp) * ola.value * -(-nch // 4) * (8 + 4 * min(nch, 4)) / (med * 1e-3) / 1e12
+    rows["firarb"] = crow(tm, med, (4 + 4 * rate) * n * nch, lds_frac=round(lds_tbs / (256.0 * 256 * 2.4e9 / 1e12), 4),
+                          valu_frac=round(tfl / (2.0 * 29.1 * 1024 * 2.4e9 / 1e12), 4))
     _lib.check(lib.mdsp_firarb_destroy(fa))
     del x, y, ya
     torch.cuda.empty_cache()
-    # the same resampler on the other signal types (DSP.jl's default is Float64), and two small ratios: 4 channels x 2^26 samples
+    # ---- the same resampler on the other signal types and ratios: 4 channels x 2^26 samples, DSP.jl's own resample_filter design per ratio
     n2 = 1 << 26
-    # ... and (round 4) the shapes whose gains had only been measured by builder-run tools: a decimator by eight, the downsampling twin of
-    # config 5 (147//160) and the Float64 160//441 resampler, each with DSP.jl's own resample_filter design for its ratio
     for name, tdt, hdt, lt, lx, esz, (L, M) in (("resample_f64", torch.float64, np.float64, _lib.F64, _lib.F64, 8, (160, 147)),
                                                 ("resample_c32", torch.complex64, np.float32, _lib.F32, _lib.C32, 8, (160, 147)),
                                                 ("interp2_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (2, 1)),
                                                 ("decim2_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (1, 2)),
                                                 ("decim8_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (1, 8)),
+                                                ("decim16_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (1, 16)),
                                                 ("resample_147_160_f32", torch.float32, np.float32, _lib.F32, _lib.F32, 4, (147, 160)),
-                                                ("resample_160_441_f64", torch.float64, np.float64, _lib.F64, _lib.F64, 8, (160, 441))):
-        from fractions import Fraction
-        hh = resample_taps().astype(hdt) if (L, M) == (160, 147) else np.asarray(d.resample_filter(Fraction(L, M)), dtype=hdt)
-        xx = torch.randn((nch, n2), generator=g, device="cuda", dtype=tdt)
-        f2 = C.c_void_p()
-        _lib.check(lib.mdsp_fir_create(C.byref(f2), hh.ctypes.data_as(C.c_void_p), len(hh), L, M, lt, lx, nch))
-        o2 = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(f2, n2, C.byref(o2)))
-        yy = torch.empty((nch, o2.value + 1), dtype=tdt, device="cuda")
-        pth = C.c_int(-1); _lib.check(lib.mdsp_fir_kernel_path(f2, n2, C.byref(pth)))
+                                                ("resample_160_441_f64", torch.float64, np.float64, _lib.F64, _lib.F64, 8, (160, 441)),
+                                                ("resample_441_160_c64", torch.complex128, np.float64, _lib.F64, _lib.C64, 16, (441, 160))):
+        def one():
+            hh = resample_taps().astype(hdt) if (L, M) == (160, 147) else np.asarray(d.resample_filter(Fraction(L, M)), dtype=hdt)
+            xx = torch.randn((nch, n2), generator=g, device="cuda", dtype=tdt)
+            f2 = C.c_void_p()
+            _lib.check(lib.mdsp_fir_create(C.byref(f2), hh.ctypes.data_as(C.c_void_p), len(hh), L, M, lt, lx, nch))
+            o2 = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(f2, n2, C.byref(o2)))
+            yy = torch.empty((nch, o2.value + 1), dtype=tdt, device="cuda")
+            pth = C.c_int(-1); _lib.check(lib.mdsp_fir_kernel_path(f2, n2, C.byref(pth)))
 
-        def fir2():
-            _lib.check(lib.mdsp_fir_reset(f2))
-            _lib.check(lib.mdsp_fir_exec(f2, xx.data_ptr(), n2, n2, yy.data_ptr(), o2.value, o2.value + 1, C.byref(nw), stream))
+            def fir2():
+                _lib.check(lib.mdsp_fir_reset(f2))
+                _lib.check(lib.mdsp_fir_exec(f2, xx.data_ptr(), n2, n2, yy.data_ptr(), o2.value, o2.value + 1, C.byref(nw), stream))
 
-        mark(name)
-        med, best = tm.time(fir2)
-        rows[name] = roof(f"{('generic', 'register-tap', 'matrix-core')[pth.value]} polyphase kernel ({L}//{M}, {len(hh)} taps, 4 ch x 2^26 {str(tdt).split('.')[-1]}, {esz * (1 + L / M):.2f} B/sample)",
-                          med, esz * (1 + L / M) * n2 * nch, extra={"Gsamples_per_s": round(n2 * nch / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
-        _lib.check(lib.mdsp_fir_destroy(f2))
-        del xx, yy
-    torch.cuda.empty_cache()
-    # Welch at the reference's DEFAULT transform sizes (nfft = nextfastfft(n), util.jl:134, periodograms.jl:560): 7-smooth, not powers of two --
-    # the compile-time mixed-radix schedules of csrc/spectral_gen.h.  2^27 Float32 samples, 50 % overlap, 4 B/sample.
+            mark(name)
+            med, _ = tm.time(fir2)
+            rows[name] = crow(tm, med, esz * (1 + L / M) * n2 * nch, path=pth.value)   # 0 generic, 1 register taps, 2 matrix cores, 3 decimator kernel
+            _lib.check(lib.mdsp_fir_destroy(f2))
+        guarded(name, one)
+    # ---- Welch at the reference's DEFAULT transform sizes (nfft = nextfastfft(n), util.jl:134, periodograms.jl:560): the compile-time mixed-radix
+    #      schedules at 3000 / 1536, and (round 5) the DEFAULT call itself -- n = length >> 3 -- on the multi-pass engine
     n3 = 1 << 27
     xr = torch.randn(n3, generator=g, device="cuda", dtype=torch.float32)
     for nfft in (3000, 1536):
         cfg = d.WelchConfig(n3, np.float32, n=nfft, noverlap=nfft // 2, nfft=nfft, window=d.hanning, engine=d.ENGINE_FUSED)
         psd = torch.empty(cfg.nout, dtype=torch.float32, device="cuda")
         mark(f"welch_{nfft}")
-        med, best = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xr.data_ptr(), n3, 1, n3, psd.data_ptr(), cfg.nout, stream)))
-        rows[f"welch_{nfft}"] = roof(f"mixed-radix fused Welch kernel (nfft = n = {nfft} = nextfastfft size, hanning, 50 % overlap, 2^27 Float32, 4 B/sample)", med, 4.0 * n3,
-                                     extra={"Gsamples_per_s": round(n3 / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xr.data_ptr(), n3, 1, n3, psd.data_ptr(), cfg.nout, stream)))
+        rows[f"welch_{nfft}"] = crow(tm, med, 4.0 * n3)
         del cfg, psd
+
+    def welch_default(name, length):
+        cfg = d.WelchConfig(length, np.float32, window=d.hanning)          # n = length >> 3, noverlap = n >> 1, nfft = nextfastfft(n)
+        psd = torch.empty(cfg.nout, dtype=torch.float32, device="cuda")
+        mark(name)
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xr.data_ptr(), length, 1, length, psd.data_ptr(), cfg.nout, stream)))
+        rows[name] = crow(tm, med, 4.0 * length, engine=cfg.engine, nfft=cfg.nfft)
+
+    guarded("welch_default", lambda: welch_default("welch_default", n3))
+    guarded("welch_default_2p24", lambda: welch_default("welch_default_2p24", 1 << 24))
+
+    def spectrogram_default():
+        nn = n3 >> 3
+        w_, norm2_ = compute_window(d.hanning, nn)
+        plan = _StftPlan(nn, nn >> 1, nn, w_, norm2_, True, 1, np.float32, d.ENGINE_AUTO)
+        KK = d.frame_count(n3, nn, nn >> 1)
+        out = torch.empty((KK, plan.nout), dtype=torch.float32, device="cuda")
+        mark("spectrogram_default")
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, xr.data_ptr(), n3, 1, n3, out.data_ptr(), plan.nout, KK * plan.nout, stream)))
+        rows["spectrogram_default"] = crow(tm, med, 4.0 * n3 + 4.0 * KK * plan.nout, engine=plan.engine)
+
+    guarded("spectrogram_default", spectrogram_default)
+
+    def hilbert():
+        out = torch.empty(n3, dtype=torch.complex64, device="cuda")
+        mark("hilbert")
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_hilbert(xr.data_ptr(), n3, 1, n3, _lib.F32, out.data_ptr(), n3, stream)))
+        rows["hilbert"] = crow(tm, med, 12.0 * n3)
+
+    guarded("hilbert", hilbert)
+
+    def filt_long():
+        taps = (np.random.default_rng(32768).standard_normal(32768) / math.sqrt(32768)).astype(np.float32)
+        d.filt(taps, xr)                       # builds and caches the segment plans
+        mark("filt_32768")
+        med, _ = tm.time(lambda: d.filt(taps, xr))
+        rows["filt_32768"] = crow(tm, med, 8.0 * n3)
+
+    guarded("filt_32768", filt_long)
+
+    def filtfilt():
+        xs = xr[: 1 << 26]
+        b = np.asarray(lowpass_taps(256))
+        d.filtfilt(b, xs)
+        mark("filtfilt")
+        med, _ = tm.time(lambda: d.filtfilt(b, xs))
+        rows["filtfilt"] = crow(tm, med, 8.0 * (1 << 26))
+
+    guarded("filtfilt", filtfilt)
+
+    def mt():
+        xs = xr[: 1 << 22].contiguous()
+        d.mt_pgram(xs, nw=4, ntapers=7)        # DPSS tapers (host eigenproblem) and the per-taper plans are built here, outside the timing
+        mark("mt_pgram")
+        med, _ = tm.time(lambda: d.mt_pgram(xs, nw=4, ntapers=7))
+        rows["mt_pgram"] = crow(tm, med, 4.0 * (1 << 22), tapers=7)
+
+    guarded("mt_pgram", mt)
     del xr
-    # filt with a LONG filter: 5120 taps (config 5's prototype length), where optimalfftfiltlength asks for nfft 65536 (dspbase.jl:268-291); the fused
-    # engine runs it as a partitioned overlap-save.  2^28 Float32 samples, 8 B/sample.
-    from dsp_jl_amd.dspbase import OlsPlan
+    torch.cuda.empty_cache()
+
+    def conv2d():
+        A = torch.randn((4096, 4096), generator=g, device="cuda", dtype=torch.float32)
+        B = np.random.default_rng(33).standard_normal((33, 33)).astype(np.float32)
+        d.conv(A, B)
+        mark("conv2d")
+        med, _ = tm.time(lambda: d.conv(A, B))
+        rows["conv2d"] = crow(tm, med, 4.0 * 4096 * 4096 + 4.0 * (4096 + 32) ** 2)
+
+    guarded("conv2d", conv2d)
+    # ---- filt with a LONG filter: 5120 taps (partitioned overlap-save), 2^28 Float32
     n4 = 1 << 28
     xl = torch.randn(n4, generator=g, device="cuda", dtype=torch.float32)
     yl = torch.empty_like(xl)
     tl = (np.random.default_rng(5120).standard_normal(5120) / math.sqrt(5120)).astype(np.float32)
     pl = OlsPlan(tl, d.optimalfftfiltlength(5120, n4), n4, 0, d.ENGINE_FUSED)
     mark("filt_5120")
-    med, best = tm.time(lambda: _lib.check(lib.mdsp_ols_exec(pl._h, xl.data_ptr(), n4, 1, n4, yl.data_ptr(), n4, n4, stream)))
-    rows["filt_5120"] = roof("partitioned overlap-save kernel (filt, 5120 taps, 2^28 Float32, 8 B/sample)", med, 8.0 * n4,
-                             extra={"Gsamples_per_s": round(n4 / med / 1e6, 2), "best_ms": round(best, 4), **spread(tm)})
+    med, _ = tm.time(lambda: _lib.check(lib.mdsp_ols_exec(pl._h, xl.data_ptr(), n4, 1, n4, yl.data_ptr(), n4, n4, stream)))
+    rows["filt_5120"] = crow(tm, med, 8.0 * n4)
     del pl, xl, yl
     torch.cuda.empty_cache()
+
+    # ---- Float64 (DSP.jl's default eltype: util.jl:92-104): the headline pair at 2^29 samples, Welch at the 5000- and 8000-point nextfastfft sizes
+    def f64_rows():
+        n5 = 1 << 29
+        xd = torch.randn(n5, generator=g, device="cuda", dtype=torch.float64)
+        yd = torch.empty_like(xd)
+        pl64 = OlsPlan(np.asarray(lowpass_taps(256), dtype=np.float64), 2048, n5, _lib.OLS_FILT, d.ENGINE_AUTO)
+        mark("filt_f64")
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_ols_exec(pl64._h, xd.data_ptr(), n5, 1, n5, yd.data_ptr(), n5, n5, stream)))
+        rows["filt_f64"] = crow(tm, med, 16.0 * n5)
+        del yd, pl64
+        cfg = d.WelchConfig(n5, np.float64, n=4096, noverlap=2048, window=d.hanning)
+        psd = torch.empty(cfg.nout, dtype=torch.float64, device="cuda")
+        mark("welch_f64")
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xd.data_ptr(), n5, 1, n5, psd.data_ptr(), cfg.nout, stream)))
+        rows["welch_f64"] = crow(tm, med, 8.0 * n5)
+        n6 = 1 << 27
+        for nfft in (5000, 8000):
+            cfg = d.WelchConfig(n6, np.float64, n=nfft, noverlap=nfft // 2, nfft=nfft, window=d.hanning)
+            psd = torch.empty(cfg.nout, dtype=torch.float64, device="cuda")
+            mark(f"welch_f64_{nfft}")
+            med, _ = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xd.data_ptr(), n6, 1, n6, psd.data_ptr(), cfg.nout, stream)))
+            rows[f"welch_f64_{nfft}"] = crow(tm, med, 8.0 * n6, engine=cfg.engine)
+
+    guarded("f64", f64_rows)
     return rows
 
 
-NEW_ROWS_R4 = ("welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64")
 
 
 def measure_host_path(lib, _lib, d, log2n):
@@ -481,8 +606,7 @@ def measure_host_path(lib, _lib, d, log2n):
     x = rng.standard_normal(n, dtype=np.float32)
     plan = OlsPlan(np.asarray(lowpass_taps(256)), 2048, n, _lib.OLS_FILT, d.ENGINE_AUTO)
     cfg = d.WelchConfig(n, np.float32, n=4096, noverlap=2048, window=d.hanning)
-    res = {"sample": f"2^{log2n} Float32 samples (bounded sample of the headline workload); wall clock of the synchronous call, PCIe included",
-           "unit": "Gsamples/s", "note": "reported separately: never part of `value`"}
+    res = {"sample": f"2^{log2n} Float32 samples; wall clock of the synchronous host-pointer calls, PCIe included; never part of `value`", "unit": "Gsamples/s"}
 
     def wall(fn, reps=3):
         fn()
@@ -524,8 +648,7 @@ def measure_host_path(lib, _lib, d, log2n):
             sig = (rng.standard_normal(ns, dtype=np.float32) + 1j * rng.standard_normal(ns, dtype=np.float32)).astype(np.complex64)
             C.memmove(pi, sig.ctypes.data_as(C.c_void_p), ns * 8)
             t = wall(lambda: _lib.check(lib.mdsp_stft_exec_host(sp._h, pi, ns, 1, ns, po, 1024, K * 1024, _lib.HOST_PINNED)))
-            res["stft_pinned"] = {"Gsamples_per_s": round(ns / t / 1e9, 3), "GBps_pcie_d2h": round(8.0 * K * 1024 / t / 1e9, 1), "GBps_pcie_h2d": round(8.0 * ns / t / 1e9, 1),
-                                  "sample": f"one channel of 2^{log2n - 3} ComplexF32 samples, nfft 1024, hop 256 -> {K} columns"}
+            res["stft_pinned"] = {"Gsamples_per_s": round(ns / t / 1e9, 3), "GBps_pcie_d2h": round(8.0 * K * 1024 / t / 1e9, 1), "log2n": log2n - 3}
         finally:
             lib.mdsp_host_free(pi); lib.mdsp_host_free(po)
         nr = 1 << (log2n - 1)
@@ -545,8 +668,7 @@ def measure_host_path(lib, _lib, d, log2n):
                 _lib.check(lib.mdsp_fir_exec_host(fh, pi, nr, nr, po, ol.value, ol.value + 1, C.byref(nw), _lib.HOST_PINNED))
 
             t = wall(fir_host)
-            res["resample_pinned"] = {"Gsamples_per_s": round(nr / t / 1e9, 3), "GBps_pcie_both_ways": round(4.0 * (nr + ol.value) / t / 1e9, 1),
-                                      "sample": f"one channel of 2^{log2n - 1} Float32 samples, 160//147, 5120 taps -> {ol.value} outputs"}
+            res["resample_pinned"] = {"Gsamples_per_s": round(nr / t / 1e9, 3), "GBps_pcie_both_ways": round(4.0 * (nr + ol.value) / t / 1e9, 1), "log2n": log2n - 1}
         finally:
             lib.mdsp_host_free(pi); lib.mdsp_host_free(po)
             lib.mdsp_fir_destroy(fh)
@@ -584,6 +706,10 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.describe_rows:
+        for k, (what, shape, bps) in ROW_INFO.items():
+            print(f"{k:24s} {what}; {shape}; {bps} B per input sample")
+        return
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     if args.gpus is None:
@@ -682,9 +808,8 @@ def main():
         coll = lambda: (psd.sum(0, dtype=torch.float64), mean, float(world))     # (this rank's contribution, the collective's result, divisor)
         names = ("filt", "welch")
         alg = (8.0 * n, 4.0 * n)
-        kern = ("ols_fused_kernel (overlap-save filt, 8 B/sample)", "mdsp_welch_w64_asm (one wavefront per transform, hand-allocated; + zero / reduce / finalize; 4 B/sample)")
-        workload = (f"filt(256-tap overlap-save, nfft=2048) + welch_pgram(nfft=4096, hanning, 50% overlap) per 2^{log2n}-sample Float32 stream; "
-                    "one stream (channel) per GPU; RCCL all-reduce of the 2049-bin PSD for N>1")
+        kern = ("ols_fused_kernel (overlap-save filt, 8 B/sample)", "mdsp_welch_w64c_asm + reduce + finalize (4 B/sample)")
+        workload = f"filt(256 taps, overlap-save nfft 2048) + welch_pgram(nfft 4096, hanning, 50 %) per 2^{log2n}-sample Float32 stream; one stream per GPU; RCCL all-reduce of the PSD for N>1"
         metric, dtype, engine_used = METRIC, "f32", {1: "fused", 2: "rocfft"}[plan.engine]
     elif args.config == "stft":
         from dsp_jl_amd.periodograms import _StftPlan, compute_window
@@ -793,14 +918,15 @@ def main():
                             "ok" if world > 1 else "ok (1 rank: local channel sum only, nothing crossed a link)")
 
     if rank == 0:
+        # ONE compact line: the driver keeps a bounded tail of it, so nothing is said twice -- one traffic_source, no per-row descriptions (ROW_INFO /
+        # --describe-rows have them), stage times as flat numbers in `config` and every row's fraction of the roof once more as flat numbers in `roofline`
         out = {
             "metric": metric,
             "value": round(units_per_rank * world / dt * args.steps / 1e9, 3), "unit": "Gsamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "samples_per_gpu": units_per_rank, "engine": engine_used, "collective": collective,
-                       "collective_check": collective_check,
-                       "stages_ms": {names[0]: round(t_a, 4), names[1]: round(t_b, 4)}},
+                       "collective_check": collective_check, f"stage_ms_{names[0]}": round(t_a, 4), f"stage_ms_{names[1].split()[0]}": round(t_b, 4)},
         }
         traffic, traffic_source = committed_traffic()
         if world == 1 and not args.no_live_pmc:
@@ -814,38 +940,44 @@ def main():
                 traffic_source = f"{traffic_source}; live pass unavailable ({src})"
         tkey = {"filtwelch": ("ols_fused_bytes_per_launch", "welch_fused_bytes_per_launch"), "stft": ("stft_bytes_per_launch", None),
                 "resample": ("resample_bytes_per_launch", None)}[args.config]
-        main_roof = roof(kern[0], t_a, alg[0], traffic.get(tkey[0]) if traffic else None, {"traffic_source": traffic_source})
+        main_roof = roof(kern[0], t_a, alg[0], traffic.get(tkey[0]) if traffic else None)
         kernels = {}
         if args.config == "filtwelch":
-            other = roof(kern[1], t_b, alg[1], traffic.get(tkey[1]) if traffic else None, {"traffic_source": traffic_source})
+            other = roof(kern[1], t_b, alg[1], traffic.get(tkey[1]) if traffic else None)
             # the Welch kernel's other roof: 5 N log2 N flop per 4096-point transform of 4096 new samples against the packed-FP32 add/multiply
             # rate (butterflies are adds, not FMAs): 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz
             tfl = 5.0 * 4096 * 12 * (units_per_rank / 4096) / (t_b * 1e-3) / 1e12
-            other["valu"] = {"achieved": round(tfl, 1), "peak": 78.6, "unit": "TFLOP/s (packed f32 add/mul)", "frac": round(tfl / 78.6, 4)}
+            other["valu_frac"] = round(tfl / 78.6, 4)
             if t_b > t_a:            # `roofline` is the dominant (longer) kernel of the step
                 main_roof, other = other, main_roof
-            kernels["other"] = other
-            out["config"]["stage_Gsamples_per_s"] = {"filt": round(units_per_rank / t_a / 1e6, 2), "welch": round(units_per_rank / t_b / 1e6, 2)}
-            # on-box yardsticks: float4 copy (2 x 4 GiB moved) and read-only stream
+            kernels["other"] = {k: other[k] for k in ("kernel", "achieved", "frac", "traffic", "ms_per_launch", "algorithmic_bytes_per_launch") if k in other}
+            if "valu_frac" in other:
+                kernels["other"]["valu_frac"] = other["valu_frac"]
+            main_roof["other_kernel_ms"] = round(min(t_a, t_b), 4)
+            main_roof["other_kernel_frac"] = kernels["other"]["frac"]
+            # on-box yardsticks: float4 copy (2 x 4 GiB moved), read-only stream, and the best 1:1 copy this box does (nontemporal float4, four workgroups per CU)
             nb = units_per_rank * 4
             mark("yardsticks")
             med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench(y.data_ptr(), x.data_ptr(), nb, stream)), reps=3)
-            kernels["copy_float4_GBps"] = round(2 * nb / med / 1e6, 1)
+            kernels["copy_GBps"] = round(2 * nb / med / 1e6, 1)
             med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 4, 8, stream)), reps=3)
-            kernels["read_float4_GBps"] = round(nb / med / 1e6, 1)
-            # the best 1:1 copy this box does (MI355X_MICROARCH.md quotes 6.29 TB/s): nontemporal float4, four workgroups per CU
+            kernels["read_GBps"] = round(nb / med / 1e6, 1)
             med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 2, 4, stream)), reps=3)
-            kernels["copy_float4_nontemporal_4wg_GBps"] = round(2 * nb / med / 1e6, 1)
+            kernels["copy_nt_4wg_GBps"] = round(2 * nb / med / 1e6, 1)
         out["roofline"] = main_roof
+        out["traffic_source"] = traffic_source
         if world == 1 and not args.no_rows and args.config == "filtwelch":
             del x, y
             torch.cuda.empty_cache()
             try:
-                kernels.update(measure_rows(tm, lib, _lib, d, stream, mark))
-                for key in ("stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32") + NEW_ROWS_R4:
-                    if key in kernels and traffic:
-                        kernels[key]["traffic"] = traffic.get(f"{key}_bytes_per_launch")
-                        kernels[key]["traffic_source"] = traffic_source
+                rows = measure_rows(tm, lib, _lib, d, stream, mark)
+                for key, r in rows.items():
+                    tb = traffic.get(f"{key}_bytes_per_launch") if traffic else None
+                    if tb and "frac" in r:     # HBM bytes per launch of the row's dominant kernel / its algorithmic bytes
+                        r["traffic_x"] = round(tb / (r["frac"] * HBM_PEAK_GBS * 1e9 * r["ms"] * 1e-3), 3)
+                    if "frac" in r:
+                        main_roof[f"f_{key}"] = r["frac"]
+                kernels.update(rows)
             except Exception as e:  # pragma: no cover
                 kernels["rows_error"] = str(e)
         out["kernels"] = kernels

@@ -45,8 +45,9 @@ def pmc(path):
 # belong to the row of the first, so a row's counters never mix with another row's dispatches of the same template instantiation.
 MARK_KERNEL, MARK_BASE = "mdsp_fill_kernel", 100
 ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resample_f64", "resample_c32", "interp2_f32", "decim2_f32",
-        "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64")   # == bench.py Marks.ROWS
-
+        "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64",
+        "decim16_f32", "resample_441_160_c64", "welch_default", "welch_default_2p24", "spectrogram_default", "filt_32768", "filt_f64", "welch_f64",
+        "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt")   # == bench.py Marks.ROWS
 
 def rows(path, min_ns=20000):
     """Per bench row: the kernels dispatched in that row's marker segment with their mean counter values -> {row: {kernel: {...}}}.
@@ -84,10 +85,12 @@ def dominant(rowd, pat=""):
 ROW_KERNELS = (("ols_fused", "step", "ols_fused_kernel"), ("welch_fused", "step", "welch_"), ("copy", "yardsticks", "mdsp_copy_kernel"),
                ("stft", "stft", "stft_"), ("spectrogram", "spectrogram", "stft_"), ("resample", "resample", "polyphase_"), ("firarb", "firarb", "arbitrary_fir_kernel"),
                ("resample_f64", "resample_f64", "polyphase_"), ("resample_c32", "resample_c32", "polyphase_"), ("interp2_f32", "interp2_f32", "polyphase_"),
-               ("decim2_f32", "decim2_f32", "polyphase_"), ("welch_3000", "welch_3000", "gen_"), ("welch_1536", "welch_1536", "gen_"),
-               ("filt_5120", "filt_5120", "upols"), ("decim8_f32", "decim8_f32", "polyphase_"), ("resample_147_160_f32", "resample_147_160_f32", "polyphase_"),
-               ("resample_160_441_f64", "resample_160_441_f64", "polyphase_"))
-
+               ("decim2_f32", "decim2_f32", ""), ("welch_3000", "welch_3000", "gen_"), ("welch_1536", "welch_1536", "gen_"),
+               ("filt_5120", "filt_5120", "upols"), ("decim8_f32", "decim8_f32", ""), ("resample_147_160_f32", "resample_147_160_f32", "polyphase_"),
+               ("resample_160_441_f64", "resample_160_441_f64", "polyphase_"),
+               # round 5 (pattern "": the row's dominant kernel whatever its name -- several rows run more than one kernel: the figure is that kernel's alone)
+               ("decim16_f32", "decim16_f32", ""), ("resample_441_160_c64", "resample_441_160_c64", ""), ("filt_f64", "filt_f64", "ols_"), ("welch_f64", "welch_f64", "welch_"),
+               ("welch_f64_5000", "welch_f64_5000", "gen_"), ("welch_f64_8000", "welch_f64_8000", "gen_"), ("hilbert", "hilbert", ""))
 
 def traffic_rows(fetch_db, write_db):
     """HBM bytes per launch of each row's dominant kernel from separate --pmc FETCH_SIZE / WRITE_SIZE passes of a marker-carrying bench.py run
