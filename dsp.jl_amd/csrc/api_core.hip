@@ -67,6 +67,7 @@ static void read_tunables_locked() {
     t.host_chunk_mib = std::max(1, geti("MDSP_HOST_CHUNK_MIB", 64));
     t.ols_prefetch = geti("MDSP_OLS_PREFETCH", 0);
     t.gen_wide = geti("MDSP_GEN_WIDE", 1);
+    t.gen_ct_f64_max = geti("MDSP_GEN_CT_F64_MAX", 8000);
     t.bigfft = geti("MDSP_BIGFFT", 1);
     t.big_chunk_mib = std::max(1, geti("MDSP_BIG_CHUNK_MIB", 1024));
     t.big_groups = std::max(0, geti("MDSP_BIG_GROUPS", 0));

@@ -149,6 +149,7 @@ struct Tunables {
     int fir_mm_ng = 0;                  // MDSP_FIR_MM_NG           : at most this many 16 CH-row groups per tile (0 = default 8)
     int fir_mm_nd = 0, fir_mm_ns = 0;   // MDSP_FIR_MM_ND / _NS     : its DMA / store waves (0 = default: 2 DMA waves, 2 store waves for ratios >= 1, else 4)
     int gen_wide = 1;                   // MDSP_GEN_WIDE=0          : nextfastfft sizes: round 3's schedules of small radices instead of the three-pass composite-radix ones
+    int gen_ct_f64_max = 8000;          // MDSP_GEN_CT_F64_MAX      : Float64 nextfastfft sizes above this leave the single-workgroup compile-time schedules (for the multi-pass engine)
     int ols_prefetch = 0;               // MDSP_OLS_PREFETCH=1      : overlap-save kernel with software prefetch of the next unit (default: off)
     int bigfft = 1;                     // MDSP_BIGFFT=0            : transforms above the one-workgroup sizes go to the rocFFT pipeline instead of the multi-pass fused engine (bigfft.hip)
     int big_chunk_mib = 1024;           // MDSP_BIG_CHUNK_MIB       : work buffer of the multi-pass engine per launch group.  Measured 16 .. 2048 MiB (profiles/r05_bigfft_sessions.json):

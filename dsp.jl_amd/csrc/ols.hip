@@ -888,8 +888,9 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
     if constexpr (N == 2048 && !CPLX && !DBL) {
         switch (variant) {
             //                                    R  N   E  G  TW PAD CPLX MINW NBUF PREF HREG PERM   (TW: 0 global, 1 regs, 2 LDS)
-            case 1: return launch_fused_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, true, true, false>(a, s);   // identity lanes, pad 4 (previous default)
             case 2: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, false>(a, s);   // identity lanes, pad 5 (best E = 8 form)
+#ifdef MDSP_DEBUG_KNOBS   // the variants that lost (HISTORY.md section 4.2): only in builds made with -DMDSP_DEBUG_KNOBS
+            case 1: return launch_fused_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, true, true, false>(a, s);   // identity lanes, pad 4 (previous default)
             case 10: return launch_fused_variant<R, N, 8, 1, 1, 5, CPLX, 2, 2, true, true, true>(a, s);   // permuted lanes, pad 5
             case 11: return launch_fused_variant<R, N, 16, 2, 1, 5, CPLX, 2, 1, true, true, false>(a, s);  // E = 16: two waves per transform
             case 12: return launch_fused_variant<R, N, 16, 2, 1, 4, CPLX, 2, 1, true, true, false>(a, s);  // (= default)
@@ -924,6 +925,7 @@ template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a
             case 35: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 3, 1, false, true, false, true>(a, s);   // 29 + staged stores
             case 36: return launch_fused_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, false, true, false, false, true>(a, s);   // 30 + the next unit's span staged in LDS by DMA
             case 37: return launch_fused_variant<R, N, 16, 1, 3, 4, CPLX, 3, 1, false, true, false, false, true>(a, s);   // 29 (hybrid twiddles, <= 168 VGPRs) + DMA staging
+#endif
             // DEFAULT (= 30): register twiddles, filter spectrum in registers, no software prefetch, ONE transform per 128-thread workgroup
             // (191 VGPRs, four workgroups of two waves per CU).  12-round interleaved A/B on two boxes (profiles/r02l_ols_decoupled.json,
             // r02e_ols_ab.json): 1.85 / 1.78 ms vs 1.93 / 1.86 (29: hybrid twiddles, 3 waves per SIMD) vs 2.05 / 1.97 (26: the same kernel
@@ -1249,86 +1251,13 @@ int mdsp_ols_plan_geometry(mdsp_ols_plan plan, int64_t* exec_nfft, int64_t* exec
     return MDSP_OK;
 }
 
-// ---- the hand-allocated kernel of the headline shape (csrc/ols_w64_asm.s, generated by tools/gen_ols_asm.py) -------------------------------------------
-// Real Float32, 256 taps, nfft 2048: one wavefront per FOUR blocks (two 2048-point transforms as 32 x 64 with one exchange each way, no barrier),
-// 3211 instructions per unit.  It runs whole INTERIOR units -- four consecutive blocks starting at a multiple of four (so that a block range and the
-// whole column make the same choice for every block: host-pipeline chunks stay bit-identical to the device-resident call), all four windows inside
-// x, all outputs inside y, first block >= 4; the few blocks in front of and behind them go through ols_fused_kernel.
-#include "ols_w64_asm_co.h"   // static const unsigned char ols_w64_asm_co[]; generated by build.py from ols_w64_asm.s
-
-struct OlsAsmArgs {
-    const float* x;
-    float* y;
-    const float* H;
-    const float* tw;
-    int64_t ldx, ldy, g_first, nunits, run_len;
-};
-static_assert(sizeof(OlsAsmArgs) == 72, "kernarg layout of mdsp_ols_w64_asm");
-
-__global__ __launch_bounds__(64) void ols_w64asm_prepare_kernel(const cx<float>* __restrict__ table, float* __restrict__ tw) {
-    const int lane = threadIdx.x, ke = lane & 31;   // lane (ke, tau): W2048^{8 ke j}, W2048^{ke j}, j = 1..7
-    for (int j = 1; j < 8; ++j) {
-        const cx<float> a = table[(8 * ke * j) & 2047], b = table[(ke * j) & 2047];
-        tw[28 * lane + 2 * (j - 1)] = a.x;
-        tw[28 * lane + 2 * (j - 1) + 1] = a.y;
-        tw[28 * lane + 14 + 2 * (j - 1)] = b.x;
-        tw[28 * lane + 14 + 2 * (j - 1) + 1] = b.y;
-    }
-}
-
-static int ols_w64asm_function(hipFunction_t* fn) {
-    static std::mutex mu;
-    static hipModule_t mods[64];
-    static hipFunction_t fns[64];
-    int dev = 0;
-    MDSP_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    if (!fns[dev & 63]) {
-        MDSP_HIP(hipModuleLoadData(&mods[dev & 63], ols_w64_asm_co));
-        MDSP_HIP(hipModuleGetFunction(&fns[dev & 63], mods[dev & 63], "mdsp_ols_w64_asm"));
-    }
-    *fn = fns[dev & 63];
-    return MDSP_OK;
-}
-
-static bool ols_w64asm_eligible(const mdsp_ols_plan_s* pl) {
-    // MDSP_OLS_VARIANT=40 only: measured 1.85 ms per 2^30 samples against 1.73 for ols_fused_kernel (gpurun_out/s9, profiles/r04_ols_asm_ablation.json) -- both
-    // sit at the box's mixed read + write rate (without its loads the kernel takes 1.02 ms, without its stores 0.98-1.22), so the default stays ols_fused_kernel
-    return pl->engine == MDSP_ENGINE_FUSED && pl->dtype == MDSP_F32 && pl->partitions == 1 && pl->nfft == 2048 && pl->nb == 256 && pl->variant == 40 &&
-           tunables().runs_per_slot == 1 && tunables().wg_per_cu == 0;
-}
-
-// units [0, nunits) of every column: blocks g_first + 4 u .. + 3
-static int ols_run_w64asm(mdsp_ols_plan_s* pl, const void* x, int64_t ncols, int64_t ldx, void* y, int64_t ldy, int64_t g_first, int64_t nunits, hipStream_t s) {
-    hipFunction_t fn = nullptr;
-    MDSP_TRY(ols_w64asm_function(&fn));
-    if (pl->w64tw.bytes == 0) {
-        MDSP_TRY(pl->w64tw.reserve(64 * 28 * sizeof(float)));
-        hipLaunchKernelGGL(ols_w64asm_prepare_kernel, dim3(1), dim3(64), 0, s, pl->table.as<cx<float>>(), pl->w64tw.as<float>());
-        MDSP_LAUNCH_CHECK();
-    }
-    const int64_t per_col = std::max<int64_t>(1, (int64_t)device_cu_count() / std::max<int64_t>(1, ncols));
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(nunits, 8), per_col));
-    OlsAsmArgs ka;
-    ka.x = static_cast<const float*>(x);
-    ka.y = static_cast<float*>(y);
-    ka.H = pl->H.as<float>();
-    ka.tw = pl->w64tw.as<float>();
-    ka.ldx = ldx;
-    ka.ldy = ldy;
-    ka.g_first = g_first;
-    ka.nunits = nunits;
-    ka.run_len = cdiv(nunits, (int64_t)grid * 8);
-    size_t ksz = sizeof(ka);
-    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ksz, HIP_LAUNCH_PARAM_END};
-    MDSP_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, (unsigned)ncols, 1, 512, 1, 1, 0, s, nullptr, cfg));
-    return MDSP_OK;
-}
+// (Round 4's hand-allocated kernel of the headline shape -- one wavefront per four blocks, csrc/ols_w64_asm.s -- measured 5 - 7 % SLOWER than ols_fused_kernel on
+// two boxes (profiles/r04_ols_asm_ablation.json) and was removed in round 5 together with its generator; HISTORY.md section 4.2 has the record.)
 
 // blocks [g_begin, g_end) of every column's block grid (g_end < 0: all).  x / y may be "virtual" bases: only the elements those blocks
 // touch are dereferenced (mdsp_ols_exec_range).
 static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev, int64_t nout, int64_t ldy,
-                         int64_t g_begin, int64_t g_end, hipStream_t s, int64_t x_lo = 0, bool no_asm = false) {
+                         int64_t g_begin, int64_t g_end, hipStream_t s, int64_t x_lo = 0) {
     const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
     const int64_t nblocks = cdiv(nout, plan->L);
     if (plan->partitions > 1) {   // long filters: uniformly partitioned overlap-save
@@ -1341,23 +1270,6 @@ static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int6
     }
     if (g_end < 0 || g_end > nblocks) g_end = nblocks;
     if (g_begin >= g_end) return MDSP_OK;
-    if (!no_asm && ols_w64asm_eligible(plan)) {
-        const int64_t inside = std::min(nx, nout) / plan->L;                    // blocks whose windows and outputs lie wholly inside x and y
-        const int64_t ga = (std::max<int64_t>(g_begin, 4) + 3) & ~int64_t(3), gb = std::min(g_end, inside) & ~int64_t(3);
-        if (gb - ga >= 4 * 64) {   // runs of at least 64 whole units (shorter ranges: ols_fused_kernel spreads pairs of blocks over more CUs)
-            auto edge = [&](int64_t b0, int64_t b1) -> int {                     // ols_fused_kernel on the blocks the units do not cover, column by column
-                if (b0 >= b1) return MDSP_OK;
-                const size_t esz = dtype_size(plan->dtype);
-                for (int64_t c = 0; c < ncols; ++c)
-                    MDSP_TRY(ols_exec_core(plan, static_cast<const char*>(x_dev) + (size_t)(c * ldx) * esz, nx, 1, nx, static_cast<char*>(y_dev) + (size_t)(c * ldy) * esz,
-                                           nout, nout, b0, b1, s, x_lo, true));
-                return MDSP_OK;
-            };
-            MDSP_TRY(edge(g_begin, ga));
-            MDSP_TRY(ols_run_w64asm(plan, x_dev, ncols, ldx, y_dev, ldy, ga, (gb - ga) / 4, s));
-            return edge(gb, g_end);
-        }
-    }
     if (plan->engine == MDSP_ENGINE_ROCFFT) {
         const int64_t ub = g_begin, ue = (g_begin == 0 && g_end == nblocks) ? -1 : g_end;
         if (cplx) return dbl ? exec_rocfft<double, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s, ub, ue)

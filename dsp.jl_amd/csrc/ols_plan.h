@@ -16,5 +16,4 @@ struct mdsp_ols_plan_s {
     mdsp::DevBuf td, fd;
     int64_t batch = 0;
     int variant = 0;  // fused kernel variant (tuning knob, MDSP_OLS_VARIANT)
-    mdsp::DevBuf w64tw;   // mdsp_ols_w64_asm: per-lane twiddles (64 x 28 Float32), built at the plan's first launch of that kernel
 };

@@ -696,7 +696,13 @@ int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) 
     // real-signal columns up to 4096 points (1.4-3x), complex columns above (1.6x); elsewhere the two are within 20 % and rocFFT is kept.
     // Round 3: the sizes with a compile-time schedule (spectral_gen.h, Float32 / ComplexF32) beat the rocFFT pipeline 2-9x in every mode
     // (profiles/r03d_mixed_ct.json) and are always taken.
-    const bool gen_wins = big_ok || fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
+    // ... taken by AUTO where it measured faster than the rocFFT pipeline (profiles/r05_big_vs_rocfft.json, 2^26 samples): powers of two from 16384 on
+    // (two-stage register passes: Welch 1.5 - 2.2x, columns 1.1 - 1.4x; the 8192-point Float64 split loses 0.7 - 0.8x), other 7-smooth sizes from
+    // 50000 points on for Welch and real-signal columns (1.1 - 1.7x at 50000 / 100000 / 125000 / 200000; complex columns lose 0.7 - 0.9x there, and
+    // below 50000 the generic passes' small tiles lose to rocFFT at most sizes: 8400 .. 10000 0.7x, 20000 0.5x, 40000 1.0x)
+    const bool pow2 = (nfft & (nfft - 1)) == 0;
+    const bool big_wins = big_ok && (pow2 ? nfft >= 16384 : (nfft >= 50000 && !(kind == 1 && dtype_is_complex(dtype))));
+    const bool gen_wins = big_wins || fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
                           (gen_size_ok(dtype, nfft) && ((nfft <= 4096) == (kind == 0 || !dtype_is_complex(dtype))));
     if (eng == MDSP_ENGINE_AUTO) eng = gen_wins ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
     if (eng == MDSP_ENGINE_FUSED && !fused_ok)
@@ -1534,14 +1540,22 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
             if constexpr (N == 4096 && sizeof(R) == 4) {  // tuning alternatives of the headline shape (MDSP_WELCH_VARIANT)
                 done = true;
                 //                                              R  N  E   G  TW PAD MINW NBUF
-                if (pl->variant == 10) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 1>(pl, a, st, &nslices);        // identity lanes, pad 4 (previous default)
+                // product builds: 18 (the round-2 form: identity lanes, pad 5), 30 (welch_half3_kernel, the default below the hand-allocated kernel's stream
+                // length) and 43 (mdsp_welch_w64c_asm, the default); every other variant lost its A/B (HISTORY.md section 4.3) and is built with -DMDSP_DEBUG_KNOBS only
+                if (pl->variant == 18) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, false>(pl, a, st, &nslices);   // identity lanes, pad 5
+                else if (pl->variant == 30) rc = welch_run_half3<N, 5, 1>(pl, a, st, &nslices);   // round 3: paired samples, branch-free, window in the first stage
+                else if (pl->variant == 43) {   // ... the same, hand-allocated, shared half-frame carried (csrc/welch_w64c_asm.s): reduces into pl->reduced itself
+                    bool handled = false;
+                    rc = w64::welch_run_w64asm(pl, a, st, &handled);
+                    if (rc == MDSP_OK && handled) goto reduced_done;
+                }
+#ifdef MDSP_DEBUG_KNOBS
+                else if (pl->variant == 10) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 1>(pl, a, st, &nslices);        // identity lanes, pad 4 (previous default)
                 else if (pl->variant == 11) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 2>(pl, a, st, &nslices);
-                else if (pl->variant == 18) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, false>(pl, a, st, &nslices);   // identity lanes, pad 5
                 else if (pl->variant == 19) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 2, true>(pl, a, st, &nslices);    // permuted, two LDS buffers
                 else if (pl->variant == 20) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, true>(pl, a, st, &nslices);    // permuted lanes, pad 5
                 else if (pl->variant == 21) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 2, false>(pl, a, st, &nslices);   // identity lanes, pad 5, two LDS buffers
                 else if (pl->variant == 22) rc = welch_run_half<R, N, EH, GH, 1, 4, 2, 2, 2>(pl, a, st, &nslices);       // wave-private last exchange (one real barrier per transform)
-                // no software prefetch, register diets for a third workgroup per CU
                 else if (pl->variant == 23) rc = welch_run_half<R, N, EH, GH, 1, 5, 2, 1, 0, false>(pl, a, st, &nslices);   // registers, no prefetch (still two workgroups)
                 else if (pl->variant == 24) rc = welch_run_half<R, N, EH, GH, 3, 5, 3, 1, 0, false>(pl, a, st, &nslices);   // hybrid twiddles, scalar accumulators, <= 168 VGPRs
                 else if (pl->variant == 25) rc = welch_run_half<R, N, EH, GH, 3, 4, 3, 1, 0, false>(pl, a, st, &nslices);   // same, pad 4
@@ -1553,24 +1567,17 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
                 else if (pl->variant == 15) rc = welch_run_half<R, N, 8, 1, 1, 4, 4, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 16) rc = welch_run_half<R, N, EH, GH, 3, 4, 3, 1>(pl, a, st, &nslices);
                 else if (pl->variant == 17) rc = welch_run_half<R, N, EH, GH, 3, 4, 2, 1>(pl, a, st, &nslices);
-                else if (pl->variant == 30) rc = welch_run_half3<N, 5, 1>(pl, a, st, &nslices);   // round 3: paired samples, branch-free, window in the first stage
-#ifndef MDSP_WELCH_PROF
                 else if (pl->variant == 31) rc = welch_run_half3<N, 5, 2>(pl, a, st, &nslices);   // ... with two LDS buffers (one barrier per exchange)
-#endif
                 else if (pl->variant == 32) rc = welch_run_half3<N, 4, 1>(pl, a, st, &nslices);   // ... pad 4
                 else if (pl->variant == 33) rc = welch_run_half3<N, 5, 1, true>(pl, a, st, &nslices);   // ... two units in flight (two register sets)
                 else if (pl->variant == 34) rc = welch_run_half3<N, 4, 1, true>(pl, a, st, &nslices);
-                else if (pl->variant == 42 || pl->variant == 43) {   // ... the same, hand-allocated (csrc/welch_w64_asm.s; 43: welch_w64c_asm.s, shared half-frame carried): reduces into pl->reduced itself
-                    bool handled = false;
-                    rc = w64::welch_run_w64asm(pl, a, st, &handled, pl->variant == 43);
-                    if (rc == MDSP_OK && handled) goto reduced_done;
-                }
                 else if (pl->variant == 41) rc = w64::welch_run_w64b(pl, a, st, &nslices);  // ... two waves per SIMD: two-level twiddles, direct loads
                 else if (pl->variant == 40) rc = w64::welch_run_w64(pl, a, st, &nslices);   // round 4: one wavefront per transform, 64 x 64, one exchange
                 else if (pl->variant == 35 || pl->variant == 36) {   // half-frames staged in LDS by DMA, two units ahead (pad 5 / pad 4)
                     rc = pl->variant == 35 ? welch_run_half4<N, 5>(pl, a, st, &nslices) : welch_run_half4<N, 4>(pl, a, st, &nslices);
                     if (rc == -1000) rc = welch_run_half3<N, 5, 1>(pl, a, st, &nslices);
                 }
+#endif
                 else done = false;
             }
             if (!done) {
@@ -1598,6 +1605,7 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
         }
     }
     if constexpr (N == 4096 && !CPLX && sizeof(R) == 4) {
+#ifdef MDSP_DEBUG_KNOBS
         switch (pl->variant) {  // tuning alternatives (MDSP_WELCH_VARIANT), built for the headline shape only
             //                                  R  N   E  G TW PAD CPLX MINW NBUF PREF WIN64      (TW: 0 global, 1 regs, 2 LDS)
             case 1: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 2, true, false>(pl, a, st, &nslices); break;
@@ -1612,6 +1620,9 @@ int welch_launch_n(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st) {
             case 10: rc = welch_run_variant<R, N, 8, 1, 1, 4, CPLX, 2, 2, true, false>(pl, a, st, &nslices); break;
             default: rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, false>(pl, a, st, &nslices); break;
         }
+#else
+        rc = welch_run_variant<R, N, 16, 1, 1, 4, CPLX, 2, 1, true, false>(pl, a, st, &nslices);
+#endif
     } else {
         bool done = false;
         if constexpr (CPLX && sizeof(R) == 4 && Gm::E > 4) {   // complex Float32 frames advancing by whole elements: overlap stays in registers

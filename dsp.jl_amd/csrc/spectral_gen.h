@@ -511,7 +511,7 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     return MDSP_OK;
 }
 inline bool gen_ct_size(int dtype, int64_t nfft, bool direct) {
-    if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > (direct ? GEN_CT_F64_MAX : GEN_CT_F64_REAL_COLUMNS_MAX))) return false;
+    if (!MDSP_GEN_CT || (dtype_is_double(dtype) && nfft > std::min<int64_t>(tunables().gen_ct_f64_max, direct ? GEN_CT_F64_MAX : GEN_CT_F64_REAL_COLUMNS_MAX))) return false;
     switch (nfft) {
 #define MDSP_X(N, ...) case N:
         MDSP_GEN_CT_SIZES(MDSP_X)

@@ -47,6 +47,7 @@ constexpr int WIN_BYTES = HALF * 8;                               // (w[p], w[p 
 constexpr int LDS_BYTES = WIN_BYTES + 4 * WAVE_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
+#ifdef MDSP_DEBUG_KNOBS   // the two HIP forms of this transform (variants 40 / 41) lost to the hand-allocated one: debug builds only (HISTORY.md section 4.3)
 // the 64 x 64 transposition of fft_w64.h on the wave's registers: v[slot64(ke)] = M[lane][ke] in, v[T] = M[T][lane] out
 __device__ __forceinline__ void transpose64(cx<float> (&v)[64], cx<float>* xb, int lane) {
     cx<float> m[64];   // logical registers
@@ -373,6 +374,8 @@ inline int welch_run_w64(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int
     return MDSP_OK;
 }
 
+#endif   // MDSP_DEBUG_KNOBS
+
 // ---- the hand-allocated forms: csrc/welch_w64c_asm.s (variant 43, the default: tools/gen_welch_asm_c.py) and csrc/welch_w64_asm.s (variant 42:
 // tools/gen_welch_asm.py) -----------------------------------------------------------------------------------------------------------------------------
 // Same transform as welch_w64b_kernel (two waves per SIMD, two-level twiddles, direct loads) with every register assigned by the generator: all 256
@@ -384,8 +387,9 @@ inline int welch_run_w64(mdsp_welch_plan_s* pl, SpecArgs& a, hipStream_t st, int
 //   * Float32 partial rows part[((slot nch + ch) nflush + f) N + bin]: a wave with U units writes exactly ceil(U / 128) of its nflush rows, the row
 //     reduction skips the others (no zeroing);
 //   * the units they run all have both frames; the odd last frame of a channel goes through welch_half3_kernel and is added to the same sums.
-#include "welch_w64_asm_co.h"    // static const unsigned char welch_w64_asm_co[]; generated by build.py from welch_w64_asm.s
-#include "welch_w64c_asm_co.h"   // ... welch_w64c_asm_co[]: the same kernel with the shared half-frame carried (tools/gen_welch_asm_c.py)
+#include "welch_w64c_asm_co.h"   // static const unsigned char welch_w64c_asm_co[]; generated by build.py from welch_w64c_asm.s (tools/gen_welch_asm_c.py)
+// (variant 42, csrc/welch_w64_asm.s -- the first hand-allocated form, which re-read the shared half-frame: 1.32 x the algorithmic bytes -- was removed in round 5;
+// its generator tools/gen_welch_asm.py stays: gen_welch_asm_c.py builds on its scheduler, allocator and emulator)
 
 struct W64AsmArgs {
     const float* s;
@@ -476,8 +480,9 @@ inline int w64asm_function(hipFunction_t* fn, bool carry) {
     std::lock_guard<std::mutex> lk(mu);
     W64AsmModule& m = mods[carry ? 1 : 0][dev & 63];
     if (!m.fn) {
-        MDSP_HIP(hipModuleLoadData(&m.mod, carry ? welch_w64c_asm_co : welch_w64_asm_co));
-        MDSP_HIP(hipModuleGetFunction(&m.fn, m.mod, carry ? "mdsp_welch_w64c_asm" : "mdsp_welch_w64_asm"));
+        (void)carry;
+        MDSP_HIP(hipModuleLoadData(&m.mod, welch_w64c_asm_co));
+        MDSP_HIP(hipModuleGetFunction(&m.fn, m.mod, "mdsp_welch_w64c_asm"));
     }
     *fn = m.fn;
     return MDSP_OK;

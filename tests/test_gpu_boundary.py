@@ -887,7 +887,7 @@ def test_polyphase_nonfinite_samples_leave_the_reference_hole(d, torch, L, M, nt
     assert outs["regtap"][1] != 2                                  # MDSP_FIR_MM=0 never takes the matrix-core kernel
 
 
-@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36, 40, 41, 42, 43])
+@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 35, 36, 40, 41, 43])
 def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
     """welch_half3_kernel (paired samples, role-swapping units, window folded into the first butterfly stage, frame b's first half loaded a
     second time under the unit's have-frame-b predicate): every frame count parity, the odd last frame, one to three frames, several
@@ -895,6 +895,8 @@ def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
     against the round-2 kernel (same frames, same accumulators; only the rounding of the first stage differs)."""
     from dsp_jl_amd import _lib
     from oracle import periodograms as opg, windows as ow
+    if variant not in (30, 43) and not _lib.lib().mdsp_debug_knobs():
+        pytest.skip("product builds keep the default (43), its fallback (30) and the round-2 form (18); the variants that lost are built with -DMDSP_DEBUG_KNOBS only")
     rng = np.random.default_rng(300 + variant)
     try:
         for length in (4096, 6144, 8191, 8192, 10240, 12288, 100_000, 4096 * 700 + 2048, (1 << 23) + 4097):
@@ -1116,6 +1118,9 @@ def test_host_pipeline_polyphase_filter(d, torch):
 
 @pytest.mark.parametrize("variant", [36, 37])
 def test_overlap_save_lds_dma_staging_is_bit_identical(d, torch, variant):
+    from dsp_jl_amd import _lib as _l
+    if not _l.lib().mdsp_debug_knobs():
+        pytest.skip("variants 36 / 37 lost their A/B and are built with -DMDSP_DEBUG_KNOBS only (round 5)")
     """ols_fused_kernel<..., XDMA>: the next unit's span goes HBM -> LDS by buffer_load ... lds while this unit is transformed.  Only WHERE the
     samples wait changes, so outputs must equal the direct-load kernel bit for bit: signals of every edge shape (shorter than a block, one unit,
     an odd block count, leading zero padding, the clamped tail), several columns (units of different columns alternate in a slot), conv mode
@@ -1150,52 +1155,6 @@ def test_overlap_save_lds_dma_staging_is_bit_identical(d, torch, variant):
                 _lib.check(lib.mdsp_ols_exec_range(plan._h, xs.data_ptr(), lo, hi - lo, nx, ys.data_ptr(), g0, g1 - g0, nx, None))
                 torch.cuda.synchronize()
                 assert torch.equal(ys, ref[0, g0 * L:hi])
-    finally:
-        _lib.set_tunable("MDSP_OLS_VARIANT", None)
-
-
-def test_overlap_save_hand_allocated_kernel_vs_oracle(d, torch):
-    """mdsp_ols_w64_asm (MDSP_OLS_VARIANT=40; csrc/ols_w64_asm.s, generated by tools/gen_ols_asm.py): one wavefront per four blocks, 2048 = 32 x 64 with one
-    exchange each way, the inverse transform run as a forward transform of the swapped product.  It takes the interior units of a column (multiples of
-    four blocks, runs of at least 64 units) and leaves the edges to ols_fused_kernel -- so: columns that are all edge (too short), columns with both,
-    several columns with a leading dimension, conv mode, a block range from a slice, all against the default kernel (different factorisation: equal to
-    rounding) and against the Float64 oracle, norm-wise and element-wise."""
-    from conftest import ulps_of_max
-    from dsp_jl_amd import _lib
-    from dsp_jl_amd.dspbase import OlsPlan
-    from oracle import dspbase as odsp
-    rng = np.random.default_rng(4040)
-    lib = _lib.lib()
-    b = _taps(256, np.float32)
-    try:
-        for nx, ncols, mode in ((100_000, 1, _lib.OLS_FILT), (1793 * 4 * 64 + 1793 * 4, 1, _lib.OLS_FILT), (1_000_003, 1, _lib.OLS_FILT), (2_000_001, 3, _lib.OLS_FILT),
-                                (700_001, 2, _lib.OLS_CONV), ((1 << 24) + 12345, 1, _lib.OLS_FILT)):
-            x = torch.from_numpy(rng.standard_normal((ncols, nx)).astype(np.float32)).cuda()
-            nout = nx if mode == _lib.OLS_FILT else nx + 255
-            _lib.set_tunable("MDSP_OLS_VARIANT", "0")
-            ref = OlsPlan(b, 2048, nx, mode, d.ENGINE_FUSED).exec(x, nout)
-            _lib.set_tunable("MDSP_OLS_VARIANT", "40")
-            plan = OlsPlan(b, 2048, nx, mode, d.ENGINE_FUSED)
-            got = plan.exec(x, nout)
-            torch.cuda.synchronize()
-            assert torch.equal(plan.exec(x, nout), got)                       # deterministic
-            for c in range(ncols):
-                assert relerr(got[c].cpu().numpy(), ref[c].double().cpu().numpy()) < 1e-6, (nx, c)
-            if nx <= 1_000_003:
-                want = odsp.filt_ba(b.astype(np.float64), 1.0, x[0].cpu().numpy().astype(np.float64)) if mode == _lib.OLS_FILT else None
-                if want is not None:
-                    assert relerr(got[0].cpu().numpy(), want) < TOL32
-                    u = max(ulps_of_max(got[0, k:k + 600].cpu().numpy(), want[k:k + 600]) for k in range(0, nx - 600, 50_000))
-                    assert u < 2 * 1.0 * 11, u
-            if nx == 1_000_003:
-                # a block range from a slice: blocks [100, 500) hold 100 aligned units -> the same kernels take the same blocks as in the whole column
-                L, g0, g1 = 1793, 100, 500
-                lo, hi = g0 * L - 255, g1 * L
-                xs = x[0, lo:hi].contiguous()
-                ys = torch.empty(hi - g0 * L, dtype=torch.float32, device="cuda")
-                _lib.check(lib.mdsp_ols_exec_range(plan._h, xs.data_ptr(), lo, hi - lo, nx, ys.data_ptr(), g0, g1 - g0, nx, None))
-                torch.cuda.synchronize()
-                assert torch.equal(ys, got[0, g0 * L:hi])
     finally:
         _lib.set_tunable("MDSP_OLS_VARIANT", None)
 
