@@ -31,7 +31,13 @@ template <int N_, int T_, int LDSIN_, int... RS> struct CtSched {
         for (int i = 0; i < p; ++i) v += ntw(i);
         return v;
     }
-    static constexpr int NTW = twoff(P) > 0 ? twoff(P) : 1;
+    // Round 5, flag 2048 (Float64 from 4800 points): NO register-resident twiddles -- W_N^m = hi[m >> 7] lo[m & 127] from two small LDS tables (the
+    // first 128 roots and every 128th), one complex product more per twiddle.  The register form needs sum_p M(p) (R_p - 1) complex values: 60 at
+    // 8000 = 5 5 5 8 8 -- 240 VGPRs of doubles next to the butterflies, the window and the sums, i.e. 100 - 184 scratch operations per kernel and HBM
+    // traffic 1.8 (5000) to 6.9 (8000) times the algorithmic bytes (bench.py rows welch_f64_5000 / _8000, profiles/r05_f64_twiddles.json).
+    static constexpr bool TW2L = (LDSIN_ & 2048) != 0;
+    static constexpr int TWS = 128, NTWHI = (N + TWS - 1) / TWS;
+    static constexpr int NTW = (!TW2L && twoff(P) > 0) ? twoff(P) : 1;
     static constexpr int BINS = (N + T - 1) / T;
     // Round 4: one element of padding behind every output GROUP of a pass (group = Ns R consecutive elements = the next pass's Ns) wherever the group's
     // byte stride aliases the LDS banks (G % 4 == 0: 16-lane groups of a ds_write_b64 that straddle two groups hit the same banks -- 28 % of the LDS

@@ -182,8 +182,22 @@ __global__ __launch_bounds__(256) void gen_spectral_kernel(GenArgs a) {
 //     32 banks by itself, and every read is contiguous by lane.
 #include "ct_sched.h"   // struct CtSched<N, T, flags, radices...>, MDSP_GEN_CT_SIZES, MDSP_GEN_CT_WIDE_SIZES (host-testable)
 
+// two-level twiddle tables in LDS (CtSched::TW2L): lo[i] = W^i, i < 128; hi[i] = W^{128 i}
+template <typename R> struct CtTw {
+    const cx<R>*lo, *hi;
+};
+// twiddle q of the butterfly whose index inside its group is k, pass p: W_N^{q k N / (Ns R)} (< N: no reduction needed)
+template <typename S, int p, typename R>
+__device__ __forceinline__ cx<R> ct_tw(const cx<R> (&tw)[S::NTW], CtTw<R> t2, int m, int q, unsigned k) {
+    if constexpr (!S::TW2L) return tw[S::twoff(p) + m * (S::radix(p) - 1) + (q - 1)];
+    else {
+        const unsigned e = (unsigned)q * k * (unsigned)(S::N / (S::ns(p) * S::radix(p)));
+        return fft::cmul(fft::ld2(t2.hi + (e >> 7)), fft::ld2(t2.lo + (e & 127u)));
+    }
+}
+
 template <typename S, int p, typename R> __device__ __forceinline__ void ct_load_twiddles(cx<R> (&tw)[S::NTW], const cx<R>* roots, int t) {
-    if constexpr (p < S::P) {
+    if constexpr (p < S::P && !S::TW2L) {
         if constexpr (p > 0) {
             constexpr int Rdx = S::radix(p), Ns = S::ns(p), stride = S::N / (Ns * Rdx);
 #pragma unroll
@@ -199,7 +213,7 @@ template <typename S, int p, typename R> __device__ __forceinline__ void ct_load
 
 // passes p .. END-1, ping-ponging between the two buffers (a barrier behind each); returns the buffer the last of them wrote
 template <typename S, int p, int END = S::P, typename R>
-__device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, const cx<R> (&tw)[S::NTW], int t) {
+__device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, const cx<R> (&tw)[S::NTW], int t, CtTw<R> t2 = CtTw<R>{nullptr, nullptr}) {
     if constexpr (p >= END) return in;
     else {
         constexpr int Rdx = S::radix(p), Ns = S::ns(p), nbf = S::nbf(p), M = S::M(p);
@@ -211,25 +225,25 @@ __device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, c
                 const unsigned jb = S::gin(p) ? j + j / (unsigned)(S::gin(p) ? S::gin(p) : 1) : j;
 #pragma unroll
                 for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + jb + S::rstride(p) * q);
+                const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
                 if constexpr (p > 0) {
 #pragma unroll
-                    for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
+                    for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], ct_tw<S, p>(tw, t2, m, q, k));
                 }
                 fft::gen_bfly<Rdx>(v);
-                const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
                 cx<R>* o = out + hi * (unsigned)(Ns * Rdx + (S::padded(p) ? 1 : 0)) + k;
 #pragma unroll
                 for (int q = 0; q < Rdx; ++q) fft::st2(o + Ns * q, v[q]);
             }
         }
         __syncthreads();
-        return ct_passes<S, p + 1, END>(out, const_cast<cx<R>*>(in), tw, t);
+        return ct_passes<S, p + 1, END>(out, const_cast<cx<R>*>(in), tw, t, t2);
     }
 }
 
 // the middle passes on ONE buffer (CtSched::INPLACE): every butterfly of the pass is read into registers, a barrier, then twiddles, butterflies and
 // the scatter, a barrier
-template <typename S, int p, int END, typename R> __device__ __forceinline__ void ct_passes_inplace(cx<R>* buf, const cx<R> (&tw)[S::NTW], int t) {
+template <typename S, int p, int END, typename R> __device__ __forceinline__ void ct_passes_inplace(cx<R>* buf, const cx<R> (&tw)[S::NTW], int t, CtTw<R> t2 = CtTw<R>{nullptr, nullptr}) {
     if constexpr (p < END) {
         constexpr int Rdx = S::radix(p), Ns = S::ns(p), nbf = S::nbf(p), M = S::M(p);
         cx<R> v[M][Rdx];
@@ -247,17 +261,17 @@ template <typename S, int p, int END, typename R> __device__ __forceinline__ voi
         for (int m = 0; m < M; ++m) {
             const unsigned j = (unsigned)(t + S::T * m);
             if ((m + 1) * S::T <= nbf || j < (unsigned)nbf) {
-#pragma unroll
-                for (int q = 1; q < Rdx; ++q) v[m][q] = fft::cmul(v[m][q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
-                fft::gen_bfly<Rdx>(v[m]);
                 const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
+#pragma unroll
+                for (int q = 1; q < Rdx; ++q) v[m][q] = fft::cmul(v[m][q], ct_tw<S, p>(tw, t2, m, q, k));
+                fft::gen_bfly<Rdx>(v[m]);
                 cx<R>* o = buf + hi * (unsigned)(Ns * Rdx + (S::padded(p) ? 1 : 0)) + k;
 #pragma unroll
                 for (int q = 0; q < Rdx; ++q) fft::st2(o + Ns * q, v[m][q]);
             }
         }
         __syncthreads();
-        ct_passes_inplace<S, p + 1, END>(buf, tw, t);
+        ct_passes_inplace<S, p + 1, END>(buf, tw, t, t2);
     }
 }
 
@@ -317,7 +331,7 @@ __device__ __forceinline__ void ct_pass0_global(const TT* fa, int64_t hop, bool 
 // The last pass with its results left in registers: butterfly j produces the bins j + (N / R) q in natural order -- lanes j = t, t + 1, ... own
 // contiguous bins, so |Z|^2 sums and complex columns are consumed (and stored, coalesced) without another trip through LDS.
 template <typename S, typename R, typename F>
-__device__ __forceinline__ void ct_last_pass_regs(const cx<R>* in, const cx<R> (&tw)[S::NTW], int t, F&& consume) {
+__device__ __forceinline__ void ct_last_pass_regs(const cx<R>* in, const cx<R> (&tw)[S::NTW], int t, CtTw<R> t2, F&& consume) {
     constexpr int p = S::P - 1, Rdx = S::radix(p), nbf = S::nbf(p), M = S::M(p);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -327,8 +341,9 @@ __device__ __forceinline__ void ct_last_pass_regs(const cx<R>* in, const cx<R> (
             const unsigned jb = S::gin(p) ? (unsigned)j + (unsigned)j / (unsigned)(S::gin(p) ? S::gin(p) : 1) : (unsigned)j;
 #pragma unroll
             for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + jb + S::rstride(p) * q);
+            const unsigned k = (unsigned)j % (unsigned)S::ns(p);
 #pragma unroll
-            for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], tw[S::twoff(p) + m * (Rdx - 1) + (q - 1)]);
+            for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], ct_tw<S, p>(tw, t2, m, q, k));
             fft::gen_bfly<Rdx>(v);
 #pragma unroll
             for (int q = 0; q < Rdx; ++q) consume(m, q, j + nbf * q, v[q]);
@@ -355,6 +370,13 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
     const int64_t u0 = gslot * a.per_slot;
     cx<R> tw[S::NTW];
     ct_load_twiddles<S, 0>(tw, static_cast<const cx<R>*>(a.roots), t);
+    __shared__ __attribute__((aligned(16))) cx<R> twlo[S::TW2L ? S::TWS : 1], twhi[S::TW2L ? S::NTWHI : 1];
+    const CtTw<R> t2{twlo, twhi};
+    if constexpr (S::TW2L) {   // (read behind the first barrier of the frame loop)
+        const cx<R>* g = static_cast<const cx<R>*>(a.roots);
+        for (int i = t; i < S::TWS; i += T) fft::st2(twlo + i, g[i]);
+        for (int i = t; i < S::NTWHI; i += T) fft::st2(twhi + i, g[(unsigned)i * S::TWS]);
+    }
     R w0[W0];   // window at the points of this thread's first-pass butterflies (Float32 signals: rounded to Float32 first, as the other fused kernels do)
 #pragma unroll
     for (int m = 0; m < S::M(0); ++m)
@@ -423,15 +445,15 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
                 }
             }
             __syncthreads();
-            (void)ct_passes<S, 0, 1>(bufB, bufA, tw, t);   // pass 0: bufB -> bufA (ends with a barrier)
+            (void)ct_passes<S, 0, 1>(bufB, bufA, tw, t, t2);   // pass 0: bufB -> bufA (ends with a barrier)
         }
         if constexpr (!LDSIN) __syncthreads();
         const int64_t o0 = ch * a.chs + f0 * a.ldo;
         if constexpr (DIRECT) {
             const cx<R>* src = bufA;
-            if constexpr (INPL) ct_passes_inplace<S, 1, S::P - 1>(bufA, tw, t);
-            else src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t);
-            ct_last_pass_regs<S>(src, tw, t, [&](int m, int q, int k, cx<R> z) {
+            if constexpr (INPL) ct_passes_inplace<S, 1, S::P - 1>(bufA, tw, t, t2);
+            else src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t, t2);
+            ct_last_pass_regs<S>(src, tw, t, t2, [&](int m, int q, int k, cx<R> z) {
                 if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
                     if (live) acc[m * RL + q] += (double)(z.x * z.x + z.y * z.y);
                 } else if (live && k < a.nout) {   // complex signal: two-sided columns (periodograms.jl:876)
@@ -443,7 +465,7 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
                 }
             });
         } else {
-            const cx<R>* src = ct_passes<S, 1>(bufA, bufB, tw, t);   // ends with a barrier; natural-order spectrum in LDS
+            const cx<R>* src = ct_passes<S, 1>(bufA, bufB, tw, t, t2);   // ends with a barrier; natural-order spectrum in LDS
             if (live) {
                 for (int j = t; j < a.nout; j += T) {
                     const bool mirror = j > N / 2;                              // real -> two-sided: X[N-k] = conj(X[k]) (fft2oneortwosided!, :234-244)
@@ -520,6 +542,15 @@ inline bool gen_ct_size(int dtype, int64_t nfft, bool direct) {
         default: return false;
     }
 }
+// Float64 schedules that take their twiddles from the two LDS tables (CtSched flag 2048) instead of registers: where it measured faster
+// (profiles/r05_f64_twiddles.json, 2^27 samples): Welch at 4800 (0.73 -> 1.21 TB/s), 5120, 6144 and 8000 (0.62 -> 0.83); ComplexF64 columns at 4800, 6000
+// (1.69 -> 1.85), 6400 (1.85 -> 2.46) and 8000 (1.68 -> 2.07).  Not at 5000 (columns 3.05 -> 2.38) and not for Welch at 6000 / 6400 (-5 ... -7 %: those
+// keep 48 - 82 spilled registers either way -- the single-buffer pass holds all of a pass's butterflies in registers).
+constexpr int gen_ct_f64_tw2l(int N, int mode) {
+    if (N < 4800 || N == 5000) return 0;
+    if (mode == 0 && (N == 6000 || N == 6400)) return 0;
+    return 2048;
+}
 template <typename R, bool CPLX, int MODE>
 bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial, int* rc) {
     if constexpr (MDSP_GEN_CT && sizeof(R) == 4) {
@@ -549,10 +580,10 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
             *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) & ~1536, __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (MODE == 0 || CPLX) {                                                                  \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | 16, __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | 16 | gen_ct_f64_tw2l(N, MODE), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (N <= GEN_CT_F64_REAL_COLUMNS_MAX) {                                                   \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) & ~1536, __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | gen_ct_f64_tw2l(N, MODE), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         }                                                                                                          \
         break;
