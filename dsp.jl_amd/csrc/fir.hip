@@ -757,26 +757,39 @@ MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void dec
     const int64_t zf = a.zb + m0 * M;                           // first staged sample
     const int H = a.nbh * P * M;                                // samples between the two halves of a real tile
     if (a.ablate & 2) {
-    } else if (zf >= a.hl) {
-        // steady state: the tile lies inside x.  A descriptor based at the tile's first sample (reads past the end of the signal return 0), eight
-        // independent loads (pairs of them for a real signal's two halves) in flight per thread before the LDS writes
-        const XS* src = xc + (zf - a.hl);
-        const __amdgpu_buffer_rsrc_t rs = io::make_rsrc(src, (a.xlen - (zf - a.hl)) * (long long)sizeof(XS));
-        constexpr int U = 8, SZ = (int)sizeof(XS);
-        for (int k0 = threadIdx.x; k0 < a.nz; k0 += U * 256) {
-            XS v0[U], v1[CPLX ? 1 : U];
+    } else if (zf >= a.hl && zf - a.hl + a.nz + (CPLX ? 0 : H) <= a.xlen) {
+        // steady state: the tile (both halves of a real one) lies wholly inside x.  16-byte loads -- four Float32 samples, two Float64 / ComplexF32, one
+        // ComplexF64 -- four of them (pairs of them for a real signal's two halves) in flight per thread; consecutive samples sit at consecutive LDS
+        // positions (a block's padding never falls inside a group: block lengths are multiples of 16 samples, groups start at multiples of 4)
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        constexpr int NV = 16 / (int)sizeof(XS), U = 4;
+        const __amdgpu_buffer_rsrc_t rs = io::make_rsrc(xc + (zf - a.hl), (a.xlen - (zf - a.hl)) * (long long)sizeof(XS));
+        auto elem = [](const u4v& q, int i) -> XS {
+            if constexpr (std::is_same_v<XS, float>) return __uint_as_float(q[i]);
+            else if constexpr (std::is_same_v<XS, double>) return __hiloint2double((int)q[2 * i + 1], (int)q[2 * i]);
+            else if constexpr (std::is_same_v<XS, cx<float>>) return XS{__uint_as_float(q[2 * i]), __uint_as_float(q[2 * i + 1])};
+            else return XS{__hiloint2double((int)q[1], (int)q[0]), __hiloint2double((int)q[3], (int)q[2])};
+        };
+        for (int k0 = threadIdx.x * NV; k0 < a.nz; k0 += U * 256 * NV) {
+            u4v va[U], vb[CPLX ? 1 : U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = k0 + u * 256;
-                v0[u] = io::Ld<XS>::load(rs, k < a.nz ? k * SZ : io::OOB);
-                if constexpr (!CPLX) v1[u] = io::Ld<XS>::load(rs, k < a.nz ? (k + H) * SZ : io::OOB);
+                const int k = k0 + u * 256 * NV;
+                va[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k < a.nz ? k * (int)sizeof(XS) : io::OOB, 0, 0);
+                if constexpr (!CPLX) vb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k < a.nz ? (k + H) * (int)sizeof(XS) : io::OOB, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = k0 + u * 256;
+                const int k = k0 + u * 256 * NV;
                 if (k < a.nz) {
-                    if constexpr (CPLX) zs[dec_pos(k, M, a.blkmagic)] = {v0[u].x, v0[u].y};
-                    else zs[dec_pos(k, M, a.blkmagic)] = {v0[u], v1[u]};
+                    V* dst = zs + dec_pos(k, M, a.blkmagic);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        if constexpr (CPLX) {
+                            const XS v = elem(va[u], i);
+                            dst[i] = {v.x, v.y};
+                        } else dst[i] = {elem(va[u], i), elem(vb[u], i)};
+                    }
                 }
             }
         }
@@ -1834,9 +1847,9 @@ DecGeo fir_dec_geo(const mdsp_fir_s* f) {
     DecGeo g;
     if (f->L != 1 || f->M < 2 || f->M > 64 || tunables().fir_dec == 0 || tunables().fir_exact || f->exact || MDSP_DBG(fir_generic)) return g;
     if (f->acc_double != dtype_is_double(f->x_dtype)) return g;   // Float32 samples under Float64 taps: the generic kernel converts as it stages
-    // Where it wins (profiles/r05_fir_dec_ab.json, 4 channels x 2^26 samples, resample_filter taps): Float64 / ComplexF64 from M = 4 on (1.03 - 4.4x),
-    // Float32 / ComplexF32 at M = 4 (1.03 - 1.06x) and from M = 8 on (1.0 - 3.7x); at M = 2, 3 and the Float32 M = 5, 6 the matrix-core kernel's
-    // short products stay ahead (0.37 - 0.53 of the roof against 0.23 - 0.42).  MDSP_FIR_DEC=3 takes it for every M <= 64 (tests).
+    // Where it wins (profiles/r05_fir_dec_ab.json, 4 channels x 2^26 samples, resample_filter taps): Float64 / ComplexF64 from M = 4 on (1.1 - 4.1x),
+    // Float32 / ComplexF32 at M = 4 (1.17 - 1.19x) and from M = 8 on (1.1 - 3.9x); at M = 2, 3 and the Float32 M = 5, 6, 7 the matrix-core kernel's
+    // short products stay ahead (0.31 - 0.54 of the roof against 0.24 - 0.38).  MDSP_FIR_DEC=3 takes it for every M <= 64 (tests).
     if (tunables().fir_dec == 1 && !(f->acc_double ? f->M >= 4 : (f->M == 4 || f->M >= 8))) return g;
     const bool dbl = f->acc_double, cplx = dtype_is_complex(f->x_dtype);
     const int M = (int)f->M;
