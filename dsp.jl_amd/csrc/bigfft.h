@@ -31,5 +31,12 @@ int welch(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, in
 int stft(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, int64_t K, int64_t hop, const double* win_dev, void* out, int64_t ldo,
          int64_t nout, int onesided, int psd, int accumulate, double r, hipStream_t st);
 
+// Overlap-save with blocks no single workgroup holds (ols.hip routes filters beyond the partitioned kernels here).  ols_size: the transform
+// length for a filter of nb taps and (a hint, 0: unknown) nout outputs per column (0: not this engine).  ols: blocks [g0, g1) of ONE column's block grid (block length N - nb + 1; g0 even for real
+// signals) -- x / y are the column's (possibly virtual) bases as in mdsp_ols_exec_range, H the filter's full natural-order spectrum, 1 / N folded in.
+int64_t ols_size(int dtype, int64_t nb, int64_t nout_hint);
+int ols(EngineHolder& h, int dtype, int64_t N, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout, int64_t g0, int64_t g1,
+        hipStream_t st);
+
 }  // namespace big
 }  // namespace mdsp

@@ -53,7 +53,12 @@ template <typename R> struct BigArgs {
     int n, psd, accumulate, acc_add;
     int64_t nout;
     R m1;
-    int out_mode;       // the two-stage kernel: OUT of big_pass_kernel as a run-time value (0, 2, 3)
+    // overlap-save on the same passes (in_mode 3 / 4, OUT 4): two real blocks per transform, x -> FFT -> . H -> FFT of the conjugate -> y
+    const void* H;      // the filter's spectrum, natural order, 1 / N folded in
+    const void* src2;   // in_mode 4: natural-order spectra [ntrans][N] (what OUT 3 left)
+    int64_t nx, nb1, L; // signal length, nb - 1, outputs per block (N - nb + 1); K = number of blocks, nout = outputs of the column
+    int ols_cplx;       // complex signal and taps: one block per transform
+    int out_mode;       // the two-stage kernel: OUT of big_pass_kernel as a run-time value (0, 2, 3, 4)
     int ablate;         // MDSP_BIG_ABLATE (profiling; results are garbage): 1 no sub-transforms, 2 no stores, 4 no loads after the first item, 8 no tile twiddles
 };
 
@@ -106,7 +111,7 @@ template <typename R, int OUT, int E> __global__ __launch_bounds__(TPB, (E < ele
                 }
                 return z;
             });
-        } else {
+        } else if (a.in_mode == 2) {
             const cx<R>* fa = static_cast<const cx<R>*>(a.s) + u * a.hop;
             load_regs<R, E>(p, tc, tid, pre, [&](int64_t pos) {
                 cx<R> z = {(R)0, (R)0};
@@ -116,6 +121,33 @@ template <typename R, int OUT, int E> __global__ __launch_bounds__(TPB, (E < ele
                     z = {v.x * w, v.y * w};
                 }
                 return z;
+            });
+        } else if (a.in_mode == 3) {   // overlap-save: blocks 2u and 2u + 1 of the column, nb - 1 samples of history in front (zeros before the signal and behind it)
+            if (a.ols_cplx) {
+                const cx<R>* xs = static_cast<const cx<R>*>(a.s);
+                const int64_t ia = u * a.L - a.nb1;
+                load_regs<R, E>(p, tc, tid, pre, [&](int64_t pos) {
+                    const int64_t i = ia + pos;
+                    return (i >= 0 && i < a.nx) ? xs[i] : cx<R>{(R)0, (R)0};
+                });
+            } else {
+                const R* xs = static_cast<const R*>(a.s);
+                const int64_t ia = 2 * u * a.L - a.nb1, ib = ia + a.L;
+                const bool haveB = 2 * u + 1 < a.K;
+                load_regs<R, E>(p, tc, tid, pre, [&](int64_t pos) {
+                    cx<R> z = {(R)0, (R)0};
+                    const int64_t i = ia + pos, j = ib + pos;
+                    if (i >= 0 && i < a.nx) z.x = xs[i];
+                    if (haveB && j >= 0 && j < a.nx) z.y = xs[j];
+                    return z;
+                });
+            }
+        } else {                        // overlap-save, the way back: conj(Z H) -- the inverse transform is the forward one of the conjugate, conjugated
+            const cx<R>* zs = static_cast<const cx<R>*>(a.src2) + t * N;
+            const cx<R>* Hs = static_cast<const cx<R>*>(a.H);
+            load_regs<R, E>(p, tc, tid, pre, [&](int64_t pos) {
+                const cx<R> v = fft::cmul(zs[pos], Hs[pos]);
+                return cx<R>{v.x, -v.y};
             });
         }
     };
@@ -165,9 +197,27 @@ template <typename R, int OUT, int E> __global__ __launch_bounds__(TPB, (E < ele
                     } else static_cast<cx<R>*>(a.out)[o0 + k] = z;
                 }
             });
-        } else {
+        } else if constexpr (OUT == 3) {
             cx<R>* o = static_cast<cx<R>*>(a.out) + t * N;
             phase_store<R, E>(p, tc, tid, src, twc, twb, [&](int, int64_t k, cx<R> z) { o[k] = z; });
+        } else {   // OUT 4, overlap-save: the L valid samples of both blocks (y = conj of what the transform of the conjugate left)
+            if (a.ols_cplx) {
+                cx<R>* yo = static_cast<cx<R>*>(a.out);
+                phase_store<R, E>(p, tc, tid, src, twc, twb, [&](int, int64_t k, cx<R> z) {
+                    const int64_t o = u * a.L + (k - a.nb1);
+                    if (k >= a.nb1 && o < a.nout) yo[o] = cx<R>{z.x, -z.y};
+                });
+            } else {
+                R* yo = static_cast<R*>(a.out);
+                const bool haveB = 2 * u + 1 < a.K;
+                phase_store<R, E>(p, tc, tid, src, twc, twb, [&](int, int64_t k, cx<R> z) {
+                    if (k >= a.nb1) {
+                        const int64_t o = 2 * u * a.L + (k - a.nb1);
+                        if (o < a.nout) yo[o] = z.x;
+                        if (haveB && o + a.L < a.nout) yo[o + a.L] = -z.y;
+                    }
+                });
+            }
         }
         __syncthreads();   // the buffer the stores read is the one the next item's samples or first sub-pass write
         tile = ntile;
@@ -234,7 +284,7 @@ __global__ __launch_bounds__(TPB, (sizeof(R) == 4 ? 2 : 1)) void big_fast_kernel
                 }
                 return z;
             });
-        } else {
+        } else if (a.in_mode == 2) {
             const cx<R>* fa = static_cast<const cx<R>*>(a.s) + u * a.hop;
             fast_load<R, RA, TJ>(p, tc, tid, pre, [&](int64_t pos) {
                 cx<R> z = {(R)0, (R)0};
@@ -244,6 +294,33 @@ __global__ __launch_bounds__(TPB, (sizeof(R) == 4 ? 2 : 1)) void big_fast_kernel
                     z = {v.x * w, v.y * w};
                 }
                 return z;
+            });
+        } else if (a.in_mode == 3) {   // overlap-save: blocks 2u and 2u + 1 of the column, nb - 1 samples of history in front (zeros before the signal and behind it)
+            if (a.ols_cplx) {
+                const cx<R>* xs = static_cast<const cx<R>*>(a.s);
+                const int64_t ia = u * a.L - a.nb1;
+                fast_load<R, RA, TJ>(p, tc, tid, pre, [&](int64_t pos) {
+                    const int64_t i = ia + pos;
+                    return (i >= 0 && i < a.nx) ? xs[i] : cx<R>{(R)0, (R)0};
+                });
+            } else {
+                const R* xs = static_cast<const R*>(a.s);
+                const int64_t ia = 2 * u * a.L - a.nb1, ib = ia + a.L;
+                const bool haveB = 2 * u + 1 < a.K;
+                fast_load<R, RA, TJ>(p, tc, tid, pre, [&](int64_t pos) {
+                    cx<R> z = {(R)0, (R)0};
+                    const int64_t i = ia + pos, j = ib + pos;
+                    if (i >= 0 && i < a.nx) z.x = xs[i];
+                    if (haveB && j >= 0 && j < a.nx) z.y = xs[j];
+                    return z;
+                });
+            }
+        } else {                        // overlap-save, the way back: conj(Z H) -- the inverse transform is the forward one of the conjugate, conjugated
+            const cx<R>* zs = static_cast<const cx<R>*>(a.src2) + t * N;
+            const cx<R>* Hs = static_cast<const cx<R>*>(a.H);
+            fast_load<R, RA, TJ>(p, tc, tid, pre, [&](int64_t pos) {
+                const cx<R> v = fft::cmul(zs[pos], Hs[pos]);
+                return cx<R>{v.x, -v.y};
             });
         }
     };
@@ -289,9 +366,27 @@ __global__ __launch_bounds__(TPB, (sizeof(R) == 4 ? 2 : 1)) void big_fast_kernel
                     } else static_cast<cx<R>*>(a.out)[o0 + k] = z;
                 }
             });
-        } else {
+        } else if (a.out_mode == 3) {
             cx<R>* o = static_cast<cx<R>*>(a.out) + t * N;
             fast_store<R, RA, TJ>(p, tc, tid, y, twc, twb, [&](int, int64_t k, cx<R> z) { o[k] = z; });
+        } else {   // 4, overlap-save: the L valid samples of both blocks
+            if (a.ols_cplx) {
+                cx<R>* yo = static_cast<cx<R>*>(a.out);
+                fast_store<R, RA, TJ>(p, tc, tid, y, twc, twb, [&](int, int64_t k, cx<R> z) {
+                    const int64_t o = u * a.L + (k - a.nb1);
+                    if (k >= a.nb1 && o < a.nout) yo[o] = cx<R>{z.x, -z.y};
+                });
+            } else {
+                R* yo = static_cast<R*>(a.out);
+                const bool haveB = 2 * u + 1 < a.K;
+                fast_store<R, RA, TJ>(p, tc, tid, y, twc, twb, [&](int, int64_t k, cx<R> z) {
+                    if (k >= a.nb1) {
+                        const int64_t o = 2 * u * a.L + (k - a.nb1);
+                        if (o < a.nout) yo[o] = z.x;
+                        if (haveB && o + a.L < a.nout) yo[o + a.L] = -z.y;
+                    }
+                });
+            }
         }
         tile = ntile;
         t = nt;
@@ -524,7 +619,79 @@ int run(Engine* e, int mode, const void* s, int64_t K, int64_t hop, const double
     return MDSP_OK;
 }
 
+// Overlap-save of one column on the engine's passes: blocks [g0, g1) of the column's grid (g0 even for real signals).  Forward passes read the
+// blocks straight from the signal (in_mode 3), the last one leaves natural-order spectra (OUT 3); the way back starts from conj(Z H) (in_mode 4)
+// and its last pass stores the L valid samples of each block (OUT 4).
+template <typename R> int run_ols(Engine* e, bool cplx, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout, int64_t g0, int64_t g1, hipStream_t st) {
+    const int64_t N = e->nfft, L = N - (nb - 1);
+    const int64_t u0 = cplx ? g0 : g0 / 2, u1 = cplx ? g1 : cdiv(g1, 2);
+    if (u1 <= u0) return MDSP_OK;
+    const int64_t per = (int64_t)sizeof(cx<R>) * N;
+    const int64_t C = std::max<int64_t>(1, std::min<int64_t>(u1 - u0, ((int64_t)tunables().big_chunk_mib << 20) / (2 * per)));
+    MDSP_TRY(e->work.reserve((size_t)(per * C)));
+    MDSP_TRY(e->nat.reserve((size_t)(per * C)));
+    const int cus = device_cu_count();
+    for (int64_t c0 = u0; c0 < u1; c0 += C) {
+        const int64_t cnt = std::min<int64_t>(C, u1 - c0);
+        for (int dir = 0; dir < 2; ++dir) {
+            for (int p = 0; p < e->P; ++p) {
+                BigArgs<R> a{};
+                a.p = e->pass[p];
+                a.in_mode = p == 0 ? (dir == 0 ? 3 : 4) : 0;
+                a.s = x;
+                a.buf = e->work.as<cx<R>>();
+                a.src2 = e->nat.p;
+                a.H = H;
+                a.t0 = c0;
+                a.ntrans = cnt;
+                a.K = g1;          // blocks past the range do not exist for this call (second block of the last pair)
+                a.nx = nx;
+                a.nb1 = nb - 1;
+                a.L = L;
+                a.nout = nout;
+                a.ols_cplx = cplx ? 1 : 0;
+                a.ablate = tunables().big_ablate;
+                const int64_t wgs = (int64_t)cus * (tunables().big_wgs > 0 ? tunables().big_wgs : ((a.p.Rp > RMAX / 2 || (a.p.fTJ && sizeof(R) == 8)) ? 1 : (a.p.fTJ && a.p.Rp <= 64 ? 4 : 2)));
+                int groups = tunables().big_groups > 0 ? tunables().big_groups : (int)cdiv(wgs, a.p.ntiles);
+                groups = (int)std::max<int64_t>(1, std::min<int64_t>(groups, cnt));
+                const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(a.p.ntiles, wgs / groups));
+                if (p < e->P - 1) {
+                    MDSP_TRY((launch_pass<R, 0>(a, lanes, groups, st)));
+                } else if (dir == 0) {
+                    a.out = e->nat.p;
+                    MDSP_TRY((launch_pass<R, 3>(a, lanes, groups, st)));
+                } else {
+                    a.out = y;
+                    MDSP_TRY((launch_pass<R, 4>(a, lanes, groups, st)));
+                }
+            }
+        }
+    }
+    return MDSP_OK;
+}
+
 }  // namespace
+
+int64_t ols_size(int dtype, int64_t nb, int64_t nout_hint) {
+    if (!tunables().bigfft || nb < 2) return 0;
+    (void)dtype;
+    // 2^20 points (three two-stage passes of 64 / 128 / 128: the fastest of 2^17 .. 2^21 for 32768 .. 131072 taps of either precision,
+    // profiles/r05_big_ols.json), more while the filter covers over an eighth of the block; less when one block already holds the whole signal
+    int64_t N = (int64_t)1 << 20;
+    while (N < 8 * nb) N <<= 1;
+    while (nout_hint > 0 && N / 2 >= 2 * nb && N / 2 - (nb - 1) >= nout_hint) N >>= 1;
+    if (tunables().big_ols_log2n > 0) N = (int64_t)1 << tunables().big_ols_log2n;
+    if (N > ((int64_t)1 << 26) || N < 2 * nb || N <= 4096) return 0;
+    int R[MAXP];
+    return factorise(N, R, tunables().big_rmax) >= 2 ? N : 0;
+}
+
+int ols(EngineHolder& h, int dtype, int64_t N, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout, int64_t g0, int64_t g1, hipStream_t st) {
+    Engine* e = nullptr;
+    MDSP_TRY(get_engine(h, dtype, 0, N, &e));
+    const bool cplx = dtype_is_complex(dtype);
+    return dtype_is_double(dtype) ? run_ols<double>(e, cplx, x, nx, H, nb, y, nout, g0, g1, st) : run_ols<float>(e, cplx, x, nx, H, nb, y, nout, g0, g1, st);
+}
 
 bool size_ok(int dtype, int64_t nfft) {
     if (!tunables().bigfft) return false;

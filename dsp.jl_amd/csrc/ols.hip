@@ -1136,10 +1136,15 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     int64_t exec_nfft = nfft;
     int parts = 1;
     const bool fused_ok = fused_geometry(dtype, nb, nfft, &exec_nfft, &parts);
-    if (eng == MDSP_ENGINE_AUTO) eng = fused_ok ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
-    if (eng == MDSP_ENGINE_FUSED && !fused_ok)
-        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft >= 256 and filters of at most %d taps; got nfft=%lld, %lld taps",
-                  dtype_is_double(dtype) ? 8192 : 16384, (long long)nfft, (long long)nb);
+    // filters beyond four partitions of the largest in-LDS transform: the same convolution in blocks of 8 .. 16 nb points on the multi-pass engine
+    const int64_t lds_max = dtype_is_double(dtype) ? 4096 : 8192;
+    const int64_t big_n = (!fused_ok && eng != MDSP_ENGINE_ROCFFT && nb > 2 * lds_max) ? mdsp::big::ols_size(dtype, nb, nx_hint > 1 ? nx_hint + (mode == MDSP_OLS_CONV ? nb - 1 : 0) : 0) : 0;
+    if (eng == MDSP_ENGINE_AUTO) eng = (fused_ok || big_n) ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
+    if (eng == MDSP_ENGINE_FUSED && !fused_ok && big_n) {
+        exec_nfft = big_n;
+        parts = 1;
+    } else if (eng == MDSP_ENGINE_FUSED && !fused_ok)
+        MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "fused engine supports power-of-two nfft >= 256; got nfft=%lld, %lld taps", (long long)nfft, (long long)nb);
     if (eng != MDSP_ENGINE_FUSED && eng != MDSP_ENGINE_ROCFFT) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid engine %d", engine);
     if (eng != MDSP_ENGINE_FUSED) {
         exec_nfft = nfft;
@@ -1157,6 +1162,7 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     pl->nfft = exec_nfft;
     pl->L = parts > 1 ? exec_nfft / 2 : exec_nfft - (nb - 1);
     pl->variant = tunables().ols_variant;
+    pl->big = eng == MDSP_ENGINE_FUSED && !fused_ok;
     nfft = exec_nfft;   // from here on: the transform size that executes
 
     // Filter spectrum in double on the host.  FILT: taps scaled by 1/nfft before the transform (filt.jl:499);
@@ -1221,7 +1227,7 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     int st = MDSP_OK;
     const bool half = (eng == MDSP_ENGINE_ROCFFT) && !cplx;
     st = dbl ? upload_spectrum<double>(pl, Hf, half) : upload_spectrum<float>(pl, Hf, half);
-    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED) st = dbl ? upload_table<double>(pl->table, nfft) : upload_table<float>(pl->table, nfft);
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !pl->big) st = dbl ? upload_table<double>(pl->table, nfft) : upload_table<float>(pl->table, nfft);
     if (st != MDSP_OK) {
         delete pl;
         return st;
@@ -1270,6 +1276,13 @@ static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int6
     }
     if (g_end < 0 || g_end > nblocks) g_end = nblocks;
     if (g_begin >= g_end) return MDSP_OK;
+    if (plan->big) {   // one column at a time: a column's blocks fill the chip by themselves
+        const size_t esz = dtype_size(plan->dtype);
+        for (int64_t c = 0; c < ncols; ++c)
+            MDSP_TRY(mdsp::big::ols(plan->bigeng, plan->dtype, plan->nfft, static_cast<const char*>(x_dev) + (size_t)(c * ldx) * esz, nx, plan->H.p, plan->nb,
+                                    static_cast<char*>(y_dev) + (size_t)(c * ldy) * esz, nout, g_begin, g_end, s));
+        return MDSP_OK;
+    }
     if (plan->engine == MDSP_ENGINE_ROCFFT) {
         const int64_t ub = g_begin, ue = (g_begin == 0 && g_end == nblocks) ? -1 : g_end;
         if (cplx) return dbl ? exec_rocfft<double, true>(plan, x_dev, nx, ncols, ldx, y_dev, nout, ldy, s, ub, ue)

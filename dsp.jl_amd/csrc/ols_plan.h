@@ -3,6 +3,7 @@
 
 #include "common.h"
 #include "rocfft_wrap.h"
+#include "bigfft.h"
 
 struct mdsp_ols_plan_s {
     int dtype = MDSP_F32, mode = MDSP_OLS_FILT, engine = MDSP_ENGINE_ROCFFT;
@@ -16,4 +17,7 @@ struct mdsp_ols_plan_s {
     mdsp::DevBuf td, fd;
     int64_t batch = 0;
     int variant = 0;  // fused kernel variant (tuning knob, MDSP_OLS_VARIANT)
+    // filters beyond the partitioned kernels: blocks of nfft = 8 .. 16 nb points on the multi-pass engine (bigfft.hip), H = nfft entries, natural order
+    bool big = false;
+    mdsp::big::EngineHolder bigeng;
 };

@@ -223,20 +223,8 @@ def conv(u, v, algorithm: str = "auto", out_len: int | None = None, engine: int 
         else:
             nfft = optimalfftfiltlength(len(small_h), max(nu, nv))
         cols, _ = _dev.to_columns(big, W)
-        seg = {4: 16384, 8: 8192}.get(np.dtype(W).itemsize, 0) if W.kind == "f" else 0     # filters.FUSED_MAX_TAPS
-        if alg == "fft_overlapsave" and engine == _lib.ENGINE_AUTO and seg and len(small_h) > seg and max(nu, nv) > seg:
-            # beyond the fused engine's partitioned range: conv is linear in the kernel, so the full result is the sum of conv(big, segment k) placed at
-            # k seg (filters._fftfilt_segments; mdsp_shift_add) -- every segment on the fused engine instead of one rocFFT-engine plan
-            res = _dev.torch.zeros((1, full), dtype=cols.dtype, device=cols.device)
-            for k in range(-(-len(small_h) // seg)):
-                hk = np.ascontiguousarray(small_h[k * seg:(k + 1) * seg])
-                nk = max(nu, nv) + len(hk) - 1
-                plan = OlsPlan(hk, max(256, 1 << (2 * len(hk) - 1).bit_length()), max(nu, nv), _lib.OLS_CONV, _lib.ENGINE_FUSED, cached=True)   # a power of two >= 2 nb
-                t = plan.exec(cols, nk)
-                _lib.check(_lib.lib().mdsp_shift_add(_dev.ptr(res), _dev.ptr(t), k * seg + nk, k * seg, 1, full, nk, _dev.md_dtype(W), _dev.stream_ptr()))
-        else:
-            plan = OlsPlan(small_h, nfft, max(nu, nv), _lib.OLS_CONV, engine, cached=True)     # the library's own plan LRU (mdsp_ols_plan_cached)
-            res = plan.exec(cols, full)
+        plan = OlsPlan(small_h, nfft, max(nu, nv), _lib.OLS_CONV, engine, cached=True)     # the library's own plan LRU (mdsp_ols_plan_cached); any kernel length
+        res = plan.exec(cols, full)
     res = _cast_result(res, T)[0]
     if n_out > full:
         pad = _dev.torch.zeros(n_out, dtype=res.dtype, device=res.device)

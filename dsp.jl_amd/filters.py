@@ -54,44 +54,14 @@ def _fftfilt(b: np.ndarray, x, nfft: int, engine: int = _lib.ENGINE_AUTO):
     if nfft < len(b):
         raise ArgumentError("nfft must be at least length(b)")
     taps = b.astype(Wc)
-    seg = FUSED_MAX_TAPS[np.dtype(Wc).itemsize]
-    if engine == _lib.ENGINE_AUTO and len(taps) > seg and nx > seg:
-        out = _fftfilt_segments(taps, cols, nx, seg)
-    else:
-        plan = OlsPlan(taps, nfft, nx, _lib.OLS_FILT, engine, cached=True)     # the library's own plan LRU (mdsp_ols_plan_cached)
-        out = plan.exec(cols, nx)
+    plan = OlsPlan(taps, nfft, nx, _lib.OLS_FILT, engine, cached=True)     # the library's own plan LRU (mdsp_ols_plan_cached); any filter length
+    out = plan.exec(cols, nx)
     return _dev.from_columns(_cast_result(out, W) if W.kind in "iu" else out, shape, x)
 
 
-# the longest filter the fused engine's partitioned kernels take (four partitions of half an in-LDS transform: DESIGN.md 4.11), by element size
+# the longest filter the fused engine's partitioned kernels take (four partitions of half an in-LDS transform: DESIGN.md 4.4), by element size;
+# longer ones run in blocks of 2^20 points on the multi-pass engine inside the same plan (mdsp_ols_plan_geometry)
 FUSED_MAX_TAPS = {4: 16384, 8: 8192}
-
-
-def _fused_nfft(nb: int) -> int:
-    """A transform length the fused engine accepts for nb taps whatever the signal length (a power of two >= 2 nb; it re-blocks long filters by
-    itself, and optimalfftfiltlength may return a 7-smooth length for signals not much longer than the filter)."""
-    return max(256, 1 << (2 * nb - 1).bit_length())
-
-
-def _fftfilt_segments(taps: np.ndarray, cols, nx: int, seg: int):
-    """Filters beyond the partitioned range of the fused engine: fftfilt is linear in b, so  filt(b, x) = sum_k delay(filt(b[k seg : (k + 1) seg], x), k seg);
-    every segment runs the partitioned fused kernel (1.3 TB/s at 16384 Float32 taps) instead of the rocFFT engine at the reference's block length
-    (0.09-0.16 TB/s at 32768-65536 taps), and `mdsp_shift_add` accumulates the delayed outputs.  Same result as the single plan up to summation order."""
-    lib = _lib.lib()
-    out = None
-    for k in range(-(-len(taps) // seg)):
-        hk = np.ascontiguousarray(taps[k * seg:(k + 1) * seg])
-        if k * seg >= nx:
-            break                                   # this segment only reaches outputs beyond the signal
-        plan = OlsPlan(hk, _fused_nfft(len(hk)), nx, _lib.OLS_FILT, _lib.ENGINE_FUSED, cached=True)
-        t = plan.exec(cols, nx)
-        if out is None:
-            out = t
-        else:
-            ncols = int(t.shape[0])
-            _lib.check(lib.mdsp_shift_add(out.data_ptr(), t.data_ptr(), nx, k * seg, ncols, nx, nx, _lib.F32 if taps.dtype == np.float32 else _lib.F64,
-                                          _dev.stream_ptr()))
-    return out
 
 
 def fftfilt(b, x, nfft: int | None = None, engine: int = _lib.ENGINE_AUTO):

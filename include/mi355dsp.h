@@ -114,16 +114,19 @@ int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len /* 
 /* What actually executes.  mdsp_ols_plan_info reports the REFERENCE's geometry (the nfft optimalfftfiltlength / the caller chose, dspbase.jl:268-291);
  * the fused engine runs it as it is up to nfft = 8192 (4096 in Float64).  Longer filters -- ~1100 taps and more, where the reference asks for
  * nfft = 16384 ... 2^20 -- are re-blocked: one block of the largest in-LDS transform while the filter covers at most half of it, else a
- * uniformly partitioned filter (2..4 partitions of exec_nfft/2 taps, spectra of the last blocks kept in registers).  Same outputs within rounding. */
+ * uniformly partitioned filter (2..4 partitions of exec_nfft/2 taps, spectra of the last blocks kept in registers).  Beyond four partitions
+ * (more than 16384 Float32 / 8192 Float64 taps, any of the four dtypes) the blocks no longer fit a workgroup: exec_nfft = 2^20 points (more beyond
+ * 131072 taps), each block transformed by the multi-pass engine that also runs the large spectral transforms (three passes over HBM each way,
+ * the filter's spectrum multiplied in between: DESIGN.md 4.5); partitions = 1.  Same outputs within rounding, one plan for every filter length
+ * with 2 nb <= 2^26. */
 int mdsp_ols_plan_geometry(mdsp_ols_plan plan, int64_t* exec_nfft, int64_t* exec_block_len, int* partitions);
 /* x_dev: (nx, ncols) ld ldx;  y_dev: (nout, ncols) ld ldy.  nout = nx (filt), nx+nb-1 (conv), or any
  * 0 <= nout <= nx+nb-1.  x and y must not alias (Filters/filt.jl:438-439). */
 int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,
                   int64_t nout, int64_t ldy, void* stream);
-/* y[shift + i, c] += t[i, c] for 0 <= i < n - shift, every column (real Float32 / Float64).  The one piece of arithmetic a host needs to run filters
- * LONGER than the fused engine's partitioned range (16384 Float32 / 8192 Float64 taps) on it instead of the rocFFT engine: split the taps into segments
- * of that length, filter with each (filt: causal, same length as x), and add segment k's output delayed by k * segment_length -- the reference's own
- * result, fftfilt being linear in b (Filters/filt.jl:479-521).  dsp.jl_amd/filters.py and julia/MI355DSP.jl do exactly that for `filt` / `fftfilt`. */
+/* y[shift + i, c] += t[i, c] for 0 <= i < n - shift, every column (real Float32 / Float64): sums delayed partial outputs on the device -- fftfilt is
+ * linear in b, so hosts that split a filter into segments themselves (up to round 4 the only way past the partitioned range; mdsp_ols_plan_create
+ * takes any length since) add segment k's output delayed by k * segment_length with this. */
 int mdsp_shift_add(void* y_dev, const void* t_dev, int64_t n, int64_t shift, int64_t ncols, int64_t ldy, int64_t ldt, int real_dtype, void* stream);
 /* Blocks [first_block, first_block + nblocks_range) of the SAME block grid mdsp_ols_exec uses for one column of nx samples /
  * nout outputs, from a slice of the signal: xs_dev holds x[xs_first .. xs_first + xs_len) and must cover the samples those blocks

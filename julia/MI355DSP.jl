@@ -256,31 +256,12 @@ end
 # fftfilt(b, x[, nfft]) / fftfilt!(out, b, x[, nfft])   Filters/filt.jl:458-476, _fftfilt! :479-521
 # Device arrays: one launch sequence on resident data.  Host Arrays: the chunked H2D || kernel || D2H pipeline (same block grid, so
 # both return bit-identical results).
-# the longest filter the fused engine's partitioned kernels take (DESIGN.md 4.11); longer ones run as a delayed sum of segments (fftfilt is linear in b)
-fused_max_taps(::Type{W}) where {W} = sizeof(W) == 4 ? 16384 : 8192
-function shift_add!(y::DeviceArray{W}, t::DeviceArray{W}, shift::Integer) where {W<:Union{Float32,Float64}}
-    n = size(y, 1)
-    check(ccall((:mdsp_shift_add, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Int64, Int64, Cint, Ptr{Cvoid}),
-                y.ptr, t.ptr, n, shift, ncolumns(y), n, n, mdtype(W), C_NULL))
-    y
-end
+# (filters of any length: beyond the partitioned kernels -- 16384 Float32 / 8192 Float64 taps -- the plan runs blocks of 2^20 points on the multi-pass engine)
 function fftfilt(b::AbstractVector{H}, x::DeviceArray{T}, nfft::Integer=optimalfftfiltlength(length(b), length(x))) where {H<:Real,T<:Real}
     W = fftintype(promote_type(H, T))
     xd = todevice(x, W)
-    nx, seg = size(xd, 1), fused_max_taps(W)
-    taps = convert(Vector{W}, b)
-    if length(taps) > seg && nx > seg           # beyond the partitioned range: sum_k delay(filt(b[k seg + 1 : (k + 1) seg], x), k seg) on the fused engine
-        y = nothing
-        for k in 0:cld(length(taps), seg)-1
-            k * seg >= nx && break
-            hk = taps[k*seg+1:min(end, (k + 1) * seg)]
-            plan = cached_ols_plan(hk, max(256, nextpow(2, 2 * length(hk))), nx, OLS_FILT, ENGINE_FUSED)   # a power of two >= 2 nb: the fused engine re-blocks by itself
-            t = ols_exec!(DeviceArray{W}(size(xd)), plan, xd, nx)
-            y = y === nothing ? t : shift_add!(y, t, k * seg)
-        end
-        return y
-    end
-    plan = cached_ols_plan(taps, nfft, nx, OLS_FILT)
+    nx = size(xd, 1)
+    plan = cached_ols_plan(convert(Vector{W}, b), nfft, nx, OLS_FILT)
     ols_exec!(DeviceArray{W}(size(xd)), plan, xd, nx)
 end
 function fftfilt(b::AbstractVector{H}, x::AbstractArray{T}, nfft::Integer=optimalfftfiltlength(length(b), length(x));

@@ -926,35 +926,81 @@ def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_filters_beyond_the_partitioned_range_stay_correct(d, torch, dt):
-    """32768 taps: beyond the four 4096-tap partitions of the fused engine (16384 Float32 / 8192 Float64 taps).  `filt(b, x)` runs them as a delayed sum
-    of segments on the fused engine (mdsp_shift_add; filters.py _fftfilt_segments), an explicit rocFFT-engine plan at the reference's own block length
-    (optimalfftfiltlength, dspbase.jl:268-291) gives the same convolution, both against the oracle; a single FUSED plan of that length is declined with
-    the reference-side error class instead of computing something else."""
+    """32768 taps: beyond the four partitions of the single-workgroup kernels (16384 Float32 / 8192 Float64 taps).  The SAME plan object takes them
+    (no host-side segment sums since round 5): blocks of 2^20 points -- fewer when one block holds the signal -- on the multi-pass engine
+    (bigfft.hip run_ols), reported by mdsp_ols_plan_geometry.  Against the oracle (filt.jl:479-521), against an explicit rocFFT-engine plan at the
+    reference's own block length (optimalfftfiltlength, dspbase.jl:268-291), several columns, signals shorter than the filter, conv, a block range
+    (bit-identical to the whole-column call) and the host-pointer pipeline."""
+    import ctypes as C
     from dsp_jl_amd import _lib
     from dsp_jl_amd.dspbase import OlsPlan
     from oracle import filt as ofilt
+    lib = _lib.lib()
     rng = np.random.default_rng(32768)
-    nb, nx = 32768, 700_000 + 11
+    nb, nx = 32768, 2_700_000 + 11
     b = (rng.standard_normal(nb) / np.sqrt(nb)).astype(dt)
     x = rng.standard_normal(nx).astype(dt)
-    got = d.filt(b, torch.from_numpy(x).cuda()).cpu().numpy()
+    xd = torch.from_numpy(x).cuda()
+    got = d.filt(b, xd).cpu().numpy()
     ref = ofilt.fftfilt(b.astype(np.float64), x.astype(np.float64))
     tol = TOL32 if dt == np.float32 else 1e-12
     assert relerr(got, ref) < tol
-    roc = d.fftfilt(b, torch.from_numpy(x).cuda(), d.optimalfftfiltlength(nb, nx), engine=d.ENGINE_ROCFFT).cpu().numpy()
+    roc = d.fftfilt(b, xd, d.optimalfftfiltlength(nb, nx), engine=d.ENGINE_ROCFFT).cpu().numpy()
     assert relerr(roc, ref) < tol and relerr(got, roc.astype(np.float64)) < 2 * tol
-    # two columns, and a signal shorter than the filter's second segment reaches
+    plan = OlsPlan(b, d.optimalfftfiltlength(nb, nx), nx, _lib.OLS_FILT, d.ENGINE_AUTO)
+    en, el, ep = C.c_int64(), C.c_int64(), C.c_int()
+    _lib.check(lib.mdsp_ols_plan_geometry(plan._h, C.byref(en), C.byref(el), C.byref(ep)))
+    assert plan.engine == d.ENGINE_FUSED and (en.value, el.value, ep.value) == (1 << 20, (1 << 20) - nb + 1, 1)
+    # blocks [2, 3) of the same grid from a slice of the signal: what the host pipeline and a time-axis split over GPUs issue
+    L = el.value
+    lo, hi = 2 * L - (nb - 1), min(nx, 3 * L)
+    ys = torch.full((hi - 2 * L,), float("nan"), dtype=xd.dtype, device="cuda")
+    _lib.check(lib.mdsp_ols_exec_range(plan._h, xd[lo:hi].data_ptr(), lo, hi - lo, nx, ys.data_ptr(), 2, 1, nx, torch.cuda.current_stream().cuda_stream))
+    assert np.array_equal(ys.cpu().numpy(), got[2 * L:hi])
+    # host arrays: the chunked H2D || kernels || D2H pipeline on the same plan geometry
+    assert np.array_equal(plan.exec_host(x.reshape(1, -1), nx)[0], got)
+    # two columns, and a signal shorter than the filter
     X = rng.standard_normal((40_000, 2)).astype(dt)
     Y = d.filt(b, torch.from_numpy(X).cuda()).cpu().numpy()
     for c in range(2):
         assert relerr(Y[:, c], ofilt.fftfilt(b.astype(np.float64), X[:, c].astype(np.float64))) < tol, c
-    # conv is linear in the kernel too: the full convolution (nx + nb - 1 samples) as the sum of the segments' convolutions
     from oracle import dspbase as odsp
-    cv = d.conv(torch.from_numpy(x).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    cv = d.conv(xd, torch.from_numpy(b).cuda()).cpu().numpy()
     assert cv.shape == (nx + nb - 1,)
     assert relerr(cv, odsp.conv(x.astype(np.float64), b.astype(np.float64))) < tol
-    with pytest.raises(d.UnsupportedError):
-        OlsPlan(b, d.optimalfftfiltlength(nb, nx), nx, _lib.OLS_FILT, d.ENGINE_FUSED)
+    # an explicit FUSED request is the same plan (up to round 4: UnsupportedError)
+    pf = OlsPlan(b, d.optimalfftfiltlength(nb, nx), nx, _lib.OLS_FILT, d.ENGINE_FUSED)
+    assert np.array_equal(pf.exec(xd.reshape(1, -1), nx).cpu().numpy()[0], got)
+
+
+@pytest.mark.parametrize("dt", [np.complex64, np.complex128])
+def test_long_complex_filters_on_the_multipass_engine(d, torch, dt):
+    """conv of complex signals with 20001 complex taps (one block per transform instead of two): against numpy's Float64 transform-domain product,
+    and 150000 real taps in Float32 -- the block grows to 2^21 points (eight times the filter)."""
+    rng = np.random.default_rng(20001)
+    nb, nx = 20001, 1_300_017
+    b = ((rng.standard_normal(nb) + 1j * rng.standard_normal(nb)) / np.sqrt(nb)).astype(dt)
+    x = (rng.standard_normal(nx) + 1j * rng.standard_normal(nx)).astype(dt)
+    nf = 1 << 21
+    ref = np.fft.ifft(np.fft.fft(x.astype(np.complex128), nf) * np.fft.fft(b.astype(np.complex128), nf))[:nx + nb - 1]
+    got = d.conv(torch.from_numpy(x).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    assert got.shape == ref.shape
+    assert relerr(got, ref) < (TOL32 if dt == np.complex64 else 1e-12)
+    if dt == np.complex64:
+        import ctypes as C
+        from dsp_jl_amd import _lib
+        from dsp_jl_amd.dspbase import OlsPlan
+        nb = 150_000
+        h = (rng.standard_normal(nb) / np.sqrt(nb)).astype(np.float32)
+        xr = rng.standard_normal(5_000_000).astype(np.float32)
+        y = d.filt(h, torch.from_numpy(xr).cuda()).cpu().numpy()
+        nf = 1 << 23
+        r = np.fft.irfft(np.fft.rfft(xr.astype(np.float64), nf) * np.fft.rfft(h.astype(np.float64), nf), nf)[:len(xr)]
+        assert relerr(y, r) < TOL32
+        plan = OlsPlan(h, d.optimalfftfiltlength(nb, len(xr)), len(xr), _lib.OLS_FILT, d.ENGINE_AUTO)
+        en = C.c_int64()
+        _lib.check(_lib.lib().mdsp_ols_plan_geometry(plan._h, C.byref(en), None, None))
+        assert en.value == 1 << 21
 
 
 def test_welch_hand_allocated_kernel_several_channels(d, torch):
