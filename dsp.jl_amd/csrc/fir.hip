@@ -1510,7 +1510,7 @@ int fir_mm_tsel(int64_t steps) { return steps <= 4 ? 4 : steps <= 8 ? 8 : steps 
 // tight (round 4, only tried where nothing else fits the LDS -- shapes that would otherwise fall to the generic kernel at 0.03 - 0.07 of the roofline):
 //   rb_cap > 0: rows of at most rb_cap rounds for L < 16 (ComplexF64 1//16: 14 rounds of 16 samples fit where the conflict-best 15 miss by 1 KiB);
 //   Float32 windows of 33 - 40 k-steps take the 40-step register form with single-chunk waves instead of 48 (ComplexF32 160//441: the 32 samples
-//   less of window tail per buffer are what the tile misses).
+//   less of window tail per buffer are what the tile misses); ComplexF64 windows of 13 - 14 k-steps take a 14-step form (round 5).
 FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0) {   // allow_regs: round 3's register-tap rules (fewer chunks / shorter rows)
     FirMGeo g;
     const bool t64 = allow_regs && tunables().fir_mm_t64 != 0;
@@ -1585,6 +1585,11 @@ FirMGeo fir_mm_geo_compute(const mdsp_fir_s* f, bool allow_regs, int rb_cap = 0)
     if (rb_cap < 0 && g.esz == 4 && steps > 32 && steps <= 40) {
         g.T = 40;
         g.steps = 40;
+        chmax = 1;
+    } else
+    if (rb_cap < 0 && g.esz == 8 && g.CS == 2 && steps > 12 && steps <= 14) {   // (round 5) ComplexF64 160//147 with resample_filter's 5921 taps (13 k-steps): the 16-step
+        g.T = 14;                                                                  // form's window tail misses the LDS by 2 KiB and the cell fell to the generic kernel (0.125)
+        g.steps = 14;
         chmax = 1;
     } else {
         g.T = fir_mm_tsel(steps);
@@ -1776,6 +1781,9 @@ template <typename R, int CS, int CH> int fir_mm_dispatch_t(mdsp_fir_s* f, const
         case 4: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 4, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 4>(f, a, g, st);
         case 8: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 8, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 8>(f, a, g, st);
         case 12: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 12, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 12>(f, a, g, st);
+        case 14:
+            if constexpr (sizeof(R) == 8 && CS == 2 && CH == 1) return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 14, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 14>(f, a, g, st);
+            MDSP_FAIL(MDSP_ERR_ASSERTION, "the 14-step form exists for ComplexF64 single-chunk waves only");
         case 16: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 16, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 16>(f, a, g, st);
         case 20: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 20, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 20>(f, a, g, st);
         case 24: return g.rowpad > 0 ? fir_mm_launch<R, CS, CH, 24, true>(f, a, g, st) : fir_mm_launch<R, CS, CH, 24>(f, a, g, st);
