@@ -80,6 +80,7 @@ static void read_tunables_locked() {
     t.fir_mm = geti("MDSP_FIR_MM", -1);
     t.fir_exact = geti("MDSP_FIR_EXACT", 0);
     t.fir_dec = geti("MDSP_FIR_DEC", 1);
+    t.fir_dec_wgs = geti("MDSP_FIR_DEC_WGS", 0);
     t.fir_dec_ablate = geti("MDSP_FIR_DEC_ABLATE", 0);
     t.fir_mm_rows = geti("MDSP_FIR_MM_ROWS", -1);
     t.fir_mm_ng = geti("MDSP_FIR_MM_NG", 0);

@@ -750,50 +750,93 @@ MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void dec
     V* red = reinterpret_cast<V*>(tl + (((size_t)nqp * M + 3) & ~(size_t)3));
     const int64_t ch = blockIdx.y;
     const int TO = (CPLX ? 1 : 2) * a.nbh * P;                  // outputs per tile
-    const int64_t m0 = (int64_t)blockIdx.x * TO;
-    if (m0 >= a.nout) return;
+    const int64_t ntile = (a.nout + TO - 1) / TO;
     const XS* xc = static_cast<const XS*>(a.x) + ch * a.ldx;
     const XS* hc = static_cast<const XS*>(a.hist) + ch * (int64_t)a.hl;
-    const int64_t zf = a.zb + m0 * M;                           // first staged sample
     const int H = a.nbh * P * M;                                // samples between the two halves of a real tile
-    if (a.ablate & 2) {
-    } else if (zf >= a.hl && zf - a.hl + a.nz + (CPLX ? 0 : H) <= a.xlen) {
-        // steady state: the tile (both halves of a real one) lies wholly inside x.  16-byte loads -- four Float32 samples, two Float64 / ComplexF32, one
-        // ComplexF64 -- four of them (pairs of them for a real signal's two halves) in flight per thread; consecutive samples sit at consecutive LDS
-        // positions (a block's padding never falls inside a group: block lengths are multiples of 16 samples, groups start at multiples of 4)
-        typedef unsigned u4v __attribute__((ext_vector_type(4)));
-        constexpr int NV = 16 / (int)sizeof(XS), U = 4;
+    // Float64 / ComplexF64 (PRE): a workgroup walks tiles blockIdx.x, + gridDim.x, ... with the NEXT tile's samples on their way from HBM (in registers: at
+    // most 40 KiB a tile, ten 16-byte loads a thread) while this tile is multiplied; they are written to the LDS behind the barrier that ends it.  One
+    // tile per workgroup -- the first form -- left staging and arithmetic to overlap across co-resident workgroups only, and they added up
+    // (profiles/r05_fir_dec_ab.json "ablation").  Float64 1//4 ... 1//16 0.92 - 1.00 -> 0.82 - 0.98 ms, ComplexF64 1.93 - 2.23 -> 1.54 - 2.02.
+    // Float32 / ComplexF32 keep one tile per workgroup: their 170 registers leave no room for the tile in flight at three workgroups per CU, and every
+    // form that made room measured slower -- two workgroups per CU 0.51 ms at 1//8 against 0.44, eight outputs per block with three 0.64, with four
+    // workgroups and 30 KiB tiles 0.88, 24 KiB tiles 0.64 (profiles/r05_fir_dec_ab.json "prefetch_forms").
+    // Steady state: the tile (both halves of a real one) lies wholly inside x.  16-byte loads -- four Float32 samples, two Float64 / ComplexF32, one
+    // ComplexF64; consecutive samples sit at consecutive LDS positions (a block's padding never falls inside a group: block lengths are multiples
+    // of 16 samples, groups start at multiples of 4)
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    constexpr int NV = 16 / (int)sizeof(XS);
+    constexpr bool PRE = sizeof(R) == 8;
+    constexpr int NIT = PRE ? (CPLX ? 10 : 5) : 1;              // nz sizeof(V) <= 40 KiB (fir_dec_geo): 256 threads x NIT x 16 (32: both halves) bytes
+    u4v pa[NIT], pb[CPLX ? 1 : NIT];
+    const bool fits = a.nz <= 256 * NIT * NV;                   // (filters of several thousand taps per phase: the tile outgrows the registers -- staged in place)
+    auto inside = [&](int64_t tile) {
+        const int64_t zf = a.zb + tile * TO * M;
+        return tile < ntile && !(a.ablate & 2) && zf >= a.hl && zf - a.hl + a.nz + (CPLX ? 0 : H) <= a.xlen;
+    };
+    auto steady = [&](int64_t tile) { return PRE && fits && inside(tile); };
+    auto issue = [&](int64_t tile) __attribute__((always_inline)) {
+        const int64_t zf = a.zb + tile * TO * M;
         const __amdgpu_buffer_rsrc_t rs = io::make_rsrc(xc + (zf - a.hl), (a.xlen - (zf - a.hl)) * (long long)sizeof(XS));
-        auto elem = [](const u4v& q, int i) -> XS {
-            if constexpr (std::is_same_v<XS, float>) return __uint_as_float(q[i]);
-            else if constexpr (std::is_same_v<XS, double>) return __hiloint2double((int)q[2 * i + 1], (int)q[2 * i]);
-            else if constexpr (std::is_same_v<XS, cx<float>>) return XS{__uint_as_float(q[2 * i]), __uint_as_float(q[2 * i + 1])};
-            else return XS{__hiloint2double((int)q[1], (int)q[0]), __hiloint2double((int)q[3], (int)q[2])};
-        };
-        for (int k0 = threadIdx.x * NV; k0 < a.nz; k0 += U * 256 * NV) {
-            u4v va[U], vb[CPLX ? 1 : U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + u * 256 * NV;
-                va[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k < a.nz ? k * (int)sizeof(XS) : io::OOB, 0, 0);
-                if constexpr (!CPLX) vb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k < a.nz ? (k + H) * (int)sizeof(XS) : io::OOB, 0, 0);
-            }
+        for (int u = 0; u < NIT; ++u) {
+            const int k = (threadIdx.x + u * 256) * NV;
+            pa[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k < a.nz ? k * (int)sizeof(XS) : io::OOB, 0, 0);
+            if constexpr (!CPLX) pb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k < a.nz ? (k + H) * (int)sizeof(XS) : io::OOB, 0, 0);
+        }
+    };
+    auto elem = [](const u4v& q, int i) -> XS {
+        if constexpr (std::is_same_v<XS, float>) return __uint_as_float(q[i]);
+        else if constexpr (std::is_same_v<XS, double>) return __hiloint2double((int)q[2 * i + 1], (int)q[2 * i]);
+        else if constexpr (std::is_same_v<XS, cx<float>>) return XS{__uint_as_float(q[2 * i]), __uint_as_float(q[2 * i + 1])};
+        else return XS{__hiloint2double((int)q[1], (int)q[0]), __hiloint2double((int)q[3], (int)q[2])};
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = k0 + u * 256 * NV;
-                if (k < a.nz) {
-                    V* dst = zs + dec_pos(k, M, a.blkmagic);
+        for (int u = 0; u < NIT; ++u) {
+            const int k = (threadIdx.x + u * 256) * NV;
+            if (k < a.nz) {
+                V* dst = zs + dec_pos(k, M, a.blkmagic);
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) {
-                        if constexpr (CPLX) {
-                            const XS v = elem(va[u], i);
-                            dst[i] = {v.x, v.y};
-                        } else dst[i] = {elem(va[u], i), elem(vb[u], i)};
-                    }
+                for (int i = 0; i < NV; ++i) {
+                    if constexpr (CPLX) {
+                        const XS v = elem(pa[u], i);
+                        dst[i] = {v.x, v.y};
+                    } else dst[i] = {elem(pa[u], i), elem(pb[u], i)};
                 }
             }
         }
-    } else {   // the first tile(s) straddle the history
+    };
+    auto stage_slow = [&](int64_t tile) {   // tiles that straddle the history or the end of x
+        const int64_t zf = a.zb + tile * TO * M;
+        if (inside(tile)) {                 // (a tile beyond the registers: 16-byte loads, four in flight, straight to the LDS)
+            constexpr int U = 4;
+            const __amdgpu_buffer_rsrc_t rs = io::make_rsrc(xc + (zf - a.hl), (a.xlen - (zf - a.hl)) * (long long)sizeof(XS));
+            for (int k0 = threadIdx.x * NV; k0 < a.nz; k0 += U * 256 * NV) {
+                u4v va[U], vb[CPLX ? 1 : U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + u * 256 * NV;
+                    va[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k < a.nz ? k * (int)sizeof(XS) : io::OOB, 0, 0);
+                    if constexpr (!CPLX) vb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k < a.nz ? (k + H) * (int)sizeof(XS) : io::OOB, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + u * 256 * NV;
+                    if (k < a.nz) {
+                        V* dst = zs + dec_pos(k, M, a.blkmagic);
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) {
+                            if constexpr (CPLX) {
+                                const XS v = elem(va[u], i);
+                                dst[i] = {v.x, v.y};
+                            } else dst[i] = {elem(va[u], i), elem(vb[u], i)};
+                        }
+                    }
+                }
+            }
+            return;
+        }
         auto sample = [&](int64_t zi) -> XS {
             if (zi < a.hl) return hc[zi];
             if (zi - a.hl < a.xlen) return xc[zi - a.hl];
@@ -805,77 +848,91 @@ MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void dec
                 zs[dec_pos(k, M, a.blkmagic)] = {v.x, v.y};
             } else zs[dec_pos(k, M, a.blkmagic)] = {sample(zf + k), sample(zf + k + H)};
         }
-    }
+    };
+    int64_t tile = blockIdx.x;
+    bool pre = steady(tile);                                    // workgroup-uniform
+    if (pre) issue(tile);
     {
         const R* pf = static_cast<const R*>(a.pfbT);
         for (int k = threadIdx.x; k < nqp * M; k += 256) tl[k] = k < a.tp ? pf[k] : (R)0;
     }
-    __syncthreads();
     const int r = threadIdx.x & (Mp - 1), gq = threadIdx.x >> a.logMp, ng = 256 >> a.logMp;
     const bool lane_on = r < M;
     const int rr = lane_on ? r : 0;
     V* myred = red + (size_t)gq * PH * (Mp + 1);
     using Y = std::conditional_t<CPLX, cx<R>, R>;
     Y* yc = static_cast<Y*>(a.y) + ch * a.ldy;
-    for (int bl = gq; bl < a.nbh; bl += ng) {
-        V acc[P];
+    for (; tile < ntile; tile += gridDim.x) {
+        const int64_t m0 = tile * TO;
+        if (PRE && pre) commit();
+        else if (!(a.ablate & 2)) stage_slow(tile);
+        __syncthreads();
+        if constexpr (PRE) {
+            pre = steady(tile + gridDim.x);
+            if (pre) issue(tile + gridDim.x);
+        }
+        for (int bl = gq; bl < a.nbh; bl += ng) {
+            V acc[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) acc[p] = {(R)0, (R)0};
-        // sample (bl P + t) M + r of the tile sits at  bl (P + 1) M + (t + t div P) M + r : t = q0 + j walks the window
-        const V* zb = zs + (size_t)bl * (P + 1) * M + rr;
-        for (int q0 = 0; q0 < ((a.ablate & 1) ? 0 : a.nq); q0 += QC) {
-            R g[QC];
-            V w[P + QC - 1];
+            for (int p = 0; p < P; ++p) acc[p] = {(R)0, (R)0};
+            // sample (bl P + t) M + r of the tile sits at  bl (P + 1) M + (t + t div P) M + r : t = q0 + j walks the window
+            const V* zb = zs + (size_t)bl * (P + 1) * M + rr;
+            for (int q0 = 0; q0 < ((a.ablate & 1) ? 0 : a.nq); q0 += QC) {
+                R g[QC];
+                V w[P + QC - 1];
 #pragma unroll
-            for (int u = 0; u < QC; ++u) g[u] = tl[(q0 + u) * M + rr];
+                for (int u = 0; u < QC; ++u) g[u] = tl[(q0 + u) * M + rr];
 #pragma unroll
-            for (int j = 0; j < P + QC - 1; ++j) {
-                const int t = q0 + j;
-                w[j] = zb[(t + t / P) * M];
-            }
-            if ((q0 + QC) * M <= a.tp) {   // every tap of the chunk exists (uniform)
+                for (int j = 0; j < P + QC - 1; ++j) {
+                    const int t = q0 + j;
+                    w[j] = zb[(t + t / P) * M];
+                }
+                if ((q0 + QC) * M <= a.tp) {   // every tap of the chunk exists (uniform)
 #pragma unroll
-                for (int u = 0; u < QC; ++u)
-#pragma unroll
-                    for (int p = 0; p < P; ++p) acc[p] = dec_fma(w[p + u], g[u], acc[p]);
-            } else {                       // the last chunk: positions past the filter's end are not read (a NaN there must not reach the output).  A lane
-                                           // whose tap does not exist sits the step out under the execution mask (first form: a select per multiply-add --
-                                           // 256 v_cndmask next to 128 packed FMAs, the chunk cost as much as three others: profiles/r05_fir_dec_ab.json)
-#pragma unroll
-                for (int u = 0; u < QC; ++u) {
-                    if ((q0 + u) * M + rr < a.tp) {
+                    for (int u = 0; u < QC; ++u)
 #pragma unroll
                         for (int p = 0; p < P; ++p) acc[p] = dec_fma(w[p + u], g[u], acc[p]);
+                } else {                       // the last chunk: positions past the filter's end are not read (a NaN there must not reach the output).  A lane
+                                               // whose tap does not exist sits the step out under the execution mask (first form: a select per multiply-add --
+                                               // 256 v_cndmask next to 128 packed FMAs, the chunk cost as much as three others: profiles/r05_fir_dec_ab.json)
+#pragma unroll
+                    for (int u = 0; u < QC; ++u) {
+                        if ((q0 + u) * M + rr < a.tp) {
+#pragma unroll
+                            for (int p = 0; p < P; ++p) acc[p] = dec_fma(w[p + u], g[u], acc[p]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // keeps the eight guarded groups apart (if-conversion would bring the selects back)
                     }
-                    __builtin_amdgcn_sched_barrier(0);   // keeps the eight guarded groups apart (if-conversion would bring the selects back)
+                }
+            }
+            // the M partial sums of every output meet in LDS (the lanes of a group sit in one wavefront: its DS operations execute in order)
+#pragma unroll
+            for (int p0 = 0; p0 < ((a.ablate & 4) ? 0 : P); p0 += PH) {
+                __builtin_amdgcn_wave_barrier();
+                if (lane_on) {
+#pragma unroll
+                    for (int p = 0; p < PH; ++p) myred[p * (Mp + 1) + r] = acc[p0 + p];
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int pp = r; pp < PH; pp += Mp) {
+                    V s = myred[pp * (Mp + 1)];
+                    for (int k = 1; k < M; ++k) {
+                        const V t = myred[pp * (Mp + 1) + k];
+                        s.x += t.x;
+                        s.y += t.y;
+                    }
+                    const int64_t m = m0 + (int64_t)bl * P + p0 + pp;
+                    if constexpr (CPLX) {
+                        if (m < a.nout) yc[m] = Y{s.x, s.y};
+                    } else {
+                        if (m < a.nout) yc[m] = s.x;
+                        if (m + (int64_t)a.nbh * P < a.nout) yc[m + (int64_t)a.nbh * P] = s.y;
+                    }
                 }
             }
         }
-        // the M partial sums of every output meet in LDS (the lanes of a group sit in one wavefront: its DS operations execute in order)
-#pragma unroll
-        for (int p0 = 0; p0 < ((a.ablate & 4) ? 0 : P); p0 += PH) {
-            __builtin_amdgcn_wave_barrier();
-            if (lane_on) {
-#pragma unroll
-                for (int p = 0; p < PH; ++p) myred[p * (Mp + 1) + r] = acc[p0 + p];
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (int pp = r; pp < PH; pp += Mp) {
-                V s = myred[pp * (Mp + 1)];
-                for (int k = 1; k < M; ++k) {
-                    const V t = myred[pp * (Mp + 1) + k];
-                    s.x += t.x;
-                    s.y += t.y;
-                }
-                const int64_t m = m0 + (int64_t)bl * P + p0 + pp;
-                if constexpr (CPLX) {
-                    if (m < a.nout) yc[m] = Y{s.x, s.y};
-                } else {
-                    if (m < a.nout) yc[m] = s.x;
-                    if (m + (int64_t)a.nbh * P < a.nout) yc[m + (int64_t)a.nbh * P] = s.y;
-                }
-            }
-        }
+        if constexpr (!PRE) break;   // (one tile per workgroup: straight-line code -- as a loop the Float32 form spilt 27 registers and ran 1.5x slower)
+        __syncthreads();   // every group has read its last window before the next tile's samples overwrite them
     }
 }
 
@@ -1912,7 +1969,11 @@ template <typename R, bool CPLX, int P> int fir_dec_launch(mdsp_fir_s* f, const 
     if (tunables().fir_dec == 2) kern = decimator_kernel<R, CPLX, P, 0>;   // MDSP_FIR_DEC=2: the run-time M form for every M
     if (g.lds > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
     const int64_t TO = (int64_t)(CPLX ? 1 : 2) * g.nbh * P;
-    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(a.nout, TO), (unsigned)f->nch), dim3(256), g.lds, st, d);
+    // Float64: the workgroups that stay resident (two a CU), each walking its share of the tiles with the next one's samples in flight; Float32: one tile each
+    const int64_t ntile = cdiv(a.nout, TO);
+    const int wgs = tunables().fir_dec_wgs > 0 ? tunables().fir_dec_wgs : 2;
+    const int64_t per = sizeof(R) == 8 ? std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, f->nch)) : ntile;
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(ntile, per), (unsigned)f->nch), dim3(256), g.lds, st, d);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
 }
