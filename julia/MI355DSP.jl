@@ -95,16 +95,25 @@ function plan_cache_partitions()
     check(ccall((:mdsp_plan_cache_partitions, lib), Cint, (Ref{Int64}, Ref{Int64}), p, r))
     (partitions = Int(p[]), reaped = Int(r[]))
 end
-# Julia tasks migrate between OS threads: a task that borrows cached plans binds its own partition (thread-local in the library, so it is bound
-# again after every yield point that may migrate the task -- `with_plan_context` does that around one call).
+# Julia tasks migrate between OS threads, the library's binding is thread-local: `with_plan_context` pins the task to its thread for the duration
+# (sticky, restored afterwards), so the binding is made and cleared on the SAME thread and no other task scheduled there inherits it.  A context
+# derived from the task (the default id) is released when the call returns -- its plans are freed with it, nothing lingers for the global cap to
+# trim; pass an id of your own (and call plan_cache_release_context when its work is done) to keep plans across calls.
 plan_cache_set_context(id::Integer) = check(ccall((:mdsp_plan_cache_set_context, lib), Cint, (UInt64,), UInt64(id)))
 plan_cache_release_context(id::Integer) = check(ccall((:mdsp_plan_cache_release_context, lib), Cint, (UInt64,), UInt64(id)))
-function with_plan_context(f, id::Integer=objectid(current_task()) % UInt64)
-    plan_cache_set_context(id)
+function with_plan_context(f, id::Union{Integer,Nothing}=nothing)
+    t = current_task()
+    own = id === nothing
+    ctx = own ? (objectid(t) % UInt64) | (UInt64(1) << 62) : UInt64(id)
+    was_sticky = t.sticky
+    t.sticky = true                  # no migration between the two bindings below
+    plan_cache_set_context(ctx)
     try
         return f()
     finally
         plan_cache_set_context(0)
+        own && plan_cache_release_context(ctx)
+        t.sticky = was_sticky
     end
 end
 
