@@ -35,8 +35,11 @@ int stft(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, int
 // length for a filter of nb taps and (a hint, 0: unknown) nout outputs per column (0: not this engine).  ols: blocks [g0, g1) of ONE column's block grid (block length N - nb + 1; g0 even for real
 // signals) -- x / y are the column's (possibly virtual) bases as in mdsp_ols_exec_range, H the filter's full natural-order spectrum, 1 / N folded in.
 int64_t ols_size(int dtype, int64_t nb, int64_t nout_hint);
-int ols(EngineHolder& h, int dtype, int64_t N, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout, int64_t g0, int64_t g1,
-        hipStream_t st);
+// > 0: a transform of N points runs in the rows form (N = R0 x S, S = 8192 Float32 / 4096 Float64: column pass, one row kernel on the single-workgroup
+// transforms of ols.hip, column pass back) and H is expected ROW-MAJOR in its layout, H'[k1 S + k2] = H[k1 + R0 k2]; 0: natural order, three passes each way
+int ols_rows_r0(int dtype, int64_t N);
+int ols(EngineHolder& h, int dtype, int64_t N, int R0 /* ols_rows_r0 when H was laid out */, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout,
+        int64_t g0, int64_t g1, hipStream_t st);
 
 }  // namespace big
 }  // namespace mdsp

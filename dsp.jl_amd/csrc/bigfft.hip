@@ -27,6 +27,9 @@ using namespace mdsp;
 using mdsp::fft::cx;
 
 namespace mdsp {
+// ols.hip: the row kernel of the long-filter convolution and the root table of its transforms
+int ols_rows(int dbl, void* work, int64_t rows, int hrows, const void* Hrows, const void* table, const void* rt0, const void* rt1, int rlogS, hipStream_t st);
+int ols_rows_table(int dbl, DevBuf& buf);
 namespace big {
 
 struct Engine {
@@ -36,6 +39,11 @@ struct Engine {
     Pass pass[MAXP];
     DevBuf tables, work, nat, partial, winR;
     const double* win_src = nullptr;   // the Float64 window winR was converted from
+    // overlap-save, rows form: nfft = R0 x S with S the longest single-workgroup transform (8192 Float32 / 4096 Float64).  pass[0] is the forward
+    // column pass (twiddles behind it), inv0 the same pass with tables of ones (the row kernel has applied the inverse twiddle already)
+    int rowsR0 = 0;
+    Pass inv0;
+    DevBuf rowtab;                     // the S forward roots of the row transforms (ols.hip)
 };
 EngineHolder::~EngineHolder() { delete p; }
 
@@ -142,6 +150,12 @@ template <typename R, int OUT, int E> __global__ __launch_bounds__(TPB, (E < ele
                     return z;
                 });
             }
+        } else if (a.in_mode == 5) {   // overlap-save, rows form: the way back starts from the conjugate of what the row kernel left in the work buffer
+            const cx<R>* zs = a.buf + t * N;
+            load_regs<R, E>(p, tc, tid, pre, [&](int64_t pos) {
+                const cx<R> v = zs[pos];
+                return cx<R>{v.x, -v.y};
+            });
         } else {                        // overlap-save, the way back: conj(Z H) -- the inverse transform is the forward one of the conjugate, conjugated
             const cx<R>* zs = static_cast<const cx<R>*>(a.src2) + t * N;
             const cx<R>* Hs = static_cast<const cx<R>*>(a.H);
@@ -315,6 +329,12 @@ __global__ __launch_bounds__(TPB, (sizeof(R) == 4 ? 2 : 1)) void big_fast_kernel
                     return z;
                 });
             }
+        } else if (a.in_mode == 5) {   // overlap-save, rows form: the way back starts from the conjugate of what the row kernel left in the work buffer
+            const cx<R>* zs = a.buf + t * N;
+            fast_load<R, RA, TJ>(p, tc, tid, pre, [&](int64_t pos) {
+                const cx<R> v = zs[pos];
+                return cx<R>{v.x, -v.y};
+            });
         } else {                        // overlap-save, the way back: conj(Z H) -- the inverse transform is the forward one of the conjugate, conjugated
             const cx<R>* zs = static_cast<const cx<R>*>(a.src2) + t * N;
             const cx<R>* Hs = static_cast<const cx<R>*>(a.H);
@@ -481,8 +501,50 @@ template <typename R> int build(Engine* e) {
     return MDSP_OK;
 }
 
+template <typename R> int build_rows(Engine* e, int R0) {
+    HostPlan<R> hp;
+    const int Rf[2] = {R0, (int)(e->nfft / R0)};
+    if (!make_plan_factors<R>(e->nfft, hp, Rf, 2, tunables().big_fast != 0, true)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "no column pass of %d points", R0);
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t nr = al(hp.roots[0].size()), n0 = al(hp.T0[0].size()), n1 = al(hp.T1[0].size());
+    std::vector<cx<R>> all(nr + 2 * (n0 + n1), cx<R>{(R)1, (R)0});
+    std::copy(hp.roots[0].begin(), hp.roots[0].end(), all.begin());
+    std::copy(hp.T0[0].begin(), hp.T0[0].end(), all.begin() + (long)nr);
+    std::copy(hp.T1[0].begin(), hp.T1[0].end(), all.begin() + (long)(nr + n0));
+    MDSP_TRY(e->tables.reserve(sizeof(cx<R>) * all.size()));
+    MDSP_HIP(hipMemcpy(e->tables.p, all.data(), sizeof(cx<R>) * all.size(), hipMemcpyHostToDevice));
+    const cx<R>* dev = e->tables.as<cx<R>>();
+    e->P = 1;
+    e->pass[0] = hp.pass[0];
+    e->pass[0].roots = dev;
+    e->pass[0].T0 = dev + nr;
+    e->pass[0].T1 = dev + nr + n0;
+    e->inv0 = e->pass[0];
+    e->inv0.T0 = dev + nr + n0 + n1;          // ones
+    e->inv0.T1 = dev + nr + n0 + n1 + n0;
+    e->rowsR0 = R0;
+    return ols_rows_table(sizeof(R) == 8, e->rowtab);
+}
+
+int get_engine_rows(EngineHolder& h, int dtype, int64_t nfft, int R0, Engine** out) {
+    if (h.p && (h.p->dtype != dtype || h.p->rowsR0 != R0 || h.p->nfft != nfft)) {
+        delete h.p;
+        h.p = nullptr;
+    }
+    if (!h.p) {
+        std::unique_ptr<Engine> e(new Engine());
+        e->dtype = dtype;
+        e->n = 0;
+        e->nfft = nfft;
+        MDSP_TRY(dtype_is_double(dtype) ? build_rows<double>(e.get(), R0) : build_rows<float>(e.get(), R0));
+        h.p = e.release();
+    }
+    *out = h.p;
+    return MDSP_OK;
+}
+
 int get_engine(EngineHolder& h, int dtype, int64_t n, int64_t nfft, Engine** out) {
-    if (h.p && (h.p->dtype != dtype || h.p->n != n || h.p->nfft != nfft)) {
+    if (h.p && (h.p->dtype != dtype || h.p->n != n || h.p->nfft != nfft || h.p->rowsR0 != 0)) {
         delete h.p;
         h.p = nullptr;
     }
@@ -670,24 +732,95 @@ template <typename R> int run_ols(Engine* e, bool cplx, const void* x, int64_t n
     return MDSP_OK;
 }
 
+// The rows form: nfft = R0 x S.  Column pass (R0-point transforms along the stride-S dimension, the inter-pass twiddle behind them), then ONE kernel per
+// row that does the S-point transform, the row of the filter's spectrum, the inverse S-point transform and the inverse twiddle (ols.hip: the
+// single-workgroup transforms, in place), then the inverse column pass straight into y: 7 trips of 8 nfft bytes through HBM per transform instead of 13.
+template <typename R> int run_ols_rows(Engine* e, bool cplx, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout, int64_t g0, int64_t g1, hipStream_t st) {
+    const int64_t N = e->nfft, L = N - (nb - 1);
+    const int64_t u0 = cplx ? g0 : g0 / 2, u1 = cplx ? g1 : cdiv(g1, 2);
+    if (u1 <= u0) return MDSP_OK;
+    const int64_t per = (int64_t)sizeof(cx<R>) * N;
+    const int64_t C = std::max<int64_t>(1, std::min<int64_t>(u1 - u0, ((int64_t)tunables().big_chunk_mib << 20) / per));
+    MDSP_TRY(e->work.reserve((size_t)(per * C)));
+    const int cus = device_cu_count();
+    for (int64_t c0 = u0; c0 < u1; c0 += C) {
+        const int64_t cnt = std::min<int64_t>(C, u1 - c0);
+        for (int dir = 0; dir < 2; ++dir) {
+            BigArgs<R> a{};
+            a.p = dir == 0 ? e->pass[0] : e->inv0;
+            a.in_mode = dir == 0 ? 3 : 5;
+            a.s = x;
+            a.buf = e->work.as<cx<R>>();
+            a.t0 = c0;
+            a.ntrans = cnt;
+            a.K = g1;
+            a.nx = nx;
+            a.nb1 = nb - 1;
+            a.L = L;
+            a.nout = nout;
+            a.ols_cplx = cplx ? 1 : 0;
+            a.ablate = tunables().big_ablate;
+            // workgroups per CU of the column passes, measured 1 .. 6 (r05_s26.sh): four for the 64-point pass in either precision (Float64: 0.79 TB/s with one,
+            // 1.00 with two or four), two otherwise
+            const int64_t wgs = (int64_t)cus * (tunables().big_wgs > 0 ? tunables().big_wgs : (a.p.fTJ && a.p.Rp <= 64 ? 4 : 2));
+            int groups = tunables().big_groups > 0 ? tunables().big_groups : (int)cdiv(wgs, a.p.ntiles);
+            groups = (int)std::max<int64_t>(1, std::min<int64_t>(groups, cnt));
+            const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(a.p.ntiles, wgs / groups));
+            if (dir == 0) {
+                MDSP_TRY((launch_pass<R, 0>(a, lanes, groups, st)));
+                MDSP_TRY(ols_rows(sizeof(R) == 8, e->work.p, cnt * e->rowsR0, e->rowsR0, H, e->rowtab.p, e->pass[0].T0, e->pass[0].T1, e->pass[0].logS, st));
+            } else {
+                a.out = y;
+                MDSP_TRY((launch_pass<R, 4>(a, lanes, groups, st)));
+            }
+        }
+    }
+    return MDSP_OK;
+}
+
 }  // namespace
+
+int ols_rows_r0(int dtype, int64_t N) {
+    if (tunables().big_ols_rows == 0) return 0;
+    const int64_t S = dtype_is_double(dtype) ? 4096 : 8192;
+    if (N % S) return 0;
+    const int64_t r = N / S;
+    return (r == 32 || r == 64 || r == 128 || r == 256) ? (int)r : 0;
+}
 
 int64_t ols_size(int dtype, int64_t nb, int64_t nout_hint) {
     if (!tunables().bigfft || nb < 2) return 0;
-    (void)dtype;
-    // 2^20 points (three two-stage passes of 64 / 128 / 128: the fastest of 2^17 .. 2^21 for 32768 .. 131072 taps of either precision,
-    // profiles/r05_big_ols.json), more while the filter covers over an eighth of the block; less when one block already holds the whole signal
-    int64_t N = (int64_t)1 << 20;
-    while (N < 8 * nb) N <<= 1;
+    const bool dbl = dtype_is_double(dtype);
+    // The rows form first (profiles/r05_big_ols.json): R0 = 64 rows -- the column pass whose tiles are 32 columns wide, 128-byte runs of a real Float32 signal -- is
+    // the fastest while the filter stays under a quarter of the block (Float32 2^19: 0.90 / 0.86 / 0.75 TB/s at 32768 / 65536 / 131072 taps; Float64 2^18: 1.00
+    // at 32768), then R0 = 256 (Float32 2^21: 0.73; Float64 2^20: 0.83 / 0.79 at 65536 / 131072); R0 = 128 measured slowest at every length (0.62 / 0.71).
+    // Beyond those, three passes each way on natural-order spectra: 2^20 points, more while the filter covers over an eighth of the block (0.41 - 0.58).
+    const int64_t S = dbl ? 4096 : 8192;
+    int64_t N = 0;
+    if (tunables().big_ols_rows != 0) {
+        if (4 * nb <= 64 * S) N = 64 * S;
+        else if (4 * nb <= 256 * S) N = 256 * S;
+    }
+    if (N == 0) {
+        N = (int64_t)1 << 20;
+        while (N < 8 * nb) N <<= 1;
+    }
+    // less when one block already holds the whole signal
     while (nout_hint > 0 && N / 2 >= 2 * nb && N / 2 - (nb - 1) >= nout_hint) N >>= 1;
     if (tunables().big_ols_log2n > 0) N = (int64_t)1 << tunables().big_ols_log2n;
     if (N > ((int64_t)1 << 26) || N < 2 * nb || N <= 4096) return 0;
+    if (ols_rows_r0(dtype, N)) return N;
     int R[MAXP];
     return factorise(N, R, tunables().big_rmax) >= 2 ? N : 0;
 }
 
-int ols(EngineHolder& h, int dtype, int64_t N, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout, int64_t g0, int64_t g1, hipStream_t st) {
+int ols(EngineHolder& h, int dtype, int64_t N, int R0, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout, int64_t g0, int64_t g1, hipStream_t st) {
     Engine* e = nullptr;
+    if (R0) {
+        MDSP_TRY(get_engine_rows(h, dtype, N, R0, &e));
+        const bool cplx = dtype_is_complex(dtype);
+        return dtype_is_double(dtype) ? run_ols_rows<double>(e, cplx, x, nx, H, nb, y, nout, g0, g1, st) : run_ols_rows<float>(e, cplx, x, nx, H, nb, y, nout, g0, g1, st);
+    }
     MDSP_TRY(get_engine(h, dtype, 0, N, &e));
     const bool cplx = dtype_is_complex(dtype);
     return dtype_is_double(dtype) ? run_ols<double>(e, cplx, x, nx, H, nb, y, nout, g0, g1, st) : run_ols<float>(e, cplx, x, nx, H, nb, y, nout, g0, g1, st);

@@ -139,12 +139,18 @@ template <typename R> struct HostPlan {
 };
 
 // false: N cannot be planned (a prime factor above 7, or a factor that no schedule covers)
+// first_only: the factors are (R_0, N / R_0) and only pass 0 is built -- the rows of N / R_0 points belong to somebody else (overlap-save: the
+// single-workgroup transforms of ols.hip)
+template <typename R> bool make_plan_factors(int64_t N, HostPlan<R>& hp, const int* Rf, int P, bool fast, bool first_only = false);
 template <typename R> bool make_plan(int64_t N, HostPlan<R>& hp, int rmax = RMAX, bool fast = true) {
-    constexpr bool dbl = sizeof(R) == 8;
     if (N < 4 || N >= ((int64_t)1 << 31) || !seven_smooth(N)) return false;
     int Rf[MAXP];
     const int P = factorise(N, Rf, rmax);
     if (P < 2) return false;
+    return make_plan_factors<R>(N, hp, Rf, P, fast);
+}
+template <typename R> bool make_plan_factors(int64_t N, HostPlan<R>& hp, const int* Rf, int P, bool fast, bool first_only) {
+    constexpr bool dbl = sizeof(R) == 8;
     hp.N = N;
     hp.P = P;
     hp.roots.assign(P, {});
@@ -153,7 +159,7 @@ template <typename R> bool make_plan(int64_t N, HostPlan<R>& hp, int rmax = RMAX
     int64_t M[MAXP];   // natural weights M_p = R_0 ... R_{p-1}
     M[0] = 1;
     for (int p = 1; p < P; ++p) M[p] = M[p - 1] * Rf[p - 1];
-    for (int p = 0; p < P; ++p) {
+    for (int p = 0; p < (first_only ? 1 : P); ++p) {
         Pass& q = hp.pass[p];
         q = Pass{};
         q.N = N;
@@ -218,6 +224,7 @@ template <typename R> bool make_plan(int64_t N, HostPlan<R>& hp, int rmax = RMAX
             q.nT1 = 1;
         }
     }
+    if (first_only) hp.P = 1;
     return true;
 }
 

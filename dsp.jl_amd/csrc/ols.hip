@@ -104,6 +104,11 @@ struct OlsFusedArgs {
     int64_t niter;          // ... runs_per_slot * run_len iterations in total (same for every slot)
     int ablate;             // profiling aid, -DMDSP_DEBUG_KNOBS builds only (MDSP_ABLATE): 1 skip HBM loads, 2 skip transforms, 4 skip stores
     int memprio;            // MDSP_OLS_PRIO: 1 loads, 2 stores, 3 both issued at raised wave priority (s_setprio)
+    // ROWS form (the middle of the long-filter convolution, mdsp::ols_rows): block g is row g mod hrows of a two-pass transform of hrows x N points --
+    // its own spectrum row H + (g mod hrows) N, and the inverse half of the inter-pass twiddle, conj(W^{(g mod hrows) n}), on the way out
+    int hrows;
+    const void *rt0, *rt1;  // W_{hrows N}^m = rt1[m >> rlogS] * rt0[m & (2^rlogS - 1)]
+    int rlogS;
 };
 
 // Raw samples of one unit as they come from HBM: two real blocks (a, b) or one complex block.
@@ -264,8 +269,10 @@ template <int T> __device__ __forceinline__ void ols_dma_issue(const OlsFusedArg
     for (int g = wave; g < ntail; g += NW) dma64(r, base + (unsigned)nfull * 1024u + (unsigned)g * 256u, nfull * 1024 + g * 256 + lane * 4);
 }
 
-template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, int PERM = false, bool STAGE = false, bool XDMA = false>
+template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW, int NBUF, bool PREFETCH, bool HREG = true, int PERM = false, bool STAGE = false, bool XDMA = false,
+          bool ROWS = false>
 __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedArgs a) {
+    static_assert(!ROWS || (CPLX && !HREG && !PERM), "the rows form: complex blocks, one spectrum row per block");
     using C = fft::Cfg<N, E>;
     constexpr int T = C::T;
     static_assert(T % 64 == 0, "a transform must own whole wavefronts (uniform descriptors)");
@@ -352,12 +359,27 @@ __global__ __launch_bounds__((N / E) * G, MINW) void ols_fused_kernel(OlsFusedAr
             for (int e = 0; e < E; ++e) v[e] = fft::cmul(v[e], Hr[e]);
         } else {  // spectrum streamed from L2 (16 KiB, always resident) instead of living in 2E VGPRs
             cx<R> hh[E];
+            if constexpr (ROWS) {
+                const __amdgpu_buffer_rsrc_t hrow = io::make_rsrc(static_cast<const cx<R>*>(a.H) + (cur.p % a.hrows) * N, (int64_t)N * (int64_t)sizeof(cx<R>));
+                io::load_window<cx<R>, E, T>(hh, hrow, 0, ti);
+            } else
             io::load_window<cx<R>, E, T>(hh, hrsrc, 0, ti);
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = fft::cmul(v[e], hh[e]);
         }
         // inverse transform (unnormalised, like plan_brfft / inv(p).p)
         fft::wg_fft<C, +1, TWMODE, PADSHIFT, NBUF, (C::P - 1) % NBUF, 0, PERM>(v, t, tw, twsrc, lds);
+        if constexpr (ROWS) {   // conj(W^{k1 (ti + T e)}) = conj(W^{k1 ti} W^{k1 T e}): one table walk per thread and row, E uniform ones (scalar loads)
+            const cx<R>*t0 = static_cast<const cx<R>*>(a.rt0), *t1 = static_cast<const cx<R>*>(a.rt1);
+            const unsigned k1 = (unsigned)(cur.p % a.hrows), mask = (1u << a.rlogS) - 1u;
+            const auto root = [&](unsigned m) { return fft::cmul(t0[m & mask], t1[m >> a.rlogS]); };
+            const cx<R> w0 = root(k1 * (unsigned)ti);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const cx<R> w = fft::cmul(w0, root(k1 * (unsigned)(T * e)));
+                v[e] = fft::cmul(v[e], cx<R>{w.x, -w.y});
+            }
+        }
         }
         // no barrier needed here: with one buffer wg_fft ends every exchange with a barrier, with two the 2(P-1)
         // exchanges of a unit alternate buffers so the next unit's first write is two barriers behind its readers
@@ -846,9 +868,9 @@ template <typename R> int upload_table(DevBuf& buf, int64_t n) {
 
 // ---- fused launch ---------------------------------------------------------------------------------------
 template <typename R, int N, int E, int G, int TWMODE, int PADSHIFT, bool CPLX, int MINW = 2, int NBUF = 2, bool PREFETCH = true, bool HREG = true,
-          int PERM = false, bool STAGE = false, bool XDMA = false>
+          int PERM = false, bool STAGE = false, bool XDMA = false, bool ROWS = false>
 int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
-    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG, PERM, STAGE, XDMA>;
+    auto kern = ols_fused_kernel<R, N, E, G, TWMODE, PADSHIFT, CPLX, MINW, NBUF, PREFETCH, HREG, PERM, STAGE, XDMA, ROWS>;
     constexpr int threads = (N / E) * G;
     int per_cu = 0;
     MDSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
@@ -865,6 +887,30 @@ int launch_fused_variant(const OlsFusedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, b);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
+}
+
+// The middle of the long-filter convolution (bigfft.hip run_ols_rows): `rows` rows of S complex points in place -- forward transform, the row's spectrum,
+// inverse transform, inverse inter-pass twiddle -- on the single-workgroup transforms of this file (S = 8192 Float32, 4096 Float64).
+int ols_rows_impl(int dbl, void* work, int64_t rows, int hrows, const void* Hrows, const void* table, const void* rt0, const void* rt1, int rlogS, hipStream_t st) {
+    OlsFusedArgs a{};
+    const int64_t S = dbl ? 4096 : 8192;
+    a.x = work;
+    a.y = work;
+    a.table = table;
+    a.H = Hrows;
+    a.nx = a.nout = a.ldx = a.ldy = rows * S;
+    a.L = S;
+    a.nb = 1;
+    a.nblocks = a.units_per_col = a.nunits = rows;
+    a.u_begin = 0;
+    a.memprio = tunables().ols_prio;
+    a.hrows = hrows;
+    a.rt0 = rt0;
+    a.rt1 = rt1;
+    a.rlogS = rlogS;
+    //                                                 R   N   E  G TW PAD CPLX MINW NBUF PREF  HREG  PERM  STAGE  XDMA  ROWS
+    if (dbl) return launch_fused_variant<double, 4096, 8, 1, 1, 4, true, 2, 2, false, false, false, false, false, true>(a, st);
+    return launch_fused_variant<float, 8192, 16, 1, 1, 4, true, 2, 1, false, false, false, false, false, true>(a, st);
 }
 
 template <typename R, int N, bool CPLX> int launch_fused_n(const OlsFusedArgs& a, int variant, hipStream_t s) {
@@ -1119,6 +1165,13 @@ template <typename R> __global__ __launch_bounds__(256) void shift_add_kernel(R*
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) y[c * ldy + shift + i] += t[c * ldt + i];
 }
 
+namespace mdsp {
+int ols_rows(int dbl, void* work, int64_t rows, int hrows, const void* Hrows, const void* table, const void* rt0, const void* rt1, int rlogS, hipStream_t st) {
+    return ols_rows_impl(dbl, work, rows, hrows, Hrows, table, rt0, rt1, rlogS, st);
+}
+int ols_rows_table(int dbl, DevBuf& buf) { return dbl ? upload_table<double>(buf, 4096) : upload_table<float>(buf, 8192); }
+}  // namespace mdsp
+
 extern "C" {
 
 int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode,
@@ -1224,6 +1277,14 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
         const double sc = 1.0 / (double)nfft;
         for (auto& h : Hf) h *= sc;
     }
+    if (pl->big) pl->big_rows = mdsp::big::ols_rows_r0(dtype, nfft);
+    if (pl->big_rows) {   // the rows form multiplies row k1 of the two-pass transform by H[k1 + R0 k2], k2 along the row
+        const int64_t R0 = pl->big_rows, S = nfft / R0;
+        std::vector<zd> Hr(Hf.size());
+        for (int64_t k1 = 0; k1 < R0; ++k1)
+            for (int64_t k2 = 0; k2 < S; ++k2) Hr[(size_t)(k1 * S + k2)] = Hf[(size_t)(k1 + R0 * k2)];
+        Hf.swap(Hr);
+    }
     int st = MDSP_OK;
     const bool half = (eng == MDSP_ENGINE_ROCFFT) && !cplx;
     st = dbl ? upload_spectrum<double>(pl, Hf, half) : upload_spectrum<float>(pl, Hf, half);
@@ -1279,7 +1340,7 @@ static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int6
     if (plan->big) {   // one column at a time: a column's blocks fill the chip by themselves
         const size_t esz = dtype_size(plan->dtype);
         for (int64_t c = 0; c < ncols; ++c)
-            MDSP_TRY(mdsp::big::ols(plan->bigeng, plan->dtype, plan->nfft, static_cast<const char*>(x_dev) + (size_t)(c * ldx) * esz, nx, plan->H.p, plan->nb,
+            MDSP_TRY(mdsp::big::ols(plan->bigeng, plan->dtype, plan->nfft, plan->big_rows, static_cast<const char*>(x_dev) + (size_t)(c * ldx) * esz, nx, plan->H.p, plan->nb,
                                     static_cast<char*>(y_dev) + (size_t)(c * ldy) * esz, nout, g_begin, g_end, s));
         return MDSP_OK;
     }

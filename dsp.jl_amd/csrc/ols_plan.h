@@ -19,5 +19,6 @@ struct mdsp_ols_plan_s {
     int variant = 0;  // fused kernel variant (tuning knob, MDSP_OLS_VARIANT)
     // filters beyond the partitioned kernels: blocks of nfft = 8 .. 16 nb points on the multi-pass engine (bigfft.hip), H = nfft entries, natural order
     bool big = false;
+    int big_rows = 0;                    // > 0: H is row-major for the rows form of that engine (R0 rows: bigfft.h ols_rows_r0)
     mdsp::big::EngineHolder bigeng;
 };

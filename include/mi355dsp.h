@@ -115,10 +115,11 @@ int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len /* 
  * the fused engine runs it as it is up to nfft = 8192 (4096 in Float64).  Longer filters -- ~1100 taps and more, where the reference asks for
  * nfft = 16384 ... 2^20 -- are re-blocked: one block of the largest in-LDS transform while the filter covers at most half of it, else a
  * uniformly partitioned filter (2..4 partitions of exec_nfft/2 taps, spectra of the last blocks kept in registers).  Beyond four partitions
- * (more than 16384 Float32 / 8192 Float64 taps, any of the four dtypes) the blocks no longer fit a workgroup: exec_nfft = 2^20 points (more beyond
- * 131072 taps), each block transformed by the multi-pass engine that also runs the large spectral transforms (three passes over HBM each way,
- * the filter's spectrum multiplied in between: DESIGN.md 4.5); partitions = 1.  Same outputs within rounding, one plan for every filter length
- * with 2 nb <= 2^26. */
+ * (more than 16384 Float32 / 8192 Float64 taps, any of the four dtypes) a block no longer fits a workgroup and is transformed in passes over HBM
+ * (partitions = 1): exec_nfft = R0 x S with S the longest single-workgroup transform (8192 / 4096) -- a column pass of R0-point
+ * transforms, ONE kernel per row for transform, filter spectrum, inverse transform and twiddle, a column pass back (R0 = 64 up to S x 16 taps, 256 up
+ * to S x 64) -- and beyond that three passes each way on natural-order spectra (2^20 points and more).  Same outputs within rounding, one plan for
+ * every filter length with 2 nb <= 2^26. */
 int mdsp_ols_plan_geometry(mdsp_ols_plan plan, int64_t* exec_nfft, int64_t* exec_block_len, int* partitions);
 /* x_dev: (nx, ncols) ld ldx;  y_dev: (nout, ncols) ld ldy.  nout = nx (filt), nx+nb-1 (conv), or any
  * 0 <= nout <= nx+nb-1.  x and y must not alias (Filters/filt.jl:438-439). */

@@ -928,8 +928,8 @@ def test_welch_round3_kernel_vs_oracle_and_round2_kernel(d, torch, variant):
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_filters_beyond_the_partitioned_range_stay_correct(d, torch, dt):
     """32768 taps: beyond the four partitions of the single-workgroup kernels (16384 Float32 / 8192 Float64 taps).  The SAME plan object takes them
-    (no host-side segment sums since round 5): blocks of 2^20 points -- fewer when one block holds the signal -- on the multi-pass engine
-    (bigfft.hip run_ols), reported by mdsp_ols_plan_geometry.  Against the oracle (filt.jl:479-521), against an explicit rocFFT-engine plan at the
+    (no host-side segment sums since round 5): blocks of 2^19 (Float64: 2^18) points -- fewer when one block holds the signal -- on the multi-pass engine
+    (bigfft.hip run_ols_rows: column pass, row kernel, column pass back), reported by mdsp_ols_plan_geometry.  Against the oracle (filt.jl:479-521), against an explicit rocFFT-engine plan at the
     reference's own block length (optimalfftfiltlength, dspbase.jl:268-291), several columns, signals shorter than the filter, conv, a block range
     (bit-identical to the whole-column call) and the host-pointer pipeline."""
     import ctypes as C
@@ -951,12 +951,14 @@ def test_filters_beyond_the_partitioned_range_stay_correct(d, torch, dt):
     plan = OlsPlan(b, d.optimalfftfiltlength(nb, nx), nx, _lib.OLS_FILT, d.ENGINE_AUTO)
     en, el, ep = C.c_int64(), C.c_int64(), C.c_int()
     _lib.check(lib.mdsp_ols_plan_geometry(plan._h, C.byref(en), C.byref(el), C.byref(ep)))
-    assert plan.engine == d.ENGINE_FUSED and (en.value, el.value, ep.value) == (1 << 20, (1 << 20) - nb + 1, 1)
-    # blocks [2, 3) of the same grid from a slice of the signal: what the host pipeline and a time-axis split over GPUs issue
+    nbig = 64 * (8192 if dt == np.float32 else 4096)     # the rows form: 64 rows of the longest single-workgroup transform while the filter is under a quarter of that
+    assert plan.engine == d.ENGINE_FUSED and (en.value, el.value, ep.value) == (nbig, nbig - nb + 1, 1)
+    # blocks [2, 4) of the same grid from a slice of the signal -- a whole pair: two real blocks share a transform -- as the host pipeline and a time-axis
+    # split over GPUs issue them: bit-identical to the whole-column call
     L = el.value
-    lo, hi = 2 * L - (nb - 1), min(nx, 3 * L)
+    lo, hi = 2 * L - (nb - 1), min(nx, 4 * L)
     ys = torch.full((hi - 2 * L,), float("nan"), dtype=xd.dtype, device="cuda")
-    _lib.check(lib.mdsp_ols_exec_range(plan._h, xd[lo:hi].data_ptr(), lo, hi - lo, nx, ys.data_ptr(), 2, 1, nx, torch.cuda.current_stream().cuda_stream))
+    _lib.check(lib.mdsp_ols_exec_range(plan._h, xd[lo:hi].data_ptr(), lo, hi - lo, nx, ys.data_ptr(), 2, 2, nx, torch.cuda.current_stream().cuda_stream))
     assert np.array_equal(ys.cpu().numpy(), got[2 * L:hi])
     # host arrays: the chunked H2D || kernels || D2H pipeline on the same plan geometry
     assert np.array_equal(plan.exec_host(x.reshape(1, -1), nx)[0], got)
@@ -977,7 +979,8 @@ def test_filters_beyond_the_partitioned_range_stay_correct(d, torch, dt):
 @pytest.mark.parametrize("dt", [np.complex64, np.complex128])
 def test_long_complex_filters_on_the_multipass_engine(d, torch, dt):
     """conv of complex signals with 20001 complex taps (one block per transform instead of two): against numpy's Float64 transform-domain product,
-    and 150000 real taps in Float32 -- the block grows to 2^21 points (eight times the filter)."""
+    and 150000 real taps in Float32 -- the block grows to 2^21 points (256 rows); MDSP_BIG_OLS_ROWS=0 (three passes each way on natural-order spectra, what filters
+    beyond 2^19 taps take) gives the same convolution."""
     rng = np.random.default_rng(20001)
     nb, nx = 20001, 1_300_017
     b = ((rng.standard_normal(nb) + 1j * rng.standard_normal(nb)) / np.sqrt(nb)).astype(dt)
@@ -1002,6 +1005,16 @@ def test_long_complex_filters_on_the_multipass_engine(d, torch, dt):
         en = C.c_int64()
         _lib.check(_lib.lib().mdsp_ols_plan_geometry(plan._h, C.byref(en), None, None))
         assert en.value == 1 << 21
+        try:
+            _lib.set_tunable("MDSP_BIG_OLS_ROWS", 0)
+            p3 = OlsPlan(h[:40_000].copy(), d.optimalfftfiltlength(40_000, len(xr)), len(xr), _lib.OLS_FILT, d.ENGINE_FUSED)
+            _lib.check(_lib.lib().mdsp_ols_plan_geometry(p3._h, C.byref(en), None, None))
+            assert en.value == 1 << 20
+            y3 = p3.exec(torch.from_numpy(xr).cuda().reshape(1, -1), len(xr)).cpu().numpy()[0]
+        finally:
+            _lib.set_tunable("MDSP_BIG_OLS_ROWS", None)
+        r3 = np.fft.irfft(np.fft.rfft(xr.astype(np.float64), nf) * np.fft.rfft(h[:40_000].astype(np.float64), nf), nf)[:len(xr)]
+        assert relerr(y3, r3) < TOL32
 
 
 def test_welch_hand_allocated_kernel_several_channels(d, torch):
