@@ -77,6 +77,7 @@ static void read_tunables_locked() {
     t.big_fast = geti("MDSP_BIG_FAST", 1);
     t.big_ols_log2n = geti("MDSP_BIG_OLS_LOG2N", 0);
     t.big_ols_rows = geti("MDSP_BIG_OLS_ROWS", 1);
+    t.big_welch_rows = geti("MDSP_BIG_WELCH_ROWS", 1);
     t.fir_p = geti("MDSP_FIR_P", 0);
     t.fir_mm = geti("MDSP_FIR_MM", -1);
     t.fir_exact = geti("MDSP_FIR_EXACT", 0);

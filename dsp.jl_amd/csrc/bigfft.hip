@@ -22,6 +22,7 @@
 
 #include "bigfft.h"
 #include "bigfft_plan.h"
+#include "welch_plan.h"
 
 using namespace mdsp;
 using mdsp::fft::cx;
@@ -30,6 +31,8 @@ namespace mdsp {
 // ols.hip: the row kernel of the long-filter convolution and the root table of its transforms
 int ols_rows(int dbl, void* work, int64_t rows, int hrows, const void* Hrows, const void* table, const void* rt0, const void* rt1, int rlogS, hipStream_t st);
 int ols_rows_table(int dbl, DevBuf& buf);
+// spectral.hip: |FFT_S|^2 of `nch` rows, K frames `hop` apart, summed into the row plan's Float64 accumulator
+int welch_rows_accumulate(mdsp_welch_plan_s* pl, const void* work, int64_t K, int64_t hop, int64_t nch, hipStream_t st);
 namespace big {
 
 struct Engine {
@@ -44,6 +47,10 @@ struct Engine {
     int rowsR0 = 0;
     Pass inv0;
     DevBuf rowtab;                     // the S forward roots of the row transforms (ols.hip)
+    mdsp_welch_plan rowplan = nullptr; // Welch, rows form: the S-point complex plan whose single-workgroup kernel sums |Z|^2 over the rows (spectral.hip)
+    ~Engine() {
+        if (rowplan) mdsp_welch_plan_destroy(rowplan);
+    }
 };
 EngineHolder::~EngineHolder() { delete p; }
 
@@ -526,15 +533,15 @@ template <typename R> int build_rows(Engine* e, int R0) {
     return ols_rows_table(sizeof(R) == 8, e->rowtab);
 }
 
-int get_engine_rows(EngineHolder& h, int dtype, int64_t nfft, int R0, Engine** out) {
-    if (h.p && (h.p->dtype != dtype || h.p->rowsR0 != R0 || h.p->nfft != nfft)) {
+int get_engine_rows(EngineHolder& h, int dtype, int64_t n, int64_t nfft, int R0, Engine** out) {
+    if (h.p && (h.p->dtype != dtype || h.p->n != n || h.p->rowsR0 != R0 || h.p->nfft != nfft)) {
         delete h.p;
         h.p = nullptr;
     }
     if (!h.p) {
         std::unique_ptr<Engine> e(new Engine());
         e->dtype = dtype;
-        e->n = 0;
+        e->n = n;
         e->nfft = nfft;
         MDSP_TRY(dtype_is_double(dtype) ? build_rows<double>(e.get(), R0) : build_rows<float>(e.get(), R0));
         h.p = e.release();
@@ -778,15 +785,89 @@ template <typename R> int run_ols_rows(Engine* e, bool cplx, const void* x, int6
     return MDSP_OK;
 }
 
+// acc[k1 + R0 k2] (+)= red[k1 S + k2]: the rows' sums into the natural-order accumulator, 32 x 32 tiles through LDS (256-byte runs on both sides)
+__global__ __launch_bounds__(256) void big_rows_to_natural_kernel(const double* __restrict__ red, double* __restrict__ acc, int R0, int64_t S, int add) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t k2_0 = (int64_t)blockIdx.x * 32;
+    const int k1_0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[ty + 8 * j][tx] = red[(int64_t)(k1_0 + ty + 8 * j) * S + k2_0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t o = (int64_t)(k1_0 + tx) + (int64_t)R0 * (k2_0 + ty + 8 * j);
+        const double v = tile[tx][ty + 8 * j];
+        acc[o] = add ? acc[o] + v : v;
+    }
+}
+
+// Welch in the rows form: nfft = R0 x S.  The column pass reads the windowed frames (two real frames per transform) and leaves the twiddled columns in the
+// work buffer; the rows are then complex frames of S points, R0 channels of them, K transforms `nfft` elements apart, for the single-workgroup Welch
+// kernel (spectral.hip): two trips through HBM per transform instead of three, and no natural-order pass -- |Z|^2 is summed row-major and transposed once.
+template <typename R, bool CPLX>
+int run_welch_rows(Engine* e, const void* s, int64_t K, int64_t hop, const double* win_dev, double* acc, bool fresh, hipStream_t st) {
+    const int64_t N = e->nfft, S = N / e->rowsR0;
+    const int64_t units = CPLX ? K : cdiv(K, 2);
+    if (units == 0) return MDSP_OK;
+    const R* win = nullptr;
+    if (win_dev) {
+        if constexpr (sizeof(R) == 8) win = reinterpret_cast<const R*>(win_dev);
+        else {
+            if (e->win_src != win_dev) {
+                MDSP_TRY(e->winR.reserve(sizeof(R) * (size_t)e->n));
+                hipLaunchKernelGGL(big_window_kernel<R>, dim3((unsigned)cdiv(e->n, 256)), dim3(256), 0, st, win_dev, e->winR.as<R>(), e->n);
+                MDSP_LAUNCH_CHECK();
+                e->win_src = win_dev;
+            }
+            win = e->winR.as<R>();
+        }
+    }
+    if (!e->rowplan) {
+        const int cd = sizeof(R) == 8 ? MDSP_C64 : MDSP_C32;
+        MDSP_TRY(mdsp_welch_plan_create(&e->rowplan, S, 0, S, nullptr, 1.0, 0, cd, MDSP_ENGINE_FUSED));
+    }
+    MDSP_TRY(mdsp_welch_reset(e->rowplan));
+    const int64_t per = (int64_t)sizeof(cx<R>) * N;
+    const int64_t C = std::max<int64_t>(1, std::min<int64_t>(units, ((int64_t)tunables().big_chunk_mib << 20) / per));
+    MDSP_TRY(e->work.reserve((size_t)(per * C)));
+    const int cus = device_cu_count();
+    for (int64_t c0 = 0; c0 < units; c0 += C) {
+        const int64_t cnt = std::min<int64_t>(C, units - c0);
+        BigArgs<R> a{};
+        a.p = e->pass[0];
+        a.in_mode = CPLX ? 2 : 1;
+        a.s = s;
+        a.win = win;
+        a.buf = e->work.as<cx<R>>();
+        a.t0 = c0;
+        a.ntrans = cnt;
+        a.K = K;
+        a.hop = hop;
+        a.n = (int)e->n;
+        a.ablate = tunables().big_ablate;
+        const int64_t wgs = (int64_t)cus * (tunables().big_wgs > 0 ? tunables().big_wgs : (a.p.fTJ && a.p.Rp <= 64 ? 4 : 2));
+        int groups = tunables().big_groups > 0 ? tunables().big_groups : (int)cdiv(wgs, a.p.ntiles);
+        groups = (int)std::max<int64_t>(1, std::min<int64_t>(groups, cnt));
+        const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(a.p.ntiles, wgs / groups));
+        MDSP_TRY((launch_pass<R, 0>(a, lanes, groups, st)));
+        MDSP_TRY(welch_rows_accumulate(e->rowplan, e->work.p, cnt, N, e->rowsR0, st));
+    }
+    hipLaunchKernelGGL(big_rows_to_natural_kernel, dim3((unsigned)(S / 32), (unsigned)(e->rowsR0 / 32)), dim3(256), 0, st, e->rowplan->reduced.as<double>(), acc, e->rowsR0, S,
+                       fresh ? 0 : 1);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+
 }  // namespace
 
-int ols_rows_r0(int dtype, int64_t N) {
-    if (tunables().big_ols_rows == 0) return 0;
+static int rows_r0(int dtype, int64_t N) {
     const int64_t S = dtype_is_double(dtype) ? 4096 : 8192;
     if (N % S) return 0;
     const int64_t r = N / S;
     return (r == 32 || r == 64 || r == 128 || r == 256) ? (int)r : 0;
 }
+int ols_rows_r0(int dtype, int64_t N) { return tunables().big_ols_rows == 0 ? 0 : rows_r0(dtype, N); }
 
 int64_t ols_size(int dtype, int64_t nb, int64_t nout_hint) {
     if (!tunables().bigfft || nb < 2) return 0;
@@ -817,7 +898,7 @@ int64_t ols_size(int dtype, int64_t nb, int64_t nout_hint) {
 int ols(EngineHolder& h, int dtype, int64_t N, int R0, const void* x, int64_t nx, const void* H, int64_t nb, void* y, int64_t nout, int64_t g0, int64_t g1, hipStream_t st) {
     Engine* e = nullptr;
     if (R0) {
-        MDSP_TRY(get_engine_rows(h, dtype, N, R0, &e));
+        MDSP_TRY(get_engine_rows(h, dtype, 0, N, R0, &e));
         const bool cplx = dtype_is_complex(dtype);
         return dtype_is_double(dtype) ? run_ols_rows<double>(e, cplx, x, nx, H, nb, y, nout, g0, g1, st) : run_ols_rows<float>(e, cplx, x, nx, H, nb, y, nout, g0, g1, st);
     }
@@ -839,12 +920,22 @@ bool size_ok(int dtype, int64_t nfft) {
 int welch(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, int64_t K, int64_t hop, const double* win_dev, double* acc, bool fresh,
           hipStream_t st) {
     Engine* e = nullptr;
-    MDSP_TRY(get_engine(h, dtype, n, nfft, &e));
     const bool cplx = dtype_is_complex(dtype), dbl = dtype_is_double(dtype);
     if (K == 0) {
         if (fresh) MDSP_HIP(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nfft, st));
         return MDSP_OK;
     }
+    // nfft = R0 x S, R0 = 32 .. 256: column pass + the single-workgroup Welch kernel over the rows.  Measured against three passes (profiles/r05_welch_rows.json):
+    // 255 .. 2047 frames of a 2^27-sample stream 1.14 - 1.92x faster except Float32 at R0 = 128 (0.99x: the 128-point column pass, 8 x 16, keeps half of its
+    // threads for the second stage), the 15 frames of the default call 0.9 - 1.3x.  MDSP_BIG_WELCH_ROWS=2 takes it at R0 = 128 too.
+    int R0w = tunables().big_welch_rows ? rows_r0(dtype, nfft) : 0;
+    if (R0w == 128 && !dbl && tunables().big_welch_rows != 2) R0w = 0;
+    if (const int R0 = R0w) {
+        MDSP_TRY(get_engine_rows(h, dtype, n, nfft, R0, &e));
+        if (cplx) return dbl ? run_welch_rows<double, true>(e, s, K, hop, win_dev, acc, fresh, st) : run_welch_rows<float, true>(e, s, K, hop, win_dev, acc, fresh, st);
+        return dbl ? run_welch_rows<double, false>(e, s, K, hop, win_dev, acc, fresh, st) : run_welch_rows<float, false>(e, s, K, hop, win_dev, acc, fresh, st);
+    }
+    MDSP_TRY(get_engine(h, dtype, n, nfft, &e));
     if (cplx) return dbl ? run<double, true>(e, 0, s, K, hop, win_dev, acc, fresh, nullptr, 0, 0, 0, 0, 0, 1.0, st)
                          : run<float, true>(e, 0, s, K, hop, win_dev, acc, fresh, nullptr, 0, 0, 0, 0, 0, 1.0, st);
     return dbl ? run<double, false>(e, 0, s, K, hop, win_dev, acc, fresh, nullptr, 0, 0, 0, 0, 0, 1.0, st)

@@ -1721,6 +1721,32 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
 
 }  // namespace
 
+namespace mdsp {
+// Welch in the rows form of the multi-pass engine (bigfft.hip run_welch_rows): `nch` rows of S = pl->nfft complex points, K frames `hop` elements apart
+// (the rows of K transforms of nch x S points, column pass done) -> pl->reduced[row][bin] (+)= |FFT_S(frame)|^2 on the single-workgroup kernels.
+// pl: a complex, two-sided, window-free FUSED plan of S points (n = nfft = S).
+int welch_rows_accumulate(mdsp_welch_plan_s* pl, const void* work, int64_t K, int64_t hop, int64_t nch, hipStream_t st) {
+    if (K <= 0 || nch <= 0) return MDSP_OK;
+    SpecArgs a{};
+    a.s = work;
+    a.table = pl->table.p;
+    a.win = nullptr;
+    a.len = (K - 1) * hop + pl->n;
+    a.lds_ = pl->n;
+    a.K = K;
+    a.hop = hop;
+    a.units_per_ch = K;
+    a.nch = nch;
+    a.n = (int)pl->n;
+    a.nout = (int)pl->nout;
+    a.onesided = 0;
+    a.r = 1.0;
+    if (pl->dtype == MDSP_C32 && pl->nfft == 8192) return welch_launch_n<float, 8192, true>(pl, a, st);
+    if (pl->dtype == MDSP_C64 && pl->nfft == 4096) return welch_launch_n<double, 4096, true>(pl, a, st);
+    MDSP_FAIL(MDSP_ERR_ASSERTION, "rows of %lld points of dtype %d", (long long)pl->nfft, pl->dtype);
+}
+}  // namespace mdsp
+
 extern "C" {
 
 int mdsp_welch_plan_create(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, int64_t nfft, const double* window_host, double r, int onesided,

@@ -54,7 +54,9 @@ CASES = (  # n, noverlap, nfft, window, frames
     (100000, 50000, 125000, "hamming", 3),    # zero-padded to 2^3 5^6 = 250 x 500 (what welch_pgram(randn(10^6)) asks for is n = nfft = 125000)
     (12500, 0, 12500, None, 9),               # 100 x 125, no window, no overlap
     (30375, 30000, 30375, "hanning", 6),      # odd transform (3^5 5^3 = 135 x 225): partial tiles in every pass, hop of 375 samples
-    (262144, 131072, 524288, "hanning", 3),   # three passes (64 x 64 x 128), zero-padded
+    (262144, 131072, 524288, "hanning", 3),   # zero-padded; Welch: the rows form (64 x 8192, Float64 128 x 4096: column pass + single-workgroup Welch kernel over
+                                              # the rows), columns: three passes (64 x 64 x 128)
+    (200000, 100000, 262144, "hamming", 5),   # Welch rows form with 32 (Float64: 64) rows, odd frame count
 )
 
 
