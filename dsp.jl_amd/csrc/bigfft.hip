@@ -268,13 +268,13 @@ __global__ __launch_bounds__(TPB, (sizeof(R) == 4 ? 2 : 1)) void big_fast_kernel
     cx<R>* twc1 = twc0 + G::Rp;
     const int tid = threadIdx.x;
     const int64_t N = p.N;
-    cx<R> rt[TJ], twb[TJ];
+    cx<R> rt[G::NO], twb[G::NO];
     fast_roots<R, RA, TJ>(p, tid, rt);
     if (!p.last) fast_twb<R, RA, TJ>(p, tid, twb);
-    [[maybe_unused]] double acc[WELCH ? TJ : 1];
+    [[maybe_unused]] double acc[WELCH ? G::NO : 1];
     if constexpr (WELCH) {
 #pragma unroll
-        for (int e = 0; e < TJ; ++e) acc[e] = 0.0;
+        for (int e = 0; e < G::NO; ++e) acc[e] = 0.0;
     }
     cx<R> pre[RA];
     // MDSP_BIG_ABLATE (profiling; garbage results): 1 no butterflies, 2 no stores, 4 no loads after the first item, 8 no tile twiddles,
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(TPB, (sizeof(R) == 4 ? 2 : 1)) void big_fast_kernel
         fast_stage1<R, RA, TJ>(tid, pre, X);
         if (nhave && !(a.ablate & 4)) fetch(ntile, nt);   // the next item's samples take over the registers stage 1 has just emptied: in flight through the barrier, stage 2 and the stores
         __syncthreads();
-        cx<R> y[TJ];
+        cx<R> y[G::NO];
         fast_stage2<R, RA, TJ>(tid, X, rt, y);
         if (a.ablate & 2) {
         } else if constexpr (WELCH) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
@@ -423,9 +423,9 @@ __global__ __launch_bounds__(TPB, (sizeof(R) == 4 ? 2 : 1)) void big_fast_kernel
         if (blockIdx.x < p.ntiles) {
             const Tile tc = tile_of_b<R>(p, (int64_t)blockIdx.x, G::B);
             double* row = static_cast<double*>(a.out) + (int64_t)blockIdx.y * N;
-            cx<R> y[TJ];
+            cx<R> y[G::NO];
 #pragma unroll
-            for (int e = 0; e < TJ; ++e) y[e] = {(R)0, (R)0};
+            for (int e = 0; e < G::NO; ++e) y[e] = {(R)0, (R)0};
             fast_store<R, RA, TJ>(p, tc, tid, y, twc0, twb, [&](int e, int64_t k, cx<R>) { row[k] = a.acc_add ? row[k] + acc[e] : acc[e]; });
         }
     }
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void big_untangle_kernel(const cx<R>* __restri
 
 template <typename R> int build(Engine* e) {
     HostPlan<R> hp;
-    if (!make_plan<R>(e->nfft, hp, tunables().big_rmax, tunables().big_fast != 0)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%lld does not split into 2..4 factors of at most %d", (long long)e->nfft, RMAX);
+    if (!make_plan<R>(e->nfft, hp, tunables().big_rmax, tunables().big_fast)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%lld does not split into 2..4 factors of at most %d", (long long)e->nfft, RMAX);
     size_t total = 0;
     auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
     for (int p = 0; p < hp.P; ++p) total += al(hp.roots[p].size()) + al(hp.T0[p].size()) + al(hp.T1[p].size());
@@ -511,7 +511,7 @@ template <typename R> int build(Engine* e) {
 template <typename R> int build_rows(Engine* e, int R0) {
     HostPlan<R> hp;
     const int Rf[2] = {R0, (int)(e->nfft / R0)};
-    if (!make_plan_factors<R>(e->nfft, hp, Rf, 2, tunables().big_fast != 0, true)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "no column pass of %d points", R0);
+    if (!make_plan_factors<R>(e->nfft, hp, Rf, 2, tunables().big_fast, true)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "no column pass of %d points", R0);
     auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t nr = al(hp.roots[0].size()), n0 = al(hp.T0[0].size()), n1 = al(hp.T1[0].size());
     std::vector<cx<R>> all(nr + 2 * (n0 + n1), cx<R>{(R)1, (R)0});
@@ -593,6 +593,10 @@ template <typename R, int OUT> int launch_pass(const BigArgs<R>& a0, int lanes, 
         BigArgs<R> a = a0;
         a.out_mode = OUT;
         constexpr bool W = OUT == 1;
+        if (a.p.fRA == 16 && a.p.fTJ == 8) {
+            if constexpr (sizeof(R) == 4) return launch_fast<R, W, 16, 8>(a, lanes, groups, st);
+            else MDSP_FAIL(MDSP_ERR_ASSERTION, "the 16 x 8 form is Float32 only");
+        }
         if (a.p.fRA == 16) return launch_fast<R, W, 16, 16>(a, lanes, groups, st);
         if (a.p.fRA == 8 && a.p.fTJ == 16) return launch_fast<R, W, 8, 16>(a, lanes, groups, st);
         if (a.p.fRA == 8) return launch_fast<R, W, 8, 8>(a, lanes, groups, st);
@@ -652,7 +656,9 @@ int run(Engine* e, int mode, const void* s, int64_t K, int64_t hop, const double
             a.m1 = (R)(1.0 / r);
             a.ablate = tunables().big_ablate;
             // workgroups: `wgs` per CU resident (two fit: LDS), each walking several (tile, transform) items with the next one's samples in flight
-            const int64_t wgs = (int64_t)cus * (tunables().big_wgs > 0 ? tunables().big_wgs : ((a.p.Rp > RMAX / 2 || (a.p.fTJ && sizeof(R) == 8)) ? 1 : (a.p.fTJ && a.p.Rp <= 64 ? 4 : 2)));
+            // (Float64 two-stage passes: one, but two for the 64-point pass -- Welch at 2^22 points 0.30 -> 0.38 TB/s, profiles/r05_bigfft_sessions.json "f64_wgs")
+            const int64_t wgs = (int64_t)cus * (tunables().big_wgs > 0 ? tunables().big_wgs
+                                                : (a.p.Rp > RMAX / 2 ? 1 : (a.p.fTJ && sizeof(R) == 8) ? (a.p.Rp <= 64 ? 2 : 1) : (a.p.fTJ && a.p.Rp <= 64 ? 4 : 2)));
             int groups = tunables().big_groups > 0 ? tunables().big_groups : (int)cdiv(wgs, a.p.ntiles);
             groups = (int)std::max<int64_t>(1, std::min<int64_t>(groups, cnt));
             const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(a.p.ntiles, wgs / groups));
@@ -926,10 +932,9 @@ int welch(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, in
         return MDSP_OK;
     }
     // nfft = R0 x S, R0 = 32 .. 256: column pass + the single-workgroup Welch kernel over the rows.  Measured against three passes (profiles/r05_welch_rows.json):
-    // 255 .. 2047 frames of a 2^27-sample stream 1.14 - 1.92x faster except Float32 at R0 = 128 (0.99x: the 128-point column pass, 8 x 16, keeps half of its
-    // threads for the second stage), the 15 frames of the default call 0.9 - 1.3x.  MDSP_BIG_WELCH_ROWS=2 takes it at R0 = 128 too.
-    int R0w = tunables().big_welch_rows ? rows_r0(dtype, nfft) : 0;
-    if (R0w == 128 && !dbl && tunables().big_welch_rows != 2) R0w = 0;
+    // 255 .. 2047 frames of a 2^27-sample stream 1.14 - 1.92x faster (Float32 at R0 = 128: 0.99x with the 8 x 16 column pass, 1.17x with the 16 x 8 one that
+    // replaced it), the 15 frames of the default call 0.9 - 1.3x.
+    const int R0w = tunables().big_welch_rows ? rows_r0(dtype, nfft) : 0;
     if (const int R0 = R0w) {
         MDSP_TRY(get_engine_rows(h, dtype, n, nfft, R0, &e));
         if (cplx) return dbl ? run_welch_rows<double, true>(e, s, K, hop, win_dev, acc, fresh, st) : run_welch_rows<float, true>(e, s, K, hop, win_dev, acc, fresh, st);

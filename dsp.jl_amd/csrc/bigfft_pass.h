@@ -225,9 +225,13 @@ MDSP_HD void phase_store(const Pass& p, const Tile& t, int tid, const cx<R>* lds
 //     (loop-invariant per thread) and runs butterfly tj of the second stage (radix TJ): it now holds rows tj + RA q' in natural order, which
 //     leave for memory from registers with the inter-pass twiddle applied.
 // The last pass reads its runs coalesced along the run, so its elements take one extra trip through LDS to reach the owner of their row.
+// RA > TJ (128 = 16 x 8, Float32): a thread runs NS2 = RA / TJ second-stage butterflies, tj + TJ s -- every thread busy in both stages and tiles of
+// 256 / 8 = 32 columns; the 8 x 16 form of the same pass keeps half of its threads for the second stage and has 16-column tiles (the slowest column
+// pass of every table in profiles/r05_big_ols.json).  NO: a thread's results, NS2 x TJ.
 template <int RA, int TJ> struct FastGeo {
     static constexpr int Rp = RA * TJ, B = TPB / TJ, Bp = B + 1;
-    static_assert(TPB % TJ == 0 && RA <= TJ, "stage 2 runs on the first RA threads of a column");
+    static constexpr int NS2 = RA > TJ ? RA / TJ : 1, NO = NS2 * TJ;
+    static_assert(TPB % TJ == 0 && (RA <= TJ || RA % TJ == 0), "stage 2 runs on the first RA threads of a column, or every thread runs RA / TJ butterflies");
 };
 
 template <typename R> MDSP_HD Tile tile_of_b(const Pass& p, int64_t tile, int B) {
@@ -300,46 +304,66 @@ template <typename R, int RA, int TJ> MDSP_HD void fast_stage1(int tid, cx<R> (&
 #pragma unroll
     for (int q = 0; q < RA; ++q) fft::st2(lds + (tj * RA + q) * G::Bp + b, v[q]);
 }
-// the thread's loop-invariant second-stage twiddles W_{R_p}^{q tj}, q = 1 .. TJ - 1 (rt[0] unused)
-template <typename R, int RA, int TJ> MDSP_HD void fast_roots(const Pass& p, int tid, cx<R> (&rt)[TJ]) {
+// the thread's loop-invariant second-stage twiddles W_{R_p}^{q tj2}, q = 1 .. TJ - 1 (entry 0 of every butterfly unused)
+template <typename R, int RA, int TJ> MDSP_HD void fast_roots(const Pass& p, int tid, cx<R> (&rt)[FastGeo<RA, TJ>::NO]) {
     using G = FastGeo<RA, TJ>;
     const int tj = tid / G::B;
     const cx<R>* roots = static_cast<const cx<R>*>(p.roots);
 #pragma unroll
-    for (int q = 0; q < TJ; ++q) rt[q] = roots[tj < RA ? (q * tj) % G::Rp : 0];
+    for (int s = 0; s < G::NS2; ++s) {
+        const int tj2 = tj + TJ * s;
+#pragma unroll
+        for (int q = 0; q < TJ; ++q) rt[s * TJ + q] = roots[tj2 < RA ? (q * tj2) % G::Rp : 0];
+    }
 }
-// stage 2 (threads tj < RA): rows tj + RA q from LDS, twiddles, butterfly tj (radix TJ): y[q'] = row tj + RA q' of the sub-transform
-template <typename R, int RA, int TJ> MDSP_HD void fast_stage2(int tid, const cx<R>* lds, const cx<R> (&rt)[TJ], cx<R> (&y)[TJ]) {
+// stage 2 (butterflies tj2 = tj + TJ s < RA): rows tj2 + RA q from LDS, twiddles, radix TJ: y[s TJ + q'] = row tj2 + RA q' of the sub-transform
+template <typename R, int RA, int TJ> MDSP_HD void fast_stage2(int tid, const cx<R>* lds, const cx<R> (&rt)[FastGeo<RA, TJ>::NO], cx<R> (&y)[FastGeo<RA, TJ>::NO]) {
     using G = FastGeo<RA, TJ>;
     const int b = tid % G::B, tj = tid / G::B;
-    if (tj >= RA) return;
 #pragma unroll
-    for (int q = 0; q < TJ; ++q) y[q] = fft::ld2(lds + (tj + RA * q) * G::Bp + b);
+    for (int s = 0; s < G::NS2; ++s) {
+        const int tj2 = tj + TJ * s;
+        if (tj2 >= RA) return;
+        cx<R> z[TJ];
 #pragma unroll
-    for (int q = 1; q < TJ; ++q) y[q] = fft::cmul(y[q], rt[q]);
-    fft::gen_bfly<TJ>(y);
+        for (int q = 0; q < TJ; ++q) z[q] = fft::ld2(lds + (tj2 + RA * q) * G::Bp + b);
+#pragma unroll
+        for (int q = 1; q < TJ; ++q) z[q] = fft::cmul(z[q], rt[s * TJ + q]);
+        fft::gen_bfly<TJ>(z);
+#pragma unroll
+        for (int q = 0; q < TJ; ++q) y[s * TJ + q] = z[q];
+    }
 }
-// W_{N_p}^{b r} for the thread's output rows r = tj + RA e
-template <typename R, int RA, int TJ> MDSP_HD void fast_twb(const Pass& p, int tid, cx<R> (&twb)[TJ]) {
+// W_{N_p}^{b r} for the thread's output rows r = tj2 + RA e
+template <typename R, int RA, int TJ> MDSP_HD void fast_twb(const Pass& p, int tid, cx<R> (&twb)[FastGeo<RA, TJ>::NO]) {
     using G = FastGeo<RA, TJ>;
     const unsigned b = (unsigned)(tid % G::B), tj = (unsigned)(tid / G::B);
 #pragma unroll
-    for (int e = 0; e < TJ; ++e) twb[e] = big_root<R>(p, tj < (unsigned)RA ? b * (tj + RA * e) : 0u);
+    for (int s = 0; s < G::NS2; ++s) {
+        const unsigned tj2 = tj + (unsigned)(TJ * s);
+#pragma unroll
+        for (int e = 0; e < TJ; ++e) twb[s * TJ + e] = big_root<R>(p, tj2 < (unsigned)RA ? b * (tj2 + RA * e) : 0u);
+    }
 }
-// results out of registers: put(e, pos or k, z) as phase_store
+// results out of registers: put(e, pos or k, z) as phase_store (e < NO: s TJ + e')
 template <typename R, int RA, int TJ, typename F>
-MDSP_HD void fast_store(const Pass& p, const Tile& t, int tid, const cx<R> (&y)[TJ], const cx<R>* twc, const cx<R> (&twb)[TJ], F&& put) {
+MDSP_HD void fast_store(const Pass& p, const Tile& t, int tid, const cx<R> (&y)[FastGeo<RA, TJ>::NO], const cx<R>* twc, const cx<R> (&twb)[FastGeo<RA, TJ>::NO], F&& put) {
     using G = FastGeo<RA, TJ>;
     const int b = tid % G::B, tj = tid / G::B;
-    if (tj >= RA || b >= t.ncols) return;
+    if (b >= t.ncols) return;
     const int64_t rs = p.last ? p.N / p.Rp : t.row_stride;
     const int64_t o0 = p.last ? t.c0 + b + t.nat : t.base + b;
 #pragma unroll
-    for (int e = 0; e < TJ; ++e) {
-        const int r = tj + RA * e;
-        cx<R> z = y[e];
-        if (!p.last) z = fft::cmul(z, fft::cmul(fft::ld2(twc + r), twb[e]));
-        put(e, o0 + (int64_t)r * rs, z);
+    for (int s = 0; s < G::NS2; ++s) {
+        const int tj2 = tj + TJ * s;
+        if (tj2 >= RA) return;
+#pragma unroll
+        for (int e = 0; e < TJ; ++e) {
+            const int r = tj2 + RA * e;
+            cx<R> z = y[s * TJ + e];
+            if (!p.last) z = fft::cmul(z, fft::cmul(fft::ld2(twc + r), twb[s * TJ + e]));
+            put(s * TJ + e, o0 + (int64_t)r * rs, z);
+        }
     }
 }
 

@@ -141,16 +141,17 @@ template <typename R> struct HostPlan {
 // false: N cannot be planned (a prime factor above 7, or a factor that no schedule covers)
 // first_only: the factors are (R_0, N / R_0) and only pass 0 is built -- the rows of N / R_0 points belong to somebody else (overlap-save: the
 // single-workgroup transforms of ols.hip)
-template <typename R> bool make_plan_factors(int64_t N, HostPlan<R>& hp, const int* Rf, int P, bool fast, bool first_only = false);
-template <typename R> bool make_plan(int64_t N, HostPlan<R>& hp, int rmax = RMAX, bool fast = true) {
+template <typename R> bool make_plan_factors(int64_t N, HostPlan<R>& hp, const int* Rf, int P, int fast, bool first_only = false);
+template <typename R> bool make_plan(int64_t N, HostPlan<R>& hp, int rmax = RMAX, int fast = 1) {   // fast: 0 generic phases, 1 two-stage forms, 2 the same with 128 = 8 x 16 in Float32 too
     if (N < 4 || N >= ((int64_t)1 << 31) || !seven_smooth(N)) return false;
     int Rf[MAXP];
     const int P = factorise(N, Rf, rmax);
     if (P < 2) return false;
     return make_plan_factors<R>(N, hp, Rf, P, fast);
 }
-template <typename R> bool make_plan_factors(int64_t N, HostPlan<R>& hp, const int* Rf, int P, bool fast, bool first_only) {
+template <typename R> bool make_plan_factors(int64_t N, HostPlan<R>& hp, const int* Rf, int P, int fast, bool first_only) {
     constexpr bool dbl = sizeof(R) == 8;
+    const int fast128 = fast == 2 ? 816 : 168;
     hp.N = N;
     hp.P = P;
     hp.roots.assign(P, {});
@@ -175,6 +176,7 @@ template <typename R> bool make_plan_factors(int64_t N, HostPlan<R>& hp, const i
         q.fRA = q.fTJ = 0;
         if (fast) {
             if (q.Rp == 256) q.fRA = 16, q.fTJ = 16;
+            else if (q.Rp == 128 && !dbl && fast128 == 168) q.fRA = 16, q.fTJ = 8;   // Float32: every thread busy in both stages, 32-column tiles (bigfft_pass.h FastGeo)
             else if (q.Rp == 128) q.fRA = 8, q.fTJ = 16;
             else if (q.Rp == 64) q.fRA = 8, q.fTJ = 8;
             else if (q.Rp == 32) q.fRA = 4, q.fTJ = 8;

@@ -20,11 +20,11 @@ void fast_tile(const Pass& q, int64_t tile, std::vector<cx<R>>& buf, std::vector
     const Tile t = tile_of_b<R>(q, tile, G::B);
     std::vector<cx<R>> lds((size_t)G::Rp * G::Bp), stage((size_t)G::Rp * G::Bp), twc((size_t)G::Rp);
     std::vector<std::array<cx<R>, RA>> x(TPB);
-    std::vector<std::array<cx<R>, TJ>> y(TPB), rt(TPB), twb(TPB);
+    std::vector<std::array<cx<R>, G::NO>> y(TPB), rt(TPB), twb(TPB);
 #define ARR(T, n, a) reinterpret_cast<T(&)[n]>(*(a).data())
     for (int tid = 0; tid < TPB; ++tid) {
-        fast_roots<R, RA, TJ>(q, tid, ARR(cx<R>, TJ, rt[tid]));
-        if (!q.last) fast_twb<R, RA, TJ>(q, tid, ARR(cx<R>, TJ, twb[tid]));
+        fast_roots<R, RA, TJ>(q, tid, ARR(cx<R>, G::NO, rt[tid]));
+        if (!q.last) fast_twb<R, RA, TJ>(q, tid, ARR(cx<R>, G::NO, twb[tid]));
         fast_load<R, RA, TJ>(q, t, tid, ARR(cx<R>, RA, x[tid]), [&](int64_t pos) { return buf[(size_t)pos]; });
     }
     if (q.last) {
@@ -33,9 +33,9 @@ void fast_tile(const Pass& q, int64_t tile, std::vector<cx<R>>& buf, std::vector
     } else
         for (int tid = 0; tid < TPB; ++tid) fill_twc<R>(q, t, tid, twc.data());
     for (int tid = 0; tid < TPB; ++tid) fast_stage1<R, RA, TJ>(tid, ARR(cx<R>, RA, x[tid]), lds.data());
-    for (int tid = 0; tid < TPB; ++tid) fast_stage2<R, RA, TJ>(tid, lds.data(), ARR(const cx<R>, TJ, rt[tid]), ARR(cx<R>, TJ, y[tid]));
+    for (int tid = 0; tid < TPB; ++tid) fast_stage2<R, RA, TJ>(tid, lds.data(), ARR(const cx<R>, G::NO, rt[tid]), ARR(cx<R>, G::NO, y[tid]));
     for (int tid = 0; tid < TPB; ++tid)
-        fast_store<R, RA, TJ>(q, t, tid, ARR(const cx<R>, TJ, y[tid]), twc.data(), ARR(const cx<R>, TJ, twb[tid]), [&](int, int64_t pos, cx<R> z) {
+        fast_store<R, RA, TJ>(q, t, tid, ARR(const cx<R>, G::NO, y[tid]), twc.data(), ARR(const cx<R>, G::NO, twb[tid]), [&](int, int64_t pos, cx<R> z) {
             if (pos < 0 || pos >= N) {
                 std::printf(" index %lld out of range (two-stage form)\n", (long long)pos);
                 std::exit(1);
@@ -78,7 +78,8 @@ template <typename R> double run(int64_t N, int rmax, bool verbose, bool fast = 
         q.T1 = hp.T1[p].data();
         if (q.fTJ) {
             for (int64_t tile = 0; tile < q.ntiles; ++tile) {
-                if (q.fRA == 16) fast_tile<R, 16, 16>(q, tile, buf, out, N);
+                if (q.fRA == 16 && q.fTJ == 8) fast_tile<R, 16, 8>(q, tile, buf, out, N);
+                else if (q.fRA == 16) fast_tile<R, 16, 16>(q, tile, buf, out, N);
                 else if (q.fRA == 8 && q.fTJ == 16) fast_tile<R, 8, 16>(q, tile, buf, out, N);
                 else if (q.fRA == 8) fast_tile<R, 8, 8>(q, tile, buf, out, N);
                 else fast_tile<R, 4, 8>(q, tile, buf, out, N);
