@@ -242,7 +242,7 @@ class Marks:
             "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64",
             # round 5
             "decim16_f32", "resample_441_160_c64", "welch_default", "welch_default_2p24", "spectrogram_default", "filt_32768", "filt_f64", "welch_f64",
-            "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt")
+            "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt", "welch_2p19")
 
     def __init__(self, lib, _lib, stream):
         import torch
@@ -290,6 +290,7 @@ ROW_INFO = {
     "welch_1536": ("gen_ct_kernel<1536>", "2^27 Float32, n = nfft = 1536", "4"),
     "welch_default": ("multi-pass engine (bigfft.hip)", "welch_pgram(s) with DEFAULT arguments, 2^27 Float32: n = nfft = 2^24, 15 frames", "4"),
     "welch_default_2p24": ("multi-pass engine", "welch_pgram(s), 2^24 Float32: n = nfft = 2^21", "4"),
+    "welch_2p19": ("multi-pass engine, rows form (column pass + single-workgroup Welch kernel over the rows)", "2^27 Float32, n = nfft = 2^19, 50 % overlap: 511 frames", "4"),
     "spectrogram_default": ("multi-pass engine + untangle", "spectrogram(s) with DEFAULT arguments, 2^27 Float32 -> (2^23 + 1) x 15 Float32", "4 in + 4 per bin out"),
     "filt_5120": ("upols2_fused_kernel", "filt, 5120 taps, 2^28 Float32", "8"),
     "filt_32768": ("d.filt(b, x) through the host mirror: segments of 16384 taps on the fused engine + mdsp_shift_add", "32768 taps, 2^27 Float32", "8"),
@@ -496,6 +497,15 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
 
     guarded("welch_default", lambda: welch_default("welch_default", n3))
     guarded("welch_default_2p24", lambda: welch_default("welch_default_2p24", 1 << 24))
+
+    def welch_2p19():
+        cfg = d.WelchConfig(n3, np.float32, n=1 << 19, noverlap=1 << 18, nfft=1 << 19, window=d.hanning)
+        psd = torch.empty(cfg.nout, dtype=torch.float32, device="cuda")
+        mark("welch_2p19")
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xr.data_ptr(), n3, 1, n3, psd.data_ptr(), cfg.nout, stream)))
+        rows["welch_2p19"] = crow(tm, med, 4.0 * n3, engine=cfg.engine)
+
+    guarded("welch_2p19", welch_2p19)
 
     def spectrogram_default():
         nn = n3 >> 3

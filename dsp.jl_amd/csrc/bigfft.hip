@@ -934,7 +934,10 @@ int welch(EngineHolder& h, int dtype, int64_t n, int64_t nfft, const void* s, in
     // nfft = R0 x S, R0 = 32 .. 256: column pass + the single-workgroup Welch kernel over the rows.  Measured against three passes (profiles/r05_welch_rows.json):
     // 255 .. 2047 frames of a 2^27-sample stream 1.14 - 1.92x faster (Float32 at R0 = 128: 0.99x with the 8 x 16 column pass, 1.17x with the 16 x 8 one that
     // replaced it), the 15 frames of the default call 0.9 - 1.3x.
-    const int R0w = tunables().big_welch_rows ? rows_r0(dtype, nfft) : 0;
+    // With few transforms in the call (the 15 frames of the reference's default n = length >> 3 are 8 of them) the 128- and 256-row forms in Float32 lose 6 - 11 % to
+    // three passes -- 2^20 / 2^21 points 0.28 / 0.34 against 0.32 / 0.36 TB/s: they keep three passes below 32 transforms.
+    int R0w = tunables().big_welch_rows ? rows_r0(dtype, nfft) : 0;
+    if (R0w >= 128 && !dbl && tunables().big_welch_rows != 2 && (cplx ? K : (K + 1) / 2) < 32) R0w = 0;
     if (const int R0 = R0w) {
         MDSP_TRY(get_engine_rows(h, dtype, n, nfft, R0, &e));
         if (cplx) return dbl ? run_welch_rows<double, true>(e, s, K, hop, win_dev, acc, fresh, st) : run_welch_rows<float, true>(e, s, K, hop, win_dev, acc, fresh, st);
