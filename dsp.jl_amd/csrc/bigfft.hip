@@ -593,6 +593,10 @@ template <typename R, int OUT> int launch_pass(const BigArgs<R>& a0, int lanes, 
         BigArgs<R> a = a0;
         a.out_mode = OUT;
         constexpr bool W = OUT == 1;
+        if (a.p.fRA == 16 && a.p.fTJ == 4) {   // 64 = 16 x 4: 64-column tiles (MDSP_BIG_FAST=3)
+            if constexpr (sizeof(R) == 4) return launch_fast<R, W, 16, 4>(a, lanes, groups, st);
+            else MDSP_FAIL(MDSP_ERR_ASSERTION, "the 16 x 4 form is Float32 only");
+        }
         if (a.p.fRA == 16 && a.p.fTJ == 8) {
             if constexpr (sizeof(R) == 4) return launch_fast<R, W, 16, 8>(a, lanes, groups, st);
             else MDSP_FAIL(MDSP_ERR_ASSERTION, "the 16 x 8 form is Float32 only");

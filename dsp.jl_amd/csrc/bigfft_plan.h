@@ -178,6 +178,7 @@ template <typename R> bool make_plan_factors(int64_t N, HostPlan<R>& hp, const i
             if (q.Rp == 256) q.fRA = 16, q.fTJ = 16;
             else if (q.Rp == 128 && !dbl && fast128 == 168) q.fRA = 16, q.fTJ = 8;   // Float32: every thread busy in both stages, 32-column tiles (bigfft_pass.h FastGeo)
             else if (q.Rp == 128) q.fRA = 8, q.fTJ = 16;
+            else if (q.Rp == 64 && !dbl && fast == 3) q.fRA = 16, q.fTJ = 4;   // (MDSP_BIG_FAST=3, measured: 64-column tiles but two workgroups per CU instead of four -- 10 - 20 % slower than 8 x 8, profiles/r05_welch_rows.json)
             else if (q.Rp == 64) q.fRA = 8, q.fTJ = 8;
             else if (q.Rp == 32) q.fRA = 4, q.fTJ = 8;
         }

@@ -160,7 +160,7 @@ struct Tunables {
     int big_ols_log2n = 0;              // MDSP_BIG_OLS_LOG2N       : overlap-save beyond the partitioned kernels: log2 of the block transform (0: the rule of bigfft.hip ols_size)
     int big_ols_rows = 1;               // MDSP_BIG_OLS_ROWS=0      : long filters on three passes each way (natural-order spectra) instead of the rows form (column pass + row kernel)
     int big_welch_rows = 1;             // MDSP_BIG_WELCH_ROWS=0    : Welch at nfft = 32 .. 256 x 8192 (Float64: x 4096) on three passes instead of column pass + single-workgroup Welch kernel
-    int big_fast = 1;                   // MDSP_BIG_FAST=0          : generic LDS phases also where the two-stage register form applies (sub-transforms of 32 .. 256 points); 2: Float32 128 = 8 x 16 (round 5's first form) instead of 16 x 8
+    int big_fast = 1;                   // MDSP_BIG_FAST=0          : generic LDS phases also where the two-stage register form applies (sub-transforms of 32 .. 256 points); 2: Float32 128 = 8 x 16 (round 5's first form) instead of 16 x 8; 3: Float32 64 = 16 x 4 instead of 8 x 8 (slower)
     int big_ablate = 0;                 // MDSP_BIG_ABLATE          : profiling only (results are garbage): phases of its pass kernels switched off, see bigfft.hip
     int big_groups = 0;                 // MDSP_BIG_GROUPS          : transform groups per launch of its passes (0 = enough workgroups for four per CU)
     int plan_cache_total = 8 * MDSP_PLAN_CACHE_SIZE;   // MDSP_PLAN_CACHE_TOTAL : entries in the whole plan cache above which idle partitions are trimmed

@@ -45,7 +45,7 @@ void fast_tile(const Pass& q, int64_t tile, std::vector<cx<R>>& buf, std::vector
 #undef ARR
 }
 
-template <typename R> double run(int64_t N, int rmax, bool verbose, bool fast = true) {
+template <typename R> double run(int64_t N, int rmax, bool verbose, int fast = 1) {
     HostPlan<R> hp;
     if (!make_plan<R>(N, hp, rmax, fast)) {
         std::printf("N=%lld: no plan\n", (long long)N);
@@ -78,7 +78,8 @@ template <typename R> double run(int64_t N, int rmax, bool verbose, bool fast = 
         q.T1 = hp.T1[p].data();
         if (q.fTJ) {
             for (int64_t tile = 0; tile < q.ntiles; ++tile) {
-                if (q.fRA == 16 && q.fTJ == 8) fast_tile<R, 16, 8>(q, tile, buf, out, N);
+                if (q.fRA == 16 && q.fTJ == 4) fast_tile<R, 16, 4>(q, tile, buf, out, N);
+                else if (q.fRA == 16 && q.fTJ == 8) fast_tile<R, 16, 8>(q, tile, buf, out, N);
                 else if (q.fRA == 16) fast_tile<R, 16, 16>(q, tile, buf, out, N);
                 else if (q.fRA == 8 && q.fTJ == 16) fast_tile<R, 8, 16>(q, tile, buf, out, N);
                 else if (q.fRA == 8) fast_tile<R, 8, 8>(q, tile, buf, out, N);
@@ -140,8 +141,11 @@ int main() {
     for (int64_t N : {5000, 8192, 10000, 65536, 125000, 30375, 9604})
         chk(run<double>(N, RMAX, true), 2e-15);
     // the same powers of two through the generic phases only (what the two-stage form replaces)
-    for (int64_t N : {16384, 65536, 262144}) chk(run<float>(N, RMAX, true, false), 2e-6);
-    chk(run<double>(65536, RMAX, true, false), 2e-15);
+    for (int64_t N : {16384, 65536, 262144}) chk(run<float>(N, RMAX, true, 0), 2e-6);
+    // the other two-stage geometries of 128 (8 x 16) and 64 (16 x 4)
+    for (int64_t N : {16384, 32768, 262144}) chk(run<float>(N, RMAX, true, 2), 2e-6);
+    for (int64_t N : {16384, 262144}) chk(run<float>(N, RMAX, true, 3), 2e-6);
+    chk(run<double>(65536, RMAX, true, 0), 2e-15);
     // sub-transforms capped at 256 / 128 / 64: the other two-stage geometries
     for (int64_t N : {131072, 2097152}) chk(run<float>(N, 256, true), 3e-6);
     chk(run<float>(16384, 128, true), 2e-6);
