@@ -1174,11 +1174,15 @@ int ols_rows_table(int dbl, DevBuf& buf) { return dbl ? upload_table<double>(buf
 
 extern "C" {
 
-int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode,
-                         int engine) {
-    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
-    *plan = nullptr;
-    if (!taps_host || nb < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "filter vector b must be non-empty");
+// What a plan for (nb, nfft, nx_hint, dtype, mode, engine) executes: the engine, the transform that runs, the partitions, whether the blocks go through the
+// multi-pass engine (and in how many rows).  Pure host arithmetic, shared by mdsp_ols_plan_create and mdsp_ols_geometry_for.
+struct OlsChoice {
+    int eng = MDSP_ENGINE_ROCFFT, parts = 1, rows = 0;
+    int64_t nfft = 0, exec_nfft = 0;
+    bool big = false;
+};
+static int ols_choose(int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode, int engine, OlsChoice* c) {
+    if (nb < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "filter vector b must be non-empty");
     if (!dtype_valid(dtype)) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid dtype %d", dtype);
     if (mode != MDSP_OLS_FILT && mode != MDSP_OLS_CONV) MDSP_FAIL(MDSP_ERR_ARGUMENT, "invalid mode %d", mode);
     if (nfft == 0) nfft = mdsp_optimal_fft_len(nb, std::max<int64_t>(nx_hint, 1));
@@ -1189,7 +1193,7 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     int64_t exec_nfft = nfft;
     int parts = 1;
     const bool fused_ok = fused_geometry(dtype, nb, nfft, &exec_nfft, &parts);
-    // filters beyond four partitions of the largest in-LDS transform: the same convolution in blocks of 8 .. 16 nb points on the multi-pass engine
+    // filters beyond four partitions of the largest in-LDS transform: the same convolution in blocks on the multi-pass engine (bigfft.hip ols_size)
     const int64_t lds_max = dtype_is_double(dtype) ? 4096 : 8192;
     const int64_t big_n = (!fused_ok && eng != MDSP_ENGINE_ROCFFT && nb > 2 * lds_max) ? mdsp::big::ols_size(dtype, nb, nx_hint > 1 ? nx_hint + (mode == MDSP_OLS_CONV ? nb - 1 : 0) : 0) : 0;
     if (eng == MDSP_ENGINE_AUTO) eng = (fused_ok || big_n) ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
@@ -1203,6 +1207,37 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
         exec_nfft = nfft;
         parts = 1;
     }
+    c->eng = eng;
+    c->parts = parts;
+    c->nfft = nfft;
+    c->exec_nfft = exec_nfft;
+    c->big = eng == MDSP_ENGINE_FUSED && !fused_ok;
+    c->rows = c->big ? mdsp::big::ols_rows_r0(dtype, exec_nfft) : 0;
+    return MDSP_OK;
+}
+
+int mdsp_ols_geometry_for(int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode, int engine, int64_t* exec_nfft, int64_t* exec_block_len, int* partitions,
+                          int* engine_used, int* rows) {
+    OlsChoice c;
+    MDSP_TRY(ols_choose(nb, nfft, nx_hint, dtype, mode, engine, &c));
+    if (exec_nfft) *exec_nfft = c.exec_nfft;
+    if (exec_block_len) *exec_block_len = c.parts > 1 ? c.exec_nfft / 2 : c.exec_nfft - (nb - 1);
+    if (partitions) *partitions = c.parts;
+    if (engine_used) *engine_used = c.eng;
+    if (rows) *rows = c.rows;
+    return MDSP_OK;
+}
+
+int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode,
+                         int engine) {
+    if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
+    *plan = nullptr;
+    if (!taps_host || nb < 1) MDSP_FAIL(MDSP_ERR_ARGUMENT, "filter vector b must be non-empty");
+    OlsChoice ch;
+    MDSP_TRY(ols_choose(nb, nfft, nx_hint, dtype, mode, engine, &ch));
+    nfft = ch.nfft;
+    const int eng = ch.eng, parts = ch.parts;
+    const int64_t exec_nfft = ch.exec_nfft;
 
     auto pl = new mdsp_ols_plan_s();
     pl->dtype = dtype;
@@ -1215,7 +1250,7 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     pl->nfft = exec_nfft;
     pl->L = parts > 1 ? exec_nfft / 2 : exec_nfft - (nb - 1);
     pl->variant = tunables().ols_variant;
-    pl->big = eng == MDSP_ENGINE_FUSED && !fused_ok;
+    pl->big = ch.big;
     nfft = exec_nfft;   // from here on: the transform size that executes
 
     // Filter spectrum in double on the host.  FILT: taps scaled by 1/nfft before the transform (filt.jl:499);
@@ -1277,7 +1312,7 @@ int mdsp_ols_plan_create(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
         const double sc = 1.0 / (double)nfft;
         for (auto& h : Hf) h *= sc;
     }
-    if (pl->big) pl->big_rows = mdsp::big::ols_rows_r0(dtype, nfft);
+    pl->big_rows = ch.rows;
     if (pl->big_rows) {   // the rows form multiplies row k1 of the two-pass transform by H[k1 + R0 k2], k2 along the row
         const int64_t R0 = pl->big_rows, S = nfft / R0;
         std::vector<zd> Hr(Hf.size());

@@ -121,6 +121,11 @@ int mdsp_ols_plan_info(mdsp_ols_plan plan, int64_t* nfft, int64_t* block_len /* 
  * to S x 64) -- and beyond that three passes each way on natural-order spectra (2^20 points and more).  Same outputs within rounding, one plan for
  * every filter length with 2 nb <= 2^26. */
 int mdsp_ols_plan_geometry(mdsp_ols_plan plan, int64_t* exec_nfft, int64_t* exec_block_len, int* partitions);
+/* The same answer without a plan and without a device (pure host arithmetic: what mdsp_ols_plan_create WOULD execute for these arguments, so a host
+ * can size a time-axis split or a test can check the rule on a machine without a GPU).  engine_used: MDSP_ENGINE_*; rows: > 0 when the blocks run in
+ * the rows form of the multi-pass engine (R0 rows of 8192 / 4096 points), else 0.  Any output pointer may be NULL. */
+int mdsp_ols_geometry_for(int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, int mode, int engine, int64_t* exec_nfft, int64_t* exec_block_len,
+                          int* partitions, int* engine_used, int* rows);
 /* x_dev: (nx, ncols) ld ldx;  y_dev: (nout, ncols) ld ldy.  nout = nx (filt), nx+nb-1 (conv), or any
  * 0 <= nout <= nx+nb-1.  x and y must not alias (Filters/filt.jl:438-439). */
 int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,

@@ -225,6 +225,13 @@ function plan_geometry(h::Ptr{Cvoid})
     check(ccall((:mdsp_ols_plan_geometry, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Cint}), h, nfft, L, parts))
     (nfft = Int(nfft[]), L = Int(L[]), partitions = Int(parts[]))
 end
+# the same without a plan or a device: what a plan for these arguments would execute (rows > 0: the rows form of the multi-pass engine)
+function ols_geometry_for(nb::Integer, nfft::Integer, nx::Integer, ::Type{T}, mode::Integer=OLS_FILT, engine::Integer=ENGINE_AUTO) where {T}
+    en, L, parts, eng, rows = Ref{Int64}(0), Ref{Int64}(0), Ref{Cint}(0), Ref{Cint}(0), Ref{Cint}(0)
+    check(ccall((:mdsp_ols_geometry_for, lib), Cint, (Int64, Int64, Int64, Cint, Cint, Cint, Ref{Int64}, Ref{Int64}, Ref{Cint}, Ref{Cint}, Ref{Cint}),
+                nb, nfft, nx, mdtype(T), mode, engine, en, L, parts, eng, rows))
+    (nfft = Int(en[]), L = Int(L[]), partitions = Int(parts[]), engine = Int(eng[]), rows = Int(rows[]))
+end
 
 # The function-style entry points build a plan per call in the reference (cheap FFTW plans); here the plan comes from the LIBRARY's LRU
 # (mdsp_ols_plan_cached: keyed by device, thread, stream and the contents of the taps) -- ~45 us per call instead of ~1 ms.  The handle is

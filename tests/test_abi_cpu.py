@@ -95,6 +95,40 @@ def test_ols_block_geometry_matches_reference_table():
             _lib.check(lib.mdsp_ols_block_geometry(nb, nx, nfft, len(rows), None, None, None, None, None))
 
 
+def test_overlap_save_plan_choice_without_a_device():
+    """mdsp_ols_geometry_for: what mdsp_ols_plan_create would execute, as pure host arithmetic.  The reference's nfft runs as it is up to the largest
+    in-LDS transform (8192 Float32 / 4096 Float64), longer filters are re-blocked (one block, then 2 .. 4 partitions), and beyond 16384 / 8192 taps the
+    blocks go through the multi-pass engine: 64 rows of the longest single-workgroup transform while the filter is under a quarter of the block, then
+    256 rows, then three passes each way on 2^20 points and more; less when one block holds the whole signal."""
+    lib = _lib.lib()
+
+    def geo(nb, nx, dt, nfft=0, mode=_lib.OLS_FILT, engine=d.ENGINE_AUTO):
+        en, el, ep, eg, er = C.c_int64(), C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.mdsp_ols_geometry_for(nb, nfft, nx, dt, mode, engine, C.byref(en), C.byref(el), C.byref(ep), C.byref(eg), C.byref(er)))
+        return en.value, el.value, ep.value, eg.value, er.value
+
+    F, R = d.ENGINE_FUSED, d.ENGINE_ROCFFT
+    big = 1 << 28
+    assert geo(256, big, _lib.F32) == (2048, 2048 - 255, 1, F, 0)                       # the headline shape: the reference's own block
+    assert geo(5120, big, _lib.F32)[:4] == (4096, 2048, 3, F)                           # partitioned: 3 x 2048 taps
+    assert geo(16384, big, _lib.F32)[:4] == (8192, 4096, 4, F)
+    assert geo(16385, big, _lib.F32) == (1 << 19, (1 << 19) - 16384, 1, F, 64)          # rows form, 64 x 8192
+    assert geo(131072, big, _lib.F32) == (1 << 19, (1 << 19) - 131071, 1, F, 64)
+    assert geo(131073, big, _lib.F32) == (1 << 21, (1 << 21) - 131072, 1, F, 256)       # 256 x 8192
+    assert geo(1 << 19, big, _lib.F32)[4] == 256
+    assert geo((1 << 19) + 1, 1 << 26, _lib.F32, nfft=1 << 24) == (1 << 23, (1 << 23) - (1 << 19), 1, F, 0)   # three passes each way: 8 x the filter
+    assert geo(8193, big, _lib.F64) == (1 << 18, (1 << 18) - 8192, 1, F, 64)            # Float64: 64 x 4096
+    assert geo(65537, big, _lib.C64) == (1 << 20, (1 << 20) - 65536, 1, F, 256)
+    assert geo(32768, 80_000, _lib.F32)[0] == 1 << 17 and geo(32768, 80_000, _lib.F32)[4] == 0        # one block of 2^17 points holds the whole signal
+    assert geo(32768, 80_000, _lib.F32, mode=_lib.OLS_CONV)[0] == 1 << 18                         # conv: nx + nb - 1 outputs do not fit that block
+    assert geo(32768, big, _lib.F32, engine=R)[3] == R and geo(32768, big, _lib.F32, engine=R)[4] == 0
+    assert geo(300, 10_000, _lib.F32, nfft=3000)[3] == R                                # a 7-smooth block the caller asked for: rocFFT engine
+    with pytest.raises(d.ArgumentError):
+        geo(0, 100, _lib.F32)
+    with pytest.raises(d.ArgumentError):
+        geo(100, 1000, _lib.F32, nfft=64)
+
+
 def test_host_windows_and_design_match_oracle(golden):
     from oracle import windows as ow, design as od
     for n in (1, 2, 8, 127, 128, 4096):
