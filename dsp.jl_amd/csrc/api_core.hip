@@ -38,8 +38,72 @@ static Tunables g_tun;
 static std::once_flag g_tun_once;
 static std::mutex g_tun_mu;
 
+static const char* const kFirChoiceNames[] = {"MDSP_FIR_MM", "MDSP_FIR_DEC", "MDSP_FIR_P", "MDSP_FIR_MM_ROWS", "MDSP_FIR_MM_NG", "MDSP_FIR_MM_CH", "MDSP_FIR_MM_T64", "MDSP_FIR_MM_PRIO",
+                                               "MDSP_FIR_MM_TIGHT", "MDSP_FIR_MM_RPX", "MDSP_FIR_MM_TIEWAVES", "MDSP_FIR_MM_NBLK", "MDSP_FIR_MM_ND", "MDSP_FIR_MM_NS", "MDSP_FIR_MM_PAD"};
+int fir_choice_index(const char* name) {
+    for (size_t i = 0; i < sizeof(kFirChoiceNames) / sizeof(kFirChoiceNames[0]); ++i)
+        if (!strcmp(name, kFirChoiceNames[i])) return (int)i;
+    return -1;
+}
+int* fir_choice_field(Tunables& t, int index) {
+    switch (index) {
+        case 0: return &t.fir_mm;
+        case 1: return &t.fir_dec;
+        case 2: return &t.fir_p;
+        case 3: return &t.fir_mm_rows;
+        case 4: return &t.fir_mm_ng;
+        case 5: return &t.fir_mm_ch;
+        case 6: return &t.fir_mm_t64;
+        case 7: return &t.fir_mm_prio;
+        case 8: return &t.fir_mm_tight;
+        case 9: return &t.fir_mm_rpx;
+        case 10: return &t.fir_mm_tiewaves;
+        case 11: return &t.fir_mm_nblk;
+        case 12: return &t.fir_mm_nd;
+        case 13: return &t.fir_mm_ns;
+        case 14: return &t.fir_mm_pad;
+        default: return nullptr;
+    }
+}
+// the choice file: malformed lines are skipped (a cache, not a configuration), '#' starts a comment
+static void read_fir_choices(Tunables& t) {
+    std::string path;
+    if (const char* e = getenv("MDSP_FIR_CHOICE_FILE")) path = e;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) path = std::string(x) + "/mi355dsp/fir_choice.txt";
+    else if (const char* h = getenv("HOME")) path = std::string(h) + "/.cache/mi355dsp/fir_choice.txt";
+    if (path.empty()) return;
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[1024];
+    while (fgets(line, sizeof line, f)) {
+        if (line[0] == '#') continue;
+        FirChoice c;
+        long long L, M, n;
+        int td, xd, used = 0;
+        if (sscanf(line, "%lld %lld %lld %d %d %n", &L, &M, &n, &td, &xd, &used) < 5 || L < 1 || M < 1 || n < 1) continue;
+        c.L = L; c.M = M; c.hlen = n; c.taps_dtype = td; c.x_dtype = xd;
+        char* p = line + used;
+        while (*p && c.nset < 12) {
+            char name[64];
+            int v = 0, adv = 0;
+            if (sscanf(p, " %63[A-Z0-9_]=%d%n", name, &v, &adv) < 2) break;
+            const int idx = fir_choice_index(name);
+            if (idx >= 0) {
+                c.field[c.nset] = idx;
+                c.value[c.nset] = v;
+                ++c.nset;
+            }
+            p += adv;
+            while (*p == ',' || *p == ' ') ++p;
+        }
+        if (c.nset > 0 && t.fir_choices.size() < 4096) t.fir_choices.push_back(c);
+    }
+    fclose(f);
+}
+
 static void read_tunables_locked() {
     Tunables t;
+    read_fir_choices(t);
     auto geti = [](const char* name, int def) {
         const char* e = getenv(name);
         return e && *e ? atoi(e) : def;
@@ -111,12 +175,19 @@ static void read_tunables_locked() {
 #endif
     g_tun = t;
 }
+static thread_local const Tunables* tl_tun_override = nullptr;
 const Tunables& tunables() {
+    if (tl_tun_override) return *tl_tun_override;
     std::call_once(g_tun_once, [] {
         std::lock_guard<std::mutex> lk(g_tun_mu);
         read_tunables_locked();
     });
     return g_tun;
+}
+const Tunables* tunables_override(const Tunables* t) {
+    const Tunables* prev = tl_tun_override;
+    tl_tun_override = t;
+    return prev;
 }
 // Tuning tools only.  Readers (exec / plan paths) take no lock: a reload must not race with other threads' library calls (mi355dsp.h says so).
 static std::atomic<uint64_t> g_tun_gen{1};

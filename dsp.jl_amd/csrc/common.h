@@ -108,7 +108,19 @@ constexpr int slots_per_workgroup(int T) { return MDSP_COUPLED_SLOTS ? (T >= 256
 // Optional tuning variables (DESIGN.md section 5 "Tuning knobs") are read from the environment ONCE -- by mdsp_init(), or on
 // first use -- into this struct; exec / plan paths only ever look at the struct.  mdsp_reload_tunables() re-reads them
 // (tools/tune.py sweeps variants inside one process).  None changes results beyond rounding.
+// One line of the polyphase choice file (MDSP_FIR_CHOICE_FILE, default $XDG_CACHE_HOME/mi355dsp/fir_choice.txt or ~/.cache/mi355dsp/fir_choice.txt):
+//     L M ntaps taps_dtype x_dtype KNOB=value[,KNOB=value ...]          e.g.   1 16 583 0 0 MDSP_FIR_MM_CH=1
+// -- the polyphase knobs a box's own measurement (tools/tune_fir.py TUNE_PERSIST=1) found faster than the library's rule for that shape.  The dispatch of a
+// filter with that shape runs under those values (FirChoiceScope, fir.hip); every other shape and every other kernel family is untouched.
+struct FirChoice {
+    int64_t L = 0, M = 0, hlen = 0;
+    int taps_dtype = 0, x_dtype = 0;
+    int nset = 0;
+    int field[12];      // index into the table of fir.hip / api_core.hip (fir_choice_field)
+    int value[12];
+};
 struct Tunables {
+    std::vector<FirChoice> fir_choices; // the choice file, read with the environment (empty: no file)
     int engine = MDSP_ENGINE_AUTO;      // MDSP_ENGINE=fused|rocfft : engine of plans created with MDSP_ENGINE_AUTO
     int wg_per_cu = 0;                  // MDSP_WG_PER_CU           : persistent-grid workgroups per CU (0 = occupancy query / kernel default)
     int runs_per_slot = 1;              // MDSP_RUNS_PER_SLOT       : contiguous runs per transform slot
@@ -174,6 +186,11 @@ struct Tunables {
 };
 const Tunables& tunables();
 void reload_tunables();
+// The calling thread sees `t` instead of the process-wide struct until the returned previous override is put back (nullptr = none): per-shape choices.
+const Tunables* tunables_override(const Tunables* t);
+// field of the polyphase knob MDSP_FIR_<...> inside a Tunables (nullptr: not a knob a choice file may set)
+int* fir_choice_field(Tunables& t, int index);
+int fir_choice_index(const char* name);
 uint64_t tunables_generation();   // bumped by every reload: keys host-side memos of values derived from the tunables
 
 // ---------------------------------------------------------------- library-wide LRU of device objects (plancache.hip)

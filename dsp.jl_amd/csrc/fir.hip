@@ -1986,7 +1986,33 @@ int fir_dec_dispatch(mdsp_fir_s* f, const FirArgs& a, const DecGeo& g, hipStream
     }
 }
 
+// A filter whose shape has a line in the box's choice file (common.h FirChoice) is dispatched under that line's knob values: the calling thread's view of
+// the tunables for the duration of the scope.
+struct FirChoiceScope {
+    Tunables t;
+    const Tunables* prev = nullptr;
+    bool on = false;
+    explicit FirChoiceScope(const mdsp_fir_s* f) {
+        const Tunables& base = tunables();
+        for (const FirChoice& c : base.fir_choices) {
+            if (c.L != f->L || c.M != f->M || c.hlen != f->hlen || c.taps_dtype != f->taps_dtype || c.x_dtype != f->x_dtype) continue;
+            t = base;
+            for (int i = 0; i < c.nset; ++i)
+                if (int* field = fir_choice_field(t, c.field[i])) *field = c.value[i];
+            prev = tunables_override(&t);
+            on = true;
+            break;
+        }
+    }
+    ~FirChoiceScope() {
+        if (on) tunables_override(prev);
+    }
+    FirChoiceScope(const FirChoiceScope&) = delete;
+    FirChoiceScope& operator=(const FirChoiceScope&) = delete;
+};
+
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
+    const FirChoiceScope choice(f);
     {
         const DecGeo dg = fir_dec_geo(f);
         if (dg.ok) return fir_dec_dispatch(f, a, dg, st);
@@ -2171,6 +2197,7 @@ int mdsp_fir_mm_geometry(int64_t L, int64_t M, int64_t hlen, int taps_dtype, int
     f.taps_dtype = taps_dtype;
     f.x_dtype = x_dtype;
     f.acc_double = (taps_dtype == MDSP_F64) || dtype_is_double(x_dtype);
+    const FirChoiceScope choice(&f);
     const FirMGeo g = fir_mm_geo(&f);
     const int64_t v[12] = {g.ok ? 1 : 0, g.RB, g.Lr, g.Mr, g.NB, g.NG, g.steps, g.CH, g.CS, g.nd, g.ns, (int64_t)g.lds_bytes};
     for (int i = 0; i < 12; ++i) out12[i] = v[i];
@@ -2186,6 +2213,7 @@ int mdsp_fir_kernel_path(mdsp_fir f, int64_t xlen, int* path) {
     a.nout = f->kind == 0 ? xlen : (xlen < d0 ? 0 : mdsp_outputlength(xlen - d0 + 1, f->L, f->M, phi0));
     a.L = (int)f->L;
     a.M = (int)f->M;
+    const FirChoiceScope choice(f);
     *path = fir_dec_geo(f).ok ? 3 : fir_mm_use(f, a) ? 2 : (fir_fast_ok(f, 2) || fir_fast_ok(f, 1)) ? 1 : 0;   // 3: decimator kernel, 2: matrix cores, 1: register taps, 0: generic
     return MDSP_OK;
 }

@@ -605,6 +605,34 @@ def test_matrix_core_last_resort_tiles():
         _lib.set_tunable("MDSP_FIR_MM_TIGHT", None)
 
 
+def test_polyphase_choice_file_overrides_one_shape_only(tmp_path):
+    """The per-box choice file (common.h FirChoice; written by tools/tune_fir.py TUNE_PERSIST=1): a line names a shape -- reduced L, M, taps, dtypes -- and the
+    polyphase knobs this box measured faster for it; filters of that shape are dispatched under those values, every other shape under the library's rule.
+    Checked on the pure-host geometry entry (no device): malformed lines and unknown knobs are skipped."""
+    lib = _lib.lib()
+
+    def geo(L, M, n, td=_lib.F32, xd=_lib.F32):
+        out = (C.c_int64 * 12)()
+        _lib.check(lib.mdsp_fir_mm_geometry(L, M, n, td, xd, out))
+        return list(out)
+
+    base_a, base_b, f64_before = geo(3, 2, 96), geo(2, 1, 75), geo(3, 2, 96, _lib.F64, _lib.F64)
+    assert base_a[0] == 1 and base_a[5] > 2                      # ok, NG of the library's rule
+    f = tmp_path / "fir_choice.txt"
+    f.write_text("# a comment\n3 2 96 0 0 MDSP_FIR_MM_NG=2,MDSP_NOT_A_KNOB=7\nthis line is not a shape\n6 4 96 0 0 MDSP_FIR_MM_NG=1\n")
+    try:
+        _lib.set_tunable("MDSP_FIR_CHOICE_FILE", str(f))
+        got = geo(3, 2, 96)
+        assert got[0] == 1 and got[5] == 2 and got[7] == base_a[7]       # NG capped for this shape (the unreduced 6//4 line is never looked up: ratios are reduced)
+        assert geo(6, 4, 96) == got                                      # ... which is the same filter
+        assert geo(3, 2, 97)[5] == base_a[5] and geo(2, 1, 75) == base_b                     # other shapes: untouched
+        assert geo(3, 2, 96, _lib.F64, _lib.F64) == f64_before                               # another dtype is another shape
+    finally:
+        _lib.set_tunable("MDSP_FIR_CHOICE_FILE", str(tmp_path / "absent.txt"))
+    assert geo(3, 2, 96) == base_a
+    _lib.set_tunable("MDSP_FIR_CHOICE_FILE", None)
+
+
 def test_matrix_core_polyphase_geometry_is_consistent():
     # mdsp_fir_mm_geometry is the host arithmetic that sizes the matrix-core polyphase kernel (rows of RB rounds, blocks of 16 outputs,
     # k-steps, LDS buffers, wave roles): pure integer code, checked here without a device over random ratios and tap counts.

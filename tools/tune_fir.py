@@ -107,6 +107,30 @@ if VERIFY:
     ratio = ec["median_ms"] / er["median_ms"]
     res["verify_choice"] = {"choice_ms": ec["median_ms"], "round2_rule_ms": er["median_ms"], "choice_over_rule": round(ratio, 4), "regression": bool(ratio > 1.02)}
     print(("REGRESSION" if ratio > 1.02 else "ok") + f": {L}//{M} {DT}: library's choice {ec['median_ms']:.4f} ms, round-2 rule {er['median_ms']:.4f} ms ({ratio:.3f})", flush=True)
+# TUNE_PERSIST=1: what THIS box measured goes into the choice file the library reads (common.h FirChoice; MDSP_FIR_CHOICE_FILE, else
+# $XDG_CACHE_HOME/mi355dsp/fir_choice.txt, else ~/.cache/mi355dsp/fir_choice.txt): the first variant is the library's own rule; when another one is more
+# than 2 % faster its knobs become the shape's line (only knobs the file may carry; MDSP_WG_PER_CU / _RPAD / _VSTORE are process-wide), otherwise a line
+# left by an earlier run is removed.  The library applies a line to filters of exactly this (L, M, ntaps, dtypes) and to nothing else.
+if os.environ.get("TUNE_PERSIST") == "1" and len(variants) > 1:
+    import math
+    path = os.environ.get("MDSP_FIR_CHOICE_FILE") or os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "mi355dsp", "fir_choice.txt")
+    gq = math.gcd(L, M)
+    shape = f"{L // gq} {M // gq} {len(h)} {lt} {lx}"
+    keys = list(res["variants"].keys())
+    best = min(keys, key=lambda k: res["variants"][k]["median_ms"])
+    names = {0: ("MDSP_FIR_MM", -1), 2: ("MDSP_FIR_P", 0), 3: ("MDSP_FIR_MM_ND", 0), 4: ("MDSP_FIR_MM_NS", 0), 5: ("MDSP_FIR_MM_NG", 0), 6: ("MDSP_FIR_MM_CH", 0), 7: ("MDSP_FIR_MM_PAD", -1),
+             8: ("MDSP_FIR_MM_ROWS", -1), 11: ("MDSP_FIR_MM_PRIO", -1), 12: ("MDSP_FIR_MM_T64", 1), 13: ("MDSP_FIR_MM_NBLK", 1)}
+    lines = []
+    if os.path.exists(path):
+        lines = [ln for ln in open(path).read().splitlines() if ln.strip() and not ln.startswith(shape + " ")]
+    v = variants[keys.index(best)]
+    knobs = [f"{nm}={v[i]}" for i, (nm, dflt) in names.items() if i < len(v) and v[i] != dflt]
+    if best != keys[0] and res["variants"][best]["median_ms"] < 0.98 * res["variants"][keys[0]]["median_ms"] and knobs:
+        lines.append(shape + " " + ",".join(knobs))
+        res["persisted"] = lines[-1]
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    open(path, "w").write("# polyphase choices measured on this box (tools/tune_fir.py TUNE_PERSIST=1): L M ntaps taps_dtype x_dtype KNOB=value,...\n" + "\n".join(ln for ln in lines if not ln.startswith("#")) + "\n")
+    print("choice file", path, "->", res.get("persisted", "(the library's rule stands for this shape)"), flush=True)
 select((-1, 0, 0)); _lib.set_tunable("MDSP_FIR_MM", None); _lib.set_tunable("MDSP_WG_PER_CU", None); _lib.set_tunable("MDSP_FIR_P", None)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "tune_fir.json"), "w"), indent=1)
