@@ -148,6 +148,7 @@ static void read_tunables_locked() {
     t.fir_dec = geti("MDSP_FIR_DEC", 1);
     t.fir_dec_wgs = geti("MDSP_FIR_DEC_WGS", 0);
     t.fir_dec_ablate = geti("MDSP_FIR_DEC_ABLATE", 0);
+    t.fir_dec_nc = geti("MDSP_FIR_DEC_NC", 1);
     t.fir_mm_rows = geti("MDSP_FIR_MM_ROWS", -1);
     t.fir_mm_ng = geti("MDSP_FIR_MM_NG", 0);
     t.fir_mm_ch = geti("MDSP_FIR_MM_CH", 0);

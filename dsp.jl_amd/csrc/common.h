@@ -143,6 +143,7 @@ struct Tunables {
     int fir_dec = 1;                    // MDSP_FIR_DEC=0|2|3       : 0 = decimators (L = 1) on the matrix-core / register-tap kernels as up to round 4; default: the phase-per-lane
                                         //                            decimator kernel where it measured faster; 2 = its run-time M form for every M; 3 = the kernel for every M <= 64
     int fir_dec_wgs = 0;                // MDSP_FIR_DEC_WGS         : workgroups per CU of the decimator kernel's launch (Float64 / ComplexF64: the persistent form; 0 = 2, what stays resident)
+    int fir_dec_nc = 1;                 // MDSP_FIR_DEC_NC=0        : the decimator kernel's run-time chunk loop also for filters of five chunks per phase (default: unrolled, taps in registers, sliding window)
     int fir_dec_ablate = 0;             // MDSP_FIR_DEC_ABLATE      : profiling only: phases of the decimator kernel switched off (fir.hip)
     int fir_mm_rows = -1;               // MDSP_FIR_MM_ROWS=0|1|2   : its tiles staged as one run / row by row / one run with padded rows (default: by cost; padded rows
                                         //                            where the rows' sample stride is bank-hostile)

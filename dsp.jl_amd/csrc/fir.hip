@@ -736,7 +736,11 @@ struct DecArgs {
 __device__ __forceinline__ int dec_pos(int k, int M, unsigned blkmagic) { return k + (int)__umulhi((unsigned)k, blkmagic) * M; }
 
 // MC: M as a compile-time constant (0: run-time M) -- the window reads are then one address register plus immediates
-template <typename R, bool CPLX, int P, int MC>
+// NC: the filter's chunks of QC taps per phase as a compile-time constant (0: run-time loop).  The chunk loop is then unrolled, so a lane's taps live in registers
+// for the whole tile and its sample window SLIDES -- QC new samples per chunk instead of P + QC - 1: 8 LDS reads per 128 packed multiply-adds instead of 31.
+// NC = 5 is every decimator resample_filter designs (36.4 taps per phase and M, stream_filt.jl / design.jl:700-720): the LDS was as busy as the vector unit
+// with the run-time loop (per CU: 4 x 640 clocks of LDS reads against 2800 of multiply-adds per block).
+template <typename R, bool CPLX, int P, int MC, int NC = 0>
 MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void decimator_kernel(DecArgs a) {
     using V = DecV<R>;
     using XS = std::conditional_t<CPLX, cx<R>, R>;
@@ -809,8 +813,9 @@ MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void dec
     };
     auto stage_slow = [&](int64_t tile) {   // tiles that straddle the history or the end of x
         const int64_t zf = a.zb + tile * TO * M;
-        if (inside(tile)) {                 // (a tile beyond the registers: 16-byte loads, four in flight, straight to the LDS)
-            constexpr int U = 4;
+        if (inside(tile)) {                 // Float32: the whole tile in ONE round of 16-byte loads (ten a thread: the registers of the multiply-adds are not live
+                                            // yet; four at a time were three HBM latencies per tile); Float64 tiles beyond the registers: four in flight
+            constexpr int U = PRE ? 4 : (CPLX ? 10 : 5);
             const __amdgpu_buffer_rsrc_t rs = io::make_rsrc(xc + (zf - a.hl), (a.xlen - (zf - a.hl)) * (long long)sizeof(XS));
             for (int k0 = threadIdx.x * NV; k0 < a.nz; k0 += U * 256 * NV) {
                 u4v va[U], vb[CPLX ? 1 : U];
@@ -877,6 +882,51 @@ MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void dec
             for (int p = 0; p < P; ++p) acc[p] = {(R)0, (R)0};
             // sample (bl P + t) M + r of the tile sits at  bl (P + 1) M + (t + t div P) M + r : t = q0 + j walks the window
             const V* zb = zs + (size_t)bl * (P + 1) * M + rr;
+            if constexpr (NC > 0) {
+                if (!(a.ablate & 1)) {
+                    constexpr bool GREG = sizeof(R) == 4;   // Float64: the taps of a chunk from LDS as it starts (80 registers of taps next to the tile in flight spilt)
+                    R g[GREG ? NC * QC : QC];
+                    if constexpr (GREG) {
+#pragma unroll
+                        for (int u = 0; u < NC * QC; ++u) g[u] = tl[u * M + rr];
+                    }
+                    V w[P + QC - 1];
+#pragma unroll
+                    for (int j = 0; j < P + QC - 1; ++j) w[j] = zb[(j + j / P) * M];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const int q0 = c * QC, g0 = GREG ? q0 : 0;
+                        if constexpr (!GREG) {
+#pragma unroll
+                            for (int u = 0; u < QC; ++u) g[u] = tl[(q0 + u) * M + rr];
+                        }
+                        if (c > 0) {
+#pragma unroll
+                            for (int j = 0; j < P - 1; ++j) w[j] = w[j + QC];
+#pragma unroll
+                            for (int j = P - 1; j < P + QC - 1; ++j) {
+                                const int t = q0 + j;
+                                w[j] = zb[(t + t / P) * M];
+                            }
+                        }
+                        if (c < NC - 1 || (q0 + QC) * M <= a.tp) {
+#pragma unroll
+                            for (int u = 0; u < QC; ++u)
+#pragma unroll
+                                for (int p = 0; p < P; ++p) acc[p] = dec_fma(w[p + u], g[g0 + u], acc[p]);
+                        } else {   // the last chunk, masked as below
+#pragma unroll
+                            for (int u = 0; u < QC; ++u) {
+                                if ((q0 + u) * M + rr < a.tp) {
+#pragma unroll
+                                    for (int p = 0; p < P; ++p) acc[p] = dec_fma(w[p + u], g[g0 + u], acc[p]);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                }
+            } else
             for (int q0 = 0; q0 < ((a.ablate & 1) ? 0 : a.nq); q0 += QC) {
                 R g[QC];
                 V w[P + QC - 1];
@@ -1959,12 +2009,15 @@ template <typename R, bool CPLX, int P> int fir_dec_launch(mdsp_fir_s* f, const 
     d.ablate = tunables().fir_dec_ablate;
     d.blkmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)(P * a.M) - 1) / (uint64_t)(P * a.M));
     void (*kern)(DecArgs) = decimator_kernel<R, CPLX, P, 0>;
+    const bool nc5 = (g.nq + 7) / 8 == 5 && tunables().fir_dec_nc != 0;   // five chunks of taps per phase: what resample_filter designs for every decimator
     switch (a.M) {
         case 2: kern = decimator_kernel<R, CPLX, P, 2>; break;
-        case 4: kern = decimator_kernel<R, CPLX, P, 4>; break;
-        case 8: kern = decimator_kernel<R, CPLX, P, 8>; break;
-        case 16: kern = decimator_kernel<R, CPLX, P, 16>; break;
-        default: break;
+        case 4: kern = nc5 ? decimator_kernel<R, CPLX, P, 4, 5> : decimator_kernel<R, CPLX, P, 4>; break;
+        case 8: kern = nc5 ? decimator_kernel<R, CPLX, P, 8, 5> : decimator_kernel<R, CPLX, P, 8>; break;
+        case 16: kern = nc5 ? decimator_kernel<R, CPLX, P, 16, 5> : decimator_kernel<R, CPLX, P, 16>; break;
+        default:
+            if (nc5) kern = decimator_kernel<R, CPLX, P, 0, 5>;
+            break;
     }
     if (tunables().fir_dec == 2) kern = decimator_kernel<R, CPLX, P, 0>;   // MDSP_FIR_DEC=2: the run-time M form for every M
     if (g.lds > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
