@@ -1965,7 +1965,8 @@ DecGeo fir_dec_geo(const mdsp_fir_s* f) {
     // Where it wins (profiles/r05_fir_dec_ab.json, 4 channels x 2^26 samples, resample_filter taps): Float64 / ComplexF64 from M = 4 on (1.1 - 4.1x),
     // Float32 / ComplexF32 at M = 4 (1.17 - 1.19x) and from M = 8 on (1.1 - 3.9x); at M = 2, 3 and the Float32 M = 5, 6, 7 the matrix-core kernel's
     // short products stay ahead (0.31 - 0.54 of the roof against 0.24 - 0.38).  MDSP_FIR_DEC=3 takes it for every M <= 64 (tests).
-    if (tunables().fir_dec == 1 && !(f->acc_double ? f->M >= 4 : (f->M == 4 || f->M >= 8))) return g;
+    // (re-measured with the unrolled chunk loop, profiles/r05_fir_dec_ab.json "rule_recheck": unchanged but for real Float32 at M = 3 -- 0.52 against 0.61 ms)
+    if (tunables().fir_dec == 1 && !(f->acc_double ? f->M >= 4 : (f->M == 4 || f->M >= 8 || (f->M == 3 && !dtype_is_complex(f->x_dtype))))) return g;
     const bool dbl = f->acc_double, cplx = dtype_is_complex(f->x_dtype);
     const int M = (int)f->M;
     g.P = dbl ? 8 : 16;
@@ -2009,16 +2010,27 @@ template <typename R, bool CPLX, int P> int fir_dec_launch(mdsp_fir_s* f, const 
     d.ablate = tunables().fir_dec_ablate;
     d.blkmagic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)(P * a.M) - 1) / (uint64_t)(P * a.M));
     void (*kern)(DecArgs) = decimator_kernel<R, CPLX, P, 0>;
-    const bool nc5 = (g.nq + 7) / 8 == 5 && tunables().fir_dec_nc != 0;   // five chunks of taps per phase: what resample_filter designs for every decimator
+    // chunks of taps per phase: five is what resample_filter designs for every decimator; two .. six unrolled for M = 4, 8, 16 (the run-time loop otherwise)
+    const int nc = tunables().fir_dec_nc != 0 ? (g.nq + 7) / 8 : 0;
+#define MDSP_DEC_NC(MCV)                                                                      \
+    switch (nc) {                                                                             \
+        case 2: kern = decimator_kernel<R, CPLX, P, MCV, 2>; break;                           \
+        case 3: kern = decimator_kernel<R, CPLX, P, MCV, 3>; break;                           \
+        case 4: kern = decimator_kernel<R, CPLX, P, MCV, 4>; break;                           \
+        case 5: kern = decimator_kernel<R, CPLX, P, MCV, 5>; break;                           \
+        case 6: kern = decimator_kernel<R, CPLX, P, MCV, 6>; break;                           \
+        default: kern = decimator_kernel<R, CPLX, P, MCV>; break;                             \
+    }
     switch (a.M) {
         case 2: kern = decimator_kernel<R, CPLX, P, 2>; break;
-        case 4: kern = nc5 ? decimator_kernel<R, CPLX, P, 4, 5> : decimator_kernel<R, CPLX, P, 4>; break;
-        case 8: kern = nc5 ? decimator_kernel<R, CPLX, P, 8, 5> : decimator_kernel<R, CPLX, P, 8>; break;
-        case 16: kern = nc5 ? decimator_kernel<R, CPLX, P, 16, 5> : decimator_kernel<R, CPLX, P, 16>; break;
+        case 4: MDSP_DEC_NC(4) break;
+        case 8: MDSP_DEC_NC(8) break;
+        case 16: MDSP_DEC_NC(16) break;
         default:
-            if (nc5) kern = decimator_kernel<R, CPLX, P, 0, 5>;
+            if (nc == 5) kern = decimator_kernel<R, CPLX, P, 0, 5>;
             break;
     }
+#undef MDSP_DEC_NC
     if (tunables().fir_dec == 2) kern = decimator_kernel<R, CPLX, P, 0>;   // MDSP_FIR_DEC=2: the run-time M form for every M
     if (g.lds > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
     const int64_t TO = (int64_t)(CPLX ? 1 : 2) * g.nbh * P;
