@@ -771,7 +771,8 @@ MDSP_NO_LSO __global__ __launch_bounds__(256, (sizeof(R) == 4 ? 3 : 2)) void dec
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     constexpr int NV = 16 / (int)sizeof(XS);
     constexpr bool PRE = sizeof(R) == 8;
-    constexpr int NIT = PRE ? (CPLX ? 10 : 5) : 1;              // nz sizeof(V) <= 40 KiB (fir_dec_geo): 256 threads x NIT x 16 (32: both halves) bytes
+    constexpr int NIT = PRE ? (CPLX ? 11 : 6) : 1;              // 256 threads x NIT x 16 (32: both halves) bytes: the 40 KiB of blocks (fir_dec_geo) plus the window tail
+                                                                // (M = 16 with 40 tap steps: 43 KiB -- with ten / five loads those tiles fell out of the prefetching form)
     u4v pa[NIT], pb[CPLX ? 1 : NIT];
     const bool fits = a.nz <= 256 * NIT * NV;                   // (filters of several thousand taps per phase: the tile outgrows the registers -- staged in place)
     auto inside = [&](int64_t tile) {
