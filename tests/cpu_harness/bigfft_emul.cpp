@@ -127,6 +127,66 @@ template <typename R> double run(int64_t N, int rmax, bool verbose, int fast = 1
     return err;
 }
 
+// The rows form of the long-filter convolution (bigfft.hip run_ols_rows, ols.hip ROWS), on the host: column pass (pass 0 of a two-factor plan, through the
+// tile code above), per row the S-point transform x the row of H' x the inverse transform x the inverse inter-pass twiddle (a Float64 DFT stands in for
+// the single-workgroup kernel), then the column pass back on the conjugate with tables of ones -- against the circular convolution computed directly.
+template <typename R, int RA, int TJ> double run_rows(int R0, int S, bool verbose) {
+    const int64_t N = (int64_t)R0 * S;
+    HostPlan<R> hp;
+    const int Rf[2] = {R0, S};
+    if (!make_plan_factors<R>(N, hp, Rf, 2, 1, true) || hp.pass[0].fRA != RA || hp.pass[0].fTJ != TJ) {
+        std::printf("rows %d x %d: no column pass of that geometry\n", R0, S);
+        return 1e9;
+    }
+    Pass fwd = hp.pass[0];
+    fwd.roots = hp.roots[0].data();
+    fwd.T0 = hp.T0[0].data();
+    fwd.T1 = hp.T1[0].data();
+    std::vector<cx<R>> one0(hp.T0[0].size(), cx<R>{(R)1, (R)0}), one1(hp.T1[0].size(), cx<R>{(R)1, (R)0});
+    Pass inv = fwd;
+    inv.T0 = one0.data();
+    inv.T1 = one1.data();
+    std::mt19937_64 rng(77 + (unsigned)N);
+    std::normal_distribution<double> nd;
+    const int nb = S / 3 + 5;                      // a filter shorter than the block
+    std::vector<zd> x((size_t)N), h((size_t)N, zd(0, 0));
+    std::vector<cx<R>> buf((size_t)N), dummy((size_t)N);
+    for (int64_t i = 0; i < N; ++i) {
+        x[(size_t)i] = zd(nd(rng), nd(rng));
+        buf[(size_t)i] = {(R)x[(size_t)i].real(), (R)x[(size_t)i].imag()};
+        x[(size_t)i] = zd((double)buf[(size_t)i].x, (double)buf[(size_t)i].y);
+    }
+    for (int i = 0; i < nb; ++i) h[(size_t)i] = zd(nd(rng), 0) / (double)N;
+    const std::vector<zd> H = host_fft(h, -1);
+    for (int64_t tile = 0; tile < fwd.ntiles; ++tile) fast_tile<R, RA, TJ>(fwd, tile, buf, dummy, N);          // column pass, twiddled
+    for (int k1 = 0; k1 < R0; ++k1) {                                                                           // the row kernel
+        std::vector<zd> row((size_t)S);
+        for (int c = 0; c < S; ++c) row[(size_t)c] = zd((double)buf[(size_t)(k1 * (int64_t)S + c)].x, (double)buf[(size_t)(k1 * (int64_t)S + c)].y);
+        std::vector<zd> Z = host_fft(row, -1);
+        for (int k2 = 0; k2 < S; ++k2) Z[(size_t)k2] *= H[(size_t)(k1 + (int64_t)R0 * k2)];                     // H'[k1 S + k2] = H[k1 + R0 k2]
+        const std::vector<zd> z = host_fft(Z, +1);
+        for (int c = 0; c < S; ++c) {
+            const zd w = std::conj(unit_root((int64_t)k1 * c, N, -1));
+            const zd v = z[(size_t)c] * w;
+            buf[(size_t)(k1 * (int64_t)S + c)] = {(R)v.real(), -(R)v.imag()};                                    // the column pass back starts from the conjugate
+        }
+    }
+    for (int64_t tile = 0; tile < inv.ntiles; ++tile) fast_tile<R, RA, TJ>(inv, tile, buf, dummy, N);          // ... and its results are conjugated on the way out
+    // reference: circular convolution through Float64 transforms of the whole block
+    std::vector<zd> X = host_fft(x, -1);
+    for (int64_t k = 0; k < N; ++k) X[(size_t)k] *= H[(size_t)k];
+    const std::vector<zd> y = host_fft(X, +1);
+    double num = 0, den = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const zd d = zd((double)buf[(size_t)i].x, -(double)buf[(size_t)i].y) - y[(size_t)i];
+        num += std::norm(d);
+        den += std::norm(y[(size_t)i]);
+    }
+    const double err = std::sqrt(num / den);
+    if (verbose) std::printf("rows form %3d x %4d (%dx%d column pass): rel err %.3g\n", R0, S, RA, TJ, err);
+    return err;
+}
+
 int main() {
     int bad = 0;
     auto chk = [&](double e, double tol) {
@@ -157,6 +217,11 @@ int main() {
     // three and four passes of short sub-transforms (the digit walk of the last pass): factors capped at 16 / 12
     for (int64_t N : {4096, 65536, 20736, 50625}) chk(run<float>(N, N == 20736 ? 12 : (N == 50625 ? 15 : 16), true), 2e-6);
     chk(run<double>(65536, 16, true), 2e-15);
+    // the rows form of the long-filter convolution: 64 / 128 / 256 rows
+    chk(run_rows<float, 8, 8>(64, 256, true), 2e-6);
+    chk(run_rows<float, 16, 8>(128, 128, true), 2e-6);
+    chk(run_rows<float, 16, 16>(256, 64, true), 2e-6);
+    chk(run_rows<double, 8, 8>(64, 128, true), 2e-15);
     std::printf(bad ? "%d FAILED\n" : "OK\n", bad);
     return bad ? 1 : 0;
 }

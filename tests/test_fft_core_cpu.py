@@ -31,10 +31,14 @@ def test_compile_time_schedules_on_the_host(tmp_path):
 def test_multipass_transform_on_the_host(tmp_path):
     """tests/cpu_harness/bigfft_emul.cpp: the tile / sub-pass / store phases of the multi-pass engine (csrc/bigfft_pass.h) and its planner
     (csrc/bigfft_plan.h: factorisation, radix schedules, two-level twiddle tables) run thread by thread on the host against a Float64 DFT --
-    two, three and four passes, powers of two, the 2^a 5^b sizes of the default arguments, odd sizes with partial tiles, both precisions."""
+    two, three and four passes, powers of two, the 2^a 5^b sizes of the default arguments, odd sizes with partial tiles, both precisions, every two-stage
+    geometry (256 = 16 x 16, 128 = 16 x 8 and 8 x 16, 64 = 8 x 8 and 16 x 4, 32 = 4 x 8).  And the ROWS FORM of the long-filter convolution (bigfft.hip
+    run_ols_rows): column pass with the inter-pass twiddle, per row transform x spectrum row H'[k1 S + k2] = H[k1 + R0 k2] x inverse transform x inverse twiddle,
+    column pass back on the conjugate with tables of ones -- against the circular convolution, for 64 / 128 / 256 rows."""
     exe = str(tmp_path / "bigfft_emul")
     r = subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpu_harness", "bigfft_emul.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:]
     assert "N=   125000 f32 P=2" in r.stdout and "P=4" in r.stdout and "FAIL" not in r.stdout
+    assert r.stdout.count("rows form") == 4 and "16x8 column pass" in r.stdout
