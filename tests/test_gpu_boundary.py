@@ -1017,6 +1017,24 @@ def test_long_complex_filters_on_the_multipass_engine(d, torch, dt):
         assert relerr(y3, r3) < TOL32
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_long_filters_on_several_columns(d, torch, dt):
+    """20001 taps on three columns of 1.2 M samples (the rows form: 64 rows of the longest single-workgroup transform, one column after the other on the same
+    engine): every column bit-identical to the same column filtered alone, and against a Float64 transform-domain product."""
+    rng = np.random.default_rng(3)
+    nb, nx = 20001, 1_200_017
+    b = (rng.standard_normal(nb) / np.sqrt(nb)).astype(dt)
+    X = rng.standard_normal((nx, 3)).astype(dt)
+    Xd = torch.from_numpy(X).cuda()
+    Y = d.filt(b, Xd).cpu().numpy()
+    assert Y.shape == X.shape
+    for c in range(3):
+        assert np.array_equal(Y[:, c], d.filt(b, Xd[:, c].contiguous()).cpu().numpy()), c
+    nf = 1 << 21
+    ref = np.fft.irfft(np.fft.rfft(X[:, 1].astype(np.float64), nf) * np.fft.rfft(b.astype(np.float64), nf), nf)[:nx]
+    assert relerr(Y[:, 1], ref) < (TOL32 if dt == np.float32 else 1e-12)
+
+
 def test_welch_hand_allocated_kernel_several_channels(d, torch):
     """mdsp_welch_w64c_asm with more than one channel per launch (grid (G, nch), rows part[((slot nch + ch) nflush + f)], the two-step row reduction
     per channel): three channels of 2^23 + 4096 + 2048 k samples (even and odd frame counts reach the kernel: it takes over from eight units per CU) --
