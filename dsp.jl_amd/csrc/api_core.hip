@@ -139,6 +139,7 @@ static void read_tunables_locked() {
     t.big_ablate = geti("MDSP_BIG_ABLATE", 0);
     t.big_rmax = std::min(512, std::max(16, geti("MDSP_BIG_RMAX", 512)));
     t.big_fast = geti("MDSP_BIG_FAST", 1);
+    t.gx = geti("MDSP_GX", 1);
     t.big_ols_log2n = geti("MDSP_BIG_OLS_LOG2N", 0);
     t.big_ols_rows = geti("MDSP_BIG_OLS_ROWS", 1);
     t.big_welch_rows = geti("MDSP_BIG_WELCH_ROWS", 1);

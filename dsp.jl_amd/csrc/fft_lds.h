@@ -718,6 +718,7 @@ template <> struct CompRoots<25> {
     static constexpr double c[25] = {1.0, 0.96858316112863111949, 0.876306680043863587308, 0.728968627421411523147, 0.535826794978996618271, 0.309016994374947424102, 0.0627905195293133760762, -0.187381314585724630543, -0.425779291565072648863, -0.637423989748689710177, -0.809016994374947424102, -0.929776485888251403661, -0.99211470131447783105, -0.99211470131447783105, -0.929776485888251403661, -0.809016994374947424102, -0.637423989748689710177, -0.425779291565072648863, -0.187381314585724630543, 0.0627905195293133760762, 0.309016994374947424102, 0.535826794978996618271, 0.728968627421411523147, 0.876306680043863587308, 0.96858316112863111949};
     static constexpr double s[25] = {0.0, 0.248689887164854788242, 0.481753674101715274987, 0.684547105928688673732, 0.844327925502015078549, 0.951056516295153572116, 0.998026728428271561952, 0.982287250728688681086, 0.904827052466019527714, 0.770513242775789230803, 0.587785252292473129169, 0.368124552684677959157, 0.125333233564304245373, -0.125333233564304245373, -0.368124552684677959157, -0.587785252292473129169, -0.770513242775789230803, -0.904827052466019527714, -0.982287250728688681086, -0.998026728428271561952, -0.951056516295153572116, -0.844327925502015078549, -0.684547105928688673732, -0.481753674101715274987, -0.248689887164854788242};
 };
+#include "comp_roots_ext.h"   // 9, 14, 18, 21, 27, 28, 30, 32 (round 6: the run-time-schedule kernel of spectral_gx.h; tools/gen_comp_roots.py)
 template <int RDX, typename R> MDSP_HD void gen_bfly(cx<R> (&v)[RDX]);
 template <int N, int M, typename R> MDSP_HD cx<R> comp_twiddle(cx<R> a) {   // a exp(-2 pi i M / N), 0 <= M < N
     if constexpr (M == 0) return a;
@@ -759,6 +760,14 @@ template <int RDX, typename R> MDSP_HD void gen_bfly(cx<R> (&v)[RDX]) {
     else if constexpr (RDX == 20) bfly_comp<5, 4>(v);
     else if constexpr (RDX == 24) bfly_comp<3, 8>(v);
     else if constexpr (RDX == 25) bfly_comp<5, 5>(v);
+    else if constexpr (RDX == 9) bfly_comp<3, 3>(v);
+    else if constexpr (RDX == 14) bfly_comp<7, 2>(v);
+    else if constexpr (RDX == 18) bfly_comp<3, 6>(v);
+    else if constexpr (RDX == 21) bfly_comp<3, 7>(v);
+    else if constexpr (RDX == 27) bfly_comp<3, 9>(v);
+    else if constexpr (RDX == 28) bfly_comp<7, 4>(v);
+    else if constexpr (RDX == 30) bfly_comp<5, 6>(v);
+    else if constexpr (RDX == 32) bfly_comp<4, 8>(v);
     else bfly<RDX, -1>(v);
 }
 

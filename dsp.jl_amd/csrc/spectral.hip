@@ -35,6 +35,7 @@
 #include "rocfft_wrap.h"
 #include "welch_plan.h"
 #include "hostpipe.h"
+#include "gx_kernels.h"   // (namespace mdsp::gx and the kernel template: ahead of the anonymous namespace that includes spectral_gx.h)
 
 using namespace mdsp;
 using mdsp::fft::cx;
@@ -669,6 +670,7 @@ __global__ __launch_bounds__((N / E) * G, MINW) void stft_pair_kernel(SpecArgs a
 }
 
 #include "spectral_gen.h"
+#include "spectral_gx.h"
 
 bool fused_size_ok(int dtype, int64_t nfft) {
     const bool dbl = dtype_is_double(dtype);
@@ -679,9 +681,16 @@ bool fused_size_ok(int dtype, int64_t nfft) {
     }
 }
 
+// round 6: the run-time-schedule kernel (spectral_gx.h) takes every 7-smooth size it plans that has neither a register-resident power-of-two kernel
+// nor a compile-time schedule -- in front of the round-2 LDS kernel, the multi-pass engine and the rocFFT pipeline
+bool use_gx(int dtype, int64_t nfft, bool direct) {
+    const int m = tunables().gx;
+    if (m == 0 || !gx_size_ok(dtype, nfft)) return false;
+    return m >= 2 || (!fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct));
+}
 // the multi-pass engine takes what no single-workgroup kernel does
 bool use_big(int dtype, int64_t nfft, bool direct) {
-    return !fused_size_ok(dtype, nfft) && !gen_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && big::size_ok(dtype, nfft);
+    return !use_gx(dtype, nfft, direct) && !fused_size_ok(dtype, nfft) && !gen_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && big::size_ok(dtype, nfft);
 }
 
 // kind: 0 = Welch (sums of |X|^2), 1 = STFT / spectrogram / periodogram columns
@@ -691,7 +700,8 @@ int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) 
     // fused: the register-resident power-of-two sizes, and the mixed-radix LDS kernel for the other 7-smooth sizes nextfastfft returns
     const bool direct = kind == 0 || dtype_is_complex(dtype);   // the last pass is consumed from registers (spectral_gen.h)
     const bool big_ok = use_big(dtype, nfft, direct);   // round 5: the multi-pass engine (bigfft.hip) for everything above the one-workgroup sizes
-    const bool fused_ok = fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) || big_ok;
+    const bool gx_ok = use_gx(dtype, nfft, direct);
+    const bool fused_ok = gx_ok || fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) || big_ok;
     // AUTO takes the mixed-radix kernel where it measured faster than the rocFFT pipeline (profiles/r02g_mixed.json, 2^27 samples): Welch and
     // real-signal columns up to 4096 points (1.4-3x), complex columns above (1.6x); elsewhere the two are within 20 % and rocFFT is kept.
     // Round 3: the sizes with a compile-time schedule (spectral_gen.h, Float32 / ComplexF32) beat the rocFFT pipeline 2-9x in every mode
@@ -702,7 +712,7 @@ int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) 
     // below 50000 the generic passes' small tiles lose to rocFFT at most sizes: 8400 .. 10000 0.7x, 20000 0.5x, 40000 1.0x)
     const bool pow2 = (nfft & (nfft - 1)) == 0;
     const bool big_wins = big_ok && (pow2 ? nfft >= 16384 : (nfft >= 50000 && !(kind == 1 && dtype_is_complex(dtype))));
-    const bool gen_wins = big_wins || fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
+    const bool gen_wins = gx_ok || big_wins || fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
                           (gen_size_ok(dtype, nfft) && ((nfft <= 4096) == (kind == 0 || !dtype_is_complex(dtype))));
     if (eng == MDSP_ENGINE_AUTO) eng = gen_wins ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
     if (eng == MDSP_ENGINE_FUSED && !fused_ok)
@@ -1663,6 +1673,21 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
         }
         return MDSP_OK;
     }
+    if (use_gx(pl->dtype, pl->nfft, true)) {   // run-time-schedule kernel (spectral_gx.h): partial rows per group of workgroups, same Float64 accumulator protocol
+        GxArgs g{};
+        g.s = s; g.lds_ = lds_; g.K = K; g.hop = pl->n - pl->noverlap; g.nch = nch;
+        g.n = (int)pl->n; g.nfft = (int)pl->nfft; g.nout = (int)pl->nout; g.onesided = pl->onesided; g.r = pl->r;
+        int64_t ngroups = 0;
+        MDSP_TRY((gx_launch<R, CPLX, 0>(pl->gx, g, pl->have_win ? pl->win.as<double>() : nullptr, pl->dtype, st, &ngroups, &pl->partial)));
+        const int N = (int)pl->nfft;
+        MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)nch * (size_t)N));
+        MDSP_TRY(reduce_partials(pl, pl->partial.as<double>(), pl->reduced.as<double>(), (int)ngroups, nch, N, pl->acc_fresh ? 0 : 1, st));
+        pl->acc_fresh = false;
+        pl->acc_nslices = 1;
+        pl->acc_nacc = N;
+        pl->acc_mode = CPLX ? 1 : (pl->onesided ? 3 : 4);
+        return MDSP_OK;
+    }
     if (use_big(pl->dtype, pl->nfft, true)) {   // nfft above the one-workgroup sizes: channel by channel through the multi-pass engine, same accumulator protocol
         using TT = std::conditional_t<CPLX, cx<R>, R>;
         const int64_t N = pl->nfft;
@@ -1722,6 +1747,14 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
 }  // namespace
 
 namespace mdsp {
+int gx_run(int id, const GxArgs& a, unsigned grid_x, unsigned grid_y, int threads, size_t lds_bytes, hipStream_t st) {
+    switch (id) {
+#define MDSP_GX_CASE(ID) case ID: return gx_run_##ID(a, grid_x, grid_y, threads, lds_bytes, st);
+        MDSP_GX_CASE(0) MDSP_GX_CASE(1) MDSP_GX_CASE(2) MDSP_GX_CASE(3) MDSP_GX_CASE(4) MDSP_GX_CASE(5) MDSP_GX_CASE(6) MDSP_GX_CASE(7) MDSP_GX_CASE(8) MDSP_GX_CASE(9)
+#undef MDSP_GX_CASE
+        default: MDSP_FAIL(MDSP_ERR_ASSERTION, "gx kernel id %d", id);
+    }
+}
 // Welch in the rows form of the multi-pass engine (bigfft.hip run_welch_rows): `nch` rows of S = pl->nfft complex points, K frames `hop` elements apart
 // (the rows of K transforms of nch x S points, column pass done) -> pl->reduced[row][bin] (+)= |FFT_S(frame)|^2 on the single-workgroup kernels.
 // pl: a complex, two-sided, window-free FUSED plan of S points (n = nfft = S).
@@ -1777,7 +1810,7 @@ int mdsp_welch_plan_create(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, i
         if (st == MDSP_OK && hipMemcpy(pl->win.p, window_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
             st = set_error(MDSP_ERR_DEVICE, "window upload failed");
     }
-    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, true))   // (the multi-pass engine builds its own, much shorter, tables)
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, true) && !use_gx(dtype, nfft, true))   // (the multi-pass engine and the run-time-schedule kernel build their own, much shorter, tables)
         st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
     if (st != MDSP_OK) {
         delete pl;

@@ -1,0 +1,130 @@
+// Host side of the run-time-schedule spectral kernel (gx_kernels.h; included by spectral.hip inside its anonymous namespace): which sizes it takes, the
+// split nfft = R0 x S, root tables, launch geometry.  The kernels themselves live in their own translation units (gx_inst_*.hip) behind mdsp::gx_run.
+#pragma once
+
+#include "gx_kernels.h"
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------------
+template <typename R> __global__ __launch_bounds__(256) void gx_window_kernel(const double* __restrict__ win, R* __restrict__ out, int n, int nfft) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nfft) out[i] = i < n ? (win ? (R)win[i] : (R)1) : (R)0;
+}
+
+constexpr int GX_LDS_BYTES = 160 * 1024;
+constexpr int GX_R0_MAX = 32;
+inline int gx_emax(int) { return 16; }
+inline int gx_tmax(int) { return 512; }         // GxGeo<R>::LB
+inline int gx_cu_threads(int) { return 512; }   // 256 registers per thread
+// table entries behind the buffer for a split nfft = R0 S
+inline int gx_table_entries(int64_t nfft, int64_t S, int R0) {
+    return mdsp::gx::TWS + mdsp::gx::tw_hi_entries(S) + (R0 > 1 ? mdsp::gx::TWS + mdsp::gx::tw_hi_entries(nfft) + R0 : 0);
+}
+// the split the kernel runs nfft with: the smallest R0 whose S = nfft / R0 has a schedule next to its tables (R0 = 1: the whole transform in one workgroup)
+inline bool gx_choose(int dtype, int64_t nfft, bool welch, int* R0_out, mdsp::gx::Sched* sc_out) {
+    const int esz = dtype_is_double(dtype) ? 16 : 8, emax = gx_emax(dtype);
+    const int tmax = gx_tmax(dtype);
+    if (nfft < 64 || nfft > (int64_t)GX_R0_MAX * tmax * emax || !mdsp::gx::smooth7(nfft)) return false;
+    for (int R0 = 1; R0 <= GX_R0_MAX; ++R0) {
+        if (nfft % R0 != 0) continue;
+        const int64_t S = nfft / R0;
+        if (S > (int64_t)tmax * emax || S < 16) continue;
+        const mdsp::gx::Sched sc = mdsp::gx::plan((int)S, emax, tmax, gx_cu_threads(dtype), GX_LDS_BYTES, esz, esz * gx_table_entries(nfft, S, R0),
+                                                       welch ? esz / 2 : 0);   // Welch: the sums live in LDS, one real per bin
+        if (sc.P >= 2) {
+            if (R0_out) *R0_out = R0;
+            if (sc_out) *sc_out = sc;
+            return true;
+        }
+    }
+    return false;
+}
+inline bool gx_size_ok(int dtype, int64_t nfft) {
+    static std::mutex mu;
+    static std::vector<std::pair<int64_t, bool>> memo;   // (nfft << 1 | double) -> plannable
+    const int64_t key = (nfft << 1) | (dtype_is_double(dtype) ? 1 : 0);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& e : memo)
+            if (e.first == key) return e.second;
+    }
+    const bool ok = gx_choose(dtype, nfft, true, nullptr, nullptr);
+    std::lock_guard<std::mutex> lk(mu);
+    memo.emplace_back(key, ok);
+    return ok;
+}
+
+template <typename R> int gx_prepare(GxPlan& gp, int dtype, int64_t nfft, bool welch) {
+    if (gp.ready) return MDSP_OK;
+    if (!gx_choose(dtype, nfft, welch, &gp.R0, &gp.sc)) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "nfft=%lld has no single-workgroup schedule", (long long)nfft);
+    const int64_t S = gp.sc.N;
+    gp.nhs = mdsp::gx::tw_hi_entries(S);
+    gp.nhn = gp.R0 > 1 ? mdsp::gx::tw_hi_entries(nfft) : 0;
+    const int ntab = gx_table_entries(nfft, S, gp.R0);
+    std::vector<cx<R>> tab((size_t)ntab);
+    size_t o = 0;
+    auto root = [](int64_t k, int64_t n) { return unit_root(k % n, n, -1); };
+    for (int i = 0; i < mdsp::gx::TWS; ++i) {   // W_S^i - 1: the real part as -2 sin^2 (no cancellation)
+        const long double ang = 3.141592653589793238462643383279502884L * (long double)(i % S) / (long double)S;
+        const long double sh = sinl(ang);
+        tab[o++] = {(R)(double)(-2.0L * sh * sh), (R)root(i, S).imag()};
+    }
+    for (int i = 0; i < gp.nhs; ++i) {
+        const zd w = root((int64_t)i * mdsp::gx::TWS, S);
+        tab[o++] = {(R)w.real(), (R)w.imag()};
+    }
+    if (gp.R0 > 1) {
+        for (int i = 0; i < mdsp::gx::TWS; ++i) {
+            const long double ang = 3.141592653589793238462643383279502884L * (long double)i / (long double)nfft;
+            const long double sh = sinl(ang);
+            tab[o++] = {(R)(double)(-2.0L * sh * sh), (R)root(i, nfft).imag()};
+        }
+        for (int i = 0; i < gp.nhn; ++i) {
+            const zd w = root((int64_t)i * mdsp::gx::TWS, nfft);
+            tab[o++] = {(R)w.real(), (R)w.imag()};
+        }
+        for (int i = 0; i < gp.R0; ++i) {
+            const zd w = root(i, gp.R0);
+            tab[o++] = {(R)w.real(), (R)w.imag()};
+        }
+    }
+    MDSP_TRY(gp.tw.reserve(sizeof(cx<R>) * tab.size()));
+    MDSP_HIP(hipMemcpy(gp.tw.p, tab.data(), sizeof(cx<R>) * tab.size(), hipMemcpyHostToDevice));
+    MDSP_TRY(gp.win.reserve(sizeof(R) * (size_t)nfft));
+    gp.lds_bytes = sizeof(cx<R>) * ((size_t)gp.sc.np * (size_t)gp.sc.nbuf + (size_t)ntab) + (welch ? sizeof(R) * (size_t)S : 0);
+    gp.ready = true;
+    return MDSP_OK;
+}
+
+// a.s, lds_, K, hop, nch, n, nfft, nout, onesided, psd, accumulate, r, ldo, chs, out (columns) filled by the caller
+template <typename R, bool CPLX, int MODE>
+int gx_launch(GxPlan& gp, GxArgs& a, const double* win_dev, int dtype, hipStream_t st, int64_t* ngroups_out, DevBuf* partial) {
+    MDSP_TRY(gx_prepare<R>(gp, dtype, a.nfft, MODE == 0));
+    hipLaunchKernelGGL(gx_window_kernel<R>, dim3((unsigned)cdiv(a.nfft, 256)), dim3(256), 0, st, win_dev, gp.win.as<R>(), a.n, a.nfft);
+    MDSP_LAUNCH_CHECK();
+    a.sc = gp.sc;
+    a.nbuf = gp.sc.nbuf;
+    a.R0 = gp.R0;
+    a.nhs = gp.nhs;
+    a.nhn = gp.nhn;
+    a.tw = gp.tw.p;
+    a.win = gp.win.p;
+    const bool pair = !CPLX && (MODE == 0 || gp.R0 == 1);
+    a.pairs = pair ? 1 : 0;
+    a.units_per_ch = pair ? cdiv(a.K, 2) : a.K;
+    a.flush = 64;
+    // resident workgroups: what the registers (gx_cu_threads) and the LDS admit
+    const int per_cu = std::max<int>(1, std::min<int>(gx_cu_threads(dtype) / gp.sc.T, (int)((size_t)GX_LDS_BYTES / gp.lds_bytes)));
+    int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * (tunables().wg_per_cu > 0 ? tunables().wg_per_cu : per_cu) / std::max<int64_t>(1, a.nch));
+    int64_t groups = std::max<int64_t>(1, std::min<int64_t>(a.units_per_ch, resident / gp.R0));
+    if (gp.R0 > 1) groups = cdiv(groups, 8) * 8;   // the kernel's XCD mapping walks groups in eights
+    a.per_slot = cdiv(a.units_per_ch, groups);
+    if (gp.R0 == 1) groups = cdiv(a.units_per_ch, a.per_slot);
+    *ngroups_out = groups;
+    if (MODE == 0) {
+        MDSP_TRY(partial->reserve(sizeof(double) * (size_t)groups * (size_t)a.nch * (size_t)a.nfft));
+        a.out = partial->p;
+    }
+    if (!CPLX && MODE == 0 && !pair) MDSP_FAIL(MDSP_ERR_ASSERTION, "Welch sums always pair real frames");
+    const int id = (sizeof(R) == 8 ? 5 : 0) + (MODE == 0 ? (CPLX ? 1 : 0) : (CPLX ? 2 : (pair ? 3 : 4)));
+    return mdsp::gx_run(id, a, (unsigned)(groups * gp.R0), (unsigned)a.nch, gp.sc.T, gp.lds_bytes, st);
+}
