@@ -242,7 +242,8 @@ class Marks:
             "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64",
             # round 5
             "decim16_f32", "resample_441_160_c64", "welch_default", "welch_default_2p24", "spectrogram_default", "filt_32768", "filt_f64", "welch_f64",
-            "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt", "welch_2p19")
+            "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt", "welch_2p19",
+            "welch_8192", "welch_12500", "welch_16384", "welch_65536", "welch_125000")
 
     def __init__(self, lib, _lib, stream):
         import torch
@@ -290,10 +291,15 @@ ROW_INFO = {
     "welch_1536": ("gen_ct_kernel<1536>", "2^27 Float32, n = nfft = 1536", "4"),
     "welch_default": ("multi-pass engine (bigfft.hip)", "welch_pgram(s) with DEFAULT arguments, 2^27 Float32: n = nfft = 2^24, 15 frames", "4"),
     "welch_default_2p24": ("multi-pass engine", "welch_pgram(s), 2^24 Float32: n = nfft = 2^21", "4"),
+    "welch_8192": ("welch_half_kernel<8192>", "2^27 Float32, n = nfft = 8192, 50 % overlap (the largest register-resident power of two: the yardstick of the sizes above it)", "4"),
+    "welch_12500": ("gx_kernel (run-time schedule, csrc/gx_kernels.h)", "2^27 Float32, n = nfft = 12500 = nextfastfft(10^5 >> 3), 50 % overlap", "4"),
+    "welch_16384": ("gx_kernel, 2 x 8192 (column step fused into the loads)", "2^27 Float32, n = nfft = 16384, 50 % overlap", "4"),
+    "welch_65536": ("multi-pass engine, 256 x 256", "2^27 Float32, n = nfft = 65536, 50 % overlap", "4"),
+    "welch_125000": ("multi-pass engine, 250 x 500 (generic phases)", "2^27 Float32, n = nfft = 125000 = nextfastfft(10^6 >> 3), 50 % overlap", "4"),
     "welch_2p19": ("multi-pass engine, rows form (column pass + single-workgroup Welch kernel over the rows)", "2^27 Float32, n = nfft = 2^19, 50 % overlap: 511 frames", "4"),
     "spectrogram_default": ("multi-pass engine + untangle", "spectrogram(s) with DEFAULT arguments, 2^27 Float32 -> (2^23 + 1) x 15 Float32", "4 in + 4 per bin out"),
     "filt_5120": ("upols2_fused_kernel", "filt, 5120 taps, 2^28 Float32", "8"),
-    "filt_32768": ("d.filt(b, x) through the host mirror: segments of 16384 taps on the fused engine + mdsp_shift_add", "32768 taps, 2^27 Float32", "8"),
+    "filt_32768": ("d.filt(b, x) through the host mirror: ONE plan, rows form of the multi-pass engine (column pass, row kernel, column pass back)", "32768 taps, 2^27 Float32", "8"),
     "filt_f64": ("ols_fused_kernel<double>", "the headline filt in Float64: 256 taps, nfft 2048, 2^29 samples", "16"),
     "welch_f64": ("welch_half_kernel<double>", "the headline welch_pgram in Float64: nfft 4096, 2^29 samples", "8"),
     "welch_f64_5000": ("gen_ct_kernel<double, 5000>", "2^27 Float64, n = nfft = 5000", "8"),
@@ -506,6 +512,17 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
         rows["welch_2p19"] = crow(tm, med, 4.0 * n3, engine=cfg.engine)
 
     guarded("welch_2p19", welch_2p19)
+
+    # (round 6) the sizes either side of the old cliff at 8192 points: nextfastfft sizes of 10^5- and 10^6-sample default calls, 2^14, 2^16
+    def welch_n(nfft):
+        cfg = d.WelchConfig(n3, np.float32, n=nfft, noverlap=nfft // 2, nfft=nfft, window=d.hanning)   # AUTO
+        psd = torch.empty(cfg.nout, dtype=torch.float32, device="cuda")
+        mark(f"welch_{nfft}")
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xr.data_ptr(), n3, 1, n3, psd.data_ptr(), cfg.nout, stream)))
+        rows[f"welch_{nfft}"] = crow(tm, med, 4.0 * n3, engine=cfg.engine)
+
+    for nfft_ in (8192, 12500, 16384, 65536, 125000):
+        guarded(f"welch_{nfft_}", lambda nfft_=nfft_: welch_n(nfft_))
 
     def spectrogram_default():
         nn = n3 >> 3

@@ -75,7 +75,6 @@ PROTOTYPES = {
     "mdsp_ols_plan_geometry": (ci, [vp, pi64, pi64, pint]),
     "mdsp_ols_geometry_for": (ci, [i64, i64, i64, ci, ci, ci, pi64, pi64, pint, pint, pint]),
     "mdsp_ols_exec": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, vp]),
-    "mdsp_shift_add": (ci, [vp, vp, i64, i64, i64, i64, i64, ci, vp]),
     "mdsp_ols_exec_range": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, i64, vp]),
     "mdsp_ols_exec_host": (ci, [vp, vp, i64, i64, i64, vp, i64, i64, ci]),
     "mdsp_ols_segment": (ci, [vp, vp, i64, i64, i64, vp, vp]),

@@ -65,16 +65,20 @@ int* fir_choice_field(Tunables& t, int index) {
         default: return nullptr;
     }
 }
-// the choice file: malformed lines are skipped (a cache, not a configuration), '#' starts a comment
+// The choice file: OPT-IN (round 6) -- read only when MDSP_FIR_CHOICE_FILE names it; a drop-in keeps no hidden per-user state (up to round 5 the library
+// also looked under ~/.cache).  Its first line must be the key  "# mi355dsp-fir-choices v<library version> gfx950"  (a file measured with another library
+// version or on another architecture is ignored as a whole); malformed lines are skipped, '#' starts a comment, knob values are clamped to [-1, 64].
 static void read_fir_choices(Tunables& t) {
-    std::string path;
-    if (const char* e = getenv("MDSP_FIR_CHOICE_FILE")) path = e;
-    else if (const char* x = getenv("XDG_CACHE_HOME")) path = std::string(x) + "/mi355dsp/fir_choice.txt";
-    else if (const char* h = getenv("HOME")) path = std::string(h) + "/.cache/mi355dsp/fir_choice.txt";
-    if (path.empty()) return;
-    FILE* f = fopen(path.c_str(), "r");
+    const char* path = getenv("MDSP_FIR_CHOICE_FILE");
+    if (!path || !*path) return;
+    FILE* f = fopen(path, "r");
     if (!f) return;
-    char line[1024];
+    char line[1024], key[96];
+    snprintf(key, sizeof key, "# mi355dsp-fir-choices v%d gfx950", mdsp_version());
+    if (!fgets(line, sizeof line, f) || strncmp(line, key, strlen(key)) != 0) {
+        fclose(f);
+        return;
+    }
     while (fgets(line, sizeof line, f)) {
         if (line[0] == '#') continue;
         FirChoice c;
@@ -90,7 +94,7 @@ static void read_fir_choices(Tunables& t) {
             const int idx = fir_choice_index(name);
             if (idx >= 0) {
                 c.field[c.nset] = idx;
-                c.value[c.nset] = v;
+                c.value[c.nset] = v < -1 ? -1 : (v > 64 ? 64 : v);
                 ++c.nset;
             }
             p += adv;

@@ -11,8 +11,10 @@ namespace big {
 bool size_ok(int dtype, int64_t nfft);
 
 struct Engine;
-struct EngineHolder {   // a plan's engine (created on first use; one per plan, so one owner and one stream at a time like the plan itself)
-    Engine* p = nullptr;
+struct EngineHolder {   // a plan's engines (created on first use; one holder per plan, so one owner and one stream at a time like the plan itself)
+    Engine* p = nullptr;      // the passes form (natural-order spectra, 2 .. 4 passes)
+    Engine* rows = nullptr;   // the rows form (column pass + single-workgroup row kernel): kept NEXT to the other -- a streaming plan whose chunk sizes
+                              // vary takes either per call, and up to round 5 every flip freed one engine's work buffers and rebuilt the other's
     EngineHolder() = default;
     EngineHolder(const EngineHolder&) = delete;
     EngineHolder& operator=(const EngineHolder&) = delete;

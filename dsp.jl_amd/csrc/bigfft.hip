@@ -52,7 +52,10 @@ struct Engine {
         if (rowplan) mdsp_welch_plan_destroy(rowplan);
     }
 };
-EngineHolder::~EngineHolder() { delete p; }
+EngineHolder::~EngineHolder() {
+    delete p;
+    delete rows;
+}
 
 namespace {
 
@@ -534,24 +537,24 @@ template <typename R> int build_rows(Engine* e, int R0) {
 }
 
 int get_engine_rows(EngineHolder& h, int dtype, int64_t n, int64_t nfft, int R0, Engine** out) {
-    if (h.p && (h.p->dtype != dtype || h.p->n != n || h.p->rowsR0 != R0 || h.p->nfft != nfft)) {
-        delete h.p;
-        h.p = nullptr;
+    if (h.rows && (h.rows->dtype != dtype || h.rows->n != n || h.rows->rowsR0 != R0 || h.rows->nfft != nfft)) {
+        delete h.rows;
+        h.rows = nullptr;
     }
-    if (!h.p) {
+    if (!h.rows) {
         std::unique_ptr<Engine> e(new Engine());
         e->dtype = dtype;
         e->n = n;
         e->nfft = nfft;
         MDSP_TRY(dtype_is_double(dtype) ? build_rows<double>(e.get(), R0) : build_rows<float>(e.get(), R0));
-        h.p = e.release();
+        h.rows = e.release();
     }
-    *out = h.p;
+    *out = h.rows;
     return MDSP_OK;
 }
 
 int get_engine(EngineHolder& h, int dtype, int64_t n, int64_t nfft, Engine** out) {
-    if (h.p && (h.p->dtype != dtype || h.p->n != n || h.p->nfft != nfft || h.p->rowsR0 != 0)) {
+    if (h.p && (h.p->dtype != dtype || h.p->n != n || h.p->nfft != nfft)) {
         delete h.p;
         h.p = nullptr;
     }

@@ -182,8 +182,8 @@ int mdsp_welch_mean_allreduce(mdsp_welch_plan plan, const void* psd_dev, int64_t
 int mdsp_welch_allreduce(mdsp_welch_plan plan, mdsp_comm comm, void* stream) {
     if (!plan) MDSP_FAIL(MDSP_ERR_ARGUMENT, "plan is NULL");
     if (!comm || comm->nranks <= 1) return MDSP_OK;
-    if (plan->frames_on_device)   // the sums already are totals over ranks: reducing them again would count every rank's frames nranks times while the count is re-seeded
-        MDSP_FAIL(MDSP_ERR_ARGUMENT, "these sums have been all-reduced already (mdsp_welch_reset or mdsp_welch_accumulate first)");
+    if (plan->sums_global)   // the sums already are totals over ranks: reducing them again would count every rank's frames nranks times while the count is re-seeded
+        MDSP_FAIL(MDSP_ERR_ARGUMENT, "these sums have been all-reduced already (mdsp_welch_reset, then accumulate this rank's frames again)");
     void* acc = nullptr;
     int64_t count = 0;
     MDSP_TRY(mdsp_welch_accumulator(plan, &acc, &count));
@@ -198,6 +198,7 @@ int mdsp_welch_allreduce(mdsp_welch_plan plan, mdsp_comm comm, void* stream) {
     for (ncclResult_t r : {r1, r2, r3})
         if (r != ncclSuccess) MDSP_FAIL(MDSP_ERR_DEVICE, "ncclAllReduce (Welch sums + frame count) failed: %s", rccl().GetErrorString(r));
     plan->frames_on_device = true;
+    plan->sums_global = true;
     plan->count_stream = st;   // mdsp_welch_frames_accumulated reads the count behind THIS stream's work
     return MDSP_OK;
 }

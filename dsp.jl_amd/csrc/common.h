@@ -108,7 +108,7 @@ constexpr int slots_per_workgroup(int T) { return MDSP_COUPLED_SLOTS ? (T >= 256
 // Optional tuning variables (DESIGN.md section 5 "Tuning knobs") are read from the environment ONCE -- by mdsp_init(), or on
 // first use -- into this struct; exec / plan paths only ever look at the struct.  mdsp_reload_tunables() re-reads them
 // (tools/tune.py sweeps variants inside one process).  None changes results beyond rounding.
-// One line of the polyphase choice file (MDSP_FIR_CHOICE_FILE, default $XDG_CACHE_HOME/mi355dsp/fir_choice.txt or ~/.cache/mi355dsp/fir_choice.txt):
+// One line of the polyphase choice file (read only when MDSP_FIR_CHOICE_FILE names one; first line: "# mi355dsp-fir-choices v<version> gfx950"):
 //     L M ntaps taps_dtype x_dtype KNOB=value[,KNOB=value ...]          e.g.   1 16 583 0 0 MDSP_FIR_MM_CH=1
 // -- the polyphase knobs a box's own measurement (tools/tune_fir.py TUNE_PERSIST=1) found faster than the library's rule for that shape.  The dispatch of a
 // filter with that shape runs under those values (FirChoiceScope, fir.hip); every other shape and every other kernel family is untouched.

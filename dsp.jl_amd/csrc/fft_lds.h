@@ -670,19 +670,21 @@ template <typename R> MDSP_HD void bfly7f(cx<R> (&v)[7]) {
     constexpr R s1 = (R)0.78183148246802980870844452667406L, s2 = (R)0.97492791218182360701813168299393L, s3 = (R)0.43388373911755812047576833284836L;
     const cx<R> t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
     const cx<R> u1 = csub(v[1], v[6]), u2 = csub(v[2], v[5]), u3 = csub(v[3], v[4]);
-    const cx<R> m1 = {v[0].x + c1 * t1.x + c2 * t2.x + c3 * t3.x, v[0].y + c1 * t1.y + c2 * t2.y + c3 * t3.y};
-    const cx<R> m2 = {v[0].x + c2 * t1.x + c3 * t2.x + c1 * t3.x, v[0].y + c2 * t1.y + c3 * t2.y + c1 * t3.y};
-    const cx<R> m3 = {v[0].x + c3 * t1.x + c1 * t2.x + c2 * t3.x, v[0].y + c3 * t1.y + c1 * t2.y + c2 * t3.y};
-    const cx<R> n1 = mul_mi<-1>(cx<R>{s1 * u1.x + s2 * u2.x + s3 * u3.x, s1 * u1.y + s2 * u2.y + s3 * u3.y});
-    const cx<R> n2 = mul_mi<-1>(cx<R>{s2 * u1.x - s3 * u2.x - s1 * u3.x, s2 * u1.y - s3 * u2.y - s1 * u3.y});
-    const cx<R> n3 = mul_mi<-1>(cx<R>{s3 * u1.x - s1 * u2.x + s2 * u3.x, s3 * u1.y - s1 * u2.y + s2 * u3.y});
+    // (round 6: chains of packed multiply-adds with the constant as the scalar operand, as the radix-5 butterfly -- the component-wise form compiled to
+    // twice as many unpacked instructions)
+    const cx<R> m1 = caxpy_k(c3, t3, caxpy_k(c2, t2, caxpy_k(c1, t1, v[0])));
+    const cx<R> m2 = caxpy_k(c1, t3, caxpy_k(c3, t2, caxpy_k(c2, t1, v[0])));
+    const cx<R> m3 = caxpy_k(c2, t3, caxpy_k(c1, t2, caxpy_k(c3, t1, v[0])));
+    const cx<R> n1 = caxpy_k(s3, u3, caxpy_k(s2, u2, cscale_k(s1, u1)));    // times -i below
+    const cx<R> n2 = caxmy_k(s1, u3, caxmy_k(s3, u2, cscale_k(s2, u1)));
+    const cx<R> n3 = caxpy_k(s2, u3, caxmy_k(s1, u2, cscale_k(s3, u1)));
     v[0] = cadd(v[0], cadd(t1, cadd(t2, t3)));
-    v[1] = cadd(m1, n1);
-    v[6] = csub(m1, n1);
-    v[2] = cadd(m2, n2);
-    v[5] = csub(m2, n2);
-    v[3] = cadd(m3, n3);
-    v[4] = csub(m3, n3);
+    v[1] = add_mi<-1>(m1, n1);
+    v[6] = sub_mi<-1>(m1, n1);
+    v[2] = add_mi<-1>(m2, n2);
+    v[5] = sub_mi<-1>(m2, n2);
+    v[3] = add_mi<-1>(m3, n3);
+    v[4] = sub_mi<-1>(m3, n3);
 }
 // ---- composite radices (round 4): 6, 10, 12, 15, 20, 24, 25 as two levels of the small butterflies INSIDE the registers of one thread -------------
 // A pass of radix R1 R2 replaces two passes (one LDS round trip and one barrier less): 3000 = 5 x 24 x 25 runs three passes instead of the five

@@ -2060,9 +2060,11 @@ struct FirChoiceScope {
     bool on = false;
     explicit FirChoiceScope(const mdsp_fir_s* f) {
         const Tunables& base = tunables();
+        if (base.fir_choices.empty()) return;   // (the usual case: no choice file named)
         for (const FirChoice& c : base.fir_choices) {
             if (c.L != f->L || c.M != f->M || c.hlen != f->hlen || c.taps_dtype != f->taps_dtype || c.x_dtype != f->x_dtype) continue;
             t = base;
+            t.fir_choices.clear();   // the view carries the knob values only
             for (int i = 0; i < c.nset; ++i)
                 if (int* field = fir_choice_field(t, c.field[i])) *field = c.value[i];
             prev = tunables_override(&t);

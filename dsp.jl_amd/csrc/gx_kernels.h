@@ -82,10 +82,12 @@ template <typename R, typename TT, bool PAIR> __device__ __forceinline__ cx<R> w
 // MODE 0: Welch sums; 1: columns (STFT raw or PSD).  PAIR: real signal, two frames per transform (Welch always; columns when R0 == 1).
 template <typename R> struct GxGeo {
     static constexpr int EMAX = 16;   // points per thread and pass
-    static constexpr int LB = 512;    // threads per workgroup at most: 256 registers per thread
+    static constexpr int LB = 512;    // threads per workgroup at most
+    static constexpr int MINW = sizeof(R) == 8 ? 2 : 4;   // waves per SIMD the kernel is compiled for: Float32 128 registers per thread (two 512-thread workgroups per CU where the LDS admits them), Float64 256
 };
-template <typename R, bool CPLX, int MODE, bool PAIR>
-__global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
+// COL: nfft = R0 x S with R0 > 1 -- the decimation-in-frequency step in front of the first pass (its own instantiation: neither form carries the other's registers)
+template <typename R, bool CPLX, int MODE, bool PAIR, bool COL>
+__global__ __launch_bounds__(GxGeo<R>::LB, GxGeo<R>::MINW) void gx_kernel(GxArgs a) {
     using namespace mdsp;
     using mdsp::fft::cx;
     using TT = std::conditional_t<CPLX, cx<R>, R>;
@@ -94,14 +96,15 @@ __global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gx_smem[];
     const gx::Sched& s = a.sc;
     const int S = s.N, T = s.T, t = threadIdx.x, PL = s.P - 1;
-    cx<R>* buf0 = reinterpret_cast<cx<R>*>(gx_smem);
-    cx<R>* buf1 = a.nbuf == 2 ? buf0 + s.np : buf0;
-    cx<R>* lo1 = buf0 + a.nbuf * s.np;
+    // LDS: the root tables first (fixed addresses: a twiddle fetch is  and / shift + an immediate), then the buffer(s), then the Welch sums
+    cx<R>* lo1 = reinterpret_cast<cx<R>*>(gx_smem);
     cx<R>* hiS = lo1 + gx::TWS;
     cx<R>* lo1N = hiS + a.nhs;                                     // (R0 > 1 only: the three tables of the column step)
     cx<R>* hiN = lo1N + gx::TWS;
     cx<R>* cw = hiN + a.nhn;
-    R* accl = reinterpret_cast<R*>(a.R0 > 1 ? cw + a.R0 : lo1N);   // MODE 0: S sums, natural bin order
+    cx<R>* buf0 = a.R0 > 1 ? cw + a.R0 : lo1N;
+    cx<R>* buf1 = a.nbuf == 2 ? buf0 + s.np : buf0;
+    R* accl = reinterpret_cast<R*>(buf0 + a.nbuf * s.np);          // MODE 0: S sums, natural bin order
     {
         const int ntab = gx::TWS + a.nhs + (a.R0 > 1 ? gx::TWS + a.nhn + a.R0 : 0);
         const cx<R>* g = static_cast<const cx<R>*>(a.tw);
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
     const int64_t ch = blockIdx.y;
     const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
     const int64_t u0 = g * a.per_slot;
-    const bool col = a.R0 > 1;
+    constexpr bool col = COL;
     const int E = (S + T - 1) / T;   // natural-order points of a thread: t + T e, e < E <= EMAX
     double* part = MODE == 0 ? static_cast<double*>(a.out) + (g * a.nch + ch) * (int64_t)a.nfft + k1 : nullptr;
     bool flushed = false;
@@ -136,9 +139,10 @@ __global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
         fa = sc + f0 * a.hop;
     };
     // the samples of a unit in natural order, one VGPR offset + scalar offsets; a frame that does not exist reads zeros through an empty descriptor
-    TT pa[EMAX], pb[PAIR ? EMAX : 1];
-    R w[EMAX];
+    TT pa[COL ? 1 : EMAX], pb[(PAIR && !COL) ? EMAX : 1];
+    R w[COL ? 1 : EMAX];
     auto issue = [&](int64_t it) __attribute__((always_inline)) {
+        if constexpr (!COL) {
         const TT* fa;
         bool live, haveB;
         unit_frame(it, fa, live, haveB);
@@ -162,8 +166,9 @@ __global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
                     for (int e = e0; e < e0 + 4; ++e) pb[e] = gxk::load_so<TT>(db, off, T * e * SZ);
                 }
         }
+        }
     };
-    if (!col) {
+    if constexpr (!col) {
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) w[e] = gxk::load_so<R>(dw, t * WZ, T * e * WZ);   // (past nfft: 0 -- those points are never stored)
         issue(0);
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
         // ---- the windowed frame (pair), natural order, into the buffer the first pass reads
         {
             cx<R>* dst = cur ? buf1 : buf0;
-            if (!col) {
+            if constexpr (!col) {
 #pragma unroll
                 for (int e0 = 0; e0 < EMAX; e0 += 4)
                     if (e0 < E) {
@@ -244,21 +249,23 @@ __global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
             cx<R>* src = cur ? buf1 : buf0;
             cx<R>* dst = (cur ^ (a.nbuf - 1)) ? buf1 : buf0;
             const bool inplace = a.nbuf == 1;
+            const gx::Pass ps = gx::pass_of(s, p);
+            const int radix = s.radix[p];
 #define MDSP_GX_F(RR)                                                                                                              \
     {                                                                                                                              \
         cx<R> v[EMAX];                                                                                                             \
-        gx::pass_read<RR, EMAX>(s, p, tl, src, v);                                                                                  \
+        gx::pass_read<RR, EMAX>(ps, tl, src, v);                                                                                  \
         if (inplace) __syncthreads();   /* every operand is in registers: the buffer may be overwritten */                          \
-        gx::pass_butterflies<RR, EMAX>(s, p, tl, v, lo1, hiS);                                                                      \
+        gx::pass_butterflies<RR, EMAX>(ps, tl, v, lo1, hiS);                                                                      \
         if (p < PL) {                                                                                                              \
-            gx::pass_write<RR, EMAX>(s, p, tl, dst, v);                                                                             \
+            gx::pass_write<RR, EMAX>(ps, tl, dst, v);                                                                             \
         } else if constexpr (MODE == 0) {                                                                                          \
             /* (a unit that does not exist transformed zeros and adds nothing) */                                                  \
-            gx::last_consume<RR, EMAX>(s, tl, v, [&](int, unsigned bin, cx<R> z) {                                                  \
+            gx::last_consume<RR, EMAX>(ps, tl, v, [&](int, unsigned bin, cx<R> z) {                                                  \
                 accl[bin] += z.x * z.x + z.y * z.y;   /* the bin is this thread's alone (an LDS atomic runs at a fraction of the rate) */           \
             });                                                                                                                    \
         } else if constexpr (!PAIR) {   /* complex signal (or a real one, one frame per transform, R0 > 1): bins straight from registers */ \
-            gx::last_consume<RR, EMAX>(s, tl, v, [&](int, unsigned bin, cx<R> z) {                                                  \
+            gx::last_consume<RR, EMAX>(ps, tl, v, [&](int, unsigned bin, cx<R> z) {                                                  \
                 const int k = k1 + (int)bin * a.R0;                                                                                \
                 if (live && k < a.nout) {                                                                                          \
                     if (a.psd) {                                                                                                   \
@@ -271,10 +278,10 @@ __global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
                 }                                                                                                                  \
             });                                                                                                                    \
         } else {   /* real pairs: the natural-order spectrum goes through LDS once more (below) */                                \
-            gx::pass_write_natural<RR, EMAX>(s, tl, dst, v);                                                                        \
+            gx::pass_write_natural<RR, EMAX>(ps, tl, dst, v);                                                                        \
         }                                                                                                                          \
     }
-            MDSP_GX_SWITCH(s.radix[p], MDSP_GX_F)
+            MDSP_GX_SWITCH(radix, MDSP_GX_F)
 #undef MDSP_GX_F
             if (p < PL) {
                 __syncthreads();
@@ -339,7 +346,8 @@ __global__ __launch_bounds__(GxGeo<R>::LB) void gx_kernel(GxArgs a) {
 }
 
 // ---- one kernel per translation unit (gx_inst_<id>.hip: a gx_kernel instantiation takes minutes to compile -- 22 unrolled radix cases at three sites) -----
-// id = 5 * double + {0: Welch real pairs, 1: Welch complex, 2: columns complex, 3: columns real pairs, 4: columns real, one frame per transform (R0 > 1)}
+// id = 10 * (R0 > 1) + 5 * double + {0: Welch real pairs, 1: Welch complex, 2: columns complex, 3: columns real pairs, 4: columns real, one frame per
+// transform (R0 > 1 only)}
 namespace mdsp {
 int gx_run(int id, const GxArgs& a, unsigned grid_x, unsigned grid_y, int threads, size_t lds_bytes, hipStream_t st);
 template <typename K> inline int gx_launch_kernel(K kern, const GxArgs& a, unsigned grid_x, unsigned grid_y, int threads, size_t lds_bytes, hipStream_t st) {
@@ -349,6 +357,7 @@ template <typename K> inline int gx_launch_kernel(K kern, const GxArgs& a, unsig
     return MDSP_OK;
 }
 #define MDSP_GX_DECL(ID) int gx_run_##ID(const GxArgs& a, unsigned grid_x, unsigned grid_y, int threads, size_t lds_bytes, hipStream_t st);
-MDSP_GX_DECL(0) MDSP_GX_DECL(1) MDSP_GX_DECL(2) MDSP_GX_DECL(3) MDSP_GX_DECL(4) MDSP_GX_DECL(5) MDSP_GX_DECL(6) MDSP_GX_DECL(7) MDSP_GX_DECL(8) MDSP_GX_DECL(9)
+MDSP_GX_DECL(0) MDSP_GX_DECL(1) MDSP_GX_DECL(2) MDSP_GX_DECL(3) MDSP_GX_DECL(5) MDSP_GX_DECL(6) MDSP_GX_DECL(7) MDSP_GX_DECL(8)
+MDSP_GX_DECL(10) MDSP_GX_DECL(11) MDSP_GX_DECL(12) MDSP_GX_DECL(14) MDSP_GX_DECL(15) MDSP_GX_DECL(16) MDSP_GX_DECL(17) MDSP_GX_DECL(19)
 #undef MDSP_GX_DECL
 }  // namespace mdsp

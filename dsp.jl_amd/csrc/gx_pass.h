@@ -32,33 +32,50 @@ template <typename R> MDSP_HD cx<R> tw2(const cx<R>* lo1, const cx<R>* hi, unsig
     return fft::cadd(h, fft::cmul(h, d));
 }
 
-// butterfly m of thread t in pass p: index (clamped to a valid one for the idle lanes of a partial last trip), whether it exists, j div Ns, j mod Ns
+#ifndef MDSP_GX_TW_CHUNK
+#define MDSP_GX_TW_CHUNK 4
+#endif
+// what a pass needs of the schedule, fetched once per pass (the kernel reads the schedule from its argument block: a fetch per use is a scalar load and a
+// wait that also drains the wave's LDS queue)
+struct Pass {
+    int T, M, nbf, ns, stride, gin, rstride, gstride;
+    unsigned divm;
+    bool first;   // pass 0: no twiddles
+};
+MDSP_HD Pass pass_of(const Sched& s, int p) {
+    Pass q;
+    q.T = s.T; q.M = s.M[p]; q.nbf = s.nbf[p]; q.ns = s.ns[p]; q.stride = s.stride[p]; q.gin = s.gin[p]; q.rstride = s.rstride[p]; q.gstride = s.gstride[p];
+    q.divm = s.divm[p];
+    q.first = p == 0;
+    return q;
+}
+
+// butterfly m of thread t in a pass: index (a valid one for the idle lanes of a partial last trip), whether it exists, j div Ns, j mod Ns
 struct Bf {
     unsigned j, hi, k;
     bool on;
 };
-MDSP_HD Bf bf_of(const Sched& s, int p, int t, int m) {
+MDSP_HD Bf bf_of(const Pass& ps, int t, int m) {
     Bf b;
-    const unsigned j0 = (unsigned)(t + s.T * m);
-    b.on = j0 < (unsigned)s.nbf[p];
+    const unsigned j0 = (unsigned)(t + ps.T * m);
+    b.on = j0 < (unsigned)ps.nbf;
     b.j = b.on ? j0 : 0u;   // butterfly 0 exists in every pass
-    b.hi = s.ns[p] > 1 ? mulhi_u32(b.j, s.divm[p]) : b.j;
-    b.k = b.j - b.hi * (unsigned)s.ns[p];
+    b.hi = ps.ns > 1 ? mulhi_u32(b.j, ps.divm) : b.j;
+    b.k = b.j - b.hi * (unsigned)ps.ns;
     return b;
 }
 
-// operands of the thread's butterflies of pass p >= 1 into v[m RR + q]
-template <int RR, int EMAX, typename R> MDSP_HD void pass_read(const Sched& s, int p, int t, const cx<R>* lds, cx<R> (&v)[EMAX]) {
+// operands of the thread's butterflies into v[m RR + q]
+template <int RR, int EMAX, typename R> MDSP_HD void pass_read(const Pass& ps, int t, const cx<R>* lds, cx<R> (&v)[EMAX]) {
     constexpr int MMAX = EMAX / RR;
-    const int M = s.M[p];
-    const unsigned rs = (unsigned)s.rstride[p];
+    const unsigned rs = (unsigned)ps.rstride;
 #pragma unroll
     for (int m = 0; m < MMAX; ++m) {
-        if (m < M) {
-            const Bf b = bf_of(s, p, t, m);
-            const unsigned jb = b.j + (s.gin[p] ? b.hi : 0u);
+        if (m < ps.M) {
+            const Bf b = bf_of(ps, t, m);
+            const cx<R>* o = lds + b.j + (ps.gin ? b.hi : 0u);   // (one address, stepped: a product per operand is a quarter-rate multiply-add each)
 #pragma unroll
-            for (int q = 0; q < RR; ++q) v[m * RR + q] = fft::ld2(lds + jb + rs * (unsigned)q);
+            for (int q = 0; q < RR; ++q, o += rs) v[m * RR + q] = fft::ld2(o);
         } else {   // defined on every path: an undefined slot becomes a value carried around the unit loop (and spilled across every radix case)
 #pragma unroll
             for (int q = 0; q < RR; ++q) v[m * RR + q] = cx<R>{(R)0, (R)0};
@@ -68,103 +85,84 @@ template <int RR, int EMAX, typename R> MDSP_HD void pass_read(const Sched& s, i
     for (int i = MMAX * RR; i < EMAX; ++i) v[i] = cx<R>{(R)0, (R)0};
 }
 
-// twiddles (p >= 1) + butterflies of pass p on v[]; results stay in v[m RR + q] = output q of butterfly m
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MDSP_GX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define MDSP_GX_SCHED_FENCE() (void)0
-#endif
-template <int RR, int EMAX, typename R> MDSP_HD void pass_butterflies(const Sched& s, int p, int t, cx<R> (&v)[EMAX], const cx<R>* lo1, const cx<R>* hi) {
+// twiddles (behind the first pass) + butterflies on v[]; results stay in v[m RR + q] = output q of butterfly m
+template <int RR, int EMAX, typename R> MDSP_HD void pass_butterflies(const Pass& ps, int t, cx<R> (&v)[EMAX], const cx<R>* lo1, const cx<R>* hi) {
     constexpr int MMAX = EMAX / RR;
-    const int M = s.M[p];
 #pragma unroll
     for (int m = 0; m < MMAX; ++m) {
-        if (m < M) {
-            cx<R> u[RR];
+        if (m < ps.M) {
+            cx<R>(&u)[RR] = *reinterpret_cast<cx<R>(*)[RR]>(&v[m * RR]);   // the butterfly's slice of v[], in place
+            if (!ps.first) {
+                const Bf b = bf_of(ps, t, m);
+                const unsigned e1 = b.k * (unsigned)ps.stride;   // q e1 < N for q < RR
+                // the table reads of up to CH twiddles are issued together, then consumed (one read pair at a time, each behind its own wait, was
+                // what the compiler made of the plain loop: the full LDS latency per twiddle)
+                constexpr int CH = sizeof(R) == 8 ? 8 : MDSP_GX_TW_CHUNK;
+                unsigned e = 0;
 #pragma unroll
-            for (int q = 0; q < RR; ++q) u[q] = v[m * RR + q];
-            if (p > 0) {
-                const Bf b = bf_of(s, p, t, m);
-                const unsigned e1 = b.k * (unsigned)s.stride[p];   // q e1 < N for q < RR
-                // four table twiddles in flight at a time: hoisted all together, the 2 (RR - 1) LDS reads of a radix-16 butterfly are 60 registers
+                for (int q0 = 1; q0 < RR; q0 += CH) {
+                    cx<R> h[CH], d[CH];
 #pragma unroll
-                for (int q0 = 1; q0 < RR; q0 += 4) {
+                    for (int q = q0; q < q0 + CH && q < RR; ++q) {
+                        e += e1;   // q e1
+                        h[q - q0] = fft::ld2(hi + (e >> TWS_LOG));
+                        d[q - q0] = fft::ld2(lo1 + (e & (unsigned)(TWS - 1)));
+                    }
 #pragma unroll
-                    for (int q = q0; q < q0 + 4 && q < RR; ++q) u[q] = fft::cmul(u[q], tw2(lo1, hi, (unsigned)q * e1));
-                    MDSP_GX_SCHED_FENCE();
+                    for (int q = q0; q < q0 + CH && q < RR; ++q) u[q] = fft::cmul(u[q], fft::cadd(h[q - q0], fft::cmul(h[q - q0], d[q - q0])));
                 }
             }
             fft::gen_bfly<RR>(u);
-#pragma unroll
-            for (int q = 0; q < RR; ++q) v[m * RR + q] = u[q];
         }
     }
 }
 
-// scatter of pass p < P - 1:  (j div Ns) gstride + k + Ns q
-template <int RR, int EMAX, typename R> MDSP_HD void pass_write(const Sched& s, int p, int t, cx<R>* lds, const cx<R> (&v)[EMAX]) {
+// scatter of a pass that is not the last:  (j div Ns) gstride + k + Ns q
+template <int RR, int EMAX, typename R> MDSP_HD void pass_write(const Pass& ps, int t, cx<R>* lds, const cx<R> (&v)[EMAX]) {
     constexpr int MMAX = EMAX / RR;
-    const int M = s.M[p];
-    const unsigned ns = (unsigned)s.ns[p];
+    const unsigned ns = (unsigned)ps.ns;
 #pragma unroll
     for (int m = 0; m < MMAX; ++m) {
-        if (m < M) {
-            const Bf b = bf_of(s, p, t, m);
+        if (m < ps.M) {
+            const Bf b = bf_of(ps, t, m);
             if (b.on) {
-                cx<R>* o = lds + b.hi * (unsigned)s.gstride[p] + b.k;
+                cx<R>* o = lds + b.hi * (unsigned)ps.gstride + b.k;
 #pragma unroll
-                for (int q = 0; q < RR; ++q) fft::st2(o + ns * (unsigned)q, v[m * RR + q]);
+                for (int q = 0; q < RR; ++q, o += ns) fft::st2(o, v[m * RR + q]);
             }
         }
     }
 }
 
 // natural-order write of the LAST pass (real-signal columns read the mirror bin of another thread): bin j + nbf q, no padding
-template <int RR, int EMAX, typename R> MDSP_HD void pass_write_natural(const Sched& s, int t, cx<R>* lds, const cx<R> (&v)[EMAX]) {
+template <int RR, int EMAX, typename R> MDSP_HD void pass_write_natural(const Pass& ps, int t, cx<R>* lds, const cx<R> (&v)[EMAX]) {
     constexpr int MMAX = EMAX / RR;
-    const int p = s.P - 1, M = s.M[p];
-    const unsigned nbf = (unsigned)s.nbf[p];
+    const unsigned nbf = (unsigned)ps.nbf;
 #pragma unroll
     for (int m = 0; m < MMAX; ++m) {
-        if (m < M) {
-            const Bf b = bf_of(s, p, t, m);
+        if (m < ps.M) {
+            const Bf b = bf_of(ps, t, m);
             if (b.on) {
+                cx<R>* o = lds + b.j;
 #pragma unroll
-                for (int q = 0; q < RR; ++q) fft::st2(lds + b.j + nbf * (unsigned)q, v[m * RR + q]);
+                for (int q = 0; q < RR; ++q, o += nbf) fft::st2(o, v[m * RR + q]);
             }
         }
     }
 }
 
-// the first pass (Ns = 1: no twiddles) on operands the caller put into v[m RR + q] = x[j + nbf q]
-template <int RR, int EMAX, typename R> MDSP_HD void pass0_butterflies(const Sched& s, cx<R> (&v)[EMAX]) {
-    constexpr int MMAX = EMAX / RR;
-    const int M = s.M[0];
-#pragma unroll
-    for (int m = 0; m < MMAX; ++m) {
-        if (m < M) {
-            cx<R> u[RR];
-#pragma unroll
-            for (int q = 0; q < RR; ++q) u[q] = v[m * RR + q];
-            fft::gen_bfly<RR>(u);
-#pragma unroll
-            for (int q = 0; q < RR; ++q) v[m * RR + q] = u[q];
-        }
-    }
-}
-
 // results of the last pass: f(slot m RR + q, bin j + nbf q, value) for every butterfly the thread really owns
-template <int RR, int EMAX, typename R, typename F> MDSP_HD void last_consume(const Sched& s, int t, const cx<R> (&v)[EMAX], F&& f) {
+template <int RR, int EMAX, typename R, typename F> MDSP_HD void last_consume(const Pass& ps, int t, const cx<R> (&v)[EMAX], F&& f) {
     constexpr int MMAX = EMAX / RR;
-    const int p = s.P - 1, M = s.M[p];
-    const unsigned nbf = (unsigned)s.nbf[p];
+    const unsigned nbf = (unsigned)ps.nbf;
 #pragma unroll
     for (int m = 0; m < MMAX; ++m) {
-        if (m < M) {
-            const unsigned j = (unsigned)(t + s.T * m);
+        if (m < ps.M) {
+            const unsigned j = (unsigned)(t + ps.T * m);
             if (j < nbf) {
+                unsigned bin = j;
 #pragma unroll
-                for (int q = 0; q < RR; ++q) f(m * RR + q, j + nbf * (unsigned)q, v[m * RR + q]);
+                for (int q = 0; q < RR; ++q, bin += nbf) f(m * RR + q, bin, v[m * RR + q]);
             }
         }
     }

@@ -29,6 +29,7 @@ struct Sched {
     unsigned divm[MDSP_GX_MAXP]; // ceil(2^32 / ns): j div ns == mulhi(j, divm) for ns > 1 (exact while j ns < 2^32)
     int np = 0;                  // elements of an LDS buffer
     int nbuf = 1;                // LDS buffers: 2 = passes ping-pong (one barrier per pass), 1 = in place (two)
+    int wgs = 1;                 // workgroups of this schedule a CU holds (registers and LDS)
     double cost = 0;
 };
 
@@ -145,6 +146,7 @@ inline Sched plan(int N, int emax, int tmax, int cu_threads, int lds_bytes, int 
             const double score = s.cost / wgs * (wgs >= 4 ? 0.94 : wgs >= 2 ? 0.97 : 1.0);
             if (best.P == 0 || score < best_score) {
                 best = s;
+                best.wgs = wgs;
                 best_score = score;
             }
         }

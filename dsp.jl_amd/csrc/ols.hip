@@ -1159,12 +1159,6 @@ int exec_rocfft(mdsp_ols_plan_s* pl, const void* x, int64_t nx, int64_t ncols, i
 
 }  // namespace
 
-// y[shift + i] += t[i]: the delayed sum of a long filter's segments (mdsp_shift_add)
-template <typename R> __global__ __launch_bounds__(256) void shift_add_kernel(R* __restrict__ y, const R* __restrict__ t, int64_t cnt, int64_t shift, int64_t ldy, int64_t ldt) {
-    const int64_t c = blockIdx.y;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) y[c * ldy + shift + i] += t[c * ldt + i];
-}
-
 namespace mdsp {
 int ols_rows(int dbl, void* work, int64_t rows, int hrows, const void* Hrows, const void* table, const void* rt0, const void* rt1, int rlogS, hipStream_t st) {
     return ols_rows_impl(dbl, work, rows, hrows, Hrows, table, rt0, rt1, rlogS, st);
@@ -1407,24 +1401,6 @@ static int ols_exec_core(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int6
     a.memprio = tunables().ols_prio;
     if (cplx) return dbl ? launch_fused<double, true>(plan->nfft, a, plan->variant, s) : launch_fused<float, true>(plan->nfft, a, plan->variant, s);
     return dbl ? launch_fused<double, false>(plan->nfft, a, plan->variant, s) : launch_fused<float, false>(plan->nfft, a, plan->variant, s);
-}
-
-int mdsp_shift_add(void* y_dev, const void* t_dev, int64_t n, int64_t shift, int64_t ncols, int64_t ldy, int64_t ldt, int real_dtype, void* stream) {
-    if (real_dtype != MDSP_F32 && real_dtype != MDSP_F64) MDSP_FAIL(MDSP_ERR_ARGUMENT, "real dtype expected");
-    if (n < 0 || shift < 0 || ncols < 0 || ldy < n || ldt < n - shift) MDSP_FAIL(MDSP_ERR_DIMENSION, "shift_add: n %lld shift %lld ldy %lld ldt %lld", (long long)n, (long long)shift, (long long)ldy, (long long)ldt);
-    const int64_t cnt = n - shift;
-    if (cnt <= 0 || ncols == 0) return MDSP_OK;
-    if (!y_dev || !t_dev) MDSP_FAIL(MDSP_ERR_ARGUMENT, "NULL buffer");
-    {
-        int ndev = 0;
-        MDSP_TRY(mdsp_device_count(&ndev));
-        if (ndev <= 0) MDSP_FAIL(MDSP_ERR_DEVICE, "no HIP device visible: libmi355dsp has no CPU fallback");
-    }
-    const dim3 g((unsigned)std::min<int64_t>(cdiv(cnt, 256), (int64_t)device_cu_count() * 16), (unsigned)ncols);
-    if (real_dtype == MDSP_F32) hipLaunchKernelGGL(shift_add_kernel<float>, g, dim3(256), 0, as_stream(stream), (float*)y_dev, (const float*)t_dev, cnt, shift, ldy, ldt);
-    else hipLaunchKernelGGL(shift_add_kernel<double>, g, dim3(256), 0, as_stream(stream), (double*)y_dev, (const double*)t_dev, cnt, shift, ldy, ldt);
-    MDSP_LAUNCH_CHECK();
-    return MDSP_OK;
 }
 
 int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev, int64_t nout, int64_t ldy,

@@ -219,6 +219,11 @@ int mdsp_ols_plan_cached(mdsp_ols_plan* plan, const void* taps_host, int64_t nb,
     if (nfft == 0) nfft = mdsp_optimal_fft_len(nb, std::max<int64_t>(nx_hint, 1));   // the key holds the resolved length, not the hint
     std::string k = base_key('o', stream);
     put(k, nb); put(k, nfft); put(k, dtype); put(k, mode); put(k, engine == MDSP_ENGINE_AUTO ? tunables().engine : engine);
+    {   // long filters size their block transform by the hint (bigfft.hip ols_size): the RESOLVED block is part of the key, so a plan made for a short signal
+        // is not handed to a long one with undersized blocks, nor the reverse
+        int64_t exec_nfft = 0, exec_block = 0;
+        if (mdsp_ols_geometry_for(nb, nfft, nx_hint, dtype, mode, engine, &exec_nfft, &exec_block, nullptr, nullptr, nullptr) == MDSP_OK) put(k, exec_nfft);
+    }
     put(k, taps_host, (size_t)nb * dtype_size(dtype));
     void* h = nullptr;
     MDSP_TRY(get(k, &h, [&](void** out) { return mdsp_ols_plan_create(reinterpret_cast<mdsp_ols_plan*>(out), taps_host, nb, nfft, nx_hint, dtype, mode, engine); },

@@ -686,7 +686,10 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 bool use_gx(int dtype, int64_t nfft, bool direct) {
     const int m = tunables().gx;
     if (m == 0 || !gx_size_ok(dtype, nfft)) return false;
-    return m >= 2 || (!fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct));
+    if (m >= 2) return true;
+    // powers of two from 32768 points stay on the multi-pass engine's two register stages (0.39 - 0.48 TB/s against 0.32 at 65536 = 8 x 8192 here)
+    if ((nfft & (nfft - 1)) == 0 && nfft >= 32768 && big::size_ok(dtype, nfft)) return false;
+    return !fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct);
 }
 // the multi-pass engine takes what no single-workgroup kernel does
 bool use_big(int dtype, int64_t nfft, bool direct) {
@@ -1750,7 +1753,8 @@ namespace mdsp {
 int gx_run(int id, const GxArgs& a, unsigned grid_x, unsigned grid_y, int threads, size_t lds_bytes, hipStream_t st) {
     switch (id) {
 #define MDSP_GX_CASE(ID) case ID: return gx_run_##ID(a, grid_x, grid_y, threads, lds_bytes, st);
-        MDSP_GX_CASE(0) MDSP_GX_CASE(1) MDSP_GX_CASE(2) MDSP_GX_CASE(3) MDSP_GX_CASE(4) MDSP_GX_CASE(5) MDSP_GX_CASE(6) MDSP_GX_CASE(7) MDSP_GX_CASE(8) MDSP_GX_CASE(9)
+        MDSP_GX_CASE(0) MDSP_GX_CASE(1) MDSP_GX_CASE(2) MDSP_GX_CASE(3) MDSP_GX_CASE(5) MDSP_GX_CASE(6) MDSP_GX_CASE(7) MDSP_GX_CASE(8)
+        MDSP_GX_CASE(10) MDSP_GX_CASE(11) MDSP_GX_CASE(12) MDSP_GX_CASE(14) MDSP_GX_CASE(15) MDSP_GX_CASE(16) MDSP_GX_CASE(17) MDSP_GX_CASE(19)
 #undef MDSP_GX_CASE
         default: MDSP_FAIL(MDSP_ERR_ASSERTION, "gx kernel id %d", id);
     }
@@ -1847,6 +1851,7 @@ int mdsp_welch_reset(mdsp_welch_plan plan) {
     plan->acc_frames = 0;
     plan->acc_nch = 0;
     plan->frames_on_device = false;
+    plan->sums_global = false;
     return MDSP_OK;
 }
 
@@ -1855,6 +1860,8 @@ int mdsp_welch_accumulate(mdsp_welch_plan plan, const void* s_dev, int64_t len, 
     if (nch == 0) return MDSP_OK;
     if (!plan->acc_fresh && plan->acc_nch != nch)
         MDSP_FAIL(MDSP_ERR_DIMENSION, "accumulating %lld channels into sums of %lld channels (mdsp_welch_reset first)", (long long)nch, (long long)plan->acc_nch);
+    if (plan->sums_global)   // a later all-reduce would add the earlier global totals once per rank
+        MDSP_FAIL(MDSP_ERR_ARGUMENT, "these sums are totals over ranks (mdsp_welch_allreduce ran): mdsp_welch_reset before accumulating again");
     hipStream_t st = as_stream(stream);
     const bool cplx = dtype_is_complex(plan->dtype), dbl = dtype_is_double(plan->dtype);
     int rc;
@@ -1960,6 +1967,7 @@ struct mdsp_stft_plan_s {
     DevBuf fr, spec;
     int64_t batch = 0;
     big::EngineHolder big;             // nfft above the single-workgroup kernels: the multi-pass engine (bigfft.hip)
+    mdsp::GxPlan gx;                   // 7-smooth sizes without a compile-time schedule: the run-time-schedule kernel (spectral_gx.h)
 };
 
 namespace {
@@ -2092,6 +2100,13 @@ template <typename R, bool CPLX>
 int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* out, int64_t ldo, int64_t chs, hipStream_t st) {
     const int64_t K = mdsp_frame_count(len, pl->n, pl->noverlap);
     if (K == 0) return MDSP_OK;
+    if (use_gx(pl->dtype, pl->nfft, CPLX)) {   // run-time-schedule kernel (spectral_gx.h); multitaper plans come here once per taper (accumulate)
+        GxArgs g{};
+        g.s = s; g.out = out; g.lds_ = lds_; g.K = K; g.hop = pl->n - pl->noverlap; g.nch = nch; g.ldo = ldo; g.chs = chs;
+        g.n = (int)pl->n; g.nfft = (int)pl->nfft; g.nout = (int)pl->nout; g.onesided = pl->onesided; g.psd = pl->psd_only; g.accumulate = pl->accumulate; g.r = pl->r;
+        int64_t ngroups = 0;
+        return gx_launch<R, CPLX, 1>(pl->gx, g, pl->have_win ? pl->win_ptr : nullptr, pl->dtype, st, &ngroups, nullptr);
+    }
     if (use_big(pl->dtype, pl->nfft, CPLX)) {   // nfft above the one-workgroup sizes (bigfft.hip); multitaper plans come here once per taper (accumulate)
         using TT = std::conditional_t<CPLX, cx<R>, R>;
         const size_t osz = pl->psd_only ? sizeof(R) : sizeof(cx<R>);
@@ -2174,7 +2189,7 @@ int mdsp_stft_plan_create(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int
             st = set_error(MDSP_ERR_DEVICE, "window upload failed");
         pl->win_ptr = pl->win.as<double>();
     }
-    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, dtype_is_complex(dtype)))
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, dtype_is_complex(dtype)) && !use_gx(dtype, nfft, dtype_is_complex(dtype)))
         st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
     if (st != MDSP_OK) {
         delete pl;

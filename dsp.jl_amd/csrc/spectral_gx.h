@@ -11,32 +11,42 @@ template <typename R> __global__ __launch_bounds__(256) void gx_window_kernel(co
 }
 
 constexpr int GX_LDS_BYTES = 160 * 1024;
-constexpr int GX_R0_MAX = 32;
+constexpr int GX_R0_MAX = 8;    // column factor at most (R0 loads per point, R0 - 1 of them from the L2: 125000 = 20 x 6250 measured 3.0 ms against the multi-pass engine's 1.2)
+constexpr int GX_R0_LAST = 32;  // ... and for the few sizes below 50000 points that no R0 <= 8 splits (19683 = 9 x 2187, 46875 = 15 x 3125): still ahead of the rocFFT pipeline
 inline int gx_emax(int) { return 16; }
 inline int gx_tmax(int) { return 512; }         // GxGeo<R>::LB
-inline int gx_cu_threads(int) { return 512; }   // 256 registers per thread
+inline int gx_cu_threads(int dtype) { return dtype_is_double(dtype) ? 512 : 1024; }  // 256 / 128 registers per thread (GxGeo<R>::MINW)
 // table entries behind the buffer for a split nfft = R0 S
 inline int gx_table_entries(int64_t nfft, int64_t S, int R0) {
     return mdsp::gx::TWS + mdsp::gx::tw_hi_entries(S) + (R0 > 1 ? mdsp::gx::TWS + mdsp::gx::tw_hi_entries(nfft) + R0 : 0);
 }
-// the split the kernel runs nfft with: the smallest R0 whose S = nfft / R0 has a schedule next to its tables (R0 = 1: the whole transform in one workgroup)
+// the split the kernel runs nfft with: R0 = 1 -- the whole transform in one workgroup -- where it has a schedule; else the R0 <= GX_R0_MAX that costs least: R0
+// workgroup-units per frame, each the schedule of S = nfft / R0 points plus the column step (R0 loads and a complex multiply-add per point, a twiddle)
 inline bool gx_choose(int dtype, int64_t nfft, bool welch, int* R0_out, mdsp::gx::Sched* sc_out) {
     const int esz = dtype_is_double(dtype) ? 16 : 8, emax = gx_emax(dtype);
     const int tmax = gx_tmax(dtype);
     if (nfft < 64 || nfft > (int64_t)GX_R0_MAX * tmax * emax || !mdsp::gx::smooth7(nfft)) return false;
-    for (int R0 = 1; R0 <= GX_R0_MAX; ++R0) {
+    bool found = false;
+    double best = 0;
+    for (int R0 = 1; R0 <= (nfft < 50000 ? GX_R0_LAST : GX_R0_MAX); ++R0) {
+        if (R0 > GX_R0_MAX && found) break;
         if (nfft % R0 != 0) continue;
         const int64_t S = nfft / R0;
         if (S > (int64_t)tmax * emax || S < 16) continue;
         const mdsp::gx::Sched sc = mdsp::gx::plan((int)S, emax, tmax, gx_cu_threads(dtype), GX_LDS_BYTES, esz, esz * gx_table_entries(nfft, S, R0),
                                                        welch ? esz / 2 : 0);   // Welch: the sums live in LDS, one real per bin
-        if (sc.P >= 2) {
+        if (sc.P < 2) continue;
+        const double pts = (double)((S + sc.T - 1) / sc.T);
+        const double score = (double)R0 * (sc.cost + (R0 > 1 ? pts * (8.0 * R0 + 9.0) : 0.0)) / sc.wgs;
+        if (!found || score < best) {
+            found = true;
+            best = score;
             if (R0_out) *R0_out = R0;
             if (sc_out) *sc_out = sc;
-            return true;
         }
+        if (R0 == 1) break;   // one workgroup per transform wherever that is possible
     }
-    return false;
+    return found;
 }
 inline bool gx_size_ok(int dtype, int64_t nfft) {
     static std::mutex mu;
@@ -125,6 +135,6 @@ int gx_launch(GxPlan& gp, GxArgs& a, const double* win_dev, int dtype, hipStream
         a.out = partial->p;
     }
     if (!CPLX && MODE == 0 && !pair) MDSP_FAIL(MDSP_ERR_ASSERTION, "Welch sums always pair real frames");
-    const int id = (sizeof(R) == 8 ? 5 : 0) + (MODE == 0 ? (CPLX ? 1 : 0) : (CPLX ? 2 : (pair ? 3 : 4)));
+    const int id = (gp.R0 > 1 ? 10 : 0) + (sizeof(R) == 8 ? 5 : 0) + (MODE == 0 ? (CPLX ? 1 : 0) : (CPLX ? 2 : (pair ? 3 : 4)));
     return mdsp::gx_run(id, a, (unsigned)(groups * gp.R0), (unsigned)a.nch, gp.sc.T, gp.lds_bytes, st);
 }

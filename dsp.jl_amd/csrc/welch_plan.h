@@ -30,6 +30,8 @@ struct mdsp_welch_plan_s {
     mdsp::GxPlan gx;             // 7-smooth sizes without a compile-time schedule, up to 32 x 16384 points: the run-time-schedule kernel (spectral_gx.h)
     mdsp::DevBuf w64prep;        // mdsp_welch_w64_asm: Float32 window pairs + per-lane twiddles (built at the plan's first launch of that kernel)
     bool frames_on_device = false;
+    bool sums_global = false;    // the sums are totals over ranks (mdsp_welch_allreduce ran): only mdsp_welch_reset clears it -- accumulating into them
+                                 // and reducing again would add the earlier global totals nranks times
     hipStream_t count_stream = nullptr;   // the stream mdsp_welch_allreduce queued the count's reduction on
     int acc_nslices = 1, acc_nacc = 0, acc_mode = 0;   // welch_finalize_kernel MODE
     double* acc_ptr() const { return engine == MDSP_ENGINE_ROCFFT ? partial.as<double>() : reduced.as<double>(); }

@@ -130,10 +130,6 @@ int mdsp_ols_geometry_for(int64_t nb, int64_t nfft, int64_t nx_hint, int dtype, 
  * 0 <= nout <= nx+nb-1.  x and y must not alias (Filters/filt.jl:438-439). */
 int mdsp_ols_exec(mdsp_ols_plan plan, const void* x_dev, int64_t nx, int64_t ncols, int64_t ldx, void* y_dev,
                   int64_t nout, int64_t ldy, void* stream);
-/* y[shift + i, c] += t[i, c] for 0 <= i < n - shift, every column (real Float32 / Float64): sums delayed partial outputs on the device -- fftfilt is
- * linear in b, so hosts that split a filter into segments themselves (up to round 4 the only way past the partitioned range; mdsp_ols_plan_create
- * takes any length since) add segment k's output delayed by k * segment_length with this. */
-int mdsp_shift_add(void* y_dev, const void* t_dev, int64_t n, int64_t shift, int64_t ncols, int64_t ldy, int64_t ldt, int real_dtype, void* stream);
 /* Blocks [first_block, first_block + nblocks_range) of the SAME block grid mdsp_ols_exec uses for one column of nx samples /
  * nout outputs, from a slice of the signal: xs_dev holds x[xs_first .. xs_first + xs_len) and must cover the samples those blocks
  * read, [first_block L - (nb-1), (first_block + nblocks_range) L) clipped to [0, nx); ys_dev[0..] receives the outputs from

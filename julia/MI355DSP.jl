@@ -96,23 +96,30 @@ function plan_cache_partitions()
     (partitions = Int(p[]), reaped = Int(r[]))
 end
 # Julia tasks migrate between OS threads, the library's binding is thread-local: `with_plan_context` pins the task to its thread for the duration
-# (sticky, restored afterwards), so the binding is made and cleared on the SAME thread and no other task scheduled there inherits it.  A context
-# derived from the task (the default id) is released when the call returns -- its plans are freed with it, nothing lingers for the global cap to
-# trim; pass an id of your own (and call plan_cache_release_context when its work is done) to keep plans across calls.
+# (sticky, restored afterwards), so the binding is made and restored on the SAME thread.  Calls nest: the task keeps a stack of its contexts in
+# task-local storage, leaving a level re-binds the level above (not 0), and a context derived from the task (the default id) is released -- its
+# plans freed with it -- only when the OUTERMOST level that uses it returns (a nested default-id call derives the same id: releasing it there would
+# free plans the outer level still holds).  Pass an id of your own (and call plan_cache_release_context when its work is done) to keep plans across
+# calls.  The binding belongs to the OS thread: `f` must not yield to another task that uses the library on this thread without a context of its
+# own -- that task would run under this binding while `f` is suspended (wrap it in with_plan_context too: it re-binds on entry and on exit).
 plan_cache_set_context(id::Integer) = check(ccall((:mdsp_plan_cache_set_context, lib), Cint, (UInt64,), UInt64(id)))
 plan_cache_release_context(id::Integer) = check(ccall((:mdsp_plan_cache_release_context, lib), Cint, (UInt64,), UInt64(id)))
+const _CTX_KEY = :mi355dsp_plan_contexts
 function with_plan_context(f, id::Union{Integer,Nothing}=nothing)
     t = current_task()
     own = id === nothing
     ctx = own ? (objectid(t) % UInt64) | (UInt64(1) << 62) : UInt64(id)
+    stack = get!(() -> UInt64[], task_local_storage(), _CTX_KEY)::Vector{UInt64}
     was_sticky = t.sticky
-    t.sticky = true                  # no migration between the two bindings below
+    t.sticky = true                  # no migration between the bindings below
+    push!(stack, ctx)
     plan_cache_set_context(ctx)
     try
         return f()
     finally
-        plan_cache_set_context(0)
-        own && plan_cache_release_context(ctx)
+        pop!(stack)
+        plan_cache_set_context(isempty(stack) ? UInt64(0) : last(stack))   # back to the enclosing level's binding
+        own && !(ctx in stack) && plan_cache_release_context(ctx)          # outermost use of the derived context only
         t.sticky = was_sticky
     end
 end

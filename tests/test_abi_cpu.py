@@ -619,7 +619,8 @@ def test_polyphase_choice_file_overrides_one_shape_only(tmp_path):
     base_a, base_b, f64_before = geo(3, 2, 96), geo(2, 1, 75), geo(3, 2, 96, _lib.F64, _lib.F64)
     assert base_a[0] == 1 and base_a[5] > 2                      # ok, NG of the library's rule
     f = tmp_path / "fir_choice.txt"
-    f.write_text("# a comment\n3 2 96 0 0 MDSP_FIR_MM_NG=2,MDSP_NOT_A_KNOB=7\nthis line is not a shape\n6 4 96 0 0 MDSP_FIR_MM_NG=1\n")
+    key = f"# mi355dsp-fir-choices v{lib.mdsp_version()} gfx950\n"
+    f.write_text(key + "# a comment\n3 2 96 0 0 MDSP_FIR_MM_NG=2,MDSP_NOT_A_KNOB=7\nthis line is not a shape\n6 4 96 0 0 MDSP_FIR_MM_NG=1\n")
     try:
         _lib.set_tunable("MDSP_FIR_CHOICE_FILE", str(f))
         got = geo(3, 2, 96)
@@ -627,10 +628,16 @@ def test_polyphase_choice_file_overrides_one_shape_only(tmp_path):
         assert geo(6, 4, 96) == got                                      # ... which is the same filter
         assert geo(3, 2, 97)[5] == base_a[5] and geo(2, 1, 75) == base_b                     # other shapes: untouched
         assert geo(3, 2, 96, _lib.F64, _lib.F64) == f64_before                               # another dtype is another shape
+        # a file without the key line of THIS library version / architecture is ignored as a whole (round 6)
+        stale = tmp_path / "stale.txt"
+        stale.write_text("# mi355dsp-fir-choices v1 gfx942\n3 2 96 0 0 MDSP_FIR_MM_NG=2\n")
+        _lib.set_tunable("MDSP_FIR_CHOICE_FILE", str(stale))
+        assert geo(3, 2, 96) == base_a
     finally:
         _lib.set_tunable("MDSP_FIR_CHOICE_FILE", str(tmp_path / "absent.txt"))
     assert geo(3, 2, 96) == base_a
     _lib.set_tunable("MDSP_FIR_CHOICE_FILE", None)
+    assert geo(3, 2, 96) == base_a   # no variable, no file: nothing under ~/.cache is looked at (opt-in since round 6)
 
 
 def test_matrix_core_polyphase_geometry_is_consistent():

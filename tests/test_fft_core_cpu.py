@@ -42,3 +42,17 @@ def test_multipass_transform_on_the_host(tmp_path):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:]
     assert "N=   125000 f32 P=2" in r.stdout and "P=4" in r.stdout and "FAIL" not in r.stdout
     assert r.stdout.count("rows form") == 4 and "16x8 column pass" in r.stdout
+
+
+def test_runtime_schedule_kernel_on_the_host(tmp_path):
+    """tests/cpu_harness/gx_emul.cpp: the run-time-schedule spectral kernel's planner (csrc/gx_sched.h, with the device's planning parameters) and pass code
+    (csrc/gx_pass.h) run thread by thread on the host -- one buffer of exactly the planned size, read | barrier | butterflies + write per pass, range and
+    collision checks on every LDS index, every radix 2 .. 16, two-level twiddle tables -- and the fused column step (nfft = R0 x S, decimation in
+    frequency with the kernel's tables) against a Float64 DFT, both precisions."""
+    exe = str(tmp_path / "gx_emul")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpu_harness", "gx_emul.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for prec in ("f32", "f64"):
+        r = subprocess.run([exe, prec], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-3000:]
+        assert "columns nfft  16384 = " in r.stdout and "too large" not in r.stdout and "no schedule" not in r.stdout

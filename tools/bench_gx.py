@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The run-time-schedule spectral kernel (csrc/gx_kernels.h) against the Float64 oracle and the rocFFT pipeline: Welch (50 % overlap) at 7-smooth sizes without
-a compile-time schedule, 256 ... 262144 points.  GX_SIZES, GX_LOG2N (stream length), GX_DTYPES (f32,f64,c32,c64), GX_CHECK=0 skips the oracle.
-Writes gpurun_out/gx.json."""
+a compile-time schedule, 256 ... 65536 points.  GX_SIZES, GX_LOG2N (stream length), GX_DTYPES (f32,f64,c32,c64), GX_CHECK=0 skips the oracle,
+GX_COLUMNS=1 adds the column modes (stft 75 % overlap of complex signals: 8 + 32 B per sample; spectrogram 50 % of real ones: ~8 B per sample; timing only).
+The fused engine is whatever AUTO-with-engine=FUSED resolves to (MDSP_GX=0 in the environment: the round-5 choice).  Writes gpurun_out/gx.json."""
 import ctypes as C
 import json
 import os
@@ -66,6 +67,27 @@ for dt in os.environ.get("GX_DTYPES", "f32").split(","):
             ms = timeit(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, x.data_ptr(), nn, 1, nn, psd.data_ptr(), cfg.nout, stream)))
             row[ename] = {"ms": round(ms, 4), "Gsamples_per_s": round(nn / ms / 1e6, 1), "TBps_algorithmic": round(bps * nn / ms / 1e9, 3)}
             outs[ename] = psd.cpu().numpy().astype(np.float64)
+        if os.environ.get("GX_COLUMNS") == "1":
+            from dsp_jl_amd.periodograms import _StftPlan, compute_window
+            win, norm2 = compute_window(d.hanning, nfft)
+            for eng, ename in ((d.ENGINE_FUSED, "fused"), (d.ENGINE_ROCFFT, "rocfft")):
+                try:
+                    if cplx:
+                        hop = nfft // 4
+                        K = d.frame_count(nn, nfft, nfft - hop)
+                        plan = _StftPlan(nfft, nfft - hop, nfft, win, norm2, False, 0, NP[dt], eng)
+                        out = torch.empty((K, nfft), dtype=TD[dt], device="cuda")
+                        ms = timeit(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, x.data_ptr(), nn, 1, nn, out.data_ptr(), nfft, K * nfft, stream)))
+                        row[f"stft75_{ename}"] = {"ms": round(ms, 4), "TBps_algorithmic": round(5.0 * bps * nn / ms / 1e9, 3)}
+                    else:
+                        plan = _StftPlan(nfft, nfft // 2, nfft, win, norm2, True, 1, NP[dt], eng)
+                        K = d.frame_count(nn, nfft, nfft // 2)
+                        out = torch.empty((K, plan.nout), dtype=xr.dtype, device="cuda")
+                        ms = timeit(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, x.data_ptr(), nn, 1, nn, out.data_ptr(), plan.nout, K * plan.nout, stream)))
+                        row[f"spectrogram50_{ename}"] = {"ms": round(ms, 4), "TBps_algorithmic": round((1.0 + plan.nout / (nfft // 2)) * bps * nn / ms / 1e9, 3)}
+                    del out, plan
+                except Exception as ex:   # noqa: BLE001
+                    row[f"columns_{ename}"] = {"error": str(ex)[:200]}
         if "fused" in outs and "rocfft" in outs:
             row["fused_vs_rocfft"] = float(np.linalg.norm(outs["fused"] - outs["rocfft"]) / np.linalg.norm(outs["rocfft"]))
         if check and "fused" in outs:

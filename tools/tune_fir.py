@@ -107,13 +107,15 @@ if VERIFY:
     ratio = ec["median_ms"] / er["median_ms"]
     res["verify_choice"] = {"choice_ms": ec["median_ms"], "round2_rule_ms": er["median_ms"], "choice_over_rule": round(ratio, 4), "regression": bool(ratio > 1.02)}
     print(("REGRESSION" if ratio > 1.02 else "ok") + f": {L}//{M} {DT}: library's choice {ec['median_ms']:.4f} ms, round-2 rule {er['median_ms']:.4f} ms ({ratio:.3f})", flush=True)
-# TUNE_PERSIST=1: what THIS box measured goes into the choice file the library reads (common.h FirChoice; MDSP_FIR_CHOICE_FILE, else
-# $XDG_CACHE_HOME/mi355dsp/fir_choice.txt, else ~/.cache/mi355dsp/fir_choice.txt): the first variant is the library's own rule; when another one is more
+# TUNE_PERSIST=1: what THIS box measured goes into the choice file MDSP_FIR_CHOICE_FILE names (common.h FirChoice; the library reads it only when that variable
+# is set -- opt-in since round 6 -- and only behind its key line): the first variant is the library's own rule; when another one is more
 # than 2 % faster its knobs become the shape's line (only knobs the file may carry; MDSP_WG_PER_CU / _RPAD / _VSTORE are process-wide), otherwise a line
 # left by an earlier run is removed.  The library applies a line to filters of exactly this (L, M, ntaps, dtypes) and to nothing else.
 if os.environ.get("TUNE_PERSIST") == "1" and len(variants) > 1:
     import math
-    path = os.environ.get("MDSP_FIR_CHOICE_FILE") or os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "mi355dsp", "fir_choice.txt")
+    path = os.environ.get("MDSP_FIR_CHOICE_FILE")
+    if not path:
+        raise SystemExit("TUNE_PERSIST=1 needs MDSP_FIR_CHOICE_FILE (the library reads no default location)")
     gq = math.gcd(L, M)
     shape = f"{L // gq} {M // gq} {len(h)} {lt} {lx}"
     keys = list(res["variants"].keys())
@@ -128,8 +130,8 @@ if os.environ.get("TUNE_PERSIST") == "1" and len(variants) > 1:
     if best != keys[0] and res["variants"][best]["median_ms"] < 0.98 * res["variants"][keys[0]]["median_ms"] and knobs:
         lines.append(shape + " " + ",".join(knobs))
         res["persisted"] = lines[-1]
-    os.makedirs(os.path.dirname(path), exist_ok=True)
-    open(path, "w").write("# polyphase choices measured on this box (tools/tune_fir.py TUNE_PERSIST=1): L M ntaps taps_dtype x_dtype KNOB=value,...\n" + "\n".join(ln for ln in lines if not ln.startswith("#")) + "\n")
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    open(path, "w").write(f"# mi355dsp-fir-choices v{lib.mdsp_version()} gfx950\n# polyphase choices measured on this box (tools/tune_fir.py TUNE_PERSIST=1): L M ntaps taps_dtype x_dtype KNOB=value,...\n" + "\n".join(ln for ln in lines if not ln.startswith("#")) + "\n")
     print("choice file", path, "->", res.get("persisted", "(the library's rule stands for this shape)"), flush=True)
 select((-1, 0, 0)); _lib.set_tunable("MDSP_FIR_MM", None); _lib.set_tunable("MDSP_WG_PER_CU", None); _lib.set_tunable("MDSP_FIR_P", None)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
