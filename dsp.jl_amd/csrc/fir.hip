@@ -30,6 +30,7 @@
 #include "hostpipe.h"
 #include "devio.h"
 #include "arb_scan.h"
+#include "fir_reg.h"
 #include "fft_lds.h"
 
 using namespace mdsp;
@@ -2079,6 +2080,11 @@ struct FirChoiceScope {
     FirChoiceScope& operator=(const FirChoiceScope&) = delete;
 };
 
+bool fir_reg_use(const mdsp_fir_s* f) {
+    if (MDSP_DBG(fir_generic) || tunables().fir_exact || f->exact || f->kind == 4) return false;
+    return fir_reg_ok(f->x_dtype, f->acc_double, f->tp, f->L, f->M);
+}
+
 int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
     const FirChoiceScope choice(f);
     {
@@ -2090,6 +2096,14 @@ int fir_dispatch(mdsp_fir_s* f, FirArgs& a, hipStream_t st) {
     if (tunables().fir_p == 3 && f->tp <= 32 && fir_fast_ok(f, 3)) return fir_fast_dispatch<3>(f, a, st);   // tuning: three residues per thread
     if (fir_fast_ok(f, 2)) return fir_fast_dispatch<2>(f, a, st);
     if (fir_fast_ok(f, 1)) return fir_fast_dispatch<1>(f, a, st);
+    if (fir_reg_use(f)) {   // round 6: register taps for every other signal type where the matrix-core tile missed the LDS (fir_reg.hip)
+        FirRegArgs b{};
+        b.x = a.x; b.hist = a.hist; b.y = a.y; b.pfbT = a.pfbT;
+        b.xlen = a.xlen; b.ldx = a.ldx; b.ldy = a.ldy; b.nout = a.nout;
+        b.phi0m1 = a.phi0m1; b.d0 = a.d0;
+        b.L = a.L; b.M = a.M; b.tp = a.tp; b.hl = a.hl;
+        return fir_reg_run(f->x_dtype, f->acc_double, b, f->nch, st);
+    }
     const bool d = f->acc_double;
     switch (f->x_dtype) {
         case MDSP_F32: return d ? fir_launch<float, double, double>(f, a, st) : fir_launch<float, float, float>(f, a, st);
@@ -2282,7 +2296,7 @@ int mdsp_fir_kernel_path(mdsp_fir f, int64_t xlen, int* path) {
     a.L = (int)f->L;
     a.M = (int)f->M;
     const FirChoiceScope choice(f);
-    *path = fir_dec_geo(f).ok ? 3 : fir_mm_use(f, a) ? 2 : (fir_fast_ok(f, 2) || fir_fast_ok(f, 1)) ? 1 : 0;   // 3: decimator kernel, 2: matrix cores, 1: register taps, 0: generic
+    *path = fir_dec_geo(f).ok ? 3 : fir_mm_use(f, a) ? 2 : (fir_fast_ok(f, 2) || fir_fast_ok(f, 1) || fir_reg_use(f)) ? 1 : 0;   // 3: decimator kernel, 2: matrix cores, 1: register taps, 0: generic
     return MDSP_OK;
 }
 

@@ -682,18 +682,29 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 }
 
 // round 6: the run-time-schedule kernel (spectral_gx.h) takes every 7-smooth size it plans that has neither a register-resident power-of-two kernel
-// nor a compile-time schedule -- in front of the round-2 LDS kernel, the multi-pass engine and the rocFFT pipeline
-bool use_gx(int dtype, int64_t nfft, bool direct) {
+// nor a compile-time schedule -- in front of the round-2 LDS kernel, the multi-pass engine and the rocFFT pipeline.  kind: 0 Welch sums, 1 columns.
+// Measured against both (profiles/r06_gx_vs_r5.json: Float32 / Float64 / ComplexF32 / ComplexF64, 1125 .. 65536 points):
+//   Welch          : 2 - 7 x either at every size but the powers of two from 32768 (the multi-pass engine's two register stages: a tie)
+//   real columns   : 1.1 - 6 x, a tie with rocFFT at R0 >= 5 (12500, 40000); 16384 = 2 x 8192 loses 8 % to the multi-pass engine
+//   complex columns: wins from 4097 points while one workgroup holds the transform and up to R0 = 4 (8400, 20000); rocFFT is faster below 4097
+//                    (1.4 - 1.7 against 0.9 - 1.3 TB/s) and at R0 >= 5 (40000: 0.75 / 0.91 against 0.67 / 0.59)
+bool use_gx(int dtype, int64_t nfft, bool direct, int kind) {
     const int m = tunables().gx;
     if (m == 0 || !gx_size_ok(dtype, nfft)) return false;
     if (m >= 2) return true;
-    // powers of two from 32768 points stay on the multi-pass engine's two register stages (0.39 - 0.48 TB/s against 0.32 at 65536 = 8 x 8192 here)
-    if ((nfft & (nfft - 1)) == 0 && nfft >= 32768 && big::size_ok(dtype, nfft)) return false;
+    const bool pow2 = (nfft & (nfft - 1)) == 0;
+    if (pow2 && nfft >= (kind == 0 ? 32768 : 16384) && big::size_ok(dtype, nfft) && !(kind == 0 && ctcols_split(dtype, nfft) > 0)) return false;   // (Welch, Float32: 4 x / 8 x 8192 on the compile-time rows)
     return !fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct);
 }
+// ... and where AUTO prefers it to the rocFFT pipeline (engine = FUSED takes it wherever use_gx says so)
+bool gx_wins(int dtype, int64_t nfft, int kind) {
+    if (kind == 0 || !dtype_is_complex(dtype)) return true;
+    if (nfft <= 4096) return false;
+    return gx_split_r0(dtype, nfft) <= 4;
+}
 // the multi-pass engine takes what no single-workgroup kernel does
-bool use_big(int dtype, int64_t nfft, bool direct) {
-    return !use_gx(dtype, nfft, direct) && !fused_size_ok(dtype, nfft) && !gen_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && big::size_ok(dtype, nfft);
+bool use_big(int dtype, int64_t nfft, bool direct, int kind) {
+    return !use_gx(dtype, nfft, direct, kind) && !fused_size_ok(dtype, nfft) && !gen_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && big::size_ok(dtype, nfft);
 }
 
 // kind: 0 = Welch (sums of |X|^2), 1 = STFT / spectrogram / periodogram columns
@@ -702,8 +713,8 @@ int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) 
     if (eng == MDSP_ENGINE_AUTO) eng = tunables().engine;
     // fused: the register-resident power-of-two sizes, and the mixed-radix LDS kernel for the other 7-smooth sizes nextfastfft returns
     const bool direct = kind == 0 || dtype_is_complex(dtype);   // the last pass is consumed from registers (spectral_gen.h)
-    const bool big_ok = use_big(dtype, nfft, direct);   // round 5: the multi-pass engine (bigfft.hip) for everything above the one-workgroup sizes
-    const bool gx_ok = use_gx(dtype, nfft, direct);
+    const bool big_ok = use_big(dtype, nfft, direct, kind);   // round 5: the multi-pass engine (bigfft.hip) for everything above the one-workgroup sizes
+    const bool gx_ok = use_gx(dtype, nfft, direct, kind);
     const bool fused_ok = gx_ok || fused_size_ok(dtype, nfft) || gen_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) || big_ok;
     // AUTO takes the mixed-radix kernel where it measured faster than the rocFFT pipeline (profiles/r02g_mixed.json, 2^27 samples): Welch and
     // real-signal columns up to 4096 points (1.4-3x), complex columns above (1.6x); elsewhere the two are within 20 % and rocFFT is kept.
@@ -715,7 +726,7 @@ int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) 
     // below 50000 the generic passes' small tiles lose to rocFFT at most sizes: 8400 .. 10000 0.7x, 20000 0.5x, 40000 1.0x)
     const bool pow2 = (nfft & (nfft - 1)) == 0;
     const bool big_wins = big_ok && (pow2 ? nfft >= 16384 : (nfft >= 50000 && !(kind == 1 && dtype_is_complex(dtype))));
-    const bool gen_wins = gx_ok || big_wins || fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
+    const bool gen_wins = (gx_ok && gx_wins(dtype, nfft, kind)) || big_wins || fused_size_ok(dtype, nfft) || gen_ct_size(dtype, nfft, direct) ||
                           (gen_size_ok(dtype, nfft) && ((nfft <= 4096) == (kind == 0 || !dtype_is_complex(dtype))));
     if (eng == MDSP_ENGINE_AUTO) eng = gen_wins ? MDSP_ENGINE_FUSED : MDSP_ENGINE_ROCFFT;
     if (eng == MDSP_ENGINE_FUSED && !fused_ok)
@@ -1676,11 +1687,17 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
         }
         return MDSP_OK;
     }
-    if (use_gx(pl->dtype, pl->nfft, true)) {   // run-time-schedule kernel (spectral_gx.h): partial rows per group of workgroups, same Float64 accumulator protocol
+    if (use_gx(pl->dtype, pl->nfft, true, 0)) {   // run-time-schedule kernel (spectral_gx.h): partial rows per group of workgroups, same Float64 accumulator protocol
         GxArgs g{};
         g.s = s; g.lds_ = lds_; g.K = K; g.hop = pl->n - pl->noverlap; g.nch = nch;
         g.n = (int)pl->n; g.nfft = (int)pl->nfft; g.nout = (int)pl->nout; g.onesided = pl->onesided; g.r = pl->r;
         int64_t ngroups = 0;
+        // R0 x a row size with a COMPILE-TIME schedule (16384 = 2 x 8192, 12500 = 5 x 2500, 20000 = 4 x 5000 ...): the same decomposition on the kernels of
+        // spectral_gen.h (spectral_ctcols.hip) -- about half the vector instructions per point of the run-time schedule
+        if (tunables().gx != 4 && ctcols_split(pl->dtype, pl->nfft) > 0)
+            MDSP_TRY(ctcols_welch(pl->ctcols, pl->dtype, s, lds_, K, pl->n - pl->noverlap, nch, (int)pl->n, pl->nfft, pl->have_win ? pl->win.as<double>() : nullptr, st, &ngroups,
+                                  &pl->partial));
+        else
         MDSP_TRY((gx_launch<R, CPLX, 0>(pl->gx, g, pl->have_win ? pl->win.as<double>() : nullptr, pl->dtype, st, &ngroups, &pl->partial)));
         const int N = (int)pl->nfft;
         MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)nch * (size_t)N));
@@ -1691,7 +1708,7 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
         pl->acc_mode = CPLX ? 1 : (pl->onesided ? 3 : 4);
         return MDSP_OK;
     }
-    if (use_big(pl->dtype, pl->nfft, true)) {   // nfft above the one-workgroup sizes: channel by channel through the multi-pass engine, same accumulator protocol
+    if (use_big(pl->dtype, pl->nfft, true, 0)) {   // nfft above the one-workgroup sizes: channel by channel through the multi-pass engine, same accumulator protocol
         using TT = std::conditional_t<CPLX, cx<R>, R>;
         const int64_t N = pl->nfft;
         MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)nch * (size_t)N));
@@ -1814,7 +1831,7 @@ int mdsp_welch_plan_create(mdsp_welch_plan* plan, int64_t n, int64_t noverlap, i
         if (st == MDSP_OK && hipMemcpy(pl->win.p, window_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess)
             st = set_error(MDSP_ERR_DEVICE, "window upload failed");
     }
-    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, true) && !use_gx(dtype, nfft, true))   // (the multi-pass engine and the run-time-schedule kernel build their own, much shorter, tables)
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, true, 0) && !use_gx(dtype, nfft, true, 0))   // (the multi-pass engine and the run-time-schedule kernel build their own, much shorter, tables)
         st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
     if (st != MDSP_OK) {
         delete pl;
@@ -2100,14 +2117,14 @@ template <typename R, bool CPLX>
 int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nch, int64_t lds_, void* out, int64_t ldo, int64_t chs, hipStream_t st) {
     const int64_t K = mdsp_frame_count(len, pl->n, pl->noverlap);
     if (K == 0) return MDSP_OK;
-    if (use_gx(pl->dtype, pl->nfft, CPLX)) {   // run-time-schedule kernel (spectral_gx.h); multitaper plans come here once per taper (accumulate)
+    if (use_gx(pl->dtype, pl->nfft, CPLX, 1)) {   // run-time-schedule kernel (spectral_gx.h); multitaper plans come here once per taper (accumulate)
         GxArgs g{};
         g.s = s; g.out = out; g.lds_ = lds_; g.K = K; g.hop = pl->n - pl->noverlap; g.nch = nch; g.ldo = ldo; g.chs = chs;
         g.n = (int)pl->n; g.nfft = (int)pl->nfft; g.nout = (int)pl->nout; g.onesided = pl->onesided; g.psd = pl->psd_only; g.accumulate = pl->accumulate; g.r = pl->r;
         int64_t ngroups = 0;
         return gx_launch<R, CPLX, 1>(pl->gx, g, pl->have_win ? pl->win_ptr : nullptr, pl->dtype, st, &ngroups, nullptr);
     }
-    if (use_big(pl->dtype, pl->nfft, CPLX)) {   // nfft above the one-workgroup sizes (bigfft.hip); multitaper plans come here once per taper (accumulate)
+    if (use_big(pl->dtype, pl->nfft, CPLX, 1)) {   // nfft above the one-workgroup sizes (bigfft.hip); multitaper plans come here once per taper (accumulate)
         using TT = std::conditional_t<CPLX, cx<R>, R>;
         const size_t osz = pl->psd_only ? sizeof(R) : sizeof(cx<R>);
         for (int64_t c = 0; c < nch; ++c)
@@ -2189,7 +2206,7 @@ int mdsp_stft_plan_create(mdsp_stft_plan* plan, int64_t n, int64_t noverlap, int
             st = set_error(MDSP_ERR_DEVICE, "window upload failed");
         pl->win_ptr = pl->win.as<double>();
     }
-    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, dtype_is_complex(dtype)) && !use_gx(dtype, nfft, dtype_is_complex(dtype)))
+    if (st == MDSP_OK && eng == MDSP_ENGINE_FUSED && !use_big(dtype, nfft, dtype_is_complex(dtype), 1) && !use_gx(dtype, nfft, dtype_is_complex(dtype), 1))
         st = dtype_is_double(dtype) ? upload_roots<double>(pl->table, nfft) : upload_roots<float>(pl->table, nfft);
     if (st != MDSP_OK) {
         delete pl;

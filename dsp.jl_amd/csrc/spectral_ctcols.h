@@ -1,0 +1,16 @@
+// Welch sums at nfft = R0 x S with a compile-time schedule for the S-point rows (spectral_ctcols.hip).  Internal to the library.
+#pragma once
+
+#include "common.h"
+
+namespace mdsp {
+struct CtColsPlan {   // what a Welch plan keeps for it: roots of S and of nfft, the window in working precision
+    bool ready = false;
+    DevBuf roots, rootsN, win;
+};
+// the column factor R0 in 2 .. 8 with nfft / R0 among the instantiated row sizes (0: none)
+int ctcols_split(int dtype, int64_t nfft);
+// partial[(group, ch)][nfft] (+ reduce by the caller): Float64 sums of |Z|^2 per bin, natural order
+int ctcols_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,
+                 hipStream_t st, int64_t* ngroups, DevBuf* partial);
+}  // namespace mdsp

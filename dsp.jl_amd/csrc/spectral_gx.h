@@ -37,7 +37,8 @@ inline bool gx_choose(int dtype, int64_t nfft, bool welch, int* R0_out, mdsp::gx
                                                        welch ? esz / 2 : 0);   // Welch: the sums live in LDS, one real per bin
         if (sc.P < 2) continue;
         const double pts = (double)((S + sc.T - 1) / sc.T);
-        const double score = (double)R0 * (sc.cost + (R0 > 1 ? pts * (8.0 * R0 + 9.0) : 0.0)) / sc.wgs;
+        // (the column step's weight: 12500 = 2 x 6250 -- six passes -- measured 0.49 TB/s, 5 x 2500 -- four -- 0.39: profiles/r06_gx_sessions.json)
+        const double score = (double)R0 * (sc.cost + (R0 > 1 ? pts * (16.0 * R0 + 9.0) : 0.0)) / sc.wgs;
         if (!found || score < best) {
             found = true;
             best = score;
@@ -61,6 +62,12 @@ inline bool gx_size_ok(int dtype, int64_t nfft) {
     std::lock_guard<std::mutex> lk(mu);
     memo.emplace_back(key, ok);
     return ok;
+}
+
+// the column factor of the split (1: one workgroup per transform; 0: no schedule)
+inline int gx_split_r0(int dtype, int64_t nfft) {
+    int R0 = 0;
+    return gx_choose(dtype, nfft, true, &R0, nullptr) ? R0 : 0;
 }
 
 template <typename R> int gx_prepare(GxPlan& gp, int dtype, int64_t nfft, bool welch) {
@@ -126,7 +133,7 @@ int gx_launch(GxPlan& gp, GxArgs& a, const double* win_dev, int dtype, hipStream
     const int per_cu = std::max<int>(1, std::min<int>(gx_cu_threads(dtype) / gp.sc.T, (int)((size_t)GX_LDS_BYTES / gp.lds_bytes)));
     int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * (tunables().wg_per_cu > 0 ? tunables().wg_per_cu : per_cu) / std::max<int64_t>(1, a.nch));
     int64_t groups = std::max<int64_t>(1, std::min<int64_t>(a.units_per_ch, resident / gp.R0));
-    if (gp.R0 > 1) groups = cdiv(groups, 8) * 8;   // the kernel's XCD mapping walks groups in eights
+    if (gp.R0 > 1) groups = std::max<int64_t>(8, groups / 8 * 8);   // the kernel's XCD mapping walks groups in eights (rounded down: no second round of workgroups for a few)
     a.per_slot = cdiv(a.units_per_ch, groups);
     if (gp.R0 == 1) groups = cdiv(a.units_per_ch, a.per_slot);
     *ngroups_out = groups;

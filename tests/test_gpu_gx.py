@@ -2,7 +2,8 @@
 7-smooth transform sizes WITHOUT a compile-time schedule -- what nextfastfft (util.jl:134) returns for most frame lengths, and every default call
 (n = length(s) >> 3, periodograms.jl:560, :647, :828, :872) on a 65 537 .. 400 000-sample signal.  Sizes cover: one workgroup per transform (R0 = 1; one
 and two LDS buffers, 256 and 512 threads, every radix 2 .. 16 in first / middle / last position), the fused column step (nfft = R0 x S: 8400, 12500,
-16384, 20000, 40000 -- VERDICT r5 item 1 -- and an odd size), zero padding, odd frame counts, several channels, the streaming protocol.
+16384, 20000, 40000 -- VERDICT r5 item 1 -- and an odd size; in Float32 on the compile-time row kernels of csrc/spectral_ctcols.hip where R0 x S is one of
+theirs), zero padding, odd frame counts, several channels.
 
     Float32 / ComplexF32:  norm-wise <= 5e-6 and element-wise |err| <= 8 log2(nfft) ulp of the largest bin
     Float64 / ComplexF64:  norm-wise <= 1e-12
@@ -56,6 +57,11 @@ WELCH_CASES = (
     (40000, 20000, 40000, "hanning", 5),
     (9261, 4630, 9261, None, 4),             # odd (21^3 = 3 x 3087)
     (19000, 9500, 19683, "hanning", 3),      # 3^9 = 9 x 2187: no split with R0 <= 8 exists (the R0 <= 32 fallback)
+    # Float32 / ComplexF32: R0 x a row size with a COMPILE-TIME schedule (csrc/spectral_ctcols.hip) -- 16384 = 2 x 8192, 12500 = 2 x 6250 and 20000 = 4 x 5000 above,
+    (11520, 5760, 11520, "hanning", 5),      # 3 x 3840
+    (9000, 4000, 9216, "hamming", 4),        # 2 x 4608 = 9 16 32, zero-padded
+    (13500, 6750, 13500, None, 3),           # 2 x 6750 = 15 18 25
+    (65536, 32768, 65536, "hanning", 3),     # 8 x 8192 (Float64: the multi-pass engine)
 )
 
 
