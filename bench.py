@@ -991,6 +991,13 @@ def main():
             kernels["read_GBps"] = round(nb / med / 1e6, 1)
             med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 2, 4, stream)), reps=3)
             kernels["copy_nt_4wg_GBps"] = round(2 * nb / med / 1e6, 1)
+            # round 6: the fastest of 150 copy shapes x cache policies of tools/ubench/copy_sweep.hip (nontemporal loads, sc0 | sc1 stores, four
+            # 16-byte accesses in flight, two workgroups per CU) and the read-only stream with nontemporal loads -- the yardsticks the step kernels are priced against
+            med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 6, 2, stream)), reps=3)
+            kernels["copy_ntload_sc_store_GBps"] = round(2 * nb / med / 1e6, 1)
+            kernels["copy_best_GBps"] = max(kernels["copy_GBps"], kernels["copy_nt_4wg_GBps"], kernels["copy_ntload_sc_store_GBps"])   # the best 1:1 copy of THIS box on THESE buffers
+            med, _ = tm.time(lambda: _lib.check(lib.mdsp_copy_bench_mode(y.data_ptr(), x.data_ptr(), nb, 7, 4, stream)), reps=3)
+            kernels["read_nt_GBps"] = round(nb / med / 1e6, 1)
         out["roofline"] = main_roof
         out["traffic_source"] = traffic_source
         if world == 1 and not args.no_rows and args.config == "filtwelch":

@@ -4,6 +4,8 @@
 // registers or two LDS tables, last pass consumed from registers).  One workgroup per (frame sequence, k1); the R0 workgroups of a sequence sit on one XCD,
 // so R0 - 1 of the R0 reads of a frame come from the L2.  The run-time-schedule kernel does the same with 2 - 2.5 x the vector instructions per point
 // (run-time indexing, table twiddles): 16384 = 2 x 8192 measured 0.51 TB/s there against 2.1 for the 8192-point kernel this one is built from.
+// (Tried and dropped, session r06s17: every row keeping ONE segment of the next unit in flight through the passes, the column twiddles in LDS to make room:
+// 16384 1.06 -> 0.73 TB/s, 14000 0.86 -> 0.46 -- the second LDS array halves the residency of the smaller rows and the prefetch registers spill.)
 // Reference loops: periodograms.jl:746-759 (welch_pgram_helper!), :57-69 (ArraySplit), :142-172 (fft2pow!).
 #include <algorithm>
 
@@ -168,18 +170,19 @@ template <typename R, bool CPLX, typename S> int cols_launch(ColsArgs& ca, int64
 }
 
 // the row sizes with a COLS instantiation: the compile-time schedules from 2000 points and two powers of two (16384 = 2 x 8192, 12288 = 3 x 4096 ...).
-// Flags: group padding as in ct_sched.h's table; from 4096 points ONE LDS buffer and table twiddles (the register form holds sum_p M(p) (R_p - 1) complex
+// Flags: group padding (512) wherever a pass's output groups alias the banks (the 8192-point rows ran with 58 % of their LDS cycles in conflicts without it);
+// from 4096 points ONE LDS buffer and table twiddles (the register form holds sum_p M(p) (R_p - 1) complex
 // values next to the column step's operands)
 #define MDSP_CTCOLS_SIZES(X)                                                                                                            \
     X(2000, 256, 0, 5, 5, 5, 16) X(2400, 256, 0, 3, 5, 5, 4, 8) X(2500, 256, 0, 5, 5, 5, 5, 4) X(2560, 320, 0, 5, 8, 8, 8)                  \
     X(3000, 384, 0, 3, 5, 5, 5, 8) X(3072, 256, 512, 3, 16, 8, 8) X(3200, 256, 0, 5, 5, 8, 16) X(3840, 256, 0, 3, 5, 16, 16)                \
-    X(4000, 512, 0, 5, 5, 5, 4, 8) X(4096, 256, 2064, 16, 16, 16) X(4800, 512, 2064, 3, 5, 5, 8, 8) X(5000, 512, 2064, 5, 5, 5, 5, 8)       \
+    X(4000, 512, 0, 5, 5, 5, 4, 8) X(4096, 256, 2576, 16, 16, 16) X(4800, 512, 2064, 3, 5, 5, 8, 8) X(5000, 512, 2064, 5, 5, 5, 5, 8)       \
     X(5120, 320, 2064, 5, 16, 8, 8) X(6000, 512, 2064, 3, 5, 5, 5, 16) X(6144, 512, 2576, 3, 16, 16, 8) X(6400, 448, 2064, 5, 5, 16, 16)    \
-    X(8000, 512, 2064, 5, 5, 5, 8, 8) X(8192, 512, 2064, 16, 32, 16)                                                                        \
+    X(8000, 512, 2064, 5, 5, 5, 8, 8) X(8192, 512, 2576, 16, 32, 16)                                                                        \
     /* halves of the other nextfastfft sizes between 8193 and 16384 (three passes, composite radices; one LDS buffer, table twiddles) */   \
     /* (4200 = 25 24 7, 5600 = 7 32 25, 7500 = 12 25 25 and 8100 = 12 27 25 were tried and lost to the run-time schedule at every R0: profiles/r06_ctcols.json) */ \
-    X(4500, 320, 2064, 15, 15, 20) X(4608, 512, 2064, 9, 16, 32) X(5400, 512, 2064, 8, 27, 25) X(6250, 320, 2064, 10, 25, 25)                \
-    X(6750, 512, 2064, 15, 18, 25) X(7000, 512, 2064, 14, 20, 25) X(7200, 512, 2064, 16, 18, 25) X(7680, 512, 2064, 15, 16, 32)
+    X(4500, 320, 2064, 15, 15, 20) X(4608, 512, 2576, 9, 16, 32) X(5400, 512, 2576, 8, 27, 25) X(6250, 320, 2064, 10, 25, 25)                \
+    X(6750, 512, 2064, 15, 18, 25) X(7000, 512, 2576, 14, 20, 25) X(7200, 512, 2576, 16, 18, 25) X(7680, 512, 2576, 15, 16, 32)
 
 template <typename R, bool CPLX> int cols_dispatch(ColsArgs& ca, int64_t nch, hipStream_t st, int64_t* ngroups, DevBuf* partial) {
     switch (ca.g.N) {

@@ -12,6 +12,7 @@ from fractions import Fraction
 
 import numpy as np
 
+from oracle import filt as oflt
 from oracle import periodograms as opg
 from oracle import stream_filt as osf
 
@@ -79,3 +80,20 @@ def oracle_resample_window(get, nx: int, ratio: Fraction, h, m0: int, count: int
 
 def resample_output_length(nx: int, ratio: Fraction) -> int:
     return math.ceil(nx * Fraction(ratio))
+
+
+def oracle_filt_chunked(get, nx: int, b, chunk: int = 1 << 22):
+    """Float64 ``filt(b, x)`` of a whole stream (``get(lo, hi)`` -> host samples [lo, hi)), chunk by chunk: yields (lo, hi, y[lo:hi]).
+
+    Filters/filt.jl:479-521 computes y[n] = sum_k b[k] x[n-k] with zero initial state; outputs [lo, hi) depend on x[lo - (nb-1), hi) only, so chunk c is the
+    oracle's own fftfilt on that slice (zeros in front of the stream) with the first nb - 1 outputs dropped."""
+    b64 = np.asarray(b, dtype=np.float64)
+    nb = len(b64)
+    for lo in range(0, nx, chunk):
+        hi = min(nx, lo + chunk)
+        first = lo - (nb - 1)
+        seg = np.zeros(hi - first, dtype=np.float64)
+        src_lo = max(first, 0)
+        seg[src_lo - first:] = np.asarray(get(src_lo, hi), dtype=np.float64)
+        y = oflt.fftfilt(b64, seg)
+        yield lo, hi, y[nb - 1:]

@@ -47,3 +47,17 @@ def test_resample_window_equals_one_shot(ratio, hlen):
     for m0, cnt in ((0, 50), (1, 333), (1234, 600), (nout - 600, 600), (nout - 1, 1)):
         got = fz.oracle_resample_window(lambda lo, hi: x[lo:hi], len(x), ratio, h, m0, cnt)
         assert np.array_equal(got, ref[m0:m0 + cnt]), (m0, cnt)
+
+
+def test_filt_chunked_equals_one_shot():
+    from oracle import dspbase as odsp
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(50_000).astype(np.float32)
+    b = rng.standard_normal(256)
+    ref = odsp.filt_ba(b, 1.0, x.astype(np.float64))
+    for chunk in (1 << 12, 10_007, 1 << 16):
+        got = np.empty_like(ref)
+        for lo, hi, y in fz.oracle_filt_chunked(lambda lo, hi: x[lo:hi], len(x), b, chunk=chunk):
+            assert len(y) == hi - lo
+            got[lo:hi] = y
+        assert np.allclose(got, ref, rtol=0, atol=1e-11 * np.max(np.abs(ref)))

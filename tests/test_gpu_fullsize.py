@@ -1,5 +1,6 @@
 """GPU parity at BASELINE sizes against the CPU ORACLE (not against another GPU engine).
 
+    config 2   filt(b, x), 256 taps, nfft 2048, 2^30 Float32 samples                      EVERY output vs the Float64 oracle (round 6)
     config 3   welch_pgram nfft = 4096, hanning, 50 % overlap, 2^30 Float32 samples      whole PSD vs the Float64 oracle
     config 4   stft / spectrogram nfft = 1024, hop = 256, 8 channels x 2^26 ComplexF32   oracle columns + every column's energy
     config 5   resample 160//147, 5120 taps, 4 channels x 2^28 Float32                   oracle output windows at depth
@@ -46,6 +47,39 @@ def d():
 def torch():
     import torch as t
     return t
+
+
+def test_config2_filt_2p30_whole_stream_vs_oracle(d, torch):
+    """Filters/filt.jl:479-521 on the full stream (config 2 used to be compared with the oracle on nine 600-sample windows only): all 2^30
+    outputs of the fused overlap-save kernel against the Float64 oracle, evaluated piecewise (tests/fullsize.py oracle_filt_chunked: the oracle's own
+    fftfilt on slices with their nb - 1 samples of history).  Per chunk: norm-wise error, the largest element-wise error in Float32 unit roundoffs of the
+    chunk's largest output, and a Float64 block-sum checksum; over the stream: the same three."""
+    n = int(os.environ.get("MDSP_TEST_STREAM", 2 ** 30))
+    g = torch.Generator(device="cuda"); g.manual_seed(1776)
+    x = torch.randn(n, generator=g, device="cuda", dtype=torch.float32)
+    from test_gpu_parity import _lowpass_taps
+    b = _lowpass_taps(256, np.float32)
+    y = d.fftfilt(b, x, 2048, engine=d.ENGINE_FUSED)
+    assert y.shape == (n,) and y.dtype == torch.float32
+    err2 = ref2 = 0.0
+    worst_u = 0.0
+    sum_got = sum_ref = 0.0
+    for lo, hi, ref in fz.oracle_filt_chunked(lambda lo, hi: x[lo:hi].cpu().numpy(), n, b, chunk=1 << 24):
+        got = y[lo:hi].cpu().numpy().astype(np.float64)
+        e = got - ref
+        err2 += float(e @ e)
+        ref2 += float(ref @ ref)
+        assert np.sqrt(float(e @ e) / float(ref @ ref)) < TOL32, (lo, hi)
+        u = ulps_of_max(got, ref)
+        worst_u = max(worst_u, u)
+        assert u < 2 * ULP_FFT * 11, (lo, hi, u)     # two 2048-point transforms and a spectrum product per output: 2 log2(nfft)
+        sum_got += float(got.sum())
+        sum_ref += float(ref.sum())
+    assert np.sqrt(err2 / ref2) < TOL32
+    # the checksum of all 2^30 outputs, in Float64: rounding errors of random sign do not add up (a block of 1793 missing outputs would show as ~40 sigma
+    # against the 3 sigma this admits)
+    assert abs(sum_got - sum_ref) <= 1e-4 * np.sqrt(ref2), (sum_got, sum_ref)
+    print("config 2, whole stream: norm-wise", np.sqrt(err2 / ref2), "worst element", worst_u, "unit roundoffs of the chunk maximum")
 
 
 def test_config3_welch_2p30_vs_oracle(d, torch):
