@@ -1078,12 +1078,19 @@ def dry_main(args, world, rank):
             want = torch.stack(parts).sum(0)
         err = float((red.to(torch.float64) / nch_total - want / nch_total).norm() / (want / nch_total).norm())
         check = "ok" if err < 1e-5 else f"FAILED ({err:.3e})"
+    # every rank's channel block, gathered: rank 0 reports them (the first 8-GPU run must see rank r own channels [r per_gpu, (r + 1) per_gpu))
+    blocks = [[mine.start, mine.stop]]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [mine.start, mine.stop])
+        blocks = gathered
     if rank == 0:
         print(json.dumps({"metric": METRIC if args.config == "filtwelch" else f"dry:{args.config}", "value": None, "unit": "Gsamples/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tt.item()) / max(1, args.steps) * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry mode)",
                           "config": {"workload": f"dry run of --config {args.config}", "name": args.config, "channels_total": nch_total,
-                                     "channels_per_gpu": per_gpu, "collective": "gloo (dry)", "collective_check": check, "allreduce_floats": nred}}), flush=True)
+                                     "channels_per_gpu": per_gpu, "channel_blocks": blocks, "collective": "gloo (dry)", "collective_check": check,
+                                     "allreduce_floats": nred}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,6 +36,24 @@ def test_bench_dry_two_ranks(config, per_gpu, nred):
     assert out["config"]["collective_check"] == ("ok" if nred else "n/a (no collective on this path)")
 
 
+@pytest.mark.parametrize("config,nch_total,per_gpu", [("stft", 64, 8), ("resample", 32, 4), ("filtwelch", 8, 1)])
+def test_bench_dry_eight_ranks_own_the_baseline_channel_blocks(config, nch_total, per_gpu):
+    """The shape the driver's 8-GPU run has (BASELINE configs 4 and 5: 64 channels -> 8 per GPU, 32 -> 4 per GPU), with eight gloo ranks on the CPU: rank r
+    owns the contiguous block [r per_gpu, (r + 1) per_gpu) -- a pointer offset into the channel-major signal, no repacking -- and the one
+    collective of the path agrees with an all_gather + Float64 sum on every rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--config", config, "--dry"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["channels_total"] == nch_total and out["config"]["channels_per_gpu"] == per_gpu
+    assert out["config"]["channel_blocks"] == [[r_ * per_gpu, (r_ + 1) * per_gpu] for r_ in range(8)]
+    assert out["config"]["collective_check"] == ("n/a (no collective on this path)" if config == "stft" else "ok")
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2 --dry` with NO launcher around it (the form the driver's single-command BENCH uses) starts two ranks itself and
     reports n_gpus 2; the step's collective is cross-checked against an all_gather + Float64 sum (`collective_check`)."""

@@ -73,14 +73,36 @@ def _worker(rank, world, port, q):
         # the bare collective
         t = torch.full((1000,), float(rank + 1), dtype=torch.float64, device="cuda")
         comm.allreduce_sum(t)
+        # the statistic of `bench.py --config resample` (BASELINE config 5 "RCCL avg"): resample this rank's channels, sum the last TAIL outputs over them
+        # (mdsp_channel_sum), ONE all-reduce of TAIL floats, 1 / nch_total
+        import ctypes as C
+        from fractions import Fraction
+        lib = _lib.lib()
+        TAIL, RLEN = 256, 40_000
+        h = np.asarray(d.resample_filter(Fraction(160, 147)), dtype=np.float32)
+        nloc = len(mine)
+        xr = torch.from_numpy(S[mine.start:mine.stop, :RLEN].copy()).cuda()
+        fh = C.c_void_p()
+        _lib.check(lib.mdsp_fir_create(C.byref(fh), h.ctypes.data_as(C.c_void_p), len(h), 160, 147, _lib.F32, _lib.F32, nloc))
+        ol = C.c_int64(); _lib.check(lib.mdsp_fir_outputlength(fh, RLEN, C.byref(ol)))
+        yr = torch.empty((nloc, ol.value), dtype=torch.float32, device="cuda")
+        nw = C.c_int64()
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.mdsp_fir_exec(fh, xr.data_ptr(), RLEN, RLEN, yr.data_ptr(), ol.value, ol.value, C.byref(nw), st))
+        avg = torch.empty(TAIL, dtype=torch.float32, device="cuda")
+        tail = yr[:, ol.value - TAIL:]
+        _lib.check(lib.mdsp_channel_sum(tail.data_ptr(), TAIL, nloc, ol.value, _lib.F32, avg.data_ptr(), st))
+        _lib.check(lib.mdsp_allreduce_sum(comm._h, avg.data_ptr(), TAIL, _lib.F32, st))
+        avg.mul_(1.0 / NCH)
+        _lib.check(lib.mdsp_fir_destroy(fh))
         torch.cuda.synchronize()
-        q.put((rank, "ok", mean.cpu().numpy(), psd.cpu().numpy(), float(t[0]), list(mine), (lo, hi)))
+        q.put((rank, "ok", mean.cpu().numpy(), psd.cpu().numpy(), float(t[0]), list(mine), (lo, hi), avg.cpu().numpy()))
         dist.barrier()
         comm.close()
         dist.destroy_process_group()
     except Exception as e:   # pragma: no cover
         import traceback
-        q.put((rank, "error", traceback.format_exc(), None, None, None, None))
+        q.put((rank, "error", traceback.format_exc(), None, None, None, None, None))
         raise e
 
 
@@ -115,7 +137,14 @@ def test_rccl_two_ranks_welch_channel_mean_and_time_split():
     whole = d.welch_pgram(S[0].copy(), cfg).power.astype(np.float64)
     covered = sorted(c for r in results for c in r[5])
     assert covered == list(range(NCH))
-    for rank, _, mean, psd, summed, _, _ in results:
+    # config 5's statistic: the oracle resamples every channel, the mean of the last 256 outputs over all five channels
+    from fractions import Fraction
+    from oracle import stream_filt as osf
+    ora_tail = np.mean([osf.resample(S[c, :40_000].astype(np.float64), Fraction(160, 147))[-256:] for c in range(NCH)], axis=0)
+    for rank, _, mean, psd, summed, _, _, avg in results:
+        assert relerr(avg, ora_tail) < 2e-6, rank
+    assert np.array_equal(results[0][7], results[1][7])
+    for rank, _, mean, psd, summed, _, _, _ in results:
         assert summed == 3.0                                               # 1 + 2 over the two ranks
         assert relerr(mean, ref_mean) < 1e-6, rank                        # Float32 sum of five PSDs in a different order
         assert relerr(mean, ora_mean) < 5e-6, rank
