@@ -140,7 +140,9 @@ def test_rccl_two_ranks_welch_channel_mean_and_time_split():
     # config 5's statistic: the oracle resamples every channel, the mean of the last 256 outputs over all five channels
     from fractions import Fraction
     from oracle import stream_filt as osf
-    ora_tail = np.mean([osf.resample(S[c, :40_000].astype(np.float64), Fraction(160, 147))[-256:] for c in range(NCH)], axis=0)
+    from oracle import design as odes
+    h64 = np.asarray(odes.resample_filter(Fraction(160, 147)), dtype=np.float32).astype(np.float64)
+    ora_tail = np.mean([osf.FIRFilter(h64, Fraction(160, 147)).filt(S[c, :40_000].astype(np.float64))[-256:] for c in range(NCH)], axis=0)   # (a fresh filter: no undelay, as the workers)
     for rank, _, mean, psd, summed, _, _, avg in results:
         assert relerr(avg, ora_tail) < 2e-6, rank
     assert np.array_equal(results[0][7], results[1][7])
