@@ -1694,7 +1694,10 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
         int64_t ngroups = 0;
         // R0 x a row size with a COMPILE-TIME schedule (16384 = 2 x 8192, 12500 = 5 x 2500, 20000 = 4 x 5000 ...): the same decomposition on the kernels of
         // spectral_gen.h (spectral_ctcols.hip) -- about half the vector instructions per point of the run-time schedule
-        if (tunables().gx != 4 && ctcols_split(pl->dtype, pl->nfft) > 0)
+        if (tunables().gx != 4 && tunables().gx != 5 && ctbig_ok(pl->dtype, pl->nfft))   // one workgroup, compile-time schedule (spectral_ctbig.hip): 8400 .. 12500 points
+            MDSP_TRY(ctbig_welch(pl->ctcols, pl->dtype, s, lds_, K, pl->n - pl->noverlap, nch, (int)pl->n, pl->nfft, pl->have_win ? pl->win.as<double>() : nullptr, st, &ngroups,
+                                 &pl->partial));
+        else if (tunables().gx != 4 && ctcols_split(pl->dtype, pl->nfft) > 0)
             MDSP_TRY(ctcols_welch(pl->ctcols, pl->dtype, s, lds_, K, pl->n - pl->noverlap, nch, (int)pl->n, pl->nfft, pl->have_win ? pl->win.as<double>() : nullptr, st, &ngroups,
                                   &pl->partial));
         else

@@ -184,14 +184,29 @@ template <typename R, bool CPLX, typename S> int cols_launch(ColsArgs& ca, int64
     X(4500, 320, 2064, 15, 15, 20) X(4608, 512, 2576, 9, 16, 32) X(5400, 512, 2576, 8, 27, 25) X(6250, 320, 2064, 10, 25, 25)                \
     X(6750, 512, 2064, 15, 18, 25) X(7000, 512, 2576, 14, 20, 25) X(7200, 512, 2576, 16, 18, 25) X(7680, 512, 2576, 15, 16, 32)
 
+// Float64 / ComplexF64 rows: up to 4096 points on ONE buffer of 16-byte elements with table twiddles (the single-workgroup Float64 schedules from 4800 points
+// spill 100 - 184 registers and move 1.8 - 2.6 x the algorithmic bytes: 5000 = 2 x 2500, 8000 = 2 x 4000 run here without scratch)
+#define MDSP_CTCOLS_SIZES_F64(X)                                                                                                        \
+    X(2000, 256, 2064, 5, 5, 5, 16) X(2400, 256, 2064, 3, 5, 5, 4, 8) X(2500, 256, 2064, 5, 5, 5, 5, 4) X(2560, 320, 2064, 5, 8, 8, 8)      \
+    X(3000, 384, 2064, 3, 5, 5, 5, 8) X(3072, 256, 2576, 3, 16, 8, 8) X(3200, 256, 2064, 5, 5, 8, 16) X(4000, 512, 2064, 5, 5, 5, 4, 8)     \
+    X(4096, 256, 2576, 16, 16, 16)
+
 template <typename R, bool CPLX> int cols_dispatch(ColsArgs& ca, int64_t nch, hipStream_t st, int64_t* ngroups, DevBuf* partial) {
-    switch (ca.g.N) {
 #define MDSP_X(N, T, F, ...) \
     case N: return cols_launch<R, CPLX, CtSched<N, T, F, __VA_ARGS__>>(ca, nch, st, ngroups, partial);
-        MDSP_CTCOLS_SIZES(MDSP_X)
-#undef MDSP_X
-        default: MDSP_FAIL(MDSP_ERR_ASSERTION, "no compile-time row schedule of %d points", ca.g.N);
+    if constexpr (sizeof(R) == 4) {
+        switch (ca.g.N) {
+            MDSP_CTCOLS_SIZES(MDSP_X)
+            default: break;
+        }
+    } else {
+        switch (ca.g.N) {
+            MDSP_CTCOLS_SIZES_F64(MDSP_X)
+            default: break;
+        }
     }
+#undef MDSP_X
+    MDSP_FAIL(MDSP_ERR_ASSERTION, "no compile-time row schedule of %d points", ca.g.N);
 }
 
 template <typename R> int upload_roots_n(DevBuf& buf, int64_t n) {
@@ -209,7 +224,19 @@ template <typename R> int upload_roots_n(DevBuf& buf, int64_t n) {
 
 namespace mdsp {
 int ctcols_split(int dtype, int64_t nfft) {
-    if (dtype_is_double(dtype)) return 0;   // (Float32 / ComplexF32 instantiations only, so far)
+    if (dtype_is_double(dtype)) {
+        for (int R0 = 2; R0 <= 4; ++R0) {
+            if (nfft % R0) continue;
+            switch (nfft / R0) {
+#define MDSP_X(N, ...) case N:
+                MDSP_CTCOLS_SIZES_F64(MDSP_X)
+#undef MDSP_X
+                return R0;
+                default: break;
+            }
+        }
+        return 0;
+    }
     // R0 = 2 .. 4, and 8 x 8192 (measured, profiles/r06_ctcols.json: 16384 = 2 x 8192 1.0 TB/s, 32768 = 4 x 8192 0.79, 65536 = 8 x 8192 0.56 against the
     // multi-pass engine's 0.44; from R0 = 5 the R0 reads per point cost what the row kernel saves: 40000 = 5 x 8000 0.30 against 0.34 on the run-time schedule)
     for (int R0 = 2; R0 <= 8; ++R0) {
@@ -230,20 +257,22 @@ int ctcols_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t
     const int R0 = ctcols_split(dtype, nfft);
     if (R0 == 0) MDSP_FAIL(MDSP_ERR_ASSERTION, "nfft=%lld is not R0 x a compile-time row size", (long long)nfft);
     const int64_t S = nfft / R0;
+    const bool dbl = dtype_is_double(dtype), cplx = dtype_is_complex(dtype);
     if (!cp.ready) {
-        MDSP_TRY(upload_roots_n<float>(cp.roots, S));
-        MDSP_TRY(upload_roots_n<float>(cp.rootsN, nfft));
-        MDSP_TRY(cp.win.reserve(sizeof(float) * (size_t)nfft));
+        MDSP_TRY(dbl ? upload_roots_n<double>(cp.roots, S) : upload_roots_n<float>(cp.roots, S));
+        MDSP_TRY(dbl ? upload_roots_n<double>(cp.rootsN, nfft) : upload_roots_n<float>(cp.rootsN, nfft));
+        MDSP_TRY(cp.win.reserve((dbl ? sizeof(double) : sizeof(float)) * (size_t)nfft));
         cp.ready = true;
     }
-    hipLaunchKernelGGL(cols_window_kernel<float>, dim3((unsigned)cdiv(nfft, 256)), dim3(256), 0, st, win_dev, cp.win.as<float>(), n, (int)nfft);
+    if (dbl) hipLaunchKernelGGL(cols_window_kernel<double>, dim3((unsigned)cdiv(nfft, 256)), dim3(256), 0, st, win_dev, cp.win.as<double>(), n, (int)nfft);
+    else hipLaunchKernelGGL(cols_window_kernel<float>, dim3((unsigned)cdiv(nfft, 256)), dim3(256), 0, st, win_dev, cp.win.as<float>(), n, (int)nfft);
     MDSP_LAUNCH_CHECK();
-    const bool cplx = dtype_is_complex(dtype);
     ColsArgs ca{};
     ca.g.s = s; ca.g.roots = cp.roots.p; ca.g.lds_ = lds_; ca.g.K = K; ca.g.hop = hop; ca.g.nch = nch;
     ca.g.units_per_ch = cplx ? K : cdiv(K, 2);
     ca.g.n = n; ca.g.N = (int)S;
     ca.winf = cp.win.p; ca.rootsN = cp.rootsN.p; ca.nfft = (int)nfft; ca.R0 = R0;
+    if (dbl) return cplx ? cols_dispatch<double, true>(ca, nch, st, ngroups, partial) : cols_dispatch<double, false>(ca, nch, st, ngroups, partial);
     return cplx ? cols_dispatch<float, true>(ca, nch, st, ngroups, partial) : cols_dispatch<float, false>(ca, nch, st, ngroups, partial);
 }
 }  // namespace mdsp

@@ -22,6 +22,8 @@ x = torch.randn(n, device="cuda", dtype=torch.float32)
 S = [2000, 2400, 2500, 2560, 3000, 3072, 3200, 3840, 4000, 4096, 4800, 5000, 5120, 6000, 6144, 6400, 8000, 8192, 4200, 4500, 4608, 5400, 5600, 6250, 6750, 7000, 7200,
      7500, 7680, 8100]
 sizes = sorted({r * s for r in (2, 3, 4) for s in S if r * s > 8192})
+if os.environ.get("SWEEP_SIZES"):   # any list of nfft instead (e.g. the single-workgroup sizes of csrc/spectral_ctbig.hip)
+    sizes = [int(v) for v in os.environ["SWEEP_SIZES"].split(",")]
 
 
 def ev():
