@@ -292,9 +292,9 @@ ROW_INFO = {
     "welch_default": ("multi-pass engine (bigfft.hip)", "welch_pgram(s) with DEFAULT arguments, 2^27 Float32: n = nfft = 2^24, 15 frames", "4"),
     "welch_default_2p24": ("multi-pass engine", "welch_pgram(s), 2^24 Float32: n = nfft = 2^21", "4"),
     "welch_8192": ("welch_half_kernel<8192>", "2^27 Float32, n = nfft = 8192, 50 % overlap (the largest register-resident power of two: the yardstick of the sizes above it)", "4"),
-    "welch_12500": ("gx_kernel (run-time schedule, csrc/gx_kernels.h)", "2^27 Float32, n = nfft = 12500 = nextfastfft(10^5 >> 3), 50 % overlap", "4"),
-    "welch_16384": ("gx_kernel, 2 x 8192 (column step fused into the loads)", "2^27 Float32, n = nfft = 16384, 50 % overlap", "4"),
-    "welch_65536": ("multi-pass engine, 256 x 256", "2^27 Float32, n = nfft = 65536, 50 % overlap", "4"),
+    "welch_12500": ("gen_ct_kernel<12500 = 25 20 25> (one workgroup, one LDS buffer: csrc/spectral_ctbig.hip)", "2^27 Float32, n = nfft = 12500 = nextfastfft(10^5 >> 3), 50 % overlap", "4"),
+    "welch_16384": ("gen_ct_cols_kernel<8192 = 16 32 16>, 2 x 8192 (column step fused into the loads: csrc/spectral_ctcols.hip)", "2^27 Float32, n = nfft = 16384, 50 % overlap", "4"),
+    "welch_65536": ("gen_ct_cols_kernel<8192>, 8 x 8192 (the multi-pass engine's 256 x 256 measured 0.44 TB/s against 0.56)", "2^27 Float32, n = nfft = 65536, 50 % overlap", "4"),
     "welch_125000": ("multi-pass engine, 250 x 500 (generic phases)", "2^27 Float32, n = nfft = 125000 = nextfastfft(10^6 >> 3), 50 % overlap", "4"),
     "welch_2p19": ("multi-pass engine, rows form (column pass + single-workgroup Welch kernel over the rows)", "2^27 Float32, n = nfft = 2^19, 50 % overlap: 511 frames", "4"),
     "spectrogram_default": ("multi-pass engine + untangle", "spectrogram(s) with DEFAULT arguments, 2^27 Float32 -> (2^23 + 1) x 15 Float32", "4 in + 4 per bin out"),

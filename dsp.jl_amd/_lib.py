@@ -55,6 +55,7 @@ PROTOTYPES = {
     "mdsp_init": (ci, [ci]),
     "mdsp_shutdown": (ci, []),
     "mdsp_reload_tunables": (ci, []),
+    "mdsp_set_knob": (ci, [C.c_char_p, ci, ci]),
     "mdsp_debug_knobs": (ci, []),
     "mdsp_device_count": (ci, [pint]),
     "mdsp_malloc": (ci, [pvp, C.c_size_t]),
@@ -200,14 +201,25 @@ def lib() -> C.CDLL:
     return _lib
 
 
+# the environment variables of a product build (include/mi355dsp.h); every other MDSP_* name the tools and tests set is a knob (mdsp_set_knob)
+ENV_VARIABLES = ("MDSP_ENGINE", "MDSP_WG_PER_CU", "MDSP_PLAN_CACHE_TOTAL", "MDSP_PLAN_CACHE_IDLE", "MDSP_ROCFFT_CHUNK_MIB", "MDSP_HOST_CHUNK_MIB", "MDSP_BIG_CHUNK_MIB",
+                 "MDSP_BIGFFT", "MDSP_GX", "MDSP_FIR_MM", "MDSP_FIR_DEC", "MDSP_FIR_EXACT", "MDSP_ARB_SCAN", "MDSP_ARB_SCAN_MIN", "MDSP_FIR_CHOICE_FILE")
+_DEBUG_ENV = ("MDSP_ABLATE", "MDSP_WELCH_NOHALF", "MDSP_STFT_NOSHIFT", "MDSP_STFT_NOPAIR", "MDSP_STFT_NODIRECT", "MDSP_FIR_GENERIC", "MDSP_FIR_IDENTITY_LANES",
+              "MDSP_MT_PASSES", "MDSP_ARB_PROF")   # profiling switches of -DMDSP_DEBUG_KNOBS builds: environment only
+
+
 def set_tunable(name: str, value) -> None:
-    """Set (or, with None, clear) a tuning variable in the environment AND make the library re-read it: libmi355dsp reads its
-    environment once (mdsp_init / first use), never on exec or plan paths.  Tuning tools only."""
-    if value is None:
-        os.environ.pop(name, None)
-    else:
-        os.environ[name] = str(value)
-    check(lib().mdsp_reload_tunables())
+    """Set (or, with None, put back the default of) a tuning variable and make the library take it: one of the fifteen environment variables goes into the
+    environment (libmi355dsp reads it once -- mdsp_init / first use -- and again on mdsp_reload_tunables, never on exec or plan paths); anything else is a
+    knob and goes through mdsp_set_knob (round 6: experiments are not steered through the environment of a product build).  Tuning tools and tests only."""
+    if name in ENV_VARIABLES or name in _DEBUG_ENV:
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(value)
+        check(lib().mdsp_reload_tunables())
+        return
+    check(lib().mdsp_set_knob(name.encode(), 0 if value is None else int(value), 1 if value is None else 0))
 
 
 def check(status: int) -> None:

@@ -60,12 +60,15 @@ const char* mdsp_last_error_string(void);
 /* Select the device for the calling thread and create the per-device context (rocFFT setup, plan cache). */
 int mdsp_init(int device);
 int mdsp_shutdown(void);
-/* Optional tuning variables (MDSP_ENGINE, MDSP_*_VARIANT, MDSP_WG_PER_CU, ... -- DESIGN.md section 5) are read from the environment once,
- * by mdsp_init() or on first use; exec and plan paths never call getenv.  mdsp_reload_tunables() re-reads them (tuning sweeps inside one
- * process) and is NOT thread-safe against concurrent library calls: exec and plan paths read the table without a lock, so call it only while
- * no other thread is inside the library (tuning tools are single-threaded).  mdsp_debug_knobs() is 1 only for a library built with -DMDSP_DEBUG_KNOBS, the only builds in which the profiling switches
- * (MDSP_ABLATE, MDSP_WELCH_NOHALF, MDSP_STFT_NOSHIFT / _NOPAIR / _NODIRECT, MDSP_FIR_GENERIC, ...) exist at all. */
+/* Fifteen optional environment variables (INTEGRATION.md "Environment": MDSP_ENGINE, MDSP_WG_PER_CU, MDSP_PLAN_CACHE_TOTAL / _IDLE, MDSP_ROCFFT_CHUNK_MIB,
+ * MDSP_HOST_CHUNK_MIB, MDSP_BIG_CHUNK_MIB, MDSP_BIGFFT, MDSP_GX, MDSP_FIR_MM, MDSP_FIR_DEC, MDSP_FIR_EXACT, MDSP_ARB_SCAN, MDSP_ARB_SCAN_MIN,
+ * MDSP_FIR_CHOICE_FILE) are read once, by mdsp_init() or on first use; exec and plan paths never call getenv.  mdsp_reload_tunables() re-reads them and is NOT
+ * thread-safe against concurrent library calls (exec and plan paths read the table without a lock: tuning tools are single-threaded).
+ * Everything that only steers an experiment -- kernel variants, tile shapes, wave priorities (about fifty names up to round 5) -- is a KNOB, not an environment
+ * variable: mdsp_set_knob(name, value, 0) sets one, (name, 0, 1) puts its default back; used by tools/ and tests/ only.  mdsp_debug_knobs() is 1 only for a
+ * library built with -DMDSP_DEBUG_KNOBS, which also reads every knob from the environment and carries the profiling switches (MDSP_ABLATE, ...). */
 int mdsp_reload_tunables(void);
+int mdsp_set_knob(const char* name, int value, int unset);
 int mdsp_debug_knobs(void);
 int mdsp_device_count(int* count);
 

@@ -80,7 +80,9 @@ function device_count()
     n = Ref{Cint}(0)
     check(ccall((:mdsp_device_count, lib), Cint, (Ref{Cint},), n)); Int(n[])
 end
-reload_tunables() = check(ccall((:mdsp_reload_tunables, lib), Cint, ()))           # tuning tools only: re-read MDSP_* from ENV
+reload_tunables() = check(ccall((:mdsp_reload_tunables, lib), Cint, ()))           # tuning tools only: re-read the fifteen MDSP_* variables from ENV
+set_knob(name::AbstractString, value::Integer) = check(ccall((:mdsp_set_knob, lib), Cint, (Cstring, Cint, Cint), name, value, 0))   # experiments: not environment variables
+unset_knob(name::AbstractString) = check(ccall((:mdsp_set_knob, lib), Cint, (Cstring, Cint, Cint), name, 0, 1))
 debug_knobs() = ccall((:mdsp_debug_knobs, lib), Cint, ()) != 0
 synchronize(stream::Ptr{Cvoid}=C_NULL) = check(ccall((:mdsp_stream_synchronize, lib), Cint, (Ptr{Cvoid},), stream))
 function plan_cache_stats()
