@@ -166,7 +166,7 @@ struct Tunables {
     int gen_ct_f64_max = 8000;          // MDSP_GEN_CT_F64_MAX      : Float64 nextfastfft sizes above this leave the single-workgroup compile-time schedules (for the multi-pass engine)
     int ols_prefetch = 0;               // MDSP_OLS_PREFETCH=1      : overlap-save kernel with software prefetch of the next unit (default: off)
     int gx = 1;                         // MDSP_GX=0|2              : 0 = no run-time-schedule single-workgroup kernel (spectral_gx.h: sizes without a compile-time schedule go to
-                                        //                            the round-2 LDS kernel / the multi-pass engine / rocFFT as up to round 5); 2 = that kernel for EVERY size it plans (A/B); 4 = never the compile-time kernels of spectral_ctcols.hip / spectral_ctbig.hip, 5 = never spectral_ctbig.hip (A/B)
+                                        //                            the round-2 LDS kernel / the multi-pass engine / rocFFT as up to round 5); 2 = that kernel for EVERY size it plans (A/B); 6 = no rows above 8192 points (spectral_ctcols_big.hip); 4 = never the compile-time kernels of spectral_ctcols.hip / spectral_ctbig.hip, 5 = never spectral_ctbig.hip (A/B)
     int bigfft = 1;                     // MDSP_BIGFFT=0            : transforms above the one-workgroup sizes go to the rocFFT pipeline instead of the multi-pass fused engine (bigfft.hip)
     int big_chunk_mib = 1024;           // MDSP_BIG_CHUNK_MIB       : work buffer of the multi-pass engine per launch group.  Measured 16 .. 2048 MiB (profiles/r05_bigfft_sessions.json):
                                         //                            larger is faster up to all transforms in one group (fewer launches, one accumulator update); no Infinity Cache effect seen

@@ -14,6 +14,9 @@ template <int N_, int T_, int LDSIN_, int... RS> struct CtSched {
     static constexpr int MINW_WELCH = (LDSIN_ & 32) ? 2 : 1; // waves per SIMD the Welch kernel is compiled for (register cap 256)
     static constexpr int MINW_REAL = (LDSIN_ & 7) > 1 ? (LDSIN_ & 7) : 1;   // waves per SIMD the column (STFT) kernels are compiled for (register cap): a
                                                                  // workgroup of 6 waves puts two on some SIMDs, and two such workgroups need four there   // real-signal column modes window the frame pair into LDS first (the register-fed first pass costs them a resident workgroup)
+    // Welch sums at 16 - 50 points per thread (round 6, spectral_ctbig.hip): 4096 the window is loaded beside the samples (spectral_gen.h ct_pass0_lean)
+    // instead of living in registers; 8192 the sums are kept in the working precision and flushed to the Float64 partials every 64 units
+    static constexpr bool LEANW = (LDSIN_ & 4096) != 0, LEANA = (LDSIN_ & 8192) != 0;
     static constexpr int radix(int p) {
         constexpr int r[] = {RS...};
         return r[p];
@@ -36,6 +39,7 @@ template <int N_, int T_, int LDSIN_, int... RS> struct CtSched {
     // 8000 = 5 5 5 8 8 -- 240 VGPRs of doubles next to the butterflies, the window and the sums, i.e. 100 - 184 scratch operations per kernel and HBM
     // traffic 1.8 (5000) to 6.9 (8000) times the algorithmic bytes (bench.py rows welch_f64_5000 / _8000, profiles/r05_f64_twiddles.json).
     static constexpr bool TW2L = (LDSIN_ & 2048) != 0;
+    static constexpr bool TWD = (LDSIN_ & 16384) != 0;      // with TW2L: a butterfly's twiddles as products of ~2 sqrt(R) table values (spectral_gen.h ct_apply_twiddles)
     static constexpr int TWS = 128, NTWHI = (N + TWS - 1) / TWS;
     static constexpr int NTW = (!TW2L && twoff(P) > 0) ? twoff(P) : 1;
     static constexpr int BINS = (N + T - 1) / T;

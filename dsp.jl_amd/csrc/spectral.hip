@@ -690,7 +690,10 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 //                    (1.4 - 1.7 against 0.9 - 1.3 TB/s) and at R0 >= 5 (40000: 0.75 / 0.91 against 0.67 / 0.59)
 bool use_gx(int dtype, int64_t nfft, bool direct, int kind) {
     const int m = tunables().gx;
-    if (m == 0 || !gx_size_ok(dtype, nfft)) return false;
+    if (m == 0) return false;
+    if (kind == 0 && m != 4 && !fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && ((m != 5 && ctbig_ok(dtype, nfft)) || ctcols_split(dtype, nfft) > 0))
+        return true;   // Welch sums on a compile-time schedule (one workgroup, or R0 x S rows): whatever the run-time-schedule kernel plans
+    if (!gx_size_ok(dtype, nfft)) return false;
     if (m >= 2) return true;
     const bool pow2 = (nfft & (nfft - 1)) == 0;
     if (pow2 && nfft >= (kind == 0 ? 32768 : 16384) && big::size_ok(dtype, nfft) && !(kind == 0 && ctcols_split(dtype, nfft) > 0)) return false;   // (Welch, Float32: 4 x / 8 x 8192 on the compile-time rows)

@@ -13,6 +13,10 @@ int ctcols_split(int dtype, int64_t nfft);
 // partial[(group, ch)][nfft] (+ reduce by the caller): Float64 sums of |Z|^2 per bin, natural order
 int ctcols_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,
                  hipStream_t st, int64_t* ngroups, DevBuf* partial);
+// spectral_ctcols_big.hip: rows of 8193 .. 16384 points (the single-workgroup schedules of ctbig_sizes.h); ctcols_split / ctcols_welch route to them
+bool ctcols_big_row_ok(int dtype, int64_t S);
+int ctcols_big_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, int R0,
+                     const double* win_dev, hipStream_t st, int64_t* ngroups, DevBuf* partial);
 // spectral_ctbig.hip: nfft between 8193 and 16384 points with a single-workgroup compile-time schedule (Float32 / ComplexF32); cp holds the nfft roots
 bool ctbig_ok(int dtype, int64_t nfft);
 int ctbig_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,

@@ -21,153 +21,7 @@ using mdsp::fft::cx;
 namespace {
 #include "spectral_gen.h"
 
-struct ColsArgs {
-    GenArgs g;             // s, out (partials), roots (of S), lds_, K, hop, nch, units_per_ch, per_slot, n, N = S
-    const void* winf;      // R window[nfft] (ones without a window, zero tail)
-    const void* rootsN;    // nfft forward roots, cx<R>
-    int nfft, R0;
-};
-
-template <typename R, bool CPLX, typename S>
-__global__ __launch_bounds__(S::T, 2) void gen_ct_cols_kernel(ColsArgs ca) {
-    const GenArgs& a = ca.g;
-    using TT = std::conditional_t<CPLX, cx<R>, R>;
-    constexpr int N = S::N, T = S::T;
-    constexpr int PL = S::P - 1, RL = S::radix(PL), ML = S::M(PL), NBL = S::nbf(PL);
-    constexpr int R0r = S::radix(0), M0 = S::M(0), NB0 = S::nbf(0), W0 = M0 * R0r;
-    constexpr bool INPL = S::INPLACE;
-    constexpr int SZ = (int)sizeof(TT), WZ = (int)sizeof(R);
-    __shared__ __attribute__((aligned(16))) cx<R> buf[INPL ? S::NP : 2 * S::NP];
-    cx<R>*bufA = buf, *bufB = INPL ? buf : buf + S::NP;
-    const int t = threadIdx.x;
-    const int64_t ch = blockIdx.y;
-    const TT* sc = static_cast<const TT*>(a.s) + ch * a.lds_;
-    // group of workgroups (one frame sequence) and row k1; the R0 rows of a group on one XCD (workgroups go to the XCDs round-robin)
-    const unsigned b = blockIdx.x, xcd = b & 7u, wq = b >> 3;
-    const int k1 = (int)(wq % (unsigned)ca.R0);
-    const int64_t gslot = (int64_t)(wq / (unsigned)ca.R0) * 8 + xcd;
-    const int64_t u0 = gslot * a.per_slot;
-    cx<R> tw[S::NTW];
-    ct_load_twiddles<S, 0>(tw, static_cast<const cx<R>*>(a.roots), t);
-    __shared__ __attribute__((aligned(16))) cx<R> twlo[S::TW2L ? S::TWS : 1], twhi[S::TW2L ? S::NTWHI : 1];
-    const CtTw<R> t2{twlo, twhi};
-    if constexpr (S::TW2L) {
-        const cx<R>* g = static_cast<const cx<R>*>(a.roots);
-        for (int i = t; i < S::TWS; i += T) fft::st2(twlo + i, g[i]);
-        for (int i = t; i < S::NTWHI; i += T) fft::st2(twhi + i, g[(unsigned)i * S::TWS]);
-    }
-    // W_nfft^{i k1} at the points of this thread's first-pass butterflies: loop invariants
-    const cx<R>* rootsN = static_cast<const cx<R>*>(ca.rootsN);
-    cx<R> twc[W0];
-#pragma unroll
-    for (int m = 0; m < M0; ++m)
-#pragma unroll
-        for (int q = 0; q < R0r; ++q) {
-            const unsigned i = (unsigned)(t + T * m + NB0 * q);
-            twc[m * R0r + q] = rootsN[(unsigned)(((unsigned long long)(i < (unsigned)N ? i : 0u) * (unsigned)k1) % (unsigned)ca.nfft)];
-        }
-    double acc[ML * RL];
-#pragma unroll
-    for (int i = 0; i < ML * RL; ++i) acc[i] = 0.0;
-    const __amdgpu_buffer_rsrc_t dw = io::make_rsrc(ca.winf, (long long)ca.nfft * WZ);
-    for (int64_t it = 0; it < a.per_slot; ++it) {
-        const int64_t u = u0 + it;
-        const bool live = u < a.units_per_ch;
-        const int64_t f0 = live ? (CPLX ? u : 2 * u) : 0;
-        const bool haveB = !CPLX && live && (f0 + 1) < a.K;
-        const TT* fa = sc + f0 * a.hop;
-        const __amdgpu_buffer_rsrc_t da = io::make_rsrc(fa, live ? (long long)a.n * SZ : 0);
-        const __amdgpu_buffer_rsrc_t db = io::make_rsrc(fa + (CPLX ? 0 : a.hop), haveB ? (long long)a.n * SZ : 0);
-        // ---- first pass: the k1-th combination of the R0 segments of the windowed frame (pair), formed while loading
-        cx<R> v0[W0];
-#pragma unroll
-        for (int i = 0; i < W0; ++i) v0[i] = cx<R>{(R)0, (R)0};
-        int off = t * SZ, offw = t * WZ;
-        asm volatile("" : "+v"(off), "+v"(offw));
-        unsigned cidx = 0;   // n1 k1 mod R0
-        for (int n1 = 0; n1 < ca.R0; ++n1) {
-            const cx<R> c = rootsN[(unsigned)cidx * (unsigned)N];   // W_R0^{n1 k1} = W_nfft^{S (n1 k1 mod R0)}: wave-uniform
-            cidx += (unsigned)k1;
-            if (cidx >= (unsigned)ca.R0) cidx -= (unsigned)ca.R0;
-            TT ra[W0], rb[CPLX ? 1 : W0];
-            R w[W0];
-#pragma unroll
-            for (int m = 0; m < M0; ++m)
-#pragma unroll
-                for (int q = 0; q < R0r; ++q) {
-                    const int e = T * m + NB0 * q;
-                    ra[m * R0r + q] = io::Ld<TT>::load(da, off + e * SZ);
-                    if constexpr (!CPLX) rb[m * R0r + q] = io::Ld<TT>::load(db, off + e * SZ);
-                    w[m * R0r + q] = io::Ld<R>::load(dw, offw + e * WZ);
-                }
-#pragma unroll
-            for (int i = 0; i < W0; ++i) {
-                cx<R> z;
-                if constexpr (CPLX) z = {ra[i].x * w[i], ra[i].y * w[i]};
-                else z = {ra[i] * w[i], rb[i] * w[i]};
-                v0[i] = fft::cadd(v0[i], fft::cmul(z, c));
-            }
-            off += N * SZ;
-            offw += N * WZ;
-        }
-#pragma unroll
-        for (int m = 0; m < M0; ++m) {
-            const int j = t + T * m;
-            if ((m + 1) * T <= NB0 || j < NB0) {
-                cx<R> v[R0r];
-#pragma unroll
-                for (int q = 0; q < R0r; ++q) v[q] = k1 == 0 ? v0[m * R0r + q] : fft::cmul(v0[m * R0r + q], twc[m * R0r + q]);
-                fft::gen_bfly<R0r>(v);
-                cx<R>* o = bufA + (unsigned)j * (unsigned)(R0r + (S::padded(0) ? 1 : 0));
-#pragma unroll
-                for (int q = 0; q < R0r; ++q) fft::st2(o + q, v[q]);
-            }
-        }
-        __syncthreads();
-        // ---- the other passes exactly as gen_ct_kernel's register-consumed modes
-        const cx<R>* src = bufA;
-        if constexpr (INPL) ct_passes_inplace<S, 1, S::P - 1>(bufA, tw, t, t2);
-        else src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t, t2);
-        ct_last_pass_regs<S>(src, tw, t, t2, [&](int m, int q, int, cx<R> z) { acc[m * RL + q] += (double)(z.x * z.x + z.y * z.y); });   // (a unit that does not exist transformed zeros)
-        __syncthreads();
-    }
-    double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)ca.nfft + k1;
-#pragma unroll
-    for (int m = 0; m < ML; ++m) {
-        const int j = t + T * m;
-        if ((m + 1) * T <= NBL || j < NBL) {
-#pragma unroll
-            for (int q = 0; q < RL; ++q) part[(int64_t)(j + NBL * q) * ca.R0] = acc[m * RL + q];
-        }
-    }
-}
-
-template <typename R> __global__ __launch_bounds__(256) void cols_window_kernel(const double* __restrict__ win, R* __restrict__ out, int n, int nfft) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nfft) out[i] = i < n ? (win ? (R)win[i] : (R)1) : (R)0;
-}
-
-template <typename R, bool CPLX, typename S> int cols_launch(ColsArgs& ca, int64_t nch, hipStream_t st, int64_t* ngroups, DevBuf* partial) {
-    auto kern = gen_ct_cols_kernel<R, CPLX, S>;
-    GenArgs& a = ca.g;
-    hipFuncAttributes fa{};
-    MDSP_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
-    const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8), waves = S::T / 64;
-    const size_t lds_bytes = sizeof(cx<R>) * ((S::INPLACE ? 1 : 2) * (size_t)S::NP + (S::TW2L ? S::TWS + S::NTWHI : 0));
-    int per_cu = std::min<int>({32 / waves, (512 / regs) * 4 / waves, (int)((size_t)160 * 1024 / std::max<size_t>(lds_bytes, 1))});
-    if (per_cu < 1) per_cu = 1;
-    if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
-    const int64_t resident = std::max<int64_t>(1, (int64_t)device_cu_count() * per_cu / std::max<int64_t>(1, nch));
-    int64_t groups = std::max<int64_t>(1, std::min<int64_t>(a.units_per_ch, resident / ca.R0));
-    groups = std::max<int64_t>(8, groups / 8 * 8);   // the XCD mapping walks groups in eights; rounded DOWN: 85 -> 88 groups of three workgroups are 264 on 256 CUs, a second round for 8
-    a.per_slot = cdiv(a.units_per_ch, groups);
-    *ngroups = groups;
-    MDSP_TRY(partial->reserve(sizeof(double) * (size_t)groups * (size_t)nch * (size_t)ca.nfft));
-    a.out = partial->p;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * ca.R0), (unsigned)nch), dim3(S::T), 0, st, ca);
-    MDSP_LAUNCH_CHECK();
-    return MDSP_OK;
-}
+#include "spectral_ctcols_kernel.h"
 
 // the row sizes with a COLS instantiation: the compile-time schedules from 2000 points and two powers of two (16384 = 2 x 8192, 12288 = 3 x 4096 ...).
 // Flags: group padding (512) wherever a pass's output groups alias the banks (the 8192-point rows ran with 58 % of their LDS cycles in conflicts without it);
@@ -209,17 +63,6 @@ template <typename R, bool CPLX> int cols_dispatch(ColsArgs& ca, int64_t nch, hi
     MDSP_FAIL(MDSP_ERR_ASSERTION, "no compile-time row schedule of %d points", ca.g.N);
 }
 
-template <typename R> int upload_roots_n(DevBuf& buf, int64_t n) {
-    std::vector<cx<R>> w((size_t)n);
-    for (int64_t k = 0; k < n; ++k) {
-        const zd r = unit_root(k, n, -1);
-        w[(size_t)k] = {(R)r.real(), (R)r.imag()};
-    }
-    MDSP_TRY(buf.reserve(sizeof(cx<R>) * (size_t)n));
-    MDSP_HIP(hipMemcpy(buf.p, w.data(), sizeof(cx<R>) * (size_t)n, hipMemcpyHostToDevice));
-    return MDSP_OK;
-}
-
 }  // namespace
 
 namespace mdsp {
@@ -239,8 +82,14 @@ int ctcols_split(int dtype, int64_t nfft) {
     }
     // R0 = 2 .. 4, and 8 x 8192 (measured, profiles/r06_ctcols.json: 16384 = 2 x 8192 1.0 TB/s, 32768 = 4 x 8192 0.79, 65536 = 8 x 8192 0.56 against the
     // multi-pass engine's 0.44; from R0 = 5 the R0 reads per point cost what the row kernel saves: 40000 = 5 x 8000 0.30 against 0.34 on the run-time schedule)
+    // round 6, later: rows of 8193 .. 16384 points (spectral_ctcols_big.hip) come first -- the smallest column factor wins (MDSP_GX=6: without them)
+    // (measured, profiles/r06_ctcols_big.json: 2 x S 0.71 - 1.01 TB/s against 0.42 - 0.75 without them, 65536 = 4 x 16384 0.80 against 0.49 as 8 x 8192, and up to
+    // R0 = 8 -- 81920 = 5 x 16384 0.65, 100000 = 8 x 12500 0.46, 131072 = 8 x 16384 0.53 -- against the multi-pass engine's 0.18 - 0.35)
+    const int big_r0_max = 8;
     for (int R0 = 2; R0 <= 8; ++R0) {
-        if (nfft % R0 || (R0 > 4 && !(R0 == 8 && nfft == 65536))) continue;
+        if (nfft % R0) continue;
+        if (tunables().gx != 6 && R0 <= big_r0_max && ctcols_big_row_ok(dtype, nfft / R0)) return R0;
+        if (R0 > 4 && !(R0 == 8 && nfft == 65536)) continue;
         switch (nfft / R0) {
 #define MDSP_X(N, ...) case N:
             MDSP_CTCOLS_SIZES(MDSP_X)
@@ -257,6 +106,7 @@ int ctcols_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t
     const int R0 = ctcols_split(dtype, nfft);
     if (R0 == 0) MDSP_FAIL(MDSP_ERR_ASSERTION, "nfft=%lld is not R0 x a compile-time row size", (long long)nfft);
     const int64_t S = nfft / R0;
+    if (tunables().gx != 6 && ctcols_big_row_ok(dtype, S)) return ctcols_big_welch(cp, dtype, s, lds_, K, hop, nch, n, nfft, R0, win_dev, st, ngroups, partial);
     const bool dbl = dtype_is_double(dtype), cplx = dtype_is_complex(dtype);
     if (!cp.ready) {
         MDSP_TRY(dbl ? upload_roots_n<double>(cp.roots, S) : upload_roots_n<float>(cp.roots, S));

@@ -11,6 +11,9 @@
 // against ~9x that for the K4 -> rocFFT -> K5/K6 pipeline these sizes used to take.
 #pragma once
 
+#ifndef MDSP_GEN_LEAN_FLUSH
+#define MDSP_GEN_LEAN_FLUSH 64   // units between flushes of the lean form's Float32 sums (a power of two): as the run-time-schedule kernel (gx_kernels.h)
+#endif
 struct GenArgs {
     const void* s;
     void* out;             // Welch: double partials [slot][ch][N];  STFT: output matrices
@@ -25,6 +28,7 @@ struct GenArgs {
     int radix[MDSP_GEN_MAXP], ns[MDSP_GEN_MAXP];
     unsigned divm[MDSP_GEN_MAXP];
     double r;
+    const void* winr;      // lean compile-time schedules (CtSched flag 4096): the window in the working precision, N values (ones without a window, zero tail)
 };
 
 // bins per thread in the Welch accumulator: 16 up to N = 4096 with T = 256, 32 beyond (template parameter EMAX)
@@ -196,6 +200,35 @@ __device__ __forceinline__ cx<R> ct_tw(const cx<R> (&tw)[S::NTW], CtTw<R> t2, in
     }
 }
 
+// The twiddles of one butterfly applied to its operands 1 .. R-1.  Table form with CtSched::TWD (round 6): W^{q e1}, q = C a + b, is the product of
+// W^{b e1} (b < C) and W^{C a e1} -- about 2 sqrt(R) table values (two LDS reads and a product each) instead of R - 1, the same number of complex
+// products per butterfly: a radix-32 pass reads 20 table entries instead of 62 (the single-workgroup kernels of 8193 .. 16384 points run two waves per
+// SIMD at LDS 26 - 36 % and VALU 41 - 46 % busy: they wait on LDS latency, profiles/r06_ctbig_lean.json).
+constexpr int ct_twd_c(int r) { return r <= 6 ? r : r <= 9 ? 3 : r <= 16 ? 4 : r <= 25 ? 5 : 6; }
+template <typename S, int p, typename R>
+__device__ __forceinline__ void ct_apply_twiddles(cx<R> (&v)[S::radix(p)], const cx<R> (&tw)[S::NTW], CtTw<R> t2, int m, unsigned k) {
+    constexpr int Rdx = S::radix(p);
+    if constexpr (S::TW2L && S::TWD && (Rdx > 6)) {
+        constexpr int C = ct_twd_c(Rdx), A = (Rdx + C - 1) / C;
+        const unsigned e1 = k * (unsigned)(S::N / (S::ns(p) * Rdx));
+        auto table = [&](unsigned e) __attribute__((always_inline)) { return fft::cmul(fft::ld2(t2.hi + (e >> 7)), fft::ld2(t2.lo + (e & 127u))); };
+        cx<R> lo_[C], hi_[A];
+#pragma unroll
+        for (int b = 1; b < C; ++b) lo_[b] = table((unsigned)b * e1);
+#pragma unroll
+        for (int a = 1; a < A; ++a) hi_[a] = table((unsigned)(C * a) * e1);
+#pragma unroll
+        for (int q = 1; q < Rdx; ++q) {
+            const int a = q / C, b = q % C;
+            const cx<R> w = a == 0 ? lo_[b] : b == 0 ? hi_[a] : fft::cmul(hi_[a], lo_[b]);
+            v[q] = fft::cmul(v[q], w);
+        }
+    } else {
+#pragma unroll
+        for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], ct_tw<S, p>(tw, t2, m, q, k));
+    }
+}
+
 template <typename S, int p, typename R> __device__ __forceinline__ void ct_load_twiddles(cx<R> (&tw)[S::NTW], const cx<R>* roots, int t) {
     if constexpr (p < S::P && !S::TW2L) {
         if constexpr (p > 0) {
@@ -227,8 +260,7 @@ __device__ __forceinline__ const cx<R>* ct_passes(const cx<R>* in, cx<R>* out, c
                 for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + jb + S::rstride(p) * q);
                 const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
                 if constexpr (p > 0) {
-#pragma unroll
-                    for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], ct_tw<S, p>(tw, t2, m, q, k));
+                    ct_apply_twiddles<S, p>(v, tw, t2, m, k);
                 }
                 fft::gen_bfly<Rdx>(v);
                 cx<R>* o = out + hi * (unsigned)(Ns * Rdx + (S::padded(p) ? 1 : 0)) + k;
@@ -262,8 +294,7 @@ template <typename S, int p, int END, typename R> __device__ __forceinline__ voi
             const unsigned j = (unsigned)(t + S::T * m);
             if ((m + 1) * S::T <= nbf || j < (unsigned)nbf) {
                 const unsigned hi = j / (unsigned)Ns, k = j - hi * (unsigned)Ns;
-#pragma unroll
-                for (int q = 1; q < Rdx; ++q) v[m][q] = fft::cmul(v[m][q], ct_tw<S, p>(tw, t2, m, q, k));
+                ct_apply_twiddles<S, p>(v[m], tw, t2, m, k);
                 fft::gen_bfly<Rdx>(v[m]);
                 cx<R>* o = buf + hi * (unsigned)(Ns * Rdx + (S::padded(p) ? 1 : 0)) + k;
 #pragma unroll
@@ -321,6 +352,43 @@ __device__ __forceinline__ void ct_pass0_compute(const TT (&ra)[S::M(0)][S::radi
         }
     }
 }
+// Lean form (CtSched flag 4096, 16 points per thread at up to 1024 threads = 128 registers): the window is not kept in registers -- it is loaded beside the
+// samples, from an N-value table in the working precision that stays in L2 -- one butterfly row (m) at a time.
+template <typename S, typename R, bool CPLX, typename TT>
+__device__ __forceinline__ void ct_pass0_lean(const TT* fa, int64_t hop, bool live, bool haveB, int n, const R* winr, cx<R>* out, int t) {
+    constexpr int Rdx = S::radix(0), nbf = S::nbf(0), M = S::M(0), SZ = (int)sizeof(TT), WZ = (int)sizeof(R);
+    const __amdgpu_buffer_rsrc_t da = io::make_rsrc(fa, live ? (long long)n * SZ : 0);
+    const __amdgpu_buffer_rsrc_t db = io::make_rsrc(fa + (CPLX ? 0 : hop), (!CPLX && haveB) ? (long long)n * SZ : 0);
+    const __amdgpu_buffer_rsrc_t dw = io::make_rsrc(winr, (long long)S::N * WZ);
+    int off = t * SZ, woff = t * WZ;
+    asm volatile("" : "+v"(off), "+v"(woff));
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int j = t + S::T * m;
+        TT ra[Rdx], rb[CPLX ? 1 : Rdx];
+        R rw[Rdx];
+#pragma unroll
+        for (int q = 0; q < Rdx; ++q) ra[q] = io::Ld<TT>::load(da, off + (S::T * m + nbf * q) * SZ);
+        if constexpr (!CPLX) {
+#pragma unroll
+            for (int q = 0; q < Rdx; ++q) rb[q] = io::Ld<TT>::load(db, off + (S::T * m + nbf * q) * SZ);
+        }
+#pragma unroll
+        for (int q = 0; q < Rdx; ++q) rw[q] = io::Ld<R>::load(dw, woff + (S::T * m + nbf * q) * WZ);
+        if ((m + 1) * S::T <= nbf || j < nbf) {
+            cx<R> v[Rdx];
+#pragma unroll
+            for (int q = 0; q < Rdx; ++q) {
+                if constexpr (CPLX) v[q] = {ra[q].x * rw[q], ra[q].y * rw[q]};
+                else v[q] = {ra[q] * rw[q], rb[q] * rw[q]};
+            }
+            fft::gen_bfly<Rdx>(v);
+            cx<R>* o = out + (unsigned)j * (unsigned)(Rdx + (S::padded(0) ? 1 : 0));
+#pragma unroll
+            for (int q = 0; q < Rdx; ++q) fft::st2(o + q, v[q]);
+        }
+    }
+}
 template <typename S, typename R, bool CPLX, typename TT>
 __device__ __forceinline__ void ct_pass0_global(const TT* fa, int64_t hop, bool live, bool haveB, int n, const R (&w0)[S::M(0) * S::radix(0)], cx<R>* out, int t) {
     TT ra[S::M(0)][S::radix(0)], rb[CPLX ? 1 : S::M(0)][CPLX ? 1 : S::radix(0)];
@@ -342,8 +410,7 @@ __device__ __forceinline__ void ct_last_pass_regs(const cx<R>* in, const cx<R> (
 #pragma unroll
             for (int q = 0; q < Rdx; ++q) v[q] = fft::ld2(in + jb + S::rstride(p) * q);
             const unsigned k = (unsigned)j % (unsigned)S::ns(p);
-#pragma unroll
-            for (int q = 1; q < Rdx; ++q) v[q] = fft::cmul(v[q], ct_tw<S, p>(tw, t2, m, q, k));
+            ct_apply_twiddles<S, p>(v, tw, t2, m, k);
             fft::gen_bfly<Rdx>(v);
 #pragma unroll
             for (int q = 0; q < Rdx; ++q) consume(m, q, j + nbf * q, v[q]);
@@ -377,15 +444,20 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
         for (int i = t; i < S::TWS; i += T) fft::st2(twlo + i, g[i]);
         for (int i = t; i < S::NTWHI; i += T) fft::st2(twhi + i, g[(unsigned)i * S::TWS]);
     }
-    R w0[W0];   // window at the points of this thread's first-pass butterflies (Float32 signals: rounded to Float32 first, as the other fused kernels do)
-#pragma unroll
-    for (int m = 0; m < S::M(0); ++m)
-#pragma unroll
-        for (int q = 0; q < S::radix(0); ++q) {
-            const int i = t + T * m + S::nbf(0) * q;
-            w0[m * S::radix(0) + q] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
-        }
     constexpr bool LDSIN = !DIRECT && S::LDSIN;
+    // lean form: no per-thread window registers, sums in the working precision flushed to the Float64 partials every MDSP_GEN_LEAN_FLUSH units
+    constexpr bool LEAN = S::LEANW && MODE == 0 && !LDSIN && !S::PREFETCH;   // (window)
+    constexpr bool LEANA = S::LEANA && MODE == 0;                              // (sums)
+    R w0[LEAN ? 1 : W0];   // window at the points of this thread's first-pass butterflies (Float32 signals: rounded to Float32 first, as the other fused kernels do)
+    if constexpr (!LEAN) {
+#pragma unroll
+        for (int m = 0; m < S::M(0); ++m)
+#pragma unroll
+            for (int q = 0; q < S::radix(0); ++q) {
+                const int i = t + T * m + S::nbf(0) * q;
+                w0[m * S::radix(0) + q] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
+            }
+    }
     R wl[LDSIN ? S::BINS : 1];   // LDS-input form: the window at i = t + T q
     if constexpr (LDSIN) {
 #pragma unroll
@@ -394,11 +466,30 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
             wl[q] = i < a.n ? (a.win ? (R)a.win[i] : (R)1) : (R)0;
         }
     }
-    double acc[MODE == 0 ? ML * RL : 1];
+    std::conditional_t<LEANA, R, double> acc[MODE == 0 ? ML * RL : 1];
     if constexpr (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < ML * RL; ++i) acc[i] = 0.0;
+        for (int i = 0; i < ML * RL; ++i) acc[i] = 0;
     }
+    bool flushed = false;
+    auto flush = [&]() __attribute__((always_inline)) {   // the sums of up to MDSP_GEN_LEAN_FLUSH units into this workgroup's own Float64 partial row
+        if constexpr (MODE == 0) {
+            double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)N;
+#pragma unroll
+            for (int m = 0; m < ML; ++m) {
+                const int j = t + T * m;
+                if ((m + 1) * T <= NBL || j < NBL) {
+#pragma unroll
+                    for (int q = 0; q < RL; ++q) {
+                        double* o = part + j + NBL * q;
+                        *o = flushed ? *o + (double)acc[m * RL + q] : (double)acc[m * RL + q];
+                        if constexpr (LEANA) acc[m * RL + q] = 0;
+                    }
+                }
+            }
+            flushed = true;
+        }
+    };
     const R m1 = (R)(1.0 / a.r), m2 = (R)(2.0 / a.r);
     constexpr bool PREF = S::PREFETCH && !LDSIN;
     TT pra[PREF ? S::M(0) : 1][PREF ? S::radix(0) : 1], prb[(PREF && !CPLX) ? S::M(0) : 1][(PREF && !CPLX) ? S::radix(0) : 1];
@@ -418,11 +509,14 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
         const bool live = u < a.units_per_ch;
         const int64_t f0 = CPLX ? u : 2 * u;
         const bool haveB = !CPLX && live && (f0 + 1) < a.K;
+        int tl = t;   // lean form: a per-unit copy the compiler cannot see through -- the passes' LDS addresses are recomputed per unit instead of living in (spilled) registers
+        if constexpr (LEAN || LEANA) asm volatile("" : "+v"(tl));
         // K4 (periodograms.jl:57-69) fused into the first pass: frame * window, zero tail, straight from the signal
         if constexpr (PREF) {
-            ct_pass0_compute<S, R, CPLX>(pra, prb, w0, bufA, t);
+            ct_pass0_compute<S, R, CPLX>(pra, prb, w0, bufA, tl);
             unit_loads(it + 1);
-        } else if constexpr (!LDSIN) ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, t);
+        } else if constexpr (LEAN) ct_pass0_lean<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, static_cast<const R*>(a.winr), bufA, tl);
+        else if constexpr (!LDSIN) ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, tl);
         else {   // ... or windowed into LDS first (bufB), the first pass then runs LDS -> LDS like the others
             constexpr int BINS = S::BINS;
             const TT* fa = sc + f0 * a.hop;
@@ -445,17 +539,17 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
                 }
             }
             __syncthreads();
-            (void)ct_passes<S, 0, 1>(bufB, bufA, tw, t, t2);   // pass 0: bufB -> bufA (ends with a barrier)
+            (void)ct_passes<S, 0, 1>(bufB, bufA, tw, tl, t2);   // pass 0: bufB -> bufA (ends with a barrier)
         }
         if constexpr (!LDSIN) __syncthreads();
         const int64_t o0 = ch * a.chs + f0 * a.ldo;
         if constexpr (DIRECT) {
             const cx<R>* src = bufA;
-            if constexpr (INPL) ct_passes_inplace<S, 1, S::P - 1>(bufA, tw, t, t2);
-            else src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, t, t2);
+            if constexpr (INPL) ct_passes_inplace<S, 1, S::P - 1>(bufA, tw, tl, t2);
+            else src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, tl, t2);
             ct_last_pass_regs<S>(src, tw, t, t2, [&](int m, int q, int k, cx<R> z) {
                 if constexpr (MODE == 0) {   // K5: |Z|^2 in the working precision (one rounding per term), accumulated over frames in double
-                    if (live) acc[m * RL + q] += (double)(z.x * z.x + z.y * z.y);
+                    if (live) acc[m * RL + q] += (std::conditional_t<LEANA, R, double>)(z.x * z.x + z.y * z.y);
                 } else if (live && k < a.nout) {   // complex signal: two-sided columns (periodograms.jl:876)
                     if (a.psd) {
                         R* o = static_cast<R*>(a.out) + o0 + k;
@@ -465,7 +559,7 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
                 }
             });
         } else {
-            const cx<R>* src = ct_passes<S, 1>(bufA, bufB, tw, t, t2);   // ends with a barrier; natural-order spectrum in LDS
+            const cx<R>* src = ct_passes<S, 1>(bufA, bufB, tw, tl, t2);   // ends with a barrier; natural-order spectrum in LDS
             if (live) {
                 for (int j = t; j < a.nout; j += T) {
                     const bool mirror = j > N / 2;                              // real -> two-sided: X[N-k] = conj(X[k]) (fft2oneortwosided!, :234-244)
@@ -496,18 +590,11 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
             }
         }
         __syncthreads();   // the buffer the last pass read may be the one the next frame's first pass writes
-    }
-    if constexpr (MODE == 0) {
-        double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)N;
-#pragma unroll
-        for (int m = 0; m < ML; ++m) {
-            const int j = t + T * m;
-            if ((m + 1) * T <= NBL || j < NBL) {
-#pragma unroll
-                for (int q = 0; q < RL; ++q) part[j + NBL * q] = acc[m * RL + q];
-            }
+        if constexpr (LEANA) {
+            if ((it & (MDSP_GEN_LEAN_FLUSH - 1)) == MDSP_GEN_LEAN_FLUSH - 1) flush();
         }
     }
+    flush();
 }
 
 template <typename R, bool CPLX, int MODE, typename S>

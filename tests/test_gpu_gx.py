@@ -61,7 +61,14 @@ WELCH_CASES = (
     (11520, 5760, 11520, "hanning", 5),      # 3 x 3840
     (9000, 4000, 9216, "hamming", 4),        # 2 x 4608 = 9 16 32, zero-padded
     (13500, 6750, 13500, None, 3),           # 2 x 6750 = 15 18 25
-    (65536, 32768, 65536, "hanning", 3),     # 8 x 8192 (Float64: the multi-pass engine)
+    (65536, 32768, 65536, "hanning", 3),     # 4 x 16384 (Float64: the multi-pass engine)
+    # ... one workgroup per transform up to 16384 points in the lean forms (csrc/spectral_ctbig.hip: Float32 sums, window beside the samples, derived twiddles)
+    (15625, 7000, 15625, None, 3),           # 25 25 5 5 at 1024 threads
+    (10240, 5120, 10240, "hamming", 4),      # 32 16 20
+    # ... and as the rows of nfft = R0 x S (csrc/spectral_ctcols_big.hip)
+    (25000, 12500, 25000, "hanning", 4),     # 2 x 12500
+    (32768, 16384, 32768, "hanning", 3),     # 2 x 16384 (Float64: the multi-pass engine)
+    (100000, 50000, 100000, "hanning", 3),   # 8 x 12500
 )
 
 
@@ -106,6 +113,26 @@ def test_gx_welch_long_streams_flush_and_channels(d):
         ref = opg.welch_pgram(s[:, c], n, n // 2, window=ow.hanning, dtype=np.float64).power
         assert relerr(got[:, c], ref) < TOL32, (c, relerr(got[:, c], ref))
         assert ulps_of_max(got[:, c], ref) < _ulp_bound(n)
+
+
+def test_lean_schedules_flush_their_float32_sums(d):
+    """nfft 12500 (one workgroup per CU, Float32 sums flushed to the Float64 partials every 64 frame pairs) and 25000 = 2 x 12500 (the same rows behind the column
+    step): four channels, each long enough that every workgroup flushes more than once (256 / 4 = 64 workgroups per channel -> more than 4096 frame pairs per
+    channel), against the Float64 oracle applied chunk by chunk (tests/fullsize.py)."""
+    from oracle import windows as ow
+    from fullsize import oracle_welch_chunked
+    rng = np.random.default_rng(66)
+    for n, K in ((12500, 2 * 64 * 64 * 2 + 3), (25000, 2 * 32 * 64 * 2 + 3)):
+        hop = n - n // 2
+        length = (K - 1) * hop + n
+        s = np.stack([_signal(rng, length, np.float32) for _ in range(4)], axis=1)
+        got = np.asarray(d.welch_pgram(s, n, n // 2, window=d.hanning).power)
+        assert got.shape == (n // 2 + 1, 4)
+        for c in (0, 3):
+            ref, frames = oracle_welch_chunked(lambda lo, hi: s[lo:hi, c], length, n, n // 2, ow.hanning, chunk_frames=1024)
+            assert frames == K
+            assert relerr(got[:, c], ref) < TOL32, (n, c, relerr(got[:, c], ref))
+            assert ulps_of_max(got[:, c], ref) < _ulp_bound(n)
 
 
 @pytest.mark.parametrize("dt,tol", DTYPES)
