@@ -740,6 +740,19 @@ int resolve_engine(int engine, int dtype, int64_t nfft, int* out, int kind = 1) 
     return MDSP_OK;
 }
 
+// the window as the lean compile-time schedules read it (spectral_gen.h ct_pass0_lean): nfft values in the working precision, ones without a window, zero tail
+template <typename R> __global__ __launch_bounds__(256) void lean_window_kernel(const double* __restrict__ win, R* __restrict__ out, int n, int nfft) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < nfft) out[i] = i < n ? (win ? (R)win[i] : (R)1) : (R)0;
+}
+template <typename R> int lean_window(DevBuf& buf, const double* win, int n, int64_t nfft, hipStream_t st) {
+    MDSP_TRY(buf.reserve(sizeof(R) * (size_t)nfft));
+    hipLaunchKernelGGL(lean_window_kernel<R>, dim3((unsigned)cdiv(nfft, 256)), dim3(256), 0, st, win, buf.as<R>(), n, (int)nfft);
+    MDSP_LAUNCH_CHECK();
+    return MDSP_OK;
+}
+constexpr bool lean_window_needed(int64_t nfft, bool dbl) { return dbl && MDSP_F64_LEAN && nfft >= 4800; }   // (wherever gen_ct_f64_tw2l may set flag 4096)
+
 template <typename R> int upload_roots(DevBuf& buf, int64_t n) {
     std::vector<cx<R>> w((size_t)n);
     for (int64_t k = 0; k < n; ++k) {
@@ -1746,6 +1759,11 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
         g.s = s; g.roots = pl->table.p; g.win = a.win;
         g.len = len; g.lds_ = lds_; g.K = K; g.hop = a.hop; g.nch = nch; g.units_per_ch = a.units_per_ch;
         g.n = a.n; g.N = (int)pl->nfft; g.nout = a.nout; g.onesided = a.onesided; g.r = a.r;
+        if (lean_window_needed(pl->nfft, sizeof(R) == 8)) {
+            if (!pl->winr_ready) MDSP_TRY(lean_window<R>(pl->winr, a.win, a.n, pl->nfft, st));
+            pl->winr_ready = true;
+            g.winr = pl->winr.p;
+        }
         int64_t nslots = 0;
         MDSP_TRY((gen_launch<R, CPLX, 0>(g, nch, st, &nslots, &pl->partial)));
         const int N = (int)pl->nfft;
@@ -1991,6 +2009,7 @@ struct mdsp_stft_plan_s {
     int64_t batch = 0;
     big::EngineHolder big;             // nfft above the single-workgroup kernels: the multi-pass engine (bigfft.hip)
     mdsp::GxPlan gx;                   // 7-smooth sizes without a compile-time schedule: the run-time-schedule kernel (spectral_gx.h)
+    mdsp::DevBuf winr;                 // lean compile-time schedules (CtSched flag 4096): the window of THIS launch in the working precision (multitaper plans change it per taper)
 };
 
 namespace {
@@ -2164,6 +2183,10 @@ int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nc
         g.len = len; g.lds_ = lds_; g.K = K; g.hop = a.hop; g.nch = nch; g.ldo = ldo; g.chs = chs;
         g.units_per_ch = CPLX ? K : cdiv(K, 2);
         g.n = a.n; g.N = (int)pl->nfft; g.nout = a.nout; g.onesided = a.onesided; g.psd = pl->psd_only; g.accumulate = pl->accumulate; g.r = a.r;
+        if (CPLX && lean_window_needed(pl->nfft, sizeof(R) == 8)) {   // (per launch: the window pointer of a multitaper plan changes between tapers)
+            MDSP_TRY(lean_window<R>(pl->winr, a.win, a.n, pl->nfft, st));
+            g.winr = pl->winr.p;
+        }
         int64_t nslots = 0;
         return gen_launch<R, CPLX, 1>(g, nch, st, &nslots, nullptr);
     }

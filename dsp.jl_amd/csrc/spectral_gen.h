@@ -446,7 +446,7 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
     }
     constexpr bool LDSIN = !DIRECT && S::LDSIN;
     // lean form: no per-thread window registers, sums in the working precision flushed to the Float64 partials every MDSP_GEN_LEAN_FLUSH units
-    constexpr bool LEAN = S::LEANW && MODE == 0 && !LDSIN && !S::PREFETCH;   // (window)
+    constexpr bool LEAN = S::LEANW && DIRECT && !LDSIN && !S::PREFETCH;   // (window)
     constexpr bool LEANA = S::LEANA && MODE == 0;                              // (sums)
     R w0[LEAN ? 1 : W0];   // window at the points of this thread's first-pass butterflies (Float32 signals: rounded to Float32 first, as the other fused kernels do)
     if constexpr (!LEAN) {
@@ -633,8 +633,19 @@ inline bool gen_ct_size(int dtype, int64_t nfft, bool direct) {
 // (profiles/r05_f64_twiddles.json, 2^27 samples): Welch at 4800 (0.73 -> 1.21 TB/s), 5120, 6144 and 8000 (0.62 -> 0.83); ComplexF64 columns at 4800, 6000
 // (1.69 -> 1.85), 6400 (1.85 -> 2.46) and 8000 (1.68 -> 2.07).  Not at 5000 (columns 3.05 -> 2.38) and not for Welch at 6000 / 6400 (-5 ... -7 %: those
 // keep 48 - 82 spilled registers either way -- the single-buffer pass holds all of a pass's butterflies in registers).
-constexpr int gen_ct_f64_tw2l(int N, int mode) {
-    if (N < 4800 || N == 5000) return 0;
+// Round 6: with the window loaded beside the samples (flag 4096, ct_pass0_lean) and the twiddles derived from ~2 sqrt(R) table values (16384) NONE of the
+// Float64 schedules from 4800 points spills any more (5000: 56 -> 0 spilled registers, 6000: 193 -> 0, 6400: 142 -> 0, 8000: 57 -> 0): the register-
+// consumed modes take table twiddles at every size from 4800 points.  -DMDSP_F64_LEAN=0 keeps round 5's choice.
+#ifndef MDSP_F64_LEAN
+#define MDSP_F64_LEAN 1
+#endif
+// Measured (profiles/r06_f64_lean.json, 2^25 samples, TB/s): Welch 6000 0.57 -> 1.01, 6400 0.63 -> 1.13, 8000 0.70 -> 1.07, 5120 1.10 -> 1.20, 6144 1.23 -> 1.31
+// (4800 and 5000 within 4 %: round 5's form stays); ComplexF64 columns 4800 2.1 -> 2.9, 6000 1.7 -> 2.0, 8000 2.0 -> 2.2 (5000, 5120, 6144 lose: round 5's form).
+constexpr int gen_ct_f64_tw2l(int N, int mode, bool cplx = false) {
+    if (N < 4800) return 0;
+    if (MDSP_F64_LEAN && mode == 0 && N > 5000) return 2048 | 4096 | 16384;
+    if (MDSP_F64_LEAN && mode == 1 && cplx && (N == 4800 || N == 6000 || N == 6400 || N == 8000)) return 2048 | 4096 | 16384;
+    if (N == 5000) return 0;
     if (mode == 0 && (N == 6000 || N == 6400)) return 0;
     return 2048;
 }
@@ -667,7 +678,7 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
             *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) & ~1536, __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (MODE == 0 || CPLX) {                                                                  \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | 16 | gen_ct_f64_tw2l(N, MODE), __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | 16 | gen_ct_f64_tw2l(N, MODE, CPLX), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (N <= GEN_CT_F64_REAL_COLUMNS_MAX) {                                                   \
             *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | gen_ct_f64_tw2l(N, MODE), __VA_ARGS__>>(a, nch, st, nslots, partial); \

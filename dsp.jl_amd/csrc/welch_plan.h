@@ -29,6 +29,8 @@ struct mdsp_welch_plan_s {
     mdsp::DevBuf redtmp;         // group sums of the two-step slice reduction (reduce_partials, spectral.hip)
     mdsp::big::EngineHolder big;   // nfft above the single-workgroup kernels: the multi-pass engine (bigfft.hip), built at the first accumulate
     mdsp::GxPlan gx;             // 7-smooth sizes without a compile-time schedule, up to 32 x 16384 points: the run-time-schedule kernel (spectral_gx.h)
+    mdsp::DevBuf winr;           // lean compile-time schedules (CtSched flag 4096): the window in the working precision, nfft values, zero tail
+    bool winr_ready = false;
     mdsp::CtColsPlan ctcols;     // ... and those that are R0 x a compile-time row schedule (spectral_ctcols.hip)
     mdsp::DevBuf w64prep;        // mdsp_welch_w64_asm: Float32 window pairs + per-lane twiddles (built at the plan's first launch of that kernel)
     bool frames_on_device = false;
