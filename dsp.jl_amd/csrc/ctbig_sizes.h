@@ -53,6 +53,15 @@
     X(9000, 512, MDSP_CTBIG_FD, 18, 20, 25) X(9072, 512, MDSP_CTBIG_FD, 28, 18, 18) X(9600, 512, MDSP_CTBIG_FD, 20, 20, 24)
 #endif
 
+// Sizes that ALSO have a schedule in ct_sched.h's tables (every mode) but whose Welch sums measured faster on a three-pass schedule of this file with derived
+// twiddles (profiles/r06_ctbig_lean.json "nextfastfft_23": 2560 1.39 -> 1.78 TB/s, 3072 1.62 -> 1.97, 5120 1.22 -> 1.46, 1280 / 1600 / 3840 / 6400 +5 .. 10 %;
+// the other sixteen sizes keep their round-4 schedules)
+#ifndef MDSP_CTBIG_PREF_SIZES
+#define MDSP_CTBIG_PREF_SIZES(X) \
+    X(1280, 192, MDSP_CTBIG_FD, 20, 8, 8) X(1600, 192, MDSP_CTBIG_FD, 16, 10, 10) X(2560, 256, MDSP_CTBIG_FD, 16, 10, 16) X(3072, 256, MDSP_CTBIG_FD, 16, 12, 16) \
+    X(3840, 256, MDSP_CTBIG_FD, 16, 15, 16) X(5120, 320, MDSP_CTBIG_FD, 16, 16, 20) X(6400, 448, MDSP_CTBIG_FD, 16, 16, 25)
+#endif
+
 // ... and the 7-smooth sizes from 2100 to 8192 points that have no schedule in ct_sched.h's table (which carries every mode for 23 sizes): generated -- the
 // three factors out of {4 .. 30} and the thread count out of {256 .. 512} that give every thread at most ONE butterfly per pass with the fewest idle lanes
 // (93 of the 109 sizes have such a triple; the others stay on the run-time schedule).  Welch sums only.

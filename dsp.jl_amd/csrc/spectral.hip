@@ -691,6 +691,7 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 bool use_gx(int dtype, int64_t nfft, bool direct, int kind) {
     const int m = tunables().gx;
     if (m == 0) return false;
+    if (kind == 0 && m != 4 && m != 5 && ctbig_preferred(dtype, nfft)) return true;
     if (kind == 0 && m != 4 && !fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && ((m != 5 && ctbig_ok(dtype, nfft)) || ctcols_split(dtype, nfft) > 0))
         return true;   // Welch sums on a compile-time schedule (one workgroup, or R0 x S rows): whatever the run-time-schedule kernel plans
     if (!gx_size_ok(dtype, nfft)) return false;

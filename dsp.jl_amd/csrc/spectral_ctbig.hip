@@ -27,6 +27,7 @@ template <typename R, bool CPLX> int big_dispatch(GenArgs& a, int64_t nch, hipSt
         MDSP_CTBIG_SIZES(MDSP_X)
         MDSP_CTBIG_LEAN_SIZES(MDSP_X)
         MDSP_CTBIG_SMALL_SIZES(MDSP_X)
+        MDSP_CTBIG_PREF_SIZES(MDSP_X)
 #undef MDSP_X
         default: MDSP_FAIL(MDSP_ERR_ASSERTION, "no single-workgroup compile-time schedule of %d points", a.N);
     }
@@ -59,6 +60,18 @@ bool ctbig_ok(int dtype, int64_t nfft) {
         MDSP_CTBIG_SIZES(MDSP_X)
         MDSP_CTBIG_LEAN_SIZES(MDSP_X)
         MDSP_CTBIG_SMALL_SIZES(MDSP_X)
+        MDSP_CTBIG_PREF_SIZES(MDSP_X)
+#undef MDSP_X
+        return true;
+        default: return false;
+    }
+}
+
+bool ctbig_preferred(int dtype, int64_t nfft) {   // ... in front of the all-mode schedule the size also has (spectral.hip use_gx)
+    if (dtype_is_double(dtype)) return false;
+    switch (nfft) {
+#define MDSP_X(N, ...) case N:
+        MDSP_CTBIG_PREF_SIZES(MDSP_X)
 #undef MDSP_X
         return true;
         default: return false;

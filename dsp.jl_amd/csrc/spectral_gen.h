@@ -649,6 +649,9 @@ constexpr int gen_ct_f64_tw2l(int N, int mode, bool cplx = false) {
     if (mode == 0 && (N == 6000 || N == 6400)) return 0;
     return 2048;
 }
+#ifndef MDSP_GEN_F32_WELCH_FLAGS
+#define MDSP_GEN_F32_WELCH_FLAGS 0   // (A/B: 8192 = Float32 sums flushed every 64 units for the 23 nextfastfft sizes up to 8000 points as well)
+#endif
 template <typename R, bool CPLX, int MODE>
 bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevBuf* partial, int* rc) {
     if constexpr (MDSP_GEN_CT && sizeof(R) == 4) {
@@ -657,7 +660,7 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
 #define MDSP_X(N, T, F, ...)                                                                               \
     case N:                                                                                                \
         if constexpr (gen_ct_wide_mode(F, MODE, CPLX)) {                                                   \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, F, __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) | (MODE == 0 ? MDSP_GEN_F32_WELCH_FLAGS : 0), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                   \
         }                                                                                                  \
         break;
@@ -672,7 +675,7 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
 #define MDSP_X(N, T, F, ...)                                                                                       \
     case N:                                                                                                        \
         if constexpr (sizeof(R) == 4) {                                                                            \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, gen_ct_flags(F, MODE, CPLX), __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, gen_ct_flags(F, MODE, CPLX) | (MODE == 0 ? MDSP_GEN_F32_WELCH_FLAGS : 0), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (N <= GEN_CT_F64_TWO_BUF) {                                                            \
             *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) & ~1536, __VA_ARGS__>>(a, nch, st, nslots, partial); \
