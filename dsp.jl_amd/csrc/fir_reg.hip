@@ -127,12 +127,16 @@ template <typename XS, typename A, typename R, int TPC, int P> int launch(FirReg
     const size_t lds_bytes = (size_t)a.span * sizeof(A);
     if (lds_bytes > 150 * 1024) MDSP_FAIL(MDSP_ERR_UNSUPPORTED, "decimation factor too large for the register-tap polyphase kernel (M=%d)", a.M);
     const int64_t ntiles = cdiv(a.nrounds, (int64_t)Q);
-    // resident workgroups: the taps of P residues are P (TPC + P - 1) registers of R -- one 256-thread workgroup per SIMD quartet at 256 registers, two where the
-    // LDS admits them and the kernel stays under 128
-    const int wgs = tunables().wg_per_cu > 0 ? tunables().wg_per_cu : (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / lds_bytes));
-    const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, nch));
-    const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)nch);
+    // resident workgroups per CU: what the kernel's registers and the tile's LDS admit TOGETHER -- a launch of more than that runs a second, partial round
+    // (ComplexF64 160//441: 160 threads = 3 waves at 226 registers, two workgroups per CU; the LDS alone says three: 5.0 ms against 3.8, r06s37)
     auto go = [&](auto kern) -> int {
+        hipFuncAttributes fa{};
+        MDSP_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
+        const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8), waves = (a.NP * a.RL + 63) / 64;
+        const int by_regs = std::max(1, std::min(8, 512 / regs) * 4 / waves), by_lds = (int)std::max<size_t>(1, (size_t)(150 * 1024) / lds_bytes);
+        const int wgs = tunables().wg_per_cu > 0 ? tunables().wg_per_cu : std::min({4, by_regs, by_lds});
+        const int64_t per = std::max<int64_t>(1, (int64_t)device_cu_count() * wgs / std::max<int64_t>(1, nch));
+        const dim3 grid((unsigned)std::min<int64_t>(ntiles, per), (unsigned)nch);
         if (lds_bytes > 48 * 1024) MDSP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(kern, grid, dim3(a.NP * a.RL), lds_bytes, st, a);
         MDSP_LAUNCH_CHECK();
