@@ -13,6 +13,9 @@
 // ... | 16384: a butterfly's twiddles as products of ~2 sqrt(R) table values (ct_apply_twiddles): per size, where it measured faster (all but 7 of 192 sizes)
 #define MDSP_CTBIG_FD (MDSP_CTBIG_F | 16384)
 #define MDSP_CTBIG_LD (MDSP_CTBIG_L | 16384)
+// ... | 32768: the next unit's samples touched into the L2 behind this unit's first pass (per size: +4 % median, 12 500 1.45 -> 1.57 TB/s, 16 384 1.65 -> 1.78; r06s39)
+#define MDSP_CTBIG_LT (MDSP_CTBIG_L | 32768)
+#define MDSP_CTBIG_LDT (MDSP_CTBIG_LD | 32768)
 #define MDSP_CTBIG_AD (MDSP_CTBIG_A | 16384)
 #ifdef MDSP_CTBIG_LIST_H   // (schedule A/B sessions: a header with other MDSP_CTBIG_SIZES / MDSP_CTBIG_LEAN_SIZES lists)
 #include MDSP_CTBIG_LIST_H
@@ -23,29 +26,29 @@
 #ifndef MDSP_CTBIG_LEAN_SIZES
 #define MDSP_CTBIG_LEAN_SIZES(X) \
     X(8232, 768, MDSP_CTBIG_AD, 14, 7, 7, 12) X(8505, 768, MDSP_CTBIG_AD, 9, 7, 9, 15) X(8750, 512, MDSP_CTBIG_LD, 25, 14, 25) \
-    X(8820, 512, MDSP_CTBIG_LD, 21, 21, 20) X(8960, 768, MDSP_CTBIG_LD, 16, 5, 7, 16) X(9216, 768, MDSP_CTBIG_AD, 16, 4, 12, 12) \
-    X(9261, 512, MDSP_CTBIG_LD, 21, 21, 21) X(9375, 512, MDSP_CTBIG_LD, 25, 15, 25) X(9408, 512, MDSP_CTBIG_LD, 28, 16, 21) \
-    X(9450, 512, MDSP_CTBIG_LD, 25, 21, 18) X(9604, 768, MDSP_CTBIG_AD, 14, 7, 7, 14) X(9720, 512, MDSP_CTBIG_LD, 18, 20, 27) \
-    X(9800, 512, MDSP_CTBIG_LD, 28, 25, 14) X(10000, 512, MDSP_CTBIG_LD, 25, 20, 20) X(10080, 512, MDSP_CTBIG_LD, 21, 20, 24) \
+    X(8820, 512, MDSP_CTBIG_LDT, 21, 21, 20) X(8960, 768, MDSP_CTBIG_LDT, 16, 5, 7, 16) X(9216, 768, MDSP_CTBIG_AD, 16, 4, 12, 12) \
+    X(9261, 512, MDSP_CTBIG_LDT, 21, 21, 21) X(9375, 512, MDSP_CTBIG_LDT, 25, 15, 25) X(9408, 512, MDSP_CTBIG_LDT, 28, 16, 21) \
+    X(9450, 512, MDSP_CTBIG_LD, 25, 21, 18) X(9604, 768, MDSP_CTBIG_AD, 14, 7, 7, 14) X(9720, 512, MDSP_CTBIG_LDT, 18, 20, 27) \
+    X(9800, 512, MDSP_CTBIG_LDT, 28, 25, 14) X(10000, 512, MDSP_CTBIG_LDT, 25, 20, 20) X(10080, 512, MDSP_CTBIG_LDT, 21, 20, 24) \
     X(10125, 512, MDSP_CTBIG_LD, 27, 25, 15) X(10206, 512, MDSP_CTBIG_LD, 18, 21, 27) X(10240, 512, MDSP_CTBIG_LD, 32, 16, 20) \
     X(10290, 768, MDSP_CTBIG_AD, 15, 7, 7, 14) X(10368, 512, MDSP_CTBIG_LD, 27, 16, 24) X(10500, 512, MDSP_CTBIG_AD, 20, 25, 21) \
-    X(10584, 512, MDSP_CTBIG_AD, 24, 21, 21) X(10752, 512, MDSP_CTBIG_LD, 28, 16, 24) X(10800, 512, MDSP_CTBIG_LD, 25, 24, 18) \
-    X(10935, 512, MDSP_CTBIG_LD, 27, 15, 27) X(10976, 512, MDSP_CTBIG_LD, 14, 28, 28) X(11025, 768, MDSP_CTBIG_LD, 7, 7, 15, 15) \
-    X(11200, 512, MDSP_CTBIG_LD, 25, 28, 16) X(11250, 512, MDSP_CTBIG_LD, 25, 18, 25) X(11340, 512, MDSP_CTBIG_LD, 27, 28, 15) \
-    X(11520, 512, MDSP_CTBIG_LD, 20, 24, 24) X(11664, 512, MDSP_CTBIG_LD, 27, 24, 18) X(11760, 512, MDSP_CTBIG_LD, 28, 28, 15) \
-    X(11907, 512, MDSP_CTBIG_LD, 21, 21, 27) X(12000, 512, MDSP_CTBIG_LD, 20, 24, 25) X(12096, 512, MDSP_CTBIG_LD, 21, 24, 24) \
-    X(12150, 512, MDSP_CTBIG_LD, 18, 25, 27) X(12288, 512, MDSP_CTBIG_LD, 32, 16, 24) X(12348, 896, MDSP_CTBIG_LD, 9, 14, 14, 7) \
-    X(12500, 512, MDSP_CTBIG_LD, 25, 20, 25) X(12544, 512, MDSP_CTBIG_LD, 16, 28, 28) X(12600, 512, MDSP_CTBIG_LD, 25, 28, 18) \
-    X(12800, 512, MDSP_CTBIG_LD, 32, 16, 25) X(12960, 512, MDSP_CTBIG_LD, 27, 30, 16) X(13122, 512, MDSP_CTBIG_LD, 18, 27, 27) \
-    X(13125, 512, MDSP_CTBIG_LD, 25, 25, 21) X(13230, 1024, MDSP_CTBIG_LD, 9, 14, 15, 7) X(13440, 512, MDSP_CTBIG_LD, 30, 28, 16) \
-    X(13500, 512, MDSP_CTBIG_LD, 15, 30, 30) X(13608, 512, MDSP_CTBIG_LD, 27, 28, 18) X(13720, 1024, MDSP_CTBIG_LD, 14, 14, 14, 5) \
-    X(13824, 512, MDSP_CTBIG_LD, 32, 16, 27) X(14000, 768, MDSP_CTBIG_LD, 14, 10, 10, 10) X(14112, 512, MDSP_CTBIG_LD, 28, 28, 18) \
-    X(14175, 1024, MDSP_CTBIG_LD, 15, 15, 9, 7) X(14336, 512, MDSP_CTBIG_LD, 32, 16, 28) X(14400, 512, MDSP_CTBIG_LD, 30, 30, 16) \
-    X(14580, 768, MDSP_CTBIG_LD, 15, 12, 9, 9) X(14700, 768, MDSP_CTBIG_LD, 15, 14, 10, 7) X(15000, 768, MDSP_CTBIG_LD, 15, 10, 10, 10) \
-    X(15120, 768, MDSP_CTBIG_LD, 14, 9, 10, 12) X(15360, 512, MDSP_CTBIG_LD, 16, 32, 30) X(15552, 768, MDSP_CTBIG_LD, 9, 12, 12, 12) \
-    X(15625, 1024, MDSP_CTBIG_LD, 25, 25, 5, 5) X(15680, 768, MDSP_CTBIG_LD, 14, 14, 10, 8) X(15750, 640, MDSP_CTBIG_LD, 14, 15, 15, 5) \
-    X(15876, 768, MDSP_CTBIG_LD, 14, 14, 9, 9) X(16000, 1024, MDSP_CTBIG_LD, 10, 10, 16, 10) X(16128, 768, MDSP_CTBIG_LD, 12, 12, 14, 8) \
-    X(16200, 768, MDSP_CTBIG_L, 12, 15, 15, 6) X(16384, 512, MDSP_CTBIG_LD, 32, 32, 16)
+    X(10584, 512, MDSP_CTBIG_AD, 24, 21, 21) X(10752, 512, MDSP_CTBIG_LD, 28, 16, 24) X(10800, 512, MDSP_CTBIG_LDT, 25, 24, 18) \
+    X(10935, 512, MDSP_CTBIG_LD, 27, 15, 27) X(10976, 512, MDSP_CTBIG_LDT, 14, 28, 28) X(11025, 768, MDSP_CTBIG_LDT, 7, 7, 15, 15) \
+    X(11200, 512, MDSP_CTBIG_LDT, 25, 28, 16) X(11250, 512, MDSP_CTBIG_LDT, 25, 18, 25) X(11340, 512, MDSP_CTBIG_LD, 27, 28, 15) \
+    X(11520, 512, MDSP_CTBIG_LDT, 20, 24, 24) X(11664, 512, MDSP_CTBIG_LDT, 27, 24, 18) X(11760, 512, MDSP_CTBIG_LDT, 28, 28, 15) \
+    X(11907, 512, MDSP_CTBIG_LDT, 21, 21, 27) X(12000, 512, MDSP_CTBIG_LD, 20, 24, 25) X(12096, 512, MDSP_CTBIG_LDT, 21, 24, 24) \
+    X(12150, 512, MDSP_CTBIG_LD, 18, 25, 27) X(12288, 512, MDSP_CTBIG_LDT, 32, 16, 24) X(12348, 896, MDSP_CTBIG_LDT, 9, 14, 14, 7) \
+    X(12500, 512, MDSP_CTBIG_LDT, 25, 20, 25) X(12544, 512, MDSP_CTBIG_LDT, 16, 28, 28) X(12600, 512, MDSP_CTBIG_LDT, 25, 28, 18) \
+    X(12800, 512, MDSP_CTBIG_LDT, 32, 16, 25) X(12960, 512, MDSP_CTBIG_LDT, 27, 30, 16) X(13122, 512, MDSP_CTBIG_LDT, 18, 27, 27) \
+    X(13125, 512, MDSP_CTBIG_LD, 25, 25, 21) X(13230, 1024, MDSP_CTBIG_LDT, 9, 14, 15, 7) X(13440, 512, MDSP_CTBIG_LDT, 30, 28, 16) \
+    X(13500, 512, MDSP_CTBIG_LDT, 15, 30, 30) X(13608, 512, MDSP_CTBIG_LDT, 27, 28, 18) X(13720, 1024, MDSP_CTBIG_LD, 14, 14, 14, 5) \
+    X(13824, 512, MDSP_CTBIG_LDT, 32, 16, 27) X(14000, 768, MDSP_CTBIG_LDT, 14, 10, 10, 10) X(14112, 512, MDSP_CTBIG_LDT, 28, 28, 18) \
+    X(14175, 1024, MDSP_CTBIG_LD, 15, 15, 9, 7) X(14336, 512, MDSP_CTBIG_LDT, 32, 16, 28) X(14400, 512, MDSP_CTBIG_LDT, 30, 30, 16) \
+    X(14580, 768, MDSP_CTBIG_LDT, 15, 12, 9, 9) X(14700, 768, MDSP_CTBIG_LDT, 15, 14, 10, 7) X(15000, 768, MDSP_CTBIG_LDT, 15, 10, 10, 10) \
+    X(15120, 768, MDSP_CTBIG_LD, 14, 9, 10, 12) X(15360, 512, MDSP_CTBIG_LDT, 16, 32, 30) X(15552, 768, MDSP_CTBIG_LDT, 9, 12, 12, 12) \
+    X(15625, 640, MDSP_CTBIG_LD, 25, 25, 25) X(15680, 768, MDSP_CTBIG_LDT, 14, 14, 10, 8) X(15750, 640, MDSP_CTBIG_LD, 14, 15, 15, 5) \
+    X(15876, 768, MDSP_CTBIG_LDT, 14, 14, 9, 9) X(16000, 1024, MDSP_CTBIG_LD, 10, 10, 16, 10) X(16128, 768, MDSP_CTBIG_LDT, 12, 12, 14, 8) \
+    X(16200, 768, MDSP_CTBIG_L, 12, 15, 15, 6) X(16384, 512, MDSP_CTBIG_LDT, 32, 32, 16)
 #endif
 #ifndef MDSP_CTBIG_SIZES
 #define MDSP_CTBIG_SIZES(X) \

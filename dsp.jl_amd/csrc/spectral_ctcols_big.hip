@@ -20,12 +20,15 @@ namespace {
 #include "spectral_ctcols_kernel.h"
 #include "ctbig_sizes.h"
 
-constexpr int ROW_FLAGS = 4096 | 8192 | 16384;   // lean rows whatever form the size takes as a whole transform
+#ifndef MDSP_ROW_TOUCH
+#define MDSP_ROW_TOUCH 32768   // every row touches its share of the next unit's span into the L2 (A/B r06s40)
+#endif
+constexpr int ROW_FLAGS = 4096 | 8192 | 16384 | MDSP_ROW_TOUCH;   // lean rows whatever form the size takes as a whole transform
 
 template <typename R, bool CPLX> int big_rows_dispatch(ColsArgs& ca, int64_t nch, hipStream_t st, int64_t* ngroups, DevBuf* partial) {
     switch (ca.g.N) {
 #define MDSP_X(N, T, F, ...) \
-    case N: return cols_launch<R, CPLX, CtSched<N, T, (F) | ROW_FLAGS, __VA_ARGS__>>(ca, nch, st, ngroups, partial);
+    case N: return cols_launch<R, CPLX, CtSched<N, T, ((F) & ~32768) | ROW_FLAGS, __VA_ARGS__>>(ca, nch, st, ngroups, partial);
         MDSP_CTBIG_SIZES(MDSP_X)
         MDSP_CTBIG_LEAN_SIZES(MDSP_X)
 #undef MDSP_X

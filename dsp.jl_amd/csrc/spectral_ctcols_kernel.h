@@ -13,7 +13,7 @@ struct ColsArgs {
 // CtSched flag 8192 keeps the sums in the working precision (flushed to the Float64 partials every MDSP_GEN_LEAN_FLUSH units), 4096 loads the column
 // twiddles W_nfft^{i k1} beside the samples (from the nfft-root table, which stays in L2) instead of keeping them in 2 N / T registers.
 template <typename R, bool CPLX, typename S>
-__global__ __launch_bounds__(S::T, (sizeof(cx<R>) * S::NP > 80 * 1024 && S::T > 512) ? 4 : 2) void gen_ct_cols_kernel(ColsArgs ca) {
+__global__ __launch_bounds__(S::T, (sizeof(cx<R>) * S::NP > 80 * 1024 && S::T > 512) ? (S::T / 64 + 3) / 4 : 2) void gen_ct_cols_kernel(ColsArgs ca) {   // (waves per SIMD: one workgroup of the big rows, two of the others)
     const GenArgs& a = ca.g;
     using TT = std::conditional_t<CPLX, cx<R>, R>;
     constexpr int N = S::N, T = S::T;
@@ -57,6 +57,8 @@ __global__ __launch_bounds__(S::T, (sizeof(cx<R>) * S::NP > 80 * 1024 && S::T > 
     std::conditional_t<LEANA, R, double> acc[ML * RL];
 #pragma unroll
     for (int i = 0; i < ML * RL; ++i) acc[i] = 0;
+    constexpr int NTOUCH = S::TOUCH ? (N * SZ * (CPLX ? 2 : 3) / 2 / 128 + T - 1) / T : 1;   // 128-byte lines of a unit's span per thread and workgroup of the group
+    [[maybe_unused]] float touched[NTOUCH] = {};
     bool flushed = false;
     auto flush = [&]() __attribute__((always_inline)) {
         double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)ca.nfft + k1;
@@ -148,12 +150,25 @@ __global__ __launch_bounds__(S::T, (sizeof(cx<R>) * S::NP > 80 * 1024 && S::T > 
             }
         }
         __syncthreads();
+        if (S::TOUCH && ca.R0 >= 4) {   // (measured r06s40: +3 .. 6 % from R0 = 4, -3 .. 5 % at R0 = 2, 3) this workgroup's share (every R0-th 128-byte line) of the NEXT unit's span, into the L2 while the passes run (gen_ct_kernel does the same)
+            const int64_t un = u + 1;
+            const bool nlive = it + 1 < a.per_slot && un < a.units_per_ch;
+            const int64_t fn = CPLX ? un : 2 * un;
+            const long long nspan = nlive ? ((long long)a.n + ((!CPLX && fn + 1 < a.K) ? a.hop : 0)) * (long long)SZ : 0;
+            const __amdgpu_buffer_rsrc_t dn = io::make_rsrc(sc + fn * a.hop, nspan);
+#pragma unroll
+            for (int i = 0; i < NTOUCH; ++i) touched[i] = io::Ld<float>::load(dn, (k1 + ca.R0 * (tl + T * i)) * 128);
+        }
         // ---- the other passes exactly as gen_ct_kernel's register-consumed modes
         const cx<R>* src = bufA;
         if constexpr (INPL) ct_passes_inplace<S, 1, S::P - 1>(bufA, tw, tl, t2);
         else src = ct_passes<S, 1, S::P - 1>(bufA, bufB, tw, tl, t2);
         ct_last_pass_regs<S>(src, tw, tl, t2, [&](int m, int q, int, cx<R> z) { acc[m * RL + q] += (std::conditional_t<LEANA, R, double>)(z.x * z.x + z.y * z.y); });   // (a unit that does not exist transformed zeros)
         __syncthreads();
+        if (S::TOUCH && ca.R0 >= 4) {
+#pragma unroll
+            for (int i = 0; i < NTOUCH; ++i) asm volatile("" ::"v"(touched[i]));
+        }
         if constexpr (LEANA) {
             if ((it & (MDSP_GEN_LEAN_FLUSH - 1)) == MDSP_GEN_LEAN_FLUSH - 1) flush();
         }

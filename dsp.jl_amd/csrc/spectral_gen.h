@@ -471,6 +471,8 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
 #pragma unroll
         for (int i = 0; i < ML * RL; ++i) acc[i] = 0;
     }
+    constexpr int NTOUCH = S::TOUCH ? (N * (int)sizeof(TT) * (CPLX ? 2 : 3) / 2 / 128 + T - 1) / T : 1;   // 128-byte lines of a unit's span per thread
+    [[maybe_unused]] float touched[NTOUCH];
     bool flushed = false;
     auto flush = [&]() __attribute__((always_inline)) {   // the sums of up to MDSP_GEN_LEAN_FLUSH units into this workgroup's own Float64 partial row
         if constexpr (MODE == 0) {
@@ -515,7 +517,20 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
         if constexpr (PREF) {
             ct_pass0_compute<S, R, CPLX>(pra, prb, w0, bufA, tl);
             unit_loads(it + 1);
-        } else if constexpr (LEAN) ct_pass0_lean<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, static_cast<const R*>(a.winr), bufA, tl);
+        } else if constexpr (LEAN) {
+            ct_pass0_lean<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, static_cast<const R*>(a.winr), bufA, tl);
+            if constexpr (S::TOUCH) {
+                // the NEXT unit's samples pulled into the L2 while this unit runs its passes: one dword per 128-byte line, consumed (by nothing) at the end of the
+                // unit -- the workgroup fills the LDS, so nothing else overlaps a unit's loads; behind this they come from the L2 instead of HBM
+                const int64_t un = u + 1;
+                const bool nlive = it + 1 < a.per_slot && un < a.units_per_ch;
+                const int64_t fn = CPLX ? un : 2 * un;
+                const long long nspan = nlive ? ((long long)a.n + ((!CPLX && fn + 1 < a.K) ? a.hop : 0)) * (long long)sizeof(TT) : 0;
+                const __amdgpu_buffer_rsrc_t dn = io::make_rsrc(sc + fn * a.hop, nspan);
+#pragma unroll
+                for (int i = 0; i < NTOUCH; ++i) touched[i] = io::Ld<float>::load(dn, (tl + T * i) * 128);   // (past the span: the descriptor's zero)
+            }
+        }
         else if constexpr (!LDSIN) ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, tl);
         else {   // ... or windowed into LDS first (bufB), the first pass then runs LDS -> LDS like the others
             constexpr int BINS = S::BINS;
@@ -590,6 +605,10 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
             }
         }
         __syncthreads();   // the buffer the last pass read may be the one the next frame's first pass writes
+        if constexpr (S::TOUCH && LEAN) {
+#pragma unroll
+            for (int i = 0; i < NTOUCH; ++i) asm volatile("" ::"v"(touched[i]));
+        }
         if constexpr (LEANA) {
             if ((it & (MDSP_GEN_LEAN_FLUSH - 1)) == MDSP_GEN_LEAN_FLUSH - 1) flush();
         }
