@@ -75,23 +75,24 @@ template <int N_, int T_, int LDSIN_, int... RS> struct CtSched {
 #endif
 // N -> schedule (odd radix first where N has one, the widest radix last; T ~ N / 8 threads so that a thread runs 1-4 butterflies per pass)
 #define MDSP_GEN_CT_SIZES(X)                                                                                                      \
-    X(1000, 128, 0, 5, 5, 5, 8) X(1200, 192, 0, 3, 5, 5, 16) X(1280, 128, 0, 5, 16, 16) X(1500, 192, 0, 3, 5, 5, 5, 4)                \
-    X(1536, 192, 0, 3, 8, 8, 8) X(1600, 128, 0, 5, 5, 8, 8) X(1920, 128, 0, 3, 5, 8, 16) X(2000, 256, 0, 5, 5, 5, 16)                 \
-    X(2400, 256, 0, 3, 5, 5, 4, 8) X(2500, 256, 0, 5, 5, 5, 5, 4) X(2560, 320, 0, 5, 8, 8, 8) X(3000, 384, 4, 3, 5, 5, 5, 8)          \
-    X(3072, 256, 1536, 3, 16, 8, 8) X(3200, 256, 0, 5, 5, 8, 16) X(3840, 256, 0, 3, 5, 16, 16) X(4000, 512, 1, 5, 5, 5, 4, 8)            \
-    X(4800, 512, 0, 3, 5, 5, 8, 8) X(5000, 512, 0, 5, 5, 5, 5, 8) X(5120, 320, 0, 5, 16, 8, 8) X(6000, 512, 0, 3, 5, 5, 5, 16)        \
-    X(6144, 512, 512, 3, 16, 16, 8) X(6400, 448, 0, 5, 5, 16, 16) X(8000, 512, 0, 5, 5, 5, 8, 8)
+    X(1000, 128, 0, 5, 5, 5, 8) X(1200, 192, 32768, 3, 5, 5, 16) X(1280, 128, 0, 5, 16, 16) X(1500, 192, 0, 3, 5, 5, 5, 4)                \
+    X(1536, 192, 32768, 3, 8, 8, 8) X(1600, 128, 0, 5, 5, 8, 8) X(1920, 128, 32768, 3, 5, 8, 16) X(2000, 256, 32768, 5, 5, 5, 16)                 \
+    X(2400, 256, 32768, 3, 5, 5, 4, 8) X(2500, 256, 32768, 5, 5, 5, 5, 4) X(2560, 320, 0, 5, 8, 8, 8) X(3000, 384, 4, 3, 5, 5, 5, 8)          \
+    X(3072, 256, 1536, 3, 16, 8, 8) X(3200, 256, 32768, 5, 5, 8, 16) X(3840, 256, 0, 3, 5, 16, 16) X(4000, 512, 32769, 5, 5, 5, 4, 8)            \
+    X(4800, 512, 32768, 3, 5, 5, 8, 8) X(5000, 512, 32768, 5, 5, 5, 5, 8) X(5120, 320, 0, 5, 16, 8, 8) X(6000, 512, 0, 3, 5, 5, 5, 16)        \
+    X(6144, 512, 33280, 3, 16, 16, 8) X(6400, 448, 0, 5, 5, 16, 16) X(8000, 512, 32768, 5, 5, 5, 8, 8)
 // Round 4: Float32 schedules with composite radices (fft_lds.h bfly_comp: 6 ... 25 inside one thread's registers) -- THREE passes where the list
 // above runs four or five, one or two LDS round trips and barriers less per transform; fewer, fatter threads (T ~ N / 24).  Taken where the
 // butterfly counts N / R fill the lanes of T threads (>= 78 % in every pass); MDSP_GEN_WIDE=0 keeps the list above.
 // Flags: 16 one LDS buffer, 32 Welch kernel compiled for two waves per SIMD, 64 / 128 / 256 NOT taken for Welch / complex columns / real columns
 // (measured per mode, tools/bench_wide.py, profiles/r04_wide_schedules.json; 1000, 1600 and 8000 were tried and lost in every mode).
 #define MDSP_GEN_CT_WIDE_SIZES(X)                                                                                               \
-    X(1200, 64, 48, 5, 12, 20) X(1500, 64, 304, 5, 12, 25) X(1920, 128, 48, 15, 8, 16) X(2000, 128, 304, 5, 16, 25)                 \
-    X(2400, 128, 48, 5, 20, 24) X(2500, 128, 304, 25, 10, 10) X(3000, 128, 48, 5, 24, 25) X(3200, 128, 368, 25, 8, 16)               \
-    X(3840, 256, 48, 15, 16, 16) X(4800, 320, 48, 15, 16, 20) X(5000, 256, 48, 25, 10, 20) X(6000, 256, 304, 25, 24, 10)            \
+    X(1200, 64, 32816, 5, 12, 20) X(1500, 64, 304, 5, 12, 25) X(1920, 128, 32816, 15, 8, 16) X(2000, 128, 33072, 5, 16, 25)                 \
+    X(2400, 128, 32816, 5, 20, 24) X(2500, 128, 33072, 25, 10, 10) X(3000, 128, 48, 5, 24, 25) X(3200, 128, 33136, 25, 8, 16)               \
+    X(3840, 256, 48, 15, 16, 16) X(4800, 320, 32816, 15, 16, 20) X(5000, 256, 32816, 25, 10, 20) X(6000, 256, 304, 25, 24, 10)            \
     X(6400, 256, 368, 25, 16, 16)
-constexpr int gen_ct_flags(int flags, int mode, bool cplx) { return ((flags & 1024) && !(mode == 0 || cplx)) ? (flags & ~512) : flags; }   // 1024: padding only where the last pass is consumed from registers
+constexpr int gen_ct_touch(int flags, int mode) { return mode == 0 ? flags : (flags & ~32768); }   // 32768 (the next unit touched into the L2): measured for Welch sums only (r06s42)
+constexpr int gen_ct_flags(int flags, int mode, bool cplx) { return gen_ct_touch(((flags & 1024) && !(mode == 0 || cplx)) ? (flags & ~512) : flags, mode); }   // 1024: padding only where the last pass is consumed from registers
 constexpr bool gen_ct_wide_mode(int flags, int mode, bool cplx) { return !(flags & (mode == 0 ? 64 : cplx ? 128 : 256)); }
 // (The single LDS buffer was also tried on the small-radix list above -- flag 16 on all of it, tools/sessions/r04_s28: Welch -1 ... -5 %, ComplexF32 STFT
 // -1 ... -4 %: those kernels are register-, not LDS-limited in residency, and the extra barrier per pass costs.)

@@ -519,17 +519,6 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
             unit_loads(it + 1);
         } else if constexpr (LEAN) {
             ct_pass0_lean<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, static_cast<const R*>(a.winr), bufA, tl);
-            if constexpr (S::TOUCH) {
-                // the NEXT unit's samples pulled into the L2 while this unit runs its passes: one dword per 128-byte line, consumed (by nothing) at the end of the
-                // unit -- the workgroup fills the LDS, so nothing else overlaps a unit's loads; behind this they come from the L2 instead of HBM
-                const int64_t un = u + 1;
-                const bool nlive = it + 1 < a.per_slot && un < a.units_per_ch;
-                const int64_t fn = CPLX ? un : 2 * un;
-                const long long nspan = nlive ? ((long long)a.n + ((!CPLX && fn + 1 < a.K) ? a.hop : 0)) * (long long)sizeof(TT) : 0;
-                const __amdgpu_buffer_rsrc_t dn = io::make_rsrc(sc + fn * a.hop, nspan);
-#pragma unroll
-                for (int i = 0; i < NTOUCH; ++i) touched[i] = io::Ld<float>::load(dn, (tl + T * i) * 128);   // (past the span: the descriptor's zero)
-            }
         }
         else if constexpr (!LDSIN) ct_pass0_global<S, R, CPLX>(sc + f0 * a.hop, a.hop, live, haveB, a.n, w0, bufA, tl);
         else {   // ... or windowed into LDS first (bufB), the first pass then runs LDS -> LDS like the others
@@ -557,6 +546,17 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
             (void)ct_passes<S, 0, 1>(bufB, bufA, tw, tl, t2);   // pass 0: bufB -> bufA (ends with a barrier)
         }
         if constexpr (!LDSIN) __syncthreads();
+        if constexpr (S::TOUCH && !LDSIN && !S::PREFETCH) {
+            // the NEXT unit's samples pulled into the L2 while this unit runs its passes: one dword per 128-byte line, consumed (by nothing) at the end of the
+            // unit -- the workgroup fills the LDS, so nothing else overlaps a unit's loads; behind this they come from the L2 instead of HBM
+            const int64_t un = u + 1;
+            const bool nlive = it + 1 < a.per_slot && un < a.units_per_ch;
+            const int64_t fn = CPLX ? un : 2 * un;
+            const long long nspan = nlive ? ((long long)a.n + ((!CPLX && fn + 1 < a.K) ? a.hop : 0)) * (long long)sizeof(TT) : 0;
+            const __amdgpu_buffer_rsrc_t dn = io::make_rsrc(sc + fn * a.hop, nspan);
+#pragma unroll
+            for (int i = 0; i < NTOUCH; ++i) touched[i] = io::Ld<float>::load(dn, (tl + T * i) * 128);   // (past the span: the descriptor's zero)
+        }
         const int64_t o0 = ch * a.chs + f0 * a.ldo;
         if constexpr (DIRECT) {
             const cx<R>* src = bufA;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
             }
         }
         __syncthreads();   // the buffer the last pass read may be the one the next frame's first pass writes
-        if constexpr (S::TOUCH && LEAN) {
+        if constexpr (S::TOUCH && !LDSIN && !S::PREFETCH) {
 #pragma unroll
             for (int i = 0; i < NTOUCH; ++i) asm volatile("" ::"v"(touched[i]));
         }
@@ -679,7 +679,7 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
 #define MDSP_X(N, T, F, ...)                                                                               \
     case N:                                                                                                \
         if constexpr (gen_ct_wide_mode(F, MODE, CPLX)) {                                                   \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) | (MODE == 0 ? MDSP_GEN_F32_WELCH_FLAGS : 0), __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, gen_ct_touch(F, MODE) | (MODE == 0 ? MDSP_GEN_F32_WELCH_FLAGS : 0), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                   \
         }                                                                                                  \
         break;
@@ -697,13 +697,13 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
             *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, gen_ct_flags(F, MODE, CPLX) | (MODE == 0 ? MDSP_GEN_F32_WELCH_FLAGS : 0), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (N <= GEN_CT_F64_TWO_BUF) {                                                            \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) & ~1536, __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, (F) & ~(1536 | 32768), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (MODE == 0 || CPLX) {                                                                  \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | 16 | gen_ct_f64_tw2l(N, MODE, CPLX), __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~(1536 | 32768)) | 16 | gen_ct_f64_tw2l(N, MODE, CPLX), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         } else if constexpr (N <= GEN_CT_F64_REAL_COLUMNS_MAX) {                                                   \
-            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~1536) | gen_ct_f64_tw2l(N, MODE), __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~(1536 | 32768)) | gen_ct_f64_tw2l(N, MODE), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         }                                                                                                          \
         break;
