@@ -658,11 +658,14 @@ inline bool gen_ct_size(int dtype, int64_t nfft, bool direct) {
 #ifndef MDSP_F64_LEAN
 #define MDSP_F64_LEAN 1
 #endif
+#ifndef MDSP_F64_TOUCH
+#define MDSP_F64_TOUCH 0   // (32768 = the next unit touched into the L2: measured for Float64 / ComplexF64 Welch sums at 5120 .. 8000 points, r06s46: within +-2 %, not taken)
+#endif
 // Measured (profiles/r06_f64_lean.json, 2^25 samples, TB/s): Welch 6000 0.57 -> 1.01, 6400 0.63 -> 1.13, 8000 0.70 -> 1.07, 5120 1.10 -> 1.20, 6144 1.23 -> 1.31
 // (4800 and 5000 within 4 %: round 5's form stays); ComplexF64 columns 4800 2.1 -> 2.9, 6000 1.7 -> 2.0, 8000 2.0 -> 2.2 (5000, 5120, 6144 lose: round 5's form).
 constexpr int gen_ct_f64_tw2l(int N, int mode, bool cplx = false) {
     if (N < 4800) return 0;
-    if (MDSP_F64_LEAN && mode == 0 && N > 5000) return 2048 | 4096 | 16384;
+    if (MDSP_F64_LEAN && mode == 0 && N > 5000) return 2048 | 4096 | 16384 | MDSP_F64_TOUCH;
     if (MDSP_F64_LEAN && mode == 1 && cplx && (N == 4800 || N == 6000 || N == 6400 || N == 8000)) return 2048 | 4096 | 16384;
     if (N == 5000) return 0;
     if (mode == 0 && (N == 6000 || N == 6400)) return 0;
