@@ -243,7 +243,7 @@ class Marks:
             # round 5
             "decim16_f32", "resample_441_160_c64", "welch_default", "welch_default_2p24", "spectrogram_default", "filt_32768", "filt_f64", "welch_f64",
             "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt", "welch_2p19",
-            "welch_8192", "welch_12500", "welch_16384", "welch_65536", "welch_125000")
+            "welch_8192", "welch_12500", "welch_16384", "welch_65536", "welch_125000", "welch_200000")
 
     def __init__(self, lib, _lib, stream):
         import torch
@@ -292,10 +292,11 @@ ROW_INFO = {
     "welch_default": ("multi-pass engine (bigfft.hip)", "welch_pgram(s) with DEFAULT arguments, 2^27 Float32: n = nfft = 2^24, 15 frames", "4"),
     "welch_default_2p24": ("multi-pass engine", "welch_pgram(s), 2^24 Float32: n = nfft = 2^21", "4"),
     "welch_8192": ("welch_half_kernel<8192>", "2^27 Float32, n = nfft = 8192, 50 % overlap (the largest register-resident power of two: the yardstick of the sizes above it)", "4"),
-    "welch_12500": ("gen_ct_kernel<12500 = 25 20 25> (one workgroup, one LDS buffer: csrc/spectral_ctbig.hip)", "2^27 Float32, n = nfft = 12500 = nextfastfft(10^5 >> 3), 50 % overlap", "4"),
-    "welch_16384": ("gen_ct_cols_kernel<8192 = 16 32 16>, 2 x 8192 (column step fused into the loads: csrc/spectral_ctcols.hip)", "2^27 Float32, n = nfft = 16384, 50 % overlap", "4"),
-    "welch_65536": ("gen_ct_cols_kernel<8192>, 8 x 8192 (the multi-pass engine's 256 x 256 measured 0.44 TB/s against 0.56)", "2^27 Float32, n = nfft = 65536, 50 % overlap", "4"),
-    "welch_125000": ("multi-pass engine, 250 x 500 (generic phases)", "2^27 Float32, n = nfft = 125000 = nextfastfft(10^6 >> 3), 50 % overlap", "4"),
+    "welch_12500": ("gen_ct_kernel<12500 = 25 20 25>, lean form (one workgroup, one LDS buffer: csrc/spectral_ctbig.hip)", "2^27 Float32, n = nfft = 12500 = nextfastfft(10^5 >> 3), 50 % overlap", "4"),
+    "welch_16384": ("gen_ct_kernel<16384 = 32 32 16>, lean form (one workgroup of 512 threads, 134 KiB of LDS: csrc/spectral_ctbig.hip)", "2^27 Float32, n = nfft = 16384, 50 % overlap", "4"),
+    "welch_65536": ("gen_ct_cols_kernel<16384>, 4 x 16384 (column step fused into the loads: csrc/spectral_ctcols_big.hip; the multi-pass engine's 256 x 256 measured 0.44 TB/s)", "2^27 Float32, n = nfft = 65536, 50 % overlap", "4"),
+    "welch_125000": ("gen_ct_cols_kernel<15625 = 25 25 25>, 8 x 15625 (the multi-pass engine's 250 x 500 measured 0.25 TB/s)", "2^27 Float32, n = nfft = 125000 = nextfastfft(10^6 >> 3), 50 % overlap", "4"),
+    "welch_200000": ("rows_col_kernel<16> + gen_ct_kernel<12500> over the rows: 16 x 12500 in two kernels (csrc/spectral_ctrows.hip; the multi-pass engine measured 0.15 TB/s)", "2^27 Float32, n = nfft = 200000 = nextfastfft(1.6 10^6 >> 3), 50 % overlap", "4"),
     "welch_2p19": ("multi-pass engine, rows form (column pass + single-workgroup Welch kernel over the rows)", "2^27 Float32, n = nfft = 2^19, 50 % overlap: 511 frames", "4"),
     "spectrogram_default": ("multi-pass engine + untangle", "spectrogram(s) with DEFAULT arguments, 2^27 Float32 -> (2^23 + 1) x 15 Float32", "4 in + 4 per bin out"),
     "filt_5120": ("upols2_fused_kernel", "filt, 5120 taps, 2^28 Float32", "8"),
@@ -521,7 +522,7 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
         med, _ = tm.time(lambda: _lib.check(lib.mdsp_welch_exec(cfg._h, xr.data_ptr(), n3, 1, n3, psd.data_ptr(), cfg.nout, stream)))
         rows[f"welch_{nfft}"] = crow(tm, med, 4.0 * n3, engine=cfg.engine)
 
-    for nfft_ in (8192, 12500, 16384, 65536, 125000):
+    for nfft_ in (8192, 12500, 16384, 65536, 125000, 200000):
         guarded(f"welch_{nfft_}", lambda nfft_=nfft_: welch_n(nfft_))
 
     def spectrogram_default():

@@ -688,11 +688,23 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 //   real columns   : 1.1 - 6 x, a tie with rocFFT at R0 >= 5 (12500, 40000); 16384 = 2 x 8192 loses 8 % to the multi-pass engine
 //   complex columns: wins from 4097 points while one workgroup holds the transform and up to R0 = 4 (8400, 20000); rocFFT is faster below 4097
 //                    (1.4 - 1.7 against 0.9 - 1.3 TB/s) and at R0 >= 5 (40000: 0.75 / 0.91 against 0.67 / 0.59)
+// nfft = R0 x S in two kernels (spectral_ctrows.hip), R0 up to 32: where no fused column step exists (R0 > 8 -- 200000 = 16 x 12500, 250000 = 16 x 15625: 0.48 / 0.40 TB/s
+// against the multi-pass engine's 0.15 / 0.18; 150000 .. 500000: 0.36 - 0.49 against 0.08 - 0.10, r06s47 / r06s49).  Against the fused rows of R0 = 5 .. 8 it measured -2 .. +17 % (each of its two kernels takes what the
+// fused one does) and loses below: those stay fused.  MDSP_GX=8: wherever a split exists (A/B), MDSP_GX=-1: never.
+int ctrows_r0(int dtype, int64_t nfft) {
+    const int m = tunables().gx;
+    if (m == 0 || m == -1 || m == 4 || m == 5 || m == 6 || ctbig_ok(dtype, nfft)) return 0;
+    const int any = ctrows_split(dtype, nfft, 2);
+    if (any == 0) return 0;
+    if (m == 8) return any;
+    if (nfft >= 524288 && (nfft & (nfft - 1)) == 0) return 0;   // 2^19 = 32 x 16384: 0.46 against 0.52 on the multi-pass engine's rows form (r06s49); 2^18 0.53 against 0.49
+    return ctcols_split(dtype, nfft) == 0 ? any : 0;
+}
 bool use_gx(int dtype, int64_t nfft, bool direct, int kind) {
     const int m = tunables().gx;
     if (m == 0) return false;
     if (kind == 0 && m != 4 && m != 5 && ctbig_preferred(dtype, nfft)) return true;
-    if (kind == 0 && m != 4 && !fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && ((m != 5 && ctbig_ok(dtype, nfft)) || ctcols_split(dtype, nfft) > 0))
+    if (kind == 0 && m != 4 && !fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && ((m != 5 && ctbig_ok(dtype, nfft)) || ctcols_split(dtype, nfft) > 0 || ctrows_r0(dtype, nfft) > 0))
         return true;   // Welch sums on a compile-time schedule (one workgroup, or R0 x S rows): whatever the run-time-schedule kernel plans
     if (!gx_size_ok(dtype, nfft)) return false;
     if (m >= 2) return true;
@@ -1714,7 +1726,16 @@ int welch_accumulate_fused(mdsp_welch_plan_s* pl, const void* s, int64_t len, in
         if (tunables().gx != 4 && tunables().gx != 5 && ctbig_ok(pl->dtype, pl->nfft))   // one workgroup, compile-time schedule (spectral_ctbig.hip): 8400 .. 12500 points
             MDSP_TRY(ctbig_welch(pl->ctcols, pl->dtype, s, lds_, K, pl->n - pl->noverlap, nch, (int)pl->n, pl->nfft, pl->have_win ? pl->win.as<double>() : nullptr, st, &ngroups,
                                  &pl->partial));
-        else if (tunables().gx != 4 && ctcols_split(pl->dtype, pl->nfft) > 0)
+        else if (const int r0rows = ctrows_r0(pl->dtype, pl->nfft); r0rows > 0) {   // nfft = R0 x S in two kernels (spectral_ctrows.hip): straight into the accumulator
+            MDSP_TRY(pl->reduced.reserve(sizeof(double) * (size_t)nch * (size_t)pl->nfft));
+            MDSP_TRY(ctrows_welch(pl->ctrows, pl->dtype, r0rows, s, lds_, K, pl->n - pl->noverlap, nch, (int)pl->n, pl->nfft, pl->have_win ? pl->win.as<double>() : nullptr,
+                                  pl->reduced.as<double>(), pl->acc_fresh, st));
+            pl->acc_fresh = false;
+            pl->acc_nslices = 1;
+            pl->acc_nacc = (int)pl->nfft;
+            pl->acc_mode = CPLX ? 1 : (pl->onesided ? 3 : 4);
+            return MDSP_OK;
+        } else if (tunables().gx != 4 && ctcols_split(pl->dtype, pl->nfft) > 0)
             MDSP_TRY(ctcols_welch(pl->ctcols, pl->dtype, s, lds_, K, pl->n - pl->noverlap, nch, (int)pl->n, pl->nfft, pl->have_win ? pl->win.as<double>() : nullptr, st, &ngroups,
                                   &pl->partial));
         else

@@ -79,7 +79,7 @@ bool ctbig_preferred(int dtype, int64_t nfft) {   // ... in front of the all-mod
 }
 
 int ctbig_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,
-                hipStream_t st, int64_t* nslots, DevBuf* partial) {
+                hipStream_t st, int64_t* nslots, DevBuf* partial, int accumulate) {
     if (!ctbig_ok(dtype, nfft)) MDSP_FAIL(MDSP_ERR_ASSERTION, "nfft=%lld has no single-workgroup compile-time schedule", (long long)nfft);
     if (!cp.ready) {
         MDSP_TRY(upload_roots_n<float>(cp.roots, nfft));
@@ -92,7 +92,7 @@ int ctbig_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t 
     GenArgs g{};
     g.s = s; g.roots = cp.roots.p; g.win = win_dev; g.winr = cp.win.p;
     g.lds_ = lds_; g.K = K; g.hop = hop; g.nch = nch; g.units_per_ch = cplx ? K : cdiv(K, 2);
-    g.n = n; g.N = (int)nfft;
+    g.n = n; g.N = (int)nfft; g.accumulate = accumulate;
     return cplx ? big_dispatch<float, true>(g, nch, st, nslots, partial) : big_dispatch<float, false>(g, nch, st, nslots, partial);
 }
 }  // namespace mdsp

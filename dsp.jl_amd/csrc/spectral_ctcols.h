@@ -20,6 +20,7 @@ int ctcols_big_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int
 // spectral_ctbig.hip: nfft between 8193 and 16384 points with a single-workgroup compile-time schedule (Float32 / ComplexF32); cp holds the nfft roots
 bool ctbig_ok(int dtype, int64_t nfft);
 bool ctbig_preferred(int dtype, int64_t nfft);   // a size that also has an all-mode compile-time schedule, Welch sums faster here
+// (accumulate: the partial rows of an earlier launch with at least as many slots are added to instead of overwritten -- spectral_ctrows.hip)
 int ctbig_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,
-                hipStream_t st, int64_t* nslots, DevBuf* partial);
+                hipStream_t st, int64_t* nslots, DevBuf* partial, int accumulate = 0);
 }  // namespace mdsp

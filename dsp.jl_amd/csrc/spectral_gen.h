@@ -473,7 +473,7 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
     }
     constexpr int NTOUCH = S::TOUCH ? (N * (int)sizeof(TT) * (CPLX ? 2 : 3) / 2 / 128 + T - 1) / T : 1;   // 128-byte lines of a unit's span per thread
     [[maybe_unused]] float touched[NTOUCH];
-    bool flushed = false;
+    bool flushed = MODE == 0 && a.accumulate != 0;   // (Welch sums: a.accumulate = the partial row holds the sums of an earlier launch, spectral_ctrows.hip)
     auto flush = [&]() __attribute__((always_inline)) {   // the sums of up to MDSP_GEN_LEAN_FLUSH units into this workgroup's own Float64 partial row
         if constexpr (MODE == 0) {
             double* part = static_cast<double*>(a.out) + (gslot * a.nch + ch) * (int64_t)N;

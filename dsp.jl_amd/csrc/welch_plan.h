@@ -7,6 +7,7 @@
 #include "bigfft.h"
 #include "gx_plan.h"
 #include "spectral_ctcols.h"
+#include "spectral_ctrows.h"
 
 struct mdsp_welch_plan_s {
     int dtype = MDSP_F32, engine = MDSP_ENGINE_ROCFFT, onesided = 1;
@@ -31,6 +32,7 @@ struct mdsp_welch_plan_s {
     mdsp::GxPlan gx;             // 7-smooth sizes without a compile-time schedule, up to 32 x 16384 points: the run-time-schedule kernel (spectral_gx.h)
     mdsp::DevBuf winr;           // lean compile-time schedules (CtSched flag 4096): the window in the working precision, nfft values, zero tail
     bool winr_ready = false;
+    mdsp::CtRowsPlan ctrows;     // ... or R0 x S in two kernels from R0 = 5 (spectral_ctrows.hip)
     mdsp::CtColsPlan ctcols;     // ... and those that are R0 x a compile-time row schedule (spectral_ctcols.hip)
     mdsp::DevBuf w64prep;        // mdsp_welch_w64_asm: Float32 window pairs + per-lane twiddles (built at the plan's first launch of that kernel)
     bool frames_on_device = false;

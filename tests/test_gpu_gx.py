@@ -69,6 +69,9 @@ WELCH_CASES = (
     (25000, 12500, 25000, "hanning", 4),     # 2 x 12500
     (32768, 16384, 32768, "hanning", 3),     # 2 x 16384 (Float64: the multi-pass engine)
     (100000, 50000, 100000, "hanning", 3),   # 8 x 12500
+    # ... and in two kernels where R0 > 8 (csrc/spectral_ctrows.hip: column kernel into a work buffer, the single-workgroup kernel over the rows)
+    (200000, 100000, 200000, "hanning", 3),  # 16 x 12500
+    (150000, 70000, 150000, None, 4),        # 10 x 15000, odd frame count
 )
 
 
@@ -133,6 +136,28 @@ def test_lean_schedules_flush_their_float32_sums(d):
             assert frames == K
             assert relerr(got[:, c], ref) < TOL32, (n, c, relerr(got[:, c], ref))
             assert ulps_of_max(got[:, c], ref) < _ulp_bound(n)
+
+
+def test_two_kernel_rows_form_in_chunks_and_channels(d):
+    """nfft = 150000 = 10 x 15000 in two kernels with a work buffer of 16 MiB (MDSP_BIG_CHUNK_MIB): two channels, 61 frames = 31 frame pairs in chunks of six -- the
+    row kernel's partial sums persist from chunk to chunk."""
+    from oracle import periodograms as opg, windows as ow
+    from dsp_jl_amd import _lib
+    rng = np.random.default_rng(67)
+    n, K = 150000, 61
+    hop = n - n // 2
+    length = (K - 1) * hop + n + 17
+    s = np.stack([_signal(rng, length, np.float32) for _ in range(2)], axis=1)
+    _lib.set_tunable("MDSP_BIG_CHUNK_MIB", 16)
+    try:
+        got = np.asarray(d.welch_pgram(s, n, n // 2, window=d.hamming).power)
+    finally:
+        _lib.set_tunable("MDSP_BIG_CHUNK_MIB", None)
+    assert got.shape == (n // 2 + 1, 2)
+    for c in range(2):
+        ref = opg.welch_pgram(s[:, c], n, n // 2, window=ow.hamming, dtype=np.float64).power
+        assert relerr(got[:, c], ref) < TOL32, (c, relerr(got[:, c], ref))
+        assert ulps_of_max(got[:, c], ref) < _ulp_bound(n)
 
 
 @pytest.mark.parametrize("dt,tol", DTYPES)
