@@ -7,7 +7,9 @@
 //   the sums leave in natural order: X[k1 + R0 k2] = FFT_S(row k1)[k2].
 // The work buffer is cut into chunks of MDSP_BIG_CHUNK_MIB (1 GiB; chunks of 128 MiB, to read the rows back from the Infinity Cache, measured 5 - 15 % SLOWER: more
 // launches, no cache effect -- r06s47).  Each of the two kernels takes about what the fused column step takes at R0 = 5 .. 8, so this form serves the sizes that have
-// no fused one: R0 = 9 .. 32.  Float32 / ComplexF32;
+// no fused one: R0 = 9 .. 32.  (Also measured and dropped, r06s51: the row kernel of chunk c on a second stream beside the column kernel of chunk c + 1, six chunks on
+// two buffers -- 0.27 - 0.38 TB/s against 0.35 - 0.53 in order: at these call lengths the extra launches and event waits cost more than the overlap returns.)
+// Float32 / ComplexF32;
 // S any size of ctbig_sizes.h, R0 any radix fft_lds.h has a butterfly for (2 .. 32): 125000 = 8 x 15625, 200000 = 16 x 12500, 2^19 = 32 x 16384.
 // Reference loops: periodograms.jl:746-759 (welch_pgram_helper!), :57-69 (ArraySplit), :142-172 (fft2pow!).
 #include <algorithm>
