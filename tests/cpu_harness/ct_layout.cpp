@@ -13,6 +13,9 @@
 
 #include "../../dsp.jl_amd/csrc/fft_lds.h"
 #include "../../dsp.jl_amd/csrc/ct_sched.h"
+#ifdef CT_BIG   // the single-workgroup tables of round 6 (ctbig_sizes.h: 177 schedules up to 16384 points); the reference DFT on every CT_BIG-th bin
+#include "../../dsp.jl_amd/csrc/ctbig_sizes.h"
+#endif
 
 using namespace mdsp::fft;
 
@@ -71,7 +74,12 @@ template <typename S, typename R> double check_schedule(bool inplace) {
     for (int i = 0; i < N; ++i) a[i] = {(R)x[i].real(), (R)x[i].imag()};
     run_passes<S, R, 0>(a, b, roots, result, inplace);
     double err2 = 0, norm = 0;
-    for (int k = 0; k < N; ++k) {
+#ifdef CT_BIG
+    constexpr int KSTEP = N > 4096 ? CT_BIG : 7;
+#else
+    constexpr int KSTEP = 1;
+#endif
+    for (int k = 0; k < N; k += KSTEP) {
         std::complex<double> acc = 0;
         for (int n = 0; n < N; ++n) acc += std::complex<double>((double)(R)x[n].real(), (double)(R)x[n].imag()) * w[(int)(((long long)n * k) % N)];
         err2 += std::norm(std::complex<double>(result[k].x, result[k].y) - acc);
@@ -85,14 +93,22 @@ int main() {
 #define MDSP_X(N, T, F, ...)                                                                                                         \
     {                                                                                                                                \
         using S = CtSched<N, T, F, __VA_ARGS__>;                                                                                     \
-        const double e2 = check_schedule<S, float>(false), e1 = check_schedule<S, float>(true);                                     \
+        static_assert(sizeof(cx<float>) * ((S::INPLACE ? 1 : 2) * (size_t)S::NP + (S::TW2L ? S::TWS + S::NTWHI : 0)) <= 160 * 1024, "LDS");   \
+        const double e2 = S::INPLACE ? 0.0 : check_schedule<S, float>(false), e1 = check_schedule<S, float>(true);                 \
         const bool ok = e1 < 3e-6 && e2 < 3e-6;                                                                                      \
         printf("N %5d T %3d flags %4d passes %d NP %5d: two buffers %.2e, one buffer %.2e%s\n", N, T, F, S::P, S::NP, e2, e1, ok ? "" : "  FAIL"); \
         bad |= !ok;                                                                                                                  \
         ++count;                                                                                                                     \
     }
+#ifdef CT_BIG
+    MDSP_CTBIG_SIZES(MDSP_X)
+    MDSP_CTBIG_LEAN_SIZES(MDSP_X)
+    MDSP_CTBIG_SMALL_SIZES(MDSP_X)
+    MDSP_CTBIG_PREF_SIZES(MDSP_X)
+#else
     MDSP_GEN_CT_SIZES(MDSP_X)
     MDSP_GEN_CT_WIDE_SIZES(MDSP_X)
+#endif
 #undef MDSP_X
     {   // Float64 on the small-radix list with the padding bits stripped, as gen_ct_dispatch instantiates it
         using S = CtSched<3000, 384, 4 & ~1536, 3, 5, 5, 5, 8>;

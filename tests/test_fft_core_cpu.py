@@ -28,6 +28,18 @@ def test_compile_time_schedules_on_the_host(tmp_path):
     assert "36 schedules" in r.stdout and "N  3072 T 256 flags 1536 passes 4 NP  3136" in r.stdout and "FAIL" not in r.stdout
 
 
+def test_single_workgroup_tables_on_the_host(tmp_path):
+    """The same harness over the single-workgroup tables of round 6 (csrc/ctbig_sizes.h: 177 schedules from 1280 to 16384 points, three or four passes at 192 .. 1024
+    threads on one LDS buffer): radices multiply to N, the padded buffer and the twiddle tables fit 160 KiB (static_assert), and the passes -- run with the schedule
+    type's index arithmetic on one buffer -- give the DFT (every 61st bin against a Float64 sum above 4096 points)."""
+    exe = str(tmp_path / "ct_layout_big")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-DCT_BIG=61", os.path.join(ROOT, "tests", "cpu_harness", "ct_layout.cpp"), "-o", exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout[-3000:]
+    assert "177 schedules: OK" in r.stdout and "N 16384 T 512" in r.stdout, r.stdout[-500:]
+
+
 def test_multipass_transform_on_the_host(tmp_path):
     """tests/cpu_harness/bigfft_emul.cpp: the tile / sub-pass / store phases of the multi-pass engine (csrc/bigfft_pass.h) and its planner
     (csrc/bigfft_plan.h: factorisation, radix schedules, two-level twiddle tables) run thread by thread on the host against a Float64 DFT --
