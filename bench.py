@@ -295,9 +295,9 @@ ROW_INFO = {
     "welch_12500": ("gen_ct_kernel<12500 = 25 20 25>, lean form (one workgroup, one LDS buffer: csrc/spectral_ctbig.hip)", "2^27 Float32, n = nfft = 12500 = nextfastfft(10^5 >> 3), 50 % overlap", "4"),
     "welch_16384": ("gen_ct_kernel<16384 = 32 32 16>, lean form (one workgroup of 512 threads, 134 KiB of LDS: csrc/spectral_ctbig.hip)", "2^27 Float32, n = nfft = 16384, 50 % overlap", "4"),
     "welch_65536": ("gen_ct_cols_kernel<16384>, 4 x 16384 (column step fused into the loads: csrc/spectral_ctcols_big.hip; the multi-pass engine's 256 x 256 measured 0.44 TB/s)", "2^27 Float32, n = nfft = 65536, 50 % overlap", "4"),
-    "welch_125000": ("gen_ct_cols_kernel<15625 = 25 25 25>, 8 x 15625 (the multi-pass engine's 250 x 500 measured 0.25 TB/s)", "2^27 Float32, n = nfft = 125000 = nextfastfft(10^6 >> 3), 50 % overlap", "4"),
+    "welch_125000": ("rows_col_kernel<8> + gen_ct_kernel<15625 = 25 25 25> over the rows: 8 x 15625 in two kernels (csrc/spectral_ctrows.hip; the multi-pass engine's 250 x 500 measured 0.25 TB/s)", "2^27 Float32, n = nfft = 125000 = nextfastfft(10^6 >> 3), 50 % overlap", "4"),
     "welch_200000": ("rows_col_kernel<16> + gen_ct_kernel<12500> over the rows: 16 x 12500 in two kernels (csrc/spectral_ctrows.hip; the multi-pass engine measured 0.15 TB/s)", "2^27 Float32, n = nfft = 200000 = nextfastfft(1.6 10^6 >> 3), 50 % overlap", "4"),
-    "welch_2p19": ("multi-pass engine, rows form (column pass + single-workgroup Welch kernel over the rows)", "2^27 Float32, n = nfft = 2^19, 50 % overlap: 511 frames", "4"),
+    "welch_2p19": ("rows_col_kernel<32> + gen_ct_kernel<16384> over the rows: 32 x 16384 in two kernels (round 5: the multi-pass engine's rows form, 64 x 8192, 0.56 TB/s)", "2^27 Float32, n = nfft = 2^19, 50 % overlap: 511 frames", "4"),
     "spectrogram_default": ("multi-pass engine + untangle", "spectrogram(s) with DEFAULT arguments, 2^27 Float32 -> (2^23 + 1) x 15 Float32", "4 in + 4 per bin out"),
     "filt_5120": ("upols2_fused_kernel", "filt, 5120 taps, 2^28 Float32", "8"),
     "filt_32768": ("d.filt(b, x) through the host mirror: ONE plan, rows form of the multi-pass engine (column pass, row kernel, column pass back)", "32768 taps, 2^27 Float32", "8"),

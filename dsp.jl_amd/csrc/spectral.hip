@@ -688,17 +688,18 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 //   real columns   : 1.1 - 6 x, a tie with rocFFT at R0 >= 5 (12500, 40000); 16384 = 2 x 8192 loses 8 % to the multi-pass engine
 //   complex columns: wins from 4097 points while one workgroup holds the transform and up to R0 = 4 (8400, 20000); rocFFT is faster below 4097
 //                    (1.4 - 1.7 against 0.9 - 1.3 TB/s) and at R0 >= 5 (40000: 0.75 / 0.91 against 0.67 / 0.59)
-// nfft = R0 x S in two kernels (spectral_ctrows.hip), R0 up to 32: where no fused column step exists (R0 > 8 -- 200000 = 16 x 12500, 250000 = 16 x 15625: 0.48 / 0.40 TB/s
-// against the multi-pass engine's 0.15 / 0.18; 150000 .. 500000: 0.36 - 0.49 against 0.08 - 0.10, r06s47 / r06s49).  Against the fused rows of R0 = 5 .. 8 it measured -2 .. +17 % (each of its two kernels takes what the
-// fused one does) and loses below: those stay fused.  MDSP_GX=8: wherever a split exists (A/B), MDSP_GX=-1: never.
+// nfft = R0 x S in two kernels (spectral_ctrows.hip), R0 up to 32: from R0 = 6.  Measured (profiles/r06_ctrows.json, TB/s): 98304 = 6 x 16384 0.70 against 0.61
+// on the fused column step, 100000 = 8 x 12500 0.66 / 0.49, 131072 0.74 / 0.54; a tie at R0 = 5 (81920: 0.69 / 0.69); the fused step wins below (65536 = 4 x 16384
+// 0.74 / 0.81, 32768 0.76 / 1.01).  Beyond eight rows there is no fused step: 150000 .. 500000 points 0.50 - 0.67 against the multi-pass engine's 0.08 - 0.18, 2^19 =
+// 32 x 16384 0.73 against 0.52 on the engine's rows form.  MDSP_GX=8: wherever a split exists (A/B), MDSP_GX=-1: never.
 int ctrows_r0(int dtype, int64_t nfft) {
     const int m = tunables().gx;
     if (m == 0 || m == -1 || m == 4 || m == 5 || m == 6 || ctbig_ok(dtype, nfft)) return 0;
     const int any = ctrows_split(dtype, nfft, 2);
     if (any == 0) return 0;
     if (m == 8) return any;
-    if (nfft >= 524288 && (nfft & (nfft - 1)) == 0) return 0;   // 2^19 = 32 x 16384: 0.46 against 0.52 on the multi-pass engine's rows form (r06s49); 2^18 0.53 against 0.49
-    return ctcols_split(dtype, nfft) == 0 ? any : 0;
+    const int fused = ctcols_split(dtype, nfft);
+    return (fused == 0 || fused >= 6) ? any : 0;
 }
 bool use_gx(int dtype, int64_t nfft, bool direct, int kind) {
     const int m = tunables().gx;

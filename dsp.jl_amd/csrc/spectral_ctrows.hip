@@ -6,8 +6,7 @@
 //             |Z|^2 into Float64 partial rows that persist over the chunks of a call;
 //   the sums leave in natural order: X[k1 + R0 k2] = FFT_S(row k1)[k2].
 // The work buffer is cut into chunks of MDSP_BIG_CHUNK_MIB (1 GiB; chunks of 128 MiB, to read the rows back from the Infinity Cache, measured 5 - 15 % SLOWER: more
-// launches, no cache effect -- r06s47).  Each of the two kernels takes about what the fused column step takes at R0 = 5 .. 8, so this form serves the sizes that have
-// no fused one: R0 = 9 .. 32.  (Also measured and dropped, r06s51: the row kernel of chunk c on a second stream beside the column kernel of chunk c + 1, six chunks on
+// launches, no cache effect -- r06s47).  Taken from R0 = 6 (spectral.hip ctrows_r0: the fused step wins to R0 = 4, a tie at 5).  (Also measured and dropped, r06s51: the row kernel of chunk c on a second stream beside the column kernel of chunk c + 1, six chunks on
 // two buffers -- 0.27 - 0.38 TB/s against 0.35 - 0.53 in order: at these call lengths the extra launches and event waits cost more than the overlap returns.)
 // Float32 / ComplexF32;
 // S any size of ctbig_sizes.h, R0 any radix fft_lds.h has a butterfly for (2 .. 32): 125000 = 8 x 15625, 200000 = 16 x 12500, 2^19 = 32 x 16384.
@@ -64,10 +63,24 @@ template <int R0, bool CPLX> __global__ __launch_bounds__(256) void rows_col_ker
     fft::gen_bfly<R0>(z);
     cx<float>* o = a.work + ((ch * R0) * a.cnt + ul) * (int64_t)a.S + i;
     fft::st2(o, z[0]);
+    // W_nfft^{i k1}: a lane's k1-th twiddle sits k1 table entries from its neighbour's -- fetched directly, the R0 - 1 twiddles of a wave touch ~R0^2 / 2 cache lines
+    // (r06s54: this kernel at 0.35 ms of the 0.55 a 2^26-sample call takes).  Only the powers of two are fetched (W^{i 2^j}: R0 lines in all); the others are products
+    // of at most log2(R0) of them -- two or three roundings more on a twiddle.
+    constexpr int NB = R0 <= 2 ? 1 : R0 <= 4 ? 2 : R0 <= 8 ? 3 : R0 <= 16 ? 4 : 5;
+    cx<float> wp[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wp[j] = a.rootsN[(unsigned)(((unsigned long long)(unsigned)i << j) % (unsigned)a.nfft)];
 #pragma unroll
     for (int k1 = 1; k1 < R0; ++k1) {
-        const unsigned e = (unsigned)(((unsigned long long)(unsigned)i * (unsigned)k1) % (unsigned)a.nfft);
-        fft::st2(o + (int64_t)k1 * a.cnt * a.S, fft::cmul(z[k1], a.rootsN[e]));
+        cx<float> w{1.0f, 0.0f};
+        bool first = true;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (k1 & (1 << j)) {
+                w = first ? wp[j] : fft::cmul(w, wp[j]);
+                first = false;
+            }
+        fft::st2(o + (int64_t)k1 * a.cnt * a.S, fft::cmul(z[k1], w));
     }
 }
 
