@@ -155,7 +155,7 @@ def test_default_arguments_take_the_multipass_engine(d, torch):
     assert relerr(pg.power, rp.power) < TOL64
 
 
-@pytest.mark.parametrize("n,nov,nfft", [(20000, 10000, None), (250000, 125000, 262144)])   # (the second: the rows form -- 32 rows of 8192 points)
+@pytest.mark.parametrize("n,nov,nfft", [(20000, 10000, None), (250000, 125000, 262144)])   # (the second: 16 rows of 16384 points in two kernels, csrc/spectral_ctrows.hip -- up to round 5 the multi-pass engine's rows form, 32 rows of 8192 points)
 def test_multichannel_streaming_and_multitaper_on_large_transforms(d, torch, n, nov, nfft):
     from oracle import periodograms as opg, windows as ow
     rng = np.random.default_rng(57)
