@@ -716,6 +716,7 @@ bool use_gx(int dtype, int64_t nfft, bool direct, int kind) {
 // ... and where AUTO prefers it to the rocFFT pipeline (engine = FUSED takes it wherever use_gx says so)
 bool gx_wins(int dtype, int64_t nfft, int kind) {
     if (kind == 0 || !dtype_is_complex(dtype)) return true;
+    if (tunables().gx != 4 && tunables().gx != 5 && ctbig_cols_ok(dtype, nfft)) return true;   // single-workgroup compile-time columns: 1.6 - 2.9 TB/s against rocFFT's 0.3 - 1.4 (r06s58)
     if (nfft <= 4096) return false;
     return gx_split_r0(dtype, nfft) <= 4;
 }
@@ -2033,6 +2034,7 @@ struct mdsp_stft_plan_s {
     big::EngineHolder big;             // nfft above the single-workgroup kernels: the multi-pass engine (bigfft.hip)
     mdsp::GxPlan gx;                   // 7-smooth sizes without a compile-time schedule: the run-time-schedule kernel (spectral_gx.h)
     mdsp::DevBuf winr;                 // lean compile-time schedules (CtSched flag 4096): the window of THIS launch in the working precision (multitaper plans change it per taper)
+    mdsp::CtColsPlan ctbig;            // columns on the single-workgroup schedules of ctbig_sizes.h (spectral_ctbig_cols.hip)
 };
 
 namespace {
@@ -2166,6 +2168,12 @@ int stft_exec_fused(mdsp_stft_plan_s* pl, const void* s, int64_t len, int64_t nc
     const int64_t K = mdsp_frame_count(len, pl->n, pl->noverlap);
     if (K == 0) return MDSP_OK;
     if (use_gx(pl->dtype, pl->nfft, CPLX, 1)) {   // run-time-schedule kernel (spectral_gx.h); multitaper plans come here once per taper (accumulate)
+        if (tunables().gx != 4 && tunables().gx != 5 && ctbig_cols_ok(pl->dtype, pl->nfft)) {   // ... or a single-workgroup compile-time schedule (spectral_ctbig_cols.hip)
+            CtBigColsArgs c{};
+            c.s = s; c.out = out; c.win = pl->have_win ? pl->win_ptr : nullptr; c.len = len; c.lds_ = lds_; c.K = K; c.hop = pl->n - pl->noverlap; c.nch = nch; c.ldo = ldo; c.chs = chs;
+            c.n = (int)pl->n; c.nfft = pl->nfft; c.nout = (int)pl->nout; c.onesided = pl->onesided; c.psd = pl->psd_only; c.accumulate = pl->accumulate; c.r = pl->r;
+            return ctbig_stft(pl->ctbig, pl->dtype, c, st);
+        }
         GxArgs g{};
         g.s = s; g.out = out; g.lds_ = lds_; g.K = K; g.hop = pl->n - pl->noverlap; g.nch = nch; g.ldo = ldo; g.chs = chs;
         g.n = (int)pl->n; g.nfft = (int)pl->nfft; g.nout = (int)pl->nout; g.onesided = pl->onesided; g.psd = pl->psd_only; g.accumulate = pl->accumulate; g.r = pl->r;

@@ -23,4 +23,17 @@ bool ctbig_preferred(int dtype, int64_t nfft);   // a size that also has an all-
 // (accumulate: the partial rows of an earlier launch with at least as many slots are added to instead of overwritten -- spectral_ctrows.hip)
 int ctbig_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,
                 hipStream_t st, int64_t* nslots, DevBuf* partial, int accumulate = 0);
+// spectral_ctbig_cols.hip: STFT / spectrogram / periodogram columns on the same single-workgroup schedules (complex signals to 16384 points, real ones to 9600)
+struct CtBigColsArgs {
+    const void* s;
+    void* out;
+    const double* win;   // n doubles or nullptr (the window of THIS launch)
+    int64_t len, lds_, K, hop, nch, ldo, chs;
+    int n;
+    int64_t nfft;
+    int nout, onesided, psd, accumulate;
+    double r;
+};
+bool ctbig_cols_ok(int dtype, int64_t nfft);
+int ctbig_stft(CtColsPlan& cp, int dtype, const CtBigColsArgs& a, hipStream_t st);
 }  // namespace mdsp

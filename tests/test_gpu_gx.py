@@ -166,7 +166,9 @@ def test_gx_stft_spectrogram_periodogram_vs_oracle(d, dt, tol):
     rng = np.random.default_rng(63)
     cplx = np.dtype(dt).kind == "c"
     f32 = dt in (np.float32, np.complex64)
-    for (n, nov, nfft, wname, K) in WELCH_CASES[:3] + WELCH_CASES[5:8] + WELCH_CASES[10:11]:
+    # ... and the column modes of the single-workgroup compile-time schedules (csrc/spectral_ctbig_cols.hip): real signals to 9600 points, complex ones to 16384
+    extra = ((3087, 1500, 3087, "hanning", 5), (9600, 4800, 9600, "hamming", 4), (9000, 2000, 9216, "hanning", 3), (10240, 5120, 10240, "hamming", 3), (15625, 7000, 15625, None, 3))
+    for (n, nov, nfft, wname, K) in WELCH_CASES[:3] + WELCH_CASES[5:8] + WELCH_CASES[10:11] + extra:
         win = getattr(ow, wname) if wname else None
         dwin = getattr(d, wname) if wname else None
         length = (K - 1) * (n - nov) + n + 5
@@ -186,6 +188,20 @@ def test_gx_stft_spectrogram_periodogram_vs_oracle(d, dt, tol):
         pg = d.periodogram(x, nfft=nfft, window=dwin, fs=2.0)
         rp = opg.periodogram(x, nfft=nfft, window=win, fs=2.0, dtype=np.float64)
         assert pg.power.shape == rp.power.shape and relerr(pg.power, rp.power) < tol, (n, nfft)
+
+
+def test_multitaper_on_the_compile_time_columns(d):
+    """mt_pgram of Float32 / ComplexF32 signals of 3087 and 6912 samples (nfft = nextfastfft(n) = n: single-workgroup compile-time columns,
+    csrc/spectral_ctbig_cols.hip): one launch per taper, each with its own window, accumulated into the same PSD (multitaper.jl:240-243)."""
+    from oracle import multitaper as omt
+    rng = np.random.default_rng(68)
+    for n in (3087, 6912):
+        for dt in (np.float32, np.complex64):
+            x = _signal(rng, n, dt)
+            got = d.mt_pgram(x, nw=4, ntapers=5, fs=2.0)
+            ref_power, ref_freq = omt.mt_pgram(x.astype(np.float64 if dt == np.float32 else np.complex128), nw=4, ntapers=5, fs=2.0)
+            assert np.array_equal(got.freq, ref_freq)
+            assert relerr(got.power, ref_power) < TOL32, (n, dt, relerr(got.power, ref_power))
 
 
 def test_gx_default_calls_on_mid_size_signals(d):
