@@ -243,7 +243,7 @@ class Marks:
             # round 5
             "decim16_f32", "resample_441_160_c64", "welch_default", "welch_default_2p24", "spectrogram_default", "filt_32768", "filt_f64", "welch_f64",
             "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt", "welch_2p19",
-            "welch_8192", "welch_12500", "welch_16384", "welch_65536", "welch_125000", "welch_200000")
+            "welch_8192", "welch_12500", "welch_16384", "welch_65536", "welch_125000", "welch_200000", "spectrogram_8400")
 
     def __init__(self, lib, _lib, stream):
         import torch
@@ -298,6 +298,7 @@ ROW_INFO = {
     "welch_125000": ("rows_col_kernel<8> + gen_ct_kernel<15625 = 25 25 25> over the rows: 8 x 15625 in two kernels (csrc/spectral_ctrows.hip; the multi-pass engine's 250 x 500 measured 0.25 TB/s)", "2^27 Float32, n = nfft = 125000 = nextfastfft(10^6 >> 3), 50 % overlap", "4"),
     "welch_200000": ("rows_col_kernel<16> + gen_ct_kernel<12500> over the rows: 16 x 12500 in two kernels (csrc/spectral_ctrows.hip; the multi-pass engine measured 0.15 TB/s)", "2^27 Float32, n = nfft = 200000 = nextfastfft(1.6 10^6 >> 3), 50 % overlap", "4"),
     "welch_2p19": ("rows_col_kernel<32> + gen_ct_kernel<16384> over the rows: 32 x 16384 in two kernels (round 5: the multi-pass engine's rows form, 64 x 8192, 0.56 TB/s)", "2^27 Float32, n = nfft = 2^19, 50 % overlap: 511 frames", "4"),
+    "spectrogram_8400": ("gen_ct_kernel<8400 = 20 20 21>, column mode (one workgroup, two LDS buffers: csrc/spectral_ctbig_cols.hip; round 5: rocFFT pipeline 0.29 TB/s)", "2^27 Float32 -> 4201 x 31955 Float32, n = nfft = 8400, 50 % overlap", "4 in + 4 per bin out"),
     "spectrogram_default": ("multi-pass engine + untangle", "spectrogram(s) with DEFAULT arguments, 2^27 Float32 -> (2^23 + 1) x 15 Float32", "4 in + 4 per bin out"),
     "filt_5120": ("upols2_fused_kernel", "filt, 5120 taps, 2^28 Float32", "8"),
     "filt_32768": ("d.filt(b, x) through the host mirror: ONE plan, rows form of the multi-pass engine (column pass, row kernel, column pass back)", "32768 taps, 2^27 Float32", "8"),
@@ -536,6 +537,19 @@ def measure_rows(tm, lib, _lib, d, stream, mark=lambda row: None):
         rows["spectrogram_default"] = crow(tm, med, 4.0 * n3 + 4.0 * KK * plan.nout, engine=plan.engine)
 
     guarded("spectrogram_default", spectrogram_default)
+
+    # (round 6) spectrogram of a real signal at a nextfastfft size past 8192 points: n = nfft = 8400 = nextfastfft(67000 >> 3), 50 % overlap
+    def spectrogram_8400():
+        nn = 8400
+        w_, norm2_ = compute_window(d.hanning, nn)
+        plan = _StftPlan(nn, nn >> 1, nn, w_, norm2_, True, 1, np.float32, d.ENGINE_AUTO)
+        KK = d.frame_count(n3, nn, nn >> 1)
+        out = torch.empty((KK, plan.nout), dtype=torch.float32, device="cuda")
+        mark("spectrogram_8400")
+        med, _ = tm.time(lambda: _lib.check(lib.mdsp_stft_exec(plan._h, xr.data_ptr(), n3, 1, n3, out.data_ptr(), plan.nout, KK * plan.nout, stream)))
+        rows["spectrogram_8400"] = crow(tm, med, 4.0 * n3 + 4.0 * KK * plan.nout, engine=plan.engine)
+
+    guarded("spectrogram_8400", spectrogram_8400)
 
     def hilbert():
         out = torch.empty(n3, dtype=torch.complex64, device="cuda")

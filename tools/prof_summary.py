@@ -48,7 +48,7 @@ ROWS = ("step", "yardsticks", "stft", "spectrogram", "resample", "firarb", "resa
         "welch_3000", "welch_1536", "filt_5120", "decim8_f32", "resample_147_160_f32", "resample_160_441_f64",
         "decim16_f32", "resample_441_160_c64", "welch_default", "welch_default_2p24", "spectrogram_default", "filt_32768", "filt_f64", "welch_f64",
         "welch_f64_5000", "welch_f64_8000", "mt_pgram", "hilbert", "conv2d", "filtfilt", "welch_2p19",
-        "welch_8192", "welch_12500", "welch_16384", "welch_65536", "welch_125000", "welch_200000")   # == bench.py Marks.ROWS
+        "welch_8192", "welch_12500", "welch_16384", "welch_65536", "welch_125000", "welch_200000", "spectrogram_8400")   # == bench.py Marks.ROWS
 
 def rows(path, min_ns=20000):
     """Per bench row: the kernels dispatched in that row's marker segment with their mean counter values -> {row: {kernel: {...}}}.
