@@ -17,6 +17,7 @@ template <int N_, int T_, int LDSIN_, int... RS> struct CtSched {
     // Welch sums at 16 - 50 points per thread (round 6, spectral_ctbig.hip): 4096 the window is loaded beside the samples (spectral_gen.h ct_pass0_lean)
     // instead of living in registers; 8192 the sums are kept in the working precision and flushed to the Float64 partials every 64 units
     static constexpr bool LEANW = (LDSIN_ & 4096) != 0, LEANA = (LDSIN_ & 8192) != 0;
+    static constexpr bool INPLACE_ALL = (LDSIN_ & 65536) != 0;   // with 16: the real-signal column modes run on the one buffer as well (spectral_ctbig_cols.hip: to 16384 points)
     static constexpr bool TOUCH = (LDSIN_ & 32768) != 0;     // with 4096: the next unit's samples touched (one dword per 128-byte line) behind this unit's first pass
     static constexpr int radix(int p) {
         constexpr int r[] = {RS...};

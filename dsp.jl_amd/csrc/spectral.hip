@@ -707,6 +707,8 @@ bool use_gx(int dtype, int64_t nfft, bool direct, int kind) {
     if (kind == 0 && m != 4 && m != 5 && ctbig_preferred(dtype, nfft)) return true;
     if (kind == 0 && m != 4 && !fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && ((m != 5 && ctbig_ok(dtype, nfft)) || ctcols_split(dtype, nfft) > 0 || ctrows_r0(dtype, nfft) > 0))
         return true;   // Welch sums on a compile-time schedule (one workgroup, or R0 x S rows): whatever the run-time-schedule kernel plans
+    if (kind == 1 && m != 4 && m != 5 && !fused_size_ok(dtype, nfft) && !gen_ct_size(dtype, nfft, direct) && ctbig_cols_ok(dtype, nfft))
+        return true;   // columns on a single-workgroup compile-time schedule (spectral_ctbig_cols.hip), 16384 points included
     if (!gx_size_ok(dtype, nfft)) return false;
     if (m >= 2) return true;
     const bool pow2 = (nfft & (nfft - 1)) == 0;

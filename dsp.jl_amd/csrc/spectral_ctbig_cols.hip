@@ -1,6 +1,7 @@
 // STFT / spectrogram / periodogram columns on the single-workgroup compile-time schedules of ctbig_sizes.h (round 6): the column modes of gen_ct_kernel
 // (spectral_gen.h MODE 1) over the same size tables as the Welch sums of spectral_ctbig.hip -- complex signals at every size up to 16384 points (the last pass is
-// consumed from registers: one LDS buffer), real signals (two frames per transform, untangled from the natural-order spectrum in a second buffer) up to 9600 points.
+// consumed from registers: one LDS buffer), real signals (two frames per transform; the last pass leaves the natural-order spectrum in the same buffer, from which the two
+// frames are untangled) likewise.
 // The sizes that also have an all-mode schedule in ct_sched.h keep it.  Float32 / ComplexF32.
 // Reference loops: periodograms.jl:872-897 (stft), :828-860 (spectrogram), :57-69 (ArraySplit), :142-172 / :234-244 (fft2pow!, fft2oneortwosided!).
 #include <algorithm>
@@ -19,8 +20,8 @@ namespace {
 
 #include "ctbig_sizes.h"
 
-constexpr int REAL_COLUMNS_MAX = 9600;   // two buffers of N + padding complex values and the twiddle tables in 160 KiB
-constexpr int col_flags(int f, bool cplx) { return cplx ? (f & ~(8192 | 32768)) : (f & ~(4096 | 8192 | 32768)); }   // no sums; the window stays in registers for real signals
+constexpr int REAL_COLUMNS_MAX = 16384;   // (real-signal columns on ONE buffer, CtSched flag 65536: up to round 6's first form two buffers, 9600 points)
+constexpr int col_flags(int f, bool cplx) { return cplx ? (f & ~(8192 | 32768)) : ((f & ~(4096 | 8192 | 32768)) | 65536); }   // no sums; real signals: the window in registers, one buffer
 
 template <typename R, bool CPLX> int cols_dispatch(GenArgs& a, int64_t nch, hipStream_t st) {
     int64_t nslots = 0;

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
     // Welch sums and complex columns take the last pass's results from registers; real-signal columns need the mirror bin N - k of another
     // thread (A[k] = (Z[k] + conj Z[N-k]) / 2), so their last pass goes through LDS once more
     constexpr bool DIRECT = MODE == 0 || CPLX;
-    constexpr bool INPL = S::INPLACE && DIRECT;
+    constexpr bool INPL = S::INPLACE && (DIRECT || S::INPLACE_ALL);   // (INPLACE_ALL, round 6: real-signal columns on one buffer too -- the last pass writes the natural-order
+                                                                       // spectrum over its own operands, behind the barrier that follows its reads)
     __shared__ __attribute__((aligned(16))) cx<R> buf[INPL ? S::NP : 2 * S::NP];
     cx<R>*bufA = buf, *bufB = INPL ? buf : buf + S::NP;
     const int t = threadIdx.x;
@@ -574,7 +575,9 @@ __global__ __launch_bounds__(S::T, (MODE == 1 && sizeof(R) == 4) ? S::MINW_REAL 
                 }
             });
         } else {
-            const cx<R>* src = ct_passes<S, 1>(bufA, bufB, tw, tl, t2);   // ends with a barrier; natural-order spectrum in LDS
+            const cx<R>* src = bufA;
+            if constexpr (INPL) ct_passes_inplace<S, 1, S::P>(bufA, tw, tl, t2);   // (every pass in place, the last one included: ends with a barrier)
+            else src = ct_passes<S, 1>(bufA, bufB, tw, tl, t2);   // ends with a barrier; natural-order spectrum in LDS
             if (live) {
                 for (int j = t; j < a.nout; j += T) {
                     const bool mirror = j > N / 2;                              // real -> two-sided: X[N-k] = conj(X[k]) (fft2oneortwosided!, :234-244)
@@ -622,7 +625,7 @@ int gen_ct_launch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, DevB
     hipFuncAttributes fa{};
     MDSP_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
     const int regs = std::max(8, (fa.numRegs + 7) / 8 * 8), waves = S::T / 64;
-    const size_t lds_bytes = sizeof(cx<R>) * ((S::INPLACE && (MODE == 0 || CPLX)) ? 1 : 2) * (size_t)S::NP;
+    const size_t lds_bytes = sizeof(cx<R>) * ((S::INPLACE && (MODE == 0 || CPLX || S::INPLACE_ALL)) ? 1 : 2) * (size_t)S::NP;
     int per_cu = std::min<int>({32 / waves, (512 / regs) * 4 / waves, (int)((size_t)160 * 1024 / lds_bytes)});
     if (per_cu < 1) per_cu = 1;
     if (tunables().wg_per_cu > 0) per_cu = tunables().wg_per_cu;
