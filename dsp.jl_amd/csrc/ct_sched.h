@@ -100,5 +100,5 @@ constexpr bool gen_ct_wide_mode(int flags, int mode, bool cplx) { return !(flags
 // Float64 / ComplexF64 (DSP.jl's default element type): up to 3000 points two buffers of N x 16 bytes as in Float32; beyond (round 4), the
 // register-consumed modes (Welch sums, complex columns) run on ONE buffer (CtSched flag 16, ct_passes_inplace): 8000 x 16 bytes = 125 KiB; real-signal
 // columns need the natural-order spectrum in LDS next to the pass's input, i.e. two buffers, which fit up to 5000 points.
-constexpr int GEN_CT_F64_TWO_BUF = 3000, GEN_CT_F64_MAX = 8000, GEN_CT_F64_REAL_COLUMNS_MAX = 5000;
+constexpr int GEN_CT_F64_TWO_BUF = 3000, GEN_CT_F64_MAX = 8000, GEN_CT_F64_REAL_COLUMNS_TWO_BUF = 5000, GEN_CT_F64_REAL_COLUMNS_MAX = 8000;   // (real columns above 5000 points: one buffer, round 6)
 // direct: Welch sums or complex columns (the last pass is consumed from registers)

@@ -708,8 +708,11 @@ bool gen_ct_dispatch(GenArgs& a, int64_t nch, hipStream_t st, int64_t* nslots, D
         } else if constexpr (MODE == 0 || CPLX) {                                                                  \
             *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~(1536 | 32768)) | 16 | gen_ct_f64_tw2l(N, MODE, CPLX), __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
-        } else if constexpr (N <= GEN_CT_F64_REAL_COLUMNS_MAX) {                                                   \
+        } else if constexpr (N <= GEN_CT_F64_REAL_COLUMNS_TWO_BUF) {                                               \
             *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~(1536 | 32768)) | gen_ct_f64_tw2l(N, MODE), __VA_ARGS__>>(a, nch, st, nslots, partial); \
+            return true;                                                                                           \
+        } else {   /* real-signal columns beyond: ONE buffer, the last pass leaves the spectrum in place (flag 65536, round 6) */ \
+            *rc = gen_ct_launch<R, CPLX, MODE, CtSched<N, T, ((F) & ~(1536 | 32768)) | 16 | 65536 | 2048, __VA_ARGS__>>(a, nch, st, nslots, partial); \
             return true;                                                                                           \
         }                                                                                                          \
         break;

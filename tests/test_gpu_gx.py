@@ -190,6 +190,22 @@ def test_gx_stft_spectrogram_periodogram_vs_oracle(d, dt, tol):
         assert pg.power.shape == rp.power.shape and relerr(pg.power, rp.power) < tol, (n, nfft)
 
 
+def test_float64_real_columns_on_one_buffer(d):
+    """Float64 real-signal STFT / spectrogram at 6000 and 8000 points: the compile-time schedules of csrc/ct_sched.h on ONE LDS buffer of 16-byte elements (the last pass
+    leaves the natural-order spectrum over its operands, the two frames of a transform are untangled from there) -- two buffers end at 5000 points."""
+    from oracle import periodograms as opg, windows as ow
+    rng = np.random.default_rng(69)
+    for n, nov, K in ((6000, 3000, 5), (8000, 2000, 4)):
+        s = _signal(rng, (K - 1) * (n - nov) + n + 3, np.float64)
+        for onesided in (True, False):
+            got = d.stft(s, n, nov, window=d.hanning, onesided=onesided)
+            ref = opg.stft(s, n, nov, window=ow.hanning, onesided=onesided, dtype=np.float64)
+            assert got.shape == ref.shape and relerr(got, ref) < TOL64, (n, onesided, relerr(got, ref))
+        sp = d.spectrogram(s, n, nov, window=d.hanning, fs=3.0)
+        rs = opg.spectrogram(s, n, nov, window=ow.hanning, fs=3.0, dtype=np.float64)
+        assert relerr(sp.power, rs.power) < TOL64
+
+
 def test_multitaper_on_the_compile_time_columns(d):
     """mt_pgram of Float32 / ComplexF32 signals of 3087 and 6912 samples (nfft = nextfastfft(n) = n: single-workgroup compile-time columns,
     csrc/spectral_ctbig_cols.hip): one launch per taper, each with its own window, accumulated into the same PSD (multitaper.jl:240-243)."""
