@@ -54,7 +54,7 @@ template <typename R> int upload_roots_n(DevBuf& buf, int64_t n) {
 
 namespace mdsp {
 bool ctbig_ok(int dtype, int64_t nfft) {
-    if (dtype_is_double(dtype)) return false;
+    if (dtype_is_double(dtype)) return tunables().gx != 3 && ctbig64_ok(nfft);   // (MDSP_GX=3: Float64 stays on the run-time schedule, A/B)
     switch (nfft) {
 #define MDSP_X(N, ...) case N:
         MDSP_CTBIG_SIZES(MDSP_X)
@@ -81,6 +81,7 @@ bool ctbig_preferred(int dtype, int64_t nfft) {   // ... in front of the all-mod
 int ctbig_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,
                 hipStream_t st, int64_t* nslots, DevBuf* partial, int accumulate) {
     if (!ctbig_ok(dtype, nfft)) MDSP_FAIL(MDSP_ERR_ASSERTION, "nfft=%lld has no single-workgroup compile-time schedule", (long long)nfft);
+    if (dtype_is_double(dtype)) return ctbig64_welch(cp, dtype_is_complex(dtype), s, lds_, K, hop, nch, n, nfft, win_dev, st, nslots, partial, accumulate);
     if (!cp.ready) {
         MDSP_TRY(upload_roots_n<float>(cp.roots, nfft));
         MDSP_TRY(cp.win.reserve(sizeof(float) * (size_t)nfft));

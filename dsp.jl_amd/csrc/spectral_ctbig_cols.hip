@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void cols_window_kernel(const double* __restri
 
 namespace mdsp {
 bool ctbig_cols_ok(int dtype, int64_t nfft) {
-    if (dtype_is_double(dtype)) return false;
+    if (dtype_is_double(dtype)) return tunables().gx != 3 && ctbig64_ok(nfft);
     const bool cplx = dtype_is_complex(dtype);
     switch (nfft) {
 #define MDSP_X(N, ...) case N:
@@ -63,6 +63,7 @@ bool ctbig_cols_ok(int dtype, int64_t nfft) {
 
 int ctbig_stft(CtColsPlan& cp, int dtype, const CtBigColsArgs& c, hipStream_t st) {
     if (!ctbig_cols_ok(dtype, c.nfft)) MDSP_FAIL(MDSP_ERR_ASSERTION, "nfft=%lld has no single-workgroup column schedule", (long long)c.nfft);
+    if (dtype_is_double(dtype)) return ctbig64_stft(cp, dtype_is_complex(dtype), c, st);
     if (!cp.ready) {
         std::vector<cx<float>> w((size_t)c.nfft);
         for (int64_t k = 0; k < c.nfft; ++k) {

@@ -36,4 +36,10 @@ struct CtBigColsArgs {
 };
 bool ctbig_cols_ok(int dtype, int64_t nfft);
 int ctbig_stft(CtColsPlan& cp, int dtype, const CtBigColsArgs& a, hipStream_t st);
+// spectral_ctbig_f64.hip: the same for Float64 / ComplexF64 (sizes whose one buffer of 16-byte elements fits: to 9600 points); ctbig_ok / ctbig_welch / ctbig_cols_ok /
+// ctbig_stft route there
+bool ctbig64_ok(int64_t nfft);
+int ctbig64_welch(CtColsPlan& cp, bool cplx, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev, hipStream_t st,
+                  int64_t* nslots, DevBuf* partial, int accumulate);
+int ctbig64_stft(CtColsPlan& cp, bool cplx, const CtBigColsArgs& c, hipStream_t st);
 }  // namespace mdsp
