@@ -17,6 +17,10 @@ int ctcols_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t
 bool ctcols_big_row_ok(int dtype, int64_t S);
 int ctcols_big_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, int R0,
                      const double* win_dev, hipStream_t st, int64_t* ngroups, DevBuf* partial);
+// spectral_ctcols_f64.hip: Float64 / ComplexF64 rows of 4097 .. 9600 points (the same tables), R0 = 2 .. 8
+bool ctcols64_row_ok(int64_t S);
+int ctcols64_welch(CtColsPlan& cp, bool cplx, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, int R0, const double* win_dev,
+                   hipStream_t st, int64_t* ngroups, DevBuf* partial);
 // spectral_ctbig.hip: nfft between 8193 and 16384 points with a single-workgroup compile-time schedule (Float32 / ComplexF32); cp holds the nfft roots
 bool ctbig_ok(int dtype, int64_t nfft);
 bool ctbig_preferred(int dtype, int64_t nfft);   // a size that also has an all-mode compile-time schedule, Welch sums faster here

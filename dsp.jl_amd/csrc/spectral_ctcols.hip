@@ -68,8 +68,10 @@ template <typename R, bool CPLX> int cols_dispatch(ColsArgs& ca, int64_t nch, hi
 namespace mdsp {
 int ctcols_split(int dtype, int64_t nfft) {
     if (dtype_is_double(dtype)) {
-        for (int R0 = 2; R0 <= 4; ++R0) {
+        for (int R0 = 2; R0 <= 8; ++R0) {
             if (nfft % R0) continue;
+            if (tunables().gx != 6 && tunables().gx != 3 && ctcols64_row_ok(nfft / R0)) return R0;   // rows of 4097 .. 9600 points (spectral_ctcols_f64.hip)
+            if (R0 > 4) continue;
             switch (nfft / R0) {
 #define MDSP_X(N, ...) case N:
                 MDSP_CTCOLS_SIZES_F64(MDSP_X)
@@ -107,6 +109,8 @@ int ctcols_welch(CtColsPlan& cp, int dtype, const void* s, int64_t lds_, int64_t
     if (R0 == 0) MDSP_FAIL(MDSP_ERR_ASSERTION, "nfft=%lld is not R0 x a compile-time row size", (long long)nfft);
     const int64_t S = nfft / R0;
     if (tunables().gx != 6 && ctcols_big_row_ok(dtype, S)) return ctcols_big_welch(cp, dtype, s, lds_, K, hop, nch, n, nfft, R0, win_dev, st, ngroups, partial);
+    if (dtype_is_double(dtype) && tunables().gx != 6 && tunables().gx != 3 && ctcols64_row_ok(S))
+        return ctcols64_welch(cp, dtype_is_complex(dtype), s, lds_, K, hop, nch, n, nfft, R0, win_dev, st, ngroups, partial);
     const bool dbl = dtype_is_double(dtype), cplx = dtype_is_complex(dtype);
     if (!cp.ready) {
         MDSP_TRY(dbl ? upload_roots_n<double>(cp.roots, S) : upload_roots_n<float>(cp.roots, S));
