@@ -694,12 +694,12 @@ bool fused_size_ok(int dtype, int64_t nfft) {
 // 32 x 16384 0.73 against 0.52 on the engine's rows form.  MDSP_GX=8: wherever a split exists (A/B), MDSP_GX=-1: never.
 int ctrows_r0(int dtype, int64_t nfft) {
     const int m = tunables().gx;
-    if (m == 0 || m == -1 || m == 4 || m == 5 || m == 6 || ctbig_ok(dtype, nfft)) return 0;
+    if (m == 0 || m == -1 || m == 4 || m == 5 || m == 6 || ctbig_ok(dtype, nfft) || (m == 3 && dtype_is_double(dtype))) return 0;
     const int any = ctrows_split(dtype, nfft, 2);
     if (any == 0) return 0;
     if (m == 8) return any;
     const int fused = ctcols_split(dtype, nfft);
-    return (fused == 0 || fused >= 6) ? any : 0;
+    return (fused == 0 || fused >= (dtype_is_double(dtype) ? 5 : 6)) ? any : 0;   // (Float64, r06s71 / r06s72: 48000 = 5 x 9600 0.60 against 0.51 fused, 57600 0.62 / 0.45; a tie at R0 = 4)
 }
 bool use_gx(int dtype, int64_t nfft, bool direct, int kind) {
     const int m = tunables().gx;

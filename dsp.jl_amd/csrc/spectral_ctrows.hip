@@ -8,7 +8,7 @@
 // The work buffer is cut into chunks of MDSP_BIG_CHUNK_MIB (1 GiB; chunks of 128 MiB, to read the rows back from the Infinity Cache, measured 5 - 15 % SLOWER: more
 // launches, no cache effect -- r06s47).  Taken from R0 = 6 (spectral.hip ctrows_r0: the fused step wins to R0 = 4, a tie at 5).  (Also measured and dropped, r06s51: the row kernel of chunk c on a second stream beside the column kernel of chunk c + 1, six chunks on
 // two buffers -- 0.27 - 0.38 TB/s against 0.35 - 0.53 in order: at these call lengths the extra launches and event waits cost more than the overlap returns.)
-// Float32 / ComplexF32;
+// Float32 / ComplexF32 with rows of 8193 .. 16384 points, Float64 / ComplexF64 with rows of 4097 .. 9600;
 // S any size of ctbig_sizes.h, R0 any radix fft_lds.h has a butterfly for (2 .. 32): 125000 = 8 x 15625, 200000 = 16 x 12500, 2^19 = 32 x 16384.
 // Reference loops: periodograms.jl:746-759 (welch_pgram_helper!), :57-69 (ArraySplit), :142-172 (fft2pow!).
 #include <algorithm>
@@ -26,15 +26,15 @@ namespace {
 
 struct RowsColArgs {
     const void* s;        // signal, channel stride lds_
-    cx<float>* work;      // [ch][k1][unit][S]
-    const float* win;     // nfft values (ones without a window, zero tail)
-    const cx<float>* rootsN;
+    void* work;           // cx<R> [ch][k1][unit][S]
+    const void* win;      // R: nfft values (ones without a window, zero tail)
+    const void* rootsN;   // cx<R>: the nfft forward roots
     int64_t lds_, K, hop, u0, cnt;   // frames of the call, first unit and units of this chunk
     int n, nfft, S;
 };
 
-template <int R0, bool CPLX> __global__ __launch_bounds__(256) void rows_col_kernel(RowsColArgs a) {
-    using TT = std::conditional_t<CPLX, cx<float>, float>;
+template <int R0, bool CPLX, typename R> __global__ __launch_bounds__(256) void rows_col_kernel(RowsColArgs a) {
+    using TT = std::conditional_t<CPLX, cx<R>, R>;
     constexpr int SZ = (int)sizeof(TT);
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
     const int64_t ul = blockIdx.y, ch = blockIdx.z, u = a.u0 + ul;
@@ -43,17 +43,18 @@ template <int R0, bool CPLX> __global__ __launch_bounds__(256) void rows_col_ker
     const bool haveB = !CPLX && (f0 + 1) < a.K;
     const __amdgpu_buffer_rsrc_t da = io::make_rsrc(fa, (long long)a.n * SZ);
     const __amdgpu_buffer_rsrc_t db = io::make_rsrc(fa + (CPLX ? 0 : a.hop), haveB ? (long long)a.n * SZ : 0);
-    const __amdgpu_buffer_rsrc_t dw = io::make_rsrc(a.win, (long long)a.nfft * 4);
+    const __amdgpu_buffer_rsrc_t dw = io::make_rsrc(a.win, (long long)a.nfft * (int)sizeof(R));
+    const cx<R>* rootsN = static_cast<const cx<R>*>(a.rootsN);
     if (i >= a.S) return;
-    cx<float> z[R0];
+    cx<R> z[R0];
     TT ra[R0], rb[CPLX ? 1 : R0];
-    float w[R0];
+    R w[R0];
 #pragma unroll
     for (int n1 = 0; n1 < R0; ++n1) {
         const int idx = a.S * n1 + i;
         ra[n1] = io::Ld<TT>::load(da, idx * SZ);
         if constexpr (!CPLX) rb[n1] = io::Ld<TT>::load(db, idx * SZ);
-        w[n1] = io::Ld<float>::load(dw, idx * 4);
+        w[n1] = io::Ld<R>::load(dw, idx * (int)sizeof(R));
     }
 #pragma unroll
     for (int n1 = 0; n1 < R0; ++n1) {
@@ -61,18 +62,18 @@ template <int R0, bool CPLX> __global__ __launch_bounds__(256) void rows_col_ker
         else z[n1] = {ra[n1] * w[n1], rb[n1] * w[n1]};
     }
     fft::gen_bfly<R0>(z);
-    cx<float>* o = a.work + ((ch * R0) * a.cnt + ul) * (int64_t)a.S + i;
+    cx<R>* o = static_cast<cx<R>*>(a.work) + ((ch * R0) * a.cnt + ul) * (int64_t)a.S + i;
     fft::st2(o, z[0]);
     // W_nfft^{i k1}: a lane's k1-th twiddle sits k1 table entries from its neighbour's -- fetched directly, the R0 - 1 twiddles of a wave touch ~R0^2 / 2 cache lines
     // (r06s54: this kernel at 0.35 ms of the 0.55 a 2^26-sample call takes).  Only the powers of two are fetched (W^{i 2^j}: R0 lines in all); the others are products
     // of at most log2(R0) of them -- two or three roundings more on a twiddle.
     constexpr int NB = R0 <= 2 ? 1 : R0 <= 4 ? 2 : R0 <= 8 ? 3 : R0 <= 16 ? 4 : 5;
-    cx<float> wp[NB];
+    cx<R> wp[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) wp[j] = a.rootsN[(unsigned)(((unsigned long long)(unsigned)i << j) % (unsigned)a.nfft)];
+    for (int j = 0; j < NB; ++j) wp[j] = rootsN[(unsigned)(((unsigned long long)(unsigned)i << j) % (unsigned)a.nfft)];
 #pragma unroll
     for (int k1 = 1; k1 < R0; ++k1) {
-        cx<float> w{1.0f, 0.0f};
+        cx<R> w{(R)1, (R)0};
         bool first = true;
 #pragma unroll
         for (int j = 0; j < NB; ++j)
@@ -109,17 +110,17 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const double* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void rows_window_kernel(const double* __restrict__ win, float* __restrict__ out, int n, int nfft) {
+template <typename R> __global__ __launch_bounds__(256) void rows_window_kernel(const double* __restrict__ win, R* __restrict__ out, int n, int nfft) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (i < nfft) out[i] = i < n ? (win ? (float)win[i] : 1.0f) : 0.0f;
+    if (i < nfft) out[i] = i < n ? (win ? (R)win[i] : (R)1) : (R)0;
 }
 
-template <bool CPLX> int launch_cols(int R0, const RowsColArgs& a, int64_t nch, hipStream_t st) {
+template <bool CPLX, typename R> int launch_cols(int R0, const RowsColArgs& a, int64_t nch, hipStream_t st) {
     const dim3 grid((unsigned)cdiv(a.S, 256), (unsigned)a.cnt, (unsigned)nch);
     switch (R0) {
-#define MDSP_X(R)                                                                   \
-    case R:                                                                         \
-        hipLaunchKernelGGL((rows_col_kernel<R, CPLX>), grid, dim3(256), 0, st, a); \
+#define MDSP_X(R_)                                                                  \
+    case R_:                                                                        \
+        hipLaunchKernelGGL((rows_col_kernel<R_, CPLX, R>), grid, dim3(256), 0, st, a); \
         break;
         MDSP_X(2) MDSP_X(3) MDSP_X(4) MDSP_X(5) MDSP_X(6) MDSP_X(7) MDSP_X(8) MDSP_X(9) MDSP_X(10) MDSP_X(12) MDSP_X(14) MDSP_X(15) MDSP_X(16) MDSP_X(18) MDSP_X(20) MDSP_X(21)
         MDSP_X(24) MDSP_X(25) MDSP_X(27) MDSP_X(28) MDSP_X(30) MDSP_X(32)
@@ -141,34 +142,37 @@ bool radix_ok(int r) {
 }  // namespace
 
 namespace mdsp {
+// rows: Float32 -- a single-workgroup schedule above 8192 points; Float64 (round 6, later) -- one above 4096 points whose buffer of 16-byte elements fits (to 9600)
+static bool row_ok(bool dbl, int64_t S) { return dbl ? (S > 4096 && ctbig_ok(MDSP_C64, S)) : (S > 8192 && ctbig_ok(MDSP_C32, S)); }
+
 int ctrows_split(int dtype, int64_t nfft, int r0_min) {
-    if (dtype_is_double(dtype)) return 0;
+    const bool dbl = dtype_is_double(dtype);
     for (int R0 = std::max(2, r0_min); R0 <= 32; ++R0)
-        if (nfft % R0 == 0 && radix_ok(R0) && ctbig_ok(MDSP_C32, nfft / R0) && nfft / R0 > 8192) return R0;
+        if (nfft % R0 == 0 && radix_ok(R0) && row_ok(dbl, nfft / R0)) return R0;
     return 0;
 }
 
-int ctrows_welch(CtRowsPlan& rp, int dtype, int R0, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,
-                 double* acc, bool fresh, hipStream_t st) {
+template <typename R>
+static int ctrows_run(CtRowsPlan& rp, bool cplx, int R0, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev, double* acc,
+                      bool fresh, hipStream_t st) {
     const int64_t S = nfft / R0;
-    if (dtype_is_double(dtype) || nfft % R0 || !radix_ok(R0) || !ctbig_ok(MDSP_C32, S)) MDSP_FAIL(MDSP_ERR_ASSERTION, "nfft=%lld is not %d rows of a single-workgroup size", (long long)nfft, R0);
-    const bool cplx = dtype_is_complex(dtype);
     const int64_t units = cplx ? K : cdiv(K, 2);
     if (units == 0) return MDSP_OK;
     if (!rp.ready) {
-        std::vector<cx<float>> w((size_t)nfft);
+        std::vector<cx<R>> w((size_t)nfft);
         for (int64_t k = 0; k < nfft; ++k) {
             const zd r = unit_root(k, nfft, -1);
-            w[(size_t)k] = {(float)r.real(), (float)r.imag()};
+            w[(size_t)k] = {(R)r.real(), (R)r.imag()};
         }
-        MDSP_TRY(rp.rootsN.reserve(sizeof(cx<float>) * (size_t)nfft));
-        MDSP_HIP(hipMemcpy(rp.rootsN.p, w.data(), sizeof(cx<float>) * (size_t)nfft, hipMemcpyHostToDevice));
-        MDSP_TRY(rp.win.reserve(sizeof(float) * (size_t)nfft));
-        hipLaunchKernelGGL(rows_window_kernel, dim3((unsigned)cdiv(nfft, 256)), dim3(256), 0, st, win_dev, rp.win.as<float>(), n, (int)nfft);
+        MDSP_TRY(rp.rootsN.reserve(sizeof(cx<R>) * (size_t)nfft));
+        MDSP_HIP(hipMemcpy(rp.rootsN.p, w.data(), sizeof(cx<R>) * (size_t)nfft, hipMemcpyHostToDevice));
+        MDSP_TRY(rp.win.reserve(sizeof(R) * (size_t)nfft));
+        hipLaunchKernelGGL(rows_window_kernel<R>, dim3((unsigned)cdiv(nfft, 256)), dim3(256), 0, st, win_dev, rp.win.as<R>(), n, (int)nfft);
         MDSP_LAUNCH_CHECK();
         rp.ready = true;
     }
-    const int64_t per = (int64_t)sizeof(cx<float>) * nfft * nch;   // work bytes per unit
+    const int rowtype = sizeof(R) == 8 ? MDSP_C64 : MDSP_C32;
+    const int64_t per = (int64_t)sizeof(cx<R>) * nfft * nch;   // work bytes per unit
     const int mib = std::max(16, tunables().big_chunk_mib);
     const int64_t C = std::max<int64_t>(1, std::min<int64_t>(units, ((int64_t)mib << 20) / per));
     MDSP_TRY(rp.work.reserve((size_t)(per * C)));
@@ -176,18 +180,26 @@ int ctrows_welch(CtRowsPlan& rp, int dtype, int R0, const void* s, int64_t lds_,
     for (int64_t c0 = 0; c0 < units; c0 += C) {
         const int64_t cnt = std::min<int64_t>(C, units - c0);
         RowsColArgs a{};
-        a.s = s; a.work = rp.work.as<cx<float>>(); a.win = rp.win.as<float>(); a.rootsN = rp.rootsN.as<cx<float>>();
+        a.s = s; a.work = rp.work.p; a.win = rp.win.p; a.rootsN = rp.rootsN.p;
         a.lds_ = lds_; a.K = K; a.hop = hop; a.u0 = c0; a.cnt = cnt; a.n = n; a.nfft = (int)nfft; a.S = (int)S;
-        MDSP_TRY(cplx ? launch_cols<true>(R0, a, nch, st) : launch_cols<false>(R0, a, nch, st));
+        MDSP_TRY(cplx ? (launch_cols<true, R>(R0, a, nch, st)) : (launch_cols<false, R>(R0, a, nch, st)));
         int64_t nslots = 0;
         // rows: (channel, k1) are the row kernel's channels, `cnt` frames of S points S apart; its partial rows persist from chunk to chunk (the first chunk is the
         // largest: it writes every slot a later one adds to)
-        MDSP_TRY(ctbig_welch(rp.rows, MDSP_C32, rp.work.p, cnt * S, cnt, S, nch * R0, (int)S, S, nullptr, st, &nslots, &rp.partial, c0 > 0 ? 1 : 0));
+        MDSP_TRY(ctbig_welch(rp.rows, rowtype, rp.work.p, cnt * S, cnt, S, nch * R0, (int)S, S, nullptr, st, &nslots, &rp.partial, c0 > 0 ? 1 : 0));
         if (c0 == 0) nslots0 = nslots;
     }
     const dim3 grid((unsigned)cdiv(S, 32), (unsigned)cdiv(R0, 32), (unsigned)nch);
     hipLaunchKernelGGL(rows_reduce_kernel, grid, dim3(256), 0, st, rp.partial.as<double>(), acc, R0, (int)S, (int)nslots0, nch * R0, fresh ? 0 : 1);
     MDSP_LAUNCH_CHECK();
     return MDSP_OK;
+}
+
+int ctrows_welch(CtRowsPlan& rp, int dtype, int R0, const void* s, int64_t lds_, int64_t K, int64_t hop, int64_t nch, int n, int64_t nfft, const double* win_dev,
+                 double* acc, bool fresh, hipStream_t st) {
+    const bool dbl = dtype_is_double(dtype), cplx = dtype_is_complex(dtype);
+    if (nfft % R0 || !radix_ok(R0) || !row_ok(dbl, nfft / R0)) MDSP_FAIL(MDSP_ERR_ASSERTION, "nfft=%lld is not %d rows of a single-workgroup size", (long long)nfft, R0);
+    return dbl ? ctrows_run<double>(rp, cplx, R0, s, lds_, K, hop, nch, n, nfft, win_dev, acc, fresh, st)
+               : ctrows_run<float>(rp, cplx, R0, s, lds_, K, hop, nch, n, nfft, win_dev, acc, fresh, st);
 }
 }  // namespace mdsp

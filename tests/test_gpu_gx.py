@@ -71,6 +71,7 @@ WELCH_CASES = (
     (100000, 50000, 100000, "hanning", 3),   # 8 x 12500
     (16800, 8400, 16800, "hamming", 4),      # 2 x 8400: Float32 csrc/spectral_ctcols_big.hip, Float64 csrc/spectral_ctcols_f64.hip (rows of 16-byte elements to 9600 points)
     (28800, 14000, 28800, None, 3),          # 3 x 9600
+    (96000, 48000, 96000, "hanning", 3),     # Float32: 6 x 16000, Float64: 10 x 9600, both in two kernels
     # ... and in two kernels where R0 > 8 (csrc/spectral_ctrows.hip: column kernel into a work buffer, the single-workgroup kernel over the rows)
     (200000, 100000, 200000, "hanning", 3),  # 16 x 12500
     (150000, 70000, 150000, None, 4),        # 10 x 15000, odd frame count
